@@ -1,0 +1,926 @@
+/*
+ * oracle/kkt_oracle.c  --  TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * Plain-C restatement of the reference's KKT layer that sits above the LDL
+ * engine (Clarabel.rs v0.11.1, paths relative to /root/reference/src):
+ *   - CSC block count/fill helpers            algebra/csc/utils.rs:16-307
+ *   - assemble_kkt_matrix + LDLDataMap        solver/core/kktsolvers/direct/quasidef/kkt_assembly.rs:20-183
+ *                                             .../quasidef/datamaps.rs:112-405
+ *   - triu/tril symv                          algebra/csc/matrix_math.rs:178-208
+ *   - norm_inf (NaN propagating), stable norm algebra/vecmath.rs:132-142,206-226
+ *   - DirectLDLKKTSolver update / regularise / solve / iterative refinement
+ *                                             .../quasidef/directldlkktsolver.rs:134-405
+ *   - Zero / Nonnegative / SecondOrder cone scaling + Hs blocks
+ *                                             solver/core/cones/{zerocone,nonnegativecone,socone}.rs
+ * Used ONLY by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline.
+ * The LDL engine underneath is oracle/qdldl_oracle.c.
+ *
+ * Parity status: pinned by kkt_assembly.rs:185-355 (triu AND tril patterns),
+ * matrix.rs:250-286 (symv, quad_form), vector.rs norm KATs; the cone Hs
+ * blocks have no reference KATs and are cross-checked by the
+ * NT identities Hs*z = s in tests/test_oracle_kats.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- from qdldl_oracle.c ------------------------------------------------ */
+typedef struct orc_qdldl orc_qdldl;
+int orc_qdldl_new(orc_qdldl **out, int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai,
+                  const double *Ax, const int64_t *perm, const signed char *Dsigns, int logical,
+                  int reg_enable, double reg_eps, double reg_delta);
+void orc_qdldl_free(orc_qdldl *f);
+int orc_qdldl_solve(orc_qdldl *f, double *b);
+void orc_qdldl_update_values(orc_qdldl *f, const int64_t *idx, const double *v, int64_t k);
+void orc_qdldl_scale_values(orc_qdldl *f, const int64_t *idx, double s, int64_t k);
+int orc_qdldl_refactor(orc_qdldl *f);
+int orc_qdldl_dinv_is_finite(const orc_qdldl *f);
+
+/* cone tags (shared numbering with include/clarabel_hip.h) */
+enum { CONE_ZERO = 0, CONE_NONNEG = 1, CONE_SOC = 2, CONE_EXP = 3, CONE_POW = 4,
+       CONE_GENPOW = 5, CONE_PSDTRI = 6 };
+enum { SHAPE_TRIU = 0, SHAPE_TRIL = 1 };
+
+#define SOC_NO_EXPANSION_MAX_SIZE 4 /* socone.rs:46 */
+
+/* ------------------------------------------------------------------------ */
+/* vector helpers                                                            */
+/* ------------------------------------------------------------------------ */
+/* vecmath.rs:132-142 */
+double orc_norm_inf(const double *v, int64_t n) {
+    double out = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        if (isnan(v[i])) return NAN;
+        double a = fabs(v[i]);
+        out = out > a ? out : a; /* T::max */
+    }
+    return out;
+}
+/* vecmath.rs:206-226 stable_norm */
+double orc_norm2(const double *v, int64_t n) {
+    double scale = 0.0, sumsq = 1.0;
+    for (int64_t i = 0; i < n; i++) {
+        double xi = v[i];
+        if (xi == 0.0) continue;
+        double a = fabs(xi);
+        if (scale < a) {
+            double r = scale / a;
+            sumsq = 1.0 + sumsq * r * r;
+            scale = a;
+        } else {
+            double r = a / scale;
+            sumsq = sumsq + r * r;
+        }
+    }
+    return scale * sqrt(sumsq);
+}
+static double dotp(const double *a, const double *b, int64_t n) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; i++) s += a[i] * b[i];
+    return s;
+}
+static int all_finite(const double *v, int64_t n) {
+    for (int64_t i = 0; i < n; i++)
+        if (!isfinite(v[i])) return 0;
+    return 1;
+}
+
+/* matrix_math.rs:178-208 _csc_symv_unsafe:  y = a*A*x + b*y, A stored as one
+ * triangle (works identically for triu or tril) */
+void orc_symv(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, double *y,
+              const double *x, double a, double b) {
+    for (int64_t i = 0; i < n; i++) y[i] *= b;
+    for (int64_t col = 0; col < n; col++) {
+        double xcol = x[col];
+        for (int64_t p = Ap[col]; p < Ap[col + 1]; p++) {
+            int64_t row = Ai[p];
+            double Aij = Ax[p];
+            y[row] += a * Aij * xcol;
+            if (row != col) y[col] += a * Aij * x[row];
+        }
+    }
+}
+/* matrix_math.rs:212-257 _csc_quad_form (triu) */
+double orc_quad_form_triu(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+                          const double *y, const double *x) {
+    double out = 0.0;
+    for (int64_t col = 0; col < n; col++) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int64_t p = Ap[col]; p < Ap[col + 1]; p++) {
+            int64_t row = Ai[p];
+            if (row < col) {
+                t1 += Ax[p] * x[row];
+                t2 += Ax[p] * y[row];
+            } else if (row == col) {
+                out += Ax[p] * x[col] * y[col];
+            }
+        }
+        out += t1 * y[col] + t2 * x[col];
+    }
+    return out;
+}
+
+/* ------------------------------------------------------------------------ */
+/* cones                                                                     */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int tag;
+    int64_t dim;   /* SOC/NN/Zero: numel; PSD: matrix side n; GenPow: dim1 */
+    int64_t dim2;  /* GenPow dim2 */
+    int64_t numel;
+    int hs_diag;   /* Hs_is_diagonal */
+    int sparse;    /* is_sparse_expandable */
+    int64_t pdim;  /* 2 for sparse SOC, 3 for GenPow */
+    int64_t cone_start;  /* rng_cones[i].start */
+    int64_t block_start; /* rng_blocks[i].start */
+    int64_t block_len;
+    /* scaling state */
+    double *w, *lam;
+    double eta;
+    double *u, *v;
+    double d;
+} orc_cone;
+
+typedef struct {
+    int64_t ncones;
+    orc_cone *c;
+    int64_t numel;     /* m */
+    int64_t nblockvals; /* rng_blocks.last().end */
+    int64_t pdim_total;
+    int64_t nsparse;
+} orc_cones;
+
+static int64_t tri_number(int64_t k) { return k * (k + 1) / 2; }
+
+void orc_cones_free(orc_cones *cs) {
+    if (!cs) return;
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        free(cs->c[i].w); free(cs->c[i].lam); free(cs->c[i].u); free(cs->c[i].v);
+    }
+    free(cs->c);
+    free(cs);
+}
+
+/* compositecone.rs:36-128 (new / make_rng_cones / make_rng_blocks) */
+orc_cones *orc_cones_new(int64_t ncones, const int32_t *tags, const int64_t *dims,
+                         const int64_t *dims2) {
+    orc_cones *cs = (orc_cones *)calloc(1, sizeof(orc_cones));
+    cs->ncones = ncones;
+    cs->c = (orc_cone *)calloc((size_t)(ncones > 0 ? ncones : 1), sizeof(orc_cone));
+    int64_t cstart = 0, bstart = 0;
+    for (int64_t i = 0; i < ncones; i++) {
+        orc_cone *c = &cs->c[i];
+        c->tag = tags[i];
+        c->dim = dims[i];
+        c->dim2 = dims2 ? dims2[i] : 0;
+        switch (c->tag) {
+        case CONE_ZERO: case CONE_NONNEG:
+            c->numel = c->dim; c->hs_diag = 1; c->sparse = 0; break;
+        case CONE_SOC:
+            c->numel = c->dim;
+            c->sparse = c->dim > SOC_NO_EXPANSION_MAX_SIZE; /* socone.rs:54-60 */
+            c->hs_diag = c->sparse;                         /* socone.rs:213-215 */
+            c->pdim = c->sparse ? 2 : 0;
+            break;
+        case CONE_EXP: case CONE_POW:
+            c->numel = 3; c->hs_diag = 0; c->sparse = 0; break;
+        case CONE_GENPOW:
+            c->numel = c->dim + c->dim2; c->hs_diag = 1; c->sparse = 1; c->pdim = 3; break;
+        case CONE_PSDTRI:
+            c->numel = tri_number(c->dim); c->hs_diag = 0; c->sparse = 0; break;
+        default: c->numel = 0;
+        }
+        c->cone_start = cstart;
+        c->block_start = bstart;
+        c->block_len = c->hs_diag ? c->numel : tri_number(c->numel);
+        cstart += c->numel;
+        bstart += c->block_len;
+        if (c->sparse) { cs->pdim_total += c->pdim; cs->nsparse += 1; }
+        if (c->tag == CONE_NONNEG || c->tag == CONE_SOC) {
+            c->w = (double *)calloc((size_t)c->numel, sizeof(double));
+            c->lam = (double *)calloc((size_t)c->numel, sizeof(double));
+        }
+        if (c->tag == CONE_SOC && c->sparse) {
+            c->u = (double *)calloc((size_t)c->numel, sizeof(double));
+            c->v = (double *)calloc((size_t)c->numel, sizeof(double));
+            c->d = 1.0;
+        }
+    }
+    cs->numel = cstart;
+    cs->nblockvals = bstart;
+    return cs;
+}
+int64_t orc_cones_numel(const orc_cones *cs) { return cs->numel; }
+int64_t orc_cones_nblockvals(const orc_cones *cs) { return cs->nblockvals; }
+int64_t orc_cones_pdim(const orc_cones *cs) { return cs->pdim_total; }
+
+/* socone.rs:388-406 */
+static double soc_residual(const double *z, int64_t n) {
+    double z1 = orc_norm2(z + 1, n - 1);
+    return (z[0] - z1) * (z[0] + z1);
+}
+static double sqrt_soc_residual(const double *z, int64_t n) {
+    double r = soc_residual(z, n);
+    return r > 0.0 ? sqrt(r) : 0.0;
+}
+
+/* socone.rs:134-211 SecondOrderCone::update_scaling */
+static int soc_update_scaling(orc_cone *c, const double *s, const double *z) {
+    int64_t n = c->numel;
+    double zscale = sqrt_soc_residual(z, n);
+    double sscale = sqrt_soc_residual(s, n);
+    if (zscale == 0.0 || sscale == 0.0) return 0;
+    c->eta = sqrt(sscale / zscale);
+    double *w = c->w;
+    double rs = 1.0 / sscale; /* w.scale(sscale.recip()) */
+    for (int64_t i = 0; i < n; i++) w[i] = s[i] * rs;
+    w[0] += z[0] / zscale;
+    double mrz = -(1.0 / zscale); /* axpby(-zscale.recip(), z1, 1) */
+    for (int64_t i = 1; i < n; i++) w[i] = mrz * z[i] + 1.0 * w[i];
+    double wscale = sqrt_soc_residual(w, n);
+    if (wscale == 0.0) return 0;
+    double rw = 1.0 / wscale;
+    for (int64_t i = 0; i < n; i++) w[i] *= rw;
+    double w1sq = dotp(w + 1, w + 1, n - 1);
+    w[0] = sqrt(1.0 + w1sq);
+    /* lambda, :174-184 */
+    double gamma = 0.5 * wscale;
+    double *lam = c->lam;
+    lam[0] = gamma;
+    double ca = (gamma + z[0] / zscale) / sscale;
+    double cb = (gamma + s[0] / sscale) / zscale;
+    for (int64_t i = 1; i < n; i++) lam[i] = ca * s[i] + cb * z[i];
+    double sc = 1.0 / (s[0] / sscale + z[0] / zscale + 2.0 * gamma);
+    for (int64_t i = 1; i < n; i++) lam[i] *= sc;
+    double sq = sqrt(sscale * zscale);
+    for (int64_t i = 0; i < n; i++) lam[i] *= sq;
+    /* sparse expansion terms, :187-208 */
+    if (c->sparse) {
+        double alpha = 2.0 * w[0];
+        double wsq = w[0] * w[0] + w1sq;
+        double wsqinv = 1.0 / wsq;
+        c->d = 0.5 * wsqinv;
+        double u0 = sqrt(wsq - c->d);
+        double u1 = alpha / u0;
+        double v0 = 0.0;
+        double v1 = sqrt(2.0 * (2.0 + wsqinv) / (2.0 * wsq - wsqinv));
+        c->u[0] = u0;
+        for (int64_t i = 1; i < n; i++) c->u[i] = u1 * w[i] + 0.0 * c->u[i];
+        c->v[0] = v0;
+        for (int64_t i = 1; i < n; i++) c->v[i] = v1 * w[i] + 0.0 * c->v[i];
+    }
+    return 1;
+}
+
+/* compositecone.rs:226-243 update_scaling (Zero/NN/SOC only; other cone types
+ * keep whatever Hs the caller stored with orc_kkt_set_hs_override) */
+int orc_cones_update_scaling(orc_cones *cs, const double *s, const double *z) {
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        orc_cone *c = &cs->c[i];
+        const double *si = s + c->cone_start, *zi = z + c->cone_start;
+        if (c->tag == CONE_NONNEG) { /* nonnegativecone.rs:77-90 */
+            for (int64_t k = 0; k < c->numel; k++) {
+                c->lam[k] = sqrt(si[k] * zi[k]);
+                c->w[k] = sqrt(si[k] / zi[k]);
+            }
+        } else if (c->tag == CONE_SOC) {
+            if (!soc_update_scaling(c, si, zi)) return 0;
+        }
+    }
+    return 1;
+}
+
+/* compositecone.rs:253-257 get_Hs + per-cone get_Hs */
+void orc_cones_get_Hs(const orc_cones *cs, double *Hs) {
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        double *blk = Hs + c->block_start;
+        if (c->tag == CONE_ZERO) { /* zerocone.rs:94-96 */
+            for (int64_t k = 0; k < c->block_len; k++) blk[k] = 0.0;
+        } else if (c->tag == CONE_NONNEG) { /* nonnegativecone.rs:96-101 */
+            for (int64_t k = 0; k < c->numel; k++) blk[k] = c->w[k] * c->w[k];
+        } else if (c->tag == CONE_SOC) { /* socone.rs:217-246 */
+            double eta2 = c->eta * c->eta;
+            if (c->sparse) {
+                for (int64_t k = 0; k < c->numel; k++) blk[k] = eta2;
+                blk[0] *= c->d;
+            } else {
+                const double *w = c->w;
+                blk[0] = (M_SQRT2 * w[0] - 1.0) * (M_SQRT2 * w[0] + 1.0);
+                int64_t h = 1;
+                for (int64_t col = 1; col < c->numel; col++) {
+                    double wcol = w[col];
+                    for (int64_t row = 0; row <= col; row++) blk[h++] = 2.0 * w[row] * wcol;
+                    blk[h - 1] += 1.0;
+                }
+                for (int64_t k = 0; k < c->block_len; k++) blk[k] *= eta2;
+            }
+        }
+        /* other cone types: left untouched (caller-provided) */
+    }
+}
+
+/* mul_Hs: nonnegativecone.rs:103-108, socone.rs:248-256, zerocone.rs:98-100 */
+void orc_cones_mul_Hs(const orc_cones *cs, double *y, const double *x) {
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        double *yi = y + c->cone_start;
+        const double *xi = x + c->cone_start;
+        if (c->tag == CONE_ZERO) {
+            for (int64_t k = 0; k < c->numel; k++) yi[k] = 0.0;
+        } else if (c->tag == CONE_NONNEG) {
+            for (int64_t k = 0; k < c->numel; k++) yi[k] = c->w[k] * (c->w[k] * xi[k]);
+        } else if (c->tag == CONE_SOC) {
+            double cc = dotp(c->w, xi, c->numel) * 2.0;
+            for (int64_t k = 0; k < c->numel; k++) yi[k] = xi[k];
+            yi[0] = -xi[0];
+            for (int64_t k = 0; k < c->numel; k++) yi[k] = cc * c->w[k] + 1.0 * yi[k];
+            double e2 = c->eta * c->eta;
+            for (int64_t k = 0; k < c->numel; k++) yi[k] *= e2;
+        }
+    }
+}
+/* state accessors for tests */
+double orc_cone_eta(const orc_cones *cs, int64_t i) { return cs->c[i].eta; }
+double orc_cone_d(const orc_cones *cs, int64_t i) { return cs->c[i].d; }
+const double *orc_cone_w(const orc_cones *cs, int64_t i) { return cs->c[i].w; }
+const double *orc_cone_lambda(const orc_cones *cs, int64_t i) { return cs->c[i].lam; }
+const double *orc_cone_u(const orc_cones *cs, int64_t i) { return cs->c[i].u; }
+const double *orc_cone_v(const orc_cones *cs, int64_t i) { return cs->c[i].v; }
+
+/* ------------------------------------------------------------------------ */
+/* CSC block helpers: algebra/csc/utils.rs (K.colptr used as counters)        */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int64_t m, n;
+    int64_t *colptr, *rowval;
+    double *nzval;
+    int64_t nnz;
+} orc_csc;
+
+static void colcount_dense_triangle(orc_csc *K, int64_t initcol, int64_t blockcols, int shape) {
+    for (int64_t k = 0; k < blockcols; k++) /* utils.rs:16-33 */
+        K->colptr[initcol + k] += (shape == SHAPE_TRIU) ? (k + 1) : (blockcols - k);
+}
+static void colcount_diag(orc_csc *K, int64_t initcol, int64_t blockcols) { /* :37-40 */
+    for (int64_t k = 0; k < blockcols; k++) K->colptr[initcol + k] += 1;
+}
+static int missing_diag(const orc_csc *M, int64_t i) { /* :50-52 */
+    return M->colptr[i] == M->colptr[i + 1] || M->rowval[M->colptr[i + 1] - 1] != i;
+}
+static void colcount_missing_diag(orc_csc *K, const orc_csc *M, int64_t initcol) { /* :45-57 */
+    for (int64_t i = 0; i < M->n; i++)
+        if (missing_diag(M, i)) K->colptr[i + initcol] += 1;
+}
+static void colcount_colvec(orc_csc *K, int64_t n, int64_t firstrow, int64_t firstcol) {
+    (void)firstrow; /* :62-65 */
+    K->colptr[firstcol] += n;
+}
+static void colcount_rowvec(orc_csc *K, int64_t n, int64_t firstrow, int64_t firstcol) {
+    (void)firstrow; /* :70-76 */
+    for (int64_t k = 0; k < n; k++) K->colptr[firstcol + k] += 1;
+}
+static void colcount_block(orc_csc *K, const orc_csc *M, int64_t initcol, int transpose) {
+    if (transpose) { /* :80-94 */
+        for (int64_t p = 0; p < M->nnz; p++) K->colptr[initcol + M->rowval[p]] += 1;
+    } else {
+        for (int64_t i = 0; i < M->n; i++) K->colptr[initcol + i] += M->colptr[i + 1] - M->colptr[i];
+    }
+}
+static void fill_colvec(orc_csc *K, int64_t *vtoKKT, int64_t len, int64_t initrow, int64_t initcol) {
+    for (int64_t i = 0; i < len; i++) { /* :98-106 */
+        int64_t dest = K->colptr[initcol];
+        K->rowval[dest] = initrow + i;
+        K->nzval[dest] = 0.0;
+        vtoKKT[i] = dest;
+        K->colptr[initcol] += 1;
+    }
+}
+static void fill_rowvec(orc_csc *K, int64_t *vtoKKT, int64_t len, int64_t initrow, int64_t initcol) {
+    for (int64_t i = 0; i < len; i++) { /* :110-119 */
+        int64_t col = initcol + i;
+        int64_t dest = K->colptr[col];
+        K->rowval[dest] = initrow;
+        K->nzval[dest] = 0.0;
+        vtoKKT[i] = dest;
+        K->colptr[col] += 1;
+    }
+}
+static void fill_block(orc_csc *K, const orc_csc *M, int64_t *MtoKKT, int64_t initrow,
+                       int64_t initcol, int transpose) {
+    for (int64_t i = 0; i < M->n; i++) { /* :124-157 */
+        for (int64_t j = M->colptr[i]; j < M->colptr[i + 1]; j++) {
+            int64_t col, row;
+            if (transpose) {
+                col = M->rowval[j] + initcol;
+                row = i + initrow;
+            } else {
+                col = i + initcol;
+                row = M->rowval[j] + initrow;
+            }
+            int64_t dest = K->colptr[col];
+            K->rowval[dest] = row;
+            K->nzval[dest] = M->nzval[j];
+            MtoKKT[j] = dest;
+            K->colptr[col] += 1;
+        }
+    }
+}
+static void fill_dense_triangle(orc_csc *K, int64_t *blocktoKKT, int64_t offset, int64_t blockdim,
+                                int shape) {
+    int64_t kidx = 0; /* :161-219 */
+    if (shape == SHAPE_TRIU) {
+        for (int64_t col = offset; col < offset + blockdim; col++)
+            for (int64_t row = offset; row <= col; row++) {
+                int64_t dest = K->colptr[col];
+                K->rowval[dest] = row;
+                K->nzval[dest] = 0.0;
+                K->colptr[col] += 1;
+                blocktoKKT[kidx++] = dest;
+            }
+    } else {
+        for (int64_t row = offset; row < offset + blockdim; row++)
+            for (int64_t col = offset; col <= row; col++) {
+                int64_t dest = K->colptr[col];
+                K->rowval[dest] = row;
+                K->nzval[dest] = 0.0;
+                K->colptr[col] += 1;
+                blocktoKKT[kidx++] = dest;
+            }
+    }
+}
+static void fill_diag(orc_csc *K, int64_t *diagtoKKT, int64_t offset, int64_t blockdim) {
+    for (int64_t i = 0; i < blockdim; i++) { /* :223-231 */
+        int64_t col = offset + i;
+        int64_t dest = K->colptr[col];
+        K->rowval[dest] = col;
+        K->nzval[dest] = 0.0;
+        K->colptr[col] += 1;
+        diagtoKKT[i] = dest;
+    }
+}
+static void fill_missing_diag(orc_csc *K, const orc_csc *M, int64_t initcol) {
+    for (int64_t i = 0; i < M->n; i++) /* :236-249 */
+        if (missing_diag(M, i)) {
+            int64_t dest = K->colptr[i + initcol];
+            K->rowval[dest] = i + initcol;
+            K->nzval[dest] = 0.0;
+            K->colptr[i + initcol] += 1;
+        }
+}
+static void colcount_to_colptr(orc_csc *K) { /* :253-260 */
+    int64_t cur = 0;
+    for (int64_t i = 0; i <= K->n; i++) {
+        int64_t c = K->colptr[i];
+        K->colptr[i] = cur;
+        cur += c;
+    }
+}
+static void backshift_colptrs(orc_csc *K) { /* :271-274 */
+    for (int64_t i = K->n; i > 0; i--) K->colptr[i] = K->colptr[i - 1];
+    K->colptr[0] = 0;
+}
+static int64_t count_diagonal_entries_triu(const orc_csc *M) { /* :276-291 */
+    int64_t c = 0;
+    for (int64_t i = 0; i < M->n; i++)
+        if (M->colptr[i + 1] != M->colptr[i] && M->rowval[M->colptr[i + 1] - 1] == i) c++;
+    return c;
+}
+
+/* ------------------------------------------------------------------------ */
+/* LDLDataMap + assemble_kkt_matrix                                          */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int64_t n, m, p, nnzP, nnzA;
+    int64_t *P, *A, *Hsblocks, *diagP, *diag_full;
+    int64_t nHs;
+    /* sparse maps, in cone order: for SOC  u[numel], v[numel], D[2];
+     * for GenPow p[numel], q[dim1], r[dim2], D[3]  (datamaps.rs:112-116,227-232) */
+    int64_t nsparse;
+    int64_t **sp_u, **sp_v, **sp_q; /* SOC: u,v  GenPow: p->sp_u, q->sp_v, r->sp_q */
+    int64_t (*sp_D)[3];
+} orc_map;
+
+typedef struct {
+    orc_csc K;
+    orc_map map;
+    int shape;
+} orc_kktmat;
+
+static void map_free(orc_map *mp) {
+    free(mp->P); free(mp->A); free(mp->Hsblocks); free(mp->diagP); free(mp->diag_full);
+    for (int64_t i = 0; i < mp->nsparse; i++) {
+        if (mp->sp_u) free(mp->sp_u[i]);
+        if (mp->sp_v) free(mp->sp_v[i]);
+        if (mp->sp_q) free(mp->sp_q[i]);
+    }
+    free(mp->sp_u); free(mp->sp_v); free(mp->sp_q); free(mp->sp_D);
+}
+void orc_kktmat_free(orc_kktmat *km) {
+    if (!km) return;
+    free(km->K.colptr); free(km->K.rowval); free(km->K.nzval);
+    map_free(&km->map);
+    free(km);
+}
+
+/* kkt_assembly.rs:20-183 */
+orc_kktmat *orc_assemble_kkt(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
+                             const double *Px, const int64_t *Ap, const int64_t *Ai,
+                             const double *Ax, const orc_cones *cones, int shape) {
+    orc_kktmat *km = (orc_kktmat *)calloc(1, sizeof(orc_kktmat));
+    km->shape = shape;
+    orc_csc P = {n, n, (int64_t *)Pp, (int64_t *)Pi, (double *)Px, Pp[n]};
+    orc_csc A = {m, n, (int64_t *)Ap, (int64_t *)Ai, (double *)Ax, Ap[n]};
+    orc_map *map = &km->map;
+    /* LDLDataMap::new, datamaps.rs:365-404 */
+    int64_t p = cones->pdim_total;
+    map->n = n; map->m = m; map->p = p; map->nnzP = P.nnz; map->nnzA = A.nnz;
+    map->P = (int64_t *)calloc((size_t)(P.nnz > 0 ? P.nnz : 1), sizeof(int64_t));
+    map->A = (int64_t *)calloc((size_t)(A.nnz > 0 ? A.nnz : 1), sizeof(int64_t));
+    map->nHs = cones->nblockvals;
+    map->Hsblocks = (int64_t *)calloc((size_t)(map->nHs > 0 ? map->nHs : 1), sizeof(int64_t));
+    map->diagP = (int64_t *)calloc((size_t)(n > 0 ? n : 1), sizeof(int64_t));
+    map->diag_full = (int64_t *)calloc((size_t)(n + m + p > 0 ? n + m + p : 1), sizeof(int64_t));
+    map->nsparse = cones->nsparse;
+    size_t ns = (size_t)(map->nsparse > 0 ? map->nsparse : 1);
+    map->sp_u = (int64_t **)calloc(ns, sizeof(int64_t *));
+    map->sp_v = (int64_t **)calloc(ns, sizeof(int64_t *));
+    map->sp_q = (int64_t **)calloc(ns, sizeof(int64_t *));
+    map->sp_D = (int64_t(*)[3])calloc(ns, sizeof(int64_t[3]));
+    int64_t nnz_vec = 0;
+    {
+        int64_t si = 0;
+        for (int64_t i = 0; i < cones->ncones; i++) {
+            const orc_cone *c = &cones->c[i];
+            if (!c->sparse) continue;
+            if (c->tag == CONE_SOC) {
+                map->sp_u[si] = (int64_t *)calloc((size_t)c->numel, sizeof(int64_t));
+                map->sp_v[si] = (int64_t *)calloc((size_t)c->numel, sizeof(int64_t));
+                nnz_vec += 2 * c->numel; /* datamaps.rs:131-133 */
+            } else {                     /* GenPow, datamaps.rs:248-250 */
+                map->sp_u[si] = (int64_t *)calloc((size_t)c->numel, sizeof(int64_t));            /* p */
+                map->sp_v[si] = (int64_t *)calloc((size_t)(c->dim > 0 ? c->dim : 1), sizeof(int64_t));   /* q */
+                map->sp_q[si] = (int64_t *)calloc((size_t)(c->dim2 > 0 ? c->dim2 : 1), sizeof(int64_t)); /* r */
+                nnz_vec += c->numel + c->dim + c->dim2;
+            }
+            si++;
+        }
+    }
+    /* kkt_assembly.rs:33-46 */
+    int64_t nnz_diagP = count_diagonal_entries_triu(&P);
+    int64_t nnzKKT = P.nnz + n - nnz_diagP + A.nnz + map->nHs + nnz_vec + p;
+    int64_t N = m + n + p;
+    orc_csc *K = &km->K;
+    K->m = N; K->n = N; K->nnz = nnzKKT;
+    K->colptr = (int64_t *)calloc((size_t)N + 1, sizeof(int64_t));
+    K->rowval = (int64_t *)calloc((size_t)(nnzKKT > 0 ? nnzKKT : 1), sizeof(int64_t));
+    K->nzval = (double *)calloc((size_t)(nnzKKT > 0 ? nnzKKT : 1), sizeof(double));
+
+    /* _kkt_assemble_colcounts, :53-103 */
+    if (shape == SHAPE_TRIU) {
+        colcount_block(K, &P, 0, 0);
+        colcount_missing_diag(K, &P, 0);
+        colcount_block(K, &A, n, 1);
+    } else {
+        colcount_missing_diag(K, &P, 0);
+        colcount_block(K, &P, 0, 1);
+        colcount_block(K, &A, 0, 0);
+    }
+    {
+        int64_t pcol = m + n, si = 0;
+        for (int64_t i = 0; i < cones->ncones; i++) {
+            const orc_cone *c = &cones->c[i];
+            int64_t row = c->cone_start + n;
+            if (c->hs_diag) colcount_diag(K, row, c->numel);
+            else colcount_dense_triangle(K, row, c->numel, shape);
+            if (c->sparse) {
+                if (c->tag == CONE_SOC) { /* datamaps.rs:149-171 */
+                    if (shape == SHAPE_TRIU) {
+                        colcount_colvec(K, c->numel, row, pcol);
+                        colcount_colvec(K, c->numel, row, pcol + 1);
+                    } else {
+                        colcount_rowvec(K, c->numel, pcol, row);
+                        colcount_rowvec(K, c->numel, pcol + 1, row);
+                    }
+                } else { /* datamaps.rs:266-292 */
+                    if (shape == SHAPE_TRIU) {
+                        colcount_colvec(K, c->dim, row, pcol);
+                        colcount_colvec(K, c->dim2, row + c->dim, pcol + 1);
+                        colcount_colvec(K, c->numel, row, pcol + 2);
+                    } else {
+                        colcount_rowvec(K, c->dim, pcol, row);
+                        colcount_rowvec(K, c->dim2, pcol + 1, row + c->dim);
+                        colcount_rowvec(K, c->numel, pcol + 2, row);
+                    }
+                }
+                colcount_diag(K, pcol, c->pdim);
+                pcol += c->pdim;
+                si++;
+            }
+        }
+    }
+    /* _kkt_assemble_fill, :105-183 */
+    colcount_to_colptr(K);
+    if (shape == SHAPE_TRIU) {
+        fill_block(K, &P, map->P, 0, 0, 0);
+        fill_missing_diag(K, &P, 0);
+        fill_block(K, &A, map->A, 0, n, 1);
+    } else {
+        fill_missing_diag(K, &P, 0);
+        fill_block(K, &P, map->P, 0, 0, 1);
+        fill_block(K, &A, map->A, n, 0, 0);
+    }
+    {
+        int64_t pcol = m + n, si = 0;
+        for (int64_t i = 0; i < cones->ncones; i++) {
+            const orc_cone *c = &cones->c[i];
+            int64_t row = c->cone_start + n;
+            int64_t *block = map->Hsblocks + c->block_start;
+            if (c->hs_diag) fill_diag(K, block, row, c->numel);
+            else fill_dense_triangle(K, block, row, c->numel, shape);
+            if (c->sparse) {
+                if (c->tag == CONE_SOC) { /* datamaps.rs:173-197: v first, then u */
+                    if (shape == SHAPE_TRIU) {
+                        fill_colvec(K, map->sp_v[si], c->numel, row, pcol);
+                        fill_colvec(K, map->sp_u[si], c->numel, row, pcol + 1);
+                    } else {
+                        fill_rowvec(K, map->sp_v[si], c->numel, pcol, row);
+                        fill_rowvec(K, map->sp_u[si], c->numel, pcol + 1, row);
+                    }
+                } else { /* datamaps.rs:294-319: q, r, p */
+                    if (shape == SHAPE_TRIU) {
+                        fill_colvec(K, map->sp_v[si], c->dim, row, pcol);
+                        fill_colvec(K, map->sp_q[si], c->dim2, row + c->dim, pcol + 1);
+                        fill_colvec(K, map->sp_u[si], c->numel, row, pcol + 2);
+                    } else {
+                        fill_rowvec(K, map->sp_v[si], c->dim, pcol, row);
+                        fill_rowvec(K, map->sp_q[si], c->dim2, pcol + 1, row + c->dim);
+                        fill_rowvec(K, map->sp_u[si], c->numel, pcol + 2, row);
+                    }
+                }
+                fill_diag(K, map->sp_D[si], pcol, c->pdim);
+                pcol += c->pdim;
+                si++;
+            }
+        }
+    }
+    backshift_colptrs(K);
+    if (shape == SHAPE_TRIU) { /* :165-182 */
+        for (int64_t i = 0; i < N; i++) map->diag_full[i] = K->colptr[i + 1] - 1;
+        for (int64_t i = 0; i < n; i++) map->diagP[i] = K->colptr[i + 1] - 1;
+    } else {
+        for (int64_t i = 0; i < N; i++) map->diag_full[i] = K->colptr[i];
+        for (int64_t i = 0; i < n; i++) map->diagP[i] = K->colptr[i];
+    }
+    return km;
+}
+int64_t orc_kktmat_dim(const orc_kktmat *km) { return km->K.n; }
+int64_t orc_kktmat_nnz(const orc_kktmat *km) { return km->K.nnz; }
+const int64_t *orc_kktmat_colptr(const orc_kktmat *km) { return km->K.colptr; }
+const int64_t *orc_kktmat_rowval(const orc_kktmat *km) { return km->K.rowval; }
+double *orc_kktmat_nzval(orc_kktmat *km) { return km->K.nzval; }
+const int64_t *orc_kktmat_map_P(const orc_kktmat *km) { return km->map.P; }
+const int64_t *orc_kktmat_map_A(const orc_kktmat *km) { return km->map.A; }
+const int64_t *orc_kktmat_map_Hs(const orc_kktmat *km) { return km->map.Hsblocks; }
+const int64_t *orc_kktmat_map_diagP(const orc_kktmat *km) { return km->map.diagP; }
+const int64_t *orc_kktmat_map_diag_full(const orc_kktmat *km) { return km->map.diag_full; }
+int64_t orc_kktmat_nsparse(const orc_kktmat *km) { return km->map.nsparse; }
+const int64_t *orc_kktmat_map_u(const orc_kktmat *km, int64_t i) { return km->map.sp_u[i]; }
+const int64_t *orc_kktmat_map_v(const orc_kktmat *km, int64_t i) { return km->map.sp_v[i]; }
+const int64_t *orc_kktmat_map_q(const orc_kktmat *km, int64_t i) { return km->map.sp_q[i]; }
+const int64_t *orc_kktmat_map_D(const orc_kktmat *km, int64_t i) { return km->map.sp_D[i]; }
+
+/* ------------------------------------------------------------------------ */
+/* DirectLDLKKTSolver (with the QDLDL engine)                                */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    /* CoreSettings fields consumed by the path, settings.rs:139-181 */
+    int static_reg_enable;
+    double static_reg_constant, static_reg_proportional;
+    int dynamic_reg_enable; /* NB ignored by the qdldl adapter (ldlsolvers/qdldl.rs:38) */
+    double dynamic_reg_eps, dynamic_reg_delta;
+    int ir_enable;
+    double ir_reltol, ir_abstol;
+    int32_t ir_max_iter;
+    double ir_stop_ratio;
+} orc_settings;
+
+void orc_settings_default(orc_settings *s) { /* settings.rs:139-181 defaults */
+    s->static_reg_enable = 1;
+    s->static_reg_constant = 1e-8;
+    s->static_reg_proportional = 2.220446049250313e-16 * 2.220446049250313e-16;
+    s->dynamic_reg_enable = 1;
+    s->dynamic_reg_eps = 1e-13;
+    s->dynamic_reg_delta = 2e-7;
+    s->ir_enable = 1;
+    s->ir_reltol = 1e-13;
+    s->ir_abstol = 1e-12;
+    s->ir_max_iter = 10;
+    s->ir_stop_ratio = 5.0;
+}
+
+typedef struct {
+    int64_t m, n, p, N;
+    double *x, *b, *work1, *work2;
+    orc_kktmat *km;
+    signed char *dsigns;
+    double *Hsblocks;
+    orc_qdldl *ldl;
+    orc_cones *cones; /* not owned */
+    double diagonal_regularizer;
+    int32_t last_ir_iters; /* oracle-only instrumentation */
+} orc_kktsolver;
+
+void orc_kktsolver_free(orc_kktsolver *ks) {
+    if (!ks) return;
+    free(ks->x); free(ks->b); free(ks->work1); free(ks->work2); free(ks->dsigns);
+    free(ks->Hsblocks);
+    if (ks->ldl) orc_qdldl_free(ks->ldl);
+    orc_kktmat_free(ks->km);
+    free(ks);
+}
+
+/* directldlkktsolver.rs:60-118 (+ _fill_signs :392-405), qdldl engine with an
+ * explicit permutation (ldlsolvers/qdldl.rs:18-49: logical=true,
+ * regularize_enable=true, eps/delta from settings). */
+orc_kktsolver *orc_kktsolver_new(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
+                                 const double *Px, const int64_t *Ap, const int64_t *Ai,
+                                 const double *Ax, orc_cones *cones, const orc_settings *st,
+                                 const int64_t *perm, int *err) {
+    orc_kktsolver *ks = (orc_kktsolver *)calloc(1, sizeof(orc_kktsolver));
+    ks->km = orc_assemble_kkt(n, m, Pp, Pi, Px, Ap, Ai, Ax, cones, SHAPE_TRIU);
+    int64_t p = ks->km->map.p, N = n + m + p;
+    ks->m = m; ks->n = n; ks->p = p; ks->N = N;
+    ks->cones = cones;
+    size_t NN = (size_t)(N > 0 ? N : 1);
+    ks->x = (double *)calloc(NN, sizeof(double));
+    ks->b = (double *)calloc(NN, sizeof(double));
+    ks->work1 = (double *)calloc(NN, sizeof(double));
+    ks->work2 = (double *)calloc(NN, sizeof(double));
+    ks->dsigns = (signed char *)malloc(NN);
+    for (int64_t i = 0; i < N; i++) ks->dsigns[i] = 1;
+    for (int64_t i = n; i < n + m; i++) ks->dsigns[i] = -1;
+    {
+        int64_t pp = m + n;
+        for (int64_t i = 0; i < cones->ncones; i++) {
+            const orc_cone *c = &cones->c[i];
+            if (!c->sparse) continue;
+            if (c->tag == CONE_SOC) { /* datamaps.rs:134-136 */
+                ks->dsigns[pp] = -1; ks->dsigns[pp + 1] = 1;
+            } else {                  /* datamaps.rs:251-253 */
+                ks->dsigns[pp] = -1; ks->dsigns[pp + 1] = -1; ks->dsigns[pp + 2] = 1;
+            }
+            pp += c->pdim;
+        }
+    }
+    ks->Hsblocks = (double *)calloc((size_t)(cones->nblockvals > 0 ? cones->nblockvals : 1), sizeof(double));
+    int64_t *ident = NULL;
+    if (!perm) {
+        ident = (int64_t *)malloc(NN * sizeof(int64_t));
+        for (int64_t i = 0; i < N; i++) ident[i] = i;
+        perm = ident;
+    }
+    int rc = orc_qdldl_new(&ks->ldl, N, N, ks->km->K.colptr, ks->km->K.rowval, ks->km->K.nzval,
+                           perm, ks->dsigns, 1, 1, st->dynamic_reg_eps, st->dynamic_reg_delta);
+    free(ident);
+    if (err) *err = rc;
+    if (rc != 0) {
+        orc_kktsolver_free(ks);
+        return NULL;
+    }
+    return ks;
+}
+
+/* directldlkktsolver.rs:351-390 */
+static void update_values(orc_kktsolver *ks, const int64_t *idx, const double *v, int64_t k) {
+    for (int64_t i = 0; i < k; i++) ks->km->K.nzval[idx[i]] = v[i];
+    orc_qdldl_update_values(ks->ldl, idx, v, k);
+}
+static void scale_values(orc_kktsolver *ks, const int64_t *idx, double s, int64_t k) {
+    for (int64_t i = 0; i < k; i++) ks->km->K.nzval[idx[i]] *= s;
+    orc_qdldl_scale_values(ks->ldl, idx, s, k);
+}
+
+/* directldlkktsolver.rs:217-264 + :324-329 */
+static int regularize_and_refactor(orc_kktsolver *ks, const orc_settings *st) {
+    orc_map *map = &ks->km->map;
+    double *Kx = ks->km->K.nzval;
+    double *diag_kkt = ks->work1, *diag_shifted = ks->work2;
+    int64_t N = ks->N;
+    if (st->static_reg_enable) {
+        for (int64_t i = 0; i < N; i++) diag_kkt[i] = Kx[map->diag_full[i]];
+        double maxdiag = orc_norm_inf(diag_kkt, N);
+        double eps = st->static_reg_constant + st->static_reg_proportional * maxdiag;
+        for (int64_t i = 0; i < N; i++)
+            diag_shifted[i] = (ks->dsigns[i] == 1) ? diag_kkt[i] + eps : diag_kkt[i] - eps;
+        update_values(ks, map->diag_full, diag_shifted, N);
+        ks->diagonal_regularizer = eps;
+    }
+    int rc = orc_qdldl_refactor(ks->ldl); /* reference unwrap()s: zero pivot would panic */
+    int ok = (rc == 0) && orc_qdldl_dinv_is_finite(ks->ldl);
+    if (st->static_reg_enable)
+        for (int64_t i = 0; i < N; i++) Kx[map->diag_full[i]] = diag_kkt[i];
+    return ok;
+}
+
+/* directldlkktsolver.rs:134-158.  hs_override: optional full Hsblocks vector
+ * whose entries are used for cone types the oracle does not restate
+ * (Exp/Pow/GenPow/PSD); may be NULL. */
+int orc_kktsolver_update(orc_kktsolver *ks, const orc_settings *st, const double *hs_override) {
+    orc_map *map = &ks->km->map;
+    orc_cones *cones = ks->cones;
+    if (hs_override) memcpy(ks->Hsblocks, hs_override, (size_t)cones->nblockvals * sizeof(double));
+    orc_cones_get_Hs(cones, ks->Hsblocks);
+    for (int64_t i = 0; i < cones->nblockvals; i++) ks->Hsblocks[i] = -ks->Hsblocks[i];
+    update_values(ks, map->Hsblocks, ks->Hsblocks, cones->nblockvals);
+    int64_t si = 0;
+    for (int64_t i = 0; i < cones->ncones; i++) {
+        const orc_cone *c = &cones->c[i];
+        if (!c->sparse) continue;
+        if (c->tag == CONE_SOC) { /* datamaps.rs:199-220 */
+            double eta2 = c->eta * c->eta;
+            update_values(ks, map->sp_u[si], c->u, c->numel);
+            update_values(ks, map->sp_v[si], c->v, c->numel);
+            scale_values(ks, map->sp_u[si], -eta2, c->numel);
+            scale_values(ks, map->sp_v[si], -eta2, c->numel);
+            double dd[2] = {-eta2, eta2};
+            update_values(ks, map->sp_D[si], dd, 2);
+        }
+        si++;
+    }
+    return regularize_and_refactor(ks, st);
+}
+
+/* directldlkktsolver.rs:160-166 */
+void orc_kktsolver_setrhs(orc_kktsolver *ks, const double *rhsx, const double *rhsz) {
+    memcpy(ks->b, rhsx, (size_t)ks->n * sizeof(double));
+    memcpy(ks->b + ks->n, rhsz, (size_t)ks->m * sizeof(double));
+    for (int64_t i = ks->n + ks->m; i < ks->N; i++) ks->b[i] = 0.0;
+}
+
+/* ldlsolvers/qdldl.rs:91-95 */
+static void ldl_solve(orc_kktsolver *ks, double *x, const double *b) {
+    memcpy(x, b, (size_t)ks->N * sizeof(double));
+    orc_qdldl_solve(ks->ldl, x);
+}
+/* directldlkktsolver.rs:334-347 */
+static double get_refine_error(orc_kktsolver *ks, double *e, const double *b, const double *xi) {
+    memcpy(e, b, (size_t)ks->N * sizeof(double));
+    orc_symv(ks->N, ks->km->K.colptr, ks->km->K.rowval, ks->km->K.nzval, e, xi, -1.0, 1.0);
+    return orc_norm_inf(e, ks->N);
+}
+/* directldlkktsolver.rs:266-321 */
+static int iterative_refinement(orc_kktsolver *ks, const orc_settings *st) {
+    double *x = ks->x, *b = ks->b, *e = ks->work1, *dx = ks->work2;
+    int64_t N = ks->N;
+    ks->last_ir_iters = 0;
+    double normb = orc_norm_inf(b, N);
+    double norme = get_refine_error(ks, e, b, x);
+    if (!isfinite(norme)) return 0;
+    for (int32_t it = 0; it < st->ir_max_iter; it++) {
+        if (norme <= st->ir_abstol + st->ir_reltol * normb) break;
+        double lastnorme = norme;
+        ldl_solve(ks, dx, e);
+        for (int64_t i = 0; i < N; i++) dx[i] = 1.0 * x[i] + 1.0 * dx[i];
+        norme = get_refine_error(ks, e, b, dx);
+        ks->last_ir_iters += 1;
+        if (!isfinite(norme)) return 0;
+        double improved = lastnorme / norme;
+        if (improved < st->ir_stop_ratio) {
+            if (improved > 1.0) { double *t = x; x = dx; dx = t; }
+            break;
+        }
+        { double *t = x; x = dx; dx = t; }
+    }
+    /* mem::swap on Vec<T> swaps the buffers; keep ks->x pointing at the result */
+    if (x != ks->x) { ks->work2 = ks->x; ks->x = x; }
+    return 1;
+}
+/* directldlkktsolver.rs:168-189 + getlhs :205-215 */
+int orc_kktsolver_solve(orc_kktsolver *ks, const orc_settings *st, double *lhsx, double *lhsz) {
+    ldl_solve(ks, ks->x, ks->b);
+    int ok = st->ir_enable ? iterative_refinement(ks, st) : all_finite(ks->x, ks->N);
+    if (ok) {
+        if (lhsx) memcpy(lhsx, ks->x, (size_t)ks->n * sizeof(double));
+        if (lhsz) memcpy(lhsz, ks->x + ks->n, (size_t)ks->m * sizeof(double));
+    }
+    return ok;
+}
+int64_t orc_kktsolver_dim(const orc_kktsolver *ks) { return ks->N; }
+int64_t orc_kktsolver_pdim(const orc_kktsolver *ks) { return ks->p; }
+const double *orc_kktsolver_x(const orc_kktsolver *ks) { return ks->x; }
+double *orc_kktsolver_b(orc_kktsolver *ks) { return ks->b; }
+orc_kktmat *orc_kktsolver_kktmat(orc_kktsolver *ks) { return ks->km; }
+orc_qdldl *orc_kktsolver_ldl(orc_kktsolver *ks) { return ks->ldl; }
+const signed char *orc_kktsolver_dsigns(const orc_kktsolver *ks) { return ks->dsigns; }
+int32_t orc_kktsolver_last_ir_iters(const orc_kktsolver *ks) { return ks->last_ir_iters; }
+double orc_kktsolver_regularizer(const orc_kktsolver *ks) { return ks->diagonal_regularizer; }
+/* full-N solve straight on the internal b (lets tests set sparse-cone rows too) */
+int orc_kktsolver_solve_full(orc_kktsolver *ks, const orc_settings *st, const double *b, double *x) {
+    memcpy(ks->b, b, (size_t)ks->N * sizeof(double));
+    ldl_solve(ks, ks->x, ks->b);
+    int ok = st->ir_enable ? iterative_refinement(ks, st) : all_finite(ks->x, ks->N);
+    if (ok && x) memcpy(x, ks->x, (size_t)ks->N * sizeof(double));
+    return ok;
+}

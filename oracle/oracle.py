@@ -1,0 +1,489 @@
+"""ctypes binding of the CPU oracle (oracle/*.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product (clarabel.rs_amd) never does.
+
+The oracle restates the reference's qdldl engine and DirectLDLKKTSolver
+(see the headers of qdldl_oracle.c / kkt_oracle.c for file:line citations).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+i64 = np.int64
+f64 = np.float64
+P_I64 = C.POINTER(C.c_int64)
+P_F64 = C.POINTER(C.c_double)
+P_I8 = C.POINTER(C.c_int8)
+P_I32 = C.POINTER(C.c_int32)
+
+ERR_NAMES = {0: "ok", 1: "IncompatibleDimension", 2: "EmptyColumn", 3: "NotUpperTriangular",
+             4: "ZeroPivot", 5: "InvalidPermutation", 6: "SymbolicOnly"}
+
+CONE_ZERO, CONE_NONNEG, CONE_SOC, CONE_EXP, CONE_POW, CONE_GENPOW, CONE_PSDTRI = range(7)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("qdldl_oracle.c", "kkt_oracle.c")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_qdldl_new.restype = C.c_int
+        for name in ("n", "nnzL", "nnzA", "positive_inertia", "regularize_count"):
+            getattr(L, "orc_qdldl_" + name).restype = C.c_int64
+        for name in ("Lp", "Li", "etree", "Lnz", "Ap", "Ai", "AtoPAPt"):
+            getattr(L, "orc_qdldl_" + name).restype = P_I64
+        for name in ("Lx", "D", "Dinv", "Ax"):
+            getattr(L, "orc_qdldl_" + name).restype = P_F64
+        L.orc_norm_inf.restype = C.c_double
+        L.orc_norm2.restype = C.c_double
+        L.orc_quad_form_triu.restype = C.c_double
+        L.orc_cones_new.restype = C.c_void_p
+        for name in ("numel", "nblockvals", "pdim"):
+            getattr(L, "orc_cones_" + name).restype = C.c_int64
+        L.orc_cone_eta.restype = C.c_double
+        L.orc_cone_d.restype = C.c_double
+        for name in ("w", "lambda", "u", "v"):
+            getattr(L, "orc_cone_" + name).restype = P_F64
+        L.orc_assemble_kkt.restype = C.c_void_p
+        L.orc_kktmat_dim.restype = C.c_int64
+        L.orc_kktmat_nnz.restype = C.c_int64
+        L.orc_kktmat_nsparse.restype = C.c_int64
+        for name in ("colptr", "rowval", "map_P", "map_A", "map_Hs", "map_diagP", "map_diag_full",
+                     "map_u", "map_v", "map_q", "map_D"):
+            getattr(L, "orc_kktmat_" + name).restype = P_I64
+        L.orc_kktmat_nzval.restype = P_F64
+        L.orc_kktsolver_new.restype = C.c_void_p
+        L.orc_kktsolver_dim.restype = C.c_int64
+        L.orc_kktsolver_pdim.restype = C.c_int64
+        L.orc_kktsolver_x.restype = P_F64
+        L.orc_kktsolver_b.restype = P_F64
+        L.orc_kktsolver_kktmat.restype = C.c_void_p
+        L.orc_kktsolver_ldl.restype = C.c_void_p
+        L.orc_kktsolver_dsigns.restype = P_I8
+        L.orc_kktsolver_last_ir_iters.restype = C.c_int32
+        L.orc_kktsolver_regularizer.restype = C.c_double
+    return _LIB
+
+
+def _pi(a):
+    return a.ctypes.data_as(P_I64)
+
+
+def _pf(a):
+    return a.ctypes.data_as(P_F64)
+
+
+def _ai(a):
+    return np.ascontiguousarray(a, dtype=i64)
+
+
+def _af(a):
+    return np.ascontiguousarray(a, dtype=f64)
+
+
+def _view(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+
+class Settings(C.Structure):
+    """orc_settings / CoreSettings subset (settings.rs:139-181)."""
+    _fields_ = [("static_reg_enable", C.c_int), ("static_reg_constant", C.c_double),
+                ("static_reg_proportional", C.c_double), ("dynamic_reg_enable", C.c_int),
+                ("dynamic_reg_eps", C.c_double), ("dynamic_reg_delta", C.c_double),
+                ("ir_enable", C.c_int), ("ir_reltol", C.c_double), ("ir_abstol", C.c_double),
+                ("ir_max_iter", C.c_int32), ("ir_stop_ratio", C.c_double)]
+
+    @staticmethod
+    def default():
+        s = Settings()
+        lib().orc_settings_default(C.byref(s))
+        return s
+
+
+# ----------------------------------------------------------------------------
+# free functions
+# ----------------------------------------------------------------------------
+def invperm(p):
+    p = _ai(p)
+    ip = np.zeros_like(p)
+    rc = lib().orc_invperm(C.c_int64(len(p)), _pi(p), _pi(ip))
+    if rc:
+        raise ValueError(ERR_NAMES[rc])
+    return ip
+
+
+def permute(b, p):
+    b, p = _af(b), _ai(p)
+    x = np.zeros_like(b)
+    lib().orc_permute(C.c_int64(len(p)), _pf(x), _pf(b), _pi(p))
+    return x
+
+
+def ipermute(b, p):
+    b, p = _af(b), _ai(p)
+    x = np.zeros_like(b)
+    lib().orc_ipermute(C.c_int64(len(p)), _pf(x), _pf(b), _pi(p))
+    return x
+
+
+def permute_symmetric(n, Ap, Ai, Ax, iperm):
+    Ap, Ai, Ax, iperm = _ai(Ap), _ai(Ai), _af(Ax), _ai(iperm)
+    nnz = int(Ap[n])
+    Pc = np.zeros(n + 1, dtype=i64)
+    Pr = np.zeros(nnz, dtype=i64)
+    Pv = np.zeros(nnz, dtype=f64)
+    mp = np.zeros(nnz, dtype=i64)
+    lib().orc_permute_symmetric(C.c_int64(n), _pi(Ap), _pi(Ai), _pf(Ax), _pi(iperm), _pi(Pc),
+                                _pi(Pr), _pf(Pv), _pi(mp))
+    return Pc, Pr, Pv, mp
+
+
+def etree(n, Ap, Ai):
+    Ap, Ai = _ai(Ap), _ai(Ai)
+    work = np.zeros(max(n, 1), dtype=i64)
+    Lnz = np.zeros(max(n, 1), dtype=i64)
+    et = np.zeros(max(n, 1), dtype=i64)
+    lib().orc_etree(C.c_int64(n), _pi(Ap), _pi(Ai), _pi(work), _pi(Lnz), _pi(et))
+    return et[:n], Lnz[:n]
+
+
+def lsolve(Lp, Li, Lx, x):
+    Lp, Li, Lx, x = _ai(Lp), _ai(Li), _af(Lx), _af(x).copy()
+    lib().orc_lsolve(C.c_int64(len(x)), _pi(Lp), _pi(Li), _pf(Lx), _pf(x))
+    return x
+
+
+def ltsolve(Lp, Li, Lx, x):
+    Lp, Li, Lx, x = _ai(Lp), _ai(Li), _af(Lx), _af(x).copy()
+    lib().orc_ltsolve(C.c_int64(len(x)), _pi(Lp), _pi(Li), _pf(Lx), _pf(x))
+    return x
+
+
+def solve_factors(Lp, Li, Lx, Dinv, b):
+    Lp, Li, Lx, Dinv, b = _ai(Lp), _ai(Li), _af(Lx), _af(Dinv), _af(b).copy()
+    lib().orc_solve_factors(C.c_int64(len(b)), _pi(Lp), _pi(Li), _pf(Lx), _pf(Dinv), _pf(b))
+    return b
+
+
+def symv(n, Ap, Ai, Ax, y, x, a, b):
+    Ap, Ai, Ax, y, x = _ai(Ap), _ai(Ai), _af(Ax), _af(y).copy(), _af(x)
+    lib().orc_symv(C.c_int64(n), _pi(Ap), _pi(Ai), _pf(Ax), _pf(y), _pf(x), C.c_double(a), C.c_double(b))
+    return y
+
+
+def quad_form_triu(n, Ap, Ai, Ax, y, x):
+    Ap, Ai, Ax, y, x = _ai(Ap), _ai(Ai), _af(Ax), _af(y), _af(x)
+    return lib().orc_quad_form_triu(C.c_int64(n), _pi(Ap), _pi(Ai), _pf(Ax), _pf(y), _pf(x))
+
+
+def norm_inf(v):
+    v = _af(v)
+    return lib().orc_norm_inf(_pf(v), C.c_int64(len(v)))
+
+
+def norm2(v):
+    v = _af(v)
+    return lib().orc_norm2(_pf(v), C.c_int64(len(v)))
+
+
+# ----------------------------------------------------------------------------
+# QDLDLFactorisation
+# ----------------------------------------------------------------------------
+class QDLDL:
+    """QDLDLFactorisation (qdldl.rs:72-211) with an explicit permutation."""
+
+    def __init__(self, n, Ap, Ai, Ax, perm=None, Dsigns=None, logical=False, regularize_enable=True,
+                 regularize_eps=1e-12, regularize_delta=1e-7, m=None):
+        Ap, Ai, Ax = _ai(Ap), _ai(Ai), _af(Ax)
+        perm = _ai(np.arange(n) if perm is None else perm)
+        self._h = C.c_void_p()
+        ds = None
+        if Dsigns is not None:
+            ds = np.ascontiguousarray(Dsigns, dtype=np.int8)
+        rc = lib().orc_qdldl_new(C.byref(self._h), C.c_int64(n if m is None else m), C.c_int64(n), _pi(Ap),
+                                 _pi(Ai), _pf(Ax), _pi(perm),
+                                 ds.ctypes.data_as(P_I8) if ds is not None else None,
+                                 C.c_int(int(logical)), C.c_int(int(regularize_enable)),
+                                 C.c_double(regularize_eps), C.c_double(regularize_delta))
+        if rc:
+            self._h = None
+            raise ValueError(ERR_NAMES[rc])
+        self.n = n
+        self.perm = perm
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_qdldl_free(self._h)
+            self._h = None
+
+    def solve(self, b):
+        b = _af(b).copy()
+        rc = lib().orc_qdldl_solve(self._h, _pf(b))
+        if rc:
+            raise RuntimeError(ERR_NAMES[rc])
+        return b
+
+    def update_values(self, idx, vals):
+        idx, vals = _ai(idx), _af(vals)
+        lib().orc_qdldl_update_values(self._h, _pi(idx), _pf(vals), C.c_int64(len(idx)))
+
+    def scale_values(self, idx, s):
+        idx = _ai(idx)
+        lib().orc_qdldl_scale_values(self._h, _pi(idx), C.c_double(s), C.c_int64(len(idx)))
+
+    def offset_values(self, idx, off, signs):
+        idx = _ai(idx)
+        signs = np.ascontiguousarray(signs, dtype=np.int8)
+        lib().orc_qdldl_offset_values(self._h, _pi(idx), C.c_double(off), signs.ctypes.data_as(P_I8),
+                                      C.c_int64(len(idx)))
+
+    def refactor(self):
+        rc = lib().orc_qdldl_refactor(self._h)
+        if rc:
+            raise RuntimeError(ERR_NAMES[rc])
+        return bool(lib().orc_qdldl_dinv_is_finite(self._h))
+
+    @property
+    def nnzL(self):
+        return lib().orc_qdldl_nnzL(self._h)
+
+    @property
+    def nnzA(self):
+        return lib().orc_qdldl_nnzA(self._h)
+
+    @property
+    def positive_inertia(self):
+        return lib().orc_qdldl_positive_inertia(self._h)
+
+    @property
+    def regularize_count(self):
+        return lib().orc_qdldl_regularize_count(self._h)
+
+    def _arr(self, name, n, dtype):
+        return _view(getattr(lib(), "orc_qdldl_" + name)(self._h), n, dtype)
+
+    @property
+    def Lp(self):
+        return self._arr("Lp", self.n + 1, i64)
+
+    @property
+    def Li(self):
+        return self._arr("Li", self.nnzL, i64)
+
+    @property
+    def Lx(self):
+        return self._arr("Lx", self.nnzL, f64)
+
+    @property
+    def D(self):
+        return self._arr("D", self.n, f64)
+
+    @property
+    def Dinv(self):
+        return self._arr("Dinv", self.n, f64)
+
+    @property
+    def etree(self):
+        return self._arr("etree", self.n, i64)
+
+    @property
+    def Lnz(self):
+        return self._arr("Lnz", self.n, i64)
+
+    @property
+    def triuA(self):
+        nnz = self.nnzA
+        return (self._arr("Ap", self.n + 1, i64), self._arr("Ai", nnz, i64), self._arr("Ax", nnz, f64))
+
+    @property
+    def AtoPAPt(self):
+        return self._arr("AtoPAPt", self.nnzA, i64)
+
+
+# ----------------------------------------------------------------------------
+# cones + KKT
+# ----------------------------------------------------------------------------
+class Cones:
+    """CompositeCone subset (compositecone.rs:11-128).  `specs` is a list of
+    (tag, dim) or (tag, dim, dim2)."""
+
+    def __init__(self, specs):
+        self.specs = [tuple(s) + (0,) * (3 - len(s)) for s in specs]
+        tags = np.array([s[0] for s in self.specs], dtype=np.int32)
+        dims = np.array([s[1] for s in self.specs], dtype=i64)
+        dims2 = np.array([s[2] for s in self.specs], dtype=i64)
+        self._h = C.c_void_p(lib().orc_cones_new(C.c_int64(len(self.specs)), tags.ctypes.data_as(P_I32),
+                                                 _pi(dims), _pi(dims2)))
+        self.numel = lib().orc_cones_numel(self._h)
+        self.nblockvals = lib().orc_cones_nblockvals(self._h)
+        self.pdim = lib().orc_cones_pdim(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_cones_free(self._h)
+            self._h = None
+
+    def update_scaling(self, s, z):
+        s, z = _af(s), _af(z)
+        return bool(lib().orc_cones_update_scaling(self._h, _pf(s), _pf(z)))
+
+    def get_Hs(self, init=None):
+        Hs = np.zeros(self.nblockvals) if init is None else _af(init).copy()
+        lib().orc_cones_get_Hs(self._h, _pf(Hs))
+        return Hs
+
+    def mul_Hs(self, x):
+        x = _af(x)
+        y = np.zeros_like(x)
+        lib().orc_cones_mul_Hs(self._h, _pf(y), _pf(x))
+        return y
+
+    def numel_of(self, i):
+        tag, dim, dim2 = self.specs[i]
+        if tag in (CONE_EXP, CONE_POW):
+            return 3
+        if tag == CONE_PSDTRI:
+            return dim * (dim + 1) // 2
+        if tag == CONE_GENPOW:
+            return dim + dim2
+        return dim
+
+    def state(self, i):
+        L = lib()
+        n = self.numel_of(i)
+        out = {"eta": L.orc_cone_eta(self._h, C.c_int64(i)), "d": L.orc_cone_d(self._h, C.c_int64(i))}
+        for name in ("w", "lambda", "u", "v"):
+            p = getattr(L, "orc_cone_" + name)(self._h, C.c_int64(i))
+            out[name] = _view(p, n, f64) if p else None
+        return out
+
+
+class KKTMatrix:
+    """assemble_kkt_matrix result (kkt_assembly.rs:20-52)."""
+
+    def __init__(self, h, owned=True):
+        self._h = C.c_void_p(h)
+        self._owned = owned
+        L = lib()
+        self.N = L.orc_kktmat_dim(self._h)
+        self.nnz = L.orc_kktmat_nnz(self._h)
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "_h", None):
+            lib().orc_kktmat_free(self._h)
+            self._h = None
+
+    @property
+    def colptr(self):
+        return _view(lib().orc_kktmat_colptr(self._h), self.N + 1, i64)
+
+    @property
+    def rowval(self):
+        return _view(lib().orc_kktmat_rowval(self._h), self.nnz, i64)
+
+    @property
+    def nzval(self):
+        return _view(lib().orc_kktmat_nzval(self._h), self.nnz, f64)
+
+    def set_nzval(self, v):
+        v = _af(v)
+        assert len(v) == self.nnz
+        C.memmove(lib().orc_kktmat_nzval(self._h), v.ctypes.data, v.nbytes)
+
+    def map(self, name, n, i=None):
+        f = getattr(lib(), "orc_kktmat_map_" + name)
+        p = f(self._h) if i is None else f(self._h, C.c_int64(i))
+        return _view(p, n, i64)
+
+    @property
+    def nsparse(self):
+        return lib().orc_kktmat_nsparse(self._h)
+
+
+def assemble_kkt(n, m, P, A, cones, shape="triu"):
+    """P, A: (colptr,rowval,nzval) CSC triples."""
+    Pp, Pi, Px = _ai(P[0]), _ai(P[1]), _af(P[2])
+    Ap, Ai, Ax = _ai(A[0]), _ai(A[1]), _af(A[2])
+    h = lib().orc_assemble_kkt(C.c_int64(n), C.c_int64(m), _pi(Pp), _pi(Pi), _pf(Px), _pi(Ap), _pi(Ai),
+                               _pf(Ax), cones._h, C.c_int(0 if shape == "triu" else 1))
+    return KKTMatrix(h)
+
+
+class KKTSolver:
+    """DirectLDLKKTSolver (directldlkktsolver.rs:18-405) over the qdldl engine."""
+
+    def __init__(self, n, m, P, A, cones, settings=None, perm=None):
+        self.settings = settings or Settings.default()
+        self.cones = cones
+        Pp, Pi, Px = _ai(P[0]), _ai(P[1]), _af(P[2])
+        Ap, Ai, Ax = _ai(A[0]), _ai(A[1]), _af(A[2])
+        err = C.c_int(0)
+        pp = None
+        if perm is not None:
+            perm = _ai(perm)
+            pp = _pi(perm)
+        h = lib().orc_kktsolver_new(C.c_int64(n), C.c_int64(m), _pi(Pp), _pi(Pi), _pf(Px), _pi(Ap), _pi(Ai),
+                                    _pf(Ax), cones._h, C.byref(self.settings), pp, C.byref(err))
+        if not h:
+            raise ValueError(ERR_NAMES.get(err.value, str(err.value)))
+        self._h = C.c_void_p(h)
+        self.n, self.m = n, m
+        self.N = lib().orc_kktsolver_dim(self._h)
+        self.p = lib().orc_kktsolver_pdim(self._h)
+        self.kkt = KKTMatrix(lib().orc_kktsolver_kktmat(self._h), owned=False)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_kktsolver_free(self._h)
+            self._h = None
+
+    @property
+    def dsigns(self):
+        return _view(lib().orc_kktsolver_dsigns(self._h), self.N, np.int8)
+
+    def update(self, hs_override=None):
+        ho = None
+        if hs_override is not None:
+            hs_override = _af(hs_override)
+            ho = _pf(hs_override)
+        return bool(lib().orc_kktsolver_update(self._h, C.byref(self.settings), ho))
+
+    def setrhs(self, rhsx, rhsz):
+        rhsx, rhsz = _af(rhsx), _af(rhsz)
+        lib().orc_kktsolver_setrhs(self._h, _pf(rhsx), _pf(rhsz))
+
+    def solve(self):
+        x = np.zeros(self.n)
+        z = np.zeros(self.m)
+        ok = bool(lib().orc_kktsolver_solve(self._h, C.byref(self.settings), _pf(x), _pf(z)))
+        return ok, x, z
+
+    def solve_full(self, b):
+        b = _af(b)
+        x = np.zeros(self.N)
+        ok = bool(lib().orc_kktsolver_solve_full(self._h, C.byref(self.settings), _pf(b), _pf(x)))
+        return ok, x
+
+    @property
+    def last_ir_iters(self):
+        return lib().orc_kktsolver_last_ir_iters(self._h)
+
+    @property
+    def regularizer(self):
+        return lib().orc_kktsolver_regularizer(self._h)

@@ -1,0 +1,352 @@
+"""Pins the CPU oracle against every known-answer test the reference holds for
+the KKT path.  Citations are relative to /root/reference/src."""
+import numpy as np
+import pytest
+
+UNKNOWN = -1
+
+
+def mat4():
+    # qdldl/test.rs:5-21
+    return 4, [0, 1, 3, 6, 8], [0, 0, 1, 0, 1, 2, 2, 3], [8., -3., 8., 2., -1., 8., -1., 1.]
+
+
+def test_invperm(oracle):
+    # qdldl/test.rs:31-47
+    oracle.invperm([3, 0, 2, 1])
+    with pytest.raises(ValueError):
+        oracle.invperm([3, 0, 2, 0])
+    with pytest.raises(ValueError):
+        oracle.invperm([4, 0, 2, 1])
+
+
+def test_permute(oracle):
+    # qdldl/test.rs:49-61
+    perm = [3, 0, 2, 1]
+    b = [1., 2., 3., 4.]
+    x = oracle.permute(b, perm)
+    assert list(x) == [4., 1., 3., 2.]
+    assert list(oracle.ipermute(x, perm)) == b
+
+
+def test_solve_from_factors(oracle):
+    # qdldl/test.rs:63-100 (exact equality, as in the reference)
+    Lp = [0, 2, 4, 5, 5]
+    Li = [1, 2, 2, 3, 3]
+    Lx = [1., 2., 1., 7., -3.]
+    dinv = [0.25, -1.0, -0.5, 1.0]
+    x = [-3., 2., 1., 4.]
+    assert list(oracle.lsolve(Lp, Li, Lx, [-3., -1., -3., 15.])) == x
+    assert list(oracle.ltsolve(Lp, Li, Lx, [1., 31., -11., 4.])) == x
+    assert list(oracle.solve_factors(Lp, Li, Lx, dinv, [4., -27., -1., -279.])) == x
+
+
+def test_etree(oracle):
+    # qdldl/test.rs:102-121
+    n, Ap, Ai, _ = mat4()
+    et, _ = oracle.etree(n, Ap, Ai)
+    assert list(et) == [1, 2, 3, UNKNOWN]
+
+
+def test_permute_symmetric(oracle):
+    # qdldl/test.rs:131-164
+    n, Ap, Ai, Ax = mat4()
+    Pc, Pr, Pv, mp = oracle.permute_symmetric(n, Ap, Ai, Ax, [0, 1, 2, 3])
+    assert list(Pc) == Ap and list(Pr) == Ai and list(Pv) == Ax
+    assert list(mp) == list(range(len(Ax)))
+    Ax2 = [float(i + 1) for i in range(len(Ax))]
+    iperm = oracle.invperm([2, 3, 0, 1])
+    Pc, Pr, Pv, _ = oracle.permute_symmetric(n, Ap, Ai, Ax2, iperm)
+    assert list(Pc) == [0, 1, 3, 5, 8]
+    assert list(Pr) == [0, 0, 1, 2, 0, 2, 3, 0]
+    assert list(Pv) == [6.0, 7.0, 8.0, 1.0, 4.0, 2.0, 3.0, 5.0]
+
+
+@pytest.mark.parametrize("perm", [[0, 1, 2, 3], [3, 0, 1, 2], [3, 0, 2, 1]])
+def test_solve_basic(oracle, perm):
+    # qdldl/test.rs:194-230 ([3,0,1,2] is the AMD answer of test_amd :123-129)
+    n, Ap, Ai, Ax = mat4()
+    f = oracle.QDLDL(n, Ap, Ai, Ax, perm=perm)
+    x = f.solve([20.0, -22.0, 32.0, -7.0])
+    assert np.max(np.abs(x - np.array([1., -2., 3., -4.]))) <= 1e-8
+
+
+def test_solve_logical(oracle):
+    # qdldl/test.rs:232-264
+    n, Ap, Ai, Ax = mat4()
+    f = oracle.QDLDL(n, Ap, Ai, Ax, logical=True)
+    with pytest.raises(RuntimeError):
+        f.solve([20.0, -22.0, 32.0, -7.0])
+    assert f.refactor()
+    x = f.solve([20.0, -22.0, 32.0, -7.0])
+    assert np.max(np.abs(x - np.array([1., -2., 3., -4.]))) <= 1e-8
+
+
+def test_bad_numeric_pivot(oracle):
+    # qdldl/test.rs:266-283
+    n, Ap, Ai, Ax = mat4()
+    A0 = list(Ax)
+    A0[0] = 0.
+    with pytest.raises(ValueError, match="ZeroPivot"):
+        oracle.QDLDL(n, Ap, Ai, A0, regularize_enable=False)
+    A1 = list(Ax)
+    A1[-1] = 0.
+    # the reference runs this case under its AMD ordering, perm=[3,0,1,2] (test_amd, :123-129),
+    # which makes the zeroed A[3,3] the first pivot
+    with pytest.raises(ValueError, match="ZeroPivot"):
+        oracle.QDLDL(n, Ap, Ai, A1, perm=[3, 0, 1, 2], regularize_enable=False)
+
+
+def test_structure_errors(oracle):
+    # qdldl/test.rs:285-318 (dense 3x3 => not triu; zero column)
+    Ap = [0, 3, 6, 9]
+    Ai = [0, 1, 2] * 3
+    Ax = [1., 2., 1., 3., 3., 4., 5., 6., 7.]
+    with pytest.raises(ValueError, match="NotUpperTriangular"):
+        oracle.QDLDL(3, Ap, Ai, Ax, logical=True)
+    # [1 0 5; 0 0 6; 1 0 7] in CSC: col1 empty (and col0 has a tril entry -> triu check first
+    # in the reference: check order is square, triu, empty col (qdldl.rs:213-228))
+    Ap = [0, 1, 1, 4]
+    Ai = [0, 0, 1, 2]
+    Ax = [1., 5., 6., 7.]
+    with pytest.raises(ValueError, match="EmptyColumn"):
+        oracle.QDLDL(3, Ap, Ai, Ax, logical=True)
+
+
+def test_faer_kat(oracle):
+    # ldlsolvers/faer_ldl.rs:352-404 -- boundary KAT shared by all engines
+    colptr = [0, 1, 2, 4, 6, 8, 10]
+    rowval = [0, 1, 0, 2, 1, 3, 0, 4, 1, 5]
+    nzval = [1.0, 2.0, 1.0, -1.0, 1.0, -2.0, -1.0, -3.0, -1.0, -4.0]
+    ds = [1, 1, -1, -1, -1, -1]
+    b = [1., 2., 3., 4., 5., 6.]
+    for perm in ([0, 1, 2, 3, 4, 5], [5, 3, 1, 4, 2, 0]):
+        f = oracle.QDLDL(6, colptr, rowval, nzval, perm=perm, Dsigns=ds, logical=True,
+                         regularize_eps=1e-13, regularize_delta=2e-7)
+        tri = f.triuA
+        mp = f.AtoPAPt
+        assert all(nzval[i] == tri[2][mp[i]] for i in range(len(nzval)))
+        assert f.refactor()
+        x = f.solve(b)
+        xs = [1.0, 0.9090909090909091, -2.0, -1.5454545454545454, -2.0, -1.7272727272727275]
+        assert np.max(np.abs(x - xs)) < 1e-10
+        f.update_values([9], [-10.0])
+        assert f.refactor()
+        x = f.solve(b)
+        xs = [1.0, 1.3076923076923077, -2.0, -1.346153846153846, -2.0, -0.7307692307692306]
+        assert np.max(np.abs(x - xs)) < 1e-10
+        f.offset_values([1, 2], 3., [1, -1])
+        f.scale_values([1, 2], 2.)
+        tri = f.triuA
+        assert tri[2][mp[1]] == (2.0 + 3.) * 2 and tri[2][mp[2]] == (1.0 - 3.) * 2
+
+
+def test_symv_quadform(oracle):
+    # algebra/tests/matrix.rs:4-14,250-286
+    Ap, Ai, Ax = [0, 1, 3, 6, 8], [0, 0, 1, 0, 1, 2, 2, 3], [4., -3., 8., 7., -1., 2., -3., 1.]
+    x = [1., 2., -3., -4.]
+    y = [0., 1., -1., 2.]
+    out = oracle.symv(4, Ap, Ai, Ax, y, x, -2., 3.)
+    assert list(out) == [46.0, -29.0, -25.0, -4.0]
+    # tril storage of the same matrix (A.t())
+    Lp, Li, Lx = [0, 3, 5, 7, 8], [0, 1, 2, 1, 2, 2, 3, 3], [4., -3., 7., 8., -1., 2., -3., 1.]
+    out = oracle.symv(4, Lp, Li, Lx, y, x, -2., 3.)
+    assert list(out) == [46.0, -29.0, -25.0, -4.0]
+    assert oracle.quad_form_triu(4, Ap, Ai, Ax, y, x) == 15.
+
+
+def test_norms(oracle):
+    # algebra/tests/vector.rs:103-180 (norm_inf NaN propagation; stable norm)
+    assert oracle.norm_inf([1., -5., 3.]) == 5.
+    assert np.isnan(oracle.norm_inf([1., np.nan, 3.]))
+    assert oracle.norm_inf([1., np.inf, 3.]) == np.inf
+    assert oracle.norm2([3., 4.]) == 5.
+    assert abs(oracle.norm2([1e200, 1e200]) - np.sqrt(2) * 1e200) < 1e186
+    assert oracle.norm2([0., 0.]) == 0.
+
+
+# ---- KKT assembly: kkt_assembly.rs:185-355 ------------------------------------
+def _dense_to_csc(M):
+    M = np.asarray(M, dtype=float)
+    colptr, rowval, nzval = [0], [], []
+    for j in range(M.shape[1]):
+        for i in range(M.shape[0]):
+            if M[i, j] != 0:
+                rowval.append(i)
+                nzval.append(M[i, j])
+        colptr.append(len(rowval))
+    return colptr, rowval, nzval
+
+
+def _csc_to_dense(N, colptr, rowval, nzval):
+    M = np.zeros((N, N))
+    for j in range(N):
+        for p in range(colptr[j], colptr[j + 1]):
+            M[rowval[p], j] += nzval[p]
+    return M
+
+
+P3 = [[1., 2., 4.], [0., 3., 5.], [0., 0., 6.]]
+A63 = [[7., 0., 8.], [0., 9., 10.], [1., 2., 3.], [7., 0., 8.], [0., 9., 10.], [1., 2., 3.]]
+
+
+def _assemble(oracle, specs, shape):
+    cones = oracle.Cones(specs)
+    K = oracle.assemble_kkt(3, 6, _dense_to_csc(P3), _dense_to_csc(A63), cones, shape)
+    return K, cones
+
+
+def _expected(shape, lower_right, extra=None):
+    P = np.array(P3)
+    A = np.array(A63)
+    N = 9 if extra is None else 11
+    M = np.zeros((N, N))
+    M[:3, :3] = P
+    M[:3, 3:9] = A.T
+    M[3:9, 3:9] = lower_right
+    if extra is not None:
+        M[3:9, 9] = 2.
+        M[3:9, 10] = 3.
+        M[9, 9] = 4.
+        M[10, 10] = 4.
+    return M if shape == "triu" else M.T
+
+
+@pytest.mark.parametrize("shape", ["triu", "tril"])
+def test_kkt_assembly_nncone(oracle, shape):
+    K, _ = _assemble(oracle, [(oracle.CONE_NONNEG, 6)], shape)
+    v = K.nzval
+    v[K.map("Hs", 6)] = -1.
+    got = _csc_to_dense(9, K.colptr, K.rowval, v)
+    assert np.array_equal(got, _expected(shape, -np.eye(6)))
+    # exact CSC pattern == CscMatrix::from(dense) pattern (sorted rows, no explicit zeros dropped
+    # except that structural entries are all nonzero here)
+    cp, rv, nv = _dense_to_csc(_expected(shape, -np.eye(6)))
+    assert list(K.colptr) == cp and list(K.rowval) == rv and list(v) == nv
+
+
+@pytest.mark.parametrize("shape", ["triu", "tril"])
+def test_kkt_assembly_expcones(oracle, shape):
+    K, _ = _assemble(oracle, [(oracle.CONE_EXP, 3), (oracle.CONE_EXP, 3)], shape)
+    v = K.nzval
+    v[K.map("Hs", 12)] = -1.
+    blk = -np.triu(np.ones((3, 3)))
+    lr = np.zeros((6, 6))
+    lr[:3, :3] = blk
+    lr[3:, 3:] = blk
+    exp = _expected(shape, lr)
+    cp, rv, nv = _dense_to_csc(exp)
+    assert list(K.colptr) == cp and list(K.rowval) == rv and list(v) == nv
+
+
+@pytest.mark.parametrize("shape", ["triu", "tril"])
+def test_kkt_assembly_socone(oracle, shape):
+    K, cones = _assemble(oracle, [(oracle.CONE_SOC, 6)], shape)
+    assert K.nsparse == 1 and cones.pdim == 2
+    v = K.nzval
+    v[K.map("v", 6, 0)] = 2.
+    v[K.map("u", 6, 0)] = 3.
+    v[K.map("D", 2, 0)] = 4.
+    v[K.map("Hs", 6)] = -1.
+    exp = _expected(shape, -np.eye(6), extra=True)
+    cp, rv, nv = _dense_to_csc(exp)
+    assert list(K.colptr) == cp and list(K.rowval) == rv and list(v) == nv
+    # diag_full: last (triu) / first (tril) entry of each column
+    df = K.map("diag_full", 11)
+    assert all(K.rowval[df[j]] == j for j in range(11))
+
+
+def test_kkt_missing_diag_and_signs(oracle):
+    # P with a missing diagonal entry -> structural zero inserted (kkt_assembly.rs:120-121)
+    P = [[1., 2., 0.], [0., 0., 5.], [0., 0., 0.]]
+    cones = oracle.Cones([(oracle.CONE_ZERO, 1), (oracle.CONE_NONNEG, 2), (oracle.CONE_SOC, 3)])
+    K = oracle.assemble_kkt(3, 6, _dense_to_csc(P), _dense_to_csc(A63), cones, "triu")
+    df = K.map("diag_full", K.N)
+    assert K.N == 9 and all(K.rowval[df[j]] == j for j in range(9))
+    # nnz formula kkt_assembly.rs:38-44: nnzP(3) + n(3) - diagP(1) + nnzA(14) + Hs(1+2+6) + 0 + 0
+    assert K.nnz == 3 + 3 - 1 + 14 + 9
+    ks = oracle.KKTSolver(3, 6, _dense_to_csc(P), _dense_to_csc(A63), cones)
+    assert list(ks.dsigns) == [1, 1, 1] + [-1] * 6
+
+
+# ---- cones: NT identities (no KATs in the reference) ----------------
+def _rand_soc(rng, n):
+    v = rng.standard_normal(n)
+    v[0] = np.linalg.norm(v[1:]) + rng.uniform(0.1, 2.0)
+    return v
+
+
+@pytest.mark.parametrize("dim", [3, 4, 5, 50])
+def test_soc_scaling_identities(oracle, dim):
+    rng = np.random.default_rng(dim)
+    s, z = _rand_soc(rng, dim), _rand_soc(rng, dim)
+    cones = oracle.Cones([(oracle.CONE_SOC, dim)])
+    assert cones.update_scaling(s, z)
+    # Hs z = s for the NT scaling (W'W z = s)
+    assert np.allclose(cones.mul_Hs(z), s, rtol=1e-10, atol=1e-12)
+    st = cones.state(0)
+    w, eta = st["w"], st["eta"]
+    J = np.diag([1.] + [-1.] * (dim - 1))
+    H = eta ** 2 * (2 * np.outer(w, w) - J)
+    Hs = cones.get_Hs()
+    if dim <= 4:
+        # dense packed triu, column major (csc/utils.rs:183-200)
+        k = 0
+        for col in range(dim):
+            for row in range(col + 1):
+                assert abs(Hs[k] - H[row, col]) < 1e-10 * max(1, abs(H[row, col]))
+                k += 1
+    else:
+        # sparse form: H = eta^2 (D + u u' - v v')  (socone.rs:187-223)
+        D = np.diag(Hs) / eta ** 2
+        u, v = st["u"], st["v"]
+        assert np.allclose(eta ** 2 * (D + np.outer(u, u) - np.outer(v, v)), H, rtol=1e-9, atol=1e-11)
+
+
+def test_nn_scaling(oracle):
+    rng = np.random.default_rng(0)
+    s, z = rng.uniform(0.1, 3, 7), rng.uniform(0.1, 3, 7)
+    cones = oracle.Cones([(oracle.CONE_NONNEG, 7)])
+    cones.update_scaling(s, z)
+    assert np.allclose(cones.get_Hs(), s / z, rtol=1e-15)
+    assert np.allclose(cones.mul_Hs(z), s, rtol=1e-15)
+
+
+# ---- full KKT solver: sparse-SOC expansion == dense Hs ---------------------------
+def test_kktsolver_matches_dense(oracle):
+    rng = np.random.default_rng(5)
+    n, dims = 6, [3, 2, 7, 4]
+    specs = [(oracle.CONE_ZERO, dims[0]), (oracle.CONE_NONNEG, dims[1]), (oracle.CONE_SOC, dims[2]),
+             (oracle.CONE_SOC, dims[3])]
+    m = sum(dims)
+    A = rng.standard_normal((m, n)) * (rng.uniform(size=(m, n)) < 0.6)
+    Pd = rng.standard_normal((n, n))
+    Pd = np.triu(Pd @ Pd.T + n * np.eye(n))
+    s = np.concatenate([np.zeros(3), rng.uniform(0.5, 2, 2), _rand_soc(rng, 7), _rand_soc(rng, 4)])
+    z = np.concatenate([np.zeros(3), rng.uniform(0.5, 2, 2), _rand_soc(rng, 7), _rand_soc(rng, 4)])
+    cones = oracle.Cones(specs)
+    assert cones.update_scaling(s, z)
+    ks = oracle.KKTSolver(n, m, _dense_to_csc(Pd), _dense_to_csc(A), cones)
+    assert ks.p == 2 and ks.N == n + m + 2
+    assert ks.update()
+    # dense reference: K = [P A'; A -H] with H built from mul_Hs columns
+    H = np.zeros((m, m))
+    for j in range(m):
+        e = np.zeros(m)
+        e[j] = 1.
+        H[:, j] = cones.mul_Hs(e)
+    Pfull = Pd + np.triu(Pd, 1).T
+    Kd = np.block([[Pfull, A.T], [A, -H]])
+    eps = ks.regularizer
+    Kreg = Kd + np.diag([eps] * n + [-eps] * m)
+    rhsx, rhsz = rng.standard_normal(n), rng.standard_normal(m)
+    ks.setrhs(rhsx, rhsz)
+    ok, x, zz = ks.solve()
+    assert ok
+    ref = np.linalg.solve(Kd + np.diag([0.] * n + [-1e-30] * 3 + [0.] * (m - 3)) if False else Kreg, np.concatenate([rhsx, rhsz]))
+    # IR is against the UNregularised K (directldlkktsolver.rs:255-261); zero-cone rows make Kd
+    # nonsingular here since A has full column rank on those rows w.h.p. -> compare to Kd solve
+    ref0 = np.linalg.solve(Kd, np.concatenate([rhsx, rhsz]))
+    got = np.concatenate([x, zz])
+    assert np.max(np.abs(got - ref0)) <= 1e-8 * max(1, np.max(np.abs(ref0)))
+    assert ref.shape == got.shape

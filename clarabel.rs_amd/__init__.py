@@ -1,0 +1,419 @@
+"""clarabel.rs_amd -- host-side mirror (Python/ctypes) of the MI355X-native KKT
+backend's C ABI (include/clarabel_hip.h).
+
+The reference's host language is Rust (absent from this image), so the mirror of
+its operator interface is written in Python over the C ABI, keeping the
+reference's names, argument meaning and error behaviour:
+
+  HipDirectLDLSolver   <->  trait DirectLDLSolver<f64>
+                            (src/solver/core/kktsolvers/direct/quasidef/mod.rs:14-26,
+                             reference engine ldlsolvers/qdldl.rs:18-107)
+  HipKKTSolver         <->  trait KKTSolver<f64> / DirectLDLKKTSolver
+                            (src/solver/core/kktsolvers/mod.rs:7-18,
+                             quasidef/directldlkktsolver.rs:18-405)
+
+There is NO CPU fallback: every numeric call runs hand-written HIP kernels from
+csrc/ through libclarabel_hip.so, and the import fails loudly when that library
+is missing.  (The CPU oracle under /oracle is test infrastructure and is never
+imported from here.)
+
+Because the directory name contains a dot it cannot be imported with a plain
+`import`; use `__graft_entry__.load_package()` (or tests/conftest.py's `hip`
+fixture), which loads it under the module name `clarabel_rs_amd`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclarabel_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clarabel_hip.h")
+
+u64 = np.uint64
+f64 = np.float64
+P_U64 = C.POINTER(C.c_uint64)
+P_I64 = C.POINTER(C.c_int64)
+P_F64 = C.POINTER(C.c_double)
+P_I8 = C.POINTER(C.c_int8)
+P_I32 = C.POINTER(C.c_int32)
+
+# chip_status
+OK, ERR_DIM, ERR_EMPTY_COLUMN, ERR_NOT_TRIU, ERR_ZERO_PIVOT, ERR_BAD_PERM = 0, -1, -2, -3, -4, -5
+ERR_NOT_FACTORED, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED = -6, -7, -8, -9, -10
+STATUS_NAMES = {0: "ok", -1: "IncompatibleDimension", -2: "EmptyColumn", -3: "NotUpperTriangular",
+                -4: "ZeroPivot", -5: "InvalidPermutation", -6: "NotFactored", -7: "NoDevice", -8: "HipError",
+                -9: "BadArgument", -10: "Unsupported"}
+DEVICE_HOST_ONLY = -2
+
+# SupportedConeT tags
+ZeroConeT, NonnegativeConeT, SecondOrderConeT, ExponentialConeT, PowerConeT, GenPowerConeT, PSDTriangleConeT = range(7)
+
+# profile families of chip_kkt_profile
+PF_NONE, PF_SYMV_T, PF_BWD_T, PF_FWD_T, PF_FACTOR_T = range(5)
+
+
+class ChipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = ""
+        try:
+            msg = lib().chip_last_error().decode()
+        except Exception:
+            pass
+        super().__init__("%s: %s (%d) %s" % (where, STATUS_NAMES.get(code, "?"), code, msg))
+
+
+class Settings(C.Structure):
+    """chip_settings == the CoreSettings fields the path consumes
+    (src/solver/implementations/default/settings.rs:126-181) + engine knobs."""
+    _fields_ = [("static_regularization_enable", C.c_int32), ("static_regularization_constant", C.c_double),
+                ("static_regularization_proportional", C.c_double), ("dynamic_regularization_enable", C.c_int32),
+                ("dynamic_regularization_eps", C.c_double), ("dynamic_regularization_delta", C.c_double),
+                ("iterative_refinement_enable", C.c_int32), ("iterative_refinement_reltol", C.c_double),
+                ("iterative_refinement_abstol", C.c_double), ("iterative_refinement_max_iter", C.c_int32),
+                ("iterative_refinement_stop_ratio", C.c_double), ("device", C.c_int32),
+                ("amd_dense_scale", C.c_double), ("use_graph", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+    @staticmethod
+    def default(**kw):
+        s = Settings()
+        lib().chip_settings_default(C.byref(s))
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+
+class Info(C.Structure):
+    """chip_info == LinearSolverInfo (src/solver/core/kktsolvers/mod.rs:27-38) + factor statistics."""
+    _fields_ = [("name", C.c_char * 16), ("threads", C.c_int64), ("direct", C.c_int32), ("nnzA", C.c_int64),
+                ("nnzL", C.c_int64), ("positive_inertia", C.c_int64), ("regularize_count", C.c_int64),
+                ("n", C.c_int64), ("n_levels", C.c_int64), ("amd_lnz", C.c_double), ("amd_ndiv", C.c_double),
+                ("amd_nmultsubs_ldl", C.c_double), ("last_ir_iterations", C.c_int32),
+                ("last_regularizer", C.c_double)]
+
+
+_LIB = None
+
+
+def build(verbose=False):
+    """Compile csrc/ into libclarabel_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: the HIP extension is mandatory (no CPU fallback). "
+                              "Run `python -c 'import __graft_entry__ as g; g.build()'`." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.chip_last_error.restype = C.c_char_p
+        L.chip_kkt_stream.restype = C.c_void_p
+        _LIB = L
+    return _LIB
+
+
+def device_count():
+    return int(lib().chip_device_count())
+
+
+def _u(a):
+    return np.ascontiguousarray(a, dtype=u64)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=f64)
+
+
+def _pu(a):
+    return a.ctypes.data_as(P_U64)
+
+
+def _pf(a):
+    return a.ctypes.data_as(P_F64)
+
+
+def _check(rc, where):
+    if rc < 0:
+        raise ChipError(rc, where)
+    return rc
+
+
+def amd_order(n, colptr, rowval, dense_scale=1.5):
+    """AMD ordering of the symmetric matrix with upper triangle (colptr,rowval).
+    Replaces `amd::order` at src/qdldl/qdldl.rs:905-917.  Returns (perm, iperm, info3)."""
+    colptr, rowval = _u(colptr), _u(rowval)
+    perm = np.zeros(n, dtype=u64)
+    iperm = np.zeros(n, dtype=u64)
+    info = np.zeros(3)
+    _check(lib().chip_amd_order(C.c_int64(n), _pu(colptr), _pu(rowval), C.c_double(dense_scale), _pu(perm),
+                                _pu(iperm), _pf(info)), "chip_amd_order")
+    return perm.astype(np.int64), iperm.astype(np.int64), info
+
+
+class CscMatrix:
+    """CscMatrix<f64> (src/algebra/csc/core.rs:45-60): m, n, colptr, rowval, nzval."""
+
+    def __init__(self, m, n, colptr, rowval, nzval):
+        self.m, self.n = int(m), int(n)
+        self.colptr = _u(colptr)
+        self.rowval = _u(rowval)
+        self.nzval = _f(nzval)
+        assert len(self.colptr) == self.n + 1 and len(self.rowval) == len(self.nzval)
+
+    @property
+    def nnz(self):
+        return int(self.colptr[-1])
+
+    @staticmethod
+    def from_scipy(M):
+        M = M.tocsc()
+        M.sort_indices()
+        return CscMatrix(M.shape[0], M.shape[1], M.indptr, M.indices, M.data)
+
+
+class HipDirectLDLSolver:
+    """`direct_solve_method = "hip"`: DirectLDLSolver<f64> on the MI355X.
+
+    new(KKT, Dsigns, settings, perm)  -- ldlsolvers/config.rs:21-22
+    required_matrix_shape() = Triu     -- quasidef/mod.rs:14-16"""
+
+    def __init__(self, KKT, Dsigns, settings=None, perm=None):
+        assert KKT.m == KKT.n, "KKT matrix is not square"  # ldlsolvers/qdldl.rs:24
+        self.settings = settings or Settings.default()
+        self.n = KKT.n
+        self._h = C.c_void_p()
+        ds = np.ascontiguousarray(Dsigns, dtype=np.int8)
+        pp = None
+        if perm is not None:
+            perm = _u(perm)
+            pp = _pu(perm)
+        _check(lib().chip_ldl_create(C.byref(self._h), C.c_int64(self.n), _pu(KKT.colptr), _pu(KKT.rowval),
+                                     _pf(KKT.nzval), ds.ctypes.data_as(P_I8), pp, C.byref(self.settings)),
+               "chip_ldl_create")
+
+    @staticmethod
+    def required_matrix_shape():
+        return "triu"
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().chip_ldl_destroy(self._h)
+            self._h = None
+
+    def update_values(self, index, values):
+        index, values = _u(index), _f(values)
+        _check(lib().chip_ldl_update_values(self._h, _pu(index), _pf(values), C.c_int64(len(index))), "update_values")
+
+    def scale_values(self, index, scale):
+        index = _u(index)
+        _check(lib().chip_ldl_scale_values(self._h, _pu(index), C.c_double(scale), C.c_int64(len(index))),
+               "scale_values")
+
+    def offset_values(self, index, offset, signs):
+        index = _u(index)
+        signs = np.ascontiguousarray(signs, dtype=np.int8)
+        assert len(index) == len(signs)  # qdldl.rs:167
+        _check(lib().chip_ldl_offset_values(self._h, _pu(index), C.c_double(offset), signs.ctypes.data_as(P_I8),
+                                            C.c_int64(len(index))), "offset_values")
+
+    def set_values(self, nzval):
+        nzval = _f(nzval)
+        _check(lib().chip_ldl_set_values(self._h, _pf(nzval)), "set_values")
+
+    def refactor(self, kkt=None):
+        """-> bool (all Dinv finite), ldlsolvers/qdldl.rs:98-106"""
+        return bool(_check(lib().chip_ldl_refactor(self._h), "refactor"))
+
+    def solve(self, kkt, x, b):
+        """x <- K^-1 b; b untouched (ldlsolvers/qdldl.rs:91-96)"""
+        b = _f(b)
+        assert x.dtype == f64 and x.flags.c_contiguous and len(x) == self.n and len(b) == self.n
+        _check(lib().chip_ldl_solve(self._h, _pf(x), _pf(b)), "solve")
+
+    def solve_dev(self, x_ptr, b_ptr):
+        _check(lib().chip_ldl_solve_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(b_ptr)), "solve_dev")
+
+    def linear_solver_info(self):
+        info = Info()
+        _check(lib().chip_ldl_info(self._h, C.byref(info)), "info")
+        return info
+
+    @property
+    def perm(self):
+        p = np.zeros(self.n, dtype=u64)
+        _check(lib().chip_ldl_get_perm(self._h, _pu(p)), "get_perm")
+        return p.astype(np.int64)
+
+    def symbolic(self):
+        info = self.linear_solver_info()
+        et = np.zeros(self.n, dtype=u64)
+        Lp = np.zeros(self.n + 1, dtype=u64)
+        Li = np.zeros(max(info.nnzL, 1), dtype=u64)
+        lv = np.zeros(info.n_levels + 1, dtype=u64)
+        _check(lib().chip_ldl_get_symbolic(self._h, _pu(et), _pu(Lp), _pu(Li), _pu(lv)), "get_symbolic")
+        et = et.astype(np.int64)  # UINT64_MAX -> -1
+        return et, Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), lv.astype(np.int64)
+
+    def factors(self):
+        info = self.linear_solver_info()
+        Lp = np.zeros(self.n + 1, dtype=u64)
+        Li = np.zeros(max(info.nnzL, 1), dtype=u64)
+        Lx = np.zeros(max(info.nnzL, 1))
+        D = np.zeros(self.n)
+        Dinv = np.zeros(self.n)
+        _check(lib().chip_ldl_get_factors(self._h, _pu(Lp), _pu(Li), _pf(Lx), _pf(D), _pf(Dinv)), "get_factors")
+        return Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), Lx[:info.nnzL], D, Dinv
+
+
+class HipKKTSolver:
+    """KKTSolver<f64> (kktsolvers/mod.rs:7-18) == DirectLDLKKTSolver on the device.
+
+    new(P, A, cones, m, n, settings) -- directldlkktsolver.rs:60-118.
+    `cones`: list of (tag, dim) or (tag, dim, dim2) SupportedConeT descriptors."""
+
+    def __init__(self, P, A, cones, m, n, settings=None, perm=None):
+        assert P.n == n and A.n == n and A.m == m
+        self.settings = settings or Settings.default()
+        self.cones = [tuple(c) + (0,) * (3 - len(c)) for c in cones]
+        tags = np.array([c[0] for c in self.cones], dtype=np.int32)
+        dims = np.array([c[1] for c in self.cones], dtype=np.int64)
+        dims2 = np.array([c[2] for c in self.cones], dtype=np.int64)
+        self._h = C.c_void_p()
+        pp = None
+        if perm is not None:
+            perm = _u(perm)
+            pp = _pu(perm)
+        _check(lib().chip_kkt_create(C.byref(self._h), C.c_int64(n), C.c_int64(m), _pu(P.colptr), _pu(P.rowval),
+                                     _pf(P.nzval), _pu(A.colptr), _pu(A.rowval), _pf(A.nzval),
+                                     C.c_int64(len(self.cones)), tags.ctypes.data_as(P_I32),
+                                     dims.ctypes.data_as(P_I64), dims2.ctypes.data_as(P_I64),
+                                     C.byref(self.settings), pp), "chip_kkt_create")
+        d = (C.c_int64 * 6)()
+        lib().chip_kkt_dims(self._h, d)
+        self.n, self.m, self.p, self.N, self.nnzK, self.nHs = [int(v) for v in d]
+        self.nnzP, self.nnzA = P.nnz, A.nnz
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().chip_kkt_destroy(self._h)
+            self._h = None
+
+    # -- layout introspection (host) ------------------------------------------
+    def kkt_matrix(self):
+        cp = np.zeros(self.N + 1, dtype=u64)
+        rv = np.zeros(max(self.nnzK, 1), dtype=u64)
+        nz = np.zeros(max(self.nnzK, 1))
+        _check(lib().chip_kkt_get_matrix(self._h, _pu(cp), _pu(rv), _pf(nz)), "get_matrix")
+        return CscMatrix(self.N, self.N, cp, rv[:self.nnzK], nz[:self.nnzK])
+
+    def maps(self):
+        mP = np.zeros(max(self.nnzP, 1), dtype=u64)
+        mA = np.zeros(max(self.nnzA, 1), dtype=u64)
+        mH = np.zeros(max(self.nHs, 1), dtype=u64)
+        dP = np.zeros(max(self.n, 1), dtype=u64)
+        dF = np.zeros(max(self.N, 1), dtype=u64)
+        ds = np.zeros(max(self.N, 1), dtype=np.int8)
+        _check(lib().chip_kkt_get_map(self._h, _pu(mP), _pu(mA), _pu(mH), _pu(dP), _pu(dF),
+                                      ds.ctypes.data_as(P_I8)), "get_map")
+        return {"P": mP[:self.nnzP].astype(np.int64), "A": mA[:self.nnzA].astype(np.int64),
+                "Hsblocks": mH[:self.nHs].astype(np.int64), "diagP": dP[:self.n].astype(np.int64),
+                "diag_full": dF[:self.N].astype(np.int64), "dsigns": ds[:self.N]}
+
+    @property
+    def perm(self):
+        p = np.zeros(self.N, dtype=u64)
+        _check(lib().chip_kkt_get_perm(self._h, _pu(p)), "get_perm")
+        return p.astype(np.int64)
+
+    def symbolic(self):
+        info = self.linear_solver_info()
+        et = np.zeros(self.N, dtype=u64)
+        Lp = np.zeros(self.N + 1, dtype=u64)
+        Li = np.zeros(max(info.nnzL, 1), dtype=u64)
+        lv = np.zeros(info.n_levels + 1, dtype=u64)
+        _check(lib().chip_kkt_get_symbolic(self._h, _pu(et), _pu(Lp), _pu(Li), _pu(lv)), "get_symbolic")
+        return et.astype(np.int64), Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), lv.astype(np.int64)
+
+    def values(self):
+        nz = np.zeros(max(self.nnzK, 1))
+        _check(lib().chip_kkt_get_values(self._h, _pf(nz)), "get_values")
+        return nz[:self.nnzK]
+
+    # -- the KKTSolver trait -----------------------------------------------------
+    def update_scaling(self, s, z):
+        """cones.update_scaling(s, z, mu, strategy) for the device-held cones -> bool"""
+        s, z = _f(s), _f(z)
+        assert len(s) == self.m and len(z) == self.m
+        return bool(_check(lib().chip_kkt_update_scaling(self._h, _pf(s), _pf(z)), "update_scaling"))
+
+    def update_scaling_dev(self, s_ptr, z_ptr):
+        return bool(_check(lib().chip_kkt_update_scaling_dev(self._h, C.c_void_p(s_ptr), C.c_void_p(z_ptr)),
+                           "update_scaling_dev"))
+
+    def update(self, hsblocks=None):
+        """KKTSolver::update(cones, settings) -> bool"""
+        hp = None
+        if hsblocks is not None:
+            hsblocks = _f(hsblocks)
+            assert len(hsblocks) == self.nHs
+            hp = _pf(hsblocks)
+        return bool(_check(lib().chip_kkt_update(self._h, hp), "update"))
+
+    def setrhs(self, rhsx, rhsz):
+        rhsx, rhsz = _f(rhsx), _f(rhsz)
+        assert len(rhsx) == self.n and len(rhsz) == self.m
+        _check(lib().chip_kkt_setrhs(self._h, _pf(rhsx), _pf(rhsz)), "setrhs")
+
+    def setrhs_dev(self, x_ptr, z_ptr):
+        _check(lib().chip_kkt_setrhs_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(z_ptr)), "setrhs_dev")
+
+    def solve(self, lhsx=None, lhsz=None):
+        """KKTSolver::solve(lhsx, lhsz, settings) -> bool"""
+        px = _pf(lhsx) if lhsx is not None else None
+        pz = _pf(lhsz) if lhsz is not None else None
+        return bool(_check(lib().chip_kkt_solve(self._h, px, pz), "solve"))
+
+    def solve_dev(self, x_ptr, z_ptr):
+        return bool(_check(lib().chip_kkt_solve_dev(self._h, C.c_void_p(x_ptr) if x_ptr else None,
+                                                    C.c_void_p(z_ptr) if z_ptr else None), "solve_dev"))
+
+    def solve_full(self, b):
+        b = _f(b)
+        assert len(b) == self.N
+        x = np.zeros(self.N)
+        ok = bool(_check(lib().chip_kkt_solve_full(self._h, _pf(x), _pf(b)), "solve_full"))
+        return ok, x
+
+    def update_P(self, Pnzval):
+        Pnzval = _f(Pnzval)
+        assert len(Pnzval) == self.nnzP
+        _check(lib().chip_kkt_update_P(self._h, _pf(Pnzval)), "update_P")
+
+    def update_A(self, Anzval):
+        Anzval = _f(Anzval)
+        assert len(Anzval) == self.nnzA
+        _check(lib().chip_kkt_update_A(self._h, _pf(Anzval)), "update_A")
+
+    def mul_Hs_dev(self, y_ptr, x_ptr):
+        _check(lib().chip_kkt_mul_Hs_dev(self._h, C.c_void_p(y_ptr), C.c_void_p(x_ptr)), "mul_Hs_dev")
+
+    def linear_solver_info(self):
+        info = Info()
+        _check(lib().chip_kkt_info(self._h, C.byref(info)), "info")
+        return info
+
+    def synchronize(self):
+        _check(lib().chip_kkt_synchronize(self._h), "synchronize")
+
+    def profile(self, family):
+        _check(lib().chip_kkt_profile(self._h, C.c_int32(family)), "profile")
+
+    def profile_read(self):
+        out = (C.c_double * 8)()
+        _check(lib().chip_kkt_profile_read(self._h, out), "profile_read")
+        return {"launches": int(out[0]), "ms": float(out[1]), "family": int(out[2])}

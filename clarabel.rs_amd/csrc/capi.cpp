@@ -1,0 +1,734 @@
+// capi.cpp -- the C ABI of include/clarabel_hip.h.
+//   chip_ldl_*  : DirectLDLSolver<f64>   (quasidef/mod.rs:14-26; behaviour of ldlsolvers/qdldl.rs)
+//   chip_kkt_*  : KKTSolver<f64> as implemented by DirectLDLKKTSolver
+//                 (quasidef/directldlkktsolver.rs:18-405), device resident
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "engine.hpp"
+
+using namespace chip;
+
+namespace {
+
+thread_local std::string g_last;
+
+int fail(int code, const std::string &msg) {
+    set_error(msg);
+    return code;
+}
+
+const i64 *as_i64(const uint64_t *p) { return reinterpret_cast<const i64 *>(p); }
+
+double bits_to_double(unsigned long long b) {
+    double d;
+    std::memcpy(&d, &b, sizeof(d));
+    return d;
+}
+
+void fill_info(const Engine &E, chip_info *info) {
+    std::memset(info, 0, sizeof(*info));
+    std::strncpy(info->name, "hip", sizeof(info->name) - 1);
+    info->threads = 1;
+    info->direct = 1;
+    info->nnzA = E.nnzK;
+    info->nnzL = E.nnzL;
+    info->n = E.N;
+    info->n_levels = E.nlevels;
+    info->amd_lnz = E.amd.lnz;
+    info->amd_ndiv = E.amd.ndiv;
+    info->amd_nmultsubs_ldl = E.amd.nmultsubs_ldl;
+    info->regularize_count = E.last_regularize_count;
+    info->positive_inertia = -1;
+}
+
+int count_positive(Engine &E, i64 *out) {
+    std::vector<double> d((size_t)E.N);
+    if (E.N) CHIP_HIP(hipMemcpy(d.data(), E.D, (size_t)E.N * sizeof(double), hipMemcpyDeviceToHost));
+    i64 c = 0;
+    for (double v : d) c += v > 0.0;
+    *out = c;
+    return CHIP_OK;
+}
+
+} // namespace
+
+// ===========================================================================
+struct chip_ldl {
+    Engine E;
+    std::vector<double> hK; // host mirror of the caller's K.nzval (update/scale/offset land here)
+    bool dirty = true;
+    double *d_b = nullptr, *d_x = nullptr, *d_y = nullptr;
+};
+
+struct chip_kkt {
+    KktLayout K;
+    Engine E;
+    // int32 device copies of the LDLDataMap pieces the kernels index with
+    int *mapHs = nullptr, *diag_full = nullptr, *mapP = nullptr, *mapA = nullptr;
+    // cones
+    int nn_count = 0, zero_count = 0;
+    int *nn_rows = nullptr, *nn_hsidx = nullptr, *zero_rows = nullptr;
+    dev::SocView soc{};
+    bool has_hostHs = false; // cones whose Hs must come from the host (Exp/Pow/PSD)
+    double *d_s = nullptr, *d_z = nullptr, *d_w = nullptr, *d_lam = nullptr;
+    double *d_rhs = nullptr, *d_lhs = nullptr; // n+m staging
+    double *bp = nullptr, *x = nullptr, *e = nullptr, *dx = nullptr; // N, permuted numbering
+    double *d_tmp = nullptr;                                         // max(N, nHs, nnzP, nnzA) staging
+    size_t tmp_len = 0;
+    int last_ir = 0;
+    double last_eps = 0;
+    bool scaling_pending_check = false;
+};
+
+extern "C" {
+
+void chip_settings_default(chip_settings *s) {
+    std::memset(s, 0, sizeof(*s));
+    s->static_regularization_enable = 1;
+    s->static_regularization_constant = 1e-8;
+    s->static_regularization_proportional = 2.220446049250313e-16 * 2.220446049250313e-16;
+    s->dynamic_regularization_enable = 1;
+    s->dynamic_regularization_eps = 1e-13;
+    s->dynamic_regularization_delta = 2e-7;
+    s->iterative_refinement_enable = 1;
+    s->iterative_refinement_reltol = 1e-13;
+    s->iterative_refinement_abstol = 1e-12;
+    s->iterative_refinement_max_iter = 10;
+    s->iterative_refinement_stop_ratio = 5.0;
+    s->device = -1;
+    s->amd_dense_scale = 1.5;
+    s->use_graph = 0;
+}
+
+const char *chip_last_error(void) {
+    g_last = get_error();
+    return g_last.c_str();
+}
+
+int32_t chip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t chip_amd_order(int64_t n, const uint64_t *colptr, const uint64_t *rowval, double dense_scale,
+                       uint64_t *perm, uint64_t *iperm, double *info3) {
+    if (n < 0 || !colptr || !perm) return fail(CHIP_ERR_ARG, "chip_amd_order: bad argument");
+    for (i64 c = 0; c < n; c++)
+        for (uint64_t p = colptr[c]; p < colptr[c + 1]; p++)
+            if (rowval[p] > (uint64_t)c) return fail(CHIP_ERR_NOT_TRIU, "matrix is not upper triangular");
+    std::vector<i64> p;
+    AmdInfo info;
+    int rc = amd_order(n, as_i64(colptr), as_i64(rowval), dense_scale, p, &info);
+    if (rc) return fail(CHIP_ERR_ARG, "amd_order failed");
+    for (i64 k = 0; k < n; k++) {
+        perm[k] = (uint64_t)p[k];
+        if (iperm) iperm[p[k]] = (uint64_t)k;
+    }
+    if (info3) {
+        info3[0] = info.lnz;
+        info3[1] = info.ndiv;
+        info3[2] = info.nmultsubs_ldl;
+    }
+    return CHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// L1
+// ---------------------------------------------------------------------------
+int32_t chip_ldl_create(chip_ldl **out, int64_t n, const uint64_t *colptr, const uint64_t *rowval,
+                        const double *nzval, const int8_t *dsigns, const uint64_t *perm_or_null,
+                        const chip_settings *settings) {
+    if (!out || n < 0 || !colptr || !rowval || !nzval) return fail(CHIP_ERR_ARG, "chip_ldl_create: bad argument");
+    *out = nullptr;
+    chip_settings st;
+    if (settings) st = *settings;
+    else chip_settings_default(&st);
+    std::vector<i64> perm0;
+    if (perm_or_null) perm0.assign(as_i64(perm_or_null), as_i64(perm_or_null) + n);
+    Symbolic S;
+    int rc = analyse(n, as_i64(colptr), as_i64(rowval), dsigns, perm0, st.amd_dense_scale, S);
+    if (rc) return rc;
+    std::unique_ptr<chip_ldl> h(new chip_ldl());
+    h->hK.assign(nzval, nzval + S.nnzK);
+    if (st.device == CHIP_DEVICE_HOST_ONLY) {
+        h->E.init_host_only(S, st);
+        *out = h.release();
+        return CHIP_OK;
+    }
+    rc = h->E.init(S, st);
+    if (rc) return rc;
+    h->dirty = true;
+    if ((rc = h->E.alloc(&h->d_b, (size_t)n))) return rc;
+    if ((rc = h->E.alloc(&h->d_x, (size_t)n))) return rc;
+    if ((rc = h->E.alloc(&h->d_y, (size_t)n))) return rc;
+    *out = h.release();
+    return CHIP_OK;
+}
+
+void chip_ldl_destroy(chip_ldl *h) { delete h; }
+
+int32_t chip_ldl_update_values(chip_ldl *h, const uint64_t *index, const double *values, int64_t k) {
+    if (!h) return CHIP_ERR_ARG;
+    for (i64 i = 0; i < k; i++) {
+        if (index[i] >= (uint64_t)h->E.nnzK) return fail(CHIP_ERR_ARG, "update_values: index out of range");
+        h->hK[index[i]] = values[i];
+    }
+    h->dirty = true;
+    return CHIP_OK;
+}
+int32_t chip_ldl_scale_values(chip_ldl *h, const uint64_t *index, double scale, int64_t k) {
+    if (!h) return CHIP_ERR_ARG;
+    for (i64 i = 0; i < k; i++) {
+        if (index[i] >= (uint64_t)h->E.nnzK) return fail(CHIP_ERR_ARG, "scale_values: index out of range");
+        h->hK[index[i]] *= scale;
+    }
+    h->dirty = true;
+    return CHIP_OK;
+}
+int32_t chip_ldl_offset_values(chip_ldl *h, const uint64_t *index, double offset, const int8_t *signs,
+                               int64_t k) {
+    if (!h) return CHIP_ERR_ARG;
+    for (i64 i = 0; i < k; i++) {
+        if (index[i] >= (uint64_t)h->E.nnzK) return fail(CHIP_ERR_ARG, "offset_values: index out of range");
+        if (signs[i] > 0) h->hK[index[i]] += offset;
+        else if (signs[i] < 0) h->hK[index[i]] -= offset;
+    }
+    h->dirty = true;
+    return CHIP_OK;
+}
+int32_t chip_ldl_set_values(chip_ldl *h, const double *kkt_nzval) {
+    if (!h || !kkt_nzval) return CHIP_ERR_ARG;
+    std::memcpy(h->hK.data(), kkt_nzval, (size_t)h->E.nnzK * sizeof(double));
+    h->dirty = true;
+    return CHIP_OK;
+}
+#define NEED_DEVICE(E) \
+    if ((E).host_only) return fail(CHIP_ERR_NO_DEVICE, "host-only handle: no numeric work without a GPU")
+
+int32_t chip_ldl_get_symbolic(const chip_ldl *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,
+                              uint64_t *lvlptr) {
+    if (!h) return CHIP_ERR_ARG;
+    return h->E.get_symbolic(etree, Lp, Li, lvlptr);
+}
+
+int32_t chip_ldl_refactor(chip_ldl *h) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    if (h->dirty && E.nnzK) {
+        CHIP_HIP(hipMemcpyAsync(E.Kx, h->hK.data(), (size_t)E.nnzK * sizeof(double), hipMemcpyHostToDevice,
+                                E.stream));
+        h->dirty = false;
+    }
+    return E.refactor(false, nullptr);
+}
+int32_t chip_ldl_solve_dev(chip_ldl *h, double *x_dev, const double *b_dev) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first refactor()");
+    CHIP_HIP(hipSetDevice(E.device));
+    dev::permute_in(E.stream, h->d_y, b_dev, E.perm, E.N);
+    E.enqueue_solve_inplace(h->d_y);
+    dev::permute_out(E.stream, x_dev, h->d_y, E.perm, E.N);
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+int32_t chip_ldl_solve(chip_ldl *h, double *x, const double *b) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first refactor()");
+    CHIP_HIP(hipSetDevice(E.device));
+    const size_t bytes = (size_t)E.N * sizeof(double);
+    if (E.N) CHIP_HIP(hipMemcpyAsync(h->d_b, b, bytes, hipMemcpyHostToDevice, E.stream));
+    int rc = chip_ldl_solve_dev(h, h->d_x, h->d_b);
+    if (rc) return rc;
+    if (E.N) CHIP_HIP(hipMemcpyAsync(x, h->d_x, bytes, hipMemcpyDeviceToHost, E.stream));
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    return CHIP_OK;
+}
+int32_t chip_ldl_info(const chip_ldl *h, chip_info *info) {
+    if (!h || !info) return CHIP_ERR_ARG;
+    fill_info(h->E, info);
+    if (h->E.factored && !h->E.host_only) {
+        i64 c = 0;
+        int rc = count_positive(const_cast<Engine &>(h->E), &c);
+        if (rc) return rc;
+        info->positive_inertia = c;
+    }
+    return CHIP_OK;
+}
+int32_t chip_ldl_get_perm(const chip_ldl *h, uint64_t *perm) {
+    if (!h || !perm) return CHIP_ERR_ARG;
+    for (int i = 0; i < h->E.N; i++) perm[i] = (uint64_t)h->E.h_perm[i];
+    return CHIP_OK;
+}
+int32_t chip_ldl_get_factors(chip_ldl *h, uint64_t *Lp, uint64_t *Li, double *Lx, double *D, double *Dinv) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    const size_t n = (size_t)E.N, nl = (size_t)E.nnzL;
+    std::vector<int> tmp;
+    if (Lp) {
+        tmp.resize(n + 1);
+        CHIP_HIP(hipMemcpy(tmp.data(), E.Lp, (n + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i <= n; i++) Lp[i] = (uint64_t)tmp[i];
+    }
+    if (Li && nl) {
+        tmp.resize(nl);
+        CHIP_HIP(hipMemcpy(tmp.data(), E.Li, nl * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nl; i++) Li[i] = (uint64_t)tmp[i];
+    }
+    if (Lx && nl) CHIP_HIP(hipMemcpy(Lx, E.Lx, nl * sizeof(double), hipMemcpyDeviceToHost));
+    if (D && n) CHIP_HIP(hipMemcpy(D, E.D, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (Dinv && n) CHIP_HIP(hipMemcpy(Dinv, E.Dinv, n * sizeof(double), hipMemcpyDeviceToHost));
+    return CHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// L2
+// ---------------------------------------------------------------------------
+static std::vector<int> narrow(const std::vector<i64> &v, size_t n) {
+    std::vector<int> o(n);
+    for (size_t i = 0; i < n; i++) o[i] = (int)v[i];
+    return o;
+}
+
+int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pcolptr,
+                        const uint64_t *Prowval, const double *Pnzval, const uint64_t *Acolptr,
+                        const uint64_t *Arowval, const double *Anzval, int64_t ncones,
+                        const int32_t *cone_tags, const int64_t *cone_dims, const int64_t *cone_dims2,
+                        const chip_settings *settings, const uint64_t *perm_or_null) {
+    if (!out || n < 0 || m < 0 || !Pcolptr || !Acolptr) return fail(CHIP_ERR_ARG, "chip_kkt_create: bad argument");
+    *out = nullptr;
+    chip_settings st;
+    if (settings) st = *settings;
+    else chip_settings_default(&st);
+    std::unique_ptr<chip_kkt> h(new chip_kkt());
+    KktLayout &K = h->K;
+    i64 mm = 0;
+    int rc = build_cone_specs(ncones, cone_tags, cone_dims, cone_dims2, K.cones, mm, K.p, K.nHs);
+    if (rc) return CHIP_ERR_ARG;
+    if (mm != m) return fail(CHIP_ERR_DIM, "cone dimensions do not add up to m");
+    for (const ConeSpec &c : K.cones)
+        if (c.tag == CHIP_CONE_GENPOWER)
+            return fail(CHIP_ERR_UNSUPPORTED,
+                        "GenPowerCone is not held on the device yet; use the L1 boundary (chip_ldl_*)");
+    rc = assemble_kkt_triu(n, m, as_i64(Pcolptr), as_i64(Prowval), Pnzval, as_i64(Acolptr), as_i64(Arowval),
+                           Anzval, K);
+    if (rc) return rc;
+    std::vector<i64> perm0;
+    if (perm_or_null) perm0.assign(as_i64(perm_or_null), as_i64(perm_or_null) + K.N);
+    Symbolic S;
+    rc = analyse(K.N, K.colptr.data(), K.rowval.data(), K.dsigns.data(), perm0, st.amd_dense_scale, S);
+    if (rc) return rc;
+    Engine &E = h->E;
+    if (st.device == CHIP_DEVICE_HOST_ONLY) {
+        E.init_host_only(S, st);
+        *out = h.release();
+        return CHIP_OK;
+    }
+    rc = E.init(S, st);
+    if (rc) return rc;
+    if (K.nnz) CHIP_HIP(hipMemcpy(E.Kx, K.nzval.data(), (size_t)K.nnz * sizeof(double), hipMemcpyHostToDevice));
+
+    // ---- index maps as int32 ------------------------------------------------
+    if ((rc = E.upload(&h->mapHs, narrow(K.mapHs, (size_t)K.nHs), (size_t)K.nHs))) return rc;
+    if ((rc = E.upload(&h->diag_full, narrow(K.diag_full, (size_t)K.N), (size_t)K.N))) return rc;
+    const size_t nnzP = (size_t)Pcolptr[n], nnzA = (size_t)Acolptr[n];
+    if ((rc = E.upload(&h->mapP, narrow(K.mapP, nnzP), nnzP))) return rc;
+    if ((rc = E.upload(&h->mapA, narrow(K.mapA, nnzA), nnzA))) return rc;
+
+    // ---- cone work lists ----------------------------------------------------
+    std::vector<int> nn_rows, nn_hs, zero_rows, s_start, s_dim, s_hs, s_sidx, s_ptr, mapU, mapV, mapD;
+    for (const ConeSpec &c : K.cones) {
+        if (c.tag == CHIP_CONE_NONNEGATIVE) {
+            for (i64 k = 0; k < c.numel; k++) {
+                nn_rows.push_back((int)(c.start + k));
+                nn_hs.push_back((int)(c.block_start + k));
+            }
+        } else if (c.tag == CHIP_CONE_ZERO) {
+            for (i64 k = 0; k < c.numel; k++) zero_rows.push_back((int)(c.start + k));
+        } else if (c.tag == CHIP_CONE_SECONDORDER) {
+            s_start.push_back((int)c.start);
+            s_dim.push_back((int)c.numel);
+            s_hs.push_back((int)c.block_start);
+            s_sidx.push_back((int)c.sparse_idx);
+        } else {
+            h->has_hostHs = true;
+        }
+    }
+    const size_t nsp = K.sp_ptr.size() ? K.sp_ptr.size() - 1 : 0;
+    s_ptr = narrow(K.sp_ptr, nsp + 1);
+    mapU = narrow(K.sp_u, (size_t)(nsp ? K.sp_ptr[nsp] : 0));
+    mapV = narrow(K.sp_v, (size_t)(nsp ? K.sp_ptr[nsp] : 0));
+    for (size_t s = 0; s < nsp; s++) {
+        mapD.push_back((int)K.sp_D[3 * s]);
+        mapD.push_back((int)K.sp_D[3 * s + 1]);
+    }
+    h->nn_count = (int)nn_rows.size();
+    h->zero_count = (int)zero_rows.size();
+    if ((rc = E.upload(&h->nn_rows, nn_rows, nn_rows.size()))) return rc;
+    if ((rc = E.upload(&h->nn_hsidx, nn_hs, nn_hs.size()))) return rc;
+    if ((rc = E.upload(&h->zero_rows, zero_rows, zero_rows.size()))) return rc;
+    dev::SocView &sv = h->soc;
+    sv.ncones = (int)s_start.size();
+    int *p_start, *p_dim, *p_hs, *p_sidx, *p_ptr, *p_mu, *p_mv, *p_md;
+    if ((rc = E.upload(&p_start, s_start, s_start.size()))) return rc;
+    if ((rc = E.upload(&p_dim, s_dim, s_dim.size()))) return rc;
+    if ((rc = E.upload(&p_hs, s_hs, s_hs.size()))) return rc;
+    if ((rc = E.upload(&p_sidx, s_sidx, s_sidx.size()))) return rc;
+    if ((rc = E.upload(&p_ptr, s_ptr, s_ptr.size()))) return rc;
+    if ((rc = E.upload(&p_mu, mapU, mapU.size()))) return rc;
+    if ((rc = E.upload(&p_mv, mapV, mapV.size()))) return rc;
+    if ((rc = E.upload(&p_md, mapD, mapD.size()))) return rc;
+    sv.start = p_start;
+    sv.dim = p_dim;
+    sv.hs_start = p_hs;
+    sv.sparse_idx = p_sidx;
+    sv.sp_ptr = p_ptr;
+    sv.mapHs = h->mapHs;
+    sv.mapU = p_mu;
+    sv.mapV = p_mv;
+    sv.mapD = p_md;
+    if ((rc = E.alloc(&h->d_s, (size_t)m))) return rc;
+    if ((rc = E.alloc(&h->d_z, (size_t)m))) return rc;
+    if ((rc = E.alloc(&h->d_w, (size_t)m))) return rc;
+    if ((rc = E.alloc(&h->d_lam, (size_t)m))) return rc;
+    CHIP_HIP(hipMemset(h->d_w, 0, (size_t)(m ? m : 1) * sizeof(double)));
+    CHIP_HIP(hipMemset(h->d_lam, 0, (size_t)(m ? m : 1) * sizeof(double)));
+    sv.w = h->d_w;
+    sv.lam = h->d_lam;
+    double *st8;
+    if ((rc = E.alloc(&st8, (size_t)sv.ncones * 8))) return rc;
+    CHIP_HIP(hipMemset(st8, 0, (size_t)(sv.ncones ? sv.ncones : 1) * 8 * sizeof(double)));
+    sv.eta = st8;
+    sv.d = st8;
+    sv.fail = &E.mb_dev->soc_fail;
+    // ---- vectors -------------------------------------------------------------
+    if ((rc = E.alloc(&h->d_rhs, (size_t)(n + m)))) return rc;
+    if ((rc = E.alloc(&h->d_lhs, (size_t)(n + m)))) return rc;
+    if ((rc = E.alloc(&h->bp, (size_t)K.N))) return rc;
+    if ((rc = E.alloc(&h->x, (size_t)K.N))) return rc;
+    if ((rc = E.alloc(&h->e, (size_t)K.N))) return rc;
+    if ((rc = E.alloc(&h->dx, (size_t)K.N))) return rc;
+    h->tmp_len = std::max<size_t>({(size_t)K.N, (size_t)K.nHs, nnzP, nnzA, 1});
+    if ((rc = E.alloc(&h->d_tmp, h->tmp_len))) return rc;
+    CHIP_HIP(hipMemset(h->bp, 0, (size_t)(K.N ? K.N : 1) * sizeof(double)));
+    *out = h.release();
+    return CHIP_OK;
+}
+
+void chip_kkt_destroy(chip_kkt *h) { delete h; }
+
+int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[6]) {
+    if (!h) return CHIP_ERR_ARG;
+    out[0] = h->K.n;
+    out[1] = h->K.m;
+    out[2] = h->K.p;
+    out[3] = h->K.N;
+    out[4] = h->K.nnz;
+    out[5] = h->K.nHs;
+    return CHIP_OK;
+}
+int32_t chip_kkt_get_matrix(const chip_kkt *h, uint64_t *colptr, uint64_t *rowval, double *nzval) {
+    if (!h) return CHIP_ERR_ARG;
+    const KktLayout &K = h->K;
+    if (colptr)
+        for (i64 i = 0; i <= K.N; i++) colptr[i] = (uint64_t)K.colptr[i];
+    if (rowval)
+        for (i64 i = 0; i < K.nnz; i++) rowval[i] = (uint64_t)K.rowval[i];
+    if (nzval) std::memcpy(nzval, K.nzval.data(), (size_t)K.nnz * sizeof(double));
+    return CHIP_OK;
+}
+int32_t chip_kkt_get_map(const chip_kkt *h, uint64_t *mapP, uint64_t *mapA, uint64_t *mapHs, uint64_t *diagP,
+                         uint64_t *diag_full, int8_t *dsigns) {
+    if (!h) return CHIP_ERR_ARG;
+    const KktLayout &K = h->K;
+    auto cp = [](uint64_t *dst, const std::vector<i64> &src, size_t n) {
+        if (dst)
+            for (size_t i = 0; i < n; i++) dst[i] = (uint64_t)src[i];
+    };
+    cp(mapP, K.mapP, K.mapP.size() - 1);
+    cp(mapA, K.mapA, K.mapA.size() - 1);
+    cp(mapHs, K.mapHs, (size_t)K.nHs);
+    cp(diagP, K.diagP, (size_t)K.n);
+    cp(diag_full, K.diag_full, (size_t)K.N);
+    if (dsigns) std::memcpy(dsigns, K.dsigns.data(), (size_t)K.N);
+    return CHIP_OK;
+}
+
+int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const double *z_dev) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    if (h->soc.ncones) CHIP_HIP(hipMemsetAsync(&E.mb_dev->soc_fail, 0, sizeof(int), E.stream));
+    dev::nn_update(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam);
+    dev::soc_update_scaling(E.stream, h->soc, s_dev, z_dev);
+    CHIP_HIP(hipGetLastError());
+    h->scaling_pending_check = h->soc.ncones > 0; // verdict is folded into the next update()
+    return 1;
+}
+int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z) {
+    if (!h || !s || !z) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    const size_t bytes = (size_t)h->K.m * sizeof(double);
+    if (bytes) {
+        CHIP_HIP(hipMemcpyAsync(h->d_s, s, bytes, hipMemcpyHostToDevice, E.stream));
+        CHIP_HIP(hipMemcpyAsync(h->d_z, z, bytes, hipMemcpyHostToDevice, E.stream));
+    }
+    int rc = chip_kkt_update_scaling_dev(h, h->d_s, h->d_z);
+    if (rc < 0) return rc;
+    if (h->soc.ncones) {
+        rc = E.read_mailbox();
+        if (rc) return rc;
+        h->scaling_pending_check = false;
+        return E.mb_host->soc_fail ? 0 : 1;
+    }
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    return 1;
+}
+
+int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    const KktLayout &K = h->K;
+    CHIP_HIP(hipSetDevice(E.device));
+    if (h->has_hostHs) {
+        if (!hsblocks_or_null)
+            return fail(CHIP_ERR_ARG, "update: Hs blocks are required for Exp/Pow/PSD cones");
+        for (const ConeSpec &c : K.cones) {
+            if (c.tag == CHIP_CONE_ZERO || c.tag == CHIP_CONE_NONNEGATIVE || c.tag == CHIP_CONE_SECONDORDER)
+                continue;
+            CHIP_HIP(hipMemcpyAsync(h->d_tmp + c.block_start, hsblocks_or_null + c.block_start,
+                                    (size_t)c.block_len * sizeof(double), hipMemcpyHostToDevice, E.stream));
+            dev::scatter_values(E.stream, E.Kx, h->mapHs + c.block_start, h->d_tmp + c.block_start,
+                                (int)c.block_len, -1.0);
+        }
+    }
+    dev::nn_write_hs(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx);
+    dev::soc_write_kkt(E.stream, h->soc, E.Kx);
+    int ok = E.refactor(h->E.st.static_regularization_enable != 0, h->diag_full);
+    if (ok < 0) return ok;
+    h->last_eps = E.st.static_regularization_enable ? E.mb_host->eps : 0.0;
+    if (h->scaling_pending_check) {
+        h->scaling_pending_check = false;
+        if (E.mb_host->soc_fail) return 0;
+    }
+    return ok;
+}
+
+int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *rhsz_dev) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    dev::setrhs_perm(E.stream, h->bp, rhsx_dev, rhsz_dev, E.perm, (int)h->K.n, (int)h->K.m, E.N);
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+int32_t chip_kkt_setrhs(chip_kkt *h, const double *rhsx, const double *rhsz) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    const size_t n = (size_t)h->K.n, m = (size_t)h->K.m;
+    if (n) CHIP_HIP(hipMemcpyAsync(h->d_rhs, rhsx, n * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    if (m) CHIP_HIP(hipMemcpyAsync(h->d_rhs + n, rhsz, m * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    int rc = chip_kkt_setrhs_dev(h, h->d_rhs, h->d_rhs + n);
+    if (rc) return rc;
+    CHIP_HIP(hipStreamSynchronize(E.stream)); // the caller may reuse rhsx/rhsz
+    return CHIP_OK;
+}
+
+// x <- K^-1 bp with iterative refinement (directldlkktsolver.rs:168-189, :266-321);
+// everything in the engine's permuted numbering.  Returns the reference's bool.
+static int solve_core(chip_kkt *h) {
+    Engine &E = h->E;
+    const chip_settings &st = E.st;
+    const int N = E.N;
+    if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
+    h->last_ir = 0;
+    CHIP_HIP(hipMemcpyAsync(h->x, h->bp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
+    E.enqueue_solve_inplace(h->x);
+    Mailbox *mb = E.mb_dev;
+    CHIP_HIP(hipMemsetAsync(mb->nrm, 0, sizeof(mb->nrm) + sizeof(mb->nan), E.stream));
+    if (!st.iterative_refinement_enable) {
+        dev::norm_inf(E.stream, h->x, N, &mb->nrm[0], &mb->nan[0]);
+        int rc = E.read_mailbox();
+        if (rc) return rc;
+        const double nx = bits_to_double(E.mb_host->nrm[0]);
+        return (!E.mb_host->nan[0] && std::isfinite(nx)) ? 1 : 0;
+    }
+    double *x = h->x, *dx = h->dx;
+    dev::norm_inf(E.stream, h->bp, N, &mb->nrm[0], &mb->nan[0]);
+    E.enqueue_residual(h->e, h->bp, x);
+    dev::norm_inf(E.stream, h->e, N, &mb->nrm[1], &mb->nan[1]);
+    int rc = E.read_mailbox();
+    if (rc) return rc;
+    const double normb = E.mb_host->nan[0] ? NAN : bits_to_double(E.mb_host->nrm[0]);
+    double norme = E.mb_host->nan[1] ? NAN : bits_to_double(E.mb_host->nrm[1]);
+    if (!std::isfinite(norme)) return 0;
+    for (int it = 0; it < st.iterative_refinement_max_iter; it++) {
+        if (norme <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb) break;
+        const double lastnorme = norme;
+        CHIP_HIP(hipMemcpyAsync(dx, h->e, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
+        E.enqueue_solve_inplace(dx);
+        dev::add_vec(E.stream, dx, x, N);
+        CHIP_HIP(hipMemsetAsync(&mb->nrm[1], 0, sizeof(unsigned long long), E.stream));
+        CHIP_HIP(hipMemsetAsync(&mb->nan[1], 0, sizeof(int), E.stream));
+        E.enqueue_residual(h->e, h->bp, dx);
+        dev::norm_inf(E.stream, h->e, N, &mb->nrm[1], &mb->nan[1]);
+        rc = E.read_mailbox();
+        if (rc) return rc;
+        norme = E.mb_host->nan[1] ? NAN : bits_to_double(E.mb_host->nrm[1]);
+        h->last_ir += 1;
+        if (!std::isfinite(norme)) return 0;
+        const double improved = lastnorme / norme;
+        if (improved < st.iterative_refinement_stop_ratio) {
+            if (improved > 1.0) std::swap(x, dx);
+            break;
+        }
+        std::swap(x, dx);
+    }
+    h->x = x; // mem::swap of the Vecs in the reference
+    h->dx = dx;
+    return 1;
+}
+
+int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev, double *lhsz_dev) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    int ok = solve_core(h);
+    if (ok != 1) return ok;
+    dev::getlhs_perm(E.stream, lhsx_dev, lhsz_dev, h->x, E.iperm, (int)h->K.n, (int)h->K.m);
+    CHIP_HIP(hipGetLastError());
+    return 1;
+}
+int32_t chip_kkt_solve(chip_kkt *h, double *lhsx, double *lhsz) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    const size_t n = (size_t)h->K.n, m = (size_t)h->K.m;
+    int ok = chip_kkt_solve_dev(h, h->d_lhs, h->d_lhs + n);
+    if (ok != 1) return ok;
+    if (lhsx && n) CHIP_HIP(hipMemcpyAsync(lhsx, h->d_lhs, n * sizeof(double), hipMemcpyDeviceToHost, E.stream));
+    if (lhsz && m) CHIP_HIP(hipMemcpyAsync(lhsz, h->d_lhs + n, m * sizeof(double), hipMemcpyDeviceToHost, E.stream));
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    return 1;
+}
+int32_t chip_kkt_solve_full(chip_kkt *h, double *x, const double *b) {
+    if (!h || !x || !b) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    const size_t bytes = (size_t)E.N * sizeof(double);
+    CHIP_HIP(hipMemcpyAsync(h->d_tmp, b, bytes, hipMemcpyHostToDevice, E.stream));
+    dev::permute_in(E.stream, h->bp, h->d_tmp, E.perm, E.N);
+    int ok = solve_core(h);
+    if (ok != 1) return ok;
+    dev::permute_out(E.stream, h->d_tmp, h->x, E.perm, E.N);
+    CHIP_HIP(hipMemcpyAsync(x, h->d_tmp, bytes, hipMemcpyDeviceToHost, E.stream));
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    return 1;
+}
+
+static int update_block(chip_kkt *h, const int *map, const double *vals, size_t k) {
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    if (!k) return CHIP_OK;
+    CHIP_HIP(hipMemcpyAsync(h->d_tmp, vals, k * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    dev::scatter_values(E.stream, E.Kx, map, h->d_tmp, (int)k, 1.0);
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    return CHIP_OK;
+}
+int32_t chip_kkt_update_P(chip_kkt *h, const double *Pnzval) {
+    if (!h || !Pnzval) return CHIP_ERR_ARG;
+    return update_block(h, h->mapP, Pnzval, h->K.mapP.size() - 1);
+}
+int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval) {
+    if (!h || !Anzval) return CHIP_ERR_ARG;
+    return update_block(h, h->mapA, Anzval, h->K.mapA.size() - 1);
+}
+int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
+    if (!h) return CHIP_ERR_ARG;
+    if (h->has_hostHs) return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: only Zero/Nonnegative/SOC cones live on the device");
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    dev::cones_mul_Hs(E.stream, h->nn_rows, h->nn_count, h->soc, h->zero_rows, h->zero_count, y_dev, x_dev);
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+int32_t chip_kkt_info(const chip_kkt *h, chip_info *info) {
+    if (!h || !info) return CHIP_ERR_ARG;
+    fill_info(h->E, info);
+    info->last_ir_iterations = h->last_ir;
+    info->last_regularizer = h->last_eps;
+    if (h->E.factored && !h->E.host_only) {
+        i64 c = 0;
+        int rc = count_positive(const_cast<Engine &>(h->E), &c);
+        if (rc) return rc;
+        info->positive_inertia = c;
+    }
+    return CHIP_OK;
+}
+int32_t chip_kkt_get_perm(const chip_kkt *h, uint64_t *perm) {
+    if (!h || !perm) return CHIP_ERR_ARG;
+    for (int i = 0; i < h->E.N; i++) perm[i] = (uint64_t)h->E.h_perm[i];
+    return CHIP_OK;
+}
+int32_t chip_kkt_get_symbolic(const chip_kkt *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,
+                              uint64_t *lvlptr) {
+    if (!h) return CHIP_ERR_ARG;
+    return h->E.get_symbolic(etree, Lp, Li, lvlptr);
+}
+int32_t chip_kkt_get_values(chip_kkt *h, double *nzval) {
+    if (!h || !nzval) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    if (E.nnzK) CHIP_HIP(hipMemcpy(nzval, E.Kx, (size_t)E.nnzK * sizeof(double), hipMemcpyDeviceToHost));
+    return CHIP_OK;
+}
+int32_t chip_kkt_synchronize(chip_kkt *h) {
+    if (!h) return CHIP_ERR_ARG;
+    NEED_DEVICE(h->E);
+    CHIP_HIP(hipStreamSynchronize(h->E.stream));
+    return CHIP_OK;
+}
+void *chip_kkt_stream(chip_kkt *h) { return (h && !h->E.host_only) ? (void *)h->E.stream : nullptr; }
+int32_t chip_kkt_profile(chip_kkt *h, int32_t family) {
+    if (!h) return CHIP_ERR_ARG;
+    h->E.prof_collect();
+    h->E.prof_family = family;
+    h->E.prof_ms_total = 0;
+    h->E.prof_launches = 0;
+    return CHIP_OK;
+}
+int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]) {
+    if (!h) return CHIP_ERR_ARG;
+    h->E.prof_collect();
+    std::memset(out, 0, 8 * sizeof(double));
+    out[0] = (double)h->E.prof_launches;
+    out[1] = h->E.prof_ms_total;
+    out[2] = (double)h->E.prof_family;
+    return CHIP_OK;
+}
+
+} // extern "C"

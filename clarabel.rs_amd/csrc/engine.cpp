@@ -1,0 +1,282 @@
+// engine.cpp -- device-resident numeric LDL' / solve / residual sequences.
+// One HIP stream per handle; dependencies between elimination-tree levels are
+// kernel boundaries on that stream (see kernels.hip for the rationale).
+#include "engine.hpp"
+
+#include <cstring>
+
+namespace chip {
+
+std::string hip_err(hipError_t e, const char *what) {
+    return std::string(what) + ": " + hipGetErrorString(e);
+}
+
+Engine::~Engine() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (hipEvent_t ev : prof_events) (void)hipEventDestroy(ev);
+    for (void *p : allocs) (void)hipFree(p);
+    if (mb_host) (void)hipHostFree(mb_host);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+template <typename T> int Engine::alloc(T **dst, size_t n) {
+    void *p = nullptr;
+    CHIP_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    allocs.push_back(p);
+    *dst = (T *)p;
+    return CHIP_OK;
+}
+template <typename T> int Engine::upload(T **dst, const std::vector<T> &src, size_t n) {
+    int rc = alloc(dst, n);
+    if (rc) return rc;
+    if (n) CHIP_HIP(hipMemcpy(*dst, src.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return CHIP_OK;
+}
+int Engine::upload_lists(DeviceLists &Dl, const LevelLists &L) {
+    Dl.t_ptr = L.t_ptr;
+    Dl.w_ptr = L.w_ptr;
+    Dl.b_ptr = L.b_ptr;
+    Dl.br_ptr = L.br_ptr;
+    int rc;
+    if ((rc = upload(&Dl.t_idx, L.t_idx, L.t_idx.size()))) return rc;
+    if ((rc = upload(&Dl.w_idx, L.w_idx, L.w_idx.size()))) return rc;
+    if ((rc = upload(&Dl.b_row, L.b_row, L.b_row.size()))) return rc;
+    if ((rc = upload(&Dl.b_beg, L.b_beg, L.b_beg.size()))) return rc;
+    if ((rc = upload(&Dl.b_end, L.b_end, L.b_end.size()))) return rc;
+    if ((rc = upload(&Dl.br_idx, L.br_idx, L.br_idx.size()))) return rc;
+    return CHIP_OK;
+}
+
+void Engine::init_host_only(const Symbolic &S, const chip_settings &settings) {
+    st = settings;
+    host_only = true;
+    N = S.N;
+    nlevels = S.nlevels;
+    nnzK = S.nnzK;
+    nnzL = S.nnzL;
+    nnzS = S.nnzS;
+    h_perm = S.perm;
+    h_lvlptr = S.lvlptr;
+    h_etree = S.etree;
+    h_Lp = S.Lp;
+    h_Li = S.Li;
+    amd = S.amd;
+}
+
+int Engine::get_symbolic(uint64_t *etree, uint64_t *oLp, uint64_t *oLi, uint64_t *lvlptr) const {
+    if (etree)
+        for (int i = 0; i < N; i++) etree[i] = h_etree[i] < 0 ? UINT64_MAX : (uint64_t)h_etree[i];
+    if (lvlptr)
+        for (int l = 0; l <= nlevels; l++) lvlptr[l] = (uint64_t)h_lvlptr[l];
+    if (oLp || oLi) {
+        std::vector<i32> tp, ti;
+        const i32 *pLp = h_Lp.data(), *pLi = h_Li.data();
+        if (!host_only) {
+            tp.resize((size_t)N + 1);
+            ti.resize((size_t)nnzL + 1);
+            CHIP_HIP(hipMemcpy(tp.data(), Lp, ((size_t)N + 1) * sizeof(int), hipMemcpyDeviceToHost));
+            if (nnzL) CHIP_HIP(hipMemcpy(ti.data(), Li, (size_t)nnzL * sizeof(int), hipMemcpyDeviceToHost));
+            pLp = tp.data();
+            pLi = ti.data();
+        }
+        if (oLp)
+            for (int i = 0; i <= N; i++) oLp[i] = (uint64_t)pLp[i];
+        if (oLi)
+            for (i64 i = 0; i < nnzL; i++) oLi[i] = (uint64_t)pLi[i];
+    }
+    return CHIP_OK;
+}
+
+int Engine::init(const Symbolic &S, const chip_settings &settings) {
+    st = settings;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (the product has no CPU fallback)");
+        return CHIP_ERR_NO_DEVICE;
+    }
+    if (st.device >= 0) {
+        CHIP_HIP(hipSetDevice(st.device));
+        device = st.device;
+    } else {
+        CHIP_HIP(hipGetDevice(&device));
+    }
+    CHIP_HIP(hipStreamCreate(&stream));
+    N = S.N;
+    nlevels = S.nlevels;
+    nnzK = S.nnzK;
+    nnzL = S.nnzL;
+    nnzS = S.nnzS;
+    h_perm = S.perm;
+    h_lvlptr = S.lvlptr;
+    h_etree = S.etree;
+    amd = S.amd;
+    int rc;
+    const size_t n = (size_t)N;
+    if ((rc = upload(&a2l, S.a2l, (size_t)nnzK))) return rc;
+    if ((rc = upload(&Lp, S.Lp, n + 1))) return rc;
+    if ((rc = upload(&Li, S.Li, (size_t)nnzL))) return rc;
+    if ((rc = upload(&Rp, S.Rp, n + 1))) return rc;
+    if ((rc = upload(&Rcol, S.Rcol, (size_t)nnzL))) return rc;
+    if ((rc = upload(&Rpos, S.Rpos, (size_t)nnzL))) return rc;
+    if ((rc = upload(&Tpos, S.Tpos, (size_t)nnzL))) return rc;
+    if ((rc = upload(&perm, S.perm, n))) return rc;
+    if ((rc = upload(&iperm, S.iperm, n))) return rc;
+    if ((rc = upload(&Sp, S.Sp, n + 1))) return rc;
+    if ((rc = upload(&Scol, S.Scol, (size_t)nnzS))) return rc;
+    if ((rc = upload(&Smap, S.Smap, (size_t)nnzS))) return rc;
+    if ((rc = upload(&dsigns, S.dsigns, n))) return rc;
+    if ((rc = alloc(&Kx, (size_t)nnzK))) return rc;
+    if ((rc = alloc(&Lx, (size_t)nnzL))) return rc;
+    if ((rc = alloc(&Rx, (size_t)nnzL))) return rc;
+    if ((rc = alloc(&D, n))) return rc;
+    if ((rc = alloc(&Dinv, n))) return rc;
+    if ((rc = alloc(&Sx, (size_t)nnzS))) return rc;
+    if ((rc = upload_lists(fac, S.fac))) return rc;
+    if ((rc = upload_lists(fwd, S.fwd))) return rc;
+    if ((rc = upload_lists(bwd, S.bwd))) return rc;
+    if ((rc = upload_lists(smv, S.smv))) return rc;
+    if ((rc = alloc(&mb_dev, 1))) return rc;
+    CHIP_HIP(hipMemset(mb_dev, 0, sizeof(Mailbox)));
+    CHIP_HIP(hipHostMalloc((void **)&mb_host, sizeof(Mailbox), hipHostMallocDefault));
+    std::memset(mb_host, 0, sizeof(Mailbox));
+    return CHIP_OK;
+}
+
+dev::LdlView Engine::view() const {
+    dev::LdlView v{};
+    v.N = N;
+    v.nnzL = (int)nnzL;
+    v.Lp = Lp;
+    v.Li = Li;
+    v.Rp = Rp;
+    v.Rcol = Rcol;
+    v.Rpos = Rpos;
+    v.Tpos = Tpos;
+    v.Lx = Lx;
+    v.Rx = Rx;
+    v.D = D;
+    v.Dinv = Dinv;
+    v.dsigns = dsigns;
+    v.status = mb_dev->status; // address arithmetic only, never dereferenced on the host
+    v.reg_eps = st.dynamic_regularization_eps;
+    v.reg_delta = st.dynamic_regularization_delta;
+    return v;
+}
+
+void Engine::prof_begin(int family) {
+    if (family != prof_family) return;
+    if (prof_used + 2 > prof_events.size()) {
+        for (int i = 0; i < 64; i++) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) return;
+            prof_events.push_back(ev);
+        }
+    }
+    (void)hipEventRecord(prof_events[prof_used], stream);
+}
+void Engine::prof_end(int family) {
+    if (family != prof_family) return;
+    if (prof_used + 2 > prof_events.size()) return;
+    (void)hipEventRecord(prof_events[prof_used + 1], stream);
+    prof_used += 2;
+    if (prof_used >= 8192) prof_collect();
+}
+void Engine::prof_collect() {
+    if (!prof_used) return;
+    (void)hipEventSynchronize(prof_events[prof_used - 1]);
+    for (size_t i = 0; i + 1 < prof_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]) == hipSuccess) {
+            prof_ms_total += ms;
+            prof_launches++;
+        }
+    }
+    prof_used = 0;
+}
+
+int Engine::read_mailbox() {
+    CHIP_HIP(hipMemcpyAsync(mb_host, mb_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, stream));
+    CHIP_HIP(hipStreamSynchronize(stream));
+    return CHIP_OK;
+}
+
+// qdldl.rs:188-200 (refactor) on the device.  With static_reg the +-eps shift of
+// directldlkktsolver.rs:217-250 is applied while the values are scattered into
+// the factor's storage; Kx itself stays unregularised (that is what the
+// refinement residual must see, :255-261), so nothing has to be "restored".
+int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
+    const dev::LdlView v = view();
+    const double *eps_ptr = nullptr;
+    if (static_reg) {
+        dev::diag_absmax_eps(stream, Kx, diag_idx_dev, N, st.static_regularization_constant,
+                             st.static_regularization_proportional, (double *)mb_dev);
+        eps_ptr = (const double *)mb_dev;
+    }
+    CHIP_HIP(hipMemsetAsync(mb_dev->status, 0, sizeof(int) * 4, stream));
+    if (nnzL) CHIP_HIP(hipMemsetAsync(Lx, 0, (size_t)nnzL * sizeof(double), stream));
+    dev::scatter_init(stream, Kx, a2l, (int)nnzK, (int)nnzL, Lx, D, dsigns, eps_ptr);
+    for (int l = 0; l < nlevels; l++) {
+        prof_begin(PF_FACTOR_T);
+        dev::factor_T(stream, v, fac.T(l));
+        prof_end(PF_FACTOR_T);
+        dev::factor_W(stream, v, fac.W(l));
+        const dev::ChunkView b = fac.B(l);
+        if (b.count) {
+            dev::factor_B(stream, v, b);
+            dev::factor_finalize(stream, v, fac.BR(l));
+        }
+    }
+    dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
+    int rc = read_mailbox();
+    if (rc) return rc;
+    factored = true;
+    last_regularize_count = mb_host->status[2];
+    if (mb_host->status[1]) {
+        // the reference adapter unwrap()s QDLDLError::ZeroPivot (ldlsolvers/qdldl.rs:104)
+        // i.e. panics; we report it as a numerical failure instead.
+        set_error("zero pivot");
+        return 0;
+    }
+    return mb_host->status[0] ? 0 : 1;
+}
+
+// qdldl.rs:755-768 in the permuted numbering, in place
+void Engine::enqueue_solve_inplace(double *xp) {
+    dev::GatherArgs f{Rp, Rcol, Rx, xp, xp, nullptr};
+    for (int l = 1; l < nlevels; l++) {
+        const dev::ChunkView b = fwd.B(l);
+        if (b.count) dev::gather_B(stream, dev::FWD, f, b);
+        prof_begin(PF_FWD_T);
+        dev::gather_T(stream, dev::FWD, f, fwd.T(l));
+        prof_end(PF_FWD_T);
+        dev::gather_W(stream, dev::FWD, f, fwd.W(l));
+    }
+    dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv};
+    for (int l = nlevels - 1; l >= 0; l--) {
+        const dev::ChunkView b = bwd.B(l);
+        if (b.count) {
+            dev::gather_Bprep(stream, dev::BWD, g, bwd.BR(l));
+            dev::gather_B(stream, dev::BWD, g, b);
+        }
+        prof_begin(PF_BWD_T);
+        dev::gather_T(stream, dev::BWD, g, bwd.T(l));
+        prof_end(PF_BWD_T);
+        dev::gather_W(stream, dev::BWD, g, bwd.W(l));
+    }
+}
+
+// e = b - K x with the UNregularised K (directldlkktsolver.rs:334-347)
+void Engine::enqueue_residual(double *e, const double *b, const double *x) {
+    dev::GatherArgs a{Sp, Scol, Sx, x, e, b};
+    const dev::ChunkView bc = smv.B(0);
+    if (bc.count) {
+        dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));
+        dev::gather_B(stream, dev::SYMV, a, bc);
+    }
+    prof_begin(PF_SYMV_T);
+    dev::gather_T(stream, dev::SYMV, a, smv.T(0));
+    prof_end(PF_SYMV_T);
+    dev::gather_W(stream, dev::SYMV, a, smv.W(0));
+}
+
+} // namespace chip

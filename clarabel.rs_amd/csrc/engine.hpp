@@ -1,0 +1,103 @@
+// engine.hpp -- device-resident LDL' engine: owns the HBM copies of the symbolic
+// structures and values and enqueues the level-scheduled kernel sequences.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/clarabel_hip.h"
+#include "host.hpp"
+#include "kernels.hpp"
+
+namespace chip {
+
+struct DeviceLists {
+    std::vector<i32> t_ptr, w_ptr, b_ptr, br_ptr; // host copies of the level pointers
+    int *t_idx = nullptr, *w_idx = nullptr, *b_row = nullptr, *b_beg = nullptr, *b_end = nullptr,
+        *br_idx = nullptr;
+    dev::ListView T(int l) const { return {t_idx + t_ptr[l], t_ptr[l + 1] - t_ptr[l]}; }
+    dev::ListView W(int l) const { return {w_idx + w_ptr[l], w_ptr[l + 1] - w_ptr[l]}; }
+    dev::ListView BR(int l) const { return {br_idx + br_ptr[l], br_ptr[l + 1] - br_ptr[l]}; }
+    dev::ChunkView B(int l) const {
+        return {b_row + b_ptr[l], b_beg + b_ptr[l], b_end + b_ptr[l], b_ptr[l + 1] - b_ptr[l]};
+    }
+};
+
+// small device<->host mailbox (one 256-byte D2H copy per decision point)
+struct Mailbox {
+    double eps;                  // static regulariser of the last refactor
+    unsigned long long tmpmax;   // scratch of diag_absmax_eps
+    unsigned long long tmpnan;
+    unsigned long long nrm[2];   // bit patterns of ||b||inf, ||e||inf
+    int nan[2];
+    int status[4];               // non-finite pivot, zero pivot, regularize_count, (unused)
+    int soc_fail;
+    int pad[19];
+};
+static_assert(sizeof(Mailbox) <= 256, "mailbox");
+
+// profile families (hipEvent pairs around each launch of ONE selected family)
+enum ProfFamily { PF_NONE = 0, PF_SYMV_T = 1, PF_BWD_T = 2, PF_FWD_T = 3, PF_FACTOR_T = 4, PF_COUNT };
+
+struct Engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    chip_settings st{};
+    int N = 0, nlevels = 0;
+    i64 nnzK = 0, nnzL = 0, nnzS = 0;
+    // symbolic (device)
+    int *a2l = nullptr, *Lp = nullptr, *Li = nullptr, *Rp = nullptr, *Rcol = nullptr, *Rpos = nullptr,
+        *Tpos = nullptr, *perm = nullptr, *iperm = nullptr, *Sp = nullptr, *Scol = nullptr, *Smap = nullptr;
+    int8_t *dsigns = nullptr;
+    // values (device)
+    double *Kx = nullptr, *Lx = nullptr, *Rx = nullptr, *D = nullptr, *Dinv = nullptr, *Sx = nullptr;
+    DeviceLists fac, fwd, bwd, smv;
+    Mailbox *mb_dev = nullptr, *mb_host = nullptr;
+    std::vector<i32> h_perm, h_lvlptr, h_etree;
+    bool host_only = false;          // CHIP_DEVICE_HOST_ONLY: symbolic results only
+    std::vector<i32> h_Lp, h_Li;     // kept only for host-only handles
+    AmdInfo amd;
+    bool factored = false;
+    i64 last_regularize_count = 0;
+    std::vector<void *> allocs;
+    // profiling
+    int prof_family = PF_NONE;
+    std::vector<hipEvent_t> prof_events; // pairs
+    size_t prof_used = 0;
+    double prof_ms_total = 0;
+    i64 prof_launches = 0;
+
+    ~Engine();
+    int init(const Symbolic &S, const chip_settings &settings);
+    void init_host_only(const Symbolic &S, const chip_settings &settings);
+    int get_symbolic(uint64_t *etree, uint64_t *Lp, uint64_t *Li, uint64_t *lvlptr) const;
+    template <typename T> int upload(T **dst, const std::vector<T> &src, size_t n);
+    template <typename T> int alloc(T **dst, size_t n);
+    int upload_lists(DeviceLists &D, const LevelLists &L);
+
+    dev::LdlView view() const;
+    // enqueue: (optional static regularisation) -> scatter -> level-scheduled factor
+    // -> refresh of the symv values; then reads the status mailbox (one sync).
+    // returns 1 ok / 0 numerical failure / <0 error
+    int refactor(bool static_reg, const int *diag_idx_dev);
+    void enqueue_solve_inplace(double *xp);                                  // permuted numbering
+    void enqueue_residual(double *e, const double *b, const double *x);     // e = b - K x (permuted)
+    int read_mailbox();                                                      // D2H + sync
+    void prof_begin(int family);
+    void prof_end(int family);
+    void prof_collect();
+};
+
+std::string hip_err(hipError_t e, const char *what);
+
+#define CHIP_HIP(expr)                                                   \
+    do {                                                                 \
+        hipError_t _e = (expr);                                          \
+        if (_e != hipSuccess) {                                          \
+            chip::set_error(chip::hip_err(_e, #expr));                   \
+            return CHIP_ERR_HIP;                                         \
+        }                                                                \
+    } while (0)
+
+} // namespace chip

@@ -1,0 +1,116 @@
+// host.hpp -- host-side (C++17) pieces of the MI355X KKT backend: fill-reducing
+// ordering, symbolic analysis (runs ONCE per problem, on the host, as
+// north_star prescribes) and KKT assembly in Clarabel's exact CSC layout.
+// Reference citations are relative to /root/reference/src.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace chip {
+
+using i64 = int64_t;
+using i32 = int32_t;
+
+// ---------------------------------------------------------------------------
+// ordering (amd_order.cpp)
+// ---------------------------------------------------------------------------
+struct AmdInfo {
+    double lnz = 0, ndiv = 0, nmultsubs_ldl = 0;
+    i64 ndense = 0;
+};
+// Approximate minimum degree (Amestoy/Davis/Duff 1996) on the pattern of
+// A + A' given triu(A) in CSC.  perm[k] = k-th eliminated original index.
+// Stands in for crate `amd 0.2.2` (qdldl.rs:905-917; dense = 10*dense_scale*sqrt(n)).
+int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
+              AmdInfo *info);
+
+// ---------------------------------------------------------------------------
+// symbolic analysis (symbolic.cpp)
+// ---------------------------------------------------------------------------
+// Work-list classes used by every level-scheduled kernel family.
+//   T : one thread per row/column        (short)
+//   W : one 256-thread workgroup per row (medium)
+//   B : rows split in chunks over many workgroups, partial sums combined with
+//       fp64 atomics (the 10^6-long budget row of the portfolio SOCP)
+struct LevelLists {
+    // per level l: T rows = t_idx[t_ptr[l]..t_ptr[l+1]), W rows likewise,
+    // B chunks = (b_row, b_beg, b_end) triples in b_ptr ranges.
+    std::vector<i32> t_ptr, t_idx, w_ptr, w_idx, b_ptr, b_row, b_beg, b_end;
+    // rows that own at least one B chunk, per level (need a pre/post pass)
+    std::vector<i32> br_ptr, br_idx;
+};
+
+struct Symbolic {
+    i32 N = 0;
+    i64 nnzK = 0; // nnz(triu K)
+    i64 nnzL = 0;
+    std::vector<i32> perm, iperm; // final elimination order (level-major), perm[new] = old
+    std::vector<int8_t> dsigns;   // permuted D signs
+    // where each entry of the caller's K.nzval lands: < nnzL -> Lx position
+    // (CSC of L), otherwise nnzL + j -> D[j]
+    std::vector<i32> a2l;
+    // L, CSC with ascending rows (structure only; values live on the device)
+    std::vector<i32> Lp, Li;
+    // L, CSR (row j: columns k ascending), Rpos = CSC position of the entry,
+    // Tpos = CSR position of each CSC entry
+    std::vector<i32> Rp, Rcol, Rpos, Tpos;
+    std::vector<i32> etree; // parent in the final numbering, -1 = root
+    i32 nlevels = 0;
+    std::vector<i32> lvlptr; // level l = columns [lvlptr[l], lvlptr[l+1])
+    // full symmetric K (both triangles) in CSR, permuted numbering; Smap =
+    // index into the caller's K.nzval (so values are refreshed by a gather)
+    i64 nnzS = 0;
+    std::vector<i32> Sp, Scol, Smap;
+    // kernel work lists
+    LevelLists fac, fwd, bwd; // factor (by column), forward solve (rows of L), backward (columns)
+    LevelLists smv;           // symv: a single pseudo-level over all rows
+    AmdInfo amd;
+};
+
+// `perm0` empty => AMD.  Returns 0 or a negative chip_status.
+int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns_or_null,
+            const std::vector<i64> &perm0, double amd_dense_scale, Symbolic &S);
+
+// ---------------------------------------------------------------------------
+// KKT assembly (kkt_assembly.cpp)  -- kkt_assembly.rs:20-183, datamaps.rs
+// ---------------------------------------------------------------------------
+struct ConeSpec {
+    i32 tag;
+    i64 dim, dim2;
+    i64 numel;
+    bool hs_diag, sparse;
+    i64 pdim;
+    i64 start;       // rng_cones[i].start
+    i64 block_start; // rng_blocks[i].start
+    i64 block_len;
+    i64 sparse_col;  // first extra KKT column of a sparse-expandable cone, else -1
+    i64 sparse_idx;  // ordinal among sparse cones
+};
+
+struct KktLayout {
+    i64 n = 0, m = 0, p = 0, N = 0, nnz = 0;
+    std::vector<ConeSpec> cones;
+    i64 nHs = 0;
+    // triu K
+    std::vector<i64> colptr, rowval;
+    std::vector<double> nzval;
+    // LDLDataMap (datamaps.rs:350-362)
+    std::vector<i64> mapP, mapA, mapHs, diagP, diag_full;
+    // sparse maps, flattened: for sparse cone s the u-entries are
+    // sp_u[sp_ptr[s] .. sp_ptr[s]+numel), same for v; D indices sp_D[3*s..]
+    std::vector<i64> sp_ptr, sp_u, sp_v, sp_D;
+    // GenPow only: q (len dim1) and r (len dim2) offsets
+    std::vector<i64> sp_q_ptr, sp_q, sp_r_ptr, sp_r;
+    std::vector<int8_t> dsigns;
+};
+
+int build_cone_specs(i64 ncones, const i32 *tags, const i64 *dims, const i64 *dims2,
+                     std::vector<ConeSpec> &out, i64 &m, i64 &p, i64 &nHs);
+int assemble_kkt_triu(i64 n, i64 m, const i64 *Pp, const i64 *Pi, const double *Px, const i64 *Ap,
+                      const i64 *Ai, const double *Ax, KktLayout &K);
+
+void set_error(const std::string &msg);
+const char *get_error();
+
+} // namespace chip

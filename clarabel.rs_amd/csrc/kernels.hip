@@ -1,0 +1,740 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels of the KKT hot path.
+//
+// Everything here is HBM-bound gather/scatter over fp64 values and int32
+// indices: no MFMA.  Design rules applied throughout
+// (/opt/skills/guides/cdna_hip_programming.md):
+//   * 64-wide wavefronts: wave reductions use 64-lane shuffles, workgroups
+//     are 256 threads = 4 waves, "wave per row" kernels pack 4 rows per group;
+//   * the elimination order is level-major (symbolic.cpp), so the thread-per-
+//     row kernels of one level read D/Dinv/ptr/x over a contiguous index range
+//     (coalesced) and the blockIdx -> slab map is XCD-aware: hardware block b
+//     runs on XCD b%8, so logical block (b%8)*per + b/8 gives every XCD (own
+//     L2) one contiguous slab of rows;
+//   * all cross-row dependencies are resolved by kernel boundaries (one launch
+//     per elimination-tree level, ~1.5us each) -- cheaper than any grid barrier
+//     on this part (MI355X_MICROARCH.md price list) and placement independent;
+//   * rows too long for one workgroup (the 10^6-entry budget row) are split in
+//     chunks over many workgroups whose partial sums meet in one fp64 atomic
+//     per chunk, never one atomic per entry.
+//
+// Reference semantics restated (citations relative to /root/reference/src):
+//   numeric LDL' + pivot rule   qdldl/qdldl.rs:469-669  (rule :645-651)
+//   L / D L' solves             qdldl/qdldl.rs:708-768
+//   symv for refinement         algebra/csc/matrix_math.rs:178-208
+//   NN / SOC scaling + Hs       solver/core/cones/nonnegativecone.rs:77-108,
+//                               solver/core/cones/socone.rs:134-256
+#include "kernels.hpp"
+
+namespace chip {
+namespace dev {
+
+namespace {
+
+constexpr int WG = 256;
+
+// XCD-aware logical block id; grids are launched with a multiple of 8 blocks.
+__device__ __forceinline__ int logical_block() {
+    const int per = gridDim.x >> 3;
+    return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+inline int grid_for(int count) {
+    int nb = (count + WG - 1) / WG;
+    nb = (nb + 7) & ~7;
+    return nb < 8 ? 8 : nb;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// sum over a 256-thread workgroup, result broadcast to every thread
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ double block_max(double v, double *red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// qdldl.rs:645-665: sign-based dynamic regularisation, then invert.
+__device__ __forceinline__ double pivot_rule(const LdlView &v, int j, double d) {
+    const double sign = (double)v.dsigns[j];
+    if (d * sign < v.reg_eps) {
+        d = v.reg_delta * sign;
+        atomicAdd(&v.status[2], 1); // rare
+    }
+    if (d == 0.0) v.status[1] = 1;
+    const double dinv = 1.0 / d;
+    if (!isfinite(dinv)) v.status[0] = 1;
+    v.D[j] = d;
+    v.Dinv[j] = dinv;
+    return dinv;
+}
+
+// ---------------------------------------------------------------------------
+// value plumbing
+// ---------------------------------------------------------------------------
+// K.nzval (caller's order) -> initial values of the factorisation: off-diagonal
+// entry (r,c) lands in its slot of column min(pr,pc) of L, a diagonal entry in
+// D[.], optionally shifted by the static regulariser +-eps
+// (directldlkktsolver.rs:233-245).  Lx is zeroed beforehand (fill-in slots).
+__global__ __launch_bounds__(WG) void k_scatter_init(const double *__restrict__ Kx,
+                                                     const int *__restrict__ a2l, int nnzK, int nnzL,
+                                                     double *Lx, double *D,
+                                                     const int8_t *__restrict__ dsigns,
+                                                     const double *eps_ptr) {
+    const double eps = eps_ptr ? eps_ptr[0] : 0.0;
+    for (int t = logical_block() * WG + threadIdx.x; t < nnzK; t += gridDim.x * WG) {
+        const int tgt = a2l[t];
+        const double val = Kx[t];
+        if (tgt >= nnzL) {
+            const int j = tgt - nnzL;
+            D[j] = eps_ptr ? (dsigns[j] == 1 ? val + eps : val - eps) : val;
+        } else {
+            Lx[tgt] = val;
+        }
+    }
+}
+__global__ __launch_bounds__(WG) void k_gather_values(double *__restrict__ Sx,
+                                                      const double *__restrict__ Kx,
+                                                      const int *__restrict__ Smap, int nnzS) {
+    for (int t = logical_block() * WG + threadIdx.x; t < nnzS; t += gridDim.x * WG) Sx[t] = Kx[Smap[t]];
+}
+__global__ __launch_bounds__(WG) void k_scatter_values(double *Kx, const int *__restrict__ map,
+                                                       const double *__restrict__ vals, int k,
+                                                       double scale) {
+    for (int t = blockIdx.x * WG + threadIdx.x; t < k; t += gridDim.x * WG) Kx[map[t]] = vals[t] * scale;
+}
+// max |K[diag]| -> bits in scal[1] (u64 compare is monotone for non-negative doubles);
+// NaN propagates like vecmath.rs:132-142 through the flag in scal[2].
+__global__ __launch_bounds__(WG) void k_diag_absmax(const double *__restrict__ Kx,
+                                                    const int *__restrict__ didx, int N,
+                                                    unsigned long long *scal) {
+    __shared__ double red[4];
+    double m = 0.0;
+    bool nan = false;
+    for (int t = blockIdx.x * WG + threadIdx.x; t < N; t += gridDim.x * WG) {
+        const double a = Kx[didx[t]];
+        if (a != a) nan = true;
+        else m = fmax(m, fabs(a));
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomicMax(&scal[1], (unsigned long long)__double_as_longlong(m));
+    if (nan) scal[2] = 1ull;
+}
+__global__ void k_eps_from_max(double c, double prop, unsigned long long *scal) {
+    double m = __longlong_as_double((long long)scal[1]);
+    if (scal[2]) m = __longlong_as_double(0x7ff8000000000000ll);
+    ((double *)scal)[0] = c + prop * m; // directldlkktsolver.rs:324-329
+}
+
+// ---------------------------------------------------------------------------
+// numeric LDL': left-looking by columns, one launch per elimination-tree level
+//
+//   c_ij = a_ij - sum_{k in rowstruct(j)} l_ik d_k l_jk   (i in colstruct(j))
+//   d_j  = a_jj - sum_k l_jk^2 d_k ;  pivot rule ;  l_ij = c_ij / d_j
+//
+// Every k in rowstruct(j) is a descendant of j (lower level, finished in an
+// earlier launch), so a level's columns are independent.  Column j's slots
+// hold a_ij on entry (k_scatter_init) and l_ij on exit, also mirrored into
+// the row-major copy Rx that the forward substitution streams.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void finish_column_serial(const LdlView &v, int j, int cb, int ce, double d) {
+    const double dinv = pivot_rule(v, j, d);
+    for (int q = cb; q < ce; ++q) {
+        const double l = v.Lx[q] * dinv;
+        v.Lx[q] = l;
+        v.Rx[v.Tpos[q]] = l;
+    }
+}
+
+// T: one thread per column (few contributions, short column)
+__global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restrict__ cols, int count) {
+    const int tid = logical_block() * WG + threadIdx.x;
+    if (tid >= count) return;
+    const int j = cols[tid];
+    double d = v.D[j];
+    const int cb = v.Lp[j], ce = v.Lp[j + 1];
+    const int rb = v.Rp[j], re = v.Rp[j + 1];
+    for (int t = rb; t < re; ++t) {
+        const int k = v.Rcol[t], p = v.Rpos[t];
+        const double ljk = v.Lx[p];
+        const double w = ljk * v.D[k];
+        d -= ljk * w;
+        const int pe = v.Lp[k + 1];
+        int q = cb;
+        for (int pp = p + 1; pp < pe; ++pp) {
+            const int i = v.Li[pp];
+            while (v.Li[q] != i) ++q; // rows below j of column k are a subset of column j
+            v.Lx[q] -= v.Lx[pp] * w;
+            ++q;
+        }
+    }
+    finish_column_serial(v, j, cb, ce, d);
+}
+
+constexpr int W_LDS_CAP = 4096; // column values kept in LDS (32 KiB of 160 KiB)
+
+__device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int hi, int row) {
+    // first q in [lo,hi) with Li[q] >= row (the row is known to be present)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (Li[mid] < row) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// W: one 256-thread workgroup per column.  Threads stride over the
+// contributing columns k; column j's running values live in LDS and receive
+// LDS fp64 atomics (ds_add_f64).  Narrow columns (<= 4 rows: the u/v and
+// budget-like separators of block-arrow KKTs) take per-thread register
+// partials + one block reduction instead of hammering 4 LDS addresses.
+__global__ __launch_bounds__(WG) void k_factor_W(LdlView v, const int *__restrict__ cols, int count) {
+    __shared__ double acc[W_LDS_CAP];
+    __shared__ double red[4];
+    __shared__ double s_dinv;
+    if ((int)blockIdx.x >= count) return;
+    const int j = cols[blockIdx.x];
+    const int cb = v.Lp[j], cn = v.Lp[j + 1] - cb;
+    const int rb = v.Rp[j], rn = v.Rp[j + 1] - rb;
+    const int tid = threadIdx.x;
+    double dpart = 0.0;
+    if (cn <= 4) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const int r0 = cn > 0 ? v.Li[cb] : -1, r1 = cn > 1 ? v.Li[cb + 1] : -1;
+        const int r2 = cn > 2 ? v.Li[cb + 2] : -1;
+        for (int t = tid; t < rn; t += WG) {
+            const int k = v.Rcol[rb + t], p = v.Rpos[rb + t];
+            const double ljk = v.Lx[p];
+            const double w = ljk * v.D[k];
+            dpart += ljk * w;
+            const int pe = v.Lp[k + 1];
+            for (int pp = p + 1; pp < pe; ++pp) {
+                const int i = v.Li[pp];
+                const double u = v.Lx[pp] * w;
+                if (i == r0) a0 += u;
+                else if (i == r1) a1 += u;
+                else if (i == r2) a2 += u;
+                else a3 += u;
+            }
+        }
+        a0 = block_sum(a0, red);
+        a1 = block_sum(a1, red);
+        a2 = block_sum(a2, red);
+        a3 = block_sum(a3, red);
+        dpart = block_sum(dpart, red);
+        if (tid == 0) {
+            const double dinv = pivot_rule(v, j, v.D[j] - dpart);
+            const double a[4] = {a0, a1, a2, a3};
+            for (int q = 0; q < cn; ++q) {
+                const double l = (v.Lx[cb + q] - a[q]) * dinv;
+                v.Lx[cb + q] = l;
+                v.Rx[v.Tpos[cb + q]] = l;
+            }
+        }
+        return;
+    }
+    const bool lds = cn <= W_LDS_CAP;
+    if (lds)
+        for (int q = tid; q < cn; q += WG) acc[q] = v.Lx[cb + q];
+    __syncthreads();
+    for (int t = tid; t < rn; t += WG) {
+        const int k = v.Rcol[rb + t], p = v.Rpos[rb + t];
+        const double ljk = v.Lx[p];
+        const double w = ljk * v.D[k];
+        dpart += ljk * w;
+        const int pe = v.Lp[k + 1];
+        int q = cb;
+        for (int pp = p + 1; pp < pe; ++pp) {
+            q = find_row(v.Li, q, cb + cn, v.Li[pp]);
+            const double u = -(v.Lx[pp] * w);
+            if (lds) atomicAdd(&acc[q - cb], u);
+            else atomicAdd(&v.Lx[q], u);
+            ++q;
+        }
+    }
+    if (!lds) __threadfence();
+    dpart = block_sum(dpart, red);
+    if (tid == 0) s_dinv = pivot_rule(v, j, v.D[j] - dpart);
+    __syncthreads();
+    const double dinv = s_dinv;
+    for (int q = tid; q < cn; q += WG) {
+        const double c = lds ? acc[q]
+                             : __hip_atomic_load(&v.Lx[cb + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double l = c * dinv;
+        v.Lx[cb + q] = l;
+        v.Rx[v.Tpos[cb + q]] = l;
+    }
+}
+
+// B: a column with a huge row count (> 16384 contributions).  Each workgroup
+// folds one chunk of contributions and meets the others in global fp64
+// atomics on the column's slots / D[j]; k_factor_finalize then pivots+scales.
+__global__ __launch_bounds__(WG) void k_factor_B(LdlView v, const int *__restrict__ crow,
+                                                 const int *__restrict__ cbeg,
+                                                 const int *__restrict__ cend, int count) {
+    __shared__ double red[4];
+    if ((int)blockIdx.x >= count) return;
+    const int j = crow[blockIdx.x];
+    const int cb = v.Lp[j], ce = v.Lp[j + 1];
+    double dpart = 0.0;
+    for (int t = cbeg[blockIdx.x] + threadIdx.x; t < cend[blockIdx.x]; t += WG) {
+        const int k = v.Rcol[t], p = v.Rpos[t];
+        const double ljk = v.Lx[p];
+        const double w = ljk * v.D[k];
+        dpart += ljk * w;
+        const int pe = v.Lp[k + 1];
+        int q = cb;
+        for (int pp = p + 1; pp < pe; ++pp) {
+            q = find_row(v.Li, q, ce, v.Li[pp]);
+            atomicAdd(&v.Lx[q], -(v.Lx[pp] * w));
+            ++q;
+        }
+    }
+    dpart = block_sum(dpart, red);
+    if (threadIdx.x == 0) atomicAdd(&v.D[j], -dpart);
+}
+__global__ __launch_bounds__(WG) void k_factor_finalize(LdlView v, const int *__restrict__ cols, int count) {
+    __shared__ double s_dinv;
+    if ((int)blockIdx.x >= count) return;
+    const int j = cols[blockIdx.x];
+    const int cb = v.Lp[j], ce = v.Lp[j + 1];
+    if (threadIdx.x == 0) s_dinv = pivot_rule(v, j, v.D[j]);
+    __syncthreads();
+    const double dinv = s_dinv;
+    for (int q = cb + threadIdx.x; q < ce; q += WG) {
+        const double l = v.Lx[q] * dinv;
+        v.Lx[q] = l;
+        v.Rx[v.Tpos[q]] = l;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// row-gather family: forward substitution (rows of L), backward substitution
+// fused with D^-1 (columns of L = rows of L'), and the residual e = b - K x.
+//   FWD : out[r]  = out[r] - sum val[t] * xin[idx[t]]           (qdldl.rs:708-719)
+//   BWD : out[r]  = out[r]*Dinv[r] - sum ...                    (qdldl.rs:737-752)
+//   SYMV: out[r]  = b[r] - sum ...                              (directldlkktsolver.rs:334-347)
+// ---------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void store_row(const GatherArgs &a, int r, double s) {
+    if (MODE == FWD) a.out[r] = a.out[r] - s;
+    else if (MODE == BWD) a.out[r] = a.out[r] * a.aux[r] - s;
+    else a.out[r] = a.aux[r] - s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_gather_T(GatherArgs a, const int *__restrict__ rows, int count) {
+    const int tid = logical_block() * WG + threadIdx.x;
+    if (tid >= count) return;
+    const int r = rows[tid];
+    const int b = a.ptr[r], e = a.ptr[r + 1];
+    double s = 0.0;
+    for (int t = b; t < e; ++t) s += a.val[t] * a.xin[a.idx[t]];
+    store_row<MODE>(a, r, s);
+}
+// W: one wavefront per row, 4 rows per workgroup
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_gather_W(GatherArgs a, const int *__restrict__ rows, int count) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= count) return;
+    const int lane = threadIdx.x & 63;
+    const int r = rows[wid];
+    const int b = a.ptr[r], e = a.ptr[r + 1];
+    double s = 0.0;
+    for (int t = b + lane; t < e; t += 64) s += a.val[t] * a.xin[a.idx[t]];
+    s = wave_sum(s);
+    if (lane == 0) store_row<MODE>(a, r, s);
+}
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_gather_Bprep(GatherArgs a, const int *__restrict__ rows, int count) {
+    const int t = blockIdx.x * WG + threadIdx.x;
+    if (t >= count) return;
+    const int r = rows[t];
+    if (MODE == BWD) a.out[r] = a.out[r] * a.aux[r];
+    else if (MODE == SYMV) a.out[r] = a.aux[r];
+}
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_gather_B(GatherArgs a, const int *__restrict__ crow,
+                                                 const int *__restrict__ cbeg,
+                                                 const int *__restrict__ cend, int count) {
+    __shared__ double red[4];
+    if ((int)blockIdx.x >= count) return;
+    double s = 0.0;
+    for (int t = cbeg[blockIdx.x] + threadIdx.x; t < cend[blockIdx.x]; t += WG)
+        s += a.val[t] * a.xin[a.idx[t]];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(&a.out[crow[blockIdx.x]], -s);
+}
+
+// ---------------------------------------------------------------------------
+// vectors
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_permute_in(double *__restrict__ y, const double *__restrict__ b,
+                                                   const int *__restrict__ perm, int N) {
+    for (int j = logical_block() * WG + threadIdx.x; j < N; j += gridDim.x * WG) y[j] = b[perm[j]];
+}
+__global__ __launch_bounds__(WG) void k_permute_out(double *__restrict__ x, const double *__restrict__ y,
+                                                    const int *__restrict__ perm, int N) {
+    for (int j = logical_block() * WG + threadIdx.x; j < N; j += gridDim.x * WG) x[perm[j]] = y[j];
+}
+// directldlkktsolver.rs:160-166 in the permuted numbering
+__global__ __launch_bounds__(WG) void k_setrhs_perm(double *__restrict__ bp, const double *__restrict__ rx,
+                                                    const double *__restrict__ rz,
+                                                    const int *__restrict__ perm, int n, int m, int N) {
+    for (int j = logical_block() * WG + threadIdx.x; j < N; j += gridDim.x * WG) {
+        const int o = perm[j];
+        bp[j] = o < n ? rx[o] : (o < n + m ? rz[o - n] : 0.0);
+    }
+}
+// directldlkktsolver.rs:205-215
+__global__ __launch_bounds__(WG) void k_getlhs_perm(double *lx, double *lz, const double *__restrict__ xp,
+                                                    const int *__restrict__ iperm, int n, int m) {
+    for (int i = logical_block() * WG + threadIdx.x; i < n + m; i += gridDim.x * WG) {
+        const double val = xp[iperm[i]];
+        if (i < n) {
+            if (lx) lx[i] = val;
+        } else if (lz) lz[i - n] = val;
+    }
+}
+__global__ __launch_bounds__(WG) void k_add_vec(double *__restrict__ dx, const double *__restrict__ x, int N) {
+    for (int i = logical_block() * WG + threadIdx.x; i < N; i += gridDim.x * WG) dx[i] = 1.0 * x[i] + 1.0 * dx[i];
+}
+__global__ __launch_bounds__(WG) void k_norm_inf(const double *__restrict__ vv, int N,
+                                                 unsigned long long *out, int *nanflag) {
+    __shared__ double red[4];
+    double m = 0.0;
+    bool nan = false;
+    for (int i = logical_block() * WG + threadIdx.x; i < N; i += gridDim.x * WG) {
+        const double a = vv[i];
+        if (a != a) nan = true;
+        else m = fmax(m, fabs(a));
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    if (nan) *nanflag = 1;
+}
+
+// ---------------------------------------------------------------------------
+// cones: scaling update + Hs blocks fused into the KKT value update
+// ---------------------------------------------------------------------------
+// nonnegativecone.rs:77-90
+__global__ __launch_bounds__(WG) void k_nn_update(const int *__restrict__ rows, int count,
+                                                  const double *__restrict__ sv,
+                                                  const double *__restrict__ zv, double *w, double *lam) {
+    for (int t = logical_block() * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
+        const int r = rows[t];
+        const double s = sv[r], z = zv[r];
+        lam[r] = sqrt(s * z);
+        w[r] = sqrt(s / z);
+    }
+}
+// get_Hs (nonnegativecone.rs:96-101) + negate + scatter (directldlkktsolver.rs:138-143)
+__global__ __launch_bounds__(WG) void k_nn_write_hs(const int *__restrict__ rows,
+                                                    const int *__restrict__ hsidx, int count,
+                                                    const double *__restrict__ w,
+                                                    const int *__restrict__ mapHs, double *Kx) {
+    for (int t = logical_block() * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
+        const double wi = w[rows[t]];
+        Kx[mapHs[hsidx[t]]] = -(wi * wi);
+    }
+}
+
+// overflow-safe 2-norm of x[1..n) over a workgroup (vecmath.rs:206-226 computes the
+// same scale*sqrt(sum (x/scale)^2) with a running scale)
+__device__ __forceinline__ double block_norm_tail(const double *x, int n, double *red) {
+    double amax = 0.0;
+    for (int i = 1 + threadIdx.x; i < n; i += WG) amax = fmax(amax, fabs(x[i]));
+    amax = block_max(amax, red);
+    if (amax == 0.0) return 0.0;
+    double ss = 0.0;
+    for (int i = 1 + threadIdx.x; i < n; i += WG) {
+        const double r = fabs(x[i]) / amax;
+        ss += r * r;
+    }
+    ss = block_sum(ss, red);
+    return amax * sqrt(ss);
+}
+
+// per-cone state layout in v.eta/v.d plus the rank-2 coefficients
+//   st[8*c + 0..7] = eta, d, u0, u1, v1, (unused)
+// socone.rs:134-211, one workgroup per cone
+__global__ __launch_bounds__(WG) void k_soc_update_scaling(SocView v, const double *__restrict__ sv,
+                                                           const double *__restrict__ zv) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c];
+    const double *s = sv + v.start[c], *z = zv + v.start[c];
+    double *w = v.w + v.start[c], *lam = v.lam + v.start[c];
+    const int tid = threadIdx.x;
+    const double z0 = z[0], s0 = s[0];
+    const double z1n = block_norm_tail(z, n, red);
+    const double s1n = block_norm_tail(s, n, red);
+    const double zres = (z0 - z1n) * (z0 + z1n), sres = (s0 - s1n) * (s0 + s1n);
+    const double zscale = zres > 0.0 ? sqrt(zres) : 0.0;
+    const double sscale = sres > 0.0 ? sqrt(sres) : 0.0;
+    if (zscale == 0.0 || sscale == 0.0) {
+        if (tid == 0) *v.fail = 1;
+        return;
+    }
+    const double eta = sqrt(sscale / zscale);
+    const double rs = 1.0 / sscale, mrz = -(1.0 / zscale);
+    for (int i = tid; i < n; i += WG) {
+        double wi = s[i] * rs;
+        if (i == 0) wi += z0 / zscale;
+        else wi = mrz * z[i] + 1.0 * wi;
+        w[i] = wi;
+    }
+    __syncthreads();
+    const double w0a = w[0];
+    const double w1n = block_norm_tail(w, n, red);
+    const double wres = (w0a - w1n) * (w0a + w1n);
+    const double wscale = wres > 0.0 ? sqrt(wres) : 0.0;
+    if (wscale == 0.0) {
+        if (tid == 0) *v.fail = 1;
+        return;
+    }
+    const double rw = 1.0 / wscale;
+    double sq = 0.0;
+    for (int i = tid; i < n; i += WG) {
+        const double wi = w[i] * rw;
+        w[i] = wi;
+        if (i > 0) sq += wi * wi;
+    }
+    const double w1sq = block_sum(sq, red);
+    const double w0 = sqrt(1.0 + w1sq);
+    // lambda, socone.rs:174-184
+    const double gamma = 0.5 * wscale;
+    const double ca = (gamma + z0 / zscale) / sscale, cb = (gamma + s0 / sscale) / zscale;
+    const double sc = 1.0 / (s0 / sscale + z0 / zscale + 2.0 * gamma);
+    const double sqz = sqrt(sscale * zscale);
+    for (int i = tid; i < n; i += WG) {
+        if (i == 0) lam[0] = gamma * sqz;
+        else lam[i] = ((ca * s[i] + cb * z[i]) * sc) * sqz;
+    }
+    if (tid == 0) {
+        w[0] = w0;
+        double *st = v.eta + 8 * c;
+        st[0] = eta;
+        // rank-2 terms, socone.rs:187-208
+        const double alpha = 2.0 * w0;
+        const double wsq = w0 * w0 + w1sq;
+        const double wsqinv = 1.0 / wsq;
+        const double d = 0.5 * wsqinv;
+        const double u0 = sqrt(wsq - d);
+        st[1] = d;
+        st[2] = u0;
+        st[3] = alpha / u0;
+        st[4] = sqrt(2.0 * (2.0 + wsqinv) / (2.0 * wsq - wsqinv));
+    }
+}
+
+// get_Hs (socone.rs:217-246) negated, and the sparse expansion columns
+// (datamaps.rs:199-220): u, v scaled by -eta^2, D = [-eta^2, +eta^2].
+__global__ __launch_bounds__(WG) void k_soc_write_kkt(SocView v, double *Kx) {
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c];
+    const double *w = v.w + v.start[c];
+    const double *st = v.eta + 8 * c;
+    const double eta2 = st[0] * st[0];
+    const int *mh = v.mapHs + v.hs_start[c];
+    const int sidx = v.sparse_idx[c];
+    if (sidx >= 0) {
+        const double d = st[1], u0 = st[2], u1 = st[3], v1 = st[4];
+        const int *mu = v.mapU + v.sp_ptr[sidx], *mv = v.mapV + v.sp_ptr[sidx];
+        for (int i = threadIdx.x; i < n; i += WG) {
+            const double h = (i == 0) ? eta2 * d : eta2;
+            Kx[mh[i]] = -h;
+            const double ui = (i == 0) ? u0 : u1 * w[i];
+            const double vi = (i == 0) ? 0.0 : v1 * w[i];
+            Kx[mu[i]] = ui * (-eta2);
+            Kx[mv[i]] = vi * (-eta2);
+        }
+        if (threadIdx.x == 0) {
+            Kx[v.mapD[2 * sidx]] = -eta2;
+            Kx[v.mapD[2 * sidx + 1]] = eta2;
+        }
+    } else if (threadIdx.x == 0) {
+        // dense packed triu of eta^2 (2 w w' - J), dim <= 4
+        const double s2 = 1.4142135623730951;
+        double h = (s2 * w[0] - 1.0) * (s2 * w[0] + 1.0);
+        Kx[mh[0]] = -(h * eta2);
+        int k = 1;
+        for (int col = 1; col < n; ++col) {
+            const double wc = w[col];
+            for (int row = 0; row <= col; ++row) {
+                h = 2.0 * w[row] * wc;
+                if (row == col) h += 1.0;
+                Kx[mh[k++]] = -(h * eta2);
+            }
+        }
+    }
+}
+
+// mul_Hs: nonnegativecone.rs:103-108, zerocone.rs:98-100
+__global__ __launch_bounds__(WG) void k_nn_mul_hs(const int *__restrict__ rows, int count,
+                                                  const double *__restrict__ w, double *y,
+                                                  const double *__restrict__ x, int zero) {
+    for (int t = logical_block() * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
+        const int r = rows[t];
+        y[r] = zero ? 0.0 : w[r] * (w[r] * x[r]);
+    }
+}
+// socone.rs:248-256
+__global__ __launch_bounds__(WG) void k_soc_mul_hs(SocView v, double *y, const double *__restrict__ x) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c];
+    const double *w = v.w + v.start[c];
+    const double *xc = x + v.start[c];
+    double *yc = y + v.start[c];
+    double dp = 0.0;
+    for (int i = threadIdx.x; i < n; i += WG) dp += w[i] * xc[i];
+    const double cc = block_sum(dp, red) * 2.0;
+    const double eta = v.eta[8 * c];
+    const double e2 = eta * eta;
+    for (int i = threadIdx.x; i < n; i += WG) {
+        const double base = (i == 0) ? -xc[0] : xc[i];
+        yc[i] = (cc * w[i] + 1.0 * base) * e2;
+    }
+}
+
+} // namespace
+
+// ===========================================================================
+// launch wrappers
+// ===========================================================================
+void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int nnzL, double *Lx,
+                  double *D, const int8_t *dsigns, const double *eps) {
+    if (nnzK == 0) return;
+    int nb = grid_for(nnzK);
+    if (nb > 4096) nb = 4096;
+    k_scatter_init<<<nb, WG, 0, s>>>(Kx, a2l, nnzK, nnzL, Lx, D, dsigns, eps);
+}
+void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap, int nnzS) {
+    if (nnzS == 0) return;
+    int nb = grid_for(nnzS);
+    if (nb > 4096) nb = 4096;
+    k_gather_values<<<nb, WG, 0, s>>>(Sx, Kx, Smap, nnzS);
+}
+void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale) {
+    if (k == 0) return;
+    int nb = (k + WG - 1) / WG;
+    if (nb > 4096) nb = 4096;
+    k_scatter_values<<<nb, WG, 0, s>>>(Kx, map, vals, k, scale);
+}
+void diag_absmax_eps(hipStream_t s, const double *Kx, const int *didx, int N, double c, double prop,
+                     double *scal) {
+    (void)hipMemsetAsync(scal, 0, 3 * sizeof(double), s);
+    if (N > 0) {
+        int nb = (N + WG - 1) / WG;
+        if (nb > 2048) nb = 2048;
+        k_diag_absmax<<<nb, WG, 0, s>>>(Kx, didx, N, (unsigned long long *)scal);
+    }
+    k_eps_from_max<<<1, 1, 0, s>>>(c, prop, (unsigned long long *)scal);
+}
+
+void factor_T(hipStream_t s, const LdlView &v, ListView c) {
+    if (c.count) k_factor_T<<<grid_for(c.count), WG, 0, s>>>(v, c.idx, c.count);
+}
+void factor_W(hipStream_t s, const LdlView &v, ListView c) {
+    if (c.count) k_factor_W<<<c.count, WG, 0, s>>>(v, c.idx, c.count);
+}
+void factor_B(hipStream_t s, const LdlView &v, ChunkView c) {
+    if (c.count) k_factor_B<<<c.count, WG, 0, s>>>(v, c.row, c.beg, c.end, c.count);
+}
+void factor_finalize(hipStream_t s, const LdlView &v, ListView c) {
+    if (c.count) k_factor_finalize<<<c.count, WG, 0, s>>>(v, c.idx, c.count);
+}
+
+#define DISPATCH_MODE(KERNEL, GRID, ...)                                   \
+    switch (m) {                                                           \
+    case FWD: KERNEL<FWD><<<GRID, WG, 0, s>>>(__VA_ARGS__); break;         \
+    case BWD: KERNEL<BWD><<<GRID, WG, 0, s>>>(__VA_ARGS__); break;         \
+    default: KERNEL<SYMV><<<GRID, WG, 0, s>>>(__VA_ARGS__); break;         \
+    }
+
+void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
+    if (!r.count) return;
+    DISPATCH_MODE(k_gather_T, grid_for(r.count), a, r.idx, r.count)
+}
+void gather_W(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
+    if (!r.count) return;
+    DISPATCH_MODE(k_gather_W, (r.count + 3) / 4, a, r.idx, r.count)
+}
+void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
+    if (!r.count || m == FWD) return;
+    DISPATCH_MODE(k_gather_Bprep, (r.count + WG - 1) / WG, a, r.idx, r.count)
+}
+void gather_B(hipStream_t s, GatherMode m, const GatherArgs &a, ChunkView c) {
+    if (!c.count) return;
+    DISPATCH_MODE(k_gather_B, c.count, a, c.row, c.beg, c.end, c.count)
+}
+
+static int stream_grid(int N) {
+    int nb = grid_for(N);
+    return nb > 2048 ? 2048 : nb;
+}
+void permute_in(hipStream_t s, double *y, const double *b, const int *perm, int N) {
+    if (N) k_permute_in<<<stream_grid(N), WG, 0, s>>>(y, b, perm, N);
+}
+void permute_out(hipStream_t s, double *x, const double *y, const int *perm, int N) {
+    if (N) k_permute_out<<<stream_grid(N), WG, 0, s>>>(x, y, perm, N);
+}
+void setrhs_perm(hipStream_t s, double *bp, const double *rx, const double *rz, const int *perm, int n,
+                 int m, int N) {
+    if (N) k_setrhs_perm<<<stream_grid(N), WG, 0, s>>>(bp, rx, rz, perm, n, m, N);
+}
+void getlhs_perm(hipStream_t s, double *lx, double *lz, const double *xp, const int *iperm, int n, int m) {
+    if (n + m) k_getlhs_perm<<<stream_grid(n + m), WG, 0, s>>>(lx, lz, xp, iperm, n, m);
+}
+void add_vec(hipStream_t s, double *dx, const double *x, int N) {
+    if (N) k_add_vec<<<stream_grid(N), WG, 0, s>>>(dx, x, N);
+}
+void norm_inf(hipStream_t s, const double *v, int N, unsigned long long *out, int *nanflag) {
+    if (N) k_norm_inf<<<stream_grid(N), WG, 0, s>>>(v, N, out, nanflag);
+}
+
+void nn_update(hipStream_t s, const int *rows, const int *hsidx, int count, const double *sv,
+               const double *zv, double *w, double *lam) {
+    (void)hsidx;
+    if (count) k_nn_update<<<stream_grid(count), WG, 0, s>>>(rows, count, sv, zv, w, lam);
+}
+void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, const double *w,
+                 const int *mapHs, double *Kx) {
+    if (count) k_nn_write_hs<<<stream_grid(count), WG, 0, s>>>(rows, hsidx, count, w, mapHs, Kx);
+}
+void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv) {
+    if (v.ncones) k_soc_update_scaling<<<v.ncones, WG, 0, s>>>(v, sv, zv);
+}
+void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx) {
+    if (v.ncones) k_soc_write_kkt<<<v.ncones, WG, 0, s>>>(v, Kx);
+}
+void cones_mul_Hs(hipStream_t s, const int *nn_rows, int nn_count, const SocView &v,
+                  const int *zero_rows, int zero_count, double *y, const double *x) {
+    if (nn_count) k_nn_mul_hs<<<stream_grid(nn_count), WG, 0, s>>>(nn_rows, nn_count, v.w, y, x, 0);
+    if (zero_count) k_nn_mul_hs<<<stream_grid(zero_count), WG, 0, s>>>(zero_rows, zero_count, v.w, y, x, 1);
+    if (v.ncones) k_soc_mul_hs<<<v.ncones, WG, 0, s>>>(v, y, x);
+}
+
+} // namespace dev
+} // namespace chip

@@ -1,0 +1,94 @@
+// kernels.hpp -- launch wrappers of the hand-written gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace chip {
+namespace dev {
+
+// device-side view of the symbolic structures (all int32 / fp64, HBM resident)
+struct LdlView {
+    int N;
+    int nnzL;
+    const int *Lp, *Li;          // L by columns, ascending rows
+    const int *Rp, *Rcol, *Rpos; // L by rows, Rpos = CSC slot of the entry
+    const int *Tpos;             // CSC slot -> CSR slot
+    double *Lx, *Rx;             // values in CSC / CSR order
+    double *D, *Dinv;
+    const int8_t *dsigns;
+    int *status; // [0]=non-finite pivot seen, [1]=zero pivot seen, [2]=regularize_count, [3]=positive inertia
+    double reg_eps, reg_delta;
+};
+
+struct ListView {
+    const int *idx; // T or W rows
+    int count;
+};
+struct ChunkView {
+    const int *row, *beg, *end;
+    int count;
+};
+
+// ---- value plumbing -----------------------------------------------------------
+void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int nnzL, double *Lx,
+                  double *D, const int8_t *dsigns, const double *eps_or_null);
+void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap, int nnzS);
+void diag_absmax_eps(hipStream_t s, const double *Kx, const int *diag_idx, int N, double c,
+                     double prop, double *scal /*[0]=eps out, uses [1] as scratch*/);
+void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale);
+
+// ---- numeric LDL' -------------------------------------------------------------
+void factor_T(hipStream_t s, const LdlView &v, ListView cols);
+void factor_W(hipStream_t s, const LdlView &v, ListView cols);
+void factor_B(hipStream_t s, const LdlView &v, ChunkView chunks);
+void factor_finalize(hipStream_t s, const LdlView &v, ListView cols);
+
+// ---- triangular solves + symv (row-gather family) -------------------------------
+enum GatherMode { FWD = 0, BWD = 1, SYMV = 2 };
+struct GatherArgs {
+    const int *ptr, *idx; // CSR-like: row r owns [ptr[r], ptr[r+1])
+    const double *val;
+    const double *xin;  // gathered vector
+    double *out;        // FWD/BWD: in-place accumulator (== xin); SYMV: e
+    const double *aux;  // BWD: Dinv; SYMV: b
+};
+void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
+void gather_W(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
+void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
+void gather_B(hipStream_t s, GatherMode m, const GatherArgs &a, ChunkView chunks);
+
+// ---- vectors ------------------------------------------------------------------
+void permute_in(hipStream_t s, double *y, const double *b, const int *perm, int N);
+void permute_out(hipStream_t s, double *x, const double *y, const int *perm, int N);
+void setrhs_perm(hipStream_t s, double *bperm, const double *rhsx, const double *rhsz,
+                 const int *perm, int n, int m, int N);
+void getlhs_perm(hipStream_t s, double *lhsx, double *lhsz, const double *xperm, const int *iperm,
+                 int n, int m);
+void add_vec(hipStream_t s, double *dx, const double *x, int N); // dx = x + dx
+// out[slot] = bit pattern of max|v| (non-negative double as u64), nanflag[slot] |= any NaN
+void norm_inf(hipStream_t s, const double *v, int N, unsigned long long *out, int *nanflag);
+
+// ---- cones --------------------------------------------------------------------
+struct SocView {
+    int ncones;
+    const int *start, *dim;      // rows in [0,m)
+    const int *hs_start;         // start of the cone's Hs block in mapHs
+    const int *sparse_idx;       // -1 for dense (dim<=4) cones
+    const int *sp_ptr;           // offsets into mapU / mapV
+    const int *mapHs, *mapU, *mapV, *mapD; // K.nzval indices
+    double *w, *lam;             // m-sized state
+    double *eta, *d;             // per-cone state
+    int *fail;
+};
+void nn_update(hipStream_t s, const int *rows, const int *hsidx, int count, const double *sv,
+               const double *zv, double *w, double *lam);
+void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, const double *w,
+                 const int *mapHs, double *Kx);
+void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv);
+void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx);
+void cones_mul_Hs(hipStream_t s, const int *nn_rows, int nn_count, const SocView &v,
+                  const int *zero_rows, int zero_count, double *y, const double *x);
+
+} // namespace dev
+} // namespace chip

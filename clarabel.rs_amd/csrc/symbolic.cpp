@@ -1,0 +1,337 @@
+// symbolic.cpp -- the once-per-problem host analysis of the quasidefinite KKT
+// matrix: ordering, symmetric permutation, elimination tree, pattern of L,
+// level sets and the per-level work lists the HIP kernels consume.
+//
+// What the reference does at this point (qdldl.rs:230-295: AMD -> permute_symmetric
+// -> _etree -> logical _factor) is kept in meaning, not in form:
+//   * the elimination order is the AMD (or user) order re-sorted LEVEL-MAJOR:
+//     nodes of elimination-tree level 0 first, then level 1, ...  A parent is
+//     always at a strictly higher level than its children, so this is a
+//     topological order of the same tree: same fill, same tree, same pivots up
+//     to rounding (SURVEY.md App. E "what a GPU design may change freely").
+//     It makes every level a contiguous index range -> coalesced per-level
+//     kernels over D, Dinv, Lp, x.
+//   * L is stored once as CSC (ascending rows) and indexed a second time by
+//     rows (CSR) so that forward substitution, backward substitution and the
+//     left-looking numeric factorisation are all pure gathers.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "host.hpp"
+
+namespace chip {
+
+static std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const char *get_error() { return g_err.c_str(); }
+
+namespace {
+
+// kernel work-list thresholds (see kernels.hip)
+constexpr i32 T_MAX = 32;      // <= T_MAX entries: one thread per row
+constexpr i32 B_MIN = 16384;   // >  B_MIN entries: split over workgroups
+constexpr i32 B_CHUNK = 4096;  // entries per B chunk
+constexpr i32 FAC_T_ROW = 8;   // factor: thread-per-column if contributions <= this
+constexpr i32 FAC_T_COL = 48;  // ... and column length <= this
+
+// upper-triangular pattern of P K P' (row = min, col = max), columns unsorted,
+// plus (optionally) for each source entry its destination slot.
+void permuted_triu(i64 n, const i64 *Ap, const i64 *Ai, const std::vector<i32> &iperm,
+                   std::vector<i64> &Cp, std::vector<i32> &Ci) {
+    Cp.assign((size_t)n + 1, 0);
+    for (i64 c = 0; c < n; c++) {
+        const i32 pc = iperm[c];
+        for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+            const i32 pr = iperm[Ai[p]];
+            Cp[(pr > pc ? pr : pc) + 1]++;
+        }
+    }
+    for (i64 c = 0; c < n; c++) Cp[c + 1] += Cp[c];
+    Ci.resize((size_t)Cp[n] + 1);
+    std::vector<i64> nextp(Cp.begin(), Cp.end() - 1);
+    for (i64 c = 0; c < n; c++) {
+        const i32 pc = iperm[c];
+        for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+            const i32 pr = iperm[Ai[p]];
+            const i32 col = pr > pc ? pr : pc, row = pr > pc ? pc : pr;
+            Ci[nextp[col]++] = row;
+        }
+    }
+}
+
+// elimination tree (parent, -1 = root) and strictly-lower column counts of L.
+void etree_counts(i64 n, const std::vector<i64> &Cp, const std::vector<i32> &Ci,
+                  std::vector<i32> &parent, std::vector<i32> &cnt) {
+    parent.assign((size_t)n, -1);
+    cnt.assign((size_t)n, 0);
+    std::vector<i32> stamp((size_t)n, -1);
+    for (i32 j = 0; j < n; j++) {
+        stamp[j] = j;
+        for (i64 p = Cp[j]; p < Cp[j + 1]; p++) {
+            i32 i = Ci[p];
+            while (stamp[i] != j) {
+                if (parent[i] < 0) parent[i] = j;
+                cnt[i]++;
+                stamp[i] = j;
+                i = parent[i];
+            }
+        }
+    }
+}
+
+struct ListBuilder {
+    LevelLists &L;
+    explicit ListBuilder(LevelLists &l) : L(l) {
+        L = LevelLists();
+        L.t_ptr.push_back(0);
+        L.w_ptr.push_back(0);
+        L.b_ptr.push_back(0);
+        L.br_ptr.push_back(0);
+    }
+    void add_T(i32 r) { L.t_idx.push_back(r); }
+    void add_W(i32 r) { L.w_idx.push_back(r); }
+    void add_B(i32 r, i64 beg, i64 end) {
+        L.br_idx.push_back(r);
+        for (i64 b = beg; b < end; b += B_CHUNK) {
+            L.b_row.push_back(r);
+            L.b_beg.push_back((i32)b);
+            L.b_end.push_back((i32)std::min<i64>(end, b + B_CHUNK));
+        }
+    }
+    void close_level() {
+        L.t_ptr.push_back((i32)L.t_idx.size());
+        L.w_ptr.push_back((i32)L.w_idx.size());
+        L.b_ptr.push_back((i32)L.b_row.size());
+        L.br_ptr.push_back((i32)L.br_idx.size());
+    }
+};
+
+} // namespace
+
+int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std::vector<i64> &perm0,
+            double amd_dense_scale, Symbolic &S) {
+    S = Symbolic();
+    if (n < 0 || n >= (i64)1 << 31) {
+        set_error("KKT dimension out of int32 range");
+        return -1;
+    }
+    // ---- check_structure (qdldl.rs:213-228): triu, no empty column ----------
+    for (i64 c = 0; c < n; c++) {
+        for (i64 p = Ap[c]; p < Ap[c + 1]; p++)
+            if (Ai[p] > c || Ai[p] < 0) {
+                set_error("matrix is not upper triangular");
+                return -3;
+            }
+    }
+    for (i64 c = 0; c < n; c++)
+        if (!(Ap[c] < Ap[c + 1])) {
+            set_error("matrix has an empty column");
+            return -2;
+        }
+    const i64 nnzK = n > 0 ? Ap[n] : 0;
+    if (nnzK >= ((i64)1 << 31) - 8) {
+        set_error("nnz(K) out of int32 range");
+        return -1;
+    }
+    S.N = (i32)n;
+    S.nnzK = nnzK;
+
+    // ---- ordering -----------------------------------------------------------
+    std::vector<i64> p0 = perm0;
+    if (p0.empty() && n > 0) {
+        int rc = amd_order(n, Ap, Ai, amd_dense_scale, p0, &S.amd);
+        if (rc) {
+            set_error("amd_order failed");
+            return rc;
+        }
+    }
+    std::vector<i32> ip0((size_t)n, -1);
+    for (i64 k = 0; k < n; k++) {
+        const i64 v = p0[k];
+        if (v < 0 || v >= n || ip0[v] != -1) {
+            set_error("invalid permutation");
+            return -5;
+        }
+        ip0[v] = (i32)k;
+    }
+    // ---- pass A: tree + levels under the given order ------------------------
+    std::vector<i64> Cp;
+    std::vector<i32> Ci, parent, cnt;
+    permuted_triu(n, Ap, Ai, ip0, Cp, Ci);
+    etree_counts(n, Cp, Ci, parent, cnt);
+    std::vector<i32> level((size_t)n, 0);
+    i32 nlevels = n > 0 ? 1 : 0;
+    for (i32 j = 0; j < n; j++) {
+        const i32 pj = parent[j];
+        if (pj >= 0 && level[pj] < level[j] + 1) level[pj] = level[j] + 1;
+        if (level[j] + 1 > nlevels) nlevels = level[j] + 1;
+    }
+    // level-major stable re-sort
+    std::vector<i32> lvlptr((size_t)nlevels + 1, 0);
+    for (i32 j = 0; j < n; j++) lvlptr[level[j] + 1]++;
+    for (i32 l = 0; l < nlevels; l++) lvlptr[l + 1] += lvlptr[l];
+    S.perm.resize((size_t)n);
+    S.iperm.resize((size_t)n);
+    {
+        std::vector<i32> pos(lvlptr.begin(), lvlptr.end() - 1);
+        for (i32 j = 0; j < n; j++) {
+            const i32 nj = pos[level[j]]++;
+            S.perm[nj] = (i32)p0[j];
+        }
+        for (i32 j = 0; j < n; j++) S.iperm[S.perm[j]] = j;
+    }
+    S.nlevels = nlevels;
+    S.lvlptr = lvlptr;
+    S.dsigns.resize((size_t)n);
+    for (i32 j = 0; j < n; j++) S.dsigns[j] = dsigns ? dsigns[S.perm[j]] : (int8_t)1;
+
+    // ---- pass B: final pattern ----------------------------------------------
+    permuted_triu(n, Ap, Ai, S.iperm, Cp, Ci);
+    etree_counts(n, Cp, Ci, parent, cnt);
+    S.etree = parent;
+    S.Lp.assign((size_t)n + 1, 0);
+    i64 nnzL = 0;
+    for (i32 j = 0; j < n; j++) {
+        nnzL += cnt[j];
+        if (nnzL >= ((i64)1 << 31) - n - 8) {
+            set_error("nnz(L) out of int32 range");
+            return -1;
+        }
+        S.Lp[j + 1] = (i32)nnzL;
+    }
+    S.nnzL = nnzL;
+    S.Li.resize((size_t)nnzL + 1);
+    {
+        // rows of L by row-subtree traversal; k ascending => ascending rows per column
+        std::vector<i32> nextp(S.Lp.begin(), S.Lp.end() - 1), stamp((size_t)n, -1);
+        for (i32 k = 0; k < n; k++) {
+            stamp[k] = k;
+            for (i64 p = Cp[k]; p < Cp[k + 1]; p++) {
+                i32 i = Ci[p];
+                while (i >= 0 && i < k && stamp[i] != k) {
+                    stamp[i] = k;
+                    S.Li[nextp[i]++] = k;
+                    i = parent[i];
+                }
+            }
+        }
+    }
+    // ---- CSR view of L ------------------------------------------------------
+    S.Rp.assign((size_t)n + 1, 0);
+    for (i64 q = 0; q < nnzL; q++) S.Rp[S.Li[q] + 1]++;
+    for (i32 j = 0; j < n; j++) S.Rp[j + 1] += S.Rp[j];
+    S.Rcol.resize((size_t)nnzL + 1);
+    S.Rpos.resize((size_t)nnzL + 1);
+    S.Tpos.resize((size_t)nnzL + 1);
+    {
+        std::vector<i32> nextp(S.Rp.begin(), S.Rp.end() - 1);
+        for (i32 k = 0; k < n; k++)
+            for (i32 q = S.Lp[k]; q < S.Lp[k + 1]; q++) {
+                const i32 t = nextp[S.Li[q]]++;
+                S.Rcol[t] = k;
+                S.Rpos[t] = q;
+                S.Tpos[q] = t;
+            }
+    }
+    // ---- K.nzval -> (Lx | D) scatter map ------------------------------------
+    S.a2l.resize((size_t)nnzK + 1);
+    for (i64 c = 0; c < n; c++) {
+        const i32 pc = S.iperm[c];
+        for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+            const i32 pr = S.iperm[Ai[p]];
+            if (pr == pc) {
+                S.a2l[p] = (i32)(nnzL + pc);
+            } else {
+                const i32 lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
+                const i32 *b = S.Li.data() + S.Lp[lo], *e = S.Li.data() + S.Lp[lo + 1];
+                const i32 *f = std::lower_bound(b, e, hi);
+                if (f == e || *f != hi) {
+                    set_error("internal: K entry missing from the pattern of L");
+                    return -9;
+                }
+                S.a2l[p] = (i32)(f - S.Li.data());
+            }
+        }
+    }
+    // ---- full symmetric K in CSR (permuted numbering) -----------------------
+    {
+        S.Sp.assign((size_t)n + 1, 0);
+        for (i64 c = 0; c < n; c++)
+            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                const i64 r = Ai[p];
+                S.Sp[S.iperm[c] + 1]++;
+                if (r != c) S.Sp[S.iperm[r] + 1]++;
+            }
+        for (i32 j = 0; j < n; j++) S.Sp[j + 1] += S.Sp[j];
+        S.nnzS = S.Sp[n];
+        S.Scol.resize((size_t)S.nnzS + 1);
+        S.Smap.resize((size_t)S.nnzS + 1);
+        // two sweeps ordered by source column in PERMUTED order would give sorted
+        // rows; a sort per row is simpler and the rows are short or already banded.
+        std::vector<i32> nextp(S.Sp.begin(), S.Sp.end() - 1);
+        for (i64 c = 0; c < n; c++)
+            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                const i64 r = Ai[p];
+                const i32 pc = S.iperm[c], pr = S.iperm[r];
+                i32 t = nextp[pc]++;
+                S.Scol[t] = pr;
+                S.Smap[t] = (i32)p;
+                if (r != c) {
+                    t = nextp[pr]++;
+                    S.Scol[t] = pc;
+                    S.Smap[t] = (i32)p;
+                }
+            }
+        std::vector<std::pair<i32, i32>> tmp;
+        for (i32 j = 0; j < n; j++) {
+            const i32 b = S.Sp[j], e = S.Sp[j + 1];
+            if (e - b < 2) continue;
+            bool sorted = true;
+            for (i32 t = b + 1; t < e && sorted; t++) sorted = S.Scol[t - 1] <= S.Scol[t];
+            if (sorted) continue;
+            tmp.resize((size_t)(e - b));
+            for (i32 t = b; t < e; t++) tmp[t - b] = {S.Scol[t], S.Smap[t]};
+            std::sort(tmp.begin(), tmp.end());
+            for (i32 t = b; t < e; t++) {
+                S.Scol[t] = tmp[t - b].first;
+                S.Smap[t] = tmp[t - b].second;
+            }
+        }
+    }
+    // ---- per-level work lists ----------------------------------------------
+    {
+        ListBuilder fac(S.fac), fwd(S.fwd), bwd(S.bwd);
+        for (i32 l = 0; l < nlevels; l++) {
+            for (i32 j = lvlptr[l]; j < lvlptr[l + 1]; j++) {
+                const i32 rj = S.Rp[j + 1] - S.Rp[j], cj = S.Lp[j + 1] - S.Lp[j];
+                // factor: column j gathers rj contributions into cj targets
+                if (rj > B_MIN) fac.add_B(j, S.Rp[j], S.Rp[j + 1]);
+                else if (rj <= FAC_T_ROW && cj <= FAC_T_COL) fac.add_T(j);
+                else fac.add_W(j);
+                // forward substitution: row j of L
+                if (rj > B_MIN) fwd.add_B(j, S.Rp[j], S.Rp[j + 1]);
+                else if (rj > T_MAX) fwd.add_W(j);
+                else if (rj > 0) fwd.add_T(j);
+                // backward substitution: column j of L
+                if (cj > B_MIN) bwd.add_B(j, S.Lp[j], S.Lp[j + 1]);
+                else if (cj > T_MAX) bwd.add_W(j);
+                else bwd.add_T(j);
+            }
+            fac.close_level();
+            fwd.close_level();
+            bwd.close_level();
+        }
+        ListBuilder smv(S.smv);
+        for (i32 j = 0; j < n; j++) {
+            const i32 len = S.Sp[j + 1] - S.Sp[j];
+            if (len > B_MIN) smv.add_B(j, S.Sp[j], S.Sp[j + 1]);
+            else if (len > T_MAX) smv.add_W(j);
+            else smv.add_T(j);
+        }
+        smv.close_level();
+    }
+    return 0;
+}
+
+} // namespace chip

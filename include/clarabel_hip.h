@@ -1,0 +1,237 @@
+/*
+ * clarabel_hip.h -- C ABI of the MI355X-native KKT linear-system backend for
+ * Clarabel (reference: oxfordcontrol/Clarabel.rs v0.11.1; citations are
+ * relative to /root/reference/src).
+ *
+ * Two levels, both mirrored 1:1 from the reference's own trait surface:
+ *
+ *  L1  chip_ldl_*   ==  trait DirectLDLSolver<f64>
+ *                       (solver/core/kktsolvers/direct/quasidef/mod.rs:14-26)
+ *                       construction signature ldlsolvers/config.rs:21-22
+ *                       reference behaviour   ldlsolvers/qdldl.rs:18-107
+ *                       This is the strict drop-in: a Rust `HipDirectLDLSolver`
+ *                        forwards each trait method to one call.
+ *
+ *  L2  chip_kkt_*   ==  trait KKTSolver<f64> (solver/core/kktsolvers/mod.rs:7-18)
+ *                       as implemented by DirectLDLKKTSolver
+ *                       (quasidef/directldlkktsolver.rs:18-405): KKT assembly,
+ *                       cone Hs blocks fused into the value update, static
+ *                       regularisation, refactor, solve + iterative refinement,
+ *                       all device resident.
+ *
+ * Conventions: plain pointers + sizes, no C++/torch types.  Index arrays are
+ * uint64_t/int64_t because the reference's CscMatrix uses usize
+ * (algebra/csc/core.rs:45-60); values are double.  Functions return
+ * CHIP_OK (0) or a negative chip_status unless documented as returning the
+ * reference's `bool` (1 = success, 0 = numerical failure).  Pointers named
+ * *_dev are device (HBM) pointers on the engine's device; all others are host.
+ * A handle is owned by the caller, single-threaded use, movable across threads
+ * (the reference requires Send+Sync: directldlkktsolver.rs:13-16).
+ */
+#ifndef CLARABEL_HIP_H
+#define CLARABEL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    CHIP_OK = 0,
+    CHIP_ERR_DIM = -1,            /* QDLDLError::IncompatibleDimension  qdldl.rs:13 */
+    CHIP_ERR_EMPTY_COLUMN = -2,   /* QDLDLError::EmptyColumn            qdldl.rs:16 */
+    CHIP_ERR_NOT_TRIU = -3,       /* QDLDLError::NotUpperTriangular     qdldl.rs:19 */
+    CHIP_ERR_ZERO_PIVOT = -4,     /* QDLDLError::ZeroPivot              qdldl.rs:22 */
+    CHIP_ERR_BAD_PERM = -5,       /* QDLDLError::InvalidPermutation     qdldl.rs:25 */
+    CHIP_ERR_NOT_FACTORED = -6,   /* solve() before the first refactor(): the reference asserts, qdldl.rs:118 */
+    CHIP_ERR_NO_DEVICE = -7,      /* HIP runtime/device unavailable (the product has NO CPU fallback) */
+    CHIP_ERR_HIP = -8,            /* a HIP call failed; see chip_last_error() */
+    CHIP_ERR_ARG = -9,
+    CHIP_ERR_UNSUPPORTED = -10
+} chip_status;
+
+/* SupportedConeT tags (solver/core/cones/supportedcone.rs) */
+typedef enum {
+    CHIP_CONE_ZERO = 0,
+    CHIP_CONE_NONNEGATIVE = 1,
+    CHIP_CONE_SECONDORDER = 2,
+    CHIP_CONE_EXPONENTIAL = 3,
+    CHIP_CONE_POWER = 4,
+    CHIP_CONE_GENPOWER = 5,
+    CHIP_CONE_PSDTRIANGLE = 6
+} chip_cone_tag;
+
+/* The CoreSettings fields the path consumes
+ * (solver/implementations/default/settings.rs:126-181) + engine knobs. */
+typedef struct {
+    int32_t static_regularization_enable;        /* true   */
+    double static_regularization_constant;       /* 1e-8   */
+    double static_regularization_proportional;   /* eps^2  */
+    int32_t dynamic_regularization_enable;       /* true; NB the qdldl adapter ignores it
+                                                    (ldlsolvers/qdldl.rs:38), and so do we  */
+    double dynamic_regularization_eps;           /* 1e-13  */
+    double dynamic_regularization_delta;         /* 2e-7   */
+    int32_t iterative_refinement_enable;         /* true   */
+    double iterative_refinement_reltol;          /* 1e-13  */
+    double iterative_refinement_abstol;          /* 1e-12  */
+    int32_t iterative_refinement_max_iter;       /* 10     */
+    double iterative_refinement_stop_ratio;      /* 5.0    */
+    /* engine knobs (no reference counterpart) */
+    int32_t device;            /* HIP device ordinal, -1 = current device,
+                                  CHIP_DEVICE_HOST_ONLY = symbolic analysis only (no GPU touched;
+                                  every numeric call then returns CHIP_ERR_NO_DEVICE) -- the
+                                  analogue of the reference's logical factorisation, qdldl.rs:40-42 */
+    double amd_dense_scale;    /* 1.5, ldlsolvers/qdldl.rs:41 */
+    int32_t use_graph;         /* capture the per-solve launch sequence in a hipGraph */
+    int32_t reserved[5];
+} chip_settings;
+
+/* LinearSolverInfo (solver/core/kktsolvers/mod.rs:27-38) + factor statistics
+ * (qdldl.rs:104-112, 203-210). */
+typedef struct {
+    char name[16];             /* "hip" */
+    int64_t threads;           /* reported as #GPUs driven by this handle (1) */
+    int32_t direct;            /* 1 */
+    int64_t nnzA;              /* nnz(triu K) */
+    int64_t nnzL;              /* nnz(L), strictly lower */
+    int64_t positive_inertia;  /* valid after refactor */
+    int64_t regularize_count;  /* dynamic regularisation hits of the last refactor */
+    int64_t n;                 /* KKT dimension N */
+    int64_t n_levels;          /* elimination-tree levels (= dependent kernel phases) */
+    double amd_lnz, amd_ndiv, amd_nmultsubs_ldl; /* amd::Info, used by ldlsolvers/auto.rs:69-77 */
+    int32_t last_ir_iterations;/* refinement rounds of the last chip_kkt_solve */
+    double last_regularizer;   /* static eps of the last update (directldlkktsolver.rs:249) */
+} chip_info;
+
+#define CHIP_DEVICE_HOST_ONLY (-2)
+
+typedef struct chip_ldl chip_ldl;
+typedef struct chip_kkt chip_kkt;
+
+void chip_settings_default(chip_settings *s);
+const char *chip_last_error(void);
+/* number of visible HIP devices (0 when there is no GPU / runtime) */
+int32_t chip_device_count(void);
+
+/* ---- host-side symbolic utilities ------------------------------------------
+ * Approximate-minimum-degree ordering of the symmetric matrix whose upper
+ * triangle is given in CSC form.  Replaces the un-vendored crate `amd 0.2.2`
+ * at its three call sites (qdldl.rs:905-917, ldlsolvers/mod.rs:15-23,
+ * auto.rs:69): dense threshold = 10*dense_scale*sqrt(n).  perm[k] = the
+ * original index eliminated k-th; iperm its inverse.  info3 (may be NULL)
+ * receives {lnz, ndiv, nmultsubs_ldl}. */
+int32_t chip_amd_order(int64_t n, const uint64_t *colptr, const uint64_t *rowval,
+                       double dense_scale, uint64_t *perm, uint64_t *iperm, double *info3);
+
+/* ---- L1: DirectLDLSolver ----------------------------------------------------
+ * ctor  == LDLConstructor (config.rs:21-22):
+ *          fn(&CscMatrix<T> [triu KKT], &[i8] [Dsigns], &CoreSettings<T>, Option<Vec<usize>> [perm])
+ * required_matrix_shape() == Triu (quasidef/mod.rs:14-16). */
+int32_t chip_ldl_create(chip_ldl **out, int64_t n, const uint64_t *colptr,
+                        const uint64_t *rowval, const double *nzval, const int8_t *dsigns,
+                        const uint64_t *perm_or_null, const chip_settings *settings);
+void chip_ldl_destroy(chip_ldl *h);
+/* update_values(&mut self, index:&[usize], values:&[T])   mod.rs:20, qdldl.rs:142-149 */
+int32_t chip_ldl_update_values(chip_ldl *h, const uint64_t *index, const double *values, int64_t k);
+/* scale_values(&mut self, index:&[usize], scale:T)        mod.rs:21, qdldl.rs:153-160 */
+int32_t chip_ldl_scale_values(chip_ldl *h, const uint64_t *index, double scale, int64_t k);
+/* offset_values(&mut self, index, offset, signs:&[i8])    mod.rs:22-23, qdldl.rs:166-183 */
+int32_t chip_ldl_offset_values(chip_ldl *h, const uint64_t *index, double offset,
+                               const int8_t *signs, int64_t k);
+/* Pardiso-style wholesale value hand-over (pardiso.rs:277-322): replaces the
+ * engine's copy of K.nzval by the caller's full array, so the 5 tiny per-SOC
+ * update calls (datamaps.rs:212-219) can be no-ops on the Rust side. */
+int32_t chip_ldl_set_values(chip_ldl *h, const double *kkt_nzval);
+/* refactor(&mut self, kkt) -> bool   mod.rs:25, ldlsolvers/qdldl.rs:98-106.
+ * returns 1 = all Dinv finite, 0 = numerical failure, <0 = chip_status. */
+int32_t chip_ldl_refactor(chip_ldl *h);
+/* solve(&mut self, kkt, x:&mut[T], b:&mut[T])   mod.rs:24, ldlsolvers/qdldl.rs:91-96.
+ * b is left untouched. */
+int32_t chip_ldl_solve(chip_ldl *h, double *x, const double *b);
+/* device-resident variant: x_dev / b_dev are HBM pointers (may alias). */
+int32_t chip_ldl_solve_dev(chip_ldl *h, double *x_dev, const double *b_dev);
+/* linear_solver_info()  kktsolvers/mod.rs:20-24 */
+int32_t chip_ldl_info(const chip_ldl *h, chip_info *info);
+/* final elimination order actually used (a topological re-sort of the AMD /
+ * user permutation by elimination-tree level; same fill, same etree) */
+int32_t chip_ldl_get_perm(const chip_ldl *h, uint64_t *perm);
+/* symbolic results in the engine's final numbering (host copies; any pointer may
+ * be NULL): etree[N] (UINT64_MAX = root, cf. qdldl.rs:426), Lp[N+1], Li[nnzL]
+ * (ascending rows per column), lvlptr[n_levels+1] (level l = columns
+ * [lvlptr[l], lvlptr[l+1])).  Also valid on CHIP_DEVICE_HOST_ONLY handles. */
+int32_t chip_ldl_get_symbolic(const chip_ldl *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,
+                              uint64_t *lvlptr);
+/* test/diagnostic access to the factors (host copies): L as CSC with sorted
+ * rows in the engine's numbering, D, Dinv.  Any pointer may be NULL. */
+int32_t chip_ldl_get_factors(chip_ldl *h, uint64_t *Lp, uint64_t *Li, double *Lx, double *D,
+                             double *Dinv);
+
+/* ---- L2: KKTSolver (DirectLDLKKTSolver) --------------------------------------
+ * new(P, A, cones, m, n, settings)  directldlkktsolver.rs:60-118.
+ * P: n x n triu CSC, A: m x n CSC, both canonically sorted (csc/core.rs:322-338).
+ * cone i: tags[i], dims[i] (Zero/NN/SOC: numel; PSD: matrix side; GenPow: dim1),
+ * dims2[i] (GenPow dim2, else 0).  Exp/Pow have numel 3. */
+int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pcolptr,
+                        const uint64_t *Prowval, const double *Pnzval, const uint64_t *Acolptr,
+                        const uint64_t *Arowval, const double *Anzval, int64_t ncones,
+                        const int32_t *cone_tags, const int64_t *cone_dims,
+                        const int64_t *cone_dims2, const chip_settings *settings,
+                        const uint64_t *perm_or_null);
+void chip_kkt_destroy(chip_kkt *h);
+/* dimensions: out[0]=n out[1]=m out[2]=p out[3]=N out[4]=nnzK out[5]=nHsblocks */
+int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[6]);
+/* the assembled (unpermuted, triu) KKT matrix and the LDLDataMap index
+ * vectors (datamaps.rs:350-362) -- host copies for tests / Rust-side mirrors. */
+int32_t chip_kkt_get_matrix(const chip_kkt *h, uint64_t *colptr, uint64_t *rowval, double *nzval);
+int32_t chip_kkt_get_map(const chip_kkt *h, uint64_t *mapP, uint64_t *mapA, uint64_t *mapHs,
+                         uint64_t *diagP, uint64_t *diag_full, int8_t *dsigns);
+/* CompositeCone::update_scaling (compositecone.rs:226-243) for the cones held
+ * on the device: Nonnegative (nonnegativecone.rs:77-90) and SecondOrder
+ * (socone.rs:134-211); Zero is a no-op.  Returns the reference's bool.
+ * s, z: m doubles (host / device variants). */
+int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z);
+int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const double *z_dev);
+/* KKTSolver::update (directldlkktsolver.rs:134-158): Hs blocks (get_Hs fused,
+ * negated), sparse-cone u/v/D columns, static regularisation, numeric refactor.
+ * hsblocks_or_null: full Hsblocks vector (host) consulted ONLY for cone types
+ * whose scaling is not held on the device (Exp/Pow/GenPow/PSD); may be NULL
+ * when there are none.  Returns the reference's bool. */
+int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null);
+/* setrhs(rhsx, rhsz)   directldlkktsolver.rs:160-166 */
+int32_t chip_kkt_setrhs(chip_kkt *h, const double *rhsx, const double *rhsz);
+int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *rhsz_dev);
+/* solve(lhsx, lhsz, settings) -> bool   directldlkktsolver.rs:168-189,
+ * incl. iterative_refinement :266-321.  Either output may be NULL. */
+int32_t chip_kkt_solve(chip_kkt *h, double *lhsx_or_null, double *lhsz_or_null);
+int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_dev_or_null);
+/* update_P / update_A   directldlkktsolver.rs:191-197 */
+int32_t chip_kkt_update_P(chip_kkt *h, const double *Pnzval);
+int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval);
+/* CompositeCone::mul_Hs (compositecone.rs:259-264) for the device-held cones:
+ * y = Hs x, m doubles, device pointers. */
+int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev);
+int32_t chip_kkt_info(const chip_kkt *h, chip_info *info);
+int32_t chip_kkt_get_perm(const chip_kkt *h, uint64_t *perm);
+int32_t chip_kkt_get_symbolic(const chip_kkt *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,
+                              uint64_t *lvlptr);
+/* current device copy of K.nzval (unregularised), for tests */
+int32_t chip_kkt_get_values(chip_kkt *h, double *nzval);
+/* full-N right-hand side / solution (incl. the p sparse-cone rows), tests only */
+int32_t chip_kkt_solve_full(chip_kkt *h, double *x, const double *b);
+/* blocks until all work queued on the handle's stream has finished */
+int32_t chip_kkt_synchronize(chip_kkt *h);
+/* HIP stream (hipStream_t) the handle launches on, for event timing */
+void *chip_kkt_stream(chip_kkt *h);
+/* hipEvent pairs (recorded on the launch stream) around every launch of ONE
+ * kernel family: 0 = off, 1 = symv residual k_gather_T<SYMV>, 2 = backward
+ * substitution k_gather_T<BWD>, 3 = forward k_gather_T<FWD>, 4 = k_factor_T.
+ * chip_kkt_profile(h, family) resets the counters; chip_kkt_profile_read
+ * returns out[0] = launches, out[1] = total ms, out[2] = family. */
+int32_t chip_kkt_profile(chip_kkt *h, int32_t family);
+int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLARABEL_HIP_H */

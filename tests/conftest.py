@@ -18,3 +18,18 @@ def oracle():
     from oracle import oracle as orc
     orc.lib()
     return orc
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """the product package (clarabel.rs_amd), loaded through its ctypes C-ABI binding"""
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def has_gpu():
+    try:
+        import __graft_entry__ as g
+        return g.load_package().device_count() > 0
+    except Exception:
+        return False

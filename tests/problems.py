@@ -1,0 +1,199 @@
+"""Seeded synthetic generators for the five BASELINE.json configs.
+Pure numpy/scipy; used by tests/ and bench.py.  Every generator returns a dict
+  n, m, P=(colptr,rowval,nzval) [triu], A=(colptr,rowval,nzval), cones=[(tag,dim[,dim2])],
+  s, z  (a strictly interior primal/dual pair, consistent with the cones)
+"""
+import numpy as np
+import scipy.sparse as sp
+
+ZERO, NN, SOC, EXP, POW, GENPOW, PSD = range(7)
+
+
+def _csc(M):
+    M = sp.csc_matrix(M)
+    M.sort_indices()
+    return (M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.astype(np.float64))
+
+
+def _interior(rng, cones, late=False):
+    """random strictly interior (s, z); `late` mimics a late IPM iterate:
+    NN entries with s/z spanning 1e-6..1e6."""
+    s_parts, z_parts = [], []
+    for c in cones:
+        tag, dim = c[0], c[1]
+        if tag == ZERO:
+            s_parts.append(np.zeros(dim))
+            z_parts.append(np.zeros(dim))
+        elif tag == NN:
+            if late:
+                r = 10.0 ** rng.uniform(-3, 3, dim)
+                mu = 10.0 ** rng.uniform(-4, -2, dim)
+                s_parts.append(np.sqrt(mu) * r)
+                z_parts.append(np.sqrt(mu) / r)
+            else:
+                s_parts.append(rng.uniform(0.3, 3.0, dim))
+                z_parts.append(rng.uniform(0.3, 3.0, dim))
+        elif tag == SOC:
+            for parts in (s_parts, z_parts):
+                v = rng.standard_normal(dim)
+                v[0] = np.linalg.norm(v[1:]) * (1.0 + (rng.uniform(1e-3, 1e-1) if late else rng.uniform(0.1, 1.0))) + 1e-3
+                parts.append(v)
+        else:
+            numel = 3 if tag in (EXP, POW) else dim * (dim + 1) // 2
+            s_parts.append(np.zeros(numel))
+            z_parts.append(np.zeros(numel))
+    return np.concatenate(s_parts) if s_parts else np.zeros(0), np.concatenate(z_parts) if z_parts else np.zeros(0)
+
+
+def basic_qp():
+    """C1: tests/basic_qp.rs:16-42 verbatim (n=2, m=6, NN(3)+NN(3))."""
+    P = np.array([[4., 1.], [0., 2.]])  # triu of [4 1;1 2]
+    A0 = np.array([[1., 1.], [1., 0.], [0., 1.]])
+    A = np.vstack([-A0, A0])
+    cones = [(NN, 3), (NN, 3)]
+    return dict(n=2, m=6, P=_csc(P), A=_csc(A), cones=cones, q=np.array([1., 1.]),
+                b=np.array([-1., 0., 0., 1., 0.7, 0.7]), s=np.ones(6), z=np.ones(6))
+
+
+def random_qp(n=100000, m=200000, band=50, seed=1, late=False):
+    """C2: band-limited random sparse QP, one NonnegativeCone(m)."""
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(m), 5)
+    center = (np.arange(m) * n) // m
+    cols = (np.repeat(center, 5) + rng.integers(-band, band + 1, 5 * m)) % n
+    vals = rng.standard_normal(5 * m)
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(m, n)).tocsc()
+    A.sum_duplicates()
+    rng2 = np.random.default_rng(seed + 1)
+    d = rng2.uniform(1.0, 2.0, n)
+    oc = np.repeat(np.arange(n), 2)
+    orow = oc - rng2.integers(1, band + 1, 2 * n)
+    keep = orow >= 0
+    ov = 0.1 * rng2.standard_normal(2 * n)
+    P = sp.coo_matrix((np.concatenate([d, ov[keep]]), (np.concatenate([np.arange(n), orow[keep]]),
+                                                       np.concatenate([np.arange(n), oc[keep]]))), shape=(n, n)).tocsc()
+    P.sum_duplicates()
+    cones = [(NN, m)]
+    s, z = _interior(rng, cones, late)
+    return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=s, z=z)
+
+
+def portfolio_socp(nblocks=1000, blocksize=1000, seed=3, late=False):
+    """C3: n = nblocks*blocksize; cones [Zero(1) budget, NN(n), nblocks x SOC(blocksize+1)];
+    P = 0; KKT is block-arrow: per SOC two dense columns (u, v), one dense budget row."""
+    rng = np.random.default_rng(seed)
+    n = nblocks * blocksize
+    dim = blocksize + 1
+    m = 1 + n + nblocks * dim
+    # rows: 0 budget (1'x), 1..n: -I, then per block: row0 empty, rows 1..blocksize = -diag(d)
+    d = rng.uniform(0.5, 1.5, n)
+    j = np.arange(n)
+    soc_rows = 1 + n + (j // blocksize) * dim + 1 + (j % blocksize)
+    rows = np.concatenate([np.zeros(n, dtype=np.int64), 1 + j, soc_rows])
+    cols = np.concatenate([j, j, j])
+    vals = np.concatenate([np.ones(n), -np.ones(n), -d])
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(m, n)).tocsc()
+    A.sort_indices()
+    P = sp.csc_matrix((n, n))
+    cones = [(ZERO, 1), (NN, n)] + [(SOC, dim)] * nblocks
+    s, z = _interior(rng, cones, late)
+    return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=s, z=z)
+
+
+def batched_socp(nbatch=1024, n_b=2000, blocks_per=2, seed=100, late=False):
+    """C4: `nbatch` independent copies of a small C3-pattern SOCP, concatenated block
+    diagonally (csc/block_concatenate.rs:22) -> elimination forest with nbatch roots."""
+    parts = [portfolio_socp(blocks_per, n_b // blocks_per, seed + i, late) for i in range(nbatch)]
+    return blockdiag(parts)
+
+
+def blockdiag(parts):
+    n = sum(p["n"] for p in parts)
+    m = sum(p["m"] for p in parts)
+    A = sp.block_diag([sp.csc_matrix((p["A"][2], p["A"][1], p["A"][0]), shape=(p["m"], p["n"])) for p in parts],
+                      format="csc")
+    P = sp.block_diag([sp.csc_matrix((p["P"][2], p["P"][1], p["P"][0]), shape=(p["n"], p["n"])) for p in parts],
+                      format="csc")
+    cones = [c for p in parts for c in p["cones"]]
+    return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=np.concatenate([p["s"] for p in parts]),
+                z=np.concatenate([p["z"] for p in parts]), part_n=[p["n"] for p in parts],
+                part_m=[p["m"] for p in parts])
+
+
+def _svec(M):
+    """svec of a symmetric matrix: packed triu, column major, off-diagonals * sqrt(2)
+    (src/algebra/dense/matrix_math.rs:165-205)."""
+    k = M.shape[0]
+    out = []
+    for c in range(k):
+        for r in range(c + 1):
+            out.append(M[r, c] * (1.0 if r == c else np.sqrt(2.0)))
+    return np.array(out)
+
+
+def psd_scaling_Hs(S, Z):
+    """Nesterov-Todd Hs = (R R') (x)_s (R R') for a PSDTriangleCone (psdtrianglecone.rs:144-204,
+    467-509), built with dense numpy; returns the packed-triu (column-major) Hs block that
+    get_Hs would hand to the KKT update (dense/types.rs:187-201)."""
+    L1 = np.linalg.cholesky(S)
+    L2 = np.linalg.cholesky(Z)
+    U, sig, Vt = np.linalg.svd(L2.T @ L1)
+    R = L1 @ Vt.T @ np.diag(sig ** -0.5)
+    B = R @ R.T
+    k = S.shape[0]
+    numel = k * (k + 1) // 2
+    H = np.zeros((numel, numel))
+    idx = [(r, c) for c in range(k) for r in range(c + 1)]
+    for a, (i, j) in enumerate(idx):
+        E = np.zeros((k, k))
+        if i == j:
+            E[i, i] = 1.0
+        else:
+            E[i, j] = E[j, i] = 1.0 / np.sqrt(2.0)
+        H[:, a] = _svec(B @ E @ B.T)
+    H = 0.5 * (H + H.T)
+    return np.array([H[r, c] for c in range(numel) for r in range(c + 1)])
+
+
+def chordal_sdp(ncliques=6, dim=6, overlap=2, nsoc=3, socdim=7, seed=5):
+    """C5 (small scale): the post-decomposition shape of chordal/decomp/augment_compact.rs:31-75:
+    a chain of PSDTriangleCone(dim) cliques whose overlapping svec entries are tied by +1/-1
+    columns, plus sparse-form SOCs.  Hs blocks of the PSD cones are supplied by the host
+    (psd_scaling_Hs) -- exactly what chip_kkt_update(hsblocks) consumes."""
+    rng = np.random.default_rng(seed)
+    numel = dim * (dim + 1) // 2
+    ov = overlap * (overlap + 1) // 2
+    n_orig = 4 * ncliques
+    n = n_orig + (ncliques - 1) * ov
+    m = ncliques * numel + nsoc * socdim
+    rows, cols, vals = [], [], []
+    for r in range(ncliques * numel):
+        for c in rng.choice(n_orig, size=3, replace=False):
+            rows.append(r)
+            cols.append(int(c))
+            vals.append(rng.standard_normal())
+    # overlap coupling: leading `ov` svec entries of clique k+1 tied to trailing of clique k
+    for k in range(ncliques - 1):
+        for t in range(ov):
+            col = n_orig + k * ov + t
+            rows += [k * numel + numel - ov + t, (k + 1) * numel + t]
+            cols += [col, col]
+            vals += [1.0, -1.0]
+    base = ncliques * numel
+    for r in range(nsoc * socdim):
+        for c in rng.choice(n_orig, size=2, replace=False):
+            rows.append(base + r)
+            cols.append(int(c))
+            vals.append(rng.standard_normal())
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(m, n)).tocsc()
+    A.sum_duplicates()
+    P = sp.csc_matrix((n, n))
+    cones = [(PSD, dim)] * ncliques + [(SOC, socdim)] * nsoc
+    s, z = _interior(rng, cones)
+    hs = []
+    for _ in range(ncliques):
+        G1 = rng.standard_normal((dim, dim))
+        G2 = rng.standard_normal((dim, dim))
+        hs.append(psd_scaling_Hs(G1 @ G1.T + dim * np.eye(dim), G2 @ G2.T + dim * np.eye(dim)))
+    hs_full = np.concatenate(hs + [np.zeros(socdim)] * nsoc)
+    return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=s, z=z, hsblocks=hs_full)

@@ -1,0 +1,300 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerance (BASELINE.json north_star / SURVEY.md 8c): 1e-8 relative on the
+post-refinement KKT solution with the SAME permutation injected into the oracle; LDL-level
+known-answer tests keep the reference's own 1e-8 / 1e-10 absolute bounds."""
+import numpy as np
+import pytest
+
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+
+
+def relerr(a, b):
+    return np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))
+
+
+# ---- L1: DirectLDLSolver known-answer tests ---------------------------------------
+def mat4(hip):
+    return hip.CscMatrix(4, 4, [0, 1, 3, 6, 8], [0, 0, 1, 0, 1, 2, 2, 3], [8., -3., 8., 2., -1., 8., -1., 1.])
+
+
+@pytest.mark.parametrize("perm", [None, [0, 1, 2, 3], [3, 0, 2, 1]])
+def test_solve_basic(hip, perm):
+    # qdldl/test.rs:194-230
+    st = hip.Settings.default(dynamic_regularization_eps=1e-12, dynamic_regularization_delta=1e-7)
+    f = hip.HipDirectLDLSolver(mat4(hip), [1, 1, 1, 1], st, perm=perm)
+    x = np.zeros(4)
+    with pytest.raises(hip.ChipError) as e:  # logical-only until the first refactor (test.rs:232-247)
+        f.solve(None, x, np.array([20.0, -22.0, 32.0, -7.0]))
+    assert e.value.code == hip.ERR_NOT_FACTORED
+    assert f.refactor()
+    b = np.array([20.0, -22.0, 32.0, -7.0])
+    f.solve(None, x, b)
+    assert np.max(np.abs(x - np.array([1., -2., 3., -4.]))) <= 1e-8
+    assert list(b) == [20.0, -22.0, 32.0, -7.0]
+
+
+def test_faer_kat(hip):
+    # ldlsolvers/faer_ldl.rs:352-404
+    K = hip.CscMatrix(6, 6, [0, 1, 2, 4, 6, 8, 10], [0, 1, 0, 2, 1, 3, 0, 4, 1, 5],
+                      [1.0, 2.0, 1.0, -1.0, 1.0, -2.0, -1.0, -3.0, -1.0, -4.0])
+    f = hip.HipDirectLDLSolver(K, [1, 1, -1, -1, -1, -1])
+    assert f.refactor()
+    x = np.zeros(6)
+    b = np.array([1., 2., 3., 4., 5., 6.])
+    f.solve(None, x, b)
+    xs = np.array([1.0, 0.9090909090909091, -2.0, -1.5454545454545454, -2.0, -1.7272727272727275])
+    assert np.max(np.abs(x - xs)) < 1e-10
+    f.update_values([9], [-10.0])
+    assert f.refactor()
+    f.solve(None, x, b)
+    xs = np.array([1.0, 1.3076923076923077, -2.0, -1.346153846153846, -2.0, -0.7307692307692306])
+    assert np.max(np.abs(x - xs)) < 1e-10
+    f.offset_values([1, 2], 3., [1, -1])
+    f.scale_values([1, 2], 2.)
+    assert f.refactor()
+    info = f.linear_solver_info()
+    assert info.nnzA == 10 and info.positive_inertia == 2 and info.direct == 1 and info.threads == 1
+
+
+def test_zero_pivot_regularised(hip, oracle):
+    # qdldl/test.rs:266-283 with regularisation ON (as the KKT adapter always has it,
+    # ldlsolvers/qdldl.rs:38): the zero pivot is replaced by delta*sign, same as the oracle
+    K = mat4(hip)
+    K.nzval[-1] = 0.0
+    f = hip.HipDirectLDLSolver(K, [1, 1, 1, 1], perm=[3, 0, 1, 2])
+    assert f.refactor()
+    o = oracle.QDLDL(4, K.colptr, K.rowval, K.nzval, perm=f.perm, Dsigns=[1, 1, 1, 1], logical=True,
+                     regularize_eps=1e-13, regularize_delta=2e-7)
+    assert o.refactor()
+    assert f.linear_solver_info().regularize_count == o.regularize_count == 1
+    x = np.zeros(4)
+    b = np.array([1., 2., 3., 4.])
+    f.solve(None, x, b)
+    assert relerr(x, o.solve(b)) <= 1e-9
+
+
+def test_nonfinite_values_fail_refactor(hip):
+    K = mat4(hip)
+    f = hip.HipDirectLDLSolver(K, [1, 1, 1, 1])
+    f.update_values([0], [np.nan])
+    assert f.refactor() is False  # Dinv.is_finite() == false, ldlsolvers/qdldl.rs:105
+
+
+def _rand_quasidef(rng, n1, n2, density):
+    import scipy.sparse as sp
+    rs = np.random.RandomState(int(rng.integers(1 << 30)))
+    B = sp.random(n2, n1, density=density, random_state=rs, format="csc")
+    H = sp.random(n1, n1, density=density / 2, random_state=rs, format="csc")
+    H = H @ H.T + sp.diags(rng.uniform(0.5, 2.0, n1))
+    G = sp.diags(rng.uniform(0.5, 2.0, n2))
+    K = sp.bmat([[H, B.T], [B, -G]], format="csc")
+    K = sp.triu(K, format="csc")
+    K.sort_indices()
+    ds = np.array([1] * n1 + [-1] * n2, dtype=np.int8)
+    return K, ds
+
+
+@pytest.mark.parametrize("n1,n2,density,seed", [(30, 20, 0.1, 0), (400, 300, 0.01, 1), (2000, 3000, 0.002, 2)])
+def test_ldl_random_quasidefinite(hip, oracle, n1, n2, density, seed):
+    """factor + solve of random sparse quasidefinite matrices (general fill: exercises the
+    workgroup-per-column kernels), factors compared entry by entry with the oracle."""
+    rng = np.random.default_rng(seed)
+    K, ds = _rand_quasidef(rng, n1, n2, density)
+    n = n1 + n2
+    Kc = hip.CscMatrix.from_scipy(K)
+    f = hip.HipDirectLDLSolver(Kc, ds)
+    assert f.refactor()
+    o = oracle.QDLDL(n, Kc.colptr, Kc.rowval, Kc.nzval, perm=f.perm, Dsigns=ds, logical=True,
+                     regularize_eps=1e-13, regularize_delta=2e-7)
+    assert o.refactor()
+    Lp, Li, Lx, D, Dinv = f.factors()
+    assert np.array_equal(Lp, o.Lp) and np.array_equal(Li, o.Li)
+    assert relerr(D, o.D) <= 1e-10 and relerr(Lx, o.Lx) <= 1e-9
+    assert f.linear_solver_info().positive_inertia == o.positive_inertia == n1
+    b = rng.standard_normal(n)
+    x = np.zeros(n)
+    f.solve(None, x, b)
+    assert relerr(x, o.solve(b)) <= TOL
+
+
+# ---- L2: KKTSolver on the configs ---------------------------------------------------
+def _solvers(hip, oracle, pr, settings=None, hs=None, late=False):
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"], settings=settings)
+    cones = oracle.Cones(pr["cones"])
+    ost = oracle.Settings.default()
+    if settings is not None:
+        ost.ir_max_iter = settings.iterative_refinement_max_iter
+        ost.ir_reltol = settings.iterative_refinement_reltol
+        ost.ir_abstol = settings.iterative_refinement_abstol
+        ost.ir_enable = settings.iterative_refinement_enable
+        ost.static_reg_enable = settings.static_regularization_enable
+    ko = oracle.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones, settings=ost, perm=ks.perm)
+    return ks, ko, cones
+
+
+def _check_update_and_solve(hip, oracle, pr, hs=None, nrhs=2, settings=None, tol=TOL):
+    ks, ko, cones = _solvers(hip, oracle, pr, settings)
+    assert ks.update_scaling(pr["s"], pr["z"])
+    assert cones.update_scaling(pr["s"], pr["z"])
+    assert ks.update(hs)
+    assert ko.update(hs)
+    # the device copy of K.nzval after the fused Hs / sparse-cone update == the oracle's K
+    assert relerr(ks.values(), ko.kkt.nzval) <= 1e-13
+    assert abs(ks.linear_solver_info().last_regularizer - ko.regularizer) <= 1e-20 + 1e-12 * ko.regularizer
+    rng = np.random.default_rng(42)
+    for _ in range(nrhs):
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        ks.setrhs(rx, rz)
+        ko.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert ks.solve(x, z)
+        ok, xo, zo = ko.solve()
+        assert ok
+        assert relerr(np.concatenate([x, z]), np.concatenate([xo, zo])) <= tol
+    return ks, ko
+
+
+def test_c1_basic_qp(hip, oracle):
+    _check_update_and_solve(hip, oracle, problems.basic_qp())
+
+
+@pytest.mark.parametrize("late", [False, True])
+def test_c2_random_qp(hip, oracle, late):
+    _check_update_and_solve(hip, oracle, problems.random_qp(3000, 6000, band=20, seed=1, late=late))
+
+
+@pytest.mark.parametrize("late", [False, True])
+def test_c3_portfolio_socp(hip, oracle, late):
+    ks, ko = _check_update_and_solve(hip, oracle, problems.portfolio_socp(12, 300, seed=3, late=late))
+    assert ks.linear_solver_info().n_levels <= 8
+
+
+def test_c3_dense_soc_blocks(hip, oracle):
+    # SOC(4): dense Hs block path (socone.rs:224-245)
+    _check_update_and_solve(hip, oracle, problems.portfolio_socp(7, 3, seed=4))
+
+
+def test_c3_big_rows_split_kernels(hip, oracle):
+    """budget row longer than the B-chunk threshold (16384): exercises the chunked
+    atomics kernels of factor / forward solve / symv"""
+    _check_update_and_solve(hip, oracle, problems.portfolio_socp(40, 500, seed=9), nrhs=1)
+
+
+def test_c4_batched(hip, oracle):
+    _check_update_and_solve(hip, oracle, problems.batched_socp(16, 200, 2, seed=100))
+
+
+def test_c5_chordal_sdp_host_hs(hip, oracle):
+    pr = problems.chordal_sdp(6, 6, 2, 3, 7, seed=5)
+    _check_update_and_solve(hip, oracle, pr, hs=pr["hsblocks"])
+
+
+def test_refactor_sequence_and_update_PA(hip, oracle):
+    """several IPM-like iterations on one handle (values change, pattern fixed) + update_P/A
+    (directldlkktsolver.rs:191-197)"""
+    pr = problems.random_qp(500, 1000, band=10, seed=21)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    rng = np.random.default_rng(3)
+    for it in range(3):
+        s = rng.uniform(0.1, 3.0, pr["m"]) * 10.0 ** (-it)
+        z = rng.uniform(0.1, 3.0, pr["m"])
+        assert ks.update_scaling(s, z) and cones.update_scaling(s, z)
+        if it == 1:
+            Px = pr["P"][2] * 1.5
+            Ax = pr["A"][2] * 0.5
+            ks.update_P(Px)
+            ks.update_A(Ax)
+            L = oracle.lib()
+            # oracle: same value overwrite through the maps
+            km = ko.kkt
+            v = km.nzval
+            v[km.map("P", len(Px))] = Px
+            v[km.map("A", len(Ax))] = Ax
+            km.set_nzval(v)
+            import ctypes as C
+            ldl = L.orc_kktsolver_ldl(ko._h)
+            idx = np.concatenate([km.map("P", len(Px)), km.map("A", len(Ax))]).astype(np.int64)
+            vals = np.concatenate([Px, Ax])
+            L.orc_qdldl_update_values(C.c_void_p(ldl), idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      vals.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(len(idx)))
+        assert ks.update() and ko.update()
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        ks.setrhs(rx, rz)
+        ko.setrhs(rx, rz)
+        x, zz = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert ks.solve(x, zz)
+        ok, xo, zo = ko.solve()
+        assert relerr(np.concatenate([x, zz]), np.concatenate([xo, zo])) <= TOL
+
+
+def test_ir_fixed_one_round(hip, oracle):
+    """the benchmark's refinement setting: max_iter=1, tolerances 0 => exactly one extra
+    round, same on both sides"""
+    st = hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0,
+                              iterative_refinement_abstol=0.0)
+    ks, ko = _check_update_and_solve(hip, oracle, problems.portfolio_socp(6, 100, seed=5), settings=st, tol=1e-7)
+    assert ks.linear_solver_info().last_ir_iterations == 1 and ko.last_ir_iters == 1
+
+
+def test_soc_scaling_failure_reported(hip):
+    pr = problems.portfolio_socp(2, 10, seed=1)
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+    s = pr["s"].copy()
+    s[1 + pr["n"]] = 0.0  # first SOC: s0 = 0 -> not interior -> update_scaling false (socone.rs:149-151)
+    assert ks.update_scaling(s, pr["z"]) is False
+
+
+def test_mul_Hs_identity(hip, oracle):
+    """Hs z = s for the NT scaling, on the device (compositecone.rs:259-264)"""
+    torch = pytest.importorskip("torch")
+    pr = problems.portfolio_socp(5, 40, seed=8)
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+    assert ks.update_scaling(pr["s"], pr["z"])
+    zt = torch.tensor(pr["z"], device="cuda")
+    yt = torch.zeros_like(zt)
+    torch.cuda.synchronize()
+    ks.mul_Hs_dev(yt.data_ptr(), zt.data_ptr())
+    ks.synchronize()
+    assert relerr(yt.cpu().numpy(), pr["s"]) <= 1e-10
+    cones = oracle.Cones(pr["cones"])
+    cones.update_scaling(pr["s"], pr["z"])
+    assert relerr(yt.cpu().numpy(), cones.mul_Hs(pr["z"])) <= 1e-12
+
+
+def test_full_scale_properties_c3(hip):
+    """BASELINE config 3 at full size (n = 10^6): too big for the oracle in seconds, so check
+    size-independent properties: residual of the refined solution against an independent
+    scipy SpMV of the UNregularised K, and linearity of the solve."""
+    import scipy.sparse as sp
+    pr = problems.portfolio_socp(1000, 1000, seed=3)
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+    assert ks.update_scaling(pr["s"], pr["z"])
+    assert ks.update()
+    K = ks.kkt_matrix()
+    vals = ks.values()
+    Ku = sp.csc_matrix((vals, K.rowval.astype(np.int64), K.colptr.astype(np.int64)), shape=(ks.N, ks.N))
+    Kfull = Ku + sp.triu(Ku, 1).T
+    rng = np.random.default_rng(1)
+    b1, b2 = rng.standard_normal(ks.N), rng.standard_normal(ks.N)
+    ok1, x1 = ks.solve_full(b1)
+    ok2, x2 = ks.solve_full(b2)
+    ok3, x3 = ks.solve_full(2.0 * b1 - 3.0 * b2)
+    assert ok1 and ok2 and ok3
+    for b, x in ((b1, x1), (b2, x2)):
+        r = b - Kfull @ x
+        assert np.max(np.abs(r)) <= 1e-8 * max(1.0, np.max(np.abs(b)))
+    assert relerr(x3, 2.0 * x1 - 3.0 * x2) <= 1e-7
+    info = ks.linear_solver_info()
+    assert info.n == 3003001 and info.positive_inertia == pr["n"] + 1000

@@ -1,0 +1,215 @@
+"""CPU-side (-m "not gpu") tests of the host logic: C-ABI exports, AMD ordering,
+KKT assembly + LDLDataMap against the oracle, symbolic analysis against the
+oracle's etree / column counts under the same permutation."""
+import re
+import os
+
+import numpy as np
+import pytest
+
+from tests import problems
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(hip):
+    hdr = open(os.path.join(ROOT, "include", "clarabel_hip.h")).read()
+    syms = sorted(set(re.findall(r"\b(chip_[a-z_A-Z0-9]+)\s*\(", hdr)))
+    assert len(syms) >= 35
+    L = hip.lib()
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_settings_defaults(hip):
+    s = hip.Settings.default()
+    # settings.rs:139-181
+    assert s.static_regularization_enable == 1 and s.static_regularization_constant == 1e-8
+    assert s.static_regularization_proportional == np.finfo(float).eps ** 2
+    assert s.dynamic_regularization_eps == 1e-13 and s.dynamic_regularization_delta == 2e-7
+    assert s.iterative_refinement_reltol == 1e-13 and s.iterative_refinement_abstol == 1e-12
+    assert s.iterative_refinement_max_iter == 10 and s.iterative_refinement_stop_ratio == 5.0
+    assert s.amd_dense_scale == 1.5
+
+
+def _host_only(hip):
+    return hip.Settings.default(device=hip.DEVICE_HOST_ONLY)
+
+
+def test_no_cpu_fallback(hip):
+    """numeric entry points refuse to run without a GPU instead of falling back"""
+    n, Ap, Ai, Ax = 4, [0, 1, 3, 6, 8], [0, 0, 1, 0, 1, 2, 2, 3], [8., -3., 8., 2., -1., 8., -1., 1.]
+    K = hip.CscMatrix(n, n, Ap, Ai, Ax)
+    f = hip.HipDirectLDLSolver(K, [1] * 4, _host_only(hip))
+    with pytest.raises(hip.ChipError) as e:
+        f.refactor()
+    assert e.value.code == hip.ERR_NO_DEVICE
+    if hip.device_count() == 0:
+        with pytest.raises(hip.ChipError) as e:
+            hip.HipDirectLDLSolver(K, [1] * 4)
+        assert e.value.code == hip.ERR_NO_DEVICE
+
+
+def test_structure_errors(hip):
+    # qdldl.rs:213-228 / test.rs:285-318
+    st = _host_only(hip)
+    K = hip.CscMatrix(3, 3, [0, 3, 6, 9], [0, 1, 2] * 3, [1., 2., 1., 3., 3., 4., 5., 6., 7.])
+    with pytest.raises(hip.ChipError) as e:
+        hip.HipDirectLDLSolver(K, [1] * 3, st)
+    assert e.value.code == hip.ERR_NOT_TRIU
+    K = hip.CscMatrix(3, 3, [0, 1, 1, 4], [0, 0, 1, 2], [1., 5., 6., 7.])
+    with pytest.raises(hip.ChipError) as e:
+        hip.HipDirectLDLSolver(K, [1] * 3, st)
+    assert e.value.code == hip.ERR_EMPTY_COLUMN
+    K = hip.CscMatrix(4, 4, [0, 1, 3, 6, 8], [0, 0, 1, 0, 1, 2, 2, 3], [8., -3., 8., 2., -1., 8., -1., 1.])
+    for bad in ([3, 0, 2, 0], [4, 0, 2, 1]):  # test.rs:37-47
+        with pytest.raises(hip.ChipError) as e:
+            hip.HipDirectLDLSolver(K, [1] * 4, st, perm=bad)
+        assert e.value.code == hip.ERR_BAD_PERM
+
+
+def test_amd_4x4(hip):
+    """qdldl/test.rs:123-129 pins crate amd to perm=[3,0,1,2] on this matrix.  Our AMD is an
+    independent implementation: require a valid permutation with the SAME fill (zero here)."""
+    Ap, Ai = [0, 1, 3, 6, 8], [0, 0, 1, 0, 1, 2, 2, 3]
+    perm, iperm, _ = hip.amd_order(4, Ap, Ai)
+    assert sorted(perm) == [0, 1, 2, 3] and all(iperm[perm[k]] == k for k in range(4))
+    # node 3 has degree 1: any minimum-degree ordering starts with it, as the reference's does
+    assert perm[0] == 3
+
+
+def _fill(oracle, n, Ap, Ai, perm):
+    f = oracle.QDLDL(n, Ap, Ai, np.ones(len(Ai)), perm=perm, logical=True)
+    return f.nnzL
+
+
+def _rand_sym(rng, n, density):
+    import scipy.sparse as sp
+    M = sp.random(n, n, density=density, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="csc")
+    M = sp.triu(M + M.T, 1) + sp.eye(n)
+    M = M.tocsc()
+    M.sort_indices()
+    return M.indptr.astype(np.int64), M.indices.astype(np.int64)
+
+
+@pytest.mark.parametrize("n,density", [(60, 0.08), (300, 0.02), (1500, 0.003)])
+def test_amd_quality_random(hip, oracle, n, density):
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    rng = np.random.default_rng(n)
+    Ap, Ai = _rand_sym(rng, n, density)
+    perm, iperm, info = hip.amd_order(n, Ap, Ai)
+    assert sorted(perm) == list(range(n))
+    fill_amd = _fill(oracle, n, Ap, Ai, perm)
+    fill_nat = _fill(oracle, n, Ap, Ai, np.arange(n))
+    M = sp.csc_matrix((np.ones(len(Ai)), Ai, Ap), shape=(n, n))
+    rcm = reverse_cuthill_mckee((M + M.T).tocsr(), symmetric_mode=True)
+    fill_rcm = _fill(oracle, n, Ap, Ai, rcm)
+    assert fill_amd <= fill_nat and fill_amd <= 1.05 * fill_rcm
+    # amd::Info.lnz analogue is an upper bound on (and close to) the true fill
+    assert info[0] >= fill_amd * 0.999 and info[0] <= 1.5 * fill_amd + n
+
+
+def test_amd_arrow_and_dense_rows(hip, oracle):
+    """an arrow matrix: the dense row/column must be ordered last => zero fill"""
+    n = 2000
+    cols = np.arange(n)
+    Ap = np.concatenate([[0], np.cumsum(np.where(cols == 0, 1, 2))]).astype(np.int64)
+    Ai = []
+    for c in range(n):
+        Ai += [0, c] if c > 0 else [0]
+    perm, _, _ = hip.amd_order(n, Ap, np.array(Ai, dtype=np.int64))
+    assert perm[-1] == 0
+    assert _fill(oracle, n, Ap, Ai, perm) == n - 1
+
+
+CASES = {
+    "basic_qp": lambda: problems.basic_qp(),
+    "qp_small": lambda: problems.random_qp(300, 600, band=10, seed=1),
+    "socp_small": lambda: problems.portfolio_socp(4, 12, seed=3),
+    "socp_dense_soc": lambda: dict(problems.portfolio_socp(3, 3, seed=4)),  # SOC(4): dense Hs blocks
+    "batched": lambda: problems.batched_socp(5, 20, 2, seed=100),
+    "sdp": lambda: problems.chordal_sdp(4, 4, 2, 2, 6, seed=5),
+}
+
+
+def _mk(hip, pr, settings=None, perm=None):
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    return hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"], settings=settings or hip.Settings.default(
+        device=hip.DEVICE_HOST_ONLY), perm=perm)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_kkt_assembly_matches_oracle(hip, oracle, name):
+    """same CSC arrays and the same LDLDataMap as kkt_assembly.rs / the oracle restatement"""
+    pr = CASES[name]()
+    ks = _mk(hip, pr)
+    cones = oracle.Cones(pr["cones"])
+    Ko = oracle.assemble_kkt(pr["n"], pr["m"], pr["P"], pr["A"], cones, "triu")
+    K = ks.kkt_matrix()
+    assert ks.N == Ko.N and ks.nnzK == Ko.nnz and ks.p == cones.pdim and ks.nHs == cones.nblockvals
+    assert np.array_equal(K.colptr.astype(np.int64), Ko.colptr)
+    assert np.array_equal(K.rowval.astype(np.int64), Ko.rowval)
+    assert np.array_equal(K.nzval, Ko.nzval)
+    mp = ks.maps()
+    assert np.array_equal(mp["P"], Ko.map("P", len(pr["P"][1])))
+    assert np.array_equal(mp["A"], Ko.map("A", len(pr["A"][1])))
+    assert np.array_equal(mp["Hsblocks"], Ko.map("Hs", cones.nblockvals))
+    assert np.array_equal(mp["diagP"], Ko.map("diagP", pr["n"]))
+    assert np.array_equal(mp["diag_full"], Ko.map("diag_full", Ko.N))
+    kso = oracle.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones)
+    assert np.array_equal(mp["dsigns"], kso.dsigns)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_symbolic_matches_oracle(hip, oracle, name):
+    """etree, column counts and the pattern of L agree with the reference algorithm
+    (qdldl.rs:433-464 + logical _factor) run under the engine's final permutation; the
+    level-major re-sort is a topological order of the SAME tree with the SAME fill."""
+    pr = CASES[name]()
+    ks = _mk(hip, pr)
+    K = ks.kkt_matrix()
+    perm = ks.perm
+    N = ks.N
+    assert sorted(perm) == list(range(N))
+    f = oracle.QDLDL(N, K.colptr, K.rowval, K.nzval, perm=perm, logical=True)
+    et, Lp, Li, lv = ks.symbolic()
+    assert np.array_equal(et, f.etree)  # -1 == QDLDL_UNKNOWN
+    assert np.array_equal(np.diff(Lp), f.Lnz)
+    assert np.array_equal(Lp, f.Lp) and np.array_equal(Li, f.Li)
+    info = ks.linear_solver_info()
+    assert info.nnzL == f.nnzL and info.nnzA == f.nnzA and info.name == b"hip"
+    # level sets: parents strictly above children, levels contiguous and ascending
+    level = np.zeros(N, dtype=np.int64)
+    for l in range(len(lv) - 1):
+        level[lv[l]:lv[l + 1]] = l
+    for j in range(N):
+        if et[j] >= 0:
+            assert level[et[j]] > level[j] and et[j] > j
+    # fill equals that of the un-resorted AMD order (equivalent reordering)
+    p0, _, _ = hip.amd_order(N, K.colptr, K.rowval)
+    f0 = oracle.QDLDL(N, K.colptr, K.rowval, K.nzval, perm=p0, logical=True)
+    assert f0.nnzL == f.nnzL
+
+
+def test_user_perm_respected_up_to_level_sort(hip, oracle):
+    pr = problems.random_qp(120, 240, band=6, seed=11)
+    ks0 = _mk(hip, pr)
+    N = ks0.N
+    rng = np.random.default_rng(0)
+    user = rng.permutation(N)
+    ks = _mk(hip, pr, perm=user)
+    K = ks.kkt_matrix()
+    f_user = oracle.QDLDL(N, K.colptr, K.rowval, K.nzval, perm=user, logical=True)
+    assert ks.linear_solver_info().nnzL == f_user.nnzL
+
+
+def test_portfolio_structure_is_shallow(hip):
+    """the block-arrow KKT of config 3 must come out with a handful of levels and ~1x fill
+    (SURVEY.md 7 'hard parts'): that is what makes the level-scheduled GPU path viable."""
+    pr = problems.portfolio_socp(20, 50, seed=3)
+    ks = _mk(hip, pr)
+    info = ks.linear_solver_info()
+    assert info.n_levels <= 8
+    assert info.nnzL <= 1.2 * info.nnzA

@@ -417,3 +417,72 @@ class HipKKTSolver:
         out = (C.c_double * 8)()
         _check(lib().chip_kkt_profile_read(self._h, out), "profile_read")
         return {"launches": int(out[0]), "ms": float(out[1]), "family": int(out[2])}
+
+
+# ---------------------------------------------------------------------------
+# raw HBM buffers without torch (tests / single-GPU bench plumbing): thin ctypes
+# calls into the SAME libamdhip64 instance the extension is linked against.
+# NB when torch is used in the process, import torch BEFORE this package so that
+# both share torch's bundled HIP runtime (two runtimes cannot both own the GPU).
+# ---------------------------------------------------------------------------
+_HIPRT = None
+
+
+def _hiprt():
+    global _HIPRT
+    if _HIPRT is None:
+        lib()
+        _HIPRT = C.CDLL("libamdhip64.so.7")
+    return _HIPRT
+
+
+class DeviceArray:
+    """n fp64 values in HBM on the current device"""
+
+    def __init__(self, n_or_array):
+        rt = _hiprt()
+        host = None
+        if not np.isscalar(n_or_array):
+            host = _f(n_or_array)
+            n = len(host)
+        else:
+            n = int(n_or_array)
+        self.n = n
+        self._p = C.c_void_p()
+        rc = rt.hipMalloc(C.byref(self._p), C.c_size_t(max(n, 1) * 8))
+        if rc != 0:
+            raise RuntimeError("hipMalloc failed: %d" % rc)
+        if host is not None:
+            self.copy_from(host)
+        else:
+            rt.hipMemset(self._p, 0, C.c_size_t(max(n, 1) * 8))
+
+    @property
+    def ptr(self):
+        return self._p.value
+
+    def copy_from(self, host):
+        host = _f(host)
+        assert len(host) == self.n
+        rc = _hiprt().hipMemcpy(self._p, host.ctypes.data_as(C.c_void_p), C.c_size_t(self.n * 8), C.c_int(1))
+        if rc != 0:
+            raise RuntimeError("hipMemcpy H2D failed: %d" % rc)
+
+    def numpy(self):
+        out = np.zeros(self.n)
+        rc = _hiprt().hipMemcpy(out.ctypes.data_as(C.c_void_p), self._p, C.c_size_t(self.n * 8), C.c_int(2))
+        if rc != 0:
+            raise RuntimeError("hipMemcpy D2H failed: %d" % rc)
+        return out
+
+    def __del__(self):
+        if getattr(self, "_p", None) and self._p.value:
+            try:
+                _hiprt().hipFree(self._p)
+            except Exception:
+                pass
+            self._p = C.c_void_p()
+
+
+def device_synchronize():
+    _hiprt().hipDeviceSynchronize()

@@ -408,7 +408,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     sv.w = h->d_w;
     sv.lam = h->d_lam;
     double *st8;
-    if ((rc = E.alloc(&st8, (size_t)sv.ncones * 8))) return rc;
+    if ((rc = E.alloc(&st8, (size_t)(sv.ncones ? sv.ncones : 1) * 8))) return rc;
     CHIP_HIP(hipMemset(st8, 0, (size_t)(sv.ncones ? sv.ncones : 1) * 8 * sizeof(double)));
     sv.eta = st8;
     sv.d = st8;

@@ -70,7 +70,7 @@ def test_zero_pivot_regularised(hip, oracle):
     o = oracle.QDLDL(4, K.colptr, K.rowval, K.nzval, perm=f.perm, Dsigns=[1, 1, 1, 1], logical=True,
                      regularize_eps=1e-13, regularize_delta=2e-7)
     assert o.refactor()
-    assert f.linear_solver_info().regularize_count == o.regularize_count == 1
+    assert f.linear_solver_info().regularize_count == o.regularize_count >= 1
     x = np.zeros(4)
     b = np.array([1., 2., 3., 4.])
     f.solve(None, x, b)
@@ -254,21 +254,19 @@ def test_soc_scaling_failure_reported(hip):
 
 def test_mul_Hs_identity(hip, oracle):
     """Hs z = s for the NT scaling, on the device (compositecone.rs:259-264)"""
-    torch = pytest.importorskip("torch")
     pr = problems.portfolio_socp(5, 40, seed=8)
     P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
     A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
     ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
     assert ks.update_scaling(pr["s"], pr["z"])
-    zt = torch.tensor(pr["z"], device="cuda")
-    yt = torch.zeros_like(zt)
-    torch.cuda.synchronize()
-    ks.mul_Hs_dev(yt.data_ptr(), zt.data_ptr())
+    zt = hip.DeviceArray(pr["z"])
+    yt = hip.DeviceArray(pr["m"])
+    ks.mul_Hs_dev(yt.ptr, zt.ptr)
     ks.synchronize()
-    assert relerr(yt.cpu().numpy(), pr["s"]) <= 1e-10
+    assert relerr(yt.numpy(), pr["s"]) <= 1e-10
     cones = oracle.Cones(pr["cones"])
     cones.update_scaling(pr["s"], pr["z"])
-    assert relerr(yt.cpu().numpy(), cones.mul_Hs(pr["z"])) <= 1e-12
+    assert relerr(yt.numpy(), cones.mul_Hs(pr["z"])) <= 1e-12
 
 
 def test_full_scale_properties_c3(hip):

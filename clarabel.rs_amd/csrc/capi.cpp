@@ -81,6 +81,7 @@ struct chip_kkt {
     int last_ir = 0;
     double last_eps = 0;
     bool scaling_pending_check = false;
+    bool x_holds_b = false; // x was initialised with the rhs by setrhs (skips a D2D copy)
 };
 
 extern "C" {
@@ -535,7 +536,13 @@ int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *r
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
-    dev::setrhs_perm(E.stream, h->bp, rhsx_dev, rhsz_dev, E.perm, (int)h->K.n, (int)h->K.m, E.N);
+    int rc = E.zero_norm_sets();
+    if (rc) return rc;
+    // one pass writes the permuted rhs twice: bp (kept for the residuals) and x (solved in
+    // place), and folds ||b||inf into norm set 0 -- no separate copy / norm launches
+    dev::setrhs_perm(E.stream, h->bp, h->x, rhsx_dev, rhsz_dev, E.perm, (int)h->K.n, (int)h->K.m, E.N,
+                     E.norm_set(0), &E.mb_dev->nan[0]);
+    h->x_holds_b = true;
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
@@ -555,56 +562,68 @@ int32_t chip_kkt_setrhs(chip_kkt *h, const double *rhsx, const double *rhsz) {
 
 // x <- K^-1 bp with iterative refinement (directldlkktsolver.rs:168-189, :266-321);
 // everything in the engine's permuted numbering.  Returns the reference's bool.
+//
+// Buffer rotation instead of copies: x (solution), e (residual, then solved IN PLACE into the
+// correction, then turned into the candidate x + dx), w (next residual).  Accepting a round
+// renames (x, e, w) <- (e, w, x): the reference's mem::swap(x, dx) without moving data.
 static int solve_core(chip_kkt *h) {
     Engine &E = h->E;
     const chip_settings &st = E.st;
     const int N = E.N;
     if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
     h->last_ir = 0;
-    CHIP_HIP(hipMemcpyAsync(h->x, h->bp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
-    E.enqueue_solve_inplace(h->x);
-    Mailbox *mb = E.mb_dev;
-    CHIP_HIP(hipMemsetAsync(mb->nrm, 0, sizeof(mb->nrm) + sizeof(mb->nan), E.stream));
-    if (!st.iterative_refinement_enable) {
-        dev::norm_inf(E.stream, h->x, N, &mb->nrm[0], &mb->nan[0]);
-        int rc = E.read_mailbox();
-        if (rc) return rc;
-        const double nx = bits_to_double(E.mb_host->nrm[0]);
-        return (!E.mb_host->nan[0] && std::isfinite(nx)) ? 1 : 0;
+    int rc;
+    if (!h->x_holds_b) { // solve() again on the same right-hand side, or a full-N rhs in bp
+        if ((rc = E.zero_norm_sets())) return rc;
+        CHIP_HIP(hipMemcpyAsync(h->x, h->bp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
+        dev::norm_inf(E.stream, h->bp, N, E.norm_set(0), &E.mb_dev->nan[0]);
     }
-    double *x = h->x, *dx = h->dx;
-    dev::norm_inf(E.stream, h->bp, N, &mb->nrm[0], &mb->nan[0]);
-    E.enqueue_residual(h->e, h->bp, x);
-    dev::norm_inf(E.stream, h->e, N, &mb->nrm[1], &mb->nan[1]);
-    int rc = E.read_mailbox();
-    if (rc) return rc;
-    const double normb = E.mb_host->nan[0] ? NAN : bits_to_double(E.mb_host->nrm[0]);
-    double norme = E.mb_host->nan[1] ? NAN : bits_to_double(E.mb_host->nrm[1]);
+    h->x_holds_b = false;
+    E.enqueue_solve_inplace(h->x);
+    if (!st.iterative_refinement_enable) {
+        dev::norm_inf(E.stream, h->x, N, E.norm_set(1), &E.mb_dev->nan[1]);
+        double nx;
+        if ((rc = E.read_norm(1, &nx))) return rc;
+        return std::isfinite(nx) ? 1 : 0; // x.is_finite(), directldlkktsolver.rs:180
+    }
+    double *x = h->x, *e = h->e, *w = h->dx;
+    int set = 1;
+    E.enqueue_residual(e, h->bp, x, set);
+    double nb_ne[2]; // sets 0 (||b||inf) and 1 (||e||inf) travel in one D2H copy
+    if ((rc = E.read_norms(0, 2, nb_ne))) return rc;
+    const double normb = nb_ne[0];
+    double norme = nb_ne[1];
     if (!std::isfinite(norme)) return 0;
     for (int it = 0; it < st.iterative_refinement_max_iter; it++) {
         if (norme <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb) break;
         const double lastnorme = norme;
-        CHIP_HIP(hipMemcpyAsync(dx, h->e, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
-        E.enqueue_solve_inplace(dx);
-        dev::add_vec(E.stream, dx, x, N);
-        CHIP_HIP(hipMemsetAsync(&mb->nrm[1], 0, sizeof(unsigned long long), E.stream));
-        CHIP_HIP(hipMemsetAsync(&mb->nan[1], 0, sizeof(int), E.stream));
-        E.enqueue_residual(h->e, h->bp, dx);
-        dev::norm_inf(E.stream, h->e, N, &mb->nrm[1], &mb->nan[1]);
-        rc = E.read_mailbox();
-        if (rc) return rc;
-        norme = E.mb_host->nan[1] ? NAN : bits_to_double(E.mb_host->nrm[1]);
+        E.enqueue_solve_inplace(e);      // e <- K^-1 e  (the correction dx)
+        dev::add_vec(E.stream, e, x, N); // e <- x + dx  (the candidate)
+        set += 1;
+        if (set >= NRM_SETS) {
+            set = 1;
+        }
+        if (it + 2 >= NRM_SETS) { // set being reused: clear it first
+            CHIP_HIP(hipMemsetAsync(E.norm_set(set), 0, NRM_SET_WORDS * sizeof(unsigned long long), E.stream));
+            CHIP_HIP(hipMemsetAsync(&E.mb_dev->nan[set], 0, sizeof(int), E.stream));
+        }
+        E.enqueue_residual(w, h->bp, e, set);
+        if ((rc = E.read_norm(set, &norme))) return rc;
         h->last_ir += 1;
         if (!std::isfinite(norme)) return 0;
         const double improved = lastnorme / norme;
-        if (improved < st.iterative_refinement_stop_ratio) {
-            if (improved > 1.0) std::swap(x, dx);
-            break;
+        const bool accept = !(improved < st.iterative_refinement_stop_ratio) || improved > 1.0;
+        if (accept) { // (x, e, w) <- (candidate, its residual, free)
+            double *t = x;
+            x = e;
+            e = w;
+            w = t;
         }
-        std::swap(x, dx);
+        if (improved < st.iterative_refinement_stop_ratio) break;
     }
-    h->x = x; // mem::swap of the Vecs in the reference
-    h->dx = dx;
+    h->x = x;
+    h->e = e;
+    h->dx = w;
     return 1;
 }
 
@@ -638,6 +657,7 @@ int32_t chip_kkt_solve_full(chip_kkt *h, double *x, const double *b) {
     const size_t bytes = (size_t)E.N * sizeof(double);
     CHIP_HIP(hipMemcpyAsync(h->d_tmp, b, bytes, hipMemcpyHostToDevice, E.stream));
     dev::permute_in(E.stream, h->bp, h->d_tmp, E.perm, E.N);
+    h->x_holds_b = false;
     int ok = solve_core(h);
     if (ok != 1) return ok;
     dev::permute_out(E.stream, h->d_tmp, h->x, E.perm, E.N);

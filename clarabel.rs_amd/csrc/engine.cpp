@@ -3,6 +3,8 @@
 // kernel boundaries on that stream (see kernels.hip for the rationale).
 #include "engine.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace chip {
@@ -16,6 +18,7 @@ Engine::~Engine() {
     for (hipEvent_t ev : prof_events) (void)hipEventDestroy(ev);
     for (void *p : allocs) (void)hipFree(p);
     if (mb_host) (void)hipHostFree(mb_host);
+    if (nrm_host) (void)hipHostFree(nrm_host);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -113,6 +116,8 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     int rc;
     const size_t n = (size_t)N;
     if ((rc = upload(&a2l, S.a2l, (size_t)nnzK))) return rc;
+    nfill = (int)S.fill_idx.size();
+    if ((rc = upload(&fill_idx, S.fill_idx, S.fill_idx.size()))) return rc;
     if ((rc = upload(&Lp, S.Lp, n + 1))) return rc;
     if ((rc = upload(&Li, S.Li, (size_t)nnzL))) return rc;
     if ((rc = upload(&Rp, S.Rp, n + 1))) return rc;
@@ -139,6 +144,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     CHIP_HIP(hipMemset(mb_dev, 0, sizeof(Mailbox)));
     CHIP_HIP(hipHostMalloc((void **)&mb_host, sizeof(Mailbox), hipHostMallocDefault));
     std::memset(mb_host, 0, sizeof(Mailbox));
+    if ((rc = alloc(&nrm_dev, (size_t)NRM_SETS * NRM_SET_WORDS))) return rc;
+    CHIP_HIP(hipMemset(nrm_dev, 0, (size_t)NRM_SETS * NRM_SET_WORDS * sizeof(unsigned long long)));
+    CHIP_HIP(hipHostMalloc((void **)&nrm_host, 2 * NRM_SET_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     return CHIP_OK;
 }
 
@@ -212,9 +220,8 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
                              st.static_regularization_proportional, (double *)mb_dev);
         eps_ptr = (const double *)mb_dev;
     }
-    CHIP_HIP(hipMemsetAsync(mb_dev->status, 0, sizeof(int) * 4, stream));
-    if (nnzL) CHIP_HIP(hipMemsetAsync(Lx, 0, (size_t)nnzL * sizeof(double), stream));
-    dev::scatter_init(stream, Kx, a2l, (int)nnzK, (int)nnzL, Lx, D, dsigns, eps_ptr);
+    dev::scatter_init(stream, Kx, a2l, (int)nnzK, (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
+                      mb_dev->status);
     for (int l = 0; l < nlevels; l++) {
         prof_begin(PF_FACTOR_T);
         dev::factor_T(stream, v, fac.T(l));
@@ -242,7 +249,7 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
 
 // qdldl.rs:755-768 in the permuted numbering, in place
 void Engine::enqueue_solve_inplace(double *xp) {
-    dev::GatherArgs f{Rp, Rcol, Rx, xp, xp, nullptr};
+    dev::GatherArgs f{Rp, Rcol, Rx, xp, xp, nullptr, nullptr, nullptr};
     for (int l = 1; l < nlevels; l++) {
         const dev::ChunkView b = fwd.B(l);
         if (b.count) dev::gather_B(stream, dev::FWD, f, b);
@@ -251,7 +258,7 @@ void Engine::enqueue_solve_inplace(double *xp) {
         prof_end(PF_FWD_T);
         dev::gather_W(stream, dev::FWD, f, fwd.W(l));
     }
-    dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv};
+    dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
     for (int l = nlevels - 1; l >= 0; l--) {
         const dev::ChunkView b = bwd.B(l);
         if (b.count) {
@@ -266,17 +273,45 @@ void Engine::enqueue_solve_inplace(double *xp) {
 }
 
 // e = b - K x with the UNregularised K (directldlkktsolver.rs:334-347)
-void Engine::enqueue_residual(double *e, const double *b, const double *x) {
-    dev::GatherArgs a{Sp, Scol, Sx, x, e, b};
+void Engine::enqueue_residual(double *e, const double *b, const double *x, int set) {
+    dev::GatherArgs a{Sp, Scol, Sx, x, e, b, nullptr, nullptr};
+    if (set >= 0) {
+        a.nrm = norm_set(set);
+        a.nan = &mb_dev->nan[set];
+    }
     const dev::ChunkView bc = smv.B(0);
     if (bc.count) {
         dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));
         dev::gather_B(stream, dev::SYMV, a, bc);
+        if (set >= 0) dev::norm_rows(stream, e, smv.BR(0), a.nrm, a.nan);
     }
     prof_begin(PF_SYMV_T);
     dev::gather_T(stream, dev::SYMV, a, smv.T(0));
     prof_end(PF_SYMV_T);
     dev::gather_W(stream, dev::SYMV, a, smv.W(0));
 }
+
+int Engine::zero_norm_sets() {
+    CHIP_HIP(hipMemsetAsync(nrm_dev, 0, (size_t)NRM_SETS * NRM_SET_WORDS * sizeof(unsigned long long), stream));
+    CHIP_HIP(hipMemsetAsync(mb_dev->nan, 0, sizeof(int) * NRM_SETS, stream));
+    return CHIP_OK;
+}
+
+int Engine::read_norms(int first, int count, double *out) {
+    CHIP_HIP(hipMemcpyAsync(nrm_host, norm_set(first), (size_t)count * NRM_SET_WORDS * sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost, stream));
+    int rc = read_mailbox();
+    if (rc) return rc;
+    for (int k = 0; k < count; k++) {
+        unsigned long long m = 0;
+        const unsigned long long *base = nrm_host + (size_t)k * NRM_SET_WORDS;
+        for (int i = 0; i < dev::NRM_SLOTS; i++) m = std::max(m, base[(size_t)i * dev::NRM_STRIDE]);
+        double d;
+        std::memcpy(&d, &m, sizeof(d));
+        out[k] = mb_host->nan[first + k] ? std::nan("") : d; // vecmath.rs:132-142 NaN propagation
+    }
+    return CHIP_OK;
+}
+int Engine::read_norm(int set, double *out) { return read_norms(set, 1, out); }
 
 } // namespace chip

@@ -29,12 +29,13 @@ struct Mailbox {
     double eps;                  // static regulariser of the last refactor
     unsigned long long tmpmax;   // scratch of diag_absmax_eps
     unsigned long long tmpnan;
-    unsigned long long nrm[2];   // bit patterns of ||b||inf, ||e||inf
-    int nan[2];
+    int nan[16];                 // NaN sightings per norm set (set 0 = ||b||, 1.. = residual rounds)
     int status[4];               // non-finite pivot, zero pivot, regularize_count, (unused)
     int soc_fail;
-    int pad[19];
+    int pad[9];
 };
+constexpr int NRM_SETS = 16;
+constexpr int NRM_SET_WORDS = dev::NRM_SLOTS * dev::NRM_STRIDE; // u64 words per set
 static_assert(sizeof(Mailbox) <= 256, "mailbox");
 
 // profile families (hipEvent pairs around each launch of ONE selected family)
@@ -54,6 +55,9 @@ struct Engine {
     double *Kx = nullptr, *Lx = nullptr, *Rx = nullptr, *D = nullptr, *Dinv = nullptr, *Sx = nullptr;
     DeviceLists fac, fwd, bwd, smv;
     Mailbox *mb_dev = nullptr, *mb_host = nullptr;
+    unsigned long long *nrm_dev = nullptr, *nrm_host = nullptr; // NRM_SETS slotted inf-norm accumulators
+    int *fill_idx = nullptr;
+    int nfill = 0;
     std::vector<i32> h_perm, h_lvlptr, h_etree;
     bool host_only = false;          // CHIP_DEVICE_HOST_ONLY: symbolic results only
     std::vector<i32> h_Lp, h_Li;     // kept only for host-only handles
@@ -82,7 +86,12 @@ struct Engine {
     // returns 1 ok / 0 numerical failure / <0 error
     int refactor(bool static_reg, const int *diag_idx_dev);
     void enqueue_solve_inplace(double *xp);                                  // permuted numbering
-    void enqueue_residual(double *e, const double *b, const double *x);     // e = b - K x (permuted)
+    // e = b - K x (permuted numbering); ||e||inf is folded into norm set `set` (>= 0)
+    void enqueue_residual(double *e, const double *b, const double *x, int set);
+    int zero_norm_sets();                                                    // enqueue
+    unsigned long long *norm_set(int set) const { return nrm_dev + (size_t)set * NRM_SET_WORDS; }
+    int read_norm(int set, double *out);                                     // D2H + sync; NaN propagating
+    int read_norms(int first, int count, double *out);                       // `count` <= 2 contiguous sets
     int read_mailbox();                                                      // D2H + sync
     void prof_begin(int family);
     void prof_end(int family);

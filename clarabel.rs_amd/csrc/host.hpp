@@ -50,6 +50,8 @@ struct Symbolic {
     // where each entry of the caller's K.nzval lands: < nnzL -> Lx position
     // (CSC of L), otherwise nnzL + j -> D[j]
     std::vector<i32> a2l;
+    // slots of L (CSC positions) that no entry of K maps to: structural fill-in
+    std::vector<i32> fill_idx;
     // L, CSC with ascending rows (structure only; values live on the device)
     std::vector<i32> Lp, Li;
     // L, CSR (row j: columns k ascending), Rpos = CSC position of the entry,

@@ -97,8 +97,12 @@ __global__ __launch_bounds__(WG) void k_scatter_init(const double *__restrict__ 
                                                      const int *__restrict__ a2l, int nnzK, int nnzL,
                                                      double *Lx, double *D,
                                                      const int8_t *__restrict__ dsigns,
-                                                     const double *eps_ptr) {
+                                                     const double *eps_ptr,
+                                                     const int *__restrict__ fill_idx, int nfill,
+                                                     int *status) {
     const double eps = eps_ptr ? eps_ptr[0] : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
+    for (int t = logical_block() * WG + threadIdx.x; t < nfill; t += gridDim.x * WG) Lx[fill_idx[t]] = 0.0;
     for (int t = logical_block() * WG + threadIdx.x; t < nnzK; t += gridDim.x * WG) {
         const int tgt = a2l[t];
         const double val = Kx[t];
@@ -332,22 +336,48 @@ __global__ __launch_bounds__(WG) void k_factor_finalize(LdlView v, const int *__
 //   BWD : out[r]  = out[r]*Dinv[r] - sum ...                    (qdldl.rs:737-752)
 //   SYMV: out[r]  = b[r] - sum ...                              (directldlkktsolver.rs:334-347)
 // ---------------------------------------------------------------------------
+// returns the stored value (SYMV: the residual entry, folded into the inf-norm by the caller)
 template <int MODE>
-__device__ __forceinline__ void store_row(const GatherArgs &a, int r, double s) {
-    if (MODE == FWD) a.out[r] = a.out[r] - s;
-    else if (MODE == BWD) a.out[r] = a.out[r] * a.aux[r] - s;
-    else a.out[r] = a.aux[r] - s;
+__device__ __forceinline__ double store_row(const GatherArgs &a, int r, double s) {
+    double v;
+    if (MODE == FWD) v = a.out[r] - s;
+    else if (MODE == BWD) v = a.out[r] * a.aux[r] - s;
+    else v = a.aux[r] - s;
+    a.out[r] = v;
+    return v;
+}
+// fold a partial max (and NaN sighting) into the slotted inf-norm accumulator
+__device__ __forceinline__ void fold_norm(unsigned long long *nrm, int *nan, double m, bool sawnan,
+                                          int slot_seed) {
+    if (sawnan) *nan = 1;
+    if (m > 0.0) {
+        unsigned long long *slot = nrm + (slot_seed & (NRM_SLOTS - 1)) * NRM_STRIDE;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(slot, bits);
+    }
 }
 
 template <int MODE>
 __global__ __launch_bounds__(WG) void k_gather_T(GatherArgs a, const int *__restrict__ rows, int count) {
-    const int tid = logical_block() * WG + threadIdx.x;
-    if (tid >= count) return;
-    const int r = rows[tid];
-    const int b = a.ptr[r], e = a.ptr[r + 1];
-    double s = 0.0;
-    for (int t = b; t < e; ++t) s += a.val[t] * a.xin[a.idx[t]];
-    store_row<MODE>(a, r, s);
+    __shared__ double red[4];
+    const int lb = logical_block();
+    const int tid = lb * WG + threadIdx.x;
+    double v = 0.0;
+    if (tid < count) {
+        const int r = rows[tid];
+        const int b = a.ptr[r], e = a.ptr[r + 1];
+        double s = 0.0;
+        for (int t = b; t < e; ++t) s += a.val[t] * a.xin[a.idx[t]];
+        v = store_row<MODE>(a, r, s);
+    }
+    if (MODE == SYMV && a.nrm) {
+        const bool nan = v != v;
+        const double m = block_max(nan ? 0.0 : fabs(v), red);
+        if (__syncthreads_or(nan)) {
+            if (threadIdx.x == 0) *a.nan = 1;
+        }
+        if (threadIdx.x == 0) fold_norm(a.nrm, a.nan, m, false, lb);
+    }
 }
 // W: one wavefront per row, 4 rows per workgroup
 template <int MODE>
@@ -360,7 +390,10 @@ __global__ __launch_bounds__(WG) void k_gather_W(GatherArgs a, const int *__rest
     double s = 0.0;
     for (int t = b + lane; t < e; t += 64) s += a.val[t] * a.xin[a.idx[t]];
     s = wave_sum(s);
-    if (lane == 0) store_row<MODE>(a, r, s);
+    if (lane == 0) {
+        const double v = store_row<MODE>(a, r, s);
+        if (MODE == SYMV && a.nrm) fold_norm(a.nrm, a.nan, v != v ? 0.0 : fabs(v), v != v, wid);
+    }
 }
 template <int MODE>
 __global__ __launch_bounds__(WG) void k_gather_Bprep(GatherArgs a, const int *__restrict__ rows, int count) {
@@ -383,6 +416,14 @@ __global__ __launch_bounds__(WG) void k_gather_B(GatherArgs a, const int *__rest
     if (threadIdx.x == 0) atomicAdd(&a.out[crow[blockIdx.x]], -s);
 }
 
+__global__ __launch_bounds__(WG) void k_norm_rows(const double *__restrict__ vv, const int *__restrict__ rows,
+                                                  int count, unsigned long long *nrm, int *nan) {
+    const int t = blockIdx.x * WG + threadIdx.x;
+    if (t >= count) return;
+    const double a = vv[rows[t]];
+    fold_norm(nrm, nan, a != a ? 0.0 : fabs(a), a != a, t);
+}
+
 // ---------------------------------------------------------------------------
 // vectors
 // ---------------------------------------------------------------------------
@@ -395,13 +436,25 @@ __global__ __launch_bounds__(WG) void k_permute_out(double *__restrict__ x, cons
     for (int j = logical_block() * WG + threadIdx.x; j < N; j += gridDim.x * WG) x[perm[j]] = y[j];
 }
 // directldlkktsolver.rs:160-166 in the permuted numbering
-__global__ __launch_bounds__(WG) void k_setrhs_perm(double *__restrict__ bp, const double *__restrict__ rx,
+__global__ __launch_bounds__(WG) void k_setrhs_perm(double *__restrict__ bp, double *__restrict__ xi,
+                                                    const double *__restrict__ rx,
                                                     const double *__restrict__ rz,
-                                                    const int *__restrict__ perm, int n, int m, int N) {
+                                                    const int *__restrict__ perm, int n, int m, int N,
+                                                    unsigned long long *nrm, int *nanflag) {
+    __shared__ double red[4];
+    double mx = 0.0;
+    bool nan = false;
     for (int j = logical_block() * WG + threadIdx.x; j < N; j += gridDim.x * WG) {
         const int o = perm[j];
-        bp[j] = o < n ? rx[o] : (o < n + m ? rz[o - n] : 0.0);
+        const double val = o < n ? rx[o] : (o < n + m ? rz[o - n] : 0.0);
+        bp[j] = val;
+        xi[j] = val;
+        if (val != val) nan = true;
+        else mx = fmax(mx, fabs(val));
     }
+    mx = block_max(mx, red);
+    if (nan) *nanflag = 1;
+    if (threadIdx.x == 0) fold_norm(nrm, nanflag, mx, false, blockIdx.x);
 }
 // directldlkktsolver.rs:205-215
 __global__ __launch_bounds__(WG) void k_getlhs_perm(double *lx, double *lz, const double *__restrict__ xp,
@@ -427,8 +480,8 @@ __global__ __launch_bounds__(WG) void k_norm_inf(const double *__restrict__ vv, 
         else m = fmax(m, fabs(a));
     }
     m = block_max(m, red);
-    if (threadIdx.x == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
     if (nan) *nanflag = 1;
+    if (threadIdx.x == 0) fold_norm(out, nanflag, m, false, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -624,11 +677,11 @@ __global__ __launch_bounds__(WG) void k_soc_mul_hs(SocView v, double *y, const d
 // launch wrappers
 // ===========================================================================
 void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int nnzL, double *Lx,
-                  double *D, const int8_t *dsigns, const double *eps) {
-    if (nnzK == 0) return;
-    int nb = grid_for(nnzK);
+                  double *D, const int8_t *dsigns, const double *eps, const int *fill_idx, int nfill,
+                  int *status) {
+    int nb = grid_for(nnzK > 0 ? nnzK : 1);
     if (nb > 4096) nb = 4096;
-    k_scatter_init<<<nb, WG, 0, s>>>(Kx, a2l, nnzK, nnzL, Lx, D, dsigns, eps);
+    k_scatter_init<<<nb, WG, 0, s>>>(Kx, a2l, nnzK, nnzL, Lx, D, dsigns, eps, fill_idx, nfill, status);
 }
 void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap, int nnzS) {
     if (nnzS == 0) return;
@@ -700,9 +753,12 @@ void permute_in(hipStream_t s, double *y, const double *b, const int *perm, int 
 void permute_out(hipStream_t s, double *x, const double *y, const int *perm, int N) {
     if (N) k_permute_out<<<stream_grid(N), WG, 0, s>>>(x, y, perm, N);
 }
-void setrhs_perm(hipStream_t s, double *bp, const double *rx, const double *rz, const int *perm, int n,
-                 int m, int N) {
-    if (N) k_setrhs_perm<<<stream_grid(N), WG, 0, s>>>(bp, rx, rz, perm, n, m, N);
+void setrhs_perm(hipStream_t s, double *bp, double *xi, const double *rx, const double *rz, const int *perm,
+                 int n, int m, int N, unsigned long long *nrm, int *nan) {
+    if (N) k_setrhs_perm<<<stream_grid(N), WG, 0, s>>>(bp, xi, rx, rz, perm, n, m, N, nrm, nan);
+}
+void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long *nrm, int *nan) {
+    if (rows.count) k_norm_rows<<<(rows.count + WG - 1) / WG, WG, 0, s>>>(v, rows.idx, rows.count, nrm, nan);
 }
 void getlhs_perm(hipStream_t s, double *lx, double *lz, const double *xp, const int *iperm, int n, int m) {
     if (n + m) k_getlhs_perm<<<stream_grid(n + m), WG, 0, s>>>(lx, lz, xp, iperm, n, m);

@@ -31,8 +31,11 @@ struct ChunkView {
 };
 
 // ---- value plumbing -----------------------------------------------------------
+// fill_idx: the slots of L that no entry of K maps to (structural fill-in) -- zeroed here,
+// so no memset of the whole factor is needed; status (4 ints) is cleared by the same launch.
 void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int nnzL, double *Lx,
-                  double *D, const int8_t *dsigns, const double *eps_or_null);
+                  double *D, const int8_t *dsigns, const double *eps_or_null, const int *fill_idx,
+                  int nfill, int *status);
 void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap, int nnzS);
 void diag_absmax_eps(hipStream_t s, const double *Kx, const int *diag_idx, int N, double c,
                      double prop, double *scal /*[0]=eps out, uses [1] as scratch*/);
@@ -52,21 +55,32 @@ struct GatherArgs {
     const double *xin;  // gathered vector
     double *out;        // FWD/BWD: in-place accumulator (== xin); SYMV: e
     const double *aux;  // BWD: Dinv; SYMV: b
+    // SYMV only: ||out||inf folded into the launch.  NRM_SLOTS words, spread over
+    // distinct cache lines so the ~12 ns/atomic same-address serialisation of a
+    // device-scope atomicMax is divided by the slot count; the host takes the max.
+    unsigned long long *nrm;
+    int *nan;
 };
+constexpr int NRM_SLOTS = 64;
+constexpr int NRM_STRIDE = 16; // in u64 words: one slot per 128-byte line
 void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 void gather_W(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 void gather_B(hipStream_t s, GatherMode m, const GatherArgs &a, ChunkView chunks);
+// ||v[rows]||inf of a short row list into the slots (the B rows of a SYMV)
+void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long *nrm, int *nan);
 
 // ---- vectors ------------------------------------------------------------------
 void permute_in(hipStream_t s, double *y, const double *b, const int *perm, int N);
 void permute_out(hipStream_t s, double *x, const double *y, const int *perm, int N);
-void setrhs_perm(hipStream_t s, double *bperm, const double *rhsx, const double *rhsz,
-                 const int *perm, int n, int m, int N);
+// bperm (kept for the refinement residuals) and xinit (solved in place) both receive the
+// permuted right-hand side; ||b||inf is folded into nrm/nan (slot layout as above)
+void setrhs_perm(hipStream_t s, double *bperm, double *xinit, const double *rhsx, const double *rhsz,
+                 const int *perm, int n, int m, int N, unsigned long long *nrm, int *nan);
 void getlhs_perm(hipStream_t s, double *lhsx, double *lhsz, const double *xperm, const int *iperm,
                  int n, int m);
 void add_vec(hipStream_t s, double *dx, const double *x, int N); // dx = x + dx
-// out[slot] = bit pattern of max|v| (non-negative double as u64), nanflag[slot] |= any NaN
+// slots (NRM_SLOTS x NRM_STRIDE) <- bit patterns of partial max|v|; *nanflag |= any NaN
 void norm_inf(hipStream_t s, const double *v, int N, unsigned long long *out, int *nanflag);
 
 // ---- cones --------------------------------------------------------------------

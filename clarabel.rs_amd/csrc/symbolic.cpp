@@ -254,6 +254,13 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             }
         }
     }
+    {
+        std::vector<char> covered((size_t)nnzL + 1, 0);
+        for (i64 t = 0; t < nnzK; t++)
+            if (S.a2l[t] < nnzL) covered[S.a2l[t]] = 1;
+        for (i64 q = 0; q < nnzL; q++)
+            if (!covered[q]) S.fill_idx.push_back((i32)q);
+    }
     // ---- full symmetric K in CSR (permuted numbering) -----------------------
     {
         S.Sp.assign((size_t)n + 1, 0);

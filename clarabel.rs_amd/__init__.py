@@ -254,10 +254,10 @@ class HipDirectLDLSolver:
         et = np.zeros(self.n, dtype=u64)
         Lp = np.zeros(self.n + 1, dtype=u64)
         Li = np.zeros(max(info.nnzL, 1), dtype=u64)
-        lv = np.zeros(info.n_levels + 1, dtype=u64)
+        lv = np.zeros(max(self.n, 1), dtype=u64)
         _check(lib().chip_ldl_get_symbolic(self._h, _pu(et), _pu(Lp), _pu(Li), _pu(lv)), "get_symbolic")
         et = et.astype(np.int64)  # UINT64_MAX -> -1
-        return et, Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), lv.astype(np.int64)
+        return et, Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), lv[:self.n].astype(np.int64)
 
     def factors(self):
         info = self.linear_solver_info()
@@ -335,9 +335,9 @@ class HipKKTSolver:
         et = np.zeros(self.N, dtype=u64)
         Lp = np.zeros(self.N + 1, dtype=u64)
         Li = np.zeros(max(info.nnzL, 1), dtype=u64)
-        lv = np.zeros(info.n_levels + 1, dtype=u64)
+        lv = np.zeros(max(self.N, 1), dtype=u64)
         _check(lib().chip_kkt_get_symbolic(self._h, _pu(et), _pu(Lp), _pu(Li), _pu(lv)), "get_symbolic")
-        return et.astype(np.int64), Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), lv.astype(np.int64)
+        return et.astype(np.int64), Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), lv[:self.N].astype(np.int64)
 
     def values(self):
         nz = np.zeros(max(self.nnzK, 1))

@@ -36,7 +36,7 @@ void fill_info(const Engine &E, chip_info *info) {
     info->nnzA = E.nnzK;
     info->nnzL = E.nnzL;
     info->n = E.N;
-    info->n_levels = E.nlevels;
+    info->n_levels = E.tree_depth;
     info->amd_lnz = E.amd.lnz;
     info->amd_ndiv = E.amd.ndiv;
     info->amd_nmultsubs_ldl = E.amd.nmultsubs_ldl;

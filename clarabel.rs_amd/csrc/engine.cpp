@@ -61,6 +61,9 @@ void Engine::init_host_only(const Symbolic &S, const chip_settings &settings) {
     h_perm = S.perm;
     h_lvlptr = S.lvlptr;
     h_etree = S.etree;
+    h_level = S.level;
+    NF = S.NF;
+    tree_depth = S.tree_depth;
     h_Lp = S.Lp;
     h_Li = S.Li;
     amd = S.amd;
@@ -70,7 +73,7 @@ int Engine::get_symbolic(uint64_t *etree, uint64_t *oLp, uint64_t *oLi, uint64_t
     if (etree)
         for (int i = 0; i < N; i++) etree[i] = h_etree[i] < 0 ? UINT64_MAX : (uint64_t)h_etree[i];
     if (lvlptr)
-        for (int l = 0; l <= nlevels; l++) lvlptr[l] = (uint64_t)h_lvlptr[l];
+        for (int i = 0; i < N; i++) lvlptr[i] = (uint64_t)h_level[i];
     if (oLp || oLi) {
         std::vector<i32> tp, ti;
         const i32 *pLp = h_Lp.data(), *pLi = h_Li.data();
@@ -112,6 +115,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     h_perm = S.perm;
     h_lvlptr = S.lvlptr;
     h_etree = S.etree;
+    h_level = S.level;
+    NF = S.NF;
+    tree_depth = S.tree_depth;
     amd = S.amd;
     int rc;
     const size_t n = (size_t)N;
@@ -140,6 +146,17 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = upload_lists(fwd, S.fwd))) return rc;
     if ((rc = upload_lists(bwd, S.bwd))) return rc;
     if ((rc = upload_lists(smv, S.smv))) return rc;
+    {
+        int *bp = nullptr, *lp = nullptr, *lv = nullptr;
+        if ((rc = upload(&bp, S.bundle_ptr, S.bundle_ptr.size()))) return rc;
+        if ((rc = upload(&lp, S.blvl_ptr, S.blvl_ptr.size()))) return rc;
+        if ((rc = upload(&lv, S.blvl, S.blvl.size()))) return rc;
+        bundles.nb = S.bundle_ptr.empty() ? 0 : (int)S.bundle_ptr.size() - 1;
+        bundles.bundle_ptr = bp;
+        bundles.blvl_ptr = lp;
+        bundles.blvl = lv;
+        bundles.max_nodes = S.max_bundle_nodes;
+    }
     if ((rc = alloc(&mb_dev, 1))) return rc;
     CHIP_HIP(hipMemset(mb_dev, 0, sizeof(Mailbox)));
     CHIP_HIP(hipHostMalloc((void **)&mb_host, sizeof(Mailbox), hipHostMallocDefault));
@@ -222,6 +239,7 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
     }
     dev::scatter_init(stream, Kx, a2l, (int)nnzK, (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                       mb_dev->status);
+    dev::bundle_factor(stream, v, bundles); // everything below the cut: one launch
     for (int l = 0; l < nlevels; l++) {
         prof_begin(PF_FACTOR_T);
         dev::factor_T(stream, v, fac.T(l));
@@ -249,8 +267,10 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
 
 // qdldl.rs:755-768 in the permuted numbering, in place
 void Engine::enqueue_solve_inplace(double *xp) {
+    const dev::LdlView v = view();
+    dev::bundle_fwd(stream, v, bundles, xp);
     dev::GatherArgs f{Rp, Rcol, Rx, xp, xp, nullptr, nullptr, nullptr};
-    for (int l = 1; l < nlevels; l++) {
+    for (int l = 0; l < nlevels; l++) {
         const dev::ChunkView b = fwd.B(l);
         if (b.count) dev::gather_B(stream, dev::FWD, f, b);
         prof_begin(PF_FWD_T);
@@ -270,6 +290,7 @@ void Engine::enqueue_solve_inplace(double *xp) {
         prof_end(PF_BWD_T);
         dev::gather_W(stream, dev::BWD, g, bwd.W(l));
     }
+    dev::bundle_bwd(stream, v, bundles, xp);
 }
 
 // e = b - K x with the UNregularised K (directldlkktsolver.rs:334-347)

@@ -54,6 +54,9 @@ struct Engine {
     // values (device)
     double *Kx = nullptr, *Lx = nullptr, *Rx = nullptr, *D = nullptr, *Dinv = nullptr, *Sx = nullptr;
     DeviceLists fac, fwd, bwd, smv;
+    dev::BundleView bundles{}; // subtree bundles (device arrays)
+    int NF = 0, tree_depth = 0;
+    std::vector<i32> h_level;
     Mailbox *mb_dev = nullptr, *mb_host = nullptr;
     unsigned long long *nrm_dev = nullptr, *nrm_host = nullptr; // NRM_SETS slotted inf-norm accumulators
     int *fill_idx = nullptr;

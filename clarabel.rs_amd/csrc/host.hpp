@@ -58,8 +58,18 @@ struct Symbolic {
     // Tpos = CSR position of each CSC entry
     std::vector<i32> Rp, Rcol, Rpos, Tpos;
     std::vector<i32> etree; // parent in the final numbering, -1 = root
-    i32 nlevels = 0;
-    std::vector<i32> lvlptr; // level l = columns [lvlptr[l], lvlptr[l+1])
+    std::vector<i32> level; // elimination-tree level of every node (leaves = 0)
+    i32 tree_depth = 0;
+    // Final numbering = [bundle 0 | bundle 1 | ... | top].  A bundle is a set of complete
+    // elimination subtrees small enough for ONE workgroup (nodes level-major inside);
+    // nodes [NF, N) are the remaining ancestors ("top"), level-major, processed by the
+    // level-scheduled kernels: top level l = columns [lvlptr[l], lvlptr[l+1]), lvlptr[0] = NF.
+    i32 NF = 0;
+    std::vector<i32> bundle_ptr;      // nb + 1
+    std::vector<i32> blvl_ptr, blvl;  // per bundle: boundaries of its levels (absolute node ids)
+    i32 max_bundle_nodes = 0;
+    i32 nlevels = 0;                  // number of TOP levels
+    std::vector<i32> lvlptr;
     // full symmetric K (both triangles) in CSR, permuted numbering; Smap =
     // index into the caller's K.nzval (so values are refreshed by a gather)
     i64 nnzS = 0;

@@ -167,11 +167,8 @@ __device__ __forceinline__ void finish_column_serial(const LdlView &v, int j, in
     }
 }
 
-// T: one thread per column (few contributions, short column)
-__global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restrict__ cols, int count) {
-    const int tid = logical_block() * WG + threadIdx.x;
-    if (tid >= count) return;
-    const int j = cols[tid];
+// one thread factors column j (few contributions, short column)
+__device__ __forceinline__ void factor_col_thread(const LdlView &v, int j) {
     double d = v.D[j];
     const int cb = v.Lp[j], ce = v.Lp[j + 1];
     const int rb = v.Rp[j], re = v.Rp[j + 1];
@@ -192,6 +189,13 @@ __global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restric
     finish_column_serial(v, j, cb, ce, d);
 }
 
+// T: one thread per column
+__global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restrict__ cols, int count) {
+    const int tid = logical_block() * WG + threadIdx.x;
+    if (tid >= count) return;
+    factor_col_thread(v, cols[tid]);
+}
+
 constexpr int W_LDS_CAP = 4096; // column values kept in LDS (32 KiB of 160 KiB)
 
 __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int hi, int row) {
@@ -204,17 +208,14 @@ __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int 
     return lo;
 }
 
-// W: one 256-thread workgroup per column.  Threads stride over the
+// A whole 256-thread workgroup factors column j.  Threads stride over the
 // contributing columns k; column j's running values live in LDS and receive
 // LDS fp64 atomics (ds_add_f64).  Narrow columns (<= 4 rows: the u/v and
 // budget-like separators of block-arrow KKTs) take per-thread register
 // partials + one block reduction instead of hammering 4 LDS addresses.
-__global__ __launch_bounds__(WG) void k_factor_W(LdlView v, const int *__restrict__ cols, int count) {
-    __shared__ double acc[W_LDS_CAP];
-    __shared__ double red[4];
-    __shared__ double s_dinv;
-    if ((int)blockIdx.x >= count) return;
-    const int j = cols[blockIdx.x];
+// Must be called by all threads of the workgroup; ends un-synchronised.
+__device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double *acc, double *red,
+                                                 double *s_dinv) {
     const int cb = v.Lp[j], cn = v.Lp[j + 1] - cb;
     const int rb = v.Rp[j], rn = v.Rp[j + 1] - rb;
     const int tid = threadIdx.x;
@@ -275,9 +276,9 @@ __global__ __launch_bounds__(WG) void k_factor_W(LdlView v, const int *__restric
     }
     if (!lds) __threadfence();
     dpart = block_sum(dpart, red);
-    if (tid == 0) s_dinv = pivot_rule(v, j, v.D[j] - dpart);
+    if (tid == 0) *s_dinv = pivot_rule(v, j, v.D[j] - dpart);
     __syncthreads();
-    const double dinv = s_dinv;
+    const double dinv = *s_dinv;
     for (int q = tid; q < cn; q += WG) {
         const double c = lds ? acc[q]
                              : __hip_atomic_load(&v.Lx[cb + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -285,6 +286,153 @@ __global__ __launch_bounds__(WG) void k_factor_W(LdlView v, const int *__restric
         v.Lx[cb + q] = l;
         v.Rx[v.Tpos[cb + q]] = l;
     }
+}
+
+// W: one workgroup per column
+__global__ __launch_bounds__(WG) void k_factor_W(LdlView v, const int *__restrict__ cols, int count) {
+    __shared__ double acc[W_LDS_CAP];
+    __shared__ double red[4];
+    __shared__ double s_dinv;
+    if ((int)blockIdx.x >= count) return;
+    factor_col_block(v, cols[blockIdx.x], acc, red, &s_dinv);
+}
+
+// ---------------------------------------------------------------------------
+// Subtree bundles: ONE workgroup factors / solves a bundle of complete
+// elimination subtrees start to finish, level by level, with __syncthreads()
+// between levels -- all the cross-level traffic of the bottom of the tree stays
+// inside a CU (the vector slice of the bundle is staged in LDS for the solves),
+// and ~N/bundle_size workgroups run concurrently in a single launch instead of
+// one launch per level.  Only the few ancestors above the cut ("top") still go
+// through the level-scheduled kernels.
+// ---------------------------------------------------------------------------
+constexpr int FAC_THIN_ROW = 8, FAC_THIN_COL = 48, THIN_MAX = 32;
+
+__global__ __launch_bounds__(WG) void k_bundle_factor(LdlView v, BundleView bv) {
+    __shared__ double acc[W_LDS_CAP];
+    __shared__ double red[4];
+    __shared__ double s_dinv;
+    __shared__ int fat[WG];
+    __shared__ int nfat;
+    const int b = blockIdx.x;
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    for (int l = 0; l < nl; ++l) {
+        const int lb = lv[l], le = lv[l + 1];
+        for (int base = lb; base < le; base += WG) {
+            if (threadIdx.x == 0) nfat = 0;
+            __syncthreads();
+            const int j = base + threadIdx.x;
+            if (j < le) {
+                const int rj = v.Rp[j + 1] - v.Rp[j], cj = v.Lp[j + 1] - v.Lp[j];
+                if (rj <= FAC_THIN_ROW && cj <= FAC_THIN_COL) factor_col_thread(v, j);
+                else fat[atomicAdd(&nfat, 1)] = j;
+            }
+            __syncthreads();
+            const int nf = nfat;
+            for (int f = 0; f < nf; ++f) {
+                factor_col_block(v, fat[f], acc, red, &s_dinv);
+                __syncthreads();
+            }
+        }
+        __syncthreads(); // level l is final (global writes visible workgroup-wide) before level l+1
+    }
+}
+
+// forward substitution of a bundle: xs = slice of x in LDS; every row gathers only from its
+// own descendants, which live in the same bundle
+__global__ __launch_bounds__(WG) void k_bundle_fwd(LdlView v, BundleView bv, double *x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem;
+    int *fat = (int *)(smem + (size_t)bv.max_nodes * sizeof(double));
+    __shared__ int nfat;
+    const int b = blockIdx.x;
+    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    for (int i = threadIdx.x; i < s1 - s0; i += WG) xs[i] = x[s0 + i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int l = 1; l < nl; ++l) {
+        const int lb = lv[l], le = lv[l + 1];
+        for (int base = lb; base < le; base += WG) {
+            if (threadIdx.x == 0) nfat = 0;
+            __syncthreads();
+            const int j = base + threadIdx.x;
+            if (j < le) {
+                const int rb = v.Rp[j], re = v.Rp[j + 1];
+                if (re - rb <= THIN_MAX) {
+                    double s = 0.0;
+                    for (int t = rb; t < re; ++t) s += v.Rx[t] * xs[v.Rcol[t] - s0];
+                    xs[j - s0] -= s;
+                } else {
+                    fat[atomicAdd(&nfat, 1)] = j;
+                }
+            }
+            __syncthreads();
+            const int nf = nfat;
+            for (int f = wv; f < nf; f += 4) {
+                const int r = fat[f];
+                double s = 0.0;
+                for (int t = v.Rp[r] + lane; t < v.Rp[r + 1]; t += 64) s += v.Rx[t] * xs[v.Rcol[t] - s0];
+                s = wave_sum(s);
+                if (lane == 0) xs[r - s0] -= s;
+            }
+            __syncthreads(); // fat list / nfat are reused by the next chunk
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < s1 - s0; i += WG) x[s0 + i] = xs[i];
+}
+
+// backward substitution (fused D^-1) of a bundle: ancestors are either in the bundle (LDS)
+// or in the top (already final in x)
+__global__ __launch_bounds__(WG) void k_bundle_bwd(LdlView v, BundleView bv, double *x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem;
+    int *fat = (int *)(smem + (size_t)bv.max_nodes * sizeof(double));
+    __shared__ int nfat;
+    const int b = blockIdx.x;
+    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    for (int i = threadIdx.x; i < s1 - s0; i += WG) xs[i] = x[s0 + i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    for (int l = nl - 1; l >= 0; --l) {
+        const int lb = lv[l], le = lv[l + 1];
+        for (int base = lb; base < le; base += WG) {
+            if (threadIdx.x == 0) nfat = 0;
+            __syncthreads();
+            const int j = base + threadIdx.x;
+            if (j < le) {
+                const int cb = v.Lp[j], ce = v.Lp[j + 1];
+                if (ce - cb <= THIN_MAX) {
+                    double s = 0.0;
+                    for (int q = cb; q < ce; ++q) {
+                        const int r = v.Li[q];
+                        s += v.Lx[q] * (r < s1 ? xs[r - s0] : x[r]);
+                    }
+                    xs[j - s0] = xs[j - s0] * v.Dinv[j] - s;
+                } else {
+                    fat[atomicAdd(&nfat, 1)] = j;
+                }
+            }
+            __syncthreads();
+            const int nf = nfat;
+            for (int f = wv; f < nf; f += 4) {
+                const int c = fat[f];
+                double s = 0.0;
+                for (int q = v.Lp[c] + lane; q < v.Lp[c + 1]; q += 64) {
+                    const int r = v.Li[q];
+                    s += v.Lx[q] * (r < s1 ? xs[r - s0] : x[r]);
+                }
+                s = wave_sum(s);
+                if (lane == 0) xs[c - s0] = xs[c - s0] * v.Dinv[c] - s;
+            }
+            __syncthreads(); // fat list / nfat are reused by the next chunk
+        }
+    }
+    for (int i = threadIdx.x; i < s1 - s0; i += WG) x[s0 + i] = xs[i];
 }
 
 // B: a column with a huge row count (> 16384 contributions).  Each workgroup
@@ -711,6 +859,16 @@ void factor_T(hipStream_t s, const LdlView &v, ListView c) {
 }
 void factor_W(hipStream_t s, const LdlView &v, ListView c) {
     if (c.count) k_factor_W<<<c.count, WG, 0, s>>>(v, c.idx, c.count);
+}
+static size_t bundle_lds(const BundleView &bv) { return (size_t)bv.max_nodes * sizeof(double) + WG * sizeof(int); }
+void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv) {
+    if (bv.nb) k_bundle_factor<<<bv.nb, WG, 0, s>>>(v, bv);
+}
+void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x) {
+    if (bv.nb) k_bundle_fwd<<<bv.nb, WG, bundle_lds(bv), s>>>(v, bv, x);
+}
+void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x) {
+    if (bv.nb) k_bundle_bwd<<<bv.nb, WG, bundle_lds(bv), s>>>(v, bv, x);
 }
 void factor_B(hipStream_t s, const LdlView &v, ChunkView c) {
     if (c.count) k_factor_B<<<c.count, WG, 0, s>>>(v, c.row, c.beg, c.end, c.count);

@@ -21,6 +21,14 @@ struct LdlView {
     double reg_eps, reg_delta;
 };
 
+// subtree bundles: bundle b = nodes [bundle_ptr[b], bundle_ptr[b+1]); its level boundaries are
+// blvl[blvl_ptr[b] .. blvl_ptr[b+1])
+struct BundleView {
+    int nb;
+    const int *bundle_ptr, *blvl_ptr, *blvl;
+    int max_nodes;
+};
+
 struct ListView {
     const int *idx; // T or W rows
     int count;
@@ -42,6 +50,9 @@ void diag_absmax_eps(hipStream_t s, const double *Kx, const int *diag_idx, int N
 void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale);
 
 // ---- numeric LDL' -------------------------------------------------------------
+void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv);
+void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x);
+void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x);
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);
 void factor_B(hipStream_t s, const LdlView &v, ChunkView chunks);

@@ -15,6 +15,7 @@
 //     rows (CSR) so that forward substitution, backward substitution and the
 //     left-looking numeric factorisation are all pure gathers.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -34,6 +35,10 @@ constexpr i32 B_MIN = 16384;   // >  B_MIN entries: split over workgroups
 constexpr i32 B_CHUNK = 4096;  // entries per B chunk
 constexpr i32 FAC_T_ROW = 8;   // factor: thread-per-column if contributions <= this
 constexpr i32 FAC_T_COL = 48;  // ... and column length <= this
+// subtree bundles (one workgroup each; the vector slice of a bundle is staged in LDS)
+constexpr i64 BUNDLE_MAX_NODES = 6144;     // 48 KiB of fp64 in LDS
+constexpr i64 BUNDLE_MAX_ENTRIES = 131072; // nnz(L rows + cols) one workgroup should stream
+constexpr i64 BUNDLE_TARGET_COUNT = 2048;  // aim for >= 8 workgroups per CU
 
 // upper-triangular pattern of P K P' (row = min, col = max), columns unsorted,
 // plus (optionally) for each source entry its destination slot.
@@ -62,21 +67,25 @@ void permuted_triu(i64 n, const i64 *Ap, const i64 *Ai, const std::vector<i32> &
 
 // elimination tree (parent, -1 = root) and strictly-lower column counts of L.
 void etree_counts(i64 n, const std::vector<i64> &Cp, const std::vector<i32> &Ci,
-                  std::vector<i32> &parent, std::vector<i32> &cnt) {
+                  std::vector<i32> &parent, std::vector<i32> &cnt, std::vector<i32> *rowcnt = nullptr) {
     parent.assign((size_t)n, -1);
     cnt.assign((size_t)n, 0);
+    if (rowcnt) rowcnt->assign((size_t)n, 0);
     std::vector<i32> stamp((size_t)n, -1);
     for (i32 j = 0; j < n; j++) {
         stamp[j] = j;
+        i32 rc = 0;
         for (i64 p = Cp[j]; p < Cp[j + 1]; p++) {
             i32 i = Ci[p];
             while (stamp[i] != j) {
                 if (parent[i] < 0) parent[i] = j;
                 cnt[i]++;
+                rc++;
                 stamp[i] = j;
                 i = parent[i];
             }
         }
+        if (rowcnt) (*rowcnt)[j] = rc;
     }
 }
 
@@ -158,29 +167,128 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // ---- pass A: tree + levels under the given order ------------------------
     std::vector<i64> Cp;
     std::vector<i32> Ci, parent, cnt;
+    std::vector<i32> rowcnt;
     permuted_triu(n, Ap, Ai, ip0, Cp, Ci);
-    etree_counts(n, Cp, Ci, parent, cnt);
+    etree_counts(n, Cp, Ci, parent, cnt, &rowcnt);
     std::vector<i32> level((size_t)n, 0);
-    i32 nlevels = n > 0 ? 1 : 0;
+    i32 depth = n > 0 ? 1 : 0;
     for (i32 j = 0; j < n; j++) {
         const i32 pj = parent[j];
         if (pj >= 0 && level[pj] < level[j] + 1) level[pj] = level[j] + 1;
-        if (level[j] + 1 > nlevels) nlevels = level[j] + 1;
+        if (level[j] + 1 > depth) depth = level[j] + 1;
     }
-    // level-major stable re-sort
-    std::vector<i32> lvlptr((size_t)nlevels + 1, 0);
-    for (i32 j = 0; j < n; j++) lvlptr[level[j] + 1]++;
-    for (i32 l = 0; l < nlevels; l++) lvlptr[l + 1] += lvlptr[l];
+    // ---- cut the forest: a node whose whole subtree is small goes (with that subtree)
+    //      into a "bundle" that ONE workgroup factors / solves start to finish; the
+    //      remaining ancestors form the "top", processed level by level by the whole GPU.
+    std::vector<i64> sub_nodes((size_t)n, 1), sub_ent((size_t)n, 0);
+    for (i32 j = 0; j < n; j++) sub_ent[j] = (i64)cnt[j] + rowcnt[j];
+    for (i32 j = 0; j < n; j++)
+        if (parent[j] >= 0) {
+            sub_nodes[parent[j]] += sub_nodes[j];
+            sub_ent[parent[j]] += sub_ent[j];
+        }
+    const bool no_bundles = std::getenv("CHIP_NO_BUNDLES") != nullptr;
+    std::vector<char> top((size_t)n, 0);
+    i64 NF = 0, maxsub = 0;
+    for (i32 j = 0; j < n; j++) {
+        top[j] = no_bundles || sub_nodes[j] > BUNDLE_MAX_NODES || sub_ent[j] > BUNDLE_MAX_ENTRIES;
+        if (!top[j]) NF++;
+    }
+    // subtree id of every forest node (roots = forest nodes whose parent is top or absent)
+    std::vector<i32> sub((size_t)n, -1);
+    i32 nsub = 0;
+    for (i32 j = (i32)n - 1; j >= 0; j--) {
+        if (top[j]) continue;
+        if (parent[j] < 0 || top[parent[j]]) {
+            sub[j] = nsub++;
+            maxsub = std::max(maxsub, sub_nodes[j]);
+        } else {
+            sub[j] = sub[parent[j]];
+        }
+    }
+    // subtrees in order of their first node (keeps the ordering's locality), packed greedily
+    std::vector<i32> first((size_t)nsub, -1), sub_size((size_t)nsub, 0);
+    for (i32 j = 0; j < n; j++)
+        if (sub[j] >= 0) {
+            if (first[sub[j]] < 0) first[sub[j]] = j;
+            sub_size[sub[j]]++;
+        }
+    std::vector<i32> sorder((size_t)nsub);
+    std::iota(sorder.begin(), sorder.end(), 0);
+    std::sort(sorder.begin(), sorder.end(), [&](i32 a, i32 b) { return first[a] < first[b]; });
+    i64 cap = (NF + BUNDLE_TARGET_COUNT - 1) / BUNDLE_TARGET_COUNT;
+    cap = std::max<i64>(cap, maxsub);
+    cap = std::max<i64>(cap, 256);
+    cap = std::min<i64>(cap, BUNDLE_MAX_NODES);
+    std::vector<i32> bundle_of_sub((size_t)nsub, 0);
+    i32 nb = 0;
+    {
+        i64 cur = 0;
+        for (i32 s : sorder) {
+            if (cur > 0 && cur + sub_size[s] > cap) {
+                nb++;
+                cur = 0;
+            }
+            bundle_of_sub[s] = nb;
+            cur += sub_size[s];
+        }
+        if (nsub > 0) nb++;
+    }
+    // final order: bundles first (level-major inside each), then the top level-major.
+    // Two stable counting sorts: by level, then by group (bundle id, or nb for top nodes).
+    std::vector<i32> bylevel((size_t)n);
+    {
+        std::vector<i32> cntl((size_t)depth + 1, 0);
+        for (i32 j = 0; j < n; j++) cntl[level[j] + 1]++;
+        for (i32 l = 0; l < depth; l++) cntl[l + 1] += cntl[l];
+        for (i32 j = 0; j < n; j++) bylevel[cntl[level[j]]++] = j;
+    }
+    std::vector<i32> order((size_t)n);
+    std::vector<i32> gptr((size_t)nb + 2, 0);
+    {
+        auto group = [&](i32 j) { return top[j] ? nb : bundle_of_sub[sub[j]]; };
+        for (i32 j = 0; j < n; j++) gptr[group(j) + 1]++;
+        for (i32 g = 0; g <= nb; g++) gptr[g + 1] += gptr[g];
+        std::vector<i32> pos(gptr.begin(), gptr.end() - 1);
+        for (i32 t = 0; t < n; t++) {
+            const i32 j = bylevel[t];
+            order[pos[group(j)]++] = j;
+        }
+    }
     S.perm.resize((size_t)n);
     S.iperm.resize((size_t)n);
-    {
-        std::vector<i32> pos(lvlptr.begin(), lvlptr.end() - 1);
-        for (i32 j = 0; j < n; j++) {
-            const i32 nj = pos[level[j]]++;
-            S.perm[nj] = (i32)p0[j];
-        }
-        for (i32 j = 0; j < n; j++) S.iperm[S.perm[j]] = j;
+    S.level.resize((size_t)n);
+    for (i32 t = 0; t < n; t++) {
+        S.perm[t] = (i32)p0[order[t]];
+        S.level[t] = level[order[t]];
     }
+    for (i32 j = 0; j < n; j++) S.iperm[S.perm[j]] = j;
+    S.tree_depth = depth;
+    S.NF = (i32)NF;
+    S.bundle_ptr.assign(gptr.begin(), gptr.begin() + nb + 1);
+    S.max_bundle_nodes = 0;
+    S.blvl_ptr.assign((size_t)nb + 1, 0);
+    for (i32 b = 0; b < nb; b++) {
+        const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
+        S.max_bundle_nodes = std::max(S.max_bundle_nodes, s1 - s0);
+        // boundaries of the (ascending) levels present in this bundle; level 0 always first
+        i32 lv = 0;
+        S.blvl.push_back(s0);
+        for (i32 t = s0; t < s1; t++)
+            while (S.level[t] > lv) {
+                S.blvl.push_back(t);
+                lv++;
+            }
+        S.blvl.push_back(s1);
+        S.blvl_ptr[b + 1] = (i32)S.blvl.size();
+    }
+    // top levels (compressed: only the levels that occur among top nodes)
+    std::vector<i32> lvlptr;
+    lvlptr.push_back((i32)NF);
+    for (i32 t = (i32)NF + 1; t < n; t++)
+        if (S.level[t] != S.level[t - 1]) lvlptr.push_back(t);
+    if (NF < n) lvlptr.push_back((i32)n);
+    const i32 nlevels = (i32)lvlptr.size() - 1;
     S.nlevels = nlevels;
     S.lvlptr = lvlptr;
     S.dsigns.resize((size_t)n);

@@ -98,7 +98,7 @@ typedef struct {
     int64_t positive_inertia;  /* valid after refactor */
     int64_t regularize_count;  /* dynamic regularisation hits of the last refactor */
     int64_t n;                 /* KKT dimension N */
-    int64_t n_levels;          /* elimination-tree levels (= dependent kernel phases) */
+    int64_t n_levels;          /* depth of the elimination tree (number of dependent phases) */
     double amd_lnz, amd_ndiv, amd_nmultsubs_ldl; /* amd::Info, used by ldlsolvers/auto.rs:69-77 */
     int32_t last_ir_iterations;/* refinement rounds of the last chip_kkt_solve */
     double last_regularizer;   /* static eps of the last update (directldlkktsolver.rs:249) */
@@ -158,10 +158,10 @@ int32_t chip_ldl_info(const chip_ldl *h, chip_info *info);
 int32_t chip_ldl_get_perm(const chip_ldl *h, uint64_t *perm);
 /* symbolic results in the engine's final numbering (host copies; any pointer may
  * be NULL): etree[N] (UINT64_MAX = root, cf. qdldl.rs:426), Lp[N+1], Li[nnzL]
- * (ascending rows per column), lvlptr[n_levels+1] (level l = columns
- * [lvlptr[l], lvlptr[l+1])).  Also valid on CHIP_DEVICE_HOST_ONLY handles. */
+ * (ascending rows per column), level[N] (elimination-tree level of each node,
+ * leaves = 0).  Also valid on CHIP_DEVICE_HOST_ONLY handles. */
 int32_t chip_ldl_get_symbolic(const chip_ldl *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,
-                              uint64_t *lvlptr);
+                              uint64_t *level);
 /* test/diagnostic access to the factors (host copies): L as CSC with sorted
  * rows in the engine's numbering, D, Dinv.  Any pointer may be NULL. */
 int32_t chip_ldl_get_factors(chip_ldl *h, uint64_t *Lp, uint64_t *Li, double *Lx, double *D,
@@ -214,7 +214,7 @@ int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev);
 int32_t chip_kkt_info(const chip_kkt *h, chip_info *info);
 int32_t chip_kkt_get_perm(const chip_kkt *h, uint64_t *perm);
 int32_t chip_kkt_get_symbolic(const chip_kkt *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,
-                              uint64_t *lvlptr);
+                              uint64_t *level);
 /* current device copy of K.nzval (unregularised), for tests */
 int32_t chip_kkt_get_values(chip_kkt *h, double *nzval);
 /* full-N right-hand side / solution (incl. the p sparse-cone rows), tests only */

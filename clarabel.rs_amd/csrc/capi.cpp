@@ -541,7 +541,7 @@ int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *r
     // one pass writes the permuted rhs twice: bp (kept for the residuals) and x (solved in
     // place), and folds ||b||inf into norm set 0 -- no separate copy / norm launches
     dev::setrhs_perm(E.stream, h->bp, h->x, rhsx_dev, rhsz_dev, E.perm, (int)h->K.n, (int)h->K.m, E.N,
-                     E.norm_set(0), &E.mb_dev->nan[0]);
+                     E.norm_set(0), E.norm_nan(0));
     h->x_holds_b = true;
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
@@ -576,50 +576,64 @@ static int solve_core(chip_kkt *h) {
     if (!h->x_holds_b) { // solve() again on the same right-hand side, or a full-N rhs in bp
         if ((rc = E.zero_norm_sets())) return rc;
         CHIP_HIP(hipMemcpyAsync(h->x, h->bp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
-        dev::norm_inf(E.stream, h->bp, N, E.norm_set(0), &E.mb_dev->nan[0]);
+        dev::norm_inf(E.stream, h->bp, N, E.norm_set(0), E.norm_nan(0));
     }
     h->x_holds_b = false;
     E.enqueue_solve_inplace(h->x);
     if (!st.iterative_refinement_enable) {
-        dev::norm_inf(E.stream, h->x, N, E.norm_set(1), &E.mb_dev->nan[1]);
+        dev::norm_inf(E.stream, h->x, N, E.norm_set(1), E.norm_nan(1));
         double nx;
         if ((rc = E.read_norm(1, &nx))) return rc;
         return std::isfinite(nx) ? 1 : 0; // x.is_finite(), directldlkktsolver.rs:180
     }
     double *x = h->x, *e = h->e, *w = h->dx;
-    int set = 1;
-    E.enqueue_residual(e, h->bp, x, set);
-    double nb_ne[2]; // sets 0 (||b||inf) and 1 (||e||inf) travel in one D2H copy
-    if ((rc = E.read_norms(0, 2, nb_ne))) return rc;
-    const double normb = nb_ne[0];
-    double norme = nb_ne[1];
+    const double abstol = st.iterative_refinement_abstol, reltol = st.iterative_refinement_reltol;
+    const double stopratio = st.iterative_refinement_stop_ratio;
+    const int maxiter = st.iterative_refinement_max_iter;
+    // The first refinement round is enqueued SPECULATIVELY together with the initial residual,
+    // so that one host synchronisation (one D2H copy of norm sets 0..2) serves both decisions of
+    // directldlkktsolver.rs:288-318; if ||e0|| already meets the tolerance the speculative
+    // candidate is simply never looked at.  Decisions are exactly the reference's.
+    E.enqueue_residual(e, h->bp, x, 1);
+    if (maxiter >= 1) {
+        // w <- e0 is needed if the round is rejected?  No: a rejected round leaves x untouched and e
+        // is dead afterwards, so e is solved in place.
+        E.enqueue_solve_inplace(e);      // e <- K^-1 e0   (the correction dx)
+        dev::add_vec(E.stream, e, x, N); // e <- x + dx    (the candidate)
+        E.enqueue_residual(w, h->bp, e, 2);
+    }
+    double nn[3] = {0, 0, 0};
+    if ((rc = E.read_norms(0, maxiter >= 1 ? 3 : 2, nn))) return rc;
+    const double normb = nn[0];
+    double norme = nn[1];
     if (!std::isfinite(norme)) return 0;
-    for (int it = 0; it < st.iterative_refinement_max_iter; it++) {
-        if (norme <= st.iterative_refinement_abstol + st.iterative_refinement_reltol * normb) break;
+    int set = 2;
+    for (int it = 0; it < maxiter; it++) {
+        if (norme <= abstol + reltol * normb) break;
         const double lastnorme = norme;
-        E.enqueue_solve_inplace(e);      // e <- K^-1 e  (the correction dx)
-        dev::add_vec(E.stream, e, x, N); // e <- x + dx  (the candidate)
-        set += 1;
-        if (set >= NRM_SETS) {
-            set = 1;
+        if (it == 0) {
+            norme = nn[2]; // already computed above
+        } else {
+            E.enqueue_solve_inplace(e);
+            dev::add_vec(E.stream, e, x, N);
+            set += 1;
+            if (set >= NRM_SETS) set = 3;
+            if (it + 2 >= NRM_SETS) // the set is being reused: clear it first
+                CHIP_HIP(hipMemsetAsync(E.norm_set(set), 0, NRM_SET_WORDS * sizeof(unsigned long long), E.stream));
+            E.enqueue_residual(w, h->bp, e, set);
+            if ((rc = E.read_norm(set, &norme))) return rc;
         }
-        if (it + 2 >= NRM_SETS) { // set being reused: clear it first
-            CHIP_HIP(hipMemsetAsync(E.norm_set(set), 0, NRM_SET_WORDS * sizeof(unsigned long long), E.stream));
-            CHIP_HIP(hipMemsetAsync(&E.mb_dev->nan[set], 0, sizeof(int), E.stream));
-        }
-        E.enqueue_residual(w, h->bp, e, set);
-        if ((rc = E.read_norm(set, &norme))) return rc;
         h->last_ir += 1;
         if (!std::isfinite(norme)) return 0;
         const double improved = lastnorme / norme;
-        const bool accept = !(improved < st.iterative_refinement_stop_ratio) || improved > 1.0;
+        const bool accept = !(improved < stopratio) || improved > 1.0;
         if (accept) { // (x, e, w) <- (candidate, its residual, free)
             double *t = x;
             x = e;
             e = w;
             w = t;
         }
-        if (improved < st.iterative_refinement_stop_ratio) break;
+        if (improved < stopratio) break;
     }
     h->x = x;
     h->e = e;

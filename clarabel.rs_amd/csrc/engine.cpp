@@ -163,7 +163,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     std::memset(mb_host, 0, sizeof(Mailbox));
     if ((rc = alloc(&nrm_dev, (size_t)NRM_SETS * NRM_SET_WORDS))) return rc;
     CHIP_HIP(hipMemset(nrm_dev, 0, (size_t)NRM_SETS * NRM_SET_WORDS * sizeof(unsigned long long)));
-    CHIP_HIP(hipHostMalloc((void **)&nrm_host, 2 * NRM_SET_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    CHIP_HIP(hipHostMalloc((void **)&nrm_host, 3 * NRM_SET_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     return CHIP_OK;
 }
 
@@ -271,24 +271,17 @@ void Engine::enqueue_solve_inplace(double *xp) {
     dev::bundle_fwd(stream, v, bundles, xp);
     dev::GatherArgs f{Rp, Rcol, Rx, xp, xp, nullptr, nullptr, nullptr};
     for (int l = 0; l < nlevels; l++) {
-        const dev::ChunkView b = fwd.B(l);
-        if (b.count) dev::gather_B(stream, dev::FWD, f, b);
         prof_begin(PF_FWD_T);
-        dev::gather_T(stream, dev::FWD, f, fwd.T(l));
+        dev::gather_merged(stream, dev::FWD, f, fwd.T(l), fwd.W(l), fwd.B(l));
         prof_end(PF_FWD_T);
-        dev::gather_W(stream, dev::FWD, f, fwd.W(l));
     }
     dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
     for (int l = nlevels - 1; l >= 0; l--) {
         const dev::ChunkView b = bwd.B(l);
-        if (b.count) {
-            dev::gather_Bprep(stream, dev::BWD, g, bwd.BR(l));
-            dev::gather_B(stream, dev::BWD, g, b);
-        }
+        if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwd.BR(l));
         prof_begin(PF_BWD_T);
-        dev::gather_T(stream, dev::BWD, g, bwd.T(l));
+        dev::gather_merged(stream, dev::BWD, g, bwd.T(l), bwd.W(l), b);
         prof_end(PF_BWD_T);
-        dev::gather_W(stream, dev::BWD, g, bwd.W(l));
     }
     dev::bundle_bwd(stream, v, bundles, xp);
 }
@@ -298,38 +291,33 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
     dev::GatherArgs a{Sp, Scol, Sx, x, e, b, nullptr, nullptr};
     if (set >= 0) {
         a.nrm = norm_set(set);
-        a.nan = &mb_dev->nan[set];
+        a.nan = norm_nan(set);
     }
     const dev::ChunkView bc = smv.B(0);
-    if (bc.count) {
-        dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));
-        dev::gather_B(stream, dev::SYMV, a, bc);
-        if (set >= 0) dev::norm_rows(stream, e, smv.BR(0), a.nrm, a.nan);
-    }
+    if (bc.count) dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));
     prof_begin(PF_SYMV_T);
-    dev::gather_T(stream, dev::SYMV, a, smv.T(0));
+    dev::gather_merged(stream, dev::SYMV, a, smv.T(0), smv.W(0), bc);
     prof_end(PF_SYMV_T);
-    dev::gather_W(stream, dev::SYMV, a, smv.W(0));
+    if (bc.count && set >= 0) dev::norm_rows(stream, e, smv.BR(0), a.nrm, a.nan);
 }
 
 int Engine::zero_norm_sets() {
     CHIP_HIP(hipMemsetAsync(nrm_dev, 0, (size_t)NRM_SETS * NRM_SET_WORDS * sizeof(unsigned long long), stream));
-    CHIP_HIP(hipMemsetAsync(mb_dev->nan, 0, sizeof(int) * NRM_SETS, stream));
     return CHIP_OK;
 }
 
 int Engine::read_norms(int first, int count, double *out) {
     CHIP_HIP(hipMemcpyAsync(nrm_host, norm_set(first), (size_t)count * NRM_SET_WORDS * sizeof(unsigned long long),
                             hipMemcpyDeviceToHost, stream));
-    int rc = read_mailbox();
-    if (rc) return rc;
+    CHIP_HIP(hipStreamSynchronize(stream));
     for (int k = 0; k < count; k++) {
         unsigned long long m = 0;
         const unsigned long long *base = nrm_host + (size_t)k * NRM_SET_WORDS;
         for (int i = 0; i < dev::NRM_SLOTS; i++) m = std::max(m, base[(size_t)i * dev::NRM_STRIDE]);
         double d;
         std::memcpy(&d, &m, sizeof(d));
-        out[k] = mb_host->nan[first + k] ? std::nan("") : d; // vecmath.rs:132-142 NaN propagation
+        const int nanflag = *(const int *)(base + (size_t)dev::NRM_SLOTS * dev::NRM_STRIDE);
+        out[k] = nanflag ? std::nan("") : d; // vecmath.rs:132-142 NaN propagation
     }
     return CHIP_OK;
 }

@@ -35,7 +35,8 @@ struct Mailbox {
     int pad[9];
 };
 constexpr int NRM_SETS = 16;
-constexpr int NRM_SET_WORDS = dev::NRM_SLOTS * dev::NRM_STRIDE; // u64 words per set
+// u64 words per set: NRM_SLOTS slotted maxima (one per 128-byte line) + one line for the NaN flag
+constexpr int NRM_SET_WORDS = (dev::NRM_SLOTS + 1) * dev::NRM_STRIDE;
 static_assert(sizeof(Mailbox) <= 256, "mailbox");
 
 // profile families (hipEvent pairs around each launch of ONE selected family)
@@ -93,8 +94,9 @@ struct Engine {
     void enqueue_residual(double *e, const double *b, const double *x, int set);
     int zero_norm_sets();                                                    // enqueue
     unsigned long long *norm_set(int set) const { return nrm_dev + (size_t)set * NRM_SET_WORDS; }
+    int *norm_nan(int set) const { return (int *)(norm_set(set) + dev::NRM_SLOTS * dev::NRM_STRIDE); }
     int read_norm(int set, double *out);                                     // D2H + sync; NaN propagating
-    int read_norms(int first, int count, double *out);                       // `count` <= 2 contiguous sets
+    int read_norms(int first, int count, double *out);                       // `count` <= 3 contiguous sets, ONE D2H copy
     int read_mailbox();                                                      // D2H + sync
     void prof_begin(int family);
     void prof_end(int family);

@@ -53,14 +53,16 @@ __device__ __forceinline__ double wave_max(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
     return v;
 }
-// sum over a 256-thread workgroup, result broadcast to every thread
+// sum over a workgroup of up to 16 waves (red[16]), result broadcast to every thread
 __device__ __forceinline__ double block_sum(double v, double *red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wv] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    double t = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
 }
 __device__ __forceinline__ double block_max(double v, double *red) {
     v = wave_max(v);
@@ -68,7 +70,9 @@ __device__ __forceinline__ double block_max(double v, double *red) {
     __syncthreads();
     if (lane == 0) red[wv] = v;
     __syncthreads();
-    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    double t = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, red[i]);
+    return t;
 }
 
 // qdldl.rs:645-665: sign-based dynamic regularisation, then invert.
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(WG) void k_scatter_values(double *Kx, const int *__
 __global__ __launch_bounds__(WG) void k_diag_absmax(const double *__restrict__ Kx,
                                                     const int *__restrict__ didx, int N,
                                                     unsigned long long *scal) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     double m = 0.0;
     bool nan = false;
     for (int t = blockIdx.x * WG + threadIdx.x; t < N; t += gridDim.x * WG) {
@@ -224,7 +228,7 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         const int r0 = cn > 0 ? v.Li[cb] : -1, r1 = cn > 1 ? v.Li[cb + 1] : -1;
         const int r2 = cn > 2 ? v.Li[cb + 2] : -1;
-        for (int t = tid; t < rn; t += WG) {
+        for (int t = tid; t < rn; t += blockDim.x) {
             const int k = v.Rcol[rb + t], p = v.Rpos[rb + t];
             const double ljk = v.Lx[p];
             const double w = ljk * v.D[k];
@@ -257,9 +261,9 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
     }
     const bool lds = cn <= W_LDS_CAP;
     if (lds)
-        for (int q = tid; q < cn; q += WG) acc[q] = v.Lx[cb + q];
+        for (int q = tid; q < cn; q += blockDim.x) acc[q] = v.Lx[cb + q];
     __syncthreads();
-    for (int t = tid; t < rn; t += WG) {
+    for (int t = tid; t < rn; t += blockDim.x) {
         const int k = v.Rcol[rb + t], p = v.Rpos[rb + t];
         const double ljk = v.Lx[p];
         const double w = ljk * v.D[k];
@@ -279,7 +283,7 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
     if (tid == 0) *s_dinv = pivot_rule(v, j, v.D[j] - dpart);
     __syncthreads();
     const double dinv = *s_dinv;
-    for (int q = tid; q < cn; q += WG) {
+    for (int q = tid; q < cn; q += blockDim.x) {
         const double c = lds ? acc[q]
                              : __hip_atomic_load(&v.Lx[cb + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double l = c * dinv;
@@ -291,7 +295,7 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
 // W: one workgroup per column
 __global__ __launch_bounds__(WG) void k_factor_W(LdlView v, const int *__restrict__ cols, int count) {
     __shared__ double acc[W_LDS_CAP];
-    __shared__ double red[4];
+    __shared__ double red[16];
     __shared__ double s_dinv;
     if ((int)blockIdx.x >= count) return;
     factor_col_block(v, cols[blockIdx.x], acc, red, &s_dinv);
@@ -307,132 +311,116 @@ __global__ __launch_bounds__(WG) void k_factor_W(LdlView v, const int *__restric
 // through the level-scheduled kernels.
 // ---------------------------------------------------------------------------
 constexpr int FAC_THIN_ROW = 8, FAC_THIN_COL = 48, THIN_MAX = 32;
+constexpr int BWG = 512;      // bundle workgroup: 8 waves -> more loads in flight per subtree
+constexpr int FATCAP = 1024;  // per-level list of rows/columns that need cooperative handling
 
-__global__ __launch_bounds__(WG) void k_bundle_factor(LdlView v, BundleView bv) {
+// Per level: every thread sweeps the level's thin columns (strided, no barriers in between,
+// so many independent gathers are in flight), parking fat columns in an LDS list that the
+// whole workgroup then works through cooperatively.
+__global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv) {
     __shared__ double acc[W_LDS_CAP];
-    __shared__ double red[4];
+    __shared__ double red[16];
     __shared__ double s_dinv;
-    __shared__ int fat[WG];
+    __shared__ int fat[FATCAP];
     __shared__ int nfat;
     const int b = blockIdx.x;
     const int *lv = bv.blvl + bv.blvl_ptr[b];
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
     for (int l = 0; l < nl; ++l) {
         const int lb = lv[l], le = lv[l + 1];
-        for (int base = lb; base < le; base += WG) {
-            if (threadIdx.x == 0) nfat = 0;
-            __syncthreads();
-            const int j = base + threadIdx.x;
-            if (j < le) {
-                const int rj = v.Rp[j + 1] - v.Rp[j], cj = v.Lp[j + 1] - v.Lp[j];
-                if (rj <= FAC_THIN_ROW && cj <= FAC_THIN_COL) factor_col_thread(v, j);
-                else fat[atomicAdd(&nfat, 1)] = j;
+        if (threadIdx.x == 0) nfat = 0;
+        __syncthreads();
+        for (int j = lb + threadIdx.x; j < le; j += BWG) {
+            const int rj = v.Rp[j + 1] - v.Rp[j], cj = v.Lp[j + 1] - v.Lp[j];
+            bool thin = rj <= FAC_THIN_ROW && cj <= FAC_THIN_COL;
+            if (!thin) {
+                const int slot = atomicAdd(&nfat, 1);
+                if (slot < FATCAP) fat[slot] = j;
+                else thin = true; // list full: fall back to the serial path (correct, slower)
             }
+            if (thin) factor_col_thread(v, j);
+        }
+        __syncthreads();
+        const int nf = min(nfat, FATCAP);
+        for (int f = 0; f < nf; ++f) {
+            factor_col_block(v, fat[f], acc, red, &s_dinv);
             __syncthreads();
-            const int nf = nfat;
+        }
+        // level l is final (global writes visible workgroup-wide) before level l+1
+    }
+}
+
+template <bool FWDMODE>
+__device__ __forceinline__ double bundle_row_dot(const LdlView &v, const double *xs, const double *x,
+                                                 int s0, int s1, int r, int first, int stride) {
+    double s = 0.0;
+    if (FWDMODE) {
+        for (int t = v.Rp[r] + first; t < v.Rp[r + 1]; t += stride) s += v.Rx[t] * xs[v.Rcol[t] - s0];
+    } else {
+        for (int q = v.Lp[r] + first; q < v.Lp[r + 1]; q += stride) {
+            const int i = v.Li[q];
+            s += v.Lx[q] * (i < s1 ? xs[i - s0] : x[i]);
+        }
+    }
+    return s;
+}
+
+// forward (rows of L, descendants only -> all inside the bundle) or backward (columns of L,
+// ancestors inside the bundle come from LDS, ancestors in the top are final in x) sweep of a
+// bundle with its slice of x staged in LDS.
+template <bool FWDMODE>
+__global__ __launch_bounds__(BWG) void k_bundle_solve(LdlView v, BundleView bv, double *x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem;
+    __shared__ double red[16];
+    __shared__ int fat[FATCAP];
+    __shared__ int nfat;
+    const int b = blockIdx.x;
+    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    for (int i = threadIdx.x; i < s1 - s0; i += BWG) xs[i] = x[s0 + i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int *ptr = FWDMODE ? v.Rp : v.Lp;
+    for (int step = FWDMODE ? 1 : 0; step < nl; ++step) {
+        const int l = FWDMODE ? step : nl - 1 - step;
+        const int lb = lv[l], le = lv[l + 1];
+        if (threadIdx.x == 0) nfat = 0;
+        __syncthreads(); // also orders the previous level's writes to xs
+        for (int j = lb + threadIdx.x; j < le; j += BWG) {
+            bool thin = ptr[j + 1] - ptr[j] <= THIN_MAX;
+            if (!thin) {
+                const int slot = atomicAdd(&nfat, 1);
+                if (slot < FATCAP) fat[slot] = j;
+                else thin = true;
+            }
+            if (thin) {
+                const double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, j, 0, 1);
+                xs[j - s0] = FWDMODE ? xs[j - s0] - s : xs[j - s0] * v.Dinv[j] - s;
+            }
+        }
+        __syncthreads();
+        const int nf = min(nfat, FATCAP);
+        if (nf <= 2) {
+            // the separators at the top of a subtree: one long row at a time, all 8 waves on it
             for (int f = 0; f < nf; ++f) {
-                factor_col_block(v, fat[f], acc, red, &s_dinv);
-                __syncthreads();
-            }
-        }
-        __syncthreads(); // level l is final (global writes visible workgroup-wide) before level l+1
-    }
-}
-
-// forward substitution of a bundle: xs = slice of x in LDS; every row gathers only from its
-// own descendants, which live in the same bundle
-__global__ __launch_bounds__(WG) void k_bundle_fwd(LdlView v, BundleView bv, double *x) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *xs = (double *)smem;
-    int *fat = (int *)(smem + (size_t)bv.max_nodes * sizeof(double));
-    __shared__ int nfat;
-    const int b = blockIdx.x;
-    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
-    const int *lv = bv.blvl + bv.blvl_ptr[b];
-    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    for (int i = threadIdx.x; i < s1 - s0; i += WG) xs[i] = x[s0 + i];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int l = 1; l < nl; ++l) {
-        const int lb = lv[l], le = lv[l + 1];
-        for (int base = lb; base < le; base += WG) {
-            if (threadIdx.x == 0) nfat = 0;
-            __syncthreads();
-            const int j = base + threadIdx.x;
-            if (j < le) {
-                const int rb = v.Rp[j], re = v.Rp[j + 1];
-                if (re - rb <= THIN_MAX) {
-                    double s = 0.0;
-                    for (int t = rb; t < re; ++t) s += v.Rx[t] * xs[v.Rcol[t] - s0];
-                    xs[j - s0] -= s;
-                } else {
-                    fat[atomicAdd(&nfat, 1)] = j;
-                }
-            }
-            __syncthreads();
-            const int nf = nfat;
-            for (int f = wv; f < nf; f += 4) {
                 const int r = fat[f];
-                double s = 0.0;
-                for (int t = v.Rp[r] + lane; t < v.Rp[r + 1]; t += 64) s += v.Rx[t] * xs[v.Rcol[t] - s0];
-                s = wave_sum(s);
-                if (lane == 0) xs[r - s0] -= s;
+                double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, threadIdx.x, BWG);
+                s = block_sum(s, red);
+                if (threadIdx.x == 0) xs[r - s0] = FWDMODE ? xs[r - s0] - s : xs[r - s0] * v.Dinv[r] - s;
             }
-            __syncthreads(); // fat list / nfat are reused by the next chunk
+        } else {
+            for (int f = wv; f < nf; f += BWG / 64) {
+                const int r = fat[f];
+                double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, lane, 64);
+                s = wave_sum(s);
+                if (lane == 0) xs[r - s0] = FWDMODE ? xs[r - s0] - s : xs[r - s0] * v.Dinv[r] - s;
+            }
         }
+        __syncthreads(); // every wave has read nfat / fat[] before the next level resets them
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < s1 - s0; i += WG) x[s0 + i] = xs[i];
-}
-
-// backward substitution (fused D^-1) of a bundle: ancestors are either in the bundle (LDS)
-// or in the top (already final in x)
-__global__ __launch_bounds__(WG) void k_bundle_bwd(LdlView v, BundleView bv, double *x) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *xs = (double *)smem;
-    int *fat = (int *)(smem + (size_t)bv.max_nodes * sizeof(double));
-    __shared__ int nfat;
-    const int b = blockIdx.x;
-    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
-    const int *lv = bv.blvl + bv.blvl_ptr[b];
-    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    for (int i = threadIdx.x; i < s1 - s0; i += WG) xs[i] = x[s0 + i];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();
-    for (int l = nl - 1; l >= 0; --l) {
-        const int lb = lv[l], le = lv[l + 1];
-        for (int base = lb; base < le; base += WG) {
-            if (threadIdx.x == 0) nfat = 0;
-            __syncthreads();
-            const int j = base + threadIdx.x;
-            if (j < le) {
-                const int cb = v.Lp[j], ce = v.Lp[j + 1];
-                if (ce - cb <= THIN_MAX) {
-                    double s = 0.0;
-                    for (int q = cb; q < ce; ++q) {
-                        const int r = v.Li[q];
-                        s += v.Lx[q] * (r < s1 ? xs[r - s0] : x[r]);
-                    }
-                    xs[j - s0] = xs[j - s0] * v.Dinv[j] - s;
-                } else {
-                    fat[atomicAdd(&nfat, 1)] = j;
-                }
-            }
-            __syncthreads();
-            const int nf = nfat;
-            for (int f = wv; f < nf; f += 4) {
-                const int c = fat[f];
-                double s = 0.0;
-                for (int q = v.Lp[c] + lane; q < v.Lp[c + 1]; q += 64) {
-                    const int r = v.Li[q];
-                    s += v.Lx[q] * (r < s1 ? xs[r - s0] : x[r]);
-                }
-                s = wave_sum(s);
-                if (lane == 0) xs[c - s0] = xs[c - s0] * v.Dinv[c] - s;
-            }
-            __syncthreads(); // fat list / nfat are reused by the next chunk
-        }
-    }
-    for (int i = threadIdx.x; i < s1 - s0; i += WG) x[s0 + i] = xs[i];
+    for (int i = threadIdx.x; i < s1 - s0; i += BWG) x[s0 + i] = xs[i];
 }
 
 // B: a column with a huge row count (> 16384 contributions).  Each workgroup
@@ -441,7 +429,7 @@ __global__ __launch_bounds__(WG) void k_bundle_bwd(LdlView v, BundleView bv, dou
 __global__ __launch_bounds__(WG) void k_factor_B(LdlView v, const int *__restrict__ crow,
                                                  const int *__restrict__ cbeg,
                                                  const int *__restrict__ cend, int count) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     if ((int)blockIdx.x >= count) return;
     const int j = crow[blockIdx.x];
     const int cb = v.Lp[j], ce = v.Lp[j + 1];
@@ -507,7 +495,7 @@ __device__ __forceinline__ void fold_norm(unsigned long long *nrm, int *nan, dou
 
 template <int MODE>
 __global__ __launch_bounds__(WG) void k_gather_T(GatherArgs a, const int *__restrict__ rows, int count) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int lb = logical_block();
     const int tid = lb * WG + threadIdx.x;
     double v = 0.0;
@@ -555,13 +543,65 @@ template <int MODE>
 __global__ __launch_bounds__(WG) void k_gather_B(GatherArgs a, const int *__restrict__ crow,
                                                  const int *__restrict__ cbeg,
                                                  const int *__restrict__ cend, int count) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     if ((int)blockIdx.x >= count) return;
     double s = 0.0;
     for (int t = cbeg[blockIdx.x] + threadIdx.x; t < cend[blockIdx.x]; t += WG)
         s += a.val[t] * a.xin[a.idx[t]];
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(&a.out[crow[blockIdx.x]], -s);
+}
+
+// T, W and B work of one level in ONE launch: the three classes are independent, so their
+// blocks simply coexist in the grid (long B chunks first, then wave-per-row, then the
+// thread-per-row slab with its XCD-aware mapping).  off8 = first T block, a multiple of 8.
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_gather_merged(GatherArgs a, const int *__restrict__ trows, int tcount,
+                                                      const int *__restrict__ wrows, int wcount,
+                                                      const int *__restrict__ crow,
+                                                      const int *__restrict__ cbeg,
+                                                      const int *__restrict__ cend, int ccount, int off8) {
+    __shared__ double red[16];
+    const int bid = blockIdx.x;
+    if (bid >= off8) {
+        const int lb0 = bid - off8, per = (gridDim.x - off8) >> 3;
+        const int lb = (lb0 & 7) * per + (lb0 >> 3);
+        const int tid = lb * WG + threadIdx.x;
+        double v = 0.0;
+        if (tid < tcount) {
+            const int r = trows[tid];
+            const int b = a.ptr[r], e = a.ptr[r + 1];
+            double s = 0.0;
+            for (int t = b; t < e; ++t) s += a.val[t] * a.xin[a.idx[t]];
+            v = store_row<MODE>(a, r, s);
+        }
+        if (MODE == SYMV && a.nrm) {
+            const bool nan = v != v;
+            const double m = block_max(nan ? 0.0 : fabs(v), red);
+            if (__syncthreads_or(nan)) {
+                if (threadIdx.x == 0) *a.nan = 1;
+            }
+            if (threadIdx.x == 0) fold_norm(a.nrm, a.nan, m, false, lb);
+        }
+    } else if (bid < ccount) {
+        double s = 0.0;
+        for (int t = cbeg[bid] + threadIdx.x; t < cend[bid]; t += WG) s += a.val[t] * a.xin[a.idx[t]];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) atomicAdd(&a.out[crow[bid]], -s);
+    } else {
+        const int wid = (bid - ccount) * 4 + (threadIdx.x >> 6);
+        if (wid >= wcount) return;
+        const int lane = threadIdx.x & 63;
+        const int r = wrows[wid];
+        const int b = a.ptr[r], e = a.ptr[r + 1];
+        double s = 0.0;
+        for (int t = b + lane; t < e; t += 64) s += a.val[t] * a.xin[a.idx[t]];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const double v = store_row<MODE>(a, r, s);
+            if (MODE == SYMV && a.nrm) fold_norm(a.nrm, a.nan, v != v ? 0.0 : fabs(v), v != v, wid);
+        }
+    }
 }
 
 __global__ __launch_bounds__(WG) void k_norm_rows(const double *__restrict__ vv, const int *__restrict__ rows,
@@ -589,7 +629,7 @@ __global__ __launch_bounds__(WG) void k_setrhs_perm(double *__restrict__ bp, dou
                                                     const double *__restrict__ rz,
                                                     const int *__restrict__ perm, int n, int m, int N,
                                                     unsigned long long *nrm, int *nanflag) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     double mx = 0.0;
     bool nan = false;
     for (int j = logical_block() * WG + threadIdx.x; j < N; j += gridDim.x * WG) {
@@ -619,7 +659,7 @@ __global__ __launch_bounds__(WG) void k_add_vec(double *__restrict__ dx, const d
 }
 __global__ __launch_bounds__(WG) void k_norm_inf(const double *__restrict__ vv, int N,
                                                  unsigned long long *out, int *nanflag) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     double m = 0.0;
     bool nan = false;
     for (int i = logical_block() * WG + threadIdx.x; i < N; i += gridDim.x * WG) {
@@ -678,7 +718,7 @@ __device__ __forceinline__ double block_norm_tail(const double *x, int n, double
 // socone.rs:134-211, one workgroup per cone
 __global__ __launch_bounds__(WG) void k_soc_update_scaling(SocView v, const double *__restrict__ sv,
                                                            const double *__restrict__ zv) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int c = blockIdx.x;
     if (c >= v.ncones) return;
     const int n = v.dim[c];
@@ -801,7 +841,7 @@ __global__ __launch_bounds__(WG) void k_nn_mul_hs(const int *__restrict__ rows, 
 }
 // socone.rs:248-256
 __global__ __launch_bounds__(WG) void k_soc_mul_hs(SocView v, double *y, const double *__restrict__ x) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int c = blockIdx.x;
     if (c >= v.ncones) return;
     const int n = v.dim[c];
@@ -860,15 +900,15 @@ void factor_T(hipStream_t s, const LdlView &v, ListView c) {
 void factor_W(hipStream_t s, const LdlView &v, ListView c) {
     if (c.count) k_factor_W<<<c.count, WG, 0, s>>>(v, c.idx, c.count);
 }
-static size_t bundle_lds(const BundleView &bv) { return (size_t)bv.max_nodes * sizeof(double) + WG * sizeof(int); }
+static size_t bundle_lds(const BundleView &bv) { return ((size_t)bv.max_nodes * sizeof(double) + 15) & ~(size_t)15; }
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv) {
-    if (bv.nb) k_bundle_factor<<<bv.nb, WG, 0, s>>>(v, bv);
+    if (bv.nb) k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv);
 }
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x) {
-    if (bv.nb) k_bundle_fwd<<<bv.nb, WG, bundle_lds(bv), s>>>(v, bv, x);
+    if (bv.nb) k_bundle_solve<true><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x);
 }
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x) {
-    if (bv.nb) k_bundle_bwd<<<bv.nb, WG, bundle_lds(bv), s>>>(v, bv, x);
+    if (bv.nb) k_bundle_solve<false><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x);
 }
 void factor_B(hipStream_t s, const LdlView &v, ChunkView c) {
     if (c.count) k_factor_B<<<c.count, WG, 0, s>>>(v, c.row, c.beg, c.end, c.count);
@@ -884,6 +924,14 @@ void factor_finalize(hipStream_t s, const LdlView &v, ListView c) {
     default: KERNEL<SYMV><<<GRID, WG, 0, s>>>(__VA_ARGS__); break;         \
     }
 
+void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t, ListView w, ChunkView c) {
+    if (!t.count && !w.count && !c.count) return;
+    const int nbW = (w.count + 3) / 4;
+    const int off8 = (c.count + nbW + 7) & ~7;
+    const int nbT = t.count ? grid_for(t.count) : 0;
+    const int grid = off8 + nbT;
+    DISPATCH_MODE(k_gather_merged, grid, a, t.idx, t.count, w.idx, w.count, c.row, c.beg, c.end, c.count, off8)
+}
 void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
     if (!r.count) return;
     DISPATCH_MODE(k_gather_T, grid_for(r.count), a, r.idx, r.count)

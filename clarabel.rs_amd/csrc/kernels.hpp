@@ -77,6 +77,8 @@ constexpr int NRM_STRIDE = 16; // in u64 words: one slot per 128-byte line
 void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 void gather_W(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
+// T + W + B lists of one level in a single launch (B rows still need gather_Bprep first)
+void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t, ListView w, ChunkView c);
 void gather_B(hipStream_t s, GatherMode m, const GatherArgs &a, ChunkView chunks);
 // ||v[rows]||inf of a short row list into the slots (the B rows of a SYMV)
 void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long *nrm, int *nan);

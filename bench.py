@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--blocksize", type=int, default=1000)
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1 auto, 0 off)")
     ap.add_argument("--profile-family", type=int, default=1,
-                    help="kernel family timed with hipEvents for the roofline (1 = symv k_gather_T<SYMV>)")
+                    help="kernel family timed with hipEvents for the roofline (1 = symv k_gather_merged<2>)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,14 +132,27 @@ def main():
         value = world * args.steps / elapsed
         Bm = algorithmic_bytes(ks.N, ks.nnzK, info.nnzL, ks.nHs, m)
         fam_bytes = {1: Bm["symv"]}.get(args.profile_family)
-        fam_name = {1: "k_gather_T<SYMV> (residual e = b - Kx)", 2: "k_gather_T<BWD>", 3: "k_gather_T<FWD>",
+        fam_name = {1: "k_gather_merged<2> (SYMV: residual e = b - Kx with ||e||inf folded in)",
+                    2: "k_gather_merged<1> (BWD top levels)", 3: "k_gather_merged<0> (FWD top levels)",
                     4: "k_factor_T"}.get(args.profile_family, "?")
+        # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> tools/pmc_summarize.py ->
+        # profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, see that script).  PMC counters
+        # cannot be collected from inside the timed run, so the committed summary of the same
+        # command is quoted; null when the workload differs from the profiled one.
+        traffic = None
+        try:
+            import glob
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            if pj and args.nblocks == 1000 and args.blocksize == 1000 and args.profile_family == 1:
+                traffic = json.load(open(pj[-1]))["kernels"]["k_gather_merged<2>"]["hbm_bytes"]
+        except Exception:
+            traffic = None
         roof = None
         if prof["launches"] > 0 and fam_bytes:
             avg_ms = prof["ms"] / prof["launches"]
             ach = fam_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": fam_name,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": fam_name,
                     "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
                     "algorithmic_bytes_per_launch": fam_bytes,
                     "whole_step": {"algorithmic_bytes": Bm["iter"],

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restric
     factor_col_thread(v, cols[tid]);
 }
 
-constexpr int W_LDS_CAP = 4096; // column values kept in LDS (32 KiB of 160 KiB)
+constexpr int W_LDS_CAP = 2048; // column values + row ids kept in LDS (16 + 8 KiB of 160 KiB)
 
 __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int hi, int row) {
     // first q in [lo,hi) with Li[q] >= row (the row is known to be present)
@@ -218,8 +218,8 @@ __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int 
 // budget-like separators of block-arrow KKTs) take per-thread register
 // partials + one block reduction instead of hammering 4 LDS addresses.
 // Must be called by all threads of the workgroup; ends un-synchronised.
-__device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double *acc, double *red,
-                                                 double *s_dinv) {
+__device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double *acc, int *rows,
+                                                 double *red, double *s_dinv) {
     const int cb = v.Lp[j], cn = v.Lp[j + 1] - cb;
     const int rb = v.Rp[j], rn = v.Rp[j + 1] - rb;
     const int tid = threadIdx.x;
@@ -261,21 +261,48 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
     }
     const bool lds = cn <= W_LDS_CAP;
     if (lds)
-        for (int q = tid; q < cn; q += blockDim.x) acc[q] = v.Lx[cb + q];
+        for (int q = tid; q < cn; q += blockDim.x) {
+            acc[q] = v.Lx[cb + q];
+            rows[q] = v.Li[cb + q];
+        }
     __syncthreads();
-    for (int t = tid; t < rn; t += blockDim.x) {
-        const int k = v.Rcol[rb + t], p = v.Rpos[rb + t];
-        const double ljk = v.Lx[p];
-        const double w = ljk * v.D[k];
-        dpart += ljk * w;
-        const int pe = v.Lp[k + 1];
-        int q = cb;
-        for (int pp = p + 1; pp < pe; ++pp) {
-            q = find_row(v.Li, q, cb + cn, v.Li[pp]);
-            const double u = -(v.Lx[pp] * w);
-            if (lds) atomicAdd(&acc[q - cb], u);
-            else atomicAdd(&v.Lx[q], u);
-            ++q;
+    if (lds && cn >= 24) {
+        // general-fill columns: contributing columns have long tails.  One WAVE per contribution:
+        // its lanes stream the tail of column k coalesced, locate each row in column j's row list
+        // by a binary search that runs entirely in LDS, and add into the LDS accumulator.
+        const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+        for (int t = wv; t < rn; t += nw) {
+            const int k = v.Rcol[rb + t], p = v.Rpos[rb + t];
+            const double ljk = v.Lx[p];
+            const double w = ljk * v.D[k];
+            if (lane == 0) dpart += ljk * w;
+            const int pe = v.Lp[k + 1];
+            for (int pp = p + 1 + lane; pp < pe; pp += 64) {
+                const int i = v.Li[pp];
+                int lo = 0, hi = cn;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rows[mid] < i) lo = mid + 1;
+                    else hi = mid;
+                }
+                atomicAdd(&acc[lo], -(v.Lx[pp] * w));
+            }
+        }
+    } else {
+        for (int t = tid; t < rn; t += blockDim.x) {
+            const int k = v.Rcol[rb + t], p = v.Rpos[rb + t];
+            const double ljk = v.Lx[p];
+            const double w = ljk * v.D[k];
+            dpart += ljk * w;
+            const int pe = v.Lp[k + 1];
+            int q = cb;
+            for (int pp = p + 1; pp < pe; ++pp) {
+                q = find_row(v.Li, q, cb + cn, v.Li[pp]);
+                const double u = -(v.Lx[pp] * w);
+                if (lds) atomicAdd(&acc[q - cb], u);
+                else atomicAdd(&v.Lx[q], u);
+                ++q;
+            }
         }
     }
     if (!lds) __threadfence();
@@ -293,12 +320,13 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
 }
 
 // W: one workgroup per column
-__global__ __launch_bounds__(WG) void k_factor_W(LdlView v, const int *__restrict__ cols, int count) {
+__global__ __launch_bounds__(1024) void k_factor_W(LdlView v, const int *__restrict__ cols, int count) {
     __shared__ double acc[W_LDS_CAP];
+    __shared__ int rows[W_LDS_CAP];
     __shared__ double red[16];
     __shared__ double s_dinv;
     if ((int)blockIdx.x >= count) return;
-    factor_col_block(v, cols[blockIdx.x], acc, red, &s_dinv);
+    factor_col_block(v, cols[blockIdx.x], acc, rows, red, &s_dinv);
 }
 
 // ---------------------------------------------------------------------------
@@ -319,6 +347,7 @@ constexpr int FATCAP = 1024;  // per-level list of rows/columns that need cooper
 // whole workgroup then works through cooperatively.
 __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv) {
     __shared__ double acc[W_LDS_CAP];
+    __shared__ int rows[W_LDS_CAP];
     __shared__ double red[16];
     __shared__ double s_dinv;
     __shared__ int fat[FATCAP];
@@ -343,7 +372,7 @@ __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv)
         __syncthreads();
         const int nf = min(nfat, FATCAP);
         for (int f = 0; f < nf; ++f) {
-            factor_col_block(v, fat[f], acc, red, &s_dinv);
+            factor_col_block(v, fat[f], acc, rows, red, &s_dinv);
             __syncthreads();
         }
         // level l is final (global writes visible workgroup-wide) before level l+1
@@ -898,7 +927,7 @@ void factor_T(hipStream_t s, const LdlView &v, ListView c) {
     if (c.count) k_factor_T<<<grid_for(c.count), WG, 0, s>>>(v, c.idx, c.count);
 }
 void factor_W(hipStream_t s, const LdlView &v, ListView c) {
-    if (c.count) k_factor_W<<<c.count, WG, 0, s>>>(v, c.idx, c.count);
+    if (c.count) k_factor_W<<<c.count, 1024, 0, s>>>(v, c.idx, c.count);
 }
 static size_t bundle_lds(const BundleView &bv) { return ((size_t)bv.max_nodes * sizeof(double) + 15) & ~(size_t)15; }
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv) {

@@ -124,11 +124,8 @@ def _svec(M):
     """svec of a symmetric matrix: packed triu, column major, off-diagonals * sqrt(2)
     (src/algebra/dense/matrix_math.rs:165-205)."""
     k = M.shape[0]
-    out = []
-    for c in range(k):
-        for r in range(c + 1):
-            out.append(M[r, c] * (1.0 if r == c else np.sqrt(2.0)))
-    return np.array(out)
+    r, c = np.tril_indices(k)  # row-major lower == column-major upper of a symmetric matrix
+    return M[r, c] * np.where(r == c, 1.0, np.sqrt(2.0))
 
 
 def psd_scaling_Hs(S, Z):
@@ -142,17 +139,20 @@ def psd_scaling_Hs(S, Z):
     B = R @ R.T
     k = S.shape[0]
     numel = k * (k + 1) // 2
-    H = np.zeros((numel, numel))
-    idx = [(r, c) for c in range(k) for r in range(c + 1)]
-    for a, (i, j) in enumerate(idx):
-        E = np.zeros((k, k))
-        if i == j:
-            E[i, i] = 1.0
-        else:
-            E[i, j] = E[j, i] = 1.0 / np.sqrt(2.0)
-        H[:, a] = _svec(B @ E @ B.T)
+    # column a of H = svec(B E_a B'), E_a the a-th svec basis matrix; vectorised over a
+    ci, cj = np.tril_indices(k)          # basis index a <-> (i, j) = (cj, ci) with i <= j
+    i_idx, j_idx = cj, ci
+    scale_a = np.where(i_idx == j_idx, 1.0, 1.0 / np.sqrt(2.0))
+    # (B E B')[p, q] = s * (B[p,i] B[q,j] + B[p,j] B[q,i]) (off-diagonal), B[p,i] B[q,i] (diagonal)
+    rp, rq = np.tril_indices(k)
+    p_idx, q_idx = rq, rp                # output svec entry (p, q), p <= q
+    wgt = np.where(p_idx == q_idx, 1.0, np.sqrt(2.0))
+    T1 = B[p_idx][:, i_idx] * B[q_idx][:, j_idx]
+    T2 = B[p_idx][:, j_idx] * B[q_idx][:, i_idx]
+    H = np.where(i_idx == j_idx, T1, (T1 + T2) * scale_a) * wgt[:, None]
     H = 0.5 * (H + H.T)
-    return np.array([H[r, c] for c in range(numel) for r in range(c + 1)])
+    r, c = np.tril_indices(numel)
+    return H[r, c]
 
 
 def chordal_sdp(ncliques=6, dim=6, overlap=2, nsoc=3, socdim=7, seed=5):

@@ -274,15 +274,17 @@ class HipKKTSolver:
     """KKTSolver<f64> (kktsolvers/mod.rs:7-18) == DirectLDLKKTSolver on the device.
 
     new(P, A, cones, m, n, settings) -- directldlkktsolver.rs:60-118.
-    `cones`: list of (tag, dim) or (tag, dim, dim2) SupportedConeT descriptors."""
+    `cones`: list of (tag, dim), (tag, dim, dim2) or (tag, dim, dim2, alpha) SupportedConeT
+    descriptors (alpha = PowerConeT exponent)."""
 
     def __init__(self, P, A, cones, m, n, settings=None, perm=None):
         assert P.n == n and A.n == n and A.m == m
         self.settings = settings or Settings.default()
-        self.cones = [tuple(c) + (0,) * (3 - len(c)) for c in cones]
+        self.cones = [(tuple(c) + (0, 0, 0.5)[len(c) - 1:])[:4] if len(c) < 4 else tuple(c) for c in cones]
         tags = np.array([c[0] for c in self.cones], dtype=np.int32)
         dims = np.array([c[1] for c in self.cones], dtype=np.int64)
         dims2 = np.array([c[2] for c in self.cones], dtype=np.int64)
+        alphas = np.array([c[3] for c in self.cones], dtype=np.float64)
         self._h = C.c_void_p()
         pp = None
         if perm is not None:
@@ -291,7 +293,7 @@ class HipKKTSolver:
         _check(lib().chip_kkt_create(C.byref(self._h), C.c_int64(n), C.c_int64(m), _pu(P.colptr), _pu(P.rowval),
                                      _pf(P.nzval), _pu(A.colptr), _pu(A.rowval), _pf(A.nzval),
                                      C.c_int64(len(self.cones)), tags.ctypes.data_as(P_I32),
-                                     dims.ctypes.data_as(P_I64), dims2.ctypes.data_as(P_I64),
+                                     dims.ctypes.data_as(P_I64), dims2.ctypes.data_as(P_I64), _pf(alphas),
                                      C.byref(self.settings), pp), "chip_kkt_create")
         d = (C.c_int64 * 6)()
         lib().chip_kkt_dims(self._h, d)
@@ -345,14 +347,17 @@ class HipKKTSolver:
         return nz[:self.nnzK]
 
     # -- the KKTSolver trait -----------------------------------------------------
-    def update_scaling(self, s, z):
-        """cones.update_scaling(s, z, mu, strategy) for the device-held cones -> bool"""
+    def update_scaling(self, s, z, mu=1.0, strategy=0):
+        """cones.update_scaling(s, z, mu, strategy) for the device-held cones -> bool
+        (strategy 0 = PrimalDual, 1 = Dual; mu only matters for Exp/Pow cones under Dual)"""
         s, z = _f(s), _f(z)
         assert len(s) == self.m and len(z) == self.m
-        return bool(_check(lib().chip_kkt_update_scaling(self._h, _pf(s), _pf(z)), "update_scaling"))
+        return bool(_check(lib().chip_kkt_update_scaling(self._h, _pf(s), _pf(z), C.c_double(mu),
+                                                         C.c_int32(strategy)), "update_scaling"))
 
-    def update_scaling_dev(self, s_ptr, z_ptr):
-        return bool(_check(lib().chip_kkt_update_scaling_dev(self._h, C.c_void_p(s_ptr), C.c_void_p(z_ptr)),
+    def update_scaling_dev(self, s_ptr, z_ptr, mu=1.0, strategy=0):
+        return bool(_check(lib().chip_kkt_update_scaling_dev(self._h, C.c_void_p(s_ptr), C.c_void_p(z_ptr),
+                                                             C.c_double(mu), C.c_int32(strategy)),
                            "update_scaling_dev"))
 
     def update(self, hsblocks=None):

@@ -72,7 +72,8 @@ struct chip_kkt {
     int nn_count = 0, zero_count = 0;
     int *nn_rows = nullptr, *nn_hsidx = nullptr, *zero_rows = nullptr;
     dev::SocView soc{};
-    bool has_hostHs = false; // cones whose Hs must come from the host (Exp/Pow/PSD)
+    dev::Ns3View ns3{};      // Exponential / Power cones
+    bool has_hostHs = false; // cones whose Hs must come from the host (PSD)
     double *d_s = nullptr, *d_z = nullptr, *d_w = nullptr, *d_lam = nullptr;
     double *d_rhs = nullptr, *d_lhs = nullptr; // n+m staging
     double *bp = nullptr, *x = nullptr, *e = nullptr, *dx = nullptr; // N, permuted numbering
@@ -307,7 +308,8 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
                         const uint64_t *Prowval, const double *Pnzval, const uint64_t *Acolptr,
                         const uint64_t *Arowval, const double *Anzval, int64_t ncones,
                         const int32_t *cone_tags, const int64_t *cone_dims, const int64_t *cone_dims2,
-                        const chip_settings *settings, const uint64_t *perm_or_null) {
+                        const double *cone_alphas_or_null, const chip_settings *settings,
+                        const uint64_t *perm_or_null) {
     if (!out || n < 0 || m < 0 || !Pcolptr || !Acolptr) return fail(CHIP_ERR_ARG, "chip_kkt_create: bad argument");
     *out = nullptr;
     chip_settings st;
@@ -350,6 +352,8 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
 
     // ---- cone work lists ----------------------------------------------------
     std::vector<int> nn_rows, nn_hs, zero_rows, s_start, s_dim, s_hs, s_sidx, s_ptr, mapU, mapV, mapD;
+    std::vector<int> n3_start, n3_hs, n3_tag;
+    std::vector<double> n3_alpha;
     for (const ConeSpec &c : K.cones) {
         if (c.tag == CHIP_CONE_NONNEGATIVE) {
             for (i64 k = 0; k < c.numel; k++) {
@@ -363,9 +367,36 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
             s_dim.push_back((int)c.numel);
             s_hs.push_back((int)c.block_start);
             s_sidx.push_back((int)c.sparse_idx);
+        } else if (c.tag == CHIP_CONE_EXPONENTIAL || c.tag == CHIP_CONE_POWER) {
+            const size_t ci = (size_t)(&c - K.cones.data());
+            n3_start.push_back((int)c.start);
+            n3_hs.push_back((int)c.block_start);
+            n3_tag.push_back((int)c.tag);
+            const double al = cone_alphas_or_null ? cone_alphas_or_null[ci] : 0.5;
+            if (c.tag == CHIP_CONE_POWER && !(al > 0.0 && al < 1.0))
+                return fail(CHIP_ERR_ARG, "PowerConeT exponent must lie in (0,1)");
+            n3_alpha.push_back(al);
         } else {
             h->has_hostHs = true;
         }
+    }
+    {
+        dev::Ns3View &nv = h->ns3;
+        nv.ncones = (int)n3_start.size();
+        int *p1, *p2, *p3;
+        double *pa, *pst;
+        if ((rc = E.upload(&p1, n3_start, n3_start.size()))) return rc;
+        if ((rc = E.upload(&p2, n3_hs, n3_hs.size()))) return rc;
+        if ((rc = E.upload(&p3, n3_tag, n3_tag.size()))) return rc;
+        if ((rc = E.upload(&pa, n3_alpha, n3_alpha.size()))) return rc;
+        if ((rc = E.alloc(&pst, (size_t)(nv.ncones ? nv.ncones : 1) * 18))) return rc;
+        CHIP_HIP(hipMemset(pst, 0, (size_t)(nv.ncones ? nv.ncones : 1) * 18 * sizeof(double)));
+        nv.start = p1;
+        nv.hs_start = p2;
+        nv.tag = p3;
+        nv.alpha = pa;
+        nv.state = pst;
+        nv.mapHs = h->mapHs;
     }
     const size_t nsp = K.sp_ptr.size() ? K.sp_ptr.size() - 1 : 0;
     s_ptr = narrow(K.sp_ptr, nsp + 1);
@@ -467,7 +498,8 @@ int32_t chip_kkt_get_map(const chip_kkt *h, uint64_t *mapP, uint64_t *mapA, uint
     return CHIP_OK;
 }
 
-int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const double *z_dev) {
+int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const double *z_dev, double mu,
+                                    int32_t strategy) {
     if (!h) return CHIP_ERR_ARG;
     Engine &E = h->E;
     NEED_DEVICE(E);
@@ -475,11 +507,12 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
     if (h->soc.ncones) CHIP_HIP(hipMemsetAsync(&E.mb_dev->soc_fail, 0, sizeof(int), E.stream));
     dev::nn_update(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam);
     dev::soc_update_scaling(E.stream, h->soc, s_dev, z_dev);
+    dev::ns3_update_scaling(E.stream, h->ns3, s_dev, z_dev, mu, strategy);
     CHIP_HIP(hipGetLastError());
     h->scaling_pending_check = h->soc.ncones > 0; // verdict is folded into the next update()
     return 1;
 }
-int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z) {
+int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z, double mu, int32_t strategy) {
     if (!h || !s || !z) return CHIP_ERR_ARG;
     Engine &E = h->E;
     NEED_DEVICE(E);
@@ -489,7 +522,7 @@ int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z) {
         CHIP_HIP(hipMemcpyAsync(h->d_s, s, bytes, hipMemcpyHostToDevice, E.stream));
         CHIP_HIP(hipMemcpyAsync(h->d_z, z, bytes, hipMemcpyHostToDevice, E.stream));
     }
-    int rc = chip_kkt_update_scaling_dev(h, h->d_s, h->d_z);
+    int rc = chip_kkt_update_scaling_dev(h, h->d_s, h->d_z, mu, strategy);
     if (rc < 0) return rc;
     if (h->soc.ncones) {
         rc = E.read_mailbox();
@@ -509,10 +542,9 @@ int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
     CHIP_HIP(hipSetDevice(E.device));
     if (h->has_hostHs) {
         if (!hsblocks_or_null)
-            return fail(CHIP_ERR_ARG, "update: Hs blocks are required for Exp/Pow/PSD cones");
+            return fail(CHIP_ERR_ARG, "update: Hs blocks are required for PSD cones");
         for (const ConeSpec &c : K.cones) {
-            if (c.tag == CHIP_CONE_ZERO || c.tag == CHIP_CONE_NONNEGATIVE || c.tag == CHIP_CONE_SECONDORDER)
-                continue;
+            if (c.tag != CHIP_CONE_PSDTRIANGLE) continue;
             CHIP_HIP(hipMemcpyAsync(h->d_tmp + c.block_start, hsblocks_or_null + c.block_start,
                                     (size_t)c.block_len * sizeof(double), hipMemcpyHostToDevice, E.stream));
             dev::scatter_values(E.stream, E.Kx, h->mapHs + c.block_start, h->d_tmp + c.block_start,
@@ -521,6 +553,7 @@ int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
     }
     dev::nn_write_hs(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx);
     dev::soc_write_kkt(E.stream, h->soc, E.Kx);
+    dev::ns3_write_hs(E.stream, h->ns3, E.Kx);
     int ok = E.refactor(h->E.st.static_regularization_enable != 0, h->diag_full);
     if (ok < 0) return ok;
     h->last_eps = E.st.static_regularization_enable ? E.mb_host->eps : 0.0;
@@ -700,11 +733,12 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval) {
 }
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     if (!h) return CHIP_ERR_ARG;
-    if (h->has_hostHs) return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: only Zero/Nonnegative/SOC cones live on the device");
+    if (h->has_hostHs) return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: PSD cone scalings are not held on the device");
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
     dev::cones_mul_Hs(E.stream, h->nn_rows, h->nn_count, h->soc, h->zero_rows, h->zero_count, y_dev, x_dev);
+    dev::ns3_mul_hs(E.stream, h->ns3, y_dev, x_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }

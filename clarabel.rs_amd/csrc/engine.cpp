@@ -323,4 +323,12 @@ int Engine::read_norms(int first, int count, double *out) {
 }
 int Engine::read_norm(int set, double *out) { return read_norms(set, 1, out); }
 
+// the C ABI layer allocates / uploads these element types through the engine
+template int Engine::alloc<int>(int **, size_t);
+template int Engine::alloc<double>(double **, size_t);
+template int Engine::alloc<int8_t>(int8_t **, size_t);
+template int Engine::upload<int>(int **, const std::vector<int> &, size_t);
+template int Engine::upload<double>(double **, const std::vector<double> &, size_t);
+template int Engine::upload<int8_t>(int8_t **, const std::vector<int8_t> &, size_t);
+
 } // namespace chip

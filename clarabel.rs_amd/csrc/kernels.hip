@@ -613,8 +613,20 @@ __global__ __launch_bounds__(WG) void k_gather_merged(GatherArgs a, const int *_
             if (threadIdx.x == 0) fold_norm(a.nrm, a.nan, m, false, lb);
         }
     } else if (bid < ccount) {
-        double s = 0.0;
-        for (int t = cbeg[bid] + threadIdx.x; t < cend[bid]; t += WG) s += a.val[t] * a.xin[a.idx[t]];
+        // 4 independent gathers in flight per thread (the chunk is one long dot product)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const int ce = cend[bid];
+        int t = cbeg[bid] + threadIdx.x;
+        for (; t + 3 * WG < ce; t += 4 * WG) {
+            const int i0 = a.idx[t], i1 = a.idx[t + WG], i2 = a.idx[t + 2 * WG], i3 = a.idx[t + 3 * WG];
+            const double v0 = a.val[t], v1 = a.val[t + WG], v2 = a.val[t + 2 * WG], v3 = a.val[t + 3 * WG];
+            s0 += v0 * a.xin[i0];
+            s1 += v1 * a.xin[i1];
+            s2 += v2 * a.xin[i2];
+            s3 += v3 * a.xin[i3];
+        }
+        for (; t < ce; t += WG) s0 += a.val[t] * a.xin[a.idx[t]];
+        double s = (s0 + s1) + (s2 + s3);
         s = block_sum(s, red);
         if (threadIdx.x == 0) atomicAdd(&a.out[crow[bid]], -s);
     } else {
@@ -859,6 +871,209 @@ __global__ __launch_bounds__(WG) void k_soc_write_kkt(SocView v, double *Kx) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Exponential / Power cones: 3x3 closed forms, one thread per cone.
+// state per cone (18 doubles): Hs[6] | H_dual[6] | grad[3] | z[3]; packed triu
+// order [00,01,11,02,12,22] (dense3x3/core.rs) == the KKT dense-triangle fill order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double logsafe(double v) { return v <= 0.0 ? -INFINITY : log(v); }
+__device__ __forceinline__ void sym3_mul(const double *H, double *y, const double *x) {
+    y[0] = (H[0] * x[0]) + (H[1] * x[1]) + (H[3] * x[2]);
+    y[1] = (H[1] * x[0]) + (H[2] * x[1]) + (H[4] * x[2]);
+    y[2] = (H[3] * x[0]) + (H[4] * x[1]) + (H[5] * x[2]);
+}
+// expcone.rs:396-458 (Wright omega, two refinement sweeps)
+__device__ double wright_omega(double z) {
+    double p, w;
+    if (z < 1.0 + 3.141592653589793) {
+        const double zm1 = z - 1.0;
+        p = zm1;
+        w = 1.0 + p * 0.5;
+        p *= zm1;
+        w += p * (1. / 16.0);
+        p *= zm1;
+        w -= p * (1. / 192.0);
+        p *= zm1;
+        w -= p * (1. / 3072.0);
+        p *= zm1;
+        w += p * (13. / 61440.0);
+    } else {
+        const double logz = logsafe(z), zinv = 1.0 / z;
+        w = z - logz;
+        double q = logz * zinv;
+        w += q;
+        q *= zinv;
+        w += q * (logz / 2.0 - 1.0);
+        q *= zinv;
+        w += q * (logz * logz / 3.0 - logz * 1.5 + 1.0);
+    }
+    double r = z - w - logsafe(w);
+    for (int it = 0; it < 2; it++) {
+        const double wp1 = w + 1.0;
+        const double t = wp1 * (wp1 + (r * 2.0) / 3.0);
+        w *= 1.0 + (r / wp1) * (t - r * 0.5) / (t - r);
+        const double r4 = r * r * r * r;
+        const double wp16 = wp1 * wp1 * wp1 * wp1 * wp1 * wp1;
+        r = (w * w * 2.0 - w * 8.0 - 1.0) / (wp16 * 72.0) * r4;
+    }
+    return w;
+}
+// powcone.rs:447-491 + nonsymmetric_common.rs:193-219
+__device__ double pow_newton_raphson(double s3, double phi, double a) {
+    const double eps = 2.220446049250313e-16;
+    double x = -1.0 / s3 + (s3 * 2.0 + sqrt((phi * phi) / (s3 * s3) + phi * 3.0)) / (phi - s3 * s3);
+    const double t0 = -2.0 * a * logsafe(a) - 2.0 * (1.0 - a) * logsafe(1.0 - a);
+    for (int iter = 0; iter < 100; iter++) {
+        const double t1 = x * x, t2 = (2.0 * x) / s3;
+        const double dfdx = (a * a * 2.0) / (a * x + (1.0 + a) / s3) +
+                            ((1.0 - a) * 2.0) * (1.0 - a) / ((1.0 - a) * x + (2.0 - a) / s3) -
+                            ((x + 1.0 / s3) * 2.0) / (t1 + t2);
+        const double t2b = (x * 2.0) / s3;
+        const double f = 2.0 * a * logsafe(2.0 * a * t1 + (1.0 + a) * t2b) +
+                         2.0 * (1.0 - a) * logsafe(2.0 * (1.0 - a) * t1 + (2.0 - a) * t2b) - logsafe(phi) -
+                         logsafe(t1 + t2b) - 2.0 * logsafe(t2b) + t0;
+        const double dx = -f / dfdx;
+        if (dx < eps || fabs(dx / x) < sqrt(eps) || fabs(dfdx) < eps) break;
+        x += dx;
+    }
+    return x;
+}
+// update_scaling of expcone.rs:106-124 / powcone.rs:99-117 with update_Hs of
+// nonsymmetric_common.rs:53-143; strategy 0 = PrimalDual, 1 = Dual
+__global__ __launch_bounds__(WG) void k_ns3_update_scaling(Ns3View v, const double *__restrict__ sv,
+                                                           const double *__restrict__ zv, double mu_in,
+                                                           int strategy) {
+    const int c = blockIdx.x * WG + threadIdx.x;
+    if (c >= v.ncones) return;
+    const double eps = 2.220446049250313e-16;
+    const double *s = sv + v.start[c], *z = zv + v.start[c];
+    double *Hs = v.state + 18 * c, *Hd = Hs + 6, *grad = Hs + 12, *zc = Hs + 15;
+    const double a = v.alpha[c];
+    const bool isexp = v.tag[c] == 3;
+    double zt[3];
+    if (isexp) { // expcone.rs:330-353, 361-373
+        const double l = logsafe(-z[2] / z[0]);
+        const double r = -z[0] * l - z[0] + z[1];
+        const double c2 = 1.0 / r;
+        grad[0] = c2 * l - 1.0 / z[0];
+        grad[1] = -c2;
+        grad[2] = (c2 * z[0] - 1.0) / z[2];
+        Hd[0] = (r * r - z[0] * r + l * l * z[0] * z[0]) / (r * z[0] * z[0] * r);
+        Hd[1] = -l / (r * r);
+        Hd[2] = 1.0 / (r * r);
+        Hd[3] = (z[1] - z[0]) / (r * r * z[2]);
+        Hd[4] = -z[0] / (r * r * z[2]);
+        Hd[5] = (r * r - z[0] * r + z[0] * z[0]) / (r * r * z[2] * z[2]);
+        const double om = wright_omega(1.0 - s[0] / s[1] - logsafe(s[1] / s[2]));
+        zt[0] = 1.0 / ((om - 1.0) * s[1]);
+        zt[1] = zt[0] + zt[0] * logsafe(om * s[1] / s[2]) - 1.0 / s[1];
+        zt[2] = om / ((1.0 - om) * s[2]);
+    } else { // powcone.rs:353-386, 394-420
+        const double phi = pow(z[0] / a, 2.0 * a) * pow(z[1] / (1.0 - a), 2.0 - 2.0 * a);
+        const double psi = phi - z[2] * z[2];
+        double g0 = 2.0 * a * phi / (z[0] * psi);
+        double g1 = 2.0 * (1.0 - a) * phi / (z[1] * psi);
+        double g2 = -2.0 * z[2] / psi;
+        Hd[0] = g0 * g0 - 2.0 * a * (2.0 * a - 1.0) * phi / (z[0] * z[0] * psi) + (1.0 - a) / (z[0] * z[0]);
+        Hd[1] = g0 * g1 - 4.0 * a * (1.0 - a) * phi / (z[0] * z[1] * psi);
+        Hd[2] = g1 * g1 - 2.0 * (1.0 - a) * (1.0 - 2.0 * a) * phi / (z[1] * z[1] * psi) + a / (z[1] * z[1]);
+        Hd[3] = g0 * g2;
+        Hd[4] = g1 * g2;
+        Hd[5] = g2 * g2 + 2.0 / psi;
+        grad[0] = -2.0 * a * phi / (z[0] * psi) - (1.0 - a) / z[0];
+        grad[1] = -2.0 * (1.0 - a) * phi / (z[1] * psi) - a / z[1];
+        grad[2] = 2.0 * z[2] / psi;
+        const double phis = pow(s[0], 2.0 * a) * pow(s[1], 2.0 - a * 2.0);
+        const double abs_s = fabs(s[2]);
+        if (abs_s > eps) {
+            zt[2] = pow_newton_raphson(abs_s, phis, a);
+            if (s[2] < 0.0) zt[2] = -zt[2];
+            zt[0] = -(a * zt[2] * s[2] + 1.0 + a) / s[0];
+            zt[1] = -((1.0 - a) * zt[2] * s[2] + 2.0 - a) / s[1];
+        } else {
+            zt[2] = 0.0;
+            zt[0] = -(1.0 + a) / s[0];
+            zt[1] = -(2.0 - a) / s[1];
+        }
+    }
+    zc[0] = z[0];
+    zc[1] = z[1];
+    zc[2] = z[2];
+    if (strategy == 1) {
+        for (int i = 0; i < 6; i++) Hs[i] = mu_in * Hd[i];
+        return;
+    }
+    const double *st = grad;
+    const double dot_sz = s[0] * z[0] + s[1] * z[1] + s[2] * z[2];
+    const double mu = dot_sz / 3.0;
+    const double mut = (st[0] * zt[0] + st[1] * zt[1] + st[2] * zt[2]) / 3.0;
+    double ds[3], dz[3], tmp[3];
+    for (int i = 0; i < 3; i++) {
+        ds[i] = s[i] + mu * st[i];
+        dz[i] = z[i] + mu * zt[i];
+    }
+    const double dot_dsz = ds[0] * dz[0] + ds[1] * dz[1] + ds[2] * dz[2];
+    const double de1 = mu * mut - 1.0;
+    double q0 = zt[0] * (Hd[0] * zt[0] + Hd[1] * zt[1] + Hd[3] * zt[2]);
+    q0 += zt[1] * (Hd[1] * zt[0] + Hd[2] * zt[1] + Hd[4] * zt[2]);
+    q0 += zt[2] * (Hd[3] * zt[0] + Hd[4] * zt[1] + Hd[5] * zt[2]);
+    const double de2 = q0 - 3.0 * mut * mut;
+    if (fabs(de1) > sqrt(eps) && fabs(de2) > eps && dot_sz > 0.0 && dot_dsz > 0.0) {
+        sym3_mul(Hd, tmp, zt);
+        for (int i = 0; i < 3; i++) tmp[i] = mut * st[i] - tmp[i];
+        const int IDX[3][3] = {{0, 1, 3}, {1, 2, 4}, {3, 4, 5}};
+        double W6[6];
+        for (int i = 0; i < 6; i++) W6[i] = Hd[i];
+        for (int i = 0; i < 3; i++)
+            for (int j = i; j < 3; j++) W6[IDX[i][j]] -= st[i] * st[j] / 3.0 + tmp[i] * tmp[j] / de2;
+        double sumsq = 0.0;
+        sumsq += W6[0] * W6[0] + W6[2] * W6[2] + W6[5] * W6[5];
+        sumsq += (W6[1] * W6[1] + W6[3] * W6[3] + W6[4] * W6[4]) * 2.0;
+        const double t = mu * sqrt(sumsq);
+        double ax[3];
+        ax[0] = z[1] * zt[2] - z[2] * zt[1];
+        ax[1] = z[2] * zt[0] - z[0] * zt[2];
+        ax[2] = z[0] * zt[1] - z[1] * zt[0];
+        // stable 2-norm (vecmath.rs:206-226), sequential as in the reference
+        double scale = 0.0, ssq = 1.0;
+        for (int i = 0; i < 3; i++) {
+            if (ax[i] == 0.0) continue;
+            const double aa = fabs(ax[i]);
+            if (scale < aa) {
+                const double rr = scale / aa;
+                ssq = 1.0 + ssq * rr * rr;
+                scale = aa;
+            } else {
+                const double rr = aa / scale;
+                ssq = ssq + rr * rr;
+            }
+        }
+        const double nrm = scale * sqrt(ssq);
+        if (nrm != 0.0) {
+            const double rn = 1.0 / nrm;
+            for (int i = 0; i < 3; i++) ax[i] *= rn;
+        }
+        for (int i = 0; i < 3; i++)
+            for (int j = i; j < 3; j++)
+                Hs[IDX[i][j]] = s[i] * s[j] / dot_sz + ds[i] * ds[j] / dot_dsz + t * ax[i] * ax[j];
+    } else {
+        for (int i = 0; i < 6; i++) Hs[i] = mu * Hd[i];
+    }
+}
+// get_Hs (expcone.rs:130-133) negated + scattered
+__global__ __launch_bounds__(WG) void k_ns3_write_hs(Ns3View v, double *Kx) {
+    const int t = blockIdx.x * WG + threadIdx.x;
+    if (t >= v.ncones * 6) return;
+    const int c = t / 6, k = t - 6 * c;
+    Kx[v.mapHs[v.hs_start[c] + k]] = -v.state[18 * c + k];
+}
+// mul_Hs (expcone.rs:135-137)
+__global__ __launch_bounds__(WG) void k_ns3_mul_hs(Ns3View v, double *y, const double *__restrict__ x) {
+    const int c = blockIdx.x * WG + threadIdx.x;
+    if (c >= v.ncones) return;
+    sym3_mul(v.state + 18 * c, y + v.start[c], x + v.start[c]);
+}
+
 // mul_Hs: nonnegativecone.rs:103-108, zerocone.rs:98-100
 __global__ __launch_bounds__(WG) void k_nn_mul_hs(const int *__restrict__ rows, int count,
                                                   const double *__restrict__ w, double *y,
@@ -1019,6 +1234,16 @@ void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const
 }
 void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx) {
     if (v.ncones) k_soc_write_kkt<<<v.ncones, WG, 0, s>>>(v, Kx);
+}
+void ns3_update_scaling(hipStream_t s, const Ns3View &v, const double *sv, const double *zv, double mu,
+                        int strategy) {
+    if (v.ncones) k_ns3_update_scaling<<<(v.ncones + WG - 1) / WG, WG, 0, s>>>(v, sv, zv, mu, strategy);
+}
+void ns3_write_hs(hipStream_t s, const Ns3View &v, double *Kx) {
+    if (v.ncones) k_ns3_write_hs<<<(v.ncones * 6 + WG - 1) / WG, WG, 0, s>>>(v, Kx);
+}
+void ns3_mul_hs(hipStream_t s, const Ns3View &v, double *y, const double *x) {
+    if (v.ncones) k_ns3_mul_hs<<<(v.ncones + WG - 1) / WG, WG, 0, s>>>(v, y, x);
 }
 void cones_mul_Hs(hipStream_t s, const int *nn_rows, int nn_count, const SocView &v,
                   const int *zero_rows, int zero_count, double *y, const double *x) {

@@ -108,6 +108,21 @@ struct SocView {
     double *eta, *d;             // per-cone state
     int *fail;
 };
+// Exponential / Power cones (3-dimensional, non-symmetric): per-cone state of 18 doubles
+// = Hs[6] | H_dual[6] | grad[3] | z[3]
+struct Ns3View {
+    int ncones;
+    const int *start;    // rows in [0,m)
+    const int *hs_start; // start of the cone's 6-entry Hs block in mapHs
+    const int *tag;      // 3 = Exponential, 4 = Power
+    const double *alpha; // PowerConeT exponent
+    double *state;
+    const int *mapHs;
+};
+void ns3_update_scaling(hipStream_t s, const Ns3View &v, const double *sv, const double *zv, double mu,
+                        int strategy);
+void ns3_write_hs(hipStream_t s, const Ns3View &v, double *Kx);
+void ns3_mul_hs(hipStream_t s, const Ns3View &v, double *y, const double *x);
 void nn_update(hipStream_t s, const int *rows, const int *hsidx, int count, const double *sv,
                const double *zv, double *w, double *lam);
 void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, const double *w,

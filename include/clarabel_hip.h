@@ -171,13 +171,14 @@ int32_t chip_ldl_get_factors(chip_ldl *h, uint64_t *Lp, uint64_t *Li, double *Lx
  * new(P, A, cones, m, n, settings)  directldlkktsolver.rs:60-118.
  * P: n x n triu CSC, A: m x n CSC, both canonically sorted (csc/core.rs:322-338).
  * cone i: tags[i], dims[i] (Zero/NN/SOC: numel; PSD: matrix side; GenPow: dim1),
- * dims2[i] (GenPow dim2, else 0).  Exp/Pow have numel 3. */
+ * dims2[i] (GenPow dim2, else 0), alphas[i] (PowerConeT exponent, else ignored; NULL when
+ * there is no power cone).  Exp/Pow have numel 3. */
 int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pcolptr,
                         const uint64_t *Prowval, const double *Pnzval, const uint64_t *Acolptr,
                         const uint64_t *Arowval, const double *Anzval, int64_t ncones,
                         const int32_t *cone_tags, const int64_t *cone_dims,
-                        const int64_t *cone_dims2, const chip_settings *settings,
-                        const uint64_t *perm_or_null);
+                        const int64_t *cone_dims2, const double *cone_alphas_or_null,
+                        const chip_settings *settings, const uint64_t *perm_or_null);
 void chip_kkt_destroy(chip_kkt *h);
 /* dimensions: out[0]=n out[1]=m out[2]=p out[3]=N out[4]=nnzK out[5]=nHsblocks */
 int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[6]);
@@ -186,16 +187,21 @@ int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[6]);
 int32_t chip_kkt_get_matrix(const chip_kkt *h, uint64_t *colptr, uint64_t *rowval, double *nzval);
 int32_t chip_kkt_get_map(const chip_kkt *h, uint64_t *mapP, uint64_t *mapA, uint64_t *mapHs,
                          uint64_t *diagP, uint64_t *diag_full, int8_t *dsigns);
-/* CompositeCone::update_scaling (compositecone.rs:226-243) for the cones held
- * on the device: Nonnegative (nonnegativecone.rs:77-90) and SecondOrder
- * (socone.rs:134-211); Zero is a no-op.  Returns the reference's bool.
- * s, z: m doubles (host / device variants). */
-int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z);
-int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const double *z_dev);
+/* CompositeCone::update_scaling(s, z, mu, scaling_strategy) (compositecone.rs:226-243) for
+ * the cones held on the device: Nonnegative (nonnegativecone.rs:77-90), SecondOrder
+ * (socone.rs:134-211), Exponential (expcone.rs:106-124) and Power (powcone.rs:99-117) with the
+ * primal-dual / dual scalings of nonsymmetric_common.rs:53-143; Zero is a no-op.
+ * strategy: 0 = ScalingStrategy::PrimalDual, 1 = ::Dual (core/solver.rs:77-80).
+ * Returns the reference's bool.  s, z: m doubles (host / device variants; the _dev variant
+ * defers the SOC interior check to the next chip_kkt_update so that it stays asynchronous). */
+int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z, double mu,
+                                int32_t strategy);
+int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const double *z_dev, double mu,
+                                    int32_t strategy);
 /* KKTSolver::update (directldlkktsolver.rs:134-158): Hs blocks (get_Hs fused,
  * negated), sparse-cone u/v/D columns, static regularisation, numeric refactor.
  * hsblocks_or_null: full Hsblocks vector (host) consulted ONLY for cone types
- * whose scaling is not held on the device (Exp/Pow/GenPow/PSD); may be NULL
+ * whose scaling is not held on the device (PSD); may be NULL
  * when there are none.  Returns the reference's bool. */
 int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null);
 /* setrhs(rhsx, rhsz)   directldlkktsolver.rs:160-166 */

@@ -140,6 +140,10 @@ typedef struct {
     double eta;
     double *u, *v;
     double d;
+    /* Exp / Pow cones (expcone.rs:18-30, powcone.rs:8-22) */
+    double alpha;
+    double Hs3[6], Hdual[6], grad3[3], zc[3];
+    int ns_valid; /* Hs3 computed by update_scaling (else get_Hs leaves the caller's values) */
 } orc_cone;
 
 typedef struct {
@@ -163,8 +167,14 @@ void orc_cones_free(orc_cones *cs) {
 }
 
 /* compositecone.rs:36-128 (new / make_rng_cones / make_rng_blocks) */
+orc_cones *orc_cones_new_ex(int64_t ncones, const int32_t *tags, const int64_t *dims,
+                            const int64_t *dims2, const double *alphas);
 orc_cones *orc_cones_new(int64_t ncones, const int32_t *tags, const int64_t *dims,
                          const int64_t *dims2) {
+    return orc_cones_new_ex(ncones, tags, dims, dims2, NULL);
+}
+orc_cones *orc_cones_new_ex(int64_t ncones, const int32_t *tags, const int64_t *dims,
+                            const int64_t *dims2, const double *alphas) {
     orc_cones *cs = (orc_cones *)calloc(1, sizeof(orc_cones));
     cs->ncones = ncones;
     cs->c = (orc_cone *)calloc((size_t)(ncones > 0 ? ncones : 1), sizeof(orc_cone));
@@ -174,6 +184,7 @@ orc_cones *orc_cones_new(int64_t ncones, const int32_t *tags, const int64_t *dim
         c->tag = tags[i];
         c->dim = dims[i];
         c->dim2 = dims2 ? dims2[i] : 0;
+        c->alpha = alphas ? alphas[i] : 0.5;
         switch (c->tag) {
         case CONE_ZERO: case CONE_NONNEG:
             c->numel = c->dim; c->hs_diag = 1; c->sparse = 0; break;
@@ -273,9 +284,198 @@ static int soc_update_scaling(orc_cone *c, const double *s, const double *z) {
     return 1;
 }
 
+/* ---- Exponential / Power cones ------------------------------------------- */
+static double logsafe(double v) { return v <= 0.0 ? -INFINITY : log(v); } /* scalarmath.rs:14-20 */
+/* packed triu 3x3: [00,01,11,02,12,22] (dense3x3/core.rs:25-57) */
+static void sym3_mul(const double *H, double *y, const double *x) {
+    y[0] = (H[0] * x[0]) + (H[1] * x[1]) + (H[3] * x[2]);
+    y[1] = (H[1] * x[0]) + (H[2] * x[1]) + (H[4] * x[2]);
+    y[2] = (H[3] * x[0]) + (H[4] * x[1]) + (H[5] * x[2]);
+}
+static double sym3_quad(const double *H, const double *y, const double *x) {
+    double out = 0.0;
+    out += y[0] * (H[0] * x[0] + H[1] * x[1] + H[3] * x[2]);
+    out += y[1] * (H[1] * x[0] + H[2] * x[1] + H[4] * x[2]);
+    out += y[2] * (H[3] * x[0] + H[4] * x[1] + H[5] * x[2]);
+    return out;
+}
+static double sym3_norm_fro(const double *d) {
+    double sumsq = 0.0;
+    sumsq += d[0] * d[0] + d[2] * d[2] + d[5] * d[5];
+    sumsq += (d[1] * d[1] + d[3] * d[3] + d[4] * d[4]) * 2.0;
+    return sqrt(sumsq);
+}
+static const int SYM3_IDX[3][3] = {{0, 1, 3}, {1, 2, 4}, {3, 4, 5}};
+
+/* expcone.rs:396-458 */
+double orc_wright_omega(double z) {
+    double p, w;
+    if (z < 1.0 + M_PI) {
+        double zm1 = z - 1.0;
+        p = zm1;
+        w = 1.0 + p * 0.5;
+        p *= zm1;
+        w += p * (1. / 16.0);
+        p *= zm1;
+        w -= p * (1. / 192.0);
+        p *= zm1;
+        w -= p * (1. / 3072.0);
+        p *= zm1;
+        w += p * (13. / 61440.0);
+    } else {
+        double logz = logsafe(z), zinv = 1.0 / z;
+        w = z - logz;
+        double q = logz * zinv;
+        w += q;
+        q *= zinv;
+        w += q * (logz / 2.0 - 1.0);
+        q *= zinv;
+        w += q * (logz * logz / 3.0 - logz * 1.5 + 1.0);
+    }
+    double r = z - w - logsafe(w);
+    for (int it = 0; it < 2; it++) {
+        double wp1 = w + 1.0;
+        double t = wp1 * (wp1 + (r * 2.0) / 3.0);
+        w *= 1.0 + (r / wp1) * (t - r * 0.5) / (t - r);
+        double r4 = r * r * r * r;
+        double wp16 = wp1 * wp1 * wp1 * wp1 * wp1 * wp1;
+        r = (w * w * 2.0 - w * 8.0 - 1.0) / (wp16 * 72.0) * r4;
+    }
+    return w;
+}
+/* expcone.rs:330-353 */
+static void exp_update_dual_grad_H(orc_cone *c, const double *z) {
+    double *grad = c->grad3, *H = c->Hdual;
+    double l = logsafe(-z[2] / z[0]);
+    double r = -z[0] * l - z[0] + z[1];
+    double c2 = 1.0 / r;
+    grad[0] = c2 * l - 1.0 / z[0];
+    grad[1] = -c2;
+    grad[2] = (c2 * z[0] - 1.0) / z[2];
+    H[0] = (r * r - z[0] * r + l * l * z[0] * z[0]) / (r * z[0] * z[0] * r);
+    H[1] = -l / (r * r);
+    H[2] = 1.0 / (r * r);
+    H[3] = (z[1] - z[0]) / (r * r * z[2]);
+    H[4] = -z[0] / (r * r * z[2]);
+    H[5] = (r * r - z[0] * r + z[0] * z[0]) / (r * r * z[2] * z[2]);
+}
+/* expcone.rs:361-373 */
+static void exp_gradient_primal(const double *s, double *g) {
+    double om = orc_wright_omega(1.0 - s[0] / s[1] - logsafe(s[1] / s[2]));
+    g[0] = 1.0 / ((om - 1.0) * s[1]);
+    g[1] = g[0] + g[0] * logsafe(om * s[1] / s[2]) - 1.0 / s[1];
+    g[2] = om / ((1.0 - om) * s[2]);
+}
+/* powcone.rs:353-386 */
+static void pow_update_dual_grad_H(orc_cone *c, const double *z) {
+    double *H = c->Hdual, *g = c->grad3;
+    double a = c->alpha;
+    double phi = pow(z[0] / a, 2.0 * a) * pow(z[1] / (1.0 - a), 2.0 - 2.0 * a);
+    double psi = phi - z[2] * z[2];
+    g[0] = 2.0 * a * phi / (z[0] * psi);
+    g[1] = 2.0 * (1.0 - a) * phi / (z[1] * psi);
+    g[2] = -2.0 * z[2] / psi;
+    H[0] = g[0] * g[0] - 2.0 * a * (2.0 * a - 1.0) * phi / (z[0] * z[0] * psi) + (1.0 - a) / (z[0] * z[0]);
+    H[1] = g[0] * g[1] - 4.0 * a * (1.0 - a) * phi / (z[0] * z[1] * psi);
+    H[2] = g[1] * g[1] - 2.0 * (1.0 - a) * (1.0 - 2.0 * a) * phi / (z[1] * z[1] * psi) + a / (z[1] * z[1]);
+    H[3] = g[0] * g[2];
+    H[4] = g[1] * g[2];
+    H[5] = g[2] * g[2] + 2.0 / psi;
+    g[0] = -2.0 * a * phi / (z[0] * psi) - (1.0 - a) / z[0];
+    g[1] = -2.0 * (1.0 - a) * phi / (z[1] * psi) - a / z[1];
+    g[2] = 2.0 * z[2] / psi;
+}
+/* powcone.rs:447-491 + nonsymmetric_common.rs:193-219 */
+static double pow_newton_raphson(double s3, double phi, double a) {
+    const double eps = 2.220446049250313e-16;
+    double x = -1.0 / s3 + (s3 * 2.0 + sqrt((phi * phi) / (s3 * s3) + phi * 3.0)) / (phi - s3 * s3);
+    double t0 = -2.0 * a * logsafe(a) - 2.0 * (1.0 - a) * logsafe(1.0 - a);
+    for (int iter = 0; iter < 100; iter++) {
+        double t1 = x * x, t2 = (2.0 * x) / s3;
+        double dfdx = (a * a * 2.0) / (a * x + (1.0 + a) / s3) +
+                      ((1.0 - a) * 2.0) * (1.0 - a) / ((1.0 - a) * x + (2.0 - a) / s3) -
+                      ((x + 1.0 / s3) * 2.0) / (t1 + t2);
+        double t2b = (x * 2.0) / s3;
+        double f = 2.0 * a * logsafe(2.0 * a * t1 + (1.0 + a) * t2b) +
+                   2.0 * (1.0 - a) * logsafe(2.0 * (1.0 - a) * t1 + (2.0 - a) * t2b) - logsafe(phi) -
+                   logsafe(t1 + t2b) - 2.0 * logsafe(t2b) + t0;
+        double dx = -f / dfdx;
+        if (dx < eps || fabs(dx / x) < sqrt(eps) || fabs(dfdx) < eps) break;
+        x += dx;
+    }
+    return x;
+}
+/* powcone.rs:394-420 */
+static void pow_gradient_primal(const orc_cone *c, const double *s, double *g) {
+    const double eps = 2.220446049250313e-16;
+    double a = c->alpha;
+    double phi = pow(s[0], 2.0 * a) * pow(s[1], 2.0 - a * 2.0);
+    double abs_s = fabs(s[2]);
+    if (abs_s > eps) {
+        g[2] = pow_newton_raphson(abs_s, phi, a);
+        if (s[2] < 0.0) g[2] = -g[2];
+        g[0] = -(a * g[2] * s[2] + 1.0 + a) / s[0];
+        g[1] = -((1.0 - a) * g[2] * s[2] + 2.0 - a) / s[1];
+    } else {
+        g[2] = 0.0;
+        g[0] = -(1.0 + a) / s[0];
+        g[1] = -(2.0 - a) / s[1];
+    }
+}
+/* nonsymmetric_common.rs:53-143 update_Hs; strategy: 0 = PrimalDual, 1 = Dual (core/solver.rs:77-80) */
+static void ns3_update_Hs(orc_cone *c, const double *s, const double *z, double mu_in, int strategy) {
+    const double eps = 2.220446049250313e-16;
+    double *Hd = c->Hdual, *Hs = c->Hs3;
+    if (strategy == 1) {
+        for (int i = 0; i < 6; i++) Hs[i] = mu_in * Hd[i];
+        return;
+    }
+    double zt[3];
+    if (c->tag == CONE_EXP) exp_gradient_primal(s, zt);
+    else pow_gradient_primal(c, s, zt);
+    const double *st = c->grad3;
+    double ds[3], tmp[3], dz[3];
+    double dot_sz = dotp(s, z, 3);
+    double mu = dot_sz / 3.0;
+    double mut = dotp(st, zt, 3) / 3.0;
+    for (int i = 0; i < 3; i++) {
+        ds[i] = s[i] + mu * st[i];
+        dz[i] = z[i] + mu * zt[i];
+    }
+    double dot_dsz = dotp(ds, dz, 3);
+    double de1 = mu * mut - 1.0;
+    double de2 = sym3_quad(Hd, zt, zt) - 3.0 * mut * mut;
+    if (fabs(de1) > sqrt(eps) && fabs(de2) > eps && dot_sz > 0.0 && dot_dsz > 0.0) {
+        sym3_mul(Hd, tmp, zt);
+        for (int i = 0; i < 3; i++) tmp[i] = mut * st[i] - tmp[i];
+        for (int i = 0; i < 6; i++) Hs[i] = Hd[i];
+        for (int i = 0; i < 3; i++)
+            for (int j = i; j < 3; j++) Hs[SYM3_IDX[i][j]] -= st[i] * st[j] / 3.0 + tmp[i] * tmp[j] / de2;
+        double t = mu * sym3_norm_fro(Hs);
+        double ax[3];
+        ax[0] = z[1] * zt[2] - z[2] * zt[1];
+        ax[1] = z[2] * zt[0] - z[0] * zt[2];
+        ax[2] = z[0] * zt[1] - z[1] * zt[0];
+        double nrm = orc_norm2(ax, 3); /* normalize(), vecmath.rs:74-81 */
+        if (nrm != 0.0) {
+            double rn = 1.0 / nrm;
+            for (int i = 0; i < 3; i++) ax[i] *= rn;
+        }
+        for (int i = 0; i < 3; i++)
+            for (int j = i; j < 3; j++)
+                Hs[SYM3_IDX[i][j]] = s[i] * s[j] / dot_sz + ds[i] * ds[j] / dot_dsz + t * ax[i] * ax[j];
+    } else {
+        for (int i = 0; i < 6; i++) Hs[i] = mu * Hd[i];
+    }
+}
+
 /* compositecone.rs:226-243 update_scaling (Zero/NN/SOC only; other cone types
  * keep whatever Hs the caller stored with orc_kkt_set_hs_override) */
+int orc_cones_update_scaling_ex(orc_cones *cs, const double *s, const double *z, double mu, int strategy);
 int orc_cones_update_scaling(orc_cones *cs, const double *s, const double *z) {
+    return orc_cones_update_scaling_ex(cs, s, z, 1.0, 0);
+}
+int orc_cones_update_scaling_ex(orc_cones *cs, const double *s, const double *z, double mu, int strategy) {
     for (int64_t i = 0; i < cs->ncones; i++) {
         orc_cone *c = &cs->c[i];
         const double *si = s + c->cone_start, *zi = z + c->cone_start;
@@ -286,6 +486,12 @@ int orc_cones_update_scaling(orc_cones *cs, const double *s, const double *z) {
             }
         } else if (c->tag == CONE_SOC) {
             if (!soc_update_scaling(c, si, zi)) return 0;
+        } else if (c->tag == CONE_EXP || c->tag == CONE_POW) { /* expcone.rs:106-124, powcone.rs:99-117 */
+            if (c->tag == CONE_EXP) exp_update_dual_grad_H(c, zi);
+            else pow_update_dual_grad_H(c, zi);
+            ns3_update_Hs(c, si, zi, mu, strategy);
+            c->zc[0] = zi[0]; c->zc[1] = zi[1]; c->zc[2] = zi[2];
+            c->ns_valid = 1;
         }
     }
     return 1;
@@ -317,6 +523,9 @@ void orc_cones_get_Hs(const orc_cones *cs, double *Hs) {
                 for (int64_t k = 0; k < c->block_len; k++) blk[k] *= eta2;
             }
         }
+        else if ((c->tag == CONE_EXP || c->tag == CONE_POW) && c->ns_valid) { /* expcone.rs:130-133 */
+            for (int64_t k = 0; k < 6; k++) blk[k] = c->Hs3[k];
+        }
         /* other cone types: left untouched (caller-provided) */
     }
 }
@@ -338,9 +547,14 @@ void orc_cones_mul_Hs(const orc_cones *cs, double *y, const double *x) {
             for (int64_t k = 0; k < c->numel; k++) yi[k] = cc * c->w[k] + 1.0 * yi[k];
             double e2 = c->eta * c->eta;
             for (int64_t k = 0; k < c->numel; k++) yi[k] *= e2;
+        } else if (c->tag == CONE_EXP || c->tag == CONE_POW) { /* expcone.rs:135-137 */
+            sym3_mul(c->Hs3, yi, xi);
         }
     }
 }
+const double *orc_cone_Hs3(const orc_cones *cs, int64_t i) { return cs->c[i].Hs3; }
+const double *orc_cone_Hdual(const orc_cones *cs, int64_t i) { return cs->c[i].Hdual; }
+const double *orc_cone_grad3(const orc_cones *cs, int64_t i) { return cs->c[i].grad3; }
 /* state accessors for tests */
 double orc_cone_eta(const orc_cones *cs, int64_t i) { return cs->c[i].eta; }
 double orc_cone_d(const orc_cones *cs, int64_t i) { return cs->c[i].d; }

@@ -52,6 +52,10 @@ def lib():
         L.orc_norm2.restype = C.c_double
         L.orc_quad_form_triu.restype = C.c_double
         L.orc_cones_new.restype = C.c_void_p
+        L.orc_cones_new_ex.restype = C.c_void_p
+        L.orc_wright_omega.restype = C.c_double
+        for name in ("Hs3", "Hdual", "grad3"):
+            getattr(L, "orc_cone_" + name).restype = P_F64
         for name in ("numel", "nblockvals", "pdim"):
             getattr(L, "orc_cones_" + name).restype = C.c_int64
         L.orc_cone_eta.restype = C.c_double
@@ -321,15 +325,16 @@ class QDLDL:
 # ----------------------------------------------------------------------------
 class Cones:
     """CompositeCone subset (compositecone.rs:11-128).  `specs` is a list of
-    (tag, dim) or (tag, dim, dim2)."""
+    (tag, dim), (tag, dim, dim2) or (tag, dim, dim2, alpha) [alpha: PowerConeT exponent]."""
 
     def __init__(self, specs):
-        self.specs = [tuple(s) + (0,) * (3 - len(s)) for s in specs]
+        self.specs = [(tuple(s) + (0, 0, 0.5)[len(s) - 1:])[:4] if len(s) < 4 else tuple(s) for s in specs]
         tags = np.array([s[0] for s in self.specs], dtype=np.int32)
         dims = np.array([s[1] for s in self.specs], dtype=i64)
         dims2 = np.array([s[2] for s in self.specs], dtype=i64)
-        self._h = C.c_void_p(lib().orc_cones_new(C.c_int64(len(self.specs)), tags.ctypes.data_as(P_I32),
-                                                 _pi(dims), _pi(dims2)))
+        alphas = np.array([s[3] for s in self.specs], dtype=f64)
+        self._h = C.c_void_p(lib().orc_cones_new_ex(C.c_int64(len(self.specs)), tags.ctypes.data_as(P_I32),
+                                                    _pi(dims), _pi(dims2), _pf(alphas)))
         self.numel = lib().orc_cones_numel(self._h)
         self.nblockvals = lib().orc_cones_nblockvals(self._h)
         self.pdim = lib().orc_cones_pdim(self._h)
@@ -339,9 +344,10 @@ class Cones:
             lib().orc_cones_free(self._h)
             self._h = None
 
-    def update_scaling(self, s, z):
+    def update_scaling(self, s, z, mu=1.0, strategy=0):
+        """Cone::update_scaling(s, z, mu, strategy); strategy 0 = PrimalDual, 1 = Dual"""
         s, z = _af(s), _af(z)
-        return bool(lib().orc_cones_update_scaling(self._h, _pf(s), _pf(z)))
+        return bool(lib().orc_cones_update_scaling_ex(self._h, _pf(s), _pf(z), C.c_double(mu), C.c_int(strategy)))
 
     def get_Hs(self, init=None):
         Hs = np.zeros(self.nblockvals) if init is None else _af(init).copy()
@@ -355,7 +361,7 @@ class Cones:
         return y
 
     def numel_of(self, i):
-        tag, dim, dim2 = self.specs[i]
+        tag, dim, dim2 = self.specs[i][:3]
         if tag in (CONE_EXP, CONE_POW):
             return 3
         if tag == CONE_PSDTRI:
@@ -371,6 +377,9 @@ class Cones:
         for name in ("w", "lambda", "u", "v"):
             p = getattr(L, "orc_cone_" + name)(self._h, C.c_int64(i))
             out[name] = _view(p, n, f64) if p else None
+        out["Hs3"] = _view(L.orc_cone_Hs3(self._h, C.c_int64(i)), 6, f64)
+        out["Hdual"] = _view(L.orc_cone_Hdual(self._h, C.c_int64(i)), 6, f64)
+        out["grad3"] = _view(L.orc_cone_grad3(self._h, C.c_int64(i)), 3, f64)
         return out
 
 

@@ -197,3 +197,53 @@ def chordal_sdp(ncliques=6, dim=6, overlap=2, nsoc=3, socdim=7, seed=5):
         hs.append(psd_scaling_Hs(G1 @ G1.T + dim * np.eye(dim), G2 @ G2.T + dim * np.eye(dim)))
     hs_full = np.concatenate(hs + [np.zeros(socdim)] * nsoc)
     return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=s, z=z, hsblocks=hs_full)
+
+
+def exp_interior(rng, scale=0.05):
+    """a strictly interior primal/dual pair of the exponential cone near the central point of
+    expcone.rs:94-100 (unit_initialization)"""
+    c = np.array([-1.051383945322714, 0.556409619469370, 1.258967884768947])
+    return c * (1.0 + scale * rng.standard_normal(3)), c * (1.0 + scale * rng.standard_normal(3))
+
+
+def pow_interior(rng, alpha):
+    """interior of K_pow(alpha) = {s0^a s1^(1-a) >= |s2|} and of its dual
+    {(z0/a)^a (z1/(1-a))^(1-a) >= |z2|}"""
+    s = np.array([rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0), 0.0])
+    s[2] = rng.uniform(-0.8, 0.8) * s[0] ** alpha * s[1] ** (1 - alpha)
+    z = np.array([rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0), 0.0])
+    z[2] = rng.uniform(-0.8, 0.8) * (z[0] / alpha) ** alpha * (z[1] / (1 - alpha)) ** (1 - alpha)
+    return s, z
+
+
+def mixed_conic(nexp=40, npow=30, nsoc=5, socdim=9, nn=50, seed=11):
+    """all device-held cone kinds in one problem (cf. tests/mixed_conic.rs): Zero, Nonnegative,
+    SecondOrder (sparse and dense), Exponential, Power; A random sparse, P diagonal-dominant"""
+    rng = np.random.default_rng(seed)
+    cones, s_parts, z_parts = [(ZERO, 3), (NN, nn)], [np.zeros(3), rng.uniform(0.3, 3, nn)], \
+        [np.zeros(3), rng.uniform(0.3, 3, nn)]
+    for i in range(nsoc):
+        d = socdim if i % 2 == 0 else 3
+        cones.append((SOC, d))
+        for parts in (s_parts, z_parts):
+            v = rng.standard_normal(d)
+            v[0] = np.linalg.norm(v[1:]) * 1.5 + 0.1
+            parts.append(v)
+    for _ in range(nexp):
+        cones.append((EXP, 3))
+        s, z = exp_interior(rng)
+        s_parts.append(s)
+        z_parts.append(z)
+    for _ in range(npow):
+        a = float(rng.uniform(0.15, 0.85))
+        cones.append((POW, 3, 0, a))
+        s, z = pow_interior(rng, a)
+        s_parts.append(s)
+        z_parts.append(z)
+    s, z = np.concatenate(s_parts), np.concatenate(z_parts)
+    m = len(s)
+    n = max(8, m // 3)
+    A = sp.random(m, n, density=min(1.0, 4.0 / n), random_state=np.random.RandomState(seed), format="csc")
+    A = A + sp.csc_matrix((np.ones(min(m, n)), (np.arange(min(m, n)), np.arange(min(m, n)))), shape=(m, n))
+    P = sp.diags(rng.uniform(0.5, 1.5, n)).tocsc()
+    return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=s, z=z)

@@ -195,6 +195,33 @@ def test_c5_chordal_sdp_host_hs(hip, oracle):
     _check_update_and_solve(hip, oracle, pr, hs=pr["hsblocks"])
 
 
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_mixed_conic_exp_pow_on_device(hip, oracle, strategy):
+    """Exponential / Power cone scalings computed ON THE DEVICE (expcone.rs:106-124,
+    powcone.rs:99-117, nonsymmetric_common.rs:53-143), both scaling strategies"""
+    pr = problems.mixed_conic(seed=11)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    mu = 0.43
+    assert ks.update_scaling(pr["s"], pr["z"], mu, strategy)
+    assert cones.update_scaling(pr["s"], pr["z"], mu, strategy)
+    assert ks.update() and ko.update()
+    assert relerr(ks.values(), ko.kkt.nzval) <= 1e-12
+    rng = np.random.default_rng(2)
+    rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+    ks.setrhs(rx, rz)
+    ko.setrhs(rx, rz)
+    x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+    assert ks.solve(x, z)
+    ok, xo, zo = ko.solve()
+    assert ok and relerr(np.concatenate([x, z]), np.concatenate([xo, zo])) <= TOL
+    # mul_Hs on the device against the oracle
+    xt = hip.DeviceArray(rz)
+    yt = hip.DeviceArray(pr["m"])
+    ks.mul_Hs_dev(yt.ptr, xt.ptr)
+    ks.synchronize()
+    assert relerr(yt.numpy(), cones.mul_Hs(rz)) <= 1e-12
+
+
 def test_refactor_sequence_and_update_PA(hip, oracle):
     """several IPM-like iterations on one handle (values change, pattern fixed) + update_P/A
     (directldlkktsolver.rs:191-197)"""

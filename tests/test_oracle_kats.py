@@ -350,3 +350,54 @@ def test_kktsolver_matches_dense(oracle):
     got = np.concatenate([x, zz])
     assert np.max(np.abs(got - ref0)) <= 1e-8 * max(1, np.max(np.abs(ref0)))
     assert ref.shape == got.shape
+
+
+# ---- Exponential / Power cones (no Hs KATs in the reference; identities instead) ----------
+def test_wright_omega(oracle):
+    # expcone.rs:461-472
+    import ctypes as C
+    L = oracle.lib()
+    for z in [1e-7, 1e-5, 1e-3, 1e-1, 1e1, 1e3, 1e5, 1e7, 1e9]:
+        y = L.orc_wright_omega(C.c_double(z))
+        assert abs(z - (y + np.log(y))) / z < 1e-9
+
+
+def _dual_barrier(tag, z, alpha):
+    if tag == 3:  # f*(z) = -log(z1 - z0 - z0 log(z2/-z0)) - log(-z0) - log(z2)
+        l = np.log(-z[2] / z[0])
+        return -np.log(-z[0] * l - z[0] + z[1]) - np.log(-z[0]) - np.log(z[2])
+    phi = (z[0] / alpha) ** (2 * alpha) * (z[1] / (1 - alpha)) ** (2 - 2 * alpha)
+    return -np.log(phi - z[2] ** 2) - (1 - alpha) * np.log(z[0]) - alpha * np.log(z[1])
+
+
+@pytest.mark.parametrize("tag,alpha", [(3, 0.5), (4, 0.6), (4, 0.1)])
+def test_nonsymmetric_cone_scalings(oracle, tag, alpha):
+    from tests import problems
+    rng = np.random.default_rng(int(tag * 10 + alpha * 100))
+    s, z = problems.exp_interior(rng) if tag == 3 else problems.pow_interior(rng, alpha)
+    cones = oracle.Cones([(tag, 3, 0, alpha)])
+    assert cones.update_scaling(s, z, 0.37, 0)
+    st = cones.state(0)
+    # grad / H_dual are the gradient and Hessian of the dual barrier (finite differences)
+    h = 1e-6
+    g_fd = np.array([(_dual_barrier(tag, z + h * e, alpha) - _dual_barrier(tag, z - h * e, alpha)) / (2 * h)
+                     for e in np.eye(3)])
+    assert np.allclose(st["grad3"], g_fd, rtol=1e-6, atol=1e-8)
+    Hd = st["Hdual"]
+    H = np.array([[Hd[0], Hd[1], Hd[3]], [Hd[1], Hd[2], Hd[4]], [Hd[3], Hd[4], Hd[5]]])
+    H_fd = np.zeros((3, 3))
+    for j, e in enumerate(np.eye(3)):
+        cp, cm = oracle.Cones([(tag, 3, 0, alpha)]), oracle.Cones([(tag, 3, 0, alpha)])
+        cp.update_scaling(s, z + h * e, 1.0, 1)
+        cm.update_scaling(s, z - h * e, 1.0, 1)
+        H_fd[:, j] = (cp.state(0)["grad3"] - cm.state(0)["grad3"]) / (2 * h)
+    assert np.allclose(H, H_fd, rtol=1e-5, atol=1e-7)
+    # <grad f*(z), z> = -3 (logarithmic homogeneity, degree 3)
+    assert abs(st["grad3"] @ z + 3.0) < 1e-10
+    # primal-dual scaling satisfies the secant equation Hs z = s (nonsymmetric_common.rs:131-138)
+    assert np.allclose(cones.mul_Hs(z), s, rtol=1e-10, atol=1e-12)
+    # dual scaling: Hs = mu * H_dual
+    cd = oracle.Cones([(tag, 3, 0, alpha)])
+    cd.update_scaling(s, z, 0.37, 1)
+    assert np.allclose(cd.state(0)["Hs3"], 0.37 * Hd, rtol=1e-14)
+    assert np.allclose(cd.get_Hs(), 0.37 * Hd, rtol=1e-14)

@@ -37,6 +37,13 @@ from tests import problems
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def baseline_metric():
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "IPM iterations/sec (KKT factor+solve) at n=10^6 SOCP, 1/2/4/8 GPUs"
+
+
 def algorithmic_bytes(N, nnzK, nnzL, nnzHs, m):
     """SURVEY.md 8(d) byte model (i32 indices, fp64 values), per unit of work."""
     B_update = 12 * nnzHs + 24 * N + 16 * m
@@ -64,10 +71,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch N > 1 as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    # one process per GPU; CHIP_BENCH_BACKEND=gloo + several ranks on one GPU is a plumbing test mode
+    backend = os.environ.get("CHIP_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     hip = graft.load_package()
 
     # ---- this rank's shard ----------------------------------------------------
@@ -88,7 +104,8 @@ def main():
     rhs = [(torch.tensor(rng.standard_normal(n), device=dev), torch.tensor(rng.standard_normal(m), device=dev))
            for _ in range(3)]
     lhs = torch.zeros(n + m, device=dev, dtype=torch.float64)
-    gathered = torch.zeros(world * (n + m), device=dev, dtype=torch.float64) if world > 1 else None
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = torch.zeros(world * (n + m), device=gdev, dtype=torch.float64) if world > 1 else None
     torch.cuda.synchronize()
 
     def step():
@@ -100,8 +117,10 @@ def main():
             if not ks.solve_dev(lhs.data_ptr(), lhs.data_ptr() + 8 * n):
                 raise RuntimeError("KKT solve failed")
             if world > 1:
+                # every rank ends up with the full step direction (dx, dz) of the block-diagonal
+                # problem: RCCL all-gather over xGMI (6 x 24 MB shards at 8 GPUs)
                 ks.synchronize()  # the engine runs on its own stream
-                dist.all_gather_into_tensor(gathered, lhs)
+                dist.all_gather_into_tensor(gathered, lhs if backend == "nccl" else lhs.cpu())
 
     def sync_all():
         ks.synchronize()
@@ -122,7 +141,7 @@ def main():
     prof = ks.profile_read()
     ks.profile(0)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ir = ks.linear_solver_info().last_ir_iterations
@@ -162,7 +181,7 @@ def main():
         if world == 1 and args.cpu_steps != 0:
             cpu = cpu_baseline(pr, ks, args)
         out = {
-            "metric": "IPM iterations/sec (KKT factor+solve) at n=10^6 SOCP",
+            "metric": baseline_metric(),
             "value": round(value, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -47,6 +47,31 @@ int Engine::upload_lists(DeviceLists &Dl, const LevelLists &L) {
     if ((rc = upload(&Dl.b_beg, L.b_beg, L.b_beg.size()))) return rc;
     if ((rc = upload(&Dl.b_end, L.b_end, L.b_end.size()))) return rc;
     if ((rc = upload(&Dl.br_idx, L.br_idx, L.br_idx.size()))) return rc;
+    if ((rc = upload(&Dl.d_t_ptr, L.t_ptr, L.t_ptr.size()))) return rc;
+    if ((rc = upload(&Dl.d_w_ptr, L.w_ptr, L.w_ptr.size()))) return rc;
+    // runs of narrow levels (no B chunks, few rows): candidates for the chain kernel
+    const int nl = (int)L.t_ptr.size() - 1;
+    Dl.chain_end.assign((size_t)(nl > 0 ? nl : 0), 0);
+    Dl.chain_begin.assign((size_t)(nl > 0 ? nl : 0), 0);
+    auto narrow = [&](int l) {
+        return L.b_ptr[l + 1] == L.b_ptr[l] && L.t_ptr[l + 1] - L.t_ptr[l] <= 2048 &&
+               L.w_ptr[l + 1] - L.w_ptr[l] <= 64;
+    };
+    for (int l = 0; l < nl;) {
+        int e = l;
+        while (e < nl && narrow(e)) e++;
+        if (e - l >= 2) {
+            for (int k = l; k < e; k++) {
+                Dl.chain_end[k] = e;
+                Dl.chain_begin[k] = l;
+            }
+            l = e;
+        } else {
+            Dl.chain_end[l] = l + 1;
+            Dl.chain_begin[l] = l;
+            l++;
+        }
+    }
     return CHIP_OK;
 }
 
@@ -270,18 +295,32 @@ void Engine::enqueue_solve_inplace(double *xp) {
     const dev::LdlView v = view();
     dev::bundle_fwd(stream, v, bundles, xp);
     dev::GatherArgs f{Rp, Rcol, Rx, xp, xp, nullptr, nullptr, nullptr};
-    for (int l = 0; l < nlevels; l++) {
+    for (int l = 0; l < nlevels;) {
+        const int e = fwd.chain_end[l];
+        if (e > l + 1) { // a chain-like stretch: one single-workgroup launch for levels [l, e)
+            dev::gather_chain(stream, dev::FWD, f, fwd.t_idx, fwd.d_t_ptr, fwd.w_idx, fwd.d_w_ptr, l, e);
+            l = e;
+            continue;
+        }
         prof_begin(PF_FWD_T);
         dev::gather_merged(stream, dev::FWD, f, fwd.T(l), fwd.W(l), fwd.B(l));
         prof_end(PF_FWD_T);
+        l++;
     }
     dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
-    for (int l = nlevels - 1; l >= 0; l--) {
+    for (int l = nlevels - 1; l >= 0;) {
+        const int b0 = bwd.chain_begin[l]; // first level of the run of narrow levels that ends at l
+        if (bwd.chain_end[l] == l + 1 && l + 1 - b0 >= 2) {
+            dev::gather_chain(stream, dev::BWD, g, bwd.t_idx, bwd.d_t_ptr, bwd.w_idx, bwd.d_w_ptr, b0, l + 1);
+            l = b0 - 1;
+            continue;
+        }
         const dev::ChunkView b = bwd.B(l);
         if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwd.BR(l));
         prof_begin(PF_BWD_T);
         dev::gather_merged(stream, dev::BWD, g, bwd.T(l), bwd.W(l), b);
         prof_end(PF_BWD_T);
+        l--;
     }
     dev::bundle_bwd(stream, v, bundles, xp);
 }

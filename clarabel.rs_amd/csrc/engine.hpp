@@ -16,6 +16,10 @@ struct DeviceLists {
     std::vector<i32> t_ptr, w_ptr, b_ptr, br_ptr; // host copies of the level pointers
     int *t_idx = nullptr, *w_idx = nullptr, *b_row = nullptr, *b_beg = nullptr, *b_end = nullptr,
         *br_idx = nullptr;
+    int *d_t_ptr = nullptr, *d_w_ptr = nullptr; // device copies of the level pointers (chain kernel)
+    // chain_end[l] > l + 1: levels [l, chain_end[l]) form a run of narrow levels handled by one
+    // single-workgroup launch; otherwise l + 1
+    std::vector<i32> chain_end, chain_begin;
     dev::ListView T(int l) const { return {t_idx + t_ptr[l], t_ptr[l + 1] - t_ptr[l]}; }
     dev::ListView W(int l) const { return {w_idx + w_ptr[l], w_ptr[l + 1] - w_ptr[l]}; }
     dev::ListView BR(int l) const { return {br_idx + br_ptr[l], br_ptr[l + 1] - br_ptr[l]}; }

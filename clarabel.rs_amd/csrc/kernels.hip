@@ -200,6 +200,7 @@ __global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restric
     factor_col_thread(v, cols[tid]);
 }
 
+constexpr int RCAP = 1024;     // contributions per flattened batch (scan needs blockDim >= RCAP/2)
 constexpr int W_LDS_CAP = 2048; // column values + row ids kept in LDS (16 + 8 KiB of 160 KiB)
 
 __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int hi, int row) {
@@ -218,8 +219,8 @@ __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int 
 // budget-like separators of block-arrow KKTs) take per-thread register
 // partials + one block reduction instead of hammering 4 LDS addresses.
 // Must be called by all threads of the workgroup; ends un-synchronised.
-__device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double *acc, int *rows,
-                                                 double *red, double *s_dinv) {
+__device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double *acc, int *rows, int *cst,
+                                                 double *cw, int *coff, double *red, double *s_dinv) {
     const int cb = v.Lp[j], cn = v.Lp[j + 1] - cb;
     const int rb = v.Rp[j], rn = v.Rp[j + 1] - rb;
     const int tid = threadIdx.x;
@@ -267,25 +268,55 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
         }
     __syncthreads();
     if (lds && cn >= 24) {
-        // general-fill columns: contributing columns have long tails.  One WAVE per contribution:
-        // its lanes stream the tail of column k coalesced, locate each row in column j's row list
-        // by a binary search that runs entirely in LDS, and add into the LDS accumulator.
-        const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
-        for (int t = wv; t < rn; t += nw) {
-            const int k = v.Rcol[rb + t], p = v.Rpos[rb + t];
-            const double ljk = v.Lx[p];
-            const double w = ljk * v.D[k];
-            if (lane == 0) dpart += ljk * w;
-            const int pe = v.Lp[k + 1];
-            for (int pp = p + 1 + lane; pp < pe; pp += 64) {
-                const int i = v.Li[pp];
-                int lo = 0, hi = cn;
-                while (lo < hi) {
+        // General-fill columns: the contributing columns have long tails of very different
+        // lengths.  The (contribution, tail entry) pairs are FLATTENED: per batch of up to RCAP
+        // contributions an exclusive scan of the tail lengths is built in LDS, then the threads
+        // stride over the flat update index u -- adjacent lanes read adjacent entries of a tail
+        // (coalesced), every iteration's loads are independent of the previous one, and both
+        // lookups (owner of u, slot of the row in column j) are binary searches in LDS.
+        for (int base = 0; base < rn; base += RCAP) {
+            const int nbt = min(RCAP, rn - base);
+            __syncthreads(); // previous batch fully consumed
+            for (int t = tid; t < nbt; t += blockDim.x) {
+                const int k = v.Rcol[rb + base + t], p = v.Rpos[rb + base + t];
+                const double ljk = v.Lx[p];
+                const double w = ljk * v.D[k];
+                dpart += ljk * w;
+                cst[t] = p + 1;
+                cw[t] = w;
+                coff[t + 1] = v.Lp[k + 1] - (p + 1);
+            }
+            if (tid == 0) coff[0] = 0;
+            __syncthreads();
+            // inclusive scan of coff[1..nbt] (Hillis-Steele, <= 10 rounds)
+            for (int off = 1; off < nbt; off <<= 1) {
+                int add0 = 0, add1 = 0;
+                const int i0 = tid + 1, i1 = tid + 1 + (int)blockDim.x;
+                if (i0 <= nbt && i0 - off >= 1) add0 = coff[i0 - off];
+                if (i1 <= nbt && i1 - off >= 1) add1 = coff[i1 - off];
+                __syncthreads();
+                if (i0 <= nbt) coff[i0] += add0;
+                if (i1 <= nbt) coff[i1] += add1;
+                __syncthreads();
+            }
+            const int total = coff[nbt];
+            for (int u = tid; u < total; u += blockDim.x) {
+                int lo = 0, hi = nbt; // last t with coff[t] <= u
+                while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if (rows[mid] < i) lo = mid + 1;
+                    if (coff[mid] <= u) lo = mid;
                     else hi = mid;
                 }
-                atomicAdd(&acc[lo], -(v.Lx[pp] * w));
+                const int pp = cst[lo] + (u - coff[lo]);
+                const int i = v.Li[pp];
+                const double val = v.Lx[pp] * cw[lo];
+                int l2 = 0, h2 = cn;
+                while (l2 < h2) {
+                    const int mid = (l2 + h2) >> 1;
+                    if (rows[mid] < i) l2 = mid + 1;
+                    else h2 = mid;
+                }
+                atomicAdd(&acc[l2], -val);
             }
         }
     } else {
@@ -323,10 +354,13 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
 __global__ __launch_bounds__(1024) void k_factor_W(LdlView v, const int *__restrict__ cols, int count) {
     __shared__ double acc[W_LDS_CAP];
     __shared__ int rows[W_LDS_CAP];
+    __shared__ int cst[RCAP];
+    __shared__ double cw[RCAP];
+    __shared__ int coff[RCAP + 1];
     __shared__ double red[16];
     __shared__ double s_dinv;
     if ((int)blockIdx.x >= count) return;
-    factor_col_block(v, cols[blockIdx.x], acc, rows, red, &s_dinv);
+    factor_col_block(v, cols[blockIdx.x], acc, rows, cst, cw, coff, red, &s_dinv);
 }
 
 // ---------------------------------------------------------------------------
@@ -348,6 +382,9 @@ constexpr int FATCAP = 1024;  // per-level list of rows/columns that need cooper
 __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv) {
     __shared__ double acc[W_LDS_CAP];
     __shared__ int rows[W_LDS_CAP];
+    __shared__ int cst[RCAP];
+    __shared__ double cw[RCAP];
+    __shared__ int coff[RCAP + 1];
     __shared__ double red[16];
     __shared__ double s_dinv;
     __shared__ int fat[FATCAP];
@@ -372,7 +409,7 @@ __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv)
         __syncthreads();
         const int nf = min(nfat, FATCAP);
         for (int f = 0; f < nf; ++f) {
-            factor_col_block(v, fat[f], acc, rows, red, &s_dinv);
+            factor_col_block(v, fat[f], acc, rows, cst, cw, coff, red, &s_dinv);
             __syncthreads();
         }
         // level l is final (global writes visible workgroup-wide) before level l+1
@@ -642,6 +679,34 @@ __global__ __launch_bounds__(WG) void k_gather_merged(GatherArgs a, const int *_
             const double v = store_row<MODE>(a, r, s);
             if (MODE == SYMV && a.nrm) fold_norm(a.nrm, a.nan, v != v ? 0.0 : fabs(v), v != v, wid);
         }
+    }
+}
+
+// A run of consecutive NARROW levels (a chain-like stretch of the elimination tree: a handful
+// of rows per level) handled by ONE 1024-thread workgroup that walks the levels with
+// __syncthreads() in between -- ~1 us per level instead of one ~5-9 us launch per level.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_chain(GatherArgs a, const int *__restrict__ t_idx,
+                                                const int *__restrict__ t_ptr,
+                                                const int *__restrict__ w_idx,
+                                                const int *__restrict__ w_ptr, int l0, int l1) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int step = 0; step < l1 - l0; ++step) {
+        const int l = (MODE == FWD) ? l0 + step : l1 - 1 - step;
+        for (int i = t_ptr[l] + tid; i < t_ptr[l + 1]; i += 1024) {
+            const int r = t_idx[i];
+            double s = 0.0;
+            for (int t = a.ptr[r]; t < a.ptr[r + 1]; ++t) s += a.val[t] * a.xin[a.idx[t]];
+            store_row<MODE>(a, r, s);
+        }
+        for (int i = w_ptr[l] + wv; i < w_ptr[l + 1]; i += 16) {
+            const int r = w_idx[i];
+            double s = 0.0;
+            for (int t = a.ptr[r] + lane; t < a.ptr[r + 1]; t += 64) s += a.val[t] * a.xin[a.idx[t]];
+            s = wave_sum(s);
+            if (lane == 0) store_row<MODE>(a, r, s);
+        }
+        __syncthreads(); // level l final and visible workgroup-wide
     }
 }
 
@@ -1175,6 +1240,12 @@ void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t,
     const int nbT = t.count ? grid_for(t.count) : 0;
     const int grid = off8 + nbT;
     DISPATCH_MODE(k_gather_merged, grid, a, t.idx, t.count, w.idx, w.count, c.row, c.beg, c.end, c.count, off8)
+}
+void gather_chain(hipStream_t s, GatherMode m, const GatherArgs &a, const int *t_idx, const int *t_ptr,
+                  const int *w_idx, const int *w_ptr, int l0, int l1) {
+    if (l1 <= l0) return;
+    if (m == FWD) k_chain<FWD><<<1, 1024, 0, s>>>(a, t_idx, t_ptr, w_idx, w_ptr, l0, l1);
+    else k_chain<BWD><<<1, 1024, 0, s>>>(a, t_idx, t_ptr, w_idx, w_ptr, l0, l1);
 }
 void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
     if (!r.count) return;

@@ -103,27 +103,40 @@ def main():
     z_d = torch.tensor(pr["z"], device=dev)
     rhs = [(torch.tensor(rng.standard_normal(n), device=dev), torch.tensor(rng.standard_normal(m), device=dev))
            for _ in range(3)]
-    lhs = torch.zeros(n + m, device=dev, dtype=torch.float64)
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = torch.zeros(world * (n + m), device=gdev, dtype=torch.float64) if world > 1 else None
+    # one (lhs, gathered) pair per solve of a step: the all-gather of solve k is asynchronous and
+    # overlaps the compute of the following solves; its buffers are only reused one step later
+    lhs = [torch.zeros(n + m, device=dev, dtype=torch.float64) for _ in range(3)]
+    gathered = [torch.zeros(world * (n + m), device=gdev, dtype=torch.float64) if world > 1 else None
+                for _ in range(3)]
+    works = [None, None, None]
     torch.cuda.synchronize()
 
     def step():
         ks.update_scaling_dev(s_d.data_ptr(), z_d.data_ptr())
         if not ks.update():
             raise RuntimeError("KKT update failed")
-        for rx, rz in rhs:
+        for k, (rx, rz) in enumerate(rhs):
+            if works[k] is not None:
+                works[k].wait()  # the gather that used these buffers one step ago
+                works[k] = None
             ks.setrhs_dev(rx.data_ptr(), rz.data_ptr())
-            if not ks.solve_dev(lhs.data_ptr(), lhs.data_ptr() + 8 * n):
+            if not ks.solve_dev(lhs[k].data_ptr(), lhs[k].data_ptr() + 8 * n):
                 raise RuntimeError("KKT solve failed")
             if world > 1:
                 # every rank ends up with the full step direction (dx, dz) of the block-diagonal
-                # problem: RCCL all-gather over xGMI (6 x 24 MB shards at 8 GPUs)
-                ks.synchronize()  # the engine runs on its own stream
-                dist.all_gather_into_tensor(gathered, lhs if backend == "nccl" else lhs.cpu())
+                # problem: RCCL all-gather over xGMI (7 x 24 MB received per rank at 8 GPUs),
+                # launched once this rank's solve is complete and left running behind the next solve
+                ks.synchronize()
+                works[k] = dist.all_gather_into_tensor(gathered[k], lhs[k] if backend == "nccl" else lhs[k].cpu(),
+                                                       async_op=True)
 
     def sync_all():
         ks.synchronize()
+        for k in range(3):
+            if works[k] is not None:
+                works[k].wait()
+                works[k] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--blocksize", type=int, default=1000)
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1 auto, 0 off)")
     ap.add_argument("--profile-family", type=int, default=1,
-                    help="kernel family timed with hipEvents for the roofline (1 = symv k_gather_merged<2>)")
+                    help="kernel family timed with hipEvents for the roofline (1 = k_bundle_symv)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,8 +163,10 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.steps / elapsed
         Bm = algorithmic_bytes(ks.N, ks.nnzK, info.nnzL, ks.nHs, m)
-        fam_bytes = {1: Bm["symv"]}.get(args.profile_family)
-        fam_name = {1: "k_gather_merged<2> (SYMV: residual e = b - Kx with ||e||inf folded in)",
+        # family 1 = the dominant kernel: residual of all bundle rows, K stored once (U):
+        # 12 B per streamed K entry + 24 B per row (x, b read; e written)
+        fam_bytes = {1: 12 * ks.nnzU + 24 * ks.NF}.get(args.profile_family)
+        fam_name = {1: "k_bundle_symv (residual e = b - Kx over the %d bundle rows, ||e||inf folded in)" % ks.NF,
                     2: "k_gather_merged<1> (BWD top levels)", 3: "k_gather_merged<0> (FWD top levels)",
                     4: "k_factor_T"}.get(args.profile_family, "?")
         # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> tools/pmc_summarize.py ->
@@ -176,7 +178,7 @@ def main():
             import glob
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
             if pj and args.nblocks == 1000 and args.blocksize == 1000 and args.profile_family == 1:
-                traffic = json.load(open(pj[-1]))["kernels"]["k_gather_merged<2>"]["hbm_bytes"]
+                traffic = json.load(open(pj[-1]))["kernels"]["k_bundle_symv"]["hbm_bytes"]
         except Exception:
             traffic = None
         roof = None

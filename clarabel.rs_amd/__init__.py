@@ -295,9 +295,9 @@ class HipKKTSolver:
                                      C.c_int64(len(self.cones)), tags.ctypes.data_as(P_I32),
                                      dims.ctypes.data_as(P_I64), dims2.ctypes.data_as(P_I64), _pf(alphas),
                                      C.byref(self.settings), pp), "chip_kkt_create")
-        d = (C.c_int64 * 6)()
+        d = (C.c_int64 * 8)()
         lib().chip_kkt_dims(self._h, d)
-        self.n, self.m, self.p, self.N, self.nnzK, self.nHs = [int(v) for v in d]
+        self.n, self.m, self.p, self.N, self.nnzK, self.nHs, self.NF, self.nnzU = [int(v) for v in d]
         self.nnzP, self.nnzA = P.nnz, A.nnz
 
     def __del__(self):

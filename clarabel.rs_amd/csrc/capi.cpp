@@ -22,12 +22,6 @@ int fail(int code, const std::string &msg) {
 
 const i64 *as_i64(const uint64_t *p) { return reinterpret_cast<const i64 *>(p); }
 
-double bits_to_double(unsigned long long b) {
-    double d;
-    std::memcpy(&d, &b, sizeof(d));
-    return d;
-}
-
 void fill_info(const Engine &E, chip_info *info) {
     std::memset(info, 0, sizeof(*info));
     std::strncpy(info->name, "hip", sizeof(info->name) - 1);
@@ -461,7 +455,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
 
 void chip_kkt_destroy(chip_kkt *h) { delete h; }
 
-int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[6]) {
+int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[8]) {
     if (!h) return CHIP_ERR_ARG;
     out[0] = h->K.n;
     out[1] = h->K.m;
@@ -469,6 +463,8 @@ int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[6]) {
     out[3] = h->K.N;
     out[4] = h->K.nnz;
     out[5] = h->K.nHs;
+    out[6] = h->E.NF;
+    out[7] = h->E.nnzU;
     return CHIP_OK;
 }
 int32_t chip_kkt_get_matrix(const chip_kkt *h, uint64_t *colptr, uint64_t *rowval, double *nzval) {

@@ -83,6 +83,7 @@ void Engine::init_host_only(const Symbolic &S, const chip_settings &settings) {
     nnzK = S.nnzK;
     nnzL = S.nnzL;
     nnzS = S.nnzS;
+    nnzU = S.nnzU;
     h_perm = S.perm;
     h_lvlptr = S.lvlptr;
     h_etree = S.etree;
@@ -160,6 +161,11 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = upload(&Sp, S.Sp, n + 1))) return rc;
     if ((rc = upload(&Scol, S.Scol, (size_t)nnzS))) return rc;
     if ((rc = upload(&Smap, S.Smap, (size_t)nnzS))) return rc;
+    nnzU = S.nnzU;
+    if ((rc = upload(&Up, S.Up, S.Up.size()))) return rc;
+    if ((rc = upload(&Ucol, S.Ucol, (size_t)nnzU))) return rc;
+    if ((rc = upload(&Umap, S.Umap, (size_t)nnzU))) return rc;
+    if ((rc = alloc(&Ux, (size_t)nnzU))) return rc;
     if ((rc = upload(&dsigns, S.dsigns, n))) return rc;
     if ((rc = alloc(&Kx, (size_t)nnzK))) return rc;
     if ((rc = alloc(&Lx, (size_t)nnzL))) return rc;
@@ -277,6 +283,7 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
         }
     }
     dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
+    dev::gather_values(stream, Ux, Kx, Umap, (int)nnzU);
     int rc = read_mailbox();
     if (rc) return rc;
     factored = true;
@@ -334,8 +341,9 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
     }
     const dev::ChunkView bc = smv.B(0);
     if (bc.count) dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));
+    dev::gather_merged(stream, dev::SYMV, a, smv.T(0), smv.W(0), bc); // the top rows (full rows)
     prof_begin(PF_SYMV_T);
-    dev::gather_merged(stream, dev::SYMV, a, smv.T(0), smv.W(0), bc);
+    dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan); // everything else
     prof_end(PF_SYMV_T);
     if (bc.count && set >= 0) dev::norm_rows(stream, e, smv.BR(0), a.nrm, a.nan);
 }

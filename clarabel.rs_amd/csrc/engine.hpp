@@ -54,7 +54,10 @@ struct Engine {
     i64 nnzK = 0, nnzL = 0, nnzS = 0;
     // symbolic (device)
     int *a2l = nullptr, *Lp = nullptr, *Li = nullptr, *Rp = nullptr, *Rcol = nullptr, *Rpos = nullptr,
-        *Tpos = nullptr, *perm = nullptr, *iperm = nullptr, *Sp = nullptr, *Scol = nullptr, *Smap = nullptr;
+        *Tpos = nullptr, *perm = nullptr, *iperm = nullptr, *Sp = nullptr, *Scol = nullptr, *Smap = nullptr,
+        *Up = nullptr, *Ucol = nullptr, *Umap = nullptr;
+    i64 nnzU = 0;
+    double *Ux = nullptr;
     int8_t *dsigns = nullptr;
     // values (device)
     double *Kx = nullptr, *Lx = nullptr, *Rx = nullptr, *D = nullptr, *Dinv = nullptr, *Sx = nullptr;

@@ -70,10 +70,14 @@ struct Symbolic {
     i32 max_bundle_nodes = 0;
     i32 nlevels = 0;                  // number of TOP levels
     std::vector<i32> lvlptr;
-    // full symmetric K (both triangles) in CSR, permuted numbering; Smap =
-    // index into the caller's K.nzval (so values are refreshed by a gather)
-    i64 nnzS = 0;
+    // K for the residual e = b - K x, permuted numbering; *map = index into the caller's
+    // K.nzval (values are refreshed by a gather at every refactor):
+    //   U : rows i < NF (bundle nodes): diagonal + entries to ancestors, each K entry ONCE
+    //   S : rows i >= NF (top nodes): the full row (both triangles); Sp has N+1 entries,
+    //       empty rows for i < NF
+    i64 nnzS = 0, nnzU = 0;
     std::vector<i32> Sp, Scol, Smap;
+    std::vector<i32> Up, Ucol, Umap;
     // kernel work lists
     LevelLists fac, fwd, bwd; // factor (by column), forward solve (rows of L), backward (columns)
     LevelLists smv;           // symv: a single pseudo-level over all rows

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restric
     factor_col_thread(v, cols[tid]);
 }
 
-constexpr int RCAP = 1024;     // contributions per flattened batch (scan needs blockDim >= RCAP/2)
+constexpr int RCAP = 512;      // contributions per flattened batch (scan needs blockDim >= RCAP/2)
 constexpr int W_LDS_CAP = 2048; // column values + row ids kept in LDS (16 + 8 KiB of 160 KiB)
 
 __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int hi, int row) {
@@ -453,17 +453,49 @@ __global__ __launch_bounds__(BWG) void k_bundle_solve(LdlView v, BundleView bv, 
         const int lb = lv[l], le = lv[l + 1];
         if (threadIdx.x == 0) nfat = 0;
         __syncthreads(); // also orders the previous level's writes to xs
-        for (int j = lb + threadIdx.x; j < le; j += BWG) {
-            bool thin = ptr[j + 1] - ptr[j] <= THIN_MAX;
-            if (!thin) {
-                const int slot = atomicAdd(&nfat, 1);
-                if (slot < FATCAP) fat[slot] = j;
-                else thin = true;
+        // thin rows, two per thread in lockstep (independent load chains in flight; a single
+        // workgroup's sweep is latency-bound, not bandwidth-bound)
+        const int *cidx = FWDMODE ? v.Rcol : v.Li;
+        const double *cval = FWDMODE ? v.Rx : v.Lx;
+        for (int j0 = lb + threadIdx.x; j0 < le; j0 += 2 * BWG) {
+            int jr[2], tb[2], te[2];
+            double sum[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + u * BWG;
+                jr[u] = j < le ? j : -1;
+                tb[u] = j < le ? ptr[j] : 0;
+                te[u] = j < le ? ptr[j + 1] : 0;
+                sum[u] = 0.0;
+                if (te[u] - tb[u] > THIN_MAX) {
+                    const int slot = atomicAdd(&nfat, 1);
+                    if (slot < FATCAP) {
+                        fat[slot] = j;
+                        jr[u] = -1; // handled cooperatively below
+                        te[u] = tb[u];
+                    }
+                }
             }
-            if (thin) {
-                const double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, j, 0, 1);
-                xs[j - s0] = FWDMODE ? xs[j - s0] - s : xs[j - s0] * v.Dinv[j] - s;
+            const int maxlen = max(te[0] - tb[0], te[1] - tb[1]);
+            for (int k = 0; k < maxlen; ++k) {
+                int ii[2];
+                double vv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bool ok = tb[u] + k < te[u];
+                    ii[u] = ok ? cidx[tb[u] + k] : -1;
+                    vv[u] = ok ? cval[tb[u] + k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (ii[u] >= 0) sum[u] += vv[u] * ((FWDMODE || ii[u] < s1) ? xs[ii[u] - s0] : x[ii[u]]);
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (jr[u] >= 0) {
+                    const int j = jr[u];
+                    xs[j - s0] = FWDMODE ? xs[j - s0] - sum[u] : xs[j - s0] * v.Dinv[j] - sum[u];
+                }
         }
         __syncthreads();
         const int nf = min(nfat, FATCAP);
@@ -679,6 +711,87 @@ __global__ __launch_bounds__(WG) void k_gather_merged(GatherArgs a, const int *_
             const double v = store_row<MODE>(a, r, s);
             if (MODE == SYMV && a.nrm) fold_norm(a.nrm, a.nan, v != v ? 0.0 : fabs(v), v != v, wid);
         }
+    }
+}
+
+// Residual e = b - K x for the rows of one bundle, with the symmetric matrix read ONCE:
+// U row i = diagonal + entries (i, j) to ancestors j > i.  Every entry is applied in both
+// directions: gathered into row i's own sum, and scattered (LDS fp64 atomic) into row j when j
+// is in the bundle; rows j in the top are produced by the level-scheduled gather over their full
+// rows instead.  x and e slices live in LDS; ||e||inf of the bundle is folded into the slots.
+__global__ __launch_bounds__(BWG) void k_bundle_symv(BundleView bv, const int *__restrict__ Up,
+                                                     const int *__restrict__ Ucol,
+                                                     const double *__restrict__ Ux,
+                                                     const double *__restrict__ x,
+                                                     const double *__restrict__ b, double *e,
+                                                     unsigned long long *nrm, int *nanflag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem;
+    double *es = xs + bv.max_nodes;
+    __shared__ double red[16];
+    const int bid = blockIdx.x;
+    const int s0 = bv.bundle_ptr[bid], s1 = bv.bundle_ptr[bid + 1], nloc = s1 - s0;
+    for (int i = threadIdx.x; i < nloc; i += BWG) {
+        xs[i] = x[s0 + i];
+        es[i] = b[s0 + i];
+    }
+    __syncthreads();
+    // four rows per thread in lockstep: the row-pointer loads of the 4 rows, then entry k of the
+    // 4 rows, are independent of each other -> 4-8 global loads in flight per thread instead of a
+    // chain of dependent ones (these kernels are latency-, not bandwidth-limited per workgroup)
+    for (int i0 = threadIdx.x; i0 < nloc; i0 += 4 * BWG) {
+        int tb[4], te[4];
+        double acc[4], xi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * BWG;
+            const bool ok = i < nloc;
+            tb[u] = ok ? Up[s0 + i] : 0;
+            te[u] = ok ? Up[s0 + i + 1] : 0;
+            xi[u] = ok ? xs[i] : 0.0;
+            acc[u] = 0.0;
+        }
+        int maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) maxlen = max(maxlen, te[u] - tb[u]);
+        for (int k = 0; k < maxlen; ++k) {
+            int jj[4];
+            double vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = tb[u] + k < te[u];
+                jj[u] = ok ? Ucol[tb[u] + k] : -1;
+                vv[u] = ok ? Ux[tb[u] + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = jj[u];
+                if (j < 0) continue;
+                if (j < s1) {
+                    acc[u] += vv[u] * xs[j - s0];
+                    if (j != s0 + i0 + u * BWG) atomicAdd(&es[j - s0], -(vv[u] * xi[u]));
+                } else {
+                    acc[u] += vv[u] * x[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * BWG < nloc) atomicAdd(&es[i0 + u * BWG], -acc[u]);
+    }
+    __syncthreads();
+    double m = 0.0;
+    bool nan = false;
+    for (int i = threadIdx.x; i < nloc; i += BWG) {
+        const double val = es[i];
+        e[s0 + i] = val;
+        if (val != val) nan = true;
+        else m = fmax(m, fabs(val));
+    }
+    if (nrm) {
+        m = block_max(m, red);
+        if (nan) *nanflag = 1;
+        if (threadIdx.x == 0) fold_norm(nrm, nanflag, m, false, bid);
     }
 }
 
@@ -1218,6 +1331,12 @@ void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x
 }
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x) {
     if (bv.nb) k_bundle_solve<false><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x);
+}
+void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
+                 const double *x, const double *b, double *e, unsigned long long *nrm, int *nan) {
+    if (!bv.nb) return;
+    const size_t lds = ((size_t)bv.max_nodes * 2 * sizeof(double) + 15) & ~(size_t)15;
+    k_bundle_symv<<<bv.nb, BWG, lds, s>>>(bv, Up, Ucol, Ux, x, b, e, nrm, nan);
 }
 void factor_B(hipStream_t s, const LdlView &v, ChunkView c) {
     if (c.count) k_factor_B<<<c.count, WG, 0, s>>>(v, c.row, c.beg, c.end, c.count);

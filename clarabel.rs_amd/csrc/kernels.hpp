@@ -53,6 +53,9 @@ void scatter_values(hipStream_t s, double *Kx, const int *map, const double *val
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv);
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x);
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x);
+// e[bundle rows] = b - K x with K stored once (U: row i = diagonal + entries to ancestors)
+void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
+                 const double *x, const double *b, double *e, unsigned long long *nrm, int *nan);
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);
 void factor_B(hipStream_t s, const LdlView &v, ChunkView chunks);

@@ -369,50 +369,74 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         for (i64 q = 0; q < nnzL; q++)
             if (!covered[q]) S.fill_idx.push_back((i32)q);
     }
-    // ---- full symmetric K in CSR (permuted numbering) -----------------------
+    // ---- K for the refinement residual e = b - K x (permuted numbering) ------
+    // Every nonzero K_ij (i < j in the final numbering) joins a node to one of its ANCESTORS,
+    // so i and j are in the same bundle or j is a top node.  Bundle rows therefore use the
+    // symmetric matrix stored ONCE, row-wise by the smaller index (U: row i holds its diagonal
+    // and its entries to ancestors); one workgroup per bundle applies each entry in both
+    // directions inside LDS.  Only the (few) top rows keep a full row-wise copy (S).
     {
+        const i32 NFi = S.NF;
+        S.Up.assign((size_t)NFi + 1, 0);
         S.Sp.assign((size_t)n + 1, 0);
         for (i64 c = 0; c < n; c++)
             for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-                const i64 r = Ai[p];
-                S.Sp[S.iperm[c] + 1]++;
-                if (r != c) S.Sp[S.iperm[r] + 1]++;
-            }
-        for (i32 j = 0; j < n; j++) S.Sp[j + 1] += S.Sp[j];
-        S.nnzS = S.Sp[n];
-        S.Scol.resize((size_t)S.nnzS + 1);
-        S.Smap.resize((size_t)S.nnzS + 1);
-        // two sweeps ordered by source column in PERMUTED order would give sorted
-        // rows; a sort per row is simpler and the rows are short or already banded.
-        std::vector<i32> nextp(S.Sp.begin(), S.Sp.end() - 1);
-        for (i64 c = 0; c < n; c++)
-            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-                const i64 r = Ai[p];
-                const i32 pc = S.iperm[c], pr = S.iperm[r];
-                i32 t = nextp[pc]++;
-                S.Scol[t] = pr;
-                S.Smap[t] = (i32)p;
-                if (r != c) {
-                    t = nextp[pr]++;
-                    S.Scol[t] = pc;
-                    S.Smap[t] = (i32)p;
+                const i32 pc = S.iperm[c], pr = S.iperm[Ai[p]];
+                const i32 lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
+                if (lo < NFi) S.Up[lo + 1]++;
+                if (hi >= NFi) {
+                    S.Sp[hi + 1]++;
+                    if (lo >= NFi && lo != hi) S.Sp[lo + 1]++;
                 }
             }
-        std::vector<std::pair<i32, i32>> tmp;
-        for (i32 j = 0; j < n; j++) {
-            const i32 b = S.Sp[j], e = S.Sp[j + 1];
-            if (e - b < 2) continue;
-            bool sorted = true;
-            for (i32 t = b + 1; t < e && sorted; t++) sorted = S.Scol[t - 1] <= S.Scol[t];
-            if (sorted) continue;
-            tmp.resize((size_t)(e - b));
-            for (i32 t = b; t < e; t++) tmp[t - b] = {S.Scol[t], S.Smap[t]};
-            std::sort(tmp.begin(), tmp.end());
-            for (i32 t = b; t < e; t++) {
-                S.Scol[t] = tmp[t - b].first;
-                S.Smap[t] = tmp[t - b].second;
+        for (i32 j = 0; j < NFi; j++) S.Up[j + 1] += S.Up[j];
+        for (i32 j = 0; j < n; j++) S.Sp[j + 1] += S.Sp[j];
+        S.nnzU = S.Up[NFi];
+        S.nnzS = S.Sp[n];
+        S.Ucol.resize((size_t)S.nnzU + 1);
+        S.Umap.resize((size_t)S.nnzU + 1);
+        S.Scol.resize((size_t)S.nnzS + 1);
+        S.Smap.resize((size_t)S.nnzS + 1);
+        std::vector<i32> nu(S.Up.begin(), S.Up.end() - 1), ns(S.Sp.begin(), S.Sp.end() - 1);
+        for (i64 c = 0; c < n; c++)
+            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                const i32 pc = S.iperm[c], pr = S.iperm[Ai[p]];
+                const i32 lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
+                if (lo < NFi) {
+                    const i32 t = nu[lo]++;
+                    S.Ucol[t] = hi;
+                    S.Umap[t] = (i32)p;
+                }
+                if (hi >= NFi) {
+                    i32 t = ns[hi]++;
+                    S.Scol[t] = lo;
+                    S.Smap[t] = (i32)p;
+                    if (lo >= NFi && lo != hi) {
+                        t = ns[lo]++;
+                        S.Scol[t] = hi;
+                        S.Smap[t] = (i32)p;
+                    }
+                }
             }
-        }
+        auto sort_rows = [](const std::vector<i32> &ptr, i32 nrows, std::vector<i32> &col, std::vector<i32> &map) {
+            std::vector<std::pair<i32, i32>> tmp;
+            for (i32 j = 0; j < nrows; j++) {
+                const i32 b = ptr[j], e = ptr[j + 1];
+                if (e - b < 2) continue;
+                bool sorted = true;
+                for (i32 t = b + 1; t < e && sorted; t++) sorted = col[t - 1] <= col[t];
+                if (sorted) continue;
+                tmp.resize((size_t)(e - b));
+                for (i32 t = b; t < e; t++) tmp[t - b] = {col[t], map[t]};
+                std::sort(tmp.begin(), tmp.end());
+                for (i32 t = b; t < e; t++) {
+                    col[t] = tmp[t - b].first;
+                    map[t] = tmp[t - b].second;
+                }
+            }
+        };
+        sort_rows(S.Up, NFi, S.Ucol, S.Umap);
+        sort_rows(S.Sp, (i32)n, S.Scol, S.Smap);
     }
     // ---- per-level work lists ----------------------------------------------
     {
@@ -438,7 +462,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             bwd.close_level();
         }
         ListBuilder smv(S.smv);
-        for (i32 j = 0; j < n; j++) {
+        for (i32 j = S.NF; j < n; j++) {
             const i32 len = S.Sp[j + 1] - S.Sp[j];
             if (len > B_MIN) smv.add_B(j, S.Sp[j], S.Sp[j + 1]);
             else if (len > T_MAX) smv.add_W(j);

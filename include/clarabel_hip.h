@@ -180,8 +180,10 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
                         const int64_t *cone_dims2, const double *cone_alphas_or_null,
                         const chip_settings *settings, const uint64_t *perm_or_null);
 void chip_kkt_destroy(chip_kkt *h);
-/* dimensions: out[0]=n out[1]=m out[2]=p out[3]=N out[4]=nnzK out[5]=nHsblocks */
-int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[6]);
+/* dimensions: out[0]=n out[1]=m out[2]=p out[3]=N out[4]=nnzK out[5]=nHsblocks
+ * out[6]=NF (nodes inside subtree bundles; N-NF = "top" nodes) out[7]=nnzU (K entries whose
+ * smaller index is a bundle node: what the bundle residual kernel streams) */
+int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[8]);
 /* the assembled (unpermuted, triu) KKT matrix and the LDLDataMap index
  * vectors (datamaps.rs:350-362) -- host copies for tests / Rust-side mirrors. */
 int32_t chip_kkt_get_matrix(const chip_kkt *h, uint64_t *colptr, uint64_t *rowval, double *nzval);

@@ -407,6 +407,29 @@ class HipKKTSolver:
     def mul_Hs_dev(self, y_ptr, x_ptr):
         _check(lib().chip_kkt_mul_Hs_dev(self._h, C.c_void_p(y_ptr), C.c_void_p(x_ptr)), "mul_Hs_dev")
 
+    # -- CompositeCone operations either side of the solve (device pointers, m doubles) -----
+    def affine_ds_dev(self, ds_ptr, s_ptr):
+        _check(lib().chip_kkt_affine_ds_dev(self._h, C.c_void_p(ds_ptr), C.c_void_p(s_ptr)), "affine_ds")
+
+    def combined_ds_shift_dev(self, shift_ptr, step_z_ptr, step_s_ptr, sigma_mu):
+        _check(lib().chip_kkt_combined_ds_shift_dev(self._h, C.c_void_p(shift_ptr), C.c_void_p(step_z_ptr),
+                                                    C.c_void_p(step_s_ptr), C.c_double(sigma_mu)), "combined_ds_shift")
+
+    def ds_from_dz_offset_dev(self, out_ptr, ds_ptr, z_ptr):
+        _check(lib().chip_kkt_ds_from_dz_offset_dev(self._h, C.c_void_p(out_ptr), C.c_void_p(ds_ptr),
+                                                    C.c_void_p(z_ptr)), "ds_from_dz_offset")
+
+    def step_length_dev(self, dz_ptr, ds_ptr, z_ptr, s_ptr, alpha_max=1.0):
+        a = C.c_double(0)
+        _check(lib().chip_kkt_step_length_dev(self._h, C.c_void_p(dz_ptr), C.c_void_p(ds_ptr), C.c_void_p(z_ptr),
+                                              C.c_void_p(s_ptr), C.c_double(alpha_max), C.byref(a)), "step_length")
+        return a.value
+
+    def margins_dev(self, z_ptr):
+        a, b = C.c_double(0), C.c_double(0)
+        _check(lib().chip_kkt_margins_dev(self._h, C.c_void_p(z_ptr), C.byref(a), C.byref(b)), "margins")
+        return a.value, b.value
+
     def linear_solver_info(self):
         info = Info()
         _check(lib().chip_kkt_info(self._h, C.byref(info)), "info")

@@ -77,6 +77,9 @@ struct chip_kkt {
     double last_eps = 0;
     bool scaling_pending_check = false;
     bool x_holds_b = false; // x was initialised with the rhs by setrhs (skips a D2D copy)
+    double *d_partial = nullptr; // per-block partial minima / sums of the cone reductions
+    int partial_cap = 0;
+    std::vector<double> h_partial;
 };
 
 extern "C" {
@@ -736,6 +739,99 @@ int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     dev::cones_mul_Hs(E.stream, h->nn_rows, h->nn_count, h->soc, h->zero_rows, h->zero_count, y_dev, x_dev);
     dev::ns3_mul_hs(E.stream, h->ns3, y_dev, x_dev);
     CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+#define NEED_SYMMETRIC(h)                                                                      \
+    if ((h)->has_hostHs || (h)->ns3.ncones)                                                    \
+    return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: only Zero/Nonnegative/SecondOrder cones")
+
+int32_t chip_kkt_affine_ds_dev(chip_kkt *h, double *ds_dev, const double *s_dev) {
+    if (!h || !ds_dev) return CHIP_ERR_ARG;
+    (void)s_dev;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    NEED_SYMMETRIC(h);
+    CHIP_HIP(hipSetDevice(E.device));
+    dev::cone_affine_ds(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, ds_dev);
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+int32_t chip_kkt_combined_ds_shift_dev(chip_kkt *h, double *shift_dev, double *step_z_dev, double *step_s_dev,
+                                       double sigma_mu) {
+    if (!h || !shift_dev || !step_z_dev || !step_s_dev) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    NEED_SYMMETRIC(h);
+    CHIP_HIP(hipSetDevice(E.device));
+    dev::cone_combined_ds_shift(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, shift_dev,
+                                step_z_dev, step_s_dev, sigma_mu);
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+int32_t chip_kkt_ds_from_dz_offset_dev(chip_kkt *h, double *out_dev, const double *ds_dev, const double *z_dev) {
+    if (!h || !out_dev || !ds_dev || !z_dev) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    NEED_SYMMETRIC(h);
+    CHIP_HIP(hipSetDevice(E.device));
+    dev::cone_ds_from_dz_offset(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, out_dev,
+                                ds_dev, z_dev);
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+static int ensure_partials(chip_kkt *h) {
+    if (h->d_partial) return CHIP_OK;
+    h->partial_cap = 1024 + h->soc.ncones;
+    int rc = h->E.alloc(&h->d_partial, (size_t)h->partial_cap * 2);
+    if (rc) return rc;
+    h->h_partial.resize((size_t)h->partial_cap * 2);
+    return CHIP_OK;
+}
+int32_t chip_kkt_step_length_dev(chip_kkt *h, const double *dz_dev, const double *ds_dev, const double *z_dev,
+                                 const double *s_dev, double alpha_max, double *alpha_out) {
+    if (!h || !alpha_out) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    NEED_SYMMETRIC(h);
+    CHIP_HIP(hipSetDevice(E.device));
+    int rc = ensure_partials(h);
+    if (rc) return rc;
+    const int used = dev::cone_step_length(E.stream, h->nn_rows, h->nn_count, h->soc, dz_dev, ds_dev, z_dev, s_dev,
+                                           alpha_max, h->d_partial, 1024);
+    double a = alpha_max;
+    if (used) {
+        CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)used * sizeof(double),
+                                hipMemcpyDeviceToHost, E.stream));
+        CHIP_HIP(hipStreamSynchronize(E.stream));
+        for (int i = 0; i < used; i++) a = std::min(a, h->h_partial[i]); // T::min: NaN-ignoring like f64::min
+    }
+    *alpha_out = a;
+    return CHIP_OK;
+}
+int32_t chip_kkt_margins_dev(chip_kkt *h, const double *z_dev, double *alpha_out, double *beta_out) {
+    if (!h || !alpha_out || !beta_out) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    NEED_SYMMETRIC(h);
+    CHIP_HIP(hipSetDevice(E.device));
+    int rc = ensure_partials(h);
+    if (rc) return rc;
+    double *pmin = h->d_partial, *psum = h->d_partial + h->partial_cap;
+    const int used = dev::cone_margins(E.stream, h->nn_rows, h->nn_count, h->soc, z_dev, pmin, psum, 1024);
+    double a = 1.7976931348623157e308, b = 0.0; // T::max_value(), compositecone.rs:198
+    if (used) {
+        CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), pmin, (size_t)used * sizeof(double), hipMemcpyDeviceToHost,
+                                E.stream));
+        CHIP_HIP(hipMemcpyAsync(h->h_partial.data() + h->partial_cap, psum, (size_t)used * sizeof(double),
+                                hipMemcpyDeviceToHost, E.stream));
+        CHIP_HIP(hipStreamSynchronize(E.stream));
+        for (int i = 0; i < used; i++) {
+            a = std::min(a, h->h_partial[i]);
+            b += h->h_partial[h->partial_cap + i];
+        }
+    }
+    *alpha_out = a;
+    *beta_out = b;
     return CHIP_OK;
 }
 int32_t chip_kkt_info(const chip_kkt *h, chip_info *info) {

@@ -1281,11 +1281,241 @@ __global__ __launch_bounds__(WG) void k_soc_mul_hs(SocView v, double *y, const d
     }
 }
 
+// ---------------------------------------------------------------------------
+// step / right-hand-side operations of the symmetric cones:
+// affine_ds, combined_ds_shift, ds_from_dz_offset, step_length, margins
+// ---------------------------------------------------------------------------
+// Nonnegative cone, elementwise (nonnegativecone.rs:110-153, symmetric_common.rs:53-84)
+//   OP 0: ds = lam*lam            OP 1: combined shift (dz <- w dz, ds <- ds/w, shift = ds*dz - sm)
+//   OP 2: out = ds / z            OP 3: zero fill (Zero cone rows)
+template <int OP>
+__global__ __launch_bounds__(WG) void k_nn_step_ops(const int *__restrict__ rows, int count,
+                                                    const double *__restrict__ w,
+                                                    const double *__restrict__ lam, double *o0, double *o1,
+                                                    double *o2, const double *__restrict__ i0, double sm) {
+    for (int t = logical_block() * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
+        const int r = rows[t];
+        if (OP == 0) o0[r] = lam[r] * lam[r];
+        else if (OP == 1) {
+            const double dz = 1.0 * (o1[r] * w[r]);
+            const double dsv = 1.0 * (o2[r] / w[r]);
+            o1[r] = dz;
+            o2[r] = dsv;
+            o0[r] = dsv * dz + (-sm);
+        } else if (OP == 2) o0[r] = i0[r] / o1[r];
+        else o0[r] = 0.0;
+    }
+}
+// per-block partial minima of the NN step lengths (nonnegativecone.rs:128-153)
+__global__ __launch_bounds__(WG) void k_nn_step_length(const int *__restrict__ rows, int count,
+                                                       const double *__restrict__ dz,
+                                                       const double *__restrict__ ds,
+                                                       const double *__restrict__ z,
+                                                       const double *__restrict__ s, double amax,
+                                                       double *partial) {
+    __shared__ double red[16];
+    double a = amax;
+    for (int t = blockIdx.x * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
+        const int r = rows[t];
+        if (dz[r] < 0.0) a = fmin(a, -z[r] / dz[r]);
+        if (ds[r] < 0.0) a = fmin(a, -s[r] / ds[r]);
+    }
+    a = -block_max(-a, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+// per-block partial (min z, sum max(z,0)) of NN rows (nonnegativecone.rs:58-62)
+__global__ __launch_bounds__(WG) void k_nn_margins(const int *__restrict__ rows, int count,
+                                                   const double *__restrict__ z, double *pmin, double *psum) {
+    __shared__ double red[16];
+    double a = 1.7976931348623157e308, b = 0.0;
+    for (int t = blockIdx.x * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
+        const double zi = z[rows[t]];
+        a = fmin(a, zi);
+        b += fmax(zi, 0.0);
+    }
+    a = -block_max(-a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        pmin[blockIdx.x] = a;
+        psum[blockIdx.x] = b;
+    }
+}
+
+__device__ __forceinline__ double block_dot_tail(const double *a, const double *b, int n, double *red) {
+    double s = 0.0;
+    for (int i = 1 + threadIdx.x; i < n; i += WG) s += a[i] * b[i];
+    return block_sum(s, red);
+}
+// socone.rs:421-495 on quantities already reduced by the workgroup
+__device__ __forceinline__ double soc_step_roots(double x0, double y0, double x1n, double y1n, double x1y1,
+                                                 double amax) {
+    if (x0 >= 0.0 && y0 < 0.0) amax = fmin(amax, -x0 / y0);
+    const double a = (y0 - y1n) * (y0 + y1n);
+    const double b = 2.0 * (x0 * y0 - x1y1);
+    const double cres = (x0 - x1n) * (x0 + x1n);
+    const double c = cres > 0.0 ? cres : 0.0;
+    const double d = b * b - 4.0 * a * c;
+    if ((a > 0.0 && b > 0.0) || d < 0.0) return amax;
+    if (a == 0.0) return amax;
+    if (c == 0.0) return a >= 0.0 ? amax : 0.0;
+    const double t = (b >= 0.0) ? (-b - sqrt(d)) : (-b + sqrt(d));
+    double r1 = (2.0 * c) / t, r2 = t / (2.0 * a);
+    if (r1 < 0.0) r1 = INFINITY;
+    if (r2 < 0.0) r2 = INFINITY;
+    return fmin(amax, fmin(r1, r2));
+}
+// one workgroup per second-order cone.
+//   OP 0 affine_ds (socone.rs:258-260,360-367)      OP 1 combined_ds_shift (symmetric_common.rs:53-84,
+//   OP 2 ds_from_dz_offset (socone.rs:266-287)           socone.rs:504-530)
+//   OP 3 step_length -> partial[c] (socone.rs:289-302,421-495)
+//   OP 4 margins -> pmin[c] = z0 - ||z1||, psum[c] = max(0, .) (socone.rs:104-108)
+template <int OP>
+__global__ __launch_bounds__(WG) void k_soc_step_ops(SocView v, double *o0, double *o1, double *o2,
+                                                     const double *__restrict__ i0,
+                                                     const double *__restrict__ i1,
+                                                     const double *__restrict__ i2,
+                                                     const double *__restrict__ i3, double sc,
+                                                     double *partial, double *partial2) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c], off = v.start[c], tid = threadIdx.x;
+    const double *w = v.w + off, *lam = v.lam + off;
+    const double eta = v.eta[8 * c];
+    if (OP == 0) {
+        double *ds = o0 + off;
+        double dd = 0.0;
+        for (int i = tid; i < n; i += WG) dd += lam[i] * lam[i];
+        dd = block_sum(dd, red);
+        const double l0 = lam[0];
+        for (int i = tid; i < n; i += WG) ds[i] = (i == 0) ? dd : l0 * lam[i] + l0 * lam[i];
+    } else if (OP == 1) {
+        double *sh = o0 + off, *dz = o1 + off, *dsv = o2 + off;
+        // dz <- W dz
+        const double zeta = block_dot_tail(w, dz, n, red);
+        const double x0 = dz[0];
+        const double cw = x0 + zeta / (1.0 + w[0]);
+        // ds <- W^-1 ds
+        const double zeti = block_dot_tail(w, dsv, n, red);
+        const double s0 = dsv[0];
+        const double ci = -s0 + zeti / (1.0 + w[0]);
+        __syncthreads();
+        for (int i = tid; i < n; i += WG) {
+            double a, b;
+            if (i == 0) {
+                a = (1.0 * eta) * (w[0] * x0 + zeta);
+                b = (1.0 / eta) * (w[0] * s0 - zeti);
+            } else {
+                a = (1.0 * eta * cw) * w[i];
+                a = (1.0 * eta) * dz[i] + 1.0 * a;
+                b = (1.0 / eta * ci) * w[i];
+                b = (1.0 / eta) * dsv[i] + 1.0 * b;
+            }
+            dz[i] = a;
+            dsv[i] = b;
+        }
+        __syncthreads();
+        // shift = ds o dz, shift[0] -= sigma*mu
+        double dd = 0.0;
+        for (int i = tid; i < n; i += WG) dd += dsv[i] * dz[i];
+        dd = block_sum(dd, red);
+        const double y0 = dsv[0], z0 = dz[0];
+        for (int i = tid; i < n; i += WG) sh[i] = (i == 0) ? dd + (-sc) : y0 * dz[i] + z0 * dsv[i];
+    } else if (OP == 2) {
+        double *out = o0 + off;
+        const double *d = i0 + off, *z = i1 + off;
+        const double z1n = block_norm_tail(z, n, red);
+        const double resz = (z[0] - z1n) * (z[0] + z1n);
+        const double l1d1 = block_dot_tail(lam, d, n, red);
+        const double w1d1 = block_dot_tail(w, d, n, red);
+        const double cc = lam[0] * d[0] - l1d1;
+        const double scale = cc / resz;
+        const double rl = 1.0 / lam[0];
+        for (int i = tid; i < n; i += WG) {
+            double o = (i == 0) ? z[0] : -z[i];
+            o *= scale;
+            if (i == 0) o += eta * w1d1;
+            else o += eta * (d[i] + w1d1 / (1.0 + w[0]) * w[i]);
+            out[i] = o * rl;
+        }
+    } else if (OP == 3) {
+        const double *dz = i0 + off, *dsv = i1 + off, *z = i2 + off, *s = i3 + off;
+        const double z1n = block_norm_tail(z, n, red), dz1n = block_norm_tail(dz, n, red);
+        const double zdz = block_dot_tail(z, dz, n, red);
+        const double s1n = block_norm_tail(s, n, red), ds1n = block_norm_tail(dsv, n, red);
+        const double sds = block_dot_tail(s, dsv, n, red);
+        if (tid == 0) {
+            const double az = soc_step_roots(z[0], dz[0], z1n, dz1n, zdz, sc);
+            const double as = soc_step_roots(s[0], dsv[0], s1n, ds1n, sds, sc);
+            partial[c] = fmin(az, as);
+        }
+    } else {
+        const double *z = i0 + off;
+        const double z1n = block_norm_tail(z, n, red);
+        if (tid == 0) {
+            const double a = z[0] - z1n;
+            partial[c] = a;
+            partial2[c] = fmax(0.0, a);
+        }
+    }
+}
+
 } // namespace
 
 // ===========================================================================
 // launch wrappers
 // ===========================================================================
+void cone_affine_ds(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,
+                    double *ds) {
+    if (nn) k_nn_step_ops<0><<<grid_for(nn) > 2048 ? 2048 : grid_for(nn), WG, 0, s>>>(nn_rows, nn, v.w, v.lam, ds, nullptr, nullptr, nullptr, 0.0);
+    if (nz) k_nn_step_ops<3><<<grid_for(nz) > 2048 ? 2048 : grid_for(nz), WG, 0, s>>>(zero_rows, nz, v.w, v.lam, ds, nullptr, nullptr, nullptr, 0.0);
+    if (v.ncones) k_soc_step_ops<0><<<v.ncones, WG, 0, s>>>(v, ds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, nullptr);
+}
+void cone_combined_ds_shift(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz,
+                            const SocView &v, double *shift, double *step_z, double *step_s, double sigma_mu) {
+    if (nn) k_nn_step_ops<1><<<grid_for(nn) > 2048 ? 2048 : grid_for(nn), WG, 0, s>>>(nn_rows, nn, v.w, v.lam, shift, step_z, step_s, nullptr, sigma_mu);
+    if (nz) k_nn_step_ops<3><<<grid_for(nz) > 2048 ? 2048 : grid_for(nz), WG, 0, s>>>(zero_rows, nz, v.w, v.lam, shift, nullptr, nullptr, nullptr, 0.0);
+    if (v.ncones) k_soc_step_ops<1><<<v.ncones, WG, 0, s>>>(v, shift, step_z, step_s, nullptr, nullptr, nullptr, nullptr, sigma_mu, nullptr, nullptr);
+}
+void cone_ds_from_dz_offset(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz,
+                            const SocView &v, double *out, const double *ds, const double *z) {
+    if (nn) k_nn_step_ops<2><<<grid_for(nn) > 2048 ? 2048 : grid_for(nn), WG, 0, s>>>(nn_rows, nn, v.w, v.lam, out, const_cast<double *>(z), nullptr, ds, 0.0);
+    if (nz) k_nn_step_ops<3><<<grid_for(nz) > 2048 ? 2048 : grid_for(nz), WG, 0, s>>>(zero_rows, nz, v.w, v.lam, out, nullptr, nullptr, nullptr, 0.0);
+    if (v.ncones) k_soc_step_ops<2><<<v.ncones, WG, 0, s>>>(v, out, nullptr, nullptr, ds, z, nullptr, nullptr, 0.0, nullptr, nullptr);
+}
+int cone_step_length(hipStream_t s, const int *nn_rows, int nn, const SocView &v, const double *dz,
+                     const double *ds, const double *z, const double *sv, double amax, double *partial,
+                     int partial_cap) {
+    int used = 0;
+    if (nn) {
+        int nb = (nn + WG - 1) / WG;
+        if (nb > 1024) nb = 1024;
+        if (nb > partial_cap) nb = partial_cap;
+        k_nn_step_length<<<nb, WG, 0, s>>>(nn_rows, nn, dz, ds, z, sv, amax, partial);
+        used = nb;
+    }
+    if (v.ncones) {
+        k_soc_step_ops<3><<<v.ncones, WG, 0, s>>>(v, nullptr, nullptr, nullptr, dz, ds, z, sv, amax, partial + used, nullptr);
+        used += v.ncones;
+    }
+    return used;
+}
+int cone_margins(hipStream_t s, const int *nn_rows, int nn, const SocView &v, const double *z, double *pmin,
+                 double *psum, int partial_cap) {
+    int used = 0;
+    if (nn) {
+        int nb = (nn + WG - 1) / WG;
+        if (nb > 1024) nb = 1024;
+        if (nb > partial_cap) nb = partial_cap;
+        k_nn_margins<<<nb, WG, 0, s>>>(nn_rows, nn, z, pmin, psum);
+        used = nb;
+    }
+    if (v.ncones) {
+        k_soc_step_ops<4><<<v.ncones, WG, 0, s>>>(v, nullptr, nullptr, nullptr, z, nullptr, nullptr, nullptr, 0.0, pmin + used, psum + used);
+        used += v.ncones;
+    }
+    return used;
+}
 void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int nnzL, double *Lx,
                   double *D, const int8_t *dsigns, const double *eps, const int *fill_idx, int nfill,
                   int *status) {

@@ -136,6 +136,19 @@ void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, co
                  const int *mapHs, double *Kx);
 void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv);
 void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx);
+// step / rhs operations of the symmetric cones (Zero rows, Nonnegative rows, SecondOrder cones)
+void cone_affine_ds(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,
+                    double *ds);
+void cone_combined_ds_shift(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz,
+                            const SocView &v, double *shift, double *step_z, double *step_s, double sigma_mu);
+void cone_ds_from_dz_offset(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz,
+                            const SocView &v, double *out, const double *ds, const double *z);
+// both return the number of partial results written (to be min-/sum-reduced by the host)
+int cone_step_length(hipStream_t s, const int *nn_rows, int nn, const SocView &v, const double *dz,
+                     const double *ds, const double *z, const double *sv, double amax, double *partial,
+                     int partial_cap);
+int cone_margins(hipStream_t s, const int *nn_rows, int nn, const SocView &v, const double *z, double *pmin,
+                 double *psum, int partial_cap);
 void cones_mul_Hs(hipStream_t s, const int *nn_rows, int nn_count, const SocView &v,
                   const int *zero_rows, int zero_count, double *y, const double *x);
 

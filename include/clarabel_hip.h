@@ -219,6 +219,25 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval);
 /* CompositeCone::mul_Hs (compositecone.rs:259-264) for the device-held cones:
  * y = Hs x, m doubles, device pointers. */
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev);
+/* ---- the cone operations either side of the KKT solve, for problems whose
+ * cones are all symmetric and device-held (Zero / Nonnegative / SecondOrder); m-vectors in HBM.
+ * CHIP_ERR_UNSUPPORTED otherwise.
+ *   affine_ds            compositecone.rs:266-272   (nonnegativecone.rs:110-115, socone.rs:258-260)
+ *   combined_ds_shift    compositecone.rs:274-289   (symmetric_common.rs:53-84): step_z and step_s are
+ *                        overwritten by W dz and W^-1 ds exactly as in the reference
+ *   ds_from_dz_offset    compositecone.rs:291-299   (nonnegativecone.rs:122-126, socone.rs:266-287)
+ *   step_length          compositecone.rs:300-340   (nonnegativecone.rs:128-153, socone.rs:289-302,421-495)
+ *                        *alpha_out (host) = the common (alpha_z, alpha_s) of the composite cone
+ *   margins              compositecone.rs:197-206   (nonnegativecone.rs:58-62, socone.rs:104-108)        */
+int32_t chip_kkt_affine_ds_dev(chip_kkt *h, double *ds_dev, const double *s_dev);
+int32_t chip_kkt_combined_ds_shift_dev(chip_kkt *h, double *shift_dev, double *step_z_dev,
+                                       double *step_s_dev, double sigma_mu);
+int32_t chip_kkt_ds_from_dz_offset_dev(chip_kkt *h, double *out_dev, const double *ds_dev,
+                                       const double *z_dev);
+int32_t chip_kkt_step_length_dev(chip_kkt *h, const double *dz_dev, const double *ds_dev,
+                                 const double *z_dev, const double *s_dev, double alpha_max,
+                                 double *alpha_out);
+int32_t chip_kkt_margins_dev(chip_kkt *h, const double *z_dev, double *alpha_out, double *beta_out);
 int32_t chip_kkt_info(const chip_kkt *h, chip_info *info);
 int32_t chip_kkt_get_perm(const chip_kkt *h, uint64_t *perm);
 int32_t chip_kkt_get_symbolic(const chip_kkt *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,

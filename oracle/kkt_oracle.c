@@ -555,6 +555,166 @@ void orc_cones_mul_Hs(const orc_cones *cs, double *y, const double *x) {
 const double *orc_cone_Hs3(const orc_cones *cs, int64_t i) { return cs->c[i].Hs3; }
 const double *orc_cone_Hdual(const orc_cones *cs, int64_t i) { return cs->c[i].Hdual; }
 const double *orc_cone_grad3(const orc_cones *cs, int64_t i) { return cs->c[i].grad3; }
+/* ---- step / right-hand-side operations of the symmetric cones -------- */
+/* socone.rs:504-530 (fast W / W^-1 products of the ECOS paper) */
+static void soc_mul_W(double *y, const double *x, double a, double b, const double *w, double eta, int64_t n) {
+    double zeta = dotp(w + 1, x + 1, n - 1);
+    double c = x[0] + zeta / (1.0 + w[0]);
+    y[0] = (a * eta) * (w[0] * x[0] + zeta) + b * y[0];
+    for (int64_t i = 1; i < n; i++) y[i] = (a * eta * c) * w[i] + b * y[i];
+    for (int64_t i = 1; i < n; i++) y[i] = (a * eta) * x[i] + 1.0 * y[i];
+}
+static void soc_mul_Winv(double *y, const double *x, double a, double b, const double *w, double eta, int64_t n) {
+    double zeta = dotp(w + 1, x + 1, n - 1);
+    double c = -x[0] + zeta / (1.0 + w[0]);
+    y[0] = (a / eta) * (w[0] * x[0] - zeta) + b * y[0];
+    for (int64_t i = 1; i < n; i++) y[i] = (a / eta * c) * w[i] + b * y[i];
+    for (int64_t i = 1; i < n; i++) y[i] = (a / eta) * x[i] + 1.0 * y[i];
+}
+/* socone.rs:360-367 */
+static void soc_circ_op(double *x, const double *y, const double *z, int64_t n) {
+    x[0] = dotp(y, z, n);
+    double y0 = y[0], z0 = z[0];
+    for (int64_t i = 1; i < n; i++) x[i] = y0 * z[i] + z0 * y[i];
+}
+/* compositecone.rs:266-272 affine_ds: nonnegativecone.rs:110-115, socone.rs:258-260, zerocone.rs:102-104 */
+void orc_cones_affine_ds(const orc_cones *cs, double *ds, const double *s) {
+    (void)s;
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        double *d = ds + c->cone_start;
+        if (c->tag == CONE_ZERO) {
+            for (int64_t k = 0; k < c->numel; k++) d[k] = 0.0;
+        } else if (c->tag == CONE_NONNEG) {
+            for (int64_t k = 0; k < c->numel; k++) d[k] = c->lam[k] * c->lam[k];
+        } else if (c->tag == CONE_SOC) {
+            soc_circ_op(d, c->lam, c->lam, c->numel);
+        }
+    }
+}
+/* compositecone.rs:274-289 + symmetric_common.rs:53-84 (NN, SOC), zerocone.rs:106-110 */
+void orc_cones_combined_ds_shift(const orc_cones *cs, double *shift, double *step_z, double *step_s,
+                                 double sigma_mu) {
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        double *sh = shift + c->cone_start, *dz = step_z + c->cone_start, *dsv = step_s + c->cone_start;
+        int64_t n = c->numel;
+        if (c->tag == CONE_ZERO) {
+            for (int64_t k = 0; k < n; k++) sh[k] = 0.0;
+        } else if (c->tag == CONE_NONNEG) {
+            for (int64_t k = 0; k < n; k++) sh[k] = dz[k];
+            for (int64_t k = 0; k < n; k++) dz[k] = 1.0 * (sh[k] * c->w[k]) + 0.0 * dz[k]; /* mul_W :188-194 */
+            for (int64_t k = 0; k < n; k++) sh[k] = dsv[k];
+            for (int64_t k = 0; k < n; k++) dsv[k] = 1.0 * (sh[k] / c->w[k]) + 0.0 * dsv[k]; /* mul_Winv */
+            for (int64_t k = 0; k < n; k++) sh[k] = dsv[k] * dz[k];                          /* circ_op */
+            for (int64_t k = 0; k < n; k++) sh[k] = sh[k] + (-sigma_mu);                      /* translate */
+        } else if (c->tag == CONE_SOC) {
+            memcpy(sh, dz, (size_t)n * sizeof(double));
+            soc_mul_W(dz, sh, 1.0, 0.0, c->w, c->eta, n);
+            memcpy(sh, dsv, (size_t)n * sizeof(double));
+            soc_mul_Winv(dsv, sh, 1.0, 0.0, c->w, c->eta, n);
+            soc_circ_op(sh, dsv, dz, n);
+            sh[0] += -sigma_mu; /* scaled_unit_shift, socone.rs:110-112 */
+        }
+    }
+}
+/* compositecone.rs:291-299: nonnegativecone.rs:122-126, socone.rs:266-287, zerocone.rs:112-114 */
+void orc_cones_ds_from_dz_offset(const orc_cones *cs, double *out, const double *ds, const double *z) {
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        double *o = out + c->cone_start;
+        const double *d = ds + c->cone_start, *zi = z + c->cone_start;
+        int64_t n = c->numel;
+        if (c->tag == CONE_ZERO) {
+            for (int64_t k = 0; k < n; k++) o[k] = 0.0;
+        } else if (c->tag == CONE_NONNEG) {
+            for (int64_t k = 0; k < n; k++) o[k] = d[k] / zi[k];
+        } else if (c->tag == CONE_SOC) {
+            double resz = soc_residual(zi, n);
+            double l1d1 = dotp(c->lam + 1, d + 1, n - 1);
+            double w1d1 = dotp(c->w + 1, d + 1, n - 1);
+            for (int64_t k = 0; k < n; k++) o[k] = -zi[k];
+            o[0] = zi[0];
+            double cc = c->lam[0] * d[0] - l1d1;
+            double sc = cc / resz;
+            for (int64_t k = 0; k < n; k++) o[k] *= sc;
+            o[0] += c->eta * w1d1;
+            for (int64_t k = 1; k < n; k++) o[k] += c->eta * (d[k] + w1d1 / (1.0 + c->w[0]) * c->w[k]);
+            double rl = 1.0 / c->lam[0];
+            for (int64_t k = 0; k < n; k++) o[k] *= rl;
+        }
+    }
+}
+/* socone.rs:421-495 */
+static double soc_step_component(const double *x, const double *y, double amax, int64_t n) {
+    if (x[0] >= 0.0 && y[0] < 0.0) {
+        double t = -x[0] / y[0];
+        amax = amax < t ? amax : t;
+    }
+    double a = soc_residual(y, n);
+    double b = 2.0 * (x[0] * y[0] - dotp(x + 1, y + 1, n - 1));
+    double cres = soc_residual(x, n);
+    double c = cres > 0.0 ? cres : 0.0;
+    double d = b * b - 4.0 * a * c;
+    if ((a > 0.0 && b > 0.0) || d < 0.0) return amax;
+    if (a == 0.0) return amax;
+    if (c == 0.0) return a >= 0.0 ? amax : 0.0;
+    double t = (b >= 0.0) ? (-b - sqrt(d)) : (-b + sqrt(d));
+    double r1 = (2.0 * c) / t, r2 = t / (2.0 * a);
+    if (r1 < 0.0) r1 = INFINITY;
+    if (r2 < 0.0) r2 = INFINITY;
+    double r = r1 < r2 ? r1 : r2;
+    return amax < r ? amax : r;
+}
+/* compositecone.rs:300-340 for symmetric cones (Zero / NN / SOC): nonnegativecone.rs:128-153,
+ * socone.rs:289-302, zerocone.rs:116-127.  Returns alpha (= alpha_z = alpha_s of the composite). */
+double orc_cones_step_length(const orc_cones *cs, const double *dz, const double *ds, const double *z,
+                             const double *s, double amax) {
+    double alpha = amax;
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        const double *dzi = dz + c->cone_start, *dsi = ds + c->cone_start;
+        const double *zi = z + c->cone_start, *si = s + c->cone_start;
+        double az = alpha, as = alpha;
+        if (c->tag == CONE_NONNEG) {
+            for (int64_t k = 0; k < c->numel; k++) {
+                if (dzi[k] < 0.0) { double t = -zi[k] / dzi[k]; az = az < t ? az : t; }
+                if (dsi[k] < 0.0) { double t = -si[k] / dsi[k]; as = as < t ? as : t; }
+            }
+        } else if (c->tag == CONE_SOC) {
+            az = soc_step_component(zi, dzi, alpha, c->numel);
+            as = soc_step_component(si, dsi, alpha, c->numel);
+        }
+        double mn = az < as ? az : as;
+        alpha = alpha < mn ? alpha : mn;
+    }
+    return alpha;
+}
+/* CompositeCone::margins (compositecone.rs:130-152): (min over cones of alpha, sum of beta);
+ * nonnegativecone.rs:58-62, socone.rs:104-108, zerocone.rs margins = (inf, 0) */
+void orc_cones_margins(const orc_cones *cs, const double *z, double *alpha_out, double *beta_out) {
+    double alpha = 1.7976931348623157e308 /* T::max_value() */, beta = 0.0;
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        const double *zi = z + c->cone_start;
+        if (c->tag == CONE_NONNEG) {
+            double a = INFINITY, b = 0.0;
+            for (int64_t k = 0; k < c->numel; k++) {
+                a = a < zi[k] ? a : zi[k];
+                b += zi[k] > 0.0 ? zi[k] : 0.0;
+            }
+            alpha = alpha < a ? alpha : a;
+            beta += b;
+        } else if (c->tag == CONE_SOC) {
+            double a = zi[0] - orc_norm2(zi + 1, c->numel - 1);
+            alpha = alpha < a ? alpha : a;
+            beta += a > 0.0 ? a : 0.0;
+        }
+    }
+    *alpha_out = alpha;
+    *beta_out = beta;
+}
+
 /* state accessors for tests */
 double orc_cone_eta(const orc_cones *cs, int64_t i) { return cs->c[i].eta; }
 double orc_cone_d(const orc_cones *cs, int64_t i) { return cs->c[i].d; }

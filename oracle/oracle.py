@@ -53,6 +53,7 @@ def lib():
         L.orc_quad_form_triu.restype = C.c_double
         L.orc_cones_new.restype = C.c_void_p
         L.orc_cones_new_ex.restype = C.c_void_p
+        L.orc_cones_step_length.restype = C.c_double
         L.orc_wright_omega.restype = C.c_double
         for name in ("Hs3", "Hdual", "grad3"):
             getattr(L, "orc_cone_" + name).restype = P_F64
@@ -359,6 +360,35 @@ class Cones:
         y = np.zeros_like(x)
         lib().orc_cones_mul_Hs(self._h, _pf(y), _pf(x))
         return y
+
+    def affine_ds(self, s):
+        s = _af(s)
+        ds = np.zeros_like(s)
+        lib().orc_cones_affine_ds(self._h, _pf(ds), _pf(s))
+        return ds
+
+    def combined_ds_shift(self, step_z, step_s, sigma_mu):
+        """returns (shift, step_z', step_s') -- the reference overwrites the steps in place"""
+        dz, dsv = _af(step_z).copy(), _af(step_s).copy()
+        shift = np.zeros_like(dz)
+        lib().orc_cones_combined_ds_shift(self._h, _pf(shift), _pf(dz), _pf(dsv), C.c_double(sigma_mu))
+        return shift, dz, dsv
+
+    def ds_from_dz_offset(self, ds, z):
+        ds, z = _af(ds), _af(z)
+        out = np.zeros_like(ds)
+        lib().orc_cones_ds_from_dz_offset(self._h, _pf(out), _pf(ds), _pf(z))
+        return out
+
+    def step_length(self, dz, ds, z, s, alpha_max=1.0):
+        dz, ds, z, s = _af(dz), _af(ds), _af(z), _af(s)
+        return lib().orc_cones_step_length(self._h, _pf(dz), _pf(ds), _pf(z), _pf(s), C.c_double(alpha_max))
+
+    def margins(self, z):
+        z = _af(z)
+        a, b = C.c_double(0), C.c_double(0)
+        lib().orc_cones_margins(self._h, _pf(z), C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def numel_of(self, i):
         tag, dim, dim2 = self.specs[i][:3]

@@ -296,6 +296,54 @@ def test_mul_Hs_identity(hip, oracle):
     assert relerr(yt.numpy(), cones.mul_Hs(pr["z"])) <= 1e-12
 
 
+@pytest.mark.parametrize("late", [False, True])
+def test_cone_step_operations(hip, oracle, late):
+    """affine_ds / combined_ds_shift / ds_from_dz_offset / step_length / margins of the composite
+    cone (Zero + Nonnegative + sparse and dense SecondOrder cones) on the device vs the oracle"""
+    pr = problems.portfolio_socp(6, 257, seed=13, late=late)
+    extra = problems.portfolio_socp(3, 3, seed=14)  # SOC(4): dense-form cones
+    pr = problems.blockdiag([pr, extra])
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+    cones = oracle.Cones(pr["cones"])
+    s, z = pr["s"], pr["z"]
+    assert ks.update_scaling(s, z) and cones.update_scaling(s, z)
+    m = pr["m"]
+    rng = np.random.default_rng(5)
+    dz, dsv = 0.3 * rng.standard_normal(m), 0.3 * rng.standard_normal(m)
+    D = hip.DeviceArray
+    # affine_ds
+    out, d_s, d_z, d_ds = D(m), D(s), D(z), D(dsv)  # keep references: .ptr of a temporary dangles
+    ks.affine_ds_dev(out.ptr, d_s.ptr)
+    ks.synchronize()
+    assert relerr(out.numpy(), cones.affine_ds(s)) <= 1e-13
+    # combined_ds_shift (steps overwritten by W dz, W^-1 ds)
+    sh, tz, ts = D(m), D(dz), D(dsv)
+    ks.combined_ds_shift_dev(sh.ptr, tz.ptr, ts.ptr, 0.37)
+    ks.synchronize()
+    osh, oz, os_ = cones.combined_ds_shift(dz, dsv, 0.37)
+    assert relerr(tz.numpy(), oz) <= 1e-12 and relerr(ts.numpy(), os_) <= 1e-12
+    assert relerr(sh.numpy(), osh) <= 1e-11
+    # ds_from_dz_offset
+    o2 = D(m)
+    ks.ds_from_dz_offset_dev(o2.ptr, d_ds.ptr, d_z.ptr)
+    ks.synchronize()
+    assert relerr(o2.numpy(), cones.ds_from_dz_offset(dsv, z)) <= 1e-11
+    # step_length: several directions incl. ones that leave the cones quickly
+    for scale in (0.05, 1.0, 30.0):
+        t1, t2 = D(scale * dz), D(scale * dsv)
+        a_dev = ks.step_length_dev(t1.ptr, t2.ptr, d_z.ptr, d_s.ptr, 1.0)
+        a_ref = cones.step_length(scale * dz, scale * dsv, z, s, 1.0)
+        assert abs(a_dev - a_ref) <= 1e-12 * max(1.0, a_ref)
+    # margins
+    zz = z + 0.5 * rng.standard_normal(m)
+    d_zz = D(zz)
+    a_dev, b_dev = ks.margins_dev(d_zz.ptr)
+    a_ref, b_ref = cones.margins(zz)
+    assert abs(a_dev - a_ref) <= 1e-12 * max(1.0, abs(a_ref)) and abs(b_dev - b_ref) <= 1e-10 * max(1.0, b_ref)
+
+
 def test_full_scale_properties_c3(hip):
     """BASELINE config 3 at full size (n = 10^6): too big for the oracle in seconds, so check
     size-independent properties: residual of the refined solution against an independent

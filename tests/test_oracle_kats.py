@@ -401,3 +401,47 @@ def test_nonsymmetric_cone_scalings(oracle, tag, alpha):
     cd.update_scaling(s, z, 0.37, 1)
     assert np.allclose(cd.state(0)["Hs3"], 0.37 * Hd, rtol=1e-14)
     assert np.allclose(cd.get_Hs(), 0.37 * Hd, rtol=1e-14)
+
+
+def test_cone_step_ops_identities(oracle):
+    """no reference KATs for these either: identities of the Jordan algebra / NT scaling.
+    (symmetric_common.rs:53-96, socone.rs:258-302)"""
+    from tests import problems
+    pr = problems.portfolio_socp(3, 9, seed=21)
+    cones = oracle.Cones(pr["cones"])
+    s, z = pr["s"], pr["z"]
+    assert cones.update_scaling(s, z)
+    m = pr["m"]
+    # affine_ds = lambda o lambda, and for NT scalings  <lambda, lambda> = <s, z> per cone
+    ads = cones.affine_ds(s)
+    off = 0
+    for (tag, dim) in [(c[0], c[1]) for c in pr["cones"]]:
+        if tag == oracle.CONE_NONNEG:
+            assert np.allclose(ads[off:off + dim], s[off:off + dim] * z[off:off + dim], rtol=1e-12)
+        elif tag == oracle.CONE_SOC:
+            assert abs(ads[off] - s[off:off + dim] @ z[off:off + dim]) <= 1e-10 * abs(ads[off])
+        off += dim
+    # Delta s offset with ds = affine_ds equals s:  W'(lambda \ (lambda o lambda)) = W' lambda = s
+    assert np.allclose(cones.ds_from_dz_offset(ads, z), s, rtol=1e-9, atol=1e-11)
+    # combined shift with zero steps is -sigma*mu*e
+    sh, _, _ = cones.combined_ds_shift(np.zeros(m), np.zeros(m), 0.25)
+    e = np.zeros(m)
+    off = 0
+    for c in pr["cones"]:
+        if c[0] == oracle.CONE_NONNEG:
+            e[off:off + c[1]] = 1.0
+        elif c[0] == oracle.CONE_SOC:
+            e[off] = 1.0
+        off += c[1]
+    assert np.allclose(sh, -0.25 * e, atol=1e-15)
+    # step length: the boundary is hit exactly at alpha (some cone residual ~ 0), interior before
+    rng = np.random.default_rng(3)
+    dz, ds = rng.standard_normal(m), rng.standard_normal(m)
+    a = cones.step_length(dz, ds, z, s, 1e6)
+    assert 0 < a < 1e6
+    am, _ = cones.margins(z + 0.999 * a * dz)
+    ams, _ = cones.margins(s + 0.999 * a * ds)
+    assert min(am, ams) > 0
+    am2, _ = cones.margins(z + 1.001 * a * dz)
+    ams2, _ = cones.margins(s + 1.001 * a * ds)
+    assert min(am2, ams2) < 0

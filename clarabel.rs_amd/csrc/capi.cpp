@@ -67,7 +67,8 @@ struct chip_kkt {
     int *nn_rows = nullptr, *nn_hsidx = nullptr, *zero_rows = nullptr;
     dev::SocView soc{};
     dev::Ns3View ns3{};      // Exponential / Power cones
-    bool has_hostHs = false; // cones whose Hs must come from the host (PSD)
+    dev::PsdView psd{};      // PSD triangle cones with matrix side <= 64
+    bool has_hostHs = false; // cones whose Hs must come from the host (PSD with side > 64)
     double *d_s = nullptr, *d_z = nullptr, *d_w = nullptr, *d_lam = nullptr;
     double *d_rhs = nullptr, *d_lhs = nullptr; // n+m staging
     double *bp = nullptr, *x = nullptr, *e = nullptr, *dx = nullptr; // N, permuted numbering
@@ -349,7 +350,9 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
 
     // ---- cone work lists ----------------------------------------------------
     std::vector<int> nn_rows, nn_hs, zero_rows, s_start, s_dim, s_hs, s_sidx, s_ptr, mapU, mapV, mapD;
-    std::vector<int> n3_start, n3_hs, n3_tag;
+    std::vector<int> n3_start, n3_hs, n3_tag, pd_start, pd_dim, pd_hs, pd_off;
+    i64 pd_state = 0;
+    int pd_max = 0;
     std::vector<double> n3_alpha;
     for (const ConeSpec &c : K.cones) {
         if (c.tag == CHIP_CONE_NONNEGATIVE) {
@@ -373,9 +376,35 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
             if (c.tag == CHIP_CONE_POWER && !(al > 0.0 && al < 1.0))
                 return fail(CHIP_ERR_ARG, "PowerConeT exponent must lie in (0,1)");
             n3_alpha.push_back(al);
+        } else if (c.tag == CHIP_CONE_PSDTRIANGLE && c.dim <= 64) {
+            pd_start.push_back((int)c.start);
+            pd_dim.push_back((int)c.dim);
+            pd_hs.push_back((int)c.block_start);
+            pd_off.push_back((int)pd_state);
+            pd_state += c.dim * c.dim + c.dim;
+            pd_max = std::max<int>(pd_max, (int)c.dim);
         } else {
             h->has_hostHs = true;
         }
+    }
+    {
+        dev::PsdView &pv = h->psd;
+        pv.ncones = (int)pd_start.size();
+        pv.maxdim = pd_max;
+        int *q1, *q2, *q3, *q4;
+        double *qs;
+        if ((rc = E.upload(&q1, pd_start, pd_start.size()))) return rc;
+        if ((rc = E.upload(&q2, pd_dim, pd_dim.size()))) return rc;
+        if ((rc = E.upload(&q3, pd_hs, pd_hs.size()))) return rc;
+        if ((rc = E.upload(&q4, pd_off, pd_off.size()))) return rc;
+        if ((rc = E.alloc(&qs, (size_t)(pd_state ? pd_state : 1)))) return rc;
+        pv.start = q1;
+        pv.dim = q2;
+        pv.hs_start = q3;
+        pv.state_off = q4;
+        pv.state = qs;
+        pv.mapHs = h->mapHs;
+        pv.fail = &E.mb_dev->soc_fail;
     }
     {
         dev::Ns3View &nv = h->ns3;
@@ -503,12 +532,13 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
-    if (h->soc.ncones) CHIP_HIP(hipMemsetAsync(&E.mb_dev->soc_fail, 0, sizeof(int), E.stream));
+    if (h->soc.ncones || h->psd.ncones) CHIP_HIP(hipMemsetAsync(&E.mb_dev->soc_fail, 0, sizeof(int), E.stream));
     dev::nn_update(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam);
     dev::soc_update_scaling(E.stream, h->soc, s_dev, z_dev);
     dev::ns3_update_scaling(E.stream, h->ns3, s_dev, z_dev, mu, strategy);
+    dev::psd_update_scaling(E.stream, h->psd, s_dev, z_dev);
     CHIP_HIP(hipGetLastError());
-    h->scaling_pending_check = h->soc.ncones > 0; // verdict is folded into the next update()
+    h->scaling_pending_check = h->soc.ncones > 0 || h->psd.ncones > 0; // verdict folded into the next update()
     return 1;
 }
 int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z, double mu, int32_t strategy) {
@@ -523,7 +553,7 @@ int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z, d
     }
     int rc = chip_kkt_update_scaling_dev(h, h->d_s, h->d_z, mu, strategy);
     if (rc < 0) return rc;
-    if (h->soc.ncones) {
+    if (h->soc.ncones || h->psd.ncones) {
         rc = E.read_mailbox();
         if (rc) return rc;
         h->scaling_pending_check = false;
@@ -543,7 +573,7 @@ int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
         if (!hsblocks_or_null)
             return fail(CHIP_ERR_ARG, "update: Hs blocks are required for PSD cones");
         for (const ConeSpec &c : K.cones) {
-            if (c.tag != CHIP_CONE_PSDTRIANGLE) continue;
+            if (c.tag != CHIP_CONE_PSDTRIANGLE || c.dim <= 64) continue;
             CHIP_HIP(hipMemcpyAsync(h->d_tmp + c.block_start, hsblocks_or_null + c.block_start,
                                     (size_t)c.block_len * sizeof(double), hipMemcpyHostToDevice, E.stream));
             dev::scatter_values(E.stream, E.Kx, h->mapHs + c.block_start, h->d_tmp + c.block_start,
@@ -553,6 +583,7 @@ int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
     dev::nn_write_hs(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx);
     dev::soc_write_kkt(E.stream, h->soc, E.Kx);
     dev::ns3_write_hs(E.stream, h->ns3, E.Kx);
+    dev::psd_write_hs(E.stream, h->psd, E.Kx);
     int ok = E.refactor(h->E.st.static_regularization_enable != 0, h->diag_full);
     if (ok < 0) return ok;
     h->last_eps = E.st.static_regularization_enable ? E.mb_host->eps : 0.0;
@@ -732,7 +763,8 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval) {
 }
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     if (!h) return CHIP_ERR_ARG;
-    if (h->has_hostHs) return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: PSD cone scalings are not held on the device");
+    if (h->has_hostHs || h->psd.ncones)
+        return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: not implemented for PSD cones yet");
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
@@ -742,7 +774,7 @@ int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     return CHIP_OK;
 }
 #define NEED_SYMMETRIC(h)                                                                      \
-    if ((h)->has_hostHs || (h)->ns3.ncones)                                                    \
+    if ((h)->has_hostHs || (h)->ns3.ncones || (h)->psd.ncones)                                                  \
     return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: only Zero/Nonnegative/SecondOrder cones")
 
 int32_t chip_kkt_affine_ds_dev(chip_kkt *h, double *ds_dev, const double *s_dev) {

@@ -267,7 +267,7 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
             rows[q] = v.Li[cb + q];
         }
     __syncthreads();
-    if (lds && cn >= 24) {
+    if (cn >= 24) {
         // General-fill columns: the contributing columns have long tails of very different
         // lengths.  The (contribution, tail entry) pairs are FLATTENED: per batch of up to RCAP
         // contributions an exclusive scan of the tail lengths is built in LDS, then the threads
@@ -310,13 +310,17 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
                 const int pp = cst[lo] + (u - coff[lo]);
                 const int i = v.Li[pp];
                 const double val = v.Lx[pp] * cw[lo];
-                int l2 = 0, h2 = cn;
-                while (l2 < h2) {
-                    const int mid = (l2 + h2) >> 1;
-                    if (rows[mid] < i) l2 = mid + 1;
-                    else h2 = mid;
+                if (lds) {
+                    int l2 = 0, h2 = cn;
+                    while (l2 < h2) {
+                        const int mid = (l2 + h2) >> 1;
+                        if (rows[mid] < i) l2 = mid + 1;
+                        else h2 = mid;
+                    }
+                    atomicAdd(&acc[l2], -val);
+                } else { // column too long for LDS: same flattened walk, L2-resident lookups + atomics
+                    atomicAdd(&v.Lx[find_row(v.Li, cb, cb + cn, i)], -val);
                 }
-                atomicAdd(&acc[l2], -val);
             }
         }
     } else {
@@ -1252,6 +1256,189 @@ __global__ __launch_bounds__(WG) void k_ns3_mul_hs(Ns3View v, double *y, const d
     sym3_mul(v.state + 18 * c, y + v.start[c], x + v.start[c]);
 }
 
+// ---------------------------------------------------------------------------
+// PSD triangle cone (psdtrianglecone.rs:144-212, 467-509): one workgroup per cone,
+// all dense work (two Cholesky factors, an SVD, three small GEMMs) in LDS.
+//   S = L1 L1', Z = L2 L2', M = L2' L1 = U Sigma V'
+//   R = L1 V Sigma^-1/2,  B = R R' (the NT scaling matrix),  Hs = B (x)_s B
+// The SVD is a one-sided (Hestenes) Jacobi iteration on the columns of M: it accumulates V
+// and leaves sigma_p = ||m_p||; B does not depend on the order / signs of the singular pairs.
+// n <= PSD_MAX_DIM (three n x n fp64 matrices in LDS).
+// ---------------------------------------------------------------------------
+constexpr int PSD_MAX_DIM = 64;
+
+// in-place lower Cholesky of the column-major n x n matrix A (upper part ignored); returns false
+// (uniformly) when a pivot is not positive -> update_scaling fails like ?potrf (psdtrianglecone.rs:165-169)
+__device__ bool lds_cholesky(double *A, int n, int *flag) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            const double p = A[k + k * n];
+            if (!(p > 0.0)) *flag = 1;
+            else A[k + k * n] = sqrt(p);
+        }
+        __syncthreads();
+        if (*flag) return false;
+        const double d = A[k + k * n];
+        for (int i = k + 1 + tid; i < n; i += WG) A[i + k * n] /= d;
+        __syncthreads();
+        const int r = n - k - 1;
+        for (int idx = tid; idx < r * r; idx += WG) {
+            const int i = k + 1 + idx % r, j = k + 1 + idx / r;
+            if (j <= i) A[i + j * n] -= A[i + k * n] * A[j + k * n];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const double *__restrict__ sv,
+                                                           const double *__restrict__ zv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int flag, rotated;
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c], tid = threadIdx.x;
+    double *A = (double *)smem, *Bm = A + n * n, *Cm = Bm + n * n; // A: S -> L1, Bm: Z -> L2 -> V, Cm: M
+    const double *s = sv + v.start[c], *z = zv + v.start[c];
+    const double isq2 = 0.7071067811865476;
+    if (tid == 0) flag = 0;
+    // svec -> symmetric matrices (dense/matrix_math.rs:165-205): packed triu, column major
+    for (int idx = tid; idx < n * n; idx += WG) {
+        const int i = idx % n, j = idx / n;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int t = hi * (hi + 1) / 2 + lo;
+        const double sc = (i == j) ? 1.0 : isq2;
+        A[idx] = s[t] * sc;
+        Bm[idx] = z[t] * sc;
+    }
+    __syncthreads();
+    if (!lds_cholesky(A, n, &flag) || !lds_cholesky(Bm, n, &flag)) {
+        if (tid == 0) *v.fail = 1;
+        return;
+    }
+    // M = L2' L1
+    for (int idx = tid; idx < n * n; idx += WG) {
+        const int a = idx % n, b = idx / n;
+        double acc = 0.0;
+        for (int i = (a > b ? a : b); i < n; ++i) acc += Bm[i + a * n] * A[i + b * n];
+        Cm[idx] = acc;
+    }
+    __syncthreads();
+    // V = I (overwrites L2)
+    for (int idx = tid; idx < n * n; idx += WG) Bm[idx] = (idx % n == idx / n) ? 1.0 : 0.0;
+    __syncthreads();
+    // one-sided Jacobi, round-robin pairing over np players (np even), one thread per pair
+    const int np = (n + 1) & ~1;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        if (tid == 0) rotated = 0;
+        __syncthreads();
+        for (int r = 0; r < np - 1; ++r) {
+            if (tid < np / 2) {
+                int p, q;
+                if (tid == 0) {
+                    p = np - 1;
+                    q = r;
+                } else {
+                    p = (r + tid) % (np - 1);
+                    q = (r - tid + np - 1) % (np - 1);
+                }
+                if (p < n && q < n) {
+                    double *mp = Cm + p * n, *mq = Cm + q * n;
+                    double al = 0.0, be = 0.0, ga = 0.0;
+                    for (int i = 0; i < n; ++i) {
+                        al += mp[i] * mp[i];
+                        be += mq[i] * mq[i];
+                        ga += mp[i] * mq[i];
+                    }
+                    if (fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
+                        const double zeta = (be - al) / (2.0 * ga);
+                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                        double *vp = Bm + p * n, *vq = Bm + q * n;
+                        for (int i = 0; i < n; ++i) {
+                            const double a0 = mp[i], b0 = mq[i];
+                            mp[i] = cs * a0 - sn * b0;
+                            mq[i] = sn * a0 + cs * b0;
+                            const double a1 = vp[i], b1 = vq[i];
+                            vp[i] = cs * a1 - sn * b1;
+                            vq[i] = sn * a1 + cs * b1;
+                        }
+                        rotated = 1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (!rotated) break;
+        __syncthreads();
+    }
+    __syncthreads();
+    // sigma_p = ||m_p||; R = L1 V Sigma^-1/2 (into Cm, M is dead); needs sigma first
+    double *sig = Cm + n * n; // n extra doubles
+    for (int p = tid; p < n; p += WG) {
+        double a = 0.0;
+        for (int i = 0; i < n; ++i) a += Cm[i + p * n] * Cm[i + p * n];
+        sig[p] = sqrt(a);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += WG) {
+        const int i = idx % n, p = idx / n;
+        double acc = 0.0;
+        for (int k = 0; k <= i; ++k) acc += A[i + k * n] * Bm[k + p * n];
+        Cm[idx] = acc / sqrt(sig[p]);
+    }
+    __syncthreads();
+    // B = R R' -> HBM state (n*n) + lambda = sigma
+    double *Bout = v.state + v.state_off[c];
+    for (int idx = tid; idx < n * n; idx += WG) {
+        const int i = idx % n, j = idx / n;
+        double acc = 0.0;
+        for (int p = 0; p < n; ++p) acc += Cm[i + p * n] * Cm[j + p * n];
+        Bout[idx] = acc;
+    }
+    for (int p = tid; p < n; p += WG) Bout[n * n + p] = sig[p];
+}
+
+// get_Hs = pack_triu(skron(B)) (psdtrianglecone.rs:210-212, 467-509), negated and scattered into K.
+// Packed column-major triu: entry t <-> (row, col), row <= col; row <-> (i, j), col <-> (k, l).
+__global__ __launch_bounds__(WG) void k_psd_write_hs(PsdView v, double *Kx, int blocks_per_cone) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *B = (double *)smem;
+    const int c = blockIdx.x / blocks_per_cone, part = blockIdx.x % blocks_per_cone;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c];
+    const double *Bin = v.state + v.state_off[c];
+    for (int idx = threadIdx.x; idx < n * n; idx += WG) B[idx] = Bin[idx];
+    __syncthreads();
+    const int numel = n * (n + 1) / 2;
+    const long long total = (long long)numel * (numel + 1) / 2;
+    const int *mh = v.mapHs + v.hs_start[c];
+    const double sqrt2 = 1.4142135623730951;
+    for (long long t = (long long)part * WG + threadIdx.x; t < total; t += (long long)blocks_per_cone * WG) {
+        // col = largest cc with cc(cc+1)/2 <= t
+        long long cc = (long long)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (cc * (cc + 1) / 2 > t) --cc;
+        while ((cc + 1) * (cc + 2) / 2 <= t) ++cc;
+        const int col = (int)cc, row = (int)(t - cc * (cc + 1) / 2);
+        int l = (int)((sqrt(8.0 * col + 1.0) - 1.0) * 0.5);
+        while (l * (l + 1) / 2 > col) --l;
+        while ((l + 1) * (l + 2) / 2 <= col) ++l;
+        const int k = col - l * (l + 1) / 2;
+        int j = (int)((sqrt(8.0 * row + 1.0) - 1.0) * 0.5);
+        while (j * (j + 1) / 2 > row) --j;
+        while ((j + 1) * (j + 2) / 2 <= row) ++j;
+        const int i = row - j * (j + 1) / 2;
+        const double Ajl = B[j + l * n], Ajk = B[j + k * n];
+        double h;
+        if (i != j && k != l) h = B[i + k * n] * Ajl + B[i + l * n] * Ajk;
+        else if (i == j && k != l) h = sqrt2 * Ajl * Ajk;
+        else if (i != j && k == l) h = sqrt2 * B[i + l * n] * Ajk;
+        else h = Ajl * Ajl;
+        Kx[mh[t]] = -h;
+    }
+}
+
 // mul_Hs: nonnegativecone.rs:103-108, zerocone.rs:98-100
 __global__ __launch_bounds__(WG) void k_nn_mul_hs(const int *__restrict__ rows, int count,
                                                   const double *__restrict__ w, double *y,
@@ -1654,6 +1841,17 @@ void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const
 }
 void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx) {
     if (v.ncones) k_soc_write_kkt<<<v.ncones, WG, 0, s>>>(v, Kx);
+}
+void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv) {
+    if (!v.ncones) return;
+    const size_t lds = ((size_t)(3 * v.maxdim * v.maxdim + v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
+    k_psd_update_scaling<<<v.ncones, WG, lds, s>>>(v, sv, zv);
+}
+void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx) {
+    if (!v.ncones) return;
+    const int bpc = 16;
+    const size_t lds = ((size_t)(v.maxdim * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
+    k_psd_write_hs<<<v.ncones * bpc, WG, lds, s>>>(v, Kx, bpc);
 }
 void ns3_update_scaling(hipStream_t s, const Ns3View &v, const double *sv, const double *zv, double mu,
                         int strategy) {

@@ -126,6 +126,18 @@ struct Ns3View {
     double *state;
     const int *mapHs;
 };
+// PSD triangle cones held on the device (matrix side <= 64): state per cone = B (n*n, the NT
+// scaling matrix R R') followed by lambda (n)
+struct PsdView {
+    int ncones;
+    int maxdim;
+    const int *start, *dim, *hs_start, *state_off;
+    double *state;
+    const int *mapHs;
+    int *fail;
+};
+void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv);
+void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx);
 void ns3_update_scaling(hipStream_t s, const Ns3View &v, const double *sv, const double *zv, double mu,
                         int strategy);
 void ns3_write_hs(hipStream_t s, const Ns3View &v, double *Kx);

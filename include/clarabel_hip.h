@@ -192,7 +192,8 @@ int32_t chip_kkt_get_map(const chip_kkt *h, uint64_t *mapP, uint64_t *mapA, uint
 /* CompositeCone::update_scaling(s, z, mu, scaling_strategy) (compositecone.rs:226-243) for
  * the cones held on the device: Nonnegative (nonnegativecone.rs:77-90), SecondOrder
  * (socone.rs:134-211), Exponential (expcone.rs:106-124) and Power (powcone.rs:99-117) with the
- * primal-dual / dual scalings of nonsymmetric_common.rs:53-143; Zero is a no-op.
+ * primal-dual / dual scalings of nonsymmetric_common.rs:53-143, PSDTriangle with matrix side
+ * <= 64 (psdtrianglecone.rs:144-204: two Cholesky factors, SVD, R R', skron); Zero is a no-op.
  * strategy: 0 = ScalingStrategy::PrimalDual, 1 = ::Dual (core/solver.rs:77-80).
  * Returns the reference's bool.  s, z: m doubles (host / device variants; the _dev variant
  * defers the SOC interior check to the next chip_kkt_update so that it stays asynchronous). */
@@ -203,7 +204,7 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
 /* KKTSolver::update (directldlkktsolver.rs:134-158): Hs blocks (get_Hs fused,
  * negated), sparse-cone u/v/D columns, static regularisation, numeric refactor.
  * hsblocks_or_null: full Hsblocks vector (host) consulted ONLY for cone types
- * whose scaling is not held on the device (PSD); may be NULL
+ * whose scaling is not held on the device (PSD cones with matrix side > 64); may be NULL
  * when there are none.  Returns the reference's bool. */
 int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null);
 /* setrhs(rhsx, rhsz)   directldlkktsolver.rs:160-166 */

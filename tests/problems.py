@@ -191,10 +191,18 @@ def chordal_sdp(ncliques=6, dim=6, overlap=2, nsoc=3, socdim=7, seed=5):
     cones = [(PSD, dim)] * ncliques + [(SOC, socdim)] * nsoc
     s, z = _interior(rng, cones)
     hs = []
-    for _ in range(ncliques):
-        G1 = rng.standard_normal((dim, dim))
-        G2 = rng.standard_normal((dim, dim))
-        hs.append(psd_scaling_Hs(G1 @ G1.T + dim * np.eye(dim), G2 @ G2.T + dim * np.eye(dim)))
+    nscal = min(ncliques, 16)  # distinct scalings, cycled (the numpy oracle costs ~0.6 s per 50x50 cone)
+    cache = []
+    for k in range(ncliques):
+        if k < nscal:
+            G1 = rng.standard_normal((dim, dim))
+            G2 = rng.standard_normal((dim, dim))
+            S, Z = G1 @ G1.T + dim * np.eye(dim), G2 @ G2.T + dim * np.eye(dim)
+            cache.append((_svec(S), _svec(Z), psd_scaling_Hs(S, Z)))
+        sv, zv, h = cache[k % nscal]
+        s[k * numel:(k + 1) * numel] = sv
+        z[k * numel:(k + 1) * numel] = zv
+        hs.append(h)
     hs_full = np.concatenate(hs + [np.zeros(socdim)] * nsoc)
     return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=s, z=z, hsblocks=hs_full)
 

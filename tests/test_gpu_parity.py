@@ -4,6 +4,7 @@ post-refinement KKT solution with the SAME permutation injected into the oracle;
 known-answer tests keep the reference's own 1e-8 / 1e-10 absolute bounds."""
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 from tests import problems
 
@@ -96,6 +97,32 @@ def _rand_quasidef(rng, n1, n2, density):
     K.sort_indices()
     ds = np.array([1] * n1 + [-1] * n2, dtype=np.int8)
     return K, ds
+
+
+def test_ldl_dense_front_beyond_lds(hip, oracle):
+    """one fully dense quasidefinite matrix of order 2300: the leading columns of L are longer
+    than the factor kernel's LDS column buffer (2048) -> flattened update with L2 atomics"""
+    rng = np.random.default_rng(3)
+    n1, n2 = 2200, 100
+    M = rng.standard_normal((n1, 40))
+    A = rng.standard_normal((n2, n1))
+    K = np.block([[M @ M.T + n1 * np.eye(n1), A.T], [A, -(n2 * np.eye(n2))]])
+    K = sp.triu(sp.csc_matrix(K), format="csc")
+    K.sort_indices()
+    ds = np.array([1] * n1 + [-1] * n2, dtype=np.int8)
+    Kc = hip.CscMatrix.from_scipy(K)
+    f = hip.HipDirectLDLSolver(Kc, ds)
+    assert f.refactor()
+    o = oracle.QDLDL(n1 + n2, Kc.colptr, Kc.rowval, Kc.nzval, perm=f.perm, Dsigns=ds, logical=True,
+                     regularize_eps=1e-13, regularize_delta=2e-7)
+    assert o.refactor()
+    Lp, Li, Lx, D, Dinv = f.factors()
+    assert np.diff(Lp).max() > 2048
+    assert np.array_equal(Li, o.Li) and relerr(D, o.D) <= 1e-10 and relerr(Lx, o.Lx) <= 1e-9
+    b = rng.standard_normal(n1 + n2)
+    x = np.zeros(n1 + n2)
+    f.solve(None, x, b)
+    assert relerr(x, o.solve(b)) <= TOL
 
 
 @pytest.mark.parametrize("n1,n2,density,seed", [(30, 20, 0.1, 0), (400, 300, 0.01, 1), (2000, 3000, 0.002, 2)])
@@ -193,6 +220,39 @@ def test_c4_batched(hip, oracle):
 def test_c5_chordal_sdp_host_hs(hip, oracle):
     pr = problems.chordal_sdp(6, 6, 2, 3, 7, seed=5)
     _check_update_and_solve(hip, oracle, pr, hs=pr["hsblocks"])
+
+
+@pytest.mark.parametrize("dim", [3, 8, 21, 50])
+def test_c5_psd_scaling_on_device(hip, oracle, dim):
+    """PSDTriangleCone update_scaling on the device (psdtrianglecone.rs:144-204: chol, chol, SVD,
+    R R', skron) -- the Hs blocks are NOT handed over by the host; the oracle side uses the numpy
+    restatement tests/problems.psd_scaling_Hs for the same (S, Z)"""
+    # dim 50 = BASELINE config 5's clique size; one clique there (the generator's 4*ncliques x
+    # variables would otherwise fuse four 1275-wide blocks into a single dense front)
+    pr = problems.chordal_sdp(1 if dim == 50 else 4, dim, min(3, dim - 1), 2, 7, seed=dim)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    assert ks.update_scaling(pr["s"], pr["z"]) and cones.update_scaling(pr["s"], pr["z"])
+    assert ks.update()              # no hsblocks: computed on the device
+    assert ko.update(pr["hsblocks"])
+    assert relerr(ks.values(), ko.kkt.nzval) <= 1e-11
+    rng = np.random.default_rng(1)
+    rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+    ks.setrhs(rx, rz)
+    ko.setrhs(rx, rz)
+    x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+    assert ks.solve(x, z)
+    ok, xo, zo = ko.solve()
+    assert ok and relerr(np.concatenate([x, z]), np.concatenate([xo, zo])) <= TOL
+
+
+def test_psd_scaling_failure_reported(hip):
+    pr = problems.chordal_sdp(2, 4, 2, 1, 6, seed=2)
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+    s = pr["s"].copy()
+    s[0] = -1.0  # S[0,0] < 0: Cholesky fails -> update_scaling false (psdtrianglecone.rs:165-169)
+    assert ks.update_scaling(s, pr["z"]) is False
 
 
 @pytest.mark.parametrize("strategy", [0, 1])

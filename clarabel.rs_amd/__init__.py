@@ -143,6 +143,11 @@ def _check(rc, where):
     return rc
 
 
+def _status(rc, where):
+    """1 / 0 -> bool (the reference's is_success), negative -> ChipError"""
+    return bool(_check(rc, where))
+
+
 def amd_order(n, colptr, rowval, dense_scale=1.5):
     """AMD ordering of the symmetric matrix with upper triangle (colptr,rowval).
     Replaces `amd::order` at src/qdldl/qdldl.rs:905-917.  Returns (perm, iperm, info3)."""
@@ -430,6 +435,10 @@ class HipKKTSolver:
         _check(lib().chip_kkt_margins_dev(self._h, C.c_void_p(z_ptr), C.byref(a), C.byref(b)), "margins")
         return a.value, b.value
 
+    def scaled_unit_shift_dev(self, z_ptr, alpha, primal_cone):
+        _check(lib().chip_kkt_scaled_unit_shift_dev(self._h, C.c_void_p(z_ptr), C.c_double(alpha),
+                                                    C.c_int32(1 if primal_cone else 0)), "scaled_unit_shift")
+
     def linear_solver_info(self):
         info = Info()
         _check(lib().chip_kkt_info(self._h, C.byref(info)), "info")
@@ -445,6 +454,76 @@ class HipKKTSolver:
         out = (C.c_double * 8)()
         _check(lib().chip_kkt_profile_read(self._h, out), "profile_read")
         return {"launches": int(out[0]), "ms": float(out[1]), "family": int(out[2])}
+
+
+class CVars(C.Structure):
+    """chip_vars: DefaultVariables (default/variables.rs:12-36) with device pointers"""
+    _fields_ = [("x", C.c_void_p), ("z", C.c_void_p), ("s", C.c_void_p), ("tau", C.c_double),
+                ("kappa", C.c_double)]
+
+
+class DeviceVariables:
+    """x[n], s[m], z[m] in HBM + tau, kappa on the host (DefaultVariables::new, variables.rs:41-50)"""
+
+    def __init__(self, n, m):
+        self.n, self.m = n, m
+        self.x, self.s, self.z = DeviceArray(n), DeviceArray(m), DeviceArray(m)
+        self.tau, self.kappa = 1.0, 1.0
+
+    def cvars(self):
+        return CVars(self.x.ptr, self.z.ptr, self.s.ptr, self.tau, self.kappa)
+
+
+STEP_AFFINE, STEP_COMBINED = 0, 1
+
+
+class HipKKTSystem:
+    """DefaultKKTSystem (default/kktsystem.rs:16-292) + DefaultResiduals::update
+    (default/residuals.rs:69-111), device resident, over an existing HipKKTSolver."""
+
+    def __init__(self, kktsolver, P, A, q, b):
+        self.ks = kktsolver
+        self.n, self.m = kktsolver.n, kktsolver.m
+        self._h = C.c_void_p()
+        q, b = _f(q), _f(b)
+        _check(lib().chip_kktsystem_create(C.byref(self._h), kktsolver._h, _pu(P.colptr), _pu(P.rowval),
+                                           _pf(P.nzval), _pu(A.colptr), _pu(A.rowval), _pf(A.nzval), _pf(q),
+                                           _pf(b)), "chip_kktsystem_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().chip_kktsystem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def update(self):
+        return _status(lib().chip_kktsystem_update(self._h), "kktsystem_update")
+
+    def solve(self, lhs, rhs, variables, step_direction):
+        """lhs, rhs, variables: DeviceVariables; lhs.tau / lhs.kappa are written -> bool"""
+        cl, cr, cv = lhs.cvars(), rhs.cvars(), variables.cvars()
+        ok = _status(lib().chip_kktsystem_solve(self._h, C.byref(cl), C.byref(cr), C.byref(cv),
+                                                C.c_int32(step_direction)), "kktsystem_solve")
+        if ok:
+            lhs.tau, lhs.kappa = cl.tau, cl.kappa
+        return ok
+
+    def solve_initial_point(self, variables):
+        cv = variables.cvars()
+        return _status(lib().chip_kktsystem_solve_initial_point(self._h, C.byref(cv)), "solve_initial_point")
+
+    def residuals_update(self, variables, rx, rz, rx_inf, rz_inf, Px):
+        """device outputs (DeviceArray) + dict of the host scalars of residuals.rs:103-110"""
+        cv = variables.cvars()
+        o = (C.c_double * 5)()
+        _check(lib().chip_residuals_update(self._h, C.byref(cv), C.c_void_p(rx.ptr), C.c_void_p(rz.ptr),
+                                           C.c_void_p(rx_inf.ptr), C.c_void_p(rz_inf.ptr), C.c_void_p(Px.ptr), o),
+               "residuals_update")
+        return dict(rtau=o[0], dot_qx=o[1], dot_bz=o[2], dot_sz=o[3], dot_xPx=o[4])
+
+    def update_data(self, P=None, A=None, q=None, b=None):
+        args = [None if v is None else _f(v) for v in (P, A, q, b)]
+        _check(lib().chip_kktsystem_update_data(self._h, *[None if v is None else _pf(v) for v in args]),
+               "kktsystem_update_data")
 
 
 # ---------------------------------------------------------------------------

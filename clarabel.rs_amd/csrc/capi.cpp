@@ -206,6 +206,13 @@ int32_t chip_ldl_set_values(chip_ldl *h, const double *kkt_nzval) {
     h->dirty = true;
     return CHIP_OK;
 }
+extern "C++" {
+namespace chip {
+int kkt_device(const ::chip_kkt *h) { return h->E.device; }
+bool kkt_host_only(const ::chip_kkt *h) { return h->E.host_only; }
+} // namespace chip
+}
+
 #define NEED_DEVICE(E) \
     if ((E).host_only) return fail(CHIP_ERR_NO_DEVICE, "host-only handle: no numeric work without a GPU")
 
@@ -661,8 +668,7 @@ static int solve_core(chip_kkt *h) {
     if (maxiter >= 1) {
         // w <- e0 is needed if the round is rejected?  No: a rejected round leaves x untouched and e
         // is dead afterwards, so e is solved in place.
-        E.enqueue_solve_inplace(e);      // e <- K^-1 e0   (the correction dx)
-        dev::add_vec(E.stream, e, x, N); // e <- x + dx    (the candidate)
+        E.enqueue_solve_inplace(e, x); // e <- x + K^-1 e0   (the candidate; "+ x" fused into the sweep)
         E.enqueue_residual(w, h->bp, e, 2);
     }
     double nn[3] = {0, 0, 0};
@@ -677,8 +683,7 @@ static int solve_core(chip_kkt *h) {
         if (it == 0) {
             norme = nn[2]; // already computed above
         } else {
-            E.enqueue_solve_inplace(e);
-            dev::add_vec(E.stream, e, x, N);
+            E.enqueue_solve_inplace(e, x);
             set += 1;
             if (set >= NRM_SETS) set = 3;
             if (it + 2 >= NRM_SETS) // the set is being reused: clear it first
@@ -777,6 +782,17 @@ int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     if ((h)->has_hostHs || (h)->ns3.ncones || (h)->psd.ncones)                                                  \
     return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: only Zero/Nonnegative/SecondOrder cones")
 
+int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha, int32_t primal_cone) {
+    if (!h || !z_dev) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    NEED_SYMMETRIC(h);
+    CHIP_HIP(hipSetDevice(E.device));
+    dev::cone_unit_shift(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, z_dev, alpha,
+                         primal_cone ? 1 : 0);
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
 int32_t chip_kkt_affine_ds_dev(chip_kkt *h, double *ds_dev, const double *s_dev) {
     if (!h || !ds_dev) return CHIP_ERR_ARG;
     (void)s_dev;

@@ -178,7 +178,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = upload_lists(bwd, S.bwd))) return rc;
     if ((rc = upload_lists(smv, S.smv))) return rc;
     {
-        int *bp = nullptr, *lp = nullptr, *lv = nullptr;
+        int *bp = nullptr, *lp = nullptr, *lv = nullptr, *pf = nullptr;
+        if ((rc = upload(&pf, S.bpf, S.bpf.size()))) return rc;
+        bundles.pf = pf;
         if ((rc = upload(&bp, S.bundle_ptr, S.bundle_ptr.size()))) return rc;
         if ((rc = upload(&lp, S.blvl_ptr, S.blvl_ptr.size()))) return rc;
         if ((rc = upload(&lv, S.blvl, S.blvl.size()))) return rc;
@@ -298,7 +300,7 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
 }
 
 // qdldl.rs:755-768 in the permuted numbering, in place
-void Engine::enqueue_solve_inplace(double *xp) {
+void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
     const dev::LdlView v = view();
     dev::bundle_fwd(stream, v, bundles, xp);
     dev::GatherArgs f{Rp, Rcol, Rx, xp, xp, nullptr, nullptr, nullptr};
@@ -329,7 +331,9 @@ void Engine::enqueue_solve_inplace(double *xp) {
         prof_end(PF_BWD_T);
         l--;
     }
-    dev::bundle_bwd(stream, v, bundles, xp);
+    dev::bundle_bwd(stream, v, bundles, xp, addv);
+    // the top rows feed the bundles' backward sweeps, so their share of "+ addv" comes last
+    if (addv && N > NF) dev::add_vec(stream, xp + NF, addv + NF, N - NF);
 }
 
 // e = b - K x with the UNregularised K (directldlkktsolver.rs:334-347)

@@ -96,7 +96,8 @@ struct Engine {
     // -> refresh of the symv values; then reads the status mailbox (one sync).
     // returns 1 ok / 0 numerical failure / <0 error
     int refactor(bool static_reg, const int *diag_idx_dev);
-    void enqueue_solve_inplace(double *xp);                                  // permuted numbering
+    // xp <- K^-1 xp (permuted numbering); with addv the result is xp <- K^-1 xp + addv
+    void enqueue_solve_inplace(double *xp, const double *addv = nullptr);
     // e = b - K x (permuted numbering); ||e||inf is folded into norm set `set` (>= 0)
     void enqueue_residual(double *e, const double *b, const double *x, int set);
     int zero_norm_sets();                                                    // enqueue
@@ -111,6 +112,9 @@ struct Engine {
 };
 
 std::string hip_err(hipError_t e, const char *what);
+// for the L3 layer (kktsystem.cpp), which otherwise only uses the public chip_kkt_* entry points
+int kkt_device(const ::chip_kkt *h);
+bool kkt_host_only(const ::chip_kkt *h);
 
 #define CHIP_HIP(expr)                                                   \
     do {                                                                 \

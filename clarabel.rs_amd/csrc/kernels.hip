@@ -25,6 +25,8 @@
 //                               solver/core/cones/socone.rs:134-256
 #include "kernels.hpp"
 
+#include <algorithm>
+
 namespace chip {
 namespace dev {
 
@@ -142,7 +144,12 @@ __global__ __launch_bounds__(WG) void k_diag_absmax(const double *__restrict__ K
         else m = fmax(m, fabs(a));
     }
     m = block_max(m, red);
-    if (threadIdx.x == 0) atomicMax(&scal[1], (unsigned long long)__double_as_longlong(m));
+    // one same-address atomic per workgroup serialises (~13 ns each): skip it when the running
+    // maximum (a possibly stale read -- the maximum only grows) already covers this block
+    if (threadIdx.x == 0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        if (bits > __hip_atomic_load(&scal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&scal[1], bits);
+    }
     if (nan) scal[2] = 1ull;
 }
 __global__ void k_eps_from_max(double c, double prop, unsigned long long *scal) {
@@ -438,8 +445,16 @@ __device__ __forceinline__ double bundle_row_dot(const LdlView &v, const double 
 // forward (rows of L, descendants only -> all inside the bundle) or backward (columns of L,
 // ancestors inside the bundle come from LDS, ancestors in the top are final in x) sweep of a
 // bundle with its slice of x staged in LDS.
+//
+// Forward only: the bundle's two longest rows (bv.pf: the separator rows that close its
+// subtrees, e.g. the u / v rows of a sparse SOC) sit alone on the LAST levels, where a
+// pointer -> entries -> reduce chain would be fully exposed.  Their entries do not depend on
+// x, so every thread requests its share of them at kernel start (PF0 + PF1 register pairs);
+// when their level comes up only LDS gathers and one block reduction are left.
+constexpr int PF0 = 4, PF1 = 2;
 template <bool FWDMODE>
-__global__ __launch_bounds__(BWG) void k_bundle_solve(LdlView v, BundleView bv, double *x) {
+__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restrict__ addv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *xs = (double *)smem;
     __shared__ double red[16];
@@ -449,14 +464,69 @@ __global__ __launch_bounds__(BWG) void k_bundle_solve(LdlView v, BundleView bv, 
     const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
     const int *lv = bv.blvl + bv.blvl_ptr[b];
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    for (int i = threadIdx.x; i < s1 - s0; i += BWG) xs[i] = x[s0 + i];
+    int pr0 = -1, pr1 = -1, pe0 = 0, pe1 = 0, pb0 = 0, pb1 = 0;
+    int pi0[PF0], pi1[PF1];
+    double pv0[PF0], pv1[PF1];
+    if (FWDMODE) {
+        pr0 = bv.pf[2 * b];
+        pr1 = bv.pf[2 * b + 1];
+        pb0 = pr0 >= 0 ? v.Rp[pr0] : 0;
+        pe0 = pr0 >= 0 ? v.Rp[pr0 + 1] : 0;
+        pb1 = pr1 >= 0 ? v.Rp[pr1] : 0;
+        pe1 = pr1 >= 0 ? v.Rp[pr1 + 1] : 0;
+#pragma unroll
+        for (int q = 0; q < PF0; ++q) {
+            const unsigned t = (unsigned)(pb0 + (int)threadIdx.x + q * BWG);
+            const bool ok = (int)t < pe0;
+            pi0[q] = ok ? v.Rcol[t] : -1;
+            pv0[q] = ok ? v.Rx[t] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < PF1; ++q) {
+            const unsigned t = (unsigned)(pb1 + (int)threadIdx.x + q * BWG);
+            const bool ok = (int)t < pe1;
+            pi1[q] = ok ? v.Rcol[t] : -1;
+            pv1[q] = ok ? v.Rx[t] : 0.0;
+        }
+    }
+    // backward: x_j = x_j / d_j - sum_i l_ij x_i (qdldl.rs:737-752); the scaling of the row's own
+    // entry does not depend on the level order, so it is applied while staging (coalesced, off
+    // the per-level critical path)
+    if (FWDMODE)
+        for (int i = threadIdx.x; i < s1 - s0; i += BWG) xs[i] = x[s0 + i];
+    else
+        for (int i = threadIdx.x; i < s1 - s0; i += BWG) xs[i] = x[s0 + i] * v.Dinv[s0 + i];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int *ptr = FWDMODE ? v.Rp : v.Lp;
+    // one row by the whole workgroup; the result lands in xs[r - s0] (visible after a barrier)
+    auto coop_row = [&](int r) {
+        double s = 0.0;
+        if (FWDMODE && r == pr0) {
+#pragma unroll
+            for (int q = 0; q < PF0; ++q)
+                if (pi0[q] >= 0) s += pv0[q] * xs[pi0[q] - s0];
+            for (int t = pb0 + (int)threadIdx.x + PF0 * BWG; t < pe0; t += BWG) s += v.Rx[t] * xs[v.Rcol[t] - s0];
+        } else if (FWDMODE && r == pr1) {
+#pragma unroll
+            for (int q = 0; q < PF1; ++q)
+                if (pi1[q] >= 0) s += pv1[q] * xs[pi1[q] - s0];
+            for (int t = pb1 + (int)threadIdx.x + PF1 * BWG; t < pe1; t += BWG) s += v.Rx[t] * xs[v.Rcol[t] - s0];
+        } else {
+            s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, threadIdx.x, BWG);
+        }
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) xs[r - s0] -= s;
+    };
     for (int step = FWDMODE ? 1 : 0; step < nl; ++step) {
         const int l = FWDMODE ? step : nl - 1 - step;
         const int lb = lv[l], le = lv[l + 1];
+        __syncthreads(); // the previous level is final in xs; its fat list is no longer read
+        if (le - lb == 1) { // a level of its own: no classification pass
+            coop_row(lb);
+            continue;
+        }
         if (threadIdx.x == 0) nfat = 0;
-        __syncthreads(); // also orders the previous level's writes to xs
+        __syncthreads();
         // thin rows, two per thread in lockstep (independent load chains in flight; a single
         // workgroup's sweep is latency-bound, not bandwidth-bound)
         const int *cidx = FWDMODE ? v.Rcol : v.Li;
@@ -498,31 +568,29 @@ __global__ __launch_bounds__(BWG) void k_bundle_solve(LdlView v, BundleView bv, 
             for (int u = 0; u < 2; ++u)
                 if (jr[u] >= 0) {
                     const int j = jr[u];
-                    xs[j - s0] = FWDMODE ? xs[j - s0] - sum[u] : xs[j - s0] * v.Dinv[j] - sum[u];
+                    xs[j - s0] -= sum[u];
                 }
         }
         __syncthreads();
         const int nf = min(nfat, FATCAP);
         if (nf <= 2) {
             // the separators at the top of a subtree: one long row at a time, all 8 waves on it
-            for (int f = 0; f < nf; ++f) {
-                const int r = fat[f];
-                double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, threadIdx.x, BWG);
-                s = block_sum(s, red);
-                if (threadIdx.x == 0) xs[r - s0] = FWDMODE ? xs[r - s0] - s : xs[r - s0] * v.Dinv[r] - s;
-            }
+            for (int f = 0; f < nf; ++f) coop_row(fat[f]);
         } else {
             for (int f = wv; f < nf; f += BWG / 64) {
                 const int r = fat[f];
                 double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, lane, 64);
                 s = wave_sum(s);
-                if (lane == 0) xs[r - s0] = FWDMODE ? xs[r - s0] - s : xs[r - s0] * v.Dinv[r] - s;
+                if (lane == 0) xs[r - s0] -= s;
             }
         }
-        __syncthreads(); // every wave has read nfat / fat[] before the next level resets them
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < s1 - s0; i += BWG) x[s0 + i] = xs[i];
+    // addv: the refinement step x + dx folded into the final write of the backward sweep
+    if (addv)
+        for (int i = threadIdx.x; i < s1 - s0; i += BWG) x[s0 + i] = xs[i] + addv[s0 + i];
+    else
+        for (int i = threadIdx.x; i < s1 - s0; i += BWG) x[s0 + i] = xs[i];
 }
 
 // B: a column with a huge row count (> 16384 contributions).  Each workgroup
@@ -573,6 +641,8 @@ __global__ __launch_bounds__(WG) void k_factor_finalize(LdlView v, const int *__
 //   FWD : out[r]  = out[r] - sum val[t] * xin[idx[t]]           (qdldl.rs:708-719)
 //   BWD : out[r]  = out[r]*Dinv[r] - sum ...                    (qdldl.rs:737-752)
 //   SYMV: out[r]  = b[r] - sum ...                              (directldlkktsolver.rs:334-347)
+//   SPMV: out[r]  = aux[r] + alpha * sum ...   (sparse gemv / symv of the IPM residuals and
+//                                               RHS algebra, csc/matrix_math.rs:178-343)
 // ---------------------------------------------------------------------------
 // returns the stored value (SYMV: the residual entry, folded into the inf-norm by the caller)
 template <int MODE>
@@ -580,6 +650,7 @@ __device__ __forceinline__ double store_row(const GatherArgs &a, int r, double s
     double v;
     if (MODE == FWD) v = a.out[r] - s;
     else if (MODE == BWD) v = a.out[r] * a.aux[r] - s;
+    else if (MODE == SPMV) v = (a.aux ? a.aux[r] : 0.0) + a.alpha * s;
     else v = a.aux[r] - s;
     a.out[r] = v;
     return v;
@@ -640,6 +711,7 @@ __global__ __launch_bounds__(WG) void k_gather_Bprep(GatherArgs a, const int *__
     const int r = rows[t];
     if (MODE == BWD) a.out[r] = a.out[r] * a.aux[r];
     else if (MODE == SYMV) a.out[r] = a.aux[r];
+    else if (MODE == SPMV) a.out[r] = a.aux ? a.aux[r] : 0.0;
 }
 template <int MODE>
 __global__ __launch_bounds__(WG) void k_gather_B(GatherArgs a, const int *__restrict__ crow,
@@ -651,7 +723,7 @@ __global__ __launch_bounds__(WG) void k_gather_B(GatherArgs a, const int *__rest
     for (int t = cbeg[blockIdx.x] + threadIdx.x; t < cend[blockIdx.x]; t += WG)
         s += a.val[t] * a.xin[a.idx[t]];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(&a.out[crow[blockIdx.x]], -s);
+    if (threadIdx.x == 0) atomicAdd(&a.out[crow[blockIdx.x]], MODE == SPMV ? a.alpha * s : -s);
 }
 
 // T, W and B work of one level in ONE launch: the three classes are independent, so their
@@ -701,7 +773,7 @@ __global__ __launch_bounds__(WG) void k_gather_merged(GatherArgs a, const int *_
         for (; t < ce; t += WG) s0 += a.val[t] * a.xin[a.idx[t]];
         double s = (s0 + s1) + (s2 + s3);
         s = block_sum(s, red);
-        if (threadIdx.x == 0) atomicAdd(&a.out[crow[bid]], -s);
+        if (threadIdx.x == 0) atomicAdd(&a.out[crow[bid]], MODE == SPMV ? a.alpha * s : -s);
     } else {
         const int wid = (bid - ccount) * 4 + (threadIdx.x >> 6);
         if (wid >= wcount) return;
@@ -718,70 +790,105 @@ __global__ __launch_bounds__(WG) void k_gather_merged(GatherArgs a, const int *_
     }
 }
 
+// scatter-add of one value per lane into the LDS row accumulators (tgt < 0: nothing to add).
+// Must be called wave-converged.  When every active target of the wavefront is the SAME row
+// (consecutive rows that all couple to one separator column: the u / v columns of a sparse SOC,
+// a budget row) the 64 contributions are reduced in registers and ONE ds_add_f64 is issued
+// instead of 64 serialised same-address atomics.
+__device__ __forceinline__ void lds_scatter_add(double *acc, int tgt, double val) {
+    const unsigned long long live = __ballot(tgt >= 0);
+    if (live == 0ull) return;
+    const int lead = __ffsll((long long)live) - 1;
+    const int t0 = __shfl(tgt, lead, 64);
+    if (__popcll(live) > 1 && __ballot(tgt >= 0 && tgt != t0) == 0ull) {
+        const double sum = wave_sum(tgt >= 0 ? val : 0.0);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&acc[t0], sum);
+    } else if (tgt >= 0) {
+        atomicAdd(&acc[tgt], val);
+    }
+}
+
 // Residual e = b - K x for the rows of one bundle, with the symmetric matrix read ONCE:
 // U row i = diagonal + entries (i, j) to ancestors j > i.  Every entry is applied in both
 // directions: gathered into row i's own sum, and scattered (LDS fp64 atomic) into row j when j
 // is in the bundle; rows j in the top are produced by the level-scheduled gather over their full
 // rows instead.  x and e slices live in LDS; ||e||inf of the bundle is folded into the slots.
-__global__ __launch_bounds__(BWG) void k_bundle_symv(BundleView bv, const int *__restrict__ Up,
-                                                     const int *__restrict__ Ucol,
-                                                     const double *__restrict__ Ux,
-                                                     const double *__restrict__ x,
-                                                     const double *__restrict__ b, double *e,
-                                                     unsigned long long *nrm, int *nanflag) {
+__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bundle_symv(BundleView bv, const int *__restrict__ Up, const int *__restrict__ Ucol,
+                   const double *__restrict__ Ux, const double *__restrict__ x,
+                   const double *__restrict__ b, double *e, unsigned long long *nrm, int *nanflag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *xs = (double *)smem;
     double *es = xs + bv.max_nodes;
     __shared__ double red[16];
     const int bid = blockIdx.x;
     const int s0 = bv.bundle_ptr[bid], s1 = bv.bundle_ptr[bid + 1], nloc = s1 - s0;
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
+    // row pointers of the first sweep are requested BEFORE the vector slices are staged: they do
+    // not depend on x, so their latency overlaps the staging + barrier
+    int tb[4], te[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + u * BWG;
+        tb[u] = i < nloc ? Up[s0 + i] : 0;
+        te[u] = i < nloc ? Up[s0 + i + 1] : 0;
+    }
     for (int i = threadIdx.x; i < nloc; i += BWG) {
         xs[i] = x[s0 + i];
         es[i] = b[s0 + i];
     }
     __syncthreads();
-    // four rows per thread in lockstep: the row-pointer loads of the 4 rows, then entry k of the
-    // 4 rows, are independent of each other -> 4-8 global loads in flight per thread instead of a
-    // chain of dependent ones (these kernels are latency-, not bandwidth-limited per workgroup)
-    for (int i0 = threadIdx.x; i0 < nloc; i0 += 4 * BWG) {
-        int tb[4], te[4];
-        double acc[4], xi[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * BWG;
-            const bool ok = i < nloc;
-            tb[u] = ok ? Up[s0 + i] : 0;
-            te[u] = ok ? Up[s0 + i + 1] : 0;
-            xi[u] = ok ? xs[i] : 0.0;
-            acc[u] = 0.0;
-        }
+    // four rows per thread in lockstep: entry k of the 4 rows are independent loads -> 8 global
+    // loads in flight per thread instead of a chain of dependent ones.  Loop bounds are kept
+    // wave-uniform (lds_scatter_add uses cross-lane operations).
+    for (int w0 = wbase; w0 < nloc; w0 += 4 * BWG) {
+        const int i0 = w0 + lane;
+        double acc[4];
         int maxlen = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) maxlen = max(maxlen, te[u] - tb[u]);
+        for (int u = 0; u < 4; ++u) {
+            acc[u] = 0.0;
+            maxlen = max(maxlen, te[u] - tb[u]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
         for (int k = 0; k < maxlen; ++k) {
             int jj[4];
             double vv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool ok = tb[u] + k < te[u];
-                jj[u] = ok ? Ucol[tb[u] + k] : -1;
-                vv[u] = ok ? Ux[tb[u] + k] : 0.0;
+                const unsigned t = (unsigned)(tb[u] + k); // unsigned offset -> sgpr-base addressing
+                jj[u] = ok ? Ucol[t] : -1;
+                vv[u] = ok ? Ux[t] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = jj[u];
-                if (j < 0) continue;
-                if (j < s1) {
-                    acc[u] += vv[u] * xs[j - s0];
-                    if (j != s0 + i0 + u * BWG) atomicAdd(&es[j - s0], -(vv[u] * xi[u]));
-                } else {
-                    acc[u] += vv[u] * x[j];
+                int tgt = -1;
+                double sc = 0.0;
+                if (j >= 0) {
+                    if (j < s1) {
+                        acc[u] += vv[u] * xs[j - s0];
+                        if (j != s0 + i0 + u * BWG) {
+                            tgt = j - s0;
+                            sc = -(vv[u] * xs[i0 + u * BWG]); // own x re-read from LDS (registers are scarce)
+                        }
+                    } else {
+                        acc[u] += vv[u] * x[j];
+                    }
                 }
+                lds_scatter_add(es, tgt, sc);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i0 + u * BWG < nloc) atomicAdd(&es[i0 + u * BWG], -acc[u]);
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * BWG;
+            if (i < nloc) atomicAdd(&es[i], -acc[u]);
+            const int in = i + 4 * BWG; // the next sweep's row pointers
+            tb[u] = in < nloc ? Up[s0 + in] : 0;
+            te[u] = in < nloc ? Up[s0 + in + 1] : 0;
+        }
     }
     __syncthreads();
     double m = 0.0;
@@ -876,6 +983,29 @@ __global__ __launch_bounds__(WG) void k_getlhs_perm(double *lx, double *lz, cons
             if (lx) lx[i] = val;
         } else if (lz) lz[i - n] = val;
     }
+}
+// ---- dense vector algebra of the caller either side of the solve (vecmath.rs:83-85,
+//      :186-204): w = a x + b y, deterministic two-stage dot products -------------------------
+__global__ __launch_bounds__(WG) void k_waxpby(double *w, double a, const double *x, double b, const double *y,
+                                               int n) {
+    for (int i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG)
+        w[i] = y ? a * x[i] + b * y[i] : a * x[i];
+}
+constexpr int DOT_BLOCKS = 512;
+__global__ __launch_bounds__(WG) void k_dot_partial(const double *__restrict__ a, const double *__restrict__ b,
+                                                    int n, double *partials) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) s += a[i] * b[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(WG) void k_dot_final(const double *__restrict__ partials, int nb, double *out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += WG) s += partials[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = s;
 }
 __global__ __launch_bounds__(WG) void k_add_vec(double *__restrict__ dx, const double *__restrict__ x, int N) {
     for (int i = logical_block() * WG + threadIdx.x; i < N; i += gridDim.x * WG) dx[i] = 1.0 * x[i] + 1.0 * dx[i];
@@ -1493,6 +1623,21 @@ __global__ __launch_bounds__(WG) void k_nn_step_ops(const int *__restrict__ rows
         else o0[r] = 0.0;
     }
 }
+// scaled_unit_shift (compositecone.rs:208-214): z += alpha * e per cone -- every row of a
+// nonnegative cone (nonnegativecone.rs:64-66), the head of a second-order cone (socone.rs:110-112);
+// Zero cone rows are zeroed for the PRIMAL cone only (zerocone.rs:63-69)
+__global__ __launch_bounds__(WG) void k_unit_shift(const int *__restrict__ nn_rows, int nn,
+                                                   const int *__restrict__ zero_rows, int nz,
+                                                   const int *__restrict__ soc_start, int nsoc, double *z,
+                                                   double alpha, int primal) {
+    const int total = nn + nz + nsoc;
+    for (int t = blockIdx.x * WG + threadIdx.x; t < total; t += gridDim.x * WG) {
+        if (t < nn) z[nn_rows[t]] += alpha;
+        else if (t < nn + nz) {
+            if (primal) z[zero_rows[t - nn]] = 0.0;
+        } else z[soc_start[t - nn - nz]] += alpha;
+    }
+}
 // per-block partial minima of the NN step lengths (nonnegativecone.rs:128-153)
 __global__ __launch_bounds__(WG) void k_nn_step_length(const int *__restrict__ rows, int count,
                                                        const double *__restrict__ dz,
@@ -1652,6 +1797,11 @@ __global__ __launch_bounds__(WG) void k_soc_step_ops(SocView v, double *o0, doub
 // ===========================================================================
 // launch wrappers
 // ===========================================================================
+void cone_unit_shift(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,
+                     double *z, double alpha, int primal) {
+    const int total = nn + nz + v.ncones;
+    if (total) k_unit_shift<<<std::min(grid_for(total), 2048), WG, 0, s>>>(nn_rows, nn, zero_rows, nz, v.start, v.ncones, z, alpha, primal);
+}
 void cone_affine_ds(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,
                     double *ds) {
     if (nn) k_nn_step_ops<0><<<grid_for(nn) > 2048 ? 2048 : grid_for(nn), WG, 0, s>>>(nn_rows, nn, v.w, v.lam, ds, nullptr, nullptr, nullptr, 0.0);
@@ -1727,7 +1877,7 @@ void diag_absmax_eps(hipStream_t s, const double *Kx, const int *didx, int N, do
     (void)hipMemsetAsync(scal, 0, 3 * sizeof(double), s);
     if (N > 0) {
         int nb = (N + WG - 1) / WG;
-        if (nb > 2048) nb = 2048;
+        if (nb > 1024) nb = 1024;
         k_diag_absmax<<<nb, WG, 0, s>>>(Kx, didx, N, (unsigned long long *)scal);
     }
     k_eps_from_max<<<1, 1, 0, s>>>(c, prop, (unsigned long long *)scal);
@@ -1744,10 +1894,10 @@ void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv) {
     if (bv.nb) k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv);
 }
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x) {
-    if (bv.nb) k_bundle_solve<true><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x);
+    if (bv.nb) k_bundle_solve<true><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, nullptr);
 }
-void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x) {
-    if (bv.nb) k_bundle_solve<false><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x);
+void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const double *addv) {
+    if (bv.nb) k_bundle_solve<false><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv);
 }
 void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
                  const double *x, const double *b, double *e, unsigned long long *nrm, int *nan) {
@@ -1766,6 +1916,7 @@ void factor_finalize(hipStream_t s, const LdlView &v, ListView c) {
     switch (m) {                                                           \
     case FWD: KERNEL<FWD><<<GRID, WG, 0, s>>>(__VA_ARGS__); break;         \
     case BWD: KERNEL<BWD><<<GRID, WG, 0, s>>>(__VA_ARGS__); break;         \
+    case SPMV: KERNEL<SPMV><<<GRID, WG, 0, s>>>(__VA_ARGS__); break;       \
     default: KERNEL<SYMV><<<GRID, WG, 0, s>>>(__VA_ARGS__); break;         \
     }
 
@@ -1819,6 +1970,15 @@ void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long
 }
 void getlhs_perm(hipStream_t s, double *lx, double *lz, const double *xp, const int *iperm, int n, int m) {
     if (n + m) k_getlhs_perm<<<stream_grid(n + m), WG, 0, s>>>(lx, lz, xp, iperm, n, m);
+}
+void waxpby(hipStream_t s, double *w, double a, const double *x, double b, const double *y, int n) {
+    if (n) k_waxpby<<<stream_grid(n), WG, 0, s>>>(w, a, x, b, y, n);
+}
+int dot_scratch_doubles() { return DOT_BLOCKS; }
+void dot(hipStream_t s, const double *a, const double *b, int n, double *out, double *scratch) {
+    const int nb = n > 0 ? std::min(DOT_BLOCKS, (n + WG - 1) / WG) : 0;
+    if (nb) k_dot_partial<<<nb, WG, 0, s>>>(a, b, n, scratch);
+    k_dot_final<<<1, WG, 0, s>>>(scratch, nb, out);
 }
 void add_vec(hipStream_t s, double *dx, const double *x, int N) {
     if (N) k_add_vec<<<stream_grid(N), WG, 0, s>>>(dx, x, N);

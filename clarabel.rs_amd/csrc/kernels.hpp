@@ -26,6 +26,7 @@ struct LdlView {
 struct BundleView {
     int nb;
     const int *bundle_ptr, *blvl_ptr, *blvl;
+    const int *pf; // 2 per bundle: longest rows of L, prefetched by the forward sweep (-1: none)
     int max_nodes;
 };
 
@@ -52,7 +53,8 @@ void scatter_values(hipStream_t s, double *Kx, const int *map, const double *val
 // ---- numeric LDL' -------------------------------------------------------------
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv);
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x);
-void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x);
+// addv != nullptr: the bundle rows leave as x + addv (refinement candidate), see Engine::enqueue_solve_inplace
+void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const double *addv);
 // e[bundle rows] = b - K x with K stored once (U: row i = diagonal + entries to ancestors)
 void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
                  const double *x, const double *b, double *e, unsigned long long *nrm, int *nan);
@@ -62,7 +64,7 @@ void factor_B(hipStream_t s, const LdlView &v, ChunkView chunks);
 void factor_finalize(hipStream_t s, const LdlView &v, ListView cols);
 
 // ---- triangular solves + symv (row-gather family) -------------------------------
-enum GatherMode { FWD = 0, BWD = 1, SYMV = 2 };
+enum GatherMode { FWD = 0, BWD = 1, SYMV = 2, SPMV = 3 };
 struct GatherArgs {
     const int *ptr, *idx; // CSR-like: row r owns [ptr[r], ptr[r+1])
     const double *val;
@@ -74,6 +76,7 @@ struct GatherArgs {
     // device-scope atomicMax is divided by the slot count; the host takes the max.
     unsigned long long *nrm;
     int *nan;
+    double alpha;       // SPMV only: out = (aux ? aux : 0) + alpha * (M xin)
 };
 constexpr int NRM_SLOTS = 64;
 constexpr int NRM_STRIDE = 16; // in u64 words: one slot per 128-byte line
@@ -100,6 +103,11 @@ void setrhs_perm(hipStream_t s, double *bperm, double *xinit, const double *rhsx
 void getlhs_perm(hipStream_t s, double *lhsx, double *lhsz, const double *xperm, const int *iperm,
                  int n, int m);
 void add_vec(hipStream_t s, double *dx, const double *x, int N); // dx = x + dx
+// w = a x + b y (y == nullptr: w = a x); w may alias x or y
+void waxpby(hipStream_t s, double *w, double a, const double *x, double b, const double *y, int n);
+// *out = a . b, deterministic (fixed partition + tree); scratch: dot_scratch_doubles() doubles
+int dot_scratch_doubles();
+void dot(hipStream_t s, const double *a, const double *b, int n, double *out, double *scratch);
 // slots (NRM_SLOTS x NRM_STRIDE) <- bit patterns of partial max|v|; *nanflag |= any NaN
 void norm_inf(hipStream_t s, const double *v, int N, unsigned long long *out, int *nanflag);
 
@@ -149,6 +157,8 @@ void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, co
 void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv);
 void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx);
 // step / rhs operations of the symmetric cones (Zero rows, Nonnegative rows, SecondOrder cones)
+void cone_unit_shift(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,
+                     double *z, double alpha, int primal);
 void cone_affine_ds(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,
                     double *ds);
 void cone_combined_ds_shift(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz,

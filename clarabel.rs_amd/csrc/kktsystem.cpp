@@ -1,0 +1,385 @@
+// kktsystem.cpp -- L3 of the C ABI: DefaultKKTSystem (default/kktsystem.rs:16-292) and
+// DefaultResiduals::update (default/residuals.rs:69-111) with every vector resident in HBM.
+// Built on the public chip_kkt_* entry points (L2) and on the handle's stream; the only new
+// device work is sparse gemv / symv (the row-gather family in SPMV mode), w = a x + b y and
+// deterministic dot products.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "engine.hpp"
+
+using namespace chip;
+
+namespace {
+
+int failk(int code, const std::string &msg) {
+    set_error(msg);
+    return code;
+}
+
+constexpr int T_MAX = 32, B_MIN = 16384, B_CHUNK = 4096; // same classes as symbolic.cpp
+
+// CSR-like sparse operator y = aux + alpha * M x with its row work lists
+struct SpMat {
+    int rows = 0;
+    int *ptr = nullptr, *idx = nullptr, *map = nullptr; // map: position in the caller's nzval
+    double *val = nullptr;
+    size_t nnz = 0;
+    int *t_idx = nullptr, *w_idx = nullptr, *b_row = nullptr, *b_beg = nullptr, *b_end = nullptr, *br_idx = nullptr;
+    int nt = 0, nw = 0, nbc = 0, nbr = 0;
+};
+
+struct DevPool {
+    std::vector<void *> allocs;
+    template <typename T> int alloc(T **dst, size_t n) {
+        *dst = nullptr;
+        void *p = nullptr;
+        CHIP_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+        allocs.push_back(p);
+        *dst = (T *)p;
+        return CHIP_OK;
+    }
+    template <typename T> int upload(T **dst, const std::vector<T> &src) {
+        int rc = alloc(dst, src.size());
+        if (rc) return rc;
+        if (!src.empty()) CHIP_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+        return CHIP_OK;
+    }
+    ~DevPool() {
+        for (void *p : allocs) (void)hipFree(p);
+    }
+};
+
+int build_spmat(DevPool &pool, SpMat &M, int rows, const std::vector<int> &ptr, const std::vector<int> &idx,
+                const std::vector<int> &map) {
+    M.rows = rows;
+    M.nnz = idx.size();
+    std::vector<int> t, w, brow, bbeg, bend, br;
+    for (int r = 0; r < rows; r++) {
+        const int len = ptr[r + 1] - ptr[r];
+        if (len > B_MIN) {
+            br.push_back(r);
+            for (int b = ptr[r]; b < ptr[r + 1]; b += B_CHUNK) {
+                brow.push_back(r);
+                bbeg.push_back(b);
+                bend.push_back(std::min(ptr[r + 1], b + B_CHUNK));
+            }
+        } else if (len > T_MAX) {
+            w.push_back(r);
+        } else {
+            t.push_back(r); // includes empty rows: they must still receive aux (or 0)
+        }
+    }
+    int rc;
+    if ((rc = pool.upload(&M.ptr, ptr))) return rc;
+    if ((rc = pool.upload(&M.idx, idx))) return rc;
+    if ((rc = pool.upload(&M.map, map))) return rc;
+    if ((rc = pool.alloc(&M.val, idx.size()))) return rc;
+    if ((rc = pool.upload(&M.t_idx, t))) return rc;
+    if ((rc = pool.upload(&M.w_idx, w))) return rc;
+    if ((rc = pool.upload(&M.b_row, brow))) return rc;
+    if ((rc = pool.upload(&M.b_beg, bbeg))) return rc;
+    if ((rc = pool.upload(&M.b_end, bend))) return rc;
+    if ((rc = pool.upload(&M.br_idx, br))) return rc;
+    M.nt = (int)t.size();
+    M.nw = (int)w.size();
+    M.nbc = (int)brow.size();
+    M.nbr = (int)br.size();
+    return CHIP_OK;
+}
+
+} // namespace
+
+struct chip_kktsystem {
+    chip_kkt *kkt = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    int n = 0, m = 0;
+    size_t nnzP = 0, nnzA = 0;
+    DevPool pool;
+    SpMat Psym, Arow, Acol; // P as full symmetric rows; A by rows (A x); A by columns (A' z)
+    double *q = nullptr, *b = nullptr, *src = nullptr; // src: staging for value refreshes
+    double *x1 = nullptr, *z1 = nullptr, *x2 = nullptr, *z2 = nullptr, *workx = nullptr, *workz = nullptr,
+           *work_conic = nullptr, *wn = nullptr;
+    double *dots = nullptr, *scratch = nullptr; // 16 result slots + reduction scratch
+    double hdots[16];
+
+    void spmv(const SpMat &M, double *y, const double *aux, double alpha, const double *x) {
+        dev::GatherArgs a{M.ptr, M.idx, M.val, x, y, aux, nullptr, nullptr, alpha};
+        if (M.nbr) dev::gather_Bprep(stream, dev::SPMV, a, dev::ListView{M.br_idx, M.nbr});
+        dev::gather_merged(stream, dev::SPMV, a, dev::ListView{M.t_idx, M.nt}, dev::ListView{M.w_idx, M.nw},
+                           dev::ChunkView{M.b_row, M.b_beg, M.b_end, M.nbc});
+    }
+    int refresh(SpMat &M, const double *host_vals, size_t nsrc) {
+        if (nsrc) CHIP_HIP(hipMemcpyAsync(src, host_vals, nsrc * sizeof(double), hipMemcpyHostToDevice, stream));
+        dev::gather_values(stream, M.val, src, M.map, (int)M.nnz);
+        CHIP_HIP(hipStreamSynchronize(stream)); // src is reused by the next refresh
+        return CHIP_OK;
+    }
+    void dot(int slot, const double *a, const double *bb, int len) { dev::dot(stream, a, bb, len, dots + slot, scratch); }
+    int read_dots() {
+        CHIP_HIP(hipMemcpyAsync(hdots, dots, sizeof(hdots), hipMemcpyDeviceToHost, stream));
+        CHIP_HIP(hipStreamSynchronize(stream));
+        return CHIP_OK;
+    }
+    int copy(double *dst, const double *srcv, int len) {
+        if (len) CHIP_HIP(hipMemcpyAsync(dst, srcv, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        return CHIP_OK;
+    }
+    int zero(double *dst, int len) {
+        if (len) CHIP_HIP(hipMemsetAsync(dst, 0, (size_t)len * sizeof(double), stream));
+        return CHIP_OK;
+    }
+    // cached per update(): q.x2, b.z2, x2'Px2 (the reference recomputes the same values per solve)
+    double qx2 = 0, bz2 = 0, x2Px2 = 0;
+    int solve_constant_rhs();
+};
+
+// new values on the fixed patterns (create, and data_updating.rs:98-133)
+static int refresh_data(chip_kktsystem *h, const double *P, const double *A, const double *q, const double *b) {
+    int rc;
+    if (P && h->nnzP) {
+        if ((rc = h->refresh(h->Psym, P, h->nnzP))) return rc;
+    }
+    if (A && h->nnzA) {
+        if ((rc = h->refresh(h->Arow, A, h->nnzA))) return rc;
+        if ((rc = h->refresh(h->Acol, A, h->nnzA))) return rc;
+    }
+    if (q && h->n) CHIP_HIP(hipMemcpyAsync(h->q, q, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (b && h->m) CHIP_HIP(hipMemcpyAsync(h->b, b, (size_t)h->m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHIP_HIP(hipStreamSynchronize(h->stream));
+    return CHIP_OK;
+}
+
+int32_t chip_kktsystem_create(chip_kktsystem **out, chip_kkt *kkt, const uint64_t *Pcolptr, const uint64_t *Prowval,
+                              const double *Pnzval, const uint64_t *Acolptr, const uint64_t *Arowval,
+                              const double *Anzval, const double *q, const double *b) {
+    if (!out || !kkt || !Pcolptr || !Acolptr) return CHIP_ERR_ARG;
+    *out = nullptr;
+    if (kkt_host_only(kkt)) return failk(CHIP_ERR_NO_DEVICE, "host-only handle: no numeric work without a GPU");
+    int64_t dims[8];
+    int rc = chip_kkt_dims(kkt, dims);
+    if (rc) return rc;
+    const int64_t n = dims[0], m = dims[1];
+    const uint64_t nnzP = Pcolptr[n], nnzA = Acolptr[n];
+    if (nnzP >= (1ull << 31) || nnzA >= (1ull << 31)) return failk(CHIP_ERR_DIM, "nnz out of int32 range");
+    if ((nnzP && (!Prowval || !Pnzval)) || (nnzA && (!Arowval || !Anzval)) || (n && !q) || (m && !b))
+        return CHIP_ERR_ARG;
+    std::unique_ptr<chip_kktsystem> h(new chip_kktsystem());
+    h->kkt = kkt;
+    h->stream = (hipStream_t)chip_kkt_stream(kkt);
+    h->device = kkt_device(kkt);
+    h->n = (int)n;
+    h->m = (int)m;
+    h->nnzP = nnzP;
+    h->nnzA = nnzA;
+    CHIP_HIP(hipSetDevice(h->device));
+    // ---- P as full symmetric rows (csc/matrix_math.rs:178-208 applies each off-diagonal twice)
+    {
+        std::vector<int> ptr((size_t)n + 1, 0);
+        for (int64_t c = 0; c < n; c++)
+            for (uint64_t p = Pcolptr[c]; p < Pcolptr[c + 1]; p++) {
+                const int64_t r = (int64_t)Prowval[p];
+                if (r > c || r < 0) return failk(CHIP_ERR_NOT_TRIU, "P is not upper triangular");
+                ptr[r + 1]++;
+                if (r != c) ptr[c + 1]++;
+            }
+        for (int64_t i = 0; i < n; i++) ptr[i + 1] += ptr[i];
+        std::vector<int> idx((size_t)ptr[n]), map((size_t)ptr[n]), next(ptr.begin(), ptr.end() - 1);
+        for (int64_t c = 0; c < n; c++)
+            for (uint64_t p = Pcolptr[c]; p < Pcolptr[c + 1]; p++) {
+                const int64_t r = (int64_t)Prowval[p];
+                idx[next[r]] = (int)c;
+                map[next[r]++] = (int)p;
+                if (r != c) {
+                    idx[next[c]] = (int)r;
+                    map[next[c]++] = (int)p;
+                }
+            }
+        if ((rc = build_spmat(h->pool, h->Psym, (int)n, ptr, idx, map))) return rc;
+    }
+    // ---- A by rows (A x) and by columns (A' z)
+    {
+        std::vector<int> ptr((size_t)m + 1, 0);
+        for (uint64_t p = 0; p < nnzA; p++) {
+            if (Arowval[p] >= (uint64_t)m) return failk(CHIP_ERR_DIM, "A row index out of range");
+            ptr[Arowval[p] + 1]++;
+        }
+        for (int64_t i = 0; i < m; i++) ptr[i + 1] += ptr[i];
+        std::vector<int> idx((size_t)nnzA), map((size_t)nnzA), next(ptr.begin(), ptr.end() - 1);
+        for (int64_t c = 0; c < n; c++)
+            for (uint64_t p = Acolptr[c]; p < Acolptr[c + 1]; p++) {
+                const int t = next[Arowval[p]]++;
+                idx[t] = (int)c;
+                map[t] = (int)p;
+            }
+        if ((rc = build_spmat(h->pool, h->Arow, (int)m, ptr, idx, map))) return rc;
+        std::vector<int> cptr((size_t)n + 1), cidx((size_t)nnzA), cmap((size_t)nnzA);
+        for (int64_t c = 0; c <= n; c++) cptr[c] = (int)Acolptr[c];
+        for (uint64_t p = 0; p < nnzA; p++) {
+            cidx[p] = (int)Arowval[p];
+            cmap[p] = (int)p;
+        }
+        if ((rc = build_spmat(h->pool, h->Acol, (int)n, cptr, cidx, cmap))) return rc;
+    }
+    DevPool &pl = h->pool;
+    if ((rc = pl.alloc(&h->src, std::max<size_t>({(size_t)nnzP, (size_t)nnzA, (size_t)n, (size_t)m})))) return rc;
+    if ((rc = pl.alloc(&h->q, n)) || (rc = pl.alloc(&h->b, m))) return rc;
+    if ((rc = pl.alloc(&h->x1, n)) || (rc = pl.alloc(&h->x2, n)) || (rc = pl.alloc(&h->workx, n)) ||
+        (rc = pl.alloc(&h->wn, n)))
+        return rc;
+    if ((rc = pl.alloc(&h->z1, m)) || (rc = pl.alloc(&h->z2, m)) || (rc = pl.alloc(&h->workz, m)) ||
+        (rc = pl.alloc(&h->work_conic, m)))
+        return rc;
+    if ((rc = pl.alloc(&h->dots, 16)) || (rc = pl.alloc(&h->scratch, (size_t)dev::dot_scratch_doubles()))) return rc;
+    CHIP_HIP(hipMemset(h->dots, 0, 16 * sizeof(double)));
+    if ((rc = refresh_data(h.get(), nnzP ? Pnzval : nullptr, nnzA ? Anzval : nullptr, q, b))) return rc;
+    *out = h.release();
+    return CHIP_OK;
+}
+
+void chip_kktsystem_destroy(chip_kktsystem *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+int32_t chip_kktsystem_update_data(chip_kktsystem *h, const double *P, const double *A, const double *q,
+                                   const double *b) {
+    if (!h) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    int rc = refresh_data(h, P, A, q, b);
+    if (rc) return rc;
+    if (P && (rc = chip_kkt_update_P(h->kkt, P))) return rc; // directldlkktsolver.rs:191-197
+    if (A && (rc = chip_kkt_update_A(h->kkt, A))) return rc;
+    return CHIP_OK;
+}
+
+// kktsystem.rs:264-279
+int chip_kktsystem::solve_constant_rhs() {
+    dev::waxpby(stream, workx, -1.0, q, 0.0, nullptr, n); // workx = -q
+    int rc = chip_kkt_setrhs_dev(kkt, workx, b);
+    if (rc) return rc;
+    rc = chip_kkt_solve_dev(kkt, x2, z2);
+    if (rc != 1) return rc;
+    // scalars of the tau denominator that only depend on (x2, z2)
+    dot(0, q, x2, n);
+    dot(1, b, z2, m);
+    spmv(Psym, wn, nullptr, 1.0, x2);
+    dot(2, x2, wn, n);
+    if ((rc = read_dots())) return rc;
+    qx2 = hdots[0];
+    bz2 = hdots[1];
+    x2Px2 = hdots[2];
+    return 1;
+}
+
+int32_t chip_kktsystem_update(chip_kktsystem *h) {
+    if (!h) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    int rc = chip_kkt_update(h->kkt, nullptr);
+    if (rc != 1) return rc;
+    return h->solve_constant_rhs();
+}
+
+int32_t chip_kktsystem_solve(chip_kktsystem *h, chip_vars *lhs, const chip_vars *rhs, const chip_vars *var,
+                             int32_t step_direction) {
+    if (!h || !lhs || !rhs || !var) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    const int n = h->n, m = h->m;
+    hipStream_t s = h->stream;
+    int rc;
+    // workx = rhs.x ; work_conic = the constant term of  Hs dz + ds = -c
+    if ((rc = h->copy(h->workx, rhs->x, n))) return rc;
+    if (step_direction == CHIP_STEP_AFFINE) {
+        if ((rc = h->copy(h->work_conic, var->s, m))) return rc;
+    } else {
+        if ((rc = chip_kkt_ds_from_dz_offset_dev(h->kkt, h->work_conic, rhs->s, var->z))) return rc;
+    }
+    dev::waxpby(s, h->workz, 1.0, h->work_conic, -1.0, rhs->z, m);
+    if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->workz))) return rc;
+    rc = chip_kkt_solve_dev(h->kkt, h->x1, h->z1);
+    if (rc != 1) return rc;
+    // tau: xi = x / tau ; numerator and denominator of kktsystem.rs:170-186
+    const double tau = var->tau, kappa = var->kappa;
+    double *xi = h->workx;
+    dev::waxpby(s, xi, 1.0 / tau, var->x, 0.0, nullptr, n);
+    h->dot(3, h->q, h->x1, n);
+    h->dot(4, h->b, h->z1, m);
+    h->spmv(h->Psym, h->wn, nullptr, 1.0, h->x1); // P x1
+    h->dot(5, xi, h->wn, n);                       // xi' P x1
+    dev::waxpby(s, xi, -1.0, h->x2, 1.0, xi, n);   // xi - x2
+    h->spmv(h->Psym, h->wn, nullptr, 1.0, xi);
+    h->dot(6, xi, h->wn, n);                       // (xi - x2)' P (xi - x2)
+    if ((rc = h->read_dots())) return rc;
+    const double tau_num = rhs->tau - rhs->kappa / tau + h->hdots[3] + h->hdots[4] + 2.0 * h->hdots[5];
+    double tau_den = kappa / tau - h->qx2 - h->bz2;
+    tau_den += h->hdots[6] - h->x2Px2;
+    const double ltau = tau_num / tau_den;
+    lhs->tau = ltau;
+    dev::waxpby(s, lhs->x, 1.0, h->x1, ltau, h->x2, n);
+    dev::waxpby(s, lhs->z, 1.0, h->z1, ltau, h->z2, m);
+    // ds = -(Hs dz + c)
+    if ((rc = chip_kkt_mul_Hs_dev(h->kkt, lhs->s, lhs->z))) return rc;
+    dev::waxpby(s, lhs->s, -1.0, h->work_conic, -1.0, lhs->s, m);
+    lhs->kappa = -(rhs->kappa + kappa * ltau) / tau;
+    CHIP_HIP(hipGetLastError());
+    return 1;
+}
+
+int32_t chip_kktsystem_solve_initial_point(chip_kktsystem *h, chip_vars *var) {
+    if (!h || !var) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    const int n = h->n, m = h->m;
+    hipStream_t s = h->stream;
+    int rc;
+    if (h->nnzP == 0) { // LP initialisation: [0; b] -> (x, -s), then [-q; 0] -> z
+        if ((rc = h->zero(h->workx, n))) return rc;
+        if ((rc = h->copy(h->workz, h->b, m))) return rc;
+        if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->workz))) return rc;
+        rc = chip_kkt_solve_dev(h->kkt, var->x, var->s);
+        dev::waxpby(s, var->s, -1.0, var->s, 0.0, nullptr, m); // negate (also on failure, as the reference)
+        if (rc != 1) return rc;
+        dev::waxpby(s, h->workx, -1.0, h->q, 0.0, nullptr, n);
+        if ((rc = h->zero(h->workz, m))) return rc;
+        if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->workz))) return rc;
+        rc = chip_kkt_solve_dev(h->kkt, nullptr, var->z);
+        return rc;
+    }
+    dev::waxpby(s, h->workx, -1.0, h->q, 0.0, nullptr, n);
+    if ((rc = h->copy(h->workz, h->b, m))) return rc;
+    if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->workz))) return rc;
+    rc = chip_kkt_solve_dev(h->kkt, var->x, var->z);
+    dev::waxpby(s, var->s, -1.0, var->z, 0.0, nullptr, m);
+    return rc;
+}
+
+int32_t chip_residuals_update(chip_kktsystem *h, const chip_vars *var, double *rx, double *rz, double *rx_inf,
+                              double *rz_inf, double *Px, double out5[5]) {
+    if (!h || !var || !out5) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    const int n = h->n, m = h->m;
+    hipStream_t s = h->stream;
+    h->dot(8, h->q, var->x, n);
+    h->dot(9, h->b, var->z, m);
+    h->dot(10, var->s, var->z, m);
+    h->spmv(h->Psym, Px, nullptr, 1.0, var->x);     // Px = P x (P symmetric)
+    h->dot(11, var->x, Px, n);
+    h->spmv(h->Acol, rx_inf, nullptr, -1.0, var->z); // rx_inf = -A' z
+    h->spmv(h->Arow, rz_inf, var->s, 1.0, var->x);   // rz_inf = A x + s
+    dev::waxpby(s, rx, -1.0, Px, -var->tau, h->q, n); // rx = rx_inf - Px - q tau
+    dev::waxpby(s, rx, 1.0, rx_inf, 1.0, rx, n);
+    dev::waxpby(s, rz, 1.0, rz_inf, -var->tau, h->b, m); // rz = rz_inf - b tau
+    int rc = h->read_dots();
+    if (rc) return rc;
+    const double qx = h->hdots[8], bz = h->hdots[9], sz = h->hdots[10], xPx = h->hdots[11];
+    out5[0] = qx + bz + var->kappa + xPx / var->tau;
+    out5[1] = qx;
+    out5[2] = bz;
+    out5[3] = sz;
+    out5[4] = xPx;
+    return CHIP_OK;
+}

@@ -239,6 +239,11 @@ int32_t chip_kkt_step_length_dev(chip_kkt *h, const double *dz_dev, const double
                                  const double *z_dev, const double *s_dev, double alpha_max,
                                  double *alpha_out);
 int32_t chip_kkt_margins_dev(chip_kkt *h, const double *z_dev, double *alpha_out, double *beta_out);
+/* scaled_unit_shift  compositecone.rs:208-214 (nonnegativecone.rs:64-66, socone.rs:110-112,
+ * zerocone.rs:63-69): z += alpha * e; primal_cone != 0 selects PrimalOrDualCone::PrimalCone
+ * (Zero-cone rows are zeroed); with margins this is the initial-point fix-up
+ * _shift_to_cone_interior, default/variables.rs:231-256 */
+int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha, int32_t primal_cone);
 int32_t chip_kkt_info(const chip_kkt *h, chip_info *info);
 int32_t chip_kkt_get_perm(const chip_kkt *h, uint64_t *perm);
 int32_t chip_kkt_get_symbolic(const chip_kkt *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,
@@ -258,6 +263,52 @@ void *chip_kkt_stream(chip_kkt *h);
  * returns out[0] = launches, out[1] = total ms, out[2] = family. */
 int32_t chip_kkt_profile(chip_kkt *h, int32_t family);
 int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]);
+
+/* ===========================================================================
+ * L3 -- the caller either side of the KKT solve, device resident:
+ *   DefaultKKTSystem  src/solver/implementations/default/kktsystem.rs:16-292
+ *   DefaultResiduals  src/solver/implementations/default/residuals.rs:69-111
+ * Built on the chip_kkt handle (borrowed: it must outlive the chip_kktsystem)
+ * and launching on that handle's stream.  Vectors are DEVICE pointers: x[n],
+ * z[m], s[m] as in DefaultVariables (default/variables.rs:12-36); tau/kappa
+ * travel by value.  Dot products are deterministic two-stage reductions; the
+ * scalar algebra (tau numerator / denominator, kktsystem.rs:170-186) runs on
+ * the host in the reference's order after ONE device-to-host copy per call.
+ * Return values: 1 / 0 like the reference's bool, or a negative chip_status.
+ * ===========================================================================*/
+typedef struct chip_kktsystem chip_kktsystem;
+typedef struct {
+    double *x, *z, *s; /* device, n / m / m */
+    double tau, kappa;
+} chip_vars;
+enum { CHIP_STEP_AFFINE = 0, CHIP_STEP_COMBINED = 1 }; /* StepDirection, core/mod.rs */
+/* DefaultKKTSystem::new (kktsystem.rs:38-88) given the already-built KKTSolver; P triu CSC
+ * (n x n), A CSC (m x n), q[n], b[m] are copied to the device */
+int32_t chip_kktsystem_create(chip_kktsystem **out, chip_kkt *kkt, const uint64_t *Pcolptr,
+                              const uint64_t *Prowval, const double *Pnzval, const uint64_t *Acolptr,
+                              const uint64_t *Arowval, const double *Anzval, const double *q,
+                              const double *b);
+void chip_kktsystem_destroy(chip_kktsystem *h);
+/* KKTSystem::update (kktsystem.rs:108-125): kktsolver.update (Hs from the device-held cone
+ * state, see chip_kkt_update_scaling*) + the constant-RHS solve (x2, z2) (:264-279) */
+int32_t chip_kktsystem_update(chip_kktsystem *h);
+/* KKTSystem::solve (kktsystem.rs:127-209): lhs <- step for rhs at `variables`; lhs->tau/kappa
+ * are written.  Needs cones with mul_Hs / ds_from_dz_offset on the device, else
+ * CHIP_ERR_UNSUPPORTED. */
+int32_t chip_kktsystem_solve(chip_kktsystem *h, chip_vars *lhs, const chip_vars *rhs,
+                             const chip_vars *variables, int32_t step_direction);
+/* KKTSystem::solve_initial_point (kktsystem.rs:211-258): fills variables->x, s, z */
+int32_t chip_kktsystem_solve_initial_point(chip_kktsystem *h, chip_vars *variables);
+/* Residuals::update (residuals.rs:69-111): device outputs rx[n], rz[m], rx_inf[n], rz_inf[m],
+ * Px[n]; host outputs out5 = {r_tau, dot_qx, dot_bz, dot_sz, dot_xPx} */
+int32_t chip_residuals_update(chip_kktsystem *h, const chip_vars *variables, double *rx_dev,
+                              double *rz_dev, double *rx_inf_dev, double *rz_inf_dev, double *Px_dev,
+                              double out5[5]);
+/* data_updating.rs:98-133: new values on the same patterns (NULL = unchanged); P and A are
+ * forwarded to chip_kkt_update_P / chip_kkt_update_A */
+int32_t chip_kktsystem_update_data(chip_kktsystem *h, const double *Pnzval_or_null,
+                                   const double *Anzval_or_null, const double *q_or_null,
+                                   const double *b_or_null);
 
 #ifdef __cplusplus
 }

@@ -1298,3 +1298,191 @@ int orc_kktsolver_solve_full(orc_kktsolver *ks, const orc_settings *st, const do
     if (ok && x) memcpy(x, ks->x, (size_t)ks->N * sizeof(double));
     return ok;
 }
+
+/* ======================================================================== */
+/* L3: DefaultKKTSystem (default/kktsystem.rs:108-292) and DefaultResiduals  */
+/* (default/residuals.rs:69-111) -- the caller either side of the KKT solve. */
+/* Test infrastructure only, like the rest of this file.                     */
+/* ======================================================================== */
+/* matrix_math.rs:258-299 _csc_axpby_N / :301-343 _csc_axpby_T */
+void orc_gemv_N(int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, double *y,
+                const double *x, double a, double b) {
+    for (int64_t i = 0; i < m; i++) y[i] = b == 0.0 ? 0.0 : b * y[i];
+    if (a == 0.0) return;
+    for (int64_t j = 0; j < n; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            if (a == 1.0) y[Ai[p]] += Ax[p] * x[j];
+            else if (a == -1.0) y[Ai[p]] -= Ax[p] * x[j];
+            else y[Ai[p]] += a * Ax[p] * x[j];
+        }
+}
+void orc_gemv_T(int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, double *y,
+                const double *x, double a, double b) {
+    (void)m;
+    for (int64_t j = 0; j < n; j++) y[j] = b == 0.0 ? 0.0 : b * y[j];
+    if (a == 0.0) return;
+    for (int64_t j = 0; j < n; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            if (a == 1.0) y[j] += Ax[p] * x[Ai[p]];
+            else if (a == -1.0) y[j] -= Ax[p] * x[Ai[p]];
+            else y[j] += a * Ax[p] * x[Ai[p]];
+        }
+}
+double orc_dot(const double *a, const double *b, int64_t n) { return dotp(a, b, n); }
+
+typedef struct {
+    orc_kktsolver *ks; /* borrowed */
+    orc_cones *cones;  /* borrowed */
+    int64_t n, m, nnzP, nnzA;
+    int64_t *Pp, *Pi, *Ap, *Ai;
+    double *Px, *Ax, *q, *b;
+    double *x1, *z1, *x2, *z2, *workx, *workz, *work_conic;
+} orc_kktsystem;
+
+static void *dupmem(const void *src, size_t bytes) {
+    void *p = malloc(bytes ? bytes : 1);
+    if (bytes) memcpy(p, src, bytes);
+    return p;
+}
+void orc_kktsystem_free(orc_kktsystem *s) {
+    if (!s) return;
+    free(s->Pp); free(s->Pi); free(s->Ap); free(s->Ai); free(s->Px); free(s->Ax); free(s->q); free(s->b);
+    free(s->x1); free(s->z1); free(s->x2); free(s->z2); free(s->workx); free(s->workz); free(s->work_conic);
+    free(s);
+}
+/* kktsystem.rs:38-88 (the KKTSolver itself is built by the caller and borrowed) */
+orc_kktsystem *orc_kktsystem_new(orc_kktsolver *ks, orc_cones *cones, int64_t n, int64_t m, const int64_t *Pp,
+                                 const int64_t *Pi, const double *Px, const int64_t *Ap, const int64_t *Ai,
+                                 const double *Ax, const double *q, const double *b) {
+    orc_kktsystem *s = (orc_kktsystem *)calloc(1, sizeof(*s));
+    s->ks = ks; s->cones = cones; s->n = n; s->m = m;
+    s->nnzP = Pp[n]; s->nnzA = Ap[n];
+    s->Pp = (int64_t *)dupmem(Pp, (size_t)(n + 1) * 8); s->Pi = (int64_t *)dupmem(Pi, (size_t)s->nnzP * 8);
+    s->Px = (double *)dupmem(Px, (size_t)s->nnzP * 8);
+    s->Ap = (int64_t *)dupmem(Ap, (size_t)(n + 1) * 8); s->Ai = (int64_t *)dupmem(Ai, (size_t)s->nnzA * 8);
+    s->Ax = (double *)dupmem(Ax, (size_t)s->nnzA * 8);
+    s->q = (double *)dupmem(q, (size_t)n * 8); s->b = (double *)dupmem(b, (size_t)m * 8);
+    s->x1 = (double *)calloc((size_t)n + 1, 8); s->x2 = (double *)calloc((size_t)n + 1, 8);
+    s->workx = (double *)calloc((size_t)n + 1, 8);
+    s->z1 = (double *)calloc((size_t)m + 1, 8); s->z2 = (double *)calloc((size_t)m + 1, 8);
+    s->workz = (double *)calloc((size_t)m + 1, 8); s->work_conic = (double *)calloc((size_t)m + 1, 8);
+    return s;
+}
+const double *orc_kktsystem_x2(const orc_kktsystem *s) { return s->x2; }
+const double *orc_kktsystem_z2(const orc_kktsystem *s) { return s->z2; }
+
+/* kktsystem.rs:264-279 */
+static int kktsystem_solve_constant_rhs(orc_kktsystem *s, const orc_settings *st) {
+    for (int64_t i = 0; i < s->n; i++) s->workx[i] = -1.0 * s->q[i]; /* axpby(-1, q, 0) */
+    orc_kktsolver_setrhs(s->ks, s->workx, s->b);
+    return orc_kktsolver_solve(s->ks, st, s->x2, s->z2);
+}
+/* kktsystem.rs:108-125 */
+int orc_kktsystem_update(orc_kktsystem *s, const orc_settings *st, const double *hs_override) {
+    if (!orc_kktsolver_update(s->ks, st, hs_override)) return 0;
+    return kktsystem_solve_constant_rhs(s, st);
+}
+/* kktsystem.rs:127-209.  vars/rhs/lhs are (x[n], z[m], s[m], tau, kappa); lhs_tk = {tau, kappa} out.
+ * step_direction: 0 = Affine, 1 = Combined */
+int orc_kktsystem_solve(orc_kktsystem *s, const orc_settings *st, double *lhs_x, double *lhs_z, double *lhs_s,
+                        double *lhs_tk, const double *rhs_x, const double *rhs_z, const double *rhs_s,
+                        double rhs_tau, double rhs_kappa, const double *var_x, const double *var_z,
+                        const double *var_s, double var_tau, double var_kappa, int step_direction) {
+    const int64_t n = s->n, m = s->m;
+    double *workx = s->workx, *workz = s->workz, *cterm = s->work_conic;
+    memcpy(workx, rhs_x, (size_t)n * 8);
+    if (step_direction == 0) memcpy(cterm, var_s, (size_t)m * 8);
+    else orc_cones_ds_from_dz_offset(s->cones, cterm, rhs_s, var_z);
+    for (int64_t i = 0; i < m; i++) workz[i] = 1.0 * cterm[i] + (-1.0) * rhs_z[i]; /* waxpby */
+    orc_kktsolver_setrhs(s->ks, workx, workz);
+    if (!orc_kktsolver_solve(s->ks, st, s->x1, s->z1)) return 0;
+    /* solve for dtau */
+    double *xi = workx;
+    const double rtau = 1.0 / var_tau;
+    for (int64_t i = 0; i < n; i++) xi[i] = rtau * var_x[i]; /* axpby(recip(tau), x, 0) */
+    double tau_num = rhs_tau - rhs_kappa / var_tau + dotp(s->q, s->x1, n) + dotp(s->b, s->z1, m) +
+                     2.0 * orc_quad_form_triu(n, s->Pp, s->Pi, s->Px, xi, s->x1);
+    for (int64_t i = 0; i < n; i++) xi[i] = -1.0 * s->x2[i] + 1.0 * xi[i]; /* axpby(-1, x2, 1) */
+    double tau_den = var_kappa / var_tau - dotp(s->q, s->x2, n) - dotp(s->b, s->z2, m);
+    tau_den += orc_quad_form_triu(n, s->Pp, s->Pi, s->Px, xi, xi) -
+               orc_quad_form_triu(n, s->Pp, s->Pi, s->Px, s->x2, s->x2);
+    const double ltau = tau_num / tau_den;
+    for (int64_t i = 0; i < n; i++) lhs_x[i] = 1.0 * s->x1[i] + ltau * s->x2[i];
+    for (int64_t i = 0; i < m; i++) lhs_z[i] = 1.0 * s->z1[i] + ltau * s->z2[i];
+    orc_cones_mul_Hs(s->cones, lhs_s, lhs_z);
+    for (int64_t i = 0; i < m; i++) lhs_s[i] = -1.0 * cterm[i] + (-1.0) * lhs_s[i]; /* axpby(-1, c, -1) */
+    lhs_tk[0] = ltau;
+    lhs_tk[1] = -(rhs_kappa + var_kappa * ltau) / var_tau;
+    return 1;
+}
+/* kktsystem.rs:211-258 */
+int orc_kktsystem_solve_initial_point(orc_kktsystem *s, const orc_settings *st, double *var_x, double *var_s,
+                                      double *var_z) {
+    const int64_t n = s->n, m = s->m;
+    int ok;
+    if (s->nnzP == 0) {
+        for (int64_t i = 0; i < n; i++) s->workx[i] = 0.0;
+        memcpy(s->workz, s->b, (size_t)m * 8);
+        orc_kktsolver_setrhs(s->ks, s->workx, s->workz);
+        ok = orc_kktsolver_solve(s->ks, st, var_x, var_s);
+        for (int64_t i = 0; i < m; i++) var_s[i] = -var_s[i];
+        if (!ok) return ok;
+        for (int64_t i = 0; i < n; i++) s->workx[i] = -1.0 * s->q[i];
+        for (int64_t i = 0; i < m; i++) s->workz[i] = 0.0;
+        orc_kktsolver_setrhs(s->ks, s->workx, s->workz);
+        ok = orc_kktsolver_solve(s->ks, st, NULL, var_z);
+    } else {
+        for (int64_t i = 0; i < n; i++) s->workx[i] = -s->q[i];
+        memcpy(s->workz, s->b, (size_t)m * 8);
+        orc_kktsolver_setrhs(s->ks, s->workx, s->workz);
+        ok = orc_kktsolver_solve(s->ks, st, var_x, var_z);
+        for (int64_t i = 0; i < m; i++) var_s[i] = -var_z[i];
+    }
+    return ok;
+}
+/* residuals.rs:69-111.  out5 = {rtau, dot_qx, dot_bz, dot_sz, dot_xPx} */
+void orc_residuals_update(const orc_kktsystem *s, const double *var_x, const double *var_z, const double *var_s,
+                          double var_tau, double var_kappa, double *rx, double *rz, double *rx_inf,
+                          double *rz_inf, double *Px, double *out5) {
+    const int64_t n = s->n, m = s->m;
+    const double qx = dotp(s->q, var_x, n), bz = dotp(s->b, var_z, m), sz = dotp(var_s, var_z, m);
+    for (int64_t i = 0; i < n; i++) Px[i] = 0.0;
+    orc_symv(n, s->Pp, s->Pi, s->Px, Px, var_x, 1.0, 0.0);
+    const double xPx = dotp(var_x, Px, n);
+    orc_gemv_T(m, n, s->Ap, s->Ai, s->Ax, rx_inf, var_z, -1.0, 0.0);
+    memcpy(rz_inf, var_s, (size_t)m * 8);
+    orc_gemv_N(m, n, s->Ap, s->Ai, s->Ax, rz_inf, var_x, 1.0, 1.0);
+    for (int64_t i = 0; i < n; i++) rx[i] = -1.0 * Px[i] + (-var_tau) * s->q[i];
+    for (int64_t i = 0; i < n; i++) rx[i] = 1.0 * rx_inf[i] + 1.0 * rx[i];
+    for (int64_t i = 0; i < m; i++) rz[i] = 1.0 * rz_inf[i] + (-var_tau) * s->b[i];
+    out5[0] = qx + bz + var_kappa + xPx / var_tau;
+    out5[1] = qx; out5[2] = bz; out5[3] = sz; out5[4] = xPx;
+}
+
+/* compositecone.rs:208-214: nonnegativecone.rs:64-66, socone.rs:110-112, zerocone.rs:63-69 */
+void orc_cones_scaled_unit_shift(const orc_cones *cs, double *z, double alpha, int primal_cone) {
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        double *zi = z + c->cone_start;
+        if (c->tag == CONE_ZERO) {
+            if (primal_cone)
+                for (int64_t k = 0; k < c->numel; k++) zi[k] = 0.0;
+        } else if (c->tag == CONE_NONNEG) {
+            for (int64_t k = 0; k < c->numel; k++) zi[k] += alpha;
+        } else if (c->tag == CONE_SOC) {
+            zi[0] += alpha;
+        }
+    }
+}
+/* compositecone.rs:130-150 degree(): Zero 0, Nonnegative dim, SOC 1 */
+int64_t orc_cones_degree(const orc_cones *cs) {
+    int64_t d = 0;
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        if (c->tag == CONE_NONNEG) d += c->numel;
+        else if (c->tag == CONE_SOC) d += 1;
+        else if (c->tag == CONE_EXP || c->tag == CONE_POW) d += 3;
+        else if (c->tag == CONE_PSDTRI) d += c->dim;
+    }
+    return d;
+}

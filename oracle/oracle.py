@@ -81,6 +81,9 @@ def lib():
         L.orc_kktsolver_dsigns.restype = P_I8
         L.orc_kktsolver_last_ir_iters.restype = C.c_int32
         L.orc_kktsolver_regularizer.restype = C.c_double
+        L.orc_kktsystem_new.restype = C.c_void_p
+        L.orc_dot.restype = C.c_double
+        L.orc_cones_degree.restype = C.c_int64
     return _LIB
 
 
@@ -384,6 +387,14 @@ class Cones:
         dz, ds, z, s = _af(dz), _af(ds), _af(z), _af(s)
         return lib().orc_cones_step_length(self._h, _pf(dz), _pf(ds), _pf(z), _pf(s), C.c_double(alpha_max))
 
+    def scaled_unit_shift(self, z, alpha, primal_cone):
+        """in place on the float64 array z"""
+        lib().orc_cones_scaled_unit_shift(self._h, _pf(z), C.c_double(alpha), C.c_int(1 if primal_cone else 0))
+
+    @property
+    def degree(self):
+        return int(lib().orc_cones_degree(self._h))
+
     def margins(self, z):
         z = _af(z)
         a, b = C.c_double(0), C.c_double(0)
@@ -526,3 +537,62 @@ class KKTSolver:
     @property
     def regularizer(self):
         return lib().orc_kktsolver_regularizer(self._h)
+
+
+class Variables:
+    """DefaultVariables (default/variables.rs:12-36): x[n], s[m], z[m], tau, kappa (host arrays)"""
+
+    def __init__(self, n, m):
+        self.x, self.s, self.z = np.zeros(n), np.zeros(m), np.zeros(m)
+        self.tau, self.kappa = 1.0, 1.0
+
+
+class KKTSystem:
+    """DefaultKKTSystem (default/kktsystem.rs:16-292) + DefaultResiduals.update (default/residuals.rs:69-111)
+    over an existing KKTSolver; q, b, P (triu), A as the solver data."""
+
+    def __init__(self, kktsolver, cones, n, m, P, A, q, b):
+        self.ks, self.cones, self.n, self.m = kktsolver, cones, n, m
+        Pp, Pi, Px = _ai(P[0]), _ai(P[1]), _af(P[2])
+        Ap, Ai, Ax = _ai(A[0]), _ai(A[1]), _af(A[2])
+        q, b = _af(q), _af(b)
+        self._h = C.c_void_p(lib().orc_kktsystem_new(kktsolver._h, cones._h, C.c_int64(n), C.c_int64(m), _pi(Pp),
+                                                     _pi(Pi), _pf(Px), _pi(Ap), _pi(Ai), _pf(Ax), _pf(q), _pf(b)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_kktsystem_free(self._h)
+            self._h = None
+
+    def update(self, hs_override=None):
+        ho = None
+        if hs_override is not None:
+            hs_override = _af(hs_override)
+            ho = _pf(hs_override)
+        return bool(lib().orc_kktsystem_update(self._h, C.byref(self.ks.settings), ho))
+
+    def solve(self, lhs, rhs, variables, step_direction):
+        """step_direction: 0 = affine, 1 = combined; fills lhs (Variables) -> bool"""
+        tk = np.zeros(2)
+        ok = bool(lib().orc_kktsystem_solve(
+            self._h, C.byref(self.ks.settings), _pf(lhs.x), _pf(lhs.z), _pf(lhs.s), _pf(tk), _pf(_af(rhs.x)),
+            _pf(_af(rhs.z)), _pf(_af(rhs.s)), C.c_double(rhs.tau), C.c_double(rhs.kappa), _pf(_af(variables.x)),
+            _pf(_af(variables.z)), _pf(_af(variables.s)), C.c_double(variables.tau), C.c_double(variables.kappa),
+            C.c_int(step_direction)))
+        if ok:
+            lhs.tau, lhs.kappa = float(tk[0]), float(tk[1])
+        return ok
+
+    def solve_initial_point(self, variables):
+        return bool(lib().orc_kktsystem_solve_initial_point(self._h, C.byref(self.ks.settings), _pf(variables.x),
+                                                            _pf(variables.s), _pf(variables.z)))
+
+    def residuals(self, variables):
+        """-> dict(rx, rz, rx_inf, rz_inf, Px, rtau, dot_qx, dot_bz, dot_sz, dot_xPx)"""
+        n, m = self.n, self.m
+        rx, rz, rxi, rzi, Px, o = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(5)
+        lib().orc_residuals_update(self._h, _pf(_af(variables.x)), _pf(_af(variables.z)), _pf(_af(variables.s)),
+                                   C.c_double(variables.tau), C.c_double(variables.kappa), _pf(rx), _pf(rz),
+                                   _pf(rxi), _pf(rzi), _pf(Px), _pf(o))
+        return dict(rx=rx, rz=rz, rx_inf=rxi, rz_inf=rzi, Px=Px, rtau=o[0], dot_qx=o[1], dot_bz=o[2],
+                    dot_sz=o[3], dot_xPx=o[4])

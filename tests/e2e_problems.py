@@ -1,0 +1,44 @@
+"""The reference's own end-to-end fixtures (data copied as numbers, not code):
+tests/basic_qp.rs:6-42, tests/basic_lp.rs:5-25, tests/basic_socp.rs:5-52 with their asserted
+solutions (basic_qp.rs:100-117, basic_lp.rs:27-44, basic_socp.rs:54-70)."""
+import numpy as np
+import scipy.sparse as sp
+
+ZERO, NN, SOC = 0, 1, 2
+
+
+def _csc(M):
+    M = sp.csc_matrix(M)
+    M.sort_indices()
+    return (M.indptr.astype(np.int64), M.indices.astype(np.int64), M.data.astype(np.float64))
+
+
+def _triu(P):
+    return _csc(sp.triu(sp.csc_matrix(P), format="csc"))
+
+
+def basic_qp():
+    P = np.array([[4.0, 1.0], [1.0, 2.0]])
+    A0 = np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]])
+    A = np.vstack([-A0, A0])
+    return dict(n=2, m=6, P=_triu(P), A=_csc(A), q=[1.0, 1.0], b=[-1.0, 0.0, 0.0, 1.0, 0.7, 0.7],
+                cones=[(NN, 3), (NN, 3)], x=[0.3, 0.7], obj=1.8800000298331538, tol=1e-6)
+
+
+def basic_lp():
+    I3 = np.eye(3)
+    A = 2.0 * np.vstack([I3, -I3])
+    return dict(n=3, m=6, P=_csc(sp.csc_matrix((3, 3))), A=_csc(A), q=[3.0, -2.0, 1.0], b=[1.0] * 6,
+                cones=[(NN, 3), (NN, 3)], x=[-0.5, 0.5, -0.5], obj=-3.0, tol=1e-8)
+
+
+def basic_socp(sparse_soc=False):
+    P = np.array([[1.4652521089139698, 0.6137176286085666, -1.1527861771130112],
+                  [0.6137176286085666, 2.219109946678485, -1.4400420548730628],
+                  [-1.1527861771130112, -1.4400420548730628, 1.6014483534926371]])
+    I3 = np.eye(3)
+    A = np.vstack([2.0 * I3, -2.0 * I3, I3])
+    cones = [(NN, 3), (SOC, 6)] if sparse_soc else [(NN, 3), (NN, 3), (SOC, 3)]
+    return dict(n=3, m=9, P=_triu(P), A=_csc(A), q=[0.1, -2.0, 1.0], b=[1.0] * 6 + [0.0] * 3, cones=cones,
+                x=None if sparse_soc else [-0.5, 0.435603, -0.245459], obj=None if sparse_soc else -8.4590e-01,
+                tol=1e-4)

@@ -431,3 +431,98 @@ def test_full_scale_properties_c3(hip):
     assert relerr(x3, 2.0 * x1 - 3.0 * x2) <= 1e-7
     info = ks.linear_solver_info()
     assert info.n == 3003001 and info.positive_inertia == pr["n"] + 1000
+
+
+# ---- L3: DefaultKKTSystem / DefaultResiduals on the device ----------------------------
+def _l3_pair(hip, oracle, pr, seed=0):
+    rng = np.random.default_rng(seed)
+    n, m = pr["n"], pr["m"]
+    q, b = rng.standard_normal(n), rng.standard_normal(m)
+    P = hip.CscMatrix(n, n, *pr["P"])
+    A = hip.CscMatrix(m, n, *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], m, n)
+    sysd = hip.HipKKTSystem(ks, P, A, q, b)
+    cones = oracle.Cones(pr["cones"])
+    ko = oracle.KKTSolver(n, m, pr["P"], pr["A"], cones, perm=ks.perm)
+    syso = oracle.KKTSystem(ko, cones, n, m, pr["P"], pr["A"], q, b)
+    return ks, sysd, cones, ko, syso, rng
+
+
+def _dvars(hip, v):
+    d = hip.DeviceVariables(len(v.x), len(v.s))
+    d.x.copy_from(v.x)
+    d.s.copy_from(v.s)
+    d.z.copy_from(v.z)
+    d.tau, d.kappa = v.tau, v.kappa
+    return d
+
+
+@pytest.mark.parametrize("which", ["socp", "qp"])
+def test_l3_kktsystem_and_residuals(hip, oracle, which):
+    """chip_kktsystem_{update,solve,solve_initial_point} + chip_residuals_update against the
+    oracle restatement of default/kktsystem.rs:108-259 and default/residuals.rs:69-111"""
+    pr = problems.portfolio_socp(12, 300, seed=3) if which == "socp" else problems.random_qp(800, 1500, band=12, seed=4)
+    ks, sysd, cones, ko, syso, rng = _l3_pair(hip, oracle, pr)
+    n, m = pr["n"], pr["m"]
+    assert ks.update_scaling(pr["s"], pr["z"]) and cones.update_scaling(pr["s"], pr["z"])
+    assert sysd.update() and syso.update()
+    # variables at the scaling point; rhs = a random (well-scaled) direction request
+    v = oracle.Variables(n, m)
+    v.x, v.s, v.z = rng.standard_normal(n), pr["s"].copy(), pr["z"].copy()
+    v.tau, v.kappa = 1.3, 0.7
+    rhs = oracle.Variables(n, m)
+    rhs.x, rhs.z, rhs.s = rng.standard_normal(n), rng.standard_normal(m), cones.affine_ds(pr["s"])
+    rhs.tau, rhs.kappa = 0.4, -0.2
+    for direction in (hip.STEP_AFFINE, hip.STEP_COMBINED):
+        lo = oracle.Variables(n, m)
+        assert syso.solve(lo, rhs, v, direction)
+        ld, dr, dv = hip.DeviceVariables(n, m), _dvars(hip, rhs), _dvars(hip, v)
+        assert sysd.solve(ld, dr, dv, direction)
+        assert abs(ld.tau - lo.tau) <= TOL * max(1.0, abs(lo.tau))
+        assert abs(ld.kappa - lo.kappa) <= TOL * max(1.0, abs(lo.kappa))
+        for a, c in ((ld.x, lo.x), (ld.z, lo.z), (ld.s, lo.s)):
+            assert relerr(a.numpy(), c) <= TOL
+    # residuals
+    ro = syso.residuals(v)
+    D = hip.DeviceArray
+    rx, rz, rxi, rzi, Px = D(n), D(m), D(n), D(m), D(n)
+    rd = sysd.residuals_update(_dvars(hip, v), rx, rz, rxi, rzi, Px)
+    for k in ("rtau", "dot_qx", "dot_bz", "dot_sz", "dot_xPx"):
+        assert abs(rd[k] - ro[k]) <= 1e-10 * max(1.0, abs(ro[k]))
+    for a, k in ((rx, "rx"), (rz, "rz"), (rxi, "rx_inf"), (rzi, "rz_inf"), (Px, "Px")):
+        assert relerr(a.numpy(), ro[k]) <= 1e-12
+    # initial point (LP branch for the SOCP: P == 0; QP branch otherwise)
+    vo, vd = oracle.Variables(n, m), hip.DeviceVariables(n, m)
+    assert syso.solve_initial_point(vo) and sysd.solve_initial_point(vd)
+    for a, c in ((vd.x, vo.x), (vd.z, vo.z), (vd.s, vo.s)):
+        assert relerr(a.numpy(), c) <= TOL
+
+
+@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp"])
+def test_e2e_reference_answers_on_device(hip, oracle, name):
+    """the reference's end-to-end known answers (tests/basic_qp.rs:100-117, basic_lp.rs:27-44,
+    basic_socp.rs:54-70) reached with every L1-L3 operation on the device, and the same
+    trajectory as the oracle-backed loop"""
+    from tests import e2e_problems as E
+    from tests import ipm_driver as ipm
+    pr = getattr(E, name)()
+    args = (pr["n"], pr["m"], pr["P"], pr["A"], pr["q"], pr["b"], pr["cones"])
+    td, to = [], []
+    out = ipm.solve(ipm.HipBackend(hip, *args), pr["cones"], pr["q"], pr["b"], trace=td)
+    ref = ipm.solve(ipm.OracleBackend(oracle, *args), pr["cones"], pr["q"], pr["b"], trace=to)
+    assert out["status"] == "Solved"
+    assert np.linalg.norm(out["x"] - np.array(pr["x"])) <= pr["tol"]
+    assert abs(out["obj_val"] - pr["obj"]) <= pr["tol"]
+    assert out["iterations"] == ref["iterations"]
+    for a, c in zip(td, to):  # (mu, alpha, sigma, res_primal, res_dual, gap): same path
+        if c[0] > 1e-6:  # near convergence the iterates amplify rounding differences
+            assert abs(a[0] - c[0]) <= 1e-6 * c[0]
+            assert abs(a[1] - c[1]) <= 1e-6
+
+
+def test_e2e_sparse_soc_on_device(hip):
+    from tests import e2e_problems as E
+    from tests import ipm_driver as ipm
+    pr = E.basic_socp(sparse_soc=True)
+    be = ipm.HipBackend(hip, pr["n"], pr["m"], pr["P"], pr["A"], pr["q"], pr["b"], pr["cones"])
+    assert ipm.solve(be, pr["cones"], pr["q"], pr["b"])["status"] == "Solved"

@@ -183,6 +183,40 @@ __device__ __forceinline__ void factor_col_thread(const LdlView &v, int j) {
     double d = v.D[j];
     const int cb = v.Lp[j], ce = v.Lp[j + 1];
     const int rb = v.Rp[j], re = v.Rp[j + 1];
+    if (ce - cb <= 4) {
+        // tiny column (the bulk of block-arrow KKTs): its row ids and running values live in
+        // registers -- no search loads, no read-modify-write round trips through L2
+        const int cn = ce - cb;
+        const int r0 = cn > 0 ? v.Li[cb] : -1, r1 = cn > 1 ? v.Li[cb + 1] : -1;
+        const int r2 = cn > 2 ? v.Li[cb + 2] : -1;
+        double a0 = cn > 0 ? v.Lx[cb] : 0.0, a1 = cn > 1 ? v.Lx[cb + 1] : 0.0;
+        double a2 = cn > 2 ? v.Lx[cb + 2] : 0.0, a3 = cn > 3 ? v.Lx[cb + 3] : 0.0;
+        for (int t = rb; t < re; ++t) {
+            const int k = v.Rcol[t], p = v.Rpos[t];
+            const double ljk = v.Lx[p];
+            const double w = ljk * v.D[k];
+            d -= ljk * w;
+            const int pe = v.Lp[k + 1];
+            for (int pp = p + 1; pp < pe; ++pp) {
+                const int i = v.Li[pp];
+                const double u = v.Lx[pp] * w;
+                if (i == r0) a0 -= u;
+                else if (i == r1) a1 -= u;
+                else if (i == r2) a2 -= u;
+                else a3 -= u;
+            }
+        }
+        const double dinv = pivot_rule(v, j, d);
+        const double a[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < cn) {
+                const double l = a[q] * dinv;
+                v.Lx[cb + q] = l;
+                v.Rx[v.Tpos[cb + q]] = l;
+            }
+        return;
+    }
     for (int t = rb; t < re; ++t) {
         const int k = v.Rcol[t], p = v.Rpos[t];
         const double ljk = v.Lx[p];
@@ -427,31 +461,33 @@ __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv)
     }
 }
 
+// in-bundle part of one row (forward: row of L; backward: column of L without its top tail),
+// strided over `stride` threads starting at `first`; xs = the bundle's slice of x in LDS
 template <bool FWDMODE>
-__device__ __forceinline__ double bundle_row_dot(const LdlView &v, const double *xs, const double *x,
-                                                 int s0, int s1, int r, int first, int stride) {
+__device__ __forceinline__ double bundle_row_dot(const LdlView &v, const double *xs, int s0, int r, int first,
+                                                 int stride) {
     double s = 0.0;
     if (FWDMODE) {
         for (int t = v.Rp[r] + first; t < v.Rp[r + 1]; t += stride) s += v.Rx[t] * xs[v.Rcol[t] - s0];
     } else {
-        for (int q = v.Lp[r] + first; q < v.Lp[r + 1]; q += stride) {
-            const int i = v.Li[q];
-            s += v.Lx[q] * (i < s1 ? xs[i - s0] : x[i]);
-        }
+        for (int q = v.Lp[r] + first; q < v.Ls[r]; q += stride) s += v.Lx[q] * xs[v.Li[q] - s0];
     }
     return s;
 }
 
-// forward (rows of L, descendants only -> all inside the bundle) or backward (columns of L,
-// ancestors inside the bundle come from LDS, ancestors in the top are final in x) sweep of a
-// bundle with its slice of x staged in LDS.
-//
-// Forward only: the bundle's two longest rows (bv.pf: the separator rows that close its
-// subtrees, e.g. the u / v rows of a sparse SOC) sit alone on the LAST levels, where a
-// pointer -> entries -> reduce chain would be fully exposed.  Their entries do not depend on
-// x, so every thread requests its share of them at kernel start (PF0 + PF1 register pairs);
-// when their level comes up only LDS gathers and one block reduction are left.
-constexpr int PF0 = 4, PF1 = 2;
+// forward (rows of L, descendants only -> all inside the bundle) or backward (columns of L)
+// sweep of a bundle with its slice of x staged in LDS, one __syncthreads()-separated level at a
+// time.  A workgroup's sweep is a chain of dependent global loads per level (row pointers ->
+// entries -> gathers), so the number of sequential round trips is what is minimised:
+//  * backward: x_j = x_j / d_j - sum_i l_ij x_i (qdldl.rs:737-752).  The scaling by 1/d_j and the
+//    contributions of TOP ancestors (final in x before this kernel starts; they are the tail
+//    [Ls[j], Lp[j+1]) of each column) are applied while staging, for all rows at once; the level
+//    loop then only gathers from LDS.
+//  * the row pointers of the NEXT level's first sweep are requested before the current level is
+//    processed.
+//  * thin rows: two rows per thread, FOUR entries of each row per shot -- rows of <= 4 entries
+//    (nearly all rows of a block-arrow KKT) cost one round trip instead of one per entry.
+constexpr int ESHOT = 4;
 template <bool FWDMODE>
 __global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restrict__ addv) {
@@ -461,65 +497,66 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
     __shared__ int fat[FATCAP];
     __shared__ int nfat;
     const int b = blockIdx.x;
-    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
+    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
     const int *lv = bv.blvl + bv.blvl_ptr[b];
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    int pr0 = -1, pr1 = -1, pe0 = 0, pe1 = 0, pb0 = 0, pb1 = 0;
-    int pi0[PF0], pi1[PF1];
-    double pv0[PF0], pv1[PF1];
-    if (FWDMODE) {
-        pr0 = bv.pf[2 * b];
-        pr1 = bv.pf[2 * b + 1];
-        pb0 = pr0 >= 0 ? v.Rp[pr0] : 0;
-        pe0 = pr0 >= 0 ? v.Rp[pr0 + 1] : 0;
-        pb1 = pr1 >= 0 ? v.Rp[pr1] : 0;
-        pe1 = pr1 >= 0 ? v.Rp[pr1 + 1] : 0;
+    const int *pbeg = FWDMODE ? v.Rp : v.Lp;          // first slot of a row
+    const int *pend = FWDMODE ? v.Rp + 1 : v.Ls;      // one past its last in-bundle slot
+    const int *cidx = FWDMODE ? v.Rcol : v.Li;
+    const double *cval = FWDMODE ? v.Rx : v.Lx;
+    const int nsteps = FWDMODE ? nl - 1 : nl;         // forward: level 0 has no descendants
+    auto level_of = [&](int step) { return FWDMODE ? step + 1 : nl - 1 - step; };
+    // row pointers of the first sweep (2 rows per thread) of a level
+    int ntb[2] = {0, 0}, nte[2] = {0, 0};
+    auto request_ptrs = [&](int step) {
+        const int l = level_of(step);
+        const int lb = lv[l], le = lv[l + 1];
 #pragma unroll
-        for (int q = 0; q < PF0; ++q) {
-            const unsigned t = (unsigned)(pb0 + (int)threadIdx.x + q * BWG);
-            const bool ok = (int)t < pe0;
-            pi0[q] = ok ? v.Rcol[t] : -1;
-            pv0[q] = ok ? v.Rx[t] : 0.0;
+        for (int u = 0; u < 2; ++u) {
+            const int j = lb + (int)threadIdx.x + u * BWG;
+            ntb[u] = j < le ? pbeg[j] : 0;
+            nte[u] = j < le ? pend[j] : 0;
         }
+    };
+    if (nsteps > 0) request_ptrs(0);
+    if (FWDMODE) {
+        for (int i = threadIdx.x; i < nloc; i += BWG) xs[i] = x[s0 + i];
+    } else {
+        // staging with 1/d_j and the top-ancestor tail folded in, two rows per thread in lockstep
+        for (int i0 = threadIdx.x; i0 < nloc; i0 += 2 * BWG) {
+            int qb[2], qe[2];
+            double val[2];
 #pragma unroll
-        for (int q = 0; q < PF1; ++q) {
-            const unsigned t = (unsigned)(pb1 + (int)threadIdx.x + q * BWG);
-            const bool ok = (int)t < pe1;
-            pi1[q] = ok ? v.Rcol[t] : -1;
-            pv1[q] = ok ? v.Rx[t] : 0.0;
+            for (int u = 0; u < 2; ++u) {
+                const int i = i0 + u * BWG;
+                const bool ok = i < nloc;
+                qb[u] = ok ? v.Ls[s0 + i] : 0;
+                qe[u] = ok ? v.Lp[s0 + i + 1] : 0;
+                val[u] = ok ? x[s0 + i] * v.Dinv[s0 + i] : 0.0;
+            }
+            const int maxlen = max(qe[0] - qb[0], qe[1] - qb[1]);
+            for (int k = 0; k < maxlen; ++k) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (qb[u] + k < qe[u]) val[u] -= v.Lx[qb[u] + k] * x[v.Li[qb[u] + k]];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (i0 + u * BWG < nloc) xs[i0 + u * BWG] = val[u];
         }
     }
-    // backward: x_j = x_j / d_j - sum_i l_ij x_i (qdldl.rs:737-752); the scaling of the row's own
-    // entry does not depend on the level order, so it is applied while staging (coalesced, off
-    // the per-level critical path)
-    if (FWDMODE)
-        for (int i = threadIdx.x; i < s1 - s0; i += BWG) xs[i] = x[s0 + i];
-    else
-        for (int i = threadIdx.x; i < s1 - s0; i += BWG) xs[i] = x[s0 + i] * v.Dinv[s0 + i];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int *ptr = FWDMODE ? v.Rp : v.Lp;
     // one row by the whole workgroup; the result lands in xs[r - s0] (visible after a barrier)
     auto coop_row = [&](int r) {
-        double s = 0.0;
-        if (FWDMODE && r == pr0) {
-#pragma unroll
-            for (int q = 0; q < PF0; ++q)
-                if (pi0[q] >= 0) s += pv0[q] * xs[pi0[q] - s0];
-            for (int t = pb0 + (int)threadIdx.x + PF0 * BWG; t < pe0; t += BWG) s += v.Rx[t] * xs[v.Rcol[t] - s0];
-        } else if (FWDMODE && r == pr1) {
-#pragma unroll
-            for (int q = 0; q < PF1; ++q)
-                if (pi1[q] >= 0) s += pv1[q] * xs[pi1[q] - s0];
-            for (int t = pb1 + (int)threadIdx.x + PF1 * BWG; t < pe1; t += BWG) s += v.Rx[t] * xs[v.Rcol[t] - s0];
-        } else {
-            s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, threadIdx.x, BWG);
-        }
+        double s = bundle_row_dot<FWDMODE>(v, xs, s0, r, threadIdx.x, BWG);
         s = block_sum(s, red);
         if (threadIdx.x == 0) xs[r - s0] -= s;
     };
-    for (int step = FWDMODE ? 1 : 0; step < nl; ++step) {
-        const int l = FWDMODE ? step : nl - 1 - step;
+    for (int step = 0; step < nsteps; ++step) {
+        const int l = level_of(step);
         const int lb = lv[l], le = lv[l + 1];
+        int ftb[2] = {ntb[0], ntb[1]}, fte[2] = {nte[0], nte[1]}; // this level's first sweep
+        if (step + 1 < nsteps) request_ptrs(step + 1);            // in flight while this level runs
         __syncthreads(); // the previous level is final in xs; its fat list is no longer read
         if (le - lb == 1) { // a level of its own: no classification pass
             coop_row(lb);
@@ -527,19 +564,16 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
         }
         if (threadIdx.x == 0) nfat = 0;
         __syncthreads();
-        // thin rows, two per thread in lockstep (independent load chains in flight; a single
-        // workgroup's sweep is latency-bound, not bandwidth-bound)
-        const int *cidx = FWDMODE ? v.Rcol : v.Li;
-        const double *cval = FWDMODE ? v.Rx : v.Lx;
         for (int j0 = lb + threadIdx.x; j0 < le; j0 += 2 * BWG) {
             int jr[2], tb[2], te[2];
             double sum[2];
+            const bool first = j0 < lb + BWG;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int j = j0 + u * BWG;
                 jr[u] = j < le ? j : -1;
-                tb[u] = j < le ? ptr[j] : 0;
-                te[u] = j < le ? ptr[j + 1] : 0;
+                tb[u] = first ? ftb[u] : (j < le ? pbeg[j] : 0);
+                te[u] = first ? fte[u] : (j < le ? pend[j] : 0);
                 sum[u] = 0.0;
                 if (te[u] - tb[u] > THIN_MAX) {
                     const int slot = atomicAdd(&nfat, 1);
@@ -551,25 +585,27 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
                 }
             }
             const int maxlen = max(te[0] - tb[0], te[1] - tb[1]);
-            for (int k = 0; k < maxlen; ++k) {
-                int ii[2];
-                double vv[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const bool ok = tb[u] + k < te[u];
-                    ii[u] = ok ? cidx[tb[u] + k] : -1;
-                    vv[u] = ok ? cval[tb[u] + k] : 0.0;
-                }
+            for (int k = 0; k < maxlen; k += ESHOT) {
+                int ii[2][ESHOT];
+                double vv[2][ESHOT];
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    if (ii[u] >= 0) sum[u] += vv[u] * ((FWDMODE || ii[u] < s1) ? xs[ii[u] - s0] : x[ii[u]]);
+#pragma unroll
+                    for (int e = 0; e < ESHOT; ++e) {
+                        const unsigned t = (unsigned)(tb[u] + k + e);
+                        const bool ok = (int)t < te[u];
+                        ii[u][e] = ok ? cidx[t] : -1;
+                        vv[u][e] = ok ? cval[t] : 0.0;
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < ESHOT; ++e)
+                        if (ii[u][e] >= 0) sum[u] += vv[u][e] * xs[ii[u][e] - s0];
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                if (jr[u] >= 0) {
-                    const int j = jr[u];
-                    xs[j - s0] -= sum[u];
-                }
+                if (jr[u] >= 0) xs[jr[u] - s0] -= sum[u];
         }
         __syncthreads();
         const int nf = min(nfat, FATCAP);
@@ -579,7 +615,7 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
         } else {
             for (int f = wv; f < nf; f += BWG / 64) {
                 const int r = fat[f];
-                double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, lane, 64);
+                double s = bundle_row_dot<FWDMODE>(v, xs, s0, r, lane, 64);
                 s = wave_sum(s);
                 if (lane == 0) xs[r - s0] -= s;
             }
@@ -588,9 +624,9 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
     __syncthreads();
     // addv: the refinement step x + dx folded into the final write of the backward sweep
     if (addv)
-        for (int i = threadIdx.x; i < s1 - s0; i += BWG) x[s0 + i] = xs[i] + addv[s0 + i];
+        for (int i = threadIdx.x; i < nloc; i += BWG) x[s0 + i] = xs[i] + addv[s0 + i];
     else
-        for (int i = threadIdx.x; i < s1 - s0; i += BWG) x[s0 + i] = xs[i];
+        for (int i = threadIdx.x; i < nloc; i += BWG) x[s0 + i] = xs[i];
 }
 
 // B: a column with a huge row count (> 16384 contributions).  Each workgroup
@@ -812,80 +848,75 @@ __device__ __forceinline__ void lds_scatter_add(double *acc, int tgt, double val
 // U row i = diagonal + entries (i, j) to ancestors j > i.  Every entry is applied in both
 // directions: gathered into row i's own sum, and scattered (LDS fp64 atomic) into row j when j
 // is in the bundle; rows j in the top are produced by the level-scheduled gather over their full
-// rows instead.  x and e slices live in LDS; ||e||inf of the bundle is folded into the slots.
+// rows instead.  Only the e slice lives in LDS (it takes the atomics); x is gathered from global
+// memory -- a bundle's slice is a few tens of KB and stays in L1/L2 -- so that FOUR workgroups
+// fit a CU (two LDS slices of a 3000-node bundle would cap it at three and push the 1000
+// bundles of config 3 into a second round).  Two rows per thread, SSHOT entries of each per shot:
+// rows of <= SSHOT entries cost one round trip.  ||e||inf of the bundle is folded into the slots.
+constexpr int SSHOT = 3; // entries of a row per shot (registers: 2 rows x SSHOT x (index, value, x address))
 __global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_bundle_symv(BundleView bv, const int *__restrict__ Up, const int *__restrict__ Ucol,
                    const double *__restrict__ Ux, const double *__restrict__ x,
                    const double *__restrict__ b, double *e, unsigned long long *nrm, int *nanflag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *xs = (double *)smem;
-    double *es = xs + bv.max_nodes;
+    double *es = (double *)smem;
     __shared__ double red[16];
     const int bid = blockIdx.x;
     const int s0 = bv.bundle_ptr[bid], s1 = bv.bundle_ptr[bid + 1], nloc = s1 - s0;
     const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
-    // row pointers of the first sweep are requested BEFORE the vector slices are staged: they do
-    // not depend on x, so their latency overlaps the staging + barrier
-    int tb[4], te[4];
+    // row pointers of the first sweep are requested BEFORE the b slice is staged
+    int tb[2], te[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
         const int i = threadIdx.x + u * BWG;
         tb[u] = i < nloc ? Up[s0 + i] : 0;
         te[u] = i < nloc ? Up[s0 + i + 1] : 0;
     }
-    for (int i = threadIdx.x; i < nloc; i += BWG) {
-        xs[i] = x[s0 + i];
-        es[i] = b[s0 + i];
-    }
+    for (int i = threadIdx.x; i < nloc; i += BWG) es[i] = b[s0 + i];
     __syncthreads();
-    // four rows per thread in lockstep: entry k of the 4 rows are independent loads -> 8 global
-    // loads in flight per thread instead of a chain of dependent ones.  Loop bounds are kept
-    // wave-uniform (lds_scatter_add uses cross-lane operations).
-    for (int w0 = wbase; w0 < nloc; w0 += 4 * BWG) {
+    // loop bounds are kept wave-uniform (lds_scatter_add uses cross-lane operations)
+    for (int w0 = wbase; w0 < nloc; w0 += 2 * BWG) {
         const int i0 = w0 + lane;
-        double acc[4];
+        double acc[2] = {0.0, 0.0}, xi[2];
         int maxlen = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc[u] = 0.0;
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u * BWG;
+            xi[u] = i < nloc ? x[s0 + i] : 0.0;
             maxlen = max(maxlen, te[u] - tb[u]);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-        for (int k = 0; k < maxlen; ++k) {
-            int jj[4];
-            double vv[4];
+        for (int k = 0; k < maxlen; k += SSHOT) {
+            int jj[2][SSHOT];
+            double vv[2][SSHOT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = tb[u] + k < te[u];
-                const unsigned t = (unsigned)(tb[u] + k); // unsigned offset -> sgpr-base addressing
-                jj[u] = ok ? Ucol[t] : -1;
-                vv[u] = ok ? Ux[t] : 0.0;
-            }
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jj[u];
-                int tgt = -1;
-                double sc = 0.0;
-                if (j >= 0) {
-                    if (j < s1) {
-                        acc[u] += vv[u] * xs[j - s0];
-                        if (j != s0 + i0 + u * BWG) {
-                            tgt = j - s0;
-                            sc = -(vv[u] * xs[i0 + u * BWG]); // own x re-read from LDS (registers are scarce)
-                        }
-                    } else {
-                        acc[u] += vv[u] * x[j];
-                    }
+                for (int q = 0; q < SSHOT; ++q) {
+                    const unsigned t = (unsigned)(tb[u] + k + q); // unsigned offset -> sgpr-base addressing
+                    const bool ok = (int)t < te[u];
+                    jj[u][q] = ok ? Ucol[t] : -1;
+                    vv[u][q] = ok ? Ux[t] : 0.0;
                 }
-                lds_scatter_add(es, tgt, sc);
-            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < SSHOT; ++q) {
+                    const int j = jj[u][q];
+                    int tgt = -1;
+                    if (j >= 0) {
+                        acc[u] += vv[u][q] * x[j];
+                        if (j < s1 && j != s0 + i0 + u * BWG) tgt = j - s0;
+                    }
+                    lds_scatter_add(es, tgt, -(vv[u][q] * xi[u]));
+                }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int i = i0 + u * BWG;
             if (i < nloc) atomicAdd(&es[i], -acc[u]);
-            const int in = i + 4 * BWG; // the next sweep's row pointers
+            const int in = i + 2 * BWG; // the next sweep's row pointers
             tb[u] = in < nloc ? Up[s0 + in] : 0;
             te[u] = in < nloc ? Up[s0 + in + 1] : 0;
         }
@@ -1902,7 +1933,7 @@ void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x
 void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
                  const double *x, const double *b, double *e, unsigned long long *nrm, int *nan) {
     if (!bv.nb) return;
-    const size_t lds = ((size_t)bv.max_nodes * 2 * sizeof(double) + 15) & ~(size_t)15;
+    const size_t lds = ((size_t)bv.max_nodes * sizeof(double) + 15) & ~(size_t)15; // the e slice only
     k_bundle_symv<<<bv.nb, BWG, lds, s>>>(bv, Up, Ucol, Ux, x, b, e, nrm, nan);
 }
 void factor_B(hipStream_t s, const LdlView &v, ChunkView c) {

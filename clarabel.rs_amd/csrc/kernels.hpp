@@ -12,6 +12,7 @@ struct LdlView {
     int N;
     int nnzL;
     const int *Lp, *Li;          // L by columns, ascending rows
+    const int *Ls;               // per column: first slot whose row is a top node (tail of the column)
     const int *Rp, *Rcol, *Rpos; // L by rows, Rpos = CSC slot of the entry
     const int *Tpos;             // CSC slot -> CSR slot
     double *Lx, *Rx;             // values in CSC / CSR order
@@ -26,7 +27,6 @@ struct LdlView {
 struct BundleView {
     int nb;
     const int *bundle_ptr, *blvl_ptr, *blvl;
-    const int *pf; // 2 per bundle: longest rows of L, prefetched by the forward sweep (-1: none)
     int max_nodes;
 };
 

@@ -342,22 +342,10 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 S.Tpos[q] = t;
             }
     }
-    {   // the two longest rows of every bundle (separator rows at the top of its subtrees)
-        const i32 nbun = S.bundle_ptr.empty() ? 0 : (i32)S.bundle_ptr.size() - 1;
-        S.bpf.assign((size_t)2 * nbun, -1);
-        for (i32 b = 0; b < nbun; b++) {
-            i32 r0 = -1, r1 = -1, c0 = T_MAX, c1 = T_MAX; // c0 >= c1 > T_MAX
-            for (i32 j = S.bundle_ptr[b]; j < S.bundle_ptr[b + 1]; j++) {
-                const i32 c = S.Rp[j + 1] - S.Rp[j];
-                if (c > c0) {
-                    r1 = r0; c1 = c0; r0 = j; c0 = c;
-                } else if (c > c1) {
-                    r1 = j; c1 = c;
-                }
-            }
-            S.bpf[2 * b] = r0;
-            S.bpf[2 * b + 1] = r1;
-        }
+    S.Ls.assign((size_t)n + 1, 0);
+    for (i32 j = 0; j < n; j++) {
+        const i32 *b = S.Li.data() + S.Lp[j], *e = S.Li.data() + S.Lp[j + 1];
+        S.Ls[j] = (i32)(std::lower_bound(b, e, S.NF) - S.Li.data());
     }
     // ---- K.nzval -> (Lx | D) scatter map ------------------------------------
     S.a2l.resize((size_t)nnzK + 1);

@@ -74,7 +74,9 @@ class Settings(C.Structure):
                 ("iterative_refinement_enable", C.c_int32), ("iterative_refinement_reltol", C.c_double),
                 ("iterative_refinement_abstol", C.c_double), ("iterative_refinement_max_iter", C.c_int32),
                 ("iterative_refinement_stop_ratio", C.c_double), ("device", C.c_int32),
-                ("amd_dense_scale", C.c_double), ("use_graph", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("amd_dense_scale", C.c_double), ("use_graph", C.c_int32), ("reserved0", C.c_int32),
+                ("linesearch_backtrack_step", C.c_double), ("min_terminate_step_length", C.c_double),
+                ("reserved", C.c_int32 * 2)]
 
     @staticmethod
     def default(**kw):
@@ -438,6 +440,17 @@ class HipKKTSolver:
     def scaled_unit_shift_dev(self, z_ptr, alpha, primal_cone):
         _check(lib().chip_kkt_scaled_unit_shift_dev(self._h, C.c_void_p(z_ptr), C.c_double(alpha),
                                                     C.c_int32(1 if primal_cone else 0)), "scaled_unit_shift")
+
+    def unit_initialization_dev(self, z_ptr, s_ptr):
+        _check(lib().chip_kkt_unit_initialization_dev(self._h, C.c_void_p(z_ptr), C.c_void_p(s_ptr)),
+               "unit_initialization")
+
+    def compute_barrier_dev(self, z_ptr, s_ptr, dz_ptr, ds_ptr, alpha):
+        out = C.c_double(0)
+        _check(lib().chip_kkt_compute_barrier_dev(self._h, C.c_void_p(z_ptr), C.c_void_p(s_ptr),
+                                                  C.c_void_p(dz_ptr), C.c_void_p(ds_ptr), C.c_double(alpha),
+                                                  C.byref(out)), "compute_barrier")
+        return out.value
 
     def linear_solver_info(self):
         info = Info()

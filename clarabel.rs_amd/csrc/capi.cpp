@@ -101,6 +101,8 @@ void chip_settings_default(chip_settings *s) {
     s->device = -1;
     s->amd_dense_scale = 1.5;
     s->use_graph = 0;
+    s->linesearch_backtrack_step = 0.8;
+    s->min_terminate_step_length = 1e-4;
 }
 
 const char *chip_last_error(void) {
@@ -780,7 +782,10 @@ int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
 }
 #define NEED_SYMMETRIC(h)                                                                      \
     if ((h)->has_hostHs || (h)->ns3.ncones || (h)->psd.ncones)                                                  \
-    return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: only Zero/Nonnegative/SecondOrder cones")
+    return fail(CHIP_ERR_UNSUPPORTED, "margins / scaled_unit_shift: only Zero/Nonnegative/SecondOrder cones")
+#define NEED_STEP_OPS(h)                                                                       \
+    if ((h)->has_hostHs || (h)->psd.ncones)                                                    \
+    return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: not implemented for PSD cones yet")
 
 int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha, int32_t primal_cone) {
     if (!h || !z_dev) return CHIP_ERR_ARG;
@@ -795,12 +800,13 @@ int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha,
 }
 int32_t chip_kkt_affine_ds_dev(chip_kkt *h, double *ds_dev, const double *s_dev) {
     if (!h || !ds_dev) return CHIP_ERR_ARG;
-    (void)s_dev;
     Engine &E = h->E;
     NEED_DEVICE(E);
-    NEED_SYMMETRIC(h);
+    NEED_STEP_OPS(h);
+    if (h->ns3.ncones && !s_dev) return CHIP_ERR_ARG;
     CHIP_HIP(hipSetDevice(E.device));
     dev::cone_affine_ds(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, ds_dev);
+    dev::ns3_affine_ds(E.stream, h->ns3, ds_dev, s_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
@@ -809,10 +815,11 @@ int32_t chip_kkt_combined_ds_shift_dev(chip_kkt *h, double *shift_dev, double *s
     if (!h || !shift_dev || !step_z_dev || !step_s_dev) return CHIP_ERR_ARG;
     Engine &E = h->E;
     NEED_DEVICE(E);
-    NEED_SYMMETRIC(h);
+    NEED_STEP_OPS(h);
     CHIP_HIP(hipSetDevice(E.device));
     dev::cone_combined_ds_shift(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, shift_dev,
                                 step_z_dev, step_s_dev, sigma_mu);
+    dev::ns3_combined_ds_shift(E.stream, h->ns3, shift_dev, step_z_dev, step_s_dev, sigma_mu);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
@@ -820,16 +827,17 @@ int32_t chip_kkt_ds_from_dz_offset_dev(chip_kkt *h, double *out_dev, const doubl
     if (!h || !out_dev || !ds_dev || !z_dev) return CHIP_ERR_ARG;
     Engine &E = h->E;
     NEED_DEVICE(E);
-    NEED_SYMMETRIC(h);
+    NEED_STEP_OPS(h);
     CHIP_HIP(hipSetDevice(E.device));
     dev::cone_ds_from_dz_offset(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, out_dev,
                                 ds_dev, z_dev);
+    dev::ns3_ds_from_dz_offset(E.stream, h->ns3, out_dev, ds_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
 static int ensure_partials(chip_kkt *h) {
     if (h->d_partial) return CHIP_OK;
-    h->partial_cap = 1024 + h->soc.ncones;
+    h->partial_cap = 1024 + h->soc.ncones + (h->ns3.ncones + 255) / 256 + 8;
     int rc = h->E.alloc(&h->d_partial, (size_t)h->partial_cap * 2);
     if (rc) return rc;
     h->h_partial.resize((size_t)h->partial_cap * 2);
@@ -840,12 +848,13 @@ int32_t chip_kkt_step_length_dev(chip_kkt *h, const double *dz_dev, const double
     if (!h || !alpha_out) return CHIP_ERR_ARG;
     Engine &E = h->E;
     NEED_DEVICE(E);
-    NEED_SYMMETRIC(h);
+    NEED_STEP_OPS(h);
     CHIP_HIP(hipSetDevice(E.device));
     int rc = ensure_partials(h);
     if (rc) return rc;
-    const int used = dev::cone_step_length(E.stream, h->nn_rows, h->nn_count, h->soc, dz_dev, ds_dev, z_dev, s_dev,
-                                           alpha_max, h->d_partial, 1024);
+    // symmetric cones first (compositecone.rs:326-327)
+    int used = dev::cone_step_length(E.stream, h->nn_rows, h->nn_count, h->soc, dz_dev, ds_dev, z_dev, s_dev,
+                                     alpha_max, h->d_partial, 1024);
     double a = alpha_max;
     if (used) {
         CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)used * sizeof(double),
@@ -853,7 +862,47 @@ int32_t chip_kkt_step_length_dev(chip_kkt *h, const double *dz_dev, const double
         CHIP_HIP(hipStreamSynchronize(E.stream));
         for (int i = 0; i < used; i++) a = std::min(a, h->h_partial[i]); // T::min: NaN-ignoring like f64::min
     }
+    if (h->ns3.ncones) { // back off from the boundary, then the nonsymmetric cones (:329-337)
+        a = std::min(a, 1.0 - std::sqrt(2.220446049250313e-16));
+        used = dev::ns3_step_length(E.stream, h->ns3, dz_dev, ds_dev, z_dev, s_dev, a,
+                                    E.st.min_terminate_step_length, E.st.linesearch_backtrack_step, h->d_partial);
+        CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)used * sizeof(double),
+                                hipMemcpyDeviceToHost, E.stream));
+        CHIP_HIP(hipStreamSynchronize(E.stream));
+        for (int i = 0; i < used; i++) a = std::min(a, h->h_partial[i]);
+    }
     *alpha_out = a;
+    return CHIP_OK;
+}
+int32_t chip_kkt_compute_barrier_dev(chip_kkt *h, const double *z_dev, const double *s_dev, const double *dz_dev,
+                                     const double *ds_dev, double alpha, double *barrier_out) {
+    if (!h || !barrier_out || !z_dev || !s_dev || !dz_dev || !ds_dev) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    NEED_STEP_OPS(h);
+    CHIP_HIP(hipSetDevice(E.device));
+    int rc = ensure_partials(h);
+    if (rc) return rc;
+    const int used = dev::cone_barrier(E.stream, h->nn_rows, h->nn_count, h->soc, h->ns3, z_dev, s_dev, dz_dev,
+                                       ds_dev, alpha, h->d_partial);
+    double b = 0.0;
+    if (used) {
+        CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)used * sizeof(double),
+                                hipMemcpyDeviceToHost, E.stream));
+        CHIP_HIP(hipStreamSynchronize(E.stream));
+        for (int i = 0; i < used; i++) b += h->h_partial[i];
+    }
+    *barrier_out = b;
+    return CHIP_OK;
+}
+int32_t chip_kkt_unit_initialization_dev(chip_kkt *h, double *z_dev, double *s_dev) {
+    if (!h || !z_dev || !s_dev) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    NEED_STEP_OPS(h);
+    CHIP_HIP(hipSetDevice(E.device));
+    dev::cone_unit_initialization(E.stream, h->nn_rows, h->nn_count, h->soc, h->ns3, z_dev, s_dev, (int)h->K.m);
+    CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
 int32_t chip_kkt_margins_dev(chip_kkt *h, const double *z_dev, double *alpha_out, double *beta_out) {

@@ -1823,6 +1823,266 @@ __global__ __launch_bounds__(WG) void k_soc_step_ops(SocView v, double *o0, doub
     }
 }
 
+// ---------------------------------------------------------------------------
+// Exponential / Power cones: the step operations either side of the solve, one thread per
+// cone (expcone.rs:129-328, powcone.rs:128-337, nonsymmetric_common.rs:164-192) on the state
+// written by k_ns3_update_scaling: Hs[6] | H_dual[6] | grad[3] | z[3]
+// ---------------------------------------------------------------------------
+// dense3x3/cholesky.rs:13-57 on the packed triu [00,01,11,02,12,22]
+__device__ __forceinline__ bool chol3_factor(double *L, const double *A) {
+    double t = A[0];
+    if (t <= 0.0) return false;
+    L[0] = sqrt(t);
+    L[1] = A[1] / L[0];
+    t = A[2] - L[1] * L[1];
+    if (t <= 0.0) return false;
+    L[2] = sqrt(t);
+    L[3] = A[3] / L[0];
+    L[4] = (A[4] - L[1] * L[3]) / L[2];
+    t = A[5] - L[3] * L[3] - L[4] * L[4];
+    if (t <= 0.0) return false;
+    L[5] = sqrt(t);
+    return true;
+}
+__device__ __forceinline__ void chol3_solve(const double *L, double *x, const double *b) {
+    const double c0 = b[0] / L[0];
+    const double c1 = (b[1] - L[1] * c0) / L[2];
+    const double c2 = (b[2] - L[3] * c0 - L[4] * c1) / L[5];
+    x[2] = c2 / L[5];
+    x[1] = (c1 - L[4] * x[2]) / L[2];
+    x[0] = (c0 - L[1] * x[1] - L[3] * x[2]) / L[0];
+}
+__device__ __forceinline__ double dot3(const double *a, const double *b) {
+    return ((0.0 + a[0] * b[0]) + a[1] * b[1]) + a[2] * b[2];
+}
+__device__ bool ns3_feasible(bool isexp, bool dual, double a, const double *q) {
+    if (isexp) {
+        if (!dual) { // expcone.rs:189-203
+            if (q[2] > 0.0 && q[1] > 0.0) return q[1] * logsafe(q[2] / q[1]) - q[0] > 0.0;
+            return false;
+        }
+        if (q[2] > 0.0 && q[0] < 0.0) return q[1] - q[0] - q[0] * logsafe(-q[2] / q[0]) > 0.0; // :205-220
+        return false;
+    }
+    if (!(q[0] > 0.0 && q[1] > 0.0)) return false;
+    if (!dual) // powcone.rs:188-203
+        return exp(2.0 * a * logsafe(q[0]) + 2.0 * (1.0 - a) * logsafe(q[1])) - q[2] * q[2] > 0.0;
+    return exp((a * 2.0) * logsafe(q[0] / a) + (1.0 - a) * logsafe(q[1] / (1.0 - a)) * 2.0) - q[2] * q[2] > 0.0;
+}
+__device__ double ns3_backtrack(bool isexp, bool dual, double a, const double *dq, const double *q, double alpha,
+                                double amin, double step) {
+    for (;;) {
+        const double w[3] = {1.0 * q[0] + alpha * dq[0], 1.0 * q[1] + alpha * dq[1], 1.0 * q[2] + alpha * dq[2]};
+        if (ns3_feasible(isexp, dual, a, w)) break;
+        alpha *= step;
+        if (alpha < amin) return 0.0;
+    }
+    return alpha;
+}
+__device__ void ns3_higher_correction(bool isexp, double a, const double *Hd, const double *z, double *eta,
+                                      const double *ds, const double *v) {
+    double L[6], u[3];
+    if (!chol3_factor(L, Hd)) {
+        eta[0] = eta[1] = eta[2] = 0.0;
+        return;
+    }
+    chol3_solve(L, u, ds);
+    if (isexp) { // expcone.rs:254-308
+        eta[1] = 1.0;
+        eta[2] = -z[0] / z[2];
+        eta[0] = logsafe(eta[2]);
+        const double psi = z[0] * eta[0] - z[0] + z[1];
+        const double dpu = dot3(u, eta), dpv = dot3(v, eta);
+        const double coef =
+            ((u[0] * (v[0] / z[0] - v[2] / z[2]) + u[2] * (z[0] * v[2] / z[2] - v[0]) / z[2]) * psi -
+             2.0 * dpu * dpv) / (psi * psi * psi);
+        for (int i = 0; i < 3; i++) eta[i] *= coef;
+        const double ip2 = 1.0 / (psi * psi);
+        eta[0] += (1.0 / psi - 2.0 / z[0]) * u[0] * v[0] / (z[0] * z[0]) - u[2] * v[2] / (z[2] * z[2]) / psi +
+                  dpu * ip2 * (v[0] / z[0] - v[2] / z[2]) + dpv * ip2 * (u[0] / z[0] - u[2] / z[2]);
+        eta[2] += 2.0 * (z[0] / psi - 1.0) * u[2] * v[2] / (z[2] * z[2] * z[2]) -
+                  (u[2] * v[0] + u[0] * v[2]) / (z[2] * z[2]) / psi +
+                  dpu * ip2 * (z[0] * v[2] / (z[2] * z[2]) - v[0] / z[2]) +
+                  dpv * ip2 * (z[0] * u[2] / (z[2] * z[2]) - u[0] / z[2]);
+    } else { // powcone.rs:260-337
+        double Hp[6], Hv[3], Hu[3];
+        const double phi = pow(z[0] / a, 2.0 * a) * pow(z[1] / (1.0 - a), 2.0 - 2.0 * a);
+        const double psi = phi - z[2] * z[2];
+        eta[0] = 2.0 * a * phi / z[0];
+        eta[1] = 2.0 * (1.0 - a) * phi / z[1];
+        eta[2] = -2.0 * z[2];
+        Hp[1] = 4.0 * a * (1.0 - a) * phi / (z[0] * z[1]);
+        Hp[0] = 2.0 * a * (2.0 * a - 1.0) * phi / (z[0] * z[0]);
+        Hp[3] = 0.0;
+        Hp[2] = 2.0 * (1.0 - a) * (1.0 - 2.0 * a) * phi / (z[1] * z[1]);
+        Hp[4] = 0.0;
+        Hp[5] = -2.0;
+        const double dpu = dot3(u, eta), dpv = dot3(v, eta);
+        sym3_mul(Hp, Hv, v);
+        const double coef = (dot3(u, Hv) * psi - 2.0 * dpu * dpv) / (psi * psi * psi);
+        const double coef2 = 4.0 * a * (2.0 * a - 1.0) * (1.0 - a) * phi * (u[0] / z[0] - u[1] / z[1]) *
+                             (v[0] / z[0] - v[1] / z[1]) / psi;
+        const double ip2 = 1.0 / (psi * psi);
+        eta[0] = coef * eta[0] - 2.0 * (1.0 - a) * u[0] * v[0] / (z[0] * z[0] * z[0]) + coef2 / z[0] +
+                 Hv[0] * dpu * ip2;
+        eta[1] = coef * eta[1] - 2.0 * a * u[1] * v[1] / (z[1] * z[1] * z[1]) - coef2 / z[1] + Hv[1] * dpu * ip2;
+        eta[2] = coef * eta[2] + Hv[2] * dpu * ip2;
+        sym3_mul(Hp, Hu, u);
+        for (int i = 0; i < 3; i++) eta[i] = (dpv * ip2) * Hu[i] + 1.0 * eta[i];
+    }
+    for (int i = 0; i < 3; i++) eta[i] *= 0.5;
+}
+__device__ double ns3_barrier(bool isexp, double a, const double *z, const double *s) {
+    if (isexp) { // expcone.rs:222-252
+        const double l = logsafe(-z[2] / z[0]);
+        const double bd = -logsafe(-z[2] * z[0]) - logsafe(z[1] - z[0] - z[0] * l);
+        double om = wright_omega(1.0 - s[0] / s[1] - logsafe(s[1] / s[2]));
+        om = (om - 1.0) * (om - 1.0) / om;
+        const double bp = -logsafe(om) - logsafe(s[1]) * 2.0 - logsafe(s[2]) - 3.0;
+        return (0.0 + bd) + bp;
+    }
+    // powcone.rs:223-258 (primal gradient of :394-420)
+    const double eps = 2.220446049250313e-16;
+    const double arg1 = pow(z[0] / a, 2.0 * a) * pow(z[1] / (1.0 - a), 2.0 - 2.0 * a) - z[2] * z[2];
+    const double bd = -logsafe(arg1) - (1.0 - a) * logsafe(z[0]) - a * logsafe(z[1]);
+    double g[3];
+    const double phis = pow(s[0], 2.0 * a) * pow(s[1], 2.0 - a * 2.0);
+    const double abs_s = fabs(s[2]);
+    if (abs_s > eps) {
+        g[2] = pow_newton_raphson(abs_s, phis, a);
+        if (s[2] < 0.0) g[2] = -g[2];
+        g[0] = -(a * g[2] * s[2] + 1.0 + a) / s[0];
+        g[1] = -((1.0 - a) * g[2] * s[2] + 2.0 - a) / s[1];
+    } else {
+        g[2] = 0.0;
+        g[0] = -(1.0 + a) / s[0];
+        g[1] = -(2.0 - a) / s[1];
+    }
+    double bp = 0.0;
+    bp += logsafe(pow(-g[0] / a, 2.0 * a) * pow(-g[1] / (1.0 - a), 2.0 - a * 2.0) - g[2] * g[2]);
+    bp += (1.0 - a) * logsafe(-g[0]);
+    bp += a * logsafe(-g[1]) - 3.0;
+    return (0.0 + bd) + bp;
+}
+//   OP 0 affine_ds: o0 = i0 (= s)               OP 1 combined_ds_shift: o0 = grad*sm - eta(ds = i1, v = i0)
+//   OP 2 ds_from_dz_offset: o0 = i0 (= ds)      OP 3 step_length from sc -> partial[block] (min)
+//   OP 4 barrier at (z, s) + sc*(dz, ds) -> partial[block] (sum)        OP 5 unit_initialization (o0 = z, o1 = s)
+template <int OP>
+__global__ __launch_bounds__(WG) void k_ns3_step_ops(Ns3View v, double *o0, double *o1,
+                                                     const double *__restrict__ i0,
+                                                     const double *__restrict__ i1,
+                                                     const double *__restrict__ i2,
+                                                     const double *__restrict__ i3, double sc, double amin,
+                                                     double step, double *partial) {
+    __shared__ double red[16];
+    const int c = blockIdx.x * WG + threadIdx.x;
+    const bool live = c < v.ncones;
+    const int off = live ? v.start[c] : 0;
+    const bool isexp = live ? v.tag[c] == 3 : true;
+    const double a = live ? v.alpha[c] : 0.5;
+    const double *st = v.state + 18 * (live ? c : 0);
+    double out = OP == 3 ? sc : 0.0;
+    if (live) {
+        if (OP == 0 || OP == 2) {
+            for (int k = 0; k < 3; k++) o0[off + k] = i0[off + k];
+        } else if (OP == 1) {
+            double eta[3];
+            const double vz[3] = {i0[off], i0[off + 1], i0[off + 2]}, dsv[3] = {i1[off], i1[off + 1], i1[off + 2]};
+            ns3_higher_correction(isexp, a, st + 6, st + 15, eta, dsv, vz);
+            for (int k = 0; k < 3; k++) o0[off + k] = st[12 + k] * sc - eta[k];
+        } else if (OP == 3) {
+            const double dz[3] = {i0[off], i0[off + 1], i0[off + 2]}, dsv[3] = {i1[off], i1[off + 1], i1[off + 2]};
+            const double z[3] = {i2[off], i2[off + 1], i2[off + 2]}, s[3] = {i3[off], i3[off + 1], i3[off + 2]};
+            const double az = ns3_backtrack(isexp, true, a, dz, z, sc, amin, step);
+            const double as = ns3_backtrack(isexp, false, a, dsv, s, sc, amin, step);
+            out = fmin(az, as);
+        } else if (OP == 4) {
+            double cz[3], cs[3];
+            for (int k = 0; k < 3; k++) {
+                cz[k] = i0[off + k] + sc * i2[off + k];
+                cs[k] = i1[off + k] + sc * i3[off + k];
+            }
+            out = ns3_barrier(isexp, a, cz, cs);
+        } else if (OP == 5) {
+            double u[3];
+            if (isexp) { // expcone.rs:87-93
+                u[0] = -1.051383945322714;
+                u[1] = 0.556409619469370;
+                u[2] = 1.258967884768947;
+            } else { // powcone.rs:79-87
+                u[0] = sqrt(1.0 + a);
+                u[1] = sqrt(1.0 + (1.0 - a));
+                u[2] = 0.0;
+            }
+            for (int k = 0; k < 3; k++) o0[off + k] = o1[off + k] = u[k];
+        }
+    }
+    if (OP == 3) {
+        out = -block_max(-out, red);
+        if (threadIdx.x == 0) partial[blockIdx.x] = out;
+    } else if (OP == 4) {
+        out = block_sum(out, red);
+        if (threadIdx.x == 0) partial[blockIdx.x] = out;
+    }
+}
+// barrier of the nonnegative rows (nonnegativecone.rs:155-166): per-block partial sums
+__global__ __launch_bounds__(WG) void k_nn_barrier(const int *__restrict__ rows, int count,
+                                                   const double *__restrict__ z, const double *__restrict__ s,
+                                                   const double *__restrict__ dz,
+                                                   const double *__restrict__ ds, double alpha, double *partial) {
+    __shared__ double red[16];
+    double b = 0.0;
+    for (int t = blockIdx.x * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
+        const int r = rows[t];
+        b -= logsafe((s[r] + alpha * ds[r]) * (z[r] + alpha * dz[r]));
+    }
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = b;
+}
+// barrier of one second-order cone per workgroup (socone.rs:304-314, 410-417)
+__global__ __launch_bounds__(WG) void k_soc_barrier(SocView v, const double *__restrict__ zv,
+                                                    const double *__restrict__ sv,
+                                                    const double *__restrict__ dzv,
+                                                    const double *__restrict__ dsv, double alpha,
+                                                    double *partial) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c], off = v.start[c];
+    const double *z = zv + off, *s = sv + off, *dz = dzv + off, *ds = dsv + off;
+    double qs = 0.0, qz = 0.0, ms = 0.0, mz = 0.0;
+    for (int i = 1 + threadIdx.x; i < n; i += WG) {
+        ms = fmax(ms, fabs(s[i] + alpha * ds[i]));
+        mz = fmax(mz, fabs(z[i] + alpha * dz[i]));
+    }
+    ms = block_max(ms, red);
+    mz = block_max(mz, red);
+    for (int i = 1 + threadIdx.x; i < n; i += WG) { // scaled sums of squares (norm_shifted is overflow safe)
+        const double xs = ms > 0.0 ? (s[i] + alpha * ds[i]) / ms : 0.0, xz = mz > 0.0 ? (z[i] + alpha * dz[i]) / mz : 0.0;
+        qs += xs * xs;
+        qz += xz * xz;
+    }
+    qs = block_sum(qs, red);
+    qz = block_sum(qz, red);
+    if (threadIdx.x == 0) {
+        const double s1 = ms * sqrt(qs), z1 = mz * sqrt(qz);
+        const double s0 = s[0] + alpha * ds[0], z0 = z[0] + alpha * dz[0];
+        const double res_s = (s0 - s1) * (s0 + s1), res_z = (z0 - z1) * (z0 + z1);
+        partial[c] = (res_s > 0.0 && res_z > 0.0) ? -logsafe(res_s * res_z) * 0.5 : INFINITY;
+    }
+}
+// unit_initialization of the symmetric cones (zerocone.rs:71-74, nonnegativecone.rs:68-71, socone.rs:114-119)
+__global__ __launch_bounds__(WG) void k_sym_unit_init(const int *__restrict__ nn_rows, int nn,
+                                                      const int *__restrict__ soc_start, int nsoc, double *z,
+                                                      double *s) {
+    const int total = nn + nsoc;
+    for (int t = blockIdx.x * WG + threadIdx.x; t < total; t += gridDim.x * WG) {
+        const int r = t < nn ? nn_rows[t] : soc_start[t - nn];
+        z[r] = 1.0;
+        s[r] = 1.0;
+    }
+}
+
 } // namespace
 
 // ===========================================================================
@@ -1883,6 +2143,52 @@ int cone_margins(hipStream_t s, const int *nn_rows, int nn, const SocView &v, co
         used += v.ncones;
     }
     return used;
+}
+static int ns3_blocks(const Ns3View &v) { return (v.ncones + WG - 1) / WG; }
+void ns3_affine_ds(hipStream_t s, const Ns3View &v, double *ds, const double *sv) {
+    if (v.ncones) k_ns3_step_ops<0><<<ns3_blocks(v), WG, 0, s>>>(v, ds, nullptr, sv, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr);
+}
+void ns3_combined_ds_shift(hipStream_t s, const Ns3View &v, double *shift, const double *step_z,
+                           const double *step_s, double sigma_mu) {
+    if (v.ncones) k_ns3_step_ops<1><<<ns3_blocks(v), WG, 0, s>>>(v, shift, nullptr, step_z, step_s, nullptr, nullptr, sigma_mu, 0.0, 0.0, nullptr);
+}
+void ns3_ds_from_dz_offset(hipStream_t s, const Ns3View &v, double *out, const double *ds) {
+    if (v.ncones) k_ns3_step_ops<2><<<ns3_blocks(v), WG, 0, s>>>(v, out, nullptr, ds, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr);
+}
+int ns3_step_length(hipStream_t s, const Ns3View &v, const double *dz, const double *ds, const double *z,
+                    const double *sv, double alpha, double alpha_min, double step, double *partial) {
+    if (!v.ncones) return 0;
+    k_ns3_step_ops<3><<<ns3_blocks(v), WG, 0, s>>>(v, nullptr, nullptr, dz, ds, z, sv, alpha, alpha_min, step, partial);
+    return ns3_blocks(v);
+}
+int cone_barrier(hipStream_t s, const int *nn_rows, int nn, const SocView &soc, const Ns3View &v, const double *z,
+                 const double *sv, const double *dz, const double *ds, double alpha, double *partial) {
+    int used = 0;
+    if (nn) {
+        int nb = (nn + WG - 1) / WG;
+        if (nb > 1024) nb = 1024;
+        k_nn_barrier<<<nb, WG, 0, s>>>(nn_rows, nn, z, sv, dz, ds, alpha, partial);
+        used = nb;
+    }
+    if (soc.ncones) {
+        k_soc_barrier<<<soc.ncones, WG, 0, s>>>(soc, z, sv, dz, ds, alpha, partial + used);
+        used += soc.ncones;
+    }
+    if (v.ncones) {
+        k_ns3_step_ops<4><<<ns3_blocks(v), WG, 0, s>>>(v, nullptr, nullptr, z, sv, dz, ds, alpha, 0.0, 0.0, partial + used);
+        used += ns3_blocks(v);
+    }
+    return used;
+}
+void cone_unit_initialization(hipStream_t s, const int *nn_rows, int nn, const SocView &soc, const Ns3View &v,
+                              double *z, double *sv, int m) {
+    if (m) {
+        (void)hipMemsetAsync(z, 0, (size_t)m * sizeof(double), s);
+        (void)hipMemsetAsync(sv, 0, (size_t)m * sizeof(double), s);
+    }
+    const int total = nn + soc.ncones;
+    if (total) k_sym_unit_init<<<std::min(grid_for(total), 2048), WG, 0, s>>>(nn_rows, nn, soc.start, soc.ncones, z, sv);
+    if (v.ncones) k_ns3_step_ops<5><<<ns3_blocks(v), WG, 0, s>>>(v, z, sv, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr);
 }
 void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int nnzL, double *Lx,
                   double *D, const int8_t *dsigns, const double *eps, const int *fill_idx, int nfill,

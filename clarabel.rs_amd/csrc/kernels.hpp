@@ -157,6 +157,20 @@ void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, co
 void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv);
 void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx);
 // step / rhs operations of the symmetric cones (Zero rows, Nonnegative rows, SecondOrder cones)
+// Exponential / Power cones either side of the solve (expcone.rs:129-181, powcone.rs:128-180)
+void ns3_affine_ds(hipStream_t s, const Ns3View &v, double *ds, const double *sv);
+void ns3_combined_ds_shift(hipStream_t s, const Ns3View &v, double *shift, const double *step_z,
+                           const double *step_s, double sigma_mu);
+void ns3_ds_from_dz_offset(hipStream_t s, const Ns3View &v, double *out, const double *ds);
+// per-block minima of the backtracking line searches started at alpha -> partial; returns #partials
+int ns3_step_length(hipStream_t s, const Ns3View &v, const double *dz, const double *ds, const double *z,
+                    const double *sv, double alpha, double alpha_min, double step, double *partial);
+// compute_barrier of the composite cone (compositecone.rs:342-352): partial sums -> partial; returns #partials
+int cone_barrier(hipStream_t s, const int *nn_rows, int nn, const SocView &soc, const Ns3View &v, const double *z,
+                 const double *sv, const double *dz, const double *ds, double alpha, double *partial);
+// unit_initialization of the composite cone (compositecone.rs:208-214): z, s of length m
+void cone_unit_initialization(hipStream_t s, const int *nn_rows, int nn, const SocView &soc, const Ns3View &v,
+                              double *z, double *sv, int m);
 void cone_unit_shift(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,
                      double *z, double alpha, int primal);
 void cone_affine_ds(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,

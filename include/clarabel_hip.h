@@ -84,7 +84,11 @@ typedef struct {
                                   analogue of the reference's logical factorisation, qdldl.rs:40-42 */
     double amd_dense_scale;    /* 1.5, ldlsolvers/qdldl.rs:41 */
     int32_t use_graph;         /* capture the per-solve launch sequence in a hipGraph */
-    int32_t reserved[5];
+    int32_t reserved0;
+    /* line search of the nonsymmetric cones (settings.rs:96-104), used by chip_kkt_step_length_dev */
+    double linesearch_backtrack_step;            /* 0.8    */
+    double min_terminate_step_length;            /* 1e-4   */
+    int32_t reserved[2];
 } chip_settings;
 
 /* LinearSolverInfo (solver/core/kktsolvers/mod.rs:27-38) + factor statistics
@@ -221,8 +225,13 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval);
  * y = Hs x, m doubles, device pointers. */
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev);
 /* ---- the cone operations either side of the KKT solve, for problems whose
- * cones are all symmetric and device-held (Zero / Nonnegative / SecondOrder); m-vectors in HBM.
- * CHIP_ERR_UNSUPPORTED otherwise.
+ * cones are Zero / Nonnegative / SecondOrder / Exponential / Power; m-vectors in HBM.
+ * CHIP_ERR_UNSUPPORTED otherwise (PSD, GenPower).  Exponential / Power: affine_ds = s
+ * (expcone.rs:129-131), combined_ds_shift = sigma*mu*grad - 3rd-order correction
+ * (expcone.rs:133-142,254-308, powcone.rs:132-141,260-337; step_z / step_s are left unchanged),
+ * ds_from_dz_offset = ds, step_length = backtracking line searches (nonsymmetric_common.rs:164-192)
+ * started -- as in compositecone.rs:300-340 -- from the symmetric cones' step backed off to
+ * 1 - sqrt(eps).
  *   affine_ds            compositecone.rs:266-272   (nonnegativecone.rs:110-115, socone.rs:258-260)
  *   combined_ds_shift    compositecone.rs:274-289   (symmetric_common.rs:53-84): step_z and step_s are
  *                        overwritten by W dz and W^-1 ds exactly as in the reference
@@ -244,6 +253,14 @@ int32_t chip_kkt_margins_dev(chip_kkt *h, const double *z_dev, double *alpha_out
  * (Zero-cone rows are zeroed); with margins this is the initial-point fix-up
  * _shift_to_cone_interior, default/variables.rs:231-256 */
 int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha, int32_t primal_cone);
+/* unit_initialization  compositecone.rs:208-214 (zerocone.rs:71-74, nonnegativecone.rs:68-71,
+ * socone.rs:114-119, expcone.rs:87-93, powcone.rs:79-87): fills z[m], s[m] */
+int32_t chip_kkt_unit_initialization_dev(chip_kkt *h, double *z_dev, double *s_dev);
+/* compute_barrier  compositecone.rs:342-352 at (z, s) + alpha (dz, ds): nonnegativecone.rs:155-166,
+ * socone.rs:304-314, expcone.rs:170-252, powcone.rs:169-258; *barrier_out on the host */
+int32_t chip_kkt_compute_barrier_dev(chip_kkt *h, const double *z_dev, const double *s_dev,
+                                     const double *dz_dev, const double *ds_dev, double alpha,
+                                     double *barrier_out);
 int32_t chip_kkt_info(const chip_kkt *h, chip_info *info);
 int32_t chip_kkt_get_perm(const chip_kkt *h, uint64_t *perm);
 int32_t chip_kkt_get_symbolic(const chip_kkt *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,

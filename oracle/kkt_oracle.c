@@ -577,9 +577,160 @@ static void soc_circ_op(double *x, const double *y, const double *z, int64_t n) 
     double y0 = y[0], z0 = z[0];
     for (int64_t i = 1; i < n; i++) x[i] = y0 * z[i] + z0 * y[i];
 }
-/* compositecone.rs:266-272 affine_ds: nonnegativecone.rs:110-115, socone.rs:258-260, zerocone.rs:102-104 */
+/* ---- Exponential / Power cones: feasibility, barriers, 3rd-order correction ------------- */
+/* dense3x3/cholesky.rs:13-57 on the packed triu [00,01,11,02,12,22]; L shares the packing */
+static int chol3_factor(double *L, const double *A) {
+    double t = A[0];
+    if (t <= 0.0) return 0;
+    L[0] = sqrt(t);
+    L[1] = A[1] / L[0];
+    t = A[2] - L[1] * L[1];
+    if (t <= 0.0) return 0;
+    L[2] = sqrt(t);
+    L[3] = A[3] / L[0];
+    L[4] = (A[4] - L[1] * L[3]) / L[2];
+    t = A[5] - L[3] * L[3] - L[4] * L[4];
+    if (t <= 0.0) return 0;
+    L[5] = sqrt(t);
+    return 1;
+}
+static void chol3_solve(const double *L, double *x, const double *b) {
+    double c0 = b[0] / L[0];
+    double c1 = (b[1] - L[1] * c0) / L[2];
+    double c2 = (b[2] - L[3] * c0 - L[4] * c1) / L[5];
+    x[2] = c2 / L[5];
+    x[1] = (c1 - L[4] * x[2]) / L[2];
+    x[0] = (c0 - L[1] * x[1] - L[3] * x[2]) / L[0];
+}
+/* expcone.rs:189-220 */
+static int exp_is_primal_feasible(const double *s) {
+    if (s[2] > 0.0 && s[1] > 0.0) {
+        double res = s[1] * logsafe(s[2] / s[1]) - s[0];
+        if (res > 0.0) return 1;
+    }
+    return 0;
+}
+static int exp_is_dual_feasible(const double *z) {
+    if (z[2] > 0.0 && z[0] < 0.0) {
+        double res = z[1] - z[0] - z[0] * logsafe(-z[2] / z[0]);
+        if (res > 0.0) return 1;
+    }
+    return 0;
+}
+/* expcone.rs:222-252 */
+static double exp_barrier_primal(const double *s) {
+    double om = orc_wright_omega(1.0 - s[0] / s[1] - logsafe(s[1] / s[2]));
+    om = (om - 1.0) * (om - 1.0) / om;
+    return -logsafe(om) - logsafe(s[1]) * 2.0 - logsafe(s[2]) - 3.0;
+}
+static double exp_barrier_dual(const double *z) {
+    double l = logsafe(-z[2] / z[0]);
+    return -logsafe(-z[2] * z[0]) - logsafe(z[1] - z[0] - z[0] * l);
+}
+/* expcone.rs:254-308 */
+static void exp_higher_correction(const orc_cone *c, double *eta, const double *ds, const double *v) {
+    double L[6], u[3];
+    const double *z = c->zc;
+    if (!chol3_factor(L, c->Hdual)) { eta[0] = eta[1] = eta[2] = 0.0; return; }
+    chol3_solve(L, u, ds);
+    eta[1] = 1.0;
+    eta[2] = -z[0] / z[2];
+    eta[0] = logsafe(eta[2]);
+    double psi = z[0] * eta[0] - z[0] + z[1];
+    double dpu = dotp(u, eta, 3), dpv = dotp(v, eta, 3);
+    double coef = ((u[0] * (v[0] / z[0] - v[2] / z[2]) + u[2] * (z[0] * v[2] / z[2] - v[0]) / z[2]) * psi -
+                   2.0 * dpu * dpv) / (psi * psi * psi);
+    for (int i = 0; i < 3; i++) eta[i] *= coef;
+    double ip2 = 1.0 / (psi * psi);
+    eta[0] += (1.0 / psi - 2.0 / z[0]) * u[0] * v[0] / (z[0] * z[0]) - u[2] * v[2] / (z[2] * z[2]) / psi +
+              dpu * ip2 * (v[0] / z[0] - v[2] / z[2]) + dpv * ip2 * (u[0] / z[0] - u[2] / z[2]);
+    eta[2] += 2.0 * (z[0] / psi - 1.0) * u[2] * v[2] / (z[2] * z[2] * z[2]) -
+              (u[2] * v[0] + u[0] * v[2]) / (z[2] * z[2]) / psi +
+              dpu * ip2 * (z[0] * v[2] / (z[2] * z[2]) - v[0] / z[2]) +
+              dpv * ip2 * (z[0] * u[2] / (z[2] * z[2]) - u[0] / z[2]);
+    for (int i = 0; i < 3; i++) eta[i] *= 0.5;
+}
+/* powcone.rs:188-221 */
+static int pow_is_primal_feasible(const orc_cone *c, const double *s) {
+    double a = c->alpha;
+    if (s[0] > 0.0 && s[1] > 0.0) {
+        double res = exp(2.0 * a * logsafe(s[0]) + 2.0 * (1.0 - a) * logsafe(s[1])) - s[2] * s[2];
+        if (res > 0.0) return 1;
+    }
+    return 0;
+}
+static int pow_is_dual_feasible(const orc_cone *c, const double *z) {
+    double a = c->alpha;
+    if (z[0] > 0.0 && z[1] > 0.0) {
+        double res = exp((a * 2.0) * logsafe(z[0] / a) + (1.0 - a) * logsafe(z[1] / (1.0 - a)) * 2.0) - z[2] * z[2];
+        if (res > 0.0) return 1;
+    }
+    return 0;
+}
+/* powcone.rs:223-258 */
+static double pow_barrier_primal(const orc_cone *c, const double *s) {
+    double a = c->alpha, g[3];
+    pow_gradient_primal(c, s, g);
+    double out = 0.0;
+    out += logsafe(pow(-g[0] / a, 2.0 * a) * pow(-g[1] / (1.0 - a), 2.0 - a * 2.0) - g[2] * g[2]);
+    out += (1.0 - a) * logsafe(-g[0]);
+    out += a * logsafe(-g[1]) - 3.0;
+    return out;
+}
+static double pow_barrier_dual(const orc_cone *c, const double *z) {
+    double a = c->alpha;
+    double arg1 = pow(z[0] / a, 2.0 * a) * pow(z[1] / (1.0 - a), 2.0 - 2.0 * a) - z[2] * z[2];
+    return -logsafe(arg1) - (1.0 - a) * logsafe(z[0]) - a * logsafe(z[1]);
+}
+/* powcone.rs:260-337 */
+static void pow_higher_correction(const orc_cone *c, double *eta, const double *ds, const double *v) {
+    double L[6], u[3], Hp[6], Hv[3], Hu[3];
+    const double *z = c->zc;
+    if (!chol3_factor(L, c->Hdual)) { eta[0] = eta[1] = eta[2] = 0.0; return; }
+    chol3_solve(L, u, ds);
+    double a = c->alpha;
+    double phi = pow(z[0] / a, 2.0 * a) * pow(z[1] / (1.0 - a), 2.0 - 2.0 * a);
+    double psi = phi - z[2] * z[2];
+    eta[0] = 2.0 * a * phi / z[0];
+    eta[1] = 2.0 * (1.0 - a) * phi / z[1];
+    eta[2] = -2.0 * z[2];
+    Hp[1] = 4.0 * a * (1.0 - a) * phi / (z[0] * z[1]);
+    Hp[0] = 2.0 * a * (2.0 * a - 1.0) * phi / (z[0] * z[0]);
+    Hp[3] = 0.0;
+    Hp[2] = 2.0 * (1.0 - a) * (1.0 - 2.0 * a) * phi / (z[1] * z[1]);
+    Hp[4] = 0.0;
+    Hp[5] = -2.0;
+    double dpu = dotp(u, eta, 3), dpv = dotp(v, eta, 3);
+    sym3_mul(Hp, Hv, v);
+    double coef = (dotp(u, Hv, 3) * psi - 2.0 * dpu * dpv) / (psi * psi * psi);
+    double coef2 = 4.0 * a * (2.0 * a - 1.0) * (1.0 - a) * phi * (u[0] / z[0] - u[1] / z[1]) *
+                   (v[0] / z[0] - v[1] / z[1]) / psi;
+    double ip2 = 1.0 / (psi * psi);
+    eta[0] = coef * eta[0] - 2.0 * (1.0 - a) * u[0] * v[0] / (z[0] * z[0] * z[0]) + coef2 / z[0] + Hv[0] * dpu * ip2;
+    eta[1] = coef * eta[1] - 2.0 * a * u[1] * v[1] / (z[1] * z[1] * z[1]) - coef2 / z[1] + Hv[1] * dpu * ip2;
+    eta[2] = coef * eta[2] + Hv[2] * dpu * ip2;
+    sym3_mul(Hp, Hu, u);
+    for (int i = 0; i < 3; i++) eta[i] = (dpv * ip2) * Hu[i] + 1.0 * eta[i];
+    for (int i = 0; i < 3; i++) eta[i] *= 0.5;
+}
+/* nonsymmetric_common.rs:164-192 */
+static double ns3_backtrack(const orc_cone *c, const double *dq, const double *q, double a_init, double a_min,
+                            double step, int dual) {
+    double alpha = a_init, w[3];
+    for (;;) {
+        for (int i = 0; i < 3; i++) w[i] = 1.0 * q[i] + alpha * dq[i];
+        int ok = c->tag == CONE_EXP ? (dual ? exp_is_dual_feasible(w) : exp_is_primal_feasible(w))
+                                    : (dual ? pow_is_dual_feasible(c, w) : pow_is_primal_feasible(c, w));
+        if (ok) break;
+        alpha *= step;
+        if (alpha < a_min) { alpha = 0.0; break; }
+    }
+    return alpha;
+}
+
+/* compositecone.rs:266-272 affine_ds: nonnegativecone.rs:110-115, socone.rs:258-260, zerocone.rs:102-104,
+ * expcone.rs:129-131 / powcone.rs:128-130 (ds = s) */
 void orc_cones_affine_ds(const orc_cones *cs, double *ds, const double *s) {
-    (void)s;
     for (int64_t i = 0; i < cs->ncones; i++) {
         const orc_cone *c = &cs->c[i];
         double *d = ds + c->cone_start;
@@ -589,6 +740,8 @@ void orc_cones_affine_ds(const orc_cones *cs, double *ds, const double *s) {
             for (int64_t k = 0; k < c->numel; k++) d[k] = c->lam[k] * c->lam[k];
         } else if (c->tag == CONE_SOC) {
             soc_circ_op(d, c->lam, c->lam, c->numel);
+        } else if (c->tag == CONE_EXP || c->tag == CONE_POW) {
+            for (int k = 0; k < 3; k++) d[k] = s[c->cone_start + k];
         }
     }
 }
@@ -615,6 +768,11 @@ void orc_cones_combined_ds_shift(const orc_cones *cs, double *shift, double *ste
             soc_mul_Winv(dsv, sh, 1.0, 0.0, c->w, c->eta, n);
             soc_circ_op(sh, dsv, dz, n);
             sh[0] += -sigma_mu; /* scaled_unit_shift, socone.rs:110-112 */
+        } else if (c->tag == CONE_EXP || c->tag == CONE_POW) { /* expcone.rs:133-142, powcone.rs:132-141 */
+            double eta[3];
+            if (c->tag == CONE_EXP) exp_higher_correction(c, eta, dsv, dz);
+            else pow_higher_correction(c, eta, dsv, dz);
+            for (int k = 0; k < 3; k++) sh[k] = c->grad3[k] * sigma_mu - eta[k];
         }
     }
 }
@@ -642,6 +800,8 @@ void orc_cones_ds_from_dz_offset(const orc_cones *cs, double *out, const double 
             for (int64_t k = 1; k < n; k++) o[k] += c->eta * (d[k] + w1d1 / (1.0 + c->w[0]) * c->w[k]);
             double rl = 1.0 / c->lam[0];
             for (int64_t k = 0; k < n; k++) o[k] *= rl;
+        } else if (c->tag == CONE_EXP || c->tag == CONE_POW) { /* expcone.rs:144-146 */
+            for (int k = 0; k < 3; k++) o[k] = d[k];
         }
     }
 }
@@ -666,16 +826,19 @@ static double soc_step_component(const double *x, const double *y, double amax, 
     double r = r1 < r2 ? r1 : r2;
     return amax < r ? amax : r;
 }
-/* compositecone.rs:300-340 for symmetric cones (Zero / NN / SOC): nonnegativecone.rs:128-153,
- * socone.rs:289-302, zerocone.rs:116-127.  Returns alpha (= alpha_z = alpha_s of the composite). */
-double orc_cones_step_length(const orc_cones *cs, const double *dz, const double *ds, const double *z,
-                             const double *s, double amax) {
+/* compositecone.rs:300-340: symmetric cones first (nonnegativecone.rs:128-153, socone.rs:289-302,
+ * zerocone.rs:116-127), then -- backed off to 1 - sqrt(eps) -- the nonsymmetric ones
+ * (expcone.rs:148-168, powcone.rs:147-167 via backtrack_search).  Returns alpha (= alpha_z = alpha_s). */
+double orc_cones_step_length_ex(const orc_cones *cs, const double *dz, const double *ds, const double *z,
+                                const double *s, double amax, double backtrack_step, double alpha_min) {
     double alpha = amax;
+    int all_symmetric = 1;
     for (int64_t i = 0; i < cs->ncones; i++) {
         const orc_cone *c = &cs->c[i];
         const double *dzi = dz + c->cone_start, *dsi = ds + c->cone_start;
         const double *zi = z + c->cone_start, *si = s + c->cone_start;
         double az = alpha, as = alpha;
+        if (c->tag == CONE_EXP || c->tag == CONE_POW) { all_symmetric = 0; continue; }
         if (c->tag == CONE_NONNEG) {
             for (int64_t k = 0; k < c->numel; k++) {
                 if (dzi[k] < 0.0) { double t = -zi[k] / dzi[k]; az = az < t ? az : t; }
@@ -688,7 +851,99 @@ double orc_cones_step_length(const orc_cones *cs, const double *dz, const double
         double mn = az < as ? az : as;
         alpha = alpha < mn ? alpha : mn;
     }
+    if (!all_symmetric) {
+        double ceilv = 1.0 - sqrt(2.220446049250313e-16);
+        alpha = alpha < ceilv ? alpha : ceilv;
+        for (int64_t i = 0; i < cs->ncones; i++) {
+            const orc_cone *c = &cs->c[i];
+            if (c->tag != CONE_EXP && c->tag != CONE_POW) continue;
+            double az = ns3_backtrack(c, dz + c->cone_start, z + c->cone_start, alpha, alpha_min, backtrack_step, 1);
+            double as = ns3_backtrack(c, ds + c->cone_start, s + c->cone_start, alpha, alpha_min, backtrack_step, 0);
+            double mn = az < as ? az : as;
+            alpha = alpha < mn ? alpha : mn;
+        }
+    }
     return alpha;
+}
+double orc_cones_step_length(const orc_cones *cs, const double *dz, const double *ds, const double *z,
+                             const double *s, double amax) {
+    /* settings.rs defaults: linesearch_backtrack_step 0.8, min_terminate_step_length 1e-4 */
+    return orc_cones_step_length_ex(cs, dz, ds, z, s, amax, 0.8, 1e-4);
+}
+/* vecmath.rs norm_shifted: stable norm of (z + alpha dz) */
+static double norm2_shifted(const double *z, const double *dz, double alpha, int64_t n) {
+    double scale = 0.0, sumsq = 1.0;
+    for (int64_t i = 0; i < n; i++) {
+        double xi = z[i] + alpha * dz[i];
+        if (xi == 0.0) continue;
+        double a = fabs(xi);
+        if (scale < a) {
+            double r = scale / a;
+            sumsq = 1.0 + sumsq * r * r;
+            scale = a;
+        } else {
+            double r = a / scale;
+            sumsq = sumsq + r * r;
+        }
+    }
+    return scale * sqrt(sumsq);
+}
+/* compositecone.rs:342-352 compute_barrier: nonnegativecone.rs:155-166, socone.rs:304-314,
+ * zerocone.rs:129-131, expcone.rs:170-181, powcone.rs:169-180 */
+double orc_cones_compute_barrier(const orc_cones *cs, const double *z, const double *s, const double *dz,
+                                 const double *ds, double alpha) {
+    double barrier = 0.0;
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        const double *zi = z + c->cone_start, *si = s + c->cone_start;
+        const double *dzi = dz + c->cone_start, *dsi = ds + c->cone_start;
+        if (c->tag == CONE_NONNEG) {
+            double b = 0.0;
+            for (int64_t k = 0; k < c->numel; k++) b -= logsafe((si[k] + alpha * dsi[k]) * (zi[k] + alpha * dzi[k]));
+            barrier += b;
+        } else if (c->tag == CONE_SOC) {
+            double x0 = si[0] + alpha * dsi[0], x1 = norm2_shifted(si + 1, dsi + 1, alpha, c->numel - 1);
+            double res_s = (x0 - x1) * (x0 + x1);
+            x0 = zi[0] + alpha * dzi[0];
+            x1 = norm2_shifted(zi + 1, dzi + 1, alpha, c->numel - 1);
+            double res_z = (x0 - x1) * (x0 + x1);
+            barrier += (res_s > 0.0 && res_z > 0.0) ? -logsafe(res_s * res_z) * 0.5 : INFINITY;
+        } else if (c->tag == CONE_EXP || c->tag == CONE_POW) {
+            double cz[3], csv[3];
+            for (int k = 0; k < 3; k++) {
+                cz[k] = zi[k] + alpha * dzi[k];
+                csv[k] = si[k] + alpha * dsi[k];
+            }
+            if (c->tag == CONE_EXP) barrier += exp_barrier_dual(cz) + exp_barrier_primal(csv);
+            else barrier += pow_barrier_dual(c, cz) + pow_barrier_primal(c, csv);
+        }
+    }
+    return barrier;
+}
+/* compositecone.rs:208-214 unit_initialization: zerocone.rs:71-74, nonnegativecone.rs:68-71,
+ * socone.rs:114-119, expcone.rs:87-93, powcone.rs:79-87 */
+void orc_cones_unit_initialization(const orc_cones *cs, double *z, double *s) {
+    for (int64_t i = 0; i < cs->ncones; i++) {
+        const orc_cone *c = &cs->c[i];
+        double *zi = z + c->cone_start, *si = s + c->cone_start;
+        for (int64_t k = 0; k < c->numel; k++) zi[k] = si[k] = 0.0;
+        if (c->tag == CONE_NONNEG) {
+            for (int64_t k = 0; k < c->numel; k++) zi[k] = si[k] = 1.0;
+        } else if (c->tag == CONE_SOC) {
+            zi[0] = si[0] = 1.0;
+        } else if (c->tag == CONE_EXP) {
+            si[0] = -1.051383945322714; si[1] = 0.556409619469370; si[2] = 1.258967884768947;
+            for (int k = 0; k < 3; k++) zi[k] = si[k];
+        } else if (c->tag == CONE_POW) {
+            si[0] = sqrt(1.0 + c->alpha); si[1] = sqrt(1.0 + (1.0 - c->alpha)); si[2] = 0.0;
+            for (int k = 0; k < 3; k++) zi[k] = si[k];
+        }
+    }
+}
+int orc_cones_is_symmetric(const orc_cones *cs) {
+    for (int64_t i = 0; i < cs->ncones; i++)
+        if (cs->c[i].tag == CONE_EXP || cs->c[i].tag == CONE_POW || cs->c[i].tag == CONE_GENPOW) return 0;
+    return 1;
 }
 /* CompositeCone::margins (compositecone.rs:130-152): (min over cones of alpha, sum of beta);
  * nonnegativecone.rs:58-62, socone.rs:104-108, zerocone.rs margins = (inf, 0) */

@@ -84,6 +84,7 @@ def lib():
         L.orc_kktsystem_new.restype = C.c_void_p
         L.orc_dot.restype = C.c_double
         L.orc_cones_degree.restype = C.c_int64
+        L.orc_cones_compute_barrier.restype = C.c_double
     return _LIB
 
 
@@ -386,6 +387,18 @@ class Cones:
     def step_length(self, dz, ds, z, s, alpha_max=1.0):
         dz, ds, z, s = _af(dz), _af(ds), _af(z), _af(s)
         return lib().orc_cones_step_length(self._h, _pf(dz), _pf(ds), _pf(z), _pf(s), C.c_double(alpha_max))
+
+    def compute_barrier(self, z, s, dz, ds, alpha):
+        z, s, dz, ds = _af(z), _af(s), _af(dz), _af(ds)
+        return lib().orc_cones_compute_barrier(self._h, _pf(z), _pf(s), _pf(dz), _pf(ds), C.c_double(alpha))
+
+    def unit_initialization(self, z, s):
+        """in place on float64 arrays"""
+        lib().orc_cones_unit_initialization(self._h, _pf(z), _pf(s))
+
+    @property
+    def is_symmetric(self):
+        return bool(lib().orc_cones_is_symmetric(self._h))
 
     def scaled_unit_shift(self, z, alpha, primal_cone):
         """in place on the float64 array z"""

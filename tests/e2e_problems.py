@@ -4,7 +4,7 @@ solutions (basic_qp.rs:100-117, basic_lp.rs:27-44, basic_socp.rs:54-70)."""
 import numpy as np
 import scipy.sparse as sp
 
-ZERO, NN, SOC = 0, 1, 2
+ZERO, NN, SOC, EXP, POW = 0, 1, 2, 3, 4
 
 
 def _csc(M):
@@ -42,3 +42,20 @@ def basic_socp(sparse_soc=False):
     return dict(n=3, m=9, P=_triu(P), A=_csc(A), q=[0.1, -2.0, 1.0], b=[1.0] * 6 + [0.0] * 3, cones=cones,
                 x=None if sparse_soc else [-0.5, 0.435603, -0.245459], obj=None if sparse_soc else -8.4590e-01,
                 tol=1e-4)
+
+
+def basic_expcone():
+    # tests/basic_expcone.rs:5-36 and :38-56: max x s.t. y exp(x/y) <= z, y == 1, z == exp(5)
+    A = np.vstack([-np.eye(3), np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])])
+    return dict(n=3, m=5, P=_csc(sp.csc_matrix((3, 3))), A=_csc(A), q=[-1.0, 0.0, 0.0],
+                b=[0.0, 0.0, 0.0, 1.0, float(np.exp(5.0))], cones=[(EXP, 3), (ZERO, 2)],
+                x=[5.0, 1.0, float(np.exp(5.0))], obj=-5.0, tol=1e-6)
+
+
+def basic_powcone():
+    # tests/basic_powcone.rs:4-47: max x1^0.6 y^0.4 + x2^0.1 s.t. x1 + 2y + 3x2 == 3
+    A2 = np.array([[1.0, 2.0, 0.0, 3.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0, 1.0, 0.0]])
+    A = np.vstack([-np.eye(6), A2])
+    return dict(n=6, m=8, P=_csc(sp.csc_matrix((6, 6))), A=_csc(A), q=[0.0, 0.0, -1.0, 0.0, 0.0, -1.0],
+                b=[0.0] * 6 + [3.0, 1.0], cones=[(POW, 3, 0, 0.6), (POW, 3, 0, 0.1), (ZERO, 2)], x=None,
+                obj=-1.8458, tol=1e-3)

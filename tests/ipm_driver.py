@@ -2,7 +2,8 @@
 Python over a pluggable backend -- the CPU oracle or the HIP C ABI -- so that the reference's
 own END-TO-END known answers (tests/basic_qp.rs, basic_lp.rs, basic_socp.rs) pin the whole
 L1-L3 chain: KKT assembly, LDL', refinement, cone scalings and step operations, RHS algebra,
-residuals.  Symmetric cones only (Zero / Nonnegative / SecondOrder); no presolve and no
+residuals.  Zero / Nonnegative / SecondOrder / Exponential / Power cones (the nonsymmetric path
+with its scaling-strategy checkpoints, solver.rs:586-665); no presolve and no
 equilibration (data.equilibration = identity), which changes the iterates but not the optimum
 the reference tests assert to 1e-3 ... 1e-6.
 
@@ -12,8 +13,9 @@ import math
 
 import numpy as np
 
-ZERO, NN, SOC = 0, 1, 2
+ZERO, NN, SOC, EXP, POW = 0, 1, 2, 3, 4
 AFFINE, COMBINED = 0, 1
+PRIMAL_DUAL, DUAL = 0, 1  # ScalingStrategy, core/solver.rs:77-80
 
 
 class Vars:
@@ -32,9 +34,16 @@ class OracleBackend:
         self.ks = oracle.KKTSolver(n, m, P, A, self.cones)
         self.sys = oracle.KKTSystem(self.ks, self.cones, n, m, P, A, q, b)
         self.degree = self.cones.degree
+        self.is_symmetric = self.cones.is_symmetric
 
     def update_scaling(self, s, z, mu, strategy):
         return self.cones.update_scaling(s, z, mu, strategy)
+
+    def unit_initialization(self, z, s):
+        self.cones.unit_initialization(z, s)
+
+    def compute_barrier(self, z, s, dz, ds, alpha):
+        return self.cones.compute_barrier(z, s, dz, ds, alpha)
 
     def kkt_update(self):
         return self.sys.update()
@@ -75,7 +84,9 @@ class HipBackend:
         Pm, Am = hip.CscMatrix(n, n, *P), hip.CscMatrix(m, n, *A)
         self.ks = hip.HipKKTSolver(Pm, Am, cones, m, n)
         self.sys = hip.HipKKTSystem(self.ks, Pm, Am, q, b)
-        self.degree = sum(c[1] if c[0] == NN else (1 if c[0] == SOC else 0) for c in cones)
+        self.degree = sum(c[1] if c[0] == NN else (1 if c[0] == SOC else (3 if c[0] in (EXP, POW) else 0))
+                          for c in cones)
+        self.is_symmetric = not any(c[0] in (EXP, POW) for c in cones)
         D = hip.DeviceArray
         self._v = [hip.DeviceVariables(n, m) for _ in range(3)]  # lhs, rhs, variables
         self._r = dict(rx=D(n), rz=D(m), rx_inf=D(n), rz_inf=D(m), Px=D(n))
@@ -147,6 +158,17 @@ class HipBackend:
         self.ks.scaled_unit_shift_dev(self._t[0].ptr, alpha, primal)
         z[:] = self._t[0].numpy()
 
+    def unit_initialization(self, z, s):
+        t = self._t
+        self.ks.unit_initialization_dev(t[0].ptr, t[1].ptr)
+        z[:], s[:] = t[0].numpy(), t[1].numpy()
+
+    def compute_barrier(self, z, s, dz, ds, alpha):
+        t = self._t
+        for k, v in enumerate((z, s, dz, ds)):
+            t[k].copy_from(v)
+        return self.ks.compute_barrier_dev(t[0].ptr, t[1].ptr, t[2].ptr, t[3].ptr, alpha)
+
 
 # ---------------------------------------------------------------------------------------------
 def _unit_vectors(cones, m):
@@ -188,24 +210,41 @@ def _step_length(be, variables, step, direction, max_step_fraction):
     return alpha
 
 
+def _barrier(be, variables, step, alpha):
+    # default/variables.rs:186-207
+    coef = be.degree + 1
+    ctau, ckap = variables.tau + alpha * step.tau, variables.kappa + alpha * step.kappa
+    sz = float(np.dot(variables.s + alpha * step.s, variables.z + alpha * step.z))
+    mu = (sz + ctau * ckap) / coef
+    lg = lambda v: -math.inf if v <= 0 else math.log(v)
+    return coef * lg(mu) - lg(ctau) - lg(ckap) + be.compute_barrier(variables.z, variables.s, step.z, step.s, alpha)
+
+
 def solve(be, cones, q, b, max_iter=200, tol_gap_abs=1e-8, tol_gap_rel=1e-8, tol_feas=1e-8,
-          max_step_fraction=0.99, min_terminate_step_length=1e-4, trace=None):
+          max_step_fraction=0.99, min_terminate_step_length=1e-4, min_switch_step_length=1e-1,
+          linesearch_backtrack_step=0.8, trace=None):
     """-> dict(status, x, s, z, obj_val, iterations).  `trace`, if a list, receives
     (mu, alpha, sigma, res_primal, res_dual, gap_abs) per iteration for trajectory parity."""
     n, m = be.n, be.m
     q, b = np.asarray(q, float), np.asarray(b, float)
     variables, lhs, rhs = Vars(n, m), Vars(n, m), Vars(n, m)
     normq, normb = float(np.max(np.abs(q))) if n else 0.0, float(np.max(np.abs(b))) if m else 0.0
-    # default_start (solver.rs:525-543), symmetric cones
-    e = _unit_vectors(cones, m)
-    assert be.update_scaling(e, e, 1.0, 0)
-    be.kkt_update()
-    be.solve_initial_point(variables)
-    _shift_to_cone_interior(be, variables.s, True)
-    _shift_to_cone_interior(be, variables.z, False)
+    symmetric = be.is_symmetric
+    # default_start (solver.rs:525-543)
+    if symmetric:
+        e = _unit_vectors(cones, m)
+        assert be.update_scaling(e, e, 1.0, 0)
+        be.kkt_update()
+        be.solve_initial_point(variables)
+        _shift_to_cone_interior(be, variables.s, True)
+        _shift_to_cone_interior(be, variables.z, False)
+    else:
+        be.unit_initialization(variables.z, variables.s)  # variables.rs:167-173
+        variables.x[:] = 0.0
     variables.tau = variables.kappa = 1.0
     it, alpha, sigma = 0, 0.0, 1.0
     status = "Unsolved"
+    scaling = PRIMAL_DUAL  # Exp / Pow allow the primal-dual scaling (solver.rs:277-280)
     while True:
         res = be.residuals(variables)
         mu = (res["dot_sz"] + variables.tau * variables.kappa) / (be.degree + 1)
@@ -229,7 +268,7 @@ def solve(be, cones, q, b, max_iter=200, tol_gap_abs=1e-8, tol_gap_rel=1e-8, tol
         if it == max_iter:
             status = "MaxIterations"
             break
-        if not be.update_scaling(variables.s, variables.z, mu, 0):
+        if not be.update_scaling(variables.s, variables.z, mu, scaling):
             status = "NumericalError"
             break
         it += 1
@@ -254,11 +293,23 @@ def solve(be, cones, q, b, max_iter=200, tol_gap_abs=1e-8, tol_gap_rel=1e-8, tol
             rhs.s[:] = rhs.s + shift
             rhs.z[:] = (1.0 - sigma) * res["rz"]
             ok = be.kkt_solve(lhs, rhs, variables, COMBINED)
-        if not ok:
+        if not ok:  # strategy_checkpoint_numerical_error, solver.rs:610-628
+            if not symmetric and scaling == PRIMAL_DUAL:
+                alpha, scaling = 0.0, DUAL
+                continue
             status = "NumericalError"
             break
         alpha = _step_length(be, variables, lhs, COMBINED, max_step_fraction)
-        if alpha < min_terminate_step_length:
+        if not symmetric and scaling == DUAL:  # backtrack_step_to_barrier, solver.rs:571-584
+            for _ in range(50):
+                if _barrier(be, variables, lhs, alpha) < 1.0:
+                    break
+                alpha *= linesearch_backtrack_step
+        # strategy_checkpoint_small_step, solver.rs:630-650
+        if not symmetric and scaling == PRIMAL_DUAL and alpha < min_switch_step_length:
+            alpha, scaling = 0.0, DUAL
+            continue
+        if alpha <= max(0.0, min_terminate_step_length):
             status = "InsufficientProgress"
             break
         variables.x += alpha * lhs.x

@@ -13,14 +13,15 @@ def _run(oracle, pr, trace=None):
     return ipm.solve(be, pr["cones"], pr["q"], pr["b"], trace=trace)
 
 
-@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp"])
+@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone"])
 def test_reference_end_to_end_answers(oracle, name):
     pr = getattr(E, name)()
     out = _run(oracle, pr)
     assert out["status"] == "Solved"
-    assert np.linalg.norm(out["x"] - np.array(pr["x"])) <= pr["tol"]   # basic_*.rs: x.dist(refsol)
+    if pr["x"] is not None:
+        assert np.linalg.norm(out["x"] - np.array(pr["x"])) <= pr["tol"]   # basic_*.rs: x.dist(refsol)
     assert abs(out["obj_val"] - pr["obj"]) <= pr["tol"]
-    assert out["iterations"] <= 25
+    assert out["iterations"] <= 30
 
 
 def test_socp_sparse_soc_variant_solves(oracle):

@@ -404,6 +404,49 @@ def test_cone_step_operations(hip, oracle, late):
     assert abs(a_dev - a_ref) <= 1e-12 * max(1.0, abs(a_ref)) and abs(b_dev - b_ref) <= 1e-10 * max(1.0, b_ref)
 
 
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_nonsymmetric_cone_step_operations(hip, oracle, strategy):
+    """Exponential / Power cones mixed with Zero / NN / SOC: affine_ds, combined_ds_shift (3rd-order
+    correction, expcone.rs:254-308 / powcone.rs:260-337), ds_from_dz_offset, step_length (backtracking
+    after the symmetric cones, compositecone.rs:300-340), compute_barrier, unit_initialization"""
+    pr = problems.mixed_conic(nexp=300, npow=300, seed=21)
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+    cones = oracle.Cones(pr["cones"])
+    s, z, m = pr["s"], pr["z"], pr["m"]
+    assert ks.update_scaling(s, z, 0.31, strategy) and cones.update_scaling(s, z, 0.31, strategy)
+    rng = np.random.default_rng(6)
+    dz, dsv = 0.05 * rng.standard_normal(m), 0.05 * rng.standard_normal(m)
+    D = hip.DeviceArray
+    out, d_s, d_z, d_ds, d_dz = D(m), D(s), D(z), D(dsv), D(dz)
+    ks.affine_ds_dev(out.ptr, d_s.ptr)
+    assert relerr(out.numpy(), cones.affine_ds(s)) <= 1e-13
+    sh, tz, ts = D(m), D(dz), D(dsv)
+    ks.combined_ds_shift_dev(sh.ptr, tz.ptr, ts.ptr, 0.37)
+    osh, oz, os_ = cones.combined_ds_shift(dz, dsv, 0.37)
+    assert relerr(tz.numpy(), oz) <= 1e-12 and relerr(ts.numpy(), os_) <= 1e-12
+    assert relerr(sh.numpy(), osh) <= 1e-9
+    o2 = D(m)
+    ks.ds_from_dz_offset_dev(o2.ptr, d_ds.ptr, d_z.ptr)
+    assert relerr(o2.numpy(), cones.ds_from_dz_offset(dsv, z)) <= 1e-11
+    for scale in (0.2, 3.0, 60.0):
+        t1, t2 = D(scale * dz), D(scale * dsv)
+        a_dev = ks.step_length_dev(t1.ptr, t2.ptr, d_z.ptr, d_s.ptr, 1.0)
+        a_ref = cones.step_length(scale * dz, scale * dsv, z, s, 1.0)
+        assert abs(a_dev - a_ref) <= 1e-12 * max(1.0, a_ref)
+        assert a_dev < 1.0
+    for alpha in (0.0, 0.4):
+        b_dev = ks.compute_barrier_dev(d_z.ptr, d_s.ptr, d_dz.ptr, d_ds.ptr, alpha)
+        b_ref = cones.compute_barrier(z, s, dz, dsv, alpha)
+        assert np.isfinite(b_ref) and abs(b_dev - b_ref) <= 1e-10 * max(1.0, abs(b_ref))
+    uz, us = D(m), D(m)
+    ks.unit_initialization_dev(uz.ptr, us.ptr)
+    rz, rs = np.zeros(m), np.zeros(m)
+    cones.unit_initialization(rz, rs)
+    assert np.array_equal(uz.numpy(), rz) and np.array_equal(us.numpy(), rs)
+
+
 def test_full_scale_properties_c3(hip):
     """BASELINE config 3 at full size (n = 10^6): too big for the oracle in seconds, so check
     size-independent properties: residual of the refined solution against an independent
@@ -498,10 +541,10 @@ def test_l3_kktsystem_and_residuals(hip, oracle, which):
         assert relerr(a.numpy(), c) <= TOL
 
 
-@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp"])
+@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone"])
 def test_e2e_reference_answers_on_device(hip, oracle, name):
     """the reference's end-to-end known answers (tests/basic_qp.rs:100-117, basic_lp.rs:27-44,
-    basic_socp.rs:54-70) reached with every L1-L3 operation on the device, and the same
+    basic_socp.rs:54-70, basic_expcone.rs:38-56, basic_powcone.rs:4-47) reached with every L1-L3 operation on the device, and the same
     trajectory as the oracle-backed loop"""
     from tests import e2e_problems as E
     from tests import ipm_driver as ipm
@@ -511,7 +554,8 @@ def test_e2e_reference_answers_on_device(hip, oracle, name):
     out = ipm.solve(ipm.HipBackend(hip, *args), pr["cones"], pr["q"], pr["b"], trace=td)
     ref = ipm.solve(ipm.OracleBackend(oracle, *args), pr["cones"], pr["q"], pr["b"], trace=to)
     assert out["status"] == "Solved"
-    assert np.linalg.norm(out["x"] - np.array(pr["x"])) <= pr["tol"]
+    if pr["x"] is not None:
+        assert np.linalg.norm(out["x"] - np.array(pr["x"])) <= pr["tol"]
     assert abs(out["obj_val"] - pr["obj"]) <= pr["tol"]
     assert out["iterations"] == ref["iterations"]
     for a, c in zip(td, to):  # (mu, alpha, sigma, res_primal, res_dual, gap): same path

@@ -390,7 +390,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
             pd_dim.push_back((int)c.dim);
             pd_hs.push_back((int)c.block_start);
             pd_off.push_back((int)pd_state);
-            pd_state += c.dim * c.dim + c.dim;
+            pd_state += 3 * c.dim * c.dim + 2 * c.dim; // B | lambda | lambda^-1/2 | R | Rinv
             pd_max = std::max<int>(pd_max, (int)c.dim);
         } else {
             h->has_hostHs = true;
@@ -770,22 +770,23 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval) {
 }
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     if (!h) return CHIP_ERR_ARG;
-    if (h->has_hostHs || h->psd.ncones)
-        return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: not implemented for PSD cones yet");
+    if (h->has_hostHs)
+        return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: PSD cones with side > 64 are not held on the device");
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
     dev::cones_mul_Hs(E.stream, h->nn_rows, h->nn_count, h->soc, h->zero_rows, h->zero_count, y_dev, x_dev);
     dev::ns3_mul_hs(E.stream, h->ns3, y_dev, x_dev);
+    dev::psd_mul_hs(E.stream, h->psd, y_dev, x_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
 #define NEED_SYMMETRIC(h)                                                                      \
-    if ((h)->has_hostHs || (h)->ns3.ncones || (h)->psd.ncones)                                                  \
-    return fail(CHIP_ERR_UNSUPPORTED, "margins / scaled_unit_shift: only Zero/Nonnegative/SecondOrder cones")
+    if ((h)->has_hostHs || (h)->ns3.ncones)                                                    \
+    return fail(CHIP_ERR_UNSUPPORTED, "margins / scaled_unit_shift: symmetric, device-held cones only")
 #define NEED_STEP_OPS(h)                                                                       \
-    if ((h)->has_hostHs || (h)->psd.ncones)                                                    \
-    return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: not implemented for PSD cones yet")
+    if ((h)->has_hostHs)                                                                       \
+    return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: PSD cones with side > 64 are not held on the device")
 
 int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha, int32_t primal_cone) {
     if (!h || !z_dev) return CHIP_ERR_ARG;
@@ -795,6 +796,7 @@ int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha,
     CHIP_HIP(hipSetDevice(E.device));
     dev::cone_unit_shift(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, z_dev, alpha,
                          primal_cone ? 1 : 0);
+    dev::psd_unit_shift(E.stream, h->psd, z_dev, alpha);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
@@ -807,6 +809,7 @@ int32_t chip_kkt_affine_ds_dev(chip_kkt *h, double *ds_dev, const double *s_dev)
     CHIP_HIP(hipSetDevice(E.device));
     dev::cone_affine_ds(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, ds_dev);
     dev::ns3_affine_ds(E.stream, h->ns3, ds_dev, s_dev);
+    dev::psd_affine_ds(E.stream, h->psd, ds_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
@@ -820,6 +823,7 @@ int32_t chip_kkt_combined_ds_shift_dev(chip_kkt *h, double *shift_dev, double *s
     dev::cone_combined_ds_shift(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, shift_dev,
                                 step_z_dev, step_s_dev, sigma_mu);
     dev::ns3_combined_ds_shift(E.stream, h->ns3, shift_dev, step_z_dev, step_s_dev, sigma_mu);
+    dev::psd_combined_ds_shift(E.stream, h->psd, shift_dev, step_z_dev, step_s_dev, sigma_mu);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
@@ -832,12 +836,13 @@ int32_t chip_kkt_ds_from_dz_offset_dev(chip_kkt *h, double *out_dev, const doubl
     dev::cone_ds_from_dz_offset(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, out_dev,
                                 ds_dev, z_dev);
     dev::ns3_ds_from_dz_offset(E.stream, h->ns3, out_dev, ds_dev);
+    dev::psd_ds_from_dz_offset(E.stream, h->psd, out_dev, ds_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
 static int ensure_partials(chip_kkt *h) {
     if (h->d_partial) return CHIP_OK;
-    h->partial_cap = 1024 + h->soc.ncones + (h->ns3.ncones + 255) / 256 + 8;
+    h->partial_cap = 1024 + h->soc.ncones + h->psd.ncones + (h->ns3.ncones + 255) / 256 + 8;
     int rc = h->E.alloc(&h->d_partial, (size_t)h->partial_cap * 2);
     if (rc) return rc;
     h->h_partial.resize((size_t)h->partial_cap * 2);
@@ -855,6 +860,7 @@ int32_t chip_kkt_step_length_dev(chip_kkt *h, const double *dz_dev, const double
     // symmetric cones first (compositecone.rs:326-327)
     int used = dev::cone_step_length(E.stream, h->nn_rows, h->nn_count, h->soc, dz_dev, ds_dev, z_dev, s_dev,
                                      alpha_max, h->d_partial, 1024);
+    used += dev::psd_step_length(E.stream, h->psd, dz_dev, ds_dev, alpha_max, h->d_partial + used);
     double a = alpha_max;
     if (used) {
         CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)used * sizeof(double),
@@ -883,8 +889,9 @@ int32_t chip_kkt_compute_barrier_dev(chip_kkt *h, const double *z_dev, const dou
     CHIP_HIP(hipSetDevice(E.device));
     int rc = ensure_partials(h);
     if (rc) return rc;
-    const int used = dev::cone_barrier(E.stream, h->nn_rows, h->nn_count, h->soc, h->ns3, z_dev, s_dev, dz_dev,
-                                       ds_dev, alpha, h->d_partial);
+    int used = dev::cone_barrier(E.stream, h->nn_rows, h->nn_count, h->soc, h->ns3, z_dev, s_dev, dz_dev, ds_dev,
+                                 alpha, h->d_partial);
+    used += dev::psd_barrier(E.stream, h->psd, z_dev, s_dev, dz_dev, ds_dev, alpha, h->d_partial + used);
     double b = 0.0;
     if (used) {
         CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)used * sizeof(double),
@@ -902,6 +909,7 @@ int32_t chip_kkt_unit_initialization_dev(chip_kkt *h, double *z_dev, double *s_d
     NEED_STEP_OPS(h);
     CHIP_HIP(hipSetDevice(E.device));
     dev::cone_unit_initialization(E.stream, h->nn_rows, h->nn_count, h->soc, h->ns3, z_dev, s_dev, (int)h->K.m);
+    dev::psd_unit_initialization(E.stream, h->psd, z_dev, s_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
@@ -914,7 +922,8 @@ int32_t chip_kkt_margins_dev(chip_kkt *h, const double *z_dev, double *alpha_out
     int rc = ensure_partials(h);
     if (rc) return rc;
     double *pmin = h->d_partial, *psum = h->d_partial + h->partial_cap;
-    const int used = dev::cone_margins(E.stream, h->nn_rows, h->nn_count, h->soc, z_dev, pmin, psum, 1024);
+    int used = dev::cone_margins(E.stream, h->nn_rows, h->nn_count, h->soc, z_dev, pmin, psum, 1024);
+    used += dev::psd_margins(E.stream, h->psd, z_dev, pmin + used, psum + used);
     double a = 1.7976931348623157e308, b = 0.0; // T::max_value(), compositecone.rs:198
     if (used) {
         CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), pmin, (size_t)used * sizeof(double), hipMemcpyDeviceToHost,

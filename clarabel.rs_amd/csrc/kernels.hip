@@ -1453,6 +1453,8 @@ __device__ bool lds_cholesky(double *A, int n, int *flag) {
     return true;
 }
 
+// state of one PSD cone in HBM (doubles): B = R R' (n*n) | lambda (n) | lambda^-1/2 (n) | R (n*n) | Rinv (n*n)
+__device__ __forceinline__ int psd_state_size(int n) { return 3 * n * n + 2 * n; }
 __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const double *__restrict__ sv,
                                                            const double *__restrict__ zv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1460,7 +1462,10 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
     const int c = blockIdx.x;
     if (c >= v.ncones) return;
     const int n = v.dim[c], tid = threadIdx.x;
-    double *A = (double *)smem, *Bm = A + n * n, *Cm = Bm + n * n; // A: S -> L1, Bm: Z -> L2 -> V, Cm: M
+    // A: S -> L1, Bm: Z -> L2, Cm: M = L2' L1 -> U Sigma, Vm: V
+    double *A = (double *)smem, *Bm = A + n * n, *Cm = Bm + n * n, *Vm = Cm + n * n;
+    double *sig = Vm + n * n, *sgn = sig + n;
+    int *rank = (int *)(sgn + n);
     const double *s = sv + v.start[c], *z = zv + v.start[c];
     const double isq2 = 0.7071067811865476;
     if (tid == 0) flag = 0;
@@ -1478,16 +1483,14 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
         if (tid == 0) *v.fail = 1;
         return;
     }
-    // M = L2' L1
+    // M = L2' L1 ; V = I
     for (int idx = tid; idx < n * n; idx += WG) {
         const int a = idx % n, b = idx / n;
         double acc = 0.0;
         for (int i = (a > b ? a : b); i < n; ++i) acc += Bm[i + a * n] * A[i + b * n];
         Cm[idx] = acc;
+        Vm[idx] = (a == b) ? 1.0 : 0.0;
     }
-    __syncthreads();
-    // V = I (overwrites L2)
-    for (int idx = tid; idx < n * n; idx += WG) Bm[idx] = (idx % n == idx / n) ? 1.0 : 0.0;
     __syncthreads();
     // one-sided Jacobi, round-robin pairing over np players (np even), one thread per pair
     const int np = (n + 1) & ~1;
@@ -1516,7 +1519,7 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
                         const double zeta = (be - al) / (2.0 * ga);
                         const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                         const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                        double *vp = Bm + p * n, *vq = Bm + q * n;
+                        double *vp = Vm + p * n, *vq = Vm + q * n;
                         for (int i = 0; i < n; ++i) {
                             const double a0 = mp[i], b0 = mq[i];
                             mp[i] = cs * a0 - sn * b0;
@@ -1535,30 +1538,323 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
         __syncthreads();
     }
     __syncthreads();
-    // sigma_p = ||m_p||; R = L1 V Sigma^-1/2 (into Cm, M is dead); needs sigma first
-    double *sig = Cm + n * n; // n extra doubles
+    // sigma_p = ||m_p||; conventions LAPACK leaves open, fixed like the oracle: singular values in
+    // descending order, each right singular vector signed so that its largest entry is positive
     for (int p = tid; p < n; p += WG) {
-        double a = 0.0;
-        for (int i = 0; i < n; ++i) a += Cm[i + p * n] * Cm[i + p * n];
+        double a = 0.0, big = 0.0, sg = 1.0;
+        for (int i = 0; i < n; ++i) {
+            a += Cm[i + p * n] * Cm[i + p * n];
+            const double vv = Vm[i + p * n];
+            if (fabs(vv) > big) {
+                big = fabs(vv);
+                sg = vv < 0.0 ? -1.0 : 1.0;
+            }
+        }
         sig[p] = sqrt(a);
+        sgn[p] = sg;
     }
     __syncthreads();
+    for (int p = tid; p < n; p += WG) {
+        int r = 0;
+        for (int q = 0; q < n; ++q) r += (sig[q] > sig[p]) || (sig[q] == sig[p] && q < p);
+        rank[p] = r;
+    }
+    __syncthreads();
+    double *st = v.state + v.state_off[c];
+    double *Bout = st, *lam = st + n * n, *lis = lam + n, *Rout = lis + n, *Riout = Rout + n * n;
+    for (int p = tid; p < n; p += WG) {
+        lam[rank[p]] = sig[p];
+        lis[rank[p]] = 1.0 / sqrt(sig[p]);
+    }
+    // R = L1 V Sigma^-1/2 (column p -> rank[p]);  Rinv = Sigma^-1/2 U' L2' with U = (M V) Sigma^-1
     for (int idx = tid; idx < n * n; idx += WG) {
         const int i = idx % n, p = idx / n;
         double acc = 0.0;
-        for (int k = 0; k <= i; ++k) acc += A[i + k * n] * Bm[k + p * n];
-        Cm[idx] = acc / sqrt(sig[p]);
+        for (int k = 0; k <= i; ++k) acc += A[i + k * n] * Vm[k + p * n];
+        const double lsq = 1.0 / sqrt(sig[p]);
+        Rout[i + rank[p] * n] = acc * sgn[p] * lsq;
+        double acc2 = 0.0; // Rinv[p, i] = lsq/sig * sum_k Cm[k,p] L2[i,k]
+        for (int k = 0; k <= i; ++k) acc2 += Cm[k + p * n] * Bm[i + k * n];
+        Riout[rank[p] + i * n] = (acc2 / sig[p]) * sgn[p] * lsq;
     }
     __syncthreads();
-    // B = R R' -> HBM state (n*n) + lambda = sigma
-    double *Bout = v.state + v.state_off[c];
+    __threadfence_block();
+    // B = R R' (invariant under the conventions above)
     for (int idx = tid; idx < n * n; idx += WG) {
         const int i = idx % n, j = idx / n;
         double acc = 0.0;
-        for (int p = 0; p < n; ++p) acc += Cm[i + p * n] * Cm[j + p * n];
+        for (int p = 0; p < n; ++p) acc += Rout[i + p * n] * Rout[j + p * n];
         Bout[idx] = acc;
     }
-    for (int p = tid; p < n; p += WG) Bout[n * n + p] = sig[p];
+}
+
+// ---- PSD cone operations either side of the solve: one workgroup per cone, matrices in LDS ----
+__device__ __forceinline__ void psd_svec_to_mat(double *M, const double *x, int n, double scale_in = 1.0) {
+    const double isq2 = 0.7071067811865476;
+    for (int idx = threadIdx.x; idx < n * n; idx += WG) {
+        const int i = idx % n, j = idx / n;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        M[idx] = x[hi * (hi + 1) / 2 + lo] * ((i == j) ? 1.0 : isq2) * scale_in;
+    }
+}
+// dense/matrix_math.rs:186-205
+__device__ __forceinline__ void psd_mat_to_svec(double *y, const double *M, int n) {
+    const double isq2 = 0.7071067811865476;
+    const int numel = n * (n + 1) / 2;
+    for (int t = threadIdx.x; t < numel; t += WG) {
+        int col = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (col * (col + 1) / 2 > t) --col;
+        while ((col + 1) * (col + 2) / 2 <= t) ++col;
+        const int row = t - col * (col + 1) / 2;
+        y[t] = row == col ? M[row + col * n] : (M[row + col * n] + M[col + row * n]) * isq2;
+    }
+}
+// C = op(A) op(B), all n x n column major; A / B may live in LDS or (L2-resident) global memory
+template <bool TA, bool TB>
+__device__ __forceinline__ void psd_gemm(double *C, const double *A, const double *B, int n) {
+    for (int idx = threadIdx.x; idx < n * n; idx += WG) {
+        const int i = idx % n, j = idx / n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc += (TA ? A[k + i * n] : A[i + k * n]) * (TB ? B[j + k * n] : B[k + j * n]);
+        C[idx] = acc;
+    }
+}
+// Y = Rx' X Rx (transpose == false: W x, W^-1 x) or Rx X Rx' (true: W' x, W^-T x), psdtrianglecone.rs:340-396
+__device__ __forceinline__ void psd_mul_Wx(double *Y, double *T, const double *X, const double *Rx, int n,
+                                           bool transpose) {
+    if (transpose) {
+        psd_gemm<false, true>(T, X, Rx, n); // T = X Rx'
+        __syncthreads();
+        psd_gemm<false, false>(Y, Rx, T, n); // Y = Rx T
+    } else {
+        psd_gemm<true, false>(T, Rx, X, n); // T = Rx' X
+        __syncthreads();
+        psd_gemm<false, false>(Y, T, Rx, n); // Y = T Rx
+    }
+    __syncthreads();
+}
+// eigenvalues of the symmetric matrix A (LDS, destroyed) by parallel two-sided Jacobi: per round the
+// n/2 disjoint pairs of a round-robin schedule are rotated together (columns, then rows).  Returns
+// the smallest eigenvalue and (psum) the sum of the positive ones to every thread.
+__device__ double psd_eig_min(double *A, int n, double *cs, double *red, int *flag, double *psum) {
+    const int np = (n + 1) & ~1, half = np / 2, tid = threadIdx.x;
+    double *cc = cs, *ss = cs + half;
+    int *pp = (int *)(cs + 2 * half), *qq = pp + half;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int r = 0; r < np - 1; ++r) {
+            if (tid < half) {
+                int p, q;
+                if (tid == 0) {
+                    p = np - 1;
+                    q = r;
+                } else {
+                    p = (r + tid) % (np - 1);
+                    q = (r - tid + np - 1) % (np - 1);
+                }
+                if (p > q) {
+                    const int t = p;
+                    p = q;
+                    q = t;
+                }
+                double c = 1.0, sn = 0.0;
+                if (q < n) {
+                    const double apq = A[p + q * n], app = A[p + p * n], aqq = A[q + q * n];
+                    if (fabs(apq) > 1e-17 * sqrt(fabs(app * aqq)) && apq != 0.0) {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        sn = t * c;
+                        if (fabs(apq) > 1e-15 * (fabs(app) + fabs(aqq))) *flag = 1;
+                    }
+                } else {
+                    p = -1;
+                }
+                pp[tid] = p;
+                qq[tid] = q;
+                cc[tid] = c;
+                ss[tid] = sn;
+            }
+            __syncthreads();
+            // columns: A <- A J
+            for (int w = tid; w < half * n; w += WG) {
+                const int k = w / n, i = w % n;
+                const int p = pp[k], q = qq[k];
+                if (p < 0) continue;
+                const double c = cc[k], sn = ss[k];
+                const double a = A[i + p * n], b = A[i + q * n];
+                A[i + p * n] = c * a - sn * b;
+                A[i + q * n] = sn * a + c * b;
+            }
+            __syncthreads();
+            // rows: A <- J' A
+            for (int w = tid; w < half * n; w += WG) {
+                const int k = w / n, j = w % n;
+                const int p = pp[k], q = qq[k];
+                if (p < 0) continue;
+                const double c = cc[k], sn = ss[k];
+                const double a = A[p + j * n], b = A[q + j * n];
+                A[p + j * n] = c * a - sn * b;
+                A[q + j * n] = sn * a + c * b;
+            }
+            __syncthreads();
+        }
+        if (!*flag) break;
+        __syncthreads();
+    }
+    double mn = INFINITY, sp = 0.0;
+    for (int i = tid; i < n; i += WG) {
+        const double e = A[i + i * n];
+        mn = fmin(mn, e);
+        sp += fmax(e, 0.0);
+    }
+    mn = -block_max(-mn, red);
+    sp = block_sum(sp, red);
+    if (psum) *psum = sp;
+    return mn;
+}
+// state offsets, see psd_state_size
+struct PsdState {
+    const double *B, *lam, *lis, *R, *Ri;
+};
+__device__ __forceinline__ PsdState psd_state(const PsdView &v, int c, int n) {
+    const double *st = v.state + v.state_off[c];
+    return {st, st + n * n, st + n * n + n, st + n * n + 2 * n, st + 2 * n * n + 2 * n};
+}
+//   OP 0 mul_Hs: o0 = svec(B X B)  (== W'(W x), psdtrianglecone.rs:214-218)
+//   OP 1 affine_ds: o0 = svec(diag(lambda^2))  (:220-225)
+//   OP 2 combined_ds_shift (symmetric_common.rs:53-84): o1 <- W o1, o2 <- W^-T o2, o0 = o2 o o1 - sc e
+//   OP 3 ds_from_dz_offset (symmetric_common.rs:89-95): o0 = W'(lambda \ i0)
+//   OP 4 step_length (:235-279, 437-463) with i0 = dz, i1 = ds, alpha_max = sc -> partial[c]
+//   OP 5 margins (:104-121) of i0 -> partial[c] (min eig), partial2[c] (sum of positive eigs)
+//   OP 6 barrier (:281-303) at (i0, i1) + sc (i2, i3) -> partial[c]
+template <int OP>
+__global__ __launch_bounds__(WG) void k_psd_ops(PsdView v, double *o0, double *o1, double *o2,
+                                                const double *__restrict__ i0, const double *__restrict__ i1,
+                                                const double *__restrict__ i2, const double *__restrict__ i3,
+                                                double sc, double *partial, double *partial2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[16];
+    __shared__ int flag;
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c], off = v.start[c], tid = threadIdx.x;
+    double *X = (double *)smem, *Y = X + n * n, *T = Y + n * n, *cs = T + n * n;
+    const PsdState st = psd_state(v, c, n);
+    const int numel = n * (n + 1) / 2;
+    if (OP == 0) {
+        psd_svec_to_mat(X, i0 + off, n);
+        __syncthreads();
+        psd_gemm<false, false>(T, st.B, X, n);
+        __syncthreads();
+        psd_gemm<false, false>(Y, T, st.B, n);
+        __syncthreads();
+        psd_mat_to_svec(o0 + off, Y, n);
+    } else if (OP == 1) {
+        for (int t = tid; t < numel; t += WG) o0[off + t] = 0.0;
+        __syncthreads();
+        for (int k = tid; k < n; k += WG) o0[off + k * (k + 1) / 2 + k] = st.lam[k] * st.lam[k];
+    } else if (OP == 2) {
+        psd_svec_to_mat(X, o1 + off, n);
+        __syncthreads();
+        psd_mul_Wx(Y, T, X, st.R, n, false); // Y = W dz
+        psd_mat_to_svec(o1 + off, Y, n);
+        psd_svec_to_mat(X, o2 + off, n);
+        __syncthreads();
+        double *Z = T; // reuse after the product below is done with T
+        psd_mul_Wx(X, T, X, st.Ri, n, true); // X = W^-T ds (T = X Ri' is complete before X is overwritten)
+        psd_mat_to_svec(o2 + off, X, n);
+        __syncthreads();
+        // shift = (X Y + Y X) / 2 - sc I
+        for (int idx = tid; idx < n * n; idx += WG) {
+            const int i = idx % n, j = idx / n;
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += X[i + k * n] * Y[k + j * n] + Y[i + k * n] * X[k + j * n];
+            Z[idx] = 0.5 * acc - (i == j ? sc : 0.0);
+        }
+        __syncthreads();
+        psd_mat_to_svec(o0 + off, Z, n);
+    } else if (OP == 3) {
+        psd_svec_to_mat(X, i0 + off, n);
+        __syncthreads();
+        for (int idx = tid; idx < n * n; idx += WG) {
+            const int i = idx % n, j = idx / n;
+            X[idx] = (2.0 * X[idx]) / (st.lam[i] + st.lam[j]);
+        }
+        __syncthreads();
+        psd_mul_Wx(Y, T, X, st.R, n, true);
+        psd_mat_to_svec(o0 + off, Y, n);
+    } else if (OP == 4) {
+        double amin = sc;
+        for (int pass = 0; pass < 2; ++pass) {
+            psd_svec_to_mat(X, (pass == 0 ? i0 : i1) + off, n);
+            __syncthreads();
+            psd_mul_Wx(Y, T, X, pass == 0 ? st.R : st.Ri, n, pass == 1);
+            for (int idx = tid; idx < n * n; idx += WG) Y[idx] *= st.lis[idx % n] * st.lis[idx / n]; // lrscale
+            __syncthreads();
+            const double g = psd_eig_min(Y, n, cs, red, &flag, nullptr);
+            if (g < 0.0) amin = fmin(amin, fmin(-(1.0 / g), sc));
+            __syncthreads();
+        }
+        if (tid == 0) partial[c] = amin;
+    } else if (OP == 5) {
+        psd_svec_to_mat(X, i0 + off, n);
+        __syncthreads();
+        double sp;
+        const double mn = psd_eig_min(X, n, cs, red, &flag, &sp);
+        if (tid == 0) {
+            partial[c] = mn;
+            partial2[c] = sp;
+        }
+    } else if (OP == 6) {
+        double bar = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const double *xa = (pass == 0 ? i0 : i1) + off, *xb = (pass == 0 ? i2 : i3) + off;
+            const double isq2 = 0.7071067811865476;
+            for (int idx = tid; idx < n * n; idx += WG) {
+                const int i = idx % n, j = idx / n;
+                const int lo = i < j ? i : j, hi = i < j ? j : i;
+                const int t = hi * (hi + 1) / 2 + lo;
+                X[idx] = (1.0 * xa[t] + sc * xb[t]) * ((i == j) ? 1.0 : isq2);
+            }
+            if (tid == 0) flag = 0;
+            __syncthreads();
+            if (!lds_cholesky(X, n, &flag)) {
+                bar = INFINITY;
+            } else {
+                double ld = 0.0;
+                for (int i = tid; i < n; i += WG) ld += log(X[i + i * n]);
+                ld = block_sum(ld, red);
+                bar -= 2.0 * ld;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) partial[c] = bar;
+    }
+}
+// scaled_unit_shift / unit_initialization of the PSD cones (:123-137): diagonal svec entries
+__global__ __launch_bounds__(WG) void k_psd_diag(PsdView v, double *z, double *s2, double alpha, int init) {
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int n = v.dim[c], off = v.start[c];
+    if (init) {
+        const int numel = n * (n + 1) / 2;
+        for (int t = threadIdx.x; t < numel; t += WG) {
+            z[off + t] = 0.0;
+            s2[off + t] = 0.0;
+        }
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < n; k += WG) {
+        const int t = off + k * (k + 1) / 2 + k;
+        if (init) {
+            z[t] = 1.0;
+            s2[t] = 1.0;
+        } else {
+            z[t] += alpha;
+        }
+    }
 }
 
 // get_Hs = pack_triu(skron(B)) (psdtrianglecone.rs:210-212, 467-509), negated and scattered into K.
@@ -2341,7 +2637,8 @@ void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx) {
 }
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv) {
     if (!v.ncones) return;
-    const size_t lds = ((size_t)(3 * v.maxdim * v.maxdim + v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
+    const size_t lds = ((size_t)(4 * v.maxdim * v.maxdim + 3 * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_psd_update_scaling, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     k_psd_update_scaling<<<v.ncones, WG, lds, s>>>(v, sv, zv);
 }
 void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx) {
@@ -2349,6 +2646,54 @@ void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx) {
     const int bpc = 16;
     const size_t lds = ((size_t)(v.maxdim * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
     k_psd_write_hs<<<v.ncones * bpc, WG, lds, s>>>(v, Kx, bpc);
+}
+static size_t psd_ops_lds(const PsdView &v) {
+    return ((size_t)(3 * v.maxdim * v.maxdim + 4 * v.maxdim + 8) * sizeof(double) + 15) & ~(size_t)15;
+}
+template <typename K> static void psd_allow_lds(K kernel, size_t lds) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+#define PSD_LAUNCH(OP, ...)                                                          \
+    do {                                                                             \
+        const size_t lds_ = psd_ops_lds(v);                                          \
+        psd_allow_lds(k_psd_ops<OP>, lds_);                                          \
+        k_psd_ops<OP><<<v.ncones, WG, lds_, s>>>(v, __VA_ARGS__);                    \
+    } while (0)
+void psd_mul_hs(hipStream_t s, const PsdView &v, double *y, const double *x) {
+    if (v.ncones) PSD_LAUNCH(0, y, nullptr, nullptr, x, nullptr, nullptr, nullptr, 0.0, nullptr, nullptr);
+}
+void psd_affine_ds(hipStream_t s, const PsdView &v, double *ds) {
+    if (v.ncones) PSD_LAUNCH(1, ds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, nullptr);
+}
+void psd_combined_ds_shift(hipStream_t s, const PsdView &v, double *shift, double *step_z, double *step_s,
+                           double sigma_mu) {
+    if (v.ncones) PSD_LAUNCH(2, shift, step_z, step_s, nullptr, nullptr, nullptr, nullptr, sigma_mu, nullptr, nullptr);
+}
+void psd_ds_from_dz_offset(hipStream_t s, const PsdView &v, double *out, const double *ds) {
+    if (v.ncones) PSD_LAUNCH(3, out, nullptr, nullptr, ds, nullptr, nullptr, nullptr, 0.0, nullptr, nullptr);
+}
+int psd_step_length(hipStream_t s, const PsdView &v, const double *dz, const double *ds, double amax,
+                    double *partial) {
+    if (!v.ncones) return 0;
+    PSD_LAUNCH(4, nullptr, nullptr, nullptr, dz, ds, nullptr, nullptr, amax, partial, nullptr);
+    return v.ncones;
+}
+int psd_margins(hipStream_t s, const PsdView &v, const double *z, double *pmin, double *psum) {
+    if (!v.ncones) return 0;
+    PSD_LAUNCH(5, nullptr, nullptr, nullptr, z, nullptr, nullptr, nullptr, 0.0, pmin, psum);
+    return v.ncones;
+}
+int psd_barrier(hipStream_t s, const PsdView &v, const double *z, const double *sv, const double *dz,
+                const double *ds, double alpha, double *partial) {
+    if (!v.ncones) return 0;
+    PSD_LAUNCH(6, nullptr, nullptr, nullptr, z, sv, dz, ds, alpha, partial, nullptr);
+    return v.ncones;
+}
+void psd_unit_shift(hipStream_t s, const PsdView &v, double *z, double alpha) {
+    if (v.ncones) k_psd_diag<<<v.ncones, WG, 0, s>>>(v, z, nullptr, alpha, 0);
+}
+void psd_unit_initialization(hipStream_t s, const PsdView &v, double *z, double *sv) {
+    if (v.ncones) k_psd_diag<<<v.ncones, WG, 0, s>>>(v, z, sv, 0.0, 1);
 }
 void ns3_update_scaling(hipStream_t s, const Ns3View &v, const double *sv, const double *zv, double mu,
                         int strategy) {

@@ -146,6 +146,19 @@ struct PsdView {
 };
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv);
 void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx);
+// PSD cone operations either side of the solve (psdtrianglecone.rs:104-303, symmetric_common.rs:53-95)
+void psd_mul_hs(hipStream_t s, const PsdView &v, double *y, const double *x);
+void psd_affine_ds(hipStream_t s, const PsdView &v, double *ds);
+void psd_combined_ds_shift(hipStream_t s, const PsdView &v, double *shift, double *step_z, double *step_s,
+                           double sigma_mu);
+void psd_ds_from_dz_offset(hipStream_t s, const PsdView &v, double *out, const double *ds);
+int psd_step_length(hipStream_t s, const PsdView &v, const double *dz, const double *ds, double amax,
+                    double *partial);
+int psd_margins(hipStream_t s, const PsdView &v, const double *z, double *pmin, double *psum);
+int psd_barrier(hipStream_t s, const PsdView &v, const double *z, const double *sv, const double *dz,
+                const double *ds, double alpha, double *partial);
+void psd_unit_shift(hipStream_t s, const PsdView &v, double *z, double alpha);
+void psd_unit_initialization(hipStream_t s, const PsdView &v, double *z, double *sv);
 void ns3_update_scaling(hipStream_t s, const Ns3View &v, const double *sv, const double *zv, double mu,
                         int strategy);
 void ns3_write_hs(hipStream_t s, const Ns3View &v, double *Kx);

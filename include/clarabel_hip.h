@@ -225,8 +225,11 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval);
  * y = Hs x, m doubles, device pointers. */
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev);
 /* ---- the cone operations either side of the KKT solve, for problems whose
- * cones are Zero / Nonnegative / SecondOrder / Exponential / Power; m-vectors in HBM.
- * CHIP_ERR_UNSUPPORTED otherwise (PSD, GenPower).  Exponential / Power: affine_ds = s
+ * cones are Zero / Nonnegative / SecondOrder / Exponential / Power / PSDTriangle (side <= 64);
+ * m-vectors in HBM.  CHIP_ERR_UNSUPPORTED otherwise (larger PSD cones, GenPower).  PSDTriangle:
+ * psdtrianglecone.rs:104-303 with symmetric_common.rs:53-95 -- mul_W / mul_Winv as two n x n
+ * products with R / Rinv, circ_op, lambda \ ., step length and margins from the eigenvalues of a
+ * parallel two-sided Jacobi iteration, barrier from a Cholesky log-determinant, all in LDS.  Exponential / Power: affine_ds = s
  * (expcone.rs:129-131), combined_ds_shift = sigma*mu*grad - 3rd-order correction
  * (expcone.rs:133-142,254-308, powcone.rs:132-141,260-337; step_z / step_s are left unchanged),
  * ds_from_dz_offset = ds, step_length = backtracking line searches (nonsymmetric_common.rs:164-192)

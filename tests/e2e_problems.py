@@ -4,7 +4,7 @@ solutions (basic_qp.rs:100-117, basic_lp.rs:27-44, basic_socp.rs:54-70)."""
 import numpy as np
 import scipy.sparse as sp
 
-ZERO, NN, SOC, EXP, POW = 0, 1, 2, 3, 4
+ZERO, NN, SOC, EXP, POW, PSD = 0, 1, 2, 3, 4, 6
 
 
 def _csc(M):
@@ -59,3 +59,12 @@ def basic_powcone():
     return dict(n=6, m=8, P=_csc(sp.csc_matrix((6, 6))), A=_csc(A), q=[0.0, 0.0, -1.0, 0.0, 0.0, -1.0],
                 b=[0.0] * 6 + [3.0, 1.0], cones=[(POW, 3, 0, 0.6), (POW, 3, 0, 0.1), (ZERO, 2)], x=None,
                 obj=-1.8458, tol=1e-3)
+
+
+def basic_sdp():
+    # tests/basic_sdp.rs:6-40: min 0.5 x'x s.t. mat(b - x) PSD (3 x 3, svec coordinates)
+    I6 = sp.identity(6, format="csc")
+    return dict(n=6, m=6, P=_triu(I6), A=_csc(I6), q=[0.0] * 6, b=[-3.0, 1.0, 4.0, 1.0, 2.0, 5.0],
+                cones=[(PSD, 3)],
+                x=[-3.0729833267361095, 0.3696004167288786, -0.022226685581313674, 0.31441213129613066,
+                   -0.026739700851545107, -0.016084530571308823], obj=4.840076866013861, tol=1e-6)

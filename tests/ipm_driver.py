@@ -13,7 +13,7 @@ import math
 
 import numpy as np
 
-ZERO, NN, SOC, EXP, POW = 0, 1, 2, 3, 4
+ZERO, NN, SOC, EXP, POW, PSD = 0, 1, 2, 3, 4, 6
 AFFINE, COMBINED = 0, 1
 PRIMAL_DUAL, DUAL = 0, 1  # ScalingStrategy, core/solver.rs:77-80
 
@@ -30,9 +30,15 @@ class Vars:
 class OracleBackend:
     def __init__(self, oracle, n, m, P, A, q, b, cones):
         self.n, self.m = n, m
-        self.cones = oracle.Cones(cones)
-        self.ks = oracle.KKTSolver(n, m, P, A, self.cones)
-        self.sys = oracle.KKTSystem(self.ks, self.cones, n, m, P, A, q, b)
+        if any(c[0] == PSD for c in cones):  # PSD cones: numpy restatement (oracle/psd_numpy.py)
+            from oracle import psd_numpy
+            self.cones = psd_numpy.MixedCones(oracle, cones)
+            self.ks = oracle.KKTSolver(n, m, P, A, self.cones.c)
+            self.sys = psd_numpy.KKTSystemPy(oracle, self.ks, self.cones, n, m, P, A, q, b)
+        else:
+            self.cones = oracle.Cones(cones)
+            self.ks = oracle.KKTSolver(n, m, P, A, self.cones)
+            self.sys = oracle.KKTSystem(self.ks, self.cones, n, m, P, A, q, b)
         self.degree = self.cones.degree
         self.is_symmetric = self.cones.is_symmetric
 
@@ -84,7 +90,7 @@ class HipBackend:
         Pm, Am = hip.CscMatrix(n, n, *P), hip.CscMatrix(m, n, *A)
         self.ks = hip.HipKKTSolver(Pm, Am, cones, m, n)
         self.sys = hip.HipKKTSystem(self.ks, Pm, Am, q, b)
-        self.degree = sum(c[1] if c[0] == NN else (1 if c[0] == SOC else (3 if c[0] in (EXP, POW) else 0))
+        self.degree = sum(c[1] if c[0] in (NN, PSD) else (1 if c[0] == SOC else (3 if c[0] in (EXP, POW) else 0))
                           for c in cones)
         self.is_symmetric = not any(c[0] in (EXP, POW) for c in cones)
         D = hip.DeviceArray
@@ -171,21 +177,6 @@ class HipBackend:
 
 
 # ---------------------------------------------------------------------------------------------
-def _unit_vectors(cones, m):
-    """identity elements of the composite cone: what set_identity_scaling (compositecone.rs:216-222)
-    amounts to when fed to update_scaling -- w = 1 / eta = 1, w = e0"""
-    e = np.zeros(m)
-    pos = 0
-    for c in cones:
-        tag, dim = c[0], c[1]
-        if tag == NN:
-            e[pos:pos + dim] = 1.0
-        elif tag == SOC:
-            e[pos] = 1.0
-        pos += dim
-    return e
-
-
 def _shift_to_cone_interior(be, z, primal):
     # default/variables.rs:231-256
     min_margin, pos_margin = be.margins(z)
@@ -232,7 +223,8 @@ def solve(be, cones, q, b, max_iter=200, tol_gap_abs=1e-8, tol_gap_rel=1e-8, tol
     symmetric = be.is_symmetric
     # default_start (solver.rs:525-543)
     if symmetric:
-        e = _unit_vectors(cones, m)
+        e, e2 = np.zeros(m), np.zeros(m)
+        be.unit_initialization(e, e2)  # the identity element: set_identity_scaling, compositecone.rs:216-222
         assert be.update_scaling(e, e, 1.0, 0)
         be.kkt_update()
         be.solve_initial_point(variables)

@@ -447,6 +447,68 @@ def test_nonsymmetric_cone_step_operations(hip, oracle, strategy):
     assert np.array_equal(uz.numpy(), rz) and np.array_equal(us.numpy(), rs)
 
 
+@pytest.mark.parametrize("dim", [3, 8, 21, 50])
+def test_psd_cone_operations(hip, oracle, dim):
+    """PSDTriangleCone operations either side of the solve on the device (one workgroup per cone:
+    GEMMs with R / Rinv, Jacobi eigenvalues, Cholesky log-det) against the numpy restatement
+    oracle/psd_numpy.py, in a composite with Nonnegative and SecondOrder cones"""
+    from oracle import psd_numpy
+    pr = problems.chordal_sdp(1 if dim == 50 else 3, dim, min(3, dim - 1), 2, 7, seed=40 + dim)
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+    cones = psd_numpy.MixedCones(oracle, pr["cones"])
+    s, z, m = pr["s"], pr["z"], pr["m"]
+    assert ks.update_scaling(s, z) and cones.update_scaling(s, z)
+    rng = np.random.default_rng(dim)
+    # a symmetric-cone-friendly direction: small relative to the interior point
+    dz, dsv = 0.1 * rng.standard_normal(m), 0.1 * rng.standard_normal(m)
+    D = hip.DeviceArray
+    d_s, d_z, d_ds, d_dz = D(s), D(z), D(dsv), D(dz)
+    x = rng.standard_normal(m)
+    y, d_x = D(m), D(x)
+    ks.mul_Hs_dev(y.ptr, d_x.ptr)
+    assert relerr(y.numpy(), cones.mul_Hs(x)) <= 1e-11
+    out = D(m)
+    ks.affine_ds_dev(out.ptr, d_s.ptr)
+    assert relerr(out.numpy(), cones.affine_ds(s)) <= 1e-11
+    sh, tz, ts = D(m), D(dz), D(dsv)
+    ks.combined_ds_shift_dev(sh.ptr, tz.ptr, ts.ptr, 0.37)
+    osh, oz, os_ = cones.combined_ds_shift(dz, dsv, 0.37)
+    # scaled-space vectors: comparable thanks to the shared SVD conventions (descending, signed)
+    assert relerr(tz.numpy(), oz) <= 1e-9 and relerr(ts.numpy(), os_) <= 1e-9
+    assert relerr(sh.numpy(), osh) <= 1e-9
+    # the invariant chain: (affine_ds + shift) mapped back by ds_from_dz_offset
+    rhs_s = cones.affine_ds(s) + osh
+    o2, d_rs = D(m), D(rhs_s)
+    ks.ds_from_dz_offset_dev(o2.ptr, d_rs.ptr, d_z.ptr)
+    assert relerr(o2.numpy(), cones.ds_from_dz_offset(rhs_s, z)) <= 1e-9
+    for scale in (0.05, 1.0, 40.0):
+        t1, t2 = D(scale * dz), D(scale * dsv)
+        a_dev = ks.step_length_dev(t1.ptr, t2.ptr, d_z.ptr, d_s.ptr, 1.0)
+        a_ref = cones.step_length(scale * dz, scale * dsv, z, s, 1.0)
+        assert abs(a_dev - a_ref) <= 1e-10 * max(1.0, a_ref)
+    zz = z + 0.7 * rng.standard_normal(m)
+    d_zz = D(zz)
+    a_dev, b_dev = ks.margins_dev(d_zz.ptr)
+    a_ref, b_ref = cones.margins(zz)
+    assert abs(a_dev - a_ref) <= 1e-10 * max(1.0, abs(a_ref)) and abs(b_dev - b_ref) <= 1e-10 * max(1.0, b_ref)
+    for alpha in (0.0, 0.3):
+        b_dev = ks.compute_barrier_dev(d_z.ptr, d_s.ptr, d_dz.ptr, d_ds.ptr, alpha)
+        b_ref = cones.compute_barrier(z, s, dz, dsv, alpha)
+        assert np.isfinite(b_ref) and abs(b_dev - b_ref) <= 1e-10 * max(1.0, abs(b_ref))
+    sh2 = D(zz)
+    ks.scaled_unit_shift_dev(sh2.ptr, 0.25, True)
+    ref = zz.copy()
+    cones.scaled_unit_shift(ref, 0.25, True)
+    assert np.array_equal(sh2.numpy(), ref)
+    uz, us = D(m), D(m)
+    ks.unit_initialization_dev(uz.ptr, us.ptr)
+    rz, rs = np.zeros(m), np.zeros(m)
+    cones.unit_initialization(rz, rs)
+    assert np.array_equal(uz.numpy(), rz) and np.array_equal(us.numpy(), rs)
+
+
 def test_full_scale_properties_c3(hip):
     """BASELINE config 3 at full size (n = 10^6): too big for the oracle in seconds, so check
     size-independent properties: residual of the refined solution against an independent
@@ -541,10 +603,10 @@ def test_l3_kktsystem_and_residuals(hip, oracle, which):
         assert relerr(a.numpy(), c) <= TOL
 
 
-@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone"])
+@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp"])
 def test_e2e_reference_answers_on_device(hip, oracle, name):
     """the reference's end-to-end known answers (tests/basic_qp.rs:100-117, basic_lp.rs:27-44,
-    basic_socp.rs:54-70, basic_expcone.rs:38-56, basic_powcone.rs:4-47) reached with every L1-L3 operation on the device, and the same
+    basic_socp.rs:54-70, basic_expcone.rs:38-56, basic_powcone.rs:4-47, basic_sdp.rs:29-57) reached with every L1-L3 operation on the device, and the same
     trajectory as the oracle-backed loop"""
     from tests import e2e_problems as E
     from tests import ipm_driver as ipm

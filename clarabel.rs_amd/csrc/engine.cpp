@@ -3,6 +3,8 @@
 // kernel boundaries on that stream (see kernels.hip for the rationale).
 #include "engine.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -35,7 +37,7 @@ template <typename T> int Engine::upload(T **dst, const std::vector<T> &src, siz
     if (n) CHIP_HIP(hipMemcpy(*dst, src.data(), n * sizeof(T), hipMemcpyHostToDevice));
     return CHIP_OK;
 }
-int Engine::upload_lists(DeviceLists &Dl, const LevelLists &L) {
+int Engine::upload_lists(DeviceLists &Dl, const LevelLists &L, int chain_max_w) {
     Dl.t_ptr = L.t_ptr;
     Dl.w_ptr = L.w_ptr;
     Dl.b_ptr = L.b_ptr;
@@ -55,7 +57,7 @@ int Engine::upload_lists(DeviceLists &Dl, const LevelLists &L) {
     Dl.chain_begin.assign((size_t)(nl > 0 ? nl : 0), 0);
     auto narrow = [&](int l) {
         return L.b_ptr[l + 1] == L.b_ptr[l] && L.t_ptr[l + 1] - L.t_ptr[l] <= 2048 &&
-               L.w_ptr[l + 1] - L.w_ptr[l] <= 64;
+               L.w_ptr[l + 1] - L.w_ptr[l] <= chain_max_w;
     };
     for (int l = 0; l < nl;) {
         int e = l;
@@ -173,7 +175,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = alloc(&D, n))) return rc;
     if ((rc = alloc(&Dinv, n))) return rc;
     if ((rc = alloc(&Sx, (size_t)nnzS))) return rc;
-    if ((rc = upload_lists(fac, S.fac))) return rc;
+    if ((rc = upload_lists(fac, S.fac, 2))) return rc; // factor: W columns of a chained level run one after the other
     if ((rc = upload_lists(fwd, S.fwd))) return rc;
     if ((rc = upload_lists(bwd, S.bwd))) return rc;
     if ((rc = upload_lists(smv, S.smv))) return rc;
@@ -273,7 +275,14 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
     dev::scatter_init(stream, Kx, a2l, (int)nnzK, (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                       mb_dev->status);
     dev::bundle_factor(stream, v, bundles); // everything below the cut: one launch
-    for (int l = 0; l < nlevels; l++) {
+    const bool use_chain = std::getenv("CHIP_NO_FACTOR_CHAIN") == nullptr;
+    for (int l = 0; l < nlevels;) {
+        const int e = fac.chain_end[l];
+        if (use_chain && e - l >= 4) { // a chain-like stretch: one single-workgroup launch for levels [l, e)
+            dev::factor_chain(stream, v, fac.t_idx, fac.d_t_ptr, fac.w_idx, fac.d_w_ptr, l, e);
+            l = e;
+            continue;
+        }
         prof_begin(PF_FACTOR_T);
         dev::factor_T(stream, v, fac.T(l));
         prof_end(PF_FACTOR_T);
@@ -283,6 +292,7 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
             dev::factor_B(stream, v, b);
             dev::factor_finalize(stream, v, fac.BR(l));
         }
+        l++;
     }
     dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
     dev::gather_values(stream, Ux, Kx, Umap, (int)nnzU);

@@ -90,7 +90,8 @@ struct Engine {
     int get_symbolic(uint64_t *etree, uint64_t *Lp, uint64_t *Li, uint64_t *lvlptr) const;
     template <typename T> int upload(T **dst, const std::vector<T> &src, size_t n);
     template <typename T> int alloc(T **dst, size_t n);
-    int upload_lists(DeviceLists &D, const LevelLists &L);
+    // chain_max_w: most W rows a level may have to count as "narrow" (runs of narrow levels are chained)
+    int upload_lists(DeviceLists &D, const LevelLists &L, int chain_max_w = 64);
 
     dev::LdlView view() const;
     // enqueue: (optional static regularisation) -> scatter -> level-scheduled factor

@@ -408,6 +408,32 @@ __global__ __launch_bounds__(1024) void k_factor_W(LdlView v, const int *__restr
     factor_col_block(v, cols[blockIdx.x], acc, rows, cst, cw, coff, red, &s_dinv);
 }
 
+// A run of consecutive NARROW top levels of the factorisation (a chain-like stretch of the
+// elimination tree: a banded matrix's separator chain has one or two columns per level) walked by
+// ONE 1024-thread workgroup with __syncthreads() between levels, instead of one ~7 us launch
+// sequence per level.  Columns of a level: thread-per-column ones together, the others one after
+// the other by the whole workgroup.
+__global__ __launch_bounds__(1024) void k_factor_chain(LdlView v, const int *__restrict__ t_idx,
+                                                       const int *__restrict__ t_ptr,
+                                                       const int *__restrict__ w_idx,
+                                                       const int *__restrict__ w_ptr, int l0, int l1) {
+    __shared__ double acc[W_LDS_CAP];
+    __shared__ int rows[W_LDS_CAP];
+    __shared__ int cst[RCAP];
+    __shared__ double cw[RCAP];
+    __shared__ int coff[RCAP + 1];
+    __shared__ double red[16];
+    __shared__ double s_dinv;
+    for (int l = l0; l < l1; ++l) {
+        for (int i = t_ptr[l] + threadIdx.x; i < t_ptr[l + 1]; i += 1024) factor_col_thread(v, t_idx[i]);
+        for (int i = w_ptr[l]; i < w_ptr[l + 1]; ++i) {
+            factor_col_block(v, w_idx[i], acc, rows, cst, cw, coff, red, &s_dinv);
+            __syncthreads();
+        }
+        __syncthreads(); // level l final and visible workgroup-wide
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Subtree bundles: ONE workgroup factors / solves a bundle of complete
 // elimination subtrees start to finish, level by level, with __syncthreads()
@@ -636,21 +662,101 @@ __global__ __launch_bounds__(WG) void k_factor_B(LdlView v, const int *__restric
                                                  const int *__restrict__ cbeg,
                                                  const int *__restrict__ cend, int count) {
     __shared__ double red[16];
+    __shared__ double acc[W_LDS_CAP];
+    __shared__ int rows[W_LDS_CAP];
+    __shared__ int cst[RCAP];
+    __shared__ double cw[RCAP];
+    __shared__ int coff[RCAP + 1];
     if ((int)blockIdx.x >= count) return;
     const int j = crow[blockIdx.x];
-    const int cb = v.Lp[j], ce = v.Lp[j + 1];
+    const int cb = v.Lp[j], ce = v.Lp[j + 1], cn = ce - cb;
+    const int tb = cbeg[blockIdx.x], te = cend[blockIdx.x], tid = threadIdx.x;
     double dpart = 0.0;
-    for (int t = cbeg[blockIdx.x] + threadIdx.x; t < cend[blockIdx.x]; t += WG) {
-        const int k = v.Rcol[t], p = v.Rpos[t];
-        const double ljk = v.Lx[p];
-        const double w = ljk * v.D[k];
-        dpart += ljk * w;
-        const int pe = v.Lp[k + 1];
-        int q = cb;
-        for (int pp = p + 1; pp < pe; ++pp) {
-            q = find_row(v.Li, q, ce, v.Li[pp]);
-            atomicAdd(&v.Lx[q], -(v.Lx[pp] * w));
-            ++q;
+    if (cn >= 24 && cn <= W_LDS_CAP) {
+        // dense-front column: this workgroup folds its slice of the contributions into a private
+        // LDS copy of the column (flattened (contribution, tail entry) pairs, as factor_col_block)
+        // and meets the other slices with ONE global atomic per row at the end
+        for (int q = tid; q < cn; q += WG) {
+            acc[q] = 0.0;
+            rows[q] = v.Li[cb + q];
+        }
+        for (int base = tb; base < te; base += RCAP) {
+            const int nbt = min(RCAP, te - base);
+            __syncthreads();
+            for (int t = tid; t < nbt; t += WG) {
+                const int k = v.Rcol[base + t], p = v.Rpos[base + t];
+                const double ljk = v.Lx[p];
+                const double w = ljk * v.D[k];
+                dpart += ljk * w;
+                cst[t] = p + 1;
+                cw[t] = w;
+                coff[t + 1] = v.Lp[k + 1] - (p + 1);
+            }
+            if (tid == 0) coff[0] = 0;
+            __syncthreads();
+            for (int off = 1; off < nbt; off <<= 1) { // inclusive scan of coff[1..nbt]
+                int add0 = 0, add1 = 0;
+                const int i0 = tid + 1, i1 = tid + 1 + WG;
+                if (i0 <= nbt && i0 - off >= 1) add0 = coff[i0 - off];
+                if (i1 <= nbt && i1 - off >= 1) add1 = coff[i1 - off];
+                __syncthreads();
+                if (i0 <= nbt) coff[i0] += add0;
+                if (i1 <= nbt) coff[i1] += add1;
+                __syncthreads();
+            }
+            const int total = coff[nbt];
+            // four updates per thread in lockstep: the owner searches, then the four (row id, value)
+            // loads, then the slot searches are independent chains -> 4x the loads in flight
+            for (int u0 = tid; u0 < total; u0 += 4 * WG) {
+                int own[4], pp[4], ri[4];
+                double val[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int u = u0 + a * WG;
+                    int lo = 0, hi = nbt;
+                    if (u < total)
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (coff[mid] <= u) lo = mid;
+                            else hi = mid;
+                        }
+                    own[a] = lo;
+                    pp[a] = u < total ? cst[lo] + (u - coff[lo]) : -1;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    ri[a] = pp[a] >= 0 ? v.Li[pp[a]] : 0;
+                    val[a] = pp[a] >= 0 ? v.Lx[pp[a]] * cw[own[a]] : 0.0;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (pp[a] < 0) continue;
+                    int l2 = 0, h2 = cn;
+                    while (l2 < h2) {
+                        const int mid = (l2 + h2) >> 1;
+                        if (rows[mid] < ri[a]) l2 = mid + 1;
+                        else h2 = mid;
+                    }
+                    atomicAdd(&acc[l2], -val[a]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < cn; q += WG)
+            if (acc[q] != 0.0) atomicAdd(&v.Lx[cb + q], acc[q]);
+    } else {
+        for (int t = tb + tid; t < te; t += WG) {
+            const int k = v.Rcol[t], p = v.Rpos[t];
+            const double ljk = v.Lx[p];
+            const double w = ljk * v.D[k];
+            dpart += ljk * w;
+            const int pe = v.Lp[k + 1];
+            int q = cb;
+            for (int pp = p + 1; pp < pe; ++pp) {
+                q = find_row(v.Li, q, ce, v.Li[pp]);
+                atomicAdd(&v.Lx[q], -(v.Lx[pp] * w));
+                ++q;
+            }
         }
     }
     dpart = block_sum(dpart, red);
@@ -939,29 +1045,127 @@ void k_bundle_symv(BundleView bv, const int *__restrict__ Up, const int *__restr
 
 // A run of consecutive NARROW levels (a chain-like stretch of the elimination tree: a handful
 // of rows per level) handled by ONE 1024-thread workgroup that walks the levels with
-// __syncthreads() in between -- ~1 us per level instead of one ~5-9 us launch per level.
+// __syncthreads() in between -- a few us per level instead of one launch per level.  A level
+// is a string of dependent L2 round trips (level pointers -> row ids -> row pointers -> entries
+// -> gathers), so: the level pointers of the whole run sit in LDS, the row id and row pointers of
+// a wavefront group's row on the NEXT level are requested while the current level is computed,
+// few rows share the 16 wavefronts, and every lane keeps 4 entries in flight.
+constexpr int CHAIN_CAP = 4096; // levels per launch (LDS copy of their T / W pointers)
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_chain(GatherArgs a, const int *__restrict__ t_idx,
                                                 const int *__restrict__ t_ptr,
                                                 const int *__restrict__ w_idx,
                                                 const int *__restrict__ w_ptr, int l0, int l1) {
+    __shared__ double part[16];
+    __shared__ int tp[CHAIN_CAP + 1], wp[CHAIN_CAP + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int step = 0; step < l1 - l0; ++step) {
-        const int l = (MODE == FWD) ? l0 + step : l1 - 1 - step;
-        for (int i = t_ptr[l] + tid; i < t_ptr[l + 1]; i += 1024) {
+    const int nlev = l1 - l0; // <= CHAIN_CAP
+    for (int i = tid; i <= nlev; i += 1024) {
+        tp[i] = t_ptr[l0 + i];
+        wp[i] = w_ptr[l0 + i];
+    }
+    __syncthreads();
+    // this wavefront's role on a level with nw W rows: `share` wavefronts per row
+    auto role = [&](int nw, int &share, int &grp, int &sub) {
+        share = 1;
+        while (share < 16 && nw * share * 2 <= 16) share *= 2;
+        grp = wv / share;
+        sub = wv % share;
+    };
+    auto level_at = [&](int step) { return (MODE == FWD) ? step : nlev - 1 - step; };
+    // prefetched row of this wavefront group for the current level: id, first and last+1 slot
+    // ... and the row's own entry (rhs value, times 1/d in the backward sweep): only row r's level
+    // writes out[r], so it can be read a level ahead
+    int nr = -1, nb = 0, ne = 0;
+    double nown = 0.0;
+    auto own_of = [&](int r) { return MODE == BWD ? a.out[r] * a.aux[r] : a.out[r]; };
+    {
+        const int ll = level_at(0), nw = wp[ll + 1] - wp[ll];
+        int share, grp, sub;
+        role(nw, share, grp, sub);
+        if (grp < nw) {
+            nr = w_idx[wp[ll] + grp];
+            nb = a.ptr[nr];
+            ne = a.ptr[nr + 1];
+            nown = own_of(nr);
+        }
+    }
+    for (int step = 0; step < nlev; ++step) {
+        const int ll = level_at(step);
+        const int r0 = nr, b0 = nb, e0 = ne;
+        const double own0 = nown;
+        // request the next level's row id now; its pointers are read at the end of this level
+        int nxt = -1;
+        if (step + 1 < nlev) {
+            const int ln = level_at(step + 1), nwn = wp[ln + 1] - wp[ln];
+            int share, grp, sub;
+            role(nwn, share, grp, sub);
+            if (grp < nwn) nxt = w_idx[wp[ln] + grp];
+        }
+        for (int i = tp[ll] + tid; i < tp[ll + 1]; i += 1024) {
             const int r = t_idx[i];
             double s = 0.0;
             for (int t = a.ptr[r]; t < a.ptr[r + 1]; ++t) s += a.val[t] * a.xin[a.idx[t]];
             store_row<MODE>(a, r, s);
         }
-        for (int i = w_ptr[l] + wv; i < w_ptr[l + 1]; i += 16) {
-            const int r = w_idx[i];
-            double s = 0.0;
-            for (int t = a.ptr[r] + lane; t < a.ptr[r + 1]; t += 64) s += a.val[t] * a.xin[a.idx[t]];
-            s = wave_sum(s);
-            if (lane == 0) store_row<MODE>(a, r, s);
+        const int nw = wp[ll + 1] - wp[ll];
+        if (nw > 0) {
+            int share, grp, sub;
+            role(nw, share, grp, sub);
+            const int ngrp = 16 / share, stride = 64 * share;
+            for (int i0 = 0; i0 < nw; i0 += ngrp) {
+                const int i = i0 + grp;
+                double s = 0.0;
+                int r = -1;
+                if (i < nw) {
+                    int t, e;
+                    if (i0 == 0) {
+                        r = r0;
+                        t = b0;
+                        e = e0;
+                    } else {
+                        r = w_idx[wp[ll] + i];
+                        t = a.ptr[r];
+                        e = a.ptr[r + 1];
+                    }
+                    t += sub * 64 + lane;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    for (; t + 3 * stride < e; t += 4 * stride) {
+                        const int j0 = a.idx[t], j1 = a.idx[t + stride], j2 = a.idx[t + 2 * stride],
+                                  j3 = a.idx[t + 3 * stride];
+                        const double v0 = a.val[t], v1 = a.val[t + stride], v2 = a.val[t + 2 * stride],
+                                     v3 = a.val[t + 3 * stride];
+                        s0 += v0 * a.xin[j0];
+                        s1 += v1 * a.xin[j1];
+                        s2 += v2 * a.xin[j2];
+                        s3 += v3 * a.xin[j3];
+                    }
+                    for (; t < e; t += stride) s0 += a.val[t] * a.xin[a.idx[t]];
+                    s = wave_sum((s0 + s1) + (s2 + s3));
+                }
+                if (share == 1) {
+                    if (lane == 0 && r >= 0) {
+                        if (i0 == 0) a.out[r] = own0 - s;
+                        else store_row<MODE>(a, r, s);
+                    }
+                } else {
+                    if (lane == 0) part[wv] = s;
+                    __syncthreads();
+                    if (lane == 0 && sub == 0 && r >= 0) {
+                        double tot = 0.0;
+                        for (int q = 0; q < share; ++q) tot += part[grp * share + q];
+                        if (i0 == 0) a.out[r] = own0 - tot;
+                        else store_row<MODE>(a, r, tot);
+                    }
+                    __syncthreads();
+                }
+            }
         }
-        __syncthreads(); // level l final and visible workgroup-wide
+        nr = nxt;
+        nb = nxt >= 0 ? a.ptr[nxt] : 0;
+        ne = nxt >= 0 ? a.ptr[nxt + 1] : 0;
+        nown = nxt >= 0 ? own_of(nxt) : 0.0;
+        __syncthreads(); // level final and visible workgroup-wide
     }
 }
 
@@ -2561,11 +2765,20 @@ void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t,
     const int grid = off8 + nbT;
     DISPATCH_MODE(k_gather_merged, grid, a, t.idx, t.count, w.idx, w.count, c.row, c.beg, c.end, c.count, off8)
 }
+void factor_chain(hipStream_t s, const LdlView &v, const int *t_idx, const int *t_ptr, const int *w_idx,
+                  const int *w_ptr, int l0, int l1) {
+    if (l1 > l0) k_factor_chain<<<1, 1024, 0, s>>>(v, t_idx, t_ptr, w_idx, w_ptr, l0, l1);
+}
 void gather_chain(hipStream_t s, GatherMode m, const GatherArgs &a, const int *t_idx, const int *t_ptr,
                   const int *w_idx, const int *w_ptr, int l0, int l1) {
-    if (l1 <= l0) return;
-    if (m == FWD) k_chain<FWD><<<1, 1024, 0, s>>>(a, t_idx, t_ptr, w_idx, w_ptr, l0, l1);
-    else k_chain<BWD><<<1, 1024, 0, s>>>(a, t_idx, t_ptr, w_idx, w_ptr, l0, l1);
+    // at most CHAIN_CAP levels per launch, in sweep order
+    if (m == FWD) {
+        for (int b = l0; b < l1; b += CHAIN_CAP)
+            k_chain<FWD><<<1, 1024, 0, s>>>(a, t_idx, t_ptr, w_idx, w_ptr, b, std::min(l1, b + CHAIN_CAP));
+    } else {
+        for (int e = l1; e > l0; e -= CHAIN_CAP)
+            k_chain<BWD><<<1, 1024, 0, s>>>(a, t_idx, t_ptr, w_idx, w_ptr, std::max(l0, e - CHAIN_CAP), e);
+    }
 }
 void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
     if (!r.count) return;

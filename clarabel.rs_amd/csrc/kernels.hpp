@@ -85,6 +85,9 @@ void gather_W(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 // levels [l0, l1) of a chain-like stretch in ONE single-workgroup launch (FWD ascending, BWD
 // descending); t_idx/w_idx are the FULL list arrays, t_ptr/w_ptr their per-level pointers (device)
+// levels [l0, l1) of a chain-like stretch of the factorisation in ONE single-workgroup launch
+void factor_chain(hipStream_t s, const LdlView &v, const int *t_idx, const int *t_ptr, const int *w_idx,
+                  const int *w_ptr, int l0, int l1);
 void gather_chain(hipStream_t s, GatherMode m, const GatherArgs &a, const int *t_idx, const int *t_ptr,
                   const int *w_idx, const int *w_ptr, int l0, int l1);
 // T + W + B lists of one level in a single launch (B rows still need gather_Bprep first)

@@ -33,6 +33,8 @@ namespace {
 constexpr i32 T_MAX = 32;      // <= T_MAX entries: one thread per row
 constexpr i32 B_MIN = 16384;   // >  B_MIN entries: split over workgroups
 constexpr i32 B_CHUNK = 4096;  // entries per B chunk
+constexpr i64 F_MIN_WORK = 16384;    // factor: a column with more (contribution, tail entry) updates than this
+constexpr i64 F_CHUNK_WORK = 4096;   // ... is split over workgroups in chunks of about this many updates
 constexpr i32 FAC_T_ROW = 8;   // factor: thread-per-column if contributions <= this
 constexpr i32 FAC_T_COL = 48;  // ... and column length <= this
 // subtree bundles (one workgroup each; the vector slice of a bundle is staged in LDS)
@@ -106,6 +108,24 @@ struct ListBuilder {
             L.b_row.push_back(r);
             L.b_beg.push_back((i32)b);
             L.b_end.push_back((i32)std::min<i64>(end, b + B_CHUNK));
+        }
+    }
+    // chunks of a column of the factorisation balanced by WORK: contribution t of column j updates
+    // tail(t) = Lp[k+1] - (Rpos[t]+1) entries; a chunk closes at B_CHUNK contributions or
+    // F_CHUNK_WORK updates, whichever comes first
+    void add_B_work(i32 r, i64 beg, i64 end, const std::vector<i32> &Rcol, const std::vector<i32> &Rpos,
+                    const std::vector<i32> &Lp) {
+        L.br_idx.push_back(r);
+        i64 b = beg, work = 0;
+        for (i64 t = beg; t < end; t++) {
+            work += Lp[Rcol[t] + 1] - (Rpos[t] + 1) + 1;
+            if (t + 1 == end || t + 1 - b >= B_CHUNK || work >= F_CHUNK_WORK) {
+                L.b_row.push_back(r);
+                L.b_beg.push_back((i32)b);
+                L.b_end.push_back((i32)(t + 1));
+                b = t + 1;
+                work = 0;
+            }
         }
     }
     void close_level() {
@@ -449,8 +469,12 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         for (i32 l = 0; l < nlevels; l++) {
             for (i32 j = lvlptr[l]; j < lvlptr[l + 1]; j++) {
                 const i32 rj = S.Rp[j + 1] - S.Rp[j], cj = S.Lp[j + 1] - S.Lp[j];
-                // factor: column j gathers rj contributions into cj targets
-                if (rj > B_MIN) fac.add_B(j, S.Rp[j], S.Rp[j + 1]);
+                // factor: column j gathers rj contributions into cj targets; heavy columns (many
+                // contributions, or long tails: dense fronts) are spread over workgroups
+                i64 work = 0;
+                if (rj > FAC_T_ROW && (i64)rj * cj > F_MIN_WORK)
+                    for (i32 t = S.Rp[j]; t < S.Rp[j + 1]; t++) work += S.Lp[S.Rcol[t] + 1] - (S.Rpos[t] + 1);
+                if (rj > B_MIN || work > F_MIN_WORK) fac.add_B_work(j, S.Rp[j], S.Rp[j + 1], S.Rcol, S.Rpos, S.Lp);
                 else if (rj <= FAC_T_ROW && cj <= FAC_T_COL) fac.add_T(j);
                 else fac.add_W(j);
                 // forward substitution: row j of L

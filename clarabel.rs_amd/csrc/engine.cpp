@@ -181,7 +181,6 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = upload_lists(smv, S.smv))) return rc;
     {
         int *bp = nullptr, *lp = nullptr, *lv = nullptr;
-        if ((rc = upload(&Ls, S.Ls, S.Ls.size()))) return rc;
         if ((rc = upload(&bp, S.bundle_ptr, S.bundle_ptr.size()))) return rc;
         if ((rc = upload(&lp, S.blvl_ptr, S.blvl_ptr.size()))) return rc;
         if ((rc = upload(&lv, S.blvl, S.blvl.size()))) return rc;
@@ -207,7 +206,6 @@ dev::LdlView Engine::view() const {
     v.nnzL = (int)nnzL;
     v.Lp = Lp;
     v.Li = Li;
-    v.Ls = Ls;
     v.Rp = Rp;
     v.Rcol = Rcol;
     v.Rpos = Rpos;

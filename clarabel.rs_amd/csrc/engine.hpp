@@ -53,7 +53,6 @@ struct Engine {
     int N = 0, nlevels = 0;
     i64 nnzK = 0, nnzL = 0, nnzS = 0;
     // symbolic (device)
-    int *Ls = nullptr;
     int *a2l = nullptr, *Lp = nullptr, *Li = nullptr, *Rp = nullptr, *Rcol = nullptr, *Rpos = nullptr,
         *Tpos = nullptr, *perm = nullptr, *iperm = nullptr, *Sp = nullptr, *Scol = nullptr, *Smap = nullptr,
         *Up = nullptr, *Ucol = nullptr, *Umap = nullptr;

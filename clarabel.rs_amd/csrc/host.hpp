@@ -68,9 +68,6 @@ struct Symbolic {
     std::vector<i32> bundle_ptr;      // nb + 1
     std::vector<i32> blvl_ptr, blvl;  // per bundle: boundaries of its levels (absolute node ids)
     i32 max_bundle_nodes = 0;
-    // per column j: Ls[j] = first slot of column j whose row is a TOP node (rows ascend and the top is
-    // numbered last, so the top entries are the tail of the column); Ls[j] = Lp[j+1] if none
-    std::vector<i32> Ls;
     i32 nlevels = 0;                  // number of TOP levels
     std::vector<i32> lvlptr;
     // K for the residual e = b - K x, permuted numbering; *map = index into the caller's

@@ -487,16 +487,20 @@ __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv)
     }
 }
 
-// in-bundle part of one row (forward: row of L; backward: column of L without its top tail),
-// strided over `stride` threads starting at `first`; xs = the bundle's slice of x in LDS
+// one row (forward: row of L, all inside the bundle; backward: column of L, ancestors inside the
+// bundle from LDS, top ancestors -- final before the launch -- from x), strided over `stride`
+// threads starting at `first`; xs = the bundle's slice of x in LDS
 template <bool FWDMODE>
-__device__ __forceinline__ double bundle_row_dot(const LdlView &v, const double *xs, int s0, int r, int first,
-                                                 int stride) {
+__device__ __forceinline__ double bundle_row_dot(const LdlView &v, const double *xs, const double *x, int s0,
+                                                 int s1, int r, int first, int stride) {
     double s = 0.0;
     if (FWDMODE) {
         for (int t = v.Rp[r] + first; t < v.Rp[r + 1]; t += stride) s += v.Rx[t] * xs[v.Rcol[t] - s0];
     } else {
-        for (int q = v.Lp[r] + first; q < v.Ls[r]; q += stride) s += v.Lx[q] * xs[v.Li[q] - s0];
+        for (int q = v.Lp[r] + first; q < v.Lp[r + 1]; q += stride) {
+            const int i = v.Li[q];
+            s += v.Lx[q] * (i < s1 ? xs[i - s0] : x[i]);
+        }
     }
     return s;
 }
@@ -505,29 +509,25 @@ __device__ __forceinline__ double bundle_row_dot(const LdlView &v, const double 
 // sweep of a bundle with its slice of x staged in LDS, one __syncthreads()-separated level at a
 // time.  A workgroup's sweep is a chain of dependent global loads per level (row pointers ->
 // entries -> gathers), so the number of sequential round trips is what is minimised:
-//  * backward: x_j = x_j / d_j - sum_i l_ij x_i (qdldl.rs:737-752).  The scaling by 1/d_j and the
-//    contributions of TOP ancestors (final in x before this kernel starts; they are the tail
-//    [Ls[j], Lp[j+1]) of each column) are applied while staging, for all rows at once; the level
-//    loop then only gathers from LDS.
+//  * backward: x_j = x_j / d_j - sum_i l_ij x_i (qdldl.rs:737-752).  The scaling by 1/d_j is
+//    applied while staging (coalesced, off the per-level path).  (Folding the top-ancestor tail of
+//    every column into the staging pass as well was measured and dropped: the tails share cache
+//    lines with the in-bundle entries, so L was streamed twice -- 266 MB instead of 160 MB.)
 //  * the row pointers of the NEXT level's first sweep are requested before the current level is
 //    processed.
 //  * thin rows: two rows per thread, FOUR entries of each row per shot -- rows of <= 4 entries
 //    (nearly all rows of a block-arrow KKT) cost one round trip instead of one per entry.
 constexpr int ESHOT = 4;
 template <bool FWDMODE>
-__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restrict__ addv) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *xs = (double *)smem;
-    __shared__ double red[16];
-    __shared__ int fat[FATCAP];
-    __shared__ int nfat;
+__device__ __forceinline__ void bundle_solve_body(const LdlView &v, const BundleView &bv, double *x,
+                                                  const double *__restrict__ addv, double *xs, double *red,
+                                                  int *fat, int &nfat) {
     const int b = blockIdx.x;
     const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
     const int *lv = bv.blvl + bv.blvl_ptr[b];
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
     const int *pbeg = FWDMODE ? v.Rp : v.Lp;          // first slot of a row
-    const int *pend = FWDMODE ? v.Rp + 1 : v.Ls;      // one past its last in-bundle slot
+    const int *pend = FWDMODE ? v.Rp + 1 : v.Lp + 1;  // one past its last slot
     const int *cidx = FWDMODE ? v.Rcol : v.Li;
     const double *cval = FWDMODE ? v.Rx : v.Lx;
     const int nsteps = FWDMODE ? nl - 1 : nl;         // forward: level 0 has no descendants
@@ -548,33 +548,12 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
     if (FWDMODE) {
         for (int i = threadIdx.x; i < nloc; i += BWG) xs[i] = x[s0 + i];
     } else {
-        // staging with 1/d_j and the top-ancestor tail folded in, two rows per thread in lockstep
-        for (int i0 = threadIdx.x; i0 < nloc; i0 += 2 * BWG) {
-            int qb[2], qe[2];
-            double val[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = i0 + u * BWG;
-                const bool ok = i < nloc;
-                qb[u] = ok ? v.Ls[s0 + i] : 0;
-                qe[u] = ok ? v.Lp[s0 + i + 1] : 0;
-                val[u] = ok ? x[s0 + i] * v.Dinv[s0 + i] : 0.0;
-            }
-            const int maxlen = max(qe[0] - qb[0], qe[1] - qb[1]);
-            for (int k = 0; k < maxlen; ++k) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (qb[u] + k < qe[u]) val[u] -= v.Lx[qb[u] + k] * x[v.Li[qb[u] + k]];
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (i0 + u * BWG < nloc) xs[i0 + u * BWG] = val[u];
-        }
+        for (int i = threadIdx.x; i < nloc; i += BWG) xs[i] = x[s0 + i] * v.Dinv[s0 + i];
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // one row by the whole workgroup; the result lands in xs[r - s0] (visible after a barrier)
     auto coop_row = [&](int r) {
-        double s = bundle_row_dot<FWDMODE>(v, xs, s0, r, threadIdx.x, BWG);
+        double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, threadIdx.x, BWG);
         s = block_sum(s, red);
         if (threadIdx.x == 0) xs[r - s0] -= s;
     };
@@ -627,7 +606,8 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int e = 0; e < ESHOT; ++e)
-                        if (ii[u][e] >= 0) sum[u] += vv[u][e] * xs[ii[u][e] - s0];
+                        if (ii[u][e] >= 0)
+                            sum[u] += vv[u][e] * ((FWDMODE || ii[u][e] < s1) ? xs[ii[u][e] - s0] : x[ii[u][e]]);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -641,7 +621,7 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
         } else {
             for (int f = wv; f < nf; f += BWG / 64) {
                 const int r = fat[f];
-                double s = bundle_row_dot<FWDMODE>(v, xs, s0, r, lane, 64);
+                double s = bundle_row_dot<FWDMODE>(v, xs, x, s0, s1, r, lane, 64);
                 s = wave_sum(s);
                 if (lane == 0) xs[r - s0] -= s;
             }
@@ -653,6 +633,15 @@ void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restric
         for (int i = threadIdx.x; i < nloc; i += BWG) x[s0 + i] = xs[i] + addv[s0 + i];
     else
         for (int i = threadIdx.x; i < nloc; i += BWG) x[s0 + i] = xs[i];
+}
+template <bool FWDMODE>
+__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restrict__ addv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[16];
+    __shared__ int fat[FATCAP];
+    __shared__ int nfat;
+    bundle_solve_body<FWDMODE>(v, bv, x, addv, (double *)smem, red, fat, nfat);
 }
 
 // B: a column with a huge row count (> 16384 contributions).  Each workgroup
@@ -960,13 +949,10 @@ __device__ __forceinline__ void lds_scatter_add(double *acc, int tgt, double val
 // bundles of config 3 into a second round).  Two rows per thread, SSHOT entries of each per shot:
 // rows of <= SSHOT entries cost one round trip.  ||e||inf of the bundle is folded into the slots.
 constexpr int SSHOT = 3; // entries of a row per shot (registers: 2 rows x SSHOT x (index, value, x address))
-__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_bundle_symv(BundleView bv, const int *__restrict__ Up, const int *__restrict__ Ucol,
-                   const double *__restrict__ Ux, const double *__restrict__ x,
-                   const double *__restrict__ b, double *e, unsigned long long *nrm, int *nanflag) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *es = (double *)smem;
-    __shared__ double red[16];
+__device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int *__restrict__ Up,
+                                                 const int *__restrict__ Ucol, const double *__restrict__ Ux,
+                                                 const double *x, const double *__restrict__ b, double *e,
+                                                 unsigned long long *nrm, int *nanflag, double *es, double *red) {
     const int bid = blockIdx.x;
     const int s0 = bv.bundle_ptr[bid], s1 = bv.bundle_ptr[bid + 1], nloc = s1 - s0;
     const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
@@ -1042,7 +1028,14 @@ void k_bundle_symv(BundleView bv, const int *__restrict__ Up, const int *__restr
         if (threadIdx.x == 0) fold_norm(nrm, nanflag, m, false, bid);
     }
 }
-
+__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bundle_symv(BundleView bv, const int *__restrict__ Up, const int *__restrict__ Ucol,
+                   const double *__restrict__ Ux, const double *__restrict__ x,
+                   const double *__restrict__ b, double *e, unsigned long long *nrm, int *nanflag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[16];
+    bundle_symv_body(bv, Up, Ucol, Ux, x, b, e, nrm, nanflag, (double *)smem, red);
+}
 // A run of consecutive NARROW levels (a chain-like stretch of the elimination tree: a handful
 // of rows per level) handled by ONE 1024-thread workgroup that walks the levels with
 // __syncthreads() in between -- a few us per level instead of one launch per level.  A level

@@ -12,7 +12,6 @@ struct LdlView {
     int N;
     int nnzL;
     const int *Lp, *Li;          // L by columns, ascending rows
-    const int *Ls;               // per column: first slot whose row is a top node (tail of the column)
     const int *Rp, *Rcol, *Rpos; // L by rows, Rpos = CSC slot of the entry
     const int *Tpos;             // CSC slot -> CSR slot
     double *Lx, *Rx;             // values in CSC / CSR order

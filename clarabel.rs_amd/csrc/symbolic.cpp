@@ -362,11 +362,6 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 S.Tpos[q] = t;
             }
     }
-    S.Ls.assign((size_t)n + 1, 0);
-    for (i32 j = 0; j < n; j++) {
-        const i32 *b = S.Li.data() + S.Lp[j], *e = S.Li.data() + S.Lp[j + 1];
-        S.Ls[j] = (i32)(std::lower_bound(b, e, S.NF) - S.Li.data());
-    }
     // ---- K.nzval -> (Lx | D) scatter map ------------------------------------
     S.a2l.resize((size_t)nnzK + 1);
     for (i64 c = 0; c < n; c++) {

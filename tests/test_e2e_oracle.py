@@ -41,3 +41,15 @@ def test_kktsystem_identities(oracle):
     mus = [t[0] for t in tr]
     assert all(b < a for a, b in zip(mus, mus[1:]))  # mu decreases monotonically on this problem
     assert tr[-1][3] < 1e-8 and tr[-1][4] < 1e-8
+
+
+def test_json_fixture_hs35(oracle):
+    """the reference's on-disk problem format (default/json.rs:13-21; it ships HS35 as
+    examples/data/hs35.json): Hock-Schittkowski 35, optimum x = (4/3, 7/9, 4/9), f = 1/9"""
+    import os
+    from tests import json_problem
+    pr = json_problem.load(os.path.join(os.path.dirname(__file__), "golden", "hs35.json"))
+    out = _run(oracle, pr)
+    assert out["status"] == "Solved"
+    assert np.linalg.norm(out["x"] - np.array([4.0 / 3.0, 7.0 / 9.0, 4.0 / 9.0])) <= 1e-6
+    assert abs(out["obj_val"] + 9.0 - 1.0 / 9.0) <= 1e-6

@@ -632,3 +632,15 @@ def test_e2e_sparse_soc_on_device(hip):
     pr = E.basic_socp(sparse_soc=True)
     be = ipm.HipBackend(hip, pr["n"], pr["m"], pr["P"], pr["A"], pr["q"], pr["b"], pr["cones"])
     assert ipm.solve(be, pr["cones"], pr["q"], pr["b"])["status"] == "Solved"
+
+
+def test_json_fixture_hs35_on_device(hip):
+    import os
+    from tests import ipm_driver as ipm
+    from tests import json_problem
+    pr = json_problem.load(os.path.join(os.path.dirname(__file__), "golden", "hs35.json"))
+    be = ipm.HipBackend(hip, pr["n"], pr["m"], pr["P"], pr["A"], pr["q"], pr["b"], pr["cones"])
+    out = ipm.solve(be, pr["cones"], pr["q"], pr["b"])
+    assert out["status"] == "Solved"
+    assert np.linalg.norm(out["x"] - np.array([4.0 / 3.0, 7.0 / 9.0, 4.0 / 9.0])) <= 1e-6
+    assert abs(out["obj_val"] + 9.0 - 1.0 / 9.0) <= 1e-6

@@ -144,6 +144,10 @@ typedef struct {
     double alpha;
     double Hs3[6], Hdual[6], grad3[3], zc[3];
     int ns_valid; /* Hs3 computed by update_scaling (else get_Hs leaves the caller's values) */
+    /* GenPow (genpowcone.rs:10-47): alpha[dim1]; p[numel], q[dim1], r[dim2], d1[dim1], d2, grad[numel], z */
+    double *ga, *gp, *gq, *gr, *gd1, *ggrad, *gz;
+    double gd2, gmu, gpsi;
+    int gvalid;
 } orc_cone;
 
 typedef struct {
@@ -161,6 +165,8 @@ void orc_cones_free(orc_cones *cs) {
     if (!cs) return;
     for (int64_t i = 0; i < cs->ncones; i++) {
         free(cs->c[i].w); free(cs->c[i].lam); free(cs->c[i].u); free(cs->c[i].v);
+        free(cs->c[i].ga); free(cs->c[i].gp); free(cs->c[i].gq); free(cs->c[i].gr); free(cs->c[i].gd1);
+        free(cs->c[i].ggrad); free(cs->c[i].gz);
     }
     free(cs->c);
     free(cs);
@@ -216,6 +222,18 @@ orc_cones *orc_cones_new_ex(int64_t ncones, const int32_t *tags, const int64_t *
             c->u = (double *)calloc((size_t)c->numel, sizeof(double));
             c->v = (double *)calloc((size_t)c->numel, sizeof(double));
             c->d = 1.0;
+        }
+        if (c->tag == CONE_GENPOW) {
+            c->ga = (double *)calloc((size_t)c->dim + 1, sizeof(double));
+            c->gq = (double *)calloc((size_t)c->dim + 1, sizeof(double));
+            c->gd1 = (double *)calloc((size_t)c->dim + 1, sizeof(double));
+            c->gr = (double *)calloc((size_t)c->dim2 + 1, sizeof(double));
+            c->gp = (double *)calloc((size_t)c->numel + 1, sizeof(double));
+            c->ggrad = (double *)calloc((size_t)c->numel + 1, sizeof(double));
+            c->gz = (double *)calloc((size_t)c->numel + 1, sizeof(double));
+            for (int64_t k = 0; k < c->dim; k++) c->ga[k] = 1.0 / (double)c->dim; /* until set_genpow_alpha */
+            c->gmu = 1.0;
+            c->gpsi = (double)c->dim;
         }
     }
     cs->numel = cstart;
@@ -469,6 +487,125 @@ static void ns3_update_Hs(orc_cone *c, const double *s, const double *z, double 
     }
 }
 
+/* ---- Generalised power cone (genpowcone.rs) -------------------------------------------------- */
+/* GenPowerCone::new (genpowcone.rs:21-63): the powers alpha[dim1] of cone i; psi = 1 / sum alpha^2 */
+int orc_cones_set_genpow_alpha(orc_cones *cs, int64_t i, const double *alpha) {
+    if (i < 0 || i >= cs->ncones || cs->c[i].tag != CONE_GENPOW) return -1;
+    orc_cone *c = &cs->c[i];
+    double sq = 0.0;
+    for (int64_t k = 0; k < c->dim; k++) { c->ga[k] = alpha[k]; sq += alpha[k] * alpha[k]; }
+    c->gpsi = 1.0 / sq;
+    return 0;
+}
+/* genpowcone.rs:361-401 */
+static void genpow_update_dual_grad_H(orc_cone *c, const double *z) {
+    const int64_t d1n = c->dim, d2n = c->dim2;
+    double phi = 1.0;
+    for (int64_t k = 0; k < d1n; k++) phi = phi * pow(z[k] / c->ga[k], 2.0 * c->ga[k]);
+    double norm2w = 0.0;
+    for (int64_t k = 0; k < d2n; k++) norm2w += z[d1n + k] * z[d1n + k];
+    const double zeta = phi - norm2w;
+    double *tau = c->gq;
+    for (int64_t k = 0; k < d1n; k++) {
+        tau[k] = 2.0 * c->ga[k] / z[k];
+        c->ggrad[k] = -tau[k] * phi / zeta - (1.0 - c->ga[k]) / z[k];
+    }
+    for (int64_t k = 0; k < d2n; k++) c->ggrad[d1n + k] = (2.0 / zeta) * z[d1n + k];
+    const double p0 = sqrt(phi * (phi + norm2w) / 2.0);
+    const double p1 = -2.0 * phi / p0;
+    const double q0 = sqrt(zeta * phi / 2.0);
+    const double r1 = 2.0 * sqrt(zeta / (phi + norm2w));
+    for (int64_t k = 0; k < d1n; k++)
+        c->gd1[k] = tau[k] * phi / (zeta * z[k]) + (1.0 - c->ga[k]) / (z[k] * z[k]);
+    c->gd2 = 2.0 / zeta;
+    for (int64_t k = 0; k < d1n; k++) c->gp[k] = (p0 / zeta) * tau[k];
+    for (int64_t k = 0; k < d2n; k++) c->gp[d1n + k] = (p1 / zeta) * z[d1n + k];
+    for (int64_t k = 0; k < d1n; k++) c->gq[k] *= q0 / zeta;
+    for (int64_t k = 0; k < d2n; k++) c->gr[k] = (r1 / zeta) * z[d1n + k];
+}
+/* genpowcone.rs:279-317 */
+static int genpow_is_primal_feasible(const orc_cone *c, const double *s) {
+    for (int64_t k = 0; k < c->dim; k++) if (!(s[k] > 0.0)) return 0;
+    double res = 0.0;
+    for (int64_t k = 0; k < c->dim; k++) res = res + 2.0 * c->ga[k] * logsafe(s[k]);
+    double sq = 0.0;
+    for (int64_t k = 0; k < c->dim2; k++) sq += s[c->dim + k] * s[c->dim + k];
+    return exp(res) - sq > 0.0;
+}
+static int genpow_is_dual_feasible(const orc_cone *c, const double *z) {
+    for (int64_t k = 0; k < c->dim; k++) if (!(z[k] > 0.0)) return 0;
+    double res = 0.0;
+    for (int64_t k = 0; k < c->dim; k++) res = res + 2.0 * c->ga[k] * logsafe(z[k] / c->ga[k]);
+    double sq = 0.0;
+    for (int64_t k = 0; k < c->dim2; k++) sq += z[c->dim + k] * z[c->dim + k];
+    return exp(res) - sq > 0.0;
+}
+/* genpowcone.rs:333-356 */
+static double genpow_barrier_dual(const orc_cone *c, const double *z) {
+    double res = 0.0;
+    for (int64_t k = 0; k < c->dim; k++) res += 2.0 * c->ga[k] * logsafe(z[k] / c->ga[k]);
+    double sq = 0.0;
+    for (int64_t k = 0; k < c->dim2; k++) sq += z[c->dim + k] * z[c->dim + k];
+    res = exp(res) - sq;
+    double barrier = -logsafe(res);
+    for (int64_t k = 0; k < c->dim; k++) barrier -= logsafe(z[k]) * (1.0 - c->ga[k]);
+    return barrier;
+}
+/* genpowcone.rs:409-485 (gradient_primal, _newton_raphson_genpowcone; nonsymmetric_common.rs:193-219).
+ * NB the reference scales the w-part of the gradient with data.r (the dual-side vector), as written
+ * at genpowcone.rs:427; restated as is */
+static void genpow_gradient_primal(const orc_cone *c, double *g, const double *s) {
+    const int64_t d1n = c->dim, d2n = c->dim2;
+    const double eps = 2.220446049250313e-16;
+    double phi = 1.0;
+    for (int64_t k = 0; k < d1n; k++) phi = phi * pow(s[k], 2.0 * c->ga[k]);
+    const double *pv = s, *rv = s + d1n;
+    const double norm_r = orc_norm2(rv, d2n);
+    if (norm_r > eps) {
+        const double psi = c->gpsi;
+        double x = -(1.0 / norm_r) + (psi * norm_r + sqrt((phi / norm_r / norm_r + psi * psi - 1.0) * phi)) /
+                                         (phi - norm_r * norm_r);
+        for (int iter = 0; iter < 100; iter++) {
+            double dfdx = -(2.0 * x + 2.0 / norm_r) / (x * x + 2.0 * x / norm_r);
+            for (int64_t k = 0; k < d1n; k++)
+                dfdx = dfdx + 2.0 * c->ga[k] * norm_r / (norm_r * x + (1.0 + c->ga[k]) / c->ga[k]);
+            double f = -logsafe(2.0 * x / norm_r + x * x);
+            for (int64_t k = 0; k < d1n; k++)
+                f = f + 2.0 * c->ga[k] * (logsafe(x * norm_r + (1.0 + c->ga[k]) / c->ga[k]) - logsafe(pv[k]));
+            const double dx = -f / dfdx;
+            if (dx < eps || fabs(dx / x) < sqrt(eps) || fabs(dfdx) < eps) break;
+            x += dx;
+        }
+        const double g1 = x;
+        for (int64_t k = 0; k < d2n; k++) g[d1n + k] = (g1 / norm_r) * c->gr[k];
+        for (int64_t k = 0; k < d1n; k++) g[k] = -(1.0 + c->ga[k] + c->ga[k] * g1 * norm_r) / pv[k];
+    } else {
+        for (int64_t k = 0; k < d2n; k++) g[d1n + k] = 0.0;
+        for (int64_t k = 0; k < d1n; k++) g[k] = -(1.0 + c->ga[k]) / pv[k];
+    }
+}
+static double genpow_barrier_primal(const orc_cone *c, const double *s) {
+    double *g = (double *)malloc((size_t)(c->numel + 1) * sizeof(double));
+    genpow_gradient_primal(c, g, s);
+    for (int64_t k = 0; k < c->numel; k++) g[k] = -g[k];
+    const double out = -genpow_barrier_dual(c, g) - (double)(c->dim + 1);
+    free(g);
+    return out;
+}
+static double genpow_backtrack(const orc_cone *c, const double *dq, const double *q, double a_init, double a_min,
+                               double step, int dual) {
+    double alpha = a_init;
+    double *w = (double *)malloc((size_t)(c->numel + 1) * sizeof(double));
+    for (;;) {
+        for (int64_t i = 0; i < c->numel; i++) w[i] = 1.0 * q[i] + alpha * dq[i];
+        if (dual ? genpow_is_dual_feasible(c, w) : genpow_is_primal_feasible(c, w)) break;
+        alpha *= step;
+        if (alpha < a_min) { alpha = 0.0; break; }
+    }
+    free(w);
+    return alpha;
+}
+
 /* compositecone.rs:226-243 update_scaling (Zero/NN/SOC only; other cone types
  * keep whatever Hs the caller stored with orc_kkt_set_hs_override) */
 int orc_cones_update_scaling_ex(orc_cones *cs, const double *s, const double *z, double mu, int strategy);
@@ -492,6 +629,11 @@ int orc_cones_update_scaling_ex(orc_cones *cs, const double *s, const double *z,
             ns3_update_Hs(c, si, zi, mu, strategy);
             c->zc[0] = zi[0]; c->zc[1] = zi[1]; c->zc[2] = zi[2];
             c->ns_valid = 1;
+        } else if (c->tag == CONE_GENPOW) { /* genpowcone.rs:141-157 */
+            genpow_update_dual_grad_H(c, zi);
+            c->gmu = mu;
+            memcpy(c->gz, zi, (size_t)c->numel * sizeof(double));
+            c->gvalid = 1;
         }
     }
     return 1;
@@ -525,6 +667,9 @@ void orc_cones_get_Hs(const orc_cones *cs, double *Hs) {
         }
         else if ((c->tag == CONE_EXP || c->tag == CONE_POW) && c->ns_valid) { /* expcone.rs:130-133 */
             for (int64_t k = 0; k < 6; k++) blk[k] = c->Hs3[k];
+        } else if (c->tag == CONE_GENPOW && c->gvalid) { /* genpowcone.rs:163-171 */
+            for (int64_t k = 0; k < c->dim; k++) blk[k] = c->gmu * c->gd1[k];
+            for (int64_t k = 0; k < c->dim2; k++) blk[c->dim + k] = c->gmu * c->gd2;
         }
         /* other cone types: left untouched (caller-provided) */
     }
@@ -549,6 +694,13 @@ void orc_cones_mul_Hs(const orc_cones *cs, double *y, const double *x) {
             for (int64_t k = 0; k < c->numel; k++) yi[k] *= e2;
         } else if (c->tag == CONE_EXP || c->tag == CONE_POW) { /* expcone.rs:135-137 */
             sym3_mul(c->Hs3, yi, xi);
+        } else if (c->tag == CONE_GENPOW) { /* genpowcone.rs:173-193 */
+            const int64_t d1n = c->dim, d2n = c->dim2;
+            const double cp = dotp(c->gp, xi, c->numel), cq = dotp(c->gq, xi, d1n), cr = dotp(c->gr, xi + d1n, d2n);
+            for (int64_t k = 0; k < d1n; k++) yi[k] = c->gd1[k] * xi[k] - cq * c->gq[k];
+            for (int64_t k = 0; k < d2n; k++) yi[d1n + k] = c->gd2 * xi[d1n + k] - cr * c->gr[k];
+            for (int64_t k = 0; k < c->numel; k++) yi[k] = cp * c->gp[k] + 1.0 * yi[k];
+            for (int64_t k = 0; k < c->numel; k++) yi[k] *= c->gmu;
         }
     }
 }
@@ -740,8 +892,8 @@ void orc_cones_affine_ds(const orc_cones *cs, double *ds, const double *s) {
             for (int64_t k = 0; k < c->numel; k++) d[k] = c->lam[k] * c->lam[k];
         } else if (c->tag == CONE_SOC) {
             soc_circ_op(d, c->lam, c->lam, c->numel);
-        } else if (c->tag == CONE_EXP || c->tag == CONE_POW) {
-            for (int k = 0; k < 3; k++) d[k] = s[c->cone_start + k];
+        } else if (c->tag == CONE_EXP || c->tag == CONE_POW || c->tag == CONE_GENPOW) { /* genpowcone.rs:195-197 */
+            for (int64_t k = 0; k < c->numel; k++) d[k] = s[c->cone_start + k];
         }
     }
 }
@@ -773,6 +925,8 @@ void orc_cones_combined_ds_shift(const orc_cones *cs, double *shift, double *ste
             if (c->tag == CONE_EXP) exp_higher_correction(c, eta, dsv, dz);
             else pow_higher_correction(c, eta, dsv, dz);
             for (int k = 0; k < 3; k++) sh[k] = c->grad3[k] * sigma_mu - eta[k];
+        } else if (c->tag == CONE_GENPOW) { /* genpowcone.rs:199-204: no higher-order correction */
+            for (int64_t k = 0; k < n; k++) sh[k] = c->ggrad[k] * sigma_mu;
         }
     }
 }
@@ -800,8 +954,8 @@ void orc_cones_ds_from_dz_offset(const orc_cones *cs, double *out, const double 
             for (int64_t k = 1; k < n; k++) o[k] += c->eta * (d[k] + w1d1 / (1.0 + c->w[0]) * c->w[k]);
             double rl = 1.0 / c->lam[0];
             for (int64_t k = 0; k < n; k++) o[k] *= rl;
-        } else if (c->tag == CONE_EXP || c->tag == CONE_POW) { /* expcone.rs:144-146 */
-            for (int k = 0; k < 3; k++) o[k] = d[k];
+        } else if (c->tag == CONE_EXP || c->tag == CONE_POW || c->tag == CONE_GENPOW) { /* expcone.rs:144-146 */
+            for (int64_t k = 0; k < n; k++) o[k] = d[k];
         }
     }
 }
@@ -838,7 +992,7 @@ double orc_cones_step_length_ex(const orc_cones *cs, const double *dz, const dou
         const double *dzi = dz + c->cone_start, *dsi = ds + c->cone_start;
         const double *zi = z + c->cone_start, *si = s + c->cone_start;
         double az = alpha, as = alpha;
-        if (c->tag == CONE_EXP || c->tag == CONE_POW) { all_symmetric = 0; continue; }
+        if (c->tag == CONE_EXP || c->tag == CONE_POW || c->tag == CONE_GENPOW) { all_symmetric = 0; continue; }
         if (c->tag == CONE_NONNEG) {
             for (int64_t k = 0; k < c->numel; k++) {
                 if (dzi[k] < 0.0) { double t = -zi[k] / dzi[k]; az = az < t ? az : t; }
@@ -856,9 +1010,15 @@ double orc_cones_step_length_ex(const orc_cones *cs, const double *dz, const dou
         alpha = alpha < ceilv ? alpha : ceilv;
         for (int64_t i = 0; i < cs->ncones; i++) {
             const orc_cone *c = &cs->c[i];
-            if (c->tag != CONE_EXP && c->tag != CONE_POW) continue;
-            double az = ns3_backtrack(c, dz + c->cone_start, z + c->cone_start, alpha, alpha_min, backtrack_step, 1);
-            double as = ns3_backtrack(c, ds + c->cone_start, s + c->cone_start, alpha, alpha_min, backtrack_step, 0);
+            if (c->tag != CONE_EXP && c->tag != CONE_POW && c->tag != CONE_GENPOW) continue;
+            double az, as;
+            if (c->tag == CONE_GENPOW) { /* genpowcone.rs:210-233 */
+                az = genpow_backtrack(c, dz + c->cone_start, z + c->cone_start, alpha, alpha_min, backtrack_step, 1);
+                as = genpow_backtrack(c, ds + c->cone_start, s + c->cone_start, alpha, alpha_min, backtrack_step, 0);
+            } else {
+                az = ns3_backtrack(c, dz + c->cone_start, z + c->cone_start, alpha, alpha_min, backtrack_step, 1);
+                as = ns3_backtrack(c, ds + c->cone_start, s + c->cone_start, alpha, alpha_min, backtrack_step, 0);
+            }
             double mn = az < as ? az : as;
             alpha = alpha < mn ? alpha : mn;
         }
@@ -916,6 +1076,13 @@ double orc_cones_compute_barrier(const orc_cones *cs, const double *z, const dou
             }
             if (c->tag == CONE_EXP) barrier += exp_barrier_dual(cz) + exp_barrier_primal(csv);
             else barrier += pow_barrier_dual(c, cz) + pow_barrier_primal(c, csv);
+        } else if (c->tag == CONE_GENPOW) { /* genpowcone.rs:235-250 */
+            double *w = (double *)malloc((size_t)(c->numel + 1) * sizeof(double));
+            for (int64_t k = 0; k < c->numel; k++) w[k] = 1.0 * si[k] + alpha * dsi[k];
+            barrier += genpow_barrier_primal(c, w);
+            for (int64_t k = 0; k < c->numel; k++) w[k] = 1.0 * zi[k] + alpha * dzi[k];
+            barrier += genpow_barrier_dual(c, w);
+            free(w);
         }
     }
     return barrier;
@@ -937,6 +1104,8 @@ void orc_cones_unit_initialization(const orc_cones *cs, double *z, double *s) {
         } else if (c->tag == CONE_POW) {
             si[0] = sqrt(1.0 + c->alpha); si[1] = sqrt(1.0 + (1.0 - c->alpha)); si[2] = 0.0;
             for (int k = 0; k < 3; k++) zi[k] = si[k];
+        } else if (c->tag == CONE_GENPOW) { /* genpowcone.rs:127-135 */
+            for (int64_t k = 0; k < c->dim; k++) zi[k] = si[k] = sqrt(1.0 + c->ga[k]);
         }
     }
 }
@@ -1475,6 +1644,16 @@ int orc_kktsolver_update(orc_kktsolver *ks, const orc_settings *st, const double
             scale_values(ks, map->sp_v[si], -eta2, c->numel);
             double dd[2] = {-eta2, eta2};
             update_values(ks, map->sp_D[si], dd, 2);
+        } else if (c->tag == CONE_GENPOW) { /* datamaps.rs:322-343: maps p -> sp_u, q -> sp_v, r -> sp_q */
+            const double sqrtmu = sqrt(c->gmu);
+            update_values(ks, map->sp_v[si], c->gq, c->dim);
+            update_values(ks, map->sp_q[si], c->gr, c->dim2);
+            update_values(ks, map->sp_u[si], c->gp, c->numel);
+            scale_values(ks, map->sp_v[si], -sqrtmu, c->dim);
+            scale_values(ks, map->sp_q[si], -sqrtmu, c->dim2);
+            scale_values(ks, map->sp_u[si], -sqrtmu, c->numel);
+            double dd[3] = {-1.0, -1.0, 1.0};
+            update_values(ks, map->sp_D[si], dd, 3);
         }
         si++;
     }
@@ -1738,6 +1917,14 @@ int64_t orc_cones_degree(const orc_cones *cs) {
         else if (c->tag == CONE_SOC) d += 1;
         else if (c->tag == CONE_EXP || c->tag == CONE_POW) d += 3;
         else if (c->tag == CONE_PSDTRI) d += c->dim;
+        else if (c->tag == CONE_GENPOW) d += c->dim + 1; /* genpowcone.rs:76-78 */
     }
     return d;
+}
+
+/* compositecone.rs:155-157: false as soon as one cone (GenPow, genpowcone.rs:96-98) disallows it */
+int orc_cones_allows_primal_dual_scaling(const orc_cones *cs) {
+    for (int64_t i = 0; i < cs->ncones; i++)
+        if (cs->c[i].tag == CONE_GENPOW) return 0;
+    return 1;
 }

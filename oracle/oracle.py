@@ -337,12 +337,21 @@ class Cones:
         tags = np.array([s[0] for s in self.specs], dtype=np.int32)
         dims = np.array([s[1] for s in self.specs], dtype=i64)
         dims2 = np.array([s[2] for s in self.specs], dtype=i64)
-        alphas = np.array([s[3] for s in self.specs], dtype=f64)
+        alphas = np.array([0.5 if s[0] == CONE_GENPOW else s[3] for s in self.specs], dtype=f64)
         self._h = C.c_void_p(lib().orc_cones_new_ex(C.c_int64(len(self.specs)), tags.ctypes.data_as(P_I32),
                                                     _pi(dims), _pi(dims2), _pf(alphas)))
         self.numel = lib().orc_cones_numel(self._h)
         self.nblockvals = lib().orc_cones_nblockvals(self._h)
         self.pdim = lib().orc_cones_pdim(self._h)
+        for i, sp in enumerate(self.specs):  # GenPowerConeT(alpha, dim2): (5, len(alpha), dim2, alpha)
+            if sp[0] == CONE_GENPOW:
+                a = _af(sp[3])
+                assert len(a) == sp[1] and abs(a.sum() - 1.0) < 1e-12 and (a > 0).all()
+                lib().orc_cones_set_genpow_alpha(self._h, C.c_int64(i), _pf(a))
+
+    @property
+    def allows_primal_dual_scaling(self):
+        return bool(lib().orc_cones_allows_primal_dual_scaling(self._h))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -4,7 +4,7 @@ solutions (basic_qp.rs:100-117, basic_lp.rs:27-44, basic_socp.rs:54-70)."""
 import numpy as np
 import scipy.sparse as sp
 
-ZERO, NN, SOC, EXP, POW, PSD = 0, 1, 2, 3, 4, 6
+ZERO, NN, SOC, EXP, POW, GENPOW, PSD = 0, 1, 2, 3, 4, 5, 6
 
 
 def _csc(M):
@@ -68,3 +68,10 @@ def basic_sdp():
                 cones=[(PSD, 3)],
                 x=[-3.0729833267361095, 0.3696004167288786, -0.022226685581313674, 0.31441213129613066,
                    -0.026739700851545107, -0.016084530571308823], obj=4.840076866013861, tol=1e-6)
+
+
+def basic_genpowcone():
+    # tests/basic_genpowcone.rs:4-55: the power-cone problem with GenPowerConeT([0.6, 0.4], 1), ([0.1, 0.9], 1)
+    pr = basic_powcone()
+    pr["cones"] = [(GENPOW, 2, 1, [0.6, 0.4]), (GENPOW, 2, 1, [0.1, 0.9]), (ZERO, 2)]
+    return pr

@@ -13,7 +13,7 @@ import math
 
 import numpy as np
 
-ZERO, NN, SOC, EXP, POW, PSD = 0, 1, 2, 3, 4, 6
+ZERO, NN, SOC, EXP, POW, GENPOW, PSD = 0, 1, 2, 3, 4, 5, 6
 AFFINE, COMBINED = 0, 1
 PRIMAL_DUAL, DUAL = 0, 1  # ScalingStrategy, core/solver.rs:77-80
 
@@ -41,6 +41,7 @@ class OracleBackend:
             self.sys = oracle.KKTSystem(self.ks, self.cones, n, m, P, A, q, b)
         self.degree = self.cones.degree
         self.is_symmetric = self.cones.is_symmetric
+        self.allows_primal_dual_scaling = not any(c[0] == GENPOW for c in cones)
 
     def update_scaling(self, s, z, mu, strategy):
         return self.cones.update_scaling(s, z, mu, strategy)
@@ -90,9 +91,10 @@ class HipBackend:
         Pm, Am = hip.CscMatrix(n, n, *P), hip.CscMatrix(m, n, *A)
         self.ks = hip.HipKKTSolver(Pm, Am, cones, m, n)
         self.sys = hip.HipKKTSystem(self.ks, Pm, Am, q, b)
-        self.degree = sum(c[1] if c[0] in (NN, PSD) else (1 if c[0] == SOC else (3 if c[0] in (EXP, POW) else 0))
-                          for c in cones)
-        self.is_symmetric = not any(c[0] in (EXP, POW) for c in cones)
+        self.degree = sum(c[1] if c[0] in (NN, PSD) else (1 if c[0] == SOC else (3 if c[0] in (EXP, POW) else (
+            c[1] + 1 if c[0] == GENPOW else 0))) for c in cones)
+        self.is_symmetric = not any(c[0] in (EXP, POW, GENPOW) for c in cones)
+        self.allows_primal_dual_scaling = not any(c[0] == GENPOW for c in cones)
         D = hip.DeviceArray
         self._v = [hip.DeviceVariables(n, m) for _ in range(3)]  # lhs, rhs, variables
         self._r = dict(rx=D(n), rz=D(m), rx_inf=D(n), rz_inf=D(m), Px=D(n))
@@ -236,7 +238,7 @@ def solve(be, cones, q, b, max_iter=200, tol_gap_abs=1e-8, tol_gap_rel=1e-8, tol
     variables.tau = variables.kappa = 1.0
     it, alpha, sigma = 0, 0.0, 1.0
     status = "Unsolved"
-    scaling = PRIMAL_DUAL  # Exp / Pow allow the primal-dual scaling (solver.rs:277-280)
+    scaling = PRIMAL_DUAL if be.allows_primal_dual_scaling else DUAL  # solver.rs:277-280
     while True:
         res = be.residuals(variables)
         mu = (res["dot_sz"] + variables.tau * variables.kappa) / (be.degree + 1)

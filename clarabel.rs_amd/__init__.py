@@ -291,7 +291,7 @@ class HipKKTSolver:
         tags = np.array([c[0] for c in self.cones], dtype=np.int32)
         dims = np.array([c[1] for c in self.cones], dtype=np.int64)
         dims2 = np.array([c[2] for c in self.cones], dtype=np.int64)
-        alphas = np.array([c[3] for c in self.cones], dtype=np.float64)
+        alphas = np.array([0.5 if c[0] == 5 else c[3] for c in self.cones], dtype=np.float64)
         self._h = C.c_void_p()
         pp = None
         if perm is not None:
@@ -302,6 +302,12 @@ class HipKKTSolver:
                                      C.c_int64(len(self.cones)), tags.ctypes.data_as(P_I32),
                                      dims.ctypes.data_as(P_I64), dims2.ctypes.data_as(P_I64), _pf(alphas),
                                      C.byref(self.settings), pp), "chip_kkt_create")
+        if self.settings.device != DEVICE_HOST_ONLY:
+            for i, c in enumerate(self.cones):  # GenPowerConeT(alpha, dim2) == (5, len(alpha), dim2, alpha)
+                if c[0] == 5:
+                    a = _f(c[3])
+                    assert len(a) == c[1]
+                    _check(lib().chip_kkt_set_genpow_alpha(self._h, C.c_int64(i), _pf(a)), "set_genpow_alpha")
         d = (C.c_int64 * 8)()
         lib().chip_kkt_dims(self._h, d)
         self.n, self.m, self.p, self.N, self.nnzK, self.nHs, self.NF, self.nnzU = [int(v) for v in d]

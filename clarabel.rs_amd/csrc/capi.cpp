@@ -67,6 +67,8 @@ struct chip_kkt {
     int *nn_rows = nullptr, *nn_hsidx = nullptr, *zero_rows = nullptr;
     dev::SocView soc{};
     dev::Ns3View ns3{};      // Exponential / Power cones
+    dev::GpwView gpw{};      // generalised power cones
+    std::vector<int> gpw_cone_index, gpw_state_off, gpw_dim1; // host copies (alpha setter)
     dev::PsdView psd{};      // PSD triangle cones with matrix side <= 64
     bool has_hostHs = false; // cones whose Hs must come from the host (PSD with side > 64)
     double *d_s = nullptr, *d_z = nullptr, *d_w = nullptr, *d_lam = nullptr;
@@ -328,10 +330,6 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     int rc = build_cone_specs(ncones, cone_tags, cone_dims, cone_dims2, K.cones, mm, K.p, K.nHs);
     if (rc) return CHIP_ERR_ARG;
     if (mm != m) return fail(CHIP_ERR_DIM, "cone dimensions do not add up to m");
-    for (const ConeSpec &c : K.cones)
-        if (c.tag == CHIP_CONE_GENPOWER)
-            return fail(CHIP_ERR_UNSUPPORTED,
-                        "GenPowerCone is not held on the device yet; use the L1 boundary (chip_ldl_*)");
     rc = assemble_kkt_triu(n, m, as_i64(Pcolptr), as_i64(Prowval), Pnzval, as_i64(Acolptr), as_i64(Arowval),
                            Anzval, K);
     if (rc) return rc;
@@ -360,6 +358,8 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     // ---- cone work lists ----------------------------------------------------
     std::vector<int> nn_rows, nn_hs, zero_rows, s_start, s_dim, s_hs, s_sidx, s_ptr, mapU, mapV, mapD;
     std::vector<int> n3_start, n3_hs, n3_tag, pd_start, pd_dim, pd_hs, pd_off;
+    std::vector<int> gp_start, gp_d1, gp_d2, gp_hs, gp_off, gp_mapptr, gp_map, gp_mapD;
+    i64 gp_state = 0;
     i64 pd_state = 0;
     int pd_max = 0;
     std::vector<double> n3_alpha;
@@ -385,6 +385,20 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
             if (c.tag == CHIP_CONE_POWER && !(al > 0.0 && al < 1.0))
                 return fail(CHIP_ERR_ARG, "PowerConeT exponent must lie in (0,1)");
             n3_alpha.push_back(al);
+        } else if (c.tag == CHIP_CONE_GENPOWER) {
+            gp_start.push_back((int)c.start);
+            gp_d1.push_back((int)c.dim);
+            gp_d2.push_back((int)c.dim2);
+            gp_hs.push_back((int)c.block_start);
+            gp_off.push_back((int)gp_state);
+            gp_state += 6 * c.dim + 4 * c.dim2 + 3;
+            gp_mapptr.push_back((int)gp_map.size());
+            const i64 sidx = c.sparse_idx;
+            for (i64 k = 0; k < c.dim; k++) gp_map.push_back((int)K.sp_q[K.sp_q_ptr[sidx] + k]);
+            for (i64 k = 0; k < c.dim2; k++) gp_map.push_back((int)K.sp_r[K.sp_r_ptr[sidx] + k]);
+            for (i64 k = 0; k < c.numel; k++) gp_map.push_back((int)K.sp_u[K.sp_ptr[sidx] + k]);
+            for (int k = 0; k < 3; k++) gp_mapD.push_back((int)K.sp_D[3 * sidx + k]);
+            h->gpw_cone_index.push_back((int)(&c - K.cones.data()));
         } else if (c.tag == CHIP_CONE_PSDTRIANGLE && c.dim <= 64) {
             pd_start.push_back((int)c.start);
             pd_dim.push_back((int)c.dim);
@@ -395,6 +409,41 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
         } else {
             h->has_hostHs = true;
         }
+    }
+    {
+        dev::GpwView &gv = h->gpw;
+        gv.ncones = (int)gp_start.size();
+        int *g1, *g2, *g3, *g4, *g5, *g6, *g7, *g8;
+        double *gs;
+        if ((rc = E.upload(&g1, gp_start, gp_start.size()))) return rc;
+        if ((rc = E.upload(&g2, gp_d1, gp_d1.size()))) return rc;
+        if ((rc = E.upload(&g3, gp_d2, gp_d2.size()))) return rc;
+        if ((rc = E.upload(&g4, gp_hs, gp_hs.size()))) return rc;
+        if ((rc = E.upload(&g5, gp_off, gp_off.size()))) return rc;
+        if ((rc = E.upload(&g6, gp_mapptr, gp_mapptr.size()))) return rc;
+        if ((rc = E.upload(&g7, gp_map, gp_map.size()))) return rc;
+        if ((rc = E.upload(&g8, gp_mapD, gp_mapD.size()))) return rc;
+        // state: alpha defaults to 1/dim1 with psi = 1 / sum alpha^2 until chip_kkt_set_genpow_alpha
+        std::vector<double> st0((size_t)(gp_state ? gp_state : 1), 0.0);
+        for (size_t c = 0; c < gp_start.size(); c++) {
+            double *st = st0.data() + gp_off[c];
+            for (int k = 0; k < gp_d1[c]; k++) st[k] = 1.0 / gp_d1[c];
+            st[6 * gp_d1[c] + 4 * gp_d2[c] + 1] = 1.0;               // mu
+            st[6 * gp_d1[c] + 4 * gp_d2[c] + 2] = (double)gp_d1[c]; // psi
+        }
+        if ((rc = E.upload(&gs, st0, st0.size()))) return rc;
+        gv.start = g1;
+        gv.dim1 = g2;
+        gv.dim2 = g3;
+        gv.hs_start = g4;
+        gv.state_off = g5;
+        gv.map_ptr = g6;
+        gv.mapQRP = g7;
+        gv.mapD = g8;
+        gv.mapHs = h->mapHs;
+        gv.state = gs;
+        h->gpw_state_off = gp_off;
+        h->gpw_dim1 = gp_d1;
     }
     {
         dev::PsdView &pv = h->psd;
@@ -545,6 +594,7 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
     dev::nn_update(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam);
     dev::soc_update_scaling(E.stream, h->soc, s_dev, z_dev);
     dev::ns3_update_scaling(E.stream, h->ns3, s_dev, z_dev, mu, strategy);
+    dev::gpw_update_scaling(E.stream, h->gpw, z_dev, mu);
     dev::psd_update_scaling(E.stream, h->psd, s_dev, z_dev);
     CHIP_HIP(hipGetLastError());
     h->scaling_pending_check = h->soc.ncones > 0 || h->psd.ncones > 0; // verdict folded into the next update()
@@ -592,6 +642,7 @@ int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
     dev::nn_write_hs(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx);
     dev::soc_write_kkt(E.stream, h->soc, E.Kx);
     dev::ns3_write_hs(E.stream, h->ns3, E.Kx);
+    dev::gpw_write_kkt(E.stream, h->gpw, E.Kx);
     dev::psd_write_hs(E.stream, h->psd, E.Kx);
     int ok = E.refactor(h->E.st.static_regularization_enable != 0, h->diag_full);
     if (ok < 0) return ok;
@@ -777,12 +828,13 @@ int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     CHIP_HIP(hipSetDevice(E.device));
     dev::cones_mul_Hs(E.stream, h->nn_rows, h->nn_count, h->soc, h->zero_rows, h->zero_count, y_dev, x_dev);
     dev::ns3_mul_hs(E.stream, h->ns3, y_dev, x_dev);
+    dev::gpw_mul_hs(E.stream, h->gpw, y_dev, x_dev);
     dev::psd_mul_hs(E.stream, h->psd, y_dev, x_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
 #define NEED_SYMMETRIC(h)                                                                      \
-    if ((h)->has_hostHs || (h)->ns3.ncones)                                                    \
+    if ((h)->has_hostHs || (h)->ns3.ncones || (h)->gpw.ncones)                                 \
     return fail(CHIP_ERR_UNSUPPORTED, "margins / scaled_unit_shift: symmetric, device-held cones only")
 #define NEED_STEP_OPS(h)                                                                       \
     if ((h)->has_hostHs)                                                                       \
@@ -805,10 +857,11 @@ int32_t chip_kkt_affine_ds_dev(chip_kkt *h, double *ds_dev, const double *s_dev)
     Engine &E = h->E;
     NEED_DEVICE(E);
     NEED_STEP_OPS(h);
-    if (h->ns3.ncones && !s_dev) return CHIP_ERR_ARG;
+    if ((h->ns3.ncones || h->gpw.ncones) && !s_dev) return CHIP_ERR_ARG;
     CHIP_HIP(hipSetDevice(E.device));
     dev::cone_affine_ds(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, ds_dev);
     dev::ns3_affine_ds(E.stream, h->ns3, ds_dev, s_dev);
+    dev::gpw_copy(E.stream, h->gpw, ds_dev, s_dev);
     dev::psd_affine_ds(E.stream, h->psd, ds_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
@@ -823,6 +876,7 @@ int32_t chip_kkt_combined_ds_shift_dev(chip_kkt *h, double *shift_dev, double *s
     dev::cone_combined_ds_shift(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, shift_dev,
                                 step_z_dev, step_s_dev, sigma_mu);
     dev::ns3_combined_ds_shift(E.stream, h->ns3, shift_dev, step_z_dev, step_s_dev, sigma_mu);
+    dev::gpw_combined_ds_shift(E.stream, h->gpw, shift_dev, sigma_mu);
     dev::psd_combined_ds_shift(E.stream, h->psd, shift_dev, step_z_dev, step_s_dev, sigma_mu);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
@@ -836,13 +890,14 @@ int32_t chip_kkt_ds_from_dz_offset_dev(chip_kkt *h, double *out_dev, const doubl
     dev::cone_ds_from_dz_offset(E.stream, h->nn_rows, h->nn_count, h->zero_rows, h->zero_count, h->soc, out_dev,
                                 ds_dev, z_dev);
     dev::ns3_ds_from_dz_offset(E.stream, h->ns3, out_dev, ds_dev);
+    dev::gpw_copy(E.stream, h->gpw, out_dev, ds_dev);
     dev::psd_ds_from_dz_offset(E.stream, h->psd, out_dev, ds_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
 static int ensure_partials(chip_kkt *h) {
     if (h->d_partial) return CHIP_OK;
-    h->partial_cap = 1024 + h->soc.ncones + h->psd.ncones + (h->ns3.ncones + 255) / 256 + 8;
+    h->partial_cap = 1024 + h->soc.ncones + h->psd.ncones + h->gpw.ncones + (h->ns3.ncones + 255) / 256 + 8;
     int rc = h->E.alloc(&h->d_partial, (size_t)h->partial_cap * 2);
     if (rc) return rc;
     h->h_partial.resize((size_t)h->partial_cap * 2);
@@ -868,10 +923,13 @@ int32_t chip_kkt_step_length_dev(chip_kkt *h, const double *dz_dev, const double
         CHIP_HIP(hipStreamSynchronize(E.stream));
         for (int i = 0; i < used; i++) a = std::min(a, h->h_partial[i]); // T::min: NaN-ignoring like f64::min
     }
-    if (h->ns3.ncones) { // back off from the boundary, then the nonsymmetric cones (:329-337)
+    if (h->ns3.ncones || h->gpw.ncones) { // back off from the boundary, then the nonsymmetric cones (:329-337)
         a = std::min(a, 1.0 - std::sqrt(2.220446049250313e-16));
         used = dev::ns3_step_length(E.stream, h->ns3, dz_dev, ds_dev, z_dev, s_dev, a,
                                     E.st.min_terminate_step_length, E.st.linesearch_backtrack_step, h->d_partial);
+        used += dev::gpw_step_length(E.stream, h->gpw, dz_dev, ds_dev, z_dev, s_dev, a,
+                                     E.st.min_terminate_step_length, E.st.linesearch_backtrack_step,
+                                     h->d_partial + used);
         CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)used * sizeof(double),
                                 hipMemcpyDeviceToHost, E.stream));
         CHIP_HIP(hipStreamSynchronize(E.stream));
@@ -879,6 +937,32 @@ int32_t chip_kkt_step_length_dev(chip_kkt *h, const double *dz_dev, const double
     }
     *alpha_out = a;
     return CHIP_OK;
+}
+int32_t chip_kkt_set_genpow_alpha(chip_kkt *h, int64_t cone_index, const double *alpha) {
+    if (!h || !alpha) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    for (size_t g = 0; g < h->gpw_cone_index.size(); g++) {
+        if (h->gpw_cone_index[g] != cone_index) continue;
+        const int d1 = h->gpw_dim1[g];
+        double sum = 0.0, sq = 0.0;
+        for (int k = 0; k < d1; k++) {
+            if (!(alpha[k] > 0.0)) return fail(CHIP_ERR_ARG, "GenPowerConeT: powers must be positive"); // genpowcone.rs:27
+            sum += alpha[k];
+            sq += alpha[k] * alpha[k];
+        }
+        if (std::fabs(1.0 - sum) >= 2.220446049250313e-16 * d1 * 0.5 + 1e-15)
+            return fail(CHIP_ERR_ARG, "GenPowerConeT: powers must sum to one"); // genpowcone.rs:28
+        CHIP_HIP(hipSetDevice(E.device));
+        double *st = h->gpw.state + h->gpw_state_off[g];
+        const int d2 = (int)h->K.cones[(size_t)cone_index].dim2;
+        const double psi = 1.0 / sq;
+        CHIP_HIP(hipMemcpyAsync(st, alpha, (size_t)d1 * sizeof(double), hipMemcpyHostToDevice, E.stream));
+        CHIP_HIP(hipMemcpyAsync(st + 6 * d1 + 4 * d2 + 2, &psi, sizeof(double), hipMemcpyHostToDevice, E.stream));
+        CHIP_HIP(hipStreamSynchronize(E.stream));
+        return CHIP_OK;
+    }
+    return fail(CHIP_ERR_ARG, "cone_index is not a GenPowerConeT");
 }
 int32_t chip_kkt_compute_barrier_dev(chip_kkt *h, const double *z_dev, const double *s_dev, const double *dz_dev,
                                      const double *ds_dev, double alpha, double *barrier_out) {
@@ -892,6 +976,8 @@ int32_t chip_kkt_compute_barrier_dev(chip_kkt *h, const double *z_dev, const dou
     int used = dev::cone_barrier(E.stream, h->nn_rows, h->nn_count, h->soc, h->ns3, z_dev, s_dev, dz_dev, ds_dev,
                                  alpha, h->d_partial);
     used += dev::psd_barrier(E.stream, h->psd, z_dev, s_dev, dz_dev, ds_dev, alpha, h->d_partial + used);
+    // scratch for the GenPow primal gradients: the cones' own slices of the (otherwise NN / SOC) w state
+    used += dev::gpw_barrier(E.stream, h->gpw, z_dev, s_dev, dz_dev, ds_dev, alpha, h->d_partial + used, h->d_w);
     double b = 0.0;
     if (used) {
         CHIP_HIP(hipMemcpyAsync(h->h_partial.data(), h->d_partial, (size_t)used * sizeof(double),
@@ -910,6 +996,7 @@ int32_t chip_kkt_unit_initialization_dev(chip_kkt *h, double *z_dev, double *s_d
     CHIP_HIP(hipSetDevice(E.device));
     dev::cone_unit_initialization(E.stream, h->nn_rows, h->nn_count, h->soc, h->ns3, z_dev, s_dev, (int)h->K.m);
     dev::psd_unit_initialization(E.stream, h->psd, z_dev, s_dev);
+    dev::gpw_unit_initialization(E.stream, h->gpw, z_dev, s_dev);
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }

@@ -2576,6 +2576,226 @@ __global__ __launch_bounds__(WG) void k_sym_unit_init(const int *__restrict__ nn
     }
 }
 
+// ---------------------------------------------------------------------------
+// Generalised power cone (genpowcone.rs), one workgroup per cone
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_prod(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v *= __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double t = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t *= red[i];
+    return t;
+}
+struct GpwState {
+    double *alpha, *q, *d1, *r, *p, *grad, *z, *sc; // sc: d2, mu, psi
+};
+__device__ __forceinline__ GpwState gpw_state(const GpwView &v, int c) {
+    const int a = v.dim1[c], b = v.dim2[c];
+    double *st = v.state + v.state_off[c];
+    return {st, st + a, st + 2 * a, st + 3 * a, st + 3 * a + b, st + 4 * a + 2 * b, st + 5 * a + 3 * b,
+            st + 6 * a + 4 * b};
+}
+// genpowcone.rs:361-401
+__global__ __launch_bounds__(WG) void k_gpw_update_scaling(GpwView v, const double *__restrict__ zv, double mu) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int a = v.dim1[c], b = v.dim2[c], tid = threadIdx.x;
+    const double *z = zv + v.start[c];
+    const GpwState st = gpw_state(v, c);
+    double pr = 1.0, sq = 0.0;
+    for (int k = tid; k < a; k += WG) pr *= pow(z[k] / st.alpha[k], 2.0 * st.alpha[k]);
+    for (int k = tid; k < b; k += WG) sq += z[a + k] * z[a + k];
+    const double phi = block_prod(pr, red);
+    const double norm2w = block_sum(sq, red);
+    const double zeta = phi - norm2w;
+    const double p0 = sqrt(phi * (phi + norm2w) / 2.0);
+    const double p1 = -2.0 * phi / p0;
+    const double q0 = sqrt(zeta * phi / 2.0);
+    const double r1 = 2.0 * sqrt(zeta / (phi + norm2w));
+    for (int k = tid; k < a; k += WG) {
+        const double al = st.alpha[k], zk = z[k];
+        const double tau = 2.0 * al / zk;
+        st.grad[k] = -tau * phi / zeta - (1.0 - al) / zk;
+        st.d1[k] = tau * phi / (zeta * zk) + (1.0 - al) / (zk * zk);
+        st.p[k] = (p0 / zeta) * tau;
+        st.q[k] = tau * (q0 / zeta);
+        st.z[k] = zk;
+    }
+    for (int k = tid; k < b; k += WG) {
+        const double wk = z[a + k];
+        st.grad[a + k] = (2.0 / zeta) * wk;
+        st.p[a + k] = (p1 / zeta) * wk;
+        st.r[k] = (r1 / zeta) * wk;
+        st.z[a + k] = wk;
+    }
+    if (tid == 0) {
+        st.sc[0] = 2.0 / zeta;
+        st.sc[1] = mu;
+    }
+}
+// get_Hs (:163-171) negated into K + csc_update_sparsecone (datamaps.rs:322-343)
+__global__ __launch_bounds__(WG) void k_gpw_write_kkt(GpwView v, double *Kx) {
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int a = v.dim1[c], b = v.dim2[c], tid = threadIdx.x;
+    const GpwState st = gpw_state(v, c);
+    const double mu = st.sc[1], d2 = st.sc[0], sm = -sqrt(mu);
+    const int *mh = v.mapHs + v.hs_start[c], *mq = v.mapQRP + v.map_ptr[c], *mr = mq + a, *mp = mr + b;
+    for (int k = tid; k < a; k += WG) {
+        Kx[mh[k]] = -(mu * st.d1[k]);
+        Kx[mq[k]] = st.q[k] * sm;
+    }
+    for (int k = tid; k < b; k += WG) {
+        Kx[mh[a + k]] = -(mu * d2);
+        Kx[mr[k]] = st.r[k] * sm;
+    }
+    for (int k = tid; k < a + b; k += WG) Kx[mp[k]] = st.p[k] * sm;
+    if (tid < 3) Kx[v.mapD[3 * c + tid]] = tid == 2 ? 1.0 : -1.0;
+}
+// feasibility of q (+ al dq) in the primal (dual == false) or dual cone, genpowcone.rs:279-317
+__device__ bool gpw_feasible(const GpwState &st, int a, int b, bool dual, const double *q, const double *dq,
+                             double al, double *red) {
+    int bad = 0;
+    double res = 0.0, sq = 0.0;
+    for (int k = threadIdx.x; k < a; k += WG) {
+        const double x = dq ? 1.0 * q[k] + al * dq[k] : q[k];
+        if (!(x > 0.0)) bad = 1;
+        res += 2.0 * st.alpha[k] * logsafe(dual ? x / st.alpha[k] : x);
+    }
+    for (int k = threadIdx.x; k < b; k += WG) {
+        const double x = dq ? 1.0 * q[a + k] + al * dq[a + k] : q[a + k];
+        sq += x * x;
+    }
+    if (__syncthreads_or(bad)) return false;
+    res = block_sum(res, red);
+    sq = block_sum(sq, red);
+    return exp(res) - sq > 0.0;
+}
+// dual barrier (:333-356) of the vector sgn * (q + al dq)
+__device__ double gpw_barrier_dual(const GpwState &st, int a, int b, const double *q, const double *dq, double al,
+                                   double sgn, double *red) {
+    double res = 0.0, sq = 0.0, lg = 0.0;
+    for (int k = threadIdx.x; k < a; k += WG) {
+        const double x = sgn * (dq ? 1.0 * q[k] + al * dq[k] : q[k]);
+        res += 2.0 * st.alpha[k] * logsafe(x / st.alpha[k]);
+        lg += logsafe(x) * (1.0 - st.alpha[k]);
+    }
+    for (int k = threadIdx.x; k < b; k += WG) {
+        const double x = dq ? 1.0 * q[a + k] + al * dq[a + k] : q[a + k];
+        sq += x * x;
+    }
+    res = block_sum(res, red);
+    sq = block_sum(sq, red);
+    lg = block_sum(lg, red);
+    return -logsafe(exp(res) - sq) - lg;
+}
+//   OP 0 mul_Hs (:173-193)                 OP 1 copy (affine_ds :195-197, ds_from_dz_offset :206-208)
+//   OP 2 combined_ds_shift = grad * sm (:199-204)
+//   OP 3 step_length from sc (:210-233) -> partial[c]      OP 4 barrier at (z, s) + sc (dz, ds) (:235-250)
+//   OP 5 unit_initialization (:127-135)
+template <int OP>
+__global__ __launch_bounds__(WG) void k_gpw_ops(GpwView v, double *o0, double *o1, const double *__restrict__ i0,
+                                                const double *__restrict__ i1, const double *__restrict__ i2,
+                                                const double *__restrict__ i3, double sc, double amin,
+                                                double step, double *partial, double *work) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    if (c >= v.ncones) return;
+    const int a = v.dim1[c], b = v.dim2[c], n = a + b, off = v.start[c], tid = threadIdx.x;
+    const GpwState st = gpw_state(v, c);
+    if (OP == 0) {
+        const double *x = i0 + off;
+        double cp = 0.0, cq = 0.0, cr = 0.0;
+        for (int k = tid; k < n; k += WG) cp += st.p[k] * x[k];
+        for (int k = tid; k < a; k += WG) cq += st.q[k] * x[k];
+        for (int k = tid; k < b; k += WG) cr += st.r[k] * x[a + k];
+        cp = block_sum(cp, red);
+        cq = block_sum(cq, red);
+        cr = block_sum(cr, red);
+        const double mu = st.sc[1], d2 = st.sc[0];
+        for (int k = tid; k < n; k += WG) {
+            const double y = k < a ? st.d1[k] * x[k] - cq * st.q[k] : d2 * x[k] - cr * st.r[k - a];
+            o0[off + k] = (cp * st.p[k] + 1.0 * y) * mu;
+        }
+    } else if (OP == 1) {
+        for (int k = tid; k < n; k += WG) o0[off + k] = i0[off + k];
+    } else if (OP == 2) {
+        for (int k = tid; k < n; k += WG) o0[off + k] = st.grad[k] * sc;
+    } else if (OP == 3) {
+        double amin_z = sc, amin_s = sc;
+        for (int pass = 0; pass < 2; ++pass) {
+            const double *dq = (pass == 0 ? i0 : i1) + off, *q = (pass == 0 ? i2 : i3) + off;
+            double al = sc;
+            for (;;) {
+                if (gpw_feasible(st, a, b, pass == 0, q, dq, al, red)) break;
+                al *= step;
+                if (al < amin) {
+                    al = 0.0;
+                    break;
+                }
+            }
+            if (pass == 0) amin_z = al;
+            else amin_s = al;
+        }
+        if (tid == 0) partial[c] = fmin(amin_z, amin_s);
+    } else if (OP == 4) {
+        // dual part, then the primal barrier = -f*(-g(s)) - degree with g from a Newton iteration (:409-485)
+        const double bd = gpw_barrier_dual(st, a, b, i0 + off, i2 + off, sc, 1.0, red);
+        const double *s = i1 + off, *ds = i3 + off;
+        double *g = work + off; // scratch: the cone's slice of an m-vector
+        double pr = 1.0, sq = 0.0;
+        for (int k = tid; k < a; k += WG) pr *= pow(1.0 * s[k] + sc * ds[k], 2.0 * st.alpha[k]);
+        double mx = 0.0;
+        for (int k = tid; k < b; k += WG) mx = fmax(mx, fabs(1.0 * s[a + k] + sc * ds[a + k]));
+        const double phi = block_prod(pr, red);
+        mx = block_max(mx, red);
+        for (int k = tid; k < b; k += WG) {
+            const double x = mx > 0.0 ? (1.0 * s[a + k] + sc * ds[a + k]) / mx : 0.0;
+            sq += x * x;
+        }
+        const double norm_r = mx * sqrt(block_sum(sq, red));
+        const double eps = 2.220446049250313e-16;
+        if (norm_r > eps) {
+            const double psi = st.sc[2];
+            double x = -(1.0 / norm_r) +
+                       (psi * norm_r + sqrt((phi / norm_r / norm_r + psi * psi - 1.0) * phi)) / (phi - norm_r * norm_r);
+            for (int iter = 0; iter < 100; iter++) {
+                double df = 0.0, f = 0.0;
+                for (int k = tid; k < a; k += WG) {
+                    const double al = st.alpha[k], pk = 1.0 * s[k] + sc * ds[k];
+                    df += 2.0 * al * norm_r / (norm_r * x + (1.0 + al) / al);
+                    f += 2.0 * al * (logsafe(x * norm_r + (1.0 + al) / al) - logsafe(pk));
+                }
+                df = block_sum(df, red) + -(2.0 * x + 2.0 / norm_r) / (x * x + 2.0 * x / norm_r);
+                f = block_sum(f, red) + -logsafe(2.0 * x / norm_r + x * x);
+                const double dx = -f / df;
+                if (dx < eps || fabs(dx / x) < sqrt(eps) || fabs(df) < eps) break;
+                x += dx;
+            }
+            for (int k = tid; k < b; k += WG) g[a + k] = (x / norm_r) * st.r[k];
+            for (int k = tid; k < a; k += WG)
+                g[k] = -(1.0 + st.alpha[k] + st.alpha[k] * x * norm_r) / (1.0 * s[k] + sc * ds[k]);
+        } else {
+            for (int k = tid; k < b; k += WG) g[a + k] = 0.0;
+            for (int k = tid; k < a; k += WG) g[k] = -(1.0 + st.alpha[k]) / (1.0 * s[k] + sc * ds[k]);
+        }
+        __syncthreads();
+        const double bp = -gpw_barrier_dual(st, a, b, g, nullptr, 0.0, -1.0, red) - (double)(a + 1);
+        if (tid == 0) partial[c] = (0.0 + bp) + bd;
+    } else if (OP == 5) {
+        for (int k = tid; k < n; k += WG) {
+            const double u = k < a ? sqrt(1.0 + st.alpha[k]) : 0.0;
+            o0[off + k] = u;
+            o1[off + k] = u;
+        }
+    }
+}
+
 } // namespace
 
 // ===========================================================================
@@ -2636,6 +2856,36 @@ int cone_margins(hipStream_t s, const int *nn_rows, int nn, const SocView &v, co
         used += v.ncones;
     }
     return used;
+}
+void gpw_update_scaling(hipStream_t s, const GpwView &v, const double *zv, double mu) {
+    if (v.ncones) k_gpw_update_scaling<<<v.ncones, WG, 0, s>>>(v, zv, mu);
+}
+void gpw_write_kkt(hipStream_t s, const GpwView &v, double *Kx) {
+    if (v.ncones) k_gpw_write_kkt<<<v.ncones, WG, 0, s>>>(v, Kx);
+}
+void gpw_mul_hs(hipStream_t s, const GpwView &v, double *y, const double *x) {
+    if (v.ncones) k_gpw_ops<0><<<v.ncones, WG, 0, s>>>(v, y, nullptr, x, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr);
+}
+void gpw_copy(hipStream_t s, const GpwView &v, double *out, const double *in) {
+    if (v.ncones) k_gpw_ops<1><<<v.ncones, WG, 0, s>>>(v, out, nullptr, in, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr);
+}
+void gpw_combined_ds_shift(hipStream_t s, const GpwView &v, double *shift, double sigma_mu) {
+    if (v.ncones) k_gpw_ops<2><<<v.ncones, WG, 0, s>>>(v, shift, nullptr, nullptr, nullptr, nullptr, nullptr, sigma_mu, 0.0, 0.0, nullptr, nullptr);
+}
+int gpw_step_length(hipStream_t s, const GpwView &v, const double *dz, const double *ds, const double *z,
+                    const double *sv, double alpha, double alpha_min, double step, double *partial) {
+    if (!v.ncones) return 0;
+    k_gpw_ops<3><<<v.ncones, WG, 0, s>>>(v, nullptr, nullptr, dz, ds, z, sv, alpha, alpha_min, step, partial, nullptr);
+    return v.ncones;
+}
+int gpw_barrier(hipStream_t s, const GpwView &v, const double *z, const double *sv, const double *dz,
+                const double *ds, double alpha, double *partial, double *work) {
+    if (!v.ncones) return 0;
+    k_gpw_ops<4><<<v.ncones, WG, 0, s>>>(v, nullptr, nullptr, z, sv, dz, ds, alpha, 0.0, 0.0, partial, work);
+    return v.ncones;
+}
+void gpw_unit_initialization(hipStream_t s, const GpwView &v, double *z, double *sv) {
+    if (v.ncones) k_gpw_ops<5><<<v.ncones, WG, 0, s>>>(v, z, sv, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr, nullptr);
 }
 static int ns3_blocks(const Ns3View &v) { return (v.ncones + WG - 1) / WG; }
 void ns3_affine_ds(hipStream_t s, const Ns3View &v, double *ds, const double *sv) {

@@ -136,6 +136,15 @@ struct Ns3View {
     double *state;
     const int *mapHs;
 };
+// Generalised power cones (genpowcone.rs): one workgroup per cone.  state per cone (doubles) at
+// state_off: alpha[d1] | q[d1] | d1[d1] | r[d2] | p[d1+d2] | grad[d1+d2] | z[d1+d2] | d2, mu, psi
+struct GpwView {
+    int ncones;
+    const int *start, *dim1, *dim2, *hs_start, *state_off;
+    const int *map_ptr;               // per cone: offset of its q / r / p index runs in mapQRP (q, then r, then p)
+    const int *mapQRP, *mapD, *mapHs; // K.nzval indices (mapD: 3 per cone)
+    double *state;
+};
 // PSD triangle cones held on the device (matrix side <= 64): state per cone = B (n*n, the NT
 // scaling matrix R R') followed by lambda (n)
 struct PsdView {
@@ -186,6 +195,19 @@ int cone_barrier(hipStream_t s, const int *nn_rows, int nn, const SocView &soc, 
 // unit_initialization of the composite cone (compositecone.rs:208-214): z, s of length m
 void cone_unit_initialization(hipStream_t s, const int *nn_rows, int nn, const SocView &soc, const Ns3View &v,
                               double *z, double *sv, int m);
+// GenPow cones: update_scaling (dual scaling only, genpowcone.rs:141-157,361-401), the sparse KKT
+// expansion update (datamaps.rs:322-343) and the operations either side of the solve (:163-250)
+void gpw_update_scaling(hipStream_t s, const GpwView &v, const double *zv, double mu);
+void gpw_write_kkt(hipStream_t s, const GpwView &v, double *Kx);
+void gpw_mul_hs(hipStream_t s, const GpwView &v, double *y, const double *x);
+void gpw_copy(hipStream_t s, const GpwView &v, double *out, const double *in);          // affine_ds, ds_from_dz_offset
+void gpw_combined_ds_shift(hipStream_t s, const GpwView &v, double *shift, double sigma_mu);
+int gpw_step_length(hipStream_t s, const GpwView &v, const double *dz, const double *ds, const double *z,
+                    const double *sv, double alpha, double alpha_min, double step, double *partial);
+// work: an m-vector of scratch (the primal gradient of every cone)
+int gpw_barrier(hipStream_t s, const GpwView &v, const double *z, const double *sv, const double *dz,
+                const double *ds, double alpha, double *partial, double *work);
+void gpw_unit_initialization(hipStream_t s, const GpwView &v, double *z, double *sv);
 void cone_unit_shift(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,
                      double *z, double alpha, int primal);
 void cone_affine_ds(hipStream_t s, const int *nn_rows, int nn, const int *zero_rows, int nz, const SocView &v,

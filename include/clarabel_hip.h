@@ -225,8 +225,8 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval);
  * y = Hs x, m doubles, device pointers. */
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev);
 /* ---- the cone operations either side of the KKT solve, for problems whose
- * cones are Zero / Nonnegative / SecondOrder / Exponential / Power / PSDTriangle (side <= 64);
- * m-vectors in HBM.  CHIP_ERR_UNSUPPORTED otherwise (larger PSD cones, GenPower).  PSDTriangle:
+ * cones are Zero / Nonnegative / SecondOrder / Exponential / Power / GenPower / PSDTriangle
+ * (side <= 64); m-vectors in HBM.  CHIP_ERR_UNSUPPORTED otherwise (larger PSD cones).  PSDTriangle:
  * psdtrianglecone.rs:104-303 with symmetric_common.rs:53-95 -- mul_W / mul_Winv as two n x n
  * products with R / Rinv, circ_op, lambda \ ., step length and margins from the eigenvalues of a
  * parallel two-sided Jacobi iteration, barrier from a Cholesky log-determinant, all in LDS.  Exponential / Power: affine_ds = s
@@ -259,6 +259,12 @@ int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha,
 /* unit_initialization  compositecone.rs:208-214 (zerocone.rs:71-74, nonnegativecone.rs:68-71,
  * socone.rs:114-119, expcone.rs:87-93, powcone.rs:79-87): fills z[m], s[m] */
 int32_t chip_kkt_unit_initialization_dev(chip_kkt *h, double *z_dev, double *s_dev);
+/* GenPowerConeT(alpha, dim2) (cones/genpowcone.rs:49-63): chip_kkt_create takes dims[i] = len(alpha) and
+ * dims2[i] = dim2; the powers themselves (positive, summing to one) are handed over here, before the
+ * first chip_kkt_update_scaling (until then alpha = 1/dim1).  The cone is nonsymmetric and allows the
+ * dual scaling only (genpowcone.rs:96-98): Hs = mu H(z) as a diagonal plus the rank-3 sparse
+ * expansion [q, r, p] of datamaps.rs:227-343, all computed and written into K on the device. */
+int32_t chip_kkt_set_genpow_alpha(chip_kkt *h, int64_t cone_index, const double *alpha);
 /* compute_barrier  compositecone.rs:342-352 at (z, s) + alpha (dz, ds): nonnegativecone.rs:155-166,
  * socone.rs:304-314, expcone.rs:170-252, powcone.rs:169-258; *barrier_out on the host */
 int32_t chip_kkt_compute_barrier_dev(chip_kkt *h, const double *z_dev, const double *s_dev,

@@ -509,6 +509,102 @@ def test_psd_cone_operations(hip, oracle, dim):
     assert np.array_equal(uz.numpy(), rz) and np.array_equal(us.numpy(), rs)
 
 
+def test_genpow_cone_on_device(hip, oracle):
+    """GenPowerCone (genpowcone.rs): dual scaling, Hs diagonal + the [q, r, p] sparse expansion written
+    into K (datamaps.rs:322-343), mul_Hs, step operations, barrier; vs the oracle, plus a KKT solve"""
+    rng = np.random.default_rng(77)
+    cones, s_parts, z_parts = [(1, 5)], [rng.uniform(0.5, 2, 5)], [rng.uniform(0.5, 2, 5)]
+    for d1, d2 in ((2, 1), (3, 2), (6, 4), (40, 25)):
+        a = rng.uniform(0.2, 1.0, d1)
+        a /= a.sum()
+        a[-1] = 1.0 - a[:-1].sum()
+        cones.append((5, d1, d2, list(a)))
+        wdir = rng.standard_normal(d2)
+        for parts in (s_parts, z_parts):  # interior of K and K*: u > 0, ||w|| well below prod u^alpha
+            u = rng.uniform(0.8, 2.0, d1)
+            # same w direction in s and z: the reference's primal gradient scales its w part with the
+            # cone's r vector (built from z, genpowcone.rs:427), so only then is the barrier finite
+            w = wdir * (0.3 * np.prod((u / a) ** a) / max(np.linalg.norm(wdir), 1e-9))
+            parts.append(np.concatenate([u, w]))
+    s, z = np.concatenate(s_parts), np.concatenate(z_parts)
+    m = len(s)
+    n = 12
+    import scipy.sparse as sp2
+    A = sp2.random(m, n, density=0.3, random_state=np.random.RandomState(3), format="csc") + \
+        sp2.csc_matrix((np.ones(n), (np.arange(n), np.arange(n))), shape=(m, n))
+    P = sp2.diags(rng.uniform(0.5, 1.5, n)).tocsc()
+    pr = dict(n=n, m=m, P=problems._csc(P), A=problems._csc(A), cones=cones, s=s, z=z)
+    ks, ko, oc = _solvers(hip, oracle, pr)
+    mu = 0.43
+    assert ks.update_scaling(s, z, mu, 1) and oc.update_scaling(s, z, mu, 1)
+    assert ks.update() and ko.update()
+    assert relerr(ks.values(), ko.kkt.nzval) <= 1e-12
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    ks.setrhs(rx, rz)
+    ko.setrhs(rx, rz)
+    x, zz = np.zeros(n), np.zeros(m)
+    assert ks.solve(x, zz)
+    ok, xo, zo = ko.solve()
+    assert ok and relerr(np.concatenate([x, zz]), np.concatenate([xo, zo])) <= TOL
+    D = hip.DeviceArray
+    v = rng.standard_normal(m)
+    y, d_v = D(m), D(v)
+    ks.mul_Hs_dev(y.ptr, d_v.ptr)
+    assert relerr(y.numpy(), oc.mul_Hs(v)) <= 1e-12
+    dz, dsv = 0.05 * rng.standard_normal(m), 0.05 * rng.standard_normal(m)
+    d_s, d_z, d_ds, d_dz = D(s), D(z), D(dsv), D(dz)
+    out = D(m)
+    ks.affine_ds_dev(out.ptr, d_s.ptr)
+    assert relerr(out.numpy(), oc.affine_ds(s)) <= 1e-13
+    sh, tz, ts = D(m), D(dz), D(dsv)
+    ks.combined_ds_shift_dev(sh.ptr, tz.ptr, ts.ptr, 0.37)
+    osh, _, _ = oc.combined_ds_shift(dz, dsv, 0.37)
+    assert relerr(sh.numpy(), osh) <= 1e-12
+    for scale in (0.5, 8.0, 100.0):
+        t1, t2 = D(scale * dz), D(scale * dsv)
+        a_dev = ks.step_length_dev(t1.ptr, t2.ptr, d_z.ptr, d_s.ptr, 1.0)
+        a_ref = oc.step_length(scale * dz, scale * dsv, z, s, 1.0)
+        assert abs(a_dev - a_ref) <= 1e-12 * max(1.0, a_ref)
+    zero = D(m)
+    b_dev = ks.compute_barrier_dev(d_z.ptr, d_s.ptr, zero.ptr, zero.ptr, 0.0)
+    b_ref = oc.compute_barrier(z, s, np.zeros(m), np.zeros(m), 0.0)
+    # NB with the reference's primal gradient (w part scaled by the cone's r vector, genpowcone.rs:427)
+    # -g(s) is generally outside the dual cone, so the primal barrier is -inf on both sides
+    assert b_dev == b_ref or abs(b_dev - b_ref) <= 1e-9 * max(1.0, abs(b_ref))
+    b_dev = ks.compute_barrier_dev(d_z.ptr, d_s.ptr, d_dz.ptr, d_ds.ptr, 0.3)
+    b_ref = oc.compute_barrier(z, s, dz, dsv, 0.3)
+    assert b_dev == b_ref or abs(b_dev - b_ref) <= 1e-9 * max(1.0, abs(b_ref))
+    uz, us = D(m), D(m)
+    ks.unit_initialization_dev(uz.ptr, us.ptr)
+    rz2, rs2 = np.zeros(m), np.zeros(m)
+    oc.unit_initialization(rz2, rs2)
+    assert relerr(uz.numpy(), rz2) <= 1e-15 and relerr(us.numpy(), rs2) <= 1e-15
+
+
+def test_genpow_barrier_finite_case(hip, oracle):
+    """GenPowerCone with dim2 = 0 (pure power part): the primal gradient has no w part, -g(s) is dual
+    feasible and the barrier is finite -- checks both barrier halves against the oracle"""
+    rng = np.random.default_rng(8)
+    cones = [(5, 3, 0, [0.2, 0.3, 0.5]), (5, 2, 0, [0.6, 0.4]), (1, 2)]
+    m, n = 7, 3
+    s, z = rng.uniform(0.5, 2.0, m), rng.uniform(0.5, 2.0, m)
+    import scipy.sparse as sp2
+    A = sp2.csc_matrix(rng.standard_normal((m, n)))
+    P = sp2.identity(n, format="csc")
+    pr = dict(n=n, m=m, P=problems._csc(P), A=problems._csc(A), cones=cones, s=s, z=z)
+    ks, ko, oc = _solvers(hip, oracle, pr)
+    assert ks.update_scaling(s, z, 0.7, 1) and oc.update_scaling(s, z, 0.7, 1)
+    assert ks.update() and ko.update()
+    assert relerr(ks.values(), ko.kkt.nzval) <= 1e-12
+    D = hip.DeviceArray
+    dz, dsv = 0.1 * rng.standard_normal(m), 0.1 * rng.standard_normal(m)
+    d_s, d_z, d_ds, d_dz = D(s), D(z), D(dsv), D(dz)
+    for alpha in (0.0, 0.5):
+        b_dev = ks.compute_barrier_dev(d_z.ptr, d_s.ptr, d_dz.ptr, d_ds.ptr, alpha)
+        b_ref = oc.compute_barrier(z, s, dz, dsv, alpha)
+        assert np.isfinite(b_ref) and abs(b_dev - b_ref) <= 1e-10 * max(1.0, abs(b_ref))
+
+
 def test_full_scale_properties_c3(hip):
     """BASELINE config 3 at full size (n = 10^6): too big for the oracle in seconds, so check
     size-independent properties: residual of the refined solution against an independent
@@ -603,10 +699,10 @@ def test_l3_kktsystem_and_residuals(hip, oracle, which):
         assert relerr(a.numpy(), c) <= TOL
 
 
-@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp"])
+@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp", "basic_genpowcone"])
 def test_e2e_reference_answers_on_device(hip, oracle, name):
     """the reference's end-to-end known answers (tests/basic_qp.rs:100-117, basic_lp.rs:27-44,
-    basic_socp.rs:54-70, basic_expcone.rs:38-56, basic_powcone.rs:4-47, basic_sdp.rs:29-57) reached with every L1-L3 operation on the device, and the same
+    basic_socp.rs:54-70, basic_expcone.rs:38-56, basic_powcone.rs:4-47, basic_sdp.rs:29-57, basic_genpowcone.rs:4-55) reached with every L1-L3 operation on the device, and the same
     trajectory as the oracle-backed loop"""
     from tests import e2e_problems as E
     from tests import ipm_driver as ipm

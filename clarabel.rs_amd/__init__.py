@@ -150,6 +150,11 @@ def _status(rc, where):
     return bool(_check(rc, where))
 
 
+def auto_select(lnz, n_div, n_mult_subs_ldl):
+    """ldl_auto_select's rule (ldlsolvers/auto.rs:62-87): 'qdldl' (simplicial) or 'faer' (supernodal)"""
+    return "faer" if lib().chip_auto_select(C.c_double(lnz), C.c_double(n_div), C.c_double(n_mult_subs_ldl)) else "qdldl"
+
+
 def amd_order(n, colptr, rowval, dense_scale=1.5):
     """AMD ordering of the symmetric matrix with upper triangle (colptr,rowval).
     Replaces `amd::order` at src/qdldl/qdldl.rs:905-917.  Returns (perm, iperm, info3)."""

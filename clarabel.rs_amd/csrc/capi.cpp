@@ -107,6 +107,11 @@ void chip_settings_default(chip_settings *s) {
     s->min_terminate_step_length = 1e-4;
 }
 
+int32_t chip_auto_select(double lnz, double n_div, double n_mult_subs_ldl) {
+    const double flops = n_div + n_mult_subs_ldl, thresh = 40.0; // auto.rs:72-79
+    return (flops / lnz) < thresh ? 0 : 1;
+}
+
 const char *chip_last_error(void) {
     g_last = get_error();
     return g_last.c_str();

@@ -117,6 +117,12 @@ void chip_settings_default(chip_settings *s);
 const char *chip_last_error(void);
 /* number of visible HIP devices (0 when there is no GPU / runtime) */
 int32_t chip_device_count(void);
+/* The switching rule of ldl_auto_select (ldlsolvers/auto.rs:62-87) on the statistics of an AMD
+ * ordering (chip_amd_order's info3, or chip_info.amd_*): (n_div + n_mult_subs_ldl) / lnz < 40 selects
+ * the simplicial engine (returns 0, "qdldl"), otherwise the supernodal one (returns 1, "faer").
+ * This library has a single engine; the rule is exported so that a host-side "auto" setting can be
+ * kept without the amd crate, and as the census behind DESIGN.md section 9. */
+int32_t chip_auto_select(double lnz, double n_div, double n_mult_subs_ldl);
 
 /* ---- host-side symbolic utilities ------------------------------------------
  * Approximate-minimum-degree ordering of the symmetric matrix whose upper

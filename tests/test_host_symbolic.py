@@ -212,3 +212,17 @@ def test_portfolio_structure_is_shallow(hip):
     info = ks.linear_solver_info()
     assert info.n_levels <= 8
     assert info.nnzL <= 1.2 * info.nnzA
+
+
+def test_auto_select_rule(hip):
+    """ldl_auto_select (ldlsolvers/auto.rs:62-87): flops / nnz(L) < 40 -> simplicial ('qdldl'), else
+    supernodal ('faer'); fed with the statistics of our own AMD ordering"""
+    s = hip.Settings.default()
+    assert s.linesearch_backtrack_step == 0.8 and s.min_terminate_step_length == 1e-4  # settings.rs:96-104
+    pr = problems.portfolio_socp(20, 50, seed=3)      # block arrow: almost no fill
+    info = _mk(hip, pr).linear_solver_info()
+    assert hip.auto_select(info.amd_lnz, info.amd_ndiv, info.amd_nmultsubs_ldl) == "qdldl"
+    pr = problems.chordal_sdp(2, 30, 3, 1, 6, seed=1)  # dense 465-wide PSD blocks
+    info = _mk(hip, pr).linear_solver_info()
+    assert hip.auto_select(info.amd_lnz, info.amd_ndiv, info.amd_nmultsubs_ldl) == "faer"
+    assert hip.auto_select(100.0, 1000.0, 2999.0) == "qdldl" and hip.auto_select(100.0, 1000.0, 3000.0) == "faer"

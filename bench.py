@@ -238,7 +238,7 @@ def cpu_baseline(pr, ks, args):
     t0 = time.perf_counter()
     step()
     t1 = time.perf_counter() - t0
-    nsteps = args.cpu_steps if args.cpu_steps > 0 else max(2, min(20, int(15.0 / max(t1, 1e-3))))
+    nsteps = args.cpu_steps if args.cpu_steps > 0 else max(2, min(200, int(15.0 / max(t1, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(nsteps):
         step()

@@ -798,44 +798,6 @@ __device__ __forceinline__ void fold_norm(unsigned long long *nrm, int *nan, dou
 }
 
 template <int MODE>
-__global__ __launch_bounds__(WG) void k_gather_T(GatherArgs a, const int *__restrict__ rows, int count) {
-    __shared__ double red[16];
-    const int lb = logical_block();
-    const int tid = lb * WG + threadIdx.x;
-    double v = 0.0;
-    if (tid < count) {
-        const int r = rows[tid];
-        const int b = a.ptr[r], e = a.ptr[r + 1];
-        double s = 0.0;
-        for (int t = b; t < e; ++t) s += a.val[t] * a.xin[a.idx[t]];
-        v = store_row<MODE>(a, r, s);
-    }
-    if (MODE == SYMV && a.nrm) {
-        const bool nan = v != v;
-        const double m = block_max(nan ? 0.0 : fabs(v), red);
-        if (__syncthreads_or(nan)) {
-            if (threadIdx.x == 0) *a.nan = 1;
-        }
-        if (threadIdx.x == 0) fold_norm(a.nrm, a.nan, m, false, lb);
-    }
-}
-// W: one wavefront per row, 4 rows per workgroup
-template <int MODE>
-__global__ __launch_bounds__(WG) void k_gather_W(GatherArgs a, const int *__restrict__ rows, int count) {
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= count) return;
-    const int lane = threadIdx.x & 63;
-    const int r = rows[wid];
-    const int b = a.ptr[r], e = a.ptr[r + 1];
-    double s = 0.0;
-    for (int t = b + lane; t < e; t += 64) s += a.val[t] * a.xin[a.idx[t]];
-    s = wave_sum(s);
-    if (lane == 0) {
-        const double v = store_row<MODE>(a, r, s);
-        if (MODE == SYMV && a.nrm) fold_norm(a.nrm, a.nan, v != v ? 0.0 : fabs(v), v != v, wid);
-    }
-}
-template <int MODE>
 __global__ __launch_bounds__(WG) void k_gather_Bprep(GatherArgs a, const int *__restrict__ rows, int count) {
     const int t = blockIdx.x * WG + threadIdx.x;
     if (t >= count) return;
@@ -844,19 +806,6 @@ __global__ __launch_bounds__(WG) void k_gather_Bprep(GatherArgs a, const int *__
     else if (MODE == SYMV) a.out[r] = a.aux[r];
     else if (MODE == SPMV) a.out[r] = a.aux ? a.aux[r] : 0.0;
 }
-template <int MODE>
-__global__ __launch_bounds__(WG) void k_gather_B(GatherArgs a, const int *__restrict__ crow,
-                                                 const int *__restrict__ cbeg,
-                                                 const int *__restrict__ cend, int count) {
-    __shared__ double red[16];
-    if ((int)blockIdx.x >= count) return;
-    double s = 0.0;
-    for (int t = cbeg[blockIdx.x] + threadIdx.x; t < cend[blockIdx.x]; t += WG)
-        s += a.val[t] * a.xin[a.idx[t]];
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(&a.out[crow[blockIdx.x]], MODE == SPMV ? a.alpha * s : -s);
-}
-
 // T, W and B work of one level in ONE launch: the three classes are independent, so their
 // blocks simply coexist in the grid (long B chunks first, then wave-per-row, then the
 // thread-per-row slab with its XCD-aware mapping).  off8 = first T block, a multiple of 8.
@@ -1623,7 +1572,6 @@ __global__ __launch_bounds__(WG) void k_ns3_mul_hs(Ns3View v, double *y, const d
 // and leaves sigma_p = ||m_p||; B does not depend on the order / signs of the singular pairs.
 // n <= PSD_MAX_DIM (three n x n fp64 matrices in LDS).
 // ---------------------------------------------------------------------------
-constexpr int PSD_MAX_DIM = 64;
 
 // in-place lower Cholesky of the column-major n x n matrix A (upper part ignored); returns false
 // (uniformly) when a pivot is not positive -> update_scaling fails like ?potrf (psdtrianglecone.rs:165-169)
@@ -1650,8 +1598,7 @@ __device__ bool lds_cholesky(double *A, int n, int *flag) {
     return true;
 }
 
-// state of one PSD cone in HBM (doubles): B = R R' (n*n) | lambda (n) | lambda^-1/2 (n) | R (n*n) | Rinv (n*n)
-__device__ __forceinline__ int psd_state_size(int n) { return 3 * n * n + 2 * n; }
+// state of one PSD cone in HBM (3 n^2 + 2 n doubles): B = R R' (n*n) | lambda (n) | lambda^-1/2 (n) | R (n*n) | Rinv (n*n)
 __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const double *__restrict__ sv,
                                                            const double *__restrict__ zv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1911,7 +1858,7 @@ __device__ double psd_eig_min(double *A, int n, double *cs, double *red, int *fl
     if (psum) *psum = sp;
     return mn;
 }
-// state offsets, see psd_state_size
+// state offsets (layout above k_psd_update_scaling)
 struct PsdState {
     const double *B, *lam, *lis, *R, *Ri;
 };
@@ -3023,23 +2970,10 @@ void gather_chain(hipStream_t s, GatherMode m, const GatherArgs &a, const int *t
             k_chain<BWD><<<1, 1024, 0, s>>>(a, t_idx, t_ptr, w_idx, w_ptr, std::max(l0, e - CHAIN_CAP), e);
     }
 }
-void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
-    if (!r.count) return;
-    DISPATCH_MODE(k_gather_T, grid_for(r.count), a, r.idx, r.count)
-}
-void gather_W(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
-    if (!r.count) return;
-    DISPATCH_MODE(k_gather_W, (r.count + 3) / 4, a, r.idx, r.count)
-}
 void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView r) {
     if (!r.count || m == FWD) return;
     DISPATCH_MODE(k_gather_Bprep, (r.count + WG - 1) / WG, a, r.idx, r.count)
 }
-void gather_B(hipStream_t s, GatherMode m, const GatherArgs &a, ChunkView c) {
-    if (!c.count) return;
-    DISPATCH_MODE(k_gather_B, c.count, a, c.row, c.beg, c.end, c.count)
-}
-
 static int stream_grid(int N) {
     int nb = grid_for(N);
     return nb > 2048 ? 2048 : nb;

@@ -79,8 +79,6 @@ struct GatherArgs {
 };
 constexpr int NRM_SLOTS = 64;
 constexpr int NRM_STRIDE = 16; // in u64 words: one slot per 128-byte line
-void gather_T(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
-void gather_W(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 // levels [l0, l1) of a chain-like stretch in ONE single-workgroup launch (FWD ascending, BWD
 // descending); t_idx/w_idx are the FULL list arrays, t_ptr/w_ptr their per-level pointers (device)
@@ -91,7 +89,6 @@ void gather_chain(hipStream_t s, GatherMode m, const GatherArgs &a, const int *t
                   const int *w_idx, const int *w_ptr, int l0, int l1);
 // T + W + B lists of one level in a single launch (B rows still need gather_Bprep first)
 void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t, ListView w, ChunkView c);
-void gather_B(hipStream_t s, GatherMode m, const GatherArgs &a, ChunkView chunks);
 // ||v[rows]||inf of a short row list into the slots (the B rows of a SYMV)
 void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long *nrm, int *nan);
 

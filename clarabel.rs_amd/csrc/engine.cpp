@@ -190,6 +190,27 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         bundles.blvl = lv;
         bundles.max_nodes = S.max_bundle_nodes;
     }
+    if (S.topblk > 0) {
+        int *rs = nullptr, *ls = nullptr;
+        double *T = nullptr;
+        if ((rc = upload(&rs, S.Rsplit, S.Rsplit.size()))) return rc;
+        if ((rc = upload(&ls, S.Lsplit, S.Lsplit.size()))) return rc;
+        topblk.w = S.topblk;
+        topblk.NF = S.NF;
+        topblk.N = S.N;
+        topblk.nblocks = (S.N - S.NF + S.topblk - 1) / S.topblk;
+        if ((rc = alloc(&T, (size_t)topblk.nblocks * S.topblk * (S.topblk - 1) / 2))) return rc;
+        topblk.Rsplit = rs;
+        topblk.Lsplit = ls;
+        topblk.T = T;
+        double *ysb = nullptr;
+        int *cnt = nullptr;
+        if ((rc = alloc(&ysb, (size_t)topblk.nblocks * S.topblk))) return rc;
+        if ((rc = alloc(&cnt, (size_t)topblk.nblocks))) return rc;
+        CHIP_HIP(hipMemset(cnt, 0, (size_t)topblk.nblocks * sizeof(int)));
+        topblk.ys = ysb;
+        topblk.counters = cnt;
+    }
     if ((rc = alloc(&mb_dev, 1))) return rc;
     CHIP_HIP(hipMemset(mb_dev, 0, sizeof(Mailbox)));
     CHIP_HIP(hipHostMalloc((void **)&mb_host, sizeof(Mailbox), hipHostMallocDefault));
@@ -292,6 +313,7 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
         }
         l++;
     }
+    dev::topblk_build(stream, v, topblk); // inverses of the diagonal blocks of a tall top
     dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
     dev::gather_values(stream, Ux, Kx, Umap, (int)nnzU);
     int rc = read_mailbox();
@@ -311,6 +333,13 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
 void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
     const dev::LdlView v = view();
     dev::bundle_fwd(stream, v, bundles, xp);
+    if (topblk.nblocks) { // tall top: one dependent step per block of rows instead of per level
+        dev::topblk_solve(stream, dev::FWD, v, topblk, xp);
+        dev::topblk_solve(stream, dev::BWD, v, topblk, xp);
+        dev::bundle_bwd(stream, v, bundles, xp, addv);
+        if (addv && N > NF) dev::add_vec(stream, xp + NF, addv + NF, N - NF);
+        return;
+    }
     dev::GatherArgs f{Rp, Rcol, Rx, xp, xp, nullptr, nullptr, nullptr};
     for (int l = 0; l < nlevels;) {
         const int e = fwd.chain_end[l];

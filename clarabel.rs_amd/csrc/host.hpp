@@ -69,6 +69,15 @@ struct Symbolic {
     std::vector<i32> blvl_ptr, blvl;  // per bundle: boundaries of its levels (absolute node ids)
     i32 max_bundle_nodes = 0;
     i32 nlevels = 0;                  // number of TOP levels
+    // Blocked substitution for a TALL top (chain-like trees: thousands of sequential levels).  The
+    // top rows [NF, N) are cut into blocks of TOPBLK consecutive rows (the numbering is topological,
+    // so any consecutive range works); the unit-lower diagonal block of L of every block is inverted
+    // once per refactor, and a sweep then needs one dependent step per BLOCK instead of per level.
+    // topblk = 0: not used.  Rsplit[j - NF]: first CSR slot of row j whose column lies in j's block
+    // (the external prefix ends there); Lsplit[j - NF]: first CSC slot of column j whose row lies
+    // beyond j's block.
+    i32 topblk = 0;
+    std::vector<i32> Rsplit, Lsplit;
     std::vector<i32> lvlptr;
     // K for the residual e = b - K x, permuted numbering; *map = index into the caller's
     // K.nzval (values are refreshed by a gather at every refactor):

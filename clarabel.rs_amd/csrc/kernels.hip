@@ -1111,6 +1111,116 @@ __global__ __launch_bounds__(1024) void k_chain(GatherArgs a, const int *__restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// Blocked substitution over a tall top (chain-like elimination trees: config 2 has ~4400
+// sequential top levels).  L = [L_11 0; L_21 L_22] with unit-lower diagonal blocks of TOPBLK rows:
+//   forward   y_b = (I + L_bb)^-1 (b_b - L_b,<b y_<b)
+//   backward  x_b = (I + L_bb)^-T (D_b^-1 y_b - L_>b,b' x_>b)
+// T_b = (I + L_bb)^-1 is formed once per refactor, so a sweep has one dependent step per block
+// of 128 rows instead of one per elimination-tree level.
+// ---------------------------------------------------------------------------
+constexpr int TOPBLK = 128;
+constexpr int TOPBLK_PACK = TOPBLK * (TOPBLK - 1) / 2;
+__device__ __forceinline__ int tri_idx(int i, int k) { return i * (i - 1) / 2 + k; } // k < i
+// one workgroup per block: M = strictly-lower part of L_bb (dense, packed) in LDS, then
+// T = (I + M)^-1 column by column (columns are independent: no barriers), packed by rows
+__global__ __launch_bounds__(WG) void k_topblk_build(LdlView v, TopBlkView tb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *M = (double *)smem, *T = M + TOPBLK_PACK;
+    const int b = blockIdx.x, r0 = tb.NF + b * tb.w, w = min(tb.w, tb.N - r0), tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < TOPBLK_PACK; i += WG) M[i] = 0.0;
+    __syncthreads();
+    for (int i = wv; i < w; i += WG / 64) {
+        const int j = r0 + i;
+        for (int t = tb.Rsplit[j - tb.NF] + lane; t < v.Rp[j + 1]; t += 64) M[tri_idx(i, v.Rcol[t] - r0)] = v.Rx[t];
+    }
+    __syncthreads();
+    // column c of T: T[i][c] = -(M[i][c] + sum_{c < k < i} M[i][k] T[k][c])
+    for (int c = tid; c < w; c += WG) {
+        for (int i = c + 1; i < w; ++i) {
+            double s = M[tri_idx(i, c)];
+            for (int k = c + 1; k < i; ++k) s += M[tri_idx(i, k)] * T[tri_idx(k, c)];
+            T[tri_idx(i, c)] = -s;
+        }
+    }
+    __syncthreads();
+    double *out = tb.T + (size_t)b * TOPBLK_PACK;
+    const int np = w * (w - 1) / 2;
+    for (int i = tid; i < np; i += WG) out[i] = T[i];
+}
+// One launch per block, in sweep order on the stream.  The rows of the block are spread over
+// workgroups (a wavefront per row: the external part of the row, 4 entries per lane in flight) so
+// that the whole GPU streams them; the workgroup that finishes last (agent-scope ticket) applies
+// the inverted diagonal block from LDS and publishes the block's slice of x.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_topblk_step(LdlView v, TopBlkView tb, double *x, int b, double *ysg,
+                                                    int *counters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *T = (double *)smem, *ys = T + TOPBLK_PACK;
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r0 = tb.NF + b * tb.w, w = min(tb.w, tb.N - r0), np = w * (w - 1) / 2;
+    const int i = blockIdx.x * 16 + wv; // 16 wavefronts = 16 rows per workgroup
+    if (i < w) {
+        const int j = r0 + i;
+        int t, e;
+        const int *idx;
+        const double *val;
+        if (MODE == FWD) {
+            t = v.Rp[j];
+            e = tb.Rsplit[j - tb.NF];
+            idx = v.Rcol;
+            val = v.Rx;
+        } else {
+            t = tb.Lsplit[j - tb.NF];
+            e = v.Lp[j + 1];
+            idx = v.Li;
+            val = v.Lx;
+        }
+        t += lane;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (; t + 192 < e; t += 256) {
+            const int j0 = idx[t], j1 = idx[t + 64], j2 = idx[t + 128], j3 = idx[t + 192];
+            const double v0 = val[t], v1 = val[t + 64], v2 = val[t + 128], v3 = val[t + 192];
+            s0 += v0 * x[j0];
+            s1 += v1 * x[j1];
+            s2 += v2 * x[j2];
+            s3 += v3 * x[j3];
+        }
+        for (; t < e; t += 64) s0 += val[t] * x[idx[t]];
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) ysg[b * TOPBLK + i] = (MODE == FWD ? x[j] : x[j] * v.Dinv[j]) - s;
+    }
+    __threadfence(); // release this workgroup's rows
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&counters[b], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence(); // acquire every other workgroup's rows
+    const double *Tg = tb.T + (size_t)b * TOPBLK_PACK;
+    for (int k = tid; k < np; k += 1024) T[k] = Tg[k];
+    for (int k = tid; k < w; k += 1024) ys[k] = __hip_atomic_load(&ysg[b * TOPBLK + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // x_b = T y (forward: lower triangle, unit diagonal) or T' y (backward); 8 threads per row
+    {
+        const int r = tid >> 3, sub = tid & 7;
+        double s = 0.0;
+        if (r < w) {
+            if (MODE == FWD) {
+                for (int k = sub; k < r; k += 8) s += T[tri_idx(r, k)] * ys[k];
+            } else {
+                for (int k = r + 1 + sub; k < w; k += 8) s += T[tri_idx(k, r)] * ys[k];
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (r < w && sub == 0) x[r0 + r] = ys[r] + s;
+    }
+    if (tid == 0) counters[b] = 0; // ready for the next sweep
+}
+
 __global__ __launch_bounds__(WG) void k_norm_rows(const double *__restrict__ vv, const int *__restrict__ rows,
                                                   int count, unsigned long long *nrm, int *nan) {
     const int t = blockIdx.x * WG + threadIdx.x;
@@ -2954,6 +3064,29 @@ void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t,
     const int nbT = t.count ? grid_for(t.count) : 0;
     const int grid = off8 + nbT;
     DISPATCH_MODE(k_gather_merged, grid, a, t.idx, t.count, w.idx, w.count, c.row, c.beg, c.end, c.count, off8)
+}
+void topblk_build(hipStream_t s, const LdlView &v, const TopBlkView &tb) {
+    if (!tb.nblocks) return;
+    const size_t lds = (size_t)2 * TOPBLK_PACK * sizeof(double);
+    (void)hipFuncSetAttribute((const void *)k_topblk_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_topblk_build<<<tb.nblocks, WG, lds, s>>>(v, tb);
+}
+void topblk_solve(hipStream_t s, GatherMode m, const LdlView &v, const TopBlkView &tb, double *x) {
+    if (!tb.nblocks) return;
+    const size_t lds = (size_t)(TOPBLK_PACK + TOPBLK) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)k_topblk_step<FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_topblk_step<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    for (int step = 0; step < tb.nblocks; ++step) {
+        const int b = m == FWD ? step : tb.nblocks - 1 - step;
+        const int w = std::min(tb.w, tb.N - (tb.NF + b * tb.w));
+        const int grid = (w + 15) / 16;
+        if (m == FWD) k_topblk_step<FWD><<<grid, 1024, lds, s>>>(v, tb, x, b, tb.ys, tb.counters);
+        else k_topblk_step<BWD><<<grid, 1024, lds, s>>>(v, tb, x, b, tb.ys, tb.counters);
+    }
 }
 void factor_chain(hipStream_t s, const LdlView &v, const int *t_idx, const int *t_ptr, const int *w_idx,
                   const int *w_ptr, int l0, int l1) {

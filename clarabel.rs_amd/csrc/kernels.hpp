@@ -29,6 +29,16 @@ struct BundleView {
     int max_nodes;
 };
 
+// Blocked substitution over a tall top (host.hpp: Symbolic::topblk): block b = rows
+// [NF + b*w, min(N, NF + (b+1)*w)); T = per block the strictly-lower part of (I + L_bb)^-1, packed by
+// rows ((i, k), k < i at i(i-1)/2 + k), w(w-1)/2 doubles per block
+struct TopBlkView {
+    int nblocks, w, NF, N;
+    const int *Rsplit, *Lsplit; // indexed by j - NF
+    double *T;
+    double *ys;    // nblocks * w: the blocks' intermediate right-hand sides
+    int *counters; // nblocks arrival tickets (zero between sweeps)
+};
 struct ListView {
     const int *idx; // T or W rows
     int count;
@@ -82,6 +92,9 @@ constexpr int NRM_STRIDE = 16; // in u64 words: one slot per 128-byte line
 void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView rows);
 // levels [l0, l1) of a chain-like stretch in ONE single-workgroup launch (FWD ascending, BWD
 // descending); t_idx/w_idx are the FULL list arrays, t_ptr/w_ptr their per-level pointers (device)
+// invert the diagonal blocks of L (after a refactor) / sweep the top block by block
+void topblk_build(hipStream_t s, const LdlView &v, const TopBlkView &tb);
+void topblk_solve(hipStream_t s, GatherMode m, const LdlView &v, const TopBlkView &tb, double *x);
 // levels [l0, l1) of a chain-like stretch of the factorisation in ONE single-workgroup launch
 void factor_chain(hipStream_t s, const LdlView &v, const int *t_idx, const int *t_ptr, const int *w_idx,
                   const int *w_ptr, int l0, int l1);

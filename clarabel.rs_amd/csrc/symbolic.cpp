@@ -33,6 +33,7 @@ namespace {
 constexpr i32 T_MAX = 32;      // <= T_MAX entries: one thread per row
 constexpr i32 B_MIN = 16384;   // >  B_MIN entries: split over workgroups
 constexpr i32 B_CHUNK = 4096;  // entries per B chunk
+constexpr i32 TOPBLK = 128;       // rows per block of the blocked top substitution (kernels.hip: TOPBLK)
 constexpr i64 F_MIN_WORK = 16384;    // factor: a column with more (contribution, tail entry) updates than this
 constexpr i64 F_CHUNK_WORK = 4096;   // ... is split over workgroups in chunks of about this many updates
 constexpr i32 FAC_T_ROW = 8;   // factor: thread-per-column if contributions <= this
@@ -457,6 +458,24 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         };
         sort_rows(S.Up, NFi, S.Ucol, S.Umap);
         sort_rows(S.Sp, (i32)n, S.Scol, S.Smap);
+    }
+    // ---- blocked substitution for tall tops -----------------------------------
+    {
+        const i32 ntop = (i32)n - S.NF;
+        const bool off = std::getenv("CHIP_NO_TOPBLK") != nullptr;
+        if (!off && ntop >= 4 * TOPBLK && nlevels >= 256) {
+            S.topblk = TOPBLK;
+            S.Rsplit.resize((size_t)ntop);
+            S.Lsplit.resize((size_t)ntop);
+            for (i32 j = S.NF; j < n; j++) {
+                const i32 b = (j - S.NF) / TOPBLK, r0 = S.NF + b * TOPBLK;
+                const i32 r1 = std::min<i32>((i32)n, r0 + TOPBLK);
+                const i32 *rb = S.Rcol.data() + S.Rp[j], *re = S.Rcol.data() + S.Rp[j + 1];
+                S.Rsplit[j - S.NF] = (i32)(std::lower_bound(rb, re, r0) - S.Rcol.data());
+                const i32 *cb = S.Li.data() + S.Lp[j], *ce = S.Li.data() + S.Lp[j + 1];
+                S.Lsplit[j - S.NF] = (i32)(std::lower_bound(cb, ce, r1) - S.Li.data());
+            }
+        }
     }
     // ---- per-level work lists ----------------------------------------------
     {

@@ -196,6 +196,14 @@ def test_c2_random_qp(hip, oracle, late):
     _check_update_and_solve(hip, oracle, problems.random_qp(3000, 6000, band=20, seed=1, late=late))
 
 
+def test_c2_tall_top_blocked_substitution(hip, oracle):
+    """a banded QP whose elimination tree has a tall top (~2200 sequential levels, ~6800 rows): the
+    substitutions run block by block with inverted 128-row diagonal blocks (k_topblk_*)"""
+    pr = problems.random_qp(20000, 40000, band=50, seed=1)
+    ks, ko = _check_update_and_solve(hip, oracle, pr, nrhs=2)
+    assert ks.N - ks.NF >= 4 * 128
+
+
 @pytest.mark.parametrize("late", [False, True])
 def test_c3_portfolio_socp(hip, oracle, late):
     ks, ko = _check_update_and_solve(hip, oracle, problems.portfolio_socp(12, 300, seed=3, late=late))

@@ -463,7 +463,11 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     {
         const i32 ntop = (i32)n - S.NF;
         const bool off = std::getenv("CHIP_NO_TOPBLK") != nullptr;
-        if (!off && ntop >= 4 * TOPBLK && nlevels >= 256) {
+        // worthwhile only for chain-like tops: a block step costs ~3x a level step, so the number of
+        // blocks must be well below the number of levels (config 2: 272 blocks for 4383 levels;
+        // config 5's wide levels -- 200 rows each -- stay level scheduled)
+        const i64 nblk = (ntop + TOPBLK - 1) / TOPBLK;
+        if (!off && ntop >= 4 * TOPBLK && nlevels >= 256 && 3 * nblk < (i64)nlevels) {
             S.topblk = TOPBLK;
             S.Rsplit.resize((size_t)ntop);
             S.Lsplit.resize((size_t)ntop);

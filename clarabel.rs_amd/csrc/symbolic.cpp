@@ -35,7 +35,7 @@ constexpr i32 B_MIN = 16384;   // >  B_MIN entries: split over workgroups
 constexpr i32 B_CHUNK = 4096;  // entries per B chunk
 constexpr i32 TOPBLK = 128;       // rows per block of the blocked top substitution (kernels.hip: TOPBLK)
 constexpr i64 F_MIN_WORK = 16384;    // factor: a column with more (contribution, tail entry) updates than this
-constexpr i64 F_CHUNK_WORK = 4096;   // ... is split over workgroups in chunks of about this many updates
+constexpr i64 F_CHUNK_MIN = 1024, F_CHUNK_MAX = 4096, F_CHUNK_PARTS = 96;  // ... is split over workgroups in chunks of about this many updates
 constexpr i32 FAC_T_ROW = 8;   // factor: thread-per-column if contributions <= this
 constexpr i32 FAC_T_COL = 48;  // ... and column length <= this
 // subtree bundles (one workgroup each; the vector slice of a bundle is staged in LDS)
@@ -112,11 +112,13 @@ struct ListBuilder {
         }
     }
     // chunks of a column of the factorisation balanced by WORK: contribution t of column j updates
-    // tail(t) = Lp[k+1] - (Rpos[t]+1) entries; a chunk closes at B_CHUNK contributions or
-    // F_CHUNK_WORK updates, whichever comes first
+    // tail(t) = Lp[k+1] - (Rpos[t]+1) entries; a chunk closes at B_CHUNK contributions or at its
+    // share of the column's updates (about 1/96 of them, between 1024 and 4096: a 33k-update column
+    // of config 2 becomes ~32 chunks, an 800k-update dense PSD column of config 5 ~200)
     void add_B_work(i32 r, i64 beg, i64 end, const std::vector<i32> &Rcol, const std::vector<i32> &Rpos,
-                    const std::vector<i32> &Lp) {
+                    const std::vector<i32> &Lp, i64 total_work) {
         L.br_idx.push_back(r);
+        const i64 F_CHUNK_WORK = std::min(F_CHUNK_MAX, std::max(F_CHUNK_MIN, total_work / F_CHUNK_PARTS));
         i64 b = beg, work = 0;
         for (i64 t = beg; t < end; t++) {
             work += Lp[Rcol[t] + 1] - (Rpos[t] + 1) + 1;
@@ -490,9 +492,10 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 // factor: column j gathers rj contributions into cj targets; heavy columns (many
                 // contributions, or long tails: dense fronts) are spread over workgroups
                 i64 work = 0;
-                if (rj > FAC_T_ROW && (i64)rj * cj > F_MIN_WORK)
-                    for (i32 t = S.Rp[j]; t < S.Rp[j + 1]; t++) work += S.Lp[S.Rcol[t] + 1] - (S.Rpos[t] + 1);
-                if (rj > B_MIN || work > F_MIN_WORK) fac.add_B_work(j, S.Rp[j], S.Rp[j + 1], S.Rcol, S.Rpos, S.Lp);
+                if (rj > B_MIN || (rj > FAC_T_ROW && (i64)rj * cj > F_MIN_WORK))
+                    for (i32 t = S.Rp[j]; t < S.Rp[j + 1]; t++) work += S.Lp[S.Rcol[t] + 1] - (S.Rpos[t] + 1) + 1;
+                if (rj > B_MIN || work > F_MIN_WORK)
+                    fac.add_B_work(j, S.Rp[j], S.Rp[j + 1], S.Rcol, S.Rpos, S.Lp, work);
                 else if (rj <= FAC_T_ROW && cj <= FAC_T_COL) fac.add_T(j);
                 else fac.add_W(j);
                 // forward substitution: row j of L

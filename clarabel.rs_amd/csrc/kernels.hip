@@ -10,19 +10,26 @@
 //     (coalesced) and the blockIdx -> slab map is XCD-aware: hardware block b
 //     runs on XCD b%8, so logical block (b%8)*per + b/8 gives every XCD (own
 //     L2) one contiguous slab of rows;
-//   * all cross-row dependencies are resolved by kernel boundaries (one launch
-//     per elimination-tree level, ~1.5us each) -- cheaper than any grid barrier
-//     on this part (MI355X_MICROARCH.md price list) and placement independent;
-//   * rows too long for one workgroup (the 10^6-entry budget row) are split in
-//     chunks over many workgroups whose partial sums meet in one fp64 atomic
-//     per chunk, never one atomic per entry.
+//   * the bottom of the elimination tree is cut into subtree bundles: ONE
+//     workgroup factors / solves a bundle start to finish with its vector slice
+//     in LDS and __syncthreads() between levels; only the remaining ancestors
+//     (the "top") resolve dependencies by kernel boundaries (one launch per
+//     level, ~1.5us each -- cheaper than any grid barrier on this part,
+//     MI355X_MICROARCH.md price list), by single-workgroup chain kernels over
+//     runs of narrow levels, or block by block with inverted diagonal blocks;
+//   * rows / columns too heavy for one workgroup (the 10^6-entry budget row,
+//     dense-front columns) are split in work-balanced chunks over many
+//     workgroups whose partial results meet in one fp64 atomic per chunk or
+//     per row, never one global atomic per entry.
 //
 // Reference semantics restated (citations relative to /root/reference/src):
 //   numeric LDL' + pivot rule   qdldl/qdldl.rs:469-669  (rule :645-651)
 //   L / D L' solves             qdldl/qdldl.rs:708-768
 //   symv for refinement         algebra/csc/matrix_math.rs:178-208
-//   NN / SOC scaling + Hs       solver/core/cones/nonnegativecone.rs:77-108,
-//                               solver/core/cones/socone.rs:134-256
+//   cone scalings, Hs, step     solver/core/cones/{nonnegative,so,exp,pow,genpow,
+//   operations, barriers        psdtriangle}cone.rs, symmetric_common.rs,
+//                               nonsymmetric_common.rs, compositecone.rs
+//   sparse gemv, dots, waxpby   algebra/csc/matrix_math.rs:258-343, vecmath.rs
 #include "kernels.hpp"
 
 #include <algorithm>

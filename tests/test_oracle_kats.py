@@ -445,3 +445,106 @@ def test_cone_step_ops_identities(oracle):
     am2, _ = cones.margins(z + 1.001 * a * dz)
     ams2, _ = cones.margins(s + 1.001 * a * ds)
     assert min(am2, ams2) < 0
+
+
+def test_genpow_cone_identities(oracle):
+    """GenPowerCone (genpowcone.rs): no unit KATs in the reference, so cross-checks that do not go
+    through the restatement's formulas: grad = gradient of the dual barrier f*(z) (finite
+    differences of barrier_dual), <grad, z> = -(dim1 + 1), Hs = mu * Hessian (finite differences
+    of grad), and the KKT solve through the rank-3 sparse expansion [q, r, p] (datamaps.rs:227-343)
+    equal to a dense solve with the unexpanded Hs"""
+    rng = np.random.default_rng(12)
+    d1, d2 = 4, 3
+    a = rng.uniform(0.3, 1.0, d1)
+    a /= a.sum()
+    a[-1] = 1.0 - a[:-1].sum()
+    cones_spec = [(oracle.CONE_GENPOW, d1, d2, list(a))]
+    m = d1 + d2
+
+    def interior():
+        u = rng.uniform(0.8, 2.0, d1)
+        w = rng.standard_normal(d2)
+        w *= 0.4 * np.prod((u / a) ** a) / np.linalg.norm(w)
+        return np.concatenate([u, w])
+
+    z, s = interior(), interior()
+    mu = 0.37
+
+    def grad_at(zz):
+        c = oracle.Cones(cones_spec)
+        assert c.update_scaling(s, zz, mu, 1)
+        sh, _, _ = c.combined_ds_shift(np.zeros(m), np.zeros(m), 1.0)  # shift = grad * sigma_mu
+        return sh
+
+    def fstar(zz):  # dual barrier (genpowcone.rs:333-356) written out independently
+        phi = np.prod((zz[:d1] / a) ** (2 * a))
+        return -np.log(phi - zz[d1:] @ zz[d1:]) - np.sum((1 - a) * np.log(zz[:d1]))
+
+    g = grad_at(z)
+    h = 1e-6
+    gfd = np.array([(fstar(z + h * e) - fstar(z - h * e)) / (2 * h) for e in np.eye(m)])
+    assert np.max(np.abs(g - gfd)) <= 1e-7 * max(1.0, np.max(np.abs(g)))
+    assert abs(g @ z + (d1 + 1)) <= 1e-12
+    cones = oracle.Cones(cones_spec)
+    assert cones.update_scaling(s, z, mu, 1)
+    Hs = np.column_stack([cones.mul_Hs(e) for e in np.eye(m)])
+    Hfd = np.column_stack([(grad_at(z + h * e) - grad_at(z - h * e)) / (2 * h) for e in np.eye(m)])
+    assert np.allclose(Hs, Hs.T, atol=1e-12)
+    assert np.max(np.abs(Hs - mu * Hfd)) <= 1e-6 * np.max(np.abs(Hs))
+    # sparse expansion == dense Hs in the KKT solve
+    n = 3
+    A = rng.standard_normal((m, n))
+    Pd = np.diag(rng.uniform(1.0, 2.0, n))
+    st = oracle.Settings.default()
+    st.static_reg_enable = 0
+    ks = oracle.KKTSolver(n, m, _dense_to_csc(np.triu(Pd)), _dense_to_csc(A), cones, settings=st)
+    assert ks.p == 3
+    assert ks.update()
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    ks.setrhs(rx, rz)
+    ok, x, zz = ks.solve()
+    Kd = np.block([[Pd, A.T], [A, -Hs]])
+    ref = np.linalg.solve(Kd, np.concatenate([rx, rz]))
+    assert ok and np.max(np.abs(np.concatenate([x, zz]) - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("n", [2, 5, 17])
+def test_psd_numpy_oracle_identities(oracle, n):
+    """oracle/psd_numpy.py (PSDTriangleCone): Nesterov-Todd identities Hs z = s and
+    lambda = W z = W^-T s (diagonal), W^-1 = inverse of W, Hs = skron(R R') consistent with mul_Hs,
+    step length = distance to the boundary, margins / barrier against direct eigenvalues"""
+    from oracle import psd_numpy as PN
+    rng = np.random.default_rng(n)
+
+    def rand_pd():
+        G = rng.standard_normal((n, n))
+        return G @ G.T + n * np.eye(n)
+
+    S, Z = rand_pd(), rand_pd()
+    s, z = PN.mat_to_svec(S), PN.mat_to_svec(Z)
+    assert np.allclose(PN.svec_to_mat(s, n), S) and abs(s @ z - np.trace(S @ Z)) <= 1e-10 * abs(s @ z)
+    c = PN.PSDCone(n)
+    assert c.update_scaling(s, z)
+    assert np.max(np.abs(c.mul_Hs(z) - s)) <= 1e-10 * np.max(np.abs(s))
+    lam1, lam2 = c.mul_W(False, z), c.mul_Winv(True, s)
+    L = np.diag(c.lam)
+    assert np.max(np.abs(PN.svec_to_mat(lam1, n) - L)) <= 1e-9 * c.lam.max()
+    assert np.max(np.abs(PN.svec_to_mat(lam2, n) - L)) <= 1e-9 * c.lam.max()
+    assert np.all(np.diff(c.lam) <= 0)  # descending, the convention shared with the device
+    v = rng.standard_normal(c.numel)
+    assert np.max(np.abs(c.mul_Winv(False, c.mul_W(False, v)) - v)) <= 1e-9 * np.max(np.abs(v))
+    # Hs block (packed triu) == matrix of mul_Hs
+    H = np.column_stack([c.mul_Hs(e) for e in np.eye(c.numel)])
+    r, cc = np.tril_indices(c.numel)
+    assert np.max(np.abs(c.get_Hs() - H[cc, r])) <= 1e-10 * np.max(np.abs(H))
+    # step length: z + alpha dz hits the boundary of the cone exactly at alpha
+    dz = PN.mat_to_svec(-rand_pd())
+    ds = np.zeros(c.numel)
+    alpha = c.step_length(dz, ds, 1e9)
+    emin = np.linalg.eigvalsh(PN.svec_to_mat(z + alpha * dz, n)).min()
+    assert abs(emin) <= 1e-7 * np.linalg.eigvalsh(Z).max()
+    a, b = c.margins(z)
+    ev = np.linalg.eigvalsh(Z)
+    assert abs(a - ev.min()) <= 1e-10 * ev.max() and abs(b - ev.sum()) <= 1e-10 * ev.sum()
+    bar = c.compute_barrier(z, s, np.zeros(c.numel), np.zeros(c.numel), 0.0)
+    assert abs(bar + np.log(np.linalg.det(Z)) + np.log(np.linalg.det(S))) <= 1e-8 * abs(bar)

@@ -18,6 +18,7 @@ std::string hip_err(hipError_t e, const char *what) {
 Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     for (hipEvent_t ev : prof_events) (void)hipEventDestroy(ev);
+    for (SolveGraph &g : graphs) (void)hipGraphExecDestroy(g.exec);
     for (void *p : allocs) (void)hipFree(p);
     if (mb_host) (void)hipHostFree(mb_host);
     if (nrm_host) (void)hipHostFree(nrm_host);
@@ -135,6 +136,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         CHIP_HIP(hipGetDevice(&device));
     }
     CHIP_HIP(hipStreamCreate(&stream));
+    dev::solve_kernel_attributes();
     N = S.N;
     nlevels = S.nlevels;
     nnzK = S.nnzK;
@@ -331,6 +333,32 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
 
 // qdldl.rs:755-768 in the permuted numbering, in place
 void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
+    if (st.use_graph && prof_family == PF_NONE) {
+        for (const SolveGraph &g : graphs)
+            if (g.xp == xp && g.addv == addv) {
+                if (hipGraphLaunch(g.exec, stream) == hipSuccess) return;
+                break;
+            }
+        if (graphs.size() < 16) { // the refinement rotates three vectors: a handful of pairs at most
+            hipGraph_t gr = nullptr;
+            hipGraphExec_t ex = nullptr;
+            if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                enqueue_solve_direct(xp, addv);
+                const bool ok = hipStreamEndCapture(stream, &gr) == hipSuccess && gr &&
+                                hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) == hipSuccess;
+                if (gr) (void)hipGraphDestroy(gr);
+                if (ok && hipGraphLaunch(ex, stream) == hipSuccess) {
+                    graphs.push_back({xp, addv, ex});
+                    return;
+                }
+                if (ex) (void)hipGraphExecDestroy(ex);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    enqueue_solve_direct(xp, addv);
+}
+void Engine::enqueue_solve_direct(double *xp, const double *addv) {
     const dev::LdlView v = view();
     dev::bundle_fwd(stream, v, bundles, xp);
     if (topblk.nblocks) { // tall top: one dependent step per block of rows instead of per level

@@ -77,6 +77,14 @@ struct Engine {
     bool factored = false;
     i64 last_regularize_count = 0;
     std::vector<void *> allocs;
+    // settings.use_graph: the launch sequence of one LDL' solve captured once per (vector, addend)
+    // pair and replayed as a hipGraph (hundreds of launches for a tall top)
+    struct SolveGraph {
+        double *xp;
+        const double *addv;
+        hipGraphExec_t exec;
+    };
+    std::vector<SolveGraph> graphs;
     // profiling
     int prof_family = PF_NONE;
     std::vector<hipEvent_t> prof_events; // pairs
@@ -100,6 +108,7 @@ struct Engine {
     int refactor(bool static_reg, const int *diag_idx_dev);
     // xp <- K^-1 xp (permuted numbering); with addv the result is xp <- K^-1 xp + addv
     void enqueue_solve_inplace(double *xp, const double *addv = nullptr);
+    void enqueue_solve_direct(double *xp, const double *addv);
     // e = b - K x (permuted numbering); ||e||inf is folded into norm set `set` (>= 0)
     void enqueue_residual(double *e, const double *b, const double *x, int set);
     int zero_norm_sets();                                                    // enqueue

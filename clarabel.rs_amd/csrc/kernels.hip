@@ -3078,15 +3078,16 @@ void topblk_build(hipStream_t s, const LdlView &v, const TopBlkView &tb) {
     (void)hipFuncSetAttribute((const void *)k_topblk_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     k_topblk_build<<<tb.nblocks, WG, lds, s>>>(v, tb);
 }
+// kernels of the solve sequence that need more than 64 KB of dynamic LDS: allowed once per process,
+// outside any stream capture
+void solve_kernel_attributes() {
+    const size_t lds = (size_t)(TOPBLK_PACK + TOPBLK) * sizeof(double);
+    (void)hipFuncSetAttribute((const void *)k_topblk_step<FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_topblk_step<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 void topblk_solve(hipStream_t s, GatherMode m, const LdlView &v, const TopBlkView &tb, double *x) {
     if (!tb.nblocks) return;
     const size_t lds = (size_t)(TOPBLK_PACK + TOPBLK) * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)k_topblk_step<FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)k_topblk_step<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
     for (int step = 0; step < tb.nblocks; ++step) {
         const int b = m == FWD ? step : tb.nblocks - 1 - step;
         const int w = std::min(tb.w, tb.N - (tb.NF + b * tb.w));

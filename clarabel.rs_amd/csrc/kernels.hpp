@@ -93,6 +93,7 @@ void gather_Bprep(hipStream_t s, GatherMode m, const GatherArgs &a, ListView row
 // levels [l0, l1) of a chain-like stretch in ONE single-workgroup launch (FWD ascending, BWD
 // descending); t_idx/w_idx are the FULL list arrays, t_ptr/w_ptr their per-level pointers (device)
 // invert the diagonal blocks of L (after a refactor) / sweep the top block by block
+void solve_kernel_attributes(); // once per process, before the first (possibly captured) solve
 void topblk_build(hipStream_t s, const LdlView &v, const TopBlkView &tb);
 void topblk_solve(hipStream_t s, GatherMode m, const LdlView &v, const TopBlkView &tb, double *x);
 // levels [l0, l1) of a chain-like stretch of the factorisation in ONE single-workgroup launch

@@ -83,7 +83,8 @@ typedef struct {
                                   every numeric call then returns CHIP_ERR_NO_DEVICE) -- the
                                   analogue of the reference's logical factorisation, qdldl.rs:40-42 */
     double amd_dense_scale;    /* 1.5, ldlsolvers/qdldl.rs:41 */
-    int32_t use_graph;         /* capture the per-solve launch sequence in a hipGraph */
+    int32_t use_graph;         /* replay the launch sequence of an LDL' solve as a hipGraph (captured once per
+                                  vector pair); pays off for tall elimination trees (hundreds of launches) */
     int32_t reserved0;
     /* line search of the nonsymmetric cones (settings.rs:96-104), used by chip_kkt_step_length_dev */
     double linesearch_backtrack_step;            /* 0.8    */

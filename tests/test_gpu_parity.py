@@ -196,6 +196,13 @@ def test_c2_random_qp(hip, oracle, late):
     _check_update_and_solve(hip, oracle, problems.random_qp(3000, 6000, band=20, seed=1, late=late))
 
 
+def test_c2_solve_sequence_as_hipgraph(hip, oracle):
+    """settings.use_graph: the launch sequence of the LDL' solves replayed as hipGraphs -- same
+    results as direct launches (several right-hand sides, so every graph is replayed)"""
+    st = hip.Settings.default(use_graph=1)
+    _check_update_and_solve(hip, oracle, problems.random_qp(3000, 6000, band=20, seed=1), nrhs=4, settings=st)
+
+
 def test_c2_tall_top_blocked_substitution(hip, oracle):
     """a banded QP whose elimination tree has a tall top (~2200 sequential levels, ~6800 rows): the
     substitutions run block by block with inverted 128-row diagonal blocks (k_topblk_*)"""

@@ -23,7 +23,7 @@ def run(name, pr, hip, use_oracle, steps=5, hs=None):
     P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
     A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
     st = hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0,
-                              iterative_refinement_abstol=0.0)
+                              iterative_refinement_abstol=0.0, use_graph=1 if "--graph" in sys.argv else 0)
     t0 = time.time()
     ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"], settings=st)
     t_setup = time.time() - t0

@@ -67,6 +67,8 @@ class PSDCone:
     # psdtrianglecone.rs:144-204
     def update_scaling(self, s, z):
         n = self.n
+        if n == 0:  # bail early on a zero-length cone (:151-154)
+            return True
         S, Z = svec_to_mat(s, n), svec_to_mat(z, n)
         try:
             L1, L2 = np.linalg.cholesky(S), np.linalg.cholesky(Z)
@@ -125,6 +127,8 @@ class PSDCone:
         return self.mul_W(True, self.lambda_inv_circ_op(ds))
 
     def _step_component(self, d, amax):  # :437-463
+        if self.n == 0:
+            return amax
         D = svec_to_mat(d, self.n) * self.lisqrt[:, None] * self.lisqrt[None, :]
         gamma = np.linalg.eigvalsh(D).min()
         return min(-1.0 / gamma, amax) if gamma < 0 else amax
@@ -135,6 +139,8 @@ class PSDCone:
         return min(az, as_)
 
     def margins(self, z):  # :104-121
+        if self.n == 0:
+            return 1.7976931348623157e308, 0.0
         e = np.linalg.eigvalsh(svec_to_mat(z, self.n))
         return float(e.min()), float(np.maximum(e, 0.0).sum())
 
@@ -142,6 +148,8 @@ class PSDCone:
         z[self.diag_idx] += alpha
 
     def logdet_barrier(self, x, dx, alpha):  # :289-303
+        if self.n == 0:
+            return 0.0
         Q = svec_to_mat(x + alpha * dx, self.n)
         try:
             L = np.linalg.cholesky(Q)

@@ -620,6 +620,45 @@ def test_genpow_barrier_finite_case(hip, oracle):
         assert np.isfinite(b_ref) and abs(b_dev - b_ref) <= 1e-10 * max(1.0, abs(b_ref))
 
 
+def test_degenerate_cone_dimensions(hip, oracle):
+    """zero-length and one-dimensional cones (tests/basic_sdp.rs test_sdp_empty_cone, NonnegativeConeT(0)):
+    nothing to launch for them, everything else unaffected"""
+    from oracle import psd_numpy
+    cones = [(1, 0), (6, 0), (6, 1), (2, 2), (1, 3), (0, 0), (6, 2)]
+    rng = np.random.default_rng(4)
+    S2, Z2 = np.array([[2.0, 0.3], [0.3, 1.5]]), np.array([[1.2, -0.2], [-0.2, 0.9]])
+    s = np.concatenate([[1.7], [2.0, 0.5], rng.uniform(0.5, 2, 3), psd_numpy.mat_to_svec(S2)])
+    z = np.concatenate([[0.6], [1.5, -0.4], rng.uniform(0.5, 2, 3), psd_numpy.mat_to_svec(Z2)])
+    m, n = len(s), 3
+    import scipy.sparse as sp2
+    A = sp2.csc_matrix(rng.standard_normal((m, n)))
+    P = sp2.identity(n, format="csc")
+    pr = dict(n=n, m=m, P=problems._csc(P), A=problems._csc(A), cones=cones)
+    Pm, Am = hip.CscMatrix(n, n, *pr["P"]), hip.CscMatrix(m, n, *pr["A"])
+    ks = hip.HipKKTSolver(Pm, Am, cones, m, n)
+    mc = psd_numpy.MixedCones(oracle, cones)
+    ko = oracle.KKTSolver(n, m, pr["P"], pr["A"], mc.c, perm=ks.perm)
+    assert ks.update_scaling(s, z) and mc.update_scaling(s, z)
+    assert ks.update() and ko.update(mc.get_Hs())
+    assert relerr(ks.values(), ko.kkt.nzval) <= 1e-12
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    ks.setrhs(rx, rz)
+    ko.setrhs(rx, rz)
+    x, zz = np.zeros(n), np.zeros(m)
+    assert ks.solve(x, zz)
+    ok, xo, zo = ko.solve()
+    assert ok and relerr(np.concatenate([x, zz]), np.concatenate([xo, zo])) <= TOL
+    D = hip.DeviceArray
+    v = rng.standard_normal(m)
+    y, d_v = D(m), D(v)
+    ks.mul_Hs_dev(y.ptr, d_v.ptr)
+    assert relerr(y.numpy(), mc.mul_Hs(v)) <= 1e-12
+    d_z = D(z)
+    a_dev, b_dev = ks.margins_dev(d_z.ptr)
+    a_ref, b_ref = mc.margins(z)
+    assert abs(a_dev - a_ref) <= 1e-12 and abs(b_dev - b_ref) <= 1e-12 * max(1.0, b_ref)
+
+
 def test_full_scale_properties_c3(hip):
     """BASELINE config 3 at full size (n = 10^6): too big for the oracle in seconds, so check
     size-independent properties: residual of the refined solution against an independent

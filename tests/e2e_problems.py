@@ -75,3 +75,16 @@ def basic_genpowcone():
     pr = basic_powcone()
     pr["cones"] = [(GENPOW, 2, 1, [0.6, 0.4]), (GENPOW, 2, 1, [0.1, 0.9]), (ZERO, 2)]
     return pr
+
+
+def basic_unconstrained():
+    # tests/basic_unconstrained.rs:4-17: min 0.5 x'x + c'x, no constraints, no cones; x = -c
+    return dict(n=3, m=0, P=_triu(sp.identity(3, format="csc")), A=_csc(sp.csc_matrix((0, 3))),
+                q=[1.0, 2.0, -3.0], b=[], cones=[], x=[-1.0, -2.0, 3.0], obj=-7.0, tol=1e-6)
+
+
+def basic_eq_constrained():
+    # tests/basic_eq_constrained.rs:34-47: min 0.5 x'x s.t. x2 + x3 = 2, x2 - x3 = 0 (ZeroConeT(2))
+    A = np.array([[0.0, 1.0, 1.0], [0.0, 1.0, -1.0]])
+    return dict(n=3, m=2, P=_triu(sp.identity(3, format="csc")), A=_csc(A), q=[0.0, 0.0, 0.0], b=[2.0, 0.0],
+                cones=[(ZERO, 2)], x=[0.0, 1.0, 1.0], obj=1.0, tol=1e-6)

@@ -13,7 +13,8 @@ def _run(oracle, pr, trace=None):
     return ipm.solve(be, pr["cones"], pr["q"], pr["b"], trace=trace)
 
 
-@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp", "basic_genpowcone"])
+@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp", "basic_genpowcone", "basic_unconstrained",
+                                  "basic_eq_constrained"])
 def test_reference_end_to_end_answers(oracle, name):
     pr = getattr(E, name)()
     out = _run(oracle, pr)

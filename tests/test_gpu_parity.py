@@ -753,7 +753,8 @@ def test_l3_kktsystem_and_residuals(hip, oracle, which):
         assert relerr(a.numpy(), c) <= TOL
 
 
-@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp", "basic_genpowcone"])
+@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp", "basic_genpowcone", "basic_unconstrained",
+                                  "basic_eq_constrained"])
 def test_e2e_reference_answers_on_device(hip, oracle, name):
     """the reference's end-to-end known answers (tests/basic_qp.rs:100-117, basic_lp.rs:27-44,
     basic_socp.rs:54-70, basic_expcone.rs:38-56, basic_powcone.rs:4-47, basic_sdp.rs:29-57, basic_genpowcone.rs:4-55) reached with every L1-L3 operation on the device, and the same

@@ -88,3 +88,12 @@ def basic_eq_constrained():
     A = np.array([[0.0, 1.0, 1.0], [0.0, 1.0, -1.0]])
     return dict(n=3, m=2, P=_triu(sp.identity(3, format="csc")), A=_csc(A), q=[0.0, 0.0, 0.0], b=[2.0, 0.0],
                 cones=[(ZERO, 2)], x=[0.0, 1.0, 1.0], obj=1.0, tol=1e-6)
+
+
+def mixed_conic():
+    # tests/mixed_conic.rs:4-45: x in R^3 stacked into Zero(3), NN(3), SOC(3), Pow(0.5), Exp; optimum 0
+    I3 = np.eye(3)
+    A = np.vstack([I3] * 5)
+    return dict(n=3, m=15, P=_triu(sp.identity(3, format="csc")), A=_csc(A), q=[1.0, 1.0, 1.0], b=[0.0] * 15,
+                cones=[(ZERO, 3), (NN, 3), (SOC, 3), (POW, 3, 0, 0.5), (EXP, 3)], x=[0.0, 0.0, 0.0], obj=0.0,
+                tol=1e-8)

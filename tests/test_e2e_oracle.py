@@ -54,3 +54,15 @@ def test_json_fixture_hs35(oracle):
     assert out["status"] == "Solved"
     assert np.linalg.norm(out["x"] - np.array([4.0 / 3.0, 7.0 / 9.0, 4.0 / 9.0])) <= 1e-6
     assert abs(out["obj_val"] + 9.0 - 1.0 / 9.0) <= 1e-6
+
+
+@pytest.mark.parametrize("min_switch", [0.1, 0.999])
+def test_mixed_conic_both_scaling_strategies(oracle, min_switch):
+    """tests/mixed_conic.rs:4-45: Zero + NN + SOC + Power + Exponential in one problem; the second
+    variant (min_switch_step_length = 0.999) forces the dual scaling and the barrier backtracking
+    (solver.rs:571-584) through compute_barrier of every cone type"""
+    pr = E.mixed_conic()
+    be = ipm.OracleBackend(oracle, pr["n"], pr["m"], pr["P"], pr["A"], pr["q"], pr["b"], pr["cones"])
+    out = ipm.solve(be, pr["cones"], pr["q"], pr["b"], min_switch_step_length=min_switch)
+    assert out["status"] == "Solved"
+    assert abs(out["obj_val"]) <= 1e-8 and np.linalg.norm(out["x"]) <= 1e-6

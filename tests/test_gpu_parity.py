@@ -753,6 +753,38 @@ def test_l3_kktsystem_and_residuals(hip, oracle, which):
         assert relerr(a.numpy(), c) <= TOL
 
 
+def test_l3_update_data(hip, oracle):
+    """data_updating.rs:98-133 through chip_kktsystem_update_data: new P / A values on the same patterns
+    and new q / b reach the KKT matrix, the SpMV copies and the RHS algebra"""
+    pr = problems.random_qp(400, 700, band=10, seed=9)
+    ks, sysd, cones, ko, syso, rng = _l3_pair(hip, oracle, pr)
+    n, m = pr["n"], pr["m"]
+    P2 = (pr["P"][0], pr["P"][1], pr["P"][2] * 1.7)
+    A2 = (pr["A"][0], pr["A"][1], pr["A"][2] * rng.uniform(0.5, 1.5, len(pr["A"][2])))
+    q2, b2 = rng.standard_normal(n), rng.standard_normal(m)
+    sysd.update_data(P=P2[2], A=A2[2], q=q2, b=b2)
+    cones2 = oracle.Cones(pr["cones"])
+    ko2 = oracle.KKTSolver(n, m, P2, A2, cones2, perm=ks.perm)
+    syso2 = oracle.KKTSystem(ko2, cones2, n, m, P2, A2, q2, b2)
+    assert ks.update_scaling(pr["s"], pr["z"]) and cones2.update_scaling(pr["s"], pr["z"])
+    assert sysd.update() and syso2.update()
+    assert relerr(ks.values(), ko2.kkt.nzval) <= 1e-13
+    v = oracle.Variables(n, m)
+    v.x, v.s, v.z, v.tau, v.kappa = rng.standard_normal(n), pr["s"].copy(), pr["z"].copy(), 0.9, 1.1
+    ro = syso2.residuals(v)
+    D = hip.DeviceArray
+    rx, rz, rxi, rzi, Px = D(n), D(m), D(n), D(m), D(n)
+    rd = sysd.residuals_update(_dvars(hip, v), rx, rz, rxi, rzi, Px)
+    assert abs(rd["rtau"] - ro["rtau"]) <= 1e-10 * max(1.0, abs(ro["rtau"]))
+    assert relerr(rx.numpy(), ro["rx"]) <= 1e-12 and relerr(rz.numpy(), ro["rz"]) <= 1e-12
+    rhs = oracle.Variables(n, m)
+    rhs.x, rhs.z, rhs.s, rhs.tau, rhs.kappa = ro["rx"], ro["rz"], cones2.affine_ds(pr["s"]), ro["rtau"], 0.99
+    lo, ld = oracle.Variables(n, m), hip.DeviceVariables(n, m)
+    assert syso2.solve(lo, rhs, v, hip.STEP_AFFINE) and sysd.solve(ld, _dvars(hip, rhs), _dvars(hip, v), hip.STEP_AFFINE)
+    assert abs(ld.tau - lo.tau) <= TOL * max(1.0, abs(lo.tau))
+    assert relerr(ld.x.numpy(), lo.x) <= TOL and relerr(ld.z.numpy(), lo.z) <= TOL
+
+
 @pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp", "basic_genpowcone", "basic_unconstrained",
                                   "basic_eq_constrained"])
 def test_e2e_reference_answers_on_device(hip, oracle, name):

@@ -23,7 +23,7 @@
 
 namespace chip {
 
-static std::string g_err;
+static thread_local std::string g_err; // per thread, like errno: handles may live on different threads
 void set_error(const std::string &msg) { g_err = msg; }
 const char *get_error() { return g_err.c_str(); }
 

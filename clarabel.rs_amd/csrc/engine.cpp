@@ -192,6 +192,25 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         bundles.blvl = lv;
         bundles.max_nodes = S.max_bundle_nodes;
     }
+    if (S.nfold > 0) {
+        int *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *a4 = nullptr, *a5 = nullptr;
+        double *ts = nullptr;
+        if ((rc = upload(&a1, S.fold_rseg, S.fold_rseg.size()))) return rc;
+        if ((rc = upload(&a2, S.fold_tt, S.fold_tt.size()))) return rc;
+        if ((rc = upload(&a3, S.fold_sp, S.fold_sp.size()))) return rc;
+        if ((rc = upload(&a4, S.fold_scol, S.fold_scol.size()))) return rc;
+        if ((rc = upload(&a5, S.fold_sslot, S.fold_sslot.size()))) return rc;
+        if ((rc = alloc(&ts, 8))) return rc;
+        CHIP_HIP(hipMemset(ts, 0, 8 * sizeof(double)));
+        fold.k = S.nfold;
+        fold.NF = S.NF;
+        fold.rseg = a1;
+        fold.tt = a2;
+        fold.sp = a3;
+        fold.scol = a4;
+        fold.sslot = a5;
+        fold.tsum = ts;
+    }
     if (S.topblk > 0) {
         int *rs = nullptr, *ls = nullptr;
         double *T = nullptr;
@@ -360,7 +379,13 @@ void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
 }
 void Engine::enqueue_solve_direct(double *xp, const double *addv) {
     const dev::LdlView v = view();
-    dev::bundle_fwd(stream, v, bundles, xp);
+    dev::bundle_fwd(stream, v, bundles, xp, fold);
+    if (fold.k) { // an "arrow": the bundles have already folded the top rows; finish the k x k part
+        dev::fold_top_solve(stream, v, fold, xp);
+        dev::bundle_bwd(stream, v, bundles, xp, addv);
+        if (addv && N > NF) dev::add_vec(stream, xp + NF, addv + NF, N - NF);
+        return;
+    }
     if (topblk.nblocks) { // tall top: one dependent step per block of rows instead of per level
         dev::topblk_solve(stream, dev::FWD, v, topblk, xp);
         dev::topblk_solve(stream, dev::BWD, v, topblk, xp);
@@ -408,11 +433,18 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
         a.nrm = norm_set(set);
         a.nan = norm_nan(set);
     }
+    if (fold.k) { // top rows: bundle shares accumulated by the bundle kernel, finished by one tiny launch
+        prof_begin(PF_SYMV_T);
+        dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, fold);
+        prof_end(PF_SYMV_T);
+        dev::fold_top_residual(stream, fold, Sx, x, b, e, a.nrm, a.nan);
+        return;
+    }
     const dev::ChunkView bc = smv.B(0);
     if (bc.count) dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));
     dev::gather_merged(stream, dev::SYMV, a, smv.T(0), smv.W(0), bc); // the top rows (full rows)
     prof_begin(PF_SYMV_T);
-    dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan); // everything else
+    dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, dev::FoldView{}); // everything else
     prof_end(PF_SYMV_T);
     if (bc.count && set >= 0) dev::norm_rows(stream, e, smv.BR(0), a.nrm, a.nan);
 }

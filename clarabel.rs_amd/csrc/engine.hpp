@@ -63,6 +63,7 @@ struct Engine {
     double *Kx = nullptr, *Lx = nullptr, *Rx = nullptr, *D = nullptr, *Dinv = nullptr, *Sx = nullptr;
     DeviceLists fac, fwd, bwd, smv;
     dev::BundleView bundles{}; // subtree bundles (device arrays)
+    dev::FoldView fold{};      // few dense top rows folded into the bundle kernels (k == 0: not used)
     dev::TopBlkView topblk{};  // blocked substitution of a tall top (nblocks == 0: level-scheduled top)
     int NF = 0, tree_depth = 0;
     std::vector<i32> h_level;

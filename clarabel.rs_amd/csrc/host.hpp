@@ -78,6 +78,15 @@ struct Symbolic {
     // beyond j's block.
     i32 topblk = 0;
     std::vector<i32> Rsplit, Lsplit;
+    // "Arrow" KKTs: a top of at most TOPFOLD_MAX rows (config 3: the single budget row coupling all
+    // cones).  Their long rows are then accumulated by the BUNDLE workgroups while the bundle's slice
+    // of the vector is in LDS, and a one-workgroup kernel finishes the tiny top-top part.
+    //   fold_rseg[(b*k + i)*2 + {0,1}] : CSR slots of row NF+i of L whose columns lie in bundle b
+    //   fold_tt[i*k + j] (i > j)        : CSC slot of L(NF+i, NF+j), -1 if structurally zero
+    //   fold_sp / fold_scol / fold_sslot: per top row the entries of K with both ends in the top
+    //                                     (column index relative to NF, slot in Sx)
+    i32 nfold = 0;
+    std::vector<i32> fold_rseg, fold_tt, fold_sp, fold_scol, fold_sslot;
     std::vector<i32> lvlptr;
     // K for the residual e = b - K x, permuted numbering; *map = index into the caller's
     // K.nzval (values are refreshed by a gather at every refactor):

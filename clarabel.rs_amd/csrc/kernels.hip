@@ -528,7 +528,7 @@ constexpr int ESHOT = 4;
 template <bool FWDMODE>
 __device__ __forceinline__ void bundle_solve_body(const LdlView &v, const BundleView &bv, double *x,
                                                   const double *__restrict__ addv, double *xs, double *red,
-                                                  int *fat, int &nfat) {
+                                                  int *fat, int &nfat, const FoldView &fold) {
     const int b = blockIdx.x;
     const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
     const int *lv = bv.blvl + bv.blvl_ptr[b];
@@ -640,15 +640,36 @@ __device__ __forceinline__ void bundle_solve_body(const LdlView &v, const Bundle
         for (int i = threadIdx.x; i < nloc; i += BWG) x[s0 + i] = xs[i] + addv[s0 + i];
     else
         for (int i = threadIdx.x; i < nloc; i += BWG) x[s0 + i] = xs[i];
+    if (FWDMODE && fold.k > 0) {
+        // the few dense top rows (an "arrow"): this bundle's columns of each of them, gathered from
+        // the slice that is still in LDS; one global atomic per (bundle, top row) onto x[top], which
+        // holds the right-hand side entry
+        for (int i = 0; i < fold.k; ++i) {
+            const int tb = fold.rseg[(b * fold.k + i) * 2], te = fold.rseg[(b * fold.k + i) * 2 + 1];
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int t = tb + (int)threadIdx.x;
+            for (; t + 3 * BWG < te; t += 4 * BWG) {
+                const int j0 = v.Rcol[t], j1 = v.Rcol[t + BWG], j2 = v.Rcol[t + 2 * BWG], j3 = v.Rcol[t + 3 * BWG];
+                const double v0 = v.Rx[t], v1 = v.Rx[t + BWG], v2 = v.Rx[t + 2 * BWG], v3 = v.Rx[t + 3 * BWG];
+                a0 += v0 * xs[j0 - s0];
+                a1 += v1 * xs[j1 - s0];
+                a2 += v2 * xs[j2 - s0];
+                a3 += v3 * xs[j3 - s0];
+            }
+            for (; t < te; t += BWG) a0 += v.Rx[t] * xs[v.Rcol[t] - s0];
+            const double sum = block_sum((a0 + a1) + (a2 + a3), red);
+            if (threadIdx.x == 0 && te > tb) atomicAdd(&x[fold.NF + i], -sum);
+        }
+    }
 }
 template <bool FWDMODE>
 __global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restrict__ addv) {
+void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restrict__ addv, FoldView fold) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[16];
     __shared__ int fat[FATCAP];
     __shared__ int nfat;
-    bundle_solve_body<FWDMODE>(v, bv, x, addv, (double *)smem, red, fat, nfat);
+    bundle_solve_body<FWDMODE>(v, bv, x, addv, (double *)smem, red, fat, nfat, fold);
 }
 
 // B: a column with a huge row count (> 16384 contributions).  Each workgroup
@@ -908,7 +929,8 @@ constexpr int SSHOT = 3; // entries of a row per shot (registers: 2 rows x SSHOT
 __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int *__restrict__ Up,
                                                  const int *__restrict__ Ucol, const double *__restrict__ Ux,
                                                  const double *x, const double *__restrict__ b, double *e,
-                                                 unsigned long long *nrm, int *nanflag, double *es, double *red) {
+                                                 unsigned long long *nrm, int *nanflag, double *es, double *red,
+                                                 const FoldView &fold) {
     const int bid = blockIdx.x;
     const int s0 = bv.bundle_ptr[bid], s1 = bv.bundle_ptr[bid + 1], nloc = s1 - s0;
     const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
@@ -921,6 +943,10 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
         te[u] = i < nloc ? Up[s0 + i + 1] : 0;
     }
     for (int i = threadIdx.x; i < nloc; i += BWG) es[i] = b[s0 + i];
+    // folded top rows: this bundle's share of (K x)[top], per thread, reduced at the end
+    double tpart = 0.0; // fold.k == 1 (the usual arrow): registers
+    __shared__ double tacc[8];
+    if (fold.k > 1 && threadIdx.x < 8) tacc[threadIdx.x] = 0.0;
     __syncthreads();
     // loop bounds are kept wave-uniform (lds_scatter_add uses cross-lane operations)
     for (int w0 = wbase; w0 < nloc; w0 += 2 * BWG) {
@@ -955,7 +981,13 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
                     int tgt = -1;
                     if (j >= 0) {
                         acc[u] += vv[u][q] * x[j];
-                        if (j < s1 && j != s0 + i0 + u * BWG) tgt = j - s0;
+                        if (j < s1) {
+                            if (j != s0 + i0 + u * BWG) tgt = j - s0;
+                        } else if (fold.k == 1) {
+                            tpart += vv[u][q] * xi[u];
+                        } else if (fold.k > 1) {
+                            atomicAdd(&tacc[j - fold.NF], vv[u][q] * xi[u]);
+                        }
                     }
                     lds_scatter_add(es, tgt, -(vv[u][q] * xi[u]));
                 }
@@ -983,14 +1015,59 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
         if (nan) *nanflag = 1;
         if (threadIdx.x == 0) fold_norm(nrm, nanflag, m, false, bid);
     }
+    if (fold.k == 1) {
+        tpart = block_sum(tpart, red);
+        if (threadIdx.x == 0 && tpart != 0.0) atomicAdd(&fold.tsum[0], tpart);
+    } else if (fold.k > 1) {
+        __syncthreads();
+        if ((int)threadIdx.x < fold.k && tacc[threadIdx.x] != 0.0) atomicAdd(&fold.tsum[threadIdx.x], tacc[threadIdx.x]);
+    }
 }
 __global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_bundle_symv(BundleView bv, const int *__restrict__ Up, const int *__restrict__ Ucol,
                    const double *__restrict__ Ux, const double *__restrict__ x,
-                   const double *__restrict__ b, double *e, unsigned long long *nrm, int *nanflag) {
+                   const double *__restrict__ b, double *e, unsigned long long *nrm, int *nanflag,
+                   FoldView fold) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[16];
-    bundle_symv_body(bv, Up, Ucol, Ux, x, b, e, nrm, nanflag, (double *)smem, red);
+    bundle_symv_body(bv, Up, Ucol, Ux, x, b, e, nrm, nanflag, (double *)smem, red, fold);
+}
+// the k x k top-top part of both sweeps of a folded top (k <= 8): forward with the bundle parts already
+// subtracted from x[top], D^-1, backward
+__global__ void k_fold_top_solve(LdlView v, FoldView fold, double *x) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int k = fold.k, NF = fold.NF;
+    double y[8];
+    for (int i = 0; i < k; ++i) {
+        double s = x[NF + i];
+        for (int j = 0; j < i; ++j) {
+            const int q = fold.tt[i * k + j];
+            if (q >= 0) s -= v.Lx[q] * y[j];
+        }
+        y[i] = s;
+    }
+    for (int i = k - 1; i >= 0; --i) {
+        double s = y[i] * v.Dinv[NF + i];
+        for (int j = i + 1; j < k; ++j) {
+            const int q = fold.tt[j * k + i];
+            if (q >= 0) s -= v.Lx[q] * y[j];
+        }
+        y[i] = s; // y now holds x for rows >= i
+    }
+    for (int i = 0; i < k; ++i) x[NF + i] = y[i];
+}
+// residual of the folded top rows: bundle shares from fold.tsum (reset here), top-top entries from S
+__global__ void k_fold_top_residual(FoldView fold, const double *__restrict__ Sx, const double *__restrict__ x,
+                                    const double *__restrict__ b, double *e, unsigned long long *nrm,
+                                    int *nanflag) {
+    const int i = threadIdx.x;
+    if (blockIdx.x != 0 || i >= fold.k) return;
+    double s = fold.tsum[i];
+    fold.tsum[i] = 0.0;
+    for (int t = fold.sp[i]; t < fold.sp[i + 1]; ++t) s += Sx[fold.sslot[t]] * x[fold.NF + fold.scol[t]];
+    const double val = b[fold.NF + i] - s;
+    e[fold.NF + i] = val;
+    if (nrm) fold_norm(nrm, nanflag, val != val ? 0.0 : fabs(val), val != val, i);
 }
 // A run of consecutive NARROW levels (a chain-like stretch of the elimination tree: a handful
 // of rows per level) handled by ONE 1024-thread workgroup that walks the levels with
@@ -3037,17 +3114,25 @@ static size_t bundle_lds(const BundleView &bv) { return ((size_t)bv.max_nodes * 
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv) {
     if (bv.nb) k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv);
 }
-void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x) {
-    if (bv.nb) k_bundle_solve<true><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, nullptr);
+void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const FoldView &fold) {
+    if (bv.nb) k_bundle_solve<true><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, nullptr, fold);
 }
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const double *addv) {
-    if (bv.nb) k_bundle_solve<false><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv);
+    if (bv.nb) k_bundle_solve<false><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv, FoldView{});
+}
+void fold_top_solve(hipStream_t s, const LdlView &v, const FoldView &fold, double *x) {
+    if (fold.k) k_fold_top_solve<<<1, 64, 0, s>>>(v, fold, x);
+}
+void fold_top_residual(hipStream_t s, const FoldView &fold, const double *Sx, const double *x, const double *b,
+                       double *e, unsigned long long *nrm, int *nan) {
+    if (fold.k) k_fold_top_residual<<<1, 64, 0, s>>>(fold, Sx, x, b, e, nrm, nan);
 }
 void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
-                 const double *x, const double *b, double *e, unsigned long long *nrm, int *nan) {
+                 const double *x, const double *b, double *e, unsigned long long *nrm, int *nan,
+                 const FoldView &fold) {
     if (!bv.nb) return;
     const size_t lds = ((size_t)bv.max_nodes * sizeof(double) + 15) & ~(size_t)15; // the e slice only
-    k_bundle_symv<<<bv.nb, BWG, lds, s>>>(bv, Up, Ucol, Ux, x, b, e, nrm, nan);
+    k_bundle_symv<<<bv.nb, BWG, lds, s>>>(bv, Up, Ucol, Ux, x, b, e, nrm, nan, fold);
 }
 void factor_B(hipStream_t s, const LdlView &v, ChunkView c) {
     if (c.count) k_factor_B<<<c.count, WG, 0, s>>>(v, c.row, c.beg, c.end, c.count);

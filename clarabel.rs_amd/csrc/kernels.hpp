@@ -29,6 +29,14 @@ struct BundleView {
     int max_nodes;
 };
 
+// Few dense top rows folded into the bundle kernels (host.hpp: Symbolic::nfold); k == 0: unused
+struct FoldView {
+    int k, NF;
+    const int *rseg;               // (bundle, top row) -> CSR slot range of L
+    const int *tt;                 // k x k CSC slots of the top-top entries of L
+    const int *sp, *scol, *sslot;  // top-top entries of K (slots in Sx)
+    double *tsum;                  // k accumulators of the residual kernel (zero between uses)
+};
 // Blocked substitution over a tall top (host.hpp: Symbolic::topblk): block b = rows
 // [NF + b*w, min(N, NF + (b+1)*w)); T = per block the strictly-lower part of (I + L_bb)^-1, packed by
 // rows ((i, k), k < i at i(i-1)/2 + k), w(w-1)/2 doubles per block
@@ -61,12 +69,18 @@ void scatter_values(hipStream_t s, double *Kx, const int *map, const double *val
 
 // ---- numeric LDL' -------------------------------------------------------------
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv);
-void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x);
+// fold.k > 0: every bundle also subtracts its part of the k top rows of L from x[NF + i]
+void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const FoldView &fold);
+// the k x k top-top part of the forward sweep, D^-1, and the backward sweep, in one tiny launch
+void fold_top_solve(hipStream_t s, const LdlView &v, const FoldView &fold, double *x);
+// e[NF + i] = b - (bundle parts accumulated in fold.tsum) - (top-top part of K) x; ||.||inf folded in
+void fold_top_residual(hipStream_t s, const FoldView &fold, const double *Sx, const double *x, const double *b,
+                       double *e, unsigned long long *nrm, int *nan);
 // addv != nullptr: the bundle rows leave as x + addv (refinement candidate), see Engine::enqueue_solve_inplace
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const double *addv);
 // e[bundle rows] = b - K x with K stored once (U: row i = diagonal + entries to ancestors)
 void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
-                 const double *x, const double *b, double *e, unsigned long long *nrm, int *nan);
+                 const double *x, const double *b, double *e, unsigned long long *nrm, int *nan, const FoldView &fold);
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);
 void factor_B(hipStream_t s, const LdlView &v, ChunkView chunks);

@@ -33,6 +33,7 @@ namespace {
 constexpr i32 T_MAX = 32;      // <= T_MAX entries: one thread per row
 constexpr i32 B_MIN = 16384;   // >  B_MIN entries: split over workgroups
 constexpr i32 B_CHUNK = 4096;  // entries per B chunk
+constexpr i32 TOPFOLD_MAX = 8;    // at most this many top rows are folded into the bundle kernels (kernels.hpp)
 constexpr i32 TOPBLK = 128;       // rows per block of the blocked top substitution (kernels.hip: TOPBLK)
 constexpr i64 F_MIN_WORK = 16384;    // factor: a column with more (contribution, tail entry) updates than this
 constexpr i64 F_CHUNK_MIN = 1024, F_CHUNK_MAX = 4096, F_CHUNK_PARTS = 96;  // ... is split over workgroups in chunks of about this many updates
@@ -460,6 +461,38 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         };
         sort_rows(S.Up, NFi, S.Ucol, S.Umap);
         sort_rows(S.Sp, (i32)n, S.Scol, S.Smap);
+    }
+    // ---- few dense top rows folded into the bundle kernels ----------------------
+    {
+        const i32 ntop = (i32)n - S.NF;
+        const i32 nbun = S.bundle_ptr.empty() ? 0 : (i32)S.bundle_ptr.size() - 1;
+        if (ntop >= 1 && ntop <= TOPFOLD_MAX && nbun > 0 && std::getenv("CHIP_NO_TOPFOLD") == nullptr) {
+            const i32 k = ntop;
+            S.nfold = k;
+            S.fold_rseg.assign((size_t)nbun * k * 2, 0);
+            for (i32 i = 0; i < k; i++) {
+                const i32 r = S.NF + i;
+                const i32 *rb = S.Rcol.data() + S.Rp[r], *re = S.Rcol.data() + S.Rp[r + 1];
+                for (i32 b = 0; b < nbun; b++) {
+                    S.fold_rseg[((size_t)b * k + i) * 2] = (i32)(std::lower_bound(rb, re, S.bundle_ptr[b]) - S.Rcol.data());
+                    S.fold_rseg[((size_t)b * k + i) * 2 + 1] =
+                        (i32)(std::lower_bound(rb, re, S.bundle_ptr[b + 1]) - S.Rcol.data());
+                }
+            }
+            S.fold_tt.assign((size_t)k * k, -1);
+            for (i32 j = 0; j < k; j++)
+                for (i32 q = S.Lp[S.NF + j]; q < S.Lp[S.NF + j + 1]; q++) S.fold_tt[(size_t)(S.Li[q] - S.NF) * k + j] = q;
+            S.fold_sp.assign((size_t)k + 1, 0);
+            for (i32 i = 0; i < k; i++) {
+                const i32 r = S.NF + i;
+                for (i32 t = S.Sp[r]; t < S.Sp[r + 1]; t++)
+                    if (S.Scol[t] >= S.NF) {
+                        S.fold_scol.push_back(S.Scol[t] - S.NF);
+                        S.fold_sslot.push_back(t);
+                    }
+                S.fold_sp[i + 1] = (i32)S.fold_scol.size();
+            }
+        }
     }
     // ---- blocked substitution for tall tops -----------------------------------
     {

@@ -314,9 +314,11 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
     }
     dev::scatter_init(stream, Kx, a2l, (int)nnzK, (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                       mb_dev->status);
-    dev::bundle_factor(stream, v, bundles); // everything below the cut: one launch
+    dev::bundle_factor(stream, v, bundles, fold); // everything below the cut: one launch
+    const bool top_folded = fold.k == 1; // single top column: pivot accumulated by the bundles
+    if (top_folded) dev::fold_top_pivot(stream, v, fold);
     const bool use_chain = std::getenv("CHIP_NO_FACTOR_CHAIN") == nullptr;
-    for (int l = 0; l < nlevels;) {
+    for (int l = top_folded ? nlevels : 0; l < nlevels;) {
         const int e = fac.chain_end[l];
         if (use_chain && e - l >= 4) { // a chain-like stretch: one single-workgroup launch for levels [l, e)
             dev::factor_chain(stream, v, fac.t_idx, fac.d_t_ptr, fac.w_idx, fac.d_w_ptr, l, e);

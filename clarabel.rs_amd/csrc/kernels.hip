@@ -457,7 +457,7 @@ constexpr int FATCAP = 1024;  // per-level list of rows/columns that need cooper
 // Per level: every thread sweeps the level's thin columns (strided, no barriers in between,
 // so many independent gathers are in flight), parking fat columns in an LDS list that the
 // whole workgroup then works through cooperatively.
-__global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv) {
+__global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv, FoldView fold) {
     __shared__ double acc[W_LDS_CAP];
     __shared__ int rows[W_LDS_CAP];
     __shared__ int cst[RCAP];
@@ -492,6 +492,23 @@ __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv)
         }
         // level l is final (global writes visible workgroup-wide) before level l+1
     }
+    if (fold.k == 1) {
+        // a single dense top row (the arrow's shaft): its pivot d_t = a_tt - sum_k l_tk^2 d_k gets this
+        // bundle's share here (the l_tk were just computed as the last entries of the bundle's columns);
+        // k_fold_top_pivot then applies the pivot rule
+        __syncthreads();
+        const int tb = fold.rseg[b * 2], te = fold.rseg[b * 2 + 1];
+        double s = 0.0;
+        for (int t = tb + (int)threadIdx.x; t < te; t += BWG) {
+            const double l = v.Lx[v.Rpos[t]];
+            s += l * (l * v.D[v.Rcol[t]]);
+        }
+        s = block_sum(s, red);
+        if (threadIdx.x == 0 && te > tb) atomicAdd(&v.D[fold.NF], -s);
+    }
+}
+__global__ void k_fold_top_pivot(LdlView v, FoldView fold) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) (void)pivot_rule(v, fold.NF, v.D[fold.NF]);
 }
 
 // one row (forward: row of L, all inside the bundle; backward: column of L, ancestors inside the
@@ -3111,8 +3128,11 @@ void factor_W(hipStream_t s, const LdlView &v, ListView c) {
     if (c.count) k_factor_W<<<c.count, 1024, 0, s>>>(v, c.idx, c.count);
 }
 static size_t bundle_lds(const BundleView &bv) { return ((size_t)bv.max_nodes * sizeof(double) + 15) & ~(size_t)15; }
-void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv) {
-    if (bv.nb) k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv);
+void fold_top_pivot(hipStream_t s, const LdlView &v, const FoldView &fold) {
+    if (fold.k == 1) k_fold_top_pivot<<<1, 64, 0, s>>>(v, fold);
+}
+void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold) {
+    if (bv.nb) k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
 }
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const FoldView &fold) {
     if (bv.nb) k_bundle_solve<true><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, nullptr, fold);

@@ -68,7 +68,10 @@ void diag_absmax_eps(hipStream_t s, const double *Kx, const int *diag_idx, int N
 void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale);
 
 // ---- numeric LDL' -------------------------------------------------------------
-void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv);
+// fold.k == 1: every bundle also subtracts its share of the single top column's pivot; fold_top_pivot
+// then applies the pivot rule to it (the top needs no factor launches of its own)
+void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold);
+void fold_top_pivot(hipStream_t s, const LdlView &v, const FoldView &fold);
 // fold.k > 0: every bundle also subtracts its part of the k top rows of L from x[NF + i]
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const FoldView &fold);
 // the k x k top-top part of the forward sweep, D^-1, and the backward sweep, in one tiny launch

@@ -217,6 +217,23 @@ def test_c3_portfolio_socp(hip, oracle, late):
     assert ks.linear_solver_info().n_levels <= 8
 
 
+def test_c3_several_dense_top_rows(hip, oracle):
+    """three dense coupling rows (budget + two more equality rows over all x): the top of the
+    elimination tree has k = 3 nodes, folded into the bundle kernels with a 3 x 3 finishing step"""
+    import scipy.sparse as sp2
+    pr = problems.portfolio_socp(12, 600, seed=21)
+    n, m = pr["n"], pr["m"]
+    rng = np.random.default_rng(2)
+    A = sp2.csc_matrix((pr["A"][2], pr["A"][1], pr["A"][0]), shape=(m, n))
+    extra = sp2.csc_matrix(rng.uniform(0.5, 1.5, (2, n)))
+    A2 = sp2.vstack([A, extra], format="csc")
+    A2.sort_indices()
+    pr2 = dict(n=n, m=m + 2, P=pr["P"], A=problems._csc(A2), cones=list(pr["cones"]) + [(0, 2)],
+               s=np.concatenate([pr["s"], np.zeros(2)]), z=np.concatenate([pr["z"], np.zeros(2)]))
+    ks, ko = _check_update_and_solve(hip, oracle, pr2, nrhs=2)
+    assert ks.N - ks.NF == 3
+
+
 def test_c3_dense_soc_blocks(hip, oracle):
     # SOC(4): dense Hs block path (socone.rs:224-245)
     _check_update_and_solve(hip, oracle, problems.portfolio_socp(7, 3, seed=4))

@@ -200,8 +200,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         if ((rc = upload(&a3, S.fold_sp, S.fold_sp.size()))) return rc;
         if ((rc = upload(&a4, S.fold_scol, S.fold_scol.size()))) return rc;
         if ((rc = upload(&a5, S.fold_sslot, S.fold_sslot.size()))) return rc;
-        if ((rc = alloc(&ts, 8))) return rc;
-        CHIP_HIP(hipMemset(ts, 0, 8 * sizeof(double)));
+        const size_t nacc = (size_t)dev::fold_acc_index(3, 0, 0);
+        if ((rc = alloc(&ts, nacc))) return rc;
+        CHIP_HIP(hipMemset(ts, 0, nacc * sizeof(double)));
         fold.k = S.nfold;
         fold.NF = S.NF;
         fold.rseg = a1;
@@ -209,7 +210,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         fold.sp = a3;
         fold.scol = a4;
         fold.sslot = a5;
-        fold.tsum = ts;
+        fold.acc = ts;
     }
     if (S.topblk > 0) {
         int *rs = nullptr, *ls = nullptr;

@@ -504,11 +504,18 @@ __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv,
             s += l * (l * v.D[v.Rcol[t]]);
         }
         s = block_sum(s, red);
-        if (threadIdx.x == 0 && te > tb) atomicAdd(&v.D[fold.NF], -s);
+        if (threadIdx.x == 0 && te > tb) atomicAdd(&fold.acc[fold_acc_index(2, 0, b % FOLD_SLOTS)], s);
     }
 }
 __global__ void k_fold_top_pivot(LdlView v, FoldView fold) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) (void)pivot_rule(v, fold.NF, v.D[fold.NF]);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double d = v.D[fold.NF];
+    for (int q = 0; q < FOLD_SLOTS; ++q) {
+        double *a = &fold.acc[fold_acc_index(2, 0, q)];
+        d -= *a;
+        *a = 0.0;
+    }
+    (void)pivot_rule(v, fold.NF, d);
 }
 
 // one row (forward: row of L, all inside the bundle; backward: column of L, ancestors inside the
@@ -541,7 +548,8 @@ __device__ __forceinline__ double bundle_row_dot(const LdlView &v, const double 
 //    processed.
 //  * thin rows: two rows per thread, FOUR entries of each row per shot -- rows of <= 4 entries
 //    (nearly all rows of a block-arrow KKT) cost one round trip instead of one per entry.
-constexpr int ESHOT = 4;
+constexpr int ESHOT = 4;     // forward: all gathers come from LDS
+constexpr int ESHOT_BWD = 2; // backward: entries of top ancestors are gathered from global memory (64-bit addresses)
 template <bool FWDMODE>
 __device__ __forceinline__ void bundle_solve_body(const LdlView &v, const BundleView &bv, double *x,
                                                   const double *__restrict__ addv, double *xs, double *red,
@@ -569,6 +577,22 @@ __device__ __forceinline__ void bundle_solve_body(const LdlView &v, const Bundle
         }
     };
     if (nsteps > 0) request_ptrs(0);
+    // folded top row 0: this thread's first entries of the bundle's segment are requested now -- they
+    // do not depend on x -- and consumed in the epilogue
+    constexpr int FPF = 2;
+    int fj[FPF];
+    double fv[FPF];
+    int ftb = 0, fte = 0;
+    if (FWDMODE && fold.k > 0) {
+        ftb = fold.rseg[(b * fold.k) * 2];
+        fte = fold.rseg[(b * fold.k) * 2 + 1];
+#pragma unroll
+        for (int q = 0; q < FPF; ++q) {
+            const int t = ftb + (int)threadIdx.x + q * BWG;
+            fj[q] = t < fte ? v.Rcol[t] : -1;
+            fv[q] = t < fte ? v.Rx[t] : 0.0;
+        }
+    }
     if (FWDMODE) {
         for (int i = threadIdx.x; i < nloc; i += BWG) xs[i] = x[s0 + i];
     } else {
@@ -614,13 +638,14 @@ __device__ __forceinline__ void bundle_solve_body(const LdlView &v, const Bundle
                 }
             }
             const int maxlen = max(te[0] - tb[0], te[1] - tb[1]);
-            for (int k = 0; k < maxlen; k += ESHOT) {
-                int ii[2][ESHOT];
-                double vv[2][ESHOT];
+            constexpr int SH = FWDMODE ? ESHOT : ESHOT_BWD;
+            for (int k = 0; k < maxlen; k += SH) {
+                int ii[2][SH];
+                double vv[2][SH];
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int e = 0; e < ESHOT; ++e) {
+                    for (int e = 0; e < SH; ++e) {
                         const unsigned t = (unsigned)(tb[u] + k + e);
                         const bool ok = (int)t < te[u];
                         ii[u][e] = ok ? cidx[t] : -1;
@@ -629,7 +654,7 @@ __device__ __forceinline__ void bundle_solve_body(const LdlView &v, const Bundle
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int e = 0; e < ESHOT; ++e)
+                    for (int e = 0; e < SH; ++e)
                         if (ii[u][e] >= 0)
                             sum[u] += vv[u][e] * ((FWDMODE || ii[u][e] < s1) ? xs[ii[u][e] - s0] : x[ii[u][e]]);
             }
@@ -659,12 +684,18 @@ __device__ __forceinline__ void bundle_solve_body(const LdlView &v, const Bundle
         for (int i = threadIdx.x; i < nloc; i += BWG) x[s0 + i] = xs[i];
     if (FWDMODE && fold.k > 0) {
         // the few dense top rows (an "arrow"): this bundle's columns of each of them, gathered from
-        // the slice that is still in LDS; one global atomic per (bundle, top row) onto x[top], which
-        // holds the right-hand side entry
+        // the slice that is still in LDS; one global atomic per (bundle, top row) into the slotted
+        // accumulators that k_fold_top_solve subtracts from the right-hand side entry x[top]
         for (int i = 0; i < fold.k; ++i) {
             const int tb = fold.rseg[(b * fold.k + i) * 2], te = fold.rseg[(b * fold.k + i) * 2 + 1];
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             int t = tb + (int)threadIdx.x;
+            if (i == 0) { // prefetched part
+#pragma unroll
+                for (int q = 0; q < FPF; ++q)
+                    if (fj[q] >= 0) a0 += fv[q] * xs[fj[q] - s0];
+                t += FPF * BWG;
+            }
             for (; t + 3 * BWG < te; t += 4 * BWG) {
                 const int j0 = v.Rcol[t], j1 = v.Rcol[t + BWG], j2 = v.Rcol[t + 2 * BWG], j3 = v.Rcol[t + 3 * BWG];
                 const double v0 = v.Rx[t], v1 = v.Rx[t + BWG], v2 = v.Rx[t + 2 * BWG], v3 = v.Rx[t + 3 * BWG];
@@ -675,18 +706,25 @@ __device__ __forceinline__ void bundle_solve_body(const LdlView &v, const Bundle
             }
             for (; t < te; t += BWG) a0 += v.Rx[t] * xs[v.Rcol[t] - s0];
             const double sum = block_sum((a0 + a1) + (a2 + a3), red);
-            if (threadIdx.x == 0 && te > tb) atomicAdd(&x[fold.NF + i], -sum);
+            if (threadIdx.x == 0 && te > tb) atomicAdd(&fold.acc[fold_acc_index(0, i, b % FOLD_SLOTS)], sum);
         }
     }
 }
-template <bool FWDMODE>
 __global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_bundle_solve(LdlView v, BundleView bv, double *x, const double *__restrict__ addv, FoldView fold) {
+void k_bundle_fwd(LdlView v, BundleView bv, double *x, FoldView fold) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[16];
     __shared__ int fat[FATCAP];
     __shared__ int nfat;
-    bundle_solve_body<FWDMODE>(v, bv, x, addv, (double *)smem, red, fat, nfat, fold);
+    bundle_solve_body<true>(v, bv, x, nullptr, (double *)smem, red, fat, nfat, fold);
+}
+__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bundle_bwd(LdlView v, BundleView bv, double *x, const double *__restrict__ addv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[16];
+    __shared__ int fat[FATCAP];
+    __shared__ int nfat;
+    bundle_solve_body<false>(v, bv, x, addv, (double *)smem, red, fat, nfat, FoldView{});
 }
 
 // B: a column with a huge row count (> 16384 contributions).  Each workgroup
@@ -1034,10 +1072,11 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
     }
     if (fold.k == 1) {
         tpart = block_sum(tpart, red);
-        if (threadIdx.x == 0 && tpart != 0.0) atomicAdd(&fold.tsum[0], tpart);
+        if (threadIdx.x == 0 && tpart != 0.0) atomicAdd(&fold.acc[fold_acc_index(1, 0, bid % FOLD_SLOTS)], tpart);
     } else if (fold.k > 1) {
         __syncthreads();
-        if ((int)threadIdx.x < fold.k && tacc[threadIdx.x] != 0.0) atomicAdd(&fold.tsum[threadIdx.x], tacc[threadIdx.x]);
+        if ((int)threadIdx.x < fold.k && tacc[threadIdx.x] != 0.0)
+            atomicAdd(&fold.acc[fold_acc_index(1, threadIdx.x, bid % FOLD_SLOTS)], tacc[threadIdx.x]);
     }
 }
 __global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -1057,6 +1096,11 @@ __global__ void k_fold_top_solve(LdlView v, FoldView fold, double *x) {
     double y[8];
     for (int i = 0; i < k; ++i) {
         double s = x[NF + i];
+        for (int q = 0; q < FOLD_SLOTS; ++q) { // the bundles' shares of row i (reset for the next sweep)
+            double *a = &fold.acc[fold_acc_index(0, i, q)];
+            s -= *a;
+            *a = 0.0;
+        }
         for (int j = 0; j < i; ++j) {
             const int q = fold.tt[i * k + j];
             if (q >= 0) s -= v.Lx[q] * y[j];
@@ -1079,8 +1123,12 @@ __global__ void k_fold_top_residual(FoldView fold, const double *__restrict__ Sx
                                     int *nanflag) {
     const int i = threadIdx.x;
     if (blockIdx.x != 0 || i >= fold.k) return;
-    double s = fold.tsum[i];
-    fold.tsum[i] = 0.0;
+    double s = 0.0;
+    for (int q = 0; q < FOLD_SLOTS; ++q) {
+        double *a = &fold.acc[fold_acc_index(1, i, q)];
+        s += *a;
+        *a = 0.0;
+    }
     for (int t = fold.sp[i]; t < fold.sp[i + 1]; ++t) s += Sx[fold.sslot[t]] * x[fold.NF + fold.scol[t]];
     const double val = b[fold.NF + i] - s;
     e[fold.NF + i] = val;
@@ -3135,10 +3183,10 @@ void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const 
     if (bv.nb) k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
 }
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const FoldView &fold) {
-    if (bv.nb) k_bundle_solve<true><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, nullptr, fold);
+    if (bv.nb) k_bundle_fwd<<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, fold);
 }
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const double *addv) {
-    if (bv.nb) k_bundle_solve<false><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv, FoldView{});
+    if (bv.nb) k_bundle_bwd<<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv);
 }
 void fold_top_solve(hipStream_t s, const LdlView &v, const FoldView &fold, double *x) {
     if (fold.k) k_fold_top_solve<<<1, 64, 0, s>>>(v, fold, x);

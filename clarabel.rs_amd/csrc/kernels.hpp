@@ -35,8 +35,15 @@ struct FoldView {
     const int *rseg;               // (bundle, top row) -> CSR slot range of L
     const int *tt;                 // k x k CSC slots of the top-top entries of L
     const int *sp, *scol, *sslot;  // top-top entries of K (slots in Sx)
-    double *tsum;                  // k accumulators of the residual kernel (zero between uses)
+    // slotted accumulators (zero between uses): 3 kinds (0 forward sweep, 1 residual, 2 pivot) x 8 top rows
+    // x FOLD_SLOTS slots, one 128-byte line per slot -- a thousand bundles adding to ONE address would
+    // serialise at ~13 ns each right at the tail of the launch
+    double *acc;
 };
+constexpr int FOLD_SLOTS = 16, FOLD_STRIDE = 16;
+inline __host__ __device__ int fold_acc_index(int kind, int row, int slot) {
+    return ((kind * 8 + row) * FOLD_SLOTS + slot) * FOLD_STRIDE;
+}
 // Blocked substitution over a tall top (host.hpp: Symbolic::topblk): block b = rows
 // [NF + b*w, min(N, NF + (b+1)*w)); T = per block the strictly-lower part of (I + L_bb)^-1, packed by
 // rows ((i, k), k < i at i(i-1)/2 + k), w(w-1)/2 doubles per block

@@ -463,6 +463,11 @@ class HipKKTSolver:
                                                   C.byref(out)), "compute_barrier")
         return out.value
 
+    def degree(self):
+        d = C.c_int64()
+        _check(lib().chip_kkt_degree(self._h, C.byref(d)), "degree")
+        return d.value
+
     def linear_solver_info(self):
         info = Info()
         _check(lib().chip_kkt_info(self._h, C.byref(info)), "info")
@@ -543,6 +548,71 @@ class HipKKTSystem:
                                            C.c_void_p(rx_inf.ptr), C.c_void_p(rz_inf.ptr), C.c_void_p(Px.ptr), o),
                "residuals_update")
         return dict(rtau=o[0], dot_qx=o[1], dot_bz=o[2], dot_sz=o[3], dot_xPx=o[4])
+
+    # ---- DefaultVariables on the device (default/variables.rs:58-261) -------------------------
+    @staticmethod
+    def _p(a):
+        return C.c_void_p(a if isinstance(a, int) else a.ptr)
+
+    def calc_mu(self, variables, dot_sz):
+        cv, o = variables.cvars(), C.c_double()
+        _check(lib().chip_variables_calc_mu(self._h, C.byref(cv), C.c_double(dot_sz), C.byref(o)), "calc_mu")
+        return o.value
+
+    def affine_step_rhs(self, d, rx, rz, rtau, variables):
+        cd, cv = d.cvars(), variables.cvars()
+        _check(lib().chip_variables_affine_step_rhs(self._h, C.byref(cd), self._p(rx), self._p(rz),
+                                                    C.c_double(rtau), C.byref(cv)), "affine_step_rhs")
+        d.tau, d.kappa = cd.tau, cd.kappa
+
+    def combined_step_rhs(self, d, rx, rz, rtau, variables, step, sigma, mu, m):
+        cd, cv, cs = d.cvars(), variables.cvars(), step.cvars()
+        _check(lib().chip_variables_combined_step_rhs(self._h, C.byref(cd), self._p(rx), self._p(rz),
+                                                      C.c_double(rtau), C.byref(cv), C.byref(cs),
+                                                      C.c_double(sigma), C.c_double(mu), C.c_double(m)),
+               "combined_step_rhs")
+        d.tau, d.kappa = cd.tau, cd.kappa
+
+    def calc_step_length(self, variables, step, step_direction, max_step_fraction=0.99):
+        cv, cs, o = variables.cvars(), step.cvars(), C.c_double()
+        _check(lib().chip_variables_calc_step_length(self._h, C.byref(cv), C.byref(cs), C.c_int32(step_direction),
+                                                     C.c_double(max_step_fraction), C.byref(o)), "calc_step_length")
+        return o.value
+
+    def add_step(self, variables, step, alpha):
+        cv, cs = variables.cvars(), step.cvars()
+        _check(lib().chip_variables_add_step(self._h, C.byref(cv), C.byref(cs), C.c_double(alpha)), "add_step")
+        variables.tau, variables.kappa = cv.tau, cv.kappa
+
+    def symmetric_initialization(self, variables):
+        cv = variables.cvars()
+        _check(lib().chip_variables_symmetric_initialization(self._h, C.byref(cv)), "symmetric_initialization")
+        variables.tau, variables.kappa = cv.tau, cv.kappa
+
+    def unit_initialization(self, variables):
+        cv = variables.cvars()
+        _check(lib().chip_variables_unit_initialization(self._h, C.byref(cv)), "unit_initialization")
+        variables.tau, variables.kappa = cv.tau, cv.kappa
+
+    def barrier(self, variables, step, alpha):
+        cv, cs, o = variables.cvars(), step.cvars(), C.c_double()
+        _check(lib().chip_variables_barrier(self._h, C.byref(cv), C.byref(cs), C.c_double(alpha), C.byref(o)),
+               "barrier")
+        return o.value
+
+    def rescale(self, variables):
+        cv = variables.cvars()
+        _check(lib().chip_variables_rescale(self._h, C.byref(cv)), "rescale")
+        variables.tau, variables.kappa = cv.tau, cv.kappa
+
+    def vec_norms(self, *arrays):
+        """Euclidean norms of up to 8 DeviceArrays, one host synchronisation"""
+        k = len(arrays)
+        ptrs = (C.c_void_p * max(k, 1))(*[a.ptr for a in arrays])
+        lens = (C.c_int64 * max(k, 1))(*[a.n for a in arrays])
+        out = (C.c_double * max(k, 1))()
+        _check(lib().chip_vec_norms(self._h, C.c_int32(k), ptrs, lens, out), "vec_norms")
+        return [out[i] for i in range(k)]
 
     def update_data(self, P=None, A=None, q=None, b=None):
         args = [None if v is None else _f(v) for v in (P, A, q, b)]

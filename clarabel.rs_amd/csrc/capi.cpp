@@ -562,6 +562,27 @@ int32_t chip_kkt_dims(const chip_kkt *h, int64_t out[8]) {
     out[7] = h->E.nnzU;
     return CHIP_OK;
 }
+// CompositeCone::degree (compositecone.rs:106-108): zerocone.rs:36-38 (0), nonnegativecone.rs:39-41 (dim),
+// socone.rs:74-77 (1), psdtrianglecone.rs:77-79 (n), expcone.rs:55-57 / powcone.rs:48-50 (3),
+// genpowcone.rs:84-86 (dim1 + 1)
+int32_t chip_kkt_degree(const chip_kkt *h, int64_t *degree) {
+    if (!h || !degree) return CHIP_ERR_ARG;
+    i64 d = 0;
+    for (const ConeSpec &c : h->K.cones) {
+        switch (c.tag) {
+        case CHIP_CONE_ZERO: break;
+        case CHIP_CONE_NONNEGATIVE: d += c.dim; break;
+        case CHIP_CONE_SECONDORDER: d += 1; break;
+        case CHIP_CONE_PSDTRIANGLE: d += c.dim; break;
+        case CHIP_CONE_EXPONENTIAL:
+        case CHIP_CONE_POWER: d += 3; break;
+        case CHIP_CONE_GENPOWER: d += c.dim + 1; break;
+        default: break;
+        }
+    }
+    *degree = d;
+    return CHIP_OK;
+}
 int32_t chip_kkt_get_matrix(const chip_kkt *h, uint64_t *colptr, uint64_t *rowval, double *nzval) {
     if (!h) return CHIP_ERR_ARG;
     const KktLayout &K = h->K;

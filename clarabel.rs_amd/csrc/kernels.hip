@@ -1443,6 +1443,21 @@ __global__ __launch_bounds__(WG) void k_dot_final(const double *__restrict__ par
     s = block_sum(s, red);
     if (threadIdx.x == 0) *out = s;
 }
+// vecmath.rs:87-99  dot_shifted: sum (s + a ds)(z + a dz), same two-stage reduction
+__global__ __launch_bounds__(WG) void k_dot_shifted_partial(const double *__restrict__ z, const double *__restrict__ sv,
+                                                            const double *__restrict__ dz,
+                                                            const double *__restrict__ ds, double alpha, int n,
+                                                            double *partials) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (int i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
+        const double si = sv[i] + alpha * ds[i];
+        const double zi = z[i] + alpha * dz[i];
+        acc += si * zi;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
 __global__ __launch_bounds__(WG) void k_add_vec(double *__restrict__ dx, const double *__restrict__ x, int N) {
     for (int i = logical_block() * WG + threadIdx.x; i < N; i += gridDim.x * WG) dx[i] = 1.0 * x[i] + 1.0 * dx[i];
 }
@@ -3295,6 +3310,12 @@ int dot_scratch_doubles() { return DOT_BLOCKS; }
 void dot(hipStream_t s, const double *a, const double *b, int n, double *out, double *scratch) {
     const int nb = n > 0 ? std::min(DOT_BLOCKS, (n + WG - 1) / WG) : 0;
     if (nb) k_dot_partial<<<nb, WG, 0, s>>>(a, b, n, scratch);
+    k_dot_final<<<1, WG, 0, s>>>(scratch, nb, out);
+}
+void dot_shifted(hipStream_t s, const double *z, const double *sv, const double *dz, const double *ds, double alpha,
+                 int n, double *out, double *scratch) {
+    const int nb = n > 0 ? std::min(DOT_BLOCKS, (n + WG - 1) / WG) : 0;
+    if (nb) k_dot_shifted_partial<<<nb, WG, 0, s>>>(z, sv, dz, ds, alpha, n, scratch);
     k_dot_final<<<1, WG, 0, s>>>(scratch, nb, out);
 }
 void add_vec(hipStream_t s, double *dx, const double *x, int N) {

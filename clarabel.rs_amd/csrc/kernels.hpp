@@ -145,6 +145,9 @@ void waxpby(hipStream_t s, double *w, double a, const double *x, double b, const
 // *out = a . b, deterministic (fixed partition + tree); scratch: dot_scratch_doubles() doubles
 int dot_scratch_doubles();
 void dot(hipStream_t s, const double *a, const double *b, int n, double *out, double *scratch);
+// *out = sum (s + alpha ds)(z + alpha dz)   (vecmath.rs:87-99)
+void dot_shifted(hipStream_t s, const double *z, const double *sv, const double *dz, const double *ds, double alpha,
+                 int n, double *out, double *scratch);
 // slots (NRM_SLOTS x NRM_STRIDE) <- bit patterns of partial max|v|; *nanflag |= any NaN
 void norm_inf(hipStream_t s, const double *v, int N, unsigned long long *out, int *nanflag);
 

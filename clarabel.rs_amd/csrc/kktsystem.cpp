@@ -4,7 +4,9 @@
 // device work is sparse gemv / symv (the row-gather family in SPMV mode), w = a x + b y and
 // deterministic dot products.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <vector>
 
@@ -381,5 +383,171 @@ int32_t chip_residuals_update(chip_kktsystem *h, const chip_vars *var, double *r
     out5[2] = bz;
     out5[3] = sz;
     out5[4] = xPx;
+    return CHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DefaultVariables (default/variables.rs:58-256) on device-resident vectors: the vector algebra of
+// the step either side of the KKT solve, so that only scalars cross the boundary per iteration.
+// ---------------------------------------------------------------------------------------------
+int32_t chip_variables_calc_mu(chip_kktsystem *h, const chip_vars *var, double dot_sz, double *mu_out) {
+    if (!h || !var || !mu_out) return CHIP_ERR_ARG;
+    int64_t deg = 0;
+    int rc = chip_kkt_degree(h->kkt, &deg);
+    if (rc) return rc;
+    *mu_out = (dot_sz + var->tau * var->kappa) / (double)(deg + 1); // variables.rs:63-66
+    return CHIP_OK;
+}
+
+// variables.rs:68-79
+int32_t chip_variables_affine_step_rhs(chip_kktsystem *h, chip_vars *d, const double *rx, const double *rz,
+                                       double rtau, const chip_vars *var) {
+    if (!h || !d || !var) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->copy(d->x, rx, h->n))) return rc;
+    if ((rc = h->copy(d->z, rz, h->m))) return rc;
+    if ((rc = chip_kkt_affine_ds_dev(h->kkt, d->s, var->s))) return rc;
+    d->tau = rtau;
+    d->kappa = var->tau * var->kappa;
+    return CHIP_OK;
+}
+
+// variables.rs:81-118 (d.s must already hold affine_ds, as in the reference)
+int32_t chip_variables_combined_step_rhs(chip_kktsystem *h, chip_vars *d, const double *rx, const double *rz,
+                                         double rtau, const chip_vars *var, chip_vars *step, double sigma,
+                                         double mu, double mscale) {
+    if (!h || !d || !var || !step) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    const int n = h->n, m = h->m;
+    hipStream_t s = h->stream;
+    const double sigma_mu = sigma * mu;
+    dev::waxpby(s, d->x, 1.0 - sigma, rx, 0.0, nullptr, n);
+    d->tau = (1.0 - sigma) * rtau;
+    d->kappa = -sigma_mu + mscale * step->tau * step->kappa + var->tau * var->kappa;
+    if (mscale != 1.0) dev::waxpby(s, step->z, mscale, step->z, 0.0, nullptr, m);
+    int rc = chip_kkt_combined_ds_shift_dev(h->kkt, d->z, step->z, step->s, sigma_mu); // d.z is work
+    if (rc) return rc;
+    dev::waxpby(s, d->s, 1.0, d->s, 1.0, d->z, m);
+    dev::waxpby(s, d->z, 1.0 - sigma, rz, 0.0, nullptr, m);
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+
+// variables.rs:120-160
+int32_t chip_variables_calc_step_length(chip_kktsystem *h, const chip_vars *var, const chip_vars *step,
+                                        int32_t step_direction, double max_step_fraction, double *alpha_out) {
+    if (!h || !var || !step || !alpha_out) return CHIP_ERR_ARG;
+    const double inf = std::numeric_limits<double>::max();
+    const double a_tau = step->tau < 0.0 ? -var->tau / step->tau : inf;
+    const double a_kap = step->kappa < 0.0 ? -var->kappa / step->kappa : inf;
+    double alpha = std::min(std::min(a_tau, a_kap), 1.0);
+    int rc = chip_kkt_step_length_dev(h->kkt, step->z, step->s, var->z, var->s, alpha, &alpha);
+    if (rc) return rc;
+    if (step_direction == CHIP_STEP_COMBINED) alpha *= max_step_fraction;
+    *alpha_out = alpha;
+    return CHIP_OK;
+}
+
+// variables.rs:162-168
+int32_t chip_variables_add_step(chip_kktsystem *h, chip_vars *var, const chip_vars *step, double alpha) {
+    if (!h || !var || !step) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    dev::waxpby(s, var->x, alpha, step->x, 1.0, var->x, h->n);
+    dev::waxpby(s, var->s, alpha, step->s, 1.0, var->s, h->m);
+    dev::waxpby(s, var->z, alpha, step->z, 1.0, var->z, h->m);
+    var->tau += alpha * step->tau;
+    var->kappa += alpha * step->kappa;
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+
+// _shift_to_cone_interior, variables.rs:231-261
+static int shift_to_cone_interior(chip_kktsystem *h, double *z, int primal) {
+    double min_margin = 0.0, pos_margin = 0.0;
+    int rc = chip_kkt_margins_dev(h->kkt, z, &min_margin, &pos_margin);
+    if (rc) return rc;
+    int64_t deg = 0;
+    if ((rc = chip_kkt_degree(h->kkt, &deg))) return rc;
+    const double target = std::max(1.0, (pos_margin * 0.1) / (double)deg);
+    if (min_margin <= 0.0) {
+        if ((rc = chip_kkt_scaled_unit_shift_dev(h->kkt, z, -min_margin, primal))) return rc;
+        return chip_kkt_scaled_unit_shift_dev(h->kkt, z, target, primal);
+    }
+    if (min_margin < target) return chip_kkt_scaled_unit_shift_dev(h->kkt, z, target - min_margin, primal);
+    return chip_kkt_scaled_unit_shift_dev(h->kkt, z, 0.0, primal);
+}
+// variables.rs:170-176
+int32_t chip_variables_symmetric_initialization(chip_kktsystem *h, chip_vars *var) {
+    if (!h || !var) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    int rc;
+    if ((rc = shift_to_cone_interior(h, var->s, 1))) return rc;
+    if ((rc = shift_to_cone_interior(h, var->z, 0))) return rc;
+    var->tau = 1.0;
+    var->kappa = 1.0;
+    return CHIP_OK;
+}
+// variables.rs:178-184
+int32_t chip_variables_unit_initialization(chip_kktsystem *h, chip_vars *var) {
+    if (!h || !var) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    int rc = chip_kkt_unit_initialization_dev(h->kkt, var->z, var->s);
+    if (rc) return rc;
+    if ((rc = h->zero(var->x, h->n))) return rc;
+    var->tau = 1.0;
+    var->kappa = 1.0;
+    return CHIP_OK;
+}
+
+// variables.rs:205-227
+int32_t chip_variables_barrier(chip_kktsystem *h, const chip_vars *var, const chip_vars *step, double alpha,
+                               double *barrier_out) {
+    if (!h || !var || !step || !barrier_out) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    int64_t deg = 0;
+    int rc = chip_kkt_degree(h->kkt, &deg);
+    if (rc) return rc;
+    const double coef = (double)(deg + 1);
+    const double cur_tau = var->tau + alpha * step->tau, cur_kappa = var->kappa + alpha * step->kappa;
+    dev::dot_shifted(h->stream, var->z, var->s, step->z, step->s, alpha, h->m, h->dots + 12, h->scratch);
+    if ((rc = h->read_dots())) return rc;
+    const double mu = (h->hdots[12] + cur_tau * cur_kappa) / coef;
+    auto logsafe = [](double v) { return v <= 0.0 ? -std::numeric_limits<double>::infinity() : std::log(v); };
+    double barrier = coef * logsafe(mu) - logsafe(cur_tau) - logsafe(cur_kappa);
+    double cb = 0.0;
+    if ((rc = chip_kkt_compute_barrier_dev(h->kkt, var->z, var->s, step->z, step->s, alpha, &cb))) return rc;
+    *barrier_out = barrier + cb;
+    return CHIP_OK;
+}
+
+// variables.rs:229-239
+int32_t chip_variables_rescale(chip_kktsystem *h, chip_vars *var) {
+    if (!h || !var) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    const double inv = 1.0 / std::max(var->tau, var->kappa);
+    hipStream_t s = h->stream;
+    dev::waxpby(s, var->x, inv, var->x, 0.0, nullptr, h->n);
+    dev::waxpby(s, var->z, inv, var->z, 0.0, nullptr, h->m);
+    dev::waxpby(s, var->s, inv, var->s, 0.0, nullptr, h->m);
+    var->tau *= inv;
+    var->kappa *= inv;
+    CHIP_HIP(hipGetLastError());
+    return CHIP_OK;
+}
+
+// Euclidean norms of up to 8 device vectors with ONE host synchronisation: what DefaultInfo::update
+// (default/info.rs:142-165) needs of x, z, s, rx, rz, ... when they live in HBM.  sqrt of the
+// deterministic two-stage sum of squares (the reference's stable_norm, vecmath.rs:115-118, rescales
+// by the largest entry; identical up to rounding away from overflow/underflow).
+int32_t chip_vec_norms(chip_kktsystem *h, int32_t count, const double *const *vecs, const int64_t *lens,
+                       double *out) {
+    if (!h || count < 0 || count > 8 || (count && (!vecs || !lens || !out))) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(h->device));
+    for (int k = 0; k < count; k++) h->dot(k, vecs[k], vecs[k], (int)lens[k]);
+    int rc = h->read_dots();
+    if (rc) return rc;
+    for (int k = 0; k < count; k++) out[k] = std::sqrt(h->hdots[k]);
     return CHIP_OK;
 }

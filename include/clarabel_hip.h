@@ -343,6 +343,44 @@ int32_t chip_kktsystem_update_data(chip_kktsystem *h, const double *Pnzval_or_nu
                                    const double *Anzval_or_null, const double *q_or_null,
                                    const double *b_or_null);
 
+
+/* ---------------------------------------------------------------------------
+ * DefaultVariables (src/solver/implementations/default/variables.rs:58-261) on
+ * device-resident vectors: the step algebra either side of the KKT solve, so that a
+ * whole IPM iteration (core/solver.rs:282-434) exchanges only scalars with the host.
+ * rx / rz are the device vectors written by chip_residuals_update.
+ * ---------------------------------------------------------------------------*/
+/* CompositeCone::degree (compositecone.rs:106-108) */
+int32_t chip_kkt_degree(const chip_kkt *h, int64_t *degree);
+/* calc_mu, variables.rs:63-66 (host arithmetic on dot_sz of chip_residuals_update) */
+int32_t chip_variables_calc_mu(chip_kktsystem *h, const chip_vars *variables, double dot_sz, double *mu_out);
+/* affine_step_rhs, variables.rs:68-79: d <- (rx, rz, affine_ds(s), r_tau, tau*kappa) */
+int32_t chip_variables_affine_step_rhs(chip_kktsystem *h, chip_vars *d, const double *rx_dev,
+                                       const double *rz_dev, double rtau, const chip_vars *variables);
+/* combined_step_rhs, variables.rs:81-118: d.s must hold affine_ds (as in the reference); step->z is
+ * scaled by m when m != 1 and step->z / step->s are overwritten by the cones' combined_ds_shift */
+int32_t chip_variables_combined_step_rhs(chip_kktsystem *h, chip_vars *d, const double *rx_dev,
+                                         const double *rz_dev, double rtau, const chip_vars *variables,
+                                         chip_vars *step, double sigma, double mu, double m);
+/* calc_step_length, variables.rs:120-160 (max_step_fraction: settings.core().max_step_fraction) */
+int32_t chip_variables_calc_step_length(chip_kktsystem *h, const chip_vars *variables, const chip_vars *step,
+                                        int32_t step_direction, double max_step_fraction, double *alpha_out);
+/* add_step, variables.rs:162-168 (variables->tau / kappa updated in the struct) */
+int32_t chip_variables_add_step(chip_kktsystem *h, chip_vars *variables, const chip_vars *step, double alpha);
+/* symmetric_initialization, variables.rs:170-176 with _shift_to_cone_interior (:231-261) */
+int32_t chip_variables_symmetric_initialization(chip_kktsystem *h, chip_vars *variables);
+/* unit_initialization, variables.rs:178-184 */
+int32_t chip_variables_unit_initialization(chip_kktsystem *h, chip_vars *variables);
+/* barrier, variables.rs:205-227 (dot_shifted of vecmath.rs:87-99 + the cones' barriers) */
+int32_t chip_variables_barrier(chip_kktsystem *h, const chip_vars *variables, const chip_vars *step,
+                               double alpha, double *barrier_out);
+/* rescale, variables.rs:229-239 */
+int32_t chip_variables_rescale(chip_kktsystem *h, chip_vars *variables);
+/* Euclidean norms of up to 8 device vectors with one host synchronisation (the norms
+ * DefaultInfo::update reads, default/info.rs:142-165, with identity equilibration) */
+int32_t chip_vec_norms(chip_kktsystem *h, int32_t count, const double *const *vecs_dev, const int64_t *lens,
+                       double *out);
+
 #ifdef __cplusplus
 }
 #endif

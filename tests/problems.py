@@ -100,6 +100,21 @@ def portfolio_socp(nblocks=1000, blocksize=1000, seed=3, late=False):
     return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=s, z=z)
 
 
+def portfolio_problem(nblocks=1000, blocksize=1000, seed=3):
+    """a complete, strictly feasible and bounded problem on the config-3 pattern (portfolio_socp):
+    maximise mu'x  s.t.  1'x = nblocks,  x >= 0,  ||d_k o x_k|| <= gamma_k per block (risk budgets)."""
+    pr = portfolio_socp(nblocks, blocksize, seed)
+    rng = np.random.default_rng(seed + 1000)
+    n, dim = pr["n"], blocksize + 1
+    q = -rng.uniform(0.0, 1.0, n)
+    b = np.zeros(pr["m"])
+    b[0] = float(nblocks)
+    gamma = rng.uniform(1.5, 3.0, nblocks) / np.sqrt(blocksize)
+    b[1 + n + dim * np.arange(nblocks)] = gamma
+    pr.update(q=q, b=b)
+    return pr
+
+
 def batched_socp(nbatch=1024, n_b=2000, blocks_per=2, seed=100, late=False):
     """C4: `nbatch` independent copies of a small C3-pattern SOCP, concatenated block
     diagonally (csc/block_concatenate.rs:22) -> elimination forest with nbatch roots."""

@@ -865,3 +865,131 @@ def test_e2e_mixed_conic_on_device(hip, oracle, min_switch):
         # decided by that noise, so the two loops take different -- equally valid -- paths.  Every
         # operation agrees when fed the same inputs (checked by shadowing one loop with the other).
         assert out["iterations"] <= 30 and ref["iterations"] <= 30
+
+
+# ---- DefaultVariables on the device (default/variables.rs:58-261) ---------------------------
+@pytest.mark.parametrize("which", ["socp", "mixed"])
+def test_variables_operations_on_device(hip, oracle, which):
+    """chip_variables_* against the same algebra composed on the host from the oracle's cone
+    operations (variables.rs:63-239), plus chip_vec_norms / chip_kkt_degree"""
+    from tests import ipm_driver as ipm
+    pr = problems.portfolio_socp(6, 120, seed=5) if which == "socp" else problems.mixed_conic()
+    ks, sysd, cones, ko, syso, rng = _l3_pair(hip, oracle, pr, seed=3)
+    n, m = pr["n"], pr["m"]
+    strategy = 0
+    assert ks.update_scaling(pr["s"], pr["z"], 0.7, strategy) and cones.update_scaling(pr["s"], pr["z"], 0.7, strategy)
+    assert ks.degree() == cones.degree
+    v = oracle.Variables(n, m)
+    v.x, v.s, v.z, v.tau, v.kappa = rng.standard_normal(n), pr["s"].copy(), pr["z"].copy(), 1.2, 0.8
+    res = syso.residuals(v)
+    D = hip.DeviceArray
+    dv = _dvars(hip, v)
+    rx, rz = D(res["rx"]), D(res["rz"])
+    deg = cones.degree
+    mu = (res["dot_sz"] + v.tau * v.kappa) / (deg + 1)
+    assert abs(sysd.calc_mu(dv, res["dot_sz"]) - mu) <= 1e-15 * abs(mu)
+    # affine rhs
+    d = hip.DeviceVariables(n, m)
+    sysd.affine_step_rhs(d, rx, rz, res["rtau"], dv)
+    aff_s = cones.affine_ds(v.s)
+    assert relerr(d.x.numpy(), res["rx"]) == 0 and relerr(d.z.numpy(), res["rz"]) == 0
+    assert relerr(d.s.numpy(), aff_s) <= 1e-13
+    assert d.tau == res["rtau"] and d.kappa == v.tau * v.kappa
+    # a step (small, so that the point stays interior) and the combined rhs
+    step = oracle.Variables(n, m)
+    step.x, step.z, step.s = rng.standard_normal(n), 0.6 * rng.standard_normal(m) * np.abs(v.z).mean(), \
+        0.6 * rng.standard_normal(m) * np.abs(v.s).mean()
+    step.tau, step.kappa = -0.3, 0.2
+    sigma, mm = 0.3, 0.9
+    dstep = _dvars(hip, step)
+    sysd.combined_step_rhs(d, rx, rz, res["rtau"], dv, dstep, sigma, mu, mm)
+    shift, sz, ss = cones.combined_ds_shift(mm * step.z, step.s, sigma * mu)
+    assert relerr(d.x.numpy(), (1 - sigma) * res["rx"]) <= 1e-15
+    assert relerr(d.z.numpy(), (1 - sigma) * res["rz"]) <= 1e-15
+    assert relerr(d.s.numpy(), aff_s + shift) <= 1e-11
+    assert abs(d.tau - (1 - sigma) * res["rtau"]) <= 1e-15 * max(1, abs(res["rtau"]))
+    assert abs(d.kappa - (-sigma * mu + mm * step.tau * step.kappa + v.tau * v.kappa)) <= 1e-15
+    assert relerr(dstep.z.numpy(), sz) <= 1e-11 and relerr(dstep.s.numpy(), ss) <= 1e-11  # overwritten as the reference
+    # step length, barrier, add_step, rescale, norms on a fresh copy of the step
+    dstep = _dvars(hip, step)
+    for direction, frac in ((hip.STEP_AFFINE, 0.99), (hip.STEP_COMBINED, 0.99)):
+        a_ref = min(-v.tau / step.tau, 1.0)
+        a_ref = cones.step_length(step.z, step.s, v.z, v.s, a_ref)
+        if direction == hip.STEP_COMBINED:
+            a_ref *= frac
+        assert abs(sysd.calc_step_length(dv, dstep, direction, frac) - a_ref) <= 1e-9
+    alpha = 0.5 * a_ref
+    ctau, ckap = v.tau + alpha * step.tau, v.kappa + alpha * step.kappa
+    mu_a = (float(np.dot(v.s + alpha * step.s, v.z + alpha * step.z)) + ctau * ckap) / (deg + 1)
+    bar = (deg + 1) * np.log(mu_a) - np.log(ctau) - np.log(ckap) + cones.compute_barrier(v.z, v.s, step.z, step.s, alpha)
+    assert abs(sysd.barrier(dv, dstep, alpha) - bar) <= 1e-8 * max(1.0, abs(bar))
+    sysd.add_step(dv, dstep, alpha)
+    assert relerr(dv.x.numpy(), v.x + alpha * step.x) <= 1e-15 and relerr(dv.z.numpy(), v.z + alpha * step.z) <= 1e-15
+    assert relerr(dv.s.numpy(), v.s + alpha * step.s) <= 1e-15
+    assert abs(dv.tau - ctau) <= 1e-15 and abs(dv.kappa - ckap) <= 1e-15
+    nx, nz, nrx = sysd.vec_norms(dv.x, dv.z, rx)
+    assert abs(nx - np.linalg.norm(v.x + alpha * step.x)) <= 1e-12 * nx and abs(nrx - np.linalg.norm(res["rx"])) <= 1e-12 * nrx
+    assert abs(nz - np.linalg.norm(v.z + alpha * step.z)) <= 1e-12 * nz
+    assert sysd.vec_norms() == []
+    x_before, t_before = dv.x.numpy(), (dv.tau, dv.kappa)
+    sysd.rescale(dv)
+    sc = max(t_before)
+    assert relerr(dv.x.numpy(), x_before / sc) <= 1e-15 and abs(dv.tau - t_before[0] / sc) <= 1e-15
+    assert max(dv.tau, dv.kappa) == 1.0
+    # initialisations
+    if which == "socp":
+        w = oracle.Variables(n, m)
+        w.s, w.z = rng.standard_normal(m), rng.standard_normal(m)
+        dw = _dvars(hip, w)
+        sysd.symmetric_initialization(dw)
+        be = ipm.OracleBackend(oracle, n, m, pr["P"], pr["A"], np.zeros(n), np.zeros(m), pr["cones"])
+        ipm._shift_to_cone_interior(be, w.s, True)
+        ipm._shift_to_cone_interior(be, w.z, False)
+        assert relerr(dw.s.numpy(), w.s) <= 1e-12 and relerr(dw.z.numpy(), w.z) <= 1e-12
+        assert dw.tau == 1.0 and dw.kappa == 1.0
+    else:
+        dw = hip.DeviceVariables(n, m)
+        dw.x.copy_from(rng.standard_normal(n))
+        sysd.unit_initialization(dw)
+        zz, ss2 = np.zeros(m), np.zeros(m)
+        cones.unit_initialization(zz, ss2)
+        assert relerr(dw.z.numpy(), zz) <= 1e-15 and relerr(dw.s.numpy(), ss2) <= 1e-15
+        assert not dw.x.numpy().any() and dw.tau == 1.0 and dw.kappa == 1.0
+
+
+@pytest.mark.parametrize("name", ["basic_qp", "basic_lp", "basic_socp", "basic_expcone", "basic_powcone", "basic_sdp",
+                                  "basic_genpowcone", "basic_eq_constrained"])
+def test_device_resident_ipm_loop(hip, oracle, name):
+    """tests/ipm_device.py: the whole iteration (residuals, scaling, KKT update, both step right-hand
+    sides, both solves, step lengths, add_step) with all vectors resident in HBM reaches the
+    reference's answers along the same path as the oracle-backed loop"""
+    from tests import e2e_problems as E
+    from tests import ipm_device, ipm_driver as ipm
+    pr = getattr(E, name)()
+    args = (pr["n"], pr["m"], pr["P"], pr["A"], pr["q"], pr["b"], pr["cones"])
+    td, to = [], []
+    out = ipm_device.solve_device(hip, *args, trace=td)
+    ref = ipm.solve(ipm.OracleBackend(oracle, *args), pr["cones"], pr["q"], pr["b"], trace=to)
+    assert out["status"] == "Solved"
+    if pr["x"] is not None:
+        assert np.linalg.norm(out["x"] - np.array(pr["x"])) <= pr["tol"]
+    assert abs(out["obj_val"] - pr["obj"]) <= pr["tol"]
+    assert out["iterations"] == ref["iterations"]
+    for a, c in zip(td, to):
+        if c[0] > 1e-6:
+            assert abs(a[0] - c[0]) <= 1e-6 * c[0]
+            assert abs(a[1] - c[1]) <= 1e-6
+
+
+def test_device_resident_ipm_portfolio(hip, oracle):
+    """a feasible portfolio SOCP (config-3 shape, small) solved by the device-resident loop and by the
+    oracle-backed loop: same iteration count, same optimum"""
+    from tests import ipm_device, ipm_driver as ipm
+    pr = problems.portfolio_problem(8, 60, seed=2)
+    args = (pr["n"], pr["m"], pr["P"], pr["A"], pr["q"], pr["b"], pr["cones"])
+    out = ipm_device.solve_device(hip, *args)
+    ref = ipm.solve(ipm.OracleBackend(oracle, *args), pr["cones"], pr["q"], pr["b"])
+    assert out["status"] == "Solved" and ref["status"] == "Solved"
+    assert out["iterations"] == ref["iterations"]
+    assert abs(out["obj_val"] - ref["obj_val"]) <= 1e-7 * max(1.0, abs(ref["obj_val"]))
+    assert np.linalg.norm(out["x"] - ref["x"]) <= 1e-5 * max(1.0, np.linalg.norm(ref["x"]))

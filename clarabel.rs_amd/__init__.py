@@ -540,14 +540,19 @@ class HipKKTSystem:
         cv = variables.cvars()
         return _status(lib().chip_kktsystem_solve_initial_point(self._h, C.byref(cv)), "solve_initial_point")
 
-    def residuals_update(self, variables, rx, rz, rx_inf, rz_inf, Px):
-        """device outputs (DeviceArray) + dict of the host scalars of residuals.rs:103-110"""
+    def residuals_update(self, variables, rx, rz, rx_inf, rz_inf, Px, norms=False):
+        """device outputs (DeviceArray) + dict of the host scalars of residuals.rs:103-110; with
+        norms=True also 'norms' = (||x||, ||z||, ||s||, ||rz||, ||rx||) from the same synchronisation"""
         cv = variables.cvars()
         o = (C.c_double * 5)()
-        _check(lib().chip_residuals_update(self._h, C.byref(cv), C.c_void_p(rx.ptr), C.c_void_p(rz.ptr),
-                                           C.c_void_p(rx_inf.ptr), C.c_void_p(rz_inf.ptr), C.c_void_p(Px.ptr), o),
-               "residuals_update")
-        return dict(rtau=o[0], dot_qx=o[1], dot_bz=o[2], dot_sz=o[3], dot_xPx=o[4])
+        nrm = (C.c_double * 5)() if norms else None
+        _check(lib().chip_residuals_update_norms(self._h, C.byref(cv), C.c_void_p(rx.ptr), C.c_void_p(rz.ptr),
+                                                 C.c_void_p(rx_inf.ptr), C.c_void_p(rz_inf.ptr), C.c_void_p(Px.ptr),
+                                                 o, nrm), "residuals_update")
+        out = dict(rtau=o[0], dot_qx=o[1], dot_bz=o[2], dot_sz=o[3], dot_xPx=o[4])
+        if norms:
+            out["norms"] = tuple(nrm)
+        return out
 
     # ---- DefaultVariables on the device (default/variables.rs:58-261) -------------------------
     @staticmethod

@@ -1443,6 +1443,35 @@ __global__ __launch_bounds__(WG) void k_dot_final(const double *__restrict__ par
     s = block_sum(s, red);
     if (threadIdx.x == 0) *out = s;
 }
+// several dot products per launch pair (each with exactly the partition of the single k_dot_partial
+// / k_dot_final pair, so the values do not depend on how they are batched)
+__global__ __launch_bounds__(WG) void k_multi_dot_partial(DotBatch bt, double *partials) {
+    __shared__ double red[16];
+    const DotSpec sp = bt.s[blockIdx.y];
+    const int nb = sp.n > 0 ? min(DOT_BLOCKS, (sp.n + WG - 1) / WG) : 0;
+    if ((int)blockIdx.x >= nb) return;
+    const double *__restrict__ a = sp.a;
+    const double *__restrict__ b = sp.b;
+    double acc = 0.0;
+    for (int i = blockIdx.x * WG + threadIdx.x; i < sp.n; i += nb * WG) acc += a[i] * b[i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.y * DOT_BLOCKS + blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(WG) void k_multi_dot_final(DotBatch bt, const double *__restrict__ partials,
+                                                        double *out) {
+    __shared__ double red[16];
+    const DotSpec sp = bt.s[blockIdx.x];
+    const int nb = sp.n > 0 ? min(DOT_BLOCKS, (sp.n + WG - 1) / WG) : 0;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += WG) acc += partials[blockIdx.x * DOT_BLOCKS + i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) out[sp.slot] = acc;
+}
+// w = a x + b y + c z
+__global__ __launch_bounds__(WG) void k_lin3(double *w, double a, const double *x, double b, const double *y,
+                                             double c, const double *z, int n) {
+    for (int i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) w[i] = a * x[i] + b * y[i] + c * z[i];
+}
 // vecmath.rs:87-99  dot_shifted: sum (s + a ds)(z + a dz), same two-stage reduction
 __global__ __launch_bounds__(WG) void k_dot_shifted_partial(const double *__restrict__ z, const double *__restrict__ sv,
                                                             const double *__restrict__ dz,
@@ -3311,6 +3340,19 @@ void dot(hipStream_t s, const double *a, const double *b, int n, double *out, do
     const int nb = n > 0 ? std::min(DOT_BLOCKS, (n + WG - 1) / WG) : 0;
     if (nb) k_dot_partial<<<nb, WG, 0, s>>>(a, b, n, scratch);
     k_dot_final<<<1, WG, 0, s>>>(scratch, nb, out);
+}
+int multi_dot_scratch_doubles() { return DOT_BATCH_MAX * DOT_BLOCKS; }
+void multi_dot(hipStream_t s, const DotBatch &bt, double *out, double *scratch) {
+    if (bt.count <= 0) return;
+    int nbmax = 0;
+    for (int k = 0; k < bt.count; k++)
+        if (bt.s[k].n > 0) nbmax = std::max(nbmax, std::min(DOT_BLOCKS, (bt.s[k].n + WG - 1) / WG));
+    if (nbmax) k_multi_dot_partial<<<dim3(nbmax, bt.count), WG, 0, s>>>(bt, scratch);
+    k_multi_dot_final<<<bt.count, WG, 0, s>>>(bt, scratch, out);
+}
+void lin3(hipStream_t s, double *w, double a, const double *x, double b, const double *y, double c, const double *z,
+          int n) {
+    if (n) k_lin3<<<stream_grid(n), WG, 0, s>>>(w, a, x, b, y, c, z, n);
 }
 void dot_shifted(hipStream_t s, const double *z, const double *sv, const double *dz, const double *ds, double alpha,
                  int n, double *out, double *scratch) {

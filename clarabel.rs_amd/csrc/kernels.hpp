@@ -145,6 +145,22 @@ void waxpby(hipStream_t s, double *w, double a, const double *x, double b, const
 // *out = a . b, deterministic (fixed partition + tree); scratch: dot_scratch_doubles() doubles
 int dot_scratch_doubles();
 void dot(hipStream_t s, const double *a, const double *b, int n, double *out, double *scratch);
+// up to DOT_BATCH_MAX dot products in one launch pair: out[spec.slot] = a . b with the same fixed
+// partition as dot(); scratch: multi_dot_scratch_doubles() doubles
+constexpr int DOT_BATCH_MAX = 12;
+struct DotSpec {
+    const double *a, *b;
+    int n, slot;
+};
+struct DotBatch {
+    DotSpec s[DOT_BATCH_MAX];
+    int count;
+};
+int multi_dot_scratch_doubles();
+void multi_dot(hipStream_t s, const DotBatch &bt, double *out, double *scratch);
+// w = a x + b y + c z
+void lin3(hipStream_t s, double *w, double a, const double *x, double b, const double *y, double c, const double *z,
+          int n);
 // *out = sum (s + alpha ds)(z + alpha dz)   (vecmath.rs:87-99)
 void dot_shifted(hipStream_t s, const double *z, const double *sv, const double *dz, const double *ds, double alpha,
                  int n, double *out, double *scratch);

@@ -104,7 +104,8 @@ struct chip_kktsystem {
     SpMat Psym, Arow, Acol; // P as full symmetric rows; A by rows (A x); A by columns (A' z)
     double *q = nullptr, *b = nullptr, *src = nullptr; // src: staging for value refreshes
     double *x1 = nullptr, *z1 = nullptr, *x2 = nullptr, *z2 = nullptr, *workx = nullptr, *workz = nullptr,
-           *work_conic = nullptr, *wn = nullptr;
+           *work_conic = nullptr, *wn = nullptr, *workx2 = nullptr, *wn2 = nullptr, *negq = nullptr;
+    dev::DotBatch batch{}; // dot products queued for ONE launch pair (flushed by read_dots)
     double *dots = nullptr, *scratch = nullptr; // 16 result slots + reduction scratch
     double hdots[16];
 
@@ -120,8 +121,17 @@ struct chip_kktsystem {
         CHIP_HIP(hipStreamSynchronize(stream)); // src is reused by the next refresh
         return CHIP_OK;
     }
-    void dot(int slot, const double *a, const double *bb, int len) { dev::dot(stream, a, bb, len, dots + slot, scratch); }
+    // queue a . b -> hdots[slot]; the operands must stay untouched until read_dots()
+    void dot(int slot, const double *a, const double *bb, int len) {
+        if (batch.count == dev::DOT_BATCH_MAX) flush_dots();
+        batch.s[batch.count++] = dev::DotSpec{a, bb, len, slot};
+    }
+    void flush_dots() {
+        dev::multi_dot(stream, batch, dots, scratch);
+        batch.count = 0;
+    }
     int read_dots() {
+        flush_dots();
         CHIP_HIP(hipMemcpyAsync(hdots, dots, sizeof(hdots), hipMemcpyDeviceToHost, stream));
         CHIP_HIP(hipStreamSynchronize(stream));
         return CHIP_OK;
@@ -150,6 +160,7 @@ static int refresh_data(chip_kktsystem *h, const double *P, const double *A, con
         if ((rc = h->refresh(h->Acol, A, h->nnzA))) return rc;
     }
     if (q && h->n) CHIP_HIP(hipMemcpyAsync(h->q, q, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (q && h->n) dev::waxpby(h->stream, h->negq, -1.0, h->q, 0.0, nullptr, h->n); // the constant rhs -q
     if (b && h->m) CHIP_HIP(hipMemcpyAsync(h->b, b, (size_t)h->m * sizeof(double), hipMemcpyHostToDevice, h->stream));
     CHIP_HIP(hipStreamSynchronize(h->stream));
     return CHIP_OK;
@@ -230,12 +241,13 @@ int32_t chip_kktsystem_create(chip_kktsystem **out, chip_kkt *kkt, const uint64_
     if ((rc = pl.alloc(&h->src, std::max<size_t>({(size_t)nnzP, (size_t)nnzA, (size_t)n, (size_t)m})))) return rc;
     if ((rc = pl.alloc(&h->q, n)) || (rc = pl.alloc(&h->b, m))) return rc;
     if ((rc = pl.alloc(&h->x1, n)) || (rc = pl.alloc(&h->x2, n)) || (rc = pl.alloc(&h->workx, n)) ||
-        (rc = pl.alloc(&h->wn, n)))
+        (rc = pl.alloc(&h->wn, n)) || (rc = pl.alloc(&h->workx2, n)) || (rc = pl.alloc(&h->wn2, n)) ||
+        (rc = pl.alloc(&h->negq, n)))
         return rc;
     if ((rc = pl.alloc(&h->z1, m)) || (rc = pl.alloc(&h->z2, m)) || (rc = pl.alloc(&h->workz, m)) ||
         (rc = pl.alloc(&h->work_conic, m)))
         return rc;
-    if ((rc = pl.alloc(&h->dots, 16)) || (rc = pl.alloc(&h->scratch, (size_t)dev::dot_scratch_doubles()))) return rc;
+    if ((rc = pl.alloc(&h->dots, 16)) || (rc = pl.alloc(&h->scratch, (size_t)dev::multi_dot_scratch_doubles()))) return rc;
     CHIP_HIP(hipMemset(h->dots, 0, 16 * sizeof(double)));
     if ((rc = refresh_data(h.get(), nnzP ? Pnzval : nullptr, nnzA ? Anzval : nullptr, q, b))) return rc;
     *out = h.release();
@@ -262,20 +274,21 @@ int32_t chip_kktsystem_update_data(chip_kktsystem *h, const double *P, const dou
 
 // kktsystem.rs:264-279
 int chip_kktsystem::solve_constant_rhs() {
-    dev::waxpby(stream, workx, -1.0, q, 0.0, nullptr, n); // workx = -q
-    int rc = chip_kkt_setrhs_dev(kkt, workx, b);
+    int rc = chip_kkt_setrhs_dev(kkt, negq, b);
     if (rc) return rc;
     rc = chip_kkt_solve_dev(kkt, x2, z2);
     if (rc != 1) return rc;
     // scalars of the tau denominator that only depend on (x2, z2)
     dot(0, q, x2, n);
     dot(1, b, z2, m);
-    spmv(Psym, wn, nullptr, 1.0, x2);
-    dot(2, x2, wn, n);
+    if (nnzP) {
+        spmv(Psym, wn, nullptr, 1.0, x2);
+        dot(2, x2, wn, n);
+    }
     if ((rc = read_dots())) return rc;
     qx2 = hdots[0];
     bz2 = hdots[1];
-    x2Px2 = hdots[2];
+    x2Px2 = nnzP ? hdots[2] : 0.0;
     return 1;
 }
 
@@ -294,39 +307,43 @@ int32_t chip_kktsystem_solve(chip_kktsystem *h, chip_vars *lhs, const chip_vars 
     const int n = h->n, m = h->m;
     hipStream_t s = h->stream;
     int rc;
-    // workx = rhs.x ; work_conic = the constant term of  Hs dz + ds = -c
-    if ((rc = h->copy(h->workx, rhs->x, n))) return rc;
-    if (step_direction == CHIP_STEP_AFFINE) {
-        if ((rc = h->copy(h->work_conic, var->s, m))) return rc;
-    } else {
+    // the reference's workx = rhs.x is read in place; conic = the constant term of  Hs dz + ds = -c
+    // (the affine step's copy of s is read in place as well)
+    const double *conic = var->s;
+    if (step_direction != CHIP_STEP_AFFINE) {
         if ((rc = chip_kkt_ds_from_dz_offset_dev(h->kkt, h->work_conic, rhs->s, var->z))) return rc;
+        conic = h->work_conic;
     }
-    dev::waxpby(s, h->workz, 1.0, h->work_conic, -1.0, rhs->z, m);
-    if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->workz))) return rc;
+    dev::waxpby(s, h->workz, 1.0, conic, -1.0, rhs->z, m);
+    if ((rc = chip_kkt_setrhs_dev(h->kkt, rhs->x, h->workz))) return rc;
     rc = chip_kkt_solve_dev(h->kkt, h->x1, h->z1);
     if (rc != 1) return rc;
-    // tau: xi = x / tau ; numerator and denominator of kktsystem.rs:170-186
+    // tau: xi = x / tau ; numerator and denominator of kktsystem.rs:170-186 (all four dot
+    // products in one launch pair; the P terms vanish identically for an LP / SOCP without P)
     const double tau = var->tau, kappa = var->kappa;
-    double *xi = h->workx;
-    dev::waxpby(s, xi, 1.0 / tau, var->x, 0.0, nullptr, n);
     h->dot(3, h->q, h->x1, n);
     h->dot(4, h->b, h->z1, m);
-    h->spmv(h->Psym, h->wn, nullptr, 1.0, h->x1); // P x1
-    h->dot(5, xi, h->wn, n);                       // xi' P x1
-    dev::waxpby(s, xi, -1.0, h->x2, 1.0, xi, n);   // xi - x2
-    h->spmv(h->Psym, h->wn, nullptr, 1.0, xi);
-    h->dot(6, xi, h->wn, n);                       // (xi - x2)' P (xi - x2)
+    if (h->nnzP) {
+        double *xi = h->workx, *xd = h->workx2;
+        dev::waxpby(s, xi, 1.0 / tau, var->x, 0.0, nullptr, n);
+        h->spmv(h->Psym, h->wn, nullptr, 1.0, h->x1); // P x1
+        h->dot(5, xi, h->wn, n);                       // xi' P x1
+        dev::waxpby(s, xd, -1.0, h->x2, 1.0, xi, n);   // xi - x2
+        h->spmv(h->Psym, h->wn2, nullptr, 1.0, xd);
+        h->dot(6, xd, h->wn2, n);                      // (xi - x2)' P (xi - x2)
+    }
     if ((rc = h->read_dots())) return rc;
-    const double tau_num = rhs->tau - rhs->kappa / tau + h->hdots[3] + h->hdots[4] + 2.0 * h->hdots[5];
+    const double xiPx1 = h->nnzP ? h->hdots[5] : 0.0, dPd = h->nnzP ? h->hdots[6] : 0.0;
+    const double tau_num = rhs->tau - rhs->kappa / tau + h->hdots[3] + h->hdots[4] + 2.0 * xiPx1;
     double tau_den = kappa / tau - h->qx2 - h->bz2;
-    tau_den += h->hdots[6] - h->x2Px2;
+    tau_den += dPd - h->x2Px2;
     const double ltau = tau_num / tau_den;
     lhs->tau = ltau;
     dev::waxpby(s, lhs->x, 1.0, h->x1, ltau, h->x2, n);
     dev::waxpby(s, lhs->z, 1.0, h->z1, ltau, h->z2, m);
     // ds = -(Hs dz + c)
     if ((rc = chip_kkt_mul_Hs_dev(h->kkt, lhs->s, lhs->z))) return rc;
-    dev::waxpby(s, lhs->s, -1.0, h->work_conic, -1.0, lhs->s, m);
+    dev::waxpby(s, lhs->s, -1.0, conic, -1.0, lhs->s, m);
     lhs->kappa = -(rhs->kappa + kappa * ltau) / tau;
     CHIP_HIP(hipGetLastError());
     return 1;
@@ -340,20 +357,16 @@ int32_t chip_kktsystem_solve_initial_point(chip_kktsystem *h, chip_vars *var) {
     int rc;
     if (h->nnzP == 0) { // LP initialisation: [0; b] -> (x, -s), then [-q; 0] -> z
         if ((rc = h->zero(h->workx, n))) return rc;
-        if ((rc = h->copy(h->workz, h->b, m))) return rc;
-        if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->workz))) return rc;
+        if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->b))) return rc;
         rc = chip_kkt_solve_dev(h->kkt, var->x, var->s);
         dev::waxpby(s, var->s, -1.0, var->s, 0.0, nullptr, m); // negate (also on failure, as the reference)
         if (rc != 1) return rc;
-        dev::waxpby(s, h->workx, -1.0, h->q, 0.0, nullptr, n);
         if ((rc = h->zero(h->workz, m))) return rc;
-        if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->workz))) return rc;
+        if ((rc = chip_kkt_setrhs_dev(h->kkt, h->negq, h->workz))) return rc;
         rc = chip_kkt_solve_dev(h->kkt, nullptr, var->z);
         return rc;
     }
-    dev::waxpby(s, h->workx, -1.0, h->q, 0.0, nullptr, n);
-    if ((rc = h->copy(h->workz, h->b, m))) return rc;
-    if ((rc = chip_kkt_setrhs_dev(h->kkt, h->workx, h->workz))) return rc;
+    if ((rc = chip_kkt_setrhs_dev(h->kkt, h->negq, h->b))) return rc;
     rc = chip_kkt_solve_dev(h->kkt, var->x, var->z);
     dev::waxpby(s, var->s, -1.0, var->z, 0.0, nullptr, m);
     return rc;
@@ -361,23 +374,38 @@ int32_t chip_kktsystem_solve_initial_point(chip_kktsystem *h, chip_vars *var) {
 
 int32_t chip_residuals_update(chip_kktsystem *h, const chip_vars *var, double *rx, double *rz, double *rx_inf,
                               double *rz_inf, double *Px, double out5[5]) {
+    return chip_residuals_update_norms(h, var, rx, rz, rx_inf, rz_inf, Px, out5, nullptr);
+}
+int32_t chip_residuals_update_norms(chip_kktsystem *h, const chip_vars *var, double *rx, double *rz, double *rx_inf,
+                                    double *rz_inf, double *Px, double out5[5], double *norms5) {
     if (!h || !var || !out5) return CHIP_ERR_ARG;
     CHIP_HIP(hipSetDevice(h->device));
     const int n = h->n, m = h->m;
     hipStream_t s = h->stream;
+    int rc;
     h->dot(8, h->q, var->x, n);
     h->dot(9, h->b, var->z, m);
     h->dot(10, var->s, var->z, m);
-    h->spmv(h->Psym, Px, nullptr, 1.0, var->x);     // Px = P x (P symmetric)
-    h->dot(11, var->x, Px, n);
+    if (h->nnzP) {
+        h->spmv(h->Psym, Px, nullptr, 1.0, var->x); // Px = P x (P symmetric)
+        h->dot(11, var->x, Px, n);
+    } else if ((rc = h->zero(Px, n)))
+        return rc;
     h->spmv(h->Acol, rx_inf, nullptr, -1.0, var->z); // rx_inf = -A' z
     h->spmv(h->Arow, rz_inf, var->s, 1.0, var->x);   // rz_inf = A x + s
-    dev::waxpby(s, rx, -1.0, Px, -var->tau, h->q, n); // rx = rx_inf - Px - q tau
-    dev::waxpby(s, rx, 1.0, rx_inf, 1.0, rx, n);
-    dev::waxpby(s, rz, 1.0, rz_inf, -var->tau, h->b, m); // rz = rz_inf - b tau
-    int rc = h->read_dots();
-    if (rc) return rc;
-    const double qx = h->hdots[8], bz = h->hdots[9], sz = h->hdots[10], xPx = h->hdots[11];
+    dev::lin3(s, rx, 1.0, rx_inf, -1.0, Px, -var->tau, h->q, n); // rx = rx_inf - Px - q tau
+    dev::waxpby(s, rz, 1.0, rz_inf, -var->tau, h->b, m);         // rz = rz_inf - b tau
+    if (norms5) { // ||x||, ||z||, ||s||, ||rz||, ||rx|| (default/info.rs:142-165) in the same launch pair
+        h->dot(0, var->x, var->x, n);
+        h->dot(1, var->z, var->z, m);
+        h->dot(2, var->s, var->s, m);
+        h->dot(3, rz, rz, m);
+        h->dot(4, rx, rx, n);
+    }
+    if ((rc = h->read_dots())) return rc;
+    if (norms5)
+        for (int k = 0; k < 5; k++) norms5[k] = std::sqrt(h->hdots[k]);
+    const double qx = h->hdots[8], bz = h->hdots[9], sz = h->hdots[10], xPx = h->nnzP ? h->hdots[11] : 0.0;
     out5[0] = qx + bz + var->kappa + xPx / var->tau;
     out5[1] = qx;
     out5[2] = bz;

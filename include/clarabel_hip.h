@@ -337,6 +337,12 @@ int32_t chip_kktsystem_solve_initial_point(chip_kktsystem *h, chip_vars *variabl
 int32_t chip_residuals_update(chip_kktsystem *h, const chip_vars *variables, double *rx_dev,
                               double *rz_dev, double *rx_inf_dev, double *rz_inf_dev, double *Px_dev,
                               double out5[5]);
+/* the same + the Euclidean norms DefaultInfo::update (default/info.rs:142-165) takes of the vectors
+ * involved, norms5 = {||x||, ||z||, ||s||, ||rz||, ||rx||} (NULL = skip), reduced in the same launches
+ * and returned by the same single device-to-host copy */
+int32_t chip_residuals_update_norms(chip_kktsystem *h, const chip_vars *variables, double *rx_dev,
+                                    double *rz_dev, double *rx_inf_dev, double *rz_inf_dev, double *Px_dev,
+                                    double out5[5], double *norms5_or_null);
 /* data_updating.rs:98-133: new values on the same patterns (NULL = unchanged); P and A are
  * forwarded to chip_kkt_update_P / chip_kkt_update_A */
 int32_t chip_kktsystem_update_data(chip_kktsystem *h, const double *Pnzval_or_null,

@@ -77,13 +77,13 @@ def solve_device(hip, n, m, P, A, q, b, cones, max_iter=200, tol_gap_abs=1e-8, t
     t_loop = time.perf_counter()
     while True:
         with clock("residuals+info"):
-            res = sysd.residuals_update(variables, rx, rz, rx_inf, rz_inf, Px)
+            res = sysd.residuals_update(variables, rx, rz, rx_inf, rz_inf, Px, norms=True)
             mu = sysd.calc_mu(variables, res["dot_sz"])
             tinv = 1.0 / variables.tau
             xPx2 = res["dot_xPx"] * tinv * tinv / 2.0
             cost_primal = res["dot_qx"] * tinv + xPx2
             cost_dual = -res["dot_bz"] * tinv - xPx2
-            nx, nz, ns, nrz, nrx = sysd.vec_norms(variables.x, variables.z, variables.s, rz, rx)
+            nx, nz, ns, nrz, nrx = res["norms"]
             normx, normz, norms = nx * tinv, nz * tinv, ns * tinv
             res_primal = nrz * tinv / max(1.0, normb + normx + norms)
             res_dual = nrx * tinv / max(1.0, normq + normx + normz)

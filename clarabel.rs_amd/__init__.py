@@ -167,6 +167,18 @@ def amd_order(n, colptr, rowval, dense_scale=1.5):
     return perm.astype(np.int64), iperm.astype(np.int64), info
 
 
+def _supernodes(fn, h):
+    cnt = C.c_int64()
+    _check(fn(h, C.byref(cnt), None, None), "get_supernodes")
+    if cnt.value == 0:
+        return []
+    ptr = np.zeros(cnt.value + 1, dtype=u64)
+    _check(fn(h, C.byref(cnt), _pu(ptr), None), "get_supernodes")
+    cols = np.zeros(max(int(ptr[-1]), 1), dtype=u64)
+    _check(fn(h, C.byref(cnt), _pu(ptr), _pu(cols)), "get_supernodes")
+    return [cols[int(ptr[i]):int(ptr[i + 1])].astype(np.int64) for i in range(cnt.value)]
+
+
 class CscMatrix:
     """CscMatrix<f64> (src/algebra/csc/core.rs:45-60): m, n, colptr, rowval, nzval."""
 
@@ -271,6 +283,9 @@ class HipDirectLDLSolver:
         et = et.astype(np.int64)  # UINT64_MAX -> -1
         return et, Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), lv[:self.n].astype(np.int64)
 
+    def supernodes(self):
+        return _supernodes(lib().chip_ldl_get_supernodes, self._h)
+
     def factors(self):
         info = self.linear_solver_info()
         Lp = np.zeros(self.n + 1, dtype=u64)
@@ -358,6 +373,10 @@ class HipKKTSolver:
         lv = np.zeros(max(self.N, 1), dtype=u64)
         _check(lib().chip_kkt_get_symbolic(self._h, _pu(et), _pu(Lp), _pu(Li), _pu(lv)), "get_symbolic")
         return et.astype(np.int64), Lp.astype(np.int64), Li[:info.nnzL].astype(np.int64), lv[:self.N].astype(np.int64)
+
+    def supernodes(self):
+        """[(columns ascending, permuted numbering), ...] of the chain supernodes"""
+        return _supernodes(lib().chip_kkt_get_supernodes, self._h)
 
     def values(self):
         nz = np.zeros(max(self.nnzK, 1))

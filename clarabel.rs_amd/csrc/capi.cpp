@@ -583,6 +583,22 @@ int32_t chip_kkt_degree(const chip_kkt *h, int64_t *degree) {
     *degree = d;
     return CHIP_OK;
 }
+// diagnostics: the chain supernodes chosen by the symbolic analysis (host.hpp: Symbolic::sn_*)
+static int32_t get_supernodes(const Engine &E, int64_t *count, uint64_t *ptr, uint64_t *cols) {
+    if (!count) return CHIP_ERR_ARG;
+    *count = E.nsn > 0 ? E.nsn : 0;
+    if (ptr)
+        for (size_t i = 0; i < E.h_sn_ptr.size(); i++) ptr[i] = (uint64_t)E.h_sn_ptr[i];
+    if (cols)
+        for (size_t i = 0; i < E.h_sn_col.size(); i++) cols[i] = (uint64_t)E.h_sn_col[i];
+    return CHIP_OK;
+}
+int32_t chip_kkt_get_supernodes(const chip_kkt *h, int64_t *count, uint64_t *ptr, uint64_t *cols) {
+    return h ? get_supernodes(h->E, count, ptr, cols) : CHIP_ERR_ARG;
+}
+int32_t chip_ldl_get_supernodes(const chip_ldl *h, int64_t *count, uint64_t *ptr, uint64_t *cols) {
+    return h ? get_supernodes(h->E, count, ptr, cols) : CHIP_ERR_ARG;
+}
 int32_t chip_kkt_get_matrix(const chip_kkt *h, uint64_t *colptr, uint64_t *rowval, double *nzval) {
     if (!h) return CHIP_ERR_ARG;
     const KktLayout &K = h->K;

@@ -96,6 +96,10 @@ void Engine::init_host_only(const Symbolic &S, const chip_settings &settings) {
     h_Lp = S.Lp;
     h_Li = S.Li;
     amd = S.amd;
+    h_sn_ptr = S.sn_ptr;
+    h_sn_col = S.sn_col;
+    nsn = (int)S.sn_ptr.size() - 1;
+    nfaclevels = S.nfaclevels;
 }
 
 int Engine::get_symbolic(uint64_t *etree, uint64_t *oLp, uint64_t *oLi, uint64_t *lvlptr) const {
@@ -181,6 +185,40 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = upload_lists(fwd, S.fwd))) return rc;
     if ((rc = upload_lists(bwd, S.bwd))) return rc;
     if ((rc = upload_lists(smv, S.smv))) return rc;
+    nfaclevels = S.nfaclevels;
+    nsn = (int)S.sn_ptr.size() - 1;
+    h_sn_ptr = S.sn_ptr;
+    h_sn_col = S.sn_col;
+    if (nsn > 0) {
+        if ((rc = upload_lists(snx, S.snx))) return rc;
+        if ((rc = upload_lists(fwu, S.fwu))) return rc;
+        if ((rc = upload_lists(bwu, S.bwu))) return rc;
+        nRf = S.Rf_p.empty() ? 0 : S.Rf_p.back();
+        if ((rc = alloc(&Rfx, (size_t)nRf))) return rc;
+        if ((rc = upload(&sn_ptr, S.sn_ptr, S.sn_ptr.size()))) return rc;
+        if ((rc = upload(&sn_col, S.sn_col, S.sn_col.size()))) return rc;
+        if ((rc = upload(&sn_order, S.sn_order, S.sn_order.size()))) return rc;
+        if ((rc = upload(&Rf_p, S.Rf_p, S.Rf_p.size()))) return rc;
+        if ((rc = upload(&Rf_col, S.Rf_col, S.Rf_col.size()))) return rc;
+        if ((rc = upload(&Rf_pos, S.Rf_pos, S.Rf_pos.size()))) return rc;
+        if ((rc = upload(&upd_slot, S.upd_slot, S.upd_slot.size()))) return rc;
+        {
+            std::vector<long long> up(S.upd_ptr.begin(), S.upd_ptr.end());
+            if ((rc = upload(&upd_ptr, up, up.size()))) return rc;
+        }
+        sn_lvl_ptr = S.sn_lvl_ptr;
+        sn_lvl_nblk = S.sn_lvl_nblk;
+        sn_lvl_hmax = S.sn_lvl_hmax;
+        sn_lvl_nbmax = S.sn_lvl_nbmax;
+        sn_wmax = 0;
+        for (int sn = 0; sn < nsn; sn++) sn_wmax = std::max(sn_wmax, S.sn_ptr[sn + 1] - S.sn_ptr[sn]);
+        sn_nbmax = 0;
+        for (int l = 0; l < S.nfaclevels; l++) sn_nbmax = std::max(sn_nbmax, S.sn_lvl_nbmax[l]);
+        if (dev::snode_kernel_attributes(sn_wmax, sn_nbmax) != 0) {
+            set_error("k_factor_snode: dynamic LDS size rejected");
+            return CHIP_ERR_HIP;
+        }
+    }
     {
         int *bp = nullptr, *lp = nullptr, *lv = nullptr;
         if ((rc = upload(&bp, S.bundle_ptr, S.bundle_ptr.size()))) return rc;
@@ -319,25 +357,50 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
     const bool top_folded = fold.k == 1; // single top column: pivot accumulated by the bundles
     if (top_folded) dev::fold_top_pivot(stream, v, fold);
     const bool use_chain = std::getenv("CHIP_NO_FACTOR_CHAIN") == nullptr;
-    for (int l = top_folded ? nlevels : 0; l < nlevels;) {
-        const int e = fac.chain_end[l];
+    // units (single columns, chain supernodes) by unit level; a level's supernodes run after its
+    // single columns: first the contributions of outside columns into their members (the chunked
+    // column kernel over the external lists, no pivots), then one workgroup per supernode
+    dev::LdlView vf = v; // top-level column kernels: row lists without supernode-member columns
+    if (nsn > 0) {
+        vf.Rp = Rf_p;
+        vf.Rcol = Rf_col;
+        vf.Rpos = Rf_pos;
+    }
+    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot};
+    auto has_sn = [&](int l) { return nsn > 0 && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
+    auto run_supernodes = [&](int l) {
+        if (!has_sn(l)) return;
+        dev::factor_B(stream, vf, snx.B(l));
+        dev::factor_snodes(stream, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l], sn_wmax,
+                           sn_lvl_nblk[l], sn_lvl_hmax[l], sn_lvl_nbmax[l]);
+    };
+    for (int l = top_folded ? nfaclevels : 0; l < nfaclevels;) {
+        int e = fac.chain_end[l];
+        for (int k = l; k < e; k++)
+            if (has_sn(k)) { // a level with supernodes ends the run: they must precede the next level
+                e = k + 1;
+                break;
+            }
         if (use_chain && e - l >= 4) { // a chain-like stretch: one single-workgroup launch for levels [l, e)
-            dev::factor_chain(stream, v, fac.t_idx, fac.d_t_ptr, fac.w_idx, fac.d_w_ptr, l, e);
+            dev::factor_chain(stream, vf, fac.t_idx, fac.d_t_ptr, fac.w_idx, fac.d_w_ptr, l, e);
+            run_supernodes(e - 1);
             l = e;
             continue;
         }
         prof_begin(PF_FACTOR_T);
-        dev::factor_T(stream, v, fac.T(l));
+        dev::factor_T(stream, vf, fac.T(l));
         prof_end(PF_FACTOR_T);
-        dev::factor_W(stream, v, fac.W(l));
+        dev::factor_W(stream, vf, fac.W(l));
         const dev::ChunkView b = fac.B(l);
         if (b.count) {
-            dev::factor_B(stream, v, b);
+            dev::factor_B(stream, vf, b);
             dev::factor_finalize(stream, v, fac.BR(l));
         }
+        run_supernodes(l);
         l++;
     }
-    dev::topblk_build(stream, v, topblk); // inverses of the diagonal blocks of a tall top
+    if (nsn > 0) dev::gather_values(stream, Rfx, Lx, Rf_pos, nRf); // L at the filtered row lists (forward sweep)
+    else dev::topblk_build(stream, v, topblk); // inverses of the diagonal blocks of a tall top
     dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
     dev::gather_values(stream, Ux, Kx, Umap, (int)nnzU);
     int rc = read_mailbox();
@@ -385,6 +448,29 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
     dev::bundle_fwd(stream, v, bundles, xp, fold);
     if (fold.k) { // an "arrow": the bundles have already folded the top rows; finish the k x k part
         dev::fold_top_solve(stream, v, fold, xp);
+        dev::bundle_bwd(stream, v, bundles, xp, addv);
+        if (addv && N > NF) dev::add_vec(stream, xp + NF, addv + NF, N - NF);
+        return;
+    }
+    if (nsn > 0) {
+        // chain supernodes: units by unit level.  Forward: every top row first gathers from the columns
+        // that are not supernode members, then the level's supernodes solve their dense triangles and
+        // push L_BS x_S to their ancestors' entries; backward: the reverse, column oriented.
+        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot};
+        dev::GatherArgs f{Rf_p, Rf_col, Rfx, xp, xp, nullptr, nullptr, nullptr};
+        for (int l = 0; l < nfaclevels; l++) {
+            dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
+            dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                              sn_wmax, sn_nbmax, xp);
+        }
+        dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
+        for (int l = nfaclevels - 1; l >= 0; l--) {
+            dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                              sn_wmax, sn_nbmax, xp);
+            const dev::ChunkView b = bwu.B(l);
+            if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwu.BR(l));
+            dev::gather_merged(stream, dev::BWD, g, bwu.T(l), bwu.W(l), b);
+        }
         dev::bundle_bwd(stream, v, bundles, xp, addv);
         if (addv && N > NF) dev::add_vec(stream, xp + NF, addv + NF, N - NF);
         return;

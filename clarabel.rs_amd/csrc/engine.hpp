@@ -62,6 +62,15 @@ struct Engine {
     // values (device)
     double *Kx = nullptr, *Lx = nullptr, *Rx = nullptr, *D = nullptr, *Dinv = nullptr, *Sx = nullptr;
     DeviceLists fac, fwd, bwd, smv;
+    // chain supernodes (host.hpp: Symbolic::sn_*): factor lists `fac` and `snx` are indexed by UNIT level
+    int nfaclevels = 0, nsn = 0, sn_wmax = 0;
+    DeviceLists snx, fwu, bwu;
+    double *Rfx = nullptr; // values of L at the filtered row lists (refreshed per refactor)
+    int nRf = 0, sn_nbmax = 0;
+    int *sn_ptr = nullptr, *sn_col = nullptr, *sn_order = nullptr, *Rf_p = nullptr, *Rf_col = nullptr,
+        *Rf_pos = nullptr, *upd_slot = nullptr;
+    long long *upd_ptr = nullptr;
+    std::vector<i32> sn_lvl_ptr, sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax, h_sn_ptr, h_sn_col;
     dev::BundleView bundles{}; // subtree bundles (device arrays)
     dev::FoldView fold{};      // few dense top rows folded into the bundle kernels (k == 0: not used)
     dev::TopBlkView topblk{};  // blocked substitution of a tall top (nblocks == 0: level-scheduled top)

@@ -88,6 +88,29 @@ struct Symbolic {
     i32 nfold = 0;
     std::vector<i32> fold_rseg, fold_tt, fold_sp, fold_scol, fold_sslot;
     std::vector<i32> lvlptr;
+    // Chain supernodes of the top (symbolic.cpp): supernode s = columns sn_col[sn_ptr[s] .. sn_ptr[s+1])
+    // (ascending, each the parent of the previous one); all its columns are padded to the dense
+    // trapezoid {later members} + struct(last).  sn_of[j] = supernode of column j or -1.
+    // The numeric factorisation schedules UNITS (supernodes and the remaining single top columns) by
+    // unit level (fac lists below are indexed by unit level, nfaclevels of them): per level first the
+    // ordinary columns (fac), then the contributions from OUTSIDE columns into the members of the
+    // level's supernodes (snx: chunks over the filtered row lists Rf_*), then the level's supernodes
+    // block column by block column (sn_lvl_ptr ranges of sn_order) and their dense updates of the
+    // ancestors' columns (upd_slot).
+    std::vector<i32> sn_of, sn_ptr, sn_col;
+    // row lists (CSR of L: column, CSC slot) of the top rows WITHOUT supernode-member columns; empty
+    // when there are no supernodes
+    std::vector<i32> Rf_p, Rf_col, Rf_pos;
+    std::vector<i64> upd_ptr;   // per supernode: its range of upd_slot (packed strict lower triangle of B x B)
+    std::vector<i32> upd_slot;  // CSC slot of L(B[r], B[c])
+    std::vector<i32> sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax; // per unit level: maxima over its supernodes
+    std::vector<i32> sn_lvl_ptr, sn_order;      // supernodes by unit level
+    i32 nfaclevels = 0;
+    // substitutions with supernodes, by unit level: fwu = rows of L restricted to non-member columns
+    // (all top rows; the members' dense parts and the supernodes' pushes to their B rows are done by
+    // k_snode_fwd), bwu = columns of the single top columns (the members' columns: k_snode_bwd)
+    LevelLists fwu, bwu;
+    LevelLists snx;                             // per unit level: B chunks (b_row = member column, ranges into Rf_*)
     // K for the residual e = b - K x, permuted numbering; *map = index into the caller's
     // K.nzval (values are refreshed by a gather at every refactor):
     //   U : rows i < NF (bundle nodes): diagonal + entries to ancestors, each K entry ONCE

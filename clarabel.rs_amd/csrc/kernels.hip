@@ -250,6 +250,7 @@ __global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restric
 
 constexpr int RCAP = 512;      // contributions per flattened batch (scan needs blockDim >= RCAP/2)
 constexpr int W_LDS_CAP = 2048; // column values + row ids kept in LDS (16 + 8 KiB of 160 KiB)
+constexpr int B_LDS_CAP = 4096; // the same for the chunked column kernel (padded supernode columns are long)
 
 __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int hi, int row) {
     // first q in [lo,hi) with Li[q] >= row (the row is known to be present)
@@ -734,8 +735,8 @@ __global__ __launch_bounds__(WG) void k_factor_B(LdlView v, const int *__restric
                                                  const int *__restrict__ cbeg,
                                                  const int *__restrict__ cend, int count) {
     __shared__ double red[16];
-    __shared__ double acc[W_LDS_CAP];
-    __shared__ int rows[W_LDS_CAP];
+    __shared__ double acc[B_LDS_CAP];
+    __shared__ int rows[B_LDS_CAP];
     __shared__ int cst[RCAP];
     __shared__ double cw[RCAP];
     __shared__ int coff[RCAP + 1];
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(WG) void k_factor_B(LdlView v, const int *__restric
     const int cb = v.Lp[j], ce = v.Lp[j + 1], cn = ce - cb;
     const int tb = cbeg[blockIdx.x], te = cend[blockIdx.x], tid = threadIdx.x;
     double dpart = 0.0;
-    if (cn >= 24 && cn <= W_LDS_CAP) {
+    if (cn >= 24 && cn <= B_LDS_CAP) {
         // dense-front column: this workgroup folds its slice of the contributions into a private
         // LDS copy of the column (flattened (contribution, tail entry) pairs, as factor_col_block)
         // and meets the other slices with ONE global atomic per row at the end
@@ -847,6 +848,413 @@ __global__ __launch_bounds__(WG) void k_factor_finalize(LdlView v, const int *__
         v.Lx[q] = l;
         v.Rx[v.Tpos[q]] = l;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Chain supernodes (host.hpp: Symbolic::sn_*): w columns c_0 < ... < c_{w-1}, each the parent of the
+// previous one, all padded to the dense trapezoid  rows(c_t) = [c_{t+1}, ..., c_{w-1}, B...]  with
+// B = struct(c_{w-1}), so that panel entry (i, t), i > t, is Lx[Lp[c_t] + i - t - 1] (panel rows i < w
+// are the members, rows >= w the nb rows of B).  On entry Lx / D of the members hold K minus the
+// contributions of all columns that are NOT supernode members (the sparse column kernels over the
+// filtered row lists) and minus the dense updates of descendant supernodes (k_snode_extend).
+// All supernodes of a unit level advance together, one block column of SN_NB at a time, kernel
+// boundaries acting as the grid-wide synchronisation:
+//   k_snode_update(b): A'[i, J_b] -= sum_{k < j0} L[i,k] d_k L[j,k] for all panel rows i >= j0 = 64 b,
+//      left-looking, 16 x 64 tiles on the f64 matrix cores (v_mfma_f64_16x16x4_f64, four per A
+//      operand); the (d_k L[j,k]) operand is staged in LDS SN_KC columns at a time, the L[i,k] operand is
+//      streamed from the finished columns in 128-byte runs, SN_U requests in flight per lane;
+//   k_snode_diag(b): the 64 x 64 diagonal block column by column with the sign-based dynamic
+//      regularisation of qdldl.rs:645-665 in LDS;  k_snode_rows(b): the rows below it, one thread per
+//      row, by forward substitution against the block;
+//   k_snode_extend: once a supernode is complete, its update of the ANCESTORS' columns, the
+//      nb x nb matrix L_B D L_B' (the multifrontal "update matrix"), computed with the same tiles
+//      and subtracted at precomputed slots (upd_slot) with fp64 atomics.
+// ~64 flops per streamed double instead of the ~1/8 of the per-entry gathers of the column kernels.
+// ---------------------------------------------------------------------------
+constexpr int SN_NB = 64;
+constexpr int SN_KC = 128;  // 64 * 128 * 8 = 64 KiB
+constexpr int SN_U = 8;     // A operands requested ahead of the matrix instructions that consume them
+constexpr int SN_WG = 512;
+constexpr int SN_ROWS = 256; // panel rows per workgroup of the update kernels: 8 waves x 2 tiles of 16
+typedef double snode_v4d __attribute__((ext_vector_type(4)));
+
+struct SnodeGeom {
+    const int *cols;
+    int w, nb, h, e;
+};
+__device__ __forceinline__ SnodeGeom snode_geom(const LdlView &v, const SnodeView &sv, int sn) {
+    SnodeGeom g;
+    g.cols = sv.sn_col + sv.sn_ptr[sn];
+    g.w = sv.sn_ptr[sn + 1] - sv.sn_ptr[sn];
+    g.e = g.cols[g.w - 1];
+    g.nb = v.Lp[g.e + 1] - v.Lp[g.e];
+    g.h = g.w + g.nb;
+    return g;
+}
+
+// acc[2][4] += L[rows of this wave's two tiles, k0..kend) * (d L[jrow0.., k])' ; emit per element.
+// EXTEND = false: targets are the supernode's own block column (plain stores, each element owned by
+// one lane); true: the ancestors' columns through upd_slot (atomics).
+template <bool EXTEND>
+__device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &sv, const SnodeGeom &g, int sn,
+                                            const int *colbase, double *Wl, int jrow0, int ncols, int kend,
+                                            int row_begin) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4, l15 = lane & 15;
+    const int i0[2] = {row_begin + wave * 32, row_begin + wave * 32 + 16};
+    const int irow[2] = {i0[0] + l15, i0[1] + l15};
+    const bool rowok[2] = {irow[0] < g.h, irow[1] < g.h};
+    snode_v4d acc[2][SN_NB / 16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < SN_NB / 16; ++c) acc[t][c] = snode_v4d{0.0, 0.0, 0.0, 0.0};
+    for (int kc0 = 0; kc0 < kend; kc0 += SN_KC) {
+        const int kcn = min(SN_KC, kend - kc0);
+        const int kcn4 = (kcn + 3) & ~3;
+        __syncthreads(); // the previous chunk has been consumed
+        for (int idx = tid; idx < kcn4 * SN_NB; idx += SN_WG) {
+            const int kk = idx / SN_NB, jj = idx % SN_NB;
+            double val = 0.0;
+            if (kk < kcn && jj < ncols) {
+                const int k = kc0 + kk;
+                val = v.Lx[colbase[k] + jrow0 + jj] * v.D[g.cols[k]];
+            }
+            Wl[idx] = val;
+        }
+        __syncthreads();
+        if (i0[0] >= g.h) continue; // (after the barriers: the whole wave is beyond the panel)
+        for (int kk = 0; kk < kcn4; kk += 4 * SN_U) {
+            double a[2][SN_U];
+#pragma unroll
+            for (int u = 0; u < SN_U; ++u) { // independent 128-byte runs in flight
+                const int kl = kk + 4 * u + kq;
+                const bool kok = kl < kcn;
+                const int cb = kok ? colbase[kc0 + kl] : 0;
+                a[0][u] = (kok && rowok[0]) ? v.Lx[cb + irow[0]] : 0.0;
+                a[1][u] = (kok && rowok[1]) ? v.Lx[cb + irow[1]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < SN_U; ++u) {
+                if (kk + 4 * u < kcn4) {
+                    const int kl = kk + 4 * u + kq;
+#pragma unroll
+                    for (int c = 0; c < SN_NB / 16; ++c) {
+                        const double bw = Wl[kl * SN_NB + 16 * c + l15];
+                        acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][u], bw, acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][u], bw, acc[1][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    const int *Bn = v.Li + v.Lp[g.e]; // node ids of the rows of B
+    const long long ubase = EXTEND ? sv.upd_ptr[sn] : 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0[t] + kq + 4 * r;
+            if (i >= g.h) continue;
+#pragma unroll
+            for (int c = 0; c < SN_NB / 16; ++c) {
+                const int jj = l15 + 16 * c;
+                if (jj >= ncols) continue;
+                const int j = jrow0 + jj;
+                const double val = acc[t][c][r];
+                if (!EXTEND) {
+                    if (i > j) v.Lx[colbase[j] + i] -= val;
+                    else if (i == j) v.D[g.cols[j]] -= val;
+                } else {
+                    const int rB = i - g.w, cB = j - g.w;
+                    if (rB > cB) {
+                        const long long u = ubase + (long long)cB * g.nb - (long long)cB * (cB + 1) / 2 + (rB - cB - 1);
+                        atomicAdd(&v.Lx[sv.upd_slot[u]], -val);
+                    } else if (rB == cB) {
+                        atomicAdd(&v.D[Bn[cB]], -val);
+                    }
+                }
+            }
+        }
+}
+
+__device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
+    Wl = (double *)smem;
+    return (int *)(Wl + SN_KC * SN_NB);
+}
+// grid (row groups, supernodes of the level)
+__global__ __launch_bounds__(SN_WG) void k_snode_update(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                        int b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Wl;
+    int *colbase = snode_lds(smem, Wl);
+    const int sn = order[blockIdx.y];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int row_begin = j0 + (int)blockIdx.x * SN_ROWS;
+    if (row_begin >= g.h) return;
+    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = v.Lp[g.cols[t]] - t - 1;
+    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), j0, row_begin);
+}
+// grid (row groups, column blocks of B, supernodes of the level)
+__global__ __launch_bounds__(SN_WG) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Wl;
+    int *colbase = snode_lds(smem, Wl);
+    const int sn = order[blockIdx.z];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int c0 = (int)blockIdx.y * SN_NB;
+    if (c0 >= g.nb) return;
+    const int row_begin = g.w + c0 + (int)blockIdx.x * SN_ROWS;
+    if (row_begin >= g.h) return;
+    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = v.Lp[g.cols[t]] - t - 1;
+    snode_tiles<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SN_NB, g.nb - c0), g.w, row_begin);
+}
+// grid (supernodes of the level): the SN_NB x SN_NB diagonal block of block column b, column by
+// column in LDS (two barriers per column; the pivots and their regularisation stay in LDS until
+// the end); leaves the scaled block in Lx / Rx and (d, 1/d) in D / Dinv
+constexpr int SN_DWG = 256;
+__global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                       int b) {
+    __shared__ double T[SN_NB * SN_NB]; // row-major
+    __shared__ double dl[SN_NB], dinvl[SN_NB], lcol[SN_NB], sgn[SN_NB];
+    __shared__ int colbase[SN_NB];
+    __shared__ int nreg, bad;
+    const int sn = order[blockIdx.x];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x;
+    if (tid < nbw) {
+        const int c = g.cols[j0 + tid];
+        colbase[tid] = v.Lp[c] - (j0 + tid) - 1;
+        dl[tid] = v.D[c];
+        sgn[tid] = (double)v.dsigns[c];
+    }
+    if (tid == 0) nreg = 0, bad = 0;
+    __syncthreads();
+    for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_DWG) {
+        const int ii = idx / SN_NB, jj = idx % SN_NB;
+        T[idx] = (ii > jj && ii < nbw) ? v.Lx[colbase[jj] + j0 + ii] : 0.0;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < nbw; ++jj) {
+        // pivot rule (qdldl.rs:645-665), evaluated redundantly by every thread from LDS
+        double d = dl[jj];
+        const double sg = sgn[jj];
+        const bool reg = d * sg < v.reg_eps;
+        if (reg) d = v.reg_delta * sg;
+        const double dinv = 1.0 / d;
+        if (tid == 0) {
+            if (reg) nreg++;
+            if (d == 0.0) bad |= 2;
+            if (!isfinite(dinv)) bad |= 1;
+            dinvl[jj] = dinv;
+        }
+        if (tid > jj && tid < nbw) {
+            const double l = T[tid * SN_NB + jj] * dinv;
+            lcol[tid] = l;
+            T[tid * SN_NB + jj] = l;
+        }
+        __syncthreads();
+        if (tid == 0) dl[jj] = d;
+        const int rem = nbw - jj - 1; // trailing (ii >= j2 > jj) part of the block
+        for (int idx = tid; idx < rem * rem; idx += SN_DWG) {
+            const int ii = jj + 1 + idx / rem, j2 = jj + 1 + idx % rem;
+            if (ii >= j2) {
+                const double upd = lcol[ii] * d * lcol[j2];
+                if (ii == j2) dl[j2] -= upd;
+                else T[ii * SN_NB + j2] -= upd;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < nbw) {
+        const int c = g.cols[j0 + tid];
+        v.D[c] = dl[tid];
+        v.Dinv[c] = dinvl[tid];
+    }
+    if (tid == 0) {
+        if (nreg) atomicAdd(&v.status[2], nreg);
+        if (bad & 2) v.status[1] = 1;
+        if (bad & 1) v.status[0] = 1;
+    }
+    for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_DWG) { // the block's strict lower triangle
+        const int ii = idx / SN_NB, jj = idx % SN_NB;
+        if (ii > jj && ii < nbw) {
+            const int q = colbase[jj] + j0 + ii;
+            const double l = T[idx];
+            v.Lx[q] = l;
+            v.Rx[v.Tpos[q]] = l;
+        }
+    }
+}
+// grid (row groups of SN_DWG rows, supernodes of the level): the rows below the diagonal block of
+// block column b, one thread per row, forward substitution against the (finished) block
+__global__ __launch_bounds__(SN_DWG) void k_snode_rows(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                       int b) {
+    __shared__ double dT[SN_NB * SN_NB]; // d_q * L_JJ[jj][q]
+    __shared__ double dinvl[SN_NB];
+    __shared__ int colbase[SN_NB];
+    const int sn = order[blockIdx.y];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x;
+    const int i = j0 + nbw + (int)blockIdx.x * SN_DWG + tid;
+    if (j0 + nbw + (int)blockIdx.x * SN_DWG >= g.h) return;
+    if (tid < nbw) {
+        const int c = g.cols[j0 + tid];
+        colbase[tid] = v.Lp[c] - (j0 + tid) - 1;
+        dinvl[tid] = v.Dinv[c];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_DWG) {
+        const int ii = idx / SN_NB, jj = idx % SN_NB;
+        dT[idx] = (ii > jj && ii < nbw) ? v.Lx[colbase[jj] + j0 + ii] * v.D[g.cols[j0 + jj]] : 0.0;
+    }
+    __syncthreads();
+    if (i >= g.h) return;
+    double x[SN_NB];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = jj < nbw ? v.Lx[colbase[jj] + i] : 0.0;
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) {
+        if (jj < nbw) {
+            double sacc = x[jj];
+#pragma unroll
+            for (int q = 0; q < jj; ++q) sacc -= x[q] * dT[jj * SN_NB + q];
+            x[jj] = sacc * dinvl[jj];
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj)
+        if (jj < nbw) {
+            const int q = colbase[jj] + i;
+            v.Lx[q] = x[jj];
+            v.Rx[v.Tpos[q]] = x[jj];
+        }
+}
+
+// Substitutions through a chain supernode, one workgroup per supernode of the unit level, the
+// members' slice of x (and the nb entries of the rows of B) in LDS, block columns of SN_NB:
+//   forward  (qdldl.rs:708-719): x_S <- (I + L_SS)^-1 x_S block by block -- the 64 unknowns of a block
+//            by one wave (values in registers, broadcast by lane shuffles), then every row below the
+//            block subtracts its 64 products (columns streamed, one row per thread) -- and finally
+//            x_B -= L_BS x_S is pushed to the ancestors' entries with one atomic per row;
+//   backward (qdldl.rs:737-752): x_S <- D^-1 x_S - L_BS' x_B - L_SS' x_S, last block first: one wave per
+//            column reduces the rows below the block, then the block itself backwards in one wave.
+// The rows' contributions from columns that are not supernode members are gathered beforehand by the
+// row-gather kernels over the filtered lists (Engine: fwu / bwu).
+constexpr int SN_XB_CAP = 4096; // rows of B kept in LDS (beyond: global atomics / loads)
+struct SnodeSolveLds {
+    double *xs, *xB, *Tl, *csum;
+    int *colbase;
+};
+__device__ __forceinline__ SnodeSolveLds snode_solve_lds(char *smem, int wmax, int nbcap) {
+    SnodeSolveLds L;
+    L.xs = (double *)smem;
+    L.xB = L.xs + wmax;
+    L.Tl = L.xB + nbcap;
+    L.csum = L.Tl + SN_NB * SN_NB;
+    L.colbase = (int *)(L.csum + SN_NB);
+    return L;
+}
+__global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                     double *x, int wmax, int nbcap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SnodeSolveLds L = snode_solve_lds(smem, wmax, nbcap);
+    const int sn = order[blockIdx.x];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *Bn = v.Li + v.Lp[g.e];
+    const bool ldsB = g.nb <= nbcap;
+    for (int t = tid; t < g.w; t += SN_WG) {
+        L.colbase[t] = v.Lp[g.cols[t]] - t - 1;
+        L.xs[t] = x[g.cols[t]];
+    }
+    if (ldsB)
+        for (int r = tid; r < g.nb; r += SN_WG) L.xB[r] = 0.0;
+    __syncthreads();
+    for (int j0 = 0; j0 < g.w; j0 += SN_NB) {
+        const int nbw = min(SN_NB, g.w - j0);
+        for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_WG) {
+            const int ii = idx / SN_NB, jj = idx % SN_NB;
+            L.Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[L.colbase[j0 + jj] + j0 + ii] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) { // the block's unknowns: lane = row, values in registers
+            double xv = lane < nbw ? L.xs[j0 + lane] : 0.0;
+            for (int jj = 0; jj < nbw; ++jj) {
+                const double xj = __shfl(xv, jj);
+                if (lane > jj) xv -= L.Tl[lane * SN_NB + jj] * xj;
+            }
+            if (lane < nbw) L.xs[j0 + lane] = xv;
+        }
+        __syncthreads();
+        // rows below the block
+        for (int i = j0 + nbw + tid; i < g.h; i += SN_WG) {
+            double sacc = 0.0;
+#pragma unroll 8
+            for (int jj = 0; jj < nbw; ++jj) sacc += v.Lx[L.colbase[j0 + jj] + i] * L.xs[j0 + jj];
+            if (i < g.w) L.xs[i] -= sacc;
+            else if (ldsB) L.xB[i - g.w] -= sacc;
+            else atomicAdd(&x[Bn[i - g.w]], -sacc);
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < g.w; t += SN_WG) x[g.cols[t]] = L.xs[t];
+    if (ldsB)
+        for (int r = tid; r < g.nb; r += SN_WG) atomicAdd(&x[Bn[r]], L.xB[r]);
+}
+__global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                     double *x, int wmax, int nbcap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SnodeSolveLds L = snode_solve_lds(smem, wmax, nbcap);
+    const int sn = order[blockIdx.x];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *Bn = v.Li + v.Lp[g.e];
+    const bool ldsB = g.nb <= nbcap;
+    for (int t = tid; t < g.w; t += SN_WG) {
+        const int c = g.cols[t];
+        L.colbase[t] = v.Lp[c] - t - 1;
+        L.xs[t] = x[c] * v.Dinv[c];
+    }
+    if (ldsB)
+        for (int r = tid; r < g.nb; r += SN_WG) L.xB[r] = x[Bn[r]];
+    __syncthreads();
+    const int nblk = (g.w + SN_NB - 1) / SN_NB;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * SN_NB, nbw = min(SN_NB, g.w - j0), j1 = j0 + nbw;
+        for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_WG) {
+            const int ii = idx / SN_NB, jj = idx % SN_NB;
+            L.Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[L.colbase[j0 + jj] + j0 + ii] : 0.0;
+        }
+        // rows below the block (finished members, then B): one wave per column, lanes along the column
+        for (int jj = wave; jj < nbw; jj += SN_WG / 64) {
+            const int cb = L.colbase[j0 + jj];
+            double sacc = 0.0;
+            for (int i = j1 + lane; i < g.h; i += 64) {
+                const double xi = i < g.w ? L.xs[i] : (ldsB ? L.xB[i - g.w] : x[Bn[i - g.w]]);
+                sacc += v.Lx[cb + i] * xi;
+            }
+            sacc = wave_sum(sacc);
+            if (lane == 0) L.csum[jj] = sacc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double xv = lane < nbw ? L.xs[j0 + lane] - L.csum[lane] : 0.0;
+            for (int jj = nbw - 1; jj >= 0; --jj) {
+                const double xj = __shfl(xv, jj);
+                if (lane < jj) xv -= L.Tl[jj * SN_NB + lane] * xj;
+            }
+            if (lane < nbw) L.xs[j0 + lane] = xv;
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < g.w; t += SN_WG) x[g.cols[t]] = L.xs[t];
 }
 
 // ---------------------------------------------------------------------------
@@ -3248,6 +3656,47 @@ void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *
 }
 void factor_B(hipStream_t s, const LdlView &v, ChunkView c) {
     if (c.count) k_factor_B<<<c.count, WG, 0, s>>>(v, c.row, c.beg, c.end, c.count);
+}
+static size_t snode_solve_lds_bytes(int wmax, int nbcap) {
+    return (size_t)(wmax + nbcap + SN_NB * SN_NB + SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int);
+}
+static size_t snode_lds_bytes(int wmax) { return (size_t)(SN_KC * SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int); }
+int snode_kernel_attributes(int wmax, int nbmax) {
+    const int lds = (int)snode_lds_bytes(wmax);
+    int rc = (int)hipFuncSetAttribute((const void *)k_snode_update, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_extend, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
+    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    return rc;
+}
+void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
+                  int wmax_all, int nbmax_all, double *x) {
+    if (!count) return;
+    const int nbcap = std::min(nbmax_all, SN_XB_CAP);
+    const size_t lds = snode_solve_lds_bytes(wmax_all, nbcap);
+    if (m == FWD) k_snode_fwd<<<count, SN_WG, lds, s>>>(v, sv, order, x, wmax_all, nbcap);
+    else k_snode_bwd<<<count, SN_WG, lds, s>>>(v, sv, order, x, wmax_all, nbcap);
+}
+// all supernodes order[0..count) of one unit level: block columns one after the other, then their
+// updates of the ancestors.  nblk / hmax / nbmax: maxima over these supernodes.
+void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order, int count, int wmax_all,
+                   int nblk, int hmax, int nbmax) {
+    if (!count) return;
+    const size_t lds = snode_lds_bytes(wmax_all);
+    for (int b = 0; b < nblk; ++b) {
+        if (b > 0) {
+            const int rows = hmax - b * SN_NB;
+            if (rows > 0)
+                k_snode_update<<<dim3((rows + SN_ROWS - 1) / SN_ROWS, count), SN_WG, lds, s>>>(v, sv, order, b);
+        }
+        k_snode_diag<<<count, SN_DWG, 0, s>>>(v, sv, order, b);
+        const int below = hmax - (b + 1) * SN_NB;
+        if (below > 0) k_snode_rows<<<dim3((below + SN_DWG - 1) / SN_DWG, count), SN_DWG, 0, s>>>(v, sv, order, b);
+    }
+    if (nbmax > 0 && sv.upd_slot)
+        k_snode_extend<<<dim3((nbmax + SN_ROWS - 1) / SN_ROWS, (nbmax + SN_NB - 1) / SN_NB, count), SN_WG, lds, s>>>(
+            v, sv, order);
 }
 void factor_finalize(hipStream_t s, const LdlView &v, ListView c) {
     if (c.count) k_factor_finalize<<<c.count, WG, 0, s>>>(v, c.idx, c.count);

@@ -94,6 +94,16 @@ void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);
 void factor_B(hipStream_t s, const LdlView &v, ChunkView chunks);
+// chain supernodes (host.hpp: Symbolic::sn_*)
+struct SnodeView {
+    const int *sn_ptr, *sn_col;
+    const long long *upd_ptr; // per supernode: offset of its packed strict lower triangle of B x B in upd_slot
+    const int *upd_slot;      // CSC slot of L(B[r], B[c]), r > c  (nullptr: no dense ancestor updates)
+};
+int snode_kernel_attributes(int wmax, int nbmax);
+
+void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order, int count, int wmax_all,
+                   int nblk, int hmax, int nbmax);
 void factor_finalize(hipStream_t s, const LdlView &v, ListView cols);
 
 // ---- triangular solves + symv (row-gather family) -------------------------------
@@ -127,6 +137,9 @@ void gather_chain(hipStream_t s, GatherMode m, const GatherArgs &a, const int *t
                   const int *w_idx, const int *w_ptr, int l0, int l1);
 // T + W + B lists of one level in a single launch (B rows still need gather_Bprep first)
 void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t, ListView w, ChunkView c);
+// forward / backward substitution through the supernodes order[0..count) of one unit level
+void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
+                  int wmax_all, int nbmax_all, double *x);
 // ||v[rows]||inf of a short row list into the slots (the B rows of a SYMV)
 void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long *nrm, int *nan);
 

@@ -39,6 +39,12 @@ constexpr i64 F_MIN_WORK = 16384;    // factor: a column with more (contribution
 constexpr i64 F_CHUNK_MIN = 1024, F_CHUNK_MAX = 4096, F_CHUNK_PARTS = 96;  // ... is split over workgroups in chunks of about this many updates
 constexpr i32 FAC_T_ROW = 8;   // factor: thread-per-column if contributions <= this
 constexpr i32 FAC_T_COL = 48;  // ... and column length <= this
+// chain supernodes of the top (dense trapezoids factored by one workgroup each, kernels.hip k_factor_snode)
+constexpr i32 SN_MIN_W = 16;       // shorter chains stay ordinary columns
+constexpr i32 SN_MAX_W = 4096;     // longer chains are cut
+constexpr i32 SN_PAD_ABS = 16;     // explicit zeros tolerated per column: max(SN_PAD_ABS, SN_PAD_REL * padded length)
+constexpr double SN_PAD_REL = 0.5;
+constexpr i64 SN_UPD_BUDGET = 600000000; // entries of the ancestor-update slot maps (4 bytes each)
 // subtree bundles (one workgroup each; the vector slice of a bundle is staged in LDS)
 constexpr i64 BUNDLE_MAX_NODES = 6144;     // 48 KiB of fp64 in LDS
 constexpr i64 BUNDLE_MAX_ENTRIES = 131072; // nnz(L rows + cols) one workgroup should stream
@@ -322,6 +328,74 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     permuted_triu(n, Ap, Ai, S.iperm, Cp, Ci);
     etree_counts(n, Cp, Ci, parent, cnt);
     S.etree = parent;
+    // ---- chain supernodes among the top columns ---------------------------------
+    // A chain j -> parent(j) -> ... of top columns in which every node is the heaviest child of its
+    // parent has nested structures: struct(j) is contained in {later chain nodes} + struct(last).
+    // Padding every column of a chain segment to exactly that set (explicit zeros) turns the segment
+    // into a dense trapezoid -- rows = [later members..., struct(last)...] in ascending order, so the
+    // entry (panel row i, member t) sits at Lp[c_t] + i - t - 1 -- which k_factor_snode factors with
+    // dense block operations instead of per-entry index gathers.  Only the pattern changes (a superset
+    // of the true one; the added entries are exact zeros), so every other kernel works unchanged.
+    std::vector<char> sn_skip((size_t)n, 0); // member that is not the last column of its supernode
+    S.sn_of.assign((size_t)n, -1);
+    S.sn_ptr.assign(1, 0);
+    if (std::getenv("CHIP_NO_SNODE") == nullptr && S.NF < n) {
+        const i32 NFi = S.NF;
+        std::vector<i32> best((size_t)n, -1);
+        for (i32 j = NFi; j < n; j++) {
+            const i32 pj = parent[j];
+            if (pj >= 0 && (best[pj] < 0 || cnt[j] > cnt[best[pj]])) best[pj] = j;
+        }
+        std::vector<char> linked((size_t)n, 0);
+        for (i32 pj = NFi; pj < n; pj++)
+            if (best[pj] >= 0) linked[best[pj]] = 1;
+        std::vector<i32> chain;
+        std::vector<std::pair<i32, std::vector<i32>>> found; // (first column, columns ascending)
+        for (i32 h = NFi; h < n; h++) {
+            if (linked[h]) continue; // not the top end of a chain
+            chain.clear();
+            for (i32 j = h; j >= NFi; j = best[j]) {
+                chain.push_back(j); // descending: last column first
+                if (best[j] < 0) break;
+            }
+            size_t a = 0;
+            while (a < chain.size()) {
+                const i32 e = chain[a];
+                size_t b = a + 1;
+                while (b < chain.size() && (i32)(b - a) < SN_MAX_W) {
+                    const i64 padded = (i64)cnt[e] + (i64)(b - a);
+                    const i64 zeros = padded - cnt[chain[b]];
+                    if (zeros > std::max<i64>(SN_PAD_ABS, (i64)(SN_PAD_REL * (double)padded))) break;
+                    b++;
+                }
+                if ((i32)(b - a) >= SN_MIN_W) {
+                    std::vector<i32> cols(chain.begin() + a, chain.begin() + b);
+                    std::reverse(cols.begin(), cols.end());
+                    found.emplace_back(cols.front(), std::move(cols));
+                }
+                a = b;
+            }
+        }
+        std::sort(found.begin(), found.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        i64 upd_budget = SN_UPD_BUDGET;
+        for (auto &f : found) {
+            const i32 id = (i32)S.sn_ptr.size() - 1;
+            const std::vector<i32> &cols = f.second;
+            const i32 w = (i32)cols.size(), e = cols.back();
+            const i64 upd = (i64)cnt[e] * (cnt[e] - 1) / 2; // slots of its update of the ancestors
+            if (upd > upd_budget) continue;                  // (stays a run of ordinary columns)
+            upd_budget -= upd;
+            for (i32 t = 0; t < w; t++) {
+                S.sn_of[cols[t]] = id;
+                S.sn_col.push_back(cols[t]);
+                if (t + 1 < w) {
+                    sn_skip[cols[t]] = 1;
+                    cnt[cols[t]] = cnt[e] + (w - 1 - t); // padded length
+                }
+            }
+            S.sn_ptr.push_back((i32)S.sn_col.size());
+        }
+    }
     S.Lp.assign((size_t)n + 1, 0);
     i64 nnzL = 0;
     for (i32 j = 0; j < n; j++) {
@@ -343,9 +417,20 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 i32 i = Ci[p];
                 while (i >= 0 && i < k && stamp[i] != k) {
                     stamp[i] = k;
-                    S.Li[nextp[i]++] = k;
+                    if (!sn_skip[i]) S.Li[nextp[i]++] = k;
                     i = parent[i];
                 }
+            }
+        }
+        // padded members: later members of the supernode, then the structure of its last column
+        for (size_t sn = 0; sn + 1 < S.sn_ptr.size(); sn++) {
+            const i32 *cols = S.sn_col.data() + S.sn_ptr[sn];
+            const i32 w = S.sn_ptr[sn + 1] - S.sn_ptr[sn], e = cols[w - 1];
+            const i32 nb = S.Lp[e + 1] - S.Lp[e];
+            for (i32 t = 0; t + 1 < w; t++) {
+                i32 q = S.Lp[cols[t]];
+                for (i32 u = t + 1; u < w; u++) S.Li[q++] = cols[u];
+                for (i32 r = 0; r < nb; r++) S.Li[q++] = S.Li[S.Lp[e] + r];
             }
         }
     }
@@ -518,19 +603,10 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     }
     // ---- per-level work lists ----------------------------------------------
     {
-        ListBuilder fac(S.fac), fwd(S.fwd), bwd(S.bwd);
+        ListBuilder fwd(S.fwd), bwd(S.bwd);
         for (i32 l = 0; l < nlevels; l++) {
             for (i32 j = lvlptr[l]; j < lvlptr[l + 1]; j++) {
                 const i32 rj = S.Rp[j + 1] - S.Rp[j], cj = S.Lp[j + 1] - S.Lp[j];
-                // factor: column j gathers rj contributions into cj targets; heavy columns (many
-                // contributions, or long tails: dense fronts) are spread over workgroups
-                i64 work = 0;
-                if (rj > B_MIN || (rj > FAC_T_ROW && (i64)rj * cj > F_MIN_WORK))
-                    for (i32 t = S.Rp[j]; t < S.Rp[j + 1]; t++) work += S.Lp[S.Rcol[t] + 1] - (S.Rpos[t] + 1) + 1;
-                if (rj > B_MIN || work > F_MIN_WORK)
-                    fac.add_B_work(j, S.Rp[j], S.Rp[j + 1], S.Rcol, S.Rpos, S.Lp, work);
-                else if (rj <= FAC_T_ROW && cj <= FAC_T_COL) fac.add_T(j);
-                else fac.add_W(j);
                 // forward substitution: row j of L
                 if (rj > B_MIN) fwd.add_B(j, S.Rp[j], S.Rp[j + 1]);
                 else if (rj > T_MAX) fwd.add_W(j);
@@ -540,9 +616,152 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 else if (cj > T_MAX) bwd.add_W(j);
                 else bwd.add_T(j);
             }
-            fac.close_level();
             fwd.close_level();
             bwd.close_level();
+        }
+        // numeric factorisation: UNITS (supernodes, single columns) by unit level.  Without
+        // supernodes the unit levels are the top levels above.
+        const i32 NFi = S.NF;
+        const i32 nsn = (i32)S.sn_ptr.size() - 1;
+        std::vector<i32> ulev((size_t)n, 0), childmax((size_t)n, -1);
+        std::vector<i32> sn_level((size_t)std::max(nsn, 0), 0);
+        i32 nfl = 0;
+        for (i32 j = NFi; j < n; j++) {
+            const i32 sn = S.sn_of[j];
+            i32 lv;
+            if (sn < 0) {
+                lv = childmax[j] + 1;
+                ulev[j] = lv;
+            } else {
+                if (j != S.sn_col[S.sn_ptr[sn + 1] - 1]) continue; // decided at the last member
+                lv = 0;
+                for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) lv = std::max(lv, childmax[S.sn_col[t]] + 1);
+                for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) ulev[S.sn_col[t]] = lv;
+                sn_level[sn] = lv;
+            }
+            nfl = std::max(nfl, lv + 1);
+            const i32 pj = S.etree[j];
+            if (pj >= 0) childmax[pj] = std::max(childmax[pj], lv);
+        }
+        S.nfaclevels = nfl;
+        // row lists of the top without the contributions of supernode members: those arrive as dense
+        // updates (k_snode_update inside a supernode, k_snode_extend from a descendant supernode)
+        if (nsn > 0) {
+            S.Rf_p.assign((size_t)n + 1, 0);
+            for (i32 j = NFi; j < n; j++) {
+                i32 c = 0;
+                for (i32 q = S.Rp[j]; q < S.Rp[j + 1]; q++) c += S.sn_of[S.Rcol[q]] < 0;
+                S.Rf_p[j + 1] = c;
+            }
+            for (i32 j = 0; j < n; j++) S.Rf_p[j + 1] += S.Rf_p[j];
+            S.Rf_col.resize((size_t)S.Rf_p[n] + 1);
+            S.Rf_pos.resize((size_t)S.Rf_p[n] + 1);
+            for (i32 j = NFi; j < n; j++) {
+                i32 o = S.Rf_p[j];
+                for (i32 q = S.Rp[j]; q < S.Rp[j + 1]; q++)
+                    if (S.sn_of[S.Rcol[q]] < 0) {
+                        S.Rf_col[o] = S.Rcol[q];
+                        S.Rf_pos[o] = S.Rpos[q];
+                        o++;
+                    }
+            }
+            // slots of the ancestor updates: supernode s subtracts L_B D L_B' at (B[r], B[c]), r > c
+            S.upd_ptr.assign((size_t)nsn + 1, 0);
+            for (i32 sn = 0; sn < nsn; sn++) {
+                const i32 e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                const i64 nb = S.Lp[e + 1] - S.Lp[e];
+                S.upd_ptr[sn + 1] = S.upd_ptr[sn] + nb * (nb - 1) / 2;
+            }
+            S.upd_slot.resize((size_t)S.upd_ptr[nsn] + 1);
+            for (i32 sn = 0; sn < nsn; sn++) {
+                const i32 e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                const i32 *B = S.Li.data() + S.Lp[e];
+                const i32 nb = S.Lp[e + 1] - S.Lp[e];
+                i64 u = S.upd_ptr[sn];
+                for (i32 c = 0; c < nb; c++) {
+                    const i32 j = B[c];
+                    i32 q = S.Lp[j];
+                    const i32 qe = S.Lp[j + 1];
+                    for (i32 r = c + 1; r < nb; r++) {
+                        while (q < qe && S.Li[q] < B[r]) q++;
+                        if (q >= qe || S.Li[q] != B[r]) {
+                            set_error("internal: supernode update target missing from the pattern of L");
+                            return -9;
+                        }
+                        S.upd_slot[u++] = q;
+                    }
+                }
+            }
+        }
+        const std::vector<i32> &FRp = nsn > 0 ? S.Rf_p : S.Rp, &FRcol = nsn > 0 ? S.Rf_col : S.Rcol,
+                               &FRpos = nsn > 0 ? S.Rf_pos : S.Rpos;
+        // buckets by unit level
+        std::vector<i32> lcount((size_t)nfl + 1, 0), bucket((size_t)std::max<i64>(n - NFi, 0));
+        for (i32 j = NFi; j < n; j++)
+            if (S.sn_of[j] < 0) lcount[ulev[j] + 1]++;
+        for (i32 l = 0; l < nfl; l++) lcount[l + 1] += lcount[l];
+        {
+            std::vector<i32> pos(lcount.begin(), lcount.end() - 1);
+            for (i32 j = NFi; j < n; j++)
+                if (S.sn_of[j] < 0) bucket[pos[ulev[j]]++] = j;
+        }
+        S.sn_order.resize((size_t)std::max(nsn, 0));
+        std::iota(S.sn_order.begin(), S.sn_order.end(), 0);
+        std::stable_sort(S.sn_order.begin(), S.sn_order.end(), [&](i32 a, i32 b) { return sn_level[a] < sn_level[b]; });
+        S.sn_lvl_ptr.assign((size_t)nfl + 1, 0);
+        for (i32 sn = 0; sn < nsn; sn++) S.sn_lvl_ptr[sn_level[sn] + 1]++;
+        for (i32 l = 0; l < nfl; l++) S.sn_lvl_ptr[l + 1] += S.sn_lvl_ptr[l];
+        S.sn_lvl_nblk.assign((size_t)nfl, 0);
+        S.sn_lvl_hmax.assign((size_t)nfl, 0);
+        S.sn_lvl_nbmax.assign((size_t)nfl, 0);
+        ListBuilder fac(S.fac), snx(S.snx), fwu(S.fwu), bwu(S.bwu);
+        for (i32 l = 0; l < nfl; l++) {
+            for (i32 u = lcount[l]; u < lcount[l + 1]; u++) {
+                const i32 j = bucket[u];
+                const i32 rj = FRp[j + 1] - FRp[j], cj = S.Lp[j + 1] - S.Lp[j];
+                // factor: column j gathers rj contributions into cj targets; heavy columns (many
+                // contributions, or long tails: dense fronts) are spread over workgroups
+                i64 work = 0;
+                if (rj > B_MIN || (rj > FAC_T_ROW && (i64)rj * cj > F_MIN_WORK))
+                    for (i32 t = FRp[j]; t < FRp[j + 1]; t++) work += S.Lp[FRcol[t] + 1] - (FRpos[t] + 1) + 1;
+                if (rj > B_MIN || work > F_MIN_WORK)
+                    fac.add_B_work(j, FRp[j], FRp[j + 1], FRcol, FRpos, S.Lp, work);
+                else if (rj <= FAC_T_ROW && cj <= FAC_T_COL) fac.add_T(j);
+                else fac.add_W(j);
+                if (nsn > 0) { // substitutions by unit level (used instead of fwd / bwd when there are supernodes)
+                    if (rj > B_MIN) fwu.add_B(j, FRp[j], FRp[j + 1]);
+                    else if (rj > T_MAX) fwu.add_W(j);
+                    else if (rj > 0) fwu.add_T(j);
+                    if (cj > B_MIN) bwu.add_B(j, S.Lp[j], S.Lp[j + 1]);
+                    else if (cj > T_MAX) bwu.add_W(j);
+                    else bwu.add_T(j);
+                }
+            }
+            for (i32 o = S.sn_lvl_ptr[l]; o < S.sn_lvl_ptr[l + 1]; o++) {
+                const i32 sn = S.sn_order[o];
+                const i32 w = S.sn_ptr[sn + 1] - S.sn_ptr[sn], e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                const i32 nbel = S.Lp[e + 1] - S.Lp[e];
+                S.sn_lvl_nblk[l] = std::max(S.sn_lvl_nblk[l], (w + 63) / 64);
+                S.sn_lvl_hmax[l] = std::max(S.sn_lvl_hmax[l], w + nbel);
+                S.sn_lvl_nbmax[l] = std::max(S.sn_lvl_nbmax[l], nbel);
+                for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) {
+                    const i32 j = S.sn_col[t];
+                    const i32 eb = FRp[j], ee = FRp[j + 1];
+                    if (ee == eb) continue;
+                    i64 work = 0;
+                    for (i32 q = eb; q < ee; q++) work += S.Lp[FRcol[q] + 1] - (FRpos[q] + 1) + 1;
+                    snx.add_B_work(j, eb, ee, FRcol, FRpos, S.Lp, work);
+                    // forward substitution: the member's row restricted to non-member columns
+                    const i32 rj = ee - eb;
+                    if (rj > B_MIN) fwu.add_B(j, eb, ee);
+                    else if (rj > T_MAX) fwu.add_W(j);
+                    else fwu.add_T(j);
+                }
+            }
+            fac.close_level();
+            snx.close_level();
+            fwu.close_level();
+            bwu.close_level();
         }
         ListBuilder smv(S.smv);
         for (i32 j = S.NF; j < n; j++) {

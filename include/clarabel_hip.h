@@ -281,6 +281,12 @@ int32_t chip_kkt_info(const chip_kkt *h, chip_info *info);
 int32_t chip_kkt_get_perm(const chip_kkt *h, uint64_t *perm);
 int32_t chip_kkt_get_symbolic(const chip_kkt *h, uint64_t *etree, uint64_t *Lp, uint64_t *Li,
                               uint64_t *level);
+/* diagnostics: chain supernodes of the top chosen by the symbolic analysis -- runs of columns, each
+ * the elimination-tree parent of the previous one, whose structures are padded (explicit zeros) to one
+ * dense trapezoid that a single workgroup factors with dense block operations.  *count supernodes;
+ * ptr[count + 1] / cols[ptr[count]] (permuted numbering) may be NULL.  Call with NULLs first to size. */
+int32_t chip_kkt_get_supernodes(const chip_kkt *h, int64_t *count, uint64_t *ptr, uint64_t *cols);
+int32_t chip_ldl_get_supernodes(const chip_ldl *h, int64_t *count, uint64_t *ptr, uint64_t *cols);
 /* current device copy of K.nzval (unregularised), for tests */
 int32_t chip_kkt_get_values(chip_kkt *h, double *nzval);
 /* full-N right-hand side / solution (incl. the p sparse-cone rows), tests only */

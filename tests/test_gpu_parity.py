@@ -993,3 +993,53 @@ def test_device_resident_ipm_portfolio(hip, oracle):
     assert out["iterations"] == ref["iterations"]
     assert abs(out["obj_val"] - ref["obj_val"]) <= 1e-7 * max(1.0, abs(ref["obj_val"]))
     assert np.linalg.norm(out["x"] - ref["x"]) <= 1e-5 * max(1.0, np.linalg.norm(ref["x"]))
+
+
+# ---- chain supernodes: dense trapezoids factored on the matrix cores --------------------------
+@pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp", "wide_psd"])
+def test_chain_supernodes_factor_parity(hip, oracle, which, monkeypatch):
+    """k_factor_snode (padded chain supernodes of the top, v_mfma_f64_16x16x4_f64 block updates) against
+    the oracle and against the column-by-column path (CHIP_NO_SNODE): same solution, same pivots, the
+    padded entries of L exactly zero"""
+    if which == "banded_qp":
+        pr, hs = problems.random_qp(20000, 40000, band=50, seed=1), None
+    elif which == "chordal_sdp":
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    else:  # one supernode wider than a k-chunk of the kernel (w > 384 + 32)
+        pr = problems.chordal_sdp(2, 40, 6, 1, 5, seed=7)
+        hs = pr["hsblocks"]
+    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=2)
+    sns = ks.supernodes()
+    assert len(sns) > 0
+    if which == "wide_psd":
+        assert max(len(c) for c in sns) > 416
+    # the same factorisation without supernodes, through the L1 handle on the same K and permutation
+    K = ks.kkt_matrix()
+    vals = ks.values()
+    Kc = hip.CscMatrix(ks.N, ks.N, K.colptr, K.rowval, vals)
+    dsigns = ks.maps()["dsigns"]
+    st = hip.Settings.default()
+    fa = hip.HipDirectLDLSolver(Kc, dsigns, st, perm=ks.perm)
+    monkeypatch.setenv("CHIP_NO_SNODE", "1")
+    fb = hip.HipDirectLDLSolver(Kc, dsigns, st, perm=ks.perm)
+    monkeypatch.delenv("CHIP_NO_SNODE")
+    assert len(fa.supernodes()) > 0 and fb.supernodes() == []
+    fa.refactor()
+    fb.refactor()
+    Lpa, Lia, Lxa, Da, _ = fa.factors()
+    Lpb, Lib, Lxb, Db, _ = fb.factors()
+    assert relerr(Da, Db) <= 1e-9
+    # entry by entry: common entries agree, padded entries are exact zeros
+    import scipy.sparse as sp
+    N = ks.N
+    La = sp.csc_matrix((Lxa, Lia, Lpa), shape=(N, N))
+    Lb = sp.csc_matrix((Lxb, Lib, Lpb), shape=(N, N))
+    diff = (La - Lb).tocoo()
+    assert np.max(np.abs(diff.data), initial=0.0) <= 1e-9 * max(1.0, np.max(np.abs(Lxb)))
+    pad = sp.csc_matrix((np.ones(len(Lia)), Lia, Lpa), shape=(N, N)) - sp.csc_matrix((np.ones(len(Lib)), Lib, Lpb), shape=(N, N))
+    pad.eliminate_zeros()
+    assert (pad.data > 0).all()  # a superset
+    if which != "wide_psd":  # (that block is dense already: nothing to pad)
+        assert pad.nnz > 0
+        assert np.abs(np.asarray(La[pad.nonzero()])).max() == 0.0

@@ -226,3 +226,41 @@ def test_auto_select_rule(hip):
     info = _mk(hip, pr).linear_solver_info()
     assert hip.auto_select(info.amd_lnz, info.amd_ndiv, info.amd_nmultsubs_ldl) == "faer"
     assert hip.auto_select(100.0, 1000.0, 2999.0) == "qdldl" and hip.auto_select(100.0, 1000.0, 3000.0) == "faer"
+
+
+def test_chain_supernodes_pad_to_dense_trapezoids(hip, monkeypatch):
+    """symbolic.cpp chain supernodes: each is a parent chain of top columns; every member's structure
+    is exactly [later members..., struct(last)...] (ascending), and the padded pattern is a superset of
+    the unpadded one (CHIP_NO_SNODE) with the same elimination tree and permutation"""
+    from tests import problems
+    st = _host_only(hip)
+    found = 0
+    for pr in (problems.random_qp(3000, 6000, band=30, seed=2), problems.chordal_sdp(8, 12, 3, 4, 7, seed=5)):
+        P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+        A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+        ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"], settings=st)
+        et, Lp, Li, lv = ks.symbolic()
+        sns = ks.supernodes()
+        monkeypatch.setenv("CHIP_NO_SNODE", "1")
+        k0 = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"], settings=st)
+        monkeypatch.delenv("CHIP_NO_SNODE")
+        et0, Lp0, Li0, _ = k0.symbolic()
+        assert k0.supernodes() == []
+        assert (ks.perm == k0.perm).all() and (et == et0).all()
+        for j in range(ks.N):  # superset, column by column
+            assert set(Li0[Lp0[j]:Lp0[j + 1]]) <= set(Li[Lp[j]:Lp[j + 1]])
+        seen = set()
+        for cols in sns:
+            found += 1
+            w, last = len(cols), cols[-1]
+            assert w >= 16 and cols[0] >= ks.NF
+            below = Li[Lp[last]:Lp[last + 1]]
+            for t in range(w):
+                assert cols[t] not in seen
+                seen.add(int(cols[t]))
+                if t + 1 < w:
+                    assert et[cols[t]] == cols[t + 1]
+                assert list(Li[Lp[cols[t]]:Lp[cols[t] + 1]]) == list(cols[t + 1:]) + list(below)
+        if not sns:
+            assert (Lp == Lp0).all()
+    assert found > 0

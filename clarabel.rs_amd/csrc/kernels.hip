@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restric
 
 constexpr int RCAP = 512;      // contributions per flattened batch (scan needs blockDim >= RCAP/2)
 constexpr int W_LDS_CAP = 2048; // column values + row ids kept in LDS (16 + 8 KiB of 160 KiB)
-constexpr int B_LDS_CAP = 4096; // the same for the chunked column kernel (padded supernode columns are long)
+constexpr int B_LDS_CAP = 2048; // the same for the chunked column kernel (padded supernode columns are long)
 
 __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int hi, int row) {
     // first q in [lo,hi) with Li[q] >= row (the row is known to be present)
@@ -1235,12 +1235,18 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
         // rows below the block (finished members, then B): one wave per column, lanes along the column
         for (int jj = wave; jj < nbw; jj += SN_WG / 64) {
             const int cb = L.colbase[j0 + jj];
-            double sacc = 0.0;
-            for (int i = j1 + lane; i < g.h; i += 64) {
-                const double xi = i < g.w ? L.xs[i] : (ldsB ? L.xB[i - g.w] : x[Bn[i - g.w]]);
-                sacc += v.Lx[cb + i] * xi;
+            double sacc = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            auto xat = [&](int i) { return i < g.w ? L.xs[i] : (ldsB ? L.xB[i - g.w] : x[Bn[i - g.w]]); };
+            int i = j1 + lane;
+            for (; i + 192 < g.h; i += 256) { // four independent 512-byte runs of the column in flight
+                const double l0 = v.Lx[cb + i], l1 = v.Lx[cb + i + 64], l2 = v.Lx[cb + i + 128], l3 = v.Lx[cb + i + 192];
+                sacc += l0 * xat(i);
+                s1 += l1 * xat(i + 64);
+                s2 += l2 * xat(i + 128);
+                s3 += l3 * xat(i + 192);
             }
-            sacc = wave_sum(sacc);
+            for (; i < g.h; i += 64) sacc += v.Lx[cb + i] * xat(i);
+            sacc = wave_sum((sacc + s1) + (s2 + s3));
             if (lane == 0) L.csum[jj] = sacc;
         }
         __syncthreads();

@@ -49,6 +49,7 @@ constexpr i64 SN_UPD_BUDGET = 600000000; // entries of the ancestor-update slot 
 constexpr i64 BUNDLE_MAX_NODES = 6144;     // 48 KiB of fp64 in LDS
 constexpr i64 BUNDLE_MAX_ENTRIES = 131072; // nnz(L rows + cols) one workgroup should stream
 constexpr i64 BUNDLE_TARGET_COUNT = 2048;  // aim for >= 8 workgroups per CU
+constexpr i32 BUNDLE_MAX_COL = 512;        // columns longer than this are not bundled
 
 // upper-triangular pattern of P K P' (row = min, col = max), columns unsorted,
 // plus (optionally) for each source entry its destination slot.
@@ -221,7 +222,11 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     std::vector<char> top((size_t)n, 0);
     i64 NF = 0, maxsub = 0;
     for (i32 j = 0; j < n; j++) {
-        top[j] = no_bundles || sub_nodes[j] > BUNDLE_MAX_NODES || sub_ent[j] > BUNDLE_MAX_ENTRIES;
+        // (a long column belongs to a dense front near the root: it is left to the top -- chain
+        // supernodes -- even when its subtree is small; the top stays closed under "parent of")
+        if (no_bundles || sub_nodes[j] > BUNDLE_MAX_NODES || sub_ent[j] > BUNDLE_MAX_ENTRIES || cnt[j] > BUNDLE_MAX_COL)
+            top[j] = 1;
+        if (top[j] && parent[j] >= 0) top[parent[j]] = 1;
         if (!top[j]) NF++;
     }
     // subtree id of every forest node (roots = forest nodes whose parent is top or absent)

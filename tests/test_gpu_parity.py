@@ -139,8 +139,16 @@ def test_ldl_random_quasidefinite(hip, oracle, n1, n2, density, seed):
                      regularize_eps=1e-13, regularize_delta=2e-7)
     assert o.refactor()
     Lp, Li, Lx, D, Dinv = f.factors()
-    assert np.array_equal(Lp, o.Lp) and np.array_equal(Li, o.Li)
-    assert relerr(D, o.D) <= 1e-10 and relerr(Lx, o.Lx) <= 1e-9
+    if not f.supernodes():
+        assert np.array_equal(Lp, o.Lp) and np.array_equal(Li, o.Li)
+        assert relerr(Lx, o.Lx) <= 1e-9
+    else:  # chain supernodes pad the pattern with explicit zeros: compare as matrices
+        La = sp.csc_matrix((Lx, Li, Lp), shape=(n, n))
+        Lo = sp.csc_matrix((o.Lx, o.Li, o.Lp), shape=(n, n))
+        assert abs(La - Lo).max() <= 1e-9 * max(1.0, np.abs(o.Lx).max())
+        pat = sp.csc_matrix((np.ones(len(Li)), Li, Lp), shape=(n, n)) - sp.csc_matrix((np.ones(len(o.Li)), o.Li, o.Lp), shape=(n, n))
+        assert pat.data.min(initial=0.0) >= 0.0
+    assert relerr(D, o.D) <= 1e-10
     assert f.linear_solver_info().positive_inertia == o.positive_inertia == n1
     b = rng.standard_normal(n)
     x = np.zeros(n)

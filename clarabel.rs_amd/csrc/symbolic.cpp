@@ -50,6 +50,7 @@ constexpr i64 BUNDLE_MAX_NODES = 6144;     // 48 KiB of fp64 in LDS
 constexpr i64 BUNDLE_MAX_ENTRIES = 131072; // nnz(L rows + cols) one workgroup should stream
 constexpr i64 BUNDLE_TARGET_COUNT = 2048;  // aim for >= 8 workgroups per CU
 constexpr i32 BUNDLE_MAX_COL = 512;        // columns longer than this are not bundled
+constexpr i64 BUNDLE_MAX_WORK = 8000000;   // sum of (column length)^2 one workgroup should factor with per-entry gathers
 
 // upper-triangular pattern of P K P' (row = min, col = max), columns unsorted,
 // plus (optionally) for each source entry its destination slot.
@@ -211,12 +212,16 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // ---- cut the forest: a node whose whole subtree is small goes (with that subtree)
     //      into a "bundle" that ONE workgroup factors / solves start to finish; the
     //      remaining ancestors form the "top", processed level by level by the whole GPU.
-    std::vector<i64> sub_nodes((size_t)n, 1), sub_ent((size_t)n, 0);
-    for (i32 j = 0; j < n; j++) sub_ent[j] = (i64)cnt[j] + rowcnt[j];
+    std::vector<i64> sub_nodes((size_t)n, 1), sub_ent((size_t)n, 0), sub_work((size_t)n, 0);
+    for (i32 j = 0; j < n; j++) {
+        sub_ent[j] = (i64)cnt[j] + rowcnt[j];
+        sub_work[j] = (i64)cnt[j] * cnt[j]; // ~ multiply-adds of column j's updates
+    }
     for (i32 j = 0; j < n; j++)
         if (parent[j] >= 0) {
             sub_nodes[parent[j]] += sub_nodes[j];
             sub_ent[parent[j]] += sub_ent[j];
+            sub_work[parent[j]] += sub_work[j];
         }
     const bool no_bundles = std::getenv("CHIP_NO_BUNDLES") != nullptr;
     std::vector<char> top((size_t)n, 0);
@@ -224,7 +229,8 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     for (i32 j = 0; j < n; j++) {
         // (a long column belongs to a dense front near the root: it is left to the top -- chain
         // supernodes -- even when its subtree is small; the top stays closed under "parent of")
-        if (no_bundles || sub_nodes[j] > BUNDLE_MAX_NODES || sub_ent[j] > BUNDLE_MAX_ENTRIES || cnt[j] > BUNDLE_MAX_COL)
+        if (no_bundles || sub_nodes[j] > BUNDLE_MAX_NODES || sub_ent[j] > BUNDLE_MAX_ENTRIES || cnt[j] > BUNDLE_MAX_COL ||
+            sub_work[j] > BUNDLE_MAX_WORK)
             top[j] = 1;
         if (top[j] && parent[j] >= 0) top[parent[j]] = 1;
         if (!top[j]) NF++;

@@ -3697,7 +3697,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const i
                 k_snode_update<<<dim3((rows + SN_ROWS - 1) / SN_ROWS, count), SN_WG, lds, s>>>(v, sv, order, b);
         }
         k_snode_diag<<<count, SN_DWG, 0, s>>>(v, sv, order, b);
-        const int below = hmax - (b + 1) * SN_NB;
+        const int below = hmax - b * SN_NB - 1; // (a narrow last block leaves more rows below it)
         if (below > 0) k_snode_rows<<<dim3((below + SN_DWG - 1) / SN_DWG, count), SN_DWG, 0, s>>>(v, sv, order, b);
     }
     if (nbmax > 0 && sv.upd_slot)

@@ -461,12 +461,12 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         for (int l = 0; l < nfaclevels; l++) {
             dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
             dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                              sn_wmax, sn_nbmax, xp);
+                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp);
         }
         dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
         for (int l = nfaclevels - 1; l >= 0; l--) {
             dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                              sn_wmax, sn_nbmax, xp);
+                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp);
             const dev::ChunkView b = bwu.B(l);
             if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwu.BR(l));
             dev::gather_merged(stream, dev::BWD, g, bwu.T(l), bwu.W(l), b);

@@ -1161,8 +1161,9 @@ __device__ __forceinline__ SnodeSolveLds snode_solve_lds(char *smem, int wmax, i
     L.colbase = (int *)(L.csum + SN_NB);
     return L;
 }
+// with_B = 0: the rows of B are left to k_snode_push / k_snode_pull (their own multi-workgroup launches)
 __global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, const int *__restrict__ order,
-                                                     double *x, int wmax, int nbcap) {
+                                                     double *x, int wmax, int nbcap, int with_B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SnodeSolveLds L = snode_solve_lds(smem, wmax, nbcap);
     const int sn = order[blockIdx.x];
@@ -1170,11 +1171,12 @@ __global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int *Bn = v.Li + v.Lp[g.e];
     const bool ldsB = g.nb <= nbcap;
+    const int hrows = with_B ? g.h : g.w;
     for (int t = tid; t < g.w; t += SN_WG) {
         L.colbase[t] = v.Lp[g.cols[t]] - t - 1;
         L.xs[t] = x[g.cols[t]];
     }
-    if (ldsB)
+    if (ldsB && with_B)
         for (int r = tid; r < g.nb; r += SN_WG) L.xB[r] = 0.0;
     __syncthreads();
     for (int j0 = 0; j0 < g.w; j0 += SN_NB) {
@@ -1194,10 +1196,21 @@ __global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, co
         }
         __syncthreads();
         // rows below the block
-        for (int i = j0 + nbw + tid; i < g.h; i += SN_WG) {
+        for (int i = j0 + nbw + tid; i < hrows; i += SN_WG) {
             double sacc = 0.0;
+            if (nbw == SN_NB) { // 32 column runs in flight per thread
+#pragma unroll
+                for (int j2 = 0; j2 < SN_NB; j2 += 32) {
+                    double lv[32];
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) lv[q] = v.Lx[L.colbase[j0 + j2 + q] + i];
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) sacc += lv[q] * L.xs[j0 + j2 + q];
+                }
+            } else {
 #pragma unroll 8
-            for (int jj = 0; jj < nbw; ++jj) sacc += v.Lx[L.colbase[j0 + jj] + i] * L.xs[j0 + jj];
+                for (int jj = 0; jj < nbw; ++jj) sacc += v.Lx[L.colbase[j0 + jj] + i] * L.xs[j0 + jj];
+            }
             if (i < g.w) L.xs[i] -= sacc;
             else if (ldsB) L.xB[i - g.w] -= sacc;
             else atomicAdd(&x[Bn[i - g.w]], -sacc);
@@ -1205,11 +1218,82 @@ __global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, co
         __syncthreads();
     }
     for (int t = tid; t < g.w; t += SN_WG) x[g.cols[t]] = L.xs[t];
-    if (ldsB)
+    if (ldsB && with_B)
         for (int r = tid; r < g.nb; r += SN_WG) atomicAdd(&x[Bn[r]], L.xB[r]);
 }
+// x_B -= L_BS x_S after k_snode_fwd(with_B = 0): grid (groups of SN_WG rows of B, chunks of SN_PCH member
+// columns, supernodes); one thread per row, the chunk of x_S in LDS, one atomic per (row, chunk)
+constexpr int SN_PCH = 256;
+__global__ __launch_bounds__(SN_WG) void k_snode_push(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                      double *x) {
+    __shared__ double xs[SN_PCH];
+    __shared__ int cb[SN_PCH];
+    const int sn = order[blockIdx.z];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int t0 = (int)blockIdx.y * SN_PCH;
+    const int r0 = (int)blockIdx.x * SN_WG;
+    if (t0 >= g.w || r0 >= g.nb) return;
+    const int nt = min(SN_PCH, g.w - t0), tid = threadIdx.x;
+    if (tid < nt) {
+        const int c = g.cols[t0 + tid];
+        xs[tid] = x[c];
+        cb[tid] = v.Lp[c] - (t0 + tid) - 1 + g.w; // + panel row w + r
+    }
+    __syncthreads();
+    const int r = r0 + tid;
+    if (r >= g.nb) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int t = 0;
+    for (; t + 7 < nt; t += 8) { // eight column runs in flight per thread
+        const double l0 = v.Lx[cb[t] + r], l1 = v.Lx[cb[t + 1] + r], l2 = v.Lx[cb[t + 2] + r], l3 = v.Lx[cb[t + 3] + r];
+        const double l4 = v.Lx[cb[t + 4] + r], l5 = v.Lx[cb[t + 5] + r], l6 = v.Lx[cb[t + 6] + r],
+                     l7 = v.Lx[cb[t + 7] + r];
+        s0 += l0 * xs[t] + l4 * xs[t + 4];
+        s1 += l1 * xs[t + 1] + l5 * xs[t + 5];
+        s2 += l2 * xs[t + 2] + l6 * xs[t + 6];
+        s3 += l3 * xs[t + 3] + l7 * xs[t + 7];
+    }
+    for (; t < nt; ++t) s0 += v.Lx[cb[t] + r] * xs[t];
+    const int *Bn = v.Li + v.Lp[g.e];
+    atomicAdd(&x[Bn[r]], -((s0 + s1) + (s2 + s3)));
+}
+// x_S <- D^-1 x_S - L_BS' x_B before k_snode_bwd(with_B = 0): grid (groups of 64 member columns,
+// supernodes); one wave per column over the nb rows of B (x_B in LDS)
+__global__ __launch_bounds__(SN_WG) void k_snode_pull(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                      double *x, int nbcap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xB = (double *)smem;
+    const int sn = order[blockIdx.y];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int t0 = (int)blockIdx.x * SN_NB;
+    if (t0 >= g.w) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *Bn = v.Li + v.Lp[g.e];
+    const bool ldsB = g.nb <= nbcap;
+    if (ldsB)
+        for (int r = tid; r < g.nb; r += SN_WG) xB[r] = x[Bn[r]];
+    __syncthreads();
+    const int nt = min(SN_NB, g.w - t0);
+    for (int tt = wave; tt < nt; tt += SN_WG / 64) {
+        const int t = t0 + tt, c = g.cols[t];
+        const int base = v.Lp[c] - t - 1 + g.w;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        auto xat = [&](int r) { return ldsB ? xB[r] : x[Bn[r]]; };
+        int r = lane;
+        for (; r + 192 < g.nb; r += 256) {
+            const double l0 = v.Lx[base + r], l1 = v.Lx[base + r + 64], l2 = v.Lx[base + r + 128], l3 = v.Lx[base + r + 192];
+            s0 += l0 * xat(r);
+            s1 += l1 * xat(r + 64);
+            s2 += l2 * xat(r + 128);
+            s3 += l3 * xat(r + 192);
+        }
+        for (; r < g.nb; r += 64) s0 += v.Lx[base + r] * xat(r);
+        const double tot = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) x[c] = x[c] * v.Dinv[c] - tot;
+    }
+}
 __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, const int *__restrict__ order,
-                                                     double *x, int wmax, int nbcap) {
+                                                     double *x, int wmax, int nbcap, int with_B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SnodeSolveLds L = snode_solve_lds(smem, wmax, nbcap);
     const int sn = order[blockIdx.x];
@@ -1217,12 +1301,13 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int *Bn = v.Li + v.Lp[g.e];
     const bool ldsB = g.nb <= nbcap;
+    const int hrows = with_B ? g.h : g.w;
     for (int t = tid; t < g.w; t += SN_WG) {
         const int c = g.cols[t];
         L.colbase[t] = v.Lp[c] - t - 1;
-        L.xs[t] = x[c] * v.Dinv[c];
+        L.xs[t] = with_B ? x[c] * v.Dinv[c] : x[c]; // (k_snode_pull has applied D^-1 already)
     }
-    if (ldsB)
+    if (ldsB && with_B)
         for (int r = tid; r < g.nb; r += SN_WG) L.xB[r] = x[Bn[r]];
     __syncthreads();
     const int nblk = (g.w + SN_NB - 1) / SN_NB;
@@ -1232,22 +1317,42 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
             const int ii = idx / SN_NB, jj = idx % SN_NB;
             L.Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[L.colbase[j0 + jj] + j0 + ii] : 0.0;
         }
-        // rows below the block (finished members, then B): one wave per column, lanes along the column
-        for (int jj = wave; jj < nbw; jj += SN_WG / 64) {
-            const int cb = L.colbase[j0 + jj];
-            double sacc = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        // rows below the block (finished members, then B): each wave owns the columns wave, wave + 8, ...
+        // of the block and walks them together, lanes along the columns (8 x 2 runs in flight per lane)
+        {
+            constexpr int CPW = SN_NB / (SN_WG / 64); // columns per wave
             auto xat = [&](int i) { return i < g.w ? L.xs[i] : (ldsB ? L.xB[i - g.w] : x[Bn[i - g.w]]); };
-            int i = j1 + lane;
-            for (; i + 192 < g.h; i += 256) { // four independent 512-byte runs of the column in flight
-                const double l0 = v.Lx[cb + i], l1 = v.Lx[cb + i + 64], l2 = v.Lx[cb + i + 128], l3 = v.Lx[cb + i + 192];
-                sacc += l0 * xat(i);
-                s1 += l1 * xat(i + 64);
-                s2 += l2 * xat(i + 128);
-                s3 += l3 * xat(i + 192);
+            double sc[CPW];
+            int cbq[CPW];
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                sc[q] = 0.0;
+                const int jj = wave + q * (SN_WG / 64);
+                cbq[q] = jj < nbw ? L.colbase[j0 + jj] : INT_MIN; // (colbase itself may be -1)
             }
-            for (; i < g.h; i += 64) sacc += v.Lx[cb + i] * xat(i);
-            sacc = wave_sum((sacc + s1) + (s2 + s3));
-            if (lane == 0) L.csum[jj] = sacc;
+            int i = j1 + lane;
+            for (; i + 64 < hrows; i += 128) {
+                double l0[CPW], l1[CPW];
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) {
+                    l0[q] = cbq[q] != INT_MIN ? v.Lx[cbq[q] + i] : 0.0;
+                    l1[q] = cbq[q] != INT_MIN ? v.Lx[cbq[q] + i + 64] : 0.0;
+                }
+                const double x0 = xat(i), x1 = xat(i + 64);
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) sc[q] += l0[q] * x0 + l1[q] * x1;
+            }
+            for (; i < hrows; i += 64) {
+                const double x0 = xat(i);
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) sc[q] += (cbq[q] != INT_MIN ? v.Lx[cbq[q] + i] : 0.0) * x0;
+            }
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                const double tot = wave_sum(sc[q]);
+                const int jj = wave + q * (SN_WG / 64);
+                if (lane == 0 && jj < nbw) L.csum[jj] = tot;
+            }
         }
         __syncthreads();
         if (wave == 0) {
@@ -3676,13 +3781,25 @@ int snode_kernel_attributes(int wmax, int nbmax) {
     if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
     return rc;
 }
+// wlvl / nblvl: maxima over the supernodes of this launch.  Levels with a large B part run it in
+// separate multi-workgroup launches: one workgroup per supernode is latency bound.
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
-                  int wmax_all, int nbmax_all, double *x) {
+                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x) {
     if (!count) return;
     const int nbcap = std::min(nbmax_all, SN_XB_CAP);
     const size_t lds = snode_solve_lds_bytes(wmax_all, nbcap);
-    if (m == FWD) k_snode_fwd<<<count, SN_WG, lds, s>>>(v, sv, order, x, wmax_all, nbcap);
-    else k_snode_bwd<<<count, SN_WG, lds, s>>>(v, sv, order, x, wmax_all, nbcap);
+    const bool split = nblvl >= 256;
+    if (m == FWD) {
+        k_snode_fwd<<<count, SN_WG, lds, s>>>(v, sv, order, x, wmax_all, nbcap, split ? 0 : 1);
+        if (split)
+            k_snode_push<<<dim3((nblvl + SN_WG - 1) / SN_WG, (wlvl + SN_PCH - 1) / SN_PCH, count), SN_WG, 0, s>>>(
+                v, sv, order, x);
+    } else {
+        if (split)
+            k_snode_pull<<<dim3((wlvl + SN_NB - 1) / SN_NB, count), SN_WG, (size_t)nbcap * sizeof(double), s>>>(
+                v, sv, order, x, nbcap);
+        k_snode_bwd<<<count, SN_WG, lds, s>>>(v, sv, order, x, wmax_all, nbcap, split ? 0 : 1);
+    }
 }
 // all supernodes order[0..count) of one unit level: block columns one after the other, then their
 // updates of the ancestors.  nblk / hmax / nbmax: maxima over these supernodes.

@@ -139,7 +139,7 @@ void gather_chain(hipStream_t s, GatherMode m, const GatherArgs &a, const int *t
 void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t, ListView w, ChunkView c);
 // forward / backward substitution through the supernodes order[0..count) of one unit level
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
-                  int wmax_all, int nbmax_all, double *x);
+                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x);
 // ||v[rows]||inf of a short row list into the slots (the B rows of a SYMV)
 void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long *nrm, int *nan);
 

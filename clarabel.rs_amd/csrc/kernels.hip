@@ -3786,7 +3786,9 @@ int snode_kernel_attributes(int wmax, int nbmax) {
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
                   int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x) {
     if (!count) return;
-    const int nbcap = std::min(nbmax_all, SN_XB_CAP);
+    int cap = SN_XB_CAP;
+    if (const char *e = std::getenv("CHIP_SN_XB_CAP")) cap = std::max(1, std::min(SN_XB_CAP, std::atoi(e))); // tests
+    const int nbcap = std::min(nbmax_all, cap);
     const size_t lds = snode_solve_lds_bytes(wmax_all, nbcap);
     const bool split = nblvl >= 256;
     if (m == FWD) {

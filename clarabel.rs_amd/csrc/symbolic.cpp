@@ -15,6 +15,8 @@
 //     rows (CSR) so that forward substitution, backward substitution and the
 //     left-looking numeric factorisation are all pure gathers.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -28,6 +30,18 @@ void set_error(const std::string &msg) { g_err = msg; }
 const char *get_error() { return g_err.c_str(); }
 
 namespace {
+
+// CHIP_TIMING=1: wall-clock of the analysis phases on stderr
+struct PhaseClock {
+    bool on = std::getenv("CHIP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[chip analyse] %-28s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 // kernel work-list thresholds (see kernels.hip)
 constexpr i32 T_MAX = 32;      // <= T_MAX entries: one thread per row
@@ -178,6 +192,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     S.N = (i32)n;
     S.nnzK = nnzK;
 
+    PhaseClock clk;
     // ---- ordering -----------------------------------------------------------
     std::vector<i64> p0 = perm0;
     if (p0.empty() && n > 0) {
@@ -196,6 +211,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         }
         ip0[v] = (i32)k;
     }
+    clk("ordering");
     // ---- pass A: tree + levels under the given order ------------------------
     std::vector<i64> Cp;
     std::vector<i32> Ci, parent, cnt;
@@ -209,6 +225,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         if (pj >= 0 && level[pj] < level[j] + 1) level[pj] = level[j] + 1;
         if (level[j] + 1 > depth) depth = level[j] + 1;
     }
+    clk("pass A (etree, counts)");
     // ---- cut the forest: a node whose whole subtree is small goes (with that subtree)
     //      into a "bundle" that ONE workgroup factors / solves start to finish; the
     //      remaining ancestors form the "top", processed level by level by the whole GPU.
@@ -335,10 +352,12 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     S.dsigns.resize((size_t)n);
     for (i32 j = 0; j < n; j++) S.dsigns[j] = dsigns ? dsigns[S.perm[j]] : (int8_t)1;
 
+    clk("forest cut, renumbering");
     // ---- pass B: final pattern ----------------------------------------------
     permuted_triu(n, Ap, Ai, S.iperm, Cp, Ci);
     etree_counts(n, Cp, Ci, parent, cnt);
     S.etree = parent;
+    clk("pass B etree/counts");
     // ---- chain supernodes among the top columns ---------------------------------
     // A chain j -> parent(j) -> ... of top columns in which every node is the heaviest child of its
     // parent has nested structures: struct(j) is contained in {later chain nodes} + struct(last).
@@ -445,6 +464,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             }
         }
     }
+    clk("supernodes + pattern of L");
     // ---- CSR view of L ------------------------------------------------------
     S.Rp.assign((size_t)n + 1, 0);
     for (i64 q = 0; q < nnzL; q++) S.Rp[S.Li[q] + 1]++;
@@ -462,6 +482,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 S.Tpos[q] = t;
             }
     }
+    clk("CSR view of L");
     // ---- K.nzval -> (Lx | D) scatter map ------------------------------------
     S.a2l.resize((size_t)nnzK + 1);
     for (i64 c = 0; c < n; c++) {
@@ -489,6 +510,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         for (i64 q = 0; q < nnzL; q++)
             if (!covered[q]) S.fill_idx.push_back((i32)q);
     }
+    clk("a2l map, fill slots");
     // ---- K for the refinement residual e = b - K x (permuted numbering) ------
     // Every nonzero K_ij (i < j in the final numbering) joins a node to one of its ANCESTORS,
     // so i and j are in the same bundle or j is a top node.  Bundle rows therefore use the
@@ -558,6 +580,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         sort_rows(S.Up, NFi, S.Ucol, S.Umap);
         sort_rows(S.Sp, (i32)n, S.Scol, S.Smap);
     }
+    clk("U / S rows of K");
     // ---- few dense top rows folded into the bundle kernels ----------------------
     {
         const i32 ntop = (i32)n - S.NF;
@@ -612,6 +635,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             }
         }
     }
+    clk("fold / topblk");
     // ---- per-level work lists ----------------------------------------------
     {
         ListBuilder fwd(S.fwd), bwd(S.bwd);
@@ -783,6 +807,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         }
         smv.close_level();
     }
+    clk("work lists, update slots");
     return 0;
 }
 

@@ -1051,3 +1051,17 @@ def test_chain_supernodes_factor_parity(hip, oracle, which, monkeypatch):
     if which != "wide_psd":  # (that block is dense already: nothing to pad)
         assert pad.nnz > 0
         assert np.abs(np.asarray(La[pad.nonzero()])).max() == 0.0
+
+
+@pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
+def test_chain_supernodes_solve_without_lds_rows(hip, oracle, which, monkeypatch):
+    """the substitutions through supernodes whose rows of B exceed the LDS budget (forced here by
+    CHIP_SN_XB_CAP): global atomics / loads instead of the LDS copy, same solution"""
+    monkeypatch.setenv("CHIP_SN_XB_CAP", "16")
+    if which == "banded_qp":
+        pr, hs = problems.random_qp(20000, 40000, band=50, seed=1), None
+    else:
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=2)
+    assert len(ks.supernodes()) > 0

@@ -483,33 +483,82 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             }
     }
     clk("CSR view of L");
-    // ---- K.nzval -> (Lx | D) scatter map ------------------------------------
-    S.a2l.resize((size_t)nnzK + 1);
-    for (i64 c = 0; c < n; c++) {
-        const i32 pc = S.iperm[c];
-        for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-            const i32 pr = S.iperm[Ai[p]];
-            if (pr == pc) {
-                S.a2l[p] = (i32)(nnzL + pc);
-            } else {
-                const i32 lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
-                const i32 *b = S.Li.data() + S.Lp[lo], *e = S.Li.data() + S.Lp[lo + 1];
-                const i32 *f = std::lower_bound(b, e, hi);
-                if (f == e || *f != hi) {
-                    set_error("internal: K entry missing from the pattern of L");
-                    return -9;
-                }
-                S.a2l[p] = (i32)(f - S.Li.data());
+    // ---- the permuted upper triangle of K, twice sorted (three counting passes, no comparisons):
+    //      T : by smaller index lo, larger index hi ascending;  C2 : by hi, lo ascending; each entry
+    //      carries its position p in the caller's K.nzval.  Feeds the scatter map and the residual rows.
+    std::vector<i32> Tp((size_t)n + 1, 0), Thi((size_t)nnzK + 1), Tsrc((size_t)nnzK + 1);
+    std::vector<i32> C2p((size_t)n + 1, 0), C2lo((size_t)nnzK + 1), C2src((size_t)nnzK + 1);
+    {
+        std::vector<i32> hp((size_t)n + 1, 0), hlo((size_t)nnzK + 1), hsrc((size_t)nnzK + 1);
+        for (i64 c = 0; c < n; c++) {
+            const i32 pc = S.iperm[c];
+            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                const i32 pr = S.iperm[Ai[p]];
+                hp[(pr > pc ? pr : pc) + 1]++;
+                Tp[(pr > pc ? pc : pr) + 1]++;
             }
         }
+        for (i32 j = 0; j < n; j++) {
+            hp[j + 1] += hp[j];
+            Tp[j + 1] += Tp[j];
+        }
+        C2p = hp;
+        {
+            std::vector<i32> nx(hp.begin(), hp.end() - 1);
+            for (i64 c = 0; c < n; c++) { // pass 1: grouped by hi
+                const i32 pc = S.iperm[c];
+                for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                    const i32 pr = S.iperm[Ai[p]];
+                    const i32 lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
+                    const i32 t = nx[hi]++;
+                    hlo[t] = lo;
+                    hsrc[t] = (i32)p;
+                }
+            }
+        }
+        {
+            std::vector<i32> nx(Tp.begin(), Tp.end() - 1);
+            for (i32 hi = 0; hi < n; hi++) // pass 2: by lo, hi ascending
+                for (i32 t = hp[hi]; t < hp[hi + 1]; t++) {
+                    const i32 u = nx[hlo[t]]++;
+                    Thi[u] = hi;
+                    Tsrc[u] = hsrc[t];
+                }
+        }
+        {
+            std::vector<i32> nx(C2p.begin(), C2p.end() - 1);
+            for (i32 lo = 0; lo < n; lo++) // pass 3: by hi, lo ascending
+                for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
+                    const i32 t = nx[Thi[u]]++;
+                    C2lo[t] = lo;
+                    C2src[t] = Tsrc[u];
+                }
+        }
     }
-    {
-        std::vector<char> covered((size_t)nnzL + 1, 0);
-        for (i64 t = 0; t < nnzK; t++)
-            if (S.a2l[t] < nnzL) covered[S.a2l[t]] = 1;
-        for (i64 q = 0; q < nnzL; q++)
-            if (!covered[q]) S.fill_idx.push_back((i32)q);
+    // ---- K.nzval -> (Lx | D) scatter map: merge of row lo of T with column lo of L ----------
+    S.a2l.resize((size_t)nnzK + 1);
+    std::vector<char> covered((size_t)nnzL + 1, 0);
+    for (i32 lo = 0; lo < n; lo++) {
+        i32 q = S.Lp[lo];
+        const i32 qe = S.Lp[lo + 1];
+        for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
+            const i32 hi = Thi[u];
+            if (hi == lo) {
+                S.a2l[Tsrc[u]] = (i32)(nnzL + lo);
+                continue;
+            }
+            while (q < qe && S.Li[q] < hi) q++;
+            if (q >= qe || S.Li[q] != hi) {
+                set_error("internal: K entry missing from the pattern of L");
+                return -9;
+            }
+            S.a2l[Tsrc[u]] = q;
+            covered[q] = 1;
+        }
     }
+    for (i64 q = 0; q < nnzL; q++)
+        if (!covered[q]) S.fill_idx.push_back((i32)q);
+    std::vector<char>().swap(covered);
     clk("a2l map, fill slots");
     // ---- K for the refinement residual e = b - K x (permuted numbering) ------
     // Every nonzero K_ij (i < j in the final numbering) joins a node to one of its ANCESTORS,
@@ -519,66 +568,36 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // directions inside LDS.  Only the (few) top rows keep a full row-wise copy (S).
     {
         const i32 NFi = S.NF;
-        S.Up.assign((size_t)NFi + 1, 0);
-        S.Sp.assign((size_t)n + 1, 0);
-        for (i64 c = 0; c < n; c++)
-            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-                const i32 pc = S.iperm[c], pr = S.iperm[Ai[p]];
-                const i32 lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
-                if (lo < NFi) S.Up[lo + 1]++;
-                if (hi >= NFi) {
-                    S.Sp[hi + 1]++;
-                    if (lo >= NFi && lo != hi) S.Sp[lo + 1]++;
-                }
-            }
-        for (i32 j = 0; j < NFi; j++) S.Up[j + 1] += S.Up[j];
-        for (i32 j = 0; j < n; j++) S.Sp[j + 1] += S.Sp[j];
+        // U: rows lo < NF = rows of T (diagonal first, ancestors ascending)
+        S.Up.assign(Tp.begin(), Tp.begin() + NFi + 1);
         S.nnzU = S.Up[NFi];
+        S.Ucol.assign(Thi.begin(), Thi.begin() + S.nnzU);
+        S.Umap.assign(Tsrc.begin(), Tsrc.begin() + S.nnzU);
+        S.Ucol.push_back(0);
+        S.Umap.push_back(0);
+        // S: full rows r >= NF = column r of C2 (lo <= r ascending, diagonal last) then row r of T without its diagonal
+        S.Sp.assign((size_t)n + 1, 0);
+        for (i32 r = NFi; r < n; r++) {
+            i32 cntr = C2p[r + 1] - C2p[r];
+            for (i32 u = Tp[r]; u < Tp[r + 1]; u++) cntr += Thi[u] != r;
+            S.Sp[r + 1] = cntr;
+        }
+        for (i32 j = 0; j < n; j++) S.Sp[j + 1] += S.Sp[j];
         S.nnzS = S.Sp[n];
-        S.Ucol.resize((size_t)S.nnzU + 1);
-        S.Umap.resize((size_t)S.nnzU + 1);
         S.Scol.resize((size_t)S.nnzS + 1);
         S.Smap.resize((size_t)S.nnzS + 1);
-        std::vector<i32> nu(S.Up.begin(), S.Up.end() - 1), ns(S.Sp.begin(), S.Sp.end() - 1);
-        for (i64 c = 0; c < n; c++)
-            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-                const i32 pc = S.iperm[c], pr = S.iperm[Ai[p]];
-                const i32 lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
-                if (lo < NFi) {
-                    const i32 t = nu[lo]++;
-                    S.Ucol[t] = hi;
-                    S.Umap[t] = (i32)p;
-                }
-                if (hi >= NFi) {
-                    i32 t = ns[hi]++;
-                    S.Scol[t] = lo;
-                    S.Smap[t] = (i32)p;
-                    if (lo >= NFi && lo != hi) {
-                        t = ns[lo]++;
-                        S.Scol[t] = hi;
-                        S.Smap[t] = (i32)p;
-                    }
-                }
+        for (i32 r = NFi; r < n; r++) {
+            i32 o = S.Sp[r];
+            for (i32 t = C2p[r]; t < C2p[r + 1]; t++) {
+                S.Scol[o] = C2lo[t];
+                S.Smap[o++] = C2src[t];
             }
-        auto sort_rows = [](const std::vector<i32> &ptr, i32 nrows, std::vector<i32> &col, std::vector<i32> &map) {
-            std::vector<std::pair<i32, i32>> tmp;
-            for (i32 j = 0; j < nrows; j++) {
-                const i32 b = ptr[j], e = ptr[j + 1];
-                if (e - b < 2) continue;
-                bool sorted = true;
-                for (i32 t = b + 1; t < e && sorted; t++) sorted = col[t - 1] <= col[t];
-                if (sorted) continue;
-                tmp.resize((size_t)(e - b));
-                for (i32 t = b; t < e; t++) tmp[t - b] = {col[t], map[t]};
-                std::sort(tmp.begin(), tmp.end());
-                for (i32 t = b; t < e; t++) {
-                    col[t] = tmp[t - b].first;
-                    map[t] = tmp[t - b].second;
+            for (i32 u = Tp[r]; u < Tp[r + 1]; u++)
+                if (Thi[u] != r) {
+                    S.Scol[o] = Thi[u];
+                    S.Smap[o++] = Tsrc[u];
                 }
-            }
-        };
-        sort_rows(S.Up, NFi, S.Ucol, S.Umap);
-        sort_rows(S.Sp, (i32)n, S.Scol, S.Smap);
+        }
     }
     clk("U / S rows of K");
     // ---- few dense top rows folded into the bundle kernels ----------------------

@@ -313,6 +313,22 @@ void Engine::prof_begin(int family) {
     }
     (void)hipEventRecord(prof_events[prof_used], stream);
 }
+// the next event pair of the active family for a launch that stamps its own events
+// (hipExtLaunchKernelGGL: no launch gap inside the measured interval); nullptrs when inactive
+void Engine::prof_pair(int family, hipEvent_t *ev0, hipEvent_t *ev1) {
+    if (family != prof_family) return;
+    if (prof_used >= 8192) prof_collect();
+    if (prof_used + 2 > prof_events.size()) {
+        for (int i = 0; i < 64; i++) {
+            hipEvent_t ev;
+            if (hipEventCreate(&ev) != hipSuccess) return;
+            prof_events.push_back(ev);
+        }
+    }
+    *ev0 = prof_events[prof_used];
+    *ev1 = prof_events[prof_used + 1];
+    prof_used += 2;
+}
 void Engine::prof_end(int family) {
     if (family != prof_family) return;
     if (prof_used + 2 > prof_events.size()) return;
@@ -523,18 +539,18 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
         a.nan = norm_nan(set);
     }
     if (fold.k) { // top rows: bundle shares accumulated by the bundle kernel, finished by one tiny launch
-        prof_begin(PF_SYMV_T);
-        dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, fold);
-        prof_end(PF_SYMV_T);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        prof_pair(PF_SYMV_T, &ev0, &ev1);
+        dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, fold, ev0, ev1);
         dev::fold_top_residual(stream, fold, Sx, x, b, e, a.nrm, a.nan);
         return;
     }
     const dev::ChunkView bc = smv.B(0);
     if (bc.count) dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));
     dev::gather_merged(stream, dev::SYMV, a, smv.T(0), smv.W(0), bc); // the top rows (full rows)
-    prof_begin(PF_SYMV_T);
-    dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, dev::FoldView{}); // everything else
-    prof_end(PF_SYMV_T);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    prof_pair(PF_SYMV_T, &ev0, &ev1);
+    dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, dev::FoldView{}, ev0, ev1); // everything else
     if (bc.count && set >= 0) dev::norm_rows(stream, e, smv.BR(0), a.nrm, a.nan);
 }
 

@@ -129,6 +129,7 @@ struct Engine {
     int read_mailbox();                                                      // D2H + sync
     void prof_begin(int family);
     void prof_end(int family);
+    void prof_pair(int family, hipEvent_t *ev0, hipEvent_t *ev1);
     void prof_collect();
 };
 

@@ -90,7 +90,7 @@ void fold_top_residual(hipStream_t s, const FoldView &fold, const double *Sx, co
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const double *addv);
 // e[bundle rows] = b - K x with K stored once (U: row i = diagonal + entries to ancestors)
 void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
-                 const double *x, const double *b, double *e, unsigned long long *nrm, int *nan, const FoldView &fold);
+                 const double *x, const double *b, double *e, unsigned long long *nrm, int *nan, const FoldView &fold, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);
 void factor_B(hipStream_t s, const LdlView &v, ChunkView chunks);

@@ -899,7 +899,7 @@ __device__ __forceinline__ SnodeGeom snode_geom(const LdlView &v, const SnodeVie
 template <bool EXTEND>
 __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &sv, const SnodeGeom &g, int sn,
                                             const int *colbase, double *Wl, int jrow0, int ncols, int kend,
-                                            int row_begin) {
+                                            int row_begin, int kbeg = 0, bool atomic_emit = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, l15 = lane & 15;
     const int i0[2] = {row_begin + wave * 32, row_begin + wave * 32 + 16};
@@ -910,7 +910,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int c = 0; c < SN_NB / 16; ++c) acc[t][c] = snode_v4d{0.0, 0.0, 0.0, 0.0};
-    for (int kc0 = 0; kc0 < kend; kc0 += SN_KC) {
+    for (int kc0 = kbeg; kc0 < kend; kc0 += SN_KC) {
         const int kcn = min(SN_KC, kend - kc0);
         const int kcn4 = (kcn + 3) & ~3;
         __syncthreads(); // the previous chunk has been consumed
@@ -925,16 +925,27 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
         }
         __syncthreads();
         if (i0[0] >= g.h) continue; // (after the barriers: the whole wave is beyond the panel)
-        for (int kk = 0; kk < kcn4; kk += 4 * SN_U) {
-            double a[2][SN_U];
+        // software pipeline: the A operands of the NEXT group of 4*SN_U columns are requested before the
+        // matrix instructions of the current group are issued
+        double a[2][SN_U], an[2][SN_U];
+        auto request = [&](double(&dst)[2][SN_U], int kk) {
 #pragma unroll
             for (int u = 0; u < SN_U; ++u) { // independent 128-byte runs in flight
                 const int kl = kk + 4 * u + kq;
                 const bool kok = kl < kcn;
                 const int cb = kok ? colbase[kc0 + kl] : 0;
-                a[0][u] = (kok && rowok[0]) ? v.Lx[cb + irow[0]] : 0.0;
-                a[1][u] = (kok && rowok[1]) ? v.Lx[cb + irow[1]] : 0.0;
+                dst[0][u] = (kok && rowok[0]) ? v.Lx[cb + irow[0]] : 0.0;
+                dst[1][u] = (kok && rowok[1]) ? v.Lx[cb + irow[1]] : 0.0;
             }
+        };
+        request(an, 0);
+        for (int kk = 0; kk < kcn4; kk += 4 * SN_U) {
+#pragma unroll
+            for (int u = 0; u < SN_U; ++u) {
+                a[0][u] = an[0][u];
+                a[1][u] = an[1][u];
+            }
+            if (kk + 4 * SN_U < kcn4) request(an, kk + 4 * SN_U);
 #pragma unroll
             for (int u = 0; u < SN_U; ++u) {
                 if (kk + 4 * u < kcn4) {
@@ -964,8 +975,13 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
                 const int j = jrow0 + jj;
                 const double val = acc[t][c][r];
                 if (!EXTEND) {
-                    if (i > j) v.Lx[colbase[j] + i] -= val;
-                    else if (i == j) v.D[g.cols[j]] -= val;
+                    if (atomic_emit) { // split-k: several workgroups share the element
+                        if (i > j) atomicAdd(&v.Lx[colbase[j] + i], -val);
+                        else if (i == j) atomicAdd(&v.D[g.cols[j]], -val);
+                    } else {
+                        if (i > j) v.Lx[colbase[j] + i] -= val;
+                        else if (i == j) v.D[g.cols[j]] -= val;
+                    }
                 } else {
                     const int rB = i - g.w, cB = j - g.w;
                     if (rB > cB) {
@@ -983,7 +999,9 @@ __device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
     Wl = (double *)smem;
     return (int *)(Wl + SN_KC * SN_NB);
 }
-// grid (row groups, supernodes of the level)
+// grid (row groups, supernodes of the level, k splits): with few workgroups in flight (the narrow
+// levels near the root) the finished columns are divided among gridDim.z workgroups per tile group,
+// which then meet in fp64 atomics
 __global__ __launch_bounds__(SN_WG) void k_snode_update(LdlView v, SnodeView sv, const int *__restrict__ order,
                                                         int b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -995,8 +1013,13 @@ __global__ __launch_bounds__(SN_WG) void k_snode_update(LdlView v, SnodeView sv,
     if (j0 >= g.w) return;
     const int row_begin = j0 + (int)blockIdx.x * SN_ROWS;
     if (row_begin >= g.h) return;
+    // this split's share of the k range, in whole LDS chunks
+    const int nchunks = (j0 + SN_KC - 1) / SN_KC, ns = (int)gridDim.z;
+    const int c0 = (int)(((long long)nchunks * blockIdx.z) / ns), c1 = (int)(((long long)nchunks * (blockIdx.z + 1)) / ns);
+    if (c0 >= c1) return;
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = v.Lp[g.cols[t]] - t - 1;
-    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), j0, row_begin);
+    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), min(j0, c1 * SN_KC), row_begin, c0 * SN_KC,
+                       ns > 1);
 }
 // grid (row groups, column blocks of B, supernodes of the level)
 __global__ __launch_bounds__(SN_WG) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order) {
@@ -3816,8 +3839,12 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const i
     for (int b = 0; b < nblk; ++b) {
         if (b > 0) {
             const int rows = hmax - b * SN_NB;
-            if (rows > 0)
-                k_snode_update<<<dim3((rows + SN_ROWS - 1) / SN_ROWS, count), SN_WG, lds, s>>>(v, sv, order, b);
+            if (rows > 0) {
+                const int groups = (rows + SN_ROWS - 1) / SN_ROWS, nchunks = (b * SN_NB + SN_KC - 1) / SN_KC;
+                int ksplit = 1; // fill the chip when the level has few supernodes
+                while (ksplit < 8 && ksplit * 2 <= nchunks && groups * count * ksplit < 512) ksplit *= 2;
+                k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b);
+            }
         }
         k_snode_diag<<<count, SN_DWG, 0, s>>>(v, sv, order, b);
         const int below = hmax - b * SN_NB - 1; // (a narrow last block leaves more rows below it)

@@ -1,7 +1,8 @@
 // kernels.hip -- hand-written CDNA4 (gfx950) kernels of the KKT hot path.
 //
-// Everything here is HBM-bound gather/scatter over fp64 values and int32
-// indices: no MFMA.  Design rules applied throughout
+// The sparse part is HBM-bound gather/scatter over fp64 values and int32 indices
+// (SURVEY.md 8d); the dense chain supernodes of the top use the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64, k_snode_*).  Design rules applied throughout
 // (/opt/skills/guides/cdna_hip_programming.md):
 //   * 64-wide wavefronts: wave reductions use 64-lane shuffles, workgroups
 //     are 256 threads = 4 waves, "wave per row" kernels pack 4 rows per group;

@@ -211,12 +211,18 @@ def test_c2_solve_sequence_as_hipgraph(hip, oracle):
     _check_update_and_solve(hip, oracle, problems.random_qp(3000, 6000, band=20, seed=1), nrhs=4, settings=st)
 
 
-def test_c2_tall_top_blocked_substitution(hip, oracle):
-    """a banded QP whose elimination tree has a tall top (~2200 sequential levels, ~6800 rows): the
-    substitutions run block by block with inverted 128-row diagonal blocks (k_topblk_*)"""
+@pytest.mark.parametrize("snodes", [True, False])
+def test_c2_tall_top_blocked_substitution(hip, oracle, snodes, monkeypatch):
+    """a banded QP whose elimination tree has a tall top (~2200 sequential levels, ~6800 rows): with
+    chain supernodes (default) the top runs as dense trapezoids; without them (CHIP_NO_SNODE) the
+    substitutions run block by block with inverted 128-row diagonal blocks (k_topblk_*) and the heavy
+    columns through the chunked column kernel"""
+    if not snodes:
+        monkeypatch.setenv("CHIP_NO_SNODE", "1")
     pr = problems.random_qp(20000, 40000, band=50, seed=1)
     ks, ko = _check_update_and_solve(hip, oracle, pr, nrhs=2)
     assert ks.N - ks.NF >= 4 * 128
+    assert (len(ks.supernodes()) > 0) == snodes
 
 
 @pytest.mark.parametrize("late", [False, True])

@@ -118,7 +118,11 @@ def main():
             raise RuntimeError("KKT update failed")
         for k, (rx, rz) in enumerate(rhs):
             if works[k] is not None:
-                works[k].wait()  # the gather that used these buffers one step ago
+                # the gather that used these buffers one step ago: wait() only orders torch's current
+                # stream behind it, the engine launches on its own stream -> wait on the host as well
+                works[k].wait()
+                if backend == "nccl":
+                    torch.cuda.current_stream().synchronize()
                 works[k] = None
             ks.setrhs_dev(rx.data_ptr(), rz.data_ptr())
             if not ks.solve_dev(lhs[k].data_ptr(), lhs[k].data_ptr() + 8 * n):

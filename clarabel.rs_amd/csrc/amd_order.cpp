@@ -16,25 +16,31 @@
 // garbage collection pass is needed (pool size is bounded by the symbolic
 // front sizes, i.e. O(nnz(L)) integers, allocated once per problem).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "host.hpp"
 
 namespace chip {
 
 namespace {
-using I = i64;
-constexpr I NONE = -1;
-} // namespace
 
-int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
-              AmdInfo *info) {
+// I = index type of the quotient graph: int32 whenever the symmetric adjacency (2 x off-diagonal
+// entries) fits -- the ordering is memory bound, half-width indices are ~1.5x faster -- else int64
+template <typename I>
+int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
+                   AmdInfo *info) {
+    constexpr I NONE = -1;
     perm.assign((size_t)n, 0);
     AmdInfo st;
     if (n == 0) {
         if (info) *info = st;
         return 0;
     }
+    const bool timing = std::getenv("CHIP_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     // ---- symmetric adjacency without the diagonal ---------------------------
     std::vector<I> ast((size_t)n + 1, 0);
     for (I c = 0; c < n; c++)
@@ -111,6 +117,7 @@ int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vect
     for (I i = n - 1; i >= 0; i--)
         if (!is_dense[i]) dl_insert(i, degree[i]);
 
+    const auto t_adj = std::chrono::steady_clock::now();
     I nelim = 0, mindeg = 0, lemax = 0;
     i64 wflg = 2;
 
@@ -124,6 +131,7 @@ int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vect
 
         // ---- form the new element: union of me's variables and the variables
         //      of every element adjacent to me (those elements are absorbed)
+        if (sizeof(I) == 4 && epool.size() > (size_t)2000000000) return -77; // retry with 64-bit indices
         const I mstart = (I)epool.size();
         I degme = 0;
         for (I p = ast[me]; p < ast[me] + aelen[me]; p++) {
@@ -296,6 +304,10 @@ int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vect
         st.nmultsubs_ldl += (s + lnzme) / 2.0;
     }
 
+    if (timing)
+        std::fprintf(stderr, "[chip amd] adjacency %.3f s, elimination %.3f s (%lld pivots)\n",
+                     std::chrono::duration<double>(t_adj - t_begin).count(),
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_adj).count(), (long long)pivots.size());
     // ---- expand supervariables: every absorbed variable follows its pivot ---
     std::vector<char> is_pivot((size_t)n, 0);
     for (I v : pivots) is_pivot[v] = 1;
@@ -336,6 +348,18 @@ int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vect
     if (k != n) return -9;
     if (info) *info = st;
     return 0;
+}
+
+} // namespace
+
+int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
+              AmdInfo *info) {
+    const i64 nnz = n > 0 ? Ap[n] : 0;
+    if (n < ((i64)1 << 30) && 2 * nnz < ((i64)1 << 31) - 16) {
+        const int rc = amd_order_impl<i32>(n, Ap, Ai, dense_scale, perm, info);
+        if (rc != -77) return rc;
+    }
+    return amd_order_impl<i64>(n, Ap, Ai, dense_scale, perm, info);
 }
 
 } // namespace chip

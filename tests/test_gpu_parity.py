@@ -1071,3 +1071,48 @@ def test_chain_supernodes_solve_without_lds_rows(hip, oracle, which, monkeypatch
         hs = pr["hsblocks"]
     ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=2)
     assert len(ks.supernodes()) > 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ldl_structure_fuzz_with_supernodes(hip, oracle, seed):
+    """random quasidefinite matrices built to produce all kinds of tops -- banded parts (long chains),
+    dense blocks (wide supernodes), random couplings (side subtrees hanging off chains, several unit
+    levels, narrow last blocks) -- factored and solved through chain supernodes when the analysis finds
+    them: D and the solution against the oracle with the same permutation"""
+    rng = np.random.default_rng(1000 + seed)
+    n1 = int(rng.integers(300, 1500))
+    n2 = int(rng.integers(300, 2500))
+    n = n1 + n2
+    rs = np.random.RandomState(seed)
+    band = int(rng.integers(2, 40))
+    diags = [rng.standard_normal(n1 - k) * 0.3 for k in range(1, band)]
+    H = sp.diags(diags, list(range(1, band)), shape=(n1, n1), format="csc")
+    H = H + H.T + sp.diags(rng.uniform(2.0, 4.0, n1) * band)
+    B = sp.random(n2, n1, density=float(rng.uniform(0.5, 4.0)) / n1, random_state=rs, format="csc")
+    nblk = int(rng.integers(0, 4))  # dense blocks in the (2,2) part: PSD-like cone blocks
+    G = sp.diags(rng.uniform(0.5, 2.0, n2)).tolil()
+    pos = 0
+    for _ in range(nblk):
+        w = int(rng.integers(20, 180))
+        if pos + w > n2:
+            break
+        M = rng.standard_normal((w, w))
+        G[pos:pos + w, pos:pos + w] = M @ M.T / w + np.eye(w)
+        pos += w + int(rng.integers(0, 50))
+    K = sp.triu(sp.bmat([[H, B.T], [B, -G.tocsc()]], format="csc"), format="csc")
+    K.sort_indices()
+    ds = np.array([1] * n1 + [-1] * n2, dtype=np.int8)
+    Kc = hip.CscMatrix.from_scipy(K)
+    f = hip.HipDirectLDLSolver(Kc, ds)
+    assert f.refactor()
+    o = oracle.QDLDL(n, Kc.colptr, Kc.rowval, Kc.nzval, perm=f.perm, Dsigns=ds, logical=True,
+                     regularize_eps=1e-13, regularize_delta=2e-7)
+    assert o.refactor()
+    Lp, Li, Lx, D, Dinv = f.factors()
+    assert relerr(D, o.D) <= 1e-9
+    assert f.linear_solver_info().positive_inertia == o.positive_inertia == n1
+    for _ in range(2):
+        b = rng.standard_normal(n)
+        x = np.zeros(n)
+        f.solve(None, x, b)
+        assert relerr(x, o.solve(b)) <= 1e-7

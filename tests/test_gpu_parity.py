@@ -1116,3 +1116,45 @@ def test_ldl_structure_fuzz_with_supernodes(hip, oracle, seed):
         x = np.zeros(n)
         f.solve(None, x, b)
         assert relerr(x, o.solve(b)) <= 1e-7
+
+
+def _arrow_of_bands(rng, nblocks, nrows_couple):
+    """several banded blocks of different widths joined by a few dense-ish coupling rows: the tops of
+    the blocks are separate chains that merge into one (supernodes on several unit levels, ancestor
+    updates between them)"""
+    blocks, sizes = [], []
+    for _ in range(nblocks):
+        nb = int(rng.integers(400, 1200))
+        band = int(rng.integers(8, 40))
+        diags = [rng.standard_normal(nb - k) * 0.3 for k in range(1, band)]
+        H = sp.diags(diags, list(range(1, band)), shape=(nb, nb), format="csc")
+        blocks.append(H + H.T + sp.diags(rng.uniform(2.0, 4.0, nb) * band))
+        sizes.append(nb)
+    n1 = sum(sizes)
+    H = sp.block_diag(blocks, format="csc")
+    n2 = nrows_couple
+    B = sp.random(n2, n1, density=0.05, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="csc")
+    G = sp.diags(rng.uniform(0.5, 2.0, n2))
+    K = sp.triu(sp.bmat([[H, B.T], [B, -G]], format="csc"), format="csc")
+    K.sort_indices()
+    return K, np.array([1] * n1 + [-1] * n2, dtype=np.int8), n1
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_ldl_supernode_trees(hip, oracle, seed):
+    rng = np.random.default_rng(77 + seed)
+    K, ds, n1 = _arrow_of_bands(rng, int(rng.integers(3, 6)), int(rng.integers(40, 400)))
+    n = K.shape[0]
+    Kc = hip.CscMatrix.from_scipy(K)
+    f = hip.HipDirectLDLSolver(Kc, ds)
+    assert len(f.supernodes()) >= 2
+    assert f.refactor()
+    o = oracle.QDLDL(n, Kc.colptr, Kc.rowval, Kc.nzval, perm=f.perm, Dsigns=ds, logical=True,
+                     regularize_eps=1e-13, regularize_delta=2e-7)
+    assert o.refactor()
+    Lp, Li, Lx, D, Dinv = f.factors()
+    assert relerr(D, o.D) <= 1e-9
+    b = rng.standard_normal(n)
+    x = np.zeros(n)
+    f.solve(None, x, b)
+    assert relerr(x, o.solve(b)) <= 1e-7

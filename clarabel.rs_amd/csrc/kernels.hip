@@ -1107,12 +1107,7 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, 
     }
     for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_DWG) { // the block's strict lower triangle
         const int ii = idx / SN_NB, jj = idx % SN_NB;
-        if (ii > jj && ii < nbw) {
-            const int q = colbase[jj] + j0 + ii;
-            const double l = T[idx];
-            v.Lx[q] = l;
-            v.Rx[v.Tpos[q]] = l;
-        }
+        if (ii > jj && ii < nbw) v.Lx[colbase[jj] + j0 + ii] = T[idx];
     }
 }
 // grid (row groups of SN_DWG rows, supernodes of the level): the rows below the diagonal block of
@@ -1155,11 +1150,9 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_rows(LdlView v, SnodeView sv, 
     }
 #pragma unroll
     for (int jj = 0; jj < SN_NB; ++jj)
-        if (jj < nbw) {
-            const int q = colbase[jj] + i;
-            v.Lx[q] = x[jj];
-            v.Rx[v.Tpos[q]] = x[jj];
-        }
+        if (jj < nbw) v.Lx[colbase[jj] + i] = x[jj];
+    // (no row-major mirror Rx for supernode columns: with supernodes the forward sweep of the top reads
+    // the filtered lists Rfx -- non-member columns only -- and k_snode_fwd reads Lx itself)
 }
 
 // Substitutions through a chain supernode, one workgroup per supernode of the unit level, the

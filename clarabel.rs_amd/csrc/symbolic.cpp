@@ -640,7 +640,8 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         // blocks must be well below the number of levels (config 2: 272 blocks for 4383 levels;
         // config 5's wide levels -- 200 rows each -- stay level scheduled)
         const i64 nblk = (ntop + TOPBLK - 1) / TOPBLK;
-        if (!off && ntop >= 4 * TOPBLK && nlevels >= 256 && 3 * nblk < (i64)nlevels) {
+        const bool has_sn = S.sn_ptr.size() > 1; // (with chain supernodes the top is solved through them)
+        if (!off && !has_sn && ntop >= 4 * TOPBLK && nlevels >= 256 && 3 * nblk < (i64)nlevels) {
             S.topblk = TOPBLK;
             S.Rsplit.resize((size_t)ntop);
             S.Lsplit.resize((size_t)ntop);

@@ -495,6 +495,14 @@ class HipKKTSolver:
     def synchronize(self):
         _check(lib().chip_kkt_synchronize(self._h), "synchronize")
 
+    def set_settings(self, settings):
+        """the reference passes `settings` to update() / solve() on every call (kktsolvers/mod.rs:7-18)"""
+        _check(lib().chip_kkt_set_settings(self._h, C.byref(settings)), "set_settings")
+        self.settings = settings
+
+    def scaling_ok(self):
+        return bool(_status(lib().chip_kkt_scaling_ok(self._h), "scaling_ok"))
+
     def profile(self, family):
         _check(lib().chip_kkt_profile(self._h, C.c_int32(family)), "profile")
 

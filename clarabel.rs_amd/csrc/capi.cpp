@@ -826,6 +826,35 @@ int32_t chip_kkt_solve(chip_kkt *h, double *lhsx, double *lhsz) {
     CHIP_HIP(hipStreamSynchronize(E.stream));
     return 1;
 }
+int32_t chip_kkt_set_settings(chip_kkt *h, const chip_settings *s) {
+    if (!h || !s) return CHIP_ERR_ARG;
+    chip_settings &d = h->E.st;
+    d.static_regularization_enable = s->static_regularization_enable;
+    d.static_regularization_constant = s->static_regularization_constant;
+    d.static_regularization_proportional = s->static_regularization_proportional;
+    d.dynamic_regularization_enable = s->dynamic_regularization_enable;
+    d.dynamic_regularization_eps = s->dynamic_regularization_eps;
+    d.dynamic_regularization_delta = s->dynamic_regularization_delta;
+    d.iterative_refinement_enable = s->iterative_refinement_enable;
+    d.iterative_refinement_reltol = s->iterative_refinement_reltol;
+    d.iterative_refinement_abstol = s->iterative_refinement_abstol;
+    d.iterative_refinement_max_iter = s->iterative_refinement_max_iter;
+    d.iterative_refinement_stop_ratio = s->iterative_refinement_stop_ratio;
+    d.linesearch_backtrack_step = s->linesearch_backtrack_step;
+    d.min_terminate_step_length = s->min_terminate_step_length;
+    return CHIP_OK;
+}
+int32_t chip_kkt_scaling_ok(chip_kkt *h) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    if (!h->scaling_pending_check) return 1;
+    CHIP_HIP(hipSetDevice(E.device));
+    int rc = E.read_mailbox();
+    if (rc) return rc;
+    h->scaling_pending_check = false;
+    return E.mb_host->soc_fail ? 0 : 1;
+}
 int32_t chip_kkt_solve_full(chip_kkt *h, double *x, const double *b) {
     if (!h || !x || !b) return CHIP_ERR_ARG;
     Engine &E = h->E;
@@ -843,11 +872,12 @@ int32_t chip_kkt_solve_full(chip_kkt *h, double *x, const double *b) {
     return 1;
 }
 
-static int update_block(chip_kkt *h, const int *map, const double *vals, size_t k) {
+static int update_block(chip_kkt *h, const int *map, const std::vector<i64> &hmap, const double *vals, size_t k) {
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
     if (!k) return CHIP_OK;
+    for (size_t i = 0; i < k; i++) h->K.nzval[(size_t)hmap[i]] = vals[i]; // host mirror (chip_kkt_get_matrix)
     CHIP_HIP(hipMemcpyAsync(h->d_tmp, vals, k * sizeof(double), hipMemcpyHostToDevice, E.stream));
     dev::scatter_values(E.stream, E.Kx, map, h->d_tmp, (int)k, 1.0);
     CHIP_HIP(hipStreamSynchronize(E.stream));
@@ -855,11 +885,11 @@ static int update_block(chip_kkt *h, const int *map, const double *vals, size_t 
 }
 int32_t chip_kkt_update_P(chip_kkt *h, const double *Pnzval) {
     if (!h || !Pnzval) return CHIP_ERR_ARG;
-    return update_block(h, h->mapP, Pnzval, h->K.mapP.size() - 1);
+    return update_block(h, h->mapP, h->K.mapP, Pnzval, h->K.mapP.size() - 1);
 }
 int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval) {
     if (!h || !Anzval) return CHIP_ERR_ARG;
-    return update_block(h, h->mapA, Anzval, h->K.mapA.size() - 1);
+    return update_block(h, h->mapA, h->K.mapA, Anzval, h->K.mapA.size() - 1);
 }
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     if (!h) return CHIP_ERR_ARG;

@@ -421,7 +421,9 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
     dev::gather_values(stream, Ux, Kx, Umap, (int)nnzU);
     int rc = read_mailbox();
     if (rc) return rc;
-    factored = true;
+    // a failed refactor leaves garbage in L / D / Dinv: the handle goes back to "not factored" so that
+    // a later solve() fails loudly (the reference panics on ZeroPivot, ldlsolvers/qdldl.rs:104)
+    factored = !mb_host->status[0] && !mb_host->status[1];
     last_regularize_count = mb_host->status[2];
     if (mb_host->status[1]) {
         // the reference adapter unwrap()s QDLDLError::ZeroPivot (ldlsolvers/qdldl.rs:104)

@@ -35,6 +35,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace chip {
 namespace dev {
@@ -3836,7 +3837,9 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const i
             if (rows > 0) {
                 const int groups = (rows + SN_ROWS - 1) / SN_ROWS, nchunks = (b * SN_NB + SN_KC - 1) / SN_KC;
                 int ksplit = 1; // fill the chip when the level has few supernodes
-                while (ksplit < 8 && ksplit * 2 <= nchunks && groups * count * ksplit < 512) ksplit *= 2;
+                // (CHIP_NO_SPLITK: no split -> no fp64 atomics between the splits, a fixed summation order)
+                static const bool no_splitk = std::getenv("CHIP_NO_SPLITK") != nullptr;
+                while (!no_splitk && ksplit < 8 && ksplit * 2 <= nchunks && groups * count * ksplit < 512) ksplit *= 2;
                 k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b);
             }
         }

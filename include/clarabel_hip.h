@@ -225,6 +225,17 @@ int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *r
  * incl. iterative_refinement :266-321.  Either output may be NULL. */
 int32_t chip_kkt_solve(chip_kkt *h, double *lhsx_or_null, double *lhsz_or_null);
 int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_dev_or_null);
+/* KKTSolver::solve / ::update receive `settings: &CoreSettings` on EVERY call in the reference
+ * (kktsolvers/mod.rs:7-18, directldlkktsolver.rs:134,168): this hands the current values of the
+ * regularisation and refinement fields to the following calls.  The engine knobs (device, amd_dense_scale,
+ * use_graph) keep their construction-time values. */
+int32_t chip_kkt_set_settings(chip_kkt *h, const chip_settings *settings);
+/* The verdict of the last chip_kkt_update_scaling_dev, which itself stays asynchronous and returns 1:
+ * 1 = every SOC / PSD scaling succeeded, 0 = a cone left its interior (socone.rs:146-149,
+ * psdtrianglecone.rs:165-169).  One 256-byte device-to-host copy + synchronisation; a device-resident
+ * driver calls it where the reference tests the bool of cones.update_scaling (core/solver.rs:334-338),
+ * or relies on chip_kkt_update, which reports the same verdict after the refactor. */
+int32_t chip_kkt_scaling_ok(chip_kkt *h);
 /* update_P / update_A   directldlkktsolver.rs:191-197 */
 int32_t chip_kkt_update_P(chip_kkt *h, const double *Pnzval);
 int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval);

@@ -29,11 +29,25 @@ CONE_ZERO, CONE_NONNEG, CONE_SOC, CONE_EXP, CONE_POW, CONE_GENPOW, CONE_PSDTRI =
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+    """liboracle.so (portable); with ORACLE_NATIVE=1 in the environment (set by bench.py's cpu_baseline
+    leg before the first use) a -march=native build made on THIS machine is preferred for timing."""
     srcs = [os.path.join(_HERE, f) for f in ("qdldl_oracle.c", "kkt_oracle.c")]
+    if os.environ.get("ORACLE_NATIVE") == "1":
+        so = os.path.join(_HERE, "_native", "liboracle_native.so")
+        try:
+            if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+                subprocess.check_call(["make", "-C", _HERE, "-B", "native"], stdout=subprocess.DEVNULL)
+            return so
+        except Exception:
+            pass  # no compiler on this box: fall back to the prebuilt portable library
+    so = os.path.join(_HERE, "liboracle.so")
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
+
+
+def is_native():
+    return _LIB is not None and "native" in getattr(_LIB, "_name", "")
 
 
 def lib():
@@ -559,6 +573,11 @@ class KKTSolver:
     @property
     def regularizer(self):
         return lib().orc_kktsolver_regularizer(self._h)
+
+    def ldl_regularize_count(self):
+        """dynamic-regularisation hits of the last refactor (qdldl.rs:110-112)"""
+        lib().orc_kktsolver_ldl.restype = C.c_void_p
+        return int(lib().orc_qdldl_regularize_count(C.c_void_p(lib().orc_kktsolver_ldl(self._h))))
 
 
 class Variables:

@@ -12,7 +12,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 import __graft_entry__ as g
-from tests import problems
+import __graft_entry__ as _graft_entry
+_graft_entry.load_package()
+import clarabel_rs_amd.synthetic as problems
 
 
 def census(name, pr, hip):

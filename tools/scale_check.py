@@ -16,7 +16,9 @@ import numpy as np
 import scipy.sparse as sp
 
 import __graft_entry__ as g
-from tests import problems
+import __graft_entry__ as _graft_entry
+_graft_entry.load_package()
+import clarabel_rs_amd.synthetic as problems
 
 
 def run(name, pr, hip, use_oracle, steps=5, hs=None):

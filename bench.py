@@ -8,14 +8,24 @@ reference call sites core/solver.rs:351,361,398):
     3 x solve    : LDL' solve + iterative refinement fixed at r = 1 extra round
                    (max_iter = 1, tolerances 0)  ->  6 LDL' solves + 6 symv
 All inputs (s, z, right-hand sides) are resident in HBM when the timed region
-starts; outputs stay in HBM.
+starts; outputs stay in HBM.  No PyTorch: device buffers, streams and the RCCL
+exchange all go through the C ABI (include/clarabel_hip.h).
 
-N = 1 : BASELINE config 3, portfolio SOCP n = 10^6 (1000 x SOC(1001)).
-N > 1 : weak scaling -- every rank owns one n = 10^6 shard of a block-diagonal
-        problem (N independent portfolio blocks; the elimination forest has N
-        roots, so factor/solve need no exchange); after each of the 3 solves the
-        step direction is all-gathered over RCCL/xGMI so every rank holds the
-        full (dx, dz).  value = N shards * steps / time.
+--gpus 1 (default): BASELINE config 3, portfolio SOCP n = 10^6 (1000 x SOC(1001)) --
+        the configuration the metric is quoted on -- on one MI355X; the JSON line also carries
+        `parity` (solutions against the CPU oracle on the same inputs), `cpu_baseline`
+        (the oracle, 1 core), `cpu_baseline_mt` (scipy SuperLU, labelled non-reference)
+        and `batched_c4` (BASELINE config 4 whole on this GPU: the N = 1 point of the
+        strong-scaling curve below).
+--gpus N > 1 (one process per GPU, launched by torch.distributed.run; only its env
+        vars are used): BASELINE config 4, 1024 independent SOCPs of n = 2000, sharded by
+        whole elimination trees over the ranks (clarabel.rs_amd/sharding.py: 1024/N blocks
+        each) -- STRONG scaling: the total problem is fixed.  Factor / solves / refinement
+        need no exchange; after each of the 3 solves the step direction is all-gathered
+        with RCCL over xGMI (chip_kkt_allgather_step: ordered behind the solve by an event,
+        running on its own stream behind the next solve).  value = steps / time of the
+        whole 1024-block problem.
+--workload c3|c4 forces the workload (c4 at N = 1 = the whole batched problem).
 """
 import argparse
 import json
@@ -28,13 +38,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch  # imported BEFORE the extension so both share one HIP runtime
-import torch.distributed as dist
 
 import __graft_entry__ as graft
-from tests import problems
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+TOL = 1e-8             # north_star: "solution within 1e-8 relative of reference"
 
 
 def baseline_metric():
@@ -54,14 +62,202 @@ def algorithmic_bytes(N, nnzK, nnzL, nnzHs, m):
                 iter=B_update + B_factor + 6 * B_solve + 6 * B_symv)
 
 
+def bench_settings(hip, device):
+    return hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0,
+                                iterative_refinement_abstol=0.0, device=device)
+
+
+class Workload:
+    """one rank's KKT system, resident on its GPU, and the step that is timed"""
+
+    def __init__(self, hip, pr, device, rank, nrhs=3):
+        self.hip, self.pr = hip, pr
+        n, m = pr["n"], pr["m"]
+        t0 = time.time()
+        self.ks = hip.HipKKTSolver(hip.CscMatrix(n, n, *pr["P"]), hip.CscMatrix(m, n, *pr["A"]), pr["cones"], m, n,
+                                   settings=bench_settings(hip, device))
+        self.t_setup = time.time() - t0
+        rng = np.random.default_rng(1234 + rank)
+        self.rhs_host = [(rng.standard_normal(n), rng.standard_normal(m)) for _ in range(nrhs)]
+        self.s_d, self.z_d = hip.DeviceArray(pr["s"]), hip.DeviceArray(pr["z"])
+        self.rhs = [(hip.DeviceArray(rx), hip.DeviceArray(rz)) for rx, rz in self.rhs_host]
+        self.lhs = [hip.DeviceArray(n + m) for _ in range(nrhs)]
+        self.n, self.m = n, m
+
+    def step(self, comm=None, gathered=None, counts=None):
+        ks = self.ks
+        ks.update_scaling_dev(self.s_d.ptr, self.z_d.ptr)
+        if not ks.update():
+            raise RuntimeError("KKT update failed")
+        for k, (rx, rz) in enumerate(self.rhs):
+            if comm is not None:
+                # lhs[k] / gathered[k] were handed to the all-gather one step ago: this stream waits
+                # for it ON THE DEVICE (no host synchronisation) before overwriting them
+                comm.wait(ks)
+            ks.setrhs_dev(rx.ptr, rz.ptr)
+            if not ks.solve_dev(self.lhs[k].ptr, self.lhs[k].ptr + 8 * self.n):
+                raise RuntimeError("KKT solve failed")
+            if comm is not None:
+                # every rank ends up with the full step direction (dx, dz): RCCL all-gather over xGMI,
+                # enqueued behind this solve by an event and left running behind the next solve
+                comm.allgather_step(ks, self.lhs[k].ptr, gathered[k].ptr, counts)
+
+    def run(self, steps, warmup, profile_family=0, comm=None, gathered=None, counts=None):
+        def sync():
+            self.ks.synchronize()
+            if comm is not None:
+                comm.synchronize()
+                comm.barrier()
+            self.hip.device_synchronize()
+        for _ in range(warmup):
+            self.step(comm, gathered, counts)
+        sync()
+        self.ks.profile(profile_family)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(comm, gathered, counts)
+        sync()
+        elapsed = time.perf_counter() - t0
+        prof = self.ks.profile_read()
+        self.ks.profile(0)
+        if comm is not None:
+            elapsed = float(comm.allreduce([elapsed], "max")[0])
+        return elapsed, prof
+
+    def solutions(self):
+        self.ks.synchronize()
+        return [a.numpy() for a in self.lhs]
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
+
+
+def oracle_leg(w, args, time_it=True):
+    """The CPU oracle (C restatement of the reference qdldl path + DirectLDLKKTSolver, 1 thread -- the
+    reference engine reports threads: 1, ldlsolvers/qdldl.rs:68) on the SAME workload, permutation and
+    right-hand sides: (a) parity of the GPU solutions, under the bench's fixed r = 1 refinement and under
+    the default refinement settings; (b) cpu_baseline, bounded to ~10-30 s of CPU work."""
+    os.environ["ORACLE_NATIVE"] = "1"  # -march=native build made on this box (SURVEY 8d), see oracle/Makefile
+    from oracle import oracle as orc
+    pr, ks, hip = w.pr, w.ks, w.hip
+    ost = orc.Settings.default()
+    ost.ir_max_iter, ost.ir_reltol, ost.ir_abstol = 1, 0.0, 0.0
+    cones = orc.Cones(pr["cones"])
+    ko = orc.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones, settings=ost, perm=ks.perm)
+
+    def step(keep=None):
+        cones.update_scaling(pr["s"], pr["z"])
+        assert ko.update()
+        for rx, rz in w.rhs_host:
+            ko.setrhs(rx, rz)
+            ok, x, z = ko.solve()
+            assert ok
+            if keep is not None:
+                keep.append(np.concatenate([x, z]))
+
+    ref_r1 = []
+    t0 = time.perf_counter()
+    step(ref_r1)
+    t1 = time.perf_counter() - t0
+    got_r1 = w.solutions()
+    err_r1 = max(relerr(g, r) for g, r in zip(got_r1, ref_r1))
+    # default refinement (reltol 1e-13, abstol 1e-12, <= 10 rounds) on both sides, same factorisation
+    dflt = hip.Settings.default(device=ks.settings.device)
+    ks.set_settings(dflt)
+    ko.settings = orc.Settings.default()
+    err_d, rounds = 0.0, []
+    for k, (rx, rz) in enumerate(w.rhs):
+        ks.setrhs_dev(rx.ptr, rz.ptr)
+        assert ks.solve_dev(w.lhs[k].ptr, w.lhs[k].ptr + 8 * w.n)
+        rounds.append(int(ks.linear_solver_info().last_ir_iterations))
+        ko.setrhs(*w.rhs_host[k])
+        ok, x, z = ko.solve()
+        assert ok
+        ks.synchronize()
+        err_d = max(err_d, relerr(w.lhs[k].numpy(), np.concatenate([x, z])))
+    ks.set_settings(bench_settings(hip, ks.settings.device))
+    ko.settings = ost
+    parity = {"rel_err_vs_oracle": err_d, "tol": TOL, "ok": bool(err_d <= TOL),
+              "what": "max over the %d solves of ||x_gpu - x_oracle||inf / max(1, ||x_oracle||inf), post-refinement, "
+                      "default refinement settings (rounds taken on the GPU: %s), same inputs and permutation"
+                      % (len(w.rhs), rounds),
+              "rel_err_fixed_r1": err_r1,
+              "fixed_r1": "the same for the solutions of the timed configuration (exactly one refinement round)"}
+    cpu = None
+    if time_it:
+        nsteps = args.cpu_steps if args.cpu_steps > 0 else max(2, min(200, int(15.0 / max(t1, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        el = time.perf_counter() - t0
+        cpu = {"value": round(nsteps / el, 4), "unit": "iterations/s", "cores": 1, "kind": "port",
+               "sample": "%d full steps of the same workload (N=%d) on 1 of the host's %d cores, oracle/ C restatement "
+                         "of src/qdldl + DirectLDLKKTSolver (%s), same permutation and right-hand sides"
+                         % (nsteps, ks.N, os.cpu_count() or 0,
+                            "-O3 -march=native" if orc.is_native() else "-O3 -march=x86-64-v3")}
+    return parity, cpu, ko
+
+
+def superlu_leg(w, ko):
+    """labelled NON-reference comparator (SURVEY 8d / BASELINE.md section 2): scipy.sparse.linalg.splu
+    (SuperLU, COLAMD, no pivoting) of the full symmetric regularised K + 6 triangular solves + 6 SpMV per step.
+    SuperLU is sequential apart from its BLAS calls; the host's core count is stated next to it."""
+    try:
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        km, N = ko.kkt, ko.N
+        Ku = sp.csc_matrix((km.nzval.copy(), km.rowval.astype(np.int64), km.colptr.astype(np.int64)), shape=(N, N))
+        Kf = (Ku + sp.triu(Ku, 1).T).tocsc()
+        Kr = Kf.copy()
+        Kr.setdiag(Ku.diagonal() + ko.regularizer * ko.dsigns)
+        rng = np.random.default_rng(5)
+        bs = [rng.standard_normal(N) for _ in range(3)]
+        t0 = time.perf_counter()
+        lu = spla.splu(Kr.tocsc(), permc_spec="COLAMD", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+        for b in bs:
+            x = lu.solve(b)
+            e = b - Kf @ x
+            x = x + lu.solve(e)
+            e = b - Kf @ x
+        el = time.perf_counter() - t0
+        return {"value": round(1.0 / el, 4), "unit": "iterations/s", "cores": os.cpu_count() or 0,
+                "kind": "scipy-superlu (NOT the reference; the reference's multi-threaded faer engine needs a Rust toolchain)",
+                "sample": "1 step: splu(K + static reg) + 3 x (solve, residual, solve, residual) at N=%d; SuperLU runs "
+                          "on 1 core except BLAS; final residual %.1e" % (N, float(np.max(np.abs(e))))}
+    except Exception as ex:  # a comparator, never a reason to lose the bench line
+        return {"value": None, "error": repr(ex)[:200]}
+
+
+def rendezvous_id(hip, rank, world):
+    """the 128-byte RCCL token from rank 0 to the others through a file in /tmp (single node; the
+    launcher's pid makes the name unique per run).  Setup only, never in the timed region."""
+    path = "/tmp/chip_comm_id_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+    if rank == 0:
+        tok = hip.comm_unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(tok)
+        os.replace(path + ".tmp", path)
+        return tok
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > 300:
+            raise RuntimeError("rank %d: no RCCL token from rank 0" % rank)
+        time.sleep(0.05)
+    return open(path, "rb").read()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nblocks", type=int, default=1000, help="SOC blocks per shard (default: config 3)")
+    ap.add_argument("--workload", choices=["auto", "c3", "c4"], default="auto")
+    ap.add_argument("--nblocks", type=int, default=1000, help="c3: SOC blocks (default: config 3)")
     ap.add_argument("--blocksize", type=int, default=1000)
+    ap.add_argument("--nbatch", type=int, default=1024, help="c4: independent SOCPs (default: config 4)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1 auto, 0 off)")
+    ap.add_argument("--no-extras", action="store_true", help="skip parity / cpu legs / batched_c4 (profiling runs)")
     ap.add_argument("--profile-family", type=int, default=1,
                     help="kernel family timed with hipEvents for the roofline (1 = k_bundle_symv)")
     args = ap.parse_args()
@@ -69,104 +265,50 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch N > 1 as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    # one process per GPU; CHIP_BENCH_BACKEND=gloo + several ranks on one GPU is a plumbing test mode
-    backend = os.environ.get("CHIP_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
     hip = graft.load_package()
+    import clarabel_rs_amd.synthetic as problems
+    import clarabel_rs_amd.sharding as sharding
+    ndev = hip.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    device = local_rank % ndev
+    hip.set_device(device)
+    workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
+    if world > 1 and workload != "c4":
+        raise SystemExit("N > 1 runs the sharded batched workload (c4)")
 
-    # ---- this rank's shard ----------------------------------------------------
-    pr = problems.portfolio_socp(args.nblocks, args.blocksize, seed=3 + rank)
-    n, m = pr["n"], pr["m"]
-    st = hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0,
-                              iterative_refinement_abstol=0.0, device=local_rank)
-    t0 = time.time()
-    P = hip.CscMatrix(n, n, *pr["P"])
-    A = hip.CscMatrix(m, n, *pr["A"])
-    ks = hip.HipKKTSolver(P, A, pr["cones"], m, n, settings=st)
-    t_setup = time.time() - t0
-    info = ks.linear_solver_info()
-    dev = torch.device("cuda", local_rank)
-    rng = np.random.default_rng(1234 + rank)
-    s_d = torch.tensor(pr["s"], device=dev)
-    z_d = torch.tensor(pr["z"], device=dev)
-    rhs = [(torch.tensor(rng.standard_normal(n), device=dev), torch.tensor(rng.standard_normal(m), device=dev))
-           for _ in range(3)]
-    gdev = dev if backend == "nccl" else torch.device("cpu")
-    # one (lhs, gathered) pair per solve of a step: the all-gather of solve k is asynchronous and
-    # overlaps the compute of the following solves; its buffers are only reused one step later
-    lhs = [torch.zeros(n + m, device=dev, dtype=torch.float64) for _ in range(3)]
-    gathered = [torch.zeros(world * (n + m), device=gdev, dtype=torch.float64) if world > 1 else None
-                for _ in range(3)]
-    works = [None, None, None]
-    torch.cuda.synchronize()
-
-    def step():
-        ks.update_scaling_dev(s_d.data_ptr(), z_d.data_ptr())
-        if not ks.update():
-            raise RuntimeError("KKT update failed")
-        for k, (rx, rz) in enumerate(rhs):
-            if works[k] is not None:
-                # the gather that used these buffers one step ago: wait() only orders torch's current
-                # stream behind it, the engine launches on its own stream -> wait on the host as well
-                works[k].wait()
-                if backend == "nccl":
-                    torch.cuda.current_stream().synchronize()
-                works[k] = None
-            ks.setrhs_dev(rx.data_ptr(), rz.data_ptr())
-            if not ks.solve_dev(lhs[k].data_ptr(), lhs[k].data_ptr() + 8 * n):
-                raise RuntimeError("KKT solve failed")
-            if world > 1:
-                # every rank ends up with the full step direction (dx, dz) of the block-diagonal
-                # problem: RCCL all-gather over xGMI (7 x 24 MB received per rank at 8 GPUs),
-                # launched once this rank's solve is complete and left running behind the next solve
-                ks.synchronize()
-                works[k] = dist.all_gather_into_tensor(gathered[k], lhs[k] if backend == "nccl" else lhs[k].cpu(),
-                                                       async_op=True)
-
-    def sync_all():
-        ks.synchronize()
-        for k in range(3):
-            if works[k] is not None:
-                works[k].wait()
-                works[k] = None
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    ks.profile(args.profile_family)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    prof = ks.profile_read()
-    ks.profile(0)
+    comm = gathered = counts = None
+    if workload == "c3":
+        pr = problems.portfolio_socp(args.nblocks, args.blocksize, seed=3)
+        desc = ("portfolio SOCP (BASELINE config 3): n=%d, Zero(1)+NN(%d)+%d x SOC(%d)"
+                % (pr["n"], pr["n"], args.nblocks, args.blocksize + 1))
+    else:
+        # whole elimination trees per rank, balanced by the blocks' factor work (identical blocks here)
+        ranges = sharding.partition_blocks(np.ones(args.nbatch), world)
+        b0, b1 = ranges[rank]
+        pr = problems.batched_socp(b1 - b0, 2000, 2, seed=100 + b0)
+        desc = ("batched SOCP (BASELINE config 4): %d independent SOCPs of n=2000 (2 x SOC(1001) + budget row each), "
+                "%d per GPU" % (args.nbatch, b1 - b0))
+        counts = [(e - b) * (pr["n"] + pr["m"]) // (b1 - b0) for b, e in ranges]
+    w = Workload(hip, pr, device, rank)
+    info = w.ks.linear_solver_info()
+    t_setup = w.t_setup
     if world > 1:
-        t = torch.tensor([elapsed], device=gdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ir = ks.linear_solver_info().last_ir_iterations
+        comm = hip.Comm(rendezvous_id(hip, rank, world), world, rank, device)
+        comm.attach(w.ks)
+        gathered = [hip.DeviceArray(int(sum(counts))) for _ in range(3)]
+    elapsed, prof = w.run(args.steps, args.warmup, args.profile_family, comm, gathered, counts)
+    ir = w.ks.linear_solver_info().last_ir_iterations
 
     if rank == 0:
+        ks, m = w.ks, w.m
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
-        Bm = algorithmic_bytes(ks.N, ks.nnzK, info.nnzL, ks.nHs, m)
+        value = args.steps / elapsed
+        # byte model of the WHOLE problem (all ranks): every rank holds 1/world of it
+        Bm = algorithmic_bytes(ks.N * world, ks.nnzK * world, info.nnzL * world, ks.nHs * world, m * world)
         # family 1 = the dominant kernel: residual of all bundle rows, K stored once (U):
         # 12 B per streamed K entry + 24 B per row (x, b read; e written)
         fam_bytes = {1: 12 * ks.nnzU + 24 * ks.NF}.get(args.profile_family)
@@ -174,15 +316,16 @@ def main():
                     2: "k_gather_merged<1> (BWD top levels)", 3: "k_gather_merged<0> (FWD top levels)",
                     4: "k_factor_T"}.get(args.profile_family, "?")
         # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> tools/pmc_summarize.py ->
-        # profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, see that script).  PMC counters
-        # cannot be collected from inside the timed run, so the committed summary of the same
-        # command is quoted; null when the workload differs from the profiled one.
-        traffic = None
+        # profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, see that script).  PMC counters cannot be
+        # collected from inside the timed run: the committed summary of the same command is QUOTED (with the
+        # file it comes from) -- null when the workload differs from the profiled one.
+        traffic = traffic_src = None
         try:
             import glob
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if pj and args.nblocks == 1000 and args.blocksize == 1000 and args.profile_family == 1:
+            if pj and workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000 and args.profile_family == 1:
                 traffic = json.load(open(pj[-1]))["kernels"]["k_bundle_symv"]["hbm_bytes"]
+                traffic_src = os.path.basename(pj[-1])
         except Exception:
             traffic = None
         roof = None
@@ -190,67 +333,54 @@ def main():
             avg_ms = prof["ms"] / prof["launches"]
             ach = fam_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": fam_name,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profiled_in": traffic_src,
+                    "kernel": fam_name,
                     "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
                     "algorithmic_bytes_per_launch": fam_bytes,
                     "whole_step": {"algorithmic_bytes": Bm["iter"],
                                    "achieved_GBs": round(Bm["iter"] / (ms_per_step * 1e-3) / 1e9, 1),
-                                   "frac": round(Bm["iter"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-        cpu = None
-        if world == 1 and args.cpu_steps != 0:
-            cpu = cpu_baseline(pr, ks, args)
+                                   "frac": round(Bm["iter"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4)}}
+        parity = cpu = cpu_mt = c4 = None
+        if world == 1 and not args.no_extras:
+            parity, cpu, ko = oracle_leg(w, args, time_it=args.cpu_steps != 0)
+            if args.cpu_steps != 0:
+                cpu_mt = superlu_leg(w, ko)
+            del ko
+            if workload == "c3" and args.workload == "auto":
+                # the N = 1 point of the sharded workload's strong-scaling curve: config 4 whole on this GPU
+                del w
+                pr4 = problems.batched_socp(args.nbatch, 2000, 2, seed=100)
+                w4 = Workload(hip, pr4, device, 0)
+                el4, _ = w4.run(args.steps, args.warmup)
+                i4 = w4.ks.linear_solver_info()
+                B4 = algorithmic_bytes(w4.ks.N, w4.ks.nnzK, i4.nnzL, w4.ks.nHs, w4.m)
+                par4, _, _ = oracle_leg(w4, args, time_it=False)
+                c4 = {"workload": "batched SOCP (BASELINE config 4): %d independent SOCPs of n=2000, whole problem on 1 GPU, "
+                                  "device resident" % args.nbatch,
+                      "value": round(args.steps / el4, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * el4 / args.steps, 4),
+                      "kkt_dim": w4.ks.N, "nnz_L": int(i4.nnzL), "setup_s": round(w4.t_setup, 2),
+                      "whole_step_frac_of_hbm_peak": round(B4["iter"] / (el4 / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                      "parity": par4,
+                      "note": "the --gpus N > 1 lines run THIS workload sharded (strong scaling); this is their N = 1 base"}
         out = {
             "metric": baseline_metric(),
             "value": round(value, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "portfolio SOCP (BASELINE config 3): n=%d, Zero(1)+NN(%d)+%d x SOC(%d) per shard, "
-                                   "%d shard(s) block-diagonal" % (n, n, args.nblocks, args.blocksize + 1, world),
-                       "kkt_dim": ks.N, "nnz_triu_K": ks.nnzK, "nnz_L": int(info.nnzL), "etree_levels": int(info.n_levels),
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "kkt_dim": ks.N * world if workload == "c4" else ks.N,
+                       "kkt_dim_per_gpu": ks.N, "nnz_triu_K": ks.nnzK, "nnz_L": int(info.nnzL),
+                       "etree_levels": int(info.n_levels),
                        "per_step": "1 update(scaling+Hs+static reg+refactor) + 3 solves x (LDL solve + 1 IR round)",
                        "ir_rounds": int(ir), "setup_s": round(t_setup, 2),
-                       "collective": "all_gather(step direction) x3/step over RCCL" if world > 1 else "none"},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "gpus_on_problem": int(info.threads) if world == 1 else world,
+                       "collective": ("3 x all-gather of the step direction per step, native RCCL (ncclAllGather fp64, %d doubles) "
+                                      "on its own stream, event-ordered" % int(sum(counts))) if world > 1 else "none"},
+            "roofline": roof, "parity": parity, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt, "batched_c4": c4,
         }
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
-
-
-def cpu_baseline(pr, ks, args):
-    """the CPU oracle (C restatement of the reference qdldl path, 1 thread -- the reference
-    engine reports threads: 1, ldlsolvers/qdldl.rs:68) on the SAME workload and permutation,
-    bounded to ~10-30 s of CPU work."""
-    from oracle import oracle as orc
-    ost = orc.Settings.default()
-    ost.ir_max_iter = 1
-    ost.ir_reltol = 0.0
-    ost.ir_abstol = 0.0
-    cones = orc.Cones(pr["cones"])
-    ko = orc.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones, settings=ost, perm=ks.perm)
-    rng = np.random.default_rng(99)
-    rhs = [(rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])) for _ in range(3)]
-
-    def step():
-        cones.update_scaling(pr["s"], pr["z"])
-        assert ko.update()
-        for rx, rz in rhs:
-            ko.setrhs(rx, rz)
-            ok, _, _ = ko.solve()
-            assert ok
-
-    t0 = time.perf_counter()
-    step()
-    t1 = time.perf_counter() - t0
-    nsteps = args.cpu_steps if args.cpu_steps > 0 else max(2, min(200, int(15.0 / max(t1, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(nsteps):
-        step()
-    el = time.perf_counter() - t0
-    return {"value": round(nsteps / el, 4), "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": "%d full steps of the same workload (n=%d) on 1 host core, oracle/ C restatement of "
-                      "src/qdldl + DirectLDLKKTSolver, same permutation; host has %d cores"
-                      % (nsteps, pr["n"], os.cpu_count() or 0)}
+    if comm is not None:
+        comm.synchronize()
+        comm.barrier()
 
 
 if __name__ == "__main__":

@@ -653,6 +653,61 @@ class HipKKTSystem:
 
 
 # ---------------------------------------------------------------------------
+# sharded path: RCCL communicator of the C ABI (csrc/comm.cpp)
+# ---------------------------------------------------------------------------
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """rank 0: the rendezvous token to hand to the other ranks out of band (bytes)"""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().chip_comm_get_unique_id(buf), "chip_comm_get_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """one per process / GPU; collective construction over all ranks"""
+
+    def __init__(self, unique_id, world, rank, device=-1):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().chip_comm_create(C.byref(self._h), buf, C.c_int32(world), C.c_int32(rank), C.c_int32(device)),
+               "chip_comm_create")
+        self.world, self.rank = world, rank
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().chip_comm_destroy(self._h)
+            self._h = None
+
+    def attach(self, kkt):
+        _check(lib().chip_kkt_attach_comm(kkt._h, self._h), "attach_comm")
+
+    def allgather_step(self, kkt, send_ptr, recv_ptr, counts):
+        cnt = np.ascontiguousarray(counts, dtype=np.int64)
+        assert len(cnt) == self.world
+        _check(lib().chip_kkt_allgather_step(kkt._h, self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr),
+                                             cnt.ctypes.data_as(P_I64)), "allgather_step")
+
+    def wait(self, kkt):
+        """kkt's stream waits on the device for the last all-gather"""
+        _check(lib().chip_kkt_wait_comm(kkt._h, self._h), "wait_comm")
+
+    def synchronize(self):
+        _check(lib().chip_comm_synchronize(self._h), "comm_synchronize")
+
+    def allreduce(self, vals, op="sum"):
+        v = np.ascontiguousarray(np.atleast_1d(vals), dtype=np.float64).copy()
+        _check(lib().chip_comm_allreduce(self._h, _pf(v), C.c_int32(len(v)), C.c_int32({"sum": 0, "min": 1, "max": 2}[op])),
+               "comm_allreduce")
+        return v
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+
+# ---------------------------------------------------------------------------
 # raw HBM buffers without torch (tests / single-GPU bench plumbing): thin ctypes
 # calls into the SAME libamdhip64 instance the extension is linked against.
 # NB when torch is used in the process, import torch BEFORE this package so that
@@ -715,6 +770,13 @@ class DeviceArray:
             except Exception:
                 pass
             self._p = C.c_void_p()
+
+
+def set_device(ordinal):
+    """hipSetDevice for this thread (one process per GPU: the rank's local device)"""
+    rc = _hiprt().hipSetDevice(C.c_int(int(ordinal)))
+    if rc != 0:
+        raise RuntimeError("hipSetDevice(%d) failed: %d" % (ordinal, rc))
 
 
 def device_synchronize():

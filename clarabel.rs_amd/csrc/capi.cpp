@@ -80,6 +80,7 @@ struct chip_kkt {
     double last_eps = 0;
     bool scaling_pending_check = false;
     bool x_holds_b = false; // x was initialised with the rhs by setrhs (skips a D2D copy)
+    int world = 1;               // ranks sharing the problem (chip_kkt_attach_comm)
     double *d_partial = nullptr; // per-block partial minima / sums of the cone reductions
     int partial_cap = 0;
     std::vector<double> h_partial;
@@ -218,6 +219,8 @@ int32_t chip_ldl_set_values(chip_ldl *h, const double *kkt_nzval) {
 extern "C++" {
 namespace chip {
 int kkt_device(const ::chip_kkt *h) { return h->E.device; }
+hipStream_t kkt_stream(::chip_kkt *h) { return h->E.host_only ? nullptr : h->E.stream; }
+void kkt_set_world(::chip_kkt *h, int world) { h->world = world; }
 bool kkt_host_only(const ::chip_kkt *h) { return h->E.host_only; }
 } // namespace chip
 }
@@ -1102,6 +1105,7 @@ int32_t chip_kkt_margins_dev(chip_kkt *h, const double *z_dev, double *alpha_out
 int32_t chip_kkt_info(const chip_kkt *h, chip_info *info) {
     if (!h || !info) return CHIP_ERR_ARG;
     fill_info(h->E, info);
+    info->threads = h->world;
     info->last_ir_iterations = h->last_ir;
     info->last_regularizer = h->last_eps;
     if (h->E.factored && !h->E.host_only) {

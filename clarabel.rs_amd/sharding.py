@@ -60,6 +60,20 @@ class ShardLayout:
         return np.concatenate(xs + zs) if xs else np.zeros(0, dtype=np.int64)
 
 
+def _global_index_packed(self):
+    """the same for an UNPADDED gather (chip_kkt_allgather_step with ragged counts): rank r's
+    [x_r, z_r] starts at sum(len_rank[:r])"""
+    xs, zs, base = [], [], 0
+    for r in range(self.world):
+        xs.append(base + np.arange(self.n_rank[r]))
+        zs.append(base + self.n_rank[r] + np.arange(self.m_rank[r]))
+        base += self.len_rank[r]
+    return np.concatenate(xs + zs) if xs else np.zeros(0, dtype=np.int64)
+
+
+ShardLayout.global_index_packed = _global_index_packed
+
+
 def all_gather_step(local_lhs, layout, dist, out=None, index=None):
     """all-gather of the local [dx_r, dz_r] (torch tensor, length <= layout.maxlen) into the
     global [dx, dz].  `dist` is torch.distributed (initialised by the caller)."""

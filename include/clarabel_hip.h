@@ -96,7 +96,7 @@ typedef struct {
  * (qdldl.rs:104-112, 203-210). */
 typedef struct {
     char name[16];             /* "hip" */
-    int64_t threads;           /* reported as #GPUs driven by this handle (1) */
+    int64_t threads;           /* #GPUs working on the problem: 1, or the world size after chip_kkt_attach_comm */
     int32_t direct;            /* 1 */
     int64_t nnzA;              /* nnz(triu K) */
     int64_t nnzL;              /* nnz(L), strictly lower */
@@ -403,6 +403,39 @@ int32_t chip_variables_rescale(chip_kktsystem *h, chip_vars *variables);
  * DefaultInfo::update reads, default/info.rs:142-165, with identity equilibration) */
 int32_t chip_vec_norms(chip_kktsystem *h, int32_t count, const double *const *vecs_dev, const int64_t *lens,
                        double *out);
+
+/* ===========================================================================
+ * Sharded path: one process per GPU, whole connected components of the elimination
+ * forest per rank (BASELINE config 4: 1024 independent SOCPs, 128 per GPU at 8 GPUs).  Factorisation,
+ * substitutions and refinement of a rank's blocks need no exchange; the exchange step is ONE RCCL
+ * all-gather of the step direction per KKT solve over xGMI, plus scalar reductions.  The reference has
+ * no distributed mode: these entry points have no reference counterpart; the
+ * reference-side caller is the loop of core/solver.rs:282-434, which consumes the full (dx, dz) and the
+ * scalars tau, kappa, mu, alpha.
+ * ===========================================================================*/
+typedef struct chip_comm chip_comm;
+#define CHIP_COMM_ID_BYTES 128
+/* rank 0 creates the rendezvous token (ncclGetUniqueId) and hands it to the other ranks by any
+ * out-of-band channel (file, socket, MPI): the library opens no sockets of its own */
+int32_t chip_comm_get_unique_id(uint8_t id[CHIP_COMM_ID_BYTES]);
+/* collective over all `world` ranks (ncclCommInitRank); device: HIP ordinal, -1 = current */
+int32_t chip_comm_create(chip_comm **out, const uint8_t id[CHIP_COMM_ID_BYTES], int32_t world, int32_t rank,
+                         int32_t device);
+void chip_comm_destroy(chip_comm *c);
+int32_t chip_comm_info(const chip_comm *c, int32_t *world, int32_t *rank);
+/* LinearSolverInfo.threads of the handle then reports the number of GPUs working on the problem */
+int32_t chip_kkt_attach_comm(chip_kkt *h, chip_comm *c);
+/* all-gather of the step direction: recv_dev[sum(counts[<r]) ..] <- rank r's send_dev[0 .. counts[r])
+ * (counts: `world` entries, host).  Enqueued on the communicator's stream behind the work queued so
+ * far on the handle's stream (event, no host synchronisation); returns immediately. */
+int32_t chip_kkt_allgather_step(chip_kkt *h, chip_comm *c, const double *send_dev, double *recv_dev,
+                                const int64_t *counts);
+/* the handle's stream waits (on the device) for the last chip_kkt_allgather_step -- call before
+ * send_dev / recv_dev are written again */
+int32_t chip_kkt_wait_comm(chip_kkt *h, chip_comm *c);
+int32_t chip_comm_synchronize(chip_comm *c);
+/* in-place all-reduce of up to 64 host scalars; op: 0 = sum, 1 = min, 2 = max.  Blocking. */
+int32_t chip_comm_allreduce(chip_comm *c, double *vals, int32_t count, int32_t op);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,7 @@ struct chip_kkt {
     double last_eps = 0;
     bool scaling_pending_check = false;
     bool x_holds_b = false; // x was initialised with the rhs by setrhs (skips a D2D copy)
+    double static_diag_max = 0.0; // max |P_ii|: the diagonal entries of K that no cone kernel writes
     int world = 1;               // ranks sharing the problem (chip_kkt_attach_comm)
     double *d_partial = nullptr; // per-block partial minima / sums of the cone reductions
     int partial_cap = 0;
@@ -240,8 +241,8 @@ int32_t chip_ldl_refactor(chip_ldl *h) {
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
     if (h->dirty && E.nnzK) {
-        CHIP_HIP(hipMemcpyAsync(E.Kx, h->hK.data(), (size_t)E.nnzK * sizeof(double), hipMemcpyHostToDevice,
-                                E.stream));
+        int rc = E.upload_values(h->hK.data());
+        if (rc) return rc;
         h->dirty = false;
     }
     return E.refactor(false, nullptr);
@@ -315,7 +316,7 @@ int32_t chip_ldl_get_factors(chip_ldl *h, uint64_t *Lp, uint64_t *Li, double *Lx
 // ---------------------------------------------------------------------------
 // L2
 // ---------------------------------------------------------------------------
-static std::vector<int> narrow(const std::vector<i64> &v, size_t n) {
+static std::vector<int> narrow_plain(const std::vector<i64> &v, size_t n) {
     std::vector<int> o(n);
     for (size_t i = 0; i < n; i++) o[i] = (int)v[i];
     return o;
@@ -354,7 +355,27 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     }
     rc = E.init(S, st);
     if (rc) return rc;
-    if (K.nnz) CHIP_HIP(hipMemcpy(E.Kx, K.nzval.data(), (size_t)K.nnz * sizeof(double), hipMemcpyHostToDevice));
+    if (K.nnz) { // the device keeps K.nzval in T order (host.hpp: Symbolic::k2v)
+        std::vector<double> vx((size_t)K.nnz);
+        for (i64 u = 0; u < K.nnz; u++) vx[(size_t)u] = K.nzval[(size_t)S.v2k[(size_t)u]];
+        CHIP_HIP(hipMemcpy(E.Kx, vx.data(), (size_t)K.nnz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // every LDLDataMap index the kernels use is translated ONCE into a position of that store
+    const std::vector<i32> &k2v = S.k2v;
+    auto narrow = [&k2v](const std::vector<i64> &v, size_t cnt) {
+        std::vector<int> o(cnt);
+        for (size_t i = 0; i < cnt; i++) o[i] = k2v[(size_t)v[i]];
+        return o;
+    };
+    {
+        double mx = 0.0; // the part of diag K no cone kernel writes: diag P (kkt_assembly.rs:120-121)
+        for (i64 i = 0; i < K.n; i++) {
+            const double a = K.nzval[(size_t)K.diagP[(size_t)i]];
+            if (a != a) mx = a;
+            else if (mx == mx) mx = std::max(mx, std::fabs(a));
+        }
+        h->static_diag_max = mx;
+    }
 
     // ---- index maps as int32 ------------------------------------------------
     if ((rc = E.upload(&h->mapHs, narrow(K.mapHs, (size_t)K.nHs), (size_t)K.nHs))) return rc;
@@ -402,10 +423,10 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
             gp_state += 6 * c.dim + 4 * c.dim2 + 3;
             gp_mapptr.push_back((int)gp_map.size());
             const i64 sidx = c.sparse_idx;
-            for (i64 k = 0; k < c.dim; k++) gp_map.push_back((int)K.sp_q[K.sp_q_ptr[sidx] + k]);
-            for (i64 k = 0; k < c.dim2; k++) gp_map.push_back((int)K.sp_r[K.sp_r_ptr[sidx] + k]);
-            for (i64 k = 0; k < c.numel; k++) gp_map.push_back((int)K.sp_u[K.sp_ptr[sidx] + k]);
-            for (int k = 0; k < 3; k++) gp_mapD.push_back((int)K.sp_D[3 * sidx + k]);
+            for (i64 k = 0; k < c.dim; k++) gp_map.push_back(k2v[(size_t)K.sp_q[K.sp_q_ptr[sidx] + k]]);
+            for (i64 k = 0; k < c.dim2; k++) gp_map.push_back(k2v[(size_t)K.sp_r[K.sp_r_ptr[sidx] + k]]);
+            for (i64 k = 0; k < c.numel; k++) gp_map.push_back(k2v[(size_t)K.sp_u[K.sp_ptr[sidx] + k]]);
+            for (int k = 0; k < 3; k++) gp_mapD.push_back(k2v[(size_t)K.sp_D[3 * sidx + k]]);
             h->gpw_cone_index.push_back((int)(&c - K.cones.data()));
         } else if (c.tag == CHIP_CONE_PSDTRIANGLE && c.dim <= 64) {
             pd_start.push_back((int)c.start);
@@ -491,12 +512,12 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
         nv.mapHs = h->mapHs;
     }
     const size_t nsp = K.sp_ptr.size() ? K.sp_ptr.size() - 1 : 0;
-    s_ptr = narrow(K.sp_ptr, nsp + 1);
+    s_ptr = narrow_plain(K.sp_ptr, nsp + 1);
     mapU = narrow(K.sp_u, (size_t)(nsp ? K.sp_ptr[nsp] : 0));
     mapV = narrow(K.sp_v, (size_t)(nsp ? K.sp_ptr[nsp] : 0));
     for (size_t s = 0; s < nsp; s++) {
-        mapD.push_back((int)K.sp_D[3 * s]);
-        mapD.push_back((int)K.sp_D[3 * s + 1]);
+        mapD.push_back(k2v[(size_t)K.sp_D[3 * s]]);
+        mapD.push_back(k2v[(size_t)K.sp_D[3 * s + 1]]);
     }
     h->nn_count = (int)nn_rows.size();
     h->zero_count = (int)zero_rows.size();
@@ -684,12 +705,18 @@ int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
                                 (int)c.block_len, -1.0);
         }
     }
-    dev::nn_write_hs(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx);
-    dev::soc_write_kkt(E.stream, h->soc, E.Kx);
+    // static regulariser eps = c + prop * max|diag K| (directldlkktsolver.rs:324-329): with Zero /
+    // Nonnegative / SecondOrder cones only, the kernels that write the diagonal entries leave their maxima in
+    // slots (no pass over the N diagonal entries); other cone kinds take the explicit reduction
+    const bool slot_eps = !(h->has_hostHs || h->ns3.ncones || h->gpw.ncones || h->psd.ncones);
+    unsigned long long *dslots = slot_eps && E.st.static_regularization_enable ? E.diag_slots() : nullptr;
+    dev::nn_write_hs(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx, dslots);
+    dev::soc_write_kkt(E.stream, h->soc, E.Kx, dslots);
     dev::ns3_write_hs(E.stream, h->ns3, E.Kx);
     dev::gpw_write_kkt(E.stream, h->gpw, E.Kx);
     dev::psd_write_hs(E.stream, h->psd, E.Kx);
-    int ok = E.refactor(h->E.st.static_regularization_enable != 0, h->diag_full);
+    int ok = E.refactor(h->E.st.static_regularization_enable != 0, slot_eps ? nullptr : h->diag_full,
+                        h->static_diag_max);
     if (ok < 0) return ok;
     h->last_eps = E.st.static_regularization_enable ? E.mb_host->eps : 0.0;
     if (h->scaling_pending_check) {
@@ -888,7 +915,15 @@ static int update_block(chip_kkt *h, const int *map, const std::vector<i64> &hma
 }
 int32_t chip_kkt_update_P(chip_kkt *h, const double *Pnzval) {
     if (!h || !Pnzval) return CHIP_ERR_ARG;
-    return update_block(h, h->mapP, h->K.mapP, Pnzval, h->K.mapP.size() - 1);
+    int rc = update_block(h, h->mapP, h->K.mapP, Pnzval, h->K.mapP.size() - 1);
+    double mx = 0.0;
+    for (i64 i = 0; i < h->K.n; i++) {
+        const double a = h->K.nzval[(size_t)h->K.diagP[(size_t)i]];
+        if (a != a) mx = a;
+        else if (mx == mx) mx = std::max(mx, std::fabs(a));
+    }
+    h->static_diag_max = mx;
+    return rc;
 }
 int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval) {
     if (!h || !Anzval) return CHIP_ERR_ARG;
@@ -1131,9 +1166,7 @@ int32_t chip_kkt_get_values(chip_kkt *h, double *nzval) {
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
-    CHIP_HIP(hipStreamSynchronize(E.stream));
-    if (E.nnzK) CHIP_HIP(hipMemcpy(nzval, E.Kx, (size_t)E.nnzK * sizeof(double), hipMemcpyDeviceToHost));
-    return CHIP_OK;
+    return E.download_values(nzval); // back in the caller's K.nzval order
 }
 int32_t chip_kkt_synchronize(chip_kkt *h) {
     if (!h) return CHIP_ERR_ARG;

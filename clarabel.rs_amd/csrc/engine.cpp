@@ -155,7 +155,10 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     amd = S.amd;
     int rc;
     const size_t n = (size_t)N;
-    if ((rc = upload(&a2l, S.a2l, (size_t)nnzK))) return rc;
+    nnzU = S.nnzU;
+    if ((rc = upload(&v2l, S.v2l, (size_t)(nnzK - nnzU)))) return rc;
+    h_k2v = S.k2v;
+    h_v2k = S.v2k;
     nfill = (int)S.fill_idx.size();
     if ((rc = upload(&fill_idx, S.fill_idx, S.fill_idx.size()))) return rc;
     if ((rc = upload(&Lp, S.Lp, n + 1))) return rc;
@@ -169,13 +172,11 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = upload(&Sp, S.Sp, n + 1))) return rc;
     if ((rc = upload(&Scol, S.Scol, (size_t)nnzS))) return rc;
     if ((rc = upload(&Smap, S.Smap, (size_t)nnzS))) return rc;
-    nnzU = S.nnzU;
     if ((rc = upload(&Up, S.Up, S.Up.size()))) return rc;
     if ((rc = upload(&Ucol, S.Ucol, (size_t)nnzU))) return rc;
-    if ((rc = upload(&Umap, S.Umap, (size_t)nnzU))) return rc;
-    if ((rc = alloc(&Ux, (size_t)nnzU))) return rc;
     if ((rc = upload(&dsigns, S.dsigns, n))) return rc;
     if ((rc = alloc(&Kx, (size_t)nnzK))) return rc;
+    Ux = Kx; // the U rows are the head of the value store (T order)
     if ((rc = alloc(&Lx, (size_t)nnzL))) return rc;
     if ((rc = alloc(&Rx, (size_t)nnzL))) return rc;
     if ((rc = alloc(&D, n))) return rc;
@@ -275,6 +276,8 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     CHIP_HIP(hipMemset(mb_dev, 0, sizeof(Mailbox)));
     CHIP_HIP(hipHostMalloc((void **)&mb_host, sizeof(Mailbox), hipHostMallocDefault));
     std::memset(mb_host, 0, sizeof(Mailbox));
+    if ((rc = alloc(&dslot_dev, (size_t)NRM_SET_WORDS))) return rc;
+    CHIP_HIP(hipMemset(dslot_dev, 0, (size_t)NRM_SET_WORDS * sizeof(unsigned long long)));
     if ((rc = alloc(&nrm_dev, (size_t)NRM_SETS * NRM_SET_WORDS))) return rc;
     CHIP_HIP(hipMemset(nrm_dev, 0, (size_t)NRM_SETS * NRM_SET_WORDS * sizeof(unsigned long long)));
     CHIP_HIP(hipHostMalloc((void **)&nrm_host, 3 * NRM_SET_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
@@ -299,6 +302,10 @@ dev::LdlView Engine::view() const {
     v.status = mb_dev->status; // address arithmetic only, never dereferenced on the host
     v.reg_eps = st.dynamic_regularization_eps;
     v.reg_delta = st.dynamic_regularization_delta;
+    v.Up = Up;
+    v.Ucol = Ucol;
+    v.Ux = Ux;
+    v.eps_ptr = nullptr;
     return v;
 }
 
@@ -359,15 +366,27 @@ int Engine::read_mailbox() {
 // directldlkktsolver.rs:217-250 is applied while the values are scattered into
 // the factor's storage; Kx itself stays unregularised (that is what the
 // refinement residual must see, :255-261), so nothing has to be "restored".
-int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
-    const dev::LdlView v = view();
+int Engine::refactor(bool static_reg, const int *diag_idx_dev, double static_diag_max) {
+    int rc = refactor_enqueue(static_reg, diag_idx_dev, static_diag_max);
+    if (rc) return rc;
+    return refactor_collect();
+}
+int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double static_diag_max) {
+    dev::LdlView v = view();
     const double *eps_ptr = nullptr;
     if (static_reg) {
-        dev::diag_absmax_eps(stream, Kx, diag_idx_dev, N, st.static_regularization_constant,
-                             st.static_regularization_proportional, (double *)mb_dev);
+        if (diag_idx_dev)
+            dev::diag_absmax_eps(stream, Kx, diag_idx_dev, N, st.static_regularization_constant,
+                                 st.static_regularization_proportional, (double *)mb_dev);
+        else // the cone kernels left the maxima of the diagonal entries they wrote in the slots
+            dev::eps_from_slots(stream, dslot_dev, st.static_regularization_constant,
+                                st.static_regularization_proportional, static_diag_max, (double *)mb_dev);
         eps_ptr = (const double *)mb_dev;
     }
-    dev::scatter_init(stream, Kx, a2l, (int)nnzK, (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
+    v.eps_ptr = eps_ptr;
+    // entries with both ends in the top -> the top columns of L / D; clears the status words.  The bundle
+    // columns take their initial values straight from the U rows inside k_bundle_factor.
+    dev::scatter_init(stream, Kx + nnzU, v2l, (int)(nnzK - nnzU), (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                       mb_dev->status);
     dev::bundle_factor(stream, v, bundles, fold); // everything below the cut: one launch
     const bool top_folded = fold.k == 1; // single top column: pivot accumulated by the bundles
@@ -417,8 +436,10 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev) {
     }
     if (nsn > 0) dev::gather_values(stream, Rfx, Lx, Rf_pos, nRf); // L at the filtered row lists (forward sweep)
     else dev::topblk_build(stream, v, topblk); // inverses of the diagonal blocks of a tall top
-    dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
-    dev::gather_values(stream, Ux, Kx, Umap, (int)nnzU);
+    if (!fold.k) dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS); // full rows of the top for the residual
+    return CHIP_OK;
+}
+int Engine::refactor_collect() {
     int rc = read_mailbox();
     if (rc) return rc;
     // a failed refactor leaves garbage in L / D / Dinv: the handle goes back to "not factored" so that
@@ -544,7 +565,7 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         prof_pair(PF_SYMV_T, &ev0, &ev1);
         dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, fold, ev0, ev1);
-        dev::fold_top_residual(stream, fold, Sx, x, b, e, a.nrm, a.nan);
+        dev::fold_top_residual(stream, fold, Kx, x, b, e, a.nrm, a.nan); // (top-top entries by their position in Kx)
         return;
     }
     const dev::ChunkView bc = smv.B(0);
@@ -577,6 +598,27 @@ int Engine::read_norms(int first, int count, double *out) {
     return CHIP_OK;
 }
 int Engine::read_norm(int set, double *out) { return read_norms(set, 1, out); }
+
+// the caller's K.nzval order -> the device's T order (one staging copy + one gather kernel)
+int Engine::upload_values(const double *host_nzval) {
+    if (!nnzK) return CHIP_OK;
+    int rc;
+    if (!d_v2k) {
+        if ((rc = upload(&d_v2k, h_v2k, (size_t)nnzK))) return rc;
+        if ((rc = alloc(&d_stage, (size_t)nnzK))) return rc;
+    }
+    CHIP_HIP(hipMemcpyAsync(d_stage, host_nzval, (size_t)nnzK * sizeof(double), hipMemcpyHostToDevice, stream));
+    dev::gather_values(stream, Kx, d_stage, d_v2k, (int)nnzK);
+    return CHIP_OK;
+}
+int Engine::download_values(double *host_nzval) {
+    if (!nnzK) return CHIP_OK;
+    std::vector<double> tmp((size_t)nnzK);
+    CHIP_HIP(hipStreamSynchronize(stream));
+    CHIP_HIP(hipMemcpy(tmp.data(), Kx, (size_t)nnzK * sizeof(double), hipMemcpyDeviceToHost));
+    for (i64 p = 0; p < nnzK; p++) host_nzval[p] = tmp[(size_t)h_k2v[(size_t)p]];
+    return CHIP_OK;
+}
 
 // the C ABI layer allocates / uploads these element types through the engine
 template int Engine::alloc<int>(int **, size_t);

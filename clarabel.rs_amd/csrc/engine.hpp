@@ -53,11 +53,16 @@ struct Engine {
     int N = 0, nlevels = 0;
     i64 nnzK = 0, nnzL = 0, nnzS = 0;
     // symbolic (device)
-    int *a2l = nullptr, *Lp = nullptr, *Li = nullptr, *Rp = nullptr, *Rcol = nullptr, *Rpos = nullptr,
+    int *v2l = nullptr, *Lp = nullptr, *Li = nullptr, *Rp = nullptr, *Rcol = nullptr, *Rpos = nullptr,
         *Tpos = nullptr, *perm = nullptr, *iperm = nullptr, *Sp = nullptr, *Scol = nullptr, *Smap = nullptr,
-        *Up = nullptr, *Ucol = nullptr, *Umap = nullptr;
+        *Up = nullptr, *Ucol = nullptr;
     i64 nnzU = 0;
-    double *Ux = nullptr;
+    double *Ux = nullptr; // == Kx: the U rows are the first nnzU entries of the value store
+    // Kx holds the caller's K.nzval in T order V (host.hpp: Symbolic::k2v): h_k2v[p] = position of K.nzval[p];
+    // d_v2k (device, allocated on first use) serves wholesale uploads in the caller's order (L1 boundary)
+    std::vector<i32> h_k2v, h_v2k;
+    int *d_v2k = nullptr;
+    double *d_stage = nullptr;
     int8_t *dsigns = nullptr;
     // values (device)
     double *Kx = nullptr, *Lx = nullptr, *Rx = nullptr, *D = nullptr, *Dinv = nullptr, *Sx = nullptr;
@@ -114,8 +119,18 @@ struct Engine {
     dev::LdlView view() const;
     // enqueue: (optional static regularisation) -> scatter -> level-scheduled factor
     // -> refresh of the symv values; then reads the status mailbox (one sync).
-    // returns 1 ok / 0 numerical failure / <0 error
-    int refactor(bool static_reg, const int *diag_idx_dev);
+    // returns 1 ok / 0 numerical failure / <0 error.  static_reg: eps = c + prop * max|diag K| where the
+    // maximum over the diagonal is either reduced here (diag_idx_dev = positions of the N diagonal entries in
+    // Kx) or, with diag_idx_dev == nullptr, taken from the slotted maxima the cone kernels left in
+    // diag_slots() combined with static_diag_max (the part of the diagonal no cone kernel writes)
+    int refactor(bool static_reg, const int *diag_idx_dev, double static_diag_max = 0.0);
+    int refactor_enqueue(bool static_reg, const int *diag_idx_dev, double static_diag_max);
+    int refactor_collect();
+    unsigned long long *diag_slots() const { return dslot_dev; }
+    unsigned long long *dslot_dev = nullptr; // NRM_SLOTS slotted maxima of |diag| + one NaN flag line
+    // values in the caller's order <-> the device's T order
+    int upload_values(const double *host_nzval);
+    int download_values(double *host_nzval);
     // xp <- K^-1 xp (permuted numbering); with addv the result is xp <- K^-1 xp + addv
     void enqueue_solve_inplace(double *xp, const double *addv = nullptr);
     void enqueue_solve_direct(double *xp, const double *addv);

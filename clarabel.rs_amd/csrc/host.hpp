@@ -47,10 +47,13 @@ struct Symbolic {
     i64 nnzL = 0;
     std::vector<i32> perm, iperm; // final elimination order (level-major), perm[new] = old
     std::vector<int8_t> dsigns;   // permuted D signs
-    // where each entry of the caller's K.nzval lands: < nnzL -> Lx position
-    // (CSC of L), otherwise nnzL + j -> D[j]
-    std::vector<i32> a2l;
-    // slots of L (CSC positions) that no entry of K maps to: structural fill-in
+    // The device keeps K.nzval in "T order" V: row-wise by the smaller permuted index lo, diagonal first,
+    // then the entries (lo, hi) to ancestors hi ascending.  V[u] = K.nzval[v2k[u]], k2v its inverse; row lo
+    // owns V[Vp[lo] .. Vp[lo+1]).  Rows lo < NF (bundle nodes) are the U rows below; for the rows of the top
+    // v2l[u - Vp[NF]] says where V[u] lands in the factor's storage: < nnzL -> Lx position (CSC of L),
+    // otherwise nnzL + j -> D[j].
+    std::vector<i32> k2v, v2k, Vp, v2l;
+    // slots of L in TOP columns (CSC positions) that no entry of K maps to: structural fill-in
     std::vector<i32> fill_idx;
     // L, CSC with ascending rows (structure only; values live on the device)
     std::vector<i32> Lp, Li;
@@ -84,7 +87,7 @@ struct Symbolic {
     //   fold_rseg[(b*k + i)*2 + {0,1}] : CSR slots of row NF+i of L whose columns lie in bundle b
     //   fold_tt[i*k + j] (i > j)        : CSC slot of L(NF+i, NF+j), -1 if structurally zero
     //   fold_sp / fold_scol / fold_sslot: per top row the entries of K with both ends in the top
-    //                                     (column index relative to NF, slot in Sx)
+    //                                     (column index relative to NF, position in V)
     i32 nfold = 0;
     std::vector<i32> fold_rseg, fold_tt, fold_sp, fold_scol, fold_sslot;
     std::vector<i32> lvlptr;
@@ -111,14 +114,14 @@ struct Symbolic {
     // k_snode_fwd), bwu = columns of the single top columns (the members' columns: k_snode_bwd)
     LevelLists fwu, bwu;
     LevelLists snx;                             // per unit level: B chunks (b_row = member column, ranges into Rf_*)
-    // K for the residual e = b - K x, permuted numbering; *map = index into the caller's
-    // K.nzval (values are refreshed by a gather at every refactor):
-    //   U : rows i < NF (bundle nodes): diagonal + entries to ancestors, each K entry ONCE
-    //   S : rows i >= NF (top nodes): the full row (both triangles); Sp has N+1 entries,
-    //       empty rows for i < NF
+    // K for the residual e = b - K x, permuted numbering:
+    //   U : rows i < NF (bundle nodes): diagonal + entries to ancestors, each K entry ONCE -- these ARE
+    //       the first nnzU entries of V (no copy)
+    //   S : rows i >= NF (top nodes): the full row (both triangles); Sp has N+1 entries, empty rows for
+    //       i < NF; Smap = position in V (values refreshed by a gather at every refactor)
     i64 nnzS = 0, nnzU = 0;
     std::vector<i32> Sp, Scol, Smap;
-    std::vector<i32> Up, Ucol, Umap;
+    std::vector<i32> Up, Ucol;
     // kernel work lists
     LevelLists fac, fwd, bwd; // factor (by column), forward solve (rows of L), backward (columns)
     LevelLists smv;           // symv: a single pseudo-level over all rows

@@ -168,6 +168,24 @@ __global__ void k_eps_from_max(double c, double prop, unsigned long long *scal) 
     ((double *)scal)[0] = c + prop * m; // directldlkktsolver.rs:324-329
 }
 
+// eps = c + prop * max|diag K| from the slotted maxima the cone kernels accumulated while they wrote
+// their diagonal entries (no pass over the diagonal); clears the slots for the next update
+__global__ void k_eps_from_slots(unsigned long long *slots, double c, double prop, double static_max,
+                                 double *scal) {
+    const int lane = threadIdx.x;
+    unsigned long long *sl = slots + (size_t)lane * NRM_STRIDE;
+    double m = lane < NRM_SLOTS ? __longlong_as_double((long long)*sl) : 0.0;
+    if (lane < NRM_SLOTS) *sl = 0ull;
+    m = wave_max(m);
+    if (lane == 0) {
+        m = fmax(m, static_max);
+        int *nanflag = (int *)(slots + (size_t)NRM_SLOTS * NRM_STRIDE);
+        if (*nanflag || static_max != static_max) m = __longlong_as_double(0x7ff8000000000000ll);
+        *nanflag = 0;
+        scal[0] = c + prop * m; // directldlkktsolver.rs:324-329
+    }
+}
+
 // ---------------------------------------------------------------------------
 // numeric LDL': left-looking by columns, one launch per elimination-tree level
 //
@@ -188,9 +206,21 @@ __device__ __forceinline__ void finish_column_serial(const LdlView &v, int j, in
     }
 }
 
-// one thread factors column j (few contributions, short column)
+// diagonal of bundle column j as the factorisation starts: K_jj (first entry of U row j) shifted by the
+// static regulariser (directldlkktsolver.rs:233-245: +eps where Dsigns = +1, -eps otherwise)
+__device__ __forceinline__ double diag_from_U(const LdlView &v, int j) {
+    const double val = v.Ux[v.Up[j]];
+    if (!v.eps_ptr) return val;
+    const double eps = v.eps_ptr[0];
+    return v.dsigns[j] == 1 ? val + eps : val - eps;
+}
+
+// one thread factors column j (few contributions, short column).  INIT_U: the column's initial values
+// are merged from U row j (its entries to ancestors: a subset of the column's rows, both ascending) --
+// nothing has been scattered into Lx / D beforehand; otherwise they are found in Lx / D.
+template <bool INIT_U>
 __device__ __forceinline__ void factor_col_thread(const LdlView &v, int j) {
-    double d = v.D[j];
+    double d = INIT_U ? diag_from_U(v, j) : v.D[j];
     const int cb = v.Lp[j], ce = v.Lp[j + 1];
     const int rb = v.Rp[j], re = v.Rp[j + 1];
     if (ce - cb <= 4) {
@@ -199,8 +229,29 @@ __device__ __forceinline__ void factor_col_thread(const LdlView &v, int j) {
         const int cn = ce - cb;
         const int r0 = cn > 0 ? v.Li[cb] : -1, r1 = cn > 1 ? v.Li[cb + 1] : -1;
         const int r2 = cn > 2 ? v.Li[cb + 2] : -1;
-        double a0 = cn > 0 ? v.Lx[cb] : 0.0, a1 = cn > 1 ? v.Lx[cb + 1] : 0.0;
-        double a2 = cn > 2 ? v.Lx[cb + 2] : 0.0, a3 = cn > 3 ? v.Lx[cb + 3] : 0.0;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (INIT_U) {
+            const int ub = v.Up[j] + 1, ue = v.Up[j + 1];
+            int hi[4];
+            double hv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hi[q] = ub + q < ue ? v.Ucol[ub + q] : -2;
+                hv[q] = ub + q < ue ? v.Ux[ub + q] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (hi[q] == r0) a0 = hv[q];
+                else if (hi[q] == r1) a1 = hv[q];
+                else if (hi[q] == r2) a2 = hv[q];
+                else if (hi[q] >= 0) a3 = hv[q];
+            }
+        } else {
+            a0 = cn > 0 ? v.Lx[cb] : 0.0;
+            a1 = cn > 1 ? v.Lx[cb + 1] : 0.0;
+            a2 = cn > 2 ? v.Lx[cb + 2] : 0.0;
+            a3 = cn > 3 ? v.Lx[cb + 3] : 0.0;
+        }
         for (int t = rb; t < re; ++t) {
             const int k = v.Rcol[t], p = v.Rpos[t];
             const double ljk = v.Lx[p];
@@ -227,6 +278,15 @@ __device__ __forceinline__ void factor_col_thread(const LdlView &v, int j) {
             }
         return;
     }
+    if (INIT_U) { // merge U row j into the column (slots without an entry of K: fill-in, zero)
+        int u = v.Up[j] + 1;
+        const int ue = v.Up[j + 1];
+        for (int q = cb; q < ce; ++q) {
+            double val = 0.0;
+            if (u < ue && v.Ucol[u] == v.Li[q]) val = v.Ux[u++];
+            v.Lx[q] = val;
+        }
+    }
     for (int t = rb; t < re; ++t) {
         const int k = v.Rcol[t], p = v.Rpos[t];
         const double ljk = v.Lx[p];
@@ -248,7 +308,7 @@ __device__ __forceinline__ void factor_col_thread(const LdlView &v, int j) {
 __global__ __launch_bounds__(WG) void k_factor_T(LdlView v, const int *__restrict__ cols, int count) {
     const int tid = logical_block() * WG + threadIdx.x;
     if (tid >= count) return;
-    factor_col_thread(v, cols[tid]);
+    factor_col_thread<false>(v, cols[tid]);
 }
 
 constexpr int RCAP = 512;      // contributions per flattened batch (scan needs blockDim >= RCAP/2)
@@ -271,6 +331,7 @@ __device__ __forceinline__ int find_row(const int *__restrict__ Li, int lo, int 
 // budget-like separators of block-arrow KKTs) take per-thread register
 // partials + one block reduction instead of hammering 4 LDS addresses.
 // Must be called by all threads of the workgroup; ends un-synchronised.
+template <bool INIT_U>
 __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double *acc, int *rows, int *cst,
                                                  double *cw, int *coff, double *red, double *s_dinv) {
     const int cb = v.Lp[j], cn = v.Lp[j + 1] - cb;
@@ -302,10 +363,19 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
         a3 = block_sum(a3, red);
         dpart = block_sum(dpart, red);
         if (tid == 0) {
-            const double dinv = pivot_rule(v, j, v.D[j] - dpart);
+            const double dinv = pivot_rule(v, j, (INIT_U ? diag_from_U(v, j) : v.D[j]) - dpart);
             const double a[4] = {a0, a1, a2, a3};
+            double k0[4] = {0.0, 0.0, 0.0, 0.0}; // the column's initial values
+            if (INIT_U) {
+                int u = v.Up[j] + 1;
+                const int ue = v.Up[j + 1];
+                for (int q = 0; q < cn; ++q)
+                    if (u < ue && v.Ucol[u] == v.Li[cb + q]) k0[q] = v.Ux[u++];
+            } else {
+                for (int q = 0; q < cn; ++q) k0[q] = v.Lx[cb + q];
+            }
             for (int q = 0; q < cn; ++q) {
-                const double l = (v.Lx[cb + q] - a[q]) * dinv;
+                const double l = (k0[q] - a[q]) * dinv;
                 v.Lx[cb + q] = l;
                 v.Rx[v.Tpos[cb + q]] = l;
             }
@@ -315,10 +385,24 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
     const bool lds = cn <= W_LDS_CAP;
     if (lds)
         for (int q = tid; q < cn; q += blockDim.x) {
-            acc[q] = v.Lx[cb + q];
+            acc[q] = INIT_U ? 0.0 : v.Lx[cb + q];
             rows[q] = v.Li[cb + q];
         }
     __syncthreads();
+    if (INIT_U) { // U row j -> its slots of the column (bundle columns are short: always the LDS path)
+        const int ub = v.Up[j] + 1, ue = v.Up[j + 1];
+        for (int u = ub + tid; u < ue; u += blockDim.x) {
+            const int hi = v.Ucol[u];
+            int l2 = 0, h2 = cn;
+            while (l2 < h2) {
+                const int mid = (l2 + h2) >> 1;
+                if (rows[mid] < hi) l2 = mid + 1;
+                else h2 = mid;
+            }
+            acc[l2] = v.Ux[u];
+        }
+        __syncthreads();
+    }
     if (cn >= 24) {
         // General-fill columns: the contributing columns have long tails of very different
         // lengths.  The (contribution, tail entry) pairs are FLATTENED: per batch of up to RCAP
@@ -394,7 +478,7 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
     }
     if (!lds) __threadfence();
     dpart = block_sum(dpart, red);
-    if (tid == 0) *s_dinv = pivot_rule(v, j, v.D[j] - dpart);
+    if (tid == 0) *s_dinv = pivot_rule(v, j, (INIT_U ? diag_from_U(v, j) : v.D[j]) - dpart);
     __syncthreads();
     const double dinv = *s_dinv;
     for (int q = tid; q < cn; q += blockDim.x) {
@@ -416,7 +500,7 @@ __global__ __launch_bounds__(1024) void k_factor_W(LdlView v, const int *__restr
     __shared__ double red[16];
     __shared__ double s_dinv;
     if ((int)blockIdx.x >= count) return;
-    factor_col_block(v, cols[blockIdx.x], acc, rows, cst, cw, coff, red, &s_dinv);
+    factor_col_block<false>(v, cols[blockIdx.x], acc, rows, cst, cw, coff, red, &s_dinv);
 }
 
 // A run of consecutive NARROW top levels of the factorisation (a chain-like stretch of the
@@ -436,9 +520,9 @@ __global__ __launch_bounds__(1024) void k_factor_chain(LdlView v, const int *__r
     __shared__ double red[16];
     __shared__ double s_dinv;
     for (int l = l0; l < l1; ++l) {
-        for (int i = t_ptr[l] + threadIdx.x; i < t_ptr[l + 1]; i += 1024) factor_col_thread(v, t_idx[i]);
+        for (int i = t_ptr[l] + threadIdx.x; i < t_ptr[l + 1]; i += 1024) factor_col_thread<false>(v, t_idx[i]);
         for (int i = w_ptr[l]; i < w_ptr[l + 1]; ++i) {
-            factor_col_block(v, w_idx[i], acc, rows, cst, cw, coff, red, &s_dinv);
+            factor_col_block<false>(v, w_idx[i], acc, rows, cst, cw, coff, red, &s_dinv);
             __syncthreads();
         }
         __syncthreads(); // level l final and visible workgroup-wide
@@ -486,12 +570,12 @@ __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv,
                 if (slot < FATCAP) fat[slot] = j;
                 else thin = true; // list full: fall back to the serial path (correct, slower)
             }
-            if (thin) factor_col_thread(v, j);
+            if (thin) factor_col_thread<true>(v, j);
         }
         __syncthreads();
         const int nf = min(nfat, FATCAP);
         for (int f = 0; f < nf; ++f) {
-            factor_col_block(v, fat[f], acc, rows, cst, cw, coff, red, &s_dinv);
+            factor_col_block<true>(v, fat[f], acc, rows, cst, cw, coff, red, &s_dinv);
             __syncthreads();
         }
         // level l is final (global writes visible workgroup-wide) before level l+1
@@ -2061,10 +2145,23 @@ __global__ __launch_bounds__(WG) void k_nn_update(const int *__restrict__ rows, 
 __global__ __launch_bounds__(WG) void k_nn_write_hs(const int *__restrict__ rows,
                                                     const int *__restrict__ hsidx, int count,
                                                     const double *__restrict__ w,
-                                                    const int *__restrict__ mapHs, double *Kx) {
+                                                    const int *__restrict__ mapHs, double *Kx,
+                                                    unsigned long long *dslots) {
+    __shared__ double red[16];
+    double mx = 0.0;
+    bool nan = false;
     for (int t = logical_block() * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
         const double wi = w[rows[t]];
-        Kx[mapHs[hsidx[t]]] = -(wi * wi);
+        const double h = wi * wi;
+        Kx[mapHs[hsidx[t]]] = -h;
+        if (h != h) nan = true;
+        else mx = fmax(mx, h);
+    }
+    if (dslots) { // |diag K| of these rows for the static regulariser (directldlkktsolver.rs:324-329)
+        mx = block_max(mx, red);
+        int *nanflag = (int *)(dslots + (size_t)NRM_SLOTS * NRM_STRIDE);
+        if (threadIdx.x == 0) fold_norm(dslots, nanflag, mx, false, blockIdx.x);
+        if (nan) *nanflag = 1;
     }
 }
 
@@ -2160,13 +2257,27 @@ __global__ __launch_bounds__(WG) void k_soc_update_scaling(SocView v, const doub
 
 // get_Hs (socone.rs:217-246) negated, and the sparse expansion columns
 // (datamaps.rs:199-220): u, v scaled by -eta^2, D = [-eta^2, +eta^2].
-__global__ __launch_bounds__(WG) void k_soc_write_kkt(SocView v, double *Kx) {
+__global__ __launch_bounds__(WG) void k_soc_write_kkt(SocView v, double *Kx, unsigned long long *dslots) {
     const int c = blockIdx.x;
     if (c >= v.ncones) return;
     const int n = v.dim[c];
     const double *w = v.w + v.start[c];
     const double *st = v.eta + 8 * c;
     const double eta2 = st[0] * st[0];
+    if (dslots && threadIdx.x == 0) {
+        // the diagonal entries this cone writes: sparse form eta^2 d, eta^2 (Hs) and -+eta^2 (D); dense
+        // form the diagonal of eta^2 (2 w w' - J)
+        double mx;
+        if (v.sparse_idx[c] >= 0) {
+            mx = fmax(fabs(eta2 * st[1]), fabs(eta2));
+        } else {
+            const double s2 = 1.4142135623730951;
+            mx = fabs(((s2 * w[0] - 1.0) * (s2 * w[0] + 1.0)) * eta2);
+            for (int col = 1; col < n; ++col) mx = fmax(mx, fabs((2.0 * w[col] * w[col] + 1.0) * eta2));
+        }
+        int *nanflag = (int *)(dslots + (size_t)NRM_SLOTS * NRM_STRIDE);
+        fold_norm(dslots, nanflag, mx != mx ? 0.0 : mx, mx != mx, c);
+    }
     const int *mh = v.mapHs + v.hs_start[c];
     const int sidx = v.sparse_idx[c];
     if (sidx >= 0) {
@@ -3751,6 +3862,11 @@ void diag_absmax_eps(hipStream_t s, const double *Kx, const int *didx, int N, do
     k_eps_from_max<<<1, 1, 0, s>>>(c, prop, (unsigned long long *)scal);
 }
 
+void eps_from_slots(hipStream_t s, unsigned long long *slots, double c, double prop, double static_max,
+                    double *scal) {
+    k_eps_from_slots<<<1, 64, 0, s>>>(slots, c, prop, static_max, scal);
+}
+
 void factor_T(hipStream_t s, const LdlView &v, ListView c) {
     if (c.count) k_factor_T<<<grid_for(c.count), WG, 0, s>>>(v, c.idx, c.count);
 }
@@ -3975,14 +4091,14 @@ void nn_update(hipStream_t s, const int *rows, const int *hsidx, int count, cons
     if (count) k_nn_update<<<stream_grid(count), WG, 0, s>>>(rows, count, sv, zv, w, lam);
 }
 void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, const double *w,
-                 const int *mapHs, double *Kx) {
-    if (count) k_nn_write_hs<<<stream_grid(count), WG, 0, s>>>(rows, hsidx, count, w, mapHs, Kx);
+                 const int *mapHs, double *Kx, unsigned long long *dslots) {
+    if (count) k_nn_write_hs<<<stream_grid(count), WG, 0, s>>>(rows, hsidx, count, w, mapHs, Kx, dslots);
 }
 void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv) {
     if (v.ncones) k_soc_update_scaling<<<v.ncones, WG, 0, s>>>(v, sv, zv);
 }
-void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx) {
-    if (v.ncones) k_soc_write_kkt<<<v.ncones, WG, 0, s>>>(v, Kx);
+void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx, unsigned long long *dslots) {
+    if (v.ncones) k_soc_write_kkt<<<v.ncones, WG, 0, s>>>(v, Kx, dslots);
 }
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv) {
     if (!v.ncones) return;

@@ -19,6 +19,11 @@ struct LdlView {
     const int8_t *dsigns;
     int *status; // [0]=non-finite pivot seen, [1]=zero pivot seen, [2]=regularize_count, [3]=positive inertia
     double reg_eps, reg_delta;
+    // K by rows of the smaller index for the bundle nodes (row i = diagonal first, then the entries to
+    // ancestors ascending): the bundle factorisation takes the initial values of column i from here
+    const int *Up, *Ucol;
+    const double *Ux;
+    const double *eps_ptr; // static regulariser (device scalar) applied to the diagonal while it is read; nullptr: none
 };
 
 // subtree bundles: bundle b = nodes [bundle_ptr[b], bundle_ptr[b+1]); its level boundaries are
@@ -66,9 +71,14 @@ struct ChunkView {
 // ---- value plumbing -----------------------------------------------------------
 // fill_idx: the slots of L that no entry of K maps to (structural fill-in) -- zeroed here,
 // so no memset of the whole factor is needed; status (4 ints) is cleared by the same launch.
+// (the entries with both ends in the top: Kx + nnzU, v2l, count = nnzK - nnzU)
 void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int nnzL, double *Lx,
                   double *D, const int8_t *dsigns, const double *eps_or_null, const int *fill_idx,
                   int nfill, int *status);
+// eps = c + prop * max(static_max, slotted maxima of |diag K| left by the cone kernels); the slots are
+// cleared for the next update.  scal[0] = eps out.
+void eps_from_slots(hipStream_t s, unsigned long long *slots, double c, double prop, double static_max,
+                    double *scal);
 void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap, int nnzS);
 void diag_absmax_eps(hipStream_t s, const double *Kx, const int *diag_idx, int N, double c,
                      double prop, double *scal /*[0]=eps out, uses [1] as scratch*/);
@@ -243,10 +253,12 @@ void ns3_write_hs(hipStream_t s, const Ns3View &v, double *Kx);
 void ns3_mul_hs(hipStream_t s, const Ns3View &v, double *y, const double *x);
 void nn_update(hipStream_t s, const int *rows, const int *hsidx, int count, const double *sv,
                const double *zv, double *w, double *lam);
+// dslots (may be nullptr): slotted maxima of |diagonal entries written| for the static regulariser
+// (NRM_SLOTS words of stride NRM_STRIDE + one NaN flag word at NRM_SLOTS * NRM_STRIDE)
 void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, const double *w,
-                 const int *mapHs, double *Kx);
+                 const int *mapHs, double *Kx, unsigned long long *dslots);
 void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv);
-void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx);
+void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx, unsigned long long *dslots);
 // step / rhs operations of the symmetric cones (Zero rows, Nonnegative rows, SecondOrder cones)
 // Exponential / Power cones either side of the solve (expcone.rs:129-181, powcone.rs:128-180)
 void ns3_affine_ds(hipStream_t s, const Ns3View &v, double *ds, const double *sv);

@@ -531,35 +531,47 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
                     const i32 t = nx[Thi[u]]++;
                     C2lo[t] = lo;
-                    C2src[t] = Tsrc[u];
+                    C2src[t] = u; // position in V (T order)
                 }
         }
     }
-    // ---- K.nzval -> (Lx | D) scatter map: merge of row lo of T with column lo of L ----------
-    S.a2l.resize((size_t)nnzK + 1);
-    std::vector<char> covered((size_t)nnzL + 1, 0);
-    for (i32 lo = 0; lo < n; lo++) {
-        i32 q = S.Lp[lo];
-        const i32 qe = S.Lp[lo + 1];
-        for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
-            const i32 hi = Thi[u];
-            if (hi == lo) {
-                S.a2l[Tsrc[u]] = (i32)(nnzL + lo);
-                continue;
+    // ---- the device's value store V = K.nzval in T order (row-wise by the smaller permuted index,
+    //      diagonal first, ancestors ascending): V[u] = K.nzval[Tsrc[u]].  Rows lo < NF of V are the U
+    //      rows the bundle kernels stream (residual AND the initial values of the bundle columns of the
+    //      factorisation); rows lo >= NF (entries with both ends in the top) are scattered into the top
+    //      columns of L by v2l: merge of row lo of T with column lo of L ----------
+    S.k2v.resize((size_t)nnzK + 1);
+    for (i64 u = 0; u < nnzK; u++) S.k2v[Tsrc[u]] = (i32)u;
+    S.v2k.assign(Tsrc.begin(), Tsrc.begin() + nnzK);
+    S.Vp = Tp;
+    {
+        const i32 NFi = S.NF;
+        const i32 u0 = Tp[NFi];
+        S.v2l.resize((size_t)(nnzK - u0) + 1);
+        std::vector<char> covered((size_t)nnzL + 1, 0);
+        for (i32 lo = 0; lo < n; lo++) {
+            i32 q = S.Lp[lo];
+            const i32 qe = S.Lp[lo + 1];
+            for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
+                const i32 hi = Thi[u];
+                if (hi == lo) {
+                    if (lo >= NFi) S.v2l[u - u0] = (i32)(nnzL + lo);
+                    continue;
+                }
+                while (q < qe && S.Li[q] < hi) q++;
+                if (q >= qe || S.Li[q] != hi) {
+                    set_error("internal: K entry missing from the pattern of L");
+                    return -9;
+                }
+                if (lo >= NFi) S.v2l[u - u0] = q;
+                covered[q] = 1;
             }
-            while (q < qe && S.Li[q] < hi) q++;
-            if (q >= qe || S.Li[q] != hi) {
-                set_error("internal: K entry missing from the pattern of L");
-                return -9;
-            }
-            S.a2l[Tsrc[u]] = q;
-            covered[q] = 1;
         }
+        // fill slots of the TOP columns (the bundle kernels zero their own while they merge the U rows)
+        for (i64 q = S.Lp[NFi]; q < nnzL; q++)
+            if (!covered[q]) S.fill_idx.push_back((i32)q);
     }
-    for (i64 q = 0; q < nnzL; q++)
-        if (!covered[q]) S.fill_idx.push_back((i32)q);
-    std::vector<char>().swap(covered);
-    clk("a2l map, fill slots");
+    clk("v2l map, fill slots");
     // ---- K for the refinement residual e = b - K x (permuted numbering) ------
     // Every nonzero K_ij (i < j in the final numbering) joins a node to one of its ANCESTORS,
     // so i and j are in the same bundle or j is a top node.  Bundle rows therefore use the
@@ -572,9 +584,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         S.Up.assign(Tp.begin(), Tp.begin() + NFi + 1);
         S.nnzU = S.Up[NFi];
         S.Ucol.assign(Thi.begin(), Thi.begin() + S.nnzU);
-        S.Umap.assign(Tsrc.begin(), Tsrc.begin() + S.nnzU);
         S.Ucol.push_back(0);
-        S.Umap.push_back(0);
         // S: full rows r >= NF = column r of C2 (lo <= r ascending, diagonal last) then row r of T without its diagonal
         S.Sp.assign((size_t)n + 1, 0);
         for (i32 r = NFi; r < n; r++) {
@@ -595,7 +605,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             for (i32 u = Tp[r]; u < Tp[r + 1]; u++)
                 if (Thi[u] != r) {
                     S.Scol[o] = Thi[u];
-                    S.Smap[o++] = Tsrc[u];
+                    S.Smap[o++] = u;
                 }
         }
     }
@@ -626,7 +636,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 for (i32 t = S.Sp[r]; t < S.Sp[r + 1]; t++)
                     if (S.Scol[t] >= S.NF) {
                         S.fold_scol.push_back(S.Scol[t] - S.NF);
-                        S.fold_sslot.push_back(t);
+                        S.fold_sslot.push_back(S.Smap[t]); // position in V
                     }
                 S.fold_sp[i + 1] = (i32)S.fold_scol.size();
             }

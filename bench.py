@@ -85,22 +85,26 @@ class Workload:
         self.n, self.m = n, m
 
     def step(self, comm=None, gathered=None, counts=None):
+        # one interior-point iteration's KKT work is ENQUEUED as a whole; the reference's bools (update:
+        # pivots finite and cones interior; solve: refinement residuals finite) are produced on the device
+        # and collected with one synchronisation at the end of the step
         ks = self.ks
         ks.update_scaling_dev(self.s_d.ptr, self.z_d.ptr)
-        if not ks.update():
-            raise RuntimeError("KKT update failed")
+        ks.update_enqueue()
         for k, (rx, rz) in enumerate(self.rhs):
             if comm is not None:
                 # lhs[k] / gathered[k] were handed to the all-gather one step ago: this stream waits
                 # for it ON THE DEVICE (no host synchronisation) before overwriting them
                 comm.wait(ks)
             ks.setrhs_dev(rx.ptr, rz.ptr)
-            if not ks.solve_dev(self.lhs[k].ptr, self.lhs[k].ptr + 8 * self.n):
-                raise RuntimeError("KKT solve failed")
+            ks.solve_dev_enqueue(self.lhs[k].ptr, self.lhs[k].ptr + 8 * self.n)
             if comm is not None:
                 # every rank ends up with the full step direction (dx, dz): RCCL all-gather over xGMI,
                 # enqueued behind this solve by an event and left running behind the next solve
                 comm.allgather_step(ks, self.lhs[k].ptr, gathered[k].ptr, counts)
+        uok, sok = ks.collect()
+        if not uok or len(sok) != len(self.rhs) or not all(sok):
+            raise RuntimeError("KKT step failed: update %s, solves %s" % (uok, sok))
 
     def run(self, steps, warmup, profile_family=0, comm=None, gathered=None, counts=None):
         def sync():
@@ -258,8 +262,9 @@ def main():
     ap.add_argument("--nbatch", type=int, default=1024, help="c4: independent SOCPs (default: config 4)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1 auto, 0 off)")
     ap.add_argument("--no-extras", action="store_true", help="skip parity / cpu legs / batched_c4 (profiling runs)")
-    ap.add_argument("--profile-family", type=int, default=1,
-                    help="kernel family timed with hipEvents for the roofline (1 = k_bundle_symv)")
+    ap.add_argument("--profile-family", type=int, default=5,
+                    help="kernel family timed with hipEvents for the roofline (5 = k_bundle_ir, the fused solve + "
+                         "refinement launch; 6 = k_bundle_factor; 1 = k_bundle_symv on the one-kernel-per-phase path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -311,10 +316,16 @@ def main():
         Bm = algorithmic_bytes(ks.N * world, ks.nnzK * world, info.nnzL * world, ks.nHs * world, m * world)
         # family 1 = the dominant kernel: residual of all bundle rows, K stored once (U):
         # 12 B per streamed K entry + 24 B per row (x, b read; e written)
-        fam_bytes = {1: 12 * ks.nnzU + 24 * ks.NF}.get(args.profile_family)
+        # family 5 = the fused launch: (r + 1) LDL' solves + (r + 1) residuals of SURVEY 8(d)'s per-unit figures
+        Bu = algorithmic_bytes(ks.N, ks.nnzK, info.nnzL, ks.nHs, m)
+        fam_bytes = {1: 12 * ks.nnzU + 24 * ks.NF, 5: (int(ir) + 1) * (Bu["solve"] + Bu["symv"]),
+                     6: Bu["factor"]}.get(args.profile_family)
         fam_name = {1: "k_bundle_symv (residual e = b - Kx over the %d bundle rows, ||e||inf folded in)" % ks.NF,
                     2: "k_gather_merged<1> (BWD top levels)", 3: "k_gather_merged<0> (FWD top levels)",
-                    4: "k_factor_T"}.get(args.profile_family, "?")
+                    4: "k_factor_T",
+                    5: "k_bundle_ir (one launch = setrhs + %d x (LDL' solve + residual) + refinement decisions + getlhs; "
+                       "algorithmic bytes = %d x (B_solve + B_symv))" % (int(ir) + 1, int(ir) + 1),
+                    6: "k_bundle_factor (numeric LDL' of all bundle columns)"}.get(args.profile_family, "?")
         # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> tools/pmc_summarize.py ->
         # profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, see that script).  PMC counters cannot be
         # collected from inside the timed run: the committed summary of the same command is QUOTED (with the
@@ -323,8 +334,9 @@ def main():
         try:
             import glob
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            if pj and workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000 and args.profile_family == 1:
-                traffic = json.load(open(pj[-1]))["kernels"]["k_bundle_symv"]["hbm_bytes"]
+            kname = {1: "k_bundle_symv", 5: "k_bundle_ir", 6: "k_bundle_factor"}.get(args.profile_family)
+            if pj and kname and workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000:
+                traffic = json.load(open(pj[-1]))["kernels"][kname]["hbm_bytes"]
                 traffic_src = os.path.basename(pj[-1])
         except Exception:
             traffic = None

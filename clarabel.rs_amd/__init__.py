@@ -495,6 +495,21 @@ class HipKKTSolver:
     def synchronize(self):
         _check(lib().chip_kkt_synchronize(self._h), "synchronize")
 
+    # -- asynchronous variants: enqueue a whole iteration, collect the verdicts once ------------------
+    def update_enqueue(self, hsblocks=None):
+        hb = None if hsblocks is None else _f(hsblocks)
+        _check(lib().chip_kkt_update_enqueue(self._h, None if hb is None else _pf(hb)), "update_enqueue")
+
+    def solve_dev_enqueue(self, x_ptr, z_ptr):
+        _check(lib().chip_kkt_solve_dev_enqueue(self._h, C.c_void_p(x_ptr), C.c_void_p(z_ptr)), "solve_dev_enqueue")
+
+    def collect(self):
+        """-> (update_ok, [solve_ok, ...]) of everything enqueued since the last collect; one synchronisation"""
+        uok, n = C.c_int32(1), C.c_int32(0)
+        sok = (C.c_int32 * 16)()
+        _check(lib().chip_kkt_collect(self._h, C.byref(uok), C.byref(n), sok), "collect")
+        return bool(uok.value), [bool(sok[i]) for i in range(min(n.value, 16))]
+
     def set_settings(self, settings):
         """the reference passes `settings` to update() / solve() on every call (kktsolvers/mod.rs:7-18)"""
         _check(lib().chip_kkt_set_settings(self._h, C.byref(settings)), "set_settings")

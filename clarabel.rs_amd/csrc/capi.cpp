@@ -4,6 +4,8 @@
 //                 (quasidef/directldlkktsolver.rs:18-405), device resident
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -81,6 +83,13 @@ struct chip_kkt {
     bool scaling_pending_check = false;
     bool x_holds_b = false; // x was initialised with the rhs by setrhs (skips a D2D copy)
     double static_diag_max = 0.0; // max |P_ii|: the diagonal entries of K that no cone kernel writes
+    // fused solve path (Engine::ir_fused): setrhs only notes the caller's device buffers, the solve kernel
+    // permutes them in; results of enqueued solves / updates not yet collected
+    const double *rhs_x = nullptr, *rhs_z = nullptr;
+    bool rhs_deferred = false;
+    int pend_update = 0;             // 1: an update has been enqueued and its verdict not read; 2: read, kept
+    int pend_update_ok = 1;
+    std::vector<int> pend_slots;     // ring slots of the solves enqueued since the last collect
     int world = 1;               // ranks sharing the problem (chip_kkt_attach_comm)
     double *d_partial = nullptr; // per-block partial minima / sums of the cone reductions
     int partial_cap = 0;
@@ -688,10 +697,8 @@ int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z, d
     return 1;
 }
 
-int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
-    if (!h) return CHIP_ERR_ARG;
+static int update_enqueue(chip_kkt *h, const double *hsblocks_or_null) {
     Engine &E = h->E;
-    NEED_DEVICE(E);
     const KktLayout &K = h->K;
     CHIP_HIP(hipSetDevice(E.device));
     if (h->has_hostHs) {
@@ -715,8 +722,12 @@ int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
     dev::ns3_write_hs(E.stream, h->ns3, E.Kx);
     dev::gpw_write_kkt(E.stream, h->gpw, E.Kx);
     dev::psd_write_hs(E.stream, h->psd, E.Kx);
-    int ok = E.refactor(h->E.st.static_regularization_enable != 0, slot_eps ? nullptr : h->diag_full,
-                        h->static_diag_max);
+    return E.refactor_enqueue(h->E.st.static_regularization_enable != 0, slot_eps ? nullptr : h->diag_full,
+                              h->static_diag_max);
+}
+// the verdict of the last enqueued update, from the mailbox (Engine::refactor_collect has copied it)
+static int update_verdict(chip_kkt *h, int ok) {
+    Engine &E = h->E;
     if (ok < 0) return ok;
     h->last_eps = E.st.static_regularization_enable ? E.mb_host->eps : 0.0;
     if (h->scaling_pending_check) {
@@ -725,12 +736,38 @@ int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
     }
     return ok;
 }
+int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    int rc = update_enqueue(h, hsblocks_or_null);
+    if (rc) return rc;
+    h->pend_update = 0;
+    return update_verdict(h, E.refactor_collect());
+}
+int32_t chip_kkt_update_enqueue(chip_kkt *h, const double *hsblocks_or_null) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    int rc = update_enqueue(h, hsblocks_or_null);
+    if (rc) return rc;
+    h->pend_update = 1;
+    E.factored = true; // provisionally: the verdict arrives with chip_kkt_collect
+    return CHIP_OK;
+}
 
 int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *rhsz_dev) {
     if (!h) return CHIP_ERR_ARG;
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
+    if (E.ir_fused) { // the solve kernel reads (and permutes) the caller's buffers itself, see the header
+        h->rhs_x = rhsx_dev;
+        h->rhs_z = rhsz_dev;
+        h->rhs_deferred = true;
+        h->x_holds_b = true;
+        return CHIP_OK;
+    }
     int rc = E.zero_norm_sets();
     if (rc) return rc;
     // one pass writes the permuted rhs twice: bp (kept for the residuals) and x (solved in
@@ -751,7 +788,7 @@ int32_t chip_kkt_setrhs(chip_kkt *h, const double *rhsx, const double *rhsz) {
     if (m) CHIP_HIP(hipMemcpyAsync(h->d_rhs + n, rhsz, m * sizeof(double), hipMemcpyHostToDevice, E.stream));
     int rc = chip_kkt_setrhs_dev(h, h->d_rhs, h->d_rhs + n);
     if (rc) return rc;
-    CHIP_HIP(hipStreamSynchronize(E.stream)); // the caller may reuse rhsx/rhsz
+    CHIP_HIP(hipStreamSynchronize(E.stream)); // the caller may reuse rhsx/rhsz (they were copied to d_rhs)
     return CHIP_OK;
 }
 
@@ -768,6 +805,13 @@ static int solve_core(chip_kkt *h) {
     if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
     h->last_ir = 0;
     int rc;
+    if (h->rhs_deferred) { // (fused path not taken for this solve: stage the noted right-hand side now)
+        h->rhs_deferred = false;
+        if ((rc = E.zero_norm_sets())) return rc;
+        dev::setrhs_perm(E.stream, h->bp, h->x, h->rhs_x, h->rhs_z, E.perm, (int)h->K.n, (int)h->K.m, E.N,
+                         E.norm_set(0), E.norm_nan(0));
+        h->x_holds_b = true;
+    }
     if (!h->x_holds_b) { // solve() again on the same right-hand side, or a full-N rhs in bp
         if ((rc = E.zero_norm_sets())) return rc;
         CHIP_HIP(hipMemcpyAsync(h->x, h->bp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
@@ -834,16 +878,158 @@ static int solve_core(chip_kkt *h) {
     return 1;
 }
 
+// the whole solve (setrhs permutation, LDL' solve, refinement with its decisions, getlhs) as ONE
+// persistent launch; *slot = where the verdict will appear in the result ring
+static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *slot) {
+    Engine &E = h->E;
+    if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
+    const chip_settings &st = E.st;
+    *slot = E.ir_next;
+    E.ir_next = (E.ir_next + 1) % Engine::IR_RING;
+    dev::IrView ir{};
+    ir.rx = h->rhs_x;
+    ir.rz = h->rhs_z;
+    ir.n = (int)h->K.n;
+    ir.m = (int)h->K.m;
+    ir.N = E.N;
+    ir.perm = E.perm;
+    ir.bp = h->bp;
+    ir.xa = h->x;
+    ir.xb = h->e;
+    ir.ebuf = h->dx;
+    ir.lhsx = lhsx_dev;
+    ir.lhsz = lhsz_dev;
+    ir.part = E.ir_part;
+    ir.ctl = E.ir_ctl;
+    ir.res = E.ir_res + 4 * *slot;
+    ir.abstol = st.iterative_refinement_abstol;
+    ir.reltol = st.iterative_refinement_reltol;
+    ir.stopratio = st.iterative_refinement_stop_ratio;
+    ir.maxiter = st.iterative_refinement_max_iter;
+    ir.ir_enable = st.iterative_refinement_enable;
+    static long long *dbg_dev = nullptr;
+    static const bool dbg_on = std::getenv("CHIP_IR_DEBUG") != nullptr;
+    if (dbg_on && !dbg_dev) {
+        (void)hipMalloc((void **)&dbg_dev, 128 * sizeof(long long));
+    }
+    if (dbg_on) (void)hipMemsetAsync(dbg_dev, 0, 128 * sizeof(long long), E.stream);
+    ir.dbg = dbg_on ? dbg_dev : nullptr;
+    h->rhs_deferred = false;
+    h->x_holds_b = false;
+    E.prof_begin(PF_IR);
+    const int rc = dev::bundle_ir(E.stream, E.view(), E.bundles, E.fold, ir, E.ir_grid);
+    E.prof_end(PF_IR);
+    if (rc) return fail(CHIP_ERR_HIP, hip_err((hipError_t)rc, "k_bundle_ir launch"));
+    if (dbg_on) {
+        long long t[128];
+        (void)hipStreamSynchronize(E.stream);
+        (void)hipMemcpy(t, dbg_dev, sizeof(t), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 2; w++) {
+            std::fprintf(stderr, "k_bundle_ir wg%d phases (us):", w);
+            for (int i = 1; i < 64 && t[64 * w + i]; i++) std::fprintf(stderr, " %.1f", (t[64 * w + i] - t[64 * w + i - 1]) * 0.01);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    return CHIP_OK;
+}
+// verdict of ring slot `slot` (after the stream has been synchronised and the ring copied to the host)
+static int fused_verdict(chip_kkt *h, int slot) {
+    Engine &E = h->E;
+    const int *r = E.ir_res_host + 4 * slot;
+    if (r[2] || r[0] == 0) { // the grid barrier timed out: not all workgroups were resident
+        (void)hipMemsetAsync(E.ir_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int), E.stream);
+        return fail(CHIP_ERR_HIP, "k_bundle_ir: grid barrier timed out");
+    }
+    h->last_ir = r[1];
+    return r[0] > 0 ? 1 : 0;
+}
+static int fused_read_ring(chip_kkt *h) {
+    Engine &E = h->E;
+    CHIP_HIP(hipMemcpyAsync(E.ir_res_host, E.ir_res, (size_t)Engine::IR_RING * 4 * sizeof(int), hipMemcpyDeviceToHost,
+                            E.stream));
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    return CHIP_OK;
+}
+
 int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev, double *lhsz_dev) {
     if (!h) return CHIP_ERR_ARG;
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
+    if (E.ir_fused && h->rhs_deferred && (E.prof_family == PF_NONE || E.prof_family >= PF_IR)) {
+        int slot = 0;
+        int rc = fused_enqueue(h, lhsx_dev, lhsz_dev, &slot);
+        if (rc) return rc;
+        if ((rc = fused_read_ring(h))) return rc;
+        return fused_verdict(h, slot);
+    }
     int ok = solve_core(h);
     if (ok != 1) return ok;
     dev::getlhs_perm(E.stream, lhsx_dev, lhsz_dev, h->x, E.iperm, (int)h->K.n, (int)h->K.m);
     CHIP_HIP(hipGetLastError());
     return 1;
+}
+int32_t chip_kkt_solve_dev_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    if ((int)h->pend_slots.size() >= Engine::IR_RING) return fail(CHIP_ERR_ARG, "solve_dev_enqueue: 16 solves pending, collect first");
+    if (E.ir_fused && h->rhs_deferred && (E.prof_family == PF_NONE || E.prof_family >= PF_IR)) {
+        int slot = 0;
+        int rc = fused_enqueue(h, lhsx_dev, lhsz_dev, &slot);
+        if (rc) return rc;
+        h->pend_slots.push_back(slot);
+        return CHIP_OK;
+    }
+    // no fused launch for this system: the refinement decisions need the host -- a pending update's verdict is
+    // read first (the solve must not run on a failed factorisation), then the solve runs synchronously
+    if (h->pend_update) {
+        h->pend_update = 2; // collected, verdict kept
+        h->pend_update_ok = update_verdict(h, E.refactor_collect());
+        if (h->pend_update_ok != 1) {
+            h->pend_slots.push_back(-1 - 0);
+            return CHIP_OK;
+        }
+    }
+    const int ok = chip_kkt_solve_dev(h, lhsx_dev, lhsz_dev);
+    if (ok < 0) return ok;
+    h->pend_slots.push_back(-1 - ok); // -1 = failed, -2 = succeeded (already known)
+    return CHIP_OK;
+}
+int32_t chip_kkt_collect(chip_kkt *h, int32_t *update_ok, int32_t *nsolves, int32_t solves_ok[16]) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    int rc;
+    int uok = 1;
+    bool ring = false;
+    for (int sl : h->pend_slots) ring = ring || sl >= 0;
+    if (ring) // (queued before the mailbox copy below: ONE synchronisation serves both)
+        CHIP_HIP(hipMemcpyAsync(E.ir_res_host, E.ir_res, (size_t)Engine::IR_RING * 4 * sizeof(int), hipMemcpyDeviceToHost,
+                                E.stream));
+    if (h->pend_update == 1) uok = update_verdict(h, E.refactor_collect());
+    else if (h->pend_update == 2) uok = h->pend_update_ok;
+    else CHIP_HIP(hipStreamSynchronize(E.stream));
+    h->pend_update = 0;
+    if (uok < 0) return uok;
+    if (update_ok) *update_ok = uok;
+    int n = 0;
+    rc = CHIP_OK;
+    for (int sl : h->pend_slots) {
+        int v;
+        if (sl < 0) v = -1 - sl;
+        else {
+            v = fused_verdict(h, sl);
+            if (v < 0) rc = v;
+        }
+        if (solves_ok && n < 16) solves_ok[n] = v > 0 ? 1 : 0;
+        n++;
+    }
+    h->pend_slots.clear();
+    if (nsolves) *nsolves = n;
+    return rc;
 }
 int32_t chip_kkt_solve(chip_kkt *h, double *lhsx, double *lhsz) {
     if (!h) return CHIP_ERR_ARG;

@@ -21,6 +21,7 @@ Engine::~Engine() {
     for (SolveGraph &g : graphs) (void)hipGraphExecDestroy(g.exec);
     for (void *p : allocs) (void)hipFree(p);
     if (mb_host) (void)hipHostFree(mb_host);
+    if (ir_res_host) (void)hipHostFree(ir_res_host);
     if (nrm_host) (void)hipHostFree(nrm_host);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -272,6 +273,20 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         topblk.ys = ysb;
         topblk.counters = cnt;
     }
+    if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || NF == N) &&
+        std::getenv("CHIP_NO_FUSED_IR") == nullptr) {
+        const int cap = dev::bundle_ir_capacity(bundles);
+        if (cap > 0 && (fold.k == 0 || bundles.nb <= cap)) {
+            ir_fused = true;
+            ir_grid = std::min(bundles.nb, cap);
+            if ((rc = alloc(&ir_ctl, (size_t)dev::ir_ctl_ints()))) return rc;
+            CHIP_HIP(hipMemset(ir_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int)));
+            if ((rc = alloc(&ir_res, (size_t)IR_RING * 4))) return rc;
+            CHIP_HIP(hipMemset(ir_res, 0, (size_t)IR_RING * 4 * sizeof(int)));
+            if ((rc = alloc(&ir_part, dev::ir_part_doubles(bundles.nb, fold.k)))) return rc;
+            CHIP_HIP(hipHostMalloc((void **)&ir_res_host, (size_t)IR_RING * 4 * sizeof(int), hipHostMallocDefault));
+        }
+    }
     if ((rc = alloc(&mb_dev, 1))) return rc;
     CHIP_HIP(hipMemset(mb_dev, 0, sizeof(Mailbox)));
     CHIP_HIP(hipHostMalloc((void **)&mb_host, sizeof(Mailbox), hipHostMallocDefault));
@@ -388,7 +403,9 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     // columns take their initial values straight from the U rows inside k_bundle_factor.
     dev::scatter_init(stream, Kx + nnzU, v2l, (int)(nnzK - nnzU), (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                       mb_dev->status);
+    prof_begin(PF_BFACTOR);
     dev::bundle_factor(stream, v, bundles, fold); // everything below the cut: one launch
+    prof_end(PF_BFACTOR);
     const bool top_folded = fold.k == 1; // single top column: pivot accumulated by the bundles
     if (top_folded) dev::fold_top_pivot(stream, v, fold);
     const bool use_chain = std::getenv("CHIP_NO_FACTOR_CHAIN") == nullptr;

@@ -44,7 +44,7 @@ constexpr int NRM_SET_WORDS = (dev::NRM_SLOTS + 1) * dev::NRM_STRIDE;
 static_assert(sizeof(Mailbox) <= 256, "mailbox");
 
 // profile families (hipEvent pairs around each launch of ONE selected family)
-enum ProfFamily { PF_NONE = 0, PF_SYMV_T = 1, PF_BWD_T = 2, PF_FWD_T = 3, PF_FACTOR_T = 4, PF_COUNT };
+enum ProfFamily { PF_NONE = 0, PF_SYMV_T = 1, PF_BWD_T = 2, PF_FWD_T = 3, PF_FACTOR_T = 4, PF_IR = 5, PF_BFACTOR = 6, PF_COUNT };
 
 struct Engine {
     int device = 0;
@@ -100,6 +100,13 @@ struct Engine {
         hipGraphExec_t exec;
     };
     std::vector<SolveGraph> graphs;
+    // fused solve + refinement (dev::bundle_ir): available when the system is subtree bundles plus at most a
+    // folded top, and all its workgroups are co-resident
+    static constexpr int IR_RING = 16; // result quads of the last IR_RING enqueued solves
+    bool ir_fused = false;
+    int ir_grid = 0, ir_next = 0;
+    int *ir_ctl = nullptr, *ir_res = nullptr, *ir_res_host = nullptr;
+    double *ir_part = nullptr;
     // profiling
     int prof_family = PF_NONE;
     std::vector<hipEvent_t> prof_events; // pairs

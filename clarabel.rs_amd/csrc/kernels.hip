@@ -1602,13 +1602,19 @@ __device__ __forceinline__ void lds_scatter_add(double *acc, int tgt, double val
 // fit a CU (two LDS slices of a 3000-node bundle would cap it at three and push the 1000
 // bundles of config 3 into a second round).  Two rows per thread, SSHOT entries of each per shot:
 // rows of <= SSHOT entries cost one round trip.  ||e||inf of the bundle is folded into the slots.
-constexpr int SSHOT = 3; // entries of a row per shot (registers: 2 rows x SSHOT x (index, value, x address))
+constexpr int SSHOT_DEFAULT = 3; // entries of a row per shot (registers: 2 rows x SSHOT x (index, value, x address))
+// FUSED (k_bundle_ir): the bundle id is passed in, x of the top rows comes from LDS (xt), the residual
+// stays in es (e == nullptr) and the bundle's partial results -- ||e||inf of its rows (NaN when it saw one)
+// and its shares of (K x)[top rows] -- are STORED to out_norm / out_share[0..k) instead of being added to
+// shared accumulators: the consumers reduce them in a fixed order after a grid-wide barrier.
+template <bool FUSED = false, int SSHOT = SSHOT_DEFAULT>
 __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int *__restrict__ Up,
                                                  const int *__restrict__ Ucol, const double *__restrict__ Ux,
                                                  const double *x, const double *__restrict__ b, double *e,
                                                  unsigned long long *nrm, int *nanflag, double *es, double *red,
-                                                 const FoldView &fold) {
-    const int bid = blockIdx.x;
+                                                 const FoldView &fold, int bid = blockIdx.x,
+                                                 const double *xt = nullptr, double *out_norm = nullptr,
+                                                 double *out_share = nullptr) {
     const int s0 = bv.bundle_ptr[bid], s1 = bv.bundle_ptr[bid + 1], nloc = s1 - s0;
     const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
     // row pointers of the first sweep are requested BEFORE the b slice is staged
@@ -1657,7 +1663,7 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
                     const int j = jj[u][q];
                     int tgt = -1;
                     if (j >= 0) {
-                        acc[u] += vv[u][q] * x[j];
+                        acc[u] += vv[u][q] * ((FUSED && j >= s1) ? xt[j - fold.NF] : x[j]);
                         if (j < s1) {
                             if (j != s0 + i0 + u * BWG) tgt = j - s0;
                         } else if (fold.k == 1) {
@@ -1683,9 +1689,27 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
     bool nan = false;
     for (int i = threadIdx.x; i < nloc; i += BWG) {
         const double val = es[i];
-        e[s0 + i] = val;
+        if (e) e[s0 + i] = val;
         if (val != val) nan = true;
         else m = fmax(m, fabs(val));
+    }
+    if (FUSED) {
+        m = block_max(m, red);
+        const bool anynan = __syncthreads_or(nan);
+        // (device-coherent stores: read by another workgroup inside the same launch, see ir_arrive_wait)
+        if (threadIdx.x == 0)
+            __hip_atomic_store(out_norm, anynan ? __longlong_as_double(0x7ff8000000000000ll) : m, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (fold.k == 1) {
+            tpart = block_sum(tpart, red);
+            if (threadIdx.x == 0) __hip_atomic_store(out_share, tpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (fold.k > 1) {
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int i = 0; i < fold.k; ++i)
+                    __hip_atomic_store(out_share + i, tacc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
     }
     if (nrm) {
         m = block_max(m, red);
@@ -1756,6 +1780,572 @@ __global__ void k_fold_top_residual(FoldView fold, const double *__restrict__ Sx
     e[fold.NF + i] = val;
     if (nrm) fold_norm(nrm, nanflag, val != val ? 0.0 : fabs(val), val != val, i);
 }
+// ---------------------------------------------------------------------------
+// k_bundle_ir: a WHOLE KKT solve with iterative refinement (directldlkktsolver.rs:168-189, :266-321) in ONE
+// persistent launch, for systems that consist of subtree bundles plus at most TOPFOLD_MAX folded top rows
+// (config 3: 1000 bundles + the budget row; config 4: a forest of bundles, no top).  Per refinement
+// round every workgroup does, for its bundle with the vector slice in LDS throughout:
+//     forward sweep -> [grid barrier: top rows] -> backward sweep -> candidate x (+ dx) -> residual
+//     e = b - K x into the SAME LDS array -> [grid barrier: ||e||inf, top rows of e] -> decision
+// so a solve + r refinement rounds costs 1 launch and no host round trip instead of 6 (r + 1) launches,
+// 4 (r + 1) one-thread kernels and a device-to-host copy of the norms; x never makes the
+// forward -> backward -> residual -> forward trips through HBM, and the right-hand side permutation
+// (setrhs) and the un-permutation of the result (getlhs) happen in the staging pass and the final write.
+// The refinement decisions are taken ON THE DEVICE, identically by every workgroup: each one reduces the
+// bundles' partial norms / top-row shares -- plain stores, read back in a fixed order after the barrier,
+// so the result is run-to-run reproducible -- and evaluates the reference's tests.
+// Requires all workgroups to be co-resident (cooperative launch; the host checks the occupancy) when the
+// top is folded; a forest without top only synchronises for the norms.
+// ---------------------------------------------------------------------------
+// entries per shot of the three phases inside k_bundle_ir: one less than in the stand-alone kernels -- the
+// fused kernel carries ~35 pointers in scalar registers, and what does not fit spills into vector registers
+constexpr int IR_SH_FWD = 3, IR_SH_BWD = 2, IR_SH_SYMV = 3;
+constexpr int IR_FATCAP = 256; // long rows per level handled cooperatively (more: serially, still correct)
+constexpr int IR_NSUB = 32;         // sub-counters / release words of the grid barrier, one 128-byte line each
+constexpr int IR_CTL_INTS = 32 * (1 + 2 * IR_NSUB);
+
+// Grid barrier with a reduction slot: every workgroup ARRIVES (hierarchical counters: ctl[32 (1 + s)] =
+// sub-counter s, ctl[0] = master, all monotonic over the launch and zero at its start); the workgroup
+// whose arrival completes the count is told so (IR_LAST) -- it alone reduces the partial results the
+// others stored before arriving, publishes the few reduced numbers and then RELEASES the barrier by
+// writing the generation into the release words ctl[32 (1 + IR_NSUB + s)], one per sub-group, which the
+// waiting workgroups poll (~30 pollers per cache line, with back-off).  1000 workgroups that all re-read
+// 1000 partials after a plain barrier would put 10^6 L2 requests behind every barrier.
+// A wait that cannot complete (a launch that is not co-resident) times out: IR_TIMEOUT.
+// NO agent-scope fence anywhere: on this part a release / acquire at agent scope writes back / invalidates
+// the XCD's whole L2 (the eight L2s are not coherent with each other), and a polling loop of acquire loads
+// keeps invalidating it under the workgroups that still compute (measured: 200-300 us per barrier).
+// Everything that crosses workgroups -- partial results, published reductions, counters, release words --
+// is therefore written and read with agent-scope ATOMIC stores / loads, which are performed at the device's
+// coherence point; the issuing thread waits for its own stores to complete (workgroup-scope release =
+// s_waitcnt) before it arrives.
+enum { IR_TIMEOUT = 0, IR_WAITED = 1, IR_LAST = 2 };
+__device__ __forceinline__ int ir_arrive_wait(int *ctl, int gen, int nwg) {
+    __shared__ int s_state;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // this thread's atomic stores of the partial results have completed before the arrival is issued
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const int sub = blockIdx.x % IR_NSUB;
+        const int members = nwg / IR_NSUB + (sub < nwg % IR_NSUB ? 1 : 0);
+        int state = IR_WAITED;
+        if (atomicAdd(ctl + 32 * (1 + sub), 1) + 1 == members * gen) {
+            if (atomicAdd(ctl, 1) + 1 == min(IR_NSUB, nwg) * gen) state = IR_LAST;
+        }
+        if (state != IR_LAST) {
+            const int *rel = ctl + 32 * (1 + IR_NSUB + sub);
+            long long spins = 0;
+            while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1ll << 21)) {
+                    state = IR_TIMEOUT;
+                    break;
+                }
+            }
+        }
+        s_state = state;
+    }
+    __syncthreads();
+    return s_state;
+}
+__device__ __forceinline__ void ir_release(int *ctl, int gen, int nwg) {
+    __syncthreads();
+    // (the published results were stored by thread 0; it orders them before the release words)
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (int q = 0; q < min(IR_NSUB, nwg); ++q)
+            __hip_atomic_store(ctl + 32 * (1 + IR_NSUB + q), gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// the last use of the counters in a launch: arrive without waiting; whoever completes the count zeroes
+// them (every other workgroup is done with them), so the next launch on the stream needs no memset
+__device__ __forceinline__ void ir_grid_exit(int *ctl, int gen, int nwg) {
+    if (threadIdx.x != 0) return;
+    const int sub = blockIdx.x % IR_NSUB;
+    const int members = nwg / IR_NSUB + (sub < nwg % IR_NSUB ? 1 : 0);
+    if (atomicAdd(ctl + 32 * (1 + sub), 1) + 1 == members * gen) {
+        if (atomicAdd(ctl, 1) + 1 == min(IR_NSUB, nwg) * gen) {
+            for (int q = 0; q < IR_NSUB; ++q) {
+                __hip_atomic_store(ctl + 32 * (1 + q), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctl + 32 * (1 + IR_NSUB + q), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(ctl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// values that cross workgroups inside the launch: device-coherent atomic accesses (see above)
+__device__ __forceinline__ double ir_load(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ir_store(double *p, double val) {
+    __hip_atomic_store(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? (a != a ? a : b) : fmax(a, b); }
+// NaN-propagating max over the workgroup, broadcast
+__device__ __forceinline__ double block_nanmax(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_down(v, o, 64));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double t = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = nanmax(t, red[i]);
+    return t;
+}
+
+// forward / backward sweep of bundle b over the slice xs that is ALREADY staged in LDS (backward: already
+// scaled by 1/d); entries of top rows (backward only) are read from xt[row - NF] in LDS.  Same
+// organisation as bundle_solve_body (two rows per thread, several entries per shot, long rows
+// cooperatively, next level's row pointers requested a level ahead).  Ends with a barrier.
+template <bool FWDMODE, int SH>
+__device__ __forceinline__ void bundle_sweep_lds(const LdlView &v, const BundleView &bv, int b, double *xs,
+                                                 const double *xt, int NF, double *red, int *fat, int &nfat) {
+    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    const int *pbeg = FWDMODE ? v.Rp : v.Lp;
+    const int *pend = FWDMODE ? v.Rp + 1 : v.Lp + 1;
+    const int *cidx = FWDMODE ? v.Rcol : v.Li;
+    const double *cval = FWDMODE ? v.Rx : v.Lx;
+    const int nsteps = FWDMODE ? nl - 1 : nl;
+    auto level_of = [&](int step) { return FWDMODE ? step + 1 : nl - 1 - step; };
+    auto xat = [&](int i) { return (FWDMODE || i < s1) ? xs[i - s0] : xt[i - NF]; };
+    int ntb[2] = {0, 0}, nte[2] = {0, 0};
+    auto request_ptrs = [&](int step) {
+        const int l = level_of(step);
+        const int lb = lv[l], le = lv[l + 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = lb + (int)threadIdx.x + u * BWG;
+            ntb[u] = j < le ? pbeg[j] : 0;
+            nte[u] = j < le ? pend[j] : 0;
+        }
+    };
+    if (nsteps > 0) request_ptrs(0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto row_dot = [&](int r, int first, int stride) {
+        double sum = 0.0;
+        for (int t = pbeg[r] + first; t < pend[r]; t += stride) sum += cval[t] * xat(cidx[t]);
+        return sum;
+    };
+    auto coop_row = [&](int r) {
+        double sum = row_dot(r, threadIdx.x, BWG);
+        sum = block_sum(sum, red);
+        if (threadIdx.x == 0) xs[r - s0] -= sum;
+    };
+    for (int step = 0; step < nsteps; ++step) {
+        const int l = level_of(step);
+        const int lb = lv[l], le = lv[l + 1];
+        int ftb[2] = {ntb[0], ntb[1]}, fte[2] = {nte[0], nte[1]};
+        if (step + 1 < nsteps) request_ptrs(step + 1);
+        __syncthreads();
+        if (le - lb == 1) {
+            coop_row(lb);
+            continue;
+        }
+        if (threadIdx.x == 0) nfat = 0;
+        __syncthreads();
+        for (int j0 = lb + threadIdx.x; j0 < le; j0 += 2 * BWG) {
+            int jr[2], tb[2], te[2];
+            double sum[2];
+            const bool first = j0 < lb + BWG;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + u * BWG;
+                jr[u] = j < le ? j : -1;
+                tb[u] = first ? ftb[u] : (j < le ? pbeg[j] : 0);
+                te[u] = first ? fte[u] : (j < le ? pend[j] : 0);
+                sum[u] = 0.0;
+                if (te[u] - tb[u] > THIN_MAX) {
+                    const int slot = atomicAdd(&nfat, 1);
+                    if (slot < IR_FATCAP) {
+                        fat[slot] = j;
+                        jr[u] = -1;
+                        te[u] = tb[u];
+                    }
+                }
+            }
+            const int maxlen = max(te[0] - tb[0], te[1] - tb[1]);
+            for (int k = 0; k < maxlen; k += SH) {
+                int ii[2][SH];
+                double vv[2][SH];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < SH; ++e) {
+                        const unsigned t = (unsigned)(tb[u] + k + e);
+                        const bool ok = (int)t < te[u];
+                        ii[u][e] = ok ? cidx[t] : -1;
+                        vv[u][e] = ok ? cval[t] : 0.0;
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < SH; ++e)
+                        if (ii[u][e] >= 0) sum[u] += vv[u][e] * xat(ii[u][e]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (jr[u] >= 0) xs[jr[u] - s0] -= sum[u];
+        }
+        __syncthreads();
+        const int nf = min(nfat, IR_FATCAP);
+        if (nf <= 2) {
+            for (int f = 0; f < nf; ++f) coop_row(fat[f]);
+        } else {
+            for (int f = wv; f < nf; f += BWG / 64) {
+                const int r = fat[f];
+                double sum = row_dot(r, lane, 64);
+                sum = wave_sum(sum);
+                if (lane == 0) xs[r - s0] -= sum;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// per-workgroup state of k_bundle_ir, kept in LDS so that nothing but loop counters stays in registers
+// across the sweeps (their inner loops need the whole 64-register budget of 8 waves per SIMD)
+struct IrState {
+    double normb, norme, lastnorme;
+    int rounds, ok, done, sel, par, gen, pad;
+    double btop[8], rtop[8], dxt[8], curt[8], candt[8];
+    double dinvt[8], ltt[64], ktt[64]; // constants of the folded top: 1/d, L(top, top), K(top, top) (full rows)
+};
+
+__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem;
+    __shared__ double red[16];
+    __shared__ int fat[IR_FATCAP];
+    __shared__ int nfat;
+    __shared__ IrState st;
+    const int nb = bv.nb, G = gridDim.x, k = fold.k, tid = threadIdx.x;
+    const int NF = k ? fold.NF : ir.N;
+    const bool single = nb <= G; // one bundle per workgroup: its residual never leaves LDS
+    // partial results: device-coherent stores before a barrier, reduced in a fixed order by its last arriver
+    double *pnb = ir.part;                  // [nb]       ||b||inf of the bundles' rows
+    double *pn = pnb + nb;                  // [2][nb]    ||e||inf of the bundles' rows
+    double *shf = pn + 2 * nb;              // [nb*k]     forward sweep: shares of the top rows
+    double *shs = shf + (size_t)nb * k;     // [2][nb*k]  residual: shares of (K x)[top]
+    double *pub = shs + 2 * (size_t)nb * k; // [2][32]    published reductions: [0..8) forward sums, [8] ||e||,
+                                            //            [9] ||b||, [16..24) residual sums
+    auto rhs_at = [&](int j) { // permuted right-hand side entry j (directldlkktsolver.rs:160-166)
+        const int o = ir.perm[j];
+        return o < ir.n ? ir.rx[o] : (o < ir.n + ir.m ? ir.rz[o - ir.n] : 0.0);
+    };
+    if (tid == 0) {
+        st.normb = st.norme = st.lastnorme = 0.0;
+        st.rounds = 0;
+        st.ok = 1;
+        st.done = 0;
+        st.sel = 0;
+        st.par = 0;
+        st.gen = 0;
+        if (blockIdx.x == 0) {
+            ir.res[0] = 0; // "did not finish" until the verdict is written at the very end
+            ir.res[2] = 0;
+        }
+    }
+    if (tid < 64) {
+        st.ltt[tid] = 0.0;
+        st.ktt[tid] = 0.0;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        st.btop[tid] = tid < k ? rhs_at(NF + tid) : 0.0;
+        st.curt[tid] = 0.0;
+        st.dinvt[tid] = tid < k ? v.Dinv[NF + tid] : 0.0;
+    } else if (tid >= 64 && tid < 64 + k * k) {
+        const int q = fold.tt[tid - 64];
+        if (q >= 0) st.ltt[((tid - 64) / k) * 8 + (tid - 64) % k] = v.Lx[q];
+    } else if (tid >= 128 && tid < 128 + k) {
+        const int i = tid - 128;
+        for (int t = fold.sp[i]; t < fold.sp[i + 1]; ++t) st.ktt[i * 8 + fold.scol[t]] += v.Ux[fold.sslot[t]];
+    }
+    __syncthreads();
+    int dbgn = 0;
+    auto stamp = [&]() { // diagnostics (CHIP_IR_DEBUG): phase boundaries of workgroups 0 and G/2 on the 100 MHz clock
+        if (ir.dbg && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == G / 2) && dbgn < 64)
+            ir.dbg[(blockIdx.x ? 64 : 0) + dbgn++] = wall_clock64();
+    };
+    // the last arriver of a barrier: fixed-order reductions of what the workgroups stored before arriving
+    auto reduce_forward = [&](int par) {
+        for (int i = 0; i < k; ++i) {
+            double part = 0.0;
+            for (int q = tid; q < nb; q += BWG) part += ir_load(&shf[(size_t)q * k + i]);
+            part = block_sum(part, red);
+            if (tid == 0) ir_store(&pub[par * 32 + i], part);
+        }
+    };
+    auto reduce_residual = [&](int par, bool first) { // norms NaN propagating
+        double m = 0.0;
+        if (first) {
+            for (int q = tid; q < nb; q += BWG) m = nanmax(m, ir_load(&pnb[q]));
+            m = block_nanmax(m, red);
+            if (tid == 0) ir_store(&pub[par * 32 + 9], m);
+            m = 0.0;
+        }
+        for (int q = tid; q < nb; q += BWG) m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
+        m = block_nanmax(m, red);
+        if (tid == 0) ir_store(&pub[par * 32 + 8], m);
+        for (int i = 0; i < k; ++i) {
+            double part = 0.0;
+            if (ir.ir_enable)
+                for (int q = tid; q < nb; q += BWG) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
+            part = block_sum(part, red);
+            if (tid == 0) ir_store(&pub[par * 32 + 16 + i], part);
+        }
+    };
+    // the reference's decisions about the candidate of round `round`, whose residual sums were published with
+    // parity `par`: thread 0 of every workgroup alike, state in LDS
+    auto decide = [&](int round, int par) {
+        if (tid == 0) {
+            double m = ir_load(&pub[par * 32 + 8]);
+            if (round == 0) {
+                double nbm = ir_load(&pub[par * 32 + 9]);
+                for (int i = 0; i < k; ++i) nbm = nanmax(nbm, fabs(st.btop[i]));
+                st.normb = nbm;
+            }
+            for (int i = 0; i < k; ++i) {
+                double sacc = ir_load(&pub[par * 32 + 16 + i]);
+                for (int c = 0; c < k; ++c) sacc += st.ktt[i * 8 + c] * st.candt[c];
+                // (no refinement: the top entries of x take part in the finiteness test instead)
+                st.rtop[i] = ir.ir_enable ? st.btop[i] - sacc : st.candt[i];
+                m = nanmax(m, fabs(st.rtop[i]));
+            }
+            // (rtop = top rows of the candidate's residual: consumed only if it is accepted and a round follows)
+            const double newnorm = m, tol = ir.abstol + ir.reltol * st.normb;
+            bool accept, done = false;
+            if (round == 0) {
+                accept = true;
+                st.norme = newnorm;
+                if (!(newnorm - newnorm == 0.0)) { // non-finite (:284-286; without refinement: x.is_finite(), :180)
+                    st.ok = 0;
+                    done = true;
+                } else if (!ir.ir_enable || ir.maxiter <= 0 || newnorm <= tol) {
+                    done = true;
+                }
+            } else {
+                st.rounds += 1;
+                if (!(newnorm - newnorm == 0.0)) { // :305-307
+                    st.ok = 0;
+                    accept = false;
+                    done = true;
+                } else {
+                    const double improved = st.lastnorme / newnorm;
+                    accept = !(improved < ir.stopratio) || improved > 1.0; // :309-318
+                    if (improved < ir.stopratio) done = true;
+                    if (accept) st.norme = newnorm;
+                }
+            }
+            if (accept) {
+                st.sel ^= 1;
+                for (int i = 0; i < k; ++i) st.curt[i] = st.candt[i];
+            }
+            if (!done && (st.rounds >= ir.maxiter || st.norme <= tol)) done = true; // :288-293
+            st.lastnorme = st.norme;
+            st.done = done ? 1 : 0;
+        }
+        __syncthreads();
+    };
+    stamp();
+    // Round 0 solves for x from b, round r > 0 for the correction dx from the residual of the accepted x.
+    // With a folded top the verdict on round r - 1's candidate is taken at the barrier in the MIDDLE of
+    // round r (whose forward sweep has then run speculatively on the residual in LDS): one barrier per
+    // round instead of two; only the last possible round ends with a barrier of its own.
+    bool pending = false; // a candidate whose residual partials have been stored but not yet reduced
+    for (int round = 0;; ++round) {
+        const int par = round & 1;
+        bool stop = false;
+        for (int b = blockIdx.x; b < nb; b += G) {
+            const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
+            __syncthreads();
+            if (round == 0) {
+                double mx = 0.0;
+                bool nan = false;
+                for (int i0 = tid; i0 < nloc; i0 += 4 * BWG) { // four independent perm -> rhs chains in flight
+                    int o[4];
+                    double val[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[u] = i0 + u * BWG < nloc ? ir.perm[s0 + i0 + u * BWG] : -1;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        val[u] = o[u] < 0 ? 0.0 : (o[u] < ir.n ? ir.rx[o[u]] : (o[u] < ir.n + ir.m ? ir.rz[o[u] - ir.n] : 0.0));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (o[u] >= 0) {
+                            const int i = i0 + u * BWG;
+                            xs[i] = val[u];
+                            ir.bp[s0 + i] = val[u];
+                            if (val[u] != val[u]) nan = true;
+                            else mx = fmax(mx, fabs(val[u]));
+                        }
+                }
+                mx = block_max(mx, red);
+                const bool anynan = __syncthreads_or(nan);
+                if (tid == 0) ir_store(&pnb[b], anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx);
+            } else if (!single) {
+                for (int i = tid; i < nloc; i += BWG) xs[i] = ir.ebuf[s0 + i];
+            } // (single: xs still holds this bundle's residual)
+            __syncthreads();
+            stamp();
+            bundle_sweep_lds<true, IR_SH_FWD>(v, bv, b, xs, nullptr, NF, red, fat, nfat);
+            stamp();
+            if (k) {
+                // this bundle's columns of the top rows of L against the slice in LDS
+                for (int i = 0; i < k; ++i) {
+                    const int tb = fold.rseg[(b * k + i) * 2], te = fold.rseg[(b * k + i) * 2 + 1];
+                    double a0 = 0.0, a1 = 0.0;
+                    int t = tb + tid;
+                    for (; t + BWG < te; t += 2 * BWG) {
+                        const int j0 = v.Rcol[t], j1 = v.Rcol[t + BWG];
+                        const double v0 = v.Rx[t], v1 = v.Rx[t + BWG];
+                        a0 += v0 * xs[j0 - s0];
+                        a1 += v1 * xs[j1 - s0];
+                    }
+                    for (; t < te; t += BWG) a0 += v.Rx[t] * xs[v.Rcol[t] - s0];
+                    const double sum = block_sum(a0 + a1, red);
+                    if (tid == 0) ir_store(&shf[(size_t)b * k + i], sum);
+                }
+            }
+            // D^-1 of the backward sweep (qdldl.rs:737-752) before the barrier: it does not need the top
+            for (int i = tid; i < nloc; i += BWG) xs[i] *= v.Dinv[s0 + i];
+            if (k) {
+                stamp();
+                if (tid == 0) st.gen += 1;
+                const int state = ir_arrive_wait(ir.ctl, st.gen, G);
+                if (state == IR_TIMEOUT) {
+                    if (tid == 0) ir.res[2] = 1;
+                    return;
+                }
+                stamp();
+                if (state == IR_LAST) {
+                    reduce_forward(par);
+                    if (pending) reduce_residual(par ^ 1, round == 1);
+                    ir_release(ir.ctl, st.gen, G);
+                }
+                __syncthreads();
+                if (pending) { // the verdict on the previous round's candidate
+                    decide(round - 1, par ^ 1);
+                    pending = false;
+                    if (__builtin_amdgcn_readfirstlane(st.done)) {
+                        stop = true; // (this round's forward sweep was speculative)
+                        break;
+                    }
+                }
+                // the k x k top part of both sweeps, by every workgroup alike (k <= 8)
+                if (tid == 0) {
+                    double y[8];
+                    for (int i = 0; i < k; ++i) {
+                        double sacc = (round == 0 ? st.btop[i] : st.rtop[i]) - ir_load(&pub[par * 32 + i]);
+                        for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * y[j];
+                        y[i] = sacc;
+                    }
+                    for (int i = k - 1; i >= 0; --i) {
+                        double sacc = y[i] * st.dinvt[i];
+                        for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * y[j];
+                        y[i] = sacc;
+                    }
+                    for (int i = 0; i < k; ++i) {
+                        st.dxt[i] = y[i];
+                        st.candt[i] = round == 0 ? y[i] : 1.0 * st.curt[i] + 1.0 * y[i];
+                    }
+                }
+            }
+            __syncthreads();
+            stamp();
+            bundle_sweep_lds<false, IR_SH_BWD>(v, bv, b, xs, st.dxt, NF, red, fat, nfat);
+            stamp();
+            {
+                // the candidate: x (round 0) or x + dx (directldlkktsolver.rs:300 axpby(1, x, 1))
+                const int sel = __builtin_amdgcn_readfirstlane(st.sel);
+                const double *cur = sel ? ir.xb : ir.xa;
+                double *alt = sel ? ir.xa : ir.xb;
+                if (round == 0) {
+                    for (int i = tid; i < nloc; i += BWG) alt[s0 + i] = xs[i];
+                } else {
+                    for (int i = tid; i < nloc; i += BWG) alt[s0 + i] = 1.0 * cur[s0 + i] + 1.0 * xs[i];
+                }
+                if (!ir.ir_enable) { // no refinement: only x.is_finite() is asked for (:180)
+                    double mx = 0.0;
+                    bool nan = false;
+                    for (int i = tid; i < nloc; i += BWG) {
+                        const double val = xs[i];
+                        if (val != val) nan = true;
+                        else mx = fmax(mx, fabs(val));
+                    }
+                    mx = block_max(mx, red);
+                    const bool anynan = __syncthreads_or(nan);
+                    if (tid == 0) ir_store(&pn[(size_t)par * nb + b], anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx);
+                    continue;
+                }
+                __syncthreads(); // the candidate's slice is visible workgroup-wide
+                stamp();
+                bundle_symv_body<true, IR_SH_SYMV>(bv, v.Up, v.Ucol, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
+                                       xs, red, fold, b, st.candt, &pn[(size_t)par * nb + b],
+                                       &shs[(size_t)par * nb * k + (size_t)b * k]);
+            }
+        }
+        if (stop) break;
+        pending = true;
+        // A further round is possible only with refinement on, rounds left, and (a forest without top, or
+        // several bundles per workgroup) ... the verdict then rides on that round's barrier; otherwise the
+        // round ends with a barrier of its own.
+        const bool more_possible = ir.ir_enable && round < ir.maxiter;
+        if (k && more_possible) continue;
+        stamp();
+        if (tid == 0) st.gen += 1;
+        const int state = ir_arrive_wait(ir.ctl, st.gen, G);
+        if (state == IR_TIMEOUT) {
+            if (tid == 0) ir.res[2] = 1;
+            return;
+        }
+        stamp();
+        if (state == IR_LAST) {
+            reduce_residual(par, round == 0);
+            ir_release(ir.ctl, st.gen, G);
+        }
+        __syncthreads();
+        decide(round, par);
+        pending = false;
+        if (__builtin_amdgcn_readfirstlane(st.done)) break;
+    }
+    stamp();
+    // ---- getlhs (directldlkktsolver.rs:205-215): the accepted x, un-permuted ----
+    const int ok = __builtin_amdgcn_readfirstlane(st.ok);
+    if (ok) {
+        double *cur = __builtin_amdgcn_readfirstlane(st.sel) ? ir.xb : ir.xa;
+        auto put = [&](int j, double val) {
+            const int o = ir.perm[j];
+            if (o < ir.n) {
+                if (ir.lhsx) ir.lhsx[o] = val;
+            } else if (o < ir.n + ir.m) {
+                if (ir.lhsz) ir.lhsz[o - ir.n] = val;
+            }
+        };
+        for (int b = blockIdx.x; b < nb; b += G) {
+            const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
+            for (int i = tid; i < nloc; i += BWG) put(s0 + i, cur[s0 + i]);
+        }
+        if (blockIdx.x == 0 && tid < k) {
+            put(NF + tid, st.curt[tid]);
+            cur[NF + tid] = st.curt[tid];
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        ir.res[0] = ok ? 1 : -1; // (0 = the kernel never got here)
+        ir.res[1] = st.rounds;
+        ir.res[3] = st.sel;
+        pub[64] = st.normb;
+        pub[65] = st.norme;
+    }
+    stamp();
+    ir_grid_exit(ir.ctl, __builtin_amdgcn_readfirstlane(st.gen) + 1, G);
+}
+
 // A run of consecutive NARROW levels (a chain-like stretch of the elimination tree: a handful
 // of rows per level) handled by ONE 1024-thread workgroup that walks the levels with
 // __syncthreads() in between -- a few us per level instead of one launch per level.  A level
@@ -3885,6 +4475,50 @@ void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x
 }
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const double *addv) {
     if (bv.nb) k_bundle_bwd<<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv);
+}
+int ir_ctl_ints() { return IR_CTL_INTS; }
+size_t ir_part_doubles(int nb, int k) { return (size_t)nb * (3 + 3 * (size_t)k) + 72; }
+int bundle_ir_capacity(const BundleView &bv) {
+    if (!bv.nb) return 0;
+    const size_t lds = bundle_lds(bv);
+    if (hipFuncSetAttribute((const void *)k_bundle_ir, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bundle_ir, BWG, lds) != hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    // cross-check with the LDS budget (static + dynamic, 1 KB allocation granularity assumed) and the wave slots
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void *)k_bundle_ir) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    const size_t per_wg = ((fa.sharedSizeBytes + lds + 1023) / 1024) * 1024;
+    const int by_lds = (int)(prop.maxSharedMemoryPerMultiProcessor / per_wg);
+    const int by_waves = 32 / (BWG / 64);
+    per_cu = std::min(per_cu, std::min(by_lds, by_waves));
+    return per_cu * prop.multiProcessorCount;
+}
+int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid) {
+    LdlView va = v;
+    BundleView ba = bv;
+    FoldView fa = fold;
+    IrView ia = ir;
+    // grid <= bundle_ir_capacity(): every workgroup is resident on an otherwise idle device, and a grid
+    // barrier that cannot complete times out instead of hanging.  CHIP_IR_COOP=1 asks the runtime to
+    // validate the co-residency (cooperative launch: runs on the device's cooperative queue).
+    static const bool coop = std::getenv("CHIP_IR_COOP") != nullptr;
+    if (coop) {
+        void *args[] = {(void *)&va, (void *)&ba, (void *)&fa, (void *)&ia};
+        return (int)hipLaunchCooperativeKernel((const void *)k_bundle_ir, dim3(grid), dim3(BWG), args, bundle_lds(bv), s);
+    }
+    k_bundle_ir<<<grid, BWG, bundle_lds(bv), s>>>(va, ba, fa, ia);
+    return (int)hipGetLastError();
 }
 void fold_top_solve(hipStream_t s, const LdlView &v, const FoldView &fold, double *x) {
     if (fold.k) k_fold_top_solve<<<1, 64, 0, s>>>(v, fold, x);

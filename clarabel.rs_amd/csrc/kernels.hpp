@@ -101,6 +101,32 @@ void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x
 // e[bundle rows] = b - K x with K stored once (U: row i = diagonal + entries to ancestors)
 void bundle_symv(hipStream_t s, const BundleView &bv, const int *Up, const int *Ucol, const double *Ux,
                  const double *x, const double *b, double *e, unsigned long long *nrm, int *nan, const FoldView &fold, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// ---- whole solve + iterative refinement in one persistent launch (k_bundle_ir) ----------------------
+struct IrView {
+    const double *rx, *rz; // right-hand side in the caller's order: entry o < n from rx, n <= o < n + m from rz,
+                           // the sparse-cone rows are zero (directldlkktsolver.rs:160-166)
+    int n, m, N;
+    const int *perm;       // perm[new] = old
+    double *bp;            // N: the permuted right-hand side, kept for the residuals
+    double *xa, *xb;       // N each: accepted iterate / candidate (the roles swap)
+    double *ebuf;          // N: residual spill, used only when a workgroup owns several bundles
+    double *lhsx, *lhsz;   // outputs in the caller's order (either may be nullptr)
+    double *part;          // ir_part_doubles(nb, k) doubles of partial results
+    int *ctl;              // ir_ctl_ints() ints, zero at launch: the grid barrier's counters (a launch that runs
+                           // to its end leaves them zero again; after a barrier timeout the host clears them)
+    int *res;              // 4 ints written by the launch: [0] 1 ok / -1 numerical failure (0: did not finish),
+                           // [1] refinement rounds, [2] barrier timeout, [3] the accepted x is in xb
+    double abstol, reltol, stopratio;
+    int maxiter, ir_enable;
+    long long *dbg;        // diagnostics: 128 time stamps of two workgroups, or nullptr
+};
+int ir_ctl_ints();
+size_t ir_part_doubles(int nb, int k);
+// largest co-resident grid of k_bundle_ir for these bundles (0: the kernel cannot run)
+int bundle_ir_capacity(const BundleView &bv);
+// returns hipSuccess (0) or the launch error; grid <= bundle_ir_capacity, grid >= nb when fold.k > 0
+int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid);
+
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);
 void factor_B(hipStream_t s, const LdlView &v, ChunkView chunks);

@@ -218,13 +218,34 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
  * whose scaling is not held on the device (PSD cones with matrix side > 64); may be NULL
  * when there are none.  Returns the reference's bool. */
 int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null);
-/* setrhs(rhsx, rhsz)   directldlkktsolver.rs:160-166 */
+/* setrhs(rhsx, rhsz)   directldlkktsolver.rs:160-166.  The host variant copies the vectors.  The _dev
+ * variant may BORROW the two device buffers until the following chip_kkt_solve* has run on the handle's
+ * stream: when the whole solve runs as one fused launch (systems made of subtree bundles and at most a few
+ * dense top rows: configs 3 and 4) that launch reads and permutes them itself -- they must not be
+ * overwritten from another stream or from the host in between. */
 int32_t chip_kkt_setrhs(chip_kkt *h, const double *rhsx, const double *rhsz);
 int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *rhsz_dev);
 /* solve(lhsx, lhsz, settings) -> bool   directldlkktsolver.rs:168-189,
  * incl. iterative_refinement :266-321.  Either output may be NULL. */
 int32_t chip_kkt_solve(chip_kkt *h, double *lhsx_or_null, double *lhsz_or_null);
 int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_dev_or_null);
+/* ---- asynchronous variants: enqueue on the handle's stream and return at once ------------------------
+ * The reference's update() / solve() return their bool immediately because they run on the host.  On the
+ * device the verdicts (all pivots finite, refinement residual finite, cones interior) are produced by the
+ * kernels themselves; a device-resident driver enqueues one whole interior-point iteration -- update, then
+ * the solves, chip_kkt_setrhs_dev before each -- and asks for the verdicts ONCE:
+ *   chip_kkt_update_enqueue   = chip_kkt_update without the final device-to-host copy
+ *   chip_kkt_solve_dev_enqueue = chip_kkt_solve_dev: for systems the fused launch covers (subtree bundles and
+ *                               at most a few dense top rows) the refinement decisions of
+ *                               directldlkktsolver.rs:266-321 are taken on the device and nothing is waited
+ *                               for; other systems run the synchronous solve and queue its verdict
+ *   chip_kkt_collect          synchronises the stream once; *update_ok = verdict of the last enqueued update
+ *                               (1 if none), *nsolves = solves enqueued since the last collect (at most 16
+ *                               may be pending), solves_ok[i] their bools in order.  Returns CHIP_OK or a
+ *                               negative chip_status. */
+int32_t chip_kkt_update_enqueue(chip_kkt *h, const double *hsblocks_or_null);
+int32_t chip_kkt_solve_dev_enqueue(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_dev_or_null);
+int32_t chip_kkt_collect(chip_kkt *h, int32_t *update_ok, int32_t *nsolves, int32_t solves_ok[16]);
 /* KKTSolver::solve / ::update receive `settings: &CoreSettings` on EVERY call in the reference
  * (kktsolvers/mod.rs:7-18, directldlkktsolver.rs:134,168): this hands the current values of the
  * regularisation and refinement fields to the following calls.  The engine knobs (device, amd_dense_scale,
@@ -307,8 +328,9 @@ int32_t chip_kkt_synchronize(chip_kkt *h);
 /* HIP stream (hipStream_t) the handle launches on, for event timing */
 void *chip_kkt_stream(chip_kkt *h);
 /* hipEvent pairs (recorded on the launch stream) around every launch of ONE
- * kernel family: 0 = off, 1 = symv residual k_gather_T<SYMV>, 2 = backward
- * substitution k_gather_T<BWD>, 3 = forward k_gather_T<FWD>, 4 = k_factor_T.
+ * kernel family: 0 = off, 1 = symv residual k_bundle_symv, 2 = backward
+ * substitution k_gather_T<BWD>, 3 = forward k_gather_T<FWD>, 4 = k_factor_T (families 1-4 force the
+ * one-kernel-per-phase solve path), 5 = k_bundle_ir (the fused solve + refinement launch), 6 = k_bundle_factor.
  * chip_kkt_profile(h, family) resets the counters; chip_kkt_profile_read
  * returns out[0] = launches, out[1] = total ms, out[2] = family. */
 int32_t chip_kkt_profile(chip_kkt *h, int32_t family);

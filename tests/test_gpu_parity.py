@@ -806,6 +806,45 @@ def test_run_to_run_spread(hip, which):
     assert spread <= 1e-12, "run-to-run spread %g" % spread
 
 
+@pytest.mark.parametrize("which", ["arrow", "forest", "general"])
+def test_async_enqueue_collect(hip, oracle, which):
+    """chip_kkt_update_enqueue / solve_dev_enqueue / collect: a whole iteration's KKT work enqueued without
+    a host synchronisation, verdicts collected once -- same solutions as the synchronous calls.  "arrow" and
+    "forest" run the fused solve + refinement launch with the decisions taken on the device (default
+    refinement settings: data-dependent round counts), "general" (a banded QP with a tall top) takes the
+    host-controlled path behind the same entry points."""
+    pr = {"arrow": lambda: problems.portfolio_socp(20, 300, seed=3, late=True),
+          "forest": lambda: problems.batched_socp(24, 300, 2, seed=100),
+          "general": lambda: problems.random_qp(3000, 6000, band=20, seed=1)}[which]()
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    rng = np.random.default_rng(9)
+    rhs = [(rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])) for _ in range(3)]
+    d_s, d_z = hip.DeviceArray(pr["s"]), hip.DeviceArray(pr["z"])
+    d_rhs = [(hip.DeviceArray(a), hip.DeviceArray(b)) for a, b in rhs]
+    d_lhs = [hip.DeviceArray(pr["n"] + pr["m"]) for _ in rhs]
+    for _ in range(2):  # twice: the control blocks must be reusable without host help
+        ks.update_scaling_dev(d_s.ptr, d_z.ptr)
+        ks.update_enqueue()
+        for (a, b), l in zip(d_rhs, d_lhs):
+            ks.setrhs_dev(a.ptr, b.ptr)
+            ks.solve_dev_enqueue(l.ptr, l.ptr + 8 * pr["n"])
+        uok, sok = ks.collect()
+        assert uok and sok == [True, True, True]
+    assert cones.update_scaling(pr["s"], pr["z"]) and ko.update()
+    for (a, b), l in zip(rhs, d_lhs):
+        ko.setrhs(a, b)
+        ok, xo, zo = ko.solve()
+        assert ok and relerr(l.numpy(), np.concatenate([xo, zo])) <= TOL
+    # a non-finite right-hand side: the solve's verdict is false, the handle stays usable
+    bad = hip.DeviceArray(np.full(pr["n"], np.nan))
+    ks.setrhs_dev(bad.ptr, d_rhs[0][1].ptr)
+    ks.solve_dev_enqueue(d_lhs[0].ptr, d_lhs[0].ptr + 8 * pr["n"])
+    ks.setrhs_dev(d_rhs[1][0].ptr, d_rhs[1][1].ptr)
+    ks.solve_dev_enqueue(d_lhs[1].ptr, d_lhs[1].ptr + 8 * pr["n"])
+    uok, sok = ks.collect()
+    assert uok and sok == [False, True]
+
+
 # ---- L3: DefaultKKTSystem / DefaultResiduals on the device ----------------------------
 def _l3_pair(hip, oracle, pr, seed=0):
     rng = np.random.default_rng(seed)

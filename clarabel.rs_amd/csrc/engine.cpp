@@ -273,11 +273,13 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         topblk.ys = ysb;
         topblk.counters = cnt;
     }
-    if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || NF == N) &&
+    if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || NF == N) && !S.Li16.empty() &&
         std::getenv("CHIP_NO_FUSED_IR") == nullptr) {
         const int cap = dev::bundle_ir_capacity(bundles);
         if (cap > 0 && (fold.k == 0 || bundles.nb <= cap)) {
             ir_fused = true;
+            if ((rc = upload(&Li16, S.Li16, S.Li16.size()))) return rc;
+            if ((rc = upload(&Ucol16, S.Ucol16, S.Ucol16.size()))) return rc;
             ir_grid = std::min(bundles.nb, cap);
             if ((rc = alloc(&ir_ctl, (size_t)dev::ir_ctl_ints()))) return rc;
             CHIP_HIP(hipMemset(ir_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int)));
@@ -321,6 +323,9 @@ dev::LdlView Engine::view() const {
     v.Ucol = Ucol;
     v.Ux = Ux;
     v.eps_ptr = nullptr;
+    v.Li16 = Li16;
+    v.Ucol16 = Ucol16;
+    v.mirror_rows = ir_fused ? 0 : 1;
     return v;
 }
 
@@ -454,6 +459,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     if (nsn > 0) dev::gather_values(stream, Rfx, Lx, Rf_pos, nRf); // L at the filtered row lists (forward sweep)
     else dev::topblk_build(stream, v, topblk); // inverses of the diagonal blocks of a tall top
     if (!fold.k) dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS); // full rows of the top for the residual
+    rx_valid = !ir_fused;
     return CHIP_OK;
 }
 int Engine::refactor_collect() {
@@ -501,6 +507,10 @@ void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
 }
 void Engine::enqueue_solve_direct(double *xp, const double *addv) {
     const dev::LdlView v = view();
+    if (!rx_valid) { // (a fused handle taking the one-kernel-per-phase path: these kernels stream L by rows)
+        dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzL);
+        rx_valid = true;
+    }
     dev::bundle_fwd(stream, v, bundles, xp, fold);
     if (fold.k) { // an "arrow": the bundles have already folded the top rows; finish the k x k part
         dev::fold_top_solve(stream, v, fold, xp);
@@ -644,5 +654,6 @@ template int Engine::alloc<int8_t>(int8_t **, size_t);
 template int Engine::upload<int>(int **, const std::vector<int> &, size_t);
 template int Engine::upload<double>(double **, const std::vector<double> &, size_t);
 template int Engine::upload<int8_t>(int8_t **, const std::vector<int8_t> &, size_t);
+template int Engine::upload<unsigned short>(unsigned short **, const std::vector<unsigned short> &, size_t);
 
 } // namespace chip

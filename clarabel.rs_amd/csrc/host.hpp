@@ -90,6 +90,10 @@ struct Symbolic {
     //                                     (column index relative to NF, position in V)
     i32 nfold = 0;
     std::vector<i32> fold_rseg, fold_tt, fold_sp, fold_scol, fold_sslot;
+    // bundles + (at most) a folded top only: 16-bit bundle-local row indices of the entries of the bundle
+    // columns of L (Li16, parallel to Li[0 .. Lp[NF])) and of the U rows (Ucol16); an index >= the
+    // bundle's node count nloc stands for top row NF + (index - nloc).  Empty otherwise.
+    std::vector<uint16_t> Li16, Ucol16;
     std::vector<i32> lvlptr;
     // Chain supernodes of the top (symbolic.cpp): supernode s = columns sn_col[sn_ptr[s] .. sn_ptr[s+1])
     // (ascending, each the parent of the previous one); all its columns are padded to the dense

@@ -202,7 +202,7 @@ __device__ __forceinline__ void finish_column_serial(const LdlView &v, int j, in
     for (int q = cb; q < ce; ++q) {
         const double l = v.Lx[q] * dinv;
         v.Lx[q] = l;
-        v.Rx[v.Tpos[q]] = l;
+        if (v.mirror_rows) v.Rx[v.Tpos[q]] = l;
     }
 }
 
@@ -274,7 +274,7 @@ __device__ __forceinline__ void factor_col_thread(const LdlView &v, int j) {
             if (q < cn) {
                 const double l = a[q] * dinv;
                 v.Lx[cb + q] = l;
-                v.Rx[v.Tpos[cb + q]] = l;
+                if (v.mirror_rows) v.Rx[v.Tpos[cb + q]] = l;
             }
         return;
     }
@@ -377,7 +377,7 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
             for (int q = 0; q < cn; ++q) {
                 const double l = (k0[q] - a[q]) * dinv;
                 v.Lx[cb + q] = l;
-                v.Rx[v.Tpos[cb + q]] = l;
+                if (v.mirror_rows) v.Rx[v.Tpos[cb + q]] = l;
             }
         }
         return;
@@ -486,7 +486,7 @@ __device__ __forceinline__ void factor_col_block(const LdlView &v, int j, double
                              : __hip_atomic_load(&v.Lx[cb + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double l = c * dinv;
         v.Lx[cb + q] = l;
-        v.Rx[v.Tpos[cb + q]] = l;
+        if (v.mirror_rows) v.Rx[v.Tpos[cb + q]] = l;
     }
 }
 
@@ -1653,7 +1653,8 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
                 for (int q = 0; q < SSHOT; ++q) {
                     const unsigned t = (unsigned)(tb[u] + k + q); // unsigned offset -> sgpr-base addressing
                     const bool ok = (int)t < te[u];
-                    jj[u][q] = ok ? Ucol[t] : -1;
+                    // (FUSED: Ucol points at the 16-bit bundle-local indices, >= nloc for the top rows)
+                    jj[u][q] = ok ? (FUSED ? (int)((const unsigned short *)Ucol)[t] : Ucol[t]) : -1;
                     vv[u][q] = ok ? Ux[t] : 0.0;
                 }
 #pragma unroll
@@ -1662,8 +1663,19 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
                 for (int q = 0; q < SSHOT; ++q) {
                     const int j = jj[u][q];
                     int tgt = -1;
-                    if (j >= 0) {
-                        acc[u] += vv[u][q] * ((FUSED && j >= s1) ? xt[j - fold.NF] : x[j]);
+                    if (FUSED) {
+                        if (j >= 0) {
+                            acc[u] += vv[u][q] * (j >= nloc ? xt[j - nloc] : x[s0 + j]);
+                            if (j < nloc) {
+                                if (j != i0 + u * BWG) tgt = j;
+                            } else if (fold.k == 1) {
+                                tpart += vv[u][q] * xi[u];
+                            } else {
+                                atomicAdd(&tacc[j - nloc], vv[u][q] * xi[u]);
+                            }
+                        }
+                    } else if (j >= 0) {
+                        acc[u] += vv[u][q] * x[j];
                         if (j < s1) {
                             if (j != s0 + i0 + u * BWG) tgt = j - s0;
                         } else if (fold.k == 1) {
@@ -1894,54 +1906,136 @@ __device__ __forceinline__ double block_nanmax(double v, double *red) {
     return t;
 }
 
-// forward / backward sweep of bundle b over the slice xs that is ALREADY staged in LDS (backward: already
-// scaled by 1/d); entries of top rows (backward only) are read from xt[row - NF] in LDS.  Same
-// organisation as bundle_solve_body (two rows per thread, several entries per shot, long rows
-// cooperatively, next level's row pointers requested a level ahead).  Ends with a barrier.
-template <bool FWDMODE, int SH>
-__device__ __forceinline__ void bundle_sweep_lds(const LdlView &v, const BundleView &bv, int b, double *xs,
-                                                 const double *xt, int NF, double *red, int *fat, int &nfat) {
-    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1];
+// Forward substitution of bundle b over the slice xs staged in LDS, COLUMN oriented like the reference's
+// (qdldl.rs:708-719, x[Li] -= Lx * x[i]): level by level, a node whose value is final pushes it into the
+// rows of its column of L with LDS fp64 atomics.  The long rows at the top of a subtree (the u / v columns
+// of a sparse SOC: a thousand entries each) receive their contributions from all threads as the wide levels
+// below them complete -- wave-uniform targets are reduced in registers first (lds_scatter_add) -- instead of
+// being gathered by one cooperative pass per row on a serial chain of one-node levels; pushes into the
+// folded top rows (row index >= nloc) are this bundle's shares of those rows (tacc[0..k), zeroed here).
+// Streams the columns of L with 16-bit local row indices (Li16): no row-major copy of L is needed.
+template <int SH>
+__device__ __forceinline__ void bundle_fwd_push(const LdlView &v, const BundleView &bv, int b, double *xs,
+                                                double *tacc, int k) {
+    const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
     const int *lv = bv.blvl + bv.blvl_ptr[b];
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    const int *pbeg = FWDMODE ? v.Rp : v.Lp;
-    const int *pend = FWDMODE ? v.Rp + 1 : v.Lp + 1;
-    const int *cidx = FWDMODE ? v.Rcol : v.Li;
-    const double *cval = FWDMODE ? v.Rx : v.Lx;
-    const int nsteps = FWDMODE ? nl - 1 : nl;
-    auto level_of = [&](int step) { return FWDMODE ? step + 1 : nl - 1 - step; };
-    auto xat = [&](int i) { return (FWDMODE || i < s1) ? xs[i - s0] : xt[i - NF]; };
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
+    if ((int)threadIdx.x < 8) tacc[threadIdx.x] = 0.0;
+    double tpart = 0.0; // k == 1 (the usual arrow): the single top row's share in registers
     int ntb[2] = {0, 0}, nte[2] = {0, 0};
-    auto request_ptrs = [&](int step) {
-        const int l = level_of(step);
+    auto request_ptrs = [&](int l) {
         const int lb = lv[l], le = lv[l + 1];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int j = lb + (int)threadIdx.x + u * BWG;
-            ntb[u] = j < le ? pbeg[j] : 0;
-            nte[u] = j < le ? pend[j] : 0;
+            ntb[u] = j < le ? v.Lp[j] : 0;
+            nte[u] = j < le ? v.Lp[j + 1] : 0;
         }
     };
-    if (nsteps > 0) request_ptrs(0);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    auto row_dot = [&](int r, int first, int stride) {
-        double sum = 0.0;
-        for (int t = pbeg[r] + first; t < pend[r]; t += stride) sum += cval[t] * xat(cidx[t]);
-        return sum;
-    };
-    auto coop_row = [&](int r) {
-        double sum = row_dot(r, threadIdx.x, BWG);
-        sum = block_sum(sum, red);
-        if (threadIdx.x == 0) xs[r - s0] -= sum;
-    };
-    for (int step = 0; step < nsteps; ++step) {
-        const int l = level_of(step);
+    if (nl > 0) request_ptrs(0);
+    for (int l = 0; l < nl; ++l) {
         const int lb = lv[l], le = lv[l + 1];
         int ftb[2] = {ntb[0], ntb[1]}, fte[2] = {nte[0], nte[1]};
-        if (step + 1 < nsteps) request_ptrs(step + 1);
+        if (l + 1 < nl) request_ptrs(l + 1);
+        __syncthreads(); // every push into this level's nodes has landed
+        for (int w0 = lb + wbase; w0 < le; w0 += 2 * BWG) { // wave-uniform bounds (cross-lane operations below)
+            const bool first = w0 < lb + BWG;
+            int tb[2], te[2];
+            double yj[2];
+            int maxlen = 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = w0 + lane + u * BWG;
+                tb[u] = first ? ftb[u] : (j < le ? v.Lp[j] : 0);
+                te[u] = first ? fte[u] : (j < le ? v.Lp[j + 1] : 0);
+                yj[u] = j < le ? xs[j - s0] : 0.0;
+                maxlen = max(maxlen, te[u] - tb[u]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+            for (int kk = 0; kk < maxlen; kk += SH) {
+                int ii[2][SH];
+                double vv[2][SH];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < SH; ++e) {
+                        const unsigned t = (unsigned)(tb[u] + kk + e);
+                        const bool ok = (int)t < te[u];
+                        ii[u][e] = ok ? (int)v.Li16[t] : -1;
+                        vv[u][e] = ok ? v.Lx[t] : 0.0;
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < SH; ++e) {
+                        const int i = ii[u][e];
+                        const double val = vv[u][e] * yj[u];
+                        int tgt = -1;
+                        if (i >= 0) {
+                            if (i < nloc) tgt = i;
+                            else if (k == 1) tpart += val;
+                            else atomicAdd(&tacc[i - nloc], val);
+                        }
+                        lds_scatter_add(xs, tgt, -val);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    if (k == 1) {
+        tpart = wave_sum(tpart);
+        if (lane == 0 && tpart != 0.0) atomicAdd(&tacc[0], tpart);
         __syncthreads();
-        if (le - lb == 1) {
-            coop_row(lb);
+    }
+}
+
+// Backward substitution of bundle b (qdldl.rs:737-752) over the slice xs in LDS, which already holds
+// y / d: x_j -= sum over column j of l_ij x_i, the x_i of ancestors inside the bundle from LDS, those of
+// the folded top rows from xt.  Level by level from the top of the subtrees down, two columns per thread,
+// SH entries per shot, long columns cooperatively, next level's column pointers requested a level ahead.
+template <int SH>
+__device__ __forceinline__ void bundle_bwd_lds(const LdlView &v, const BundleView &bv, int b, double *xs,
+                                               const double *xt, double *red, int *fat, int &nfat) {
+    const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    auto xat = [&](int i) { return i < nloc ? xs[i] : xt[i - nloc]; };
+    int ntb[2] = {0, 0}, nte[2] = {0, 0};
+    auto request_ptrs = [&](int l) {
+        const int lb = lv[l], le = lv[l + 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = lb + (int)threadIdx.x + u * BWG;
+            ntb[u] = j < le ? v.Lp[j] : 0;
+            nte[u] = j < le ? v.Lp[j + 1] : 0;
+        }
+    };
+    if (nl > 0) request_ptrs(nl - 1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto col_dot = [&](int j, int first, int stride) {
+        double sum = 0.0;
+        for (int t = v.Lp[j] + first; t < v.Lp[j + 1]; t += stride) sum += v.Lx[t] * xat((int)v.Li16[t]);
+        return sum;
+    };
+    for (int l = nl - 1; l >= 0; --l) {
+        const int lb = lv[l], le = lv[l + 1];
+        int ftb[2] = {ntb[0], ntb[1]}, fte[2] = {nte[0], nte[1]};
+        if (l > 0) request_ptrs(l - 1);
+        __syncthreads();
+        if (le - lb == 1) { // a level of its own
+            const int j = lb;
+            const int clen = v.Lp[j + 1] - v.Lp[j]; // (uniform)
+            if (clen > 256) {
+                double sum = col_dot(j, threadIdx.x, BWG);
+                sum = block_sum(sum, red);
+                if (threadIdx.x == 0) xs[j - s0] -= sum;
+            } else if (wv == 0) { // short column: one wave, no workgroup reduction
+                double sum = col_dot(j, lane, 64);
+                sum = wave_sum(sum);
+                if (lane == 0) xs[j - s0] -= sum;
+            }
             continue;
         }
         if (threadIdx.x == 0) nfat = 0;
@@ -1954,8 +2048,8 @@ __device__ __forceinline__ void bundle_sweep_lds(const LdlView &v, const BundleV
             for (int u = 0; u < 2; ++u) {
                 const int j = j0 + u * BWG;
                 jr[u] = j < le ? j : -1;
-                tb[u] = first ? ftb[u] : (j < le ? pbeg[j] : 0);
-                te[u] = first ? fte[u] : (j < le ? pend[j] : 0);
+                tb[u] = first ? ftb[u] : (j < le ? v.Lp[j] : 0);
+                te[u] = first ? fte[u] : (j < le ? v.Lp[j + 1] : 0);
                 sum[u] = 0.0;
                 if (te[u] - tb[u] > THIN_MAX) {
                     const int slot = atomicAdd(&nfat, 1);
@@ -1967,17 +2061,17 @@ __device__ __forceinline__ void bundle_sweep_lds(const LdlView &v, const BundleV
                 }
             }
             const int maxlen = max(te[0] - tb[0], te[1] - tb[1]);
-            for (int k = 0; k < maxlen; k += SH) {
+            for (int kk = 0; kk < maxlen; kk += SH) {
                 int ii[2][SH];
                 double vv[2][SH];
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int e = 0; e < SH; ++e) {
-                        const unsigned t = (unsigned)(tb[u] + k + e);
+                        const unsigned t = (unsigned)(tb[u] + kk + e);
                         const bool ok = (int)t < te[u];
-                        ii[u][e] = ok ? cidx[t] : -1;
-                        vv[u][e] = ok ? cval[t] : 0.0;
+                        ii[u][e] = ok ? (int)v.Li16[t] : -1;
+                        vv[u][e] = ok ? v.Lx[t] : 0.0;
                     }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -1991,15 +2085,11 @@ __device__ __forceinline__ void bundle_sweep_lds(const LdlView &v, const BundleV
         }
         __syncthreads();
         const int nf = min(nfat, IR_FATCAP);
-        if (nf <= 2) {
-            for (int f = 0; f < nf; ++f) coop_row(fat[f]);
-        } else {
-            for (int f = wv; f < nf; f += BWG / 64) {
-                const int r = fat[f];
-                double sum = row_dot(r, lane, 64);
-                sum = wave_sum(sum);
-                if (lane == 0) xs[r - s0] -= sum;
-            }
+        for (int f = wv; f < nf; f += BWG / 64) {
+            const int j = fat[f];
+            double sum = col_dot(j, lane, 64);
+            sum = wave_sum(sum);
+            if (lane == 0) xs[j - s0] -= sum;
         }
     }
     __syncthreads();
@@ -2012,6 +2102,7 @@ struct IrState {
     int rounds, ok, done, sel, par, gen, pad;
     double btop[8], rtop[8], dxt[8], curt[8], candt[8];
     double dinvt[8], ltt[64], ktt[64]; // constants of the folded top: 1/d, L(top, top), K(top, top) (full rows)
+    double tacc[8];                    // this bundle's shares of the top rows in the forward sweep
 };
 
 __global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -2192,25 +2283,10 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             } // (single: xs still holds this bundle's residual)
             __syncthreads();
             stamp();
-            bundle_sweep_lds<true, IR_SH_FWD>(v, bv, b, xs, nullptr, NF, red, fat, nfat);
+            bundle_fwd_push<IR_SH_FWD>(v, bv, b, xs, st.tacc, k);
             stamp();
-            if (k) {
-                // this bundle's columns of the top rows of L against the slice in LDS
-                for (int i = 0; i < k; ++i) {
-                    const int tb = fold.rseg[(b * k + i) * 2], te = fold.rseg[(b * k + i) * 2 + 1];
-                    double a0 = 0.0, a1 = 0.0;
-                    int t = tb + tid;
-                    for (; t + BWG < te; t += 2 * BWG) {
-                        const int j0 = v.Rcol[t], j1 = v.Rcol[t + BWG];
-                        const double v0 = v.Rx[t], v1 = v.Rx[t + BWG];
-                        a0 += v0 * xs[j0 - s0];
-                        a1 += v1 * xs[j1 - s0];
-                    }
-                    for (; t < te; t += BWG) a0 += v.Rx[t] * xs[v.Rcol[t] - s0];
-                    const double sum = block_sum(a0 + a1, red);
-                    if (tid == 0) ir_store(&shf[(size_t)b * k + i], sum);
-                }
-            }
+            // this bundle's shares of the top rows of L (accumulated by the pushes)
+            if (tid < k) ir_store(&shf[(size_t)b * k + tid], st.tacc[tid]);
             // D^-1 of the backward sweep (qdldl.rs:737-752) before the barrier: it does not need the top
             for (int i = tid; i < nloc; i += BWG) xs[i] *= v.Dinv[s0 + i];
             if (k) {
@@ -2257,7 +2333,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             }
             __syncthreads();
             stamp();
-            bundle_sweep_lds<false, IR_SH_BWD>(v, bv, b, xs, st.dxt, NF, red, fat, nfat);
+            bundle_bwd_lds<IR_SH_BWD>(v, bv, b, xs, st.dxt, red, fat, nfat);
             stamp();
             {
                 // the candidate: x (round 0) or x + dx (directldlkktsolver.rs:300 axpby(1, x, 1))
@@ -2284,7 +2360,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 }
                 __syncthreads(); // the candidate's slice is visible workgroup-wide
                 stamp();
-                bundle_symv_body<true, IR_SH_SYMV>(bv, v.Up, v.Ucol, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
+                bundle_symv_body<true, IR_SH_SYMV>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
                                        xs, red, fold, b, st.candt, &pn[(size_t)par * nb + b],
                                        &shs[(size_t)par * nb * k + (size_t)b * k]);
             }

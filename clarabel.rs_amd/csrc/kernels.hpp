@@ -24,6 +24,11 @@ struct LdlView {
     const int *Up, *Ucol;
     const double *Ux;
     const double *eps_ptr; // static regulariser (device scalar) applied to the diagonal while it is read; nullptr: none
+    // bundles + folded top only (else nullptr): 16-bit bundle-local row indices parallel to Li / Ucol for the
+    // bundle part (host.hpp: Symbolic::Li16); mirror_rows: the factorisation keeps the row-major copy Rx
+    // up to date (the fused solve kernel does not read it)
+    const unsigned short *Li16, *Ucol16;
+    int mirror_rows;
 };
 
 // subtree bundles: bundle b = nodes [bundle_ptr[b], bundle_ptr[b+1]); its level boundaries are

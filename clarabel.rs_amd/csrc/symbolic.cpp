@@ -642,6 +642,32 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             }
         }
     }
+    // ---- 16-bit bundle-local indices for the fused solve kernel (k_bundle_ir) ----------------
+    // Systems that are bundles plus at most a folded top: row index i of an entry of a bundle column /
+    // U row becomes i - s0 (its bundle starts at s0) when i lies in the bundle, nloc + (i - NF) for the
+    // (at most TOPFOLD_MAX) top rows -- 2 bytes per entry instead of 4 in all three sweeps.
+    {
+        const i32 nbun = S.bundle_ptr.empty() ? 0 : (i32)S.bundle_ptr.size() - 1;
+        const bool eligible = nbun > 0 && (S.nfold > 0 || S.NF == n) && S.max_bundle_nodes + TOPFOLD_MAX < 65535;
+        if (eligible) {
+            const i64 nLb = S.Lp[S.NF];
+            S.Li16.resize((size_t)nLb + 1);
+            S.Ucol16.resize((size_t)S.nnzU + 1);
+            for (i32 b = 0; b < nbun; b++) {
+                const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1], nloc = s1 - s0;
+                for (i32 j = s0; j < s1; j++) {
+                    for (i32 q = S.Lp[j]; q < S.Lp[j + 1]; q++) {
+                        const i32 i = S.Li[q];
+                        S.Li16[q] = (uint16_t)(i < s1 ? i - s0 : nloc + (i - S.NF));
+                    }
+                    for (i32 u = S.Up[j]; u < S.Up[j + 1]; u++) {
+                        const i32 i = S.Ucol[u];
+                        S.Ucol16[u] = (uint16_t)(i < s1 ? i - s0 : nloc + (i - S.NF));
+                    }
+                }
+            }
+        }
+    }
     // ---- blocked substitution for tall tops -----------------------------------
     {
         const i32 ntop = (i32)n - S.NF;

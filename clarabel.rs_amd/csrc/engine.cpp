@@ -208,6 +208,13 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             std::vector<long long> up(S.upd_ptr.begin(), S.upd_ptr.end());
             if ((rc = upload(&upd_ptr, up, up.size()))) return rc;
         }
+        {
+            std::vector<i32> bp((size_t)nsn + 1, 0);
+            for (int sn = 0; sn < nsn; sn++) bp[sn + 1] = bp[sn] + (S.sn_ptr[sn + 1] - S.sn_ptr[sn] + 63) / 64;
+            if ((rc = upload(&sn_blk_ptr, bp, bp.size()))) return rc;
+            if ((rc = alloc(&sn_flags, (size_t)bp[nsn] + 1))) return rc;
+            CHIP_HIP(hipMemset(sn_flags, 0, ((size_t)bp[nsn] + 1) * sizeof(int)));
+        }
         sn_lvl_ptr = S.sn_lvl_ptr;
         sn_lvl_nblk = S.sn_lvl_nblk;
         sn_lvl_hmax = S.sn_lvl_hmax;
@@ -523,16 +530,23 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         // that are not supernode members, then the level's supernodes solve their dense triangles and
         // push L_BS x_S to their ancestors' entries; backward: the reverse, column oriented.
         const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot};
+        // wide supernodes: several workgroups per supernode, pipelined through per-block flags that carry this
+        // sweep's epoch (not inside a captured graph: a replay would meet its own flags)
+        static const bool no_tri = std::getenv("CHIP_NO_SNODE_TRI") != nullptr;
+        const bool use_tri = !no_tri && !st.use_graph;
+        dev::SnodeTriView tri{sn_blk_ptr, sn_flags, 0, norm_nan(1)};
         dev::GatherArgs f{Rf_p, Rf_col, Rfx, xp, xp, nullptr, nullptr, nullptr};
+        tri.epoch = ++sn_epoch;
         for (int l = 0; l < nfaclevels; l++) {
             dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
             dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp);
+                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr);
         }
+        tri.epoch = ++sn_epoch;
         dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
         for (int l = nfaclevels - 1; l >= 0; l--) {
             dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp);
+                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr);
             const dev::ChunkView b = bwu.B(l);
             if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwu.BR(l));
             dev::gather_merged(stream, dev::BWD, g, bwu.T(l), bwu.W(l), b);

@@ -1472,6 +1472,149 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
 }
 
 // ---------------------------------------------------------------------------
+// Substitutions through WIDE chain supernodes with several workgroups per supernode (config 5: 830..1750
+// member columns; one workgroup streaming a 6 MB triangle is latency bound at ~30 GB/s).  The triangle
+// (I + L_SS) is cut into 64 x 64 blocks; workgroup (r, s) owns block row r of supernode s of the level:
+//   forward :  x_r <- (I + L_rr)^-1 (x_r - sum_{c < r} L_rc x_c)
+//   backward:  x_r <- (I + L_rr)^-T (x_r - sum_{c > r} L_cr' x_c)      (x_r already scaled by D^-1 and
+//                                                                        with L_BS' x_B taken off: k_snode_pull)
+// as a pipeline INSIDE one launch: a workgroup consumes block c as soon as the flag of x_c shows this
+// sweep's epoch, its own 64 x 64 products accumulated in registers (lane = row of the block, every wave a
+// quarter of the columns; the cross-lane / cross-wave reduction happens once at the end), then solves its
+// diagonal block in one wave and publishes x_r and its flag.  A workgroup only ever waits for workgroups
+// with a SMALLER linear block id (the backward launch numbers the block rows in reverse), which the
+// dispatcher starts first -- the usual synchronisation-free sparse triangular solve -- and the wait times
+// out rather than hang.  x_c and the flags cross workgroups inside the launch: device-coherent atomic
+// stores / loads, no agent-scope fence (see ir_arrive_wait).  The rows of B are handled by k_snode_push /
+// k_snode_pull in their own launches.
+// ---------------------------------------------------------------------------
+constexpr int SN2_WG = 256;
+template <bool FWDMODE>
+__global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                      const int *__restrict__ blk_ptr, int *flags, int epoch,
+                                                      double *x, int *timeout_flag) {
+    __shared__ double Tl[SN_NB * SN_NB];
+    __shared__ double xc[SN_NB];
+    __shared__ double part[SN2_WG / 64][SN_NB];
+    __shared__ int colbase_r[SN_NB], colbase_c[SN_NB];
+    __shared__ int s_ok;
+    const int sn = order[blockIdx.y];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int nblk = (g.w + SN_NB - 1) / SN_NB;
+    if ((int)blockIdx.x >= nblk) return;
+    const int r = FWDMODE ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = r * SN_NB, nbw = min(SN_NB, g.w - j0);
+    int *fl = flags + blk_ptr[sn];
+    constexpr int CPW = SN_NB / (SN2_WG / 64); // columns (forward) / columns of the own block (backward) per wave
+    if (tid < SN_NB) colbase_r[tid] = tid < nbw ? v.Lp[g.cols[j0 + tid]] - (j0 + tid) - 1 : 0;
+    // the diagonal block, requested before the pipeline starts (it does not depend on x)
+    __syncthreads();
+    for (int idx = tid; idx < SN_NB * SN_NB; idx += SN2_WG) {
+        const int ii = idx / SN_NB, jj = idx % SN_NB;
+        Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[colbase_r[jj] + j0 + ii] : 0.0;
+    }
+    double acc[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) acc[q] = 0.0;
+    const int nsteps = FWDMODE ? r : nblk - 1 - r;
+    for (int step = 0; step < nsteps; ++step) {
+        const int c = FWDMODE ? step : nblk - 1 - step;
+        const int c0 = c * SN_NB, ncw = min(SN_NB, g.w - c0);
+        __syncthreads(); // xc / colbase_c of the previous step consumed
+        if (tid == 0) {
+            int ok = 1;
+            long long spins = 0;
+            while (__hip_atomic_load(&fl[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1ll << 22)) {
+                    ok = 0;
+                    *timeout_flag = 1;
+                    break;
+                }
+            }
+            s_ok = ok;
+        }
+        if (FWDMODE && tid >= 64 && tid < 128) {
+            const int t = tid - 64;
+            colbase_c[t] = t < ncw ? v.Lp[g.cols[c0 + t]] - (c0 + t) - 1 : 0;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        if (tid < SN_NB)
+            xc[tid] = tid < ncw ? __hip_atomic_load(&x[g.cols[c0 + tid]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        __syncthreads();
+        if (FWDMODE) {
+            // acc[lane = row i of block r] += L(j0 + i, c0 + j) x_c[j] for this wave's columns j
+            if (lane < nbw) {
+                double lv[CPW];
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) {
+                    const int j = wave * CPW + q;
+                    lv[q] = j < ncw ? v.Lx[colbase_c[j] + j0 + lane] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) acc[0] += lv[q] * xc[wave * CPW + q];
+            }
+        } else {
+            // acc[q] (column j = wave * CPW + q of block r) += L(c0 + lane, j0 + j) x_c[lane], reduced over lanes later
+            if (lane < ncw) {
+                double lv[CPW];
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) {
+                    const int j = wave * CPW + q;
+                    lv[q] = j < nbw ? v.Lx[colbase_r[j] + c0 + lane] : 0.0;
+                }
+                const double xv = xc[lane];
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) acc[q] += lv[q] * xv;
+            }
+        }
+    }
+    __syncthreads();
+    // reduce: forward across the waves (each holds its columns' share of every row), backward across lanes
+    if (FWDMODE) {
+        part[wave][lane] = acc[0];
+    } else {
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const double tot = wave_sum(acc[q]);
+            if (lane == 0) part[0][wave * CPW + q] = tot;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double xv = 0.0;
+        if (lane < nbw) {
+            xv = x[g.cols[j0 + lane]]; // (this block's own entries: last written before this launch)
+            if (FWDMODE) {
+#pragma unroll
+                for (int w = 0; w < SN2_WG / 64; ++w) xv -= part[w][lane];
+            } else {
+                xv -= part[0][lane];
+            }
+        }
+        if (FWDMODE) {
+            for (int jj = 0; jj < nbw; ++jj) {
+                const double xj = __shfl(xv, jj);
+                if (lane > jj) xv -= Tl[lane * SN_NB + jj] * xj;
+            }
+        } else {
+            for (int jj = nbw - 1; jj >= 0; --jj) {
+                const double xj = __shfl(xv, jj);
+                if (lane < jj) xv -= Tl[jj * SN_NB + lane] * xj;
+            }
+        }
+        if (lane < nbw) __hip_atomic_store(&x[g.cols[j0 + lane]], xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every lane's store has been acknowledged (s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)) before the flag
+        // is stored: two stores to different addresses are not ordered by the memory system
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) __hip_atomic_store(&fl[r], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // row-gather family: forward substitution (rows of L), backward substitution
 // fused with D^-1 (columns of L = rows of L'), and the residual e = b - K x.
 //   FWD : out[r]  = out[r] - sum val[t] * xin[idx[t]]           (qdldl.rs:708-719)
@@ -1836,8 +1979,10 @@ __device__ __forceinline__ int ir_arrive_wait(int *ctl, int gen, int nwg) {
     __shared__ int s_state;
     __syncthreads();
     if (threadIdx.x == 0) {
-        // this thread's atomic stores of the partial results have completed before the arrival is issued
+        // this thread's atomic stores of the partial results have completed (been acknowledged) before the
+        // arrival is issued
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
         const int sub = blockIdx.x % IR_NSUB;
         const int members = nwg / IR_NSUB + (sub < nwg % IR_NSUB ? 1 : 0);
         int state = IR_WAITED;
@@ -1865,6 +2010,7 @@ __device__ __forceinline__ void ir_release(int *ctl, int gen, int nwg) {
     // (the published results were stored by thread 0; it orders them before the release words)
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
         for (int q = 0; q < min(IR_NSUB, nwg); ++q)
             __hip_atomic_store(ctl + 32 * (1 + IR_NSUB + q), gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -4632,8 +4778,28 @@ int snode_kernel_attributes(int wmax, int nbmax) {
 // wlvl / nblvl: maxima over the supernodes of this launch.  Levels with a large B part run it in
 // separate multi-workgroup launches: one workgroup per supernode is latency bound.
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
-                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x) {
+                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri) {
     if (!count) return;
+    if (tri && tri->flags && wlvl > 2 * SN_NB) {
+        // wide supernodes: the triangle by several workgroups per supernode (k_snode_tri), the rows of B by
+        // their own multi-workgroup launches
+        const int nblkmax = (wlvl + SN_NB - 1) / SN_NB;
+        if (m == FWD) {
+            k_snode_tri<true><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->flags, tri->epoch, x,
+                                                                    tri->timeout_flag);
+            if (nblvl > 0)
+                k_snode_push<<<dim3((nblvl + SN_WG - 1) / SN_WG, (wlvl + SN_PCH - 1) / SN_PCH, count), SN_WG, 0, s>>>(
+                    v, sv, order, x);
+        } else {
+            int cap = SN_XB_CAP;
+            const int nbcap = std::min(nbmax_all, cap);
+            k_snode_pull<<<dim3((wlvl + SN_NB - 1) / SN_NB, count), SN_WG, (size_t)nbcap * sizeof(double), s>>>(
+                v, sv, order, x, nbcap);
+            k_snode_tri<false><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->flags, tri->epoch, x,
+                                                                     tri->timeout_flag);
+        }
+        return;
+    }
     int cap = SN_XB_CAP;
     if (const char *e = std::getenv("CHIP_SN_XB_CAP")) cap = std::max(1, std::min(SN_XB_CAP, std::atoi(e))); // tests
     const int nbcap = std::min(nbmax_all, cap);

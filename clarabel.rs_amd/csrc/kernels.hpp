@@ -178,9 +178,17 @@ void gather_chain(hipStream_t s, GatherMode m, const GatherArgs &a, const int *t
                   const int *w_idx, const int *w_ptr, int l0, int l1);
 // T + W + B lists of one level in a single launch (B rows still need gather_Bprep first)
 void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t, ListView w, ChunkView c);
+// pipelined multi-workgroup substitution through wide supernodes (k_snode_tri): blk_ptr[sn] = first flag of
+// supernode sn (one per 64-column block), epoch = the value a finished block's flag carries in this sweep
+struct SnodeTriView {
+    const int *blk_ptr;
+    int *flags;
+    int epoch;
+    int *timeout_flag;
+};
 // forward / backward substitution through the supernodes order[0..count) of one unit level
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
-                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x);
+                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri = nullptr);
 // ||v[rows]||inf of a short row list into the slots (the B rows of a SYMV)
 void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long *nrm, int *nan);
 

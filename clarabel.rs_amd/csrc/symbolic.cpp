@@ -241,13 +241,15 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             sub_work[parent[j]] += sub_work[j];
         }
     const bool no_bundles = std::getenv("CHIP_NO_BUNDLES") != nullptr;
+    i64 max_work = BUNDLE_MAX_WORK; // (CHIP_BUNDLE_MAX_WORK: tuning / tests)
+    if (const char *e = std::getenv("CHIP_BUNDLE_MAX_WORK")) max_work = std::max<i64>(1, std::atoll(e));
     std::vector<char> top((size_t)n, 0);
     i64 NF = 0, maxsub = 0;
     for (i32 j = 0; j < n; j++) {
         // (a long column belongs to a dense front near the root: it is left to the top -- chain
         // supernodes -- even when its subtree is small; the top stays closed under "parent of")
         if (no_bundles || sub_nodes[j] > BUNDLE_MAX_NODES || sub_ent[j] > BUNDLE_MAX_ENTRIES || cnt[j] > BUNDLE_MAX_COL ||
-            sub_work[j] > BUNDLE_MAX_WORK)
+            sub_work[j] > max_work)
             top[j] = 1;
         if (top[j] && parent[j] >= 0) top[parent[j]] = 1;
         if (!top[j]) NF++;
@@ -266,11 +268,16 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     }
     // subtrees in order of their first node (keeps the ordering's locality), packed greedily
     std::vector<i32> first((size_t)nsub, -1), sub_size((size_t)nsub, 0);
+    std::vector<i64> sub_w((size_t)nsub, 0); // factorisation work of each subtree
+    i64 forest_work = 0, maxsub_work = 0;
     for (i32 j = 0; j < n; j++)
         if (sub[j] >= 0) {
             if (first[sub[j]] < 0) first[sub[j]] = j;
             sub_size[sub[j]]++;
+            sub_w[sub[j]] += (i64)cnt[j] * cnt[j];
+            forest_work += (i64)cnt[j] * cnt[j];
         }
+    for (i32 t = 0; t < nsub; t++) maxsub_work = std::max(maxsub_work, sub_w[t]);
     std::vector<i32> sorder((size_t)nsub);
     std::iota(sorder.begin(), sorder.end(), 0);
     std::sort(sorder.begin(), sorder.end(), [&](i32 a, i32 b) { return first[a] < first[b]; });
@@ -278,17 +285,22 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     cap = std::max<i64>(cap, maxsub);
     cap = std::max<i64>(cap, 256);
     cap = std::min<i64>(cap, BUNDLE_MAX_NODES);
+    // ... and balanced by WORK as well: one workgroup factors a bundle from start to finish, so the launch
+    // lasts as long as its heaviest bundle (config 2: a few bundles full of heavy subtrees took 17.8 ms)
+    const i64 wcap = std::max<i64>(std::max<i64>(forest_work / BUNDLE_TARGET_COUNT, maxsub_work), 4096);
     std::vector<i32> bundle_of_sub((size_t)nsub, 0);
     i32 nb = 0;
     {
-        i64 cur = 0;
+        i64 cur = 0, curw = 0;
         for (i32 s : sorder) {
-            if (cur > 0 && cur + sub_size[s] > cap) {
+            if (cur > 0 && (cur + sub_size[s] > cap || curw + sub_w[s] > wcap)) {
                 nb++;
                 cur = 0;
+                curw = 0;
             }
             bundle_of_sub[s] = nb;
             cur += sub_size[s];
+            curw += sub_w[s];
         }
         if (nsub > 0) nb++;
     }

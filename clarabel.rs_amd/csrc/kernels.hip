@@ -1121,78 +1121,84 @@ __global__ __launch_bounds__(SN_WG) void k_snode_extend(LdlView v, SnodeView sv,
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = v.Lp[g.cols[t]] - t - 1;
     snode_tiles<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SN_NB, g.nb - c0), g.w, row_begin);
 }
-// grid (supernodes of the level): the SN_NB x SN_NB diagonal block of block column b, column by
-// column in LDS (two barriers per column; the pivots and their regularisation stay in LDS until
-// the end); leaves the scaled block in Lx / Rx and (d, 1/d) in D / Dinv
+// grid (supernodes of the level): the SN_NB x SN_NB diagonal block of block column b, right-looking, the
+// block in REGISTERS: thread (row i = lane, column quarter q = wave) holds T[i][16 q .. 16 q + 15]; the loop
+// over the 64 columns is fully unrolled, so every register index is a compile-time constant.  Per column ONE
+// barrier: the wave that owns the column publishes it UNSCALED together with the pivot candidate (the running
+// diagonal entry of that row) in LDS -- double buffered --, then every thread evaluates the pivot rule of
+// qdldl.rs:645-665 itself, scales (l = c / d, as the reference: c * (1/d)) and applies the rank-1 update to
+// its 16 entries and to its row's running diagonal.  (The previous version kept the block in LDS with two
+// barriers and a div/mod-indexed trailing update per column: 91 us per block column; this step is the
+// sequential part of every supernode's factorisation.)  Leaves the scaled block in Lx, (d, 1/d) in D / Dinv.
 constexpr int SN_DWG = 256;
 __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, const int *__restrict__ order,
                                                        int b) {
-    __shared__ double T[SN_NB * SN_NB]; // row-major
-    __shared__ double dl[SN_NB], dinvl[SN_NB], lcol[SN_NB], sgn[SN_NB];
+    __shared__ double lcol[2][SN_NB];
+    __shared__ double sgn[SN_NB];
     __shared__ int colbase[SN_NB];
-    __shared__ int nreg, bad;
     const int sn = order[blockIdx.x];
     const SnodeGeom g = snode_geom(v, sv, sn);
     const int j0 = b * SN_NB;
     if (j0 >= g.w) return;
-    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x;
-    if (tid < nbw) {
-        const int c = g.cols[j0 + tid];
-        colbase[tid] = v.Lp[c] - (j0 + tid) - 1;
-        dl[tid] = v.D[c];
-        sgn[tid] = (double)v.dsigns[c];
-    }
-    if (tid == 0) nreg = 0, bad = 0;
-    __syncthreads();
-    for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_DWG) {
-        const int ii = idx / SN_NB, jj = idx % SN_NB;
-        T[idx] = (ii > jj && ii < nbw) ? v.Lx[colbase[jj] + j0 + ii] : 0.0;
+    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    const bool live = i < nbw;
+    if (tid < SN_NB) {
+        const int c = tid < nbw ? g.cols[j0 + tid] : 0;
+        colbase[tid] = tid < nbw ? v.Lp[c] - (j0 + tid) - 1 : 0;
+        sgn[tid] = tid < nbw ? (double)v.dsigns[c] : 1.0; // (rows beyond a narrow last block: an identity)
     }
     __syncthreads();
-    for (int jj = 0; jj < nbw; ++jj) {
-        // pivot rule (qdldl.rs:645-665), evaluated redundantly by every thread from LDS
-        double d = dl[jj];
+    const int ci = live ? g.cols[j0 + i] : 0;
+    double di = live ? v.D[ci] : 1.0; // running diagonal entry of row i (kept by all four threads of the row)
+    double T[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int j = 16 * q + cc;
+        T[cc] = (live && j < nbw && i > j) ? v.Lx[colbase[j] + j0 + i] : 0.0;
+    }
+    double dfin = 1.0, dinvfin = 1.0; // pivot of row i, recorded by the threads of wave 0
+    int nreg = 0, bad = 0;
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int qq = jj >> 4, c = jj & 15, buf = jj & 1;
+        if (q == qq) lcol[buf][i] = i == jj ? di : T[c]; // the column, unscaled (0 above the diagonal), + the pivot candidate
+        __syncthreads();
+        double d = lcol[buf][jj];
         const double sg = sgn[jj];
         const bool reg = d * sg < v.reg_eps;
         if (reg) d = v.reg_delta * sg;
         const double dinv = 1.0 / d;
-        if (tid == 0) {
-            if (reg) nreg++;
+        if (q == 0 && i == jj) {
+            dfin = d;
+            dinvfin = dinv;
+            if (reg) nreg = 1;
             if (d == 0.0) bad |= 2;
             if (!isfinite(dinv)) bad |= 1;
-            dinvl[jj] = dinv;
         }
-        if (tid > jj && tid < nbw) {
-            const double l = T[tid * SN_NB + jj] * dinv;
-            lcol[tid] = l;
-            T[tid * SN_NB + jj] = l;
+        const double l = i > jj ? lcol[buf][i] * dinv : 0.0;
+        if (q == qq) T[c] = l;
+        const double w = l * d;
+        di -= w * l;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int j2 = 16 * q + cc;
+            const double l2 = j2 > jj ? lcol[buf][j2] * dinv : 0.0;
+            T[cc] -= w * l2;
         }
-        __syncthreads();
-        if (tid == 0) dl[jj] = d;
-        const int rem = nbw - jj - 1; // trailing (ii >= j2 > jj) part of the block
-        for (int idx = tid; idx < rem * rem; idx += SN_DWG) {
-            const int ii = jj + 1 + idx / rem, j2 = jj + 1 + idx % rem;
-            if (ii >= j2) {
-                const double upd = lcol[ii] * d * lcol[j2];
-                if (ii == j2) dl[j2] -= upd;
-                else T[ii * SN_NB + j2] -= upd;
-            }
-        }
-        __syncthreads();
     }
-    if (tid < nbw) {
-        const int c = g.cols[j0 + tid];
-        v.D[c] = dl[tid];
-        v.Dinv[c] = dinvl[tid];
-    }
-    if (tid == 0) {
-        if (nreg) atomicAdd(&v.status[2], nreg);
+    if (q == 0 && live) {
+        v.D[ci] = dfin;
+        v.Dinv[ci] = dinvfin;
+        if (nreg) atomicAdd(&v.status[2], 1);
         if (bad & 2) v.status[1] = 1;
         if (bad & 1) v.status[0] = 1;
     }
-    for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_DWG) { // the block's strict lower triangle
-        const int ii = idx / SN_NB, jj = idx % SN_NB;
-        if (ii > jj && ii < nbw) v.Lx[colbase[jj] + j0 + ii] = T[idx];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int j = 16 * q + cc;
+        if (live && j < nbw && i > j) v.Lx[colbase[j] + j0 + i] = T[cc];
     }
 }
 // grid (row groups of SN_DWG rows, supernodes of the level): the rows below the diagonal block of
@@ -1489,15 +1495,14 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
 // k_snode_pull in their own launches.
 // ---------------------------------------------------------------------------
 constexpr int SN2_WG = 256;
+constexpr int SN2_WMAX = 4096; // widest supernode (symbolic.cpp: SN_MAX_W); its column bases are kept in LDS
 template <bool FWDMODE>
 __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, const int *__restrict__ order,
                                                       const int *__restrict__ blk_ptr, int *flags, int epoch,
                                                       double *x, int *timeout_flag) {
     __shared__ double Tl[SN_NB * SN_NB];
-    __shared__ double xc[SN_NB];
     __shared__ double part[SN2_WG / 64][SN_NB];
-    __shared__ int colbase_r[SN_NB], colbase_c[SN_NB];
-    __shared__ int s_ok;
+    __shared__ int colbase[SN2_WMAX]; // forward: of all earlier columns; backward: of the own block only
     const int sn = order[blockIdx.y];
     const SnodeGeom g = snode_geom(v, sv, sn);
     const int nblk = (g.w + SN_NB - 1) / SN_NB;
@@ -1506,72 +1511,64 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = r * SN_NB, nbw = min(SN_NB, g.w - j0);
     int *fl = flags + blk_ptr[sn];
-    constexpr int CPW = SN_NB / (SN2_WG / 64); // columns (forward) / columns of the own block (backward) per wave
-    if (tid < SN_NB) colbase_r[tid] = tid < nbw ? v.Lp[g.cols[j0 + tid]] - (j0 + tid) - 1 : 0;
-    // the diagonal block, requested before the pipeline starts (it does not depend on x)
+    constexpr int CPW = SN_NB / (SN2_WG / 64); // columns per wave: of block c (forward) / of the own block (backward)
+    // nothing below depends on x: column bases, the diagonal block and the own entries are requested first
+    const int cb_lo = FWDMODE ? 0 : j0, cb_hi = j0 + nbw;
+    for (int t = cb_lo + tid; t < cb_hi; t += SN2_WG) colbase[t - cb_lo] = v.Lp[g.cols[t]] - t - 1;
+    double xown = (wave == 0 && lane < nbw) ? x[g.cols[j0 + lane]] : 0.0; // (last written before this launch)
     __syncthreads();
+    const int *cbr = colbase + (FWDMODE ? j0 : 0); // column bases of the own block
     for (int idx = tid; idx < SN_NB * SN_NB; idx += SN2_WG) {
         const int ii = idx / SN_NB, jj = idx % SN_NB;
-        Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[colbase_r[jj] + j0 + ii] : 0.0;
+        Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[cbr[jj] + j0 + ii] : 0.0;
     }
     double acc[CPW];
 #pragma unroll
     for (int q = 0; q < CPW; ++q) acc[q] = 0.0;
     const int nsteps = FWDMODE ? r : nblk - 1 - r;
-    for (int step = 0; step < nsteps; ++step) {
+    // every WAVE runs the pipeline on its own (no workgroup barrier per step): it requests the L entries of
+    // the next step, waits for the flag of x_c, reads x_c (one entry per lane) and accumulates
+    double lv[CPW], ln[CPW];
+    auto request = [&](double(&dst)[CPW], int step) {
         const int c = FWDMODE ? step : nblk - 1 - step;
         const int c0 = c * SN_NB, ncw = min(SN_NB, g.w - c0);
-        __syncthreads(); // xc / colbase_c of the previous step consumed
-        if (tid == 0) {
-            int ok = 1;
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const int j = wave * CPW + q;
+            if (FWDMODE) dst[q] = (lane < nbw && j < ncw) ? v.Lx[colbase[c0 + j] + j0 + lane] : 0.0; // L(j0 + lane, c0 + j)
+            else dst[q] = (lane < ncw && j < nbw) ? v.Lx[cbr[j] + c0 + lane] : 0.0;                  // L(c0 + lane, j0 + j)
+        }
+    };
+    if (nsteps > 0) request(ln, 0);
+    bool ok = true;
+    for (int step = 0; step < nsteps && ok; ++step) {
+        const int c = FWDMODE ? step : nblk - 1 - step;
+        const int c0 = c * SN_NB, ncw = min(SN_NB, g.w - c0);
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) lv[q] = ln[q];
+        if (step + 1 < nsteps) request(ln, step + 1);
+        if (lane == 0) {
             long long spins = 0;
             while (__hip_atomic_load(&fl[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1ll << 22)) {
-                    ok = 0;
+                    ok = false;
                     *timeout_flag = 1;
                     break;
                 }
             }
-            s_ok = ok;
         }
-        if (FWDMODE && tid >= 64 && tid < 128) {
-            const int t = tid - 64;
-            colbase_c[t] = t < ncw ? v.Lp[g.cols[c0 + t]] - (c0 + t) - 1 : 0;
-        }
-        __syncthreads();
-        if (!s_ok) return;
-        if (tid < SN_NB)
-            xc[tid] = tid < ncw ? __hip_atomic_load(&x[g.cols[c0 + tid]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        __syncthreads();
+        ok = __shfl((int)ok, 0, 64) != 0;
+        if (!ok) break;
+        const double xcv = lane < ncw ? __hip_atomic_load(&x[g.cols[c0 + lane]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         if (FWDMODE) {
-            // acc[lane = row i of block r] += L(j0 + i, c0 + j) x_c[j] for this wave's columns j
-            if (lane < nbw) {
-                double lv[CPW];
 #pragma unroll
-                for (int q = 0; q < CPW; ++q) {
-                    const int j = wave * CPW + q;
-                    lv[q] = j < ncw ? v.Lx[colbase_c[j] + j0 + lane] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < CPW; ++q) acc[0] += lv[q] * xc[wave * CPW + q];
-            }
+            for (int q = 0; q < CPW; ++q) acc[0] += lv[q] * __shfl(xcv, wave * CPW + q, 64);
         } else {
-            // acc[q] (column j = wave * CPW + q of block r) += L(c0 + lane, j0 + j) x_c[lane], reduced over lanes later
-            if (lane < ncw) {
-                double lv[CPW];
 #pragma unroll
-                for (int q = 0; q < CPW; ++q) {
-                    const int j = wave * CPW + q;
-                    lv[q] = j < nbw ? v.Lx[colbase_r[j] + c0 + lane] : 0.0;
-                }
-                const double xv = xc[lane];
-#pragma unroll
-                for (int q = 0; q < CPW; ++q) acc[q] += lv[q] * xv;
-            }
+            for (int q = 0; q < CPW; ++q) acc[q] += lv[q] * xcv;
         }
     }
-    __syncthreads();
     // reduce: forward across the waves (each holds its columns' share of every row), backward across lanes
     if (FWDMODE) {
         part[wave][lane] = acc[0];
@@ -1582,11 +1579,10 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
             if (lane == 0) part[0][wave * CPW + q] = tot;
         }
     }
-    __syncthreads();
-    if (wave == 0) {
-        double xv = 0.0;
+    __syncthreads(); // (also: Tl is complete)
+    if (wave == 0 && ok) {
+        double xv = xown;
         if (lane < nbw) {
-            xv = x[g.cols[j0 + lane]]; // (this block's own entries: last written before this launch)
             if (FWDMODE) {
 #pragma unroll
                 for (int w = 0; w < SN2_WG / 64; ++w) xv -= part[w][lane];

@@ -71,8 +71,8 @@ struct chip_kkt {
     dev::Ns3View ns3{};      // Exponential / Power cones
     dev::GpwView gpw{};      // generalised power cones
     std::vector<int> gpw_cone_index, gpw_state_off, gpw_dim1; // host copies (alpha setter)
-    dev::PsdView psd{};      // PSD triangle cones with matrix side <= 64
-    bool has_hostHs = false; // cones whose Hs must come from the host (PSD with side > 64)
+    dev::PsdView psd{};      // PSD triangle cones (any matrix side)
+    bool has_hostHs = false; // cones whose Hs must come from the host (none of the SupportedConeT kinds any more)
     double *d_s = nullptr, *d_z = nullptr, *d_w = nullptr, *d_lam = nullptr;
     double *d_rhs = nullptr, *d_lhs = nullptr; // n+m staging
     double *bp = nullptr, *x = nullptr, *e = nullptr, *dx = nullptr; // N, permuted numbering
@@ -437,7 +437,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
             for (i64 k = 0; k < c.numel; k++) gp_map.push_back(k2v[(size_t)K.sp_u[K.sp_ptr[sidx] + k]]);
             for (int k = 0; k < 3; k++) gp_mapD.push_back(k2v[(size_t)K.sp_D[3 * sidx + k]]);
             h->gpw_cone_index.push_back((int)(&c - K.cones.data()));
-        } else if (c.tag == CHIP_CONE_PSDTRIANGLE && c.dim <= 64) {
+        } else if (c.tag == CHIP_CONE_PSDTRIANGLE) {
             pd_start.push_back((int)c.start);
             pd_dim.push_back((int)c.dim);
             pd_hs.push_back((int)c.block_start);
@@ -494,6 +494,12 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
         if ((rc = E.upload(&q3, pd_hs, pd_hs.size()))) return rc;
         if ((rc = E.upload(&q4, pd_off, pd_off.size()))) return rc;
         if ((rc = E.alloc(&qs, (size_t)(pd_state ? pd_state : 1)))) return rc;
+        pv.scratch = nullptr;
+        pv.scratch_stride = 0;
+        if (pd_max > 64) { // beyond the LDS budget of three / four n x n matrices: work matrices in HBM
+            pv.scratch_stride = 4LL * pd_max * pd_max + 4LL * pd_max + 16;
+            if ((rc = E.alloc(&pv.scratch, (size_t)pv.scratch_stride * pd_start.size()))) return rc;
+        }
         pv.start = q1;
         pv.dim = q2;
         pv.hs_start = q3;
@@ -705,7 +711,7 @@ static int update_enqueue(chip_kkt *h, const double *hsblocks_or_null) {
         if (!hsblocks_or_null)
             return fail(CHIP_ERR_ARG, "update: Hs blocks are required for PSD cones");
         for (const ConeSpec &c : K.cones) {
-            if (c.tag != CHIP_CONE_PSDTRIANGLE || c.dim <= 64) continue;
+            if (c.tag <= CHIP_CONE_PSDTRIANGLE) continue; // (held on the device)
             CHIP_HIP(hipMemcpyAsync(h->d_tmp + c.block_start, hsblocks_or_null + c.block_start,
                                     (size_t)c.block_len * sizeof(double), hipMemcpyHostToDevice, E.stream));
             dev::scatter_values(E.stream, E.Kx, h->mapHs + c.block_start, h->d_tmp + c.block_start,
@@ -1118,7 +1124,7 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval) {
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     if (!h) return CHIP_ERR_ARG;
     if (h->has_hostHs)
-        return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: PSD cones with side > 64 are not held on the device");
+        return fail(CHIP_ERR_UNSUPPORTED, "mul_Hs: a cone kind that is not held on the device");
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
@@ -1134,7 +1140,7 @@ int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev) {
     return fail(CHIP_ERR_UNSUPPORTED, "margins / scaled_unit_shift: symmetric, device-held cones only")
 #define NEED_STEP_OPS(h)                                                                       \
     if ((h)->has_hostHs)                                                                       \
-    return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: PSD cones with side > 64 are not held on the device")
+    return fail(CHIP_ERR_UNSUPPORTED, "cone step operations: a cone kind that is not held on the device")
 
 int32_t chip_kkt_scaled_unit_shift_dev(chip_kkt *h, double *z_dev, double alpha, int32_t primal_cone) {
     if (!h || !z_dev) return CHIP_ERR_ARG;

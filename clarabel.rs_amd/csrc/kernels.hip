@@ -3359,6 +3359,10 @@ __device__ bool lds_cholesky(double *A, int n, int *flag) {
 }
 
 // state of one PSD cone in HBM (3 n^2 + 2 n doubles): B = R R' (n*n) | lambda (n) | lambda^-1/2 (n) | R (n*n) | Rinv (n*n)
+// GS = false: the four n x n work matrices live in LDS (n <= 64); GS = true: in this cone's slice of a scratch
+// buffer in HBM (L2 resident: 4 n^2 doubles = 0.5 MB at n = 128) -- the same algorithm for cones of any size
+// (the reference calls LAPACK and has no limit, psdtrianglecone.rs:144-204)
+template <bool GS>
 __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const double *__restrict__ sv,
                                                            const double *__restrict__ zv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3367,7 +3371,8 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
     if (c >= v.ncones) return;
     const int n = v.dim[c], tid = threadIdx.x;
     // A: S -> L1, Bm: Z -> L2, Cm: M = L2' L1 -> U Sigma, Vm: V
-    double *A = (double *)smem, *Bm = A + n * n, *Cm = Bm + n * n, *Vm = Cm + n * n;
+    double *A = GS ? v.scratch + (size_t)c * v.scratch_stride : (double *)smem;
+    double *Bm = A + n * n, *Cm = Bm + n * n, *Vm = Cm + n * n;
     double *sig = Vm + n * n, *sgn = sig + n;
     int *rank = (int *)(sgn + n);
     const double *s = sv + v.start[c], *z = zv + v.start[c];
@@ -3402,14 +3407,14 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
         if (tid == 0) rotated = 0;
         __syncthreads();
         for (int r = 0; r < np - 1; ++r) {
-            if (tid < np / 2) {
+            for (int pr = tid; pr < np / 2; pr += WG) {
                 int p, q;
-                if (tid == 0) {
+                if (pr == 0) {
                     p = np - 1;
                     q = r;
                 } else {
-                    p = (r + tid) % (np - 1);
-                    q = (r - tid + np - 1) % (np - 1);
+                    p = (r + pr) % (np - 1);
+                    q = (r - pr + np - 1) % (np - 1);
                 }
                 if (p < n && q < n) {
                     double *mp = Cm + p * n, *mq = Cm + q * n;
@@ -3548,14 +3553,14 @@ __device__ double psd_eig_min(double *A, int n, double *cs, double *red, int *fl
         if (tid == 0) *flag = 0;
         __syncthreads();
         for (int r = 0; r < np - 1; ++r) {
-            if (tid < half) {
+            for (int pr = tid; pr < half; pr += WG) {
                 int p, q;
-                if (tid == 0) {
+                if (pr == 0) {
                     p = np - 1;
                     q = r;
                 } else {
-                    p = (r + tid) % (np - 1);
-                    q = (r - tid + np - 1) % (np - 1);
+                    p = (r + pr) % (np - 1);
+                    q = (r - pr + np - 1) % (np - 1);
                 }
                 if (p > q) {
                     const int t = p;
@@ -3575,10 +3580,10 @@ __device__ double psd_eig_min(double *A, int n, double *cs, double *red, int *fl
                 } else {
                     p = -1;
                 }
-                pp[tid] = p;
-                qq[tid] = q;
-                cc[tid] = c;
-                ss[tid] = sn;
+                pp[pr] = p;
+                qq[pr] = q;
+                cc[pr] = c;
+                ss[pr] = sn;
             }
             __syncthreads();
             // columns: A <- A J
@@ -3633,7 +3638,7 @@ __device__ __forceinline__ PsdState psd_state(const PsdView &v, int c, int n) {
 //   OP 4 step_length (:235-279, 437-463) with i0 = dz, i1 = ds, alpha_max = sc -> partial[c]
 //   OP 5 margins (:104-121) of i0 -> partial[c] (min eig), partial2[c] (sum of positive eigs)
 //   OP 6 barrier (:281-303) at (i0, i1) + sc (i2, i3) -> partial[c]
-template <int OP>
+template <int OP, bool GS>
 __global__ __launch_bounds__(WG) void k_psd_ops(PsdView v, double *o0, double *o1, double *o2,
                                                 const double *__restrict__ i0, const double *__restrict__ i1,
                                                 const double *__restrict__ i2, const double *__restrict__ i3,
@@ -3644,7 +3649,8 @@ __global__ __launch_bounds__(WG) void k_psd_ops(PsdView v, double *o0, double *o
     const int c = blockIdx.x;
     if (c >= v.ncones) return;
     const int n = v.dim[c], off = v.start[c], tid = threadIdx.x;
-    double *X = (double *)smem, *Y = X + n * n, *T = Y + n * n, *cs = T + n * n;
+    double *X = GS ? v.scratch + (size_t)c * v.scratch_stride : (double *)smem; // (see k_psd_update_scaling)
+    double *Y = X + n * n, *T = Y + n * n, *cs = T + n * n;
     const PsdState st = psd_state(v, c, n);
     const int numel = n * (n + 1) / 2;
     if (OP == 0) {
@@ -3763,15 +3769,19 @@ __global__ __launch_bounds__(WG) void k_psd_diag(PsdView v, double *z, double *s
 
 // get_Hs = pack_triu(skron(B)) (psdtrianglecone.rs:210-212, 467-509), negated and scattered into K.
 // Packed column-major triu: entry t <-> (row, col), row <= col; row <-> (i, j), col <-> (k, l).
+template <bool GS>
 __global__ __launch_bounds__(WG) void k_psd_write_hs(PsdView v, double *Kx, int blocks_per_cone) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *B = (double *)smem;
     const int c = blockIdx.x / blocks_per_cone, part = blockIdx.x % blocks_per_cone;
     if (c >= v.ncones) return;
     const int n = v.dim[c];
     const double *Bin = v.state + v.state_off[c];
-    for (int idx = threadIdx.x; idx < n * n; idx += WG) B[idx] = Bin[idx];
-    __syncthreads();
+    const double *B = GS ? Bin : (const double *)smem; // large cones read B = R R' where it lives (L2 resident)
+    if (!GS) {
+        double *Bl = (double *)smem;
+        for (int idx = threadIdx.x; idx < n * n; idx += WG) Bl[idx] = Bin[idx];
+        __syncthreads();
+    }
     const int numel = n * (n + 1) / 2;
     const long long total = (long long)numel * (numel + 1) / 2;
     const int *mh = v.mapHs + v.hs_start[c];
@@ -4974,15 +4984,24 @@ void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx, unsigned long lo
 }
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv) {
     if (!v.ncones) return;
+    if (v.scratch) { // cones too large for LDS: work matrices in HBM scratch
+        k_psd_update_scaling<true><<<v.ncones, WG, 0, s>>>(v, sv, zv);
+        return;
+    }
     const size_t lds = ((size_t)(4 * v.maxdim * v.maxdim + 3 * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_psd_update_scaling, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    k_psd_update_scaling<<<v.ncones, WG, lds, s>>>(v, sv, zv);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_psd_update_scaling<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_psd_update_scaling<false><<<v.ncones, WG, lds, s>>>(v, sv, zv);
 }
 void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx) {
     if (!v.ncones) return;
+    if (v.scratch) {
+        const int bpc = 64; // numel^2 / 2 entries per cone: 3.4e7 at n = 128
+        k_psd_write_hs<true><<<v.ncones * bpc, WG, 0, s>>>(v, Kx, bpc);
+        return;
+    }
     const int bpc = 16;
     const size_t lds = ((size_t)(v.maxdim * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
-    k_psd_write_hs<<<v.ncones * bpc, WG, lds, s>>>(v, Kx, bpc);
+    k_psd_write_hs<false><<<v.ncones * bpc, WG, lds, s>>>(v, Kx, bpc);
 }
 static size_t psd_ops_lds(const PsdView &v) {
     return ((size_t)(3 * v.maxdim * v.maxdim + 4 * v.maxdim + 8) * sizeof(double) + 15) & ~(size_t)15;
@@ -4992,9 +5011,13 @@ template <typename K> static void psd_allow_lds(K kernel, size_t lds) {
 }
 #define PSD_LAUNCH(OP, ...)                                                          \
     do {                                                                             \
-        const size_t lds_ = psd_ops_lds(v);                                          \
-        psd_allow_lds(k_psd_ops<OP>, lds_);                                          \
-        k_psd_ops<OP><<<v.ncones, WG, lds_, s>>>(v, __VA_ARGS__);                    \
+        if (v.scratch) {                                                             \
+            k_psd_ops<OP, true><<<v.ncones, WG, 0, s>>>(v, __VA_ARGS__);             \
+        } else {                                                                     \
+            const size_t lds_ = psd_ops_lds(v);                                      \
+            psd_allow_lds(k_psd_ops<OP, false>, lds_);                               \
+            k_psd_ops<OP, false><<<v.ncones, WG, lds_, s>>>(v, __VA_ARGS__);         \
+        }                                                                            \
     } while (0)
 void psd_mul_hs(hipStream_t s, const PsdView &v, double *y, const double *x) {
     if (v.ncones) PSD_LAUNCH(0, y, nullptr, nullptr, x, nullptr, nullptr, nullptr, 0.0, nullptr, nullptr);

@@ -261,11 +261,14 @@ struct GpwView {
     const int *mapQRP, *mapD, *mapHs; // K.nzval indices (mapD: 3 per cone)
     double *state;
 };
-// PSD triangle cones held on the device (matrix side <= 64): state per cone = B (n*n, the NT
-// scaling matrix R R') followed by lambda (n)
+// PSD triangle cones held on the device: state per cone = B (n*n, the NT scaling matrix R R') | lambda (n) |
+// lambda^-1/2 (n) | R | Rinv.  maxdim <= 64: the kernels' work matrices live in LDS (scratch == nullptr);
+// larger cones: in this cone's slice of `scratch` (scratch_stride doubles per cone, >= 4 n^2 + 4 n + 16)
 struct PsdView {
     int ncones;
     int maxdim;
+    double *scratch;
+    long long scratch_stride;
     const int *start, *dim, *hs_start, *state_off;
     double *state;
     const int *mapHs;

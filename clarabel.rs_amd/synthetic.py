@@ -170,7 +170,7 @@ def psd_scaling_Hs(S, Z):
     return H[r, c]
 
 
-def chordal_sdp(ncliques=6, dim=6, overlap=2, nsoc=3, socdim=7, seed=5):
+def chordal_sdp(ncliques=6, dim=6, overlap=2, nsoc=3, socdim=7, seed=5, with_hs=True):
     """C5 (small scale): the post-decomposition shape of chordal/decomp/augment_compact.rs:31-75:
     a chain of PSDTriangleCone(dim) cliques whose overlapping svec entries are tied by +1/-1
     columns, plus sparse-form SOCs.  Hs blocks of the PSD cones are supplied by the host
@@ -213,12 +213,13 @@ def chordal_sdp(ncliques=6, dim=6, overlap=2, nsoc=3, socdim=7, seed=5):
             G1 = rng.standard_normal((dim, dim))
             G2 = rng.standard_normal((dim, dim))
             S, Z = G1 @ G1.T + dim * np.eye(dim), G2 @ G2.T + dim * np.eye(dim)
-            cache.append((_svec(S), _svec(Z), psd_scaling_Hs(S, Z)))
+            cache.append((_svec(S), _svec(Z), psd_scaling_Hs(S, Z) if with_hs else None))
         sv, zv, h = cache[k % nscal]
         s[k * numel:(k + 1) * numel] = sv
         z[k * numel:(k + 1) * numel] = zv
         hs.append(h)
-    hs_full = np.concatenate(hs + [np.zeros(socdim)] * nsoc)
+    # (with_hs=False: large cones whose numel x numel Hs block the caller does not need on the host)
+    hs_full = np.concatenate(hs + [np.zeros(socdim)] * nsoc) if with_hs else None
     return dict(n=n, m=m, P=_csc(P), A=_csc(A), cones=cones, s=s, z=z, hsblocks=hs_full)
 
 

@@ -203,8 +203,9 @@ int32_t chip_kkt_get_map(const chip_kkt *h, uint64_t *mapP, uint64_t *mapA, uint
 /* CompositeCone::update_scaling(s, z, mu, scaling_strategy) (compositecone.rs:226-243) for
  * the cones held on the device: Nonnegative (nonnegativecone.rs:77-90), SecondOrder
  * (socone.rs:134-211), Exponential (expcone.rs:106-124) and Power (powcone.rs:99-117) with the
- * primal-dual / dual scalings of nonsymmetric_common.rs:53-143, PSDTriangle with matrix side
- * <= 64 (psdtrianglecone.rs:144-204: two Cholesky factors, SVD, R R', skron); Zero is a no-op.
+ * primal-dual / dual scalings of nonsymmetric_common.rs:53-143, PSDTriangle of any matrix side
+ * (psdtrianglecone.rs:144-204: two Cholesky factors, SVD, R R', skron; the n x n work matrices live in LDS up
+ * to side 64 and in HBM scratch beyond); Zero is a no-op.
  * strategy: 0 = ScalingStrategy::PrimalDual, 1 = ::Dual (core/solver.rs:77-80).
  * Returns the reference's bool.  s, z: m doubles (host / device variants; the _dev variant
  * defers the SOC interior check to the next chip_kkt_update so that it stays asynchronous). */
@@ -214,9 +215,9 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
                                     int32_t strategy);
 /* KKTSolver::update (directldlkktsolver.rs:134-158): Hs blocks (get_Hs fused,
  * negated), sparse-cone u/v/D columns, static regularisation, numeric refactor.
- * hsblocks_or_null: full Hsblocks vector (host) consulted ONLY for cone types
- * whose scaling is not held on the device (PSD cones with matrix side > 64); may be NULL
- * when there are none.  Returns the reference's bool. */
+ * hsblocks_or_null: full Hsblocks vector (host), consulted ONLY for cone types whose scaling is not held on
+ * the device.  Every SupportedConeT is held on the device now, so it may always be NULL; the parameter
+ * is kept for callers that compute Hs themselves.  Returns the reference's bool. */
 int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null);
 /* setrhs(rhsx, rhsz)   directldlkktsolver.rs:160-166.  The host variant copies the vectors.  The _dev
  * variant may BORROW the two device buffers until the following chip_kkt_solve* has run on the handle's
@@ -264,11 +265,11 @@ int32_t chip_kkt_update_A(chip_kkt *h, const double *Anzval);
  * y = Hs x, m doubles, device pointers. */
 int32_t chip_kkt_mul_Hs_dev(chip_kkt *h, double *y_dev, const double *x_dev);
 /* ---- the cone operations either side of the KKT solve, for problems whose
- * cones are Zero / Nonnegative / SecondOrder / Exponential / Power / GenPower / PSDTriangle
- * (side <= 64); m-vectors in HBM.  CHIP_ERR_UNSUPPORTED otherwise (larger PSD cones).  PSDTriangle:
+ * cones are Zero / Nonnegative / SecondOrder / Exponential / Power / GenPower / PSDTriangle;
+ * m-vectors in HBM.  PSDTriangle:
  * psdtrianglecone.rs:104-303 with symmetric_common.rs:53-95 -- mul_W / mul_Winv as two n x n
  * products with R / Rinv, circ_op, lambda \ ., step length and margins from the eigenvalues of a
- * parallel two-sided Jacobi iteration, barrier from a Cholesky log-determinant, all in LDS.  Exponential / Power: affine_ds = s
+ * parallel two-sided Jacobi iteration, barrier from a Cholesky log-determinant (in LDS up to side 64, in HBM scratch beyond).  Exponential / Power: affine_ds = s
  * (expcone.rs:129-131), combined_ds_shift = sigma*mu*grad - 3rd-order correction
  * (expcone.rs:133-142,254-308, powcone.rs:132-141,260-337; step_z / step_s are left unchanged),
  * ds_from_dz_offset = ds, step_length = backtracking line searches (nonsymmetric_common.rs:164-192)

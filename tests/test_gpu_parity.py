@@ -268,14 +268,15 @@ def test_c5_chordal_sdp_host_hs(hip, oracle):
     _check_update_and_solve(hip, oracle, pr, hs=pr["hsblocks"])
 
 
-@pytest.mark.parametrize("dim", [3, 8, 21, 50])
+@pytest.mark.parametrize("dim", [3, 8, 21, 50, 72])
 def test_c5_psd_scaling_on_device(hip, oracle, dim):
     """PSDTriangleCone update_scaling on the device (psdtrianglecone.rs:144-204: chol, chol, SVD,
     R R', skron) -- the Hs blocks are NOT handed over by the host; the oracle side uses the numpy
     restatement tests/problems.psd_scaling_Hs for the same (S, Z)"""
     # dim 50 = BASELINE config 5's clique size; one clique there (the generator's 4*ncliques x
     # variables would otherwise fuse four 1275-wide blocks into a single dense front)
-    pr = problems.chordal_sdp(1 if dim == 50 else 4, dim, min(3, dim - 1), 2, 7, seed=dim)
+    # (72 > 64: the work matrices of the cone kernels no longer fit LDS and live in HBM scratch)
+    pr = problems.chordal_sdp(1 if dim >= 50 else 4, dim, min(3, dim - 1), 2, 7, seed=dim)
     ks, ko, cones = _solvers(hip, oracle, pr)
     assert ks.update_scaling(pr["s"], pr["z"]) and cones.update_scaling(pr["s"], pr["z"])
     assert ks.update()              # no hsblocks: computed on the device
@@ -493,13 +494,39 @@ def test_nonsymmetric_cone_step_operations(hip, oracle, strategy):
     assert np.array_equal(uz.numpy(), rz) and np.array_equal(us.numpy(), rs)
 
 
-@pytest.mark.parametrize("dim", [3, 8, 21, 50])
+def test_psd_large_cone_hs_on_device(hip):
+    """PSDTriangleCone(128): update_scaling (two Cholesky factors, Jacobi SVD, R R') and Hs = skron(R R') on the
+    device with the work matrices in HBM scratch -- the 3.4e7 Hs entries written into K against the numpy
+    restatement, and the identity Hs z = s through mul_Hs (the oracle's scalar LDL' of an 8256-wide dense
+    front would take minutes, so no solve here: test_c5_psd_scaling_on_device[72] has it)"""
+    dim = 128
+    pr = problems.chordal_sdp(1, dim, 3, 1, 7, seed=dim, with_hs=False)
+    ks = hip.HipKKTSolver(hip.CscMatrix(pr["n"], pr["n"], *pr["P"]), hip.CscMatrix(pr["m"], pr["n"], *pr["A"]),
+                          pr["cones"], pr["m"], pr["n"])
+    assert ks.update_scaling(pr["s"], pr["z"]) and ks.update()
+    numel = dim * (dim + 1) // 2
+    S = np.zeros((dim, dim))
+    Z = np.zeros((dim, dim))
+    r, c = np.tril_indices(dim)
+    w = np.where(r == c, 1.0, 1.0 / np.sqrt(2.0))
+    S[r, c] = S[c, r] = pr["s"][:numel] * w
+    Z[r, c] = Z[c, r] = pr["z"][:numel] * w
+    hs_ref = problems.psd_scaling_Hs(S, Z)
+    mapHs = ks.maps()["Hsblocks"][:len(hs_ref)]
+    assert relerr(-ks.values()[mapHs], hs_ref) <= 1e-10
+    y, d_z = hip.DeviceArray(pr["m"]), hip.DeviceArray(pr["z"])
+    ks.mul_Hs_dev(y.ptr, d_z.ptr)
+    ks.synchronize()
+    assert relerr(y.numpy()[:numel], pr["s"][:numel]) <= 1e-9  # NT scaling: Hs z = s
+
+
+@pytest.mark.parametrize("dim", [3, 8, 21, 50, 96])
 def test_psd_cone_operations(hip, oracle, dim):
     """PSDTriangleCone operations either side of the solve on the device (one workgroup per cone:
     GEMMs with R / Rinv, Jacobi eigenvalues, Cholesky log-det) against the numpy restatement
     oracle/psd_numpy.py, in a composite with Nonnegative and SecondOrder cones"""
     from oracle import psd_numpy
-    pr = problems.chordal_sdp(1 if dim == 50 else 3, dim, min(3, dim - 1), 2, 7, seed=40 + dim)
+    pr = problems.chordal_sdp(1 if dim >= 50 else 3, dim, min(3, dim - 1), 2, 7, seed=40 + dim, with_hs=dim < 64)
     P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
     A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
     ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])

@@ -916,9 +916,9 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     static long long *dbg_dev = nullptr;
     static const bool dbg_on = std::getenv("CHIP_IR_DEBUG") != nullptr;
     if (dbg_on && !dbg_dev) {
-        (void)hipMalloc((void **)&dbg_dev, 128 * sizeof(long long));
+        (void)hipMalloc((void **)&dbg_dev, 256 * sizeof(long long));
     }
-    if (dbg_on) (void)hipMemsetAsync(dbg_dev, 0, 128 * sizeof(long long), E.stream);
+    if (dbg_on) (void)hipMemsetAsync(dbg_dev, 0, 256 * sizeof(long long), E.stream);
     ir.dbg = dbg_on ? dbg_dev : nullptr;
     h->rhs_deferred = false;
     h->x_holds_b = false;
@@ -927,7 +927,7 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     E.prof_end(PF_IR);
     if (rc) return fail(CHIP_ERR_HIP, hip_err((hipError_t)rc, "k_bundle_ir launch"));
     if (dbg_on) {
-        long long t[128];
+        long long t[256];
         (void)hipStreamSynchronize(E.stream);
         (void)hipMemcpy(t, dbg_dev, sizeof(t), hipMemcpyDeviceToHost);
         for (int w = 0; w < 2; w++) {

@@ -1746,7 +1746,7 @@ constexpr int SSHOT_DEFAULT = 3; // entries of a row per shot (registers: 2 rows
 // stays in es (e == nullptr) and the bundle's partial results -- ||e||inf of its rows (NaN when it saw one)
 // and its shares of (K x)[top rows] -- are STORED to out_norm / out_share[0..k) instead of being added to
 // shared accumulators: the consumers reduce them in a fixed order after a grid-wide barrier.
-template <bool FUSED = false, int SSHOT = SSHOT_DEFAULT>
+template <bool FUSED = false, int SSHOT = SSHOT_DEFAULT, int TW = BWG>
 __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int *__restrict__ Up,
                                                  const int *__restrict__ Ucol, const double *__restrict__ Ux,
                                                  const double *x, const double *__restrict__ b, double *e,
@@ -1760,24 +1760,24 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
     int tb[2], te[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int i = threadIdx.x + u * BWG;
+        const int i = threadIdx.x + u * TW;
         tb[u] = i < nloc ? Up[s0 + i] : 0;
         te[u] = i < nloc ? Up[s0 + i + 1] : 0;
     }
-    for (int i = threadIdx.x; i < nloc; i += BWG) es[i] = b[s0 + i];
+    for (int i = threadIdx.x; i < nloc; i += TW) es[i] = b[s0 + i];
     // folded top rows: this bundle's share of (K x)[top], per thread, reduced at the end
     double tpart = 0.0; // fold.k == 1 (the usual arrow): registers
     __shared__ double tacc[8];
     if (fold.k > 1 && threadIdx.x < 8) tacc[threadIdx.x] = 0.0;
     __syncthreads();
     // loop bounds are kept wave-uniform (lds_scatter_add uses cross-lane operations)
-    for (int w0 = wbase; w0 < nloc; w0 += 2 * BWG) {
+    for (int w0 = wbase; w0 < nloc; w0 += 2 * TW) {
         const int i0 = w0 + lane;
         double acc[2] = {0.0, 0.0}, xi[2];
         int maxlen = 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = i0 + u * BWG;
+            const int i = i0 + u * TW;
             xi[u] = i < nloc ? x[s0 + i] : 0.0;
             maxlen = max(maxlen, te[u] - tb[u]);
         }
@@ -1806,7 +1806,7 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
                         if (j >= 0) {
                             acc[u] += vv[u][q] * (j >= nloc ? xt[j - nloc] : x[s0 + j]);
                             if (j < nloc) {
-                                if (j != i0 + u * BWG) tgt = j;
+                                if (j != i0 + u * TW) tgt = j;
                             } else if (fold.k == 1) {
                                 tpart += vv[u][q] * xi[u];
                             } else {
@@ -1816,7 +1816,7 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
                     } else if (j >= 0) {
                         acc[u] += vv[u][q] * x[j];
                         if (j < s1) {
-                            if (j != s0 + i0 + u * BWG) tgt = j - s0;
+                            if (j != s0 + i0 + u * TW) tgt = j - s0;
                         } else if (fold.k == 1) {
                             tpart += vv[u][q] * xi[u];
                         } else if (fold.k > 1) {
@@ -1828,9 +1828,9 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = i0 + u * BWG;
+            const int i = i0 + u * TW;
             if (i < nloc) atomicAdd(&es[i], -acc[u]);
-            const int in = i + 2 * BWG; // the next sweep's row pointers
+            const int in = i + 2 * TW; // the next sweep's row pointers
             tb[u] = in < nloc ? Up[s0 + in] : 0;
             te[u] = in < nloc ? Up[s0 + in + 1] : 0;
         }
@@ -1838,7 +1838,7 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
     __syncthreads();
     double m = 0.0;
     bool nan = false;
-    for (int i = threadIdx.x; i < nloc; i += BWG) {
+    for (int i = threadIdx.x; i < nloc; i += TW) {
         const double val = es[i];
         if (e) e[s0 + i] = val;
         if (val != val) nan = true;
@@ -1948,9 +1948,14 @@ __global__ void k_fold_top_residual(FoldView fold, const double *__restrict__ Sx
 // Requires all workgroups to be co-resident (cooperative launch; the host checks the occupancy) when the
 // top is folded; a forest without top only synchronises for the norms.
 // ---------------------------------------------------------------------------
-// entries per shot of the three phases inside k_bundle_ir: one less than in the stand-alone kernels -- the
-// fused kernel carries ~35 pointers in scalar registers, and what does not fit spills into vector registers
-constexpr int IR_SH_FWD = 3, IR_SH_BWD = 2, IR_SH_SYMV = 3;
+// entries per shot of the three phases inside k_bundle_ir
+constexpr int IR_SH_FWD = 3, IR_SH_BWD = 3, IR_SH_SYMV = 3;
+// k_bundle_ir runs 256-thread workgroups, four per CU = 4 waves per SIMD: 128 vector registers per thread
+// instead of the 64 of the stand-alone bundle kernels (512 threads, 8 waves per SIMD) -- the fused kernel
+// carries ~35 pointers plus the software pipeline of the sweeps (entries of the next level in registers), and
+// under a 64-register budget it spilled into scratch inside the hot loops.  Each thread takes IR_RPT columns
+// of a chunk at a time.
+constexpr int IRWG = 256, IR_RPT = 2;
 constexpr int IR_FATCAP = 256; // long rows per level handled cooperatively (more: serially, still correct)
 constexpr int IR_NSUB = 32;         // sub-counters / release words of the grid barrier, one 128-byte line each
 constexpr int IR_CTL_INTS = 32 * (1 + 2 * IR_NSUB);
@@ -2048,152 +2053,117 @@ __device__ __forceinline__ double block_nanmax(double v, double *red) {
     return t;
 }
 
-// Forward substitution of bundle b over the slice xs staged in LDS, COLUMN oriented like the reference's
-// (qdldl.rs:708-719, x[Li] -= Lx * x[i]): level by level, a node whose value is final pushes it into the
-// rows of its column of L with LDS fp64 atomics.  The long rows at the top of a subtree (the u / v columns
-// of a sparse SOC: a thousand entries each) receive their contributions from all threads as the wide levels
-// below them complete -- wave-uniform targets are reduced in registers first (lds_scatter_add) -- instead of
-// being gathered by one cooperative pass per row on a serial chain of one-node levels; pushes into the
-// folded top rows (row index >= nloc) are this bundle's shares of those rows (tacc[0..k), zeroed here).
-// Streams the columns of L with 16-bit local row indices (Li16): no row-major copy of L is needed.
-template <int SH>
-__device__ __forceinline__ void bundle_fwd_push(const LdlView &v, const BundleView &bv, int b, double *xs,
-                                                double *tacc, int k) {
+// Forward / backward substitution of bundle b over the slice xs staged in LDS, both streaming the COLUMNS of
+// L (Lp, 16-bit local row indices Li16, Lx: no row-major copy of L is needed), level by level with one
+// __syncthreads() per level:
+//   forward  (qdldl.rs:708-719, x[Li] -= Lx * x[i], column oriented like the reference): a node whose value
+//            is final pushes it into the rows of its column with LDS fp64 atomics.  The long rows at the
+//            top of a subtree (the u / v columns of a sparse SOC: a thousand entries each) thus receive their
+//            contributions from all threads as the wide levels below them complete -- wave-uniform targets
+//            are reduced in registers first (lds_scatter_add) -- instead of one cooperative pass per row on a
+//            serial chain of one-node levels; pushes into the folded top rows (row index >= nloc) are this
+//            bundle's shares of those rows (tacc[0..k), zeroed here);
+//   backward (qdldl.rs:737-752; xs already holds y / d): x_j -= sum over column j of l_ij x_i, ancestors
+//            inside the bundle from LDS, the folded top rows from xt.
+// A sweep is a chain of dependent round trips (column pointers -> entries -> LDS), and the entries do NOT
+// depend on x.  The levels are therefore walked in CHUNKS of RPT x TW columns (RPT per thread) through a
+// software pipeline: while chunk c is processed, the first SH entries of the columns of chunk c + 1 and the
+// column pointers of chunk c + 2 are in flight, whatever level they belong to -- in the steady state a chunk
+// costs LDS work only (measured before: 5-7 us per 1000-node level, one exposed round trip each).  Columns
+// longer than SH take their remaining entries in place; columns longer than THIN_MAX (backward) are shared
+// by a wave after the level's last chunk.
+template <bool FWDMODE, int SH, int RPT, int TW>
+__device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const BundleView &bv, int b, double *xs,
+                                                  const double *xt, double *tacc, int k, int *fat, int &nfat) {
+    constexpr int CH = RPT * TW;
     const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
     const int *lv = bv.blvl + bv.blvl_ptr[b];
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
-    if ((int)threadIdx.x < 8) tacc[threadIdx.x] = 0.0;
-    double tpart = 0.0; // k == 1 (the usual arrow): the single top row's share in registers
-    int ntb[2] = {0, 0}, nte[2] = {0, 0};
-    auto request_ptrs = [&](int l) {
-        const int lb = lv[l], le = lv[l + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (FWDMODE && (int)threadIdx.x < 8) tacc[threadIdx.x] = 0.0;
+    double tpart = 0.0; // forward, k == 1 (the usual arrow): the single top row's share in registers
+    // chunk iterator: (level step, offset inside the level); step == nl: past the end
+    struct Chunk {
+        int step, off;
+    };
+    auto level_of = [&](int step) { return FWDMODE ? step : nl - 1 - step; };
+    auto advance = [&](Chunk c) {
+        if (c.step >= nl) return c;
+        const int l = level_of(c.step);
+        if (lv[l] + c.off + CH < lv[l + 1]) return Chunk{c.step, c.off + CH};
+        return Chunk{c.step + 1, 0};
+    };
+    int cb[RPT], ce[RPT];   // pointers of the chunk whose entries are (being) fetched
+    int p1b[RPT], p1e[RPT]; // pointers of the chunk after it
+    int ei[RPT][SH];
+    double ev[RPT][SH];
+    auto request_ptrs = [&](Chunk c, int (&pb)[RPT], int (&pe)[RPT]) {
+        const int l = level_of(c.step < nl ? c.step : nl - 1);
+        const int lb = lv[l] + c.off, le = c.step < nl ? lv[l + 1] : 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = lb + (int)threadIdx.x + u * BWG;
-            ntb[u] = j < le ? v.Lp[j] : 0;
-            nte[u] = j < le ? v.Lp[j + 1] : 0;
+        for (int u = 0; u < RPT; ++u) {
+            const int j = lb + (int)threadIdx.x + u * TW;
+            pb[u] = j < le ? v.Lp[j] : 0;
+            pe[u] = j < le ? v.Lp[j + 1] : 0;
         }
     };
-    if (nl > 0) request_ptrs(0);
-    for (int l = 0; l < nl; ++l) {
+    auto request_entries = [&](const int (&pb)[RPT], const int (&pe)[RPT]) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u)
+#pragma unroll
+            for (int e = 0; e < SH; ++e) {
+                const unsigned t = (unsigned)(pb[u] + e);
+                const bool ok = (int)t < pe[u];
+                ei[u][e] = ok ? (int)v.Li16[t] : -1;
+                ev[u][e] = ok ? v.Lx[t] : 0.0;
+            }
+    };
+    Chunk cur{0, 0};
+    Chunk nx1 = advance(cur), nx2 = advance(nx1);
+    request_ptrs(cur, cb, ce);
+    request_entries(cb, ce);
+    request_ptrs(nx1, p1b, p1e);
+    while (cur.step < nl) {
+        const int l = level_of(cur.step);
         const int lb = lv[l], le = lv[l + 1];
-        int ftb[2] = {ntb[0], ntb[1]}, fte[2] = {nte[0], nte[1]};
-        if (l + 1 < nl) request_ptrs(l + 1);
-        __syncthreads(); // every push into this level's nodes has landed
-        for (int w0 = lb + wbase; w0 < le; w0 += 2 * BWG) { // wave-uniform bounds (cross-lane operations below)
-            const bool first = w0 < lb + BWG;
-            int tb[2], te[2];
-            double yj[2];
+        const int c0 = lb + cur.off;
+        const bool level_begins = cur.off == 0, level_ends = c0 + CH >= le;
+        // this chunk's data out of the pipeline
+        int ci[RPT][SH], tb[RPT], te[RPT];
+        double cv[RPT][SH];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            tb[u] = cb[u];
+            te[u] = ce[u];
+#pragma unroll
+            for (int e = 0; e < SH; ++e) {
+                ci[u][e] = ei[u][e];
+                cv[u][e] = ev[u][e];
+            }
+        }
+        // refill: entries of the next chunk (its pointers arrived a chunk ago), pointers of the one after
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) cb[u] = p1b[u], ce[u] = p1e[u];
+        request_entries(cb, ce);
+        request_ptrs(nx2, p1b, p1e);
+        if (level_begins) {
+            __syncthreads(); // forward: every push into this level's nodes has landed; backward: its ancestors are final
+            if (!FWDMODE) {
+                if (threadIdx.x == 0) nfat = 0;
+                if (le - lb > 1) __syncthreads();
+            }
+        }
+        {
+            int jr[RPT];
+            double yj[RPT], sum[RPT];
             int maxlen = 0;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int j = w0 + lane + u * BWG;
-                tb[u] = first ? ftb[u] : (j < le ? v.Lp[j] : 0);
-                te[u] = first ? fte[u] : (j < le ? v.Lp[j + 1] : 0);
-                yj[u] = j < le ? xs[j - s0] : 0.0;
-                maxlen = max(maxlen, te[u] - tb[u]);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-            for (int kk = 0; kk < maxlen; kk += SH) {
-                int ii[2][SH];
-                double vv[2][SH];
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int e = 0; e < SH; ++e) {
-                        const unsigned t = (unsigned)(tb[u] + kk + e);
-                        const bool ok = (int)t < te[u];
-                        ii[u][e] = ok ? (int)v.Li16[t] : -1;
-                        vv[u][e] = ok ? v.Lx[t] : 0.0;
-                    }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int e = 0; e < SH; ++e) {
-                        const int i = ii[u][e];
-                        const double val = vv[u][e] * yj[u];
-                        int tgt = -1;
-                        if (i >= 0) {
-                            if (i < nloc) tgt = i;
-                            else if (k == 1) tpart += val;
-                            else atomicAdd(&tacc[i - nloc], val);
-                        }
-                        lds_scatter_add(xs, tgt, -val);
-                    }
-            }
-        }
-    }
-    __syncthreads();
-    if (k == 1) {
-        tpart = wave_sum(tpart);
-        if (lane == 0 && tpart != 0.0) atomicAdd(&tacc[0], tpart);
-        __syncthreads();
-    }
-}
-
-// Backward substitution of bundle b (qdldl.rs:737-752) over the slice xs in LDS, which already holds
-// y / d: x_j -= sum over column j of l_ij x_i, the x_i of ancestors inside the bundle from LDS, those of
-// the folded top rows from xt.  Level by level from the top of the subtrees down, two columns per thread,
-// SH entries per shot, long columns cooperatively, next level's column pointers requested a level ahead.
-template <int SH>
-__device__ __forceinline__ void bundle_bwd_lds(const LdlView &v, const BundleView &bv, int b, double *xs,
-                                               const double *xt, double *red, int *fat, int &nfat) {
-    const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
-    const int *lv = bv.blvl + bv.blvl_ptr[b];
-    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    auto xat = [&](int i) { return i < nloc ? xs[i] : xt[i - nloc]; };
-    int ntb[2] = {0, 0}, nte[2] = {0, 0};
-    auto request_ptrs = [&](int l) {
-        const int lb = lv[l], le = lv[l + 1];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = lb + (int)threadIdx.x + u * BWG;
-            ntb[u] = j < le ? v.Lp[j] : 0;
-            nte[u] = j < le ? v.Lp[j + 1] : 0;
-        }
-    };
-    if (nl > 0) request_ptrs(nl - 1);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    auto col_dot = [&](int j, int first, int stride) {
-        double sum = 0.0;
-        for (int t = v.Lp[j] + first; t < v.Lp[j + 1]; t += stride) sum += v.Lx[t] * xat((int)v.Li16[t]);
-        return sum;
-    };
-    for (int l = nl - 1; l >= 0; --l) {
-        const int lb = lv[l], le = lv[l + 1];
-        int ftb[2] = {ntb[0], ntb[1]}, fte[2] = {nte[0], nte[1]};
-        if (l > 0) request_ptrs(l - 1);
-        __syncthreads();
-        if (le - lb == 1) { // a level of its own
-            const int j = lb;
-            const int clen = v.Lp[j + 1] - v.Lp[j]; // (uniform)
-            if (clen > 256) {
-                double sum = col_dot(j, threadIdx.x, BWG);
-                sum = block_sum(sum, red);
-                if (threadIdx.x == 0) xs[j - s0] -= sum;
-            } else if (wv == 0) { // short column: one wave, no workgroup reduction
-                double sum = col_dot(j, lane, 64);
-                sum = wave_sum(sum);
-                if (lane == 0) xs[j - s0] -= sum;
-            }
-            continue;
-        }
-        if (threadIdx.x == 0) nfat = 0;
-        __syncthreads();
-        for (int j0 = lb + threadIdx.x; j0 < le; j0 += 2 * BWG) {
-            int jr[2], tb[2], te[2];
-            double sum[2];
-            const bool first = j0 < lb + BWG;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int j = j0 + u * BWG;
+            for (int u = 0; u < RPT; ++u) {
+                const int j = c0 + (int)threadIdx.x + u * TW;
                 jr[u] = j < le ? j : -1;
-                tb[u] = first ? ftb[u] : (j < le ? v.Lp[j] : 0);
-                te[u] = first ? fte[u] : (j < le ? v.Lp[j + 1] : 0);
                 sum[u] = 0.0;
-                if (te[u] - tb[u] > THIN_MAX) {
+                yj[u] = (FWDMODE && j < le) ? xs[j - s0] : 0.0;
+                if (!FWDMODE && te[u] - tb[u] > THIN_MAX) { // a long column: shared by a wave below
                     const int slot = atomicAdd(&nfat, 1);
                     if (slot < IR_FATCAP) {
                         fat[slot] = j;
@@ -2201,40 +2171,83 @@ __device__ __forceinline__ void bundle_bwd_lds(const LdlView &v, const BundleVie
                         te[u] = tb[u];
                     }
                 }
+                maxlen = max(maxlen, te[u] - tb[u]);
             }
-            const int maxlen = max(te[0] - tb[0], te[1] - tb[1]);
-            for (int kk = 0; kk < maxlen; kk += SH) {
-                int ii[2][SH];
-                double vv[2][SH];
+            if (FWDMODE) { // wave-uniform trip count (cross-lane operations below)
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+            }
+            for (int kk = 0; kk < maxlen; kk += SH) {
+                int ii[RPT][SH];
+                double vv[RPT][SH];
+                if (kk == 0) { // (prefetched)
+#pragma unroll
+                    for (int u = 0; u < RPT; ++u)
+#pragma unroll
+                        for (int e = 0; e < SH; ++e) {
+                            ii[u][e] = (tb[u] + e < te[u]) ? ci[u][e] : -1;
+                            vv[u][e] = cv[u][e];
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RPT; ++u)
+#pragma unroll
+                        for (int e = 0; e < SH; ++e) {
+                            const unsigned t = (unsigned)(tb[u] + kk + e);
+                            const bool ok = (int)t < te[u];
+                            ii[u][e] = ok ? (int)v.Li16[t] : -1;
+                            vv[u][e] = ok ? v.Lx[t] : 0.0;
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < RPT; ++u)
 #pragma unroll
                     for (int e = 0; e < SH; ++e) {
-                        const unsigned t = (unsigned)(tb[u] + kk + e);
-                        const bool ok = (int)t < te[u];
-                        ii[u][e] = ok ? (int)v.Li16[t] : -1;
-                        vv[u][e] = ok ? v.Lx[t] : 0.0;
+                        const int i = ii[u][e];
+                        if (FWDMODE) {
+                            const double val = vv[u][e] * yj[u];
+                            int tgt = -1;
+                            if (i >= 0) {
+                                if (i < nloc) tgt = i;
+                                else if (k == 1) tpart += val;
+                                else atomicAdd(&tacc[i - nloc], val);
+                            }
+                            lds_scatter_add(xs, tgt, -val);
+                        } else if (i >= 0) {
+                            sum[u] += vv[u][e] * (i < nloc ? xs[i] : xt[i - nloc]);
+                        }
                     }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int e = 0; e < SH; ++e)
-                        if (ii[u][e] >= 0) sum[u] += vv[u][e] * xat(ii[u][e]);
             }
+            if (!FWDMODE) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (jr[u] >= 0) xs[jr[u] - s0] -= sum[u];
+                for (int u = 0; u < RPT; ++u)
+                    if (jr[u] >= 0) xs[jr[u] - s0] -= sum[u];
+            }
         }
-        __syncthreads();
-        const int nf = min(nfat, IR_FATCAP);
-        for (int f = wv; f < nf; f += BWG / 64) {
-            const int j = fat[f];
-            double sum = col_dot(j, lane, 64);
-            sum = wave_sum(sum);
-            if (lane == 0) xs[j - s0] -= sum;
+        if (!FWDMODE && level_ends) { // the level's long columns, one wave each
+            __syncthreads();
+            const int nf = min(nfat, IR_FATCAP);
+            for (int f = wv; f < nf; f += TW / 64) {
+                const int j = fat[f];
+                double sacc = 0.0;
+                for (int t = v.Lp[j] + lane; t < v.Lp[j + 1]; t += 64) {
+                    const int i = (int)v.Li16[t];
+                    sacc += v.Lx[t] * (i < nloc ? xs[i] : xt[i - nloc]);
+                }
+                sacc = wave_sum(sacc);
+                if (lane == 0) xs[j - s0] -= sacc;
+            }
         }
+        cur = nx1;
+        nx1 = nx2;
+        nx2 = advance(nx2);
     }
     __syncthreads();
+    if (FWDMODE && k == 1) {
+        tpart = wave_sum(tpart);
+        if (lane == 0 && tpart != 0.0) atomicAdd(&tacc[0], tpart);
+        __syncthreads();
+    }
 }
 
 // per-workgroup state of k_bundle_ir, kept in LDS so that nothing but loop counters stays in registers
@@ -2247,7 +2260,7 @@ struct IrState {
     double tacc[8];                    // this bundle's shares of the top rows in the forward sweep
 };
 
-__global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(IRWG) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *xs = (double *)smem;
@@ -2308,7 +2321,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     auto reduce_forward = [&](int par) {
         for (int i = 0; i < k; ++i) {
             double part = 0.0;
-            for (int q = tid; q < nb; q += BWG) part += ir_load(&shf[(size_t)q * k + i]);
+            for (int q = tid; q < nb; q += IRWG) part += ir_load(&shf[(size_t)q * k + i]);
             part = block_sum(part, red);
             if (tid == 0) ir_store(&pub[par * 32 + i], part);
         }
@@ -2316,18 +2329,18 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     auto reduce_residual = [&](int par, bool first) { // norms NaN propagating
         double m = 0.0;
         if (first) {
-            for (int q = tid; q < nb; q += BWG) m = nanmax(m, ir_load(&pnb[q]));
+            for (int q = tid; q < nb; q += IRWG) m = nanmax(m, ir_load(&pnb[q]));
             m = block_nanmax(m, red);
             if (tid == 0) ir_store(&pub[par * 32 + 9], m);
             m = 0.0;
         }
-        for (int q = tid; q < nb; q += BWG) m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
+        for (int q = tid; q < nb; q += IRWG) m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
         m = block_nanmax(m, red);
         if (tid == 0) ir_store(&pub[par * 32 + 8], m);
         for (int i = 0; i < k; ++i) {
             double part = 0.0;
             if (ir.ir_enable)
-                for (int q = tid; q < nb; q += BWG) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
+                for (int q = tid; q < nb; q += IRWG) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
             part = block_sum(part, red);
             if (tid == 0) ir_store(&pub[par * 32 + 16 + i], part);
         }
@@ -2399,18 +2412,18 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             if (round == 0) {
                 double mx = 0.0;
                 bool nan = false;
-                for (int i0 = tid; i0 < nloc; i0 += 4 * BWG) { // four independent perm -> rhs chains in flight
+                for (int i0 = tid; i0 < nloc; i0 += 4 * IRWG) { // four independent perm -> rhs chains in flight
                     int o[4];
                     double val[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) o[u] = i0 + u * BWG < nloc ? ir.perm[s0 + i0 + u * BWG] : -1;
+                    for (int u = 0; u < 4; ++u) o[u] = i0 + u * IRWG < nloc ? ir.perm[s0 + i0 + u * IRWG] : -1;
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         val[u] = o[u] < 0 ? 0.0 : (o[u] < ir.n ? ir.rx[o[u]] : (o[u] < ir.n + ir.m ? ir.rz[o[u] - ir.n] : 0.0));
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (o[u] >= 0) {
-                            const int i = i0 + u * BWG;
+                            const int i = i0 + u * IRWG;
                             xs[i] = val[u];
                             ir.bp[s0 + i] = val[u];
                             if (val[u] != val[u]) nan = true;
@@ -2421,16 +2434,16 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 const bool anynan = __syncthreads_or(nan);
                 if (tid == 0) ir_store(&pnb[b], anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx);
             } else if (!single) {
-                for (int i = tid; i < nloc; i += BWG) xs[i] = ir.ebuf[s0 + i];
+                for (int i = tid; i < nloc; i += IRWG) xs[i] = ir.ebuf[s0 + i];
             } // (single: xs still holds this bundle's residual)
             __syncthreads();
             stamp();
-            bundle_fwd_push<IR_SH_FWD>(v, bv, b, xs, st.tacc, k);
+            bundle_sweep_cols<true, IR_SH_FWD, IR_RPT, IRWG>(v, bv, b, xs, nullptr, st.tacc, k, fat, nfat);
             stamp();
             // this bundle's shares of the top rows of L (accumulated by the pushes)
             if (tid < k) ir_store(&shf[(size_t)b * k + tid], st.tacc[tid]);
             // D^-1 of the backward sweep (qdldl.rs:737-752) before the barrier: it does not need the top
-            for (int i = tid; i < nloc; i += BWG) xs[i] *= v.Dinv[s0 + i];
+            for (int i = tid; i < nloc; i += IRWG) xs[i] *= v.Dinv[s0 + i];
             if (k) {
                 stamp();
                 if (tid == 0) st.gen += 1;
@@ -2475,7 +2488,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             }
             __syncthreads();
             stamp();
-            bundle_bwd_lds<IR_SH_BWD>(v, bv, b, xs, st.dxt, red, fat, nfat);
+            bundle_sweep_cols<false, IR_SH_BWD, IR_RPT, IRWG>(v, bv, b, xs, st.dxt, nullptr, k, fat, nfat);
             stamp();
             {
                 // the candidate: x (round 0) or x + dx (directldlkktsolver.rs:300 axpby(1, x, 1))
@@ -2483,14 +2496,14 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 const double *cur = sel ? ir.xb : ir.xa;
                 double *alt = sel ? ir.xa : ir.xb;
                 if (round == 0) {
-                    for (int i = tid; i < nloc; i += BWG) alt[s0 + i] = xs[i];
+                    for (int i = tid; i < nloc; i += IRWG) alt[s0 + i] = xs[i];
                 } else {
-                    for (int i = tid; i < nloc; i += BWG) alt[s0 + i] = 1.0 * cur[s0 + i] + 1.0 * xs[i];
+                    for (int i = tid; i < nloc; i += IRWG) alt[s0 + i] = 1.0 * cur[s0 + i] + 1.0 * xs[i];
                 }
                 if (!ir.ir_enable) { // no refinement: only x.is_finite() is asked for (:180)
                     double mx = 0.0;
                     bool nan = false;
-                    for (int i = tid; i < nloc; i += BWG) {
+                    for (int i = tid; i < nloc; i += IRWG) {
                         const double val = xs[i];
                         if (val != val) nan = true;
                         else mx = fmax(mx, fabs(val));
@@ -2502,7 +2515,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 }
                 __syncthreads(); // the candidate's slice is visible workgroup-wide
                 stamp();
-                bundle_symv_body<true, IR_SH_SYMV>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
+                bundle_symv_body<true, IR_SH_SYMV, IRWG>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
                                        xs, red, fold, b, st.candt, &pn[(size_t)par * nb + b],
                                        &shs[(size_t)par * nb * k + (size_t)b * k]);
             }
@@ -2546,7 +2559,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         };
         for (int b = blockIdx.x; b < nb; b += G) {
             const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
-            for (int i = tid; i < nloc; i += BWG) put(s0 + i, cur[s0 + i]);
+            for (int i = tid; i < nloc; i += IRWG) put(s0 + i, cur[s0 + i]);
         }
         if (blockIdx.x == 0 && tid < k) {
             put(NF + tid, st.curt[tid]);
@@ -4715,7 +4728,7 @@ int bundle_ir_capacity(const BundleView &bv) {
     }
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bundle_ir, BWG, lds) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bundle_ir, IRWG, lds) != hipSuccess ||
         hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
@@ -4728,7 +4741,7 @@ int bundle_ir_capacity(const BundleView &bv) {
     }
     const size_t per_wg = ((fa.sharedSizeBytes + lds + 1023) / 1024) * 1024;
     const int by_lds = (int)(prop.maxSharedMemoryPerMultiProcessor / per_wg);
-    const int by_waves = 32 / (BWG / 64);
+    const int by_waves = 32 / (IRWG / 64);
     per_cu = std::min(per_cu, std::min(by_lds, by_waves));
     return per_cu * prop.multiProcessorCount;
 }
@@ -4743,9 +4756,9 @@ int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldV
     static const bool coop = std::getenv("CHIP_IR_COOP") != nullptr;
     if (coop) {
         void *args[] = {(void *)&va, (void *)&ba, (void *)&fa, (void *)&ia};
-        return (int)hipLaunchCooperativeKernel((const void *)k_bundle_ir, dim3(grid), dim3(BWG), args, bundle_lds(bv), s);
+        return (int)hipLaunchCooperativeKernel((const void *)k_bundle_ir, dim3(grid), dim3(IRWG), args, bundle_lds(bv), s);
     }
-    k_bundle_ir<<<grid, BWG, bundle_lds(bv), s>>>(va, ba, fa, ia);
+    k_bundle_ir<<<grid, IRWG, bundle_lds(bv), s>>>(va, ba, fa, ia);
     return (int)hipGetLastError();
 }
 void fold_top_solve(hipStream_t s, const LdlView &v, const FoldView &fold, double *x) {

@@ -264,3 +264,80 @@ def test_chain_supernodes_pad_to_dense_trapezoids(hip, monkeypatch):
         if not sns:
             assert (Lp == Lp0).all()
     assert found > 0
+
+
+def test_integration_md_matches_header():
+    """INTEGRATION.md holds the Rust side of the boundary as SOURCE (no toolchain here to compile it): every
+    #[repr(C)] struct and every extern "C" prototype in it is checked against include/clarabel_hip.h --
+    field order / types, function names, parameter counts and types -- so the document cannot drift."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(root, "include", "clarabel_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+
+    def c_type(t):
+        t = " ".join(t.replace("*", " * ").split())
+        const = t.startswith("const ")
+        t = t[6:] if const else t
+        stars = t.count("*")
+        base = t.replace("*", "").strip()
+        base = {"int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "int8_t": "i8", "uint8_t": "u8", "double": "f64",
+                "char": "c_char", "void": "void", "chip_settings": "ChipSettings", "chip_info": "ChipInfo"}.get(base, base)
+        if base.startswith("chip_") or base == "void":
+            base = "c_void"  # opaque handles
+        out = base
+        for k in range(stars):
+            out = ("*const " if (const and k == 0) else "*mut ") + out
+        return out
+
+    def rust_type(t):
+        return " ".join(t.split())
+
+    # --- structs
+    for rs_name, c_name in (("ChipSettings", "chip_settings"), ("ChipInfo", "chip_info")):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % rs_name, md, flags=re.S).group(1)
+        body = re.sub(r"//[^\n]*", "", body)
+        rs_fields = [(a.strip(), rust_type(b)) for a, b in re.findall(r"(\w+)\s*:\s*([^,]+),", body)]
+        cbody = re.search(r"typedef struct \{([^}]*)\} %s;" % c_name, hdr).group(1)
+        c_fields = []
+        for decl in cbody.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"([\w ]+?)\s+([\w\[\], ]+)$", decl)
+            ty, names = m.group(1), m.group(2)
+            for nm in names.split(","):
+                nm = nm.strip()
+                arr = re.match(r"(\w+)\[(\d+)\]", nm)
+                if arr:
+                    c_fields.append((arr.group(1), "[%s; %s]" % (c_type(ty), arr.group(2))))
+                else:
+                    c_fields.append((nm, c_type(ty)))
+        assert rs_fields == c_fields, (rs_name, rs_fields, c_fields)
+    # --- prototypes
+    protos = {}
+    for m in re.finditer(r"(?:int32_t|void|const char \*)\s*(chip_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        ret = "i32" if hdr[m.start():m.start() + 7] == "int32_t" else "()"
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                arr = re.match(r"(.*?)(\w+)\[(\w*)\]$", a)  # T name[N] decays to a pointer
+                if arr:
+                    params.append(c_type(arr.group(1).strip() + " *"))
+                else:
+                    params.append(c_type(re.match(r"(.*?)(\w+)$", a).group(1).strip()))
+        protos[name] = (params, ret)
+    seen = 0
+    for block in re.findall(r'extern "C" \{(.*?)\n\}', md, flags=re.S):
+        block = re.sub(r"//[^\n]*", "", block)
+        for m in re.finditer(r"fn (chip_\w+)\s*\((.*?)\)\s*(->\s*i32)?\s*;", block, flags=re.S):
+            name, args = m.group(1), " ".join(m.group(2).split())
+            params = [rust_type(a.split(":", 1)[1]) for a in args.split(",") if a.strip()]
+            assert name in protos, "INTEGRATION.md binds %s which the header does not declare" % name
+            assert (params, "i32" if m.group(3) else "()") == protos[name], (name, params, protos[name])
+            seen += 1
+    assert seen >= 35

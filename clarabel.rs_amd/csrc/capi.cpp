@@ -923,7 +923,7 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     h->rhs_deferred = false;
     h->x_holds_b = false;
     E.prof_begin(PF_IR);
-    const int rc = dev::bundle_ir(E.stream, E.view(), E.bundles, E.fold, ir, E.ir_grid);
+    const int rc = dev::bundle_ir(E.stream, E.view(), E.bundles, E.fold, ir, E.ir_grid, E.ir_tw);
     E.prof_end(PF_IR);
     if (rc) return fail(CHIP_ERR_HIP, hip_err((hipError_t)rc, "k_bundle_ir launch"));
     if (dbg_on) {

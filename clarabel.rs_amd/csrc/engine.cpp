@@ -282,7 +282,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     }
     if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || NF == N) && !S.Li16.empty() &&
         std::getenv("CHIP_NO_FUSED_IR") == nullptr) {
-        const int cap = dev::bundle_ir_capacity(bundles);
+        const int cap = dev::bundle_ir_capacity(bundles, &ir_tw);
         if (cap > 0 && (fold.k == 0 || bundles.nb <= cap)) {
             ir_fused = true;
             if ((rc = upload(&Li16, S.Li16, S.Li16.size()))) return rc;

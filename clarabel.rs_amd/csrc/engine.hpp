@@ -109,7 +109,7 @@ struct Engine {
     bool ir_fused = false;
     bool rx_valid = false; // fused handles: the row-major copy Rx of L is only refreshed when the one-kernel-per-phase path runs
     unsigned short *Li16 = nullptr, *Ucol16 = nullptr;
-    int ir_grid = 0, ir_next = 0;
+    int ir_grid = 0, ir_next = 0, ir_tw = 256;
     int *ir_ctl = nullptr, *ir_res = nullptr, *ir_res_host = nullptr;
     double *ir_part = nullptr;
     // profiling

@@ -1955,7 +1955,7 @@ constexpr int IR_SH_FWD = 3, IR_SH_BWD = 3, IR_SH_SYMV = 3;
 // carries ~35 pointers plus the software pipeline of the sweeps (entries of the next level in registers), and
 // under a 64-register budget it spilled into scratch inside the hot loops.  Each thread takes IR_RPT columns
 // of a chunk at a time.
-constexpr int IRWG = 256, IR_RPT = 2;
+constexpr int IR_RPT = 2;
 constexpr int IR_FATCAP = 256; // long rows per level handled cooperatively (more: serially, still correct)
 constexpr int IR_NSUB = 32;         // sub-counters / release words of the grid barrier, one 128-byte line each
 constexpr int IR_CTL_INTS = 32 * (1 + 2 * IR_NSUB);
@@ -2260,7 +2260,11 @@ struct IrState {
     double tacc[8];                    // this bundle's shares of the top rows in the forward sweep
 };
 
-__global__ __launch_bounds__(IRWG) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// TW threads per workgroup: 256 when four workgroups fit a CU (4 waves per SIMD, 128 registers: config 3's
+// 3003-node bundles), 512 for bundles whose LDS slice only lets three in (config 4's 6007-node bundles: 6
+// waves per SIMD, 80 registers -- with 256 threads only 12 of a CU's 32 wave slots would be used)
+template <int TW>
+__global__ __launch_bounds__(TW) __attribute__((amdgpu_waves_per_eu(TW == 256 ? 4 : 6, TW == 256 ? 4 : 6)))
 void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *xs = (double *)smem;
@@ -2321,7 +2325,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     auto reduce_forward = [&](int par) {
         for (int i = 0; i < k; ++i) {
             double part = 0.0;
-            for (int q = tid; q < nb; q += IRWG) part += ir_load(&shf[(size_t)q * k + i]);
+            for (int q = tid; q < nb; q += TW) part += ir_load(&shf[(size_t)q * k + i]);
             part = block_sum(part, red);
             if (tid == 0) ir_store(&pub[par * 32 + i], part);
         }
@@ -2329,18 +2333,18 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     auto reduce_residual = [&](int par, bool first) { // norms NaN propagating
         double m = 0.0;
         if (first) {
-            for (int q = tid; q < nb; q += IRWG) m = nanmax(m, ir_load(&pnb[q]));
+            for (int q = tid; q < nb; q += TW) m = nanmax(m, ir_load(&pnb[q]));
             m = block_nanmax(m, red);
             if (tid == 0) ir_store(&pub[par * 32 + 9], m);
             m = 0.0;
         }
-        for (int q = tid; q < nb; q += IRWG) m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
+        for (int q = tid; q < nb; q += TW) m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
         m = block_nanmax(m, red);
         if (tid == 0) ir_store(&pub[par * 32 + 8], m);
         for (int i = 0; i < k; ++i) {
             double part = 0.0;
             if (ir.ir_enable)
-                for (int q = tid; q < nb; q += IRWG) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
+                for (int q = tid; q < nb; q += TW) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
             part = block_sum(part, red);
             if (tid == 0) ir_store(&pub[par * 32 + 16 + i], part);
         }
@@ -2412,18 +2416,18 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             if (round == 0) {
                 double mx = 0.0;
                 bool nan = false;
-                for (int i0 = tid; i0 < nloc; i0 += 4 * IRWG) { // four independent perm -> rhs chains in flight
+                for (int i0 = tid; i0 < nloc; i0 += 4 * TW) { // four independent perm -> rhs chains in flight
                     int o[4];
                     double val[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) o[u] = i0 + u * IRWG < nloc ? ir.perm[s0 + i0 + u * IRWG] : -1;
+                    for (int u = 0; u < 4; ++u) o[u] = i0 + u * TW < nloc ? ir.perm[s0 + i0 + u * TW] : -1;
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         val[u] = o[u] < 0 ? 0.0 : (o[u] < ir.n ? ir.rx[o[u]] : (o[u] < ir.n + ir.m ? ir.rz[o[u] - ir.n] : 0.0));
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (o[u] >= 0) {
-                            const int i = i0 + u * IRWG;
+                            const int i = i0 + u * TW;
                             xs[i] = val[u];
                             ir.bp[s0 + i] = val[u];
                             if (val[u] != val[u]) nan = true;
@@ -2434,16 +2438,16 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 const bool anynan = __syncthreads_or(nan);
                 if (tid == 0) ir_store(&pnb[b], anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx);
             } else if (!single) {
-                for (int i = tid; i < nloc; i += IRWG) xs[i] = ir.ebuf[s0 + i];
+                for (int i = tid; i < nloc; i += TW) xs[i] = ir.ebuf[s0 + i];
             } // (single: xs still holds this bundle's residual)
             __syncthreads();
             stamp();
-            bundle_sweep_cols<true, IR_SH_FWD, IR_RPT, IRWG>(v, bv, b, xs, nullptr, st.tacc, k, fat, nfat);
+            bundle_sweep_cols<true, IR_SH_FWD, IR_RPT, TW>(v, bv, b, xs, nullptr, st.tacc, k, fat, nfat);
             stamp();
             // this bundle's shares of the top rows of L (accumulated by the pushes)
             if (tid < k) ir_store(&shf[(size_t)b * k + tid], st.tacc[tid]);
             // D^-1 of the backward sweep (qdldl.rs:737-752) before the barrier: it does not need the top
-            for (int i = tid; i < nloc; i += IRWG) xs[i] *= v.Dinv[s0 + i];
+            for (int i = tid; i < nloc; i += TW) xs[i] *= v.Dinv[s0 + i];
             if (k) {
                 stamp();
                 if (tid == 0) st.gen += 1;
@@ -2488,7 +2492,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             }
             __syncthreads();
             stamp();
-            bundle_sweep_cols<false, IR_SH_BWD, IR_RPT, IRWG>(v, bv, b, xs, st.dxt, nullptr, k, fat, nfat);
+            bundle_sweep_cols<false, IR_SH_BWD, IR_RPT, TW>(v, bv, b, xs, st.dxt, nullptr, k, fat, nfat);
             stamp();
             {
                 // the candidate: x (round 0) or x + dx (directldlkktsolver.rs:300 axpby(1, x, 1))
@@ -2496,14 +2500,14 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 const double *cur = sel ? ir.xb : ir.xa;
                 double *alt = sel ? ir.xa : ir.xb;
                 if (round == 0) {
-                    for (int i = tid; i < nloc; i += IRWG) alt[s0 + i] = xs[i];
+                    for (int i = tid; i < nloc; i += TW) alt[s0 + i] = xs[i];
                 } else {
-                    for (int i = tid; i < nloc; i += IRWG) alt[s0 + i] = 1.0 * cur[s0 + i] + 1.0 * xs[i];
+                    for (int i = tid; i < nloc; i += TW) alt[s0 + i] = 1.0 * cur[s0 + i] + 1.0 * xs[i];
                 }
                 if (!ir.ir_enable) { // no refinement: only x.is_finite() is asked for (:180)
                     double mx = 0.0;
                     bool nan = false;
-                    for (int i = tid; i < nloc; i += IRWG) {
+                    for (int i = tid; i < nloc; i += TW) {
                         const double val = xs[i];
                         if (val != val) nan = true;
                         else mx = fmax(mx, fabs(val));
@@ -2515,7 +2519,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 }
                 __syncthreads(); // the candidate's slice is visible workgroup-wide
                 stamp();
-                bundle_symv_body<true, IR_SH_SYMV, IRWG>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
+                bundle_symv_body<true, IR_SH_SYMV, TW>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
                                        xs, red, fold, b, st.candt, &pn[(size_t)par * nb + b],
                                        &shs[(size_t)par * nb * k + (size_t)b * k]);
             }
@@ -2559,7 +2563,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         };
         for (int b = blockIdx.x; b < nb; b += G) {
             const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
-            for (int i = tid; i < nloc; i += IRWG) put(s0 + i, cur[s0 + i]);
+            for (int i = tid; i < nloc; i += TW) put(s0 + i, cur[s0 + i]);
         }
         if (blockIdx.x == 0 && tid < k) {
             put(NF + tid, st.curt[tid]);
@@ -4719,46 +4723,52 @@ void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x
 }
 int ir_ctl_ints() { return IR_CTL_INTS; }
 size_t ir_part_doubles(int nb, int k) { return (size_t)nb * (3 + 3 * (size_t)k) + 72; }
-int bundle_ir_capacity(const BundleView &bv) {
-    if (!bv.nb) return 0;
+// workgroup size of k_bundle_ir for these bundles and the largest co-resident grid (0: the kernel cannot run)
+template <int TW> static int bundle_ir_capacity_tw(const BundleView &bv) {
     const size_t lds = bundle_lds(bv);
-    if (hipFuncSetAttribute((const void *)k_bundle_ir, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)k_bundle_ir<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bundle_ir, IRWG, lds) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bundle_ir<TW>, TW, lds) != hipSuccess ||
         hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
     // cross-check with the LDS budget (static + dynamic, 1 KB allocation granularity assumed) and the wave slots
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, (const void *)k_bundle_ir) != hipSuccess) {
+    if (hipFuncGetAttributes(&fa, (const void *)k_bundle_ir<TW>) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
     const size_t per_wg = ((fa.sharedSizeBytes + lds + 1023) / 1024) * 1024;
     const int by_lds = (int)(prop.maxSharedMemoryPerMultiProcessor / per_wg);
-    const int by_waves = 32 / (IRWG / 64);
+    const int by_waves = (TW == 256 ? 16 : 24) / (TW / 64); // waves per CU the kernel was compiled for
     per_cu = std::min(per_cu, std::min(by_lds, by_waves));
     return per_cu * prop.multiProcessorCount;
 }
-int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid) {
-    LdlView va = v;
-    BundleView ba = bv;
-    FoldView fa = fold;
-    IrView ia = ir;
-    // grid <= bundle_ir_capacity(): every workgroup is resident on an otherwise idle device, and a grid
-    // barrier that cannot complete times out instead of hanging.  CHIP_IR_COOP=1 asks the runtime to
-    // validate the co-residency (cooperative launch: runs on the device's cooperative queue).
-    static const bool coop = std::getenv("CHIP_IR_COOP") != nullptr;
-    if (coop) {
-        void *args[] = {(void *)&va, (void *)&ba, (void *)&fa, (void *)&ia};
-        return (int)hipLaunchCooperativeKernel((const void *)k_bundle_ir, dim3(grid), dim3(IRWG), args, bundle_lds(bv), s);
+int bundle_ir_capacity(const BundleView &bv, int *tw) {
+    if (!bv.nb) return 0;
+    // four 256-thread workgroups per CU when the LDS slices allow it, else 512-thread workgroups
+    const int c256 = bundle_ir_capacity_tw<256>(bv);
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (c256 >= 4 * prop.multiProcessorCount) {
+        *tw = 256;
+        return c256;
     }
-    k_bundle_ir<<<grid, IRWG, bundle_lds(bv), s>>>(va, ba, fa, ia);
+    *tw = 512;
+    return bundle_ir_capacity_tw<512>(bv);
+}
+int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid,
+              int tw) {
+    // grid <= bundle_ir_capacity(): every workgroup is resident on an otherwise idle device, and a grid
+    // barrier that cannot complete times out instead of hanging
+    if (tw == 256) k_bundle_ir<256><<<grid, 256, bundle_lds(bv), s>>>(v, bv, fold, ir);
+    else k_bundle_ir<512><<<grid, 512, bundle_lds(bv), s>>>(v, bv, fold, ir);
     return (int)hipGetLastError();
 }
 void fold_top_solve(hipStream_t s, const LdlView &v, const FoldView &fold, double *x) {

@@ -127,10 +127,12 @@ struct IrView {
 };
 int ir_ctl_ints();
 size_t ir_part_doubles(int nb, int k);
-// largest co-resident grid of k_bundle_ir for these bundles (0: the kernel cannot run)
-int bundle_ir_capacity(const BundleView &bv);
+// largest co-resident grid of k_bundle_ir for these bundles (0: the kernel cannot run) and the workgroup
+// size (*tw: 256 or 512 threads) it is to be launched with
+int bundle_ir_capacity(const BundleView &bv, int *tw);
 // returns hipSuccess (0) or the launch error; grid <= bundle_ir_capacity, grid >= nb when fold.k > 0
-int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid);
+int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid,
+              int tw);
 
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);

@@ -55,15 +55,82 @@ inline int grid_for(int count) {
     return nb < 8 ? 8 : nb;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ double wave_sum_all(double v);
+__device__ __forceinline__ double wave_max_all(double v);
+// sum / max over the 64 lanes of a wavefront (every lane receives the result)
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_all(v); }
+// The same sum by data-parallel-primitive moves inside the vector ALU (row_shr 1, 2, 4, 8 inside the rows of 16
+// lanes, then row_bcast 15 / 31 across the rows: the classic gfx9 reduction) instead of six dependent trips
+// through the LDS crossbar (ds_bpermute, what __shfl_down compiles to): ~80 instead of ~700 cycles.  The total
+// is returned to EVERY lane.  Used where a reduction sits on the critical path of a sweep.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double v) { // value of the lane selected by CTRL, 0 where there is none
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v += dpp_fetch<0x111, 0xf>(v); // row_shr:1
+    v += dpp_fetch<0x112, 0xf>(v); // row_shr:2
+    v += dpp_fetch<0x114, 0xf>(v); // row_shr:4
+    v += dpp_fetch<0x118, 0xf>(v); // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += dpp_fetch<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v += dpp_fetch<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+// (lanes without a source keep their own value: old = the lane's own value, bound_ctrl off)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch_self(double v) {
+    const int l0 = __double2loint(v), h0 = __double2hiint(v);
+    const int lo = __builtin_amdgcn_update_dpp(l0, l0, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(h0, h0, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_all(double v) {
+    v = fmax(v, dpp_fetch_self<0x111, 0xf>(v));
+    v = fmax(v, dpp_fetch_self<0x112, 0xf>(v));
+    v = fmax(v, dpp_fetch_self<0x114, 0xf>(v));
+    v = fmax(v, dpp_fetch_self<0x118, 0xf>(v));
+    v = fmax(v, dpp_fetch_self<0x142, 0xa>(v));
+    v = fmax(v, dpp_fetch_self<0x143, 0xc>(v));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v) { return wave_max_all(v); }
+// the former reduction order (a butterfly through lane shuffles, lane 0 receives the result): kept for the
+// vector algebra and the cone kernels of the caller's side, see the note above "vectors" below
+__device__ __forceinline__ double wave_sum_tree(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
-__device__ __forceinline__ double wave_max(double v) {
+__device__ __forceinline__ double wave_max_tree(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
     return v;
+}
+__device__ __forceinline__ double block_sum_tree(double v, double *red) {
+    v = wave_sum_tree(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double t = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ double block_max_tree(double v, double *red) {
+    v = wave_max_tree(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double t = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, red[i]);
+    return t;
 }
 // sum over a workgroup of up to 16 waves (red[16]), result broadcast to every thread
 __device__ __forceinline__ double block_sum(double v, double *red) {
@@ -1722,10 +1789,10 @@ __global__ __launch_bounds__(WG) void k_gather_merged(GatherArgs a, const int *_
 __device__ __forceinline__ void lds_scatter_add(double *acc, int tgt, double val) {
     const unsigned long long live = __ballot(tgt >= 0);
     if (live == 0ull) return;
-    const int lead = __ffsll((long long)live) - 1;
-    const int t0 = __shfl(tgt, lead, 64);
+    const int lead = __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1);
+    const int t0 = __builtin_amdgcn_readlane(tgt, lead); // (scalar lane select: no trip through the LDS crossbar)
     if (__popcll(live) > 1 && __ballot(tgt >= 0 && tgt != t0) == 0ull) {
-        const double sum = wave_sum(tgt >= 0 ? val : 0.0);
+        const double sum = wave_sum_all(tgt >= 0 ? val : 0.0);
         if ((threadIdx.x & 63) == 0) atomicAdd(&acc[t0], sum);
     } else if (tgt >= 0) {
         atomicAdd(&acc[tgt], val);
@@ -1746,7 +1813,7 @@ constexpr int SSHOT_DEFAULT = 3; // entries of a row per shot (registers: 2 rows
 // stays in es (e == nullptr) and the bundle's partial results -- ||e||inf of its rows (NaN when it saw one)
 // and its shares of (K x)[top rows] -- are STORED to out_norm / out_share[0..k) instead of being added to
 // shared accumulators: the consumers reduce them in a fixed order after a grid-wide barrier.
-template <bool FUSED = false, int SSHOT = SSHOT_DEFAULT, int TW = BWG>
+template <bool FUSED = false, int SSHOT = SSHOT_DEFAULT, int TW = BWG, int NR = 2>
 __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int *__restrict__ Up,
                                                  const int *__restrict__ Ucol, const double *__restrict__ Ux,
                                                  const double *x, const double *__restrict__ b, double *e,
@@ -1757,9 +1824,9 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
     const int s0 = bv.bundle_ptr[bid], s1 = bv.bundle_ptr[bid + 1], nloc = s1 - s0;
     const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
     // row pointers of the first sweep are requested BEFORE the b slice is staged
-    int tb[2], te[2];
+    int tb[NR], te[NR];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NR; ++u) {
         const int i = threadIdx.x + u * TW;
         tb[u] = i < nloc ? Up[s0 + i] : 0;
         te[u] = i < nloc ? Up[s0 + i + 1] : 0;
@@ -1771,12 +1838,14 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
     if (fold.k > 1 && threadIdx.x < 8) tacc[threadIdx.x] = 0.0;
     __syncthreads();
     // loop bounds are kept wave-uniform (lds_scatter_add uses cross-lane operations)
-    for (int w0 = wbase; w0 < nloc; w0 += 2 * TW) {
+    for (int w0 = wbase; w0 < nloc; w0 += NR * TW) {
         const int i0 = w0 + lane;
-        double acc[2] = {0.0, 0.0}, xi[2];
+        double acc[NR], xi[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) acc[u] = 0.0;
         int maxlen = 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NR; ++u) {
             const int i = i0 + u * TW;
             xi[u] = i < nloc ? x[s0 + i] : 0.0;
             maxlen = max(maxlen, te[u] - tb[u]);
@@ -1784,10 +1853,10 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
         for (int k = 0; k < maxlen; k += SSHOT) {
-            int jj[2][SSHOT];
-            double vv[2][SSHOT];
+            int jj[NR][SSHOT];
+            double vv[NR][SSHOT];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < NR; ++u)
 #pragma unroll
                 for (int q = 0; q < SSHOT; ++q) {
                     const unsigned t = (unsigned)(tb[u] + k + q); // unsigned offset -> sgpr-base addressing
@@ -1797,7 +1866,7 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
                     vv[u][q] = ok ? Ux[t] : 0.0;
                 }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < NR; ++u)
 #pragma unroll
                 for (int q = 0; q < SSHOT; ++q) {
                     const int j = jj[u][q];
@@ -1827,10 +1896,10 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
                 }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NR; ++u) {
             const int i = i0 + u * TW;
             if (i < nloc) atomicAdd(&es[i], -acc[u]);
-            const int in = i + 2 * TW; // the next sweep's row pointers
+            const int in = i + NR * TW; // the next sweep's row pointers
             tb[u] = in < nloc ? Up[s0 + in] : 0;
             te[u] = in < nloc ? Up[s0 + in + 1] : 0;
         }
@@ -2173,11 +2242,8 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
                 }
                 maxlen = max(maxlen, te[u] - tb[u]);
             }
-            if (FWDMODE) { // wave-uniform trip count (cross-lane operations below)
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-            }
-            for (int kk = 0; kk < maxlen; kk += SH) {
+            // forward: wave-uniform trip count (cross-lane operations below): as long as ANY lane has entries left
+            for (int kk = 0; FWDMODE ? (__ballot(kk < maxlen) != 0ull) : (kk < maxlen); kk += SH) {
                 int ii[RPT][SH];
                 double vv[RPT][SH];
                 if (kk == 0) { // (prefetched)
@@ -2244,7 +2310,7 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
     }
     __syncthreads();
     if (FWDMODE && k == 1) {
-        tpart = wave_sum(tpart);
+        tpart = wave_sum_all(tpart);
         if (lane == 0 && tpart != 0.0) atomicAdd(&tacc[0], tpart);
         __syncthreads();
     }
@@ -2519,7 +2585,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 }
                 __syncthreads(); // the candidate's slice is visible workgroup-wide
                 stamp();
-                bundle_symv_body<true, IR_SH_SYMV, TW>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
+                bundle_symv_body<true, IR_SH_SYMV, TW, 2>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
                                        xs, red, fold, b, st.candt, &pn[(size_t)par * nb + b],
                                        &shs[(size_t)par * nb * k + (size_t)b * k]);
             }
@@ -2828,6 +2894,15 @@ __global__ __launch_bounds__(WG) void k_norm_rows(const double *__restrict__ vv,
 // ---------------------------------------------------------------------------
 // vectors
 // ---------------------------------------------------------------------------
+// From here to the end of the device code (vector algebra, dot products, cone kernels): the reductions keep
+// their former butterfly order.  Their sums feed the interior-point loop's line searches and checkpoints,
+// whose decisions the end-to-end tests compare ITERATE FOR ITERATE with the oracle-backed loop; the
+// summation order is part of what was validated there.  (The factorisation / substitution / residual kernels
+// above use the DPP reductions: their results are compared by value.)
+#define wave_sum wave_sum_tree
+#define wave_max wave_max_tree
+#define block_sum block_sum_tree
+#define block_max block_max_tree
 __global__ __launch_bounds__(WG) void k_permute_in(double *__restrict__ y, const double *__restrict__ b,
                                                    const int *__restrict__ perm, int N) {
     for (int j = logical_block() * WG + threadIdx.x; j < N; j += gridDim.x * WG) y[j] = b[perm[j]];
@@ -4529,6 +4604,11 @@ __global__ __launch_bounds__(WG) void k_gpw_ops(GpwView v, double *o0, double *o
         }
     }
 }
+
+#undef wave_sum
+#undef wave_max
+#undef block_sum
+#undef block_max
 
 } // namespace
 

@@ -87,6 +87,7 @@ struct chip_kkt {
     // permutes them in; results of enqueued solves / updates not yet collected
     const double *rhs_x = nullptr, *rhs_z = nullptr;
     bool rhs_deferred = false;
+    int *ir_run_ptr = nullptr, *ir_runs = nullptr; // run-length form of the permutation inside the bundles (dev::IrView)
     int pend_update = 0;             // 1: an update has been enqueued and its verdict not read; 2: read, kept
     int pend_update_ok = 1;
     std::vector<int> pend_slots;     // ring slots of the solves enqueued since the last collect
@@ -583,6 +584,31 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     h->tmp_len = std::max<size_t>({(size_t)K.N, (size_t)K.nHs, nnzP, nnzA, 1});
     if ((rc = E.alloc(&h->d_tmp, h->tmp_len))) return rc;
     CHIP_HIP(hipMemset(h->bp, 0, (size_t)(K.N ? K.N : 1) * sizeof(double)));
+    if (E.ir_fused) {
+        // the permutation inside every bundle as maximal ascending runs that stay inside one of the ranges
+        // [0, n) (rhsx), [n, n + m) (rhsz), [n + m, N) (zeros); used when they are long on average
+        std::vector<int> rp(1, 0), runs;
+        const std::vector<i32> &pm = E.h_perm;
+        const i64 n1 = K.n, n2 = K.n + K.m;
+        auto range_of = [&](i64 o) { return o < n1 ? 0 : (o < n2 ? 1 : 2); };
+        for (int b = 0; b < E.bundles.nb; b++) {
+            const int s0 = S.bundle_ptr[(size_t)b], s1 = S.bundle_ptr[(size_t)b + 1];
+            int t = s0;
+            while (t < s1) {
+                int e = t + 1;
+                while (e < s1 && pm[(size_t)e] == pm[(size_t)e - 1] + 1 && range_of(pm[(size_t)e]) == range_of(pm[(size_t)t])) e++;
+                runs.push_back(t - s0);
+                runs.push_back(pm[(size_t)t]);
+                runs.push_back(e - t);
+                t = e;
+            }
+            rp.push_back((int)(runs.size() / 3));
+        }
+        if (!runs.empty() && (i64)(runs.size() / 3) * 64 <= (i64)E.NF) {
+            if ((rc = E.upload(&h->ir_run_ptr, rp, rp.size()))) return rc;
+            if ((rc = E.upload(&h->ir_runs, runs, runs.size()))) return rc;
+        }
+    }
     *out = h.release();
     return CHIP_OK;
 }
@@ -672,8 +698,7 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
     if (h->soc.ncones || h->psd.ncones) CHIP_HIP(hipMemsetAsync(&E.mb_dev->soc_fail, 0, sizeof(int), E.stream));
-    dev::nn_update(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam);
-    dev::soc_update_scaling(E.stream, h->soc, s_dev, z_dev);
+    dev::sym_update_scaling(E.stream, h->soc, h->nn_rows, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam);
     dev::ns3_update_scaling(E.stream, h->ns3, s_dev, z_dev, mu, strategy);
     dev::gpw_update_scaling(E.stream, h->gpw, z_dev, mu);
     dev::psd_update_scaling(E.stream, h->psd, s_dev, z_dev);
@@ -723,8 +748,7 @@ static int update_enqueue(chip_kkt *h, const double *hsblocks_or_null) {
     // slots (no pass over the N diagonal entries); other cone kinds take the explicit reduction
     const bool slot_eps = !(h->has_hostHs || h->ns3.ncones || h->gpw.ncones || h->psd.ncones);
     unsigned long long *dslots = slot_eps && E.st.static_regularization_enable ? E.diag_slots() : nullptr;
-    dev::nn_write_hs(E.stream, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx, dslots);
-    dev::soc_write_kkt(E.stream, h->soc, E.Kx, dslots);
+    dev::sym_write_kkt(E.stream, h->soc, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx, dslots);
     dev::ns3_write_hs(E.stream, h->ns3, E.Kx);
     dev::gpw_write_kkt(E.stream, h->gpw, E.Kx);
     dev::psd_write_hs(E.stream, h->psd, E.Kx);
@@ -899,6 +923,8 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     ir.m = (int)h->K.m;
     ir.N = E.N;
     ir.perm = E.perm;
+    ir.run_ptr = h->ir_run_ptr;
+    ir.runs = h->ir_runs;
     ir.bp = h->bp;
     ir.xa = h->x;
     ir.xb = h->e;

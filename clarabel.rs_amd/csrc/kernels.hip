@@ -2316,6 +2316,7 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
     }
 }
 
+constexpr int IR_MAXRUNS = 32;
 // per-workgroup state of k_bundle_ir, kept in LDS so that nothing but loop counters stays in registers
 // across the sweeps (their inner loops need the whole 64-register budget of 8 waves per SIMD)
 struct IrState {
@@ -2324,6 +2325,7 @@ struct IrState {
     double btop[8], rtop[8], dxt[8], curt[8], candt[8];
     double dinvt[8], ltt[64], ktt[64]; // constants of the folded top: 1/d, L(top, top), K(top, top) (full rows)
     double tacc[8];                    // this bundle's shares of the top rows in the forward sweep
+    int runs[3 * IR_MAXRUNS];          // run-length form of the bundle's slice of the permutation
 };
 
 // TW threads per workgroup: 256 when four workgroups fit a CU (4 waves per SIMD, 128 registers: config 3's
@@ -2370,18 +2372,22 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         st.ktt[tid] = 0.0;
     }
     __syncthreads();
-    if (tid < 8) {
-        st.btop[tid] = tid < k ? rhs_at(NF + tid) : 0.0;
-        st.curt[tid] = 0.0;
-        st.dinvt[tid] = tid < k ? v.Dinv[NF + tid] : 0.0;
-    } else if (tid >= 64 && tid < 64 + k * k) {
-        const int q = fold.tt[tid - 64];
-        if (q >= 0) st.ltt[((tid - 64) / k) * 8 + (tid - 64) % k] = v.Lx[q];
-    } else if (tid >= 128 && tid < 128 + k) {
-        const int i = tid - 128;
-        for (int t = fold.sp[i]; t < fold.sp[i + 1]; ++t) st.ktt[i * 8 + fold.scol[t]] += v.Ux[fold.sslot[t]];
-    }
-    __syncthreads();
+    // constants of the folded top (chains of dependent loads): fetched by three different waves right before
+    // the first grid barrier, where the workgroup waits anyway -- not ahead of the staging pass
+    auto load_top_constants = [&]() {
+        if (tid < 8) {
+            st.btop[tid] = tid < k ? rhs_at(NF + tid) : 0.0;
+            st.curt[tid] = 0.0;
+            st.dinvt[tid] = tid < k ? v.Dinv[NF + tid] : 0.0;
+        } else if (tid >= 64 && tid < 64 + k * k) {
+            const int q = fold.tt[tid - 64];
+            if (q >= 0) st.ltt[((tid - 64) / k) * 8 + (tid - 64) % k] = v.Lx[q];
+        } else if (tid >= 128 && tid < 128 + k) {
+            const int i = tid - 128;
+            for (int t = fold.sp[i]; t < fold.sp[i + 1]; ++t) st.ktt[i * 8 + fold.scol[t]] += v.Ux[fold.sslot[t]];
+        }
+    };
+    if (k == 0) load_top_constants(); // (a forest: only btop / curt are cleared)
     int dbgn = 0;
     auto stamp = [&]() { // diagnostics (CHIP_IR_DEBUG): phase boundaries of workgroups 0 and G/2 on the 100 MHz clock
         if (ir.dbg && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == G / 2) && dbgn < 64)
@@ -2396,23 +2402,26 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             if (tid == 0) ir_store(&pub[par * 32 + i], part);
         }
     };
-    auto reduce_residual = [&](int par, bool first) { // norms NaN propagating
-        double m = 0.0;
-        if (first) {
-            for (int q = tid; q < nb; q += TW) m = nanmax(m, ir_load(&pnb[q]));
-            m = block_nanmax(m, red);
-            if (tid == 0) ir_store(&pub[par * 32 + 9], m);
-            m = 0.0;
+    auto reduce_residual = [&](int par, bool first) { // norms NaN propagating; every load is issued before any reduction
+        double mb = 0.0, m = 0.0, part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int q = tid; q < nb; q += TW) {
+            if (first) mb = nanmax(mb, ir_load(&pnb[q]));
+            m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
+            if (ir.ir_enable) {
+                if (k == 1) part[0] += ir_load(&shs[(size_t)par * nb + q]);
+                else
+                    for (int i = 0; i < k; ++i) part[i] += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
+            }
         }
-        for (int q = tid; q < nb; q += TW) m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
+        if (first) {
+            mb = block_nanmax(mb, red);
+            if (tid == 0) ir_store(&pub[par * 32 + 9], mb);
+        }
         m = block_nanmax(m, red);
         if (tid == 0) ir_store(&pub[par * 32 + 8], m);
         for (int i = 0; i < k; ++i) {
-            double part = 0.0;
-            if (ir.ir_enable)
-                for (int q = tid; q < nb; q += TW) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
-            part = block_sum(part, red);
-            if (tid == 0) ir_store(&pub[par * 32 + 16 + i], part);
+            const double tot = block_sum(part[i], red);
+            if (tid == 0) ir_store(&pub[par * 32 + 16 + i], tot);
         }
     };
     // the reference's decisions about the candidate of round `round`, whose residual sums were published with
@@ -2479,7 +2488,27 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         for (int b = blockIdx.x; b < nb; b += G) {
             const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
             __syncthreads();
-            if (round == 0) {
+            const int nruns = ir.runs ? ir.run_ptr[b + 1] - ir.run_ptr[b] : 0;
+            if (round == 0 && nruns > 0 && nruns <= IR_MAXRUNS) {
+                // the permutation as a few contiguous runs (descriptors in LDS): one round trip, coalesced
+                if (tid < 3 * nruns) st.runs[tid] = ir.runs[3 * ir.run_ptr[b] + tid];
+                __syncthreads();
+                double mx = 0.0;
+                bool nan = false;
+                int r = 0;
+                for (int i = tid; i < nloc; i += TW) {
+                    while (i >= st.runs[3 * r] + st.runs[3 * r + 2]) ++r; // (runs ascend in the local index)
+                    const int o = st.runs[3 * r + 1] + (i - st.runs[3 * r]);
+                    const double val = o < ir.n ? ir.rx[o] : (o < ir.n + ir.m ? ir.rz[o - ir.n] : 0.0);
+                    xs[i] = val;
+                    ir.bp[s0 + i] = val;
+                    if (val != val) nan = true;
+                    else mx = fmax(mx, fabs(val));
+                }
+                mx = block_max(mx, red);
+                const bool anynan = __syncthreads_or(nan);
+                if (tid == 0) ir_store(&pnb[b], anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx);
+            } else if (round == 0) {
                 double mx = 0.0;
                 bool nan = false;
                 for (int i0 = tid; i0 < nloc; i0 += 4 * TW) { // four independent perm -> rhs chains in flight
@@ -2516,6 +2545,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             for (int i = tid; i < nloc; i += TW) xs[i] *= v.Dinv[s0 + i];
             if (k) {
                 stamp();
+                if (round == 0) load_top_constants();
                 if (tid == 0) st.gen += 1;
                 const int state = ir_arrive_wait(ir.ctl, st.gen, G);
                 if (state == IR_TIMEOUT) {
@@ -2629,7 +2659,25 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         };
         for (int b = blockIdx.x; b < nb; b += G) {
             const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
-            for (int i = tid; i < nloc; i += TW) put(s0 + i, cur[s0 + i]);
+            const int nruns = ir.runs ? ir.run_ptr[b + 1] - ir.run_ptr[b] : 0;
+            if (nruns > 0 && nruns <= IR_MAXRUNS) {
+                __syncthreads();
+                if (tid < 3 * nruns) st.runs[tid] = ir.runs[3 * ir.run_ptr[b] + tid];
+                __syncthreads();
+                int r = 0;
+                for (int i = tid; i < nloc; i += TW) {
+                    while (i >= st.runs[3 * r] + st.runs[3 * r + 2]) ++r;
+                    const int o = st.runs[3 * r + 1] + (i - st.runs[3 * r]);
+                    const double val = cur[s0 + i];
+                    if (o < ir.n) {
+                        if (ir.lhsx) ir.lhsx[o] = val;
+                    } else if (o < ir.n + ir.m) {
+                        if (ir.lhsz) ir.lhsz[o - ir.n] = val;
+                    }
+                }
+            } else {
+                for (int i = tid; i < nloc; i += TW) put(s0 + i, cur[s0 + i]);
+            }
         }
         if (blockIdx.x == 0 && tid < k) {
             put(NF + tid, st.curt[tid]);
@@ -3030,40 +3078,6 @@ __global__ __launch_bounds__(WG) void k_norm_inf(const double *__restrict__ vv, 
 // ---------------------------------------------------------------------------
 // cones: scaling update + Hs blocks fused into the KKT value update
 // ---------------------------------------------------------------------------
-// nonnegativecone.rs:77-90
-__global__ __launch_bounds__(WG) void k_nn_update(const int *__restrict__ rows, int count,
-                                                  const double *__restrict__ sv,
-                                                  const double *__restrict__ zv, double *w, double *lam) {
-    for (int t = logical_block() * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
-        const int r = rows[t];
-        const double s = sv[r], z = zv[r];
-        lam[r] = sqrt(s * z);
-        w[r] = sqrt(s / z);
-    }
-}
-// get_Hs (nonnegativecone.rs:96-101) + negate + scatter (directldlkktsolver.rs:138-143)
-__global__ __launch_bounds__(WG) void k_nn_write_hs(const int *__restrict__ rows,
-                                                    const int *__restrict__ hsidx, int count,
-                                                    const double *__restrict__ w,
-                                                    const int *__restrict__ mapHs, double *Kx,
-                                                    unsigned long long *dslots) {
-    __shared__ double red[16];
-    double mx = 0.0;
-    bool nan = false;
-    for (int t = logical_block() * WG + threadIdx.x; t < count; t += gridDim.x * WG) {
-        const double wi = w[rows[t]];
-        const double h = wi * wi;
-        Kx[mapHs[hsidx[t]]] = -h;
-        if (h != h) nan = true;
-        else mx = fmax(mx, h);
-    }
-    if (dslots) { // |diag K| of these rows for the static regulariser (directldlkktsolver.rs:324-329)
-        mx = block_max(mx, red);
-        int *nanflag = (int *)(dslots + (size_t)NRM_SLOTS * NRM_STRIDE);
-        if (threadIdx.x == 0) fold_norm(dslots, nanflag, mx, false, blockIdx.x);
-        if (nan) *nanflag = 1;
-    }
-}
 
 // overflow-safe 2-norm of x[1..n) over a workgroup (vecmath.rs:206-226 computes the
 // same scale*sqrt(sum (x/scale)^2) with a running scale)
@@ -3084,11 +3098,28 @@ __device__ __forceinline__ double block_norm_tail(const double *x, int n, double
 // per-cone state layout in v.eta/v.d plus the rank-2 coefficients
 //   st[8*c + 0..7] = eta, d, u0, u1, v1, (unused)
 // socone.rs:134-211, one workgroup per cone
-__global__ __launch_bounds__(WG) void k_soc_update_scaling(SocView v, const double *__restrict__ sv,
-                                                           const double *__restrict__ zv) {
+// one launch for the scalings of the Nonnegative rows and the second-order cones: workgroups [0, ncones) take
+// one cone each, the following ones a slab of Nonnegative rows (nonnegativecone.rs:77-90)
+__device__ __forceinline__ void soc_update_scaling_body(const SocView &v, const double *__restrict__ sv,
+                                                        const double *__restrict__ zv, int c, double *red);
+__global__ __launch_bounds__(WG) void k_sym_update_scaling(SocView v, const int *__restrict__ nn_rows, int nn,
+                                                           const double *__restrict__ sv,
+                                                           const double *__restrict__ zv, double *w, double *lam) {
     __shared__ double red[16];
-    const int c = blockIdx.x;
-    if (c >= v.ncones) return;
+    if ((int)blockIdx.x < v.ncones) {
+        soc_update_scaling_body(v, sv, zv, blockIdx.x, red);
+        return;
+    }
+    const int nblk = gridDim.x - v.ncones, blk = blockIdx.x - v.ncones;
+    for (int t = blk * WG + threadIdx.x; t < nn; t += nblk * WG) {
+        const int r = nn_rows[t];
+        const double s = sv[r], z = zv[r];
+        lam[r] = sqrt(s * z);
+        w[r] = sqrt(s / z);
+    }
+}
+__device__ __forceinline__ void soc_update_scaling_body(const SocView &v, const double *__restrict__ sv,
+                                                        const double *__restrict__ zv, int c, double *red) {
     const int n = v.dim[c];
     const double *s = sv + v.start[c], *z = zv + v.start[c];
     double *w = v.w + v.start[c], *lam = v.lam + v.start[c];
@@ -3157,9 +3188,36 @@ __global__ __launch_bounds__(WG) void k_soc_update_scaling(SocView v, const doub
 
 // get_Hs (socone.rs:217-246) negated, and the sparse expansion columns
 // (datamaps.rs:199-220): u, v scaled by -eta^2, D = [-eta^2, +eta^2].
-__global__ __launch_bounds__(WG) void k_soc_write_kkt(SocView v, double *Kx, unsigned long long *dslots) {
-    const int c = blockIdx.x;
-    if (c >= v.ncones) return;
+__device__ __forceinline__ void soc_write_kkt_body(const SocView &v, double *Kx, unsigned long long *dslots, int c);
+// one launch for the Hs values of the second-order cones (workgroups [0, ncones)) and of the Nonnegative rows
+// (the following workgroups; get_Hs nonnegativecone.rs:96-101, negated and scattered)
+__global__ __launch_bounds__(WG) void k_sym_write_kkt(SocView v, const int *__restrict__ nn_rows,
+                                                      const int *__restrict__ nn_hsidx, int nn,
+                                                      const double *__restrict__ w, const int *__restrict__ mapHs,
+                                                      double *Kx, unsigned long long *dslots) {
+    __shared__ double red[16];
+    if ((int)blockIdx.x < v.ncones) {
+        soc_write_kkt_body(v, Kx, dslots, blockIdx.x);
+        return;
+    }
+    const int nblk = gridDim.x - v.ncones, blk = blockIdx.x - v.ncones;
+    double mx = 0.0;
+    bool nan = false;
+    for (int t = blk * WG + threadIdx.x; t < nn; t += nblk * WG) {
+        const double wi = w[nn_rows[t]];
+        const double h = wi * wi;
+        Kx[mapHs[nn_hsidx[t]]] = -h;
+        if (h != h) nan = true;
+        else mx = fmax(mx, h);
+    }
+    if (dslots) {
+        mx = block_max(mx, red);
+        int *nanflag = (int *)(dslots + (size_t)NRM_SLOTS * NRM_STRIDE);
+        if (threadIdx.x == 0) fold_norm(dslots, nanflag, mx, false, blockIdx.x);
+        if (nan) *nanflag = 1;
+    }
+}
+__device__ __forceinline__ void soc_write_kkt_body(const SocView &v, double *Kx, unsigned long long *dslots, int c) {
     const int n = v.dim[c];
     const double *w = v.w + v.start[c];
     const double *st = v.eta + 8 * c;
@@ -5070,20 +5128,17 @@ void norm_inf(hipStream_t s, const double *v, int N, unsigned long long *out, in
     if (N) k_norm_inf<<<stream_grid(N), WG, 0, s>>>(v, N, out, nanflag);
 }
 
-void nn_update(hipStream_t s, const int *rows, const int *hsidx, int count, const double *sv,
-               const double *zv, double *w, double *lam) {
-    (void)hsidx;
-    if (count) k_nn_update<<<stream_grid(count), WG, 0, s>>>(rows, count, sv, zv, w, lam);
+// Nonnegative rows + second-order cones in one launch each (scaling; Hs values)
+static int nn_blocks(int count) { return count ? std::min((count + WG - 1) / WG, 2048) : 0; }
+void sym_update_scaling(hipStream_t s, const SocView &v, const int *nn_rows, int nn, const double *sv,
+                        const double *zv, double *w, double *lam) {
+    const int grid = v.ncones + nn_blocks(nn);
+    if (grid) k_sym_update_scaling<<<grid, WG, 0, s>>>(v, nn_rows, nn, sv, zv, w, lam);
 }
-void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, const double *w,
-                 const int *mapHs, double *Kx, unsigned long long *dslots) {
-    if (count) k_nn_write_hs<<<stream_grid(count), WG, 0, s>>>(rows, hsidx, count, w, mapHs, Kx, dslots);
-}
-void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv) {
-    if (v.ncones) k_soc_update_scaling<<<v.ncones, WG, 0, s>>>(v, sv, zv);
-}
-void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx, unsigned long long *dslots) {
-    if (v.ncones) k_soc_write_kkt<<<v.ncones, WG, 0, s>>>(v, Kx, dslots);
+void sym_write_kkt(hipStream_t s, const SocView &v, const int *nn_rows, const int *nn_hsidx, int nn, const double *w,
+                   const int *mapHs, double *Kx, unsigned long long *dslots) {
+    const int grid = v.ncones + nn_blocks(nn);
+    if (grid) k_sym_write_kkt<<<grid, WG, 0, s>>>(v, nn_rows, nn_hsidx, nn, w, mapHs, Kx, dslots);
 }
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv) {
     if (!v.ncones) return;

@@ -112,6 +112,10 @@ struct IrView {
                            // the sparse-cone rows are zero (directldlkktsolver.rs:160-166)
     int n, m, N;
     const int *perm;       // perm[new] = old
+    // optional run-length form of perm inside the bundles (nullptr: per-element): bundle b owns runs
+    // [run_ptr[b], run_ptr[b+1]); run r = {first local index, first original index, length}: local index
+    // l0 + t <-> original index o0 + t, all inside ONE of the ranges [0, n), [n, n + m), [n + m, N)
+    const int *run_ptr, *runs;
     double *bp;            // N: the permuted right-hand side, kept for the residuals
     double *xa, *xb;       // N each: accepted iterate / candidate (the roles swap)
     double *ebuf;          // N: residual spill, used only when a workgroup owns several bundles
@@ -295,14 +299,14 @@ void ns3_update_scaling(hipStream_t s, const Ns3View &v, const double *sv, const
                         int strategy);
 void ns3_write_hs(hipStream_t s, const Ns3View &v, double *Kx);
 void ns3_mul_hs(hipStream_t s, const Ns3View &v, double *y, const double *x);
-void nn_update(hipStream_t s, const int *rows, const int *hsidx, int count, const double *sv,
-               const double *zv, double *w, double *lam);
+// Nonnegative rows + second-order cones, one launch each.  Scaling (nonnegativecone.rs:77-90, socone.rs:134-211)
+// and the Hs values / sparse-cone columns written into Kx (get_Hs negated, datamaps.rs:199-220).
 // dslots (may be nullptr): slotted maxima of |diagonal entries written| for the static regulariser
 // (NRM_SLOTS words of stride NRM_STRIDE + one NaN flag word at NRM_SLOTS * NRM_STRIDE)
-void nn_write_hs(hipStream_t s, const int *rows, const int *hsidx, int count, const double *w,
-                 const int *mapHs, double *Kx, unsigned long long *dslots);
-void soc_update_scaling(hipStream_t s, const SocView &v, const double *sv, const double *zv);
-void soc_write_kkt(hipStream_t s, const SocView &v, double *Kx, unsigned long long *dslots);
+void sym_update_scaling(hipStream_t s, const SocView &v, const int *nn_rows, int nn, const double *sv,
+                        const double *zv, double *w, double *lam);
+void sym_write_kkt(hipStream_t s, const SocView &v, const int *nn_rows, const int *nn_hsidx, int nn, const double *w,
+                   const int *mapHs, double *Kx, unsigned long long *dslots);
 // step / rhs operations of the symmetric cones (Zero rows, Nonnegative rows, SecondOrder cones)
 // Exponential / Power cones either side of the solve (expcone.rs:129-181, powcone.rs:128-180)
 void ns3_affine_ds(hipStream_t s, const Ns3View &v, double *ds, const double *sv);

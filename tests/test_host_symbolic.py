@@ -192,7 +192,9 @@ def test_symbolic_matches_oracle(hip, oracle, name):
     assert f0.nnzL == f.nnzL
 
 
-def test_user_perm_respected_up_to_level_sort(hip, oracle):
+def test_user_perm_respected_up_to_level_sort(hip, oracle, monkeypatch):
+    # (chain supernodes pad their columns with explicit zeros, which nnzL counts: off for the exact comparison)
+    monkeypatch.setenv("CHIP_NO_SNODE", "1")
     pr = problems.random_qp(120, 240, band=6, seed=11)
     ks0 = _mk(hip, pr)
     N = ks0.N

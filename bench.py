@@ -256,7 +256,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["auto", "c3", "c4"], default="auto")
+    ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4", "c5", "c5m"], default="auto",
+                    help="auto: c3 at N = 1, c4 at N > 1; c2 / c5 / c5m (a quarter of c5): the other BASELINE configs, "
+                         "device resident, N = 1 only")
     ap.add_argument("--nblocks", type=int, default=1000, help="c3: SOC blocks (default: config 3)")
     ap.add_argument("--blocksize", type=int, default=1000)
     ap.add_argument("--nbatch", type=int, default=1024, help="c4: independent SOCPs (default: config 4)")
@@ -284,12 +286,24 @@ def main():
     workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
     if world > 1 and workload != "c4":
         raise SystemExit("N > 1 runs the sharded batched workload (c4)")
+    if workload in ("c2", "c5", "c5m") and args.profile_family == 5:
+        args.profile_family = 0  # (no fused launch for systems with a level-scheduled top)
+    if workload in ("c5", "c5m"):
+        args.no_extras = True    # (the scalar oracle takes minutes on these dense fronts: parity is in tests/)
 
     comm = gathered = counts = None
     if workload == "c3":
         pr = problems.portfolio_socp(args.nblocks, args.blocksize, seed=3)
         desc = ("portfolio SOCP (BASELINE config 3): n=%d, Zero(1)+NN(%d)+%d x SOC(%d)"
                 % (pr["n"], pr["n"], args.nblocks, args.blocksize + 1))
+    elif workload == "c2":
+        pr = problems.random_qp(100000, 200000, band=50, seed=1)
+        desc = "random sparse QP (BASELINE config 2): n=100000, m=200000, Nonnegative cone"
+    elif workload in ("c5", "c5m"):
+        nc = 200 if workload == "c5" else 50
+        pr = problems.chordal_sdp(nc, 50, 10, nc, 51, seed=5, with_hs=False)
+        desc = ("chordal SDP (BASELINE config 5%s): %d x PSD(50) cliques with overlap 10 + %d x SOC(51); PSD scalings, "
+                "Hs = skron(R R') and all cone state on the device" % ("" if nc == 200 else ", quarter size", nc, nc))
     else:
         # whole elimination trees per rank, balanced by the blocks' factor work (identical blocks here)
         ranges = sharding.partition_blocks(np.ones(args.nbatch), world)

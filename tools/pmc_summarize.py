@@ -7,6 +7,7 @@ FETCH_SIZE tallies 128-byte requests at 64 B, i.e. reports exactly 1/2 of a coal
 stream.  Calibrated here on k_add_vec (reads 2 x 8N bytes, writes 8N): FETCH_SIZE = 8N/..."""
 import collections
 import csv
+import re
 import json
 import sys
 
@@ -17,7 +18,7 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"].replace("chip::dev::(anonymous namespace)::", "")
-        k = k.split("(")[0].replace("void ", "")
+        k = re.sub(r"<.*>", "", k.split("(")[0].replace("void ", ""))  # k_bundle_ir<256> -> k_bundle_ir
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     return {k: (c, v / c * 1024.0) for k, (c, v) in agg.items()}

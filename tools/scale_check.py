@@ -104,12 +104,12 @@ def main():
         pr = problems.batched_socp(32, 2000, 2) if small else problems.batched_socp(1024, 2000, 2, seed=100)
         run("C4 batched %d x SOCP(n=2000)" % (32 if small else 1024), pr, hip, True)
     if "c5m" in which:  # a quarter of config 5 (host setup ~15 s instead of ~60 s): kernel iteration
-        pr = problems.chordal_sdp(50, 50, 10, 50, 51, seed=5)
-        run("C5m chordal SDP 50 x PSD(50) + 50 x SOC", pr, hip, False, steps=2, hs=pr["hsblocks"])
+        pr = problems.chordal_sdp(50, 50, 10, 50, 51, seed=5, with_hs=False)
+        run("C5m chordal SDP 50 x PSD(50) + 50 x SOC (PSD scalings and Hs on the device)", pr, hip, False, steps=2)
     if "c5" in which:
         nc, dim = (8, 20) if small else (200, 50)
-        pr = problems.chordal_sdp(nc, dim, 10 if not small else 4, nc, 51 if not small else 9, seed=5)
-        run("C5 chordal SDP %d x PSD(%d) + %d x SOC" % (nc, dim, nc), pr, hip, small, steps=2, hs=pr["hsblocks"])
+        pr = problems.chordal_sdp(nc, dim, 10 if not small else 4, nc, 51 if not small else 9, seed=5, with_hs=small)
+        run("C5 chordal SDP %d x PSD(%d) + %d x SOC (PSD scalings and Hs on the device)" % (nc, dim, nc), pr, hip, small, steps=2)
 
 
 if __name__ == "__main__":

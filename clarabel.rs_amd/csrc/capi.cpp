@@ -81,6 +81,7 @@ struct chip_kkt {
     int last_ir = 0;
     double last_eps = 0;
     bool scaling_pending_check = false;
+    int scaling_gen = 0; // generation of the last update_scaling: a failing cone writes it into mailbox.soc_fail
     bool x_holds_b = false; // x was initialised with the rhs by setrhs (skips a D2D copy)
     double static_diag_max = 0.0; // max |P_ii|: the diagonal entries of K that no cone kernel writes
     // fused solve path (Engine::ir_fused): setrhs only notes the caller's device buffers, the solve kernel
@@ -697,7 +698,9 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
-    if (h->soc.ncones || h->psd.ncones) CHIP_HIP(hipMemsetAsync(&E.mb_dev->soc_fail, 0, sizeof(int), E.stream));
+    h->scaling_gen += 1; // (no memset of the flag: a failure is recognised by its generation)
+    h->soc.fail_gen = h->scaling_gen;
+    h->psd.fail_gen = h->scaling_gen;
     dev::sym_update_scaling(E.stream, h->soc, h->nn_rows, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam);
     dev::ns3_update_scaling(E.stream, h->ns3, s_dev, z_dev, mu, strategy);
     dev::gpw_update_scaling(E.stream, h->gpw, z_dev, mu);
@@ -722,7 +725,7 @@ int32_t chip_kkt_update_scaling(chip_kkt *h, const double *s, const double *z, d
         rc = E.read_mailbox();
         if (rc) return rc;
         h->scaling_pending_check = false;
-        return E.mb_host->soc_fail ? 0 : 1;
+        return E.mb_host->soc_fail == h->scaling_gen ? 0 : 1;
     }
     CHIP_HIP(hipStreamSynchronize(E.stream));
     return 1;
@@ -762,7 +765,7 @@ static int update_verdict(chip_kkt *h, int ok) {
     h->last_eps = E.st.static_regularization_enable ? E.mb_host->eps : 0.0;
     if (h->scaling_pending_check) {
         h->scaling_pending_check = false;
-        if (E.mb_host->soc_fail) return 0;
+        if (E.mb_host->soc_fail == h->scaling_gen) return 0;
     }
     return ok;
 }
@@ -975,13 +978,7 @@ static int fused_verdict(chip_kkt *h, int slot) {
     h->last_ir = r[1];
     return r[0] > 0 ? 1 : 0;
 }
-static int fused_read_ring(chip_kkt *h) {
-    Engine &E = h->E;
-    CHIP_HIP(hipMemcpyAsync(E.ir_res_host, E.ir_res, (size_t)Engine::IR_RING * 4 * sizeof(int), hipMemcpyDeviceToHost,
-                            E.stream));
-    CHIP_HIP(hipStreamSynchronize(E.stream));
-    return CHIP_OK;
-}
+static int fused_read_ring(chip_kkt *h) { return h->E.read_mailbox(); } // (the ring lives in the mailbox)
 
 int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev, double *lhsz_dev) {
     if (!h) return CHIP_ERR_ARG;
@@ -1038,12 +1035,13 @@ int32_t chip_kkt_collect(chip_kkt *h, int32_t *update_ok, int32_t *nsolves, int3
     int uok = 1;
     bool ring = false;
     for (int sl : h->pend_slots) ring = ring || sl >= 0;
-    if (ring) // (queued before the mailbox copy below: ONE synchronisation serves both)
-        CHIP_HIP(hipMemcpyAsync(E.ir_res_host, E.ir_res, (size_t)Engine::IR_RING * 4 * sizeof(int), hipMemcpyDeviceToHost,
-                                E.stream));
+    // ONE device-to-host copy (the mailbox: refactor status, cone-scaling verdict, the solves' verdict ring)
     if (h->pend_update == 1) uok = update_verdict(h, E.refactor_collect());
-    else if (h->pend_update == 2) uok = h->pend_update_ok;
-    else CHIP_HIP(hipStreamSynchronize(E.stream));
+    else {
+        if (h->pend_update == 2) uok = h->pend_update_ok;
+        if (ring && (rc = E.read_mailbox())) return rc;
+        if (!ring) CHIP_HIP(hipStreamSynchronize(E.stream));
+    }
     h->pend_update = 0;
     if (uok < 0) return uok;
     if (update_ok) *update_ok = uok;
@@ -1101,7 +1099,7 @@ int32_t chip_kkt_scaling_ok(chip_kkt *h) {
     int rc = E.read_mailbox();
     if (rc) return rc;
     h->scaling_pending_check = false;
-    return E.mb_host->soc_fail ? 0 : 1;
+    return E.mb_host->soc_fail == h->scaling_gen ? 0 : 1;
 }
 int32_t chip_kkt_solve_full(chip_kkt *h, double *x, const double *b) {
     if (!h || !x || !b) return CHIP_ERR_ARG;

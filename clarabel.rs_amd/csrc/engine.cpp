@@ -21,7 +21,6 @@ Engine::~Engine() {
     for (SolveGraph &g : graphs) (void)hipGraphExecDestroy(g.exec);
     for (void *p : allocs) (void)hipFree(p);
     if (mb_host) (void)hipHostFree(mb_host);
-    if (ir_res_host) (void)hipHostFree(ir_res_host);
     if (nrm_host) (void)hipHostFree(nrm_host);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -280,6 +279,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         topblk.ys = ysb;
         topblk.counters = cnt;
     }
+    bool need_ring = false;
     if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || NF == N) && !S.Li16.empty() &&
         std::getenv("CHIP_NO_FUSED_IR") == nullptr) {
         const int cap = dev::bundle_ir_capacity(bundles, &ir_tw);
@@ -290,16 +290,18 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             ir_grid = std::min(bundles.nb, cap);
             if ((rc = alloc(&ir_ctl, (size_t)dev::ir_ctl_ints()))) return rc;
             CHIP_HIP(hipMemset(ir_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int)));
-            if ((rc = alloc(&ir_res, (size_t)IR_RING * 4))) return rc;
-            CHIP_HIP(hipMemset(ir_res, 0, (size_t)IR_RING * 4 * sizeof(int)));
+            need_ring = true; // (ir_res = the ring inside the mailbox, set once that is allocated)
             if ((rc = alloc(&ir_part, dev::ir_part_doubles(bundles.nb, fold.k)))) return rc;
-            CHIP_HIP(hipHostMalloc((void **)&ir_res_host, (size_t)IR_RING * 4 * sizeof(int), hipHostMallocDefault));
         }
     }
     if ((rc = alloc(&mb_dev, 1))) return rc;
     CHIP_HIP(hipMemset(mb_dev, 0, sizeof(Mailbox)));
     CHIP_HIP(hipHostMalloc((void **)&mb_host, sizeof(Mailbox), hipHostMallocDefault));
     std::memset(mb_host, 0, sizeof(Mailbox));
+    if (need_ring) {
+        ir_res = mb_dev->ring; // (address arithmetic only)
+        ir_res_host = mb_host->ring;
+    }
     if ((rc = alloc(&dslot_dev, (size_t)NRM_SET_WORDS))) return rc;
     CHIP_HIP(hipMemset(dslot_dev, 0, (size_t)NRM_SET_WORDS * sizeof(unsigned long long)));
     if ((rc = alloc(&nrm_dev, (size_t)NRM_SETS * NRM_SET_WORDS))) return rc;

@@ -35,13 +35,15 @@ struct Mailbox {
     unsigned long long tmpnan;
     int nan[16];                 // NaN sightings per norm set (set 0 = ||b||, 1.. = residual rounds)
     int status[4];               // non-finite pivot, zero pivot, regularize_count, (unused)
-    int soc_fail;
+    int soc_fail;                // generation (see chip_kkt::scaling_gen) of the last failed cone scaling, 0 = none
     int pad[9];
+    int ring[64];                // verdict quads of the last 16 fused solves (Engine::ir_res points here): the
+                                 // refactor status and the solves' verdicts travel in ONE device-to-host copy
 };
 constexpr int NRM_SETS = 16;
 // u64 words per set: NRM_SLOTS slotted maxima (one per 128-byte line) + one line for the NaN flag
 constexpr int NRM_SET_WORDS = (dev::NRM_SLOTS + 1) * dev::NRM_STRIDE;
-static_assert(sizeof(Mailbox) <= 256, "mailbox");
+static_assert(sizeof(Mailbox) <= 512, "mailbox");
 
 // profile families (hipEvent pairs around each launch of ONE selected family)
 enum ProfFamily { PF_NONE = 0, PF_SYMV_T = 1, PF_BWD_T = 2, PF_FWD_T = 3, PF_FACTOR_T = 4, PF_IR = 5, PF_BFACTOR = 6, PF_COUNT };

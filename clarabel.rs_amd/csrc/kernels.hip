@@ -3131,7 +3131,7 @@ __device__ __forceinline__ void soc_update_scaling_body(const SocView &v, const 
     const double zscale = zres > 0.0 ? sqrt(zres) : 0.0;
     const double sscale = sres > 0.0 ? sqrt(sres) : 0.0;
     if (zscale == 0.0 || sscale == 0.0) {
-        if (tid == 0) *v.fail = 1;
+        if (tid == 0) *v.fail = v.fail_gen;
         return;
     }
     const double eta = sqrt(sscale / zscale);
@@ -3148,7 +3148,7 @@ __device__ __forceinline__ void soc_update_scaling_body(const SocView &v, const 
     const double wres = (w0a - w1n) * (w0a + w1n);
     const double wscale = wres > 0.0 ? sqrt(wres) : 0.0;
     if (wscale == 0.0) {
-        if (tid == 0) *v.fail = 1;
+        if (tid == 0) *v.fail = v.fail_gen;
         return;
     }
     const double rw = 1.0 / wscale;
@@ -3539,7 +3539,7 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
     }
     __syncthreads();
     if (!lds_cholesky(A, n, &flag) || !lds_cholesky(Bm, n, &flag)) {
-        if (tid == 0) *v.fail = 1;
+        if (tid == 0) *v.fail = v.fail_gen;
         return;
     }
     // M = L2' L1 ; V = I

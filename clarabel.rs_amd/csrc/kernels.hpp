@@ -245,7 +245,8 @@ struct SocView {
     const int *mapHs, *mapU, *mapV, *mapD; // K.nzval indices
     double *w, *lam;             // m-sized state
     double *eta, *d;             // per-cone state
-    int *fail;
+    int *fail;                   // a cone that leaves its interior stores fail_gen here (no clearing between updates)
+    int fail_gen;
 };
 // Exponential / Power cones (3-dimensional, non-symmetric): per-cone state of 18 doubles
 // = Hs[6] | H_dual[6] | grad[3] | z[3]
@@ -279,6 +280,7 @@ struct PsdView {
     double *state;
     const int *mapHs;
     int *fail;
+    int fail_gen;
 };
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv);
 void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx);

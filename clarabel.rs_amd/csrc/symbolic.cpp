@@ -574,14 +574,16 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         const i32 NFi = S.NF;
         const i32 u0 = Tp[NFi];
         S.v2l.resize((size_t)(nnzK - u0) + 1);
-        std::vector<char> covered((size_t)nnzL + 1, 0);
-        for (i32 lo = 0; lo < n; lo++) {
+        // (only the rows of the top: the bundle columns merge their U rows inside k_bundle_factor)
+        const i64 q0 = S.Lp[NFi];
+        std::vector<char> covered((size_t)(nnzL - q0) + 1, 0);
+        for (i32 lo = NFi; lo < n; lo++) {
             i32 q = S.Lp[lo];
             const i32 qe = S.Lp[lo + 1];
             for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
                 const i32 hi = Thi[u];
                 if (hi == lo) {
-                    if (lo >= NFi) S.v2l[u - u0] = (i32)(nnzL + lo);
+                    S.v2l[u - u0] = (i32)(nnzL + lo);
                     continue;
                 }
                 while (q < qe && S.Li[q] < hi) q++;
@@ -589,13 +591,13 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                     set_error("internal: K entry missing from the pattern of L");
                     return -9;
                 }
-                if (lo >= NFi) S.v2l[u - u0] = q;
-                covered[q] = 1;
+                S.v2l[u - u0] = q;
+                covered[(size_t)(q - q0)] = 1;
             }
         }
         // fill slots of the TOP columns (the bundle kernels zero their own while they merge the U rows)
-        for (i64 q = S.Lp[NFi]; q < nnzL; q++)
-            if (!covered[q]) S.fill_idx.push_back((i32)q);
+        for (i64 q = q0; q < nnzL; q++)
+            if (!covered[(size_t)(q - q0)]) S.fill_idx.push_back((i32)q);
     }
     clk("v2l map, fill slots");
     // ---- K for the refinement residual e = b - K x (permuted numbering) ------

@@ -2132,8 +2132,8 @@ __device__ __forceinline__ double block_nanmax(double v, double *red) {
 //            are reduced in registers first (lds_scatter_add) -- instead of one cooperative pass per row on a
 //            serial chain of one-node levels; pushes into the folded top rows (row index >= nloc) are this
 //            bundle's shares of those rows (tacc[0..k), zeroed here);
-//   backward (qdldl.rs:737-752; xs already holds y / d): x_j -= sum over column j of l_ij x_i, ancestors
-//            inside the bundle from LDS, the folded top rows from xt.
+//   backward (qdldl.rs:737-752): x_j = y_j / d_j - sum over column j of l_ij x_i, ancestors inside the bundle
+//            from LDS, the folded top rows from xt; 1 / d_j travels through the pipeline with the column pointers.
 // A sweep is a chain of dependent round trips (column pointers -> entries -> LDS), and the entries do NOT
 // depend on x.  The levels are therefore walked in CHUNKS of RPT x TW columns (RPT per thread) through a
 // software pipeline: while chunk c is processed, the first SH entries of the columns of chunk c + 1 and the
@@ -2143,7 +2143,8 @@ __device__ __forceinline__ double block_nanmax(double v, double *red) {
 // by a wave after the level's last chunk.
 template <bool FWDMODE, int SH, int RPT, int TW>
 __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const BundleView &bv, int b, double *xs,
-                                                  const double *xt, double *tacc, int k, int *fat, int &nfat) {
+                                                  const double *xt, double *tacc, int k, int *fat, int &nfat,
+                                                  const double *__restrict__ dinv = nullptr) {
     constexpr int CH = RPT * TW;
     const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
     const int *lv = bv.blvl + bv.blvl_ptr[b];
@@ -2164,9 +2165,10 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
     };
     int cb[RPT], ce[RPT];   // pointers of the chunk whose entries are (being) fetched
     int p1b[RPT], p1e[RPT]; // pointers of the chunk after it
+    double cd[RPT], p1d[RPT]; // backward: 1 / d of the same columns (dinv == nullptr: xs already holds y / d)
     int ei[RPT][SH];
     double ev[RPT][SH];
-    auto request_ptrs = [&](Chunk c, int (&pb)[RPT], int (&pe)[RPT]) {
+    auto request_ptrs = [&](Chunk c, int (&pb)[RPT], int (&pe)[RPT], double (&pd)[RPT]) {
         const int l = level_of(c.step < nl ? c.step : nl - 1);
         const int lb = lv[l] + c.off, le = c.step < nl ? lv[l + 1] : 0;
 #pragma unroll
@@ -2174,6 +2176,7 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
             const int j = lb + (int)threadIdx.x + u * TW;
             pb[u] = j < le ? v.Lp[j] : 0;
             pe[u] = j < le ? v.Lp[j + 1] : 0;
+            pd[u] = (!FWDMODE && dinv && j < le) ? dinv[j] : 1.0;
         }
     };
     auto request_entries = [&](const int (&pb)[RPT], const int (&pe)[RPT]) {
@@ -2189,9 +2192,9 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
     };
     Chunk cur{0, 0};
     Chunk nx1 = advance(cur), nx2 = advance(nx1);
-    request_ptrs(cur, cb, ce);
+    request_ptrs(cur, cb, ce, cd);
     request_entries(cb, ce);
-    request_ptrs(nx1, p1b, p1e);
+    request_ptrs(nx1, p1b, p1e, p1d);
     while (cur.step < nl) {
         const int l = level_of(cur.step);
         const int lb = lv[l], le = lv[l + 1];
@@ -2199,11 +2202,12 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
         const bool level_begins = cur.off == 0, level_ends = c0 + CH >= le;
         // this chunk's data out of the pipeline
         int ci[RPT][SH], tb[RPT], te[RPT];
-        double cv[RPT][SH];
+        double cv[RPT][SH], dj[RPT];
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
             tb[u] = cb[u];
             te[u] = ce[u];
+            dj[u] = cd[u];
 #pragma unroll
             for (int e = 0; e < SH; ++e) {
                 ci[u][e] = ei[u][e];
@@ -2212,9 +2216,9 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
         }
         // refill: entries of the next chunk (its pointers arrived a chunk ago), pointers of the one after
 #pragma unroll
-        for (int u = 0; u < RPT; ++u) cb[u] = p1b[u], ce[u] = p1e[u];
+        for (int u = 0; u < RPT; ++u) cb[u] = p1b[u], ce[u] = p1e[u], cd[u] = p1d[u];
         request_entries(cb, ce);
-        request_ptrs(nx2, p1b, p1e);
+        request_ptrs(nx2, p1b, p1e, p1d);
         if (level_begins) {
             __syncthreads(); // forward: every push into this level's nodes has landed; backward: its ancestors are final
             if (!FWDMODE) {
@@ -2236,6 +2240,7 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
                     const int slot = atomicAdd(&nfat, 1);
                     if (slot < IR_FATCAP) {
                         fat[slot] = j;
+                        xs[j - s0] *= dj[u]; // (its 1 / d now; the wave subtracts the column's sum later)
                         jr[u] = -1;
                         te[u] = tb[u];
                     }
@@ -2287,7 +2292,7 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
             if (!FWDMODE) {
 #pragma unroll
                 for (int u = 0; u < RPT; ++u)
-                    if (jr[u] >= 0) xs[jr[u] - s0] -= sum[u];
+                    if (jr[u] >= 0) xs[jr[u] - s0] = xs[jr[u] - s0] * dj[u] - sum[u]; // qdldl.rs:737-752
             }
         }
         if (!FWDMODE && level_ends) { // the level's long columns, one wave each
@@ -2541,8 +2546,6 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             stamp();
             // this bundle's shares of the top rows of L (accumulated by the pushes)
             if (tid < k) ir_store(&shf[(size_t)b * k + tid], st.tacc[tid]);
-            // D^-1 of the backward sweep (qdldl.rs:737-752) before the barrier: it does not need the top
-            for (int i = tid; i < nloc; i += TW) xs[i] *= v.Dinv[s0 + i];
             if (k) {
                 stamp();
                 if (round == 0) load_top_constants();
@@ -2588,7 +2591,14 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             }
             __syncthreads();
             stamp();
-            bundle_sweep_cols<false, IR_SH_BWD, IR_RPT, TW>(v, bv, b, xs, st.dxt, nullptr, k, fat, nfat);
+            // D^-1 of the backward sweep (qdldl.rs:737-752): through the sweep's pipeline with 128 registers; as a
+            // pass of its own in the 80-register variant (three more pipeline registers per column spill there)
+            if (TW != 256) {
+                for (int i = tid; i < nloc; i += TW) xs[i] *= v.Dinv[s0 + i];
+                __syncthreads();
+            }
+            bundle_sweep_cols<false, IR_SH_BWD, IR_RPT, TW>(v, bv, b, xs, st.dxt, nullptr, k, fat, nfat,
+                                                            TW == 256 ? v.Dinv : nullptr);
             stamp();
             {
                 // the candidate: x (round 0) or x + dx (directldlkktsolver.rs:300 axpby(1, x, 1))

@@ -102,16 +102,32 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
             if (!is_dense[adj[p]]) d++;
         degree[i] = d;
     }
+    std::vector<I> tail((size_t)n + 1, NONE);
     auto dl_insert = [&](I i, I d) {
         nxt[i] = head[d];
         prv[i] = NONE;
         if (head[d] != NONE) prv[head[d]] = i;
+        else tail[d] = i;
         head[d] = i;
+    };
+    // Ties among the variables of a freshly formed element: last-in-first-out like the classic
+    // implementations (default), or first-in-first-out (CHIP_AMD_FIFO: a variable that has been
+    // waiting at this degree goes before one that just joined it, which spreads equal-degree pivots
+    // over independent subtrees; same kind of fill, often a shallower tree, sometimes a deeper one)
+    static const bool lifo = getenv("CHIP_AMD_FIFO") == nullptr;
+    auto dl_insert_tail = [&](I i, I d) {
+        if (lifo) return dl_insert(i, d);
+        prv[i] = tail[d];
+        nxt[i] = NONE;
+        if (tail[d] != NONE) nxt[tail[d]] = i;
+        else head[d] = i;
+        tail[d] = i;
     };
     auto dl_remove = [&](I i, I d) {
         if (prv[i] != NONE) nxt[prv[i]] = nxt[i];
         else head[d] = nxt[i];
         if (nxt[i] != NONE) prv[nxt[i]] = prv[i];
+        else tail[d] = prv[i];
     };
     // insert in reverse so that ties are broken by ascending index
     for (I i = n - 1; i >= 0; i--)
@@ -275,7 +291,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
                 deg = std::min(deg, nleft - nvi);
                 if (deg < 0) deg = 0;
                 degree[i] = deg;
-                dl_insert(i, deg);
+                dl_insert_tail(i, deg);
                 mindeg = std::min(mindeg, deg);
                 epool[pd++] = i;
             }

@@ -212,10 +212,96 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         ip0[v] = (i32)k;
     }
     clk("ordering");
-    // ---- pass A: tree + levels under the given order ------------------------
     std::vector<i64> Cp;
     std::vector<i32> Ci, parent, cnt;
     std::vector<i32> rowcnt;
+    // ---- shallower tree, same fill: reorder inside chains ----------------------
+    // A chain j -> parent(j) -> ... in which every column is its parent's column plus the parent
+    // (count[j] == count[parent]+1) is a clique with one common outer structure: its members may be
+    // eliminated in ANY order without new fill, provided every column c below the chain still comes
+    // before all chain members it touches.  Minimum degree orders such members by degree ties, not by
+    // height: on config 3 it pivots a cone's (u, v) columns before the cone's last two rows, which then
+    // sit on the critical path (8 levels instead of 6).  Here each member gets its release level
+    // r = 1 + max level of the outside columns that touch it (one row-pattern walk over the tree, the
+    // same walk that counts), the members of a chain are re-sequenced by ascending r, and the whole
+    // order is re-sorted by the resulting levels.  Pass A below analyses the new order from scratch.
+    if (perm0.empty() && n > 0 && std::getenv("CHIP_NO_CHAIN_REORDER") == nullptr) {
+        permuted_triu(n, Ap, Ai, ip0, Cp, Ci);
+        etree_counts(n, Cp, Ci, parent, cnt);
+        i64 nnzL0 = 0;
+        for (i32 j = 0; j < n; j++) nnzL0 += cnt[j];
+        std::vector<i32> chain((size_t)n), nlev((size_t)n, 0), rel((size_t)n, 0), stamp((size_t)n, -1);
+        std::vector<i32> cfirst((size_t)n, -1), cnext((size_t)n, -1); // members of a chain, linked in old order
+        i32 nchains = 0;
+        // chain ids top-down is not possible in one ascending sweep; assign bottom-up instead: a node opens a
+        // chain unless a child already claimed it as the continuation of the child's chain
+        std::vector<i32> claimed((size_t)n, -1);
+        std::vector<i32> ctail((size_t)n, -1);
+        std::vector<i32> mem;
+        bool moved = false;
+        for (i32 j = 0; j < n; j++) {
+            const i32 c = claimed[j] >= 0 ? claimed[j] : nchains++;
+            chain[j] = c;
+            if (cfirst[c] < 0) cfirst[c] = j;
+            else cnext[ctail[c]] = j;
+            ctail[c] = j;
+            // release level of j: walk row j's pattern (all columns that hold j)
+            stamp[j] = j;
+            i32 r = 0;
+            for (i64 p = Cp[j]; p < Cp[j + 1]; p++) {
+                i32 i = Ci[p];
+                while (stamp[i] != j) {
+                    if (chain[i] != c && nlev[i] + 1 > r) r = nlev[i] + 1;
+                    stamp[i] = j;
+                    i = parent[i];
+                }
+            }
+            rel[j] = r;
+            const i32 pj = parent[j];
+            const bool cont = pj >= 0 && cnt[j] == cnt[pj] + 1 && claimed[pj] < 0;
+            if (cont) {
+                claimed[pj] = c;
+                continue;
+            }
+            // j closes its chain: sequence the members by release level
+            mem.clear();
+            for (i32 t = cfirst[c]; t >= 0; t = cnext[t]) mem.push_back(t);
+            if (mem.size() > 1) {
+                std::vector<i32> srt(mem);
+                std::stable_sort(srt.begin(), srt.end(), [&](i32 a, i32 b) { return rel[a] < rel[b]; });
+                if (srt != mem) moved = true;
+                i32 lv = -1;
+                for (i32 t : srt) {
+                    lv = std::max(lv + 1, rel[t]);
+                    nlev[t] = lv;
+                }
+            } else {
+                nlev[j] = r;
+            }
+        }
+        if (moved) {
+            std::vector<i32> ord((size_t)n);
+            std::iota(ord.begin(), ord.end(), 0);
+            std::stable_sort(ord.begin(), ord.end(), [&](i32 a, i32 b) { return nlev[a] < nlev[b]; });
+            std::vector<i64> p1((size_t)n);
+            std::vector<i32> ip1((size_t)n);
+            for (i32 t = 0; t < n; t++) {
+                p1[t] = p0[ord[t]];
+                ip1[p1[t]] = t;
+            }
+            std::vector<i32> parent1, cnt1;
+            permuted_triu(n, Ap, Ai, ip1, Cp, Ci);
+            etree_counts(n, Cp, Ci, parent1, cnt1);
+            i64 nnzL1 = 0;
+            for (i32 j = 0; j < n; j++) nnzL1 += cnt1[j];
+            if (nnzL1 <= nnzL0) { // (always, by the clique argument; checked because it is cheap)
+                p0.swap(p1);
+                ip0.swap(ip1);
+            }
+        }
+        clk("chain re-sequencing");
+    }
+    // ---- pass A: tree + levels under the given order ------------------------
     permuted_triu(n, Ap, Ai, ip0, Cp, Ci);
     etree_counts(n, Cp, Ci, parent, cnt, &rowcnt);
     std::vector<i32> level((size_t)n, 0);

@@ -186,10 +186,17 @@ def test_symbolic_matches_oracle(hip, oracle, name):
     for j in range(N):
         if et[j] >= 0:
             assert level[et[j]] > level[j] and et[j] > j
-    # fill equals that of the un-resorted AMD order (equivalent reordering)
+    # fill never exceeds that of the raw AMD order: the level-major re-sort is an equivalent reordering,
+    # and re-sequencing the members of a chain (symbolic.cpp "shallower tree, same fill") can only drop
+    # fill edges the raw order created among them
     p0, _, _ = hip.amd_order(N, K.colptr, K.rowval)
     f0 = oracle.QDLDL(N, K.colptr, K.rowval, K.nzval, perm=p0, logical=True)
-    assert f0.nnzL == f.nnzL
+    assert f.nnzL <= f0.nnzL
+    lv0 = np.zeros(N, dtype=np.int64)
+    for j in range(N):
+        if f0.etree[j] >= 0:
+            lv0[f0.etree[j]] = max(lv0[f0.etree[j]], lv0[j] + 1)
+    assert level.max() <= lv0.max()
 
 
 def test_user_perm_respected_up_to_level_sort(hip, oracle, monkeypatch):
@@ -212,7 +219,7 @@ def test_portfolio_structure_is_shallow(hip):
     pr = problems.portfolio_socp(20, 50, seed=3)
     ks = _mk(hip, pr)
     info = ks.linear_solver_info()
-    assert info.n_levels <= 8
+    assert info.n_levels <= 6  # (8 before the chain re-sequencing of symbolic.cpp: u, v pivoted before the last cone rows)
     assert info.nnzL <= 1.2 * info.nnzA
 
 

@@ -42,28 +42,46 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     const bool timing = std::getenv("CHIP_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     // ---- symmetric adjacency without the diagonal ---------------------------
+    // (threads own ranges of nodes and scan all of K in order: the lists come out the same for any count)
+    const i64 nnzA = Ap[n];
+    i64 par_min = 2000000;
+    if (const char *e = std::getenv("CHIP_HOST_PAR_MIN")) par_min = std::atoll(e);
+    const int T = nnzA >= par_min ? host_threads() : 1;
     std::vector<I> ast((size_t)n + 1, 0);
-    for (I c = 0; c < n; c++)
-        for (I p = Ap[c]; p < Ap[c + 1]; p++) {
-            I r = Ai[p];
-            if (r < 0 || r >= n) return -9;
-            if (r != c) {
-                ast[r + 1]++;
-                ast[c + 1]++;
+    std::vector<int> bad((size_t)T, 0);
+    run_threads(T, [&](int t, int TT) {
+        const I k0 = (I)(n * t / TT), k1 = (I)(n * (t + 1) / TT);
+        for (I c = 0; c < n; c++)
+            for (I p = Ap[c]; p < Ap[c + 1]; p++) {
+                const I r = Ai[p];
+                if (r < 0 || r >= n) {
+                    bad[t] = 1;
+                    return;
+                }
+                if (r != c) {
+                    if (r >= k0 && r < k1) ast[r + 1]++;
+                    if (c >= k0 && c < k1) ast[c + 1]++;
+                }
             }
-        }
+    });
+    for (int t = 0; t < T; t++)
+        if (bad[t]) return -9;
     for (I i = 0; i < n; i++) ast[i + 1] += ast[i];
     std::vector<I> adj((size_t)ast[n] + 1);
     {
         std::vector<I> fillp(ast.begin(), ast.end() - 1);
-        for (I c = 0; c < n; c++)
-            for (I p = Ap[c]; p < Ap[c + 1]; p++) {
-                I r = Ai[p];
-                if (r != c) {
-                    adj[fillp[r]++] = c;
-                    adj[fillp[c]++] = r;
+        const std::vector<int64_t> cuts = balanced_cuts(ast.data(), n, T);
+        run_threads(T, [&](int t, int) {
+            const I k0 = (I)cuts[t], k1 = (I)cuts[t + 1];
+            if (k0 >= k1) return;
+            for (I c = 0; c < n; c++)
+                for (I p = Ap[c]; p < Ap[c + 1]; p++) {
+                    const I r = Ai[p];
+                    if (r == c) continue;
+                    if (r >= k0 && r < k1) adj[fillp[r]++] = c;
+                    if (c >= k0 && c < k1) adj[fillp[c]++] = r;
                 }
-            }
+        });
     }
     std::vector<I> alen((size_t)n), aelen((size_t)n, 0);
     for (I i = 0; i < n; i++) alen[i] = ast[i + 1] - ast[i];
@@ -137,7 +155,15 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     I nelim = 0, mindeg = 0, lemax = 0;
     i64 wflg = 2;
 
+    double tph[5] = {0, 0, 0, 0, 0};
+    auto tick = [&](int k, std::chrono::steady_clock::time_point &t0) {
+        if (!timing) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        tph[k] += std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+    };
     while (nelim < nlive) {
+        auto tp0 = std::chrono::steady_clock::now();
         while (mindeg <= n && head[mindeg] == NONE) mindeg++;
         const I me = head[mindeg];
         dl_remove(me, mindeg);
@@ -182,6 +208,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         w[me] = 1;
         lemax = std::max(lemax, degme);
 
+        tick(0, tp0);
         // ---- pass 1: w[e] - wflg = |Le \ Lme| for every element touching Lme
         for (I q = mstart; q < mend; q++) {
             const I i = epool[q];
@@ -193,6 +220,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
                 else if (we != 0) w[e] = degree[e] + wflg - nvi;
             }
         }
+        tick(1, tp0);
         // ---- pass 2: prune each variable's list, approximate degree, hash
         for (I q = mstart; q < mend; q++) {
             const I i = epool[q];
@@ -247,6 +275,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         degree[me] = degme;
         wflg += lemax;
 
+        tick(2, tp0);
         // ---- supervariable detection among the members of Lme ----------------
         for (I q = mstart; q < mend; q++) {
             const I i0 = epool[q];
@@ -278,6 +307,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
                 wflg++;
             }
         }
+        tick(3, tp0);
         // ---- finalise: restore nv, final degrees, compact the element -------
         {
             const I nleft = nlive - nelim;
@@ -299,6 +329,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
             epool.resize((size_t)pd);
             if (elen[me] == 0) w[me] = 0;
         }
+        tick(4, tp0);
         nv[me] = 0;
         pivots.push_back(me);
         // fill statistics in the style of amd::Info (used by ldlsolvers/auto.rs:69-77)
@@ -320,10 +351,13 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         st.nmultsubs_ldl += (s + lnzme) / 2.0;
     }
 
-    if (timing)
+    if (timing) {
         std::fprintf(stderr, "[chip amd] adjacency %.3f s, elimination %.3f s (%lld pivots)\n",
                      std::chrono::duration<double>(t_adj - t_begin).count(),
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_adj).count(), (long long)pivots.size());
+        std::fprintf(stderr, "[chip amd]   element %.3f, pass 1 %.3f, pass 2 %.3f, supervariables %.3f, finalise %.3f s\n",
+                     tph[0], tph[1], tph[2], tph[3], tph[4]);
+    }
     // ---- expand supervariables: every absorbed variable follows its pivot ---
     std::vector<char> is_pivot((size_t)n, 0);
     for (I v : pivots) is_pivot[v] = 1;

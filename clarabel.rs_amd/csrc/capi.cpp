@@ -347,17 +347,21 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     std::unique_ptr<chip_kkt> h(new chip_kkt());
     KktLayout &K = h->K;
     i64 mm = 0;
+    PhaseClock clk;
+    clk.tag = "kkt_create";
     int rc = build_cone_specs(ncones, cone_tags, cone_dims, cone_dims2, K.cones, mm, K.p, K.nHs);
     if (rc) return CHIP_ERR_ARG;
     if (mm != m) return fail(CHIP_ERR_DIM, "cone dimensions do not add up to m");
     rc = assemble_kkt_triu(n, m, as_i64(Pcolptr), as_i64(Prowval), Pnzval, as_i64(Acolptr), as_i64(Arowval),
                            Anzval, K);
     if (rc) return rc;
+    clk("KKT assembly");
     std::vector<i64> perm0;
     if (perm_or_null) perm0.assign(as_i64(perm_or_null), as_i64(perm_or_null) + K.N);
     Symbolic S;
     rc = analyse(K.N, K.colptr.data(), K.rowval.data(), K.dsigns.data(), perm0, st.amd_dense_scale, S);
     if (rc) return rc;
+    clk("analysis (total)");
     Engine &E = h->E;
     if (st.device == CHIP_DEVICE_HOST_ONLY) {
         E.init_host_only(S, st);
@@ -366,6 +370,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     }
     rc = E.init(S, st);
     if (rc) return rc;
+    clk("engine init (uploads)");
     if (K.nnz) { // the device keeps K.nzval in T order (host.hpp: Symbolic::k2v)
         std::vector<double> vx((size_t)K.nnz);
         for (i64 u = 0; u < K.nnz; u++) vx[(size_t)u] = K.nzval[(size_t)S.v2k[(size_t)u]];
@@ -610,6 +615,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
             if ((rc = E.upload(&h->ir_runs, runs, runs.size()))) return rc;
         }
     }
+    clk("maps, cone tables");
     *out = h.release();
     return CHIP_OK;
 }

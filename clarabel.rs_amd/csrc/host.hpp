@@ -4,6 +4,10 @@
 // Reference citations are relative to /root/reference/src.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -175,6 +179,38 @@ int assemble_kkt_triu(i64 n, i64 m, const i64 *Pp, const i64 *Pi, const double *
                       const i64 *Ai, const double *Ax, KktLayout &K);
 
 void set_error(const std::string &msg);
+
+// CHIP_TIMING=1: wall-clock of the analysis phases on stderr
+struct PhaseClock {
+    const char *tag = "analyse";
+    bool on = std::getenv("CHIP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[chip %s] %-28s %8.3f s\n", tag, what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+// ---- host threads for the analysis passes (std::thread, no runtime dependency) ----------------
+// CHIP_HOST_THREADS overrides the default min(hardware threads, 16); 1 = everything on the caller.
+int host_threads();
+// body(t, T) on T threads (t = 0..T-1), the caller being thread 0; returns when all are done.
+void run_threads(int T, const std::function<void(int, int)> &body);
+// cut [0, n) into T contiguous ranges of about equal WEIGHT given the prefix sums ptr[0..n]
+// (ptr[0] need not be 0): cuts[t] .. cuts[t+1] is the share of thread t.
+template <class P> std::vector<int64_t> balanced_cuts(const P *ptr, int64_t n, int T) {
+    std::vector<int64_t> cuts((size_t)T + 1, n);
+    cuts[0] = 0;
+    int64_t j = 0;
+    for (int t = 1; t < T; t++) {
+        const double target = (double)ptr[0] + ((double)ptr[n] - (double)ptr[0]) * t / T;
+        while (j < n && (double)ptr[j] < target) j++;
+        cuts[t] = j;
+    }
+    return cuts;
+}
 const char *get_error();
 
 } // namespace chip

@@ -1028,9 +1028,11 @@ __global__ __launch_bounds__(WG) void k_factor_finalize(LdlView v, const int *__
 constexpr int SN_NB = 64;
 constexpr int SN_KC = 128;  // 64 * 128 * 8 = 64 KiB
 constexpr int SN_U = 8;     // A operands requested ahead of the matrix instructions that consume them
+constexpr int SN_WST = 8;   // loads in flight per thread while the LDS operand is staged
 constexpr int SN_WG = 512;
 constexpr int SN_ROWS = 256; // panel rows per workgroup of the update kernels: 8 waves x 2 tiles of 16
 typedef double snode_v4d __attribute__((ext_vector_type(4)));
+typedef double snode_v2d __attribute__((ext_vector_type(2)));
 
 struct SnodeGeom {
     const int *cols;
@@ -1055,6 +1057,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
                                             int row_begin, int kbeg = 0, bool atomic_emit = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, l15 = lane & 15;
+    __shared__ double dk[SN_KC];
     const int i0[2] = {row_begin + wave * 32, row_begin + wave * 32 + 16};
     const int irow[2] = {i0[0] + l15, i0[1] + l15};
     const bool rowok[2] = {irow[0] < g.h, irow[1] < g.h};
@@ -1067,14 +1070,23 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
         const int kcn = min(SN_KC, kend - kc0);
         const int kcn4 = (kcn + 3) & ~3;
         __syncthreads(); // the previous chunk has been consumed
-        for (int idx = tid; idx < kcn4 * SN_NB; idx += SN_WG) {
-            const int kk = idx / SN_NB, jj = idx % SN_NB;
-            double val = 0.0;
-            if (kk < kcn && jj < ncols) {
-                const int k = kc0 + kk;
-                val = v.Lx[colbase[k] + jrow0 + jj] * v.D[g.cols[k]];
+        // the chunk's pivots first (one round trip), then the (d_k L[j,k]) operand with SN_WST loads in flight
+        // per thread (as a plain loop every round was cols -> D and Lx -> LDS, two dependent global round
+        // trips, 16 rounds per chunk: longer than the chunk's matrix instructions)
+        if (tid < kcn) dk[tid] = v.D[g.cols[kc0 + tid]];
+        __syncthreads();
+        for (int base = 0; base < kcn4 * SN_NB; base += SN_WST * SN_WG) {
+            double wv[SN_WST];
+#pragma unroll
+            for (int r = 0; r < SN_WST; ++r) {
+                const int idx = base + r * SN_WG + tid, kk = idx / SN_NB, jj = idx % SN_NB;
+                wv[r] = (kk < kcn && jj < ncols) ? v.Lx[colbase[kc0 + kk] + jrow0 + jj] : 0.0;
             }
-            Wl[idx] = val;
+#pragma unroll
+            for (int r = 0; r < SN_WST; ++r) {
+                const int idx = base + r * SN_WG + tid, kk = idx / SN_NB;
+                if (idx < kcn4 * SN_NB) Wl[idx] = kk < kcn ? wv[r] * dk[kk] : 0.0;
+            }
         }
         __syncthreads();
         if (i0[0] >= g.h) continue; // (after the barriers: the whole wave is beyond the panel)
@@ -1200,7 +1212,8 @@ __global__ __launch_bounds__(SN_WG) void k_snode_extend(LdlView v, SnodeView sv,
 constexpr int SN_DWG = 256;
 __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, const int *__restrict__ order,
                                                        int b) {
-    __shared__ double lcol[2][SN_NB];
+    __shared__ __attribute__((aligned(16))) double lcol[2][SN_NB];
+    __shared__ double piv[2];
     __shared__ double sgn[SN_NB];
     __shared__ int colbase[SN_NB];
     const int sn = order[blockIdx.x];
@@ -1225,34 +1238,44 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, 
     }
     double dfin = 1.0, dinvfin = 1.0; // pivot of row i, recorded by the threads of wave 0
     int nreg = 0, bad = 0;
+    // column jj = 16 qq + c: the quarter loop stays rolled, the 16 columns of a quarter are unrolled, so T[c]
+    // is a fixed register.  The owner publishes the strictly-lower part of the column (zeros from the
+    // diagonal up) and the pivot candidate separately: every product below is then unconditional -- the 16
+    // column entries a thread needs come in as eight 16-byte LDS reads, no per-entry branches (the first
+    // version's `j2 > jj ? lcol[j2] : 0` compiled to 16 serialised conditional LDS round trips per column,
+    // 53 of its 62 us).
+    for (int qq = 0; qq < SN_NB / 16; ++qq) {
 #pragma unroll
-    for (int jj = 0; jj < SN_NB; ++jj) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int qq = jj >> 4, c = jj & 15, buf = jj & 1;
-        if (q == qq) lcol[buf][i] = i == jj ? di : T[c]; // the column, unscaled (0 above the diagonal), + the pivot candidate
-        __syncthreads();
-        double d = lcol[buf][jj];
-        const double sg = sgn[jj];
-        const bool reg = d * sg < v.reg_eps;
-        if (reg) d = v.reg_delta * sg;
-        const double dinv = 1.0 / d;
-        if (q == 0 && i == jj) {
-            dfin = d;
-            dinvfin = dinv;
-            if (reg) nreg = 1;
-            if (d == 0.0) bad |= 2;
-            if (!isfinite(dinv)) bad |= 1;
-        }
-        const double l = i > jj ? lcol[buf][i] * dinv : 0.0;
-        if (q == qq) T[c] = l;
-        const double w = l * d;
-        di -= w * l;
+        for (int c = 0; c < 16; ++c) {
+            const int jj = 16 * qq + c, buf = c & 1;
+            if (q == qq) {
+                lcol[buf][i] = i > jj ? T[c] : 0.0;
+                if (i == jj) piv[buf] = di;
+            }
+            __syncthreads();
+            double d = piv[buf];
+            const double sg = sgn[jj];
+            const bool reg = d * sg < v.reg_eps;
+            if (reg) d = v.reg_delta * sg;
+            const double dinv = 1.0 / d;
+            if (q == 0 && i == jj) {
+                dfin = d;
+                dinvfin = dinv;
+                if (reg) nreg = 1;
+                if (d == 0.0) bad |= 2;
+                if (!isfinite(dinv)) bad |= 1;
+            }
+            const double l = lcol[buf][i] * dinv; // 0 for i <= jj
+            if (q == qq) T[c] = i > jj ? l : T[c];
+            const double w = l * d;
+            di -= w * l;
+            const snode_v2d *lc = (const snode_v2d *)&lcol[buf][16 * q];
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) {
-            const int j2 = 16 * q + cc;
-            const double l2 = j2 > jj ? lcol[buf][j2] * dinv : 0.0;
-            T[cc] -= w * l2;
+            for (int c2 = 0; c2 < 8; ++c2) {
+                const snode_v2d pr = lc[c2];
+                T[2 * c2] -= w * (pr.x * dinv);
+                T[2 * c2 + 1] -= w * (pr.y * dinv);
+            }
         }
     }
     if (q == 0 && live) {
@@ -1273,7 +1296,7 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, 
 __global__ __launch_bounds__(SN_DWG) void k_snode_rows(LdlView v, SnodeView sv, const int *__restrict__ order,
                                                        int b) {
     __shared__ double dT[SN_NB * SN_NB]; // d_q * L_JJ[jj][q]
-    __shared__ double dinvl[SN_NB];
+    __shared__ double dinvl[SN_NB], dl[SN_NB];
     __shared__ int colbase[SN_NB];
     const int sn = order[blockIdx.y];
     const SnodeGeom g = snode_geom(v, sv, sn);
@@ -1286,17 +1309,31 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_rows(LdlView v, SnodeView sv, 
         const int c = g.cols[j0 + tid];
         colbase[tid] = v.Lp[c] - (j0 + tid) - 1;
         dinvl[tid] = v.Dinv[c];
+        dl[tid] = v.D[c];
     }
     __syncthreads();
-    for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_DWG) {
-        const int ii = idx / SN_NB, jj = idx % SN_NB;
-        dT[idx] = (ii > jj && ii < nbw) ? v.Lx[colbase[jj] + j0 + ii] * v.D[g.cols[j0 + jj]] : 0.0;
-    }
-    __syncthreads();
-    if (i >= g.h) return;
-    double x[SN_NB];
+    // (the pivots come from LDS: with v.D[g.cols[..]] inside this loop every one of its 16 rounds was a chain
+    // of two dependent global loads, ~25 of the kernel's 36 us; now the 16 block entries of a thread and the
+    // 64 panel entries of its row are all requested before the first is used)
+    {
+        double tv[SN_NB * SN_NB / SN_DWG];
 #pragma unroll
-    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = jj < nbw ? v.Lx[colbase[jj] + i] : 0.0;
+        for (int r = 0; r < SN_NB * SN_NB / SN_DWG; ++r) {
+            const int idx = tid + r * SN_DWG, ii = idx / SN_NB, jj = idx % SN_NB;
+            tv[r] = (ii > jj && ii < nbw) ? v.Lx[colbase[jj] + j0 + ii] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < SN_NB * SN_NB / SN_DWG; ++r) {
+            const int idx = tid + r * SN_DWG;
+            dT[idx] = tv[r] * dl[idx % SN_NB];
+        }
+    }
+    double x[SN_NB];
+    const bool rowok = i < g.h;
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = (rowok && jj < nbw) ? v.Lx[colbase[jj] + i] : 0.0;
+    __syncthreads();
+    if (!rowok) return;
 #pragma unroll
     for (int jj = 0; jj < SN_NB; ++jj) {
         if (jj < nbw) {

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "host.hpp"
 
@@ -29,19 +30,28 @@ static thread_local std::string g_err; // per thread, like errno: handles may li
 void set_error(const std::string &msg) { g_err = msg; }
 const char *get_error() { return g_err.c_str(); }
 
+int host_threads() { // (environment read on every call: a handful of calls per analysis)
+    int t = (int)std::thread::hardware_concurrency();
+    if (t < 1) t = 1;
+    if (t > 16) t = 16;
+    if (const char *e = std::getenv("CHIP_HOST_THREADS")) t = std::max(1, std::atoi(e));
+    return t;
+}
+
+void run_threads(int T, const std::function<void(int, int)> &body) {
+    if (T <= 1) {
+        body(0, 1);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)T - 1);
+    for (int t = 1; t < T; t++) th.emplace_back([&body, t, T] { body(t, T); });
+    body(0, T);
+    for (auto &x : th) x.join();
+}
+
 namespace {
 
-// CHIP_TIMING=1: wall-clock of the analysis phases on stderr
-struct PhaseClock {
-    bool on = std::getenv("CHIP_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    void operator()(const char *what) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[chip analyse] %-28s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
-        t0 = t1;
-    }
-};
 
 // kernel work-list thresholds (see kernels.hip)
 constexpr i32 T_MAX = 32;      // <= T_MAX entries: one thread per row
@@ -66,29 +76,79 @@ constexpr i64 BUNDLE_TARGET_COUNT = 2048;  // aim for >= 8 workgroups per CU
 constexpr i32 BUNDLE_MAX_COL = 512;        // columns longer than this are not bundled
 constexpr i64 BUNDLE_MAX_WORK = 1000000;   // sum of (column length)^2 one workgroup should factor with per-entry gathers (config 2: 8e6 -> 1e6 took the update from 29.8 to 24.1 ms)
 
+// threads worth starting for a pass over `items` entries
+// (CHIP_HOST_PAR_MIN: the smallest pass that is split, 2e6 entries by default; tests set it to 0)
+inline int par_threads(i64 items) {
+    i64 min_items = 2000000;
+    if (const char *e = std::getenv("CHIP_HOST_PAR_MIN")) min_items = std::atoll(e);
+    return items >= min_items ? host_threads() : 1;
+}
+
 // upper-triangular pattern of P K P' (row = min, col = max), columns unsorted,
 // plus (optionally) for each source entry its destination slot.
 void permuted_triu(i64 n, const i64 *Ap, const i64 *Ai, const std::vector<i32> &iperm,
                    std::vector<i64> &Cp, std::vector<i32> &Ci) {
+    // Threads own ranges of DESTINATION columns: every thread scans all of K (sequential reads) and
+    // places the entries of its own columns in source order, so the result does not depend on the
+    // number of threads.
+    const i64 nnz = n > 0 ? Ap[n] : 0;
+    const int T = par_threads(nnz);
     Cp.assign((size_t)n + 1, 0);
-    for (i64 c = 0; c < n; c++) {
-        const i32 pc = iperm[c];
-        for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-            const i32 pr = iperm[Ai[p]];
-            Cp[(pr > pc ? pr : pc) + 1]++;
+    if (T == 1) {
+        for (i64 c = 0; c < n; c++) {
+            const i32 pc = iperm[c];
+            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                const i32 pr = iperm[Ai[p]];
+                Cp[(pr > pc ? pr : pc) + 1]++;
+            }
         }
+        for (i64 c = 0; c < n; c++) Cp[c + 1] += Cp[c];
+        Ci.resize((size_t)Cp[n] + 1);
+        std::vector<i64> nextp(Cp.begin(), Cp.end() - 1);
+        for (i64 c = 0; c < n; c++) {
+            const i32 pc = iperm[c];
+            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                const i32 pr = iperm[Ai[p]];
+                const i32 col = pr > pc ? pr : pc, row = pr > pc ? pc : pr;
+                Ci[nextp[col]++] = row;
+            }
+        }
+        return;
     }
+    // the permuted (row, col) of every entry once, by source chunks; the two scans below are streams
+    std::vector<i32> erow((size_t)nnz + 1), ecol((size_t)nnz + 1);
+    {
+        const std::vector<int64_t> ccuts = balanced_cuts(Ap, n, T);
+        run_threads(T, [&](int t, int) {
+            for (i64 c = ccuts[t]; c < ccuts[t + 1]; c++) {
+                const i32 pc = iperm[c];
+                for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                    const i32 pr = iperm[Ai[p]];
+                    ecol[p] = pr > pc ? pr : pc;
+                    erow[p] = pr > pc ? pc : pr;
+                }
+            }
+        });
+    }
+    run_threads(T, [&](int t, int TT) {
+        const i32 k0 = (i32)(n * t / TT), k1 = (i32)(n * (t + 1) / TT);
+        for (i64 p = 0; p < nnz; p++) {
+            const i32 col = ecol[p];
+            if (col >= k0 && col < k1) Cp[col + 1]++;
+        }
+    });
     for (i64 c = 0; c < n; c++) Cp[c + 1] += Cp[c];
     Ci.resize((size_t)Cp[n] + 1);
     std::vector<i64> nextp(Cp.begin(), Cp.end() - 1);
-    for (i64 c = 0; c < n; c++) {
-        const i32 pc = iperm[c];
-        for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-            const i32 pr = iperm[Ai[p]];
-            const i32 col = pr > pc ? pr : pc, row = pr > pc ? pc : pr;
-            Ci[nextp[col]++] = row;
+    const std::vector<int64_t> cuts = balanced_cuts(Cp.data(), n, T);
+    run_threads(T, [&](int t, int) {
+        const i32 k0 = (i32)cuts[t], k1 = (i32)cuts[t + 1];
+        if (k0 >= k1) return;
+        for (i64 p = 0; p < nnz; p++) {
+            const i32 col = ecol[p];
+            if (col >= k0 && col < k1) Ci[nextp[col]++] = erow[p];
         }
-    }
+    });
 }
 
 // elimination tree (parent, -1 = root) and strictly-lower column counts of L.
@@ -225,19 +285,19 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // r = 1 + max level of the outside columns that touch it (one row-pattern walk over the tree, the
     // same walk that counts), the members of a chain are re-sequenced by ascending r, and the whole
     // order is re-sorted by the resulting levels.  Pass A below analyses the new order from scratch.
+    // (pass A runs first; when members move, the new order is analysed and, its fill being no larger, kept)
+    permuted_triu(n, Ap, Ai, ip0, Cp, Ci);
+    etree_counts(n, Cp, Ci, parent, cnt, &rowcnt);
     if (perm0.empty() && n > 0 && std::getenv("CHIP_NO_CHAIN_REORDER") == nullptr) {
-        permuted_triu(n, Ap, Ai, ip0, Cp, Ci);
-        etree_counts(n, Cp, Ci, parent, cnt);
         i64 nnzL0 = 0;
         for (i32 j = 0; j < n; j++) nnzL0 += cnt[j];
         std::vector<i32> chain((size_t)n), nlev((size_t)n, 0), rel((size_t)n, 0), stamp((size_t)n, -1);
         std::vector<i32> cfirst((size_t)n, -1), cnext((size_t)n, -1); // members of a chain, linked in old order
         i32 nchains = 0;
-        // chain ids top-down is not possible in one ascending sweep; assign bottom-up instead: a node opens a
-        // chain unless a child already claimed it as the continuation of the child's chain
+        // a node opens a chain unless a child already claimed it as the continuation of the child's chain
         std::vector<i32> claimed((size_t)n, -1);
         std::vector<i32> ctail((size_t)n, -1);
-        std::vector<i32> mem;
+        std::vector<i32> mem, srt;
         bool moved = false;
         for (i32 j = 0; j < n; j++) {
             const i32 c = claimed[j] >= 0 ? claimed[j] : nchains++;
@@ -264,46 +324,52 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 continue;
             }
             // j closes its chain: sequence the members by release level
+            if (cfirst[c] == j) {
+                nlev[j] = r;
+                continue;
+            }
             mem.clear();
             for (i32 t = cfirst[c]; t >= 0; t = cnext[t]) mem.push_back(t);
-            if (mem.size() > 1) {
-                std::vector<i32> srt(mem);
-                std::stable_sort(srt.begin(), srt.end(), [&](i32 a, i32 b) { return rel[a] < rel[b]; });
-                if (srt != mem) moved = true;
-                i32 lv = -1;
-                for (i32 t : srt) {
-                    lv = std::max(lv + 1, rel[t]);
-                    nlev[t] = lv;
-                }
-            } else {
-                nlev[j] = r;
+            srt = mem;
+            std::stable_sort(srt.begin(), srt.end(), [&](i32 x, i32 y) { return rel[x] < rel[y]; });
+            if (srt != mem) moved = true;
+            i32 lv = -1;
+            for (i32 t : srt) {
+                lv = std::max(lv + 1, rel[t]);
+                nlev[t] = lv;
             }
         }
         if (moved) {
-            std::vector<i32> ord((size_t)n);
-            std::iota(ord.begin(), ord.end(), 0);
-            std::stable_sort(ord.begin(), ord.end(), [&](i32 a, i32 b) { return nlev[a] < nlev[b]; });
+            // counting sort of the nodes by new level (stable: ties keep the old order)
+            i32 maxl = 0;
+            for (i32 j = 0; j < n; j++) maxl = std::max(maxl, nlev[j]);
+            std::vector<i32> lp((size_t)maxl + 2, 0);
+            for (i32 j = 0; j < n; j++) lp[nlev[j] + 1]++;
+            for (i32 l = 0; l <= maxl; l++) lp[l + 1] += lp[l];
             std::vector<i64> p1((size_t)n);
             std::vector<i32> ip1((size_t)n);
-            for (i32 t = 0; t < n; t++) {
-                p1[t] = p0[ord[t]];
+            for (i32 j = 0; j < n; j++) {
+                const i32 t = lp[nlev[j]]++;
+                p1[t] = p0[j];
                 ip1[p1[t]] = t;
             }
-            std::vector<i32> parent1, cnt1;
-            permuted_triu(n, Ap, Ai, ip1, Cp, Ci);
-            etree_counts(n, Cp, Ci, parent1, cnt1);
+            std::vector<i64> Cp1;
+            std::vector<i32> Ci1, parent1, cnt1, rowcnt1;
+            permuted_triu(n, Ap, Ai, ip1, Cp1, Ci1);
+            etree_counts(n, Cp1, Ci1, parent1, cnt1, &rowcnt1);
             i64 nnzL1 = 0;
             for (i32 j = 0; j < n; j++) nnzL1 += cnt1[j];
-            if (nnzL1 <= nnzL0) { // (always, by the clique argument; checked because it is cheap)
+            if (nnzL1 <= nnzL0) { // (always, by the clique argument; checked because it is free)
                 p0.swap(p1);
                 ip0.swap(ip1);
+                Cp.swap(Cp1);
+                Ci.swap(Ci1);
+                parent.swap(parent1);
+                cnt.swap(cnt1);
+                rowcnt.swap(rowcnt1);
             }
         }
-        clk("chain re-sequencing");
     }
-    // ---- pass A: tree + levels under the given order ------------------------
-    permuted_triu(n, Ap, Ai, ip0, Cp, Ci);
-    etree_counts(n, Cp, Ci, parent, cnt, &rowcnt);
     std::vector<i32> level((size_t)n, 0);
     i32 depth = n > 0 ? 1 : 0;
     for (i32 j = 0; j < n; j++) {
@@ -311,7 +377,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         if (pj >= 0 && level[pj] < level[j] + 1) level[pj] = level[j] + 1;
         if (level[j] + 1 > depth) depth = level[j] + 1;
     }
-    clk("pass A (etree, counts)");
+    clk("pass A (etree, counts, chains)");
     // ---- cut the forest: a node whose whole subtree is small goes (with that subtree)
     //      into a "bundle" that ONE workgroup factors / solves start to finish; the
     //      remaining ancestors form the "top", processed level by level by the whole GPU.
@@ -466,10 +532,22 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
 
     clk("forest cut, renumbering");
     // ---- pass B: final pattern ----------------------------------------------
+    // (the final order is a topological re-sort of pass A's tree: same filled graph, so the tree and the
+    // column counts are pass A's, renumbered; only the permuted pattern of K is built afresh)
     permuted_triu(n, Ap, Ai, S.iperm, Cp, Ci);
-    etree_counts(n, Cp, Ci, parent, cnt);
+    {
+        std::vector<i32> inv((size_t)n), parentB((size_t)n), cntB((size_t)n);
+        for (i32 t = 0; t < n; t++) inv[order[t]] = t;
+        for (i32 t = 0; t < n; t++) {
+            const i32 j = order[t];
+            parentB[t] = parent[j] >= 0 ? inv[parent[j]] : -1;
+            cntB[t] = cnt[j];
+        }
+        parent.swap(parentB);
+        cnt.swap(cntB);
+    }
     S.etree = parent;
-    clk("pass B etree/counts");
+    clk("pass B (pattern of K, renumbered tree)");
     // ---- chain supernodes among the top columns ---------------------------------
     // A chain j -> parent(j) -> ... of top columns in which every node is the heaviest child of its
     // parent has nested structures: struct(j) is contained in {later chain nodes} + struct(last).
@@ -578,21 +656,35 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     }
     clk("supernodes + pattern of L");
     // ---- CSR view of L ------------------------------------------------------
-    S.Rp.assign((size_t)n + 1, 0);
-    for (i64 q = 0; q < nnzL; q++) S.Rp[S.Li[q] + 1]++;
-    for (i32 j = 0; j < n; j++) S.Rp[j + 1] += S.Rp[j];
-    S.Rcol.resize((size_t)nnzL + 1);
-    S.Rpos.resize((size_t)nnzL + 1);
-    S.Tpos.resize((size_t)nnzL + 1);
     {
-        std::vector<i32> nextp(S.Rp.begin(), S.Rp.end() - 1);
-        for (i32 k = 0; k < n; k++)
-            for (i32 q = S.Lp[k]; q < S.Lp[k + 1]; q++) {
-                const i32 t = nextp[S.Li[q]]++;
-                S.Rcol[t] = k;
-                S.Rpos[t] = q;
-                S.Tpos[q] = t;
+        const int T = par_threads(nnzL);
+        S.Rp.assign((size_t)n + 1, 0);
+        run_threads(T, [&](int t, int TT) {
+            const i32 k0 = (i32)(n * t / TT), k1 = (i32)(n * (t + 1) / TT);
+            for (i64 q = 0; q < nnzL; q++) {
+                const i32 r = S.Li[q];
+                if (r >= k0 && r < k1) S.Rp[r + 1]++;
             }
+        });
+        for (i32 j = 0; j < n; j++) S.Rp[j + 1] += S.Rp[j];
+        S.Rcol.resize((size_t)nnzL + 1);
+        S.Rpos.resize((size_t)nnzL + 1);
+        S.Tpos.resize((size_t)nnzL + 1);
+        std::vector<i32> nextp(S.Rp.begin(), S.Rp.end() - 1);
+        const std::vector<int64_t> cuts = balanced_cuts(S.Rp.data(), n, T);
+        run_threads(T, [&](int t, int) { // threads own ranges of rows; columns scanned in order by all
+            const i32 k0 = (i32)cuts[t], k1 = (i32)cuts[t + 1];
+            if (k0 >= k1) return;
+            for (i32 k = 0; k < n; k++)
+                for (i32 q = S.Lp[k]; q < S.Lp[k + 1]; q++) {
+                    const i32 r = S.Li[q];
+                    if (r < k0 || r >= k1) continue;
+                    const i32 u = nextp[r]++;
+                    S.Rcol[u] = k;
+                    S.Rpos[u] = q;
+                    S.Tpos[q] = u;
+                }
+        });
     }
     clk("CSR view of L");
     // ---- the permuted upper triangle of K, twice sorted (three counting passes, no comparisons):
@@ -601,59 +693,93 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     std::vector<i32> Tp((size_t)n + 1, 0), Thi((size_t)nnzK + 1), Tsrc((size_t)nnzK + 1);
     std::vector<i32> C2p((size_t)n + 1, 0), C2lo((size_t)nnzK + 1), C2src((size_t)nnzK + 1);
     {
+        // (each pass: threads own ranges of destination keys and scan the whole source in order; the
+        // permuted (lo, hi) of every entry is computed once, by source chunks, so that the scans are streams)
+        const int T = par_threads(nnzK);
         std::vector<i32> hp((size_t)n + 1, 0), hlo((size_t)nnzK + 1), hsrc((size_t)nnzK + 1);
-        for (i64 c = 0; c < n; c++) {
-            const i32 pc = S.iperm[c];
-            for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-                const i32 pr = S.iperm[Ai[p]];
-                hp[(pr > pc ? pr : pc) + 1]++;
-                Tp[(pr > pc ? pc : pr) + 1]++;
-            }
+        std::vector<i32> elo((size_t)nnzK + 1), ehi((size_t)nnzK + 1);
+        {
+            const std::vector<int64_t> ccuts = balanced_cuts(Ap, n, T);
+            run_threads(T, [&](int t, int) {
+                for (i64 c = ccuts[t]; c < ccuts[t + 1]; c++) {
+                    const i32 pc = S.iperm[c];
+                    for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                        const i32 pr = S.iperm[Ai[p]];
+                        elo[p] = pr < pc ? pr : pc;
+                        ehi[p] = pr < pc ? pc : pr;
+                    }
+                }
+            });
         }
+        run_threads(T, [&](int t, int TT) {
+            const i32 k0 = (i32)(n * t / TT), k1 = (i32)(n * (t + 1) / TT);
+            for (i64 p = 0; p < nnzK; p++) {
+                const i32 hi = ehi[p], lo = elo[p];
+                if (hi >= k0 && hi < k1) hp[hi + 1]++;
+                if (lo >= k0 && lo < k1) Tp[lo + 1]++;
+            }
+        });
         for (i32 j = 0; j < n; j++) {
             hp[j + 1] += hp[j];
             Tp[j + 1] += Tp[j];
         }
         C2p = hp;
+        const std::vector<int64_t> hcuts = balanced_cuts(hp.data(), n, T), tcuts = balanced_cuts(Tp.data(), n, T);
         {
             std::vector<i32> nx(hp.begin(), hp.end() - 1);
-            for (i64 c = 0; c < n; c++) { // pass 1: grouped by hi
-                const i32 pc = S.iperm[c];
-                for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
-                    const i32 pr = S.iperm[Ai[p]];
-                    const i32 lo = pr < pc ? pr : pc, hi = pr < pc ? pc : pr;
-                    const i32 t = nx[hi]++;
-                    hlo[t] = lo;
-                    hsrc[t] = (i32)p;
+            run_threads(T, [&](int t, int) { // pass 1: grouped by hi
+                const i32 k0 = (i32)hcuts[t], k1 = (i32)hcuts[t + 1];
+                if (k0 >= k1) return;
+                for (i64 p = 0; p < nnzK; p++) {
+                    const i32 hi = ehi[p];
+                    if (hi < k0 || hi >= k1) continue;
+                    const i32 u = nx[hi]++;
+                    hlo[u] = elo[p];
+                    hsrc[u] = (i32)p;
                 }
-            }
+            });
         }
         {
             std::vector<i32> nx(Tp.begin(), Tp.end() - 1);
-            for (i32 hi = 0; hi < n; hi++) // pass 2: by lo, hi ascending
-                for (i32 t = hp[hi]; t < hp[hi + 1]; t++) {
-                    const i32 u = nx[hlo[t]]++;
-                    Thi[u] = hi;
-                    Tsrc[u] = hsrc[t];
-                }
+            run_threads(T, [&](int t, int) { // pass 2: by lo, hi ascending
+                const i32 k0 = (i32)tcuts[t], k1 = (i32)tcuts[t + 1];
+                if (k0 >= k1) return;
+                for (i32 hi = 0; hi < n; hi++)
+                    for (i32 w = hp[hi]; w < hp[hi + 1]; w++) {
+                        const i32 lo = hlo[w];
+                        if (lo < k0 || lo >= k1) continue;
+                        const i32 u = nx[lo]++;
+                        Thi[u] = hi;
+                        Tsrc[u] = hsrc[w];
+                    }
+            });
         }
         {
             std::vector<i32> nx(C2p.begin(), C2p.end() - 1);
-            for (i32 lo = 0; lo < n; lo++) // pass 3: by hi, lo ascending
-                for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
-                    const i32 t = nx[Thi[u]]++;
-                    C2lo[t] = lo;
-                    C2src[t] = u; // position in V (T order)
-                }
+            run_threads(T, [&](int t, int) { // pass 3: by hi, lo ascending
+                const i32 k0 = (i32)hcuts[t], k1 = (i32)hcuts[t + 1];
+                if (k0 >= k1) return;
+                for (i32 lo = 0; lo < n; lo++)
+                    for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
+                        const i32 hi = Thi[u];
+                        if (hi < k0 || hi >= k1) continue;
+                        const i32 w = nx[hi]++;
+                        C2lo[w] = lo;
+                        C2src[w] = u; // position in V (T order)
+                    }
+            });
         }
     }
+    clk("T / C2 orders of K");
     // ---- the device's value store V = K.nzval in T order (row-wise by the smaller permuted index,
     //      diagonal first, ancestors ascending): V[u] = K.nzval[Tsrc[u]].  Rows lo < NF of V are the U
     //      rows the bundle kernels stream (residual AND the initial values of the bundle columns of the
     //      factorisation); rows lo >= NF (entries with both ends in the top) are scattered into the top
     //      columns of L by v2l: merge of row lo of T with column lo of L ----------
     S.k2v.resize((size_t)nnzK + 1);
-    for (i64 u = 0; u < nnzK; u++) S.k2v[Tsrc[u]] = (i32)u;
+    run_threads(par_threads(nnzK), [&](int t, int TT) {
+        for (i64 u = nnzK * t / TT; u < nnzK * (t + 1) / TT; u++) S.k2v[Tsrc[u]] = (i32)u;
+    });
     S.v2k.assign(Tsrc.begin(), Tsrc.begin() + nnzK);
     S.Vp = Tp;
     {
@@ -663,24 +789,34 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         // (only the rows of the top: the bundle columns merge their U rows inside k_bundle_factor)
         const i64 q0 = S.Lp[NFi];
         std::vector<char> covered((size_t)(nnzL - q0) + 1, 0);
-        for (i32 lo = NFi; lo < n; lo++) {
-            i32 q = S.Lp[lo];
-            const i32 qe = S.Lp[lo + 1];
-            for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
-                const i32 hi = Thi[u];
-                if (hi == lo) {
-                    S.v2l[u - u0] = (i32)(nnzL + lo);
-                    continue;
+        const int T = par_threads(nnzK - u0);
+        std::vector<int64_t> cuts = balanced_cuts(Tp.data() + NFi, (i64)n - NFi, T); // rows NF.., by their entries
+        std::vector<int> bad((size_t)T, 0);
+        run_threads(T, [&](int t, int) {
+            for (i32 lo = NFi + (i32)cuts[t]; lo < NFi + (i32)cuts[t + 1]; lo++) {
+                i32 q = S.Lp[lo];
+                const i32 qe = S.Lp[lo + 1];
+                for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
+                    const i32 hi = Thi[u];
+                    if (hi == lo) {
+                        S.v2l[u - u0] = (i32)(nnzL + lo);
+                        continue;
+                    }
+                    while (q < qe && S.Li[q] < hi) q++;
+                    if (q >= qe || S.Li[q] != hi) {
+                        bad[t] = 1;
+                        return;
+                    }
+                    S.v2l[u - u0] = q;
+                    covered[(size_t)(q - q0)] = 1;
                 }
-                while (q < qe && S.Li[q] < hi) q++;
-                if (q >= qe || S.Li[q] != hi) {
-                    set_error("internal: K entry missing from the pattern of L");
-                    return -9;
-                }
-                S.v2l[u - u0] = q;
-                covered[(size_t)(q - q0)] = 1;
             }
-        }
+        });
+        for (int t = 0; t < T; t++)
+            if (bad[t]) {
+                set_error("internal: K entry missing from the pattern of L");
+                return -9;
+            }
         // fill slots of the TOP columns (the bundle kernels zero their own while they merge the U rows)
         for (i64 q = q0; q < nnzL; q++)
             if (!covered[(size_t)(q - q0)]) S.fill_idx.push_back((i32)q);
@@ -701,27 +837,34 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         S.Ucol.push_back(0);
         // S: full rows r >= NF = column r of C2 (lo <= r ascending, diagonal last) then row r of T without its diagonal
         S.Sp.assign((size_t)n + 1, 0);
-        for (i32 r = NFi; r < n; r++) {
-            i32 cntr = C2p[r + 1] - C2p[r];
-            for (i32 u = Tp[r]; u < Tp[r + 1]; u++) cntr += Thi[u] != r;
-            S.Sp[r + 1] = cntr;
-        }
+        run_threads(par_threads((i64)Tp[n] - Tp[NFi]), [&](int t, int TT) {
+            const i64 span = (i64)n - NFi;
+            for (i32 r = NFi + (i32)(span * t / TT); r < NFi + (i32)(span * (t + 1) / TT); r++) {
+                i32 cntr = C2p[r + 1] - C2p[r];
+                for (i32 u = Tp[r]; u < Tp[r + 1]; u++) cntr += Thi[u] != r;
+                S.Sp[r + 1] = cntr;
+            }
+        });
         for (i32 j = 0; j < n; j++) S.Sp[j + 1] += S.Sp[j];
         S.nnzS = S.Sp[n];
         S.Scol.resize((size_t)S.nnzS + 1);
         S.Smap.resize((size_t)S.nnzS + 1);
-        for (i32 r = NFi; r < n; r++) {
-            i32 o = S.Sp[r];
-            for (i32 t = C2p[r]; t < C2p[r + 1]; t++) {
-                S.Scol[o] = C2lo[t];
-                S.Smap[o++] = C2src[t];
-            }
-            for (i32 u = Tp[r]; u < Tp[r + 1]; u++)
-                if (Thi[u] != r) {
-                    S.Scol[o] = Thi[u];
-                    S.Smap[o++] = u;
+        const int T = par_threads(S.nnzS);
+        const std::vector<int64_t> cuts = balanced_cuts(S.Sp.data() + NFi, (i64)n - NFi, T);
+        run_threads(T, [&](int t, int) {
+            for (i32 r = NFi + (i32)cuts[t]; r < NFi + (i32)cuts[t + 1]; r++) {
+                i32 o = S.Sp[r];
+                for (i32 w = C2p[r]; w < C2p[r + 1]; w++) {
+                    S.Scol[o] = C2lo[w];
+                    S.Smap[o++] = C2src[w];
                 }
-        }
+                for (i32 u = Tp[r]; u < Tp[r + 1]; u++)
+                    if (Thi[u] != r) {
+                        S.Scol[o] = Thi[u];
+                        S.Smap[o++] = u;
+                    }
+            }
+        });
     }
     clk("U / S rows of K");
     // ---- few dense top rows folded into the bundle kernels ----------------------

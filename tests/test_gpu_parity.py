@@ -833,6 +833,42 @@ def test_run_to_run_spread(hip, which):
     assert spread <= 1e-12, "run-to-run spread %g" % spread
 
 
+@pytest.mark.parametrize("which", ["c3", "c2_supernodes", "c5_supernodes"])
+def test_threaded_analysis_same_handle(hip, which, monkeypatch):
+    """the host analysis splits its big passes over std::threads by destination ownership (symbolic.cpp,
+    amd_order.cpp): every array must come out the same for any thread count.  Forced on at a small size
+    (CHIP_HOST_PAR_MIN=0), compared with the single-thread analysis through the device: same permutation,
+    same symbolic factorisation, same pivots and a solution within the run-to-run spread."""
+    if which == "c3":
+        pr = problems.portfolio_socp(60, 200, seed=3, late=True)
+    elif which == "c2_supernodes":
+        pr = problems.random_qp(6000, 12000, band=30, seed=1, late=True)
+    else:
+        pr = problems.chordal_sdp(5, 20, 5, 4, 11, seed=7)
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    rng = np.random.default_rng(5)
+    rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+    out = []
+    for threads in (1, 5):
+        monkeypatch.setenv("CHIP_HOST_THREADS", str(threads))
+        monkeypatch.setenv("CHIP_HOST_PAR_MIN", "0")
+        ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+        assert ks.update_scaling(pr["s"], pr["z"])
+        assert ks.update()
+        info = ks.linear_solver_info()
+        ks.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert ks.solve(x, z)
+        out.append((np.asarray(ks.perm).copy(), [np.asarray(a).copy() for a in ks.symbolic()],
+                    (info.regularize_count, info.positive_inertia, info.nnzL), np.concatenate([x, z])))
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    assert out[0][2] == out[1][2]
+    assert relerr(out[1][3], out[0][3]) <= 1e-12
+
+
 @pytest.mark.parametrize("which", ["arrow", "forest", "general"])
 def test_async_enqueue_collect(hip, oracle, which):
     """chip_kkt_update_enqueue / solve_dev_enqueue / collect: a whole iteration's KKT work enqueued without

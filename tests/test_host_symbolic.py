@@ -199,6 +199,26 @@ def test_symbolic_matches_oracle(hip, oracle, name):
     assert level.max() <= lv0.max()
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_threaded_analysis_same_symbolic(hip, name, monkeypatch):
+    """the big analysis passes run on several std::threads, each owning a range of destination keys and
+    scanning the source in order: the result must not depend on the thread count (forced on for these
+    small cases with CHIP_HOST_PAR_MIN=0)"""
+    pr = CASES[name]()
+    got = []
+    for threads in (1, 3, 8):
+        monkeypatch.setenv("CHIP_HOST_THREADS", str(threads))
+        monkeypatch.setenv("CHIP_HOST_PAR_MIN", "0")
+        ks = _mk(hip, pr)
+        info = ks.linear_solver_info()
+        got.append((np.asarray(ks.perm).copy(), [np.asarray(a).copy() for a in ks.symbolic()], info.nnzL, info.n_levels))
+    for g in got[1:]:
+        assert np.array_equal(g[0], got[0][0])
+        for a, b in zip(g[1], got[0][1]):
+            assert np.array_equal(a, b)
+        assert g[2:] == got[0][2:]
+
+
 def test_user_perm_respected_up_to_level_sort(hip, oracle, monkeypatch):
     # (chain supernodes pad their columns with explicit zeros, which nnzL counts: off for the exact comparison)
     monkeypatch.setenv("CHIP_NO_SNODE", "1")

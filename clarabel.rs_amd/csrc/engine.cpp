@@ -199,6 +199,15 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         if ((rc = upload(&sn_ptr, S.sn_ptr, S.sn_ptr.size()))) return rc;
         if ((rc = upload(&sn_col, S.sn_col, S.sn_col.size()))) return rc;
         if ((rc = upload(&sn_order, S.sn_order, S.sn_order.size()))) return rc;
+        {
+            std::vector<i32> geo((size_t)2 * nsn + 2, 0);
+            for (int sn = 0; sn < nsn; sn++) {
+                const i32 e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                geo[2 * sn] = e;
+                geo[2 * sn + 1] = S.Lp[e + 1] - S.Lp[e];
+            }
+            if ((rc = upload(&sn_geo, geo, geo.size()))) return rc;
+        }
         if ((rc = upload(&Rf_p, S.Rf_p, S.Rf_p.size()))) return rc;
         if ((rc = upload(&Rf_col, S.Rf_col, S.Rf_col.size()))) return rc;
         if ((rc = upload(&Rf_pos, S.Rf_pos, S.Rf_pos.size()))) return rc;
@@ -432,7 +441,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         vf.Rcol = Rf_col;
         vf.Rpos = Rf_pos;
     }
-    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot};
+    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo};
     auto has_sn = [&](int l) { return nsn > 0 && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
     auto run_supernodes = [&](int l) {
         if (!has_sn(l)) return;
@@ -531,7 +540,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         // chain supernodes: units by unit level.  Forward: every top row first gathers from the columns
         // that are not supernode members, then the level's supernodes solve their dense triangles and
         // push L_BS x_S to their ancestors' entries; backward: the reverse, column oriented.
-        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot};
+        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo};
         // wide supernodes: several workgroups per supernode, pipelined through per-block flags that carry this
         // sweep's epoch (not inside a captured graph: a replay would meet its own flags)
         static const bool no_tri = std::getenv("CHIP_NO_SNODE_TRI") != nullptr;

@@ -1034,16 +1034,42 @@ constexpr int SN_ROWS = 256; // panel rows per workgroup of the update kernels: 
 typedef double snode_v4d __attribute__((ext_vector_type(4)));
 typedef double snode_v2d __attribute__((ext_vector_type(2)));
 
+// broadcast of lane `src` (a compile-time constant after unrolling) without the LDS crossbar
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// x <- (I + T)^-1 x (FWDMODE) or (I + T)^-T x for one SN_NB block held by ONE wave, lane = row.  Tt is the block
+// in LDS with the LANE index fastest (forward: Tt[jj * SN_NB + row] = T(row, jj); backward: Tt[jj * SN_NB +
+// row] = T(jj, row)), zero outside the strict triangle, so a narrow last block needs no bounds.  The 64
+// coefficients of a lane do not depend on x: they are read up front (conflict-free), and the 64 dependent
+// steps are a v_readlane + v_fma each (with __shfl through LDS and a 512-byte-stride read per step the same
+// loop took ~3 us of a ~9 us pipeline stage of k_snode_tri).
+template <bool FWDMODE> __device__ __forceinline__ double snode_block_solve(const double *Tt, double xv, int lane) {
+    double t[SN_NB];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) t[jj] = Tt[jj * SN_NB + lane];
+    if (FWDMODE) {
+#pragma unroll
+        for (int jj = 0; jj < SN_NB - 1; ++jj) xv -= t[jj] * readlane_f64(xv, jj);
+    } else {
+#pragma unroll
+        for (int jj = SN_NB - 1; jj > 0; --jj) xv -= t[jj] * readlane_f64(xv, jj);
+    }
+    return xv;
+}
+
 struct SnodeGeom {
     const int *cols;
     int w, nb, h, e;
 };
 __device__ __forceinline__ SnodeGeom snode_geom(const LdlView &v, const SnodeView &sv, int sn) {
     SnodeGeom g;
-    g.cols = sv.sn_col + sv.sn_ptr[sn];
-    g.w = sv.sn_ptr[sn + 1] - sv.sn_ptr[sn];
-    g.e = g.cols[g.w - 1];
-    g.nb = v.Lp[g.e + 1] - v.Lp[g.e];
+    const int p0 = sv.sn_ptr[sn], p1 = sv.sn_ptr[sn + 1];
+    g.cols = sv.sn_col + p0;
+    g.w = p1 - p0;
+    g.e = sv.sn_geo[2 * sn];
+    g.nb = sv.sn_geo[2 * sn + 1];
     g.h = g.w + g.nb;
     return g;
 }
@@ -1293,9 +1319,12 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, 
 }
 // grid (row groups of SN_DWG rows, supernodes of the level): the rows below the diagonal block of
 // block column b, one thread per row, forward substitution against the (finished) block
-__global__ __launch_bounds__(SN_DWG) void k_snode_rows(LdlView v, SnodeView sv, const int *__restrict__ order,
+// (one WAVE per workgroup: the 2016 products of a row each read a coefficient from LDS -- broadcast reads, bound
+// by the LDS issue rate of the CU -- so 64 rows per CU over many CUs beat 256 rows on a few)
+constexpr int SN_RWG = 64;
+__global__ __launch_bounds__(SN_RWG) void k_snode_rows(LdlView v, SnodeView sv, const int *__restrict__ order,
                                                        int b) {
-    __shared__ double dT[SN_NB * SN_NB]; // d_q * L_JJ[jj][q]
+    __shared__ __attribute__((aligned(16))) double dT[SN_NB * SN_NB];
     __shared__ double dinvl[SN_NB], dl[SN_NB];
     __shared__ int colbase[SN_NB];
     const int sn = order[blockIdx.y];
@@ -1303,44 +1332,59 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_rows(LdlView v, SnodeView sv, 
     const int j0 = b * SN_NB;
     if (j0 >= g.w) return;
     const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x;
-    const int i = j0 + nbw + (int)blockIdx.x * SN_DWG + tid;
-    if (j0 + nbw + (int)blockIdx.x * SN_DWG >= g.h) return;
-    if (tid < nbw) {
-        const int c = g.cols[j0 + tid];
-        colbase[tid] = v.Lp[c] - (j0 + tid) - 1;
-        dinvl[tid] = v.Dinv[c];
-        dl[tid] = v.D[c];
+    const int i = j0 + nbw + (int)blockIdx.x * SN_RWG + tid;
+    if (j0 + nbw + (int)blockIdx.x * SN_RWG >= g.h) return;
+    {
+        const bool in = tid < nbw; // (a narrow last block is padded with an identity)
+        const int c = in ? g.cols[j0 + tid] : 0;
+        colbase[tid] = in ? v.Lp[c] - (j0 + tid) - 1 : 0;
+        dinvl[tid] = in ? v.Dinv[c] : 1.0;
+        dl[tid] = in ? v.D[c] : 0.0;
     }
     __syncthreads();
-    // (the pivots come from LDS: with v.D[g.cols[..]] inside this loop every one of its 16 rounds was a chain
-    // of two dependent global loads, ~25 of the kernel's 36 us; now the 16 block entries of a thread and the
-    // 64 panel entries of its row are all requested before the first is used)
-    {
-        double tv[SN_NB * SN_NB / SN_DWG];
+    // dTt[q * SN_NB + jj] = d_q L_JJ(jj, q) for jj > q, else 0 (column q of the block contiguous); the pivots come
+    // from LDS (v.D[g.cols[..]] inside this loop was a chain of two dependent global loads per round)
+    for (int base = 0; base < SN_NB * SN_NB; base += 32 * SN_RWG) {
+        double tv[32];
 #pragma unroll
-        for (int r = 0; r < SN_NB * SN_NB / SN_DWG; ++r) {
-            const int idx = tid + r * SN_DWG, ii = idx / SN_NB, jj = idx % SN_NB;
-            tv[r] = (ii > jj && ii < nbw) ? v.Lx[colbase[jj] + j0 + ii] : 0.0;
+        for (int r = 0; r < 32; ++r) {
+            const int idx = base + tid + r * SN_RWG, q = idx / SN_NB, jj = idx % SN_NB;
+            tv[r] = (jj > q && jj < nbw) ? v.Lx[colbase[q] + j0 + jj] : 0.0;
         }
 #pragma unroll
-        for (int r = 0; r < SN_NB * SN_NB / SN_DWG; ++r) {
-            const int idx = tid + r * SN_DWG;
-            dT[idx] = tv[r] * dl[idx % SN_NB];
+        for (int r = 0; r < 32; ++r) {
+            const int idx = base + tid + r * SN_RWG;
+            dT[idx] = tv[r] * dl[idx / SN_NB];
         }
     }
     double x[SN_NB];
     const bool rowok = i < g.h;
+    const int ic = rowok ? i : g.h - 1; // (unconditional loads from a valid row: no branch per entry)
 #pragma unroll
-    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = (rowok && jj < nbw) ? v.Lx[colbase[jj] + i] : 0.0;
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = v.Lx[colbase[jj < nbw ? jj : 0] + ic];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = jj < nbw ? x[jj] : 0.0;
     __syncthreads();
     if (!rowok) return;
+    // right-looking: x_q is final after the updates of columns < q; it then updates every later entry of the
+    // row.  The products of one q are independent (the left-looking form chained 2016 FMAs on one accumulator
+    // behind serialised LDS reads: 48 us); per entry the subtractions still happen in the order q = 0, 1, ...
+    // of qdldl.rs:708-719.  Coefficients come in as 16-byte pairs (jj even, jj + 1); the pair that straddles q
+    // multiplies a stored zero.
 #pragma unroll
-    for (int jj = 0; jj < SN_NB; ++jj) {
-        if (jj < nbw) {
-            double sacc = x[jj];
+    for (int q = 0; q < SN_NB; ++q) {
+        const double xq = x[q] * dinvl[q];
+        x[q] = xq;
+        // (an opaque zero that "depends" on x_q ties this column's LDS reads to its place in the chain: left
+        // alone the compiler reads all 1024 coefficient pairs before the first product and spills them)
+        int zoff;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(xq)));
+        const snode_v2d *cf = (const snode_v2d *)&dT[q * SN_NB + zoff];
 #pragma unroll
-            for (int q = 0; q < jj; ++q) sacc -= x[q] * dT[jj * SN_NB + q];
-            x[jj] = sacc * dinvl[jj];
+        for (int p2 = (q + 1) / 2; p2 < SN_NB / 2; ++p2) {
+            const snode_v2d cc = cf[p2];
+            x[2 * p2] -= xq * cc.x;
+            x[2 * p2 + 1] -= xq * cc.y;
         }
     }
 #pragma unroll
@@ -1394,17 +1438,14 @@ __global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, co
     __syncthreads();
     for (int j0 = 0; j0 < g.w; j0 += SN_NB) {
         const int nbw = min(SN_NB, g.w - j0);
-        for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_WG) {
-            const int ii = idx / SN_NB, jj = idx % SN_NB;
+        for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_WG) { // Tl[col * SN_NB + row] (snode_block_solve)
+            const int jj = idx / SN_NB, ii = idx % SN_NB;
             L.Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[L.colbase[j0 + jj] + j0 + ii] : 0.0;
         }
         __syncthreads();
         if (wave == 0) { // the block's unknowns: lane = row, values in registers
             double xv = lane < nbw ? L.xs[j0 + lane] : 0.0;
-            for (int jj = 0; jj < nbw; ++jj) {
-                const double xj = __shfl(xv, jj);
-                if (lane > jj) xv -= L.Tl[lane * SN_NB + jj] * xj;
-            }
+            xv = snode_block_solve<true>(L.Tl, xv, lane);
             if (lane < nbw) L.xs[j0 + lane] = xv;
         }
         __syncthreads();
@@ -1570,10 +1611,7 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
         __syncthreads();
         if (wave == 0) {
             double xv = lane < nbw ? L.xs[j0 + lane] - L.csum[lane] : 0.0;
-            for (int jj = nbw - 1; jj >= 0; --jj) {
-                const double xj = __shfl(xv, jj);
-                if (lane < jj) xv -= L.Tl[jj * SN_NB + lane] * xj;
-            }
+            xv = snode_block_solve<false>(L.Tl, xv, lane);
             if (lane < nbw) L.xs[j0 + lane] = xv;
         }
         __syncthreads();
@@ -1622,8 +1660,11 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
     double xown = (wave == 0 && lane < nbw) ? x[g.cols[j0 + lane]] : 0.0; // (last written before this launch)
     __syncthreads();
     const int *cbr = colbase + (FWDMODE ? j0 : 0); // column bases of the own block
+    // the diagonal block with the solve's lane index fastest (snode_block_solve): forward Tl[col * SN_NB + row],
+    // backward Tl[row * SN_NB + col]
     for (int idx = tid; idx < SN_NB * SN_NB; idx += SN2_WG) {
-        const int ii = idx / SN_NB, jj = idx % SN_NB;
+        const int hi = idx / SN_NB, lo = idx % SN_NB;
+        const int ii = FWDMODE ? lo : hi, jj = FWDMODE ? hi : lo;
         Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[cbr[jj] + j0 + ii] : 0.0;
     }
     double acc[CPW];
@@ -1694,17 +1735,7 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
                 xv -= part[0][lane];
             }
         }
-        if (FWDMODE) {
-            for (int jj = 0; jj < nbw; ++jj) {
-                const double xj = __shfl(xv, jj);
-                if (lane > jj) xv -= Tl[lane * SN_NB + jj] * xj;
-            }
-        } else {
-            for (int jj = nbw - 1; jj >= 0; --jj) {
-                const double xj = __shfl(xv, jj);
-                if (lane < jj) xv -= Tl[jj * SN_NB + lane] * xj;
-            }
-        }
+        xv = snode_block_solve<FWDMODE>(Tl, xv, lane);
         if (lane < nbw) __hip_atomic_store(&x[g.cols[j0 + lane]], xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // every lane's store has been acknowledged (s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)) before the flag
         // is stored: two stores to different addresses are not ordered by the memory system
@@ -5051,7 +5082,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const i
         }
         k_snode_diag<<<count, SN_DWG, 0, s>>>(v, sv, order, b);
         const int below = hmax - b * SN_NB - 1; // (a narrow last block leaves more rows below it)
-        if (below > 0) k_snode_rows<<<dim3((below + SN_DWG - 1) / SN_DWG, count), SN_DWG, 0, s>>>(v, sv, order, b);
+        if (below > 0) k_snode_rows<<<dim3((below + SN_RWG - 1) / SN_RWG, count), SN_RWG, 0, s>>>(v, sv, order, b);
     }
     if (nbmax > 0 && sv.upd_slot)
         k_snode_extend<<<dim3((nbmax + SN_ROWS - 1) / SN_ROWS, (nbmax + SN_NB - 1) / SN_NB, count), SN_WG, lds, s>>>(

@@ -146,6 +146,7 @@ struct SnodeView {
     const int *sn_ptr, *sn_col;
     const long long *upd_ptr; // per supernode: offset of its packed strict lower triangle of B x B in upd_slot
     const int *upd_slot;      // CSC slot of L(B[r], B[c]), r > c  (nullptr: no dense ancestor updates)
+    const int *sn_geo;        // per supernode: (last member column e, rows of B = |struct(e)|) -- saves two dependent loads
 };
 int snode_kernel_attributes(int wmax, int nbmax);
 

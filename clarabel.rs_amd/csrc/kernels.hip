@@ -1644,6 +1644,7 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
                                                       double *x, int *timeout_flag) {
     __shared__ double Tl[SN_NB * SN_NB];
     __shared__ double part[SN2_WG / 64][SN_NB];
+    __shared__ double pulled[SN_NB]; // backward: L_B,r' x_B of the own columns; forward: the finished x_r
     __shared__ int colbase[SN2_WMAX]; // forward: of all earlier columns; backward: of the own block only
     const int sn = order[blockIdx.y];
     const SnodeGeom g = snode_geom(v, sv, sn);
@@ -1660,6 +1661,35 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
     double xown = (wave == 0 && lane < nbw) ? x[g.cols[j0 + lane]] : 0.0; // (last written before this launch)
     __syncthreads();
     const int *cbr = colbase + (FWDMODE ? j0 : 0); // column bases of the own block
+    const int *Bn = v.Li + v.Lp[g.e];              // node ids of the rows of B
+    if (!FWDMODE) {
+        // the block's own columns first take D^-1 and the rows of B: x_j <- x_j / d_j - sum_r L(B_r, j) x(B_r)
+        // (what k_snode_pull did in a launch of its own; here every block does it while it would otherwise
+        // wait for the flags of the later blocks).  Rows of B along the lanes, this wave's CPW columns together.
+        double pacc[CPW];
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) pacc[q] = 0.0;
+        for (int r0 = 0; r0 < g.nb; r0 += 64) {
+            const int r = r0 + lane;
+            const bool rok = r < g.nb;
+            const double xb = rok ? x[Bn[r]] : 0.0;
+            double lq[CPW];
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                const int j = wave * CPW + q;
+                lq[q] = (rok && j < nbw) ? v.Lx[cbr[j] + g.w + r] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) pacc[q] += lq[q] * xb;
+        }
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const double tot = wave_sum(pacc[q]);
+            if (lane == 0) pulled[wave * CPW + q] = tot;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < nbw) xown = xown * v.Dinv[g.cols[j0 + lane]] - pulled[lane];
+    }
     // the diagonal block with the solve's lane index fastest (snode_block_solve): forward Tl[col * SN_NB + row],
     // backward Tl[row * SN_NB + col]
     for (int idx = tid; idx < SN_NB * SN_NB; idx += SN2_WG) {
@@ -1742,6 +1772,25 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) __hip_atomic_store(&fl[r], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FWDMODE) pulled[lane] = lane < nbw ? xv : 0.0;
+    }
+    if (FWDMODE && g.nb > 0) {
+        // after the flag (off the pipeline's critical path): this block's share of x_B -= L_BS x_S, one row of B
+        // per thread, one atomic per (row, block) -- what k_snode_push did in a launch of its own
+        __syncthreads();
+        if (!ok) return;
+        for (int rb = tid; rb < g.nb; rb += SN2_WG) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int j2 = 0; j2 < SN_NB; j2 += 16) {
+                double lv2[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) lv2[q] = (j2 + q < nbw) ? v.Lx[cbr[j2 + q] + g.w + rb] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sacc += lv2[q] * pulled[j2 + q];
+            }
+            atomicAdd(&x[Bn[rb]], -sacc);
+        }
     }
 }
 
@@ -5032,17 +5081,11 @@ void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView
         if (m == FWD) {
             k_snode_tri<true><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->flags, tri->epoch, x,
                                                                     tri->timeout_flag);
-            if (nblvl > 0)
-                k_snode_push<<<dim3((nblvl + SN_WG - 1) / SN_WG, (wlvl + SN_PCH - 1) / SN_PCH, count), SN_WG, 0, s>>>(
-                    v, sv, order, x);
         } else {
-            int cap = SN_XB_CAP;
-            const int nbcap = std::min(nbmax_all, cap);
-            k_snode_pull<<<dim3((wlvl + SN_NB - 1) / SN_NB, count), SN_WG, (size_t)nbcap * sizeof(double), s>>>(
-                v, sv, order, x, nbcap);
             k_snode_tri<false><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->flags, tri->epoch, x,
                                                                      tri->timeout_flag);
         }
+        (void)nblvl;
         return;
     }
     int cap = SN_XB_CAP;

@@ -1062,6 +1062,28 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         S.sn_lvl_nblk.assign((size_t)nfl, 0);
         S.sn_lvl_hmax.assign((size_t)nfl, 0);
         S.sn_lvl_nbmax.assign((size_t)nfl, 0);
+        // Forward substitution, supernode members: a member's row restricted to NON-member columns (bundle
+        // columns and ordinary top columns; member columns of any supernode reach it through the dense pushes)
+        // can be gathered as soon as the ordinary top columns it refers to are final -- usually long before its own
+        // unit level.  Each member row therefore joins the gather launch of level 1 + (highest unit level of an
+        // ordinary top column in its list), 0 when it only refers to bundle columns: the gathers and the pushes
+        // are both subtractions from the same entry, their order is free.  Config 2: 27 gather launches per
+        // sweep become a handful.  (CHIP_NO_GATHER_HOIST keeps every row at its own level.)
+        std::vector<std::vector<i32>> hoisted((size_t)nfl);
+        if (nsn > 0) {
+            const bool no_hoist = std::getenv("CHIP_NO_GATHER_HOIST") != nullptr;
+            for (i32 sn = 0; sn < nsn; sn++)
+                for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) {
+                    const i32 j = S.sn_col[t];
+                    if (FRp[j + 1] == FRp[j]) continue;
+                    i32 gl = 0;
+                    if (no_hoist) gl = sn_level[sn];
+                    else
+                        for (i32 q = FRp[j]; q < FRp[j + 1]; q++)
+                            if (FRcol[q] >= NFi) gl = std::max(gl, ulev[FRcol[q]] + 1);
+                    hoisted[(size_t)std::min(gl, sn_level[sn])].push_back(j);
+                }
+        }
         ListBuilder fac(S.fac), snx(S.snx), fwu(S.fwu), bwu(S.bwu);
         for (i32 l = 0; l < nfl; l++) {
             for (i32 u = lcount[l]; u < lcount[l + 1]; u++) {
@@ -1099,12 +1121,13 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                     i64 work = 0;
                     for (i32 q = eb; q < ee; q++) work += S.Lp[FRcol[q] + 1] - (FRpos[q] + 1) + 1;
                     snx.add_B_work(j, eb, ee, FRcol, FRpos, S.Lp, work);
-                    // forward substitution: the member's row restricted to non-member columns
-                    const i32 rj = ee - eb;
-                    if (rj > B_MIN) fwu.add_B(j, eb, ee);
-                    else if (rj > T_MAX) fwu.add_W(j);
-                    else fwu.add_T(j);
                 }
+            }
+            for (const i32 j : hoisted[(size_t)l]) { // member rows whose gather belongs to this level's launch
+                const i32 eb = FRp[j], ee = FRp[j + 1], rj = ee - eb;
+                if (rj > B_MIN) fwu.add_B(j, eb, ee);
+                else if (rj > T_MAX) fwu.add_W(j);
+                else fwu.add_T(j);
             }
             fac.close_level();
             snx.close_level();

@@ -288,9 +288,11 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // (pass A runs first; when members move, the new order is analysed and, its fill being no larger, kept)
     permuted_triu(n, Ap, Ai, ip0, Cp, Ci);
     etree_counts(n, Cp, Ci, parent, cnt, &rowcnt);
-    if (perm0.empty() && n > 0 && std::getenv("CHIP_NO_CHAIN_REORDER") == nullptr) {
-        i64 nnzL0 = 0;
-        for (i32 j = 0; j < n; j++) nnzL0 += cnt[j];
+    i64 nnzL0 = 0;
+    for (i32 j = 0; j < n; j++) nnzL0 += cnt[j];
+    // (the walk costs one more pass over nnz(L): skipped for factors beyond 1e8 entries -- dense fronts, whose
+    // depth is a matter of the supernode kernels, not of single columns)
+    if (perm0.empty() && n > 0 && nnzL0 <= 100000000 && std::getenv("CHIP_NO_CHAIN_REORDER") == nullptr) {
         std::vector<i32> chain((size_t)n), nlev((size_t)n, 0), rel((size_t)n, 0), stamp((size_t)n, -1);
         std::vector<i32> cfirst((size_t)n, -1), cnext((size_t)n, -1); // members of a chain, linked in old order
         i32 nchains = 0;

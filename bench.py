@@ -21,10 +21,13 @@ exchange all go through the C ABI (include/clarabel_hip.h).
         vars are used): BASELINE config 4, 1024 independent SOCPs of n = 2000, sharded by
         whole elimination trees over the ranks (clarabel.rs_amd/sharding.py: 1024/N blocks
         each) -- STRONG scaling: the total problem is fixed.  Factor / solves / refinement
-        need no exchange; after each of the 3 solves the step direction is all-gathered
-        with RCCL over xGMI (chip_kkt_allgather_step: ordered behind the solve by an event,
-        running on its own stream behind the next solve).  value = steps / time of the
-        whole 1024-block problem.
+        need no exchange; the iteration's step direction -- the solution of the LAST of the
+        three solves, the combined direction the iterate moves along (the first two solves
+        feed block-local updates and scalars only) -- is all-gathered with RCCL over xGMI
+        (chip_kkt_allgather_step: ordered behind the solve by an event, running on its own
+        stream behind the next step's update and first two solves; --gather-every-solve
+        gathers all three solutions instead).  value = steps / time of the whole 1024-block
+        problem.
 --workload c3|c4 forces the workload (c4 at N = 1 = the whole batched problem).
 """
 import argparse
@@ -83,6 +86,7 @@ class Workload:
         self.rhs = [(hip.DeviceArray(rx), hip.DeviceArray(rz)) for rx, rz in self.rhs_host]
         self.lhs = [hip.DeviceArray(n + m) for _ in range(nrhs)]
         self.n, self.m = n, m
+        self.gather_every_solve = False
 
     def step(self, comm=None, gathered=None, counts=None):
         # one interior-point iteration's KKT work is ENQUEUED as a whole; the reference's bools (update:
@@ -91,16 +95,18 @@ class Workload:
         ks = self.ks
         ks.update_scaling_dev(self.s_d.ptr, self.z_d.ptr)
         ks.update_enqueue()
+        last = len(self.rhs) - 1
         for k, (rx, rz) in enumerate(self.rhs):
-            if comm is not None:
+            exchange = comm is not None and (self.gather_every_solve or k == last)
+            if exchange:
                 # lhs[k] / gathered[k] were handed to the all-gather one step ago: this stream waits
                 # for it ON THE DEVICE (no host synchronisation) before overwriting them
                 comm.wait(ks)
             ks.setrhs_dev(rx.ptr, rz.ptr)
             ks.solve_dev_enqueue(self.lhs[k].ptr, self.lhs[k].ptr + 8 * self.n)
-            if comm is not None:
+            if exchange:
                 # every rank ends up with the full step direction (dx, dz): RCCL all-gather over xGMI,
-                # enqueued behind this solve by an event and left running behind the next solve
+                # enqueued behind this solve by an event and left running behind the next solves
                 comm.allgather_step(ks, self.lhs[k].ptr, gathered[k].ptr, counts)
         uok, sok = ks.collect()
         if not uok or len(sok) != len(self.rhs) or not all(sok):
@@ -262,6 +268,10 @@ def main():
     ap.add_argument("--nblocks", type=int, default=1000, help="c3: SOC blocks (default: config 3)")
     ap.add_argument("--blocksize", type=int, default=1000)
     ap.add_argument("--nbatch", type=int, default=1024, help="c4: independent SOCPs (default: config 4)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="c4 at N = 1: run the all-gather path with a one-rank RCCL communicator (plumbing check)")
+    ap.add_argument("--gather-every-solve", action="store_true",
+                    help="N > 1: all-gather the solution of each of the 3 solves, not only the step direction")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1 auto, 0 off)")
     ap.add_argument("--no-extras", action="store_true", help="skip parity / cpu legs / batched_c4 (profiling runs)")
     ap.add_argument("--profile-family", type=int, default=5,
@@ -313,9 +323,11 @@ def main():
                 "%d per GPU" % (args.nbatch, b1 - b0))
         counts = [(e - b) * (pr["n"] + pr["m"]) // (b1 - b0) for b, e in ranges]
     w = Workload(hip, pr, device, rank)
+    w.gather_every_solve = bool(args.gather_every_solve)
     info = w.ks.linear_solver_info()
     t_setup = w.t_setup
-    if world > 1:
+    if world > 1 or (args.force_comm and workload == "c4"):
+        # (--force-comm: the exchange path with a one-rank communicator -- plumbing check on a single-GPU box)
         comm = hip.Comm(rendezvous_id(hip, rank, world), world, rank, device)
         comm.attach(w.ks)
         gathered = [hip.DeviceArray(int(sum(counts))) for _ in range(3)]
@@ -399,8 +411,10 @@ def main():
                        "per_step": "1 update(scaling+Hs+static reg+refactor) + 3 solves x (LDL solve + 1 IR round)",
                        "ir_rounds": int(ir), "setup_s": round(t_setup, 2),
                        "gpus_on_problem": int(info.threads) if world == 1 else world,
-                       "collective": ("3 x all-gather of the step direction per step, native RCCL (ncclAllGather fp64, %d doubles) "
-                                      "on its own stream, event-ordered" % int(sum(counts))) if world > 1 else "none"},
+                       "collective": ("%s per step, native RCCL (ncclAllGather fp64, %d doubles) on its own stream, event-ordered"
+                                      % ("3 x all-gather (every solve's solution)" if args.gather_every_solve else
+                                         "1 x all-gather of the step direction (the last solve's solution)",
+                                         int(sum(counts)))) if comm is not None else "none"},
             "roofline": roof, "parity": parity, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt, "batched_c4": c4,
         }
         print(json.dumps(out))

@@ -2454,7 +2454,7 @@ struct IrState {
 // 3003-node bundles), 512 for bundles whose LDS slice only lets three in (config 4's 6007-node bundles: 6
 // waves per SIMD, 80 registers -- with 256 threads only 12 of a CU's 32 wave slots would be used)
 template <int TW>
-__global__ __launch_bounds__(TW) __attribute__((amdgpu_waves_per_eu(TW == 256 ? 4 : 6, TW == 256 ? 4 : 6)))
+__global__ __launch_bounds__(TW) __attribute__((amdgpu_waves_per_eu(TW == 512 ? 6 : 4, TW == 512 ? 6 : 4)))
 void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *xs = (double *)smem;
@@ -5010,7 +5010,7 @@ template <int TW> static int bundle_ir_capacity_tw(const BundleView &bv) {
     }
     const size_t per_wg = ((fa.sharedSizeBytes + lds + 1023) / 1024) * 1024;
     const int by_lds = (int)(prop.maxSharedMemoryPerMultiProcessor / per_wg);
-    const int by_waves = (TW == 256 ? 16 : 24) / (TW / 64); // waves per CU the kernel was compiled for
+    const int by_waves = (TW == 512 ? 24 : 16) / (TW / 64); // waves per CU the kernel was compiled for
     per_cu = std::min(per_cu, std::min(by_lds, by_waves));
     return per_cu * prop.multiProcessorCount;
 }
@@ -5025,6 +5025,16 @@ int bundle_ir_capacity(const BundleView &bv, int *tw) {
         *tw = 256;
         return c256;
     }
+    // few large bundles (a batched problem's share of one GPU of eight): one 1024-thread workgroup per CU --
+    // a bundle's sweeps are latency chains, twice the threads take a level's columns in half the passes
+    static const bool no1024 = std::getenv("CHIP_NO_IR1024") != nullptr;
+    if (!no1024 && bv.nb <= prop.multiProcessorCount) {
+        const int c1024 = bundle_ir_capacity_tw<1024>(bv);
+        if (c1024 >= bv.nb) {
+            *tw = 1024;
+            return c1024;
+        }
+    }
     *tw = 512;
     return bundle_ir_capacity_tw<512>(bv);
 }
@@ -5033,6 +5043,7 @@ int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldV
     // grid <= bundle_ir_capacity(): every workgroup is resident on an otherwise idle device, and a grid
     // barrier that cannot complete times out instead of hanging
     if (tw == 256) k_bundle_ir<256><<<grid, 256, bundle_lds(bv), s>>>(v, bv, fold, ir);
+    else if (tw == 1024) k_bundle_ir<1024><<<grid, 1024, bundle_lds(bv), s>>>(v, bv, fold, ir);
     else k_bundle_ir<512><<<grid, 512, bundle_lds(bv), s>>>(v, bv, fold, ir);
     return (int)hipGetLastError();
 }

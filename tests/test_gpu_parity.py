@@ -869,7 +869,7 @@ def test_threaded_analysis_same_handle(hip, which, monkeypatch):
     assert relerr(out[1][3], out[0][3]) <= 1e-12
 
 
-@pytest.mark.parametrize("which", ["arrow", "forest", "general"])
+@pytest.mark.parametrize("which", ["arrow", "forest", "forest_big", "general"])
 def test_async_enqueue_collect(hip, oracle, which):
     """chip_kkt_update_enqueue / solve_dev_enqueue / collect: a whole iteration's KKT work enqueued without
     a host synchronisation, verdicts collected once -- same solutions as the synchronous calls.  "arrow" and
@@ -878,6 +878,8 @@ def test_async_enqueue_collect(hip, oracle, which):
     host-controlled path behind the same entry points."""
     pr = {"arrow": lambda: problems.portfolio_socp(20, 300, seed=3, late=True),
           "forest": lambda: problems.batched_socp(24, 300, 2, seed=100),
+          # (few 6007-node trees, config 4's share of one GPU of eight: the 1024-thread variant of the fused launch)
+          "forest_big": lambda: problems.batched_socp(6, 2000, 2, seed=100),
           "general": lambda: problems.random_qp(3000, 6000, band=20, seed=1)}[which]()
     ks, ko, cones = _solvers(hip, oracle, pr)
     rng = np.random.default_rng(9)

@@ -220,8 +220,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             std::vector<i32> bp((size_t)nsn + 1, 0);
             for (int sn = 0; sn < nsn; sn++) bp[sn + 1] = bp[sn] + (S.sn_ptr[sn + 1] - S.sn_ptr[sn] + 63) / 64;
             if ((rc = upload(&sn_blk_ptr, bp, bp.size()))) return rc;
-            if ((rc = alloc(&sn_flags, (size_t)bp[nsn] + 1))) return rc;
-            CHIP_HIP(hipMemset(sn_flags, 0, ((size_t)bp[nsn] + 1) * sizeof(int)));
+            // message slots of the pipelined substitution (k_snode_tri): 64 x 16 bytes per block, epoch 0 = never written
+            if ((rc = alloc(&sn_flags, ((size_t)bp[nsn] + 1) * 256))) return rc;
+            CHIP_HIP(hipMemset(sn_flags, 0, ((size_t)bp[nsn] + 1) * 256 * sizeof(int)));
         }
         sn_lvl_ptr = S.sn_lvl_ptr;
         sn_lvl_nblk = S.sn_lvl_nblk;

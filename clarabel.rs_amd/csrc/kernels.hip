@@ -1636,11 +1636,31 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
 // stores / loads, no agent-scope fence (see ir_arrive_wait).  The rows of B are handled by k_snode_push /
 // k_snode_pull in their own launches.
 // ---------------------------------------------------------------------------
+// One 16-byte message per unknown: (value, epoch, epoch) written by ONE dwordx4 store and read by ONE dwordx4
+// load, both device coherent (sc1, what the compiler emits for agent-scope atomics) -- a consumer that sees
+// this sweep's epoch has the value with it, in one round trip; value and flag as two stores needed the
+// producer to wait for the first to be acknowledged and the consumer to load twice (~2 of ~4.5 us per hop).
+typedef int msg_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void msg_store(int *slot, double val, int tag) {
+    msg_v4i m;
+    m.x = __double2loint(val);
+    m.y = __double2hiint(val);
+    m.z = tag;
+    m.w = tag;
+    // (s_nop: a store of more than 8 bytes reads its data registers a few cycles after issue; the compiler pads
+    // that hazard for its own stores, not for inline assembly -- without it the next VALU write clobbered the tags)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" ::"v"(slot), "v"(m) : "memory");
+}
+__device__ __forceinline__ msg_v4i msg_load(const int *slot) {
+    msg_v4i m;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(m) : "v"(slot) : "memory");
+    return m;
+}
 constexpr int SN2_WG = 256;
 constexpr int SN2_WMAX = 4096; // widest supernode (symbolic.cpp: SN_MAX_W); its column bases are kept in LDS
 template <bool FWDMODE>
 __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, const int *__restrict__ order,
-                                                      const int *__restrict__ blk_ptr, int *flags, int epoch,
+                                                      const int *__restrict__ blk_ptr, int *msg, int epoch,
                                                       double *x, int *timeout_flag) {
     __shared__ double Tl[SN_NB * SN_NB];
     __shared__ double part[SN2_WG / 64][SN_NB];
@@ -1653,7 +1673,7 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
     const int r = FWDMODE ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = r * SN_NB, nbw = min(SN_NB, g.w - j0);
-    int *fl = flags + blk_ptr[sn];
+    int *mb = msg + (size_t)blk_ptr[sn] * 256; // this supernode's message slots: block c, lane l at (c * 64 + l) * 4
     constexpr int CPW = SN_NB / (SN2_WG / 64); // columns per wave: of block c (forward) / of the own block (backward)
     // nothing below depends on x: column bases, the diagonal block and the own entries are requested first
     const int cb_lo = FWDMODE ? 0 : j0, cb_hi = j0 + nbw;
@@ -1722,20 +1742,21 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
 #pragma unroll
         for (int q = 0; q < CPW; ++q) lv[q] = ln[q];
         if (step + 1 < nsteps) request(ln, step + 1);
-        if (lane == 0) {
-            long long spins = 0;
-            while (__hip_atomic_load(&fl[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1ll << 22)) {
-                    ok = false;
-                    *timeout_flag = 1;
-                    break;
-                }
+        // every lane polls the message of "its" unknown of block c
+        msg_v4i mm;
+        for (long long spins = 0;; ++spins) {
+            mm = msg_load(mb + (c * 64 + lane) * 4);
+            const bool got = lane >= ncw || (mm.z == epoch && mm.w == epoch);
+            if (__all(got)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (spins > (1ll << 18)) {
+                ok = false;
+                if (lane == 0) *timeout_flag = 1;
+                break;
             }
         }
-        ok = __shfl((int)ok, 0, 64) != 0;
         if (!ok) break;
-        const double xcv = lane < ncw ? __hip_atomic_load(&x[g.cols[c0 + lane]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        const double xcv = lane < ncw ? __hiloint2double(mm.y, mm.x) : 0.0;
         if (FWDMODE) {
 #pragma unroll
             for (int q = 0; q < CPW; ++q) acc[0] += lv[q] * __shfl(xcv, wave * CPW + q, 64);
@@ -1766,12 +1787,10 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
             }
         }
         xv = snode_block_solve<FWDMODE>(Tl, xv, lane);
-        if (lane < nbw) __hip_atomic_store(&x[g.cols[j0 + lane]], xv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // every lane's store has been acknowledged (s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)) before the flag
-        // is stored: two stores to different addresses are not ordered by the memory system
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) __hip_atomic_store(&fl[r], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < nbw) {
+            msg_store(mb + (r * 64 + lane) * 4, xv, epoch); // to the other blocks of this sweep
+            x[g.cols[j0 + lane]] = xv;                      // to the launches that follow
+        }
         if (FWDMODE) pulled[lane] = lane < nbw ? xv : 0.0;
     }
     if (FWDMODE && g.nb > 0) {
@@ -5085,15 +5104,15 @@ int snode_kernel_attributes(int wmax, int nbmax) {
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
                   int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri) {
     if (!count) return;
-    if (tri && tri->flags && wlvl > 2 * SN_NB) {
+    if (tri && tri->msg && wlvl > 2 * SN_NB) {
         // wide supernodes: the triangle by several workgroups per supernode (k_snode_tri), the rows of B by
         // their own multi-workgroup launches
         const int nblkmax = (wlvl + SN_NB - 1) / SN_NB;
         if (m == FWD) {
-            k_snode_tri<true><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->flags, tri->epoch, x,
+            k_snode_tri<true><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri->epoch, x,
                                                                     tri->timeout_flag);
         } else {
-            k_snode_tri<false><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->flags, tri->epoch, x,
+            k_snode_tri<false><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri->epoch, x,
                                                                      tri->timeout_flag);
         }
         (void)nblvl;

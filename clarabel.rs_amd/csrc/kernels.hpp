@@ -189,7 +189,7 @@ void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t,
 // supernode sn (one per 64-column block), epoch = the value a finished block's flag carries in this sweep
 struct SnodeTriView {
     const int *blk_ptr;
-    int *flags;
+    int *msg;   // per 64-column block of every supernode: 64 messages of 16 bytes (x value, sweep epoch twice)
     int epoch;
     int *timeout_flag;
 };

@@ -162,6 +162,23 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         tph[k] += std::chrono::duration<double>(t1 - t0).count();
         t0 = t1;
     };
+    // Adjacency list of a live variable i: [ast[i], +avlen[i]) its variable neighbours, then aelen[i] elements
+    // (alen = both).  Variables first, so that the (long) variable part can stay where it is while the element
+    // part changes at every pivot that has i in its element:
+    //
+    // the approximate-degree update rescans the variable list of every member of the new element Lme to drop the
+    // entries that are themselves in Lme (or dead) and to sum the weights of the rest.  For a variable that was
+    // in the PREVIOUS pivot's element too and was cleaned then, the only entries that can need dropping now are
+    // the members that are new to Lme -- and every new member scans its own list anyway and meets the edge from
+    // its side.  So: members that scan flag the Lme members they find (`touched`); a member that was in the
+    // previous element, has not been flagged and has no merged neighbour (`dirty`) keeps its list, its weight
+    // sum and its hash (degA / hashA) without looking at it.  Config 5: 800 coupling variables with ~500-entry
+    // lists sit in the element of every one of 1.8e5 pivots -- 22 of the ordering's 27 s were these rescans.
+    std::vector<I> avlen(alen), degA((size_t)n, 0), lastscan((size_t)n, -2), touched((size_t)n, -1);
+    std::vector<uint64_t> hashA((size_t)n, 0);
+    std::vector<char> dirty((size_t)n, 0), cand;
+    I seq = 0;
+    const bool rescan_all = std::getenv("CHIP_AMD_RESCAN") != nullptr; // every member rescans (the textbook update; tests)
     while (nelim < nlive) {
         auto tp0 = std::chrono::steady_clock::now();
         while (mindeg <= n && head[mindeg] == NONE) mindeg++;
@@ -170,13 +187,14 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         I nvpiv = nv[me];
         nelim += nvpiv;
         nv[me] = -nvpiv;
+        seq++;
 
         // ---- form the new element: union of me's variables and the variables
         //      of every element adjacent to me (those elements are absorbed)
         if (sizeof(I) == 4 && epool.size() > (size_t)2000000000) return -77; // retry with 64-bit indices
         const I mstart = (I)epool.size();
         I degme = 0;
-        for (I p = ast[me]; p < ast[me] + aelen[me]; p++) {
+        for (I p = ast[me] + avlen[me]; p < ast[me] + alen[me]; p++) {
             const I e = adj[p];
             if (w[e] == 0) continue;
             const I q0 = est[e], q1 = est[e] + elen[e];
@@ -192,9 +210,10 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
             }
             w[e] = 0; // absorbed into me
         }
-        for (I p = ast[me] + aelen[me]; p < ast[me] + alen[me]; p++) {
+        for (I p = ast[me]; p < ast[me] + avlen[me]; p++) {
             const I i = adj[p];
             const I nvi = nv[i];
+            if (nvi != 0) touched[i] = seq; // me is in i's variable list: i has to clean it
             if (nvi > 0) {
                 degme += nvi;
                 nv[i] = -nvi;
@@ -213,7 +232,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         for (I q = mstart; q < mend; q++) {
             const I i = epool[q];
             const I nvi = -nv[i];
-            for (I p = ast[i]; p < ast[i] + aelen[i]; p++) {
+            for (I p = ast[i] + avlen[i]; p < ast[i] + alen[i]; p++) {
                 const I e = adj[p];
                 const i64 we = w[e];
                 if (we >= wflg) w[e] = we - nvi;
@@ -221,14 +240,12 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
             }
         }
         tick(1, tp0);
-        // ---- pass 2: prune each variable's list, approximate degree, hash
-        for (I q = mstart; q < mend; q++) {
-            const I i = epool[q];
-            const I nvi = -nv[i];
-            const I p1 = ast[i], p2 = p1 + aelen[i], pe = p1 + alen[i];
-            I pn = p1, deg = 0;
+        // ---- pass 2: prune each member's lists, approximate degree, hash
+        auto pass2_one = [&](I i, bool scan) {
+            const I p1 = ast[i], avl = avlen[i], eb = p1 + avl, ee = p1 + alen[i];
+            I deg = 0, pn = eb;
             uint64_t hash = 0;
-            for (I p = p1; p < p2; p++) {
+            for (I p = eb; p < ee; p++) { // elements, compacted in place
                 const I e = adj[p];
                 const i64 we = w[e];
                 if (we == 0) continue;
@@ -241,18 +258,58 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
                     w[e] = 0; // Le is a subset of Lme: aggressive absorption
                 }
             }
-            const I p3 = pn;
-            for (I p = p2; p < pe; p++) {
-                const I j = adj[p];
-                const I nvj = nv[j];
-                if (nvj > 0) {
-                    deg += nvj;
-                    adj[pn++] = j;
-                    hash += (uint64_t)j;
+            const I ke = pn - eb;
+            if (scan) {
+                I pv = p1, dA = 0;
+                uint64_t hA = 0;
+                for (I p = p1; p < eb; p++) {
+                    const I j = adj[p];
+                    const I nvj = nv[j];
+                    if (nvj > 0) {
+                        dA += nvj;
+                        adj[pv++] = j;
+                        hA += (uint64_t)j;
+                    } else if (nvj < 0) {
+                        touched[j] = seq; // j is in Lme as well: it has to drop i from its list
+                    }
                 }
+                const I avn = pv - p1;
+                if (avn != avl)
+                    for (I t = 0; t < ke; t++) adj[p1 + avn + t] = adj[eb + t]; // elements follow the variables
+                avlen[i] = avn;
+                degA[i] = dA;
+                hashA[i] = hA;
+                dirty[i] = 0;
             }
-            if (pn == p1) {
-                // nothing outside the new element: eliminate i together with me
+            deg += degA[i];
+            hash += hashA[i];
+            lastscan[i] = seq;
+            if (ke == 0 && avlen[i] == 0) {
+                lasthash[i] = NONE; // nothing outside the new element: eliminated together with me (below)
+            } else {
+                degree[i] = std::min(degree[i], deg);
+                adj[p1 + avlen[i] + ke] = me; // (fits: i lost me from its variables or an absorbed element)
+                aelen[i] = ke + 1;
+                alen[i] = avlen[i] + ke + 1;
+                lasthash[i] = (I)(hash % (uint64_t)n);
+            }
+        };
+        {
+            const I nm = mend - mstart;
+            cand.assign((size_t)nm, 0);
+            for (I q = mstart; q < mend; q++) {
+                const I i = epool[q];
+                cand[(size_t)(q - mstart)] = !rescan_all && lastscan[i] == seq - 1 && !dirty[i] && touched[i] != seq;
+            }
+            for (I q = mstart; q < mend; q++) // members that are new to the element (or flagged) scan and flag
+                if (!cand[(size_t)(q - mstart)]) pass2_one(epool[q], true);
+            for (I q = mstart; q < mend; q++) // the others scan only if a scanning member found them
+                if (cand[(size_t)(q - mstart)]) pass2_one(epool[q], touched[epool[q]] == seq);
+        }
+        for (I q = mstart; q < mend; q++) { // bookkeeping in member order
+            const I i = epool[q];
+            const I nvi = -nv[i];
+            if (lasthash[i] == NONE) {
                 vparent[i] = me;
                 nvpiv += nvi;
                 nelim += nvi;
@@ -260,14 +317,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
                 nv[i] = 0;
                 aelen[i] = -1;
             } else {
-                degree[i] = std::min(degree[i], deg);
-                adj[pn] = adj[p3];
-                adj[p3] = adj[p1];
-                adj[p1] = me;
-                alen[i] = pn - p1 + 1;
-                aelen[i] = p3 - p1 + 1;
-                const I h = (I)(hash % (uint64_t)n);
-                lasthash[i] = h;
+                const I h = lasthash[i];
                 hnext[i] = hhead[h];
                 hhead[h] = i;
             }
@@ -285,23 +335,26 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
             if (a == NONE) continue;
             hhead[h] = NONE;
             for (; a != NONE && hnext[a] != NONE; a = hnext[a]) {
-                const I ln = alen[a], eln = aelen[a];
-                for (I p = ast[a] + 1; p < ast[a] + ln; p++) w[adj[p]] = wflg;
-                I pb = a, b = hnext[a];
-                while (b != NONE) {
-                    bool same = (alen[b] == ln && aelen[b] == eln);
-                    for (I p = ast[b] + 1; same && p < ast[b] + ln; p++)
+                const I ln = alen[a], avl = avlen[a];
+                for (I p = ast[a]; p < ast[a] + ln - 1; p++) w[adj[p]] = wflg; // (the last entry is me)
+                I pb = a, b2 = hnext[a];
+                while (b2 != NONE) {
+                    bool same = (alen[b2] == ln && avlen[b2] == avl);
+                    for (I p = ast[b2]; same && p < ast[b2] + ln - 1; p++)
                         if (w[adj[p]] != wflg) same = false;
                     if (same) {
-                        vparent[b] = a;
-                        nv[a] += nv[b]; // both negative here
-                        nv[b] = 0;
-                        aelen[b] = -1;
-                        hnext[pb] = hnext[b];
-                        b = hnext[b];
+                        vparent[b2] = a;
+                        nv[a] += nv[b2]; // both negative here
+                        nv[b2] = 0;
+                        aelen[b2] = -1;
+                        // the neighbours' cached weight sums still hold (a took b2's weight), their lists and
+                        // hashes do not (b2 is dead): they rescan when they next meet an element
+                        for (I p = ast[b2]; p < ast[b2] + avl; p++) dirty[adj[p]] = 1;
+                        hnext[pb] = hnext[b2];
+                        b2 = hnext[b2];
                     } else {
-                        pb = b;
-                        b = hnext[b];
+                        pb = b2;
+                        b2 = hnext[b2];
                     }
                 }
                 wflg++;

@@ -110,6 +110,19 @@ def test_amd_quality_random(hip, oracle, n, density):
     assert info[0] >= fill_amd * 0.999 and info[0] <= 1.5 * fill_amd + n
 
 
+@pytest.mark.parametrize("n,density", [(200, 0.03), (800, 0.01), (500, 0.08), (3000, 0.002)])
+def test_amd_rescan_skip_is_exact(hip, n, density, monkeypatch):
+    """amd_order.cpp skips the rescan of a member's variable list when the member was in the previous pivot's
+    element and nothing that touches its list has happened since; with CHIP_AMD_RESCAN every member rescans
+    (the textbook degree update): the two orderings must be identical"""
+    rng = np.random.default_rng(n)
+    Ap, Ai = _rand_sym(rng, n, density)
+    p1, ip1, _ = hip.amd_order(n, Ap, Ai)
+    monkeypatch.setenv("CHIP_AMD_RESCAN", "1")
+    p2, ip2, _ = hip.amd_order(n, Ap, Ai)
+    assert np.array_equal(p1, p2) and np.array_equal(ip1, ip2)
+
+
 def test_amd_arrow_and_dense_rows(hip, oracle):
     """an arrow matrix: the dense row/column must be ordered last => zero fill"""
     n = 2000
@@ -197,6 +210,15 @@ def test_symbolic_matches_oracle(hip, oracle, name):
         if f0.etree[j] >= 0:
             lv0[f0.etree[j]] = max(lv0[f0.etree[j]], lv0[j] + 1)
     assert level.max() <= lv0.max()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_amd_rescan_skip_is_exact_on_kkt(hip, name, monkeypatch):
+    pr = CASES[name]()
+    k1 = _mk(hip, pr)
+    monkeypatch.setenv("CHIP_AMD_RESCAN", "1")
+    k2 = _mk(hip, pr)
+    assert np.array_equal(np.asarray(k1.perm), np.asarray(k2.perm))
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

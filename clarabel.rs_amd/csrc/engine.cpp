@@ -164,8 +164,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = upload(&Lp, S.Lp, n + 1))) return rc;
     if ((rc = upload(&Li, S.Li, (size_t)nnzL))) return rc;
     if ((rc = upload(&Rp, S.Rp, n + 1))) return rc;
-    if ((rc = upload(&Rcol, S.Rcol, (size_t)nnzL))) return rc;
-    if ((rc = upload(&Rpos, S.Rpos, (size_t)nnzL))) return rc;
+    nnzR = S.nnzR;
+    if ((rc = upload(&Rcol, S.Rcol, (size_t)nnzR))) return rc;
+    if ((rc = upload(&Rpos, S.Rpos, (size_t)nnzR))) return rc;
     if ((rc = upload(&Tpos, S.Tpos, (size_t)nnzL))) return rc;
     if ((rc = upload(&perm, S.perm, n))) return rc;
     if ((rc = upload(&iperm, S.iperm, n))) return rc;
@@ -178,7 +179,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = alloc(&Kx, (size_t)nnzK))) return rc;
     Ux = Kx; // the U rows are the head of the value store (T order)
     if ((rc = alloc(&Lx, (size_t)nnzL))) return rc;
-    if ((rc = alloc(&Rx, (size_t)nnzL))) return rc;
+    if ((rc = alloc(&Rx, (size_t)nnzR))) return rc;
     if ((rc = alloc(&D, n))) return rc;
     if ((rc = alloc(&Dinv, n))) return rc;
     if ((rc = alloc(&Sx, (size_t)nnzS))) return rc;
@@ -527,7 +528,7 @@ void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
 void Engine::enqueue_solve_direct(double *xp, const double *addv) {
     const dev::LdlView v = view();
     if (!rx_valid) { // (a fused handle taking the one-kernel-per-phase path: these kernels stream L by rows)
-        dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzL);
+        dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzR);
         rx_valid = true;
     }
     dev::bundle_fwd(stream, v, bundles, xp, fold);

@@ -54,6 +54,7 @@ struct Engine {
     chip_settings st{};
     int N = 0, nlevels = 0;
     i64 nnzK = 0, nnzL = 0, nnzS = 0;
+    i64 nnzR = 0;
     // symbolic (device)
     int *v2l = nullptr, *Lp = nullptr, *Li = nullptr, *Rp = nullptr, *Rcol = nullptr, *Rpos = nullptr,
         *Tpos = nullptr, *perm = nullptr, *iperm = nullptr, *Sp = nullptr, *Scol = nullptr, *Smap = nullptr,

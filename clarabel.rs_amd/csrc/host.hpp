@@ -49,6 +49,7 @@ struct Symbolic {
     i32 N = 0;
     i64 nnzK = 0; // nnz(triu K)
     i64 nnzL = 0;
+    i64 nnzR = 0; // entries of the row view Rp/Rcol/Rpos (= nnzL without chain supernodes; else only non-member columns)
     std::vector<i32> perm, iperm; // final elimination order (level-major), perm[new] = old
     std::vector<int8_t> dsigns;   // permuted D signs
     // The device keeps K.nzval in "T order" V: row-wise by the smaller permuted index lo, diagonal first,

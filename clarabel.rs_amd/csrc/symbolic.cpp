@@ -632,15 +632,26 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     S.Li.resize((size_t)nnzL + 1);
     {
         // rows of L by row-subtree traversal; k ascending => ascending rows per column
-        std::vector<i32> nextp(S.Lp.begin(), S.Lp.end() - 1), stamp((size_t)n, -1);
+        // (a supernode's members form a path of the tree and only its LAST column is written here -- the others
+        // get the padded pattern below --, so the walk steps over a supernode in one hop: from any member
+        // straight to the last one; rows that are themselves members of that supernode stop there.  Config 5:
+        // the walk shrinks from nnz(L) = 3.9e8 steps to the compressed structure)
+        std::vector<i32> nextp(S.Lp.begin(), S.Lp.end() - 1), stamp((size_t)n, -1), hop((size_t)n);
+        for (i32 j = 0; j < n; j++) hop[j] = j;
+        for (size_t sn = 0; sn + 1 < S.sn_ptr.size(); sn++) {
+            const i32 e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+            for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) hop[S.sn_col[t]] = e;
+        }
         for (i32 k = 0; k < n; k++) {
-            stamp[k] = k;
+            stamp[hop[k]] = k;
             for (i64 p = Cp[k]; p < Cp[k + 1]; p++) {
                 i32 i = Ci[p];
-                while (i >= 0 && i < k && stamp[i] != k) {
-                    stamp[i] = k;
-                    if (!sn_skip[i]) S.Li[nextp[i]++] = k;
-                    i = parent[i];
+                while (i >= 0 && i < k) {
+                    const i32 r = hop[i];
+                    if (r >= k || stamp[r] == k) break;
+                    stamp[r] = k;
+                    S.Li[nextp[r]++] = k;
+                    i = parent[r];
                 }
             }
         }
@@ -658,26 +669,37 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     }
     clk("supernodes + pattern of L");
     // ---- CSR view of L ------------------------------------------------------
+    // With chain supernodes only the entries in columns that are NOT supernode members are ever looked at
+    // by rows (bundle columns, ordinary top columns: the left-looking column kernels and the forward gathers;
+    // member columns act through the dense supernode kernels), so only those are listed -- config 5: a few
+    // 10^5 of 3.9e8 entries.  Tpos of a member column's entry is unused.
     {
+        const bool filter = S.sn_ptr.size() > 1;
+        auto listed = [&](i32 k) { return !filter || S.sn_of[k] < 0; };
         const int T = par_threads(nnzL);
         S.Rp.assign((size_t)n + 1, 0);
         run_threads(T, [&](int t, int TT) {
             const i32 k0 = (i32)(n * t / TT), k1 = (i32)(n * (t + 1) / TT);
-            for (i64 q = 0; q < nnzL; q++) {
-                const i32 r = S.Li[q];
-                if (r >= k0 && r < k1) S.Rp[r + 1]++;
+            for (i32 k = 0; k < n; k++) {
+                if (!listed(k)) continue;
+                for (i32 q = S.Lp[k]; q < S.Lp[k + 1]; q++) {
+                    const i32 r = S.Li[q];
+                    if (r >= k0 && r < k1) S.Rp[r + 1]++;
+                }
             }
         });
         for (i32 j = 0; j < n; j++) S.Rp[j + 1] += S.Rp[j];
-        S.Rcol.resize((size_t)nnzL + 1);
-        S.Rpos.resize((size_t)nnzL + 1);
-        S.Tpos.resize((size_t)nnzL + 1);
+        S.nnzR = S.Rp[n];
+        S.Rcol.resize((size_t)S.nnzR + 1);
+        S.Rpos.resize((size_t)S.nnzR + 1);
+        S.Tpos.assign((size_t)nnzL + 1, 0);
         std::vector<i32> nextp(S.Rp.begin(), S.Rp.end() - 1);
         const std::vector<int64_t> cuts = balanced_cuts(S.Rp.data(), n, T);
         run_threads(T, [&](int t, int) { // threads own ranges of rows; columns scanned in order by all
             const i32 k0 = (i32)cuts[t], k1 = (i32)cuts[t + 1];
             if (k0 >= k1) return;
-            for (i32 k = 0; k < n; k++)
+            for (i32 k = 0; k < n; k++) {
+                if (!listed(k)) continue;
                 for (i32 q = S.Lp[k]; q < S.Lp[k + 1]; q++) {
                     const i32 r = S.Li[q];
                     if (r < k0 || r >= k1) continue;
@@ -686,6 +708,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                     S.Rpos[u] = q;
                     S.Tpos[q] = u;
                 }
+            }
         });
     }
     clk("CSR view of L");

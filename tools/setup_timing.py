@@ -1,5 +1,5 @@
 """Wall-clock of the host-side analysis (ordering + symbolic factorisation + maps) per phase.
-usage: CHIP_TIMING=1 python tools/setup_timing.py c5m|c5|c3|c2   (CHIP_HOST_THREADS=T to pin the thread count)"""
+usage: CHIP_TIMING=1 python tools/setup_timing.py c5m|c5|c4|c3|c2   (CHIP_HOST_THREADS=T to pin the thread count)"""
 import importlib
 import os
 import sys
@@ -17,6 +17,8 @@ if which in ("c5", "c5m"):
     pr = syn.chordal_sdp(nc, 50, 10, nc, 51, seed=5, with_hs=False)
 elif which == "c3":
     pr = syn.portfolio_socp(1000, 1000, seed=3)
+elif which == "c4":
+    pr = syn.batched_socp(1024, 2000, 2, seed=100)
 elif which == "c2":
     pr = syn.random_qp(100000, 200000, band=50, seed=1)
 else:

@@ -172,6 +172,10 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if ((rc = upload(&iperm, S.iperm, n))) return rc;
     if ((rc = upload(&Sp, S.Sp, n + 1))) return rc;
     if ((rc = upload(&Scol, S.Scol, (size_t)nnzS))) return rc;
+    if (!S.xperm.empty()) { // (the residual over the top rows reads x through a supernode-contiguous copy)
+        if ((rc = upload(&xperm, S.xperm, S.xperm.size()))) return rc;
+        if ((rc = alloc(&xs_view, n))) return rc;
+    }
     if ((rc = upload(&Smap, S.Smap, (size_t)nnzS))) return rc;
     if ((rc = upload(&Up, S.Up, S.Up.size()))) return rc;
     if ((rc = upload(&Ucol, S.Ucol, (size_t)nnzU))) return rc;
@@ -621,6 +625,10 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
         dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, fold, ev0, ev1);
         dev::fold_top_residual(stream, fold, Kx, x, b, e, a.nrm, a.nan); // (top-top entries by their position in Kx)
         return;
+    }
+    if (xperm) {
+        dev::gather_values(stream, xs_view, x, xperm, N);
+        a.xin = xs_view;
     }
     const dev::ChunkView bc = smv.B(0);
     if (bc.count) dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));

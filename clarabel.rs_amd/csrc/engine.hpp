@@ -81,6 +81,8 @@ struct Engine {
     std::vector<i32> sn_lvl_ptr, sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax, h_sn_ptr, h_sn_col;
     // pipelined substitution through wide supernodes (dev::SnodeTriView): one flag per 64-column block
     int *sn_blk_ptr = nullptr, *sn_flags = nullptr;
+    int *xperm = nullptr;      // supernode-contiguous order of the nodes (residual over the top rows)
+    double *xs_view = nullptr; // x in that order
     int sn_epoch = 0;
     dev::BundleView bundles{}; // subtree bundles (device arrays)
     dev::FoldView fold{};      // few dense top rows folded into the bundle kernels (k == 0: not used)

@@ -130,6 +130,9 @@ struct Symbolic {
     //       i < NF; Smap = position in V (values refreshed by a gather at every refactor)
     i64 nnzS = 0, nnzU = 0;
     std::vector<i32> Sp, Scol, Smap;
+    // with chain supernodes: Scol refers to positions of a copy of x in which the members of a supernode are
+    // consecutive (xs[i] = x[xperm[i]]; empty = Scol holds node indices)
+    std::vector<i32> xperm;
     std::vector<i32> Up, Ucol;
     // kernel work lists
     LevelLists fac, fwd, bwd; // factor (by column), forward solve (rows of L), backward (columns)

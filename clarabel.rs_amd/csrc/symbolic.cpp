@@ -1169,6 +1169,28 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         smv.close_level();
     }
     clk("work lists, update slots");
+    // ---- residual over the top rows: a supernode-contiguous view of x ----------------------
+    // The final numbering is level major, so the members of a chain supernode -- one per level -- lie a whole
+    // level apart: a top row's entries to a dense front gather x with a stride of hundreds of bytes (config 5:
+    // every lane its own 64-byte sector, the residual over the top rows ran at 1.8 TB/s, bound by L2 sectors,
+    // not HBM).  The residual therefore reads a copy of x in which every supernode's members are consecutive
+    // (one N-element gather per residual) and Scol is renumbered to match.
+    if (S.sn_ptr.size() > 1 && S.nfold == 0 && std::getenv("CHIP_NO_XPERM") == nullptr) {
+        const i32 NFi = S.NF;
+        S.xperm.resize((size_t)n);
+        std::vector<i32> xinv((size_t)n);
+        i32 pos = 0;
+        for (; pos < NFi; pos++) S.xperm[pos] = pos;
+        for (size_t sn = 0; sn + 1 < S.sn_ptr.size(); sn++)
+            for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) S.xperm[pos++] = S.sn_col[t];
+        for (i32 j = NFi; j < n; j++)
+            if (S.sn_of[j] < 0) S.xperm[pos++] = j;
+        for (i32 i = 0; i < n; i++) xinv[S.xperm[i]] = i;
+        run_threads(par_threads(S.nnzS), [&](int t, int TT) {
+            for (i64 u = (i64)S.nnzS * t / TT; u < (i64)S.nnzS * (t + 1) / TT; u++) S.Scol[u] = xinv[S.Scol[u]];
+        });
+        clk("supernode-contiguous x view");
+    }
     return 0;
 }
 

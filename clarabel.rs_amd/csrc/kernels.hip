@@ -3708,14 +3708,20 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
         Vm[idx] = (a == b) ? 1.0 : 0.0;
     }
     __syncthreads();
-    // one-sided Jacobi, round-robin pairing over np players (np even), one thread per pair
+    // one-sided Jacobi, round-robin pairing over np players (np even), EIGHT lanes per pair: each lane takes every
+    // eighth row of the two columns (dot products as 8 partial sums + three butterfly steps inside the 8-lane
+    // group, then its share of the rotation) -- with one thread per pair 25 of the 256 threads worked and a round
+    // was ~350 dependent LDS round trips long: 4.0 ms per n = 50 cone, the longest single kernel of config 5's step
     const int np = (n + 1) & ~1;
+    constexpr int JG = 8;
+    const int jg = tid & (JG - 1);
     for (int sweep = 0; sweep < 30; ++sweep) {
         if (tid == 0) rotated = 0;
         __syncthreads();
         for (int r = 0; r < np - 1; ++r) {
-            for (int pr = tid; pr < np / 2; pr += WG) {
-                int p, q;
+            for (int pr0 = 0; pr0 < np / 2; pr0 += WG / JG) { // (every lane runs the shuffles: no early exit)
+                const int pr = pr0 + tid / JG;
+                int p = 0, q = 0;
                 if (pr == 0) {
                     p = np - 1;
                     q = r;
@@ -3723,29 +3729,42 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
                     p = (r + pr) % (np - 1);
                     q = (r - pr + np - 1) % (np - 1);
                 }
-                if (p < n && q < n) {
-                    double *mp = Cm + p * n, *mq = Cm + q * n;
-                    double al = 0.0, be = 0.0, ga = 0.0;
-                    for (int i = 0; i < n; ++i) {
-                        al += mp[i] * mp[i];
-                        be += mq[i] * mq[i];
-                        ga += mp[i] * mq[i];
+                const bool valid = pr < np / 2 && p < n && q < n;
+                double *mp = Cm + (valid ? p : 0) * n, *mq = Cm + (valid ? q : 0) * n;
+                double al = 0.0, be = 0.0, ga = 0.0;
+                if (valid)
+                    for (int i = jg; i < n; i += JG) {
+                        const double a0 = mp[i], b0 = mq[i];
+                        al += a0 * a0;
+                        be += b0 * b0;
+                        ga += a0 * b0;
                     }
-                    if (fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
-                        const double zeta = (be - al) / (2.0 * ga);
-                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                        double *vp = Vm + p * n, *vq = Vm + q * n;
-                        for (int i = 0; i < n; ++i) {
-                            const double a0 = mp[i], b0 = mq[i];
-                            mp[i] = cs * a0 - sn * b0;
-                            mq[i] = sn * a0 + cs * b0;
-                            const double a1 = vp[i], b1 = vq[i];
-                            vp[i] = cs * a1 - sn * b1;
-                            vq[i] = sn * a1 + cs * b1;
-                        }
-                        rotated = 1;
+#pragma unroll
+                for (int off = 1; off < JG; off <<= 1) {
+                    al += __shfl_xor(al, off, 64);
+                    be += __shfl_xor(be, off, 64);
+                    ga += __shfl_xor(ga, off, 64);
+                }
+                // (the butterfly adds in a different order on every lane: all eight take the leader's sums, so
+                // that they agree bit for bit on the rotation and on whether to rotate at all)
+                const int lead = (tid & 63) & ~(JG - 1);
+                al = __shfl(al, lead, 64);
+                be = __shfl(be, lead, 64);
+                ga = __shfl(ga, lead, 64);
+                if (valid && fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                    double *vp = Vm + p * n, *vq = Vm + q * n;
+                    for (int i = jg; i < n; i += JG) {
+                        const double a0 = mp[i], b0 = mq[i];
+                        mp[i] = cs * a0 - sn * b0;
+                        mq[i] = sn * a0 + cs * b0;
+                        const double a1 = vp[i], b1 = vq[i];
+                        vp[i] = cs * a1 - sn * b1;
+                        vq[i] = sn * a1 + cs * b1;
                     }
+                    if (jg == 0) rotated = 1;
                 }
             }
             __syncthreads();

@@ -1116,6 +1116,9 @@ int32_t chip_kkt_solve_full(chip_kkt *h, double *x, const double *b) {
     CHIP_HIP(hipMemcpyAsync(h->d_tmp, b, bytes, hipMemcpyHostToDevice, E.stream));
     dev::permute_in(E.stream, h->bp, h->d_tmp, E.perm, E.N);
     h->x_holds_b = false;
+    // bp was written directly: a right-hand side noted by an earlier setrhs() (borrowed pointers) is void
+    h->rhs_deferred = false;
+    h->rhs_x = h->rhs_z = nullptr;
     int ok = solve_core(h);
     if (ok != 1) return ok;
     dev::permute_out(E.stream, h->d_tmp, h->x, E.perm, E.N);

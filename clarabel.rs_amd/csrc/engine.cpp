@@ -504,6 +504,12 @@ int Engine::refactor_collect() {
 
 // qdldl.rs:755-768 in the permuted numbering, in place
 void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
+    // (a fused handle taking the one-kernel-per-phase path: these kernels stream L by rows.  Refreshed here,
+    // ahead of the graph lookup and outside any capture: a replayed graph contains no gather)
+    if (!rx_valid) {
+        dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzR);
+        rx_valid = true;
+    }
     if (st.use_graph && prof_family == PF_NONE) {
         for (const SolveGraph &g : graphs)
             if (g.xp == xp && g.addv == addv) {
@@ -531,10 +537,6 @@ void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
 }
 void Engine::enqueue_solve_direct(double *xp, const double *addv) {
     const dev::LdlView v = view();
-    if (!rx_valid) { // (a fused handle taking the one-kernel-per-phase path: these kernels stream L by rows)
-        dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzR);
-        rx_valid = true;
-    }
     dev::bundle_fwd(stream, v, bundles, xp, fold);
     if (fold.k) { // an "arrow": the bundles have already folded the top rows; finish the k x k part
         dev::fold_top_solve(stream, v, fold, xp);

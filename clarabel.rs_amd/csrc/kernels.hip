@@ -1636,16 +1636,18 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
 // stores / loads, no agent-scope fence (see ir_arrive_wait).  The rows of B are handled by k_snode_push /
 // k_snode_pull in their own launches.
 // ---------------------------------------------------------------------------
-// One 16-byte message per unknown: (value, epoch, epoch) written by ONE dwordx4 store and read by ONE dwordx4
+// One 16-byte message per unknown: (value lo, epoch, value hi, epoch) written by ONE dwordx4 store and read by ONE dwordx4
 // load, both device coherent (sc1, what the compiler emits for agent-scope atomics) -- a consumer that sees
 // this sweep's epoch has the value with it, in one round trip; value and flag as two stores needed the
 // producer to wait for the first to be acknowledged and the consumer to load twice (~2 of ~4.5 us per hop).
 typedef int msg_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void msg_store(int *slot, double val, int tag) {
     msg_v4i m;
+    // (val_lo, tag, val_hi, tag): each 8-byte half carries its own tag, so a store that the memory system
+    // splits at 8-byte granularity can never pair a fresh tag with a stale half of the value
     m.x = __double2loint(val);
-    m.y = __double2hiint(val);
-    m.z = tag;
+    m.y = tag;
+    m.z = __double2hiint(val);
     m.w = tag;
     // (s_nop: a store of more than 8 bytes reads its data registers a few cycles after issue; the compiler pads
     // that hazard for its own stores, not for inline assembly -- without it the next VALU write clobbered the tags)
@@ -1746,7 +1748,7 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
         msg_v4i mm;
         for (long long spins = 0;; ++spins) {
             mm = msg_load(mb + (c * 64 + lane) * 4);
-            const bool got = lane >= ncw || (mm.z == epoch && mm.w == epoch);
+            const bool got = lane >= ncw || (mm.y == epoch && mm.w == epoch);
             if (__all(got)) break;
             __builtin_amdgcn_s_sleep(1);
             if (spins > (1ll << 18)) {
@@ -1756,7 +1758,7 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
             }
         }
         if (!ok) break;
-        const double xcv = lane < ncw ? __hiloint2double(mm.y, mm.x) : 0.0;
+        const double xcv = lane < ncw ? __hiloint2double(mm.z, mm.x) : 0.0;
         if (FWDMODE) {
 #pragma unroll
             for (int q = 0; q < CPW; ++q) acc[0] += lv[q] * __shfl(xcv, wave * CPW + q, 64);
@@ -2529,6 +2531,9 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     auto load_top_constants = [&]() {
         if (tid < 8) {
             st.btop[tid] = tid < k ? rhs_at(NF + tid) : 0.0;
+            // (bp must hold the WHOLE permuted right-hand side afterwards: a second solve() without a new
+            // setrhs() restarts from bp, directldlkktsolver.rs:168-175 keeps self.b)
+            if (tid < k && blockIdx.x == 0) ir.bp[NF + tid] = st.btop[tid];
             st.curt[tid] = 0.0;
             st.dinvt[tid] = tid < k ? v.Dinv[NF + tid] : 0.0;
         } else if (tid >= 64 && tid < 64 + k * k) {

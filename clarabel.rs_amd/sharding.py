@@ -4,8 +4,8 @@ The KKT path shards across connected components of the elimination forest: a pro
 made of independent blocks (BASELINE config 4: 1024 independent SOCPs; or N portfolio
 shards) is split by whole blocks over ranks, one process per GPU.  Factorisation and
 triangular solves of a rank's blocks need no exchange; the only collective is an
-all-gather of the step direction after each KKT solve (RCCL over xGMI when the backend
-is "nccl"; the gloo backend is used by the CPU tests).
+all-gather of the step direction (native RCCL from C++: csrc/comm.cpp, chip_kkt_allgather_step;
+the CPU tests exercise this layout with a gloo all-gather that lives in tests/gloo_gather.py).
 
 Only layout + collective plumbing lives here; the numeric work is done by whatever
 `solver` object the caller provides (the product uses HipKKTSolver).
@@ -72,22 +72,3 @@ def _global_index_packed(self):
 
 
 ShardLayout.global_index_packed = _global_index_packed
-
-
-def all_gather_step(local_lhs, layout, dist, out=None, index=None):
-    """all-gather of the local [dx_r, dz_r] (torch tensor, length <= layout.maxlen) into the
-    global [dx, dz].  `dist` is torch.distributed (initialised by the caller)."""
-    import torch
-    pad = local_lhs
-    if local_lhs.numel() != layout.maxlen:
-        pad = torch.zeros(layout.maxlen, dtype=local_lhs.dtype, device=local_lhs.device)
-        pad[:local_lhs.numel()] = local_lhs
-    gathered = torch.empty(layout.world * layout.maxlen, dtype=pad.dtype, device=pad.device)
-    dist.all_gather_into_tensor(gathered, pad)
-    if index is None:
-        index = torch.as_tensor(layout.global_index(), device=pad.device)
-    res = gathered[index]
-    if out is not None:
-        out.copy_(res)
-        return out
-    return res

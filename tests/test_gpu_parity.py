@@ -376,6 +376,43 @@ def test_ir_fixed_one_round(hip, oracle):
     assert ks.linear_solver_info().last_ir_iterations == 1 and ko.last_ir_iters == 1
 
 
+@pytest.mark.parametrize("which", ["arrow", "forest"])
+def test_repeated_solve_on_fused_handle(hip, oracle, which):
+    """solve() twice on the same setrhs() (the reference keeps self.b, directldlkktsolver.rs:168-175), and
+    setrhs() followed by solve_full() with no solve in between, on handles whose solve is the fused persistent
+    launch (k_bundle_ir keeps the folded top's right-hand side in LDS: bp must still end up complete)"""
+    pr = problems.portfolio_socp(12, 300, seed=3) if which == "arrow" else problems.batched_socp(16, 200, 2, seed=100)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    assert ks.update_scaling(pr["s"], pr["z"]) and cones.update_scaling(pr["s"], pr["z"])
+    assert ks.update() and ko.update()
+    rng = np.random.default_rng(7)
+    rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+    ks.setrhs(rx, rz)
+    ko.setrhs(rx, rz)
+    ok, xo, zo = ko.solve()
+    assert ok
+    ref = np.concatenate([xo, zo])
+    x1, z1 = np.zeros(pr["n"]), np.zeros(pr["m"])
+    x2, z2 = np.zeros(pr["n"]), np.zeros(pr["m"])
+    assert ks.solve(x1, z1)
+    assert ks.solve(x2, z2)  # same right-hand side again, no setrhs in between
+    assert relerr(np.concatenate([x1, z1]), ref) <= TOL
+    assert relerr(np.concatenate([x2, z2]), ref) <= TOL
+    # setrhs (noted, borrowed pointers) then solve_full with a different full-N right-hand side
+    b = rng.standard_normal(ks.N)
+    ks.setrhs(rx, rz)
+    okf, xf = ks.solve_full(b)
+    okr, xr = ko.solve_full(b)
+    assert okf and okr
+    assert relerr(xf, xr) <= TOL
+    # and the handle still solves the next ordinary right-hand side
+    ks.setrhs(rz[:pr["n"]] if pr["m"] >= pr["n"] else rx, rz)
+    ko.setrhs(rz[:pr["n"]] if pr["m"] >= pr["n"] else rx, rz)
+    ok, xo, zo = ko.solve()
+    assert ks.solve(x1, z1) and ok
+    assert relerr(np.concatenate([x1, z1]), np.concatenate([xo, zo])) <= TOL
+
+
 def test_soc_scaling_failure_reported(hip):
     pr = problems.portfolio_socp(2, 10, seed=1)
     P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])

@@ -1,5 +1,5 @@
 """N > 1 path on CPU: world_size-2 gloo run of the block sharding + all-gather of the step
-direction (clarabel.rs_amd/sharding.py).  The per-rank numeric engine is the ORACLE here
+direction (layout: clarabel.rs_amd/sharding.py; gloo all-gather: tests/gloo_gather.py).  The per-rank numeric engine is the ORACLE here
 (there is no GPU in this container; the HIP engine has no CPU fallback) -- what is under
 test is the partition, the global index layout and the collective, checked against the
 unsharded oracle solve of the whole block-diagonal problem."""
@@ -28,6 +28,7 @@ def _worker(rank, world, port, nbatch, q):
     import __graft_entry__ as g
     from oracle import oracle as orc
     from tests import problems
+    from tests.gloo_gather import all_gather_step
     pkg = g.load_package()
     sharding = __import__("importlib").import_module("clarabel_rs_amd.sharding")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -53,7 +54,7 @@ def _worker(rank, world, port, nbatch, q):
         ok, x, z = ks.solve()
         assert ok
         local = torch.tensor(np.concatenate([x, z]))
-        full = sharding.all_gather_step(local, layout, dist).numpy()
+        full = all_gather_step(local, layout, dist).numpy()
         if rank == 0:
             whole = problems.blockdiag(parts)
             cw = orc.Cones(whole["cones"])

@@ -17,8 +17,9 @@ exchange all go through the C ABI (include/clarabel_hip.h).
         (the oracle, 1 core), `cpu_baseline_mt` (scipy SuperLU, labelled non-reference)
         and `batched_c4` (BASELINE config 4 whole on this GPU: the N = 1 point of the
         strong-scaling curve below).
---gpus N > 1 (one process per GPU, launched by torch.distributed.run; only its env
-        vars are used): BASELINE config 4, 1024 independent SOCPs of n = 2000, sharded by
+--gpus N > 1 (one process per GPU; launched by torch.distributed.run -- only its env vars are
+        used -- or, when WORLD_SIZE is not set, by bench.py itself as N subprocesses):
+        BASELINE config 4, 1024 independent SOCPs of n = 2000, sharded by
         whole elimination trees over the ranks (clarabel.rs_amd/sharding.py: 1024/N blocks
         each) -- STRONG scaling: the total problem is fixed.  Factor / solves / refinement
         need no exchange; the iteration's step direction -- the solution of the LAST of the
@@ -28,11 +29,20 @@ exchange all go through the C ABI (include/clarabel_hip.h).
         stream behind the next step's update and first two solves; --gather-every-solve
         gathers all three solutions instead).  value = steps / time of the whole 1024-block
         problem.
+        Every rank checks its shard against the CPU oracle on the same inputs and permutation
+        and the ranks reduce the error (max) -> `parity` in the N > 1 line; the gathered step
+        direction is compared bit for bit with the ranks' local solutions (checksums of every
+        segment all-reduced).
 --workload c3|c4 forces the workload (c4 at N = 1 = the whole batched problem).
+--workload c2|c5|c5m: the other BASELINE configs (systems whose top runs as chain supernodes), with
+        their own `roofline` (c2: HBM, the pipelined supernode substitution k_snode_tri; c5 / c5m: the f64
+        matrix cores, k_snode_update, flops from the supernode geometry), `cpu_baseline` (the oracle, bounded;
+        c5 at quarter size) and `parity` (c2 / c5m: the oracle live; c5: tests/golden/c5_full_oracle.npz).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -45,6 +55,7 @@ import numpy as np
 import __graft_entry__ as graft
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 matrix-core peak
 TOL = 1e-8             # north_star: "solution within 1e-8 relative of reference"
 
 
@@ -124,10 +135,15 @@ class Workload:
         sync()
         self.ks.profile(profile_family)
         t0 = time.perf_counter()
+        marks = [t0]
         for _ in range(steps):
-            self.step(comm, gathered, counts)
+            self.step(comm, gathered, counts)   # (ends with collect(): one synchronisation per step)
+            marks.append(time.perf_counter())
         sync()
         elapsed = time.perf_counter() - t0
+        d = np.diff(np.asarray(marks)) * 1e3
+        self.step_ms = {"min": round(float(d.min()), 4), "median": round(float(np.median(d)), 4),
+                        "max": round(float(d.max()), 4)} if len(d) else None
         prof = self.ks.profile_read()
         self.ks.profile(0)
         if comm is not None:
@@ -158,7 +174,8 @@ def oracle_leg(w, args, time_it=True):
 
     def step(keep=None):
         cones.update_scaling(pr["s"], pr["z"])
-        assert ko.update()
+        # (PSD cones: the oracle takes the numpy restatement's Hs blocks for the same (S, Z), oracle/psd_numpy.py)
+        assert ko.update(pr.get("hsblocks"))
         for rx, rz in w.rhs_host:
             ko.setrhs(rx, rz)
             ok, x, z = ko.solve()
@@ -196,7 +213,7 @@ def oracle_leg(w, args, time_it=True):
               "fixed_r1": "the same for the solutions of the timed configuration (exactly one refinement round)"}
     cpu = None
     if time_it:
-        nsteps = args.cpu_steps if args.cpu_steps > 0 else max(2, min(200, int(15.0 / max(t1, 1e-3))))
+        nsteps = args.cpu_steps if args.cpu_steps > 0 else max(1 if t1 > 20.0 else 2, min(200, int(15.0 / max(t1, 1e-3))))
         t0 = time.perf_counter()
         for _ in range(nsteps):
             step()
@@ -237,6 +254,88 @@ def superlu_leg(w, ko):
                           "on 1 core except BLAS; final residual %.1e" % (N, float(np.max(np.abs(e))))}
     except Exception as ex:  # a comparator, never a reason to lose the bench line
         return {"value": None, "error": repr(ex)[:200]}
+
+
+def fixture_parity_c5(w, hip):
+    """BASELINE config 5 at FULL size: the scalar oracle needs ~10 CPU-minutes for this factorisation, so its
+    answers are a committed fixture (tests/golden/c5_full_oracle.npz, made by tests/golden/make_c5_fixture.py:
+    same generator and seed, default refinement settings, seeded right-hand sides)."""
+    path = os.path.join(ROOT, "tests", "golden", "c5_full_oracle.npz")
+    if not os.path.exists(path):
+        return None
+    fx = np.load(path)
+    ks = w.ks
+    if int(fx["N"]) != ks.N or int(fx["n"]) != w.n or int(fx["m"]) != w.m:
+        return None
+    ks.set_settings(hip.Settings.default(device=ks.settings.device))
+    rng = np.random.default_rng(int(fx["rhs_seed"]))
+    err, rounds = 0.0, []
+    lhs = hip.DeviceArray(w.n + w.m)
+    for k in range(int(fx["nrhs"])):
+        rx, rz = hip.DeviceArray(rng.standard_normal(w.n)), hip.DeviceArray(rng.standard_normal(w.m))
+        ks.setrhs_dev(rx.ptr, rz.ptr)
+        assert ks.solve_dev(lhs.ptr, lhs.ptr + 8 * w.n)
+        ks.synchronize()
+        rounds.append(int(ks.linear_solver_info().last_ir_iterations))
+        err = max(err, relerr(lhs.numpy(), fx["solutions"][k]))
+    kv = ks.values()
+    kerr = float(np.max(np.abs(kv[fx["k_sample_idx"]] - fx["k_sample_val"])) / max(1.0, float(fx["k_absmax"])))
+    info = ks.linear_solver_info()
+    ks.set_settings(bench_settings(hip, ks.settings.device))
+    return {"rel_err_vs_oracle": err, "tol": TOL, "ok": bool(err <= TOL),
+            "what": "max over %d solves of ||x_gpu - x_oracle||inf / max(1, ||x_oracle||inf), post-refinement, default "
+                    "refinement settings (rounds on the GPU: %s, in the oracle: %s); oracle answers from the committed "
+                    "fixture tests/golden/c5_full_oracle.npz" % (int(fx["nrhs"]), rounds, fx["ir_rounds"].tolist()),
+            "kkt_values_rel_err_sample": kerr,
+            "regularize_count": [int(info.regularize_count), int(fx["regularize_count"])],
+            "positive_inertia": [int(info.positive_inertia), int(fx["positive_inertia"])]}
+
+
+def quarter_c5_cpu_baseline(hip, problems, args):
+    """cpu_baseline of the config-5 line: ONE step of the oracle on the quarter-size instance (50 cliques; the
+    full-size factorisation takes the scalar oracle ~10 minutes), permutation from the product's host analysis"""
+    os.environ["ORACLE_NATIVE"] = "1"
+    from oracle import oracle as orc
+    pr = problems.chordal_sdp(50, 50, 10, 50, 51, seed=5, with_hs=True)
+    st = hip.Settings.default(device=hip.DEVICE_HOST_ONLY)
+    hk = hip.HipKKTSolver(hip.CscMatrix(pr["n"], pr["n"], *pr["P"]), hip.CscMatrix(pr["m"], pr["n"], *pr["A"]),
+                          pr["cones"], pr["m"], pr["n"], settings=st)
+    ost = orc.Settings.default()
+    ost.ir_max_iter, ost.ir_reltol, ost.ir_abstol = 1, 0.0, 0.0
+    cones = orc.Cones(pr["cones"])
+    ko = orc.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones, settings=ost, perm=hk.perm)
+    rng = np.random.default_rng(1234)
+    rhs = [(rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])) for _ in range(3)]
+    t0 = time.perf_counter()
+    cones.update_scaling(pr["s"], pr["z"])
+    assert ko.update(pr["hsblocks"])
+    for rx, rz in rhs:
+        ko.setrhs(rx, rz)
+        assert ko.solve()[0]
+    el = time.perf_counter() - t0
+    return {"value": round(1.0 / el, 5), "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": "1 full step of the QUARTER-size instance (50 x PSD(50) + 50 x SOC(51), N=%d; the full size takes "
+                      "the scalar oracle ~10 minutes per factorisation) on 1 of the host's %d cores, oracle/ C restatement "
+                      "of src/qdldl + DirectLDLKKTSolver, Hs blocks from oracle/psd_numpy" % (ko.N, os.cpu_count() or 0)}
+
+
+def launch_ranks(args):
+    """stdlib launcher for --gpus N > 1 when no launcher set WORLD_SIZE: N subprocesses of this script, one per GPU,
+    with the environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    raise SystemExit(rc)
 
 
 def rendezvous_id(hip, rank, world):
@@ -283,8 +382,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
-        raise SystemExit("launch N > 1 as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        launch_ranks(args)  # (does not return)
     hip = graft.load_package()
     import clarabel_rs_amd.synthetic as problems
     import clarabel_rs_amd.sharding as sharding
@@ -297,9 +395,9 @@ def main():
     if world > 1 and workload != "c4":
         raise SystemExit("N > 1 runs the sharded batched workload (c4)")
     if workload in ("c2", "c5", "c5m") and args.profile_family == 5:
-        args.profile_family = 0  # (no fused launch for systems with a level-scheduled top)
-    if workload in ("c5", "c5m"):
-        args.no_extras = True    # (the scalar oracle takes minutes on these dense fronts: parity is in tests/)
+        # (no fused launch for systems with a level-scheduled top) c2: the pipelined supernode substitution
+        # (most of the step's kernel time); c5: the MFMA update tiles of the supernode factorisation
+        args.profile_family = 11 if workload == "c2" else 7
 
     comm = gathered = counts = None
     if workload == "c3":
@@ -311,7 +409,8 @@ def main():
         desc = "random sparse QP (BASELINE config 2): n=100000, m=200000, Nonnegative cone"
     elif workload in ("c5", "c5m"):
         nc = 200 if workload == "c5" else 50
-        pr = problems.chordal_sdp(nc, 50, 10, nc, 51, seed=5, with_hs=False)
+        # (quarter size: the oracle runs live and needs the numpy restatement's Hs blocks)
+        pr = problems.chordal_sdp(nc, 50, 10, nc, 51, seed=5, with_hs=(nc != 200 and not args.no_extras))
         desc = ("chordal SDP (BASELINE config 5%s): %d x PSD(50) cliques with overlap 10 + %d x SOC(51); PSD scalings, "
                 "Hs = skron(R R') and all cone state on the device" % ("" if nc == 200 else ", quarter size", nc, nc))
     else:
@@ -334,24 +433,63 @@ def main():
     elapsed, prof = w.run(args.steps, args.warmup, args.profile_family, comm, gathered, counts)
     ir = w.ks.linear_solver_info().last_ir_iterations
 
+    # ---- N > 1: every rank checks ITS shard against the oracle; the ranks reduce the verdict ----------------
+    parity_sharded = None
+    if world > 1 and not args.no_extras:
+        # (a) bit-for-bit: the gathered step direction against every rank's local solution -- checksums (sum and
+        # sum of |.|) of each rank's segment of MY gathered copy against the owner's, all-reduced
+        comm.wait(w.ks)
+        comm.synchronize()
+        w.ks.synchronize()
+        last = len(w.lhs) - 1
+        g = gathered[last].numpy()
+        own = w.lhs[last].numpy()
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        mine = np.zeros(2 * world)
+        mine[2 * rank], mine[2 * rank + 1] = float(np.sum(own)), float(np.sum(np.abs(own)))
+        truth = comm.allreduce(mine.tolist(), "sum")   # (one non-zero contribution per entry: exact)
+        seen = np.array([f(g[offs[r]:offs[r + 1]]) for r in range(world) for f in (np.sum, lambda a: np.sum(np.abs(a)))])
+        seg_diff = float(np.max(np.abs(seen - np.asarray(truth))))
+        own_equal = bool(np.array_equal(g[offs[rank]:offs[rank + 1]], own))
+        # (b) this rank's solutions against the oracle on the same shard, permutation and right-hand sides
+        par_r, _, _ = oracle_leg(w, args, time_it=False)
+        red = comm.allreduce([par_r["rel_err_vs_oracle"], par_r["rel_err_fixed_r1"], seg_diff, 0.0 if own_equal else 1.0], "max")
+        parity_sharded = {"rel_err_vs_oracle": red[0], "tol": TOL, "ok": bool(red[0] <= TOL and red[2] == 0.0 and red[3] == 0.0),
+                          "what": "max over the %d ranks (RCCL all-reduce) of each rank's max over its 3 solves of "
+                                  "||x_gpu - x_oracle||inf / max(1, ||x_oracle||inf) on its own shard, post-refinement, "
+                                  "default refinement settings, same inputs and permutation" % world,
+                          "rel_err_fixed_r1": red[1],
+                          "gathered_vs_local": {"own_slice_bit_equal_on_every_rank": bool(red[3] == 0.0),
+                                                "max_abs_diff_of_segment_checksums": red[2],
+                                                "what": "every rank's segment of the all-gathered step direction (sum and "
+                                                        "sum of |.|) against the owner's local solution"}}
     if rank == 0:
         ks, m = w.ks, w.m
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps / elapsed
         # byte model of the WHOLE problem (all ranks): every rank holds 1/world of it
         Bm = algorithmic_bytes(ks.N * world, ks.nnzK * world, info.nnzL * world, ks.nHs * world, m * world)
-        # family 1 = the dominant kernel: residual of all bundle rows, K stored once (U):
-        # 12 B per streamed K entry + 24 B per row (x, b read; e written)
+        # family 1 = residual of all bundle rows, K stored once (U): 12 B per streamed K entry + 24 B per row
         # family 5 = the fused launch: (r + 1) LDL' solves + (r + 1) residuals of SURVEY 8(d)'s per-unit figures
         Bu = algorithmic_bytes(ks.N, ks.nnzK, info.nnzL, ks.nHs, m)
+        wm = ks.work_model()
+        fam = args.profile_family
+        nsolves = len(w.rhs) * (int(ir) + 1)
+        # per-launch work of the profiled family; families 7 / 11: TOTAL work of the family per step
         fam_bytes = {1: 12 * ks.nnzU + 24 * ks.NF, 5: (int(ir) + 1) * (Bu["solve"] + Bu["symv"]),
-                     6: Bu["factor"]}.get(args.profile_family)
+                     6: Bu["factor"]}.get(fam)
         fam_name = {1: "k_bundle_symv (residual e = b - Kx over the %d bundle rows, ||e||inf folded in)" % ks.NF,
                     2: "k_gather_merged<1> (BWD top levels)", 3: "k_gather_merged<0> (FWD top levels)",
                     4: "k_factor_T",
                     5: "k_bundle_ir (one launch = setrhs + %d x (LDL' solve + residual) + refinement decisions + getlhs; "
                        "algorithmic bytes = %d x (B_solve + B_symv))" % (int(ir) + 1, int(ir) + 1),
-                    6: "k_bundle_factor (numeric LDL' of all bundle columns)"}.get(args.profile_family, "?")
+                    6: "k_bundle_factor (numeric LDL' of all bundle columns)",
+                    7: "k_snode_update (left-looking update of a 64-column block of every supernode of a unit level: "
+                       "16 x 64 tiles of v_mfma_f64_16x16x4_f64)",
+                    8: "k_snode_diag", 9: "k_snode_rows", 10: "k_snode_extend",
+                    11: "k_snode_tri (pipelined substitution through the wide chain supernodes of one unit level, "
+                        "forward and backward sweeps)",
+                    12: "k_gather_merged (supernode substitution path)"}.get(fam, "?")
         # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh -> tools/pmc_summarize.py ->
         # profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, see that script).  PMC counters cannot be
         # collected from inside the timed run: the committed summary of the same command is QUOTED (with the
@@ -360,12 +498,15 @@ def main():
         try:
             import glob
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            kname = {1: "k_bundle_symv", 5: "k_bundle_ir", 6: "k_bundle_factor"}.get(args.profile_family)
+            kname = {1: "k_bundle_symv", 5: "k_bundle_ir", 6: "k_bundle_factor"}.get(fam)
             if pj and kname and workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000:
                 traffic = json.load(open(pj[-1]))["kernels"][kname]["hbm_bytes"]
                 traffic_src = os.path.basename(pj[-1])
         except Exception:
             traffic = None
+        whole = {"algorithmic_bytes": Bm["iter"],
+                 "achieved_GBs": round(Bm["iter"] / (ms_per_step * 1e-3) / 1e9, 1),
+                 "frac": round(Bm["iter"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4)}
         roof = None
         if prof["launches"] > 0 and fam_bytes:
             avg_ms = prof["ms"] / prof["launches"]
@@ -374,14 +515,51 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profiled_in": traffic_src,
                     "kernel": fam_name,
                     "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
-                    "algorithmic_bytes_per_launch": fam_bytes,
-                    "whole_step": {"algorithmic_bytes": Bm["iter"],
-                                   "achieved_GBs": round(Bm["iter"] / (ms_per_step * 1e-3) / 1e9, 1),
-                                   "frac": round(Bm["iter"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4)}}
+                    "algorithmic_bytes_per_launch": fam_bytes, "whole_step": whole}
+        elif prof["launches"] > 0 and fam == 7 and wm["sn_update_flops"] > 0:
+            # f64 matrix cores: multiply-add flops of the update tiles from the supernode geometry (2 per
+            # multiply-add; rows at or below the block only), one refactor per step
+            per_launch = wm["sn_update_flops"] * args.steps / prof["launches"]
+            avg_ms = prof["ms"] / prof["launches"]
+            ach = per_launch / (avg_ms * 1e-3) / 1e12
+            f_dense = wm["sn_update_flops"] + wm["sn_extend_flops"] + wm["sn_diag_rows_flops"]
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F64_PEAK_TFLOPS, 4), "traffic": None, "kernel": fam_name,
+                    "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
+                    "flops_per_launch": round(per_launch), "flops_per_refactor_update_tiles": wm["sn_update_flops"],
+                    "kernel_ms_per_step": round(prof["ms"] / args.steps, 3),
+                    "whole_step": dict(whole, dense_flops_per_step=f_dense,
+                                       dense_TFLOPs_over_step=round(f_dense / (ms_per_step * 1e-3) / 1e12, 2),
+                                       dense_frac_of_mfma_peak=round(f_dense / (ms_per_step * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4))}
+        elif prof["launches"] > 0 and fam == 11 and wm["sn_panel_entries"] > 0:
+            # one sweep through the supernodes streams every entry of their dense trapezoids once: 12 B per entry
+            # of SURVEY 8(d)'s B_solve (value + index; the trapezoids need no index, the model is kept)
+            sweeps = 2 * nsolves
+            tot_bytes = 12.0 * wm["sn_panel_entries"] * sweeps * args.steps
+            per_launch = tot_bytes / prof["launches"]
+            avg_ms = prof["ms"] / prof["launches"]
+            ach = per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": fam_name,
+                    "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
+                    "algorithmic_bytes_per_launch": round(per_launch),
+                    "kernel_ms_per_step": round(prof["ms"] / args.steps, 3), "whole_step": whole}
+        elif prof["launches"] > 0:
+            roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "kernel": fam_name, "launches": prof["launches"],
+                    "avg_launch_us": round(1e3 * prof["ms"] / prof["launches"], 2),
+                    "kernel_ms_per_step": round(prof["ms"] / args.steps, 3), "whole_step": whole}
         parity = cpu = cpu_mt = c4 = None
-        if world == 1 and not args.no_extras:
-            parity, cpu, ko = oracle_leg(w, args, time_it=args.cpu_steps != 0)
+        step_ms = getattr(w, "step_ms", None)
+        if world > 1:
+            parity = parity_sharded
+        elif not args.no_extras and workload == "c5":
+            parity = fixture_parity_c5(w, hip)
             if args.cpu_steps != 0:
+                cpu = quarter_c5_cpu_baseline(hip, problems, args)
+        elif not args.no_extras:
+            parity, cpu, ko = oracle_leg(w, args, time_it=args.cpu_steps != 0)
+            if args.cpu_steps != 0 and workload in ("c3", "c4"):
                 cpu_mt = superlu_leg(w, ko)
             del ko
             if workload == "c3" and args.workload == "auto":
@@ -396,6 +574,7 @@ def main():
                 c4 = {"workload": "batched SOCP (BASELINE config 4): %d independent SOCPs of n=2000, whole problem on 1 GPU, "
                                   "device resident" % args.nbatch,
                       "value": round(args.steps / el4, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * el4 / args.steps, 4),
+                      "step_ms": w4.step_ms,
                       "kkt_dim": w4.ks.N, "nnz_L": int(i4.nnzL), "setup_s": round(w4.t_setup, 2),
                       "whole_step_frac_of_hbm_peak": round(B4["iter"] / (el4 / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                       "parity": par4,
@@ -415,9 +594,11 @@ def main():
                                       % ("3 x all-gather (every solve's solution)" if args.gather_every_solve else
                                          "1 x all-gather of the step direction (the last solve's solution)",
                                          int(sum(counts)))) if comm is not None else "none"},
+            "step_ms": step_ms,
             "roofline": roof, "parity": parity, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt, "batched_c4": c4,
         }
         print(json.dumps(out))
+        sys.stdout.flush()
     if comm is not None:
         comm.synchronize()
         comm.barrier()

@@ -526,6 +526,16 @@ class HipKKTSolver:
         _check(lib().chip_kkt_profile_read(self._h, out), "profile_read")
         return {"launches": int(out[0]), "ms": float(out[1]), "family": int(out[2])}
 
+    def work_model(self):
+        """work of the chain-supernode kernels per refactor / per sweep (chip_kkt_work_model)"""
+        out = (C.c_double * 8)()
+        _check(lib().chip_kkt_work_model(self._h, out), "work_model")
+        return {"sn_update_flops": float(out[0]), "sn_panel_entries": float(out[1]), "sn_extend_flops": float(out[2]),
+                "sn_diag_rows_flops": float(out[3]), "n_supernodes": int(out[4])}
+
+    def fused_fallbacks(self):
+        return int(lib().chip_kkt_fused_fallbacks(self._h))
+
 
 class CVars(C.Structure):
     """chip_vars: DefaultVariables (default/variables.rs:12-36) with device pointers"""
@@ -785,6 +795,12 @@ class DeviceArray:
             except Exception:
                 pass
             self._p = C.c_void_p()
+
+
+def debug_spin(device, blocks, threads=256, lds_bytes=0, usec=1000.0):
+    """diagnostics: a co-resident kernel that only spins (chip_debug_spin); blocks = 0 waits for the spinners"""
+    lib().chip_debug_spin.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double]
+    _check(lib().chip_debug_spin(device, blocks, threads, lds_bytes, float(usec)), "debug_spin")
 
 
 def set_device(ordinal):

@@ -31,7 +31,7 @@ namespace {
 // entries) fits -- the ordering is memory bound, half-width indices are ~1.5x faster -- else int64
 template <typename I>
 int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
-                   AmdInfo *info) {
+                   AmdInfo *info, i64 dense_n) {
     constexpr I NONE = -1;
     perm.assign((size_t)n, 0);
     AmdInfo st;
@@ -101,7 +101,9 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     std::vector<char> is_dense((size_t)n, 0);
 
     // ---- dense rows are pulled out and ordered last -------------------------
-    double dth = 10.0 * dense_scale * std::sqrt((double)n);
+    // (dense_n: the dimension the dense-row threshold is computed from -- the whole matrix when one connected
+    // component of it is being ordered)
+    double dth = 10.0 * dense_scale * std::sqrt((double)(dense_n > 0 ? dense_n : n));
     if (dth < 16.0) dth = 16.0;
     if (dth > (double)n) dth = (double)n;
     I ndense = 0;
@@ -455,14 +457,153 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
 
 } // namespace
 
-int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
-              AmdInfo *info) {
+static int amd_order_dn(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
+                        AmdInfo *info, i64 dense_n) {
     const i64 nnz = n > 0 ? Ap[n] : 0;
     if (n < ((i64)1 << 30) && 2 * nnz < ((i64)1 << 31) - 16) {
-        const int rc = amd_order_impl<i32>(n, Ap, Ai, dense_scale, perm, info);
+        const int rc = amd_order_impl<i32>(n, Ap, Ai, dense_scale, perm, info, dense_n);
         if (rc != -77) return rc;
     }
-    return amd_order_impl<i64>(n, Ap, Ai, dense_scale, perm, info);
+    return amd_order_impl<i64>(n, Ap, Ai, dense_scale, perm, info, dense_n);
+}
+int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
+              AmdInfo *info) {
+    return amd_order_dn(n, Ap, Ai, dense_scale, perm, info, 0);
+}
+
+// Block-diagonal matrices (BASELINE config 4: 1024 independent SOCPs; any problem made of independent blocks):
+// the graph falls into connected components, which minimum degree orders independently of each other anyway.
+// Components with IDENTICAL patterns (same size, same relative indices: compared exactly, found by hash) take
+// the ordering of one representative; the distinct patterns are ordered in parallel on the host threads.  The
+// dense-row threshold stays that of the whole matrix.  One component: the plain call.
+int amd_order_components(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
+                         AmdInfo *info) {
+    if (n <= 1 || std::getenv("CHIP_NO_COMPONENTS") != nullptr) return amd_order(n, Ap, Ai, dense_scale, perm, info);
+    // ---- connected components (union-find with path halving; the smaller index stays the root) ----
+    std::vector<i64> root((size_t)n);
+    for (i64 i = 0; i < n; i++) root[i] = i;
+    auto find = [&](i64 x) {
+        while (root[x] != x) {
+            root[x] = root[root[x]];
+            x = root[x];
+        }
+        return x;
+    };
+    for (i64 c = 0; c < n; c++)
+        for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+            const i64 r = Ai[p];
+            if (r < 0 || r >= n) return -9;
+            if (r == c) continue;
+            const i64 a = find(r), b = find(c);
+            if (a != b) root[a > b ? a : b] = a > b ? b : a;
+        }
+    std::vector<i64> comp((size_t)n, -1), csize;
+    for (i64 i = 0; i < n; i++) {
+        const i64 r = find(i);
+        if (comp[r] < 0) { // (r <= i: the root is the component's smallest node)
+            comp[r] = (i64)csize.size();
+            csize.push_back(0);
+        }
+        comp[i] = comp[r];
+        csize[comp[i]]++;
+    }
+    const i64 nc = (i64)csize.size();
+    if (nc == 1) return amd_order(n, Ap, Ai, dense_scale, perm, info);
+    // nodes by component (ascending inside: the local triangle stays upper), local ids
+    std::vector<i64> cptr((size_t)nc + 1, 0), nodes((size_t)n), lid((size_t)n);
+    for (i64 q = 0; q < nc; q++) cptr[q + 1] = cptr[q] + csize[q];
+    {
+        std::vector<i64> fill(cptr.begin(), cptr.end() - 1);
+        for (i64 i = 0; i < n; i++) {
+            lid[i] = fill[comp[i]] - cptr[comp[i]];
+            nodes[fill[comp[i]]++] = i;
+        }
+    }
+    // local patterns, all in one pair of arrays: component q owns columns cptr[q] .. cptr[q+1] of (Lp, Li)
+    std::vector<i64> Lp((size_t)n + 1, 0), Li((size_t)Ap[n]);
+    for (i64 t = 0; t < n; t++) Lp[t + 1] = Lp[t] + (Ap[nodes[t] + 1] - Ap[nodes[t]]);
+    for (i64 t = 0; t < n; t++) {
+        i64 o = Lp[t];
+        for (i64 p = Ap[nodes[t]]; p < Ap[nodes[t] + 1]; p++) Li[o++] = lid[Ai[p]];
+    }
+    // hash of every component's local pattern; identical patterns share a representative
+    std::vector<uint64_t> hsh((size_t)nc);
+    for (i64 q = 0; q < nc; q++) {
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)csize[q];
+        for (i64 t = cptr[q]; t < cptr[q + 1]; t++) {
+            h = (h ^ (uint64_t)(Lp[t + 1] - Lp[t])) * 1099511628211ull;
+            for (i64 p = Lp[t]; p < Lp[t + 1]; p++) h = (h ^ (uint64_t)Li[p]) * 1099511628211ull;
+        }
+        hsh[q] = h;
+    }
+    std::vector<i64> order((size_t)nc), rep((size_t)nc, -1), reps;
+    for (i64 q = 0; q < nc; q++) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](i64 a, i64 b) { return hsh[a] < hsh[b]; });
+    auto same = [&](i64 a, i64 b) {
+        if (csize[a] != csize[b]) return false;
+        const i64 na = csize[a];
+        if (Lp[cptr[a] + na] - Lp[cptr[a]] != Lp[cptr[b] + na] - Lp[cptr[b]]) return false;
+        for (i64 t = 0; t < na; t++)
+            if (Lp[cptr[a] + t + 1] - Lp[cptr[a] + t] != Lp[cptr[b] + t + 1] - Lp[cptr[b] + t]) return false;
+        const i64 pa = Lp[cptr[a]], pb = Lp[cptr[b]], len = Lp[cptr[a] + na] - pa;
+        for (i64 k = 0; k < len; k++)
+            if (Li[pa + k] != Li[pb + k]) return false;
+        return true;
+    };
+    for (i64 k = 0; k < nc;) {
+        i64 e = k;
+        while (e < nc && hsh[order[e]] == hsh[order[k]]) e++;
+        std::vector<i64> grp; // representatives among the components with this hash (collisions: several)
+        for (i64 t = k; t < e; t++) {
+            const i64 q = order[t];
+            for (i64 r : grp)
+                if (same(r, q)) {
+                    rep[q] = r;
+                    break;
+                }
+            if (rep[q] < 0) {
+                rep[q] = q;
+                grp.push_back(q);
+                reps.push_back(q);
+            }
+        }
+        k = e;
+    }
+    // order the representatives (in parallel: each call is single threaded at these sizes)
+    const i64 nr = (i64)reps.size();
+    std::vector<std::vector<i64>> rperm((size_t)nr);
+    std::vector<AmdInfo> rinfo((size_t)nr);
+    std::vector<int> rrc((size_t)nr, 0);
+    std::vector<i64> rep_slot((size_t)nc, -1);
+    for (i64 k = 0; k < nr; k++) rep_slot[reps[k]] = k;
+    const int T = (int)std::min<i64>(nr, host_threads());
+    run_threads(T, [&](int t, int TT) {
+        std::vector<i64> lp;
+        for (i64 k = t; k < nr; k += TT) {
+            const i64 q = reps[k], nq = csize[q], base = Lp[cptr[q]];
+            lp.assign((size_t)nq + 1, 0);
+            for (i64 j = 0; j <= nq; j++) lp[j] = Lp[cptr[q] + j] - base;
+            rrc[k] = amd_order_dn(nq, lp.data(), Li.data() + base, dense_scale, rperm[k], &rinfo[k], n);
+        }
+    });
+    for (i64 k = 0; k < nr; k++)
+        if (rrc[k]) return rrc[k];
+    perm.assign((size_t)n, 0);
+    AmdInfo tot;
+    i64 out = 0;
+    for (i64 q = 0; q < nc; q++) {
+        const i64 k = rep_slot[rep[q]];
+        const std::vector<i64> &pr = rperm[k];
+        for (i64 j = 0; j < csize[q]; j++) perm[out++] = nodes[cptr[q] + pr[j]];
+        tot.lnz += rinfo[k].lnz;
+        tot.ndiv += rinfo[k].ndiv;
+        tot.nmultsubs_ldl += rinfo[k].nmultsubs_ldl;
+        tot.ndense += rinfo[k].ndense;
+    }
+    if (std::getenv("CHIP_TIMING") != nullptr)
+        std::fprintf(stderr, "[chip amd] %lld connected components, %lld distinct patterns\n", (long long)nc, (long long)nr);
+    if (info) *info = tot;
+    return 0;
 }
 
 } // namespace chip

@@ -92,6 +92,14 @@ struct chip_kkt {
     int pend_update = 0;             // 1: an update has been enqueued and its verdict not read; 2: read, kept
     int pend_update_ok = 1;
     std::vector<int> pend_slots;     // ring slots of the solves enqueued since the last collect
+    // arguments of the fused launches by ring slot: a launch whose grid barrier timed out (its workgroups were not
+    // co-resident: another long-running kernel held their slots) is repeated on the one-kernel-per-phase path
+    struct FusedArgs {
+        const double *rx, *rz;
+        double *lx, *lz;
+    } fused_args[Engine::IR_RING] = {};
+    int fused_fallbacks = 0;
+    bool ir_test_drop = std::getenv("CHIP_IR_TEST_DROP") != nullptr; // (tests, read when the handle is created)
     int world = 1;               // ranks sharing the problem (chip_kkt_attach_comm)
     double *d_partial = nullptr; // per-block partial minima / sums of the cone reductions
     int partial_cap = 0;
@@ -955,6 +963,8 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     }
     if (dbg_on) (void)hipMemsetAsync(dbg_dev, 0, 256 * sizeof(long long), E.stream);
     ir.dbg = dbg_on ? dbg_dev : nullptr;
+    ir.test_drop = h->ir_test_drop ? 1 : 0;
+    h->fused_args[*slot] = {h->rhs_x, h->rhs_z, lhsx_dev, lhsz_dev};
     h->rhs_deferred = false;
     h->x_holds_b = false;
     E.prof_begin(PF_IR);
@@ -973,16 +983,36 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     }
     return CHIP_OK;
 }
-// verdict of ring slot `slot` (after the stream has been synchronised and the ring copied to the host)
+// verdict of ring slot `slot` (after the stream has been synchronised and the ring copied to the host);
+// FUSED_TIMEOUT: the grid barrier timed out (not all workgroups were resident), the counters have been cleared
+constexpr int FUSED_TIMEOUT = -1000;
 static int fused_verdict(chip_kkt *h, int slot) {
     Engine &E = h->E;
     const int *r = E.ir_res_host + 4 * slot;
-    if (r[2] || r[0] == 0) { // the grid barrier timed out: not all workgroups were resident
+    if (r[2] || r[0] == 0) {
         (void)hipMemsetAsync(E.ir_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int), E.stream);
-        return fail(CHIP_ERR_HIP, "k_bundle_ir: grid barrier timed out");
+        return FUSED_TIMEOUT;
     }
     h->last_ir = r[1];
     return r[0] > 0 ? 1 : 0;
+}
+static int solve_core(chip_kkt *h);
+// the solve of ring slot `slot` once more, one kernel per phase with the refinement decisions on the host
+// (same results up to rounding); the slot's right-hand side buffers must still hold what was enqueued
+static int fused_retry_unfused(chip_kkt *h, int slot) {
+    Engine &E = h->E;
+    const chip_kkt::FusedArgs &a = h->fused_args[slot];
+    h->fused_fallbacks += 1;
+    h->rhs_x = a.rx;
+    h->rhs_z = a.rz;
+    h->rhs_deferred = true;
+    h->x_holds_b = true;
+    const int ok = solve_core(h);
+    if (ok != 1) return ok;
+    dev::getlhs_perm(E.stream, a.lx, a.lz, h->x, E.iperm, (int)h->K.n, (int)h->K.m);
+    CHIP_HIP(hipGetLastError());
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    return 1;
 }
 static int fused_read_ring(chip_kkt *h) { return h->E.read_mailbox(); } // (the ring lives in the mailbox)
 
@@ -996,7 +1026,8 @@ int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev, double *lhsz_dev) {
         int rc = fused_enqueue(h, lhsx_dev, lhsz_dev, &slot);
         if (rc) return rc;
         if ((rc = fused_read_ring(h))) return rc;
-        return fused_verdict(h, slot);
+        rc = fused_verdict(h, slot);
+        return rc == FUSED_TIMEOUT ? fused_retry_unfused(h, slot) : rc;
     }
     int ok = solve_core(h);
     if (ok != 1) return ok;
@@ -1053,11 +1084,16 @@ int32_t chip_kkt_collect(chip_kkt *h, int32_t *update_ok, int32_t *nsolves, int3
     if (update_ok) *update_ok = uok;
     int n = 0;
     rc = CHIP_OK;
+    bool suspect = false; // a timed-out launch leaves the barrier counters dirty for the launches queued behind it
     for (int sl : h->pend_slots) {
         int v;
         if (sl < 0) v = -1 - sl;
         else {
             v = fused_verdict(h, sl);
+            if (v == FUSED_TIMEOUT || suspect) {
+                suspect = true;
+                v = fused_retry_unfused(h, sl);
+            }
             if (v < 0) rc = v;
         }
         if (solves_ok && n < 16) solves_ok[n] = v > 0 ? 1 : 0;
@@ -1415,6 +1451,27 @@ int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]) {
     out[0] = (double)h->E.prof_launches;
     out[1] = h->E.prof_ms_total;
     out[2] = (double)h->E.prof_family;
+    return CHIP_OK;
+}
+int32_t chip_kkt_fused_fallbacks(const chip_kkt *h) { return h ? h->fused_fallbacks : CHIP_ERR_ARG; }
+int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]) {
+    if (!h || !out) return CHIP_ERR_ARG;
+    std::memcpy(out, h->E.sn_model, 8 * sizeof(double));
+    return CHIP_OK;
+}
+// diagnostics: a kernel that only spins, on a stream of its own (co-residency tests of the persistent launches)
+int32_t chip_debug_spin(int32_t device, int32_t blocks, int32_t threads, int32_t lds_bytes, double usec) {
+    static hipStream_t spin_stream[16] = {};
+    if (device < 0 || device >= 16 || blocks < 0 || threads <= 0 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024)
+        return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(device));
+    if (blocks == 0) { // wait for the spinners launched so far
+        if (spin_stream[device]) CHIP_HIP(hipStreamSynchronize(spin_stream[device]));
+        return CHIP_OK;
+    }
+    if (!spin_stream[device]) CHIP_HIP(hipStreamCreateWithFlags(&spin_stream[device], hipStreamNonBlocking));
+    dev::debug_spin(spin_stream[device], blocks, threads, lds_bytes, usec);
+    CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
 

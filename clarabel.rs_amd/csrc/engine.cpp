@@ -229,6 +229,21 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             if ((rc = alloc(&sn_flags, ((size_t)bp[nsn] + 1) * 256))) return rc;
             CHIP_HIP(hipMemset(sn_flags, 0, ((size_t)bp[nsn] + 1) * 256 * sizeof(int)));
         }
+        for (int sn = 0; sn < nsn; sn++) {
+            const i32 e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+            const double w = S.sn_ptr[sn + 1] - S.sn_ptr[sn], nb = S.Lp[e + 1] - S.Lp[e], h = w + nb;
+            for (int b = 1; b * 64 < (int)w; b++) {
+                const double j0 = 64.0 * b, nc = std::min(64.0, w - j0);
+                sn_model[0] += 2.0 * (h - j0) * nc * j0;
+            }
+            sn_model[1] += w * (w - 1) / 2 + w * nb;
+            sn_model[2] += 2.0 * (nb * (nb + 1) / 2) * w;
+            for (int b = 0; b * 64 < (int)w; b++) {
+                const double j0 = 64.0 * b, nc = std::min(64.0, w - j0);
+                sn_model[3] += nc * nc * nc / 3.0 + (h - j0 - nc) * nc * nc;
+            }
+        }
+        sn_model[4] = nsn;
         sn_lvl_ptr = S.sn_lvl_ptr;
         sn_lvl_nblk = S.sn_lvl_nblk;
         sn_lvl_hmax = S.sn_lvl_hmax;
@@ -387,6 +402,10 @@ void Engine::prof_end(int family) {
     prof_used += 2;
     if (prof_used >= 8192) prof_collect();
 }
+dev::LaunchProf Engine::launch_prof() {
+    return dev::LaunchProf{[](void *c, int f) { ((Engine *)c)->prof_begin(f); },
+                           [](void *c, int f) { ((Engine *)c)->prof_end(f); }, this};
+}
 void Engine::prof_collect() {
     if (!prof_used) return;
     (void)hipEventSynchronize(prof_events[prof_used - 1]);
@@ -449,11 +468,12 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     }
     const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo};
     auto has_sn = [&](int l) { return nsn > 0 && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
+    const dev::LaunchProf lprof = launch_prof();
     auto run_supernodes = [&](int l) {
         if (!has_sn(l)) return;
         dev::factor_B(stream, vf, snx.B(l));
         dev::factor_snodes(stream, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l], sn_wmax,
-                           sn_lvl_nblk[l], sn_lvl_hmax[l], sn_lvl_nbmax[l]);
+                           sn_lvl_nblk[l], sn_lvl_hmax[l], sn_lvl_nbmax[l], prof_family >= PF_SN_UPDATE ? &lprof : nullptr);
     };
     for (int l = top_folded ? nfaclevels : 0; l < nfaclevels;) {
         int e = fac.chain_end[l];
@@ -556,19 +576,25 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         dev::SnodeTriView tri{sn_blk_ptr, sn_flags, 0, norm_nan(1)};
         dev::GatherArgs f{Rf_p, Rf_col, Rfx, xp, xp, nullptr, nullptr, nullptr};
         tri.epoch = ++sn_epoch;
+        const dev::LaunchProf lprof = launch_prof();
+        const dev::LaunchProf *lp = prof_family >= PF_SN_UPDATE ? &lprof : nullptr;
         for (int l = 0; l < nfaclevels; l++) {
+            prof_begin(PF_SN_GATHER);
             dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
+            prof_end(PF_SN_GATHER);
             dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr);
+                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
         }
         tri.epoch = ++sn_epoch;
         dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
         for (int l = nfaclevels - 1; l >= 0; l--) {
             dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr);
+                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
             const dev::ChunkView b = bwu.B(l);
             if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwu.BR(l));
+            prof_begin(PF_SN_GATHER);
             dev::gather_merged(stream, dev::BWD, g, bwu.T(l), bwu.W(l), b);
+            prof_end(PF_SN_GATHER);
         }
         dev::bundle_bwd(stream, v, bundles, xp, addv);
         if (addv && N > NF) dev::add_vec(stream, xp + NF, addv + NF, N - NF);

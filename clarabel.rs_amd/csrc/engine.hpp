@@ -46,7 +46,14 @@ constexpr int NRM_SET_WORDS = (dev::NRM_SLOTS + 1) * dev::NRM_STRIDE;
 static_assert(sizeof(Mailbox) <= 512, "mailbox");
 
 // profile families (hipEvent pairs around each launch of ONE selected family)
-enum ProfFamily { PF_NONE = 0, PF_SYMV_T = 1, PF_BWD_T = 2, PF_FWD_T = 3, PF_FACTOR_T = 4, PF_IR = 5, PF_BFACTOR = 6, PF_COUNT };
+enum ProfFamily {
+    PF_NONE = 0, PF_SYMV_T = 1, PF_BWD_T = 2, PF_FWD_T = 3, PF_FACTOR_T = 4, PF_IR = 5, PF_BFACTOR = 6,
+    // supernode kernels (ids shared with the launchers in kernels.hip: dev::PFK_*)
+    PF_SN_UPDATE = dev::PFK_SN_UPDATE, PF_SN_DIAG = dev::PFK_SN_DIAG, PF_SN_ROWS = dev::PFK_SN_ROWS,
+    PF_SN_EXTEND = dev::PFK_SN_EXTEND, PF_SN_TRI = dev::PFK_SN_TRI,
+    PF_SN_GATHER = 12, // k_gather_merged launches of the supernode substitution path
+    PF_COUNT
+};
 
 struct Engine {
     int device = 0;
@@ -163,6 +170,12 @@ struct Engine {
     void prof_end(int family);
     void prof_pair(int family, hipEvent_t *ev0, hipEvent_t *ev1);
     void prof_collect();
+    dev::LaunchProf launch_prof(); // hook handed to the launchers in kernels.hip (nullptr-equivalent when off)
+    // work model of the chain supernodes, per refactor / per sweep (host.hpp: Symbolic::sn_*), for the roofline
+    // figures of bench.py: [0] multiply-add flops of k_snode_update (2 per multiply-add, useful part of the
+    // tiles: rows >= the block's first row), [1] entries of the dense trapezoids (what one sweep streams),
+    // [2] flops of k_snode_extend, [3] flops of k_snode_diag + k_snode_rows, [4] #supernodes
+    double sn_model[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 std::string hip_err(hipError_t e, const char *what);

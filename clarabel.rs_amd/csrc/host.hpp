@@ -28,6 +28,9 @@ struct AmdInfo {
 // Stands in for crate `amd 0.2.2` (qdldl.rs:905-917; dense = 10*dense_scale*sqrt(n)).
 int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
               AmdInfo *info);
+// the same by connected components: identical patterns ordered once, distinct ones in parallel (amd_order.cpp)
+int amd_order_components(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
+                         AmdInfo *info);
 
 // ---------------------------------------------------------------------------
 // symbolic analysis (symbolic.cpp)

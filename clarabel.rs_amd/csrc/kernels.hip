@@ -2496,6 +2496,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     __shared__ IrState st;
     const int nb = bv.nb, G = gridDim.x, k = fold.k, tid = threadIdx.x;
     const int NF = k ? fold.NF : ir.N;
+    if (ir.test_drop && (int)blockIdx.x == G - 1 && G > 1) return; // (tests: a launch that is not co-resident)
     const bool single = nb <= G; // one bundle per workgroup: its residual never leaves LDS
     // partial results: device-coherent stores before a barrier, reduced in a fixed order by its last arriver
     double *pnb = ir.part;                  // [nb]       ||b||inf of the bundles' rows
@@ -5137,9 +5138,11 @@ int snode_kernel_attributes(int wmax, int nbmax) {
 // wlvl / nblvl: maxima over the supernodes of this launch.  Levels with a large B part run it in
 // separate multi-workgroup launches: one workgroup per supernode is latency bound.
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
-                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri) {
+                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri,
+                  const LaunchProf *lp) {
     if (!count) return;
     if (tri && tri->msg && wlvl > 2 * SN_NB) {
+        if (lp) lp->begin(lp->ctx, PFK_SN_TRI);
         // wide supernodes: the triangle by several workgroups per supernode (k_snode_tri), the rows of B by
         // their own multi-workgroup launches
         const int nblkmax = (wlvl + SN_NB - 1) / SN_NB;
@@ -5151,6 +5154,7 @@ void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView
                                                                      tri->timeout_flag);
         }
         (void)nblvl;
+        if (lp) lp->end(lp->ctx, PFK_SN_TRI);
         return;
     }
     int cap = SN_XB_CAP;
@@ -5173,9 +5177,11 @@ void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView
 // all supernodes order[0..count) of one unit level: block columns one after the other, then their
 // updates of the ancestors.  nblk / hmax / nbmax: maxima over these supernodes.
 void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order, int count, int wmax_all,
-                   int nblk, int hmax, int nbmax) {
+                   int nblk, int hmax, int nbmax, const LaunchProf *lp) {
     if (!count) return;
     const size_t lds = snode_lds_bytes(wmax_all);
+    auto pb = [&](int f) { if (lp) lp->begin(lp->ctx, f); };
+    auto pe = [&](int f) { if (lp) lp->end(lp->ctx, f); };
     for (int b = 0; b < nblk; ++b) {
         if (b > 0) {
             const int rows = hmax - b * SN_NB;
@@ -5185,16 +5191,38 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const i
                 // (CHIP_NO_SPLITK: no split -> no fp64 atomics between the splits, a fixed summation order)
                 static const bool no_splitk = std::getenv("CHIP_NO_SPLITK") != nullptr;
                 while (!no_splitk && ksplit < 8 && ksplit * 2 <= nchunks && groups * count * ksplit < 512) ksplit *= 2;
+                pb(PFK_SN_UPDATE);
                 k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b);
+                pe(PFK_SN_UPDATE);
             }
         }
+        pb(PFK_SN_DIAG);
         k_snode_diag<<<count, SN_DWG, 0, s>>>(v, sv, order, b);
+        pe(PFK_SN_DIAG);
         const int below = hmax - b * SN_NB - 1; // (a narrow last block leaves more rows below it)
-        if (below > 0) k_snode_rows<<<dim3((below + SN_RWG - 1) / SN_RWG, count), SN_RWG, 0, s>>>(v, sv, order, b);
+        if (below > 0) {
+            pb(PFK_SN_ROWS);
+            k_snode_rows<<<dim3((below + SN_RWG - 1) / SN_RWG, count), SN_RWG, 0, s>>>(v, sv, order, b);
+            pe(PFK_SN_ROWS);
+        }
     }
-    if (nbmax > 0 && sv.upd_slot)
+    if (nbmax > 0 && sv.upd_slot) {
+        pb(PFK_SN_EXTEND);
         k_snode_extend<<<dim3((nbmax + SN_ROWS - 1) / SN_ROWS, (nbmax + SN_NB - 1) / SN_NB, count), SN_WG, lds, s>>>(
             v, sv, order);
+        pe(PFK_SN_EXTEND);
+    }
+}
+__global__ void k_debug_spin(long long ticks) {
+    extern __shared__ char spin_lds[];
+    if (ticks < 0) spin_lds[threadIdx.x] = 0; // (keeps the dynamic LDS allocation alive)
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+void debug_spin(hipStream_t s, int blocks, int threads, int lds_bytes, double usec) {
+    if (lds_bytes > 65536)
+        (void)hipFuncSetAttribute((const void *)k_debug_spin, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    k_debug_spin<<<blocks, threads, (size_t)lds_bytes, s>>>((long long)(usec * 100.0)); // 100 MHz clock
 }
 void factor_finalize(hipStream_t s, const LdlView &v, ListView c) {
     if (c.count) k_factor_finalize<<<c.count, WG, 0, s>>>(v, c.idx, c.count);

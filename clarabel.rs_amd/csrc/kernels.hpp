@@ -128,6 +128,7 @@ struct IrView {
     double abstol, reltol, stopratio;
     int maxiter, ir_enable;
     long long *dbg;        // diagnostics: 128 time stamps of two workgroups, or nullptr
+    int test_drop;         // tests: the last workgroup leaves at once, so every grid barrier times out
 };
 int ir_ctl_ints();
 size_t ir_part_doubles(int nb, int k);
@@ -150,8 +151,16 @@ struct SnodeView {
 };
 int snode_kernel_attributes(int wmax, int nbmax);
 
+// optional per-launch hook: hipEvent pairs around the launches of ONE selected kernel family (engine.hpp:
+// ProfFamily; the ids of the supernode kernels are fixed here because the launchers live in kernels.hip)
+enum { PFK_SN_UPDATE = 7, PFK_SN_DIAG = 8, PFK_SN_ROWS = 9, PFK_SN_EXTEND = 10, PFK_SN_TRI = 11 };
+struct LaunchProf {
+    void (*begin)(void *ctx, int family);
+    void (*end)(void *ctx, int family);
+    void *ctx;
+};
 void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order, int count, int wmax_all,
-                   int nblk, int hmax, int nbmax);
+                   int nblk, int hmax, int nbmax, const LaunchProf *lp = nullptr);
 void factor_finalize(hipStream_t s, const LdlView &v, ListView cols);
 
 // ---- triangular solves + symv (row-gather family) -------------------------------
@@ -195,7 +204,11 @@ struct SnodeTriView {
 };
 // forward / backward substitution through the supernodes order[0..count) of one unit level
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
-                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri = nullptr);
+                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri = nullptr,
+                  const LaunchProf *lp = nullptr);
+// diagnostics / tests: a kernel of `blocks` x `threads` that only spins for `usec` microseconds on stream s
+// (co-residency tests of the persistent launches)
+void debug_spin(hipStream_t s, int blocks, int threads, int lds_bytes, double usec);
 // ||v[rows]||inf of a short row list into the slots (the B rows of a SYMV)
 void norm_rows(hipStream_t s, const double *v, ListView rows, unsigned long long *nrm, int *nan);
 

@@ -256,7 +256,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // ---- ordering -----------------------------------------------------------
     std::vector<i64> p0 = perm0;
     if (p0.empty() && n > 0) {
-        int rc = amd_order(n, Ap, Ai, amd_dense_scale, p0, &S.amd);
+        int rc = amd_order_components(n, Ap, Ai, amd_dense_scale, p0, &S.amd);
         if (rc) {
             set_error("amd_order failed");
             return rc;

@@ -336,6 +336,24 @@ void *chip_kkt_stream(chip_kkt *h);
  * returns out[0] = launches, out[1] = total ms, out[2] = family. */
 int32_t chip_kkt_profile(chip_kkt *h, int32_t family);
 int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]);
+/* further families (systems whose top runs as chain supernodes, configs 2 / 5): 7 = k_snode_update (f64 MFMA tiles),
+ * 8 = k_snode_diag, 9 = k_snode_rows, 10 = k_snode_extend, 11 = k_snode_tri (pipelined substitution through wide
+ * supernodes, both sweeps), 12 = k_gather_merged launches of the supernode substitution path.
+ * chip_kkt_work_model: the work those kernels do per refactor / per sweep, from the supernode geometry:
+ * out[0] = flops of k_snode_update per refactor (2 per multiply-add, rows at or below the block only),
+ * out[1] = entries of the dense trapezoids (streamed once per sweep), out[2] = flops of k_snode_extend,
+ * out[3] = flops of k_snode_diag + k_snode_rows, out[4] = number of supernodes. */
+int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]);
+/* number of fused solve launches (k_bundle_ir) of this handle whose grid barrier timed out -- their workgroups were not
+ * all resident because another long-running kernel held the slots -- and that were repeated on the
+ * one-kernel-per-phase path (refinement decisions on the host, same results up to rounding).  For enqueued solves the
+ * repeat happens in chip_kkt_collect, for the timed-out solve and every solve enqueued behind it, from the right-hand
+ * side buffers as they are THEN: the buffers of pending solves must stay untouched until collect. */
+int32_t chip_kkt_fused_fallbacks(const chip_kkt *h);
+/* diagnostics / tests: launches a kernel of `blocks` x `threads` (+ lds_bytes of LDS per workgroup) that only spins
+ * for `usec` microseconds, on a private stream of `device` -- the persistent launches (k_bundle_ir) must survive a
+ * co-resident kernel (the RCCL ring of the sharded path).  blocks = 0: waits for the spinners launched so far. */
+int32_t chip_debug_spin(int32_t device, int32_t blocks, int32_t threads, int32_t lds_bytes, double usec);
 
 /* ===========================================================================
  * L3 -- the caller either side of the KKT solve, device resident:

@@ -413,6 +413,67 @@ def test_repeated_solve_on_fused_handle(hip, oracle, which):
     assert relerr(np.concatenate([x1, z1]), np.concatenate([xo, zo])) <= TOL
 
 
+def _enqueue_three(hip, ks, pr, rng):
+    rhs = [(hip.DeviceArray(rng.standard_normal(pr["n"])), hip.DeviceArray(rng.standard_normal(pr["m"]))) for _ in range(3)]
+    lhs = [hip.DeviceArray(pr["n"] + pr["m"]) for _ in range(3)]
+    for (rx, rz), l in zip(rhs, lhs):
+        ks.setrhs_dev(rx.ptr, rz.ptr)
+        ks.solve_dev_enqueue(l.ptr, l.ptr + 8 * pr["n"])
+    return rhs, lhs
+
+
+def test_fused_solve_with_coresident_kernel(hip, oracle):
+    """The sharded path lets RCCL's ring kernels run on a second stream UNDER the next step's persistent
+    k_bundle_ir launches, whose grid was sized for an idle device.  A co-resident kernel that holds CU slots for a
+    while (32 / 256 workgroups x 1024 threads with 64 KB of LDS each, 3 ms) must only delay the grid barrier, never
+    break it: a config-4-share handle (a forest of 6007-node trees, one workgroup per tree) solves three enqueued
+    right-hand sides correctly while the spinner is resident, without taking the fallback path."""
+    pr = problems.batched_socp(128, 2000, 2, seed=100)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    assert ks.update_scaling(pr["s"], pr["z"]) and cones.update_scaling(pr["s"], pr["z"])
+    assert ks.update() and ko.update()
+    rng = np.random.default_rng(11)
+    for spin_blocks in (32, 256):
+        hip.debug_spin(0, spin_blocks, 1024, 65536, 3000.0)
+        rhs, lhs = _enqueue_three(hip, ks, pr, rng)
+        uok, sok = ks.collect()
+        assert uok and list(sok) == [True, True, True]
+        hip.debug_spin(0, 0)
+        for (rx, rz), l in zip(rhs, lhs):
+            ko.setrhs(rx.numpy(), rz.numpy())
+            ok, xo, zo = ko.solve()
+            assert ok and relerr(l.numpy(), np.concatenate([xo, zo])) <= TOL
+    assert ks.fused_fallbacks() == 0
+
+
+def test_fused_solve_timeout_falls_back(hip, oracle, monkeypatch):
+    """a fused launch whose workgroups are NOT all resident (forced: CHIP_IR_TEST_DROP makes the last workgroup
+    leave at once, so every grid barrier times out after ~2 s): the solve is repeated on the one-kernel-per-phase
+    path -- synchronous solve and enqueue / collect alike -- instead of reporting a failure"""
+    monkeypatch.setenv("CHIP_IR_TEST_DROP", "1")
+    pr = problems.portfolio_socp(12, 300, seed=3)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    assert ks.update_scaling(pr["s"], pr["z"]) and cones.update_scaling(pr["s"], pr["z"])
+    assert ks.update() and ko.update()
+    rng = np.random.default_rng(12)
+    rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+    ks.setrhs(rx, rz)
+    ko.setrhs(rx, rz)
+    x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+    assert ks.solve(x, z)
+    ok, xo, zo = ko.solve()
+    assert ok and relerr(np.concatenate([x, z]), np.concatenate([xo, zo])) <= TOL
+    assert ks.fused_fallbacks() == 1
+    rhs, lhs = _enqueue_three(hip, ks, pr, rng)
+    uok, sok = ks.collect()
+    assert uok and list(sok) == [True, True, True]
+    for (drx, drz), l in zip(rhs, lhs):
+        ko.setrhs(drx.numpy(), drz.numpy())
+        ok, xo, zo = ko.solve()
+        assert ok and relerr(l.numpy(), np.concatenate([xo, zo])) <= TOL
+    assert ks.fused_fallbacks() == 4
+
+
 def test_soc_scaling_failure_reported(hip):
     pr = problems.portfolio_socp(2, 10, seed=1)
     P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
@@ -836,6 +897,92 @@ def test_parity_c5_24_cliques(hip, oracle):
     pr = problems.chordal_sdp(24, 50, 10, 24, 51, seed=5)
     ks, _ = _full_scale_parity(hip, oracle, pr, hs_dev=True, nrhs=2, kvals_tol=1e-11)
     assert len(ks.supernodes()) >= 24
+
+
+# ---- BASELINE config 5 at its FULL size (200 x PSD(50) + 200 x SOC(51), N = 277 345) ------------------------
+# The scalar oracle needs ~10 CPU-minutes for this factorisation: its answers are the committed fixture
+# tests/golden/c5_full_oracle.npz (generator: tests/golden/make_c5_fixture.py, same problem generator and seed).
+C5_FIXTURE = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "c5_full_oracle.npz")
+
+
+@pytest.fixture(scope="module")
+def c5_full(hip):
+    """the full-size handle, built once (host analysis ~17 s), scaled and factored on the device"""
+    pr = problems.chordal_sdp(200, 50, 10, 200, 51, seed=5, with_hs=False)
+    P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
+    A = hip.CscMatrix(pr["m"], pr["n"], *pr["A"])
+    ks = hip.HipKKTSolver(P, A, pr["cones"], pr["m"], pr["n"])
+    assert ks.update_scaling(pr["s"], pr["z"])
+    assert ks.update()
+    yield pr, ks
+    del ks
+
+
+def test_full_scale_parity_c5(hip, c5_full):
+    """post-refinement solutions (default refinement settings) against the oracle's, <= 1e-8 relative; the device's
+    fused Hs write (PSD scalings, skron) against a seeded sample of the oracle's K.nzval; static regulariser,
+    dynamically regularised pivots and inertia equal"""
+    pr, ks = c5_full
+    fx = np.load(C5_FIXTURE)
+    assert int(fx["N"]) == ks.N == 277345 and int(fx["n"]) == pr["n"] and int(fx["m"]) == pr["m"]
+    assert len(ks.supernodes()) >= 200
+    kv = ks.values()
+    assert int(fx["k_nnz"]) == len(kv)
+    kerr = np.max(np.abs(kv[fx["k_sample_idx"]] - fx["k_sample_val"])) / max(1.0, float(fx["k_absmax"]))
+    assert kerr <= 1e-11, "K.nzval sample: %g" % kerr
+    info = ks.linear_solver_info()
+    assert abs(info.last_regularizer - float(fx["regularizer"])) <= 1e-20 + 1e-12 * float(fx["regularizer"])
+    assert info.regularize_count == int(fx["regularize_count"])
+    assert info.positive_inertia == int(fx["positive_inertia"])
+    rng = np.random.default_rng(int(fx["rhs_seed"]))
+    for k in range(int(fx["nrhs"])):
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        ks.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert ks.solve(x, z)
+        err = relerr(np.concatenate([x, z]), fx["solutions"][k])
+        assert err <= TOL, "rhs %d: rel. err vs oracle fixture %g" % (k, err)
+
+
+def test_full_scale_properties_c5(hip, c5_full):
+    """size-independent checks at the full size: residual of the refined solution against an independent scipy SpMV
+    of the UNregularised K, linearity of the solve, inertia = n + #sparse SOC"""
+    pr, ks = c5_full
+    K = ks.kkt_matrix()
+    vals = ks.values()
+    Ku = sp.csc_matrix((vals, K.rowval.astype(np.int64), K.colptr.astype(np.int64)), shape=(ks.N, ks.N))
+    rng = np.random.default_rng(1)
+    b1, b2 = rng.standard_normal(ks.N), rng.standard_normal(ks.N)
+    ok1, x1 = ks.solve_full(b1)
+    ok2, x2 = ks.solve_full(b2)
+    ok3, x3 = ks.solve_full(2.0 * b1 - 3.0 * b2)
+    assert ok1 and ok2 and ok3
+    for b, x in ((b1, x1), (b2, x2)):
+        r = b - (Ku @ x + Ku.T @ x - Ku.diagonal() * x)
+        assert np.max(np.abs(r)) <= 1e-8 * max(1.0, np.max(np.abs(b)), np.max(np.abs(x)))
+    assert relerr(x3, 2.0 * x1 - 3.0 * x2) <= 1e-7
+    assert ks.linear_solver_info().positive_inertia == pr["n"] + 200
+
+
+def test_run_to_run_spread_c5_full(hip, c5_full):
+    """four refactor + solve passes over the same values at the full size, where the 200 supernodes' update matrices
+    meet in fp64 atomics (k_snode_extend): spread of the refined solution <= 1e-12, pivot-rule outcome identical"""
+    pr, ks = c5_full
+    rng = np.random.default_rng(5)
+    rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+    sols, counts = [], []
+    for _ in range(4):
+        assert ks.update_scaling(pr["s"], pr["z"])
+        assert ks.update()
+        info = ks.linear_solver_info()
+        counts.append((info.regularize_count, info.positive_inertia))
+        ks.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert ks.solve(x, z)
+        sols.append(np.concatenate([x, z]))
+    assert len(set(counts)) == 1, counts
+    spread = max(relerr(s_, sols[0]) for s_ in sols[1:])
+    assert spread <= 1e-12, "run-to-run spread %g" % spread
 
 
 @pytest.mark.parametrize("which", ["c3", "c2_supernodes", "c5_supernodes"])

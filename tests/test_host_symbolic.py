@@ -241,6 +241,31 @@ def test_threaded_analysis_same_symbolic(hip, name, monkeypatch):
         assert g[2:] == got[0][2:]
 
 
+@pytest.mark.parametrize("which", ["identical", "ragged"])
+def test_amd_by_connected_components(hip, which, monkeypatch):
+    """block-diagonal KKT systems (BASELINE config 4): minimum degree runs once per DISTINCT component pattern
+    (identical blocks share one ordering, distinct ones are ordered in parallel) instead of once over the whole
+    graph -- a valid permutation with the same fill and the same tree depth as the whole-graph ordering"""
+    if which == "identical":
+        pr = problems.batched_socp(12, 60, 2, seed=100)
+    else:
+        pr = problems.blockdiag([problems.portfolio_socp(2, 10 + 3 * (i % 4), seed=100 + i) for i in range(9)])
+    k1 = _mk(hip, pr)
+    monkeypatch.setenv("CHIP_NO_COMPONENTS", "1")
+    k2 = _mk(hip, pr)
+    p1, p2 = np.asarray(k1.perm), np.asarray(k2.perm)
+    assert sorted(p1.tolist()) == list(range(k1.N))
+    i1, i2 = k1.linear_solver_info(), k2.linear_solver_info()
+    assert i1.nnzL == i2.nnzL and i1.n_levels == i2.n_levels
+    if which == "identical":   # every block gets the same relative order
+        K = k1.kkt_matrix()
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import connected_components
+        G = sp.csc_matrix((np.ones(len(K.rowval)), K.rowval.astype(np.int64), K.colptr.astype(np.int64)), shape=(k1.N, k1.N))
+        nc, lab = connected_components(G + G.T, directed=False)
+        assert nc == 12
+
+
 def test_user_perm_respected_up_to_level_sort(hip, oracle, monkeypatch):
     # (chain supernodes pad their columns with explicit zeros, which nnzL counts: off for the exact comparison)
     monkeypatch.setenv("CHIP_NO_SNODE", "1")

@@ -531,7 +531,8 @@ class HipKKTSolver:
         out = (C.c_double * 8)()
         _check(lib().chip_kkt_work_model(self._h, out), "work_model")
         return {"sn_update_flops": float(out[0]), "sn_panel_entries": float(out[1]), "sn_extend_flops": float(out[2]),
-                "sn_diag_rows_flops": float(out[3]), "n_supernodes": int(out[4])}
+                "sn_diag_rows_flops": float(out[3]), "n_supernodes": int(out[4]), "fold_groups": int(out[5]),
+                "n_bundles": int(out[6]), "fused_threads": int(out[7])}
 
     def fused_fallbacks(self):
         return int(lib().chip_kkt_fused_fallbacks(self._h))

@@ -167,6 +167,20 @@ int32_t chip_amd_order(int64_t n, const uint64_t *colptr, const uint64_t *rowval
 }
 
 // ---------------------------------------------------------------------------
+// workgroups the device keeps resident for the fused solve kernel (4 x 256 threads per CU): a forest with fewer
+// bundles than that is cut finer by the analysis (grouped fold).  Host-only handles: an MI355X's 256 CUs.
+static int target_workgroups(const chip_settings &st) {
+    if (const char *e = std::getenv("CHIP_TARGET_WG")) return std::atoi(e); // (tests; 0 = never refine)
+    if (st.device == CHIP_DEVICE_HOST_ONLY) return 1024;
+    int dev = st.device, cus = 0;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return 1024;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        return 1024;
+    }
+    return 4 * cus;
+}
+
 // L1
 // ---------------------------------------------------------------------------
 int32_t chip_ldl_create(chip_ldl **out, int64_t n, const uint64_t *colptr, const uint64_t *rowval,
@@ -180,7 +194,7 @@ int32_t chip_ldl_create(chip_ldl **out, int64_t n, const uint64_t *colptr, const
     std::vector<i64> perm0;
     if (perm_or_null) perm0.assign(as_i64(perm_or_null), as_i64(perm_or_null) + n);
     Symbolic S;
-    int rc = analyse(n, as_i64(colptr), as_i64(rowval), dsigns, perm0, st.amd_dense_scale, S);
+    int rc = analyse(n, as_i64(colptr), as_i64(rowval), dsigns, perm0, st.amd_dense_scale, S, target_workgroups(st));
     if (rc) return rc;
     std::unique_ptr<chip_ldl> h(new chip_ldl());
     h->hK.assign(nzval, nzval + S.nnzK);
@@ -367,7 +381,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     std::vector<i64> perm0;
     if (perm_or_null) perm0.assign(as_i64(perm_or_null), as_i64(perm_or_null) + K.N);
     Symbolic S;
-    rc = analyse(K.N, K.colptr.data(), K.rowval.data(), K.dsigns.data(), perm0, st.amd_dense_scale, S);
+    rc = analyse(K.N, K.colptr.data(), K.rowval.data(), K.dsigns.data(), perm0, st.amd_dense_scale, S, target_workgroups(st));
     if (rc) return rc;
     clk("analysis (total)");
     Engine &E = h->E;
@@ -963,15 +977,42 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     }
     if (dbg_on) (void)hipMemsetAsync(dbg_dev, 0, 256 * sizeof(long long), E.stream);
     ir.dbg = dbg_on ? dbg_dev : nullptr;
+    // CHIP_IR_DEBUG=2: stamps of EVERY workgroup, dumped to the file CHIP_IR_DEBUG_FILE (default /tmp/chip_ir_stamps.bin:
+    // int32 G, then G x 32 int64) after each launch -- tools/ir_skew.py turns them into per-phase statistics
+    static const bool dbg_all_on = dbg_on && std::atoi(std::getenv("CHIP_IR_DEBUG")) >= 2;
+    static long long *dbg_all_dev = nullptr;
+    static size_t dbg_all_len = 0;
+    ir.dbg_all = nullptr;
+    if (dbg_all_on) {
+        const size_t need = (size_t)E.ir_grid * 32;
+        if (need > dbg_all_len) {
+            if (dbg_all_dev) (void)hipFree(dbg_all_dev);
+            (void)hipMalloc((void **)&dbg_all_dev, need * sizeof(long long));
+            dbg_all_len = need;
+        }
+        (void)hipMemsetAsync(dbg_all_dev, 0, need * sizeof(long long), E.stream);
+        ir.dbg_all = dbg_all_dev;
+    }
     ir.test_drop = h->ir_test_drop ? 1 : 0;
     h->fused_args[*slot] = {h->rhs_x, h->rhs_z, lhsx_dev, lhsz_dev};
     h->rhs_deferred = false;
     h->x_holds_b = false;
     E.prof_begin(PF_IR);
-    const int rc = dev::bundle_ir(E.stream, E.view(), E.bundles, E.fold, ir, E.ir_grid, E.ir_tw);
+    const int rc = dev::bundle_ir(E.stream, E.view(), E.bundles, E.fold, ir, E.ir_grid, E.ir_tw, E.gfold);
     E.prof_end(PF_IR);
     if (rc) return fail(CHIP_ERR_HIP, hip_err((hipError_t)rc, "k_bundle_ir launch"));
-    if (dbg_on) {
+    if (dbg_all_on) {
+        (void)hipStreamSynchronize(E.stream);
+        std::vector<long long> t((size_t)E.ir_grid * 32);
+        (void)hipMemcpy(t.data(), dbg_all_dev, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        const char *path = std::getenv("CHIP_IR_DEBUG_FILE");
+        if (FILE *f = std::fopen(path ? path : "/tmp/chip_ir_stamps.bin", "wb")) {
+            const int g = E.ir_grid;
+            std::fwrite(&g, sizeof(int), 1, f);
+            std::fwrite(t.data(), sizeof(long long), t.size(), f);
+            std::fclose(f);
+        }
+    } else if (dbg_on) {
         long long t[256];
         (void)hipStreamSynchronize(E.stream);
         (void)hipMemcpy(t, dbg_dev, sizeof(t), hipMemcpyDeviceToHost);
@@ -990,7 +1031,7 @@ static int fused_verdict(chip_kkt *h, int slot) {
     Engine &E = h->E;
     const int *r = E.ir_res_host + 4 * slot;
     if (r[2] || r[0] == 0) {
-        (void)hipMemsetAsync(E.ir_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int), E.stream);
+        (void)hipMemsetAsync(E.ir_ctl, 0, E.ir_ctl_len * sizeof(int), E.stream);
         return FUSED_TIMEOUT;
     }
     h->last_ir = r[1];
@@ -1457,6 +1498,9 @@ int32_t chip_kkt_fused_fallbacks(const chip_kkt *h) { return h ? h->fused_fallba
 int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]) {
     if (!h || !out) return CHIP_ERR_ARG;
     std::memcpy(out, h->E.sn_model, 8 * sizeof(double));
+    out[5] = h->E.gfold.ng;    // groups of a grouped fold in use (0: none)
+    out[6] = h->E.bundles.nb;  // subtree bundles
+    out[7] = h->E.ir_fused ? h->E.ir_tw : 0; // threads per workgroup of the fused solve launch (0: not fused)
     return CHIP_OK;
 }
 // diagnostics: a kernel that only spins, on a stream of its own (co-residency tests of the persistent launches)

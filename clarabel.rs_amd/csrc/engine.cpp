@@ -310,18 +310,58 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         topblk.counters = cnt;
     }
     bool need_ring = false;
-    if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || NF == N) && !S.Li16.empty() &&
+    const bool grouped = S.gf_ng > 0;
+    if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || grouped || NF == N) && !S.Li16.empty() &&
         std::getenv("CHIP_NO_FUSED_IR") == nullptr) {
         const int cap = dev::bundle_ir_capacity(bundles, &ir_tw);
-        if (cap > 0 && (fold.k == 0 || bundles.nb <= cap)) {
+        if (cap > 0 && ((fold.k == 0 && !grouped) || bundles.nb <= cap)) {
             ir_fused = true;
             if ((rc = upload(&Li16, S.Li16, S.Li16.size()))) return rc;
             if ((rc = upload(&Ucol16, S.Ucol16, S.Ucol16.size()))) return rc;
             ir_grid = std::min(bundles.nb, cap);
-            if ((rc = alloc(&ir_ctl, (size_t)dev::ir_ctl_ints()))) return rc;
-            CHIP_HIP(hipMemset(ir_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int)));
+            ir_ctl_len = (size_t)dev::ir_ctl_ints() + (grouped ? (size_t)32 * S.gf_ng : 0);
+            if ((rc = alloc(&ir_ctl, ir_ctl_len))) return rc;
+            CHIP_HIP(hipMemset(ir_ctl, 0, ir_ctl_len * sizeof(int)));
             need_ring = true; // (ir_res = the ring inside the mailbox, set once that is allocated)
             if ((rc = alloc(&ir_part, dev::ir_part_doubles(bundles.nb, fold.k)))) return rc;
+            if (grouped) {
+                // grouped fold: known to k_bundle_ir / k_bundle_factor / k_gfold_top_factor only (everything else
+                // treats the top as an ordinary level-scheduled top: the unfused path stays valid as a fallback)
+                int *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *a4 = nullptr, *a5 = nullptr, *a6 = nullptr, *a7 = nullptr,
+                    *a8 = nullptr;
+                std::vector<i32> bgrp((size_t)bundles.nb, -1);
+                for (int g = 0; g < S.gf_ng; g++)
+                    for (int b = S.gf_bptr[g]; b < S.gf_bptr[g + 1]; b++) bgrp[b] = g;
+                if ((rc = upload(&a1, S.gf_ptr, S.gf_ptr.size()))) return rc;
+                if ((rc = upload(&a2, S.gf_node, S.gf_node.size()))) return rc;
+                if ((rc = upload(&a3, S.gf_bptr, S.gf_bptr.size()))) return rc;
+                if ((rc = upload(&a4, bgrp, bgrp.size()))) return rc;
+                if ((rc = upload(&a5, S.gf_tt, S.gf_tt.size()))) return rc;
+                if ((rc = upload(&a6, S.gf_sp, S.gf_sp.size()))) return rc;
+                if ((rc = upload(&a7, S.gf_scol, S.gf_scol.size()))) return rc;
+                if ((rc = upload(&a8, S.gf_sslot, S.gf_sslot.size()))) return rc;
+                double *fsh = nullptr, *rsh = nullptr, *rec = nullptr, *fac = nullptr;
+                if ((rc = alloc(&fsh, (size_t)bundles.nb * 8))) return rc;
+                if ((rc = alloc(&rsh, (size_t)bundles.nb * 16))) return rc;
+                if ((rc = alloc(&rec, (size_t)S.gf_ng * 64))) return rc;
+                if ((rc = alloc(&fac, (size_t)bundles.nb * 36))) return rc;
+                CHIP_HIP(hipMemset(rec, 0, (size_t)S.gf_ng * 64 * sizeof(double)));
+                CHIP_HIP(hipMemset(fac, 0, (size_t)bundles.nb * 36 * sizeof(double)));
+                gfold.ng = S.gf_ng;
+                gfold.ptr = a1;
+                gfold.node = a2;
+                gfold.bptr = a3;
+                gfold.bgrp = a4;
+                gfold.tt = a5;
+                gfold.sp = a6;
+                gfold.scol = a7;
+                gfold.sslot = a8;
+                gfold.fsh = fsh;
+                gfold.rsh = rsh;
+                gfold.rec = rec;
+                gfold.fac = fac;
+                gfold.gcnt = ir_ctl + dev::ir_ctl_ints();
+            }
         }
     }
     if ((rc = alloc(&mb_dev, 1))) return rc;
@@ -454,8 +494,10 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     prof_begin(PF_BFACTOR);
     dev::bundle_factor(stream, v, bundles, fold); // everything below the cut: one launch
     prof_end(PF_BFACTOR);
-    const bool top_folded = fold.k == 1; // single top column: pivot accumulated by the bundles
-    if (top_folded) dev::fold_top_pivot(stream, v, fold);
+    // single top column: pivot accumulated by the bundles; grouped fold: the k x k tops from the bundles' Schur shares
+    const bool top_folded = fold.k == 1 || gfold.ng > 0;
+    if (fold.k == 1) dev::fold_top_pivot(stream, v, fold);
+    if (gfold.ng > 0) dev::gfold_top_factor(stream, v, bundles, gfold);
     const bool use_chain = std::getenv("CHIP_NO_FACTOR_CHAIN") == nullptr;
     // units (single columns, chain supernodes) by unit level; a level's supernodes run after its
     // single columns: first the contributions of outside columns into their members (the chunked

@@ -93,6 +93,9 @@ struct Engine {
     int sn_epoch = 0;
     dev::BundleView bundles{}; // subtree bundles (device arrays)
     dev::FoldView fold{};      // few dense top rows folded into the bundle kernels (k == 0: not used)
+    dev::GFoldView gfold{};    // grouped fold (a forest of small trees with tops of <= 8 nodes; ng == 0: not used):
+                               // active only on handles whose solve is the fused launch
+    size_t ir_ctl_len = 0;     // ints of ir_ctl (the grid barrier's counters + one line per group of a grouped fold)
     dev::TopBlkView topblk{};  // blocked substitution of a tall top (nblocks == 0: level-scheduled top)
     int NF = 0, tree_depth = 0;
     std::vector<i32> h_level;

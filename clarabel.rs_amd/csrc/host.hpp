@@ -98,6 +98,19 @@ struct Symbolic {
     //                                     (column index relative to NF, position in V)
     i32 nfold = 0;
     std::vector<i32> fold_rseg, fold_tt, fold_sp, fold_scol, fold_sslot;
+    // GROUPED fold: a forest of many small trees whose tops are each at most TOPFOLD_MAX nodes (BASELINE
+    // config 4 when a GPU holds only a share of the trees: the forest cut is refined until about `target_wg`
+    // bundles exist, several per tree, and the few ancestors of a tree's bundles -- its top -- are folded into
+    // the bundle kernels per tree).  Group g = one elimination tree with a non-empty top:
+    //   gf_ptr[g] .. gf_ptr[g+1]   : its top nodes gf_node[.] (final numbering, ascending = topological)
+    //   gf_bptr[g] .. gf_bptr[g+1] : its bundles (contiguous ids); bundles beyond gf_bptr[ng] belong to no group
+    //   gf_tt[g*64 + i*8 + j]      : CSC slot of L(top_i, top_j), i > j, -1 if structurally zero
+    //   gf_sp / gf_scol / gf_sslot : per top row (index gf_ptr[g] + i) the entries of K with both ends in the
+    //                                group's top: column (index inside the group), position in V
+    // Li16 / Ucol16 then encode a top row as nloc + its index inside the bundle's group.  nfold stays 0: every
+    // kernel that does not know about groups treats the top as an ordinary level-scheduled top.
+    i32 gf_ng = 0;
+    std::vector<i32> gf_ptr, gf_node, gf_bptr, gf_tt, gf_sp, gf_scol, gf_sslot;
     // bundles + (at most) a folded top only: 16-bit bundle-local row indices of the entries of the bundle
     // columns of L (Li16, parallel to Li[0 .. Lp[NF])) and of the U rows (Ucol16); an index >= the
     // bundle's node count nloc stands for top row NF + (index - nloc).  Empty otherwise.
@@ -144,8 +157,10 @@ struct Symbolic {
 };
 
 // `perm0` empty => AMD.  Returns 0 or a negative chip_status.
+// target_wg: workgroups the device keeps resident for the fused solve kernel (CUs x 4): a forest with fewer
+// bundles than that is cut finer (grouped fold, above); 0 = never refine.
 int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns_or_null,
-            const std::vector<i64> &perm0, double amd_dense_scale, Symbolic &S);
+            const std::vector<i64> &perm0, double amd_dense_scale, Symbolic &S, i32 target_wg = 1024);
 
 // ---------------------------------------------------------------------------
 // KKT assembly (kkt_assembly.cpp)  -- kkt_assembly.rs:20-183, datamaps.rs

@@ -662,6 +662,112 @@ __global__ __launch_bounds__(BWG) void k_bundle_factor(LdlView v, BundleView bv,
         if (threadIdx.x == 0 && te > tb) atomicAdd(&fold.acc[fold_acc_index(2, 0, b % FOLD_SLOTS)], s);
     }
 }
+// grouped fold: a bundle's contribution to the Schur complement of its group's top (k <= 8 rows),
+// S[i][j] = sum over the bundle's columns c of l_ic d_c l_jc -- the entries of a column in the top rows are its
+// LAST ones (16-bit local index >= nloc).  A launch of its own behind k_bundle_factor (its 44 accumulator registers
+// would halve that kernel's occupancy): per-thread register accumulators over the packed lower triangle, reduced wave
+// by wave in a fixed order; k_gfold_top_factor subtracts the shares of a group's bundles from K_tt and factors the
+// k x k block.
+constexpr int GSWG = 256;
+__global__ __launch_bounds__(GSWG) void k_gfold_schur(LdlView v, BundleView bv, GFoldView gf) {
+    __shared__ double wsum[(GSWG / 64) * 36];
+    const int b = blockIdx.x;
+    if (gf.bgrp[b] < 0) return;
+    {
+        const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
+        double sa[36];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) sa[p] = 0.0;
+        for (int j = s0 + (int)threadIdx.x; j < s1; j += GSWG) {
+            const int cb = v.Lp[j], ce = v.Lp[j + 1];
+            double vv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vv[i] = 0.0;
+            bool any = false;
+            // (the last 8 entries of the column requested at once: the top rows sort behind the bundle's own)
+            int ti8[8];
+            double va8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int q = ce - 1 - e;
+                ti8[e] = q >= cb ? (int)v.Li16[q] - nloc : -1;
+                va8[e] = q >= cb ? v.Lx[q] : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (ti8[e] >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (ti8[e] == i) vv[i] = va8[e];
+                    any = true;
+                }
+            if (any) {
+                const double dj = v.D[j];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double wi = vv[i] * dj;
+#pragma unroll
+                    for (int jj = 0; jj <= i; ++jj) sa[i * (i + 1) / 2 + jj] += wi * vv[jj];
+                }
+            }
+        }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int p = 0; p < 36; ++p) {
+            const double t = wave_sum(sa[p]);
+            if (lane == 0) wsum[wv * 36 + p] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 36) {
+            double t = 0.0;
+            for (int w = 0; w < GSWG / 64; ++w) t += wsum[w * 36 + threadIdx.x];
+            gf.fac[(size_t)b * 36 + threadIdx.x] = t;
+        }
+    }
+}
+// grouped fold: the k x k block of every group's top -- K_tt (scattered into D / the top-top slots of Lx by
+// k_scatter_init, static regulariser included) minus the Schur contributions of the group's bundles, then LDL' with
+// the pivot rule of qdldl.rs:645-665; one thread per group
+__global__ __launch_bounds__(64) void k_gfold_top_factor(LdlView v, GFoldView gf) {
+    // one wave per group: lane p < k (k + 1) / 2 owns entry p of the packed lower triangle -- its initial value and
+    // the shares of the group's bundles (summed in a fixed order: run-to-run reproducible) -- then lane 0 factors the
+    // k x k block from LDS
+    __shared__ double A[36];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int base = gf.ptr[g], k = gf.ptr[g + 1] - base, np = k * (k + 1) / 2;
+    if (lane < np) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= lane) ++i;
+        const int j = lane - i * (i + 1) / 2;
+        double a;
+        if (i == j) a = v.D[gf.node[base + i]];
+        else {
+            const int q = gf.tt[g * 64 + i * 8 + j];
+            a = q >= 0 ? v.Lx[q] : 0.0;
+        }
+        for (int b = gf.bptr[g]; b < gf.bptr[g + 1]; ++b) a -= gf.fac[(size_t)b * 36 + lane];
+        A[lane] = a;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    for (int j = 0; j < k; ++j) {
+        const int nj = gf.node[base + j];
+        const double dinv = pivot_rule(v, nj, A[j * (j + 1) / 2 + j]);
+        for (int i = j + 1; i < k; ++i) {
+            const double aij = A[i * (i + 1) / 2 + j];
+            for (int i2 = j + 1; i2 <= i; ++i2) A[i * (i + 1) / 2 + i2] -= aij * (A[i2 * (i2 + 1) / 2 + j] * dinv);
+        }
+        for (int i = j + 1; i < k; ++i) {
+            const double lij = A[i * (i + 1) / 2 + j] * dinv;
+            A[i * (i + 1) / 2 + j] = lij;
+            const int q = gf.tt[g * 64 + i * 8 + j];
+            if (q >= 0) {
+                v.Lx[q] = lij;
+                if (v.mirror_rows) v.Rx[v.Tpos[q]] = lij;
+            }
+        }
+    }
+}
 __global__ void k_fold_top_pivot(LdlView v, FoldView fold) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double d = v.D[fold.NF];
@@ -2250,6 +2356,56 @@ __device__ __forceinline__ void ir_grid_exit(int *ctl, int gen, int nwg) {
         }
     }
 }
+// the two halves of ir_arrive_wait for the grouped fold, whose verdict on a round rides on the NEXT round without a
+// grid-wide wait in between: arrival without waiting (IR_LAST for the workgroup that completes the count: it reduces
+// and releases), and the wait for the release of generation `gen` (IR_TIMEOUT / IR_WAITED)
+__device__ __forceinline__ int ir_arrive_nowait(int *ctl, int gen, int nwg) {
+    __shared__ int s_state2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        const int sub = blockIdx.x % IR_NSUB;
+        const int members = nwg / IR_NSUB + (sub < nwg % IR_NSUB ? 1 : 0);
+        int state = IR_WAITED;
+        if (atomicAdd(ctl + 32 * (1 + sub), 1) + 1 == members * gen) {
+            if (atomicAdd(ctl, 1) + 1 == min(IR_NSUB, nwg) * gen) state = IR_LAST;
+        }
+        s_state2 = state;
+    }
+    __syncthreads();
+    return s_state2;
+}
+__device__ __forceinline__ int ir_wait_word(const int *word, int gen) {
+    __shared__ int s_state3;
+    if (threadIdx.x == 0) {
+        int state = IR_WAITED;
+        long long spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1ll << 22)) {
+                state = IR_TIMEOUT;
+                break;
+            }
+        }
+        s_state3 = state;
+    }
+    __syncthreads();
+    return s_state3;
+}
+// grouped fold: non-blocking arrival at a group's counter (monotonic over the launch); true for the workgroup whose
+// arrival completes `expect` -- it alone then reduces what the group's other workgroups stored before arriving
+__device__ __forceinline__ bool ir_group_arrive(int *cnt, int expect) {
+    __shared__ int s_glast;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        s_glast = (atomicAdd(cnt, 1) + 1 == expect) ? 1 : 0;
+    }
+    __syncthreads();
+    return s_glast != 0;
+}
 // values that cross workgroups inside the launch: device-coherent atomic accesses (see above)
 __device__ __forceinline__ double ir_load(const double *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2485,25 +2641,40 @@ struct IrState {
 // TW threads per workgroup: 256 when four workgroups fit a CU (4 waves per SIMD, 128 registers: config 3's
 // 3003-node bundles), 512 for bundles whose LDS slice only lets three in (config 4's 6007-node bundles: 6
 // waves per SIMD, 80 registers -- with 256 threads only 12 of a CU's 32 wave slots would be used)
-template <int TW>
+// GR: grouped fold (GFoldView): every workgroup owns ONE bundle (nb <= gridDim.x); the top of a bundle's tree is
+// solved by the LAST of the tree's workgroups to arrive at the group's counter, right before it arrives at the grid
+// barrier -- the others find the result in the group's record after the barrier.
+template <int TW, bool GR>
 __global__ __launch_bounds__(TW) __attribute__((amdgpu_waves_per_eu(TW == 512 ? 6 : 4, TW == 512 ? 6 : 4)))
-void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
+void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView gf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *xs = (double *)smem;
     __shared__ double red[16];
     __shared__ int fat[IR_FATCAP];
     __shared__ int nfat;
     __shared__ IrState st;
-    const int nb = bv.nb, G = gridDim.x, k = fold.k, tid = threadIdx.x;
-    const int NF = k ? fold.NF : ir.N;
+    const int nb = bv.nb, G = gridDim.x, tid = threadIdx.x;
+    const int grp = GR ? gf.bgrp[blockIdx.x] : -1;
+    const int gbase = (GR && grp >= 0) ? gf.ptr[grp] : 0;
+    const int k = GR ? (grp >= 0 ? gf.ptr[grp + 1] - gbase : 0) : fold.k; // (GR: differs between workgroups)
+    const bool folded = GR || k > 0;                                       // a barrier in the middle of every round
+    const int NF = GR ? 0 : (k ? fold.NF : ir.N);
+    const int gnb = (GR && grp >= 0) ? gf.bptr[grp + 1] - gf.bptr[grp] : 0; // workgroups of this group
+    const bool gfirst = GR && grp >= 0 && (int)blockIdx.x == gf.bptr[grp];
+    int gph = 0;                                                            // group phases passed so far
+    auto topnode = [&](int i) { return GR ? gf.node[gbase + i] : NF + i; };
+    double *grec = (GR && grp >= 0) ? gf.rec + (size_t)grp * 64 : nullptr;  // [2][32]
+    FoldView lfold = fold; // what the residual body needs to know: the number of folded rows of THIS workgroup
+    lfold.k = k;
     if (ir.test_drop && (int)blockIdx.x == G - 1 && G > 1) return; // (tests: a launch that is not co-resident)
     const bool single = nb <= G; // one bundle per workgroup: its residual never leaves LDS
     // partial results: device-coherent stores before a barrier, reduced in a fixed order by its last arriver
     double *pnb = ir.part;                  // [nb]       ||b||inf of the bundles' rows
     double *pn = pnb + nb;                  // [2][nb]    ||e||inf of the bundles' rows
+    const int kp = GR ? 0 : k;              // (GR: the shares live in gf.fsh / gf.rsh, k differs between workgroups)
     double *shf = pn + 2 * nb;              // [nb*k]     forward sweep: shares of the top rows
-    double *shs = shf + (size_t)nb * k;     // [2][nb*k]  residual: shares of (K x)[top]
-    double *pub = shs + 2 * (size_t)nb * k; // [2][32]    published reductions: [0..8) forward sums, [8] ||e||,
+    double *shs = shf + (size_t)nb * kp;    // [2][nb*k]  residual: shares of (K x)[top]
+    double *pub = shs + 2 * (size_t)nb * kp; // [2][32]   published reductions: [0..8) forward sums, [8] ||e||,
                                             //            [9] ||b||, [16..24) residual sums
     auto rhs_at = [&](int j) { // permuted right-hand side entry j (directldlkktsolver.rs:160-166)
         const int o = ir.perm[j];
@@ -2531,24 +2702,48 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
     // the first grid barrier, where the workgroup waits anyway -- not ahead of the staging pass
     auto load_top_constants = [&]() {
         if (tid < 8) {
-            st.btop[tid] = tid < k ? rhs_at(NF + tid) : 0.0;
+            st.btop[tid] = tid < k ? rhs_at(topnode(tid)) : 0.0;
             // (bp must hold the WHOLE permuted right-hand side afterwards: a second solve() without a new
             // setrhs() restarts from bp, directldlkktsolver.rs:168-175 keeps self.b)
-            if (tid < k && blockIdx.x == 0) ir.bp[NF + tid] = st.btop[tid];
+            if (tid < k && (GR ? gfirst : blockIdx.x == 0)) ir.bp[topnode(tid)] = st.btop[tid];
             st.curt[tid] = 0.0;
-            st.dinvt[tid] = tid < k ? v.Dinv[NF + tid] : 0.0;
+            st.dinvt[tid] = tid < k ? v.Dinv[topnode(tid)] : 0.0;
         } else if (tid >= 64 && tid < 64 + k * k) {
-            const int q = fold.tt[tid - 64];
-            if (q >= 0) st.ltt[((tid - 64) / k) * 8 + (tid - 64) % k] = v.Lx[q];
+            const int ti = (tid - 64) / k, tj = (tid - 64) % k;
+            const int q = GR ? gf.tt[grp * 64 + ti * 8 + tj] : fold.tt[tid - 64];
+            if (q >= 0) st.ltt[ti * 8 + tj] = v.Lx[q];
         } else if (tid >= 128 && tid < 128 + k) {
             const int i = tid - 128;
-            for (int t = fold.sp[i]; t < fold.sp[i + 1]; ++t) st.ktt[i * 8 + fold.scol[t]] += v.Ux[fold.sslot[t]];
+            const int *sp = GR ? gf.sp + gbase : fold.sp, *scol = GR ? gf.scol : fold.scol, *sslot = GR ? gf.sslot : fold.sslot;
+            for (int t = sp[i]; t < sp[i + 1]; ++t) st.ktt[i * 8 + scol[t]] += v.Ux[sslot[t]];
         }
     };
-    if (k == 0) load_top_constants(); // (a forest: only btop / curt are cleared)
+    // GR: sums of the group's shares sh[q * 8 + i] over its bundles q, in a fixed order, by wave 0 (lane = (q mod 8, i));
+    // the totals land in st.tacc (the forward sweep's own shares have been stored by then)
+    auto group_sums = [&](const double *sh) {
+        if (tid < 64) {
+            const int i = tid & 7, q8 = tid >> 3;
+            double part = 0.0;
+            for (int q = gf.bptr[grp] + q8; q < gf.bptr[grp + 1]; q += 8) part += ir_load(&sh[(size_t)q * 8 + i]);
+            part += __shfl_xor(part, 8, 64);
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (tid < 8) st.tacc[tid] = part;
+        }
+        __syncthreads();
+    };
+    if (!GR && k == 0) load_top_constants(); // (a forest: only btop / curt are cleared)
     int dbgn = 0;
     auto stamp = [&]() { // diagnostics (CHIP_IR_DEBUG): phase boundaries of workgroups 0 and G/2 on the 100 MHz clock
-        if (ir.dbg && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == G / 2) && dbgn < 64)
+        if (ir.dbg_all) {
+            if (tid == 0 && dbgn < 31) {
+                if (dbgn == 0) // HW_REG_HW_ID (4) in the low word, HW_REG_XCC_ID (20) in the high word
+                    ir.dbg_all[(size_t)blockIdx.x * 32] =
+                        (long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) |
+                        ((long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32);
+                ir.dbg_all[(size_t)blockIdx.x * 32 + 1 + dbgn++] = wall_clock64();
+            }
+        } else if (ir.dbg && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == G / 2) && dbgn < 64)
             ir.dbg[(blockIdx.x ? 64 : 0) + dbgn++] = wall_clock64();
     };
     // the last arriver of a barrier: fixed-order reductions of what the workgroups stored before arriving
@@ -2565,22 +2760,28 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         for (int q = tid; q < nb; q += TW) {
             if (first) mb = nanmax(mb, ir_load(&pnb[q]));
             m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
-            if (ir.ir_enable) {
+            if (ir.ir_enable && !GR) {
                 if (k == 1) part[0] += ir_load(&shs[(size_t)par * nb + q]);
                 else
                     for (int i = 0; i < k; ++i) part[i] += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
             }
         }
+        if (GR) // the top rows of every group: reduced by the groups' last arrivers, published in their records
+            for (int q = tid; q < gf.ng; q += TW) {
+                if (first) mb = nanmax(mb, ir_load(&gf.rec[(size_t)q * 64 + par * 32 + 25]));
+                m = nanmax(m, ir_load(&gf.rec[(size_t)q * 64 + par * 32 + 24]));
+            }
         if (first) {
             mb = block_nanmax(mb, red);
             if (tid == 0) ir_store(&pub[par * 32 + 9], mb);
         }
         m = block_nanmax(m, red);
         if (tid == 0) ir_store(&pub[par * 32 + 8], m);
-        for (int i = 0; i < k; ++i) {
-            const double tot = block_sum(part[i], red);
-            if (tid == 0) ir_store(&pub[par * 32 + 16 + i], tot);
-        }
+        if (!GR)
+            for (int i = 0; i < k; ++i) {
+                const double tot = block_sum(part[i], red);
+                if (tid == 0) ir_store(&pub[par * 32 + 16 + i], tot);
+            }
     };
     // the reference's decisions about the candidate of round `round`, whose residual sums were published with
     // parity `par`: thread 0 of every workgroup alike, state in LDS
@@ -2589,10 +2790,11 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             double m = ir_load(&pub[par * 32 + 8]);
             if (round == 0) {
                 double nbm = ir_load(&pub[par * 32 + 9]);
-                for (int i = 0; i < k; ++i) nbm = nanmax(nbm, fabs(st.btop[i]));
+                if (!GR)
+                    for (int i = 0; i < k; ++i) nbm = nanmax(nbm, fabs(st.btop[i]));
                 st.normb = nbm;
             }
-            for (int i = 0; i < k; ++i) {
+            for (int i = 0; i < (GR ? 0 : k); ++i) { // (GR: the groups' last arrivers did this, see the residual phase)
                 double sacc = ir_load(&pub[par * 32 + 16 + i]);
                 for (int c = 0; c < k; ++c) sacc += st.ktt[i * 8 + c] * st.candt[c];
                 // (no refinement: the top entries of x take part in the finiteness test instead)
@@ -2698,10 +2900,75 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             bundle_sweep_cols<true, IR_SH_FWD, IR_RPT, TW>(v, bv, b, xs, nullptr, st.tacc, k, fat, nfat);
             stamp();
             // this bundle's shares of the top rows of L (accumulated by the pushes)
-            if (tid < k) ir_store(&shf[(size_t)b * k + tid], st.tacc[tid]);
-            if (k) {
+            if (!GR && tid < k) ir_store(&shf[(size_t)b * k + tid], st.tacc[tid]);
+            if (GR && tid < 8) ir_store(&gf.fsh[(size_t)b * 8 + tid], tid < k ? st.tacc[tid] : 0.0);
+            if (folded) {
                 stamp();
                 if (round == 0) load_top_constants();
+                if (GR && grp >= 0) {
+                    // the last of the group's workgroups to arrive sums the shares and solves the group's k x k top
+                    // part of both sweeps; the record is complete before this workgroup arrives at the grid barrier
+                    ++gph;
+                    if (ir_group_arrive(gf.gcnt + grp * 32, gnb * gph)) {
+                        group_sums(gf.fsh);
+                        if (tid == 0) {
+                            double y[8], nt = 0.0, nbt = 0.0;
+                            for (int i = 0; i < k; ++i) {
+                                const double rhs_i = round == 0 ? st.btop[i] : ir_load(&grec[(par ^ 1) * 32 + 16 + i]);
+                                double sacc = rhs_i - st.tacc[i];
+                                for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * y[j];
+                                y[i] = sacc;
+                            }
+                            for (int i = k - 1; i >= 0; --i) {
+                                double sacc = y[i] * st.dinvt[i];
+                                for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * y[j];
+                                y[i] = sacc;
+                            }
+                            // (the candidate x_top + dx_top is formed AFTER the barrier: whether the previous
+                            // candidate was accepted is decided there)
+                            for (int i = 0; i < k; ++i) {
+                                ir_store(&grec[par * 32 + i], y[i]);
+                                nt = nanmax(nt, fabs(y[i]));
+                                nbt = nanmax(nbt, fabs(st.btop[i]));
+                            }
+                            if (!ir.ir_enable) { // no refinement: the top entries take part in x.is_finite() (:180)
+                                ir_store(&grec[par * 32 + 24], nt);
+                                ir_store(&grec[par * 32 + 25], nbt);
+                            }
+                            // the record is complete: release the group's other workgroups
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __builtin_amdgcn_s_waitcnt(0);
+                            __hip_atomic_store(gf.gcnt + grp * 32 + 1, gph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __syncthreads();
+                    } else if (ir_wait_word(gf.gcnt + grp * 32 + 1, gph) == IR_TIMEOUT) {
+                        if (tid == 0) ir.res[2] = 1;
+                        return;
+                    }
+                }
+                if (GR) {
+                    // no grid-wide wait between the sweeps: only the group's.  The verdict on the previous round's
+                    // candidate -- every workgroup arrived for it at the end of that round -- is awaited here, with
+                    // a forward sweep and the group's top solve between arrival and wait
+                    stamp();
+                    if (pending) {
+                        if (ir_wait_word(ir.ctl + 32 * (1 + IR_NSUB + (int)(blockIdx.x % IR_NSUB)), st.gen) == IR_TIMEOUT) {
+                            if (tid == 0) ir.res[2] = 1;
+                            return;
+                        }
+                        decide(round - 1, par ^ 1);
+                        pending = false;
+                        if (__builtin_amdgcn_readfirstlane(st.done)) {
+                            stop = true; // (this round's forward sweep was speculative)
+                            break;
+                        }
+                    }
+                    if (tid < 8 && grp >= 0) {
+                        const double y = tid < k ? ir_load(&grec[par * 32 + tid]) : 0.0;
+                        st.dxt[tid] = y;
+                        st.candt[tid] = round == 0 ? y : 1.0 * st.curt[tid] + 1.0 * y;
+                    }
+                } else {
                 if (tid == 0) st.gen += 1;
                 const int state = ir_arrive_wait(ir.ctl, st.gen, G);
                 if (state == IR_TIMEOUT) {
@@ -2710,7 +2977,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 }
                 stamp();
                 if (state == IR_LAST) {
-                    reduce_forward(par);
+                    if (!GR) reduce_forward(par);
                     if (pending) reduce_residual(par ^ 1, round == 1);
                     ir_release(ir.ctl, st.gen, G);
                 }
@@ -2723,8 +2990,8 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                         break;
                     }
                 }
-                // the k x k top part of both sweeps, by every workgroup alike (k <= 8)
                 if (tid == 0) {
+                    // the k x k top part of both sweeps, by every workgroup alike (k <= 8)
                     double y[8];
                     for (int i = 0; i < k; ++i) {
                         double sacc = (round == 0 ? st.btop[i] : st.rtop[i]) - ir_load(&pub[par * 32 + i]);
@@ -2741,6 +3008,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                         st.candt[i] = round == 0 ? y[i] : 1.0 * st.curt[i] + 1.0 * y[i];
                     }
                 }
+                } // (!GR)
             }
             __syncthreads();
             stamp();
@@ -2779,8 +3047,28 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 __syncthreads(); // the candidate's slice is visible workgroup-wide
                 stamp();
                 bundle_symv_body<true, IR_SH_SYMV, TW, 2>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
-                                       xs, red, fold, b, st.candt, &pn[(size_t)par * nb + b],
-                                       &shs[(size_t)par * nb * k + (size_t)b * k]);
+                                       xs, red, lfold, b, st.candt, &pn[(size_t)par * nb + b],
+                                       GR ? &gf.rsh[((size_t)par * nb + b) * 8] : &shs[(size_t)par * nb * k + (size_t)b * k]);
+                if (GR && grp >= 0) {
+                    // the top rows of the candidate's residual (and their norm): by the group's last arriver
+                    ++gph;
+                    if (ir_group_arrive(gf.gcnt + grp * 32, gnb * gph)) {
+                        group_sums(gf.rsh + (size_t)par * nb * 8);
+                        if (tid == 0) {
+                            double m = 0.0, mb = 0.0;
+                            for (int i = 0; i < k; ++i) {
+                                double sacc = st.tacc[i];
+                                for (int c = 0; c < k; ++c) sacc += st.ktt[i * 8 + c] * st.candt[c];
+                                const double rt = st.btop[i] - sacc;
+                                ir_store(&grec[par * 32 + 16 + i], rt);
+                                m = nanmax(m, fabs(rt));
+                                mb = nanmax(mb, fabs(st.btop[i]));
+                            }
+                            ir_store(&grec[par * 32 + 24], m);
+                            ir_store(&grec[par * 32 + 25], mb);
+                        }
+                    }
+                }
             }
         }
         if (stop) break;
@@ -2789,7 +3077,16 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         // several bundles per workgroup) ... the verdict then rides on that round's barrier; otherwise the
         // round ends with a barrier of its own.
         const bool more_possible = ir.ir_enable && round < ir.maxiter;
-        if (k && more_possible) continue;
+        if (GR && more_possible) {
+            // arrival for the verdict on this round's candidate; it is awaited in the middle of the next round
+            if (tid == 0) st.gen += 1;
+            if (ir_arrive_nowait(ir.ctl, st.gen, G) == IR_LAST) {
+                reduce_residual(par, round == 0);
+                ir_release(ir.ctl, st.gen, G);
+            }
+            continue;
+        }
+        if (folded && more_possible) continue;
         stamp();
         if (tid == 0) st.gen += 1;
         const int state = ir_arrive_wait(ir.ctl, st.gen, G);
@@ -2842,10 +3139,15 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 for (int i = tid; i < nloc; i += TW) put(s0 + i, cur[s0 + i]);
             }
         }
-        if (blockIdx.x == 0 && tid < k) {
-            put(NF + tid, st.curt[tid]);
-            cur[NF + tid] = st.curt[tid];
+        if ((GR ? gfirst : blockIdx.x == 0) && tid < k) {
+            put(topnode(tid), st.curt[tid]);
+            cur[topnode(tid)] = st.curt[tid];
         }
+    }
+    // (every workgroup is past the last barrier that follows a group phase: the group's counter is free again)
+    if (GR && gfirst && tid == 0) {
+        __hip_atomic_store(gf.gcnt + grp * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gf.gcnt + grp * 32 + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (blockIdx.x == 0 && tid == 0) {
         ir.res[0] = ok ? 1 : -1; // (0 = the kernel never got here)
@@ -5035,6 +5337,11 @@ void fold_top_pivot(hipStream_t s, const LdlView &v, const FoldView &fold) {
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold) {
     if (bv.nb) k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
 }
+void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf) {
+    if (gf.ng <= 0) return;
+    k_gfold_schur<<<bv.nb, GSWG, 0, s>>>(v, bv, gf);
+    k_gfold_top_factor<<<gf.ng, 64, 0, s>>>(v, gf);
+}
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const FoldView &fold) {
     if (bv.nb) k_bundle_fwd<<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, fold);
 }
@@ -5046,20 +5353,24 @@ size_t ir_part_doubles(int nb, int k) { return (size_t)nb * (3 + 3 * (size_t)k) 
 // workgroup size of k_bundle_ir for these bundles and the largest co-resident grid (0: the kernel cannot run)
 template <int TW> static int bundle_ir_capacity_tw(const BundleView &bv) {
     const size_t lds = bundle_lds(bv);
-    if (hipFuncSetAttribute((const void *)k_bundle_ir<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)k_bundle_ir<TW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_bundle_ir<TW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bundle_ir<TW>, TW, lds) != hipSuccess ||
+    int per_cu_g = 0; // (the grouped variant may differ by a register or two: the smaller count holds for both)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bundle_ir<TW, false>, TW, lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_g, (const void *)k_bundle_ir<TW, true>, TW, lds) != hipSuccess ||
         hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
+    per_cu = std::min(per_cu, per_cu_g);
     // cross-check with the LDS budget (static + dynamic, 1 KB allocation granularity assumed) and the wave slots
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, (const void *)k_bundle_ir<TW>) != hipSuccess) {
+    if (hipFuncGetAttributes(&fa, (const void *)k_bundle_ir<TW, true>) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
@@ -5094,12 +5405,19 @@ int bundle_ir_capacity(const BundleView &bv, int *tw) {
     return bundle_ir_capacity_tw<512>(bv);
 }
 int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid,
-              int tw) {
+              int tw, const GFoldView &gf) {
     // grid <= bundle_ir_capacity(): every workgroup is resident on an otherwise idle device, and a grid
     // barrier that cannot complete times out instead of hanging
-    if (tw == 256) k_bundle_ir<256><<<grid, 256, bundle_lds(bv), s>>>(v, bv, fold, ir);
-    else if (tw == 1024) k_bundle_ir<1024><<<grid, 1024, bundle_lds(bv), s>>>(v, bv, fold, ir);
-    else k_bundle_ir<512><<<grid, 512, bundle_lds(bv), s>>>(v, bv, fold, ir);
+    const size_t lds = bundle_lds(bv);
+    if (gf.ng > 0) {
+        if (tw == 256) k_bundle_ir<256, true><<<grid, 256, lds, s>>>(v, bv, fold, ir, gf);
+        else if (tw == 1024) k_bundle_ir<1024, true><<<grid, 1024, lds, s>>>(v, bv, fold, ir, gf);
+        else k_bundle_ir<512, true><<<grid, 512, lds, s>>>(v, bv, fold, ir, gf);
+    } else {
+        if (tw == 256) k_bundle_ir<256, false><<<grid, 256, lds, s>>>(v, bv, fold, ir, gf);
+        else if (tw == 1024) k_bundle_ir<1024, false><<<grid, 1024, lds, s>>>(v, bv, fold, ir, gf);
+        else k_bundle_ir<512, false><<<grid, 512, lds, s>>>(v, bv, fold, ir, gf);
+    }
     return (int)hipGetLastError();
 }
 void fold_top_solve(hipStream_t s, const LdlView &v, const FoldView &fold, double *x) {

@@ -50,6 +50,24 @@ struct FoldView {
     // serialise at ~13 ns each right at the tail of the launch
     double *acc;
 };
+// GROUPED fold (host.hpp: Symbolic::gf_*): a forest of small trees, each with a top of at most 8 nodes that is
+// folded into the bundle kernels of ITS tree.  ng == 0: unused.  Only k_bundle_ir, k_bundle_factor and
+// k_gfold_top_factor know about groups; every other kernel sees an ordinary level-scheduled top.
+struct GFoldView {
+    int ng;
+    const int *ptr, *node;        // group g: top nodes node[ptr[g] .. ptr[g+1]) (ascending = topological)
+    const int *bptr;              // its bundles [bptr[g], bptr[g+1]); bundles >= bptr[ng] have no top
+    const int *bgrp;              // group of every bundle, -1 = none
+    const int *tt;                // [g*64 + i*8 + j]: CSC slot of L(top_i, top_j), i > j, -1 = structurally zero
+    const int *sp, *scol, *sslot; // K entries among a group's top rows (row index ptr[g] + i): column inside the group, position in V
+    double *fsh;                  // [nb*8]    forward sweep: the bundles' shares of the top rows
+    double *rsh;                  // [2][nb*8] residual: the bundles' shares of (K x)[top]
+    double *rec;                  // [ng][2][32] published by a group's last arriver: [0,8) dx_top, [8,16) candidate x_top,
+                                  //             [16,24) residual of the top rows, [24] its max |.|, [25] max |b_top|
+    int *gcnt;                    // [ng*32] arrival counters, one 128-byte line per group, zero between launches
+    double *fac;                  // [nb*36] factorisation: a bundle's contribution to the Schur complement of its group's
+                                  //             top, packed lower triangle (i >= j at i (i + 1) / 2 + j)
+};
 constexpr int FOLD_SLOTS = 16, FOLD_STRIDE = 16;
 inline __host__ __device__ int fold_acc_index(int kind, int row, int slot) {
     return ((kind * 8 + row) * FOLD_SLOTS + slot) * FOLD_STRIDE;
@@ -128,16 +146,20 @@ struct IrView {
     double abstol, reltol, stopratio;
     int maxiter, ir_enable;
     long long *dbg;        // diagnostics: 128 time stamps of two workgroups, or nullptr
+    long long *dbg_all;    // diagnostics (CHIP_IR_DEBUG=2): 32 words per workgroup: [0] hardware id, [1..] time stamps
     int test_drop;         // tests: the last workgroup leaves at once, so every grid barrier times out
 };
-int ir_ctl_ints();
+int ir_ctl_ints();                 // (+ 32 per group of a grouped fold, appended: GFoldView::gcnt)
 size_t ir_part_doubles(int nb, int k);
 // largest co-resident grid of k_bundle_ir for these bundles (0: the kernel cannot run) and the workgroup
 // size (*tw: 256 or 512 threads) it is to be launched with
 int bundle_ir_capacity(const BundleView &bv, int *tw);
 // returns hipSuccess (0) or the launch error; grid <= bundle_ir_capacity, grid >= nb when fold.k > 0
 int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid,
-              int tw);
+              int tw, const GFoldView &gf);
+// grouped fold, after bundle_factor: every bundle's contribution to the Schur complement of its group's top
+// (k_gfold_schur -> gf.fac), then the k x k LDL' of every group's top (k_gfold_top_factor)
+void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf);
 
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);

@@ -225,7 +225,7 @@ struct ListBuilder {
 } // namespace
 
 int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std::vector<i64> &perm0,
-            double amd_dense_scale, Symbolic &S) {
+            double amd_dense_scale, Symbolic &S, i32 target_wg) {
     S = Symbolic();
     if (n < 0 || n >= (i64)1 << 31) {
         set_error("KKT dimension out of int32 range");
@@ -399,14 +399,88 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     if (const char *e = std::getenv("CHIP_BUNDLE_MAX_WORK")) max_work = std::max<i64>(1, std::atoll(e));
     std::vector<char> top((size_t)n, 0);
     i64 NF = 0, maxsub = 0;
-    for (i32 j = 0; j < n; j++) {
-        // (a long column belongs to a dense front near the root: it is left to the top -- chain
-        // supernodes -- even when its subtree is small; the top stays closed under "parent of")
-        if (no_bundles || sub_nodes[j] > BUNDLE_MAX_NODES || sub_ent[j] > BUNDLE_MAX_ENTRIES || cnt[j] > BUNDLE_MAX_COL ||
-            sub_work[j] > max_work)
-            top[j] = 1;
-        if (top[j] && parent[j] >= 0) top[parent[j]] = 1;
-        if (!top[j]) NF++;
+    auto cut_at = [&](i64 cap_nodes, std::vector<char> &tp) {
+        i64 nf = 0;
+        tp.assign((size_t)n, 0);
+        for (i32 j = 0; j < n; j++) {
+            // (a long column belongs to a dense front near the root: it is left to the top -- chain
+            // supernodes -- even when its subtree is small; the top stays closed under "parent of")
+            if (no_bundles || sub_nodes[j] > cap_nodes || sub_ent[j] > BUNDLE_MAX_ENTRIES || cnt[j] > BUNDLE_MAX_COL ||
+                sub_work[j] > max_work)
+                tp[j] = 1;
+            if (tp[j] && parent[j] >= 0) tp[parent[j]] = 1;
+            if (!tp[j]) nf++;
+        }
+        return nf;
+    };
+    NF = cut_at(BUNDLE_MAX_NODES, top);
+    // ---- a finer cut for forests that would leave most of the device idle (grouped fold, host.hpp) ----
+    // Tree root of every node; the top nodes of one tree form its GROUP.  While the cut yields fewer than 3/4 of
+    // `target_wg` bundles and every group stays within TOPFOLD_MAX nodes, the node cap is halved: a tree whose
+    // root region moves into the top falls apart into its subtrees, which are packed into several bundles per
+    // tree below.  (An arrow -- ONE tree with a dense top, config 3 -- stops at once: its top would grow past 8.)
+    std::vector<i32> root_of((size_t)n, 0);
+    for (i32 j = (i32)n - 1; j >= 0; j--) root_of[j] = parent[j] < 0 ? j : root_of[parent[j]];
+    bool grouped = false; // >= 2 trees with a non-empty top of <= TOPFOLD_MAX nodes each, no other top nodes
+    {
+        std::vector<i32> gcount((size_t)n, 0);
+        auto groups_of = [&](const std::vector<char> &tp, i32 &ng, i32 &gmax) {
+            ng = 0;
+            gmax = 0;
+            for (i32 j = 0; j < n; j++) gcount[j] = 0;
+            for (i32 j = 0; j < n; j++)
+                if (tp[j]) {
+                    if (gcount[root_of[j]]++ == 0) ng++;
+                    gmax = std::max(gmax, gcount[root_of[j]]);
+                }
+        };
+        // bundles the packing below will make of a cut: per group about target * (its share of the forest
+        // nodes), at least one per group / per ungrouped tree
+        auto estimate_bundles = [&](const std::vector<char> &tp, i64 nf) {
+            i64 nbe = 0;
+            std::vector<i64> gn((size_t)n, 0), gsubs((size_t)n, 0), gmaxs((size_t)n, 0);
+            for (i32 j = 0; j < n; j++)
+                if (!tp[j]) {
+                    gn[root_of[j]]++;
+                    if (parent[j] < 0 || tp[parent[j]]) { // root of a complete subtree: indivisible
+                        gsubs[root_of[j]]++;
+                        gmaxs[root_of[j]] = std::max(gmaxs[root_of[j]], sub_nodes[j]);
+                    }
+                }
+            for (i32 r = 0; r < n; r++)
+                if (gn[r] > 0) {
+                    const i64 want = (i64)target_wg * gn[r] / std::max<i64>(nf, 1);
+                    const i64 fit = gn[r] / std::max<i64>(gmaxs[r], 256);
+                    nbe += std::max<i64>(1, std::min<i64>(std::min<i64>(want, gsubs[r]), std::max<i64>(fit, 1)));
+                }
+            return nbe;
+        };
+        i32 ng = 0, gmax = 0;
+        groups_of(top, ng, gmax);
+        const bool refine_ok = target_wg > 0 && !no_bundles && perm0.empty() && std::getenv("CHIP_NO_GROUPFOLD") == nullptr;
+        // (measured on an MI355X, config 4's shares: 128 trees -> 8 bundles per tree 0.48 ms against 0.53 ms per step
+        // as whole trees; 256 trees -> 4 per tree 0.66 against 0.61; 512 -> 2 per tree 1.25 against 0.98: the finer cut
+        // pays once a tree can be cut into about eight bundles -- CHIP_GROUPFOLD_MIN overrides the factor)
+        i64 min_factor = 8;
+        if (const char *e = std::getenv("CHIP_GROUPFOLD_MIN")) min_factor = std::max<i64>(1, std::atoll(e));
+        if (refine_ok && gmax <= TOPFOLD_MAX && estimate_bundles(top, NF) * min_factor <= (i64)target_wg) {
+            i64 cap_nodes = BUNDLE_MAX_NODES;
+            std::vector<char> cand;
+            while (estimate_bundles(top, NF) * 4 < (i64)target_wg * 3 && cap_nodes >= 256) {
+                cap_nodes /= 2;
+                const i64 nf2 = cut_at(cap_nodes, cand);
+                i32 ng2 = 0, gmax2 = 0;
+                groups_of(cand, ng2, gmax2);
+                if (gmax2 > TOPFOLD_MAX || nf2 == 0) break;
+                if (nf2 != NF) {
+                    top.swap(cand);
+                    NF = nf2;
+                    ng = ng2;
+                    gmax = gmax2;
+                }
+            }
+        }
+        grouped = ng >= 2 && gmax <= TOPFOLD_MAX && refine_ok;
     }
     // subtree id of every forest node (roots = forest nodes whose parent is top or absent)
     std::vector<i32> sub((size_t)n, -1);
@@ -444,7 +518,59 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     const i64 wcap = std::max<i64>(std::max<i64>(forest_work / BUNDLE_TARGET_COUNT, maxsub_work), 4096);
     std::vector<i32> bundle_of_sub((size_t)nsub, 0);
     i32 nb = 0;
-    {
+    // grouped fold: group id of every tree with a non-empty top (by first top node), -1 otherwise
+    std::vector<i32> grp_of_root;
+    i32 ngroups = 0;
+    std::vector<i32> grp_first_bundle; // gf_bptr
+    if (grouped) {
+        grp_of_root.assign((size_t)n, -1);
+        for (i32 j = 0; j < n; j++)
+            if (top[j] && grp_of_root[root_of[j]] < 0) grp_of_root[root_of[j]] = ngroups++;
+        // subtrees by group (stable in `sorder`), the ungrouped ones last; per group its own node cap:
+        // about target_wg * (share of the forest nodes) bundles, never below 256 nodes
+        std::vector<i64> gnodes((size_t)ngroups, 0), gmaxsub((size_t)ngroups, 0), gwork((size_t)ngroups, 0);
+        auto grp_of_sub = [&](i32 s) { return grp_of_root[root_of[first[s]]]; };
+        for (i32 s = 0; s < nsub; s++) {
+            const i32 g = grp_of_sub(s);
+            if (g >= 0) {
+                gnodes[g] += sub_size[s];
+                gwork[g] += sub_w[s];
+                gmaxsub[g] = std::max<i64>(gmaxsub[g], sub_size[s]);
+            }
+        }
+        std::vector<std::vector<i32>> by_group((size_t)ngroups + 1);
+        for (i32 s : sorder) {
+            const i32 g = grp_of_sub(s);
+            by_group[g >= 0 ? g : ngroups].push_back(s);
+        }
+        grp_first_bundle.assign((size_t)ngroups + 1, 0);
+        for (i32 g = 0; g <= ngroups; g++) {
+            if (g < ngroups) grp_first_bundle[g] = nb;
+            i64 gcap = cap, gwcap = wcap;
+            if (g < ngroups) {
+                const i64 want = std::max<i64>(1, (i64)target_wg * gnodes[g] / std::max<i64>(NF, 1));
+                // (+ the largest subtree: the greedy packing then fills every bundle beyond nodes / want, so
+                // that at most `want` bundles come out)
+                gcap = std::max<i64>((gnodes[g] + want - 1) / want + gmaxsub[g], 256);
+                gcap = std::min<i64>(gcap, BUNDLE_MAX_NODES);
+                gwcap = std::max<i64>(wcap, 2 * ((gwork[g] + want - 1) / want));
+            }
+            i64 cur = 0, curw = 0;
+            for (i32 s : by_group[g]) {
+                if (cur > 0 && (cur + sub_size[s] > gcap || curw + sub_w[s] > gwcap)) {
+                    nb++;
+                    cur = 0;
+                    curw = 0;
+                }
+                bundle_of_sub[s] = nb;
+                cur += sub_size[s];
+                curw += sub_w[s];
+            }
+            if (cur > 0) nb++;
+            if (g + 1 == ngroups) grp_first_bundle[ngroups] = nb;
+        }
+        if (ngroups == 0) grp_first_bundle[0] = 0;
+    } else {
         i64 cur = 0, curw = 0;
         for (i32 s : sorder) {
             if (cur > 0 && (cur + sub_size[s] > cap || curw + sub_w[s] > wcap)) {
@@ -924,13 +1050,89 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             }
         }
     }
+    // ---- grouped fold (host.hpp): per tree with a non-empty top ------------------------------
+    std::vector<i32> gpos; // index of a top node inside its group (by node - NF), grouped fold only
+    if (grouped && S.nfold == 0 && ngroups >= 2 && std::getenv("CHIP_NO_TOPFOLD") == nullptr) {
+        const i32 nbun = (i32)S.bundle_ptr.size() - 1;
+        bool ok = nbun > 0;
+        for (i32 g = 0; g < ngroups && ok; g++) ok = grp_first_bundle[g + 1] > grp_first_bundle[g];
+        // group of every top node through its tree root (root_of / grp_of_root are in pass A's numbering:
+        // order[t] = pass-A node of final node t)
+        std::vector<i32> gof((size_t)(n - S.NF), -1);
+        if (ok) {
+            S.gf_ptr.assign((size_t)ngroups + 1, 0);
+            for (i32 t = S.NF; t < n; t++) {
+                const i32 g = grp_of_root[root_of[order[t]]];
+                if (g < 0) {
+                    ok = false;
+                    break;
+                }
+                gof[t - S.NF] = g;
+                S.gf_ptr[g + 1]++;
+            }
+        }
+        if (ok) {
+            for (i32 g = 0; g < ngroups; g++) S.gf_ptr[g + 1] += S.gf_ptr[g];
+            S.gf_node.assign((size_t)(n - S.NF), 0);
+            gpos.assign((size_t)(n - S.NF), 0);
+            std::vector<i32> nx(S.gf_ptr.begin(), S.gf_ptr.end() - 1);
+            for (i32 t = S.NF; t < n; t++) {
+                const i32 g = gof[t - S.NF];
+                gpos[t - S.NF] = nx[g] - S.gf_ptr[g];
+                S.gf_node[nx[g]++] = t;
+            }
+            // every bundle column / U row may only reach the top nodes of its OWN group
+            for (i32 g = 0; g < ngroups && ok; g++)
+                for (i32 b = grp_first_bundle[g]; b < grp_first_bundle[g + 1] && ok; b++)
+                    for (i32 j = S.bundle_ptr[b]; j < S.bundle_ptr[b + 1] && ok; j++)
+                        for (i32 q = S.Lp[j]; q < S.Lp[j + 1]; q++)
+                            if (S.Li[q] >= S.NF && gof[S.Li[q] - S.NF] != g) {
+                                ok = false;
+                                break;
+                            }
+            for (i32 b = grp_first_bundle[ngroups]; b < nbun && ok; b++)
+                for (i32 j = S.bundle_ptr[b]; j < S.bundle_ptr[b + 1] && ok; j++)
+                    if (S.Lp[j + 1] > S.Lp[j] && S.Li[S.Lp[j + 1] - 1] >= S.NF) ok = false;
+        }
+        if (ok) {
+            S.gf_ng = ngroups;
+            S.gf_bptr = grp_first_bundle;
+            S.gf_tt.assign((size_t)ngroups * 64, -1);
+            S.gf_sp.assign((size_t)(n - S.NF) + 1, 0);
+            for (i32 g = 0; g < ngroups; g++) {
+                const i32 k = S.gf_ptr[g + 1] - S.gf_ptr[g];
+                for (i32 j = 0; j < k; j++) {
+                    const i32 cj = S.gf_node[S.gf_ptr[g] + j];
+                    for (i32 q = S.Lp[cj]; q < S.Lp[cj + 1]; q++) S.gf_tt[(size_t)g * 64 + (size_t)gpos[S.Li[q] - S.NF] * 8 + j] = q;
+                }
+                for (i32 i = 0; i < k; i++) {
+                    const i32 r = S.gf_node[S.gf_ptr[g] + i];
+                    for (i32 t = S.Sp[r]; t < S.Sp[r + 1]; t++)
+                        if (S.Scol[t] >= S.NF) {
+                            S.gf_scol.push_back(gpos[S.Scol[t] - S.NF]);
+                            S.gf_sslot.push_back(S.Smap[t]); // position in V
+                        }
+                    S.gf_sp[(size_t)S.gf_ptr[g] + i + 1] = (i32)S.gf_scol.size();
+                }
+            }
+        } else {
+            S.gf_ptr.clear();
+            S.gf_node.clear();
+            gpos.clear();
+        }
+    }
+    if (clk.on)
+        std::fprintf(stderr, "[chip analyse] bundles %d (max %d nodes), top %d nodes, fold k = %d, grouped fold: %d groups\n",
+                     (int)S.bundle_ptr.size() - 1, (int)S.max_bundle_nodes, (int)(n - S.NF), (int)S.nfold, (int)S.gf_ng);
     // ---- 16-bit bundle-local indices for the fused solve kernel (k_bundle_ir) ----------------
     // Systems that are bundles plus at most a folded top: row index i of an entry of a bundle column /
     // U row becomes i - s0 (its bundle starts at s0) when i lies in the bundle, nloc + (i - NF) for the
     // (at most TOPFOLD_MAX) top rows -- 2 bytes per entry instead of 4 in all three sweeps.
     {
         const i32 nbun = S.bundle_ptr.empty() ? 0 : (i32)S.bundle_ptr.size() - 1;
-        const bool eligible = nbun > 0 && (S.nfold > 0 || S.NF == n) && S.max_bundle_nodes + TOPFOLD_MAX < 65535;
+        const bool eligible = nbun > 0 && (S.nfold > 0 || S.gf_ng > 0 || S.NF == n) && S.max_bundle_nodes + TOPFOLD_MAX < 65535;
+        // (grouped fold: a top row is addressed by its index inside the bundle's group)
+        auto top_index = [&](i32 i) { return S.gf_ng > 0 ? gpos[i - S.NF] : i - S.NF; };
         if (eligible) {
             const i64 nLb = S.Lp[S.NF];
             S.Li16.resize((size_t)nLb + 1);
@@ -940,11 +1142,11 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 for (i32 j = s0; j < s1; j++) {
                     for (i32 q = S.Lp[j]; q < S.Lp[j + 1]; q++) {
                         const i32 i = S.Li[q];
-                        S.Li16[q] = (uint16_t)(i < s1 ? i - s0 : nloc + (i - S.NF));
+                        S.Li16[q] = (uint16_t)(i < s1 ? i - s0 : nloc + top_index(i));
                     }
                     for (i32 u = S.Up[j]; u < S.Up[j + 1]; u++) {
                         const i32 i = S.Ucol[u];
-                        S.Ucol16[u] = (uint16_t)(i < s1 ? i - s0 : nloc + (i - S.NF));
+                        S.Ucol16[u] = (uint16_t)(i < s1 ? i - s0 : nloc + top_index(i));
                     }
                 }
             }

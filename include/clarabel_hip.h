@@ -342,7 +342,10 @@ int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]);
  * chip_kkt_work_model: the work those kernels do per refactor / per sweep, from the supernode geometry:
  * out[0] = flops of k_snode_update per refactor (2 per multiply-add, rows at or below the block only),
  * out[1] = entries of the dense trapezoids (streamed once per sweep), out[2] = flops of k_snode_extend,
- * out[3] = flops of k_snode_diag + k_snode_rows, out[4] = number of supernodes. */
+ * out[3] = flops of k_snode_diag + k_snode_rows, out[4] = number of supernodes; and of the bundle part:
+ * out[5] = groups of a grouped fold in use (a forest cut into several bundles per tree, each tree's top of at most 8
+ * nodes folded into its bundles' kernels; 0 = none), out[6] = subtree bundles, out[7] = threads per workgroup of the
+ * fused solve launch (0 = the handle's solve is not the fused launch). */
 int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]);
 /* number of fused solve launches (k_bundle_ir) of this handle whose grid barrier timed out -- their workgroups were not
  * all resident because another long-running kernel held the slots -- and that were repeated on the

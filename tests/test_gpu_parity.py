@@ -889,6 +889,40 @@ def test_full_scale_parity_c4(hip, oracle):
     assert ks.N == 1024 * 6007 and ks.N == ks.NF
 
 
+def test_full_scale_parity_c4_share_grouped_fold(hip, oracle):
+    """one GPU's share of BASELINE config 4 at N = 8 (128 of the 1024 trees): the forest is cut into several bundles
+    per tree and every tree's top (its last few columns) is folded into the kernels of ITS bundles -- grouped fold:
+    k_gfold_schur / k_gfold_top_factor in the factorisation, the group phases of k_bundle_ir<.., true> in the solve"""
+    ks, ko = _full_scale_parity(hip, oracle, problems.batched_socp(128, 2000, 2, seed=100), nrhs=2)
+    wm = ks.work_model()
+    assert wm["fold_groups"] == 128 and wm["n_bundles"] > 512 and wm["fused_threads"] == 256
+    assert ks.linear_solver_info().regularize_count == ko.ldl_regularize_count()
+    # the one-kernel-per-phase path on the same handle (the fallback of the fused launch) sees an ordinary top
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(ks.N)
+    okf, xf = ks.solve_full(b)
+    okr, xr = ko.solve_full(b)
+    assert okf and okr and relerr(xf, xr) <= TOL
+
+
+@pytest.mark.parametrize("late", [False, True])
+def test_grouped_fold_ragged_forest(hip, oracle, late, monkeypatch):
+    """grouped fold on a forest of UNEQUAL trees (tops of different sizes, one tree small enough to stay whole),
+    benign and late-iterate scalings, with and without refinement"""
+    parts = [problems.portfolio_socp(2 + (i % 3), 120 + 40 * (i % 4), seed=100 + i, late=late) for i in range(14)]
+    parts.append(problems.portfolio_socp(1, 20, seed=300, late=late))
+    pr = problems.blockdiag(parts)
+    ks, ko = _check_update_and_solve(hip, oracle, pr, nrhs=3)
+    assert ks.work_model()["fold_groups"] >= 10
+    st = hip.Settings.default(iterative_refinement_enable=0)
+    _check_update_and_solve(hip, oracle, pr, nrhs=1, settings=st)
+    st = hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0, iterative_refinement_abstol=0.0)
+    _check_update_and_solve(hip, oracle, pr, nrhs=2, settings=st)
+    monkeypatch.setenv("CHIP_NO_GROUPFOLD", "1")
+    ks2, _ = _check_update_and_solve(hip, oracle, pr, nrhs=1)
+    assert ks2.work_model()["fold_groups"] == 0
+
+
 def test_parity_c5_24_cliques(hip, oracle):
     """BASELINE config 5's shape with 24 cliques of PSD(50) + 24 sparse SOC(51) -- the largest instance the
     scalar oracle factors in well under a minute (the full 200-clique instance takes it ~10 minutes);

@@ -313,7 +313,28 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     const bool grouped = S.gf_ng > 0;
     if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || grouped || NF == N) && !S.Li16.empty() &&
         std::getenv("CHIP_NO_FUSED_IR") == nullptr) {
-        const int cap = dev::bundle_ir_capacity(bundles, &ir_tw);
+        int cap = dev::bundle_ir_capacity(bundles, &ir_tw);
+        if (cap > 0 && std::getenv("CHIP_NO_SYMV_SPLIT") == nullptr) {
+            // the residual's "split" form (kernels.hip: bundle_symv_split) needs nloc + max(0, nloc - 2 nleaf) doubles
+            // of LDS per bundle: taken when the larger slice leaves the co-resident grid and the workgroup size as
+            // they are
+            int need = 0;
+            for (int b = 0; b < bundles.nb; b++) {
+                const int s0 = S.bundle_ptr[b], nloc = S.bundle_ptr[b + 1] - s0, nleaf = S.blvl[S.blvl_ptr[b] + 1] - s0;
+                need = std::max(need, nloc + std::max(0, nloc - 2 * nleaf));
+            }
+            dev::BundleView trial = bundles;
+            trial.ir_lds_doubles = need;
+            trial.symv_split = 1;
+            int tw2 = 0;
+            const int cap2 = dev::bundle_ir_capacity(trial, &tw2);
+            if (tw2 == ir_tw && cap2 >= std::min(cap, bundles.nb)) {
+                bundles = trial;
+                cap = cap2;
+            } else {
+                cap = dev::bundle_ir_capacity(bundles, &ir_tw); // (restores the kernels' LDS attribute)
+            }
+        }
         if (cap > 0 && ((fold.k == 0 && !grouped) || bundles.nb <= cap)) {
             ir_fused = true;
             if ((rc = upload(&Li16, S.Li16, S.Li16.size()))) return rc;

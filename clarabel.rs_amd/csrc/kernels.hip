@@ -2200,6 +2200,130 @@ __device__ __forceinline__ void bundle_symv_body(const BundleView &bv, const int
             atomicAdd(&fold.acc[fold_acc_index(1, threadIdx.x, bid % FOLD_SLOTS)], tacc[threadIdx.x]);
     }
 }
+// The residual of k_bundle_ir without a single gather from global memory ("split" form; one bundle per workgroup).
+// A row's entries point at ANCESTORS, which are never leaves (level 0 of the bundle), and a leaf's own x is read by
+// its own row only.  So during the residual the LDS slice holds, instead of one full vector:
+//   e of the non-leaf nodes at their natural places xs[nleaf .. nloc) (they take the scatter-adds),
+//   x of the non-leaf nodes in the space that is left: non-leaf t at xs[t] (t < nleaf) or xs[nloc + t - nleaf],
+// nloc + max(0, nloc - 2 nleaf) doubles in all; the leaves' e goes straight to the spill vector (coalesced) and comes
+// back into xs[0 .. nleaf) once the gathers are done.  The old form gathered x from the L2 (a 24 KB window per
+// workgroup, written just before): two dependent round trips per sweep of rows, 38 of the launch's 235 us on config 3.
+template <int SSHOT, int TW, int NR>
+__device__ __forceinline__ void bundle_symv_split(const BundleView &bv, const int *__restrict__ Up,
+                                                  const unsigned short *__restrict__ Ucol16,
+                                                  const double *__restrict__ Ux, const double *x,
+                                                  const double *__restrict__ b, double *spill, double *xs, double *red,
+                                                  int k, int bid, const double *xt, double *out_norm, double *out_share) {
+    const int s0 = bv.bundle_ptr[bid], nloc = bv.bundle_ptr[bid + 1] - s0;
+    const int nleaf = bv.blvl[bv.blvl_ptr[bid] + 1] - s0, nin = nloc - nleaf;
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x - lane;
+    int tb[NR], te[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int i = threadIdx.x + u * TW;
+        tb[u] = i < nloc ? Up[s0 + i] : 0;
+        te[u] = i < nloc ? Up[s0 + i + 1] : 0;
+    }
+    auto xpos = [&](int t) { return t < nleaf ? t : nloc + (t - nleaf); }; // x of non-leaf t
+    for (int t = threadIdx.x; t < nin; t += TW) {
+        const double xv = x[s0 + nleaf + t], bv_ = b[s0 + nleaf + t];
+        xs[xpos(t)] = xv;
+        xs[nleaf + t] = bv_;
+    }
+    double tpart = 0.0;
+    __shared__ double tacc2[8];
+    if (k > 1 && threadIdx.x < 8) tacc2[threadIdx.x] = 0.0;
+    double mleaf = 0.0;
+    bool nan = false;
+    __syncthreads();
+    for (int w0 = wbase; w0 < nloc; w0 += NR * TW) {
+        const int i0 = w0 + lane;
+        double acc[NR], xi[NR], bi[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) acc[u] = 0.0;
+        int maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int i = i0 + u * TW;
+            xi[u] = i < nloc ? x[s0 + i] : 0.0;
+            bi[u] = i < nleaf ? b[s0 + i] : 0.0;
+            maxlen = max(maxlen, te[u] - tb[u]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+        for (int kk = 0; kk < maxlen; kk += SSHOT) {
+            int jj[NR][SSHOT];
+            double vv[NR][SSHOT];
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+#pragma unroll
+                for (int q = 0; q < SSHOT; ++q) {
+                    const unsigned t = (unsigned)(tb[u] + kk + q);
+                    const bool ok = (int)t < te[u];
+                    jj[u][q] = ok ? (int)Ucol16[t] : -1;
+                    vv[u][q] = ok ? Ux[t] : 0.0;
+                }
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+#pragma unroll
+                for (int q = 0; q < SSHOT; ++q) {
+                    const int j = jj[u][q], i = i0 + u * TW;
+                    int tgt = -1;
+                    if (j >= 0) {
+                        if (j >= nloc) {
+                            acc[u] += vv[u][q] * xt[j - nloc];
+                            if (k == 1) tpart += vv[u][q] * xi[u];
+                            else atomicAdd(&tacc2[j - nloc], vv[u][q] * xi[u]);
+                        } else if (j == i) {
+                            acc[u] += vv[u][q] * xi[u];
+                        } else {
+                            acc[u] += vv[u][q] * xs[xpos(j - nleaf)];
+                            tgt = j;
+                        }
+                    }
+                    lds_scatter_add(xs, tgt, -(vv[u][q] * xi[u]));
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int i = i0 + u * TW;
+            if (i < nleaf) {
+                const double val = bi[u] - acc[u];
+                spill[s0 + i] = val;
+                if (val != val) nan = true;
+                else mleaf = fmax(mleaf, fabs(val));
+            } else if (i < nloc) {
+                atomicAdd(&xs[i], -acc[u]);
+            }
+            const int in = i + NR * TW; // the next sweep's row pointers
+            tb[u] = in < nloc ? Up[s0 + in] : 0;
+            te[u] = in < nloc ? Up[s0 + in + 1] : 0;
+        }
+    }
+    __syncthreads();
+    double m = mleaf;
+    for (int i = nleaf + (int)threadIdx.x; i < nloc; i += TW) {
+        const double val = xs[i];
+        if (val != val) nan = true;
+        else m = fmax(m, fabs(val));
+    }
+    // the leaves' residual back into the slice (every thread re-reads what it wrote itself)
+    for (int i = threadIdx.x; i < nleaf; i += TW) xs[i] = spill[s0 + i];
+    m = block_max(m, red);
+    const bool anynan = __syncthreads_or(nan);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(out_norm, anynan ? __longlong_as_double(0x7ff8000000000000ll) : m, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (k == 1) {
+        tpart = block_sum(tpart, red);
+        if (threadIdx.x == 0) __hip_atomic_store(out_share, tpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (k > 1) {
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < k; ++i)
+                __hip_atomic_store(out_share + i, tacc2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 __global__ __launch_bounds__(BWG) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_bundle_symv(BundleView bv, const int *__restrict__ Up, const int *__restrict__ Ucol,
                    const double *__restrict__ Ux, const double *__restrict__ x,
@@ -3046,9 +3170,13 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
                 }
                 __syncthreads(); // the candidate's slice is visible workgroup-wide
                 stamp();
-                bundle_symv_body<true, IR_SH_SYMV, TW, 2>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
-                                       xs, red, lfold, b, st.candt, &pn[(size_t)par * nb + b],
-                                       GR ? &gf.rsh[((size_t)par * nb + b) * 8] : &shs[(size_t)par * nb * k + (size_t)b * k]);
+                double *share_out = GR ? &gf.rsh[((size_t)par * nb + b) * 8] : &shs[(size_t)par * nb * k + (size_t)b * k];
+                if (single && bv.symv_split)
+                    bundle_symv_split<IR_SH_SYMV, TW, 2>(bv, v.Up, v.Ucol16, v.Ux, alt, ir.bp, ir.ebuf, xs, red, k, b, st.candt,
+                                                         &pn[(size_t)par * nb + b], share_out);
+                else
+                    bundle_symv_body<true, IR_SH_SYMV, TW, 2>(bv, v.Up, (const int *)v.Ucol16, v.Ux, alt, ir.bp, single ? nullptr : ir.ebuf, nullptr, nullptr,
+                                       xs, red, lfold, b, st.candt, &pn[(size_t)par * nb + b], share_out);
                 if (GR && grp >= 0) {
                     // the top rows of the candidate's residual (and their norm): by the group's last arriver
                     ++gph;
@@ -5351,8 +5479,11 @@ void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x
 int ir_ctl_ints() { return IR_CTL_INTS; }
 size_t ir_part_doubles(int nb, int k) { return (size_t)nb * (3 + 3 * (size_t)k) + 72; }
 // workgroup size of k_bundle_ir for these bundles and the largest co-resident grid (0: the kernel cannot run)
+static size_t bundle_ir_lds(const BundleView &bv) {
+    return ((size_t)std::max(bv.max_nodes, bv.ir_lds_doubles) * sizeof(double) + 15) & ~(size_t)15;
+}
 template <int TW> static int bundle_ir_capacity_tw(const BundleView &bv) {
-    const size_t lds = bundle_lds(bv);
+    const size_t lds = bundle_ir_lds(bv);
     if (hipFuncSetAttribute((const void *)k_bundle_ir<TW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_bundle_ir<TW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
@@ -5408,7 +5539,7 @@ int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldV
               int tw, const GFoldView &gf) {
     // grid <= bundle_ir_capacity(): every workgroup is resident on an otherwise idle device, and a grid
     // barrier that cannot complete times out instead of hanging
-    const size_t lds = bundle_lds(bv);
+    const size_t lds = bundle_ir_lds(bv);
     if (gf.ng > 0) {
         if (tw == 256) k_bundle_ir<256, true><<<grid, 256, lds, s>>>(v, bv, fold, ir, gf);
         else if (tw == 1024) k_bundle_ir<1024, true><<<grid, 1024, lds, s>>>(v, bv, fold, ir, gf);

@@ -37,6 +37,10 @@ struct BundleView {
     int nb;
     const int *bundle_ptr, *blvl_ptr, *blvl;
     int max_nodes;
+    // k_bundle_ir only: doubles of dynamic LDS per workgroup (0: max_nodes) and whether the residual runs in its
+    // "split" form (bundle_symv_split: x of the non-leaf nodes AND the residual in LDS, no gathers from global
+    // memory), which needs nloc + max(0, nloc - 2 nleaf) doubles for every bundle
+    int ir_lds_doubles, symv_split;
 };
 
 // Few dense top rows folded into the bundle kernels (host.hpp: Symbolic::nfold); k == 0: unused

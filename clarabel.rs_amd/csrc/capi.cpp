@@ -994,6 +994,8 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
         ir.dbg_all = dbg_all_dev;
     }
     ir.test_drop = h->ir_test_drop ? 1 : 0;
+    static const bool no_flat = std::getenv("CHIP_NO_FLAT") != nullptr;
+    ir.flat = no_flat ? 0 : 1;
     h->fused_args[*slot] = {h->rhs_x, h->rhs_z, lhsx_dev, lhsz_dev};
     h->rhs_deferred = false;
     h->x_holds_b = false;

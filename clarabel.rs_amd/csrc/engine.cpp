@@ -339,6 +339,8 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             ir_fused = true;
             if ((rc = upload(&Li16, S.Li16, S.Li16.size()))) return rc;
             if ((rc = upload(&Ucol16, S.Ucol16, S.Ucol16.size()))) return rc;
+            if ((rc = upload(&Lj16, S.Lj16, S.Lj16.size()))) return rc;
+            if ((rc = upload(&Urow16, S.Urow16, S.Urow16.size()))) return rc;
             ir_grid = std::min(bundles.nb, cap);
             ir_ctl_len = (size_t)dev::ir_ctl_ints() + (grouped ? (size_t)32 * S.gf_ng : 0);
             if ((rc = alloc(&ir_ctl, ir_ctl_len))) return rc;
@@ -424,6 +426,8 @@ dev::LdlView Engine::view() const {
     v.Ux = Ux;
     v.eps_ptr = nullptr;
     v.Li16 = Li16;
+    v.Lj16 = Lj16;
+    v.Urow16 = Urow16;
     v.Ucol16 = Ucol16;
     v.mirror_rows = ir_fused ? 0 : 1;
     return v;

@@ -115,6 +115,9 @@ struct Symbolic {
     // columns of L (Li16, parallel to Li[0 .. Lp[NF])) and of the U rows (Ucol16); an index >= the
     // bundle's node count nloc stands for top row NF + (index - nloc).  Empty otherwise.
     std::vector<uint16_t> Li16, Ucol16;
+    // ... and, for the entry-parallel ("flat") sweeps and residual of k_bundle_ir, the bundle-local COLUMN of every
+    // entry of the bundle columns of L (Lj16) and the bundle-local ROW of every entry of the U rows (Urow16)
+    std::vector<uint16_t> Lj16, Urow16;
     std::vector<i32> lvlptr;
     // Chain supernodes of the top (symbolic.cpp): supernode s = columns sn_col[sn_ptr[s] .. sn_ptr[s+1])
     // (ascending, each the parent of the previous one); all its columns are padded to the dense

@@ -2750,6 +2750,299 @@ __device__ __forceinline__ void bundle_sweep_cols(const LdlView &v, const Bundle
     }
 }
 
+// ---------------------------------------------------------------------------
+// Entry-parallel ("flat") sweeps of k_bundle_ir.  The columns of a bundle are numbered level-major, so the entries of
+// one level's columns are ONE contiguous range of the CSC arrays of L: the threads stride over that range -- every
+// entry knows its row (Li16) and its column (Lj16) -- with FLAT_U independent, coalesced (index, index, value) loads in
+// flight per thread and no pointer chase at all; the updates go to the LDS slice as fp64 atomics.  A level then costs one
+// round trip plus a barrier whatever its columns look like, where the column-per-thread form (bundle_sweep_cols) walked
+// pointer -> entries -> update chains a few columns at a time: measured on config 3 (1000 bundles of 3003 nodes, 256
+// threads) a sweep's time grew by 4.4 us per 250 nodes, 1.7 TB/s marginal -- latency times trips, not bandwidth.
+//   forward : x_i -= l_ij y_j     for the entries of the columns j of level l, l ascending (qdldl.rs:708-719)
+//   backward: x_j -= l_ij x_i     after x_j *= 1 / d_j for the whole slice, l descending          (qdldl.rs:737-752)
+// ---------------------------------------------------------------------------
+constexpr int FLAT_U = 4;
+constexpr int FLAT_MAXLEV = 64;  // levels of a bundle the flat sweeps keep entry pointers for (more: column per thread)
+constexpr int FLAT_MIN_NODES = 512; // smaller bundles keep the column-per-thread form (a level must fill the workgroup)
+// lev_e[0 .. nl]: first entry of every level's columns (LDS, filled once per launch by flat_level_table)
+__device__ __forceinline__ void flat_level_table(const LdlView &v, const BundleView &bv, int b, int *lev_e) {
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    if ((int)threadIdx.x <= nl && nl <= FLAT_MAXLEV) lev_e[threadIdx.x] = v.Lp[lv[threadIdx.x]];
+}
+template <bool FWDMODE, int TW>
+__device__ __forceinline__ void bundle_sweep_flat(const LdlView &v, const BundleView &bv, int b, double *xs,
+                                                  const double *xt, double *tacc, int k, const int *lev_e) {
+    const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (FWDMODE && tid < 8) tacc[tid] = 0.0;
+    if (!FWDMODE)
+        for (int i = tid; i < nloc; i += TW) xs[i] *= v.Dinv[s0 + i];
+    double tpart = 0.0;
+    // a stream of batches of TW * FLAT_U entries, level after level; the next batch's loads are issued before the
+    // current one is consumed -- across a level boundary too (the entries do not depend on x), so a level costs its
+    // barrier plus the LDS work, not a round trip
+    int step = 0, base = 0, ee = 0;
+    auto level_range = [&](int st_, int &eb_, int &ee_) {
+        const int l = FWDMODE ? st_ : nl - 1 - st_;
+        eb_ = lev_e[l];
+        ee_ = lev_e[l + 1];
+    };
+    auto skip_empty = [&]() { // -> first non-empty level at or after `step`
+        while (step < nl) {
+            level_range(step, base, ee);
+            if (base < ee) return;
+            ++step;
+        }
+    };
+    __syncthreads(); // (lev_e, the scaled slice)
+    if (TW == 512) {
+        // (80 registers per thread in the 512-thread variant: no second batch in flight)
+        for (int st_ = 0; st_ < nl; ++st_) {
+            int eb_, ee_;
+            level_range(st_, eb_, ee_);
+            for (int bs = eb_; bs < ee_; bs += TW * FLAT_U) {
+                int ii[FLAT_U], jj[FLAT_U];
+                double vv[FLAT_U];
+#pragma unroll
+                for (int u = 0; u < FLAT_U; ++u) {
+                    const int t = bs + u * TW + tid;
+                    const bool ok = t < ee_;
+                    ii[u] = ok ? (int)v.Li16[t] : -1;
+                    jj[u] = ok ? (int)v.Lj16[t] : 0;
+                    vv[u] = ok ? v.Lx[t] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < FLAT_U; ++u) {
+                    const int i = ii[u];
+                    if (i < 0) continue;
+                    if (FWDMODE) {
+                        const double val = vv[u] * xs[jj[u]];
+                        if (i < nloc) atomicAdd(&xs[i], -val);
+                        else if (k == 1) tpart += val;
+                        else atomicAdd(&tacc[i - nloc], val);
+                    } else {
+                        atomicAdd(&xs[jj[u]], -(vv[u] * (i < nloc ? xs[i] : xt[i - nloc])));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (FWDMODE && k == 1) {
+            tpart = wave_sum_all(tpart);
+            if (lane == 0 && tpart != 0.0) atomicAdd(&tacc[0], tpart);
+        }
+        __syncthreads();
+        return;
+    }
+    skip_empty();
+    int ci[FLAT_U], cj[FLAT_U], ni[FLAT_U], nj[FLAT_U];
+    double cv[FLAT_U], nv[FLAT_U];
+    auto request = [&](int bs, int en, int *ii, int *jj, double *vv) {
+#pragma unroll
+        for (int u = 0; u < FLAT_U; ++u) {
+            const int t = bs + u * TW + tid;
+            const bool ok = t < en;
+            ii[u] = ok ? (int)v.Li16[t] : -1;
+            jj[u] = ok ? (int)v.Lj16[t] : 0;
+            vv[u] = ok ? v.Lx[t] : 0.0;
+        }
+    };
+    if (step < nl) request(base, ee, ci, cj, cv);
+    while (step < nl) {
+        // the batch after this one
+        int nstep = step, nbase = base + TW * FLAT_U, nee = ee;
+        if (nbase >= nee) {
+            nstep = step + 1;
+            while (nstep < nl) {
+                level_range(nstep, nbase, nee);
+                if (nbase < nee) break;
+                ++nstep;
+            }
+        }
+        if (nstep < nl) request(nbase, nee, ni, nj, nv);
+#pragma unroll
+        for (int u = 0; u < FLAT_U; ++u) {
+            const int i = ci[u];
+            if (i < 0) continue;
+            if (FWDMODE) {
+                const double val = cv[u] * xs[cj[u]];
+                if (i < nloc) atomicAdd(&xs[i], -val);
+                else if (k == 1) tpart += val;
+                else atomicAdd(&tacc[i - nloc], val);
+            } else {
+                atomicAdd(&xs[cj[u]], -(cv[u] * (i < nloc ? xs[i] : xt[i - nloc])));
+            }
+        }
+        if (nstep != step) __syncthreads(); // the level is complete
+        step = nstep;
+        base = nbase;
+        ee = nee;
+#pragma unroll
+        for (int u = 0; u < FLAT_U; ++u) {
+            ci[u] = ni[u];
+            cj[u] = nj[u];
+            cv[u] = nv[u];
+        }
+    }
+    if (FWDMODE && k == 1) {
+        tpart = wave_sum_all(tpart);
+        if (lane == 0 && tpart != 0.0) atomicAdd(&tacc[0], tpart);
+    }
+    __syncthreads();
+}
+
+// The residual of k_bundle_ir in the split LDS layout of bundle_symv_split, entry-parallel: the rows of the non-leaf
+// nodes are walked as ONE flat range of U entries (row Urow16, column Ucol16), both directions of every entry as LDS
+// atomics; the leaf rows (their e has no place in LDS) four rows per thread at once, their result to the spill vector.
+template <int TW>
+__device__ __forceinline__ void bundle_symv_flat(const LdlView &v, const BundleView &bv, const double *x,
+                                                 const double *__restrict__ b, double *spill, double *xs, double *red,
+                                                 int k, int bid, const double *xt, double *out_norm, double *out_share) {
+    const int *__restrict__ Up = v.Up;
+    const unsigned short *__restrict__ Ucol16 = v.Ucol16, *__restrict__ Urow16 = v.Urow16;
+    const double *__restrict__ Ux = v.Ux;
+    const int s0 = bv.bundle_ptr[bid], nloc = bv.bundle_ptr[bid + 1] - s0;
+    const int nleaf = bv.blvl[bv.blvl_ptr[bid] + 1] - s0, nin = nloc - nleaf;
+    const int tid = threadIdx.x;
+    auto xpos = [&](int t) { return t < nleaf ? t : nloc + (t - nleaf); }; // x of non-leaf t
+    // leaf rows: pointers of this thread's first four rows are requested before the staging pass
+    constexpr int LR = 4, LS = 3;
+    int tb[LR], te[LR];
+#pragma unroll
+    for (int u = 0; u < LR; ++u) {
+        const int i = tid + u * TW;
+        tb[u] = i < nleaf ? Up[s0 + i] : 0;
+        te[u] = i < nleaf ? Up[s0 + i + 1] : 0;
+    }
+    const int fb = Up[s0 + nleaf], fe = Up[s0 + nloc]; // the flat range: rows of the non-leaf nodes
+    for (int t = tid; t < nin; t += TW) {
+        const double xv = x[s0 + nleaf + t], bv_ = b[s0 + nleaf + t];
+        xs[xpos(t)] = xv;
+        xs[nleaf + t] = bv_;
+    }
+    double tpart = 0.0;
+    __shared__ double tacc3[8];
+    if (k > 1 && tid < 8) tacc3[tid] = 0.0;
+    double mleaf = 0.0;
+    bool nan = false;
+    __syncthreads();
+    // ---- leaf rows ----
+    for (int w0 = 0; w0 < nleaf; w0 += LR * TW) {
+        int jj[LR][LS];
+        double vv[LR][LS], xi[LR], bi[LR], acc[LR];
+#pragma unroll
+        for (int u = 0; u < LR; ++u) {
+            const int i = w0 + tid + u * TW;
+            xi[u] = i < nleaf ? x[s0 + i] : 0.0;
+            bi[u] = i < nleaf ? b[s0 + i] : 0.0;
+            acc[u] = 0.0;
+#pragma unroll
+            for (int q = 0; q < LS; ++q) {
+                const int t = tb[u] + q;
+                const bool ok = t < te[u];
+                jj[u][q] = ok ? (int)Ucol16[t] : -1;
+                vv[u][q] = ok ? Ux[t] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LR; ++u) {
+            const int i = w0 + tid + u * TW;
+            auto apply = [&](int j, double val) {
+                if (j >= nloc) {
+                    acc[u] += val * xt[j - nloc];
+                    if (k == 1) tpart += val * xi[u];
+                    else atomicAdd(&tacc3[j - nloc], val * xi[u]);
+                } else if (j == i) {
+                    acc[u] += val * xi[u];
+                } else {
+                    acc[u] += val * xs[xpos(j - nleaf)];
+                    atomicAdd(&xs[j], -(val * xi[u]));
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < LS; ++q)
+                if (jj[u][q] >= 0) apply(jj[u][q], vv[u][q]);
+            for (int t = tb[u] + LS; t < te[u]; ++t) apply((int)Ucol16[t], Ux[t]); // (a leaf with a long row: rare)
+            if (i < nleaf) {
+                const double val = bi[u] - acc[u];
+                spill[s0 + i] = val;
+                if (val != val) nan = true;
+                else mleaf = fmax(mleaf, fabs(val));
+            }
+            const int in = i + LR * TW;
+            tb[u] = in < nleaf ? Up[s0 + in] : 0;
+            te[u] = in < nleaf ? Up[s0 + in + 1] : 0;
+        }
+    }
+    // ---- rows of the non-leaf nodes: flat over their entries, the next batch in flight while this one is consumed ----
+    int ii[FLAT_U], jj[FLAT_U], ni[FLAT_U], nj[FLAT_U];
+    double vv[FLAT_U], nv[FLAT_U];
+    auto request = [&](int bs, int *pi, int *pj, double *pv) {
+#pragma unroll
+        for (int u = 0; u < FLAT_U; ++u) {
+            const int t = bs + u * TW + tid;
+            const bool ok = t < fe;
+            pi[u] = ok ? (int)Urow16[t] : -1;
+            pj[u] = ok ? (int)Ucol16[t] : 0;
+            pv[u] = ok ? Ux[t] : 0.0;
+        }
+    };
+    if (fb < fe) request(fb, ii, jj, vv);
+    for (int base = fb; base < fe; base += TW * FLAT_U) {
+        if (base + TW * FLAT_U < fe) request(base + TW * FLAT_U, ni, nj, nv);
+        else {
+#pragma unroll
+            for (int u = 0; u < FLAT_U; ++u) ni[u] = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < FLAT_U; ++u) {
+            const int i = ii[u], j = jj[u];
+            if (i < 0) continue;
+            const double xi = xs[xpos(i - nleaf)];
+            if (j >= nloc) {
+                atomicAdd(&xs[i], -(vv[u] * xt[j - nloc]));
+                if (k == 1) tpart += vv[u] * xi;
+                else atomicAdd(&tacc3[j - nloc], vv[u] * xi);
+            } else if (j == i) {
+                atomicAdd(&xs[i], -(vv[u] * xi));
+            } else {
+                atomicAdd(&xs[i], -(vv[u] * xs[xpos(j - nleaf)]));
+                atomicAdd(&xs[j], -(vv[u] * xi));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FLAT_U; ++u) {
+            ii[u] = ni[u];
+            jj[u] = nj[u];
+            vv[u] = nv[u];
+        }
+    }
+    __syncthreads();
+    double m = mleaf;
+    for (int i = nleaf + tid; i < nloc; i += TW) {
+        const double val = xs[i];
+        if (val != val) nan = true;
+        else m = fmax(m, fabs(val));
+    }
+    for (int i = tid; i < nleaf; i += TW) xs[i] = spill[s0 + i]; // (every thread re-reads what it wrote itself)
+    m = block_max(m, red);
+    const bool anynan = __syncthreads_or(nan);
+    if (tid == 0)
+        __hip_atomic_store(out_norm, anynan ? __longlong_as_double(0x7ff8000000000000ll) : m, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (k == 1) {
+        tpart = block_sum(tpart, red);
+        if (tid == 0) __hip_atomic_store(out_share, tpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (k > 1) {
+        __syncthreads();
+        if (tid == 0)
+            for (int i = 0; i < k; ++i)
+                __hip_atomic_store(out_share + i, tacc3[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 constexpr int IR_MAXRUNS = 32;
 // per-workgroup state of k_bundle_ir, kept in LDS so that nothing but loop counters stays in registers
 // across the sweeps (their inner loops need the whole 64-register budget of 8 waves per SIMD)
@@ -2776,6 +3069,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
     __shared__ double red[16];
     __shared__ int fat[IR_FATCAP];
     __shared__ int nfat;
+    __shared__ int lev_e[FLAT_MAXLEV + 1];
     __shared__ IrState st;
     const int nb = bv.nb, G = gridDim.x, tid = threadIdx.x;
     const int grp = GR ? gf.bgrp[blockIdx.x] : -1;
@@ -3021,7 +3315,15 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
             } // (single: xs still holds this bundle's residual)
             __syncthreads();
             stamp();
-            bundle_sweep_cols<true, IR_SH_FWD, IR_RPT, TW>(v, bv, b, xs, nullptr, st.tacc, k, fat, nfat);
+            // (entry-parallel sweeps for bundles whose levels fill the workgroup; decided per bundle, the same way in
+            // every phase)
+            const bool flat = ir.flat && nloc >= FLAT_MIN_NODES && bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1 <= FLAT_MAXLEV;
+            if (flat && (round == 0 || !single)) {
+                __syncthreads(); // (!single: the previous bundle's sweeps are done with the table)
+                flat_level_table(v, bv, b, lev_e);
+            }
+            if (flat) bundle_sweep_flat<true, TW>(v, bv, b, xs, nullptr, st.tacc, k, lev_e);
+            else bundle_sweep_cols<true, IR_SH_FWD, IR_RPT, TW>(v, bv, b, xs, nullptr, st.tacc, k, fat, nfat);
             stamp();
             // this bundle's shares of the top rows of L (accumulated by the pushes)
             if (!GR && tid < k) ir_store(&shf[(size_t)b * k + tid], st.tacc[tid]);
@@ -3138,12 +3440,16 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
             stamp();
             // D^-1 of the backward sweep (qdldl.rs:737-752): through the sweep's pipeline with 128 registers; as a
             // pass of its own in the 80-register variant (three more pipeline registers per column spill there)
-            if (TW != 256) {
-                for (int i = tid; i < nloc; i += TW) xs[i] *= v.Dinv[s0 + i];
-                __syncthreads();
+            if (flat) {
+                bundle_sweep_flat<false, TW>(v, bv, b, xs, st.dxt, nullptr, k, lev_e);
+            } else {
+                if (TW != 256) {
+                    for (int i = tid; i < nloc; i += TW) xs[i] *= v.Dinv[s0 + i];
+                    __syncthreads();
+                }
+                bundle_sweep_cols<false, IR_SH_BWD, IR_RPT, TW>(v, bv, b, xs, st.dxt, nullptr, k, fat, nfat,
+                                                                TW == 256 ? v.Dinv : nullptr);
             }
-            bundle_sweep_cols<false, IR_SH_BWD, IR_RPT, TW>(v, bv, b, xs, st.dxt, nullptr, k, fat, nfat,
-                                                            TW == 256 ? v.Dinv : nullptr);
             stamp();
             {
                 // the candidate: x (round 0) or x + dx (directldlkktsolver.rs:300 axpby(1, x, 1))
@@ -3171,7 +3477,9 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
                 __syncthreads(); // the candidate's slice is visible workgroup-wide
                 stamp();
                 double *share_out = GR ? &gf.rsh[((size_t)par * nb + b) * 8] : &shs[(size_t)par * nb * k + (size_t)b * k];
-                if (single && bv.symv_split)
+                if (single && bv.symv_split && flat)
+                    bundle_symv_flat<TW>(v, bv, alt, ir.bp, ir.ebuf, xs, red, k, b, st.candt, &pn[(size_t)par * nb + b], share_out);
+                else if (single && bv.symv_split)
                     bundle_symv_split<IR_SH_SYMV, TW, 2>(bv, v.Up, v.Ucol16, v.Ux, alt, ir.bp, ir.ebuf, xs, red, k, b, st.candt,
                                                          &pn[(size_t)par * nb + b], share_out);
                 else

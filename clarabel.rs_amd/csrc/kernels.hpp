@@ -28,6 +28,7 @@ struct LdlView {
     // bundle part (host.hpp: Symbolic::Li16); mirror_rows: the factorisation keeps the row-major copy Rx
     // up to date (the fused solve kernel does not read it)
     const unsigned short *Li16, *Ucol16;
+    const unsigned short *Lj16, *Urow16; // bundle-local column of an L entry / row of a U entry (flat sweeps)
     int mirror_rows;
 };
 
@@ -152,6 +153,7 @@ struct IrView {
     long long *dbg;        // diagnostics: 128 time stamps of two workgroups, or nullptr
     long long *dbg_all;    // diagnostics (CHIP_IR_DEBUG=2): 32 words per workgroup: [0] hardware id, [1..] time stamps
     int test_drop;         // tests: the last workgroup leaves at once, so every grid barrier times out
+    int flat;              // entry-parallel sweeps / residual (bundle_sweep_flat, bundle_symv_flat); 0: column per thread
 };
 int ir_ctl_ints();                 // (+ 32 per group of a grouped fold, appended: GFoldView::gcnt)
 size_t ir_part_doubles(int nb, int k);

@@ -1137,16 +1137,20 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             const i64 nLb = S.Lp[S.NF];
             S.Li16.resize((size_t)nLb + 1);
             S.Ucol16.resize((size_t)S.nnzU + 1);
+            S.Lj16.resize((size_t)nLb + 1);
+            S.Urow16.resize((size_t)S.nnzU + 1);
             for (i32 b = 0; b < nbun; b++) {
                 const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1], nloc = s1 - s0;
                 for (i32 j = s0; j < s1; j++) {
                     for (i32 q = S.Lp[j]; q < S.Lp[j + 1]; q++) {
                         const i32 i = S.Li[q];
                         S.Li16[q] = (uint16_t)(i < s1 ? i - s0 : nloc + top_index(i));
+                        S.Lj16[q] = (uint16_t)(j - s0);
                     }
                     for (i32 u = S.Up[j]; u < S.Up[j + 1]; u++) {
                         const i32 i = S.Ucol[u];
                         S.Ucol16[u] = (uint16_t)(i < s1 ? i - s0 : nloc + top_index(i));
+                        S.Urow16[u] = (uint16_t)(j - s0);
                     }
                 }
             }

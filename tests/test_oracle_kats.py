@@ -548,3 +548,81 @@ def test_psd_numpy_oracle_identities(oracle, n):
     assert abs(a - ev.min()) <= 1e-10 * ev.max() and abs(b - ev.sum()) <= 1e-10 * ev.sum()
     bar = c.compute_barrier(z, s, np.zeros(c.numel), np.zeros(c.numel), 0.0)
     assert abs(bar + np.log(np.linalg.det(Z)) + np.log(np.linalg.det(S))) <= 1e-8 * abs(bar)
+
+
+# ---- the reference's dense known-answer tests, pinned on oracle/psd_numpy.py ------------------------------------
+def test_psd_svec_conversions_kat():
+    """algebra/dense/matrix_math.rs:389-424 (test_svec_conversions): <svec X, svec Y> = <X, Y>, the round trip, and
+    the packed order itself -- upper triangle column by column, off-diagonals times sqrt 2 (:165-205)"""
+    from oracle import psd_numpy as PN
+    X = np.array([[1., 3., -2.], [3., -4., 7.], [-2., 7., 5.]])
+    Y = np.array([[2., 5., -4.], [5., 6., 2.], [-4., 2., -3.]])
+    x, y = PN.mat_to_svec(X), PN.mat_to_svec(Y)
+    assert abs(x @ y - np.sum(X * Y)) < 1e-12
+    assert np.max(np.abs(PN.svec_to_mat(x, 3) - X)) < 1e-12
+    r2 = np.sqrt(2.0)
+    assert np.allclose(x, [1., 3. * r2, -4., -2. * r2, 7. * r2, 5.], rtol=0, atol=1e-15)
+    # triangular_index(k) = k (k + 3) / 2 is the position of diagonal k (scalarmath.rs:28-32)
+    assert list(PN.PSDCone(3).diag_idx) == [0, 2, 5]
+
+
+CHOL_KATS = [  # algebra/dense/blas/cholesky.rs:308-378 = svd.rs:367-437: (S, X, B = S X)
+    (np.array([[4., 1.], [1., 3.]]), np.array([[2., 3.], [1., 2.]]), np.array([[9., 14.], [5., 9.]])),
+    (np.array([[8., -2., 4.], [-2., 12., 2.], [4., 2., 6.]]), np.array([[1., 2.], [3., 4.], [5., 6.]]),
+     np.array([[22., 32.], [44., 56.], [40., 52.]])),
+    (np.array([[10., 2., 3., 1.], [2., 8., 0., 3.], [3., 0., 6., 2.], [1., 3., 2., 9.]]),
+     np.array([[1., 2.], [2., 3.], [3., 1.], [4., 2.]]), np.array([[27., 31.], [30., 34.], [29., 16.], [49., 31.]])),
+]
+
+
+@pytest.mark.parametrize("S,X,B", CHOL_KATS)
+def test_psd_dense_engine_kats(S, X, B):
+    """the LAPACK calls the numpy restatement stands on, against the reference's vectors for its own engines:
+    Cholesky (cholesky.rs:380-419: L L' = S to 1e-8, solve to 1e-12), SVD (svd.rs:439-465 solve to 1e-10; :528-575
+    singular values descending, U S V' reconstructs A to 1e-10)"""
+    L = np.linalg.cholesky(S)   # what PSDCone.update_scaling / logdet_barrier call
+    assert np.max(np.abs(L @ L.T - S)) < 1e-8 and np.allclose(L, np.tril(L))
+    assert np.max(np.abs(np.linalg.solve(L.T, np.linalg.solve(L, B)) - X)) <= 1e-12
+    U, sg, Vt = np.linalg.svd(S)   # what PSDCone.update_scaling calls
+    assert np.all(np.diff(sg) <= 0)
+    assert np.max(np.abs((U * sg) @ Vt - S)) < 1e-10
+    assert np.max(np.abs(Vt.T @ ((U.T @ B) / sg[:, None]) - X)) < 1e-10
+
+
+def test_psd_dense_engine_kats_rectangular_and_logdet_and_eig():
+    from oracle import psd_numpy as PN
+    # svd.rs:492-509 (2x4 and 4x2 factor data): descending, reconstruction
+    A24 = np.array([[10., 2., 3., 1.], [2., 8., 0., 3.]])
+    for A in (A24, A24.T.copy()):
+        U, sg, Vt = np.linalg.svd(A, full_matrices=False)
+        assert np.all(np.diff(sg) <= 0) and np.max(np.abs((U * sg) @ Vt - A)) < 1e-10
+    # cholesky.rs:421-441: logdet of [[8,-2,4],[-2,12,2],[4,2,6]] = 5.69035945432406, through the cone's barrier
+    S = np.array([[8., -2., 4.], [-2., 12., 2.], [4., 2., 6.]])
+    c = PN.PSDCone(3)
+    assert abs(c.logdet_barrier(PN.mat_to_svec(S), np.zeros(6), 0.0) - 5.69035945432406) < 1e-10
+    # syevr.rs:284-318: eigenvalues of the 4x4 matrix are [-1, -1, 8, 9] (1e-6), through the cone's margins
+    E = np.array([[3., 2., 4., 0.], [2., 0., 2., 0.], [4., 2., 3., 0.], [0., 0., 0., 9.]])
+    assert np.max(np.abs(np.linalg.eigvalsh(E) - np.array([-1., -1., 8., 9.]))) < 1e-6
+    amin, apos = PN.PSDCone(4).margins(PN.mat_to_svec(E))
+    assert abs(amin + 1.0) < 1e-6 and abs(apos - 17.0) < 1e-6
+
+
+def test_psd_skron_against_its_definition():
+    """psdtrianglecone.rs:467-509 (skron) has no test in the reference: pinned by its definition instead --
+    skron(B) svec(X) = svec(B X B') for symmetric X (the operator the KKT block Hs = skron(R R') must be), entry by
+    entry, with the sqrt 2 rules of the svec basis"""
+    from oracle import psd_numpy as PN
+    rng = np.random.default_rng(4)
+    for n in (2, 3, 6):
+        G = rng.standard_normal((n, n))
+        Bm = G @ G.T + np.eye(n)
+        numel = n * (n + 1) // 2
+        packed = PN.skron_triu(Bm)
+        H = np.zeros((numel, numel))
+        r, c = np.tril_indices(numel)   # packed triu, column major == row-major lower of the transpose
+        H[c, r] = packed
+        H[r, c] = packed
+        for _ in range(3):
+            Xs = rng.standard_normal((n, n))
+            Xs = Xs + Xs.T
+            assert np.max(np.abs(H @ PN.mat_to_svec(Xs) - PN.mat_to_svec(Bm @ Xs @ Bm.T))) <= 1e-11 * np.max(np.abs(H))

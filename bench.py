@@ -338,6 +338,54 @@ def launch_ranks(args):
     raise SystemExit(rc)
 
 
+class FileComm:
+    """--fake-comm: the exchange interface of hip.Comm over files in /tmp, every rank on GPU 0 -- a PLUMBING CHECK of
+    the N > 1 code of this script (sharding, parity reduction, checksums) on a single-GPU box, where RCCL refuses two
+    ranks on one device.  Never a measurement: the line it produces says so."""
+
+    def __init__(self, hip, world, rank):
+        self.hip, self.world, self.rank, self.seq = hip, world, rank, 0
+        self.base = "/tmp/chip_fakecomm_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+
+    def _exchange(self, arr):
+        self.seq += 1
+        mine = "%s_%d_%d.npy" % (self.base, self.seq, self.rank)
+        np.save(mine + ".tmp.npy", arr)
+        os.replace(mine + ".tmp.npy", mine)
+        out = []
+        for r in range(self.world):
+            path = "%s_%d_%d.npy" % (self.base, self.seq, r)
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > 600:
+                    raise RuntimeError("fake comm: rank %d missing" % r)
+                time.sleep(0.002)
+            out.append(np.load(path))
+        return out
+
+    def attach(self, ks):
+        pass
+
+    def wait(self, ks):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def allgather_step(self, ks, send_ptr, recv_ptr, counts):
+        ks.synchronize()
+        parts = self._exchange(self.hip.DeviceArray.view(send_ptr, int(counts[self.rank])).numpy())
+        self.hip.DeviceArray.view(recv_ptr, int(sum(counts))).copy_from(np.concatenate(parts))
+
+    def allreduce(self, vals, op="sum"):
+        parts = self._exchange(np.atleast_1d(np.asarray(vals, dtype=np.float64)))
+        f = {"sum": np.sum, "max": np.max, "min": np.min}[op]
+        return f(np.stack(parts), axis=0)
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+
 def rendezvous_id(hip, rank, world):
     """the 128-byte RCCL token from rank 0 to the others through a file in /tmp (single node; the
     launcher's pid makes the name unique per run).  Setup only, never in the timed region."""
@@ -369,6 +417,9 @@ def main():
     ap.add_argument("--nbatch", type=int, default=1024, help="c4: independent SOCPs (default: config 4)")
     ap.add_argument("--force-comm", action="store_true",
                     help="c4 at N = 1: run the all-gather path with a one-rank RCCL communicator (plumbing check)")
+    ap.add_argument("--fake-comm", action="store_true",
+                    help="N > 1 on ONE GPU with a file-based stand-in for the RCCL exchange: plumbing check of this script's "
+                         "N > 1 code (never a measurement)")
     ap.add_argument("--gather-every-solve", action="store_true",
                     help="N > 1: all-gather the solution of each of the 3 solves, not only the step direction")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1 auto, 0 off)")
@@ -389,7 +440,7 @@ def main():
     ndev = hip.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    device = local_rank % ndev
+    device = 0 if args.fake_comm else local_rank % ndev
     hip.set_device(device)
     workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c4")
     if world > 1 and workload != "c4":
@@ -427,7 +478,7 @@ def main():
     t_setup = w.t_setup
     if world > 1 or (args.force_comm and workload == "c4"):
         # (--force-comm: the exchange path with a one-rank communicator -- plumbing check on a single-GPU box)
-        comm = hip.Comm(rendezvous_id(hip, rank, world), world, rank, device)
+        comm = FileComm(hip, world, rank) if args.fake_comm else hip.Comm(rendezvous_id(hip, rank, world), world, rank, device)
         comm.attach(w.ks)
         gathered = [hip.DeviceArray(int(sum(counts))) for _ in range(3)]
     elapsed, prof = w.run(args.steps, args.warmup, args.profile_family, comm, gathered, counts)
@@ -590,7 +641,8 @@ def main():
                        "per_step": "1 update(scaling+Hs+static reg+refactor) + 3 solves x (LDL solve + 1 IR round)",
                        "ir_rounds": int(ir), "setup_s": round(t_setup, 2),
                        "gpus_on_problem": int(info.threads) if world == 1 else world,
-                       "collective": ("%s per step, native RCCL (ncclAllGather fp64, %d doubles) on its own stream, event-ordered"
+                       "collective": "FILE-BASED STAND-IN on one GPU (--fake-comm): a plumbing check, NOT a measurement" if args.fake_comm else
+                                     ("%s per step, native RCCL (ncclAllGather fp64, %d doubles) on its own stream, event-ordered"
                                       % ("3 x all-gather (every solve's solution)" if args.gather_every_solve else
                                          "1 x all-gather of the step direction (the last solve's solution)",
                                          int(sum(counts)))) if comm is not None else "none"},

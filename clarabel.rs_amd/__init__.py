@@ -771,6 +771,15 @@ class DeviceArray:
         else:
             rt.hipMemset(self._p, 0, C.c_size_t(max(n, 1) * 8))
 
+    @classmethod
+    def view(cls, ptr, n):
+        """non-owning view of n fp64 values at device address `ptr` (never freed here)"""
+        a = cls.__new__(cls)
+        a.n = int(n)
+        a._p = C.c_void_p(ptr)
+        a._borrowed = True
+        return a
+
     @property
     def ptr(self):
         return self._p.value
@@ -790,6 +799,8 @@ class DeviceArray:
         return out
 
     def __del__(self):
+        if getattr(self, "_borrowed", False):
+            return
         if getattr(self, "_p", None) and self._p.value:
             try:
                 _hiprt().hipFree(self._p)

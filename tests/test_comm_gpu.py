@@ -91,3 +91,20 @@ def test_sharded_step_direction_two_gpus(hip):
     for p in procs:
         p.join(60)
     assert err <= 1e-9 * max(1.0, nrm) and threads == 2
+
+
+def test_bench_sharded_code_path_with_file_comm(hip):
+    """bench.py's N > 1 code (stdlib launcher, sharding by whole trees, per-rank oracle parity reduced over the ranks,
+    checksums of the gathered step direction) exercised on ONE GPU: two ranks on device 0 with the file-based
+    stand-in for the RCCL exchange (--fake-comm) -- RCCL itself refuses two ranks on one device."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--fake-comm", "--nbatch", "8",
+                          "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and "STAND-IN" in line["config"]["collective"]
+    par = line["parity"]
+    assert par["ok"] and par["rel_err_vs_oracle"] <= 1e-8
+    assert par["gathered_vs_local"]["own_slice_bit_equal_on_every_rank"]
+    assert par["gathered_vs_local"]["max_abs_diff_of_segment_checksums"] == 0.0

@@ -430,6 +430,7 @@ int64_t orc_qdldl_nnzL(const orc_qdldl *f) { return f->nnzL; }
 int64_t orc_qdldl_nnzA(const orc_qdldl *f) { return f->nnzA; }
 int64_t orc_qdldl_positive_inertia(const orc_qdldl *f) { return f->positive_inertia; }
 int64_t orc_qdldl_regularize_count(const orc_qdldl *f) { return f->regularize_count; }
+const int64_t *orc_qdldl_perm(const orc_qdldl *f) { return f->perm; }
 const int64_t *orc_qdldl_Lp(const orc_qdldl *f) { return f->Lp; }
 const int64_t *orc_qdldl_Li(const orc_qdldl *f) { return f->Li; }
 const double *orc_qdldl_Lx(const orc_qdldl *f) { return f->Lx; }

@@ -626,3 +626,41 @@ def test_psd_skron_against_its_definition():
             Xs = rng.standard_normal((n, n))
             Xs = Xs + Xs.T
             assert np.max(np.abs(H @ PN.mat_to_svec(Xs) - PN.mat_to_svec(Bm @ Xs @ Bm.T))) <= 1e-11 * np.max(np.abs(H))
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_mt_comparator_reproduces_the_oracle(oracle, threads):
+    """oracle/ldl_mt.c (bench.py's cpu_baseline_mt: the qdldl column algorithm on OpenMP threads) against the scalar
+    oracle on the same permuted, regularised matrix: factors entry by entry, the solve, and the residual"""
+    from oracle import ldl_mt
+    from tests import problems
+    pr = problems.portfolio_socp(6, 40, seed=3, late=True)
+    cones = oracle.Cones(pr["cones"])
+    assert cones.update_scaling(pr["s"], pr["z"])
+    ko = oracle.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones)
+    assert ko.update()
+    L = oracle.lib()
+    L.orc_kktsolver_ldl.restype = ldl_mt.C.c_void_p
+    f = ldl_mt.C.c_void_p(L.orc_kktsolver_ldl(ko._h))
+    # the engine's own permutation: recover it from a solve of unit vectors is overkill -- the KKT solver was built
+    # without one, so the oracle's AMD stand-in chose it; read it back through the public accessor
+    L.orc_qdldl_perm.restype = ldl_mt.P_I64
+    perm = np.ctypeslib.as_array(L.orc_qdldl_perm(f), shape=(ko.N,)).copy()
+    mt = ldl_mt.LdlMT(oracle, ko, perm, threads)
+    Ax = mt.values()
+    ok, reg = mt.factor(Ax, ko.settings.dynamic_reg_eps, ko.settings.dynamic_reg_delta)
+    assert ok and reg == ko.ldl_regularize_count()
+    L.orc_qdldl_Lx.restype = ldl_mt.P_F64
+    L.orc_qdldl_D.restype = ldl_mt.P_F64
+    Lx_o = np.ctypeslib.as_array(L.orc_qdldl_Lx(f), shape=(mt.nnzL,))
+    D_o = np.ctypeslib.as_array(L.orc_qdldl_D(f), shape=(mt.n,))
+    assert np.max(np.abs(mt.Lx()[:mt.nnzL] - Lx_o)) <= 1e-12 * max(1.0, np.max(np.abs(Lx_o)))
+    # (a different summation order: pivots formed by cancellation -- late-iterate scalings -- agree to fewer digits)
+    assert np.max(np.abs(mt.D() - D_o) / np.abs(D_o)) <= 1e-6
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(mt.n)
+    x = b.copy()
+    mt.solve(x)
+    e = np.empty(mt.n)
+    mt.residual(Ax, x, b, e)   # residual against the matrix that was factored: tiny
+    assert np.max(np.abs(e)) <= 1e-7 * max(1.0, np.max(np.abs(x)))

@@ -341,6 +341,21 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             if ((rc = upload(&Ucol16, S.Ucol16, S.Ucol16.size()))) return rc;
             if ((rc = upload(&Lj16, S.Lj16, S.Lj16.size()))) return rc;
             if ((rc = upload(&Urow16, S.Urow16, S.Urow16.size()))) return rc;
+            if ((rc = upload(&Rk16, S.Rk16, S.Rk16.size()))) return rc;
+            if ((rc = upload(&Ro16, S.Ro16, S.Ro16.size()))) return rc;
+            if (std::getenv("CHIP_NO_FACTOR_LDS") == nullptr) {
+                // the bundle factorisation with its L and D values in LDS: every bundle's entries must be addressable
+                // in 16 bits and two workgroups must fit a CU
+                int need = 0;
+                bool ok = true;
+                for (int b = 0; b < bundles.nb && ok; b++) {
+                    const int s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
+                    const int ne = S.Lp[s1] - S.Lp[s0];
+                    ok = ne < 65535;
+                    need = std::max(need, ne + (s1 - s0));
+                }
+                if (ok && dev::bundle_factor_lds_ok(need)) factor_lds_doubles = need;
+            }
             ir_grid = std::min(bundles.nb, cap);
             ir_ctl_len = (size_t)dev::ir_ctl_ints() + (grouped ? (size_t)32 * S.gf_ng : 0);
             if ((rc = alloc(&ir_ctl, ir_ctl_len))) return rc;
@@ -428,6 +443,8 @@ dev::LdlView Engine::view() const {
     v.Li16 = Li16;
     v.Lj16 = Lj16;
     v.Urow16 = Urow16;
+    v.Rk16 = Rk16;
+    v.Ro16 = Ro16;
     v.Ucol16 = Ucol16;
     v.mirror_rows = ir_fused ? 0 : 1;
     return v;
@@ -517,7 +534,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     dev::scatter_init(stream, Kx + nnzU, v2l, (int)(nnzK - nnzU), (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                       mb_dev->status);
     prof_begin(PF_BFACTOR);
-    dev::bundle_factor(stream, v, bundles, fold); // everything below the cut: one launch
+    dev::bundle_factor(stream, v, bundles, fold, factor_lds_doubles); // everything below the cut: one launch
     prof_end(PF_BFACTOR);
     // single top column: pivot accumulated by the bundles; grouped fold: the k x k tops from the bundles' Schur shares
     const bool top_folded = fold.k == 1 || gfold.ng > 0;

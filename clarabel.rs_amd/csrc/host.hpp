@@ -118,6 +118,10 @@ struct Symbolic {
     // ... and, for the entry-parallel ("flat") sweeps and residual of k_bundle_ir, the bundle-local COLUMN of every
     // entry of the bundle columns of L (Lj16) and the bundle-local ROW of every entry of the U rows (Urow16)
     std::vector<uint16_t> Lj16, Urow16;
+    // ... and, for the factorisation with the bundle's values resident in LDS (k_bundle_factor_lds), the row lists of
+    // the bundle rows in 16 bits: contribution t (t < Rp[NF]) of row j comes from bundle-local column Rk16[t], whose
+    // entry (j, k) is the Ro16[t]-th of column k
+    std::vector<uint16_t> Rk16, Ro16;
     std::vector<i32> lvlptr;
     // Chain supernodes of the top (symbolic.cpp): supernode s = columns sn_col[sn_ptr[s] .. sn_ptr[s+1])
     // (ascending, each the parent of the previous one); all its columns are padded to the dense

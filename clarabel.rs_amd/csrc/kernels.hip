@@ -768,6 +768,220 @@ __global__ __launch_bounds__(64) void k_gfold_top_factor(LdlView v, GFoldView gf
         }
     }
 }
+// ---------------------------------------------------------------------------
+// The same factorisation with the bundle's VALUES resident in LDS (fused handles whose bundles have < 65535 entries
+// and fit two workgroups per CU).  k_bundle_factor streams ~2.2 x the algorithmic bytes (PMC: 486 MB on config 3)
+// because the left-looking form re-reads what the workgroup wrote a level earlier -- l_jk, d_k, the tails of the
+// contributing columns -- through 32-bit row lists; here
+//   Ls[0 .. nE)  : the entries of the bundle's columns (CSC order, local slot = global slot - Lp[s0])
+//   Ds[0 .. nloc): the pivots
+// live in LDS from the merge of the U rows (initial values) to ONE coalesced write of L at the end; the level loop
+// reads only index data: Rp, the 16-bit row lists (Rk16 / Ro16), Lp of the contributing columns, Li16 of the tails.
+// Same arithmetic per entry as k_bundle_factor (sums in the same order for thin columns).
+// ---------------------------------------------------------------------------
+constexpr int FLWG = 512;
+__device__ __forceinline__ double pivot_rule_local(const LdlView &v, int j, double d, double *dout) {
+    const double sign = (double)v.dsigns[j];
+    if (d * sign < v.reg_eps) {
+        d = v.reg_delta * sign;
+        atomicAdd(&v.status[2], 1); // rare
+    }
+    if (d == 0.0) v.status[1] = 1;
+    const double dinv = 1.0 / d;
+    if (!isfinite(dinv)) v.status[0] = 1;
+    v.D[j] = d;
+    v.Dinv[j] = dinv;
+    *dout = d;
+    return dinv;
+}
+__global__ __launch_bounds__(FLWG) void k_bundle_factor_lds(LdlView v, BundleView bv, FoldView fold, int lds_doubles) {
+    extern __shared__ __attribute__((aligned(16))) char fl_smem[];
+    __shared__ double red[16];
+    __shared__ int fat[256];
+    __shared__ int nfat;
+    __shared__ double s_dinv;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
+    const int e0 = v.Lp[s0], nE = v.Lp[s1] - e0;
+    double *Ls = (double *)fl_smem, *Ds = Ls + (lds_doubles - bv.max_nodes); // (Ds behind the largest bundle's entries)
+    Ds = Ls + nE;
+    const double eps = v.eps_ptr ? v.eps_ptr[0] : 0.0;
+    // ---- initial values: U row j (diagonal first, then its entries to ancestors) merged into column j ----
+    for (int j = s0 + tid; j < s1; j += FLWG) {
+        const int cb = v.Lp[j] - e0, ce = v.Lp[j + 1] - e0;
+        int u = v.Up[j];
+        const int ue = v.Up[j + 1];
+        const double dg = v.Ux[u];
+        Ds[j - s0] = v.eps_ptr ? (v.dsigns[j] == 1 ? dg + eps : dg - eps) : dg;
+        ++u;
+        for (int q = cb; q < ce; ++q) {
+            double val = 0.0;
+            if (u < ue && v.Ucol16[u] == v.Li16[e0 + q]) val = v.Ux[u++];
+            Ls[q] = val;
+        }
+    }
+    __syncthreads();
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    // one contribution t of row j: column k (local), l_jk at local slot p; returns w = l_jk d_k and the tail range
+    auto contribution = [&](int t, int &p, int &pe, double &ljk) {
+        const int k = (int)v.Rk16[t];
+        const int kb = v.Lp[s0 + k] - e0;
+        pe = v.Lp[s0 + k + 1] - e0;
+        p = kb + (int)v.Ro16[t];
+        ljk = Ls[p];
+        return ljk * Ds[k];
+    };
+    for (int l = 0; l < nl; ++l) {
+        const int lb = lv[l], le = lv[l + 1];
+        if (tid == 0) nfat = 0;
+        __syncthreads();
+        for (int j = lb + tid; j < le; j += FLWG) {
+            const int rb = v.Rp[j], re = v.Rp[j + 1];
+            const int cb = v.Lp[j] - e0, cn = v.Lp[j + 1] - e0 - cb;
+            if (re - rb > FAC_THIN_ROW || cn > FAC_THIN_COL) {
+                const int slot = atomicAdd(&nfat, 1);
+                if (slot < 256) {
+                    fat[slot] = j;
+                    continue;
+                } // (list full: serial path below, correct but slower)
+            }
+            double d = Ds[j - s0];
+            if (cn <= 4) { // the bulk of block-arrow KKTs: row ids and running values in registers
+                const int r0 = cn > 0 ? (int)v.Li16[e0 + cb] : -1, r1 = cn > 1 ? (int)v.Li16[e0 + cb + 1] : -1;
+                const int r2 = cn > 2 ? (int)v.Li16[e0 + cb + 2] : -1;
+                double a0 = cn > 0 ? Ls[cb] : 0.0, a1 = cn > 1 ? Ls[cb + 1] : 0.0, a2 = cn > 2 ? Ls[cb + 2] : 0.0,
+                       a3 = cn > 3 ? Ls[cb + 3] : 0.0;
+                for (int t = rb; t < re; ++t) {
+                    int p, pe;
+                    double ljk;
+                    const double w = contribution(t, p, pe, ljk);
+                    d -= ljk * w;
+                    for (int pp = p + 1; pp < pe; ++pp) {
+                        const int i = (int)v.Li16[e0 + pp];
+                        const double uu = Ls[pp] * w;
+                        if (i == r0) a0 -= uu;
+                        else if (i == r1) a1 -= uu;
+                        else if (i == r2) a2 -= uu;
+                        else a3 -= uu;
+                    }
+                }
+                double dd;
+                const double dinv = pivot_rule_local(v, j, d, &dd);
+                Ds[j - s0] = dd;
+                if (cn > 0) Ls[cb] = a0 * dinv;
+                if (cn > 1) Ls[cb + 1] = a1 * dinv;
+                if (cn > 2) Ls[cb + 2] = a2 * dinv;
+                if (cn > 3) Ls[cb + 3] = a3 * dinv;
+            } else {
+                for (int t = rb; t < re; ++t) {
+                    int p, pe;
+                    double ljk;
+                    const double w = contribution(t, p, pe, ljk);
+                    d -= ljk * w;
+                    int q = cb;
+                    for (int pp = p + 1; pp < pe; ++pp) {
+                        const unsigned short i = v.Li16[e0 + pp];
+                        while (v.Li16[e0 + q] != i) ++q; // rows below j of column k are a subset of column j
+                        Ls[q] -= Ls[pp] * w;
+                        ++q;
+                    }
+                }
+                double dd;
+                const double dinv = pivot_rule_local(v, j, d, &dd);
+                Ds[j - s0] = dd;
+                for (int q = cb; q < cb + cn; ++q) Ls[q] *= dinv;
+            }
+        }
+        __syncthreads();
+        // columns with many contributions (the separators at the top of a subtree): the whole workgroup on one column
+        const int nf = min(nfat, 256);
+        for (int f = 0; f < nf; ++f) {
+            const int j = fat[f];
+            const int rb = v.Rp[j], rn = v.Rp[j + 1] - rb;
+            const int cb = v.Lp[j] - e0, cn = v.Lp[j + 1] - e0 - cb;
+            double dpart = 0.0;
+            if (cn <= 4) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                const int r0 = cn > 0 ? (int)v.Li16[e0 + cb] : -1, r1 = cn > 1 ? (int)v.Li16[e0 + cb + 1] : -1;
+                const int r2 = cn > 2 ? (int)v.Li16[e0 + cb + 2] : -1;
+                for (int t = tid; t < rn; t += FLWG) {
+                    int p, pe;
+                    double ljk;
+                    const double w = contribution(rb + t, p, pe, ljk);
+                    dpart += ljk * w;
+                    for (int pp = p + 1; pp < pe; ++pp) {
+                        const int i = (int)v.Li16[e0 + pp];
+                        const double uu = Ls[pp] * w;
+                        if (i == r0) a0 += uu;
+                        else if (i == r1) a1 += uu;
+                        else if (i == r2) a2 += uu;
+                        else a3 += uu;
+                    }
+                }
+                a0 = block_sum(a0, red);
+                a1 = block_sum(a1, red);
+                a2 = block_sum(a2, red);
+                a3 = block_sum(a3, red);
+                dpart = block_sum(dpart, red);
+                if (tid == 0) {
+                    double dd;
+                    const double dinv = pivot_rule_local(v, j, Ds[j - s0] - dpart, &dd);
+                    Ds[j - s0] = dd;
+                    const double a[4] = {a0, a1, a2, a3};
+                    for (int q = 0; q < cn; ++q) Ls[cb + q] = (Ls[cb + q] - a[q]) * dinv;
+                }
+            } else {
+                for (int t = tid; t < rn; t += FLWG) {
+                    int p, pe;
+                    double ljk;
+                    const double w = contribution(rb + t, p, pe, ljk);
+                    dpart += ljk * w;
+                    int q = cb;
+                    for (int pp = p + 1; pp < pe; ++pp) {
+                        const unsigned short i = v.Li16[e0 + pp];
+                        int lo = q, hi = cb + cn; // first slot of column j with row >= i (present by construction)
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (v.Li16[e0 + mid] < i) lo = mid + 1;
+                            else hi = mid;
+                        }
+                        q = lo;
+                        atomicAdd(&Ls[q], -(Ls[pp] * w));
+                        ++q;
+                    }
+                }
+                dpart = block_sum(dpart, red);
+                if (tid == 0) {
+                    double dd;
+                    s_dinv = pivot_rule_local(v, j, Ds[j - s0] - dpart, &dd);
+                    Ds[j - s0] = dd;
+                }
+                __syncthreads();
+                const double dinv = s_dinv;
+                for (int q = cb + tid; q < cb + cn; q += FLWG) Ls[q] *= dinv;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (fold.k == 1) {
+        // a single dense top row: d_t -= sum l_tc^2 d_c over this bundle's columns (l_tc is the LAST entry of a column
+        // that reaches the top row); k_fold_top_pivot applies the pivot rule
+        double sacc = 0.0;
+        for (int j = s0 + tid; j < s1; j += FLWG) {
+            const int ce = v.Lp[j + 1] - e0;
+            if (ce > v.Lp[j] - e0 && (int)v.Li16[e0 + ce - 1] >= nloc) {
+                const double lt = Ls[ce - 1];
+                sacc += lt * (lt * Ds[j - s0]);
+            }
+        }
+        sacc = block_sum(sacc, red);
+        if (tid == 0 && sacc != 0.0) atomicAdd(&fold.acc[fold_acc_index(2, 0, b % FOLD_SLOTS)], sacc);
+    }
+    // ---- the factor's values, once, coalesced ----
+    for (int q = tid; q < nE; q += FLWG) v.Lx[e0 + q] = Ls[q];
+}
 __global__ void k_fold_top_pivot(LdlView v, FoldView fold) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double d = v.D[fold.NF];
@@ -5770,8 +5984,26 @@ static size_t bundle_lds(const BundleView &bv) { return ((size_t)bv.max_nodes * 
 void fold_top_pivot(hipStream_t s, const LdlView &v, const FoldView &fold) {
     if (fold.k == 1) k_fold_top_pivot<<<1, 64, 0, s>>>(v, fold);
 }
-void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold) {
-    if (bv.nb) k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
+static size_t factor_lds_bytes(int lds_doubles) { return ((size_t)lds_doubles * sizeof(double) + 15) & ~(size_t)15; }
+bool bundle_factor_lds_ok(int lds_doubles) {
+    if (lds_doubles <= 0) return false;
+    const size_t lds = factor_lds_bytes(lds_doubles);
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void *)k_bundle_factor_lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (fa.sharedSizeBytes + lds > 80 * 1024 - 512) return false; // two workgroups per CU
+    if (hipFuncSetAttribute((const void *)k_bundle_factor_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles) {
+    if (!bv.nb) return;
+    if (lds_doubles > 0) k_bundle_factor_lds<<<bv.nb, FLWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold, lds_doubles);
+    else k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
 }
 void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf) {
     if (gf.ng <= 0) return;

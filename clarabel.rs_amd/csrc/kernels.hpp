@@ -29,6 +29,7 @@ struct LdlView {
     // up to date (the fused solve kernel does not read it)
     const unsigned short *Li16, *Ucol16;
     const unsigned short *Lj16, *Urow16; // bundle-local column of an L entry / row of a U entry (flat sweeps)
+    const unsigned short *Rk16, *Ro16;   // rows of L inside the bundles: bundle-local column, offset inside that column
     int mirror_rows;
 };
 
@@ -115,7 +116,10 @@ void scatter_values(hipStream_t s, double *Kx, const int *map, const double *val
 // ---- numeric LDL' -------------------------------------------------------------
 // fold.k == 1: every bundle also subtracts its share of the single top column's pivot; fold_top_pivot
 // then applies the pivot rule to it (the top needs no factor launches of its own)
-void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold);
+// lds_doubles > 0: k_bundle_factor_lds, the bundle's L and D values resident in LDS (lds_doubles = the largest
+// bundle's entries + nodes; bundle_factor_lds_ok says whether the handle qualifies)
+void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles = 0);
+bool bundle_factor_lds_ok(int lds_doubles);
 void fold_top_pivot(hipStream_t s, const LdlView &v, const FoldView &fold);
 // fold.k > 0: every bundle also subtracts its part of the k top rows of L from x[NF + i]
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const FoldView &fold);

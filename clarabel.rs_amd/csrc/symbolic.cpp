@@ -1139,6 +1139,8 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             S.Ucol16.resize((size_t)S.nnzU + 1);
             S.Lj16.resize((size_t)nLb + 1);
             S.Urow16.resize((size_t)S.nnzU + 1);
+            S.Rk16.resize((size_t)S.Rp[S.NF] + 1);
+            S.Ro16.resize((size_t)S.Rp[S.NF] + 1);
             for (i32 b = 0; b < nbun; b++) {
                 const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1], nloc = s1 - s0;
                 for (i32 j = s0; j < s1; j++) {
@@ -1146,6 +1148,11 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                         const i32 i = S.Li[q];
                         S.Li16[q] = (uint16_t)(i < s1 ? i - s0 : nloc + top_index(i));
                         S.Lj16[q] = (uint16_t)(j - s0);
+                    }
+                    for (i32 t = S.Rp[j]; t < S.Rp[j + 1]; t++) { // (row j of L: columns k of the same bundle)
+                        const i32 k = S.Rcol[t];
+                        S.Rk16[t] = (uint16_t)(k - s0);
+                        S.Ro16[t] = (uint16_t)std::min<i32>(S.Rpos[t] - S.Lp[k], 65535);
                     }
                     for (i32 u = S.Up[j]; u < S.Up[j + 1]; u++) {
                         const i32 i = S.Ucol[u];

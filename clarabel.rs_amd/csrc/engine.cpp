@@ -355,6 +355,11 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                     need = std::max(need, ne + (s1 - s0));
                 }
                 if (ok && dev::bundle_factor_lds_ok(need)) factor_lds_doubles = need;
+                if (factor_lds_doubles > 0 && !S.fu_rec.empty()) {
+                    if ((rc = upload(&fu_rec, S.fu_rec, S.fu_rec.size()))) return rc;
+                    if ((rc = upload(&fu_slot, S.fu_slot, S.fu_slot.size()))) return rc;
+                    if ((rc = upload(&fu_ptr, S.fu_ptr, S.fu_ptr.size()))) return rc;
+                }
             }
             ir_grid = std::min(bundles.nb, cap);
             ir_ctl_len = (size_t)dev::ir_ctl_ints() + (grouped ? (size_t)32 * S.gf_ng : 0);
@@ -444,6 +449,9 @@ dev::LdlView Engine::view() const {
     v.Lj16 = Lj16;
     v.Urow16 = Urow16;
     v.Rk16 = Rk16;
+    v.fu_rec = fu_rec;
+    v.fu_slot = fu_slot;
+    v.fu_ptr = fu_ptr;
     v.Ro16 = Ro16;
     v.Ucol16 = Ucol16;
     v.mirror_rows = ir_fused ? 0 : 1;

@@ -124,6 +124,8 @@ struct Engine {
     bool ir_fused = false;
     bool rx_valid = false; // fused handles: the row-major copy Rx of L is only refreshed when the one-kernel-per-phase path runs
     unsigned short *Li16 = nullptr, *Ucol16 = nullptr, *Lj16 = nullptr, *Urow16 = nullptr, *Rk16 = nullptr, *Ro16 = nullptr;
+    unsigned short *fu_rec = nullptr, *fu_slot = nullptr;
+    int *fu_ptr = nullptr;
     int factor_lds_doubles = 0; // > 0: the bundle factorisation keeps its values in LDS (k_bundle_factor_lds)
     int ir_grid = 0, ir_next = 0, ir_tw = 256;
     int *ir_ctl = nullptr, *ir_res = nullptr, *ir_res_host = nullptr;

@@ -122,6 +122,15 @@ struct Symbolic {
     // the bundle rows in 16 bits: contribution t (t < Rp[NF]) of row j comes from bundle-local column Rk16[t], whose
     // entry (j, k) is the Ro16[t]-th of column k
     std::vector<uint16_t> Rk16, Ro16;
+    // ... and the factorisation's UPDATE RECORDS for its entry-parallel form (k_bundle_factor_flat): when column k of a
+    // bundle is final, every pair (a >= b) of its entries whose lower row r_b lies in the bundle updates entry
+    // (r_a, r_b) -- or the pivot of r_b when a == b -- by l_ak d_k l_bk.  Record = 4 x 16 bits {slot of (r_a, k),
+    // slot of (r_b, k), k, target}, slots and k bundle-local, target = local slot of (r_a, r_b) or nE + r_b for a pivot;
+    // per (bundle, level of k) one contiguous range fu_ptr[blvl_ptr[b] + l] .., sorted by target inside.
+    // fu_slot[u]: where U entry u lands in the bundle's value store (0xFFFF = the diagonal).  Empty when some bundle
+    // has nE + nloc >= 65535.
+    std::vector<uint16_t> fu_rec, fu_slot;
+    std::vector<i32> fu_ptr;
     std::vector<i32> lvlptr;
     // Chain supernodes of the top (symbolic.cpp): supernode s = columns sn_col[sn_ptr[s] .. sn_ptr[s+1])
     // (ascending, each the parent of the previous one); all its columns are padded to the dense

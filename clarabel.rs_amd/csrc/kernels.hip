@@ -779,7 +779,8 @@ __global__ __launch_bounds__(64) void k_gfold_top_factor(LdlView v, GFoldView gf
 // reads only index data: Rp, the 16-bit row lists (Rk16 / Ro16), Lp of the contributing columns, Li16 of the tails.
 // Same arithmetic per entry as k_bundle_factor (sums in the same order for thin columns).
 // ---------------------------------------------------------------------------
-constexpr int FLWG = 512;
+constexpr int FLWG = 512;   // k_bundle_factor_lds
+constexpr int FFWG = 1024;  // k_bundle_factor_flat: twice the threads take a level's records in half the passes (120 -> 90 us on config 3)
 __device__ __forceinline__ double pivot_rule_local(const LdlView &v, int j, double d, double *dout) {
     const double sign = (double)v.dsigns[j];
     if (d * sign < v.reg_eps) {
@@ -981,6 +982,87 @@ __global__ __launch_bounds__(FLWG) void k_bundle_factor_lds(LdlView v, BundleVie
     }
     // ---- the factor's values, once, coalesced ----
     for (int q = tid; q < nE; q += FLWG) v.Lx[e0 + q] = Ls[q];
+}
+// ---------------------------------------------------------------------------
+// ... and entry-parallel (right-looking): no pointer is chased inside the level loop.  When the columns of a level are
+// final, every pair of entries of such a column updates one later entry or pivot -- the symbolic phase lists these
+// updates as 8-byte records {slot a, slot b, column k, target}, one contiguous range per (bundle, level), sorted by
+// target -- and the threads stride over the range: target -= l_a (l_b d_k), an LDS atomic (runs of one target reduced
+// in registers first: the pivot of a separator column takes a thousand updates).  Per level: pivots + scaling of the
+// level's columns (thread per column, LDS only), a barrier, the records, a barrier.  The initial values come from a
+// flat pass over the bundle's U entries (fu_slot says where each lands).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lds_scatter_add(double *acc, int tgt, double val);
+__global__ __launch_bounds__(FFWG) void k_bundle_factor_flat(LdlView v, BundleView bv, FoldView fold) {
+    extern __shared__ __attribute__((aligned(16))) char ff_smem[];
+    __shared__ double red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
+    const int e0 = v.Lp[s0], nE = v.Lp[s1] - e0;
+    double *Ls = (double *)ff_smem, *Ds = Ls + nE; // (contiguous: a record's target addresses either)
+    const double eps = v.eps_ptr ? v.eps_ptr[0] : 0.0;
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    const int *tp = v.fu_ptr + bv.blvl_ptr[b];
+    for (int q = tid; q < nE; q += FFWG) Ls[q] = 0.0; // (fill-in slots stay zero)
+    __syncthreads();
+    {
+        const int ub = v.Up[s0], ue = v.Up[s1];
+        for (int u = ub + tid; u < ue; u += FFWG) {
+            const unsigned short slot = v.fu_slot[u];
+            const double val = v.Ux[u];
+            if (slot == 0xFFFFu) {
+                const int j = (int)v.Urow16[u];
+                Ds[j] = v.eps_ptr ? (v.dsigns[s0 + j] == 1 ? val + eps : val - eps) : val;
+            } else {
+                Ls[slot] = val;
+            }
+        }
+    }
+    __syncthreads();
+    typedef unsigned short fu_v4 __attribute__((ext_vector_type(4)));
+    const fu_v4 *rec = (const fu_v4 *)v.fu_rec;
+    for (int l = 0; l < nl; ++l) {
+        // the level's columns are final: pivot rule, scale
+        for (int j = lv[l] + tid; j < lv[l + 1]; j += FFWG) {
+            const int cb = v.Lp[j] - e0, ce = v.Lp[j + 1] - e0;
+            double dd;
+            const double dinv = pivot_rule_local(v, j, Ds[j - s0], &dd);
+            Ds[j - s0] = dd;
+            for (int q = cb; q < ce; ++q) Ls[q] *= dinv;
+        }
+        __syncthreads();
+        const int rb = tp[l], re = tp[l + 1];
+        for (int base = rb; base < re; base += FFWG * 4) { // (wave-uniform bounds: lds_scatter_add is cross-lane)
+            fu_v4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = base + u * FFWG + tid;
+                if (t < re) r[u] = rec[t];
+                else r[u] = fu_v4{0, 0, 0, 0xFFFF};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = r[u].w != 0xFFFFu;
+                const double val = ok ? Ls[r[u].x] * (Ls[r[u].y] * Ds[r[u].z]) : 0.0;
+                lds_scatter_add(Ls, ok ? (int)r[u].w : -1, -val);
+            }
+        }
+        __syncthreads();
+    }
+    if (fold.k == 1) {
+        double sacc = 0.0;
+        for (int j = s0 + tid; j < s1; j += FFWG) {
+            const int ce = v.Lp[j + 1] - e0;
+            if (ce > v.Lp[j] - e0 && (int)v.Li16[e0 + ce - 1] >= nloc) {
+                const double lt = Ls[ce - 1];
+                sacc += lt * (lt * Ds[j - s0]);
+            }
+        }
+        sacc = block_sum(sacc, red);
+        if (tid == 0 && sacc != 0.0) atomicAdd(&fold.acc[fold_acc_index(2, 0, b % FOLD_SLOTS)], sacc);
+    }
+    for (int q = tid; q < nE; q += FFWG) v.Lx[e0 + q] = Ls[q];
 }
 __global__ void k_fold_top_pivot(LdlView v, FoldView fold) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -3295,7 +3377,7 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
     const bool gfirst = GR && grp >= 0 && (int)blockIdx.x == gf.bptr[grp];
     int gph = 0;                                                            // group phases passed so far
     auto topnode = [&](int i) { return GR ? gf.node[gbase + i] : NF + i; };
-    double *grec = (GR && grp >= 0) ? gf.rec + (size_t)grp * 64 : nullptr;  // [2][32]
+    double *grec = (GR && grp >= 0) ? gf.rec + (size_t)(grp < 0 ? 0 : grp) * 64 : nullptr;  // [2][32]
     FoldView lfold = fold; // what the residual body needs to know: the number of folded rows of THIS workgroup
     lfold.k = k;
     if (ir.test_drop && (int)blockIdx.x == G - 1 && G > 1) return; // (tests: a launch that is not co-resident)
@@ -5994,7 +6076,8 @@ bool bundle_factor_lds_ok(int lds_doubles) {
         return false;
     }
     if (fa.sharedSizeBytes + lds > 80 * 1024 - 512) return false; // two workgroups per CU
-    if (hipFuncSetAttribute((const void *)k_bundle_factor_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)k_bundle_factor_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_bundle_factor_flat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
@@ -6002,7 +6085,9 @@ bool bundle_factor_lds_ok(int lds_doubles) {
 }
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles) {
     if (!bv.nb) return;
-    if (lds_doubles > 0) k_bundle_factor_lds<<<bv.nb, FLWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold, lds_doubles);
+    static const bool no_flat = std::getenv("CHIP_NO_FACTOR_FLAT") != nullptr;
+    if (lds_doubles > 0 && v.fu_rec && !no_flat) k_bundle_factor_flat<<<bv.nb, FFWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold);
+    else if (lds_doubles > 0) k_bundle_factor_lds<<<bv.nb, FLWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold, lds_doubles);
     else k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
 }
 void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf) {

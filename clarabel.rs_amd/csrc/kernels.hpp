@@ -30,6 +30,8 @@ struct LdlView {
     const unsigned short *Li16, *Ucol16;
     const unsigned short *Lj16, *Urow16; // bundle-local column of an L entry / row of a U entry (flat sweeps)
     const unsigned short *Rk16, *Ro16;   // rows of L inside the bundles: bundle-local column, offset inside that column
+    const unsigned short *fu_rec, *fu_slot; // entry-parallel bundle factorisation (host.hpp: Symbolic::fu_rec), or nullptr
+    const int *fu_ptr;
     int mirror_rows;
 };
 

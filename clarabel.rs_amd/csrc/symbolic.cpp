@@ -15,6 +15,7 @@
 //     rows (CSR) so that forward substitution, backward substitution and the
 //     left-looking numeric factorisation are all pure gathers.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -1160,6 +1161,83 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                         S.Urow16[u] = (uint16_t)(j - s0);
                     }
                 }
+            }
+        }
+    }
+    // ---- update records of the entry-parallel bundle factorisation (host.hpp: fu_rec) ----------------
+    if (!S.Li16.empty() && std::getenv("CHIP_NO_FACTOR_FLAT") == nullptr) {
+        const i32 nbun = (i32)S.bundle_ptr.size() - 1;
+        bool ok = true;
+        for (i32 b = 0; b < nbun && ok; b++) {
+            const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
+            ok = (i64)(S.Lp[s1] - S.Lp[s0]) + (s1 - s0) < 65535;
+        }
+        if (ok) {
+            // per bundle: count, then fill (threads over bundles: every bundle owns its range of the arrays)
+            std::vector<i64> bcount((size_t)nbun + 1, 0);
+            const int T = par_threads(S.Lp[S.NF]);
+            auto pairs_of = [&](i32 k, i32 s1) { // pairs (a >= b) of column k with r_b inside the bundle
+                i64 c = 0;
+                const i32 cb = S.Lp[k], ce = S.Lp[k + 1];
+                i32 nin = 0;
+                while (cb + nin < ce && S.Li[cb + nin] < s1) nin++;
+                c = (i64)nin * (ce - cb) - (i64)nin * (nin - 1) / 2; // b over the nin in-bundle rows, a from b to the end
+                return c;
+            };
+            run_threads(T, [&](int t, int TT) {
+                for (i32 b = t; b < nbun; b += TT) {
+                    i64 c = 0;
+                    for (i32 k = S.bundle_ptr[b]; k < S.bundle_ptr[b + 1]; k++) c += pairs_of(k, S.bundle_ptr[b + 1]);
+                    bcount[b + 1] = c;
+                }
+            });
+            for (i32 b = 0; b < nbun; b++) bcount[b + 1] += bcount[b];
+            if (bcount[nbun] < ((i64)1 << 30)) {
+                S.fu_rec.resize((size_t)bcount[nbun] * 4 + 4);
+                S.fu_ptr.assign(S.blvl.size() + 1, 0);
+                S.fu_slot.assign((size_t)S.nnzU + 1, 0xFFFF);
+                run_threads(T, [&](int t, int TT) {
+                    std::vector<std::array<uint16_t, 4>> lvl;
+                    for (i32 b = t; b < nbun; b += TT) {
+                        const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1], e0 = S.Lp[s0], nE = S.Lp[s1] - e0;
+                        i64 out = bcount[b];
+                        const i32 lb0 = S.blvl_ptr[b], nl = S.blvl_ptr[b + 1] - lb0 - 1;
+                        for (i32 l = 0; l < nl; l++) {
+                            S.fu_ptr[lb0 + l] = (i32)out;
+                            lvl.clear();
+                            for (i32 k = S.blvl[lb0 + l]; k < S.blvl[lb0 + l + 1]; k++) {
+                                const i32 cb = S.Lp[k], ce = S.Lp[k + 1];
+                                for (i32 qb = cb; qb < ce && S.Li[qb] < s1; qb++) {
+                                    const i32 j = S.Li[qb]; // target column r_b (in the bundle)
+                                    const i32 *jb = S.Li.data() + S.Lp[j], *je = S.Li.data() + S.Lp[j + 1];
+                                    for (i32 qa = qb; qa < ce; qa++) {
+                                        uint16_t tgt;
+                                        if (qa == qb) tgt = (uint16_t)(nE + (j - s0));
+                                        else tgt = (uint16_t)((std::lower_bound(jb, je, S.Li[qa]) - S.Li.data()) - e0);
+                                        lvl.push_back({(uint16_t)(qa - e0), (uint16_t)(qb - e0), (uint16_t)(k - s0), tgt});
+                                    }
+                                }
+                            }
+                            std::stable_sort(lvl.begin(), lvl.end(),
+                                             [](const std::array<uint16_t, 4> &x, const std::array<uint16_t, 4> &y) { return x[3] < y[3]; });
+                            for (const auto &r : lvl) {
+                                uint16_t *dst = S.fu_rec.data() + (size_t)out * 4;
+                                dst[0] = r[0];
+                                dst[1] = r[1];
+                                dst[2] = r[2];
+                                dst[3] = r[3];
+                                out++;
+                            }
+                        }
+                        S.fu_ptr[lb0 + nl] = (i32)out; // (== bcount[b + 1]: also the first range of the next bundle)
+                        // where the U entries land: row j of U = (diagonal, entries (j, i) to ancestors i) -> slot of row i in column j
+                        for (i32 j = s0; j < s1; j++) {
+                            const i32 *jb = S.Li.data() + S.Lp[j], *je = S.Li.data() + S.Lp[j + 1];
+                            for (i32 u = S.Up[j] + 1; u < S.Up[j + 1]; u++)
+                                S.fu_slot[u] = (uint16_t)((std::lower_bound(jb, je, S.Ucol[u]) - S.Li.data()) - e0);
+                        }
+                    }
+                });
             }
         }
     }

@@ -1022,7 +1022,20 @@ __global__ __launch_bounds__(FFWG) void k_bundle_factor_flat(LdlView v, BundleVi
     __syncthreads();
     typedef unsigned short fu_v4 __attribute__((ext_vector_type(4)));
     const fu_v4 *rec = (const fu_v4 *)v.fu_rec;
+    constexpr int FU = 8; // records in flight per thread
     for (int l = 0; l < nl; ++l) {
+        const int rb = tp[l], re = tp[l + 1];
+        // the level's first records are requested BEFORE its columns are finalised: they are index data
+        fu_v4 r[FU];
+        auto request = [&](int base) {
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int t = base + u * FFWG + tid;
+                if (t < re) r[u] = rec[t];
+                else r[u] = fu_v4{0, 0, 0, 0xFFFF};
+            }
+        };
+        request(rb);
         // the level's columns are final: pivot rule, scale
         for (int j = lv[l] + tid; j < lv[l + 1]; j += FFWG) {
             const int cb = v.Lp[j] - e0, ce = v.Lp[j + 1] - e0;
@@ -1032,17 +1045,10 @@ __global__ __launch_bounds__(FFWG) void k_bundle_factor_flat(LdlView v, BundleVi
             for (int q = cb; q < ce; ++q) Ls[q] *= dinv;
         }
         __syncthreads();
-        const int rb = tp[l], re = tp[l + 1];
-        for (int base = rb; base < re; base += FFWG * 4) { // (wave-uniform bounds: lds_scatter_add is cross-lane)
-            fu_v4 r[4];
+        for (int base = rb; base < re; base += FFWG * FU) { // (wave-uniform bounds: lds_scatter_add is cross-lane)
+            if (base != rb) request(base);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = base + u * FFWG + tid;
-                if (t < re) r[u] = rec[t];
-                else r[u] = fu_v4{0, 0, 0, 0xFFFF};
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < FU; ++u) {
                 const bool ok = r[u].w != 0xFFFFu;
                 const double val = ok ? Ls[r[u].x] * (Ls[r[u].y] * Ds[r[u].z]) : 0.0;
                 lds_scatter_add(Ls, ok ? (int)r[u].w : -1, -val);

@@ -245,7 +245,12 @@ def mt_leg(w, ko):
         # reference solution of the first right-hand side: the oracle's own factorisation (already done by the caller)
         ok_ref, x_ref = ko.solve_full(bs[0])
         Kp, Ki, Kx = np.asarray(ko.kkt.colptr), np.asarray(ko.kkt.rowval), np.asarray(ko.kkt.nzval)
-        for threads in sorted({1, 4, 16, 64, ncpu} & set(range(1, ncpu + 1))):
+        t_leg = time.perf_counter()
+        for threads in sorted({1, 4, 16, 64} & set(range(1, ncpu + 1))):
+            # (bounded: more threads are tried only while they pay and the leg stays within ~30 s -- on the GPU box's
+            # 256-core host the 64- and 256-thread passes once took minutes)
+            if best is not None and (time.perf_counter() - t_leg > 20.0 or best["threads"] * 4 < threads):
+                break
             mt = ldl_mt.LdlMT(orc, ko, w.ks.perm, threads)
             Ax = mt.values()
             perm = mt.perm

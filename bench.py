@@ -246,10 +246,11 @@ def mt_leg(w, ko):
         ok_ref, x_ref = ko.solve_full(bs[0])
         Kp, Ki, Kx = np.asarray(ko.kkt.colptr), np.asarray(ko.kkt.rowval), np.asarray(ko.kkt.nzval)
         t_leg = time.perf_counter()
-        for threads in sorted({1, 4, 16, 64} & set(range(1, ncpu + 1))):
-            # (bounded: more threads are tried only while they pay and the leg stays within ~30 s -- on the GPU box's
-            # 256-core host the 64- and 256-thread passes once took minutes)
-            if best is not None and (time.perf_counter() - t_leg > 20.0 or best["threads"] * 4 < threads):
+        prev = None
+        for threads in [t for t in (1, 4, 16, 32) if t <= ncpu]:
+            # (bounded: more threads are tried only while they pay and the leg stays within ~20 s -- on the GPU box's
+            # 256-core host the 64- and 256-thread passes once took minutes and lost to 16 threads)
+            if prev is not None and (time.perf_counter() - t_leg > 20.0 or best is not prev):
                 break
             mt = ldl_mt.LdlMT(orc, ko, w.ks.perm, threads)
             Ax = mt.values()
@@ -282,6 +283,7 @@ def mt_leg(w, ko):
             cand = {"value": round(1.0 / el, 4), "threads": threads, "rel_err_vs_oracle_solution": err, "factor_ok": bool(okf)}
             if best is None or cand["value"] > best["value"]:
                 best = cand
+            prev = cand
             del mt
         return {"value": best["value"], "unit": "iterations/s", "cores": best["threads"],
                 "kind": "port-mt (oracle/ldl_mt.c: the qdldl column algorithm with the columns of an elimination-tree level "

@@ -2804,6 +2804,7 @@ __device__ __forceinline__ int ir_arrive_nowait(int *ctl, int gen, int nwg) {
 }
 __device__ __forceinline__ int ir_wait_word(const int *word, int gen) {
     __shared__ int s_state3;
+    __syncthreads(); // (every thread has read the verdict of a previous call)
     if (threadIdx.x == 0) {
         int state = IR_WAITED;
         long long spins = 0;

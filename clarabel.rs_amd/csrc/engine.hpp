@@ -82,7 +82,7 @@ struct Engine {
     DeviceLists snx, fwu, bwu;
     double *Rfx = nullptr; // values of L at the filtered row lists (refreshed per refactor)
     int nRf = 0, sn_nbmax = 0;
-    int *sn_geo = nullptr, *sn_ptr = nullptr, *sn_col = nullptr, *sn_order = nullptr, *Rf_p = nullptr, *Rf_col = nullptr,
+    int *sn_geo = nullptr, *sn_cb = nullptr, *sn_ptr = nullptr, *sn_col = nullptr, *sn_order = nullptr, *Rf_p = nullptr, *Rf_col = nullptr,
         *Rf_pos = nullptr, *upd_slot = nullptr;
     long long *upd_ptr = nullptr;
     std::vector<i32> sn_lvl_ptr, sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax, h_sn_ptr, h_sn_col;

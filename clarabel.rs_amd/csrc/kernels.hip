@@ -1469,12 +1469,14 @@ template <bool FWDMODE> __device__ __forceinline__ double snode_block_solve(cons
 
 struct SnodeGeom {
     const int *cols;
+    const int *cb; // column bases of the panel (host-computed: Lp[cols[t]] - t - 1)
     int w, nb, h, e;
 };
 __device__ __forceinline__ SnodeGeom snode_geom(const LdlView &v, const SnodeView &sv, int sn) {
     SnodeGeom g;
     const int p0 = sv.sn_ptr[sn], p1 = sv.sn_ptr[sn + 1];
     g.cols = sv.sn_col + p0;
+    g.cb = sv.sn_cb + p0;
     g.w = p1 - p0;
     g.e = sv.sn_geo[2 * sn];
     g.nb = sv.sn_geo[2 * sn + 1];
@@ -1616,7 +1618,7 @@ __global__ __launch_bounds__(SN_WG) void k_snode_update(LdlView v, SnodeView sv,
     const int nchunks = (j0 + SN_KC - 1) / SN_KC, ns = (int)gridDim.z;
     const int c0 = (int)(((long long)nchunks * blockIdx.z) / ns), c1 = (int)(((long long)nchunks * (blockIdx.z + 1)) / ns);
     if (c0 >= c1) return;
-    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = v.Lp[g.cols[t]] - t - 1;
+    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
     snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), min(j0, c1 * SN_KC), row_begin, c0 * SN_KC,
                        ns > 1);
 }
@@ -1631,7 +1633,7 @@ __global__ __launch_bounds__(SN_WG) void k_snode_extend(LdlView v, SnodeView sv,
     if (c0 >= g.nb) return;
     const int row_begin = g.w + c0 + (int)blockIdx.x * SN_ROWS;
     if (row_begin >= g.h) return;
-    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = v.Lp[g.cols[t]] - t - 1;
+    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
     snode_tiles<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SN_NB, g.nb - c0), g.w, row_begin);
 }
 // grid (supernodes of the level): the SN_NB x SN_NB diagonal block of block column b, right-looking, the
@@ -1658,7 +1660,7 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, 
     const bool live = i < nbw;
     if (tid < SN_NB) {
         const int c = tid < nbw ? g.cols[j0 + tid] : 0;
-        colbase[tid] = tid < nbw ? v.Lp[c] - (j0 + tid) - 1 : 0;
+        colbase[tid] = tid < nbw ? g.cb[j0 + tid] : 0;
         sgn[tid] = tid < nbw ? (double)v.dsigns[c] : 1.0; // (rows beyond a narrow last block: an identity)
     }
     __syncthreads();
@@ -1745,7 +1747,7 @@ __global__ __launch_bounds__(SN_RWG) void k_snode_rows(LdlView v, SnodeView sv, 
     {
         const bool in = tid < nbw; // (a narrow last block is padded with an identity)
         const int c = in ? g.cols[j0 + tid] : 0;
-        colbase[tid] = in ? v.Lp[c] - (j0 + tid) - 1 : 0;
+        colbase[tid] = in ? g.cb[j0 + tid] : 0;
         dinvl[tid] = in ? v.Dinv[c] : 1.0;
         dl[tid] = in ? v.D[c] : 0.0;
     }
@@ -1838,7 +1840,7 @@ __global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, co
     const bool ldsB = g.nb <= nbcap;
     const int hrows = with_B ? g.h : g.w;
     for (int t = tid; t < g.w; t += SN_WG) {
-        L.colbase[t] = v.Lp[g.cols[t]] - t - 1;
+        L.colbase[t] = g.cb[t];
         L.xs[t] = x[g.cols[t]];
     }
     if (ldsB && with_B)
@@ -1899,7 +1901,7 @@ __global__ __launch_bounds__(SN_WG) void k_snode_push(LdlView v, SnodeView sv, c
     if (tid < nt) {
         const int c = g.cols[t0 + tid];
         xs[tid] = x[c];
-        cb[tid] = v.Lp[c] - (t0 + tid) - 1 + g.w; // + panel row w + r
+        cb[tid] = g.cb[t0 + tid] + g.w; // + panel row w + r
     }
     __syncthreads();
     const int r = r0 + tid;
@@ -1938,7 +1940,7 @@ __global__ __launch_bounds__(SN_WG) void k_snode_pull(LdlView v, SnodeView sv, c
     const int nt = min(SN_NB, g.w - t0);
     for (int tt = wave; tt < nt; tt += SN_WG / 64) {
         const int t = t0 + tt, c = g.cols[t];
-        const int base = v.Lp[c] - t - 1 + g.w;
+        const int base = g.cb[t] + g.w;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         auto xat = [&](int r) { return ldsB ? xB[r] : x[Bn[r]]; };
         int r = lane;
@@ -1966,7 +1968,7 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
     const int hrows = with_B ? g.h : g.w;
     for (int t = tid; t < g.w; t += SN_WG) {
         const int c = g.cols[t];
-        L.colbase[t] = v.Lp[c] - t - 1;
+        L.colbase[t] = g.cb[t];
         L.xs[t] = with_B ? x[c] * v.Dinv[c] : x[c]; // (k_snode_pull has applied D^-1 already)
     }
     if (ldsB && with_B)
@@ -2087,7 +2089,7 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
     constexpr int CPW = SN_NB / (SN2_WG / 64); // columns per wave: of block c (forward) / of the own block (backward)
     // nothing below depends on x: column bases, the diagonal block and the own entries are requested first
     const int cb_lo = FWDMODE ? 0 : j0, cb_hi = j0 + nbw;
-    for (int t = cb_lo + tid; t < cb_hi; t += SN2_WG) colbase[t - cb_lo] = v.Lp[g.cols[t]] - t - 1;
+    for (int t = cb_lo + tid; t < cb_hi; t += SN2_WG) colbase[t - cb_lo] = g.cb[t];
     double xown = (wave == 0 && lane < nbw) ? x[g.cols[j0 + lane]] : 0.0; // (last written before this launch)
     __syncthreads();
     const int *cbr = colbase + (FWDMODE ? j0 : 0); // column bases of the own block

@@ -182,6 +182,7 @@ struct SnodeView {
     const long long *upd_ptr; // per supernode: offset of its packed strict lower triangle of B x B in upd_slot
     const int *upd_slot;      // CSC slot of L(B[r], B[c]), r > c  (nullptr: no dense ancestor updates)
     const int *sn_geo;        // per supernode: (last member column e, rows of B = |struct(e)|) -- saves two dependent loads
+    const int *sn_cb;         // per member (parallel to sn_col): Lp[c_t] - t - 1, the base of panel column t (entry (i, t) at cb + i)
 };
 int snode_kernel_attributes(int wmax, int nbmax);
 

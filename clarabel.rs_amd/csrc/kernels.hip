@@ -1435,7 +1435,7 @@ __global__ __launch_bounds__(WG) void k_factor_finalize(LdlView v, const int *__
 // ---------------------------------------------------------------------------
 constexpr int SN_NB = 64;
 constexpr int SN_KC = 128;  // 64 * 128 * 8 = 64 KiB
-constexpr int SN_U = 8;     // A operands requested ahead of the matrix instructions that consume them
+constexpr int SN_U = 4;     // k-groups of A operands in flight per lane (x 2 tiles; 8 needs more than 128 registers)
 constexpr int SN_WST = 8;   // loads in flight per thread while the LDS operand is staged
 constexpr int SN_WG = 512;
 constexpr int SN_ROWS = 256; // panel rows per workgroup of the update kernels: 8 waves x 2 tiles of 16
@@ -1485,8 +1485,21 @@ __device__ __forceinline__ SnodeGeom snode_geom(const LdlView &v, const SnodeVie
 }
 
 // acc[2][4] += L[rows of this wave's two tiles, k0..kend) * (d L[jrow0.., k])' ; emit per element.
-// EXTEND = false: targets are the supernode's own block column (plain stores, each element owned by
-// one lane); true: the ancestors' columns through upd_slot (atomics).
+// EXTEND = false: targets are the supernode's own block column (each element owned by one lane unless the k
+// range is split: atomic_emit); true: the ancestors' columns through upd_slot (atomics).
+//
+// Round 3 (the launch ran at 0.17 of the f64 matrix peak, one workgroup per CU):
+//  * 128 registers per lane, so that TWO workgroups share a CU (four waves per SIMD): one stages its (d L)'
+//    operand while the other multiplies.  The A operands are no longer double buffered in registers -- the
+//    entries of k-group g + 1 are requested INTO the registers of group g right after the matrix instructions
+//    that read them, SN_U groups of loads in flight per lane;
+//  * the A loads are unconditional: rows beyond the panel and columns beyond the chunk are clamped to valid
+//    entries (their products meet stored zeros of the LDS operand, or rows that are never emitted) -- the
+//    predicated form compiled to a branch and an LDS round trip per load;
+//  * the result leaves through LDS, transposed: the matrix instruction leaves a lane with ONE column of the tile
+//    (16 columns per instruction, 32 bytes of each cache line), the panel is column-major, so every emitted
+//    instruction touched 16 lines -- now a lane owns a ROW, an instruction covers four columns x 16 consecutive
+//    rows (128-byte runs), and the slot indices of the ancestor update are read the same way.
 template <bool EXTEND>
 __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &sv, const SnodeGeom &g, int sn,
                                             const int *colbase, double *Wl, int jrow0, int ncols, int kend,
@@ -1495,105 +1508,142 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
     const int kq = lane >> 4, l15 = lane & 15;
     __shared__ double dk[SN_KC];
     const int i0[2] = {row_begin + wave * 32, row_begin + wave * 32 + 16};
-    const int irow[2] = {i0[0] + l15, i0[1] + l15};
-    const bool rowok[2] = {irow[0] < g.h, irow[1] < g.h};
+    // (clamped: a row beyond the panel reads the last row, its results are not emitted)
+    const int irc[2] = {min(i0[0] + l15, g.h - 1), min(i0[1] + l15, g.h - 1)};
     snode_v4d acc[2][SN_NB / 16];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int c = 0; c < SN_NB / 16; ++c) acc[t][c] = snode_v4d{0.0, 0.0, 0.0, 0.0};
+    // the A operands are one stream of k-groups (4 SN_U columns each) over the whole k range, chunk boundaries
+    // included: group g + 1 is requested into the registers of group g as they are released, unconditionally
+    // (beyond the range: clamped, never used), so that the number of loads in flight is a constant the
+    // compiler can count (a conditional request made it wait for ALL loads at the head of every group)
+    double a[2][SN_U];
+    const bool wave_live = i0[0] < g.h; // (wave uniform)
+    auto request = [&](int u, int kabs) { // two independent 4 x 128-byte runs
+        const int cb = colbase[min(kabs + 4 * u + kq, kend - 1)];
+        a[0][u] = v.Lx[cb + irc[0]];
+        a[1][u] = v.Lx[cb + irc[1]];
+    };
+    __syncthreads(); // (the caller has just filled colbase)
+    if (wave_live && kbeg < kend) {
+#pragma unroll
+        for (int u = 0; u < SN_U; ++u) request(u, kbeg);
+    }
     for (int kc0 = kbeg; kc0 < kend; kc0 += SN_KC) {
         const int kcn = min(SN_KC, kend - kc0);
-        const int kcn4 = (kcn + 3) & ~3;
+        const int kcnu = (kcn + 4 * SN_U - 1) / (4 * SN_U) * (4 * SN_U); // whole groups: the tail rows of the operand are zeros
         __syncthreads(); // the previous chunk has been consumed
         // the chunk's pivots first (one round trip), then the (d_k L[j,k]) operand with SN_WST loads in flight
         // per thread (as a plain loop every round was cols -> D and Lx -> LDS, two dependent global round
         // trips, 16 rounds per chunk: longer than the chunk's matrix instructions)
         if (tid < kcn) dk[tid] = v.D[g.cols[kc0 + tid]];
         __syncthreads();
-        for (int base = 0; base < kcn4 * SN_NB; base += SN_WST * SN_WG) {
+        // (a wave stages whole k rows -- lane = column of the block --: the column base and the pivot of a row
+        // are wave-uniform LDS reads, and nothing per-load is worth hoisting into registers)
+        for (int kr = wave; kr < kcnu; kr += SN_WST * (SN_WG / 64)) {
             double wv[SN_WST];
 #pragma unroll
             for (int r = 0; r < SN_WST; ++r) {
-                const int idx = base + r * SN_WG + tid, kk = idx / SN_NB, jj = idx % SN_NB;
-                wv[r] = (kk < kcn && jj < ncols) ? v.Lx[colbase[kc0 + kk] + jrow0 + jj] : 0.0;
+                const int kk = kr + r * (SN_WG / 64);
+                wv[r] = v.Lx[colbase[kc0 + min(kk, kcn - 1)] + jrow0 + min(lane, ncols - 1)]; // (clamped: no branch per load)
             }
 #pragma unroll
             for (int r = 0; r < SN_WST; ++r) {
-                const int idx = base + r * SN_WG + tid, kk = idx / SN_NB;
-                if (idx < kcn4 * SN_NB) Wl[idx] = kk < kcn ? wv[r] * dk[kk] : 0.0;
+                const int kk = kr + r * (SN_WG / 64);
+                if (kk < kcnu) Wl[kk * SN_NB + lane] = (kk < kcn && lane < ncols) ? wv[r] * dk[kk] : 0.0;
             }
         }
         __syncthreads();
-        if (i0[0] >= g.h) continue; // (after the barriers: the whole wave is beyond the panel)
-        // software pipeline: the A operands of the NEXT group of 4*SN_U columns are requested before the
-        // matrix instructions of the current group are issued
-        double a[2][SN_U], an[2][SN_U];
-        auto request = [&](double(&dst)[2][SN_U], int kk) {
+        if (!wave_live) continue; // (after the barriers: the whole wave is beyond the panel)
+        for (int kk = 0; kk < kcnu; kk += 4 * SN_U) {
+            const int knext = kk + 4 * SN_U < kcnu ? kc0 + kk + 4 * SN_U : kc0 + SN_KC; // (the next chunk's first group)
 #pragma unroll
-            for (int u = 0; u < SN_U; ++u) { // independent 128-byte runs in flight
+            for (int u = 0; u < SN_U; ++u) {
                 const int kl = kk + 4 * u + kq;
-                const bool kok = kl < kcn;
-                const int cb = kok ? colbase[kc0 + kl] : 0;
-                dst[0][u] = (kok && rowok[0]) ? v.Lx[cb + irow[0]] : 0.0;
-                dst[1][u] = (kok && rowok[1]) ? v.Lx[cb + irow[1]] : 0.0;
+#pragma unroll
+                for (int c = 0; c < SN_NB / 16; ++c) {
+                    const double bw = Wl[kl * SN_NB + 16 * c + l15];
+                    acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][u], bw, acc[0][c], 0, 0, 0);
+                    acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][u], bw, acc[1][c], 0, 0, 0);
+                }
+                request(u, knext);
             }
-        };
-        request(an, 0);
-        for (int kk = 0; kk < kcn4; kk += 4 * SN_U) {
+        }
+    }
+    // ---- emit through LDS: this wave's 16 x 64 tile in its own 8 KiB of the (now free) operand buffer, element
+    //      (row rr, column jj) at jj * 16 + (rr ^ (jj & 15)) -- the swizzle keeps both the column-per-lane writes
+    //      and the row-per-lane reads off common banks
+    __syncthreads();
+    if (i0[0] >= g.h) return;
+    double *Tw = Wl + wave * (16 * SN_NB);
+    const int *Bn = v.Li + v.Lp[g.e]; // node ids of the rows of B
+    const long long ubase = EXTEND ? sv.upd_ptr[sn] : 0;
 #pragma unroll
-            for (int u = 0; u < SN_U; ++u) {
-                a[0][u] = an[0][u];
-                a[1][u] = an[1][u];
+    for (int t = 0; t < 2; ++t) {
+        if (t == 1) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < SN_NB / 16; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = l15 + 16 * c, rr = kq + 4 * r;
+                Tw[jj * 16 + (rr ^ l15)] = acc[t][c][r];
             }
-            if (kk + 4 * SN_U < kcn4) request(an, kk + 4 * SN_U);
+        __builtin_amdgcn_wave_barrier();
+        const int i = i0[t] + l15; // lane = row of the tile; an instruction covers columns 4 m + kq
+        if (i0[t] >= g.h) break;
+        const int rB = i - g.w;
 #pragma unroll
-            for (int u = 0; u < SN_U; ++u) {
-                if (kk + 4 * u < kcn4) {
-                    const int kl = kk + 4 * u + kq;
+        for (int m0 = 0; m0 < 16; m0 += 8) { // (eight at a time: registers)
+            double val[8];
 #pragma unroll
-                    for (int c = 0; c < SN_NB / 16; ++c) {
-                        const double bw = Wl[kl * SN_NB + 16 * c + l15];
-                        acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][u], bw, acc[0][c], 0, 0, 0);
-                        acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][u], bw, acc[1][c], 0, 0, 0);
+            for (int m = 0; m < 8; ++m) {
+                const int jj = 4 * (m0 + m) + kq;
+                val[m] = Tw[jj * 16 + (l15 ^ (jj & 15))];
+            }
+            if (i >= g.h) continue;
+            if (!EXTEND) {
+                if (atomic_emit) { // split-k: several workgroups share the element
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int jj = 4 * (m0 + m) + kq, j = jrow0 + jj;
+                        if (jj >= ncols) continue;
+                        if (i > j) atomicAdd(&v.Lx[colbase[j] + i], -val[m]);
+                        else if (i == j) atomicAdd(&v.D[g.cols[j]], -val[m]);
                     }
+                } else {
+                    double cur[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) { // (the eight reads together, then the eight writes)
+                        const int jj = 4 * (m0 + m) + kq, j = jrow0 + jj;
+                        cur[m] = (jj < ncols && i > j) ? v.Lx[colbase[j] + i] : 0.0;
+                    }
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int jj = 4 * (m0 + m) + kq, j = jrow0 + jj;
+                        if (jj >= ncols) continue;
+                        if (i > j) v.Lx[colbase[j] + i] = cur[m] - val[m];
+                        else if (i == j) v.D[g.cols[j]] -= val[m];
+                    }
+                }
+            } else {
+                int slot[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { // (consecutive rows of one column: consecutive slots)
+                    const int jj = 4 * (m0 + m) + kq, cB = jrow0 + jj - g.w;
+                    const bool lower = jj < ncols && rB > cB;
+                    slot[m] = lower ? sv.upd_slot[ubase + (long long)cB * g.nb - (long long)cB * (cB + 1) / 2 + (rB - cB - 1)] : -1;
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int jj = 4 * (m0 + m) + kq, cB = jrow0 + jj - g.w;
+                    if (slot[m] >= 0) atomicAdd(&v.Lx[slot[m]], -val[m]);
+                    else if (jj < ncols && rB == cB) atomicAdd(&v.D[Bn[cB]], -val[m]);
                 }
             }
         }
     }
-    const int *Bn = v.Li + v.Lp[g.e]; // node ids of the rows of B
-    const long long ubase = EXTEND ? sv.upd_ptr[sn] : 0;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0[t] + kq + 4 * r;
-            if (i >= g.h) continue;
-#pragma unroll
-            for (int c = 0; c < SN_NB / 16; ++c) {
-                const int jj = l15 + 16 * c;
-                if (jj >= ncols) continue;
-                const int j = jrow0 + jj;
-                const double val = acc[t][c][r];
-                if (!EXTEND) {
-                    if (atomic_emit) { // split-k: several workgroups share the element
-                        if (i > j) atomicAdd(&v.Lx[colbase[j] + i], -val);
-                        else if (i == j) atomicAdd(&v.D[g.cols[j]], -val);
-                    } else {
-                        if (i > j) v.Lx[colbase[j] + i] -= val;
-                        else if (i == j) v.D[g.cols[j]] -= val;
-                    }
-                } else {
-                    const int rB = i - g.w, cB = j - g.w;
-                    if (rB > cB) {
-                        const long long u = ubase + (long long)cB * g.nb - (long long)cB * (cB + 1) / 2 + (rB - cB - 1);
-                        atomicAdd(&v.Lx[sv.upd_slot[u]], -val);
-                    } else if (rB == cB) {
-                        atomicAdd(&v.D[Bn[cB]], -val);
-                    }
-                }
-            }
-        }
 }
 
 __device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
@@ -1603,7 +1653,7 @@ __device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
 // grid (row groups, supernodes of the level, k splits): with few workgroups in flight (the narrow
 // levels near the root) the finished columns are divided among gridDim.z workgroups per tile group,
 // which then meet in fp64 atomics
-__global__ __launch_bounds__(SN_WG) void k_snode_update(LdlView v, SnodeView sv, const int *__restrict__ order,
+__global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_update(LdlView v, SnodeView sv, const int *__restrict__ order,
                                                         int b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
@@ -1623,7 +1673,7 @@ __global__ __launch_bounds__(SN_WG) void k_snode_update(LdlView v, SnodeView sv,
                        ns > 1);
 }
 // grid (row groups, column blocks of B, supernodes of the level)
-__global__ __launch_bounds__(SN_WG) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order) {
+__global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
     int *colbase = snode_lds(smem, Wl);

@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(WG) void k_factor_finalize(LdlView v, const int *__
 constexpr int SN_NB = 64;
 constexpr int SN_KC = 128;  // 64 * 128 * 8 = 64 KiB
 constexpr int SN_U = 4;     // k-groups of A operands in flight per lane (x 2 tiles; 8 needs more than 128 registers)
-constexpr int SN_WST = 8;   // loads in flight per thread while the LDS operand is staged
+constexpr int SN_WST = 4;   // k rows (entry + pivot) in flight per thread while the LDS operand is staged
 constexpr int SN_WG = 512;
 constexpr int SN_ROWS = 256; // panel rows per workgroup of the update kernels: 8 waves x 2 tiles of 16
 typedef double snode_v4d __attribute__((ext_vector_type(4)));
@@ -1470,6 +1470,7 @@ template <bool FWDMODE> __device__ __forceinline__ double snode_block_solve(cons
 struct SnodeGeom {
     const int *cols;
     const int *cb; // column bases of the panel (host-computed: Lp[cols[t]] - t - 1)
+    double *d;     // pivots of the members, packed (k_snode_diag)
     int w, nb, h, e;
 };
 __device__ __forceinline__ SnodeGeom snode_geom(const LdlView &v, const SnodeView &sv, int sn) {
@@ -1477,6 +1478,7 @@ __device__ __forceinline__ SnodeGeom snode_geom(const LdlView &v, const SnodeVie
     const int p0 = sv.sn_ptr[sn], p1 = sv.sn_ptr[sn + 1];
     g.cols = sv.sn_col + p0;
     g.cb = sv.sn_cb + p0;
+    g.d = sv.sn_d + p0;
     g.w = p1 - p0;
     g.e = sv.sn_geo[2 * sn];
     g.nb = sv.sn_geo[2 * sn + 1];
@@ -1506,7 +1508,6 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
                                             int row_begin, int kbeg = 0, bool atomic_emit = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, l15 = lane & 15;
-    __shared__ double dk[SN_KC];
     const int i0[2] = {row_begin + wave * 32, row_begin + wave * 32 + 16};
     // (clamped: a row beyond the panel reads the last row, its results are not emitted)
     const int irc[2] = {min(i0[0] + l15, g.h - 1), min(i0[1] + l15, g.h - 1)};
@@ -1535,24 +1536,22 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
         const int kcn = min(SN_KC, kend - kc0);
         const int kcnu = (kcn + 4 * SN_U - 1) / (4 * SN_U) * (4 * SN_U); // whole groups: the tail rows of the operand are zeros
         __syncthreads(); // the previous chunk has been consumed
-        // the chunk's pivots first (one round trip), then the (d_k L[j,k]) operand with SN_WST loads in flight
-        // per thread (as a plain loop every round was cols -> D and Lx -> LDS, two dependent global round
-        // trips, 16 rounds per chunk: longer than the chunk's matrix instructions)
-        if (tid < kcn) dk[tid] = v.D[g.cols[kc0 + tid]];
-        __syncthreads();
-        // (a wave stages whole k rows -- lane = column of the block --: the column base and the pivot of a row
-        // are wave-uniform LDS reads, and nothing per-load is worth hoisting into registers)
+        // the (d_k L[j,k]) operand: a wave stages whole k rows -- lane = column of the block --, SN_WST rows in
+        // flight; the column base is a wave-uniform LDS read and the pivot a wave-uniform load from the packed
+        // pivots (SnodeView::sn_d), issued together with the entry it scales: ONE global round trip per batch
+        // (round 2: cols -> D -> LDS, a barrier, then the entries)
         for (int kr = wave; kr < kcnu; kr += SN_WST * (SN_WG / 64)) {
-            double wv[SN_WST];
+            double wv[SN_WST], dv[SN_WST];
 #pragma unroll
             for (int r = 0; r < SN_WST; ++r) {
-                const int kk = kr + r * (SN_WG / 64);
-                wv[r] = v.Lx[colbase[kc0 + min(kk, kcn - 1)] + jrow0 + min(lane, ncols - 1)]; // (clamped: no branch per load)
+                const int kk = min(kr + r * (SN_WG / 64), kcn - 1); // (clamped: no branch per load)
+                wv[r] = v.Lx[colbase[kc0 + kk] + jrow0 + min(lane, ncols - 1)];
+                dv[r] = g.d[kc0 + kk];
             }
 #pragma unroll
             for (int r = 0; r < SN_WST; ++r) {
                 const int kk = kr + r * (SN_WG / 64);
-                if (kk < kcnu) Wl[kk * SN_NB + lane] = (kk < kcn && lane < ncols) ? wv[r] * dk[kk] : 0.0;
+                if (kk < kcnu) Wl[kk * SN_NB + lane] = (kk < kcn && lane < ncols) ? wv[r] * dv[r] : 0.0;
             }
         }
         __syncthreads();
@@ -1664,13 +1663,12 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     if (j0 >= g.w) return;
     const int row_begin = j0 + (int)blockIdx.x * SN_ROWS;
     if (row_begin >= g.h) return;
-    // this split's share of the k range, in whole LDS chunks
-    const int nchunks = (j0 + SN_KC - 1) / SN_KC, ns = (int)gridDim.z;
-    const int c0 = (int)(((long long)nchunks * blockIdx.z) / ns), c1 = (int)(((long long)nchunks * (blockIdx.z + 1)) / ns);
+    // this split's share of the k range, in units of one block column (j0 is a multiple of SN_NB)
+    const int nunits = j0 / SN_NB, ns = (int)gridDim.z;
+    const int c0 = (int)(((long long)nunits * blockIdx.z) / ns), c1 = (int)(((long long)nunits * (blockIdx.z + 1)) / ns);
     if (c0 >= c1) return;
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
-    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), min(j0, c1 * SN_KC), row_begin, c0 * SN_KC,
-                       ns > 1);
+    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), c1 * SN_NB, row_begin, c0 * SN_NB, ns > 1);
 }
 // grid (row groups, column blocks of B, supernodes of the level)
 __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order) {
@@ -1766,6 +1764,7 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, 
     }
     if (q == 0 && live) {
         v.D[ci] = dfin;
+        g.d[j0 + i] = dfin;
         v.Dinv[ci] = dinvfin;
         if (nreg) atomicAdd(&v.status[2], 1);
         if (bad & 2) v.status[1] = 1;
@@ -1852,6 +1851,167 @@ __global__ __launch_bounds__(SN_RWG) void k_snode_rows(LdlView v, SnodeView sv, 
         if (jj < nbw) v.Lx[colbase[jj] + i] = x[jj];
     // (no row-major mirror Rx for supernode columns: with supernodes the forward sweep of the top reads
     // the filtered lists Rfx -- non-member columns only -- and k_snode_fwd reads Lx itself)
+}
+
+// ---------------------------------------------------------------------------
+// Block column b of every supernode of a unit level in ONE launch (round 3; k_snode_diag + k_snode_rows were
+// two launches of ~28 + ~33 us whatever the size, most of it latency: 64 pivots one barrier apart, then the
+// coefficient block fetched again by every workgroup of the rows kernel).  Grid (groups of SNP_WG panel rows
+// below the block, supernodes), SNP_WG = 256 threads:
+//   1. EVERY workgroup factors the 64 x 64 diagonal block itself (redundantly: latency, not throughput, is what
+//      counts here; only group 0 writes it back).  Thread (row i = lane, quarter q = wave) holds the 16 entries
+//      (i, 16 q ..) of its row, unscaled (u), and a copy of the row's running diagonal.  The columns go in
+//      groups of SNP_CB = 4: the wave that owns a group factors its four columns by itself -- pivots and the
+//      six l(c', c) it needs across lanes by v_readlane, no barrier --, publishes their unscaled entries u
+//      (double buffered) and scaled entries l (Ll, which stays) plus the pivots in LDS; after ONE barrier
+//      every thread applies the four columns to its entries right of the group: 16 barriers per block instead
+//      of 64.  Per entry the subtractions are those of the reference's row solve (qdldl.rs:610-640), in its
+//      order: u_ic -= l_ck * u_ik for k = 0, 1, ... (the SCALED entry of row c times the UNSCALED entry of the
+//      own row); d_i = a_ii - sum_k u_ik l_ik (qdldl.rs:634); the sign rule of qdldl.rs:645-665 by all lanes;
+//   2. then its SNP_WG rows below the block, one row per thread, by the same recurrence against Ll (u_Rq is
+//      final after the columns < q; l_Rq = u_Rq / d_q on the way out).
+// ---------------------------------------------------------------------------
+constexpr int SNP_WG = 256;
+constexpr int SNP_CB = 4;
+__global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snode_panel(LdlView v, SnodeView sv, const int *__restrict__ order, int b) {
+    __shared__ __attribute__((aligned(16))) double Ll[SN_NB * SN_NB];        // Ll[k * 64 + i] = l(i, k), 0 for i <= k
+    __shared__ __attribute__((aligned(16))) double ucol[2][SNP_CB][SN_NB];   // unscaled entries of a group's columns (0 for i <= c)
+    __shared__ double dinvl[SN_NB], sgn[SN_NB];
+    __shared__ int colbase[SN_NB];
+    __shared__ int s_nreg, s_bad;
+    const int sn = order[blockIdx.y];
+    const SnodeGeom g = snode_geom(v, sv, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    const int row0 = j0 + nbw + (int)blockIdx.x * SNP_WG; // first of this group's rows below the block
+    if (blockIdx.x > 0 && row0 >= g.h) return;
+    const bool live = i < nbw;
+    if (tid < SN_NB) {
+        const int c = tid < nbw ? g.cols[j0 + tid] : 0;
+        colbase[tid] = g.cb[j0 + min(tid, nbw - 1)];
+        sgn[tid] = tid < nbw ? (double)v.dsigns[c] : 1.0; // (columns beyond a narrow last block: an identity)
+    }
+    if (tid == 0) {
+        s_nreg = 0;
+        s_bad = 0;
+    }
+    __syncthreads();
+    const int ci = live ? g.cols[j0 + i] : 0;
+    double di = live ? v.D[ci] : 1.0; // running diagonal entry of row i (kept by all four threads of the row)
+    double T[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int j = 16 * q + cc;
+        T[cc] = (live && j < nbw && i > j) ? v.Lx[colbase[j] + j0 + i] : 0.0;
+    }
+    double dfin = 1.0, dinvfin = 1.0; // pivot of row i, recorded by the owner of column i
+    int nreg = 0, bad = 0;
+    // the quarter loop stays rolled; the 16 columns of a quarter are unrolled, so T[..] are fixed registers
+    for (int qq = 0; qq < SN_NB / 16; ++qq) {
+#pragma unroll
+        for (int gc = 0; gc < 16; gc += SNP_CB) {
+            const int c0 = 16 * qq + gc, buf = (gc / SNP_CB) & 1;
+            if (q == qq) { // the owner: the group's columns among themselves
+#pragma unroll
+                for (int t = 0; t < SNP_CB; ++t) {
+                    const int c = c0 + t;
+                    double d = readlane_f64(di, c); // (c is wave uniform)
+                    const double sg = sgn[c];
+                    const bool reg = d * sg < v.reg_eps;
+                    if (reg) d = v.reg_delta * sg;
+                    const double dinv = 1.0 / d;
+                    if (i == c) {
+                        dfin = d;
+                        dinvfin = dinv;
+                        if (reg) nreg = 1;
+                        if (d == 0.0) bad |= 2;
+                        if (!isfinite(dinv)) bad |= 1;
+                    }
+                    const double uc = i > c ? T[gc + t] : 0.0;
+                    const double l = uc * dinv;
+                    di -= uc * l;
+                    T[gc + t] = i > c ? l : T[gc + t];
+                    ucol[buf][t][i] = uc;
+                    Ll[c * SN_NB + i] = l;
+                    if (i == 0) dinvl[c] = dinv;
+#pragma unroll
+                    for (int t2 = t + 1; t2 < SNP_CB; ++t2) // entry (i, c0 + t2) -= l(c0 + t2, c) u(i, c)
+                        T[gc + t2] -= readlane_f64(l, c0 + t2) * uc;
+                }
+            }
+            __syncthreads();
+            // everybody: the group's columns applied to the own entries right of the group (and to the copy of the
+            // running diagonal, which the owner has already updated)
+#pragma unroll
+            for (int t = 0; t < SNP_CB; ++t) {
+                const int c = c0 + t;
+                const double uc = ucol[buf][t][i];
+                if (q != qq) di -= uc * Ll[c * SN_NB + i];
+                if (q >= qq) { // (wave uniform; earlier quarters are finished)
+                    const snode_v2d *lr = (const snode_v2d *)&Ll[c * SN_NB + 16 * q];
+#pragma unroll
+                    for (int c2 = 0; c2 < 8; ++c2) {
+                        const snode_v2d pr = lr[c2]; // l(16 q + 2 c2, c), l(16 q + 2 c2 + 1, c): zero up to the diagonal
+                        if (q > qq || 2 * c2 >= gc + SNP_CB) T[2 * c2] -= pr.x * uc;
+                        if (q > qq || 2 * c2 + 1 >= gc + SNP_CB) T[2 * c2 + 1] -= pr.y * uc;
+                    }
+                }
+            }
+        }
+    }
+    if (nreg) atomicAdd(&s_nreg, 1);
+    if (bad) atomicOr(&s_bad, bad);
+    __syncthreads(); // (also: Ll and dinvl are complete)
+    if (blockIdx.x == 0) {
+        if (q == i / 16 && live) { // the owner of column i
+            v.D[ci] = dfin;
+            v.Dinv[ci] = dinvfin;
+            g.d[j0 + i] = dfin;
+        }
+        if (tid == 0) {
+            if (s_nreg) atomicAdd(&v.status[2], s_nreg);
+            if (s_bad & 2) v.status[1] = 1;
+            if (s_bad & 1) v.status[0] = 1;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int j = 16 * q + cc;
+            if (live && j < nbw && i > j) v.Lx[colbase[j] + j0 + i] = T[cc];
+        }
+    }
+    if (row0 >= g.h) return;
+    // ---- the rows below the block: thread = row, its 64 entries in registers, right-looking (the products of one
+    //      column are independent; per entry the subtractions happen in the order k = 0, 1, ... of qdldl.rs:610-640).
+    //      (Measured and dropped: the same recurrence blocked by 16 columns with one rolled code body -- 30 KB of
+    //      code instead of 75 KB --: 57.5 us per launch against 55; the launch is not bound by instruction fetch.)
+    const int R = row0 + tid;
+    const bool rowok = R < g.h;
+    const int Rc = rowok ? R : g.h - 1; // (unconditional loads from a valid row)
+    double x[SN_NB];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = v.Lx[colbase[jj] + Rc];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = jj < nbw ? x[jj] : 0.0;
+#pragma unroll
+    for (int k = 0; k < SN_NB; ++k) {
+        const double uq = x[k];
+        // (an opaque zero that "depends" on u_q ties this column's LDS reads to its place in the chain: left
+        // alone the compiler reads all 1024 coefficient pairs before the first product and spills them)
+        int zoff;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(uq)));
+        const snode_v2d *cf = (const snode_v2d *)&Ll[k * SN_NB + zoff];
+#pragma unroll
+        for (int p2 = (k + 1) / 2; p2 < SN_NB / 2; ++p2) {
+            const snode_v2d cc = cf[p2];
+            x[2 * p2] -= cc.x * uq;
+            x[2 * p2 + 1] -= cc.y * uq;
+        }
+    }
+    if (!rowok) return;
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj)
+        if (jj < nbw) v.Lx[colbase[jj] + R] = x[jj] * dinvl[jj];
 }
 
 // Substitutions through a chain supernode, one workgroup per supernode of the unit level, the
@@ -6319,15 +6479,26 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const i
         if (b > 0) {
             const int rows = hmax - b * SN_NB;
             if (rows > 0) {
-                const int groups = (rows + SN_ROWS - 1) / SN_ROWS, nchunks = (b * SN_NB + SN_KC - 1) / SN_KC;
-                int ksplit = 1; // fill the chip when the level has few supernodes
+                const int groups = (rows + SN_ROWS - 1) / SN_ROWS;
+                int ksplit = 1; // fill the chip when the level has few supernodes: the finished columns in shares of whole block columns
                 // (CHIP_NO_SPLITK: no split -> no fp64 atomics between the splits, a fixed summation order)
                 static const bool no_splitk = std::getenv("CHIP_NO_SPLITK") != nullptr;
-                while (!no_splitk && ksplit < 8 && ksplit * 2 <= nchunks && groups * count * ksplit < 512) ksplit *= 2;
+                static const int split_target = std::getenv("CHIP_SN_SPLIT_TARGET") ? std::atoi(std::getenv("CHIP_SN_SPLIT_TARGET")) : 256;
+                static const int split_max = std::getenv("CHIP_SN_SPLIT_MAX") ? std::atoi(std::getenv("CHIP_SN_SPLIT_MAX")) : 8;
+                static const int split_unit = std::getenv("CHIP_SN_SPLIT_UNIT") ? std::atoi(std::getenv("CHIP_SN_SPLIT_UNIT")) : 1; // block columns per share, at least
+                while (!no_splitk && ksplit < split_max && ksplit * 2 * split_unit <= b && groups * count * ksplit < split_target) ksplit *= 2;
                 pb(PFK_SN_UPDATE);
                 k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b);
                 pe(PFK_SN_UPDATE);
             }
+        }
+        static const bool no_panel = std::getenv("CHIP_NO_SNODE_PANEL") != nullptr;
+        if (!no_panel) { // the diagonal block and the rows below it in one launch of one-wave workgroups
+            const int below = hmax - b * SN_NB - 1;
+            pb(PFK_SN_DIAG);
+            k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b);
+            pe(PFK_SN_DIAG);
+            continue;
         }
         pb(PFK_SN_DIAG);
         k_snode_diag<<<count, SN_DWG, 0, s>>>(v, sv, order, b);

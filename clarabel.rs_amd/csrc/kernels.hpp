@@ -183,6 +183,8 @@ struct SnodeView {
     const int *upd_slot;      // CSC slot of L(B[r], B[c]), r > c  (nullptr: no dense ancestor updates)
     const int *sn_geo;        // per supernode: (last member column e, rows of B = |struct(e)|) -- saves two dependent loads
     const int *sn_cb;         // per member (parallel to sn_col): Lp[c_t] - t - 1, the base of panel column t (entry (i, t) at cb + i)
+    double *sn_d;             // per member: its pivot d_t, written by k_snode_diag next to D[c_t] (the update tiles read the
+                              // pivots of a run of members: contiguous here, cols -> D there)
 };
 int snode_kernel_attributes(int wmax, int nbmax);
 

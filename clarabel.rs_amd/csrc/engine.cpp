@@ -219,6 +219,8 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 for (i32 p = S.sn_ptr[sn]; p < S.sn_ptr[sn + 1]; p++) cb[p] = S.Lp[S.sn_col[p]] - (p - S.sn_ptr[sn]) - 1;
             if ((rc = upload(&sn_cb, cb, cb.size()))) return rc;
             if ((rc = alloc(&sn_d, S.sn_col.size() + 1))) return rc;
+            if ((rc = alloc(&sn_cnt, (size_t)nsn + 1))) return rc;
+            CHIP_HIP(hipMemset(sn_cnt, 0, ((size_t)nsn + 1) * sizeof(int)));
         }
         if ((rc = upload(&Rf_p, S.Rf_p, S.Rf_p.size()))) return rc;
         if ((rc = upload(&Rf_col, S.Rf_col, S.Rf_col.size()))) return rc;
@@ -565,7 +567,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         vf.Rcol = Rf_col;
         vf.Rpos = Rf_pos;
     }
-    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d};
+    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_cnt};
     auto has_sn = [&](int l) { return nsn > 0 && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
     const dev::LaunchProf lprof = launch_prof();
     auto run_supernodes = [&](int l) {
@@ -667,7 +669,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         // chain supernodes: units by unit level.  Forward: every top row first gathers from the columns
         // that are not supernode members, then the level's supernodes solve their dense triangles and
         // push L_BS x_S to their ancestors' entries; backward: the reverse, column oriented.
-        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d};
+        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_cnt};
         // wide supernodes: several workgroups per supernode, pipelined through per-block flags that carry this
         // sweep's epoch (not inside a captured graph: a replay would meet its own flags)
         static const bool no_tri = std::getenv("CHIP_NO_SNODE_TRI") != nullptr;

@@ -1962,15 +1962,27 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     if (nreg) atomicAdd(&s_nreg, 1);
     if (bad) atomicOr(&s_bad, bad);
-    __syncthreads(); // (also: Ll and dinvl are complete)
-    if (blockIdx.x == 0) {
+    __syncthreads(); // (also: Ll and dinvl are complete, and every entry of the unfactored block has been consumed)
+    // The factored block goes back IN PLACE, and the workgroups of a large launch do not all run at the same time:
+    // a workgroup that starts late must still find the UNFACTORED block.  So the block is written by the last of
+    // the supernode's workgroups to get here -- all of them hold the same result -- which needs no waiting: a
+    // counter per supernode, reset by the one that finds it complete.
+    if (tid == 0) {
+        const int nwg = max(1, (g.h - (j0 + nbw) + SNP_WG - 1) / SNP_WG); // workgroups of this supernode that got past the early return
+        const int old = __hip_atomic_fetch_add(&sv.sn_cnt[sn], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_nreg = old == nwg - 1 ? (s_nreg | 0x40000000) : s_nreg;
+        if (old == nwg - 1) __hip_atomic_store(&sv.sn_cnt[sn], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool writer = (s_nreg & 0x40000000) != 0;
+    if (writer) {
         if (q == i / 16 && live) { // the owner of column i
             v.D[ci] = dfin;
             v.Dinv[ci] = dinvfin;
             g.d[j0 + i] = dfin;
         }
         if (tid == 0) {
-            if (s_nreg) atomicAdd(&v.status[2], s_nreg);
+            if (s_nreg & 0xffff) atomicAdd(&v.status[2], s_nreg & 0xffff);
             if (s_bad & 2) v.status[1] = 1;
             if (s_bad & 1) v.status[0] = 1;
         }

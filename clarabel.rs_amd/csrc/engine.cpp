@@ -203,7 +203,20 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         if ((rc = alloc(&Rfx, (size_t)nRf))) return rc;
         if ((rc = upload(&sn_ptr, S.sn_ptr, S.sn_ptr.size()))) return rc;
         if ((rc = upload(&sn_col, S.sn_col, S.sn_col.size()))) return rc;
-        if ((rc = upload(&sn_order, S.sn_order, S.sn_order.size()))) return rc;
+        {
+            // the supernodes in level order as records (kernels.hip: SN_REC = 8 ints): id, first member, width, last
+            // member column, rows of B
+            std::vector<i32> rec(S.sn_order.size() * 8 + 8, 0);
+            for (size_t k = 0; k < S.sn_order.size(); k++) {
+                const i32 sn = S.sn_order[k], p0 = S.sn_ptr[sn], e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                rec[8 * k] = sn;
+                rec[8 * k + 1] = p0;
+                rec[8 * k + 2] = S.sn_ptr[sn + 1] - p0;
+                rec[8 * k + 3] = e;
+                rec[8 * k + 4] = S.Lp[e + 1] - S.Lp[e];
+            }
+            if ((rc = upload(&sn_order, rec, rec.size()))) return rc;
+        }
         {
             std::vector<i32> geo((size_t)2 * nsn + 2, 0);
             for (int sn = 0; sn < nsn; sn++) {
@@ -219,6 +232,11 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 for (i32 p = S.sn_ptr[sn]; p < S.sn_ptr[sn + 1]; p++) cb[p] = S.Lp[S.sn_col[p]] - (p - S.sn_ptr[sn]) - 1;
             if ((rc = upload(&sn_cb, cb, cb.size()))) return rc;
             if ((rc = alloc(&sn_d, S.sn_col.size() + 1))) return rc;
+            {
+                std::vector<int8_t> sg(S.sn_col.size() + 1, 1);
+                for (size_t q = 0; q < S.sn_col.size(); q++) sg[q] = S.dsigns[S.sn_col[q]];
+                if ((rc = upload(&sn_sg, sg, sg.size()))) return rc;
+            }
             if ((rc = alloc(&sn_cnt, (size_t)nsn + 1))) return rc;
             CHIP_HIP(hipMemset(sn_cnt, 0, ((size_t)nsn + 1) * sizeof(int)));
         }
@@ -567,13 +585,13 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         vf.Rcol = Rf_col;
         vf.Rpos = Rf_pos;
     }
-    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_cnt};
+    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, sn_cnt};
     auto has_sn = [&](int l) { return nsn > 0 && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
     const dev::LaunchProf lprof = launch_prof();
     auto run_supernodes = [&](int l) {
         if (!has_sn(l)) return;
         dev::factor_B(stream, vf, snx.B(l));
-        dev::factor_snodes(stream, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l], sn_wmax,
+        dev::factor_snodes(stream, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l], sn_wmax,
                            sn_lvl_nblk[l], sn_lvl_hmax[l], sn_lvl_nbmax[l], prof_family >= PF_SN_UPDATE ? &lprof : nullptr);
     };
     for (int l = top_folded ? nfaclevels : 0; l < nfaclevels;) {
@@ -669,7 +687,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         // chain supernodes: units by unit level.  Forward: every top row first gathers from the columns
         // that are not supernode members, then the level's supernodes solve their dense triangles and
         // push L_BS x_S to their ancestors' entries; backward: the reverse, column oriented.
-        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_cnt};
+        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, sn_cnt};
         // wide supernodes: several workgroups per supernode, pipelined through per-block flags that carry this
         // sweep's epoch (not inside a captured graph: a replay would meet its own flags)
         static const bool no_tri = std::getenv("CHIP_NO_SNODE_TRI") != nullptr;
@@ -683,13 +701,13 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
             prof_begin(PF_SN_GATHER);
             dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
             prof_end(PF_SN_GATHER);
-            dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+            dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
                               sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
         }
         tri.epoch = ++sn_epoch;
         dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
         for (int l = nfaclevels - 1; l >= 0; l--) {
-            dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+            dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
                               sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
             const dev::ChunkView b = bwu.B(l);
             if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwu.BR(l));

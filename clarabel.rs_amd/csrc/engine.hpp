@@ -87,6 +87,7 @@ struct Engine {
     long long *upd_ptr = nullptr;
     double *sn_d = nullptr; // pivots of the supernode members, packed (dev::SnodeView::sn_d)
     int *sn_cnt = nullptr;  // dev::SnodeView::sn_cnt
+    int8_t *sn_sg = nullptr; // dev::SnodeView::sn_sg
     std::vector<i32> sn_lvl_ptr, sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax, h_sn_ptr, h_sn_col;
     // pipelined substitution through wide supernodes (dev::SnodeTriView): one flag per 64-column block
     int *sn_blk_ptr = nullptr, *sn_flags = nullptr;

@@ -1471,17 +1471,26 @@ struct SnodeGeom {
     const int *cols;
     const int *cb; // column bases of the panel (host-computed: Lp[cols[t]] - t - 1)
     double *d;     // pivots of the members, packed (k_snode_diag)
+    const int8_t *sg; // signs of the members, packed
     int w, nb, h, e;
 };
-__device__ __forceinline__ SnodeGeom snode_geom(const LdlView &v, const SnodeView &sv, int sn) {
+// The supernodes of a unit level come as RECORDS in level order (`order` points at the level's first record):
+// (supernode id, first member p0, width w, last member column e, rows of B, -, -, -) -- one 32-byte read where the
+// kernels of rounds 1-2 chased order -> sn -> sn_ptr / sn_geo (three dependent loads at the head of every launch).
+constexpr int SN_REC = 8;
+__device__ __forceinline__ SnodeGeom snode_geom(const SnodeView &sv, const int *__restrict__ order, int idx, int &sn) {
+    typedef int rec_v4i __attribute__((ext_vector_type(4)));
+    const rec_v4i r0 = *(const rec_v4i *)(order + SN_REC * idx);
+    const int nb = order[SN_REC * idx + 4];
     SnodeGeom g;
-    const int p0 = sv.sn_ptr[sn], p1 = sv.sn_ptr[sn + 1];
-    g.cols = sv.sn_col + p0;
-    g.cb = sv.sn_cb + p0;
-    g.d = sv.sn_d + p0;
-    g.w = p1 - p0;
-    g.e = sv.sn_geo[2 * sn];
-    g.nb = sv.sn_geo[2 * sn + 1];
+    sn = r0.x;
+    g.cols = sv.sn_col + r0.y;
+    g.cb = sv.sn_cb + r0.y;
+    g.d = sv.sn_d + r0.y;
+    g.sg = sv.sn_sg + r0.y;
+    g.w = r0.z;
+    g.e = r0.w;
+    g.nb = nb;
     g.h = g.w + g.nb;
     return g;
 }
@@ -1657,8 +1666,8 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
     int *colbase = snode_lds(smem, Wl);
-    const int sn = order[blockIdx.y];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int j0 = b * SN_NB;
     if (j0 >= g.w) return;
     const int row_begin = j0 + (int)blockIdx.x * SN_ROWS;
@@ -1675,8 +1684,8 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
     int *colbase = snode_lds(smem, Wl);
-    const int sn = order[blockIdx.z];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.z, sn);
     const int c0 = (int)blockIdx.y * SN_NB;
     if (c0 >= g.nb) return;
     const int row_begin = g.w + c0 + (int)blockIdx.x * SN_ROWS;
@@ -1700,16 +1709,15 @@ __global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, 
     __shared__ double piv[2];
     __shared__ double sgn[SN_NB];
     __shared__ int colbase[SN_NB];
-    const int sn = order[blockIdx.x];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.x, sn);
     const int j0 = b * SN_NB;
     if (j0 >= g.w) return;
     const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, q = tid >> 6;
     const bool live = i < nbw;
     if (tid < SN_NB) {
-        const int c = tid < nbw ? g.cols[j0 + tid] : 0;
         colbase[tid] = tid < nbw ? g.cb[j0 + tid] : 0;
-        sgn[tid] = tid < nbw ? (double)v.dsigns[c] : 1.0; // (rows beyond a narrow last block: an identity)
+        sgn[tid] = tid < nbw ? (double)g.sg[j0 + tid] : 1.0; // (rows beyond a narrow last block: an identity)
     }
     __syncthreads();
     const int ci = live ? g.cols[j0 + i] : 0;
@@ -1786,8 +1794,8 @@ __global__ __launch_bounds__(SN_RWG) void k_snode_rows(LdlView v, SnodeView sv, 
     __shared__ __attribute__((aligned(16))) double dT[SN_NB * SN_NB];
     __shared__ double dinvl[SN_NB], dl[SN_NB];
     __shared__ int colbase[SN_NB];
-    const int sn = order[blockIdx.y];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int j0 = b * SN_NB;
     if (j0 >= g.w) return;
     const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x;
@@ -1879,8 +1887,8 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     __shared__ double dinvl[SN_NB], sgn[SN_NB];
     __shared__ int colbase[SN_NB];
     __shared__ int s_nreg, s_bad;
-    const int sn = order[blockIdx.y];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int j0 = b * SN_NB;
     if (j0 >= g.w) return;
     const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, q = tid >> 6;
@@ -1888,9 +1896,8 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (blockIdx.x > 0 && row0 >= g.h) return;
     const bool live = i < nbw;
     if (tid < SN_NB) {
-        const int c = tid < nbw ? g.cols[j0 + tid] : 0;
         colbase[tid] = g.cb[j0 + min(tid, nbw - 1)];
-        sgn[tid] = tid < nbw ? (double)v.dsigns[c] : 1.0; // (columns beyond a narrow last block: an identity)
+        sgn[tid] = tid < nbw ? (double)g.sg[j0 + tid] : 1.0; // (columns beyond a narrow last block: an identity)
     }
     if (tid == 0) {
         s_nreg = 0;
@@ -2055,8 +2062,8 @@ __global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, co
                                                      double *x, int wmax, int nbcap, int with_B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SnodeSolveLds L = snode_solve_lds(smem, wmax, nbcap);
-    const int sn = order[blockIdx.x];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.x, sn);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int *Bn = v.Li + v.Lp[g.e];
     const bool ldsB = g.nb <= nbcap;
@@ -2114,8 +2121,8 @@ __global__ __launch_bounds__(SN_WG) void k_snode_push(LdlView v, SnodeView sv, c
                                                       double *x) {
     __shared__ double xs[SN_PCH];
     __shared__ int cb[SN_PCH];
-    const int sn = order[blockIdx.z];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.z, sn);
     const int t0 = (int)blockIdx.y * SN_PCH;
     const int r0 = (int)blockIdx.x * SN_WG;
     if (t0 >= g.w || r0 >= g.nb) return;
@@ -2149,8 +2156,8 @@ __global__ __launch_bounds__(SN_WG) void k_snode_pull(LdlView v, SnodeView sv, c
                                                       double *x, int nbcap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *xB = (double *)smem;
-    const int sn = order[blockIdx.y];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int t0 = (int)blockIdx.x * SN_NB;
     if (t0 >= g.w) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2182,8 +2189,8 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
                                                      double *x, int wmax, int nbcap, int with_B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SnodeSolveLds L = snode_solve_lds(smem, wmax, nbcap);
-    const int sn = order[blockIdx.x];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.x, sn);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int *Bn = v.Li + v.Lp[g.e];
     const bool ldsB = g.nb <= nbcap;
@@ -2300,8 +2307,8 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
     __shared__ double part[SN2_WG / 64][SN_NB];
     __shared__ double pulled[SN_NB]; // backward: L_B,r' x_B of the own columns; forward: the finished x_r
     __shared__ int colbase[SN2_WMAX]; // forward: of all earlier columns; backward: of the own block only
-    const int sn = order[blockIdx.y];
-    const SnodeGeom g = snode_geom(v, sv, sn);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int nblk = (g.w + SN_NB - 1) / SN_NB;
     if ((int)blockIdx.x >= nblk) return;
     const int r = FWDMODE ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;

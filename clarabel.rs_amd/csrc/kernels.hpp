@@ -185,6 +185,7 @@ struct SnodeView {
     const int *sn_cb;         // per member (parallel to sn_col): Lp[c_t] - t - 1, the base of panel column t (entry (i, t) at cb + i)
     double *sn_d;             // per member: its pivot d_t, written by k_snode_diag next to D[c_t] (the update tiles read the
                               // pivots of a run of members: contiguous here, cols -> D there)
+    const int8_t *sn_sg;      // per member: dsigns[c_t] (the block factorisation reads the signs of a run of members)
     int *sn_cnt;              // per supernode: workgroups of k_snode_panel that have finished with the unfactored diagonal
                               // block (zero between launches: the last one resets it)
 };

@@ -585,7 +585,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         vf.Rcol = Rf_col;
         vf.Rpos = Rf_pos;
     }
-    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, sn_cnt};
+    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, nullptr, sn_cnt};
     auto has_sn = [&](int l) { return nsn > 0 && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
     const dev::LaunchProf lprof = launch_prof();
     auto run_supernodes = [&](int l) {
@@ -687,7 +687,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         // chain supernodes: units by unit level.  Forward: every top row first gathers from the columns
         // that are not supernode members, then the level's supernodes solve their dense triangles and
         // push L_BS x_S to their ancestors' entries; backward: the reverse, column oriented.
-        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, sn_cnt};
+        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, nullptr, sn_cnt};
         // wide supernodes: several workgroups per supernode, pipelined through per-block flags that carry this
         // sweep's epoch (not inside a captured graph: a replay would meet its own flags)
         static const bool no_tri = std::getenv("CHIP_NO_SNODE_TRI") != nullptr;

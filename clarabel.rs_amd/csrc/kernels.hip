@@ -1467,6 +1467,13 @@ template <bool FWDMODE> __device__ __forceinline__ double snode_block_solve(cons
     return xv;
 }
 
+// CHIP_SN_DEBUG: wall-clock stamps (10 ns ticks) of ONE workgroup of a supernode launch at its phase boundaries;
+// `drain` first waits for the loads in flight, so that a phase owns the latency of what it requested
+__device__ __forceinline__ void sn_stamp(long long *dbg, bool me, int slot, bool drain = false) {
+    if (!dbg) return;
+    if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (me) dbg[slot] = wall_clock64();
+}
 struct SnodeGeom {
     const int *cols;
     const int *cb; // column bases of the panel (host-computed: Lp[cols[t]] - t - 1)
@@ -1536,7 +1543,10 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
         a[0][u] = v.Lx[cb + irc[0]];
         a[1][u] = v.Lx[cb + irc[1]];
     };
+    const bool dbgme = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+    sn_stamp(sv.dbg, dbgme, 16);
     __syncthreads(); // (the caller has just filled colbase)
+    sn_stamp(sv.dbg, dbgme, 17, true);
     if (wave_live && kbeg < kend) {
 #pragma unroll
         for (int u = 0; u < SN_U; ++u) request(u, kbeg);
@@ -1564,6 +1574,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
             }
         }
         __syncthreads();
+        if (kc0 == kbeg) sn_stamp(sv.dbg, dbgme, 18);
         if (!wave_live) continue; // (after the barriers: the whole wave is beyond the panel)
         for (int kk = 0; kk < kcnu; kk += 4 * SN_U) {
             const int knext = kk + 4 * SN_U < kcnu ? kc0 + kk + 4 * SN_U : kc0 + SN_KC; // (the next chunk's first group)
@@ -1580,6 +1591,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
             }
         }
     }
+    sn_stamp(sv.dbg, dbgme, 19);
     // ---- emit through LDS: this wave's 16 x 64 tile in its own 8 KiB of the (now free) operand buffer, element
     //      (row rr, column jj) at jj * 16 + (rr ^ (jj & 15)) -- the swizzle keeps both the column-per-lane writes
     //      and the row-per-lane reads off common banks
@@ -1652,6 +1664,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
             }
         }
     }
+    sn_stamp(sv.dbg, dbgme, 20, true);
 }
 
 __device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
@@ -1892,6 +1905,8 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int j0 = b * SN_NB;
     if (j0 >= g.w) return;
     const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    const bool dbgme = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    sn_stamp(sv.dbg, dbgme, 0);
     const int row0 = j0 + nbw + (int)blockIdx.x * SNP_WG; // first of this group's rows below the block
     if (blockIdx.x > 0 && row0 >= g.h) return;
     const bool live = i < nbw;
@@ -1904,6 +1919,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         s_bad = 0;
     }
     __syncthreads();
+    sn_stamp(sv.dbg, dbgme, 1);
     const int ci = live ? g.cols[j0 + i] : 0;
     double di = live ? v.D[ci] : 1.0; // running diagonal entry of row i (kept by all four threads of the row)
     double T[16];
@@ -1912,6 +1928,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int j = 16 * q + cc;
         T[cc] = (live && j < nbw && i > j) ? v.Lx[colbase[j] + j0 + i] : 0.0;
     }
+    sn_stamp(sv.dbg, dbgme, 2, true);
     double dfin = 1.0, dinvfin = 1.0; // pivot of row i, recorded by the owner of column i
     int nreg = 0, bad = 0;
     // the quarter loop stays rolled; the 16 columns of a quarter are unrolled, so T[..] are fixed registers
@@ -1967,6 +1984,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
     }
+    sn_stamp(sv.dbg, dbgme, 3);
     if (nreg) atomicAdd(&s_nreg, 1);
     if (bad) atomicOr(&s_bad, bad);
     __syncthreads(); // (also: Ll and dinvl are complete, and every entry of the unfactored block has been consumed)
@@ -1999,6 +2017,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (live && j < nbw && i > j) v.Lx[colbase[j] + j0 + i] = T[cc];
         }
     }
+    sn_stamp(sv.dbg, dbgme, 4, true);
     if (row0 >= g.h) return;
     // ---- the rows below the block: thread = row, its 64 entries in registers, right-looking (the products of one
     //      column are independent; per entry the subtractions happen in the order k = 0, 1, ... of qdldl.rs:610-640).
@@ -2012,6 +2031,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int jj = 0; jj < SN_NB; ++jj) x[jj] = v.Lx[colbase[jj] + Rc];
 #pragma unroll
     for (int jj = 0; jj < SN_NB; ++jj) x[jj] = jj < nbw ? x[jj] : 0.0;
+    sn_stamp(sv.dbg, dbgme, 5, true);
 #pragma unroll
     for (int k = 0; k < SN_NB; ++k) {
         const double uq = x[k];
@@ -2027,10 +2047,12 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             x[2 * p2 + 1] -= cc.y * uq;
         }
     }
+    sn_stamp(sv.dbg, dbgme, 6);
     if (!rowok) return;
 #pragma unroll
     for (int jj = 0; jj < SN_NB; ++jj)
         if (jj < nbw) v.Lx[colbase[jj] + R] = x[jj] * dinvl[jj];
+    sn_stamp(sv.dbg, dbgme, 7, true);
 }
 
 // Substitutions through a chain supernode, one workgroup per supernode of the unit level, the
@@ -6488,9 +6510,103 @@ void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView
 }
 // all supernodes order[0..count) of one unit level: block columns one after the other, then their
 // updates of the ancestors.  nblk / hmax / nbmax: maxima over these supernodes.
-void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order, int count, int wmax_all,
+namespace {
+// CHIP_SN_DEBUG=1: every launch of the update tiles / the panel kernel is followed by a synchronisation and the
+// stamps of its workgroup 0 are accumulated; the per-phase means are printed when the process ends
+struct SnDebug {
+    long long *dev = nullptr;
+    double sum[2][8] = {};
+    long n[2] = {0, 0};
+    bool on = false;
+    SnDebug() {
+        on = std::getenv("CHIP_SN_DEBUG") != nullptr;
+        mode = on ? std::atoi(std::getenv("CHIP_SN_DEBUG")) : 0;
+        if (on) {
+            (void)hipMalloc((void **)&dev, (64 + (size_t)RING * 32) * sizeof(long long));
+            (void)hipMemset(dev, 0, (64 + (size_t)RING * 32) * sizeof(long long));
+        }
+    }
+    void collect(hipStream_t s, int kind) { // kind 0: panel (slots 0..7), 1: update tiles (slots 16..20)
+        long long t[64];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(t, dev, sizeof(t), hipMemcpyDeviceToHost);
+        const int base = kind ? 16 : 0, cnt = kind ? 5 : 8;
+        for (int i = 1; i < cnt; i++)
+            if (t[base + i] && t[base + i - 1]) sum[kind][i] += (t[base + i] - t[base + i - 1]) * 0.01;
+        n[kind]++;
+        (void)hipMemset(dev, 0, 64 * sizeof(long long));
+    }
+    // CHIP_SN_DEBUG=2: no synchronisation; launch k stamps into its own 32 slots of a ring, and at the end the time
+    // between the LAST stamp of a launch and the FIRST stamp of the next one (what a kernel boundary costs) is printed
+    static constexpr int RING = 2048;
+    int mode = 0;
+    long nring = 0;
+    std::vector<int> kinds;
+    long long *ring_slot(int kind) {
+        if ((nring % RING) == 0 && nring) flush_ring();
+        kinds.push_back(kind);
+        return dev + 64 + (size_t)(nring++ % RING) * 32;
+    }
+    double gap_sum[2] = {0, 0}, in_sum[2] = {0, 0};
+    long gap_n[2] = {0, 0};
+    void flush_ring() {
+        (void)hipDeviceSynchronize();
+        std::vector<long long> t((size_t)RING * 32);
+        (void)hipMemcpy(t.data(), dev + 64, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        const long cnt = (long)kinds.size();
+        long long prev_last = 0;
+        for (long k = 0; k < cnt; k++) {
+            const long long *r = t.data() + (size_t)k * 32;
+            const int base = kinds[k] ? 16 : 0, hi = kinds[k] ? 20 : 7;
+            long long first = r[base], last = 0;
+            for (int i = base; i <= hi; i++) last = std::max(last, r[i]);
+            if (first && prev_last && first > prev_last && first - prev_last < 100000) { // (< 1 ms: same factorisation)
+                gap_sum[kinds[k]] += (first - prev_last) * 0.01;
+                in_sum[kinds[k]] += (last - first) * 0.01;
+                gap_n[kinds[k]]++;
+                for (int i = base + 1; i <= hi; i++)
+                    if (r[i] && r[i - 1]) sum[kinds[k]][i - base] += (r[i] - r[i - 1]) * 0.01;
+                n[kinds[k]]++;
+            }
+            prev_last = last;
+        }
+        kinds.clear();
+        (void)hipMemset(dev + 64, 0, (size_t)RING * 32 * sizeof(long long));
+    }
+    ~SnDebug() {
+        if (on && mode == 2) {
+            flush_ring();
+            for (int k = 0; k < 2; k++)
+                if (gap_n[k])
+                    std::fprintf(stderr, "[chip sn debug] %s: mean over %ld launches: %.2f us between the previous launch's last stamp and this one's first, %.2f us inside (workgroup 0)\n",
+                                 k ? "k_snode_update" : "k_snode_panel", gap_n[k], gap_sum[k] / gap_n[k], in_sum[k] / gap_n[k]);
+        }
+        if (!on) return;
+        const char *pn[8] = {"", "geometry+colbase", "block loads", "block factorisation", "write-back", "row loads", "rows recurrence", "stores"};
+        const char *un[5] = {"", "colbase", "first operand staged", "matrix instructions (all chunks)", "emit"};
+        if (n[0]) {
+            std::fprintf(stderr, "[chip sn debug] k_snode_panel, workgroup 0, mean over %ld launches (us):", n[0]);
+            for (int i = 1; i < 8; i++) std::fprintf(stderr, " %s %.2f;", pn[i], sum[0][i] / n[0]);
+            std::fprintf(stderr, "\n");
+        }
+        if (n[1]) {
+            std::fprintf(stderr, "[chip sn debug] k_snode_update, workgroup 0, mean over %ld launches (us):", n[1]);
+            for (int i = 1; i < 5; i++) std::fprintf(stderr, " %s %.2f;", un[i], sum[1][i] / n[1]);
+            std::fprintf(stderr, "\n");
+        }
+    }
+};
+SnDebug &sn_debug() {
+    static SnDebug d;
+    return d;
+}
+} // namespace
+void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, const int *order, int count, int wmax_all,
                    int nblk, int hmax, int nbmax, const LaunchProf *lp) {
     if (!count) return;
+    SnodeView sv = sv_in;
+    SnDebug &dbg = sn_debug();
+    if (dbg.on) sv.dbg = dbg.dev;
     const size_t lds = snode_lds_bytes(wmax_all);
     auto pb = [&](int f) { if (lp) lp->begin(lp->ctx, f); };
     auto pe = [&](int f) { if (lp) lp->end(lp->ctx, f); };
@@ -6507,16 +6623,20 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const i
                 static const int split_unit = std::getenv("CHIP_SN_SPLIT_UNIT") ? std::atoi(std::getenv("CHIP_SN_SPLIT_UNIT")) : 1; // block columns per share, at least
                 while (!no_splitk && ksplit < split_max && ksplit * 2 * split_unit <= b && groups * count * ksplit < split_target) ksplit *= 2;
                 pb(PFK_SN_UPDATE);
+                if (dbg.mode == 2) sv.dbg = dbg.ring_slot(1) - 16 + 16; // (slots 16..20 of the launch's 32)
                 k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b);
                 pe(PFK_SN_UPDATE);
+                if (dbg.on && dbg.mode != 2) dbg.collect(s, 1);
             }
         }
         static const bool no_panel = std::getenv("CHIP_NO_SNODE_PANEL") != nullptr;
         if (!no_panel) { // the diagonal block and the rows below it in one launch of one-wave workgroups
             const int below = hmax - b * SN_NB - 1;
             pb(PFK_SN_DIAG);
+            if (dbg.mode == 2) sv.dbg = dbg.ring_slot(0);
             k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b);
             pe(PFK_SN_DIAG);
+            if (dbg.on && dbg.mode != 2) dbg.collect(s, 0);
             continue;
         }
         pb(PFK_SN_DIAG);
@@ -6532,7 +6652,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const i
     if (nbmax > 0 && sv.upd_slot) {
         pb(PFK_SN_EXTEND);
         k_snode_extend<<<dim3((nbmax + SN_ROWS - 1) / SN_ROWS, (nbmax + SN_NB - 1) / SN_NB, count), SN_WG, lds, s>>>(
-            v, sv, order);
+            v, sv_in, order);
         pe(PFK_SN_EXTEND);
     }
 }

@@ -186,6 +186,7 @@ struct SnodeView {
     double *sn_d;             // per member: its pivot d_t, written by k_snode_diag next to D[c_t] (the update tiles read the
                               // pivots of a run of members: contiguous here, cols -> D there)
     const int8_t *sn_sg;      // per member: dsigns[c_t] (the block factorisation reads the signs of a run of members)
+    long long *dbg;           // CHIP_SN_DEBUG: phase stamps of workgroup 0 of the launch (64 slots), else nullptr
     int *sn_cnt;              // per supernode: workgroups of k_snode_panel that have finished with the unfactored diagonal
                               // block (zero between launches: the last one resets it)
 };

@@ -1,3 +1,6 @@
+"""Host side of the setup of BASELINE config 5 (chordal SDP with <ncliques> cliques, default 200) without touching a GPU
+(device = HOST_ONLY): KKT assembly, ordering, symbolic analysis.  CHIP_TIMING=1 prints the stages.
+usage: CHIP_TIMING=1 python tools/host_setup_timing.py [ncliques]"""
 import sys, time, os
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import __graft_entry__ as g

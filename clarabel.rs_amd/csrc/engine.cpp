@@ -621,7 +621,13 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     }
     if (nsn > 0) dev::gather_values(stream, Rfx, Lx, Rf_pos, nRf); // L at the filtered row lists (forward sweep)
     else dev::topblk_build(stream, v, topblk); // inverses of the diagonal blocks of a tall top
-    if (!fold.k) dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS); // full rows of the top for the residual
+    // full rows of the top for the residual of the one-kernel-per-phase path; a handle whose fused launch folds the
+    // top per group never reads them unless that launch falls back: refreshed on demand (enqueue_residual)
+    sx_valid = false;
+    if (!fold.k && !(ir_fused && gfold.ng > 0)) {
+        dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
+        sx_valid = true;
+    }
     rx_valid = !ir_fused;
     return CHIP_OK;
 }
@@ -772,6 +778,10 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
         dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, fold, ev0, ev1);
         dev::fold_top_residual(stream, fold, Kx, x, b, e, a.nrm, a.nan); // (top-top entries by their position in Kx)
         return;
+    }
+    if (!sx_valid) { // (K's values have not changed since the refactor: every write to them is followed by one)
+        dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
+        sx_valid = true;
     }
     if (xperm) {
         dev::gather_values(stream, xs_view, x, xperm, N);

@@ -126,6 +126,7 @@ struct Engine {
     static constexpr int IR_RING = 16; // result quads of the last IR_RING enqueued solves
     bool ir_fused = false;
     bool rx_valid = false; // fused handles: the row-major copy Rx of L is only refreshed when the one-kernel-per-phase path runs
+    bool sx_valid = false; // grouped fold: the full rows Sx of the top likewise (the fused launch reads K's own values)
     unsigned short *Li16 = nullptr, *Ucol16 = nullptr, *Lj16 = nullptr, *Urow16 = nullptr, *Rk16 = nullptr, *Ro16 = nullptr;
     unsigned short *fu_rec = nullptr, *fu_slot = nullptr;
     int *fu_ptr = nullptr;

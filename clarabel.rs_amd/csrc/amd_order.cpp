@@ -49,6 +49,36 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     const int T = nnzA >= par_min ? host_threads() : 1;
     std::vector<I> ast((size_t)n + 1, 0);
     std::vector<int> bad((size_t)T, 0);
+    RawBuf<I> adj((size_t)2 * (size_t)nnzA + 1); // (no zero fill; sized for every entry off the diagonal)
+    if (sizeof(I) == 4) {
+        // one stable bucket pass (host.hpp): entry (r, c) of K goes to the lists of r and of c, source order kept
+        {
+            const std::vector<int64_t> ccuts = balanced_cuts(Ap, n, T);
+            run_threads(T, [&](int t, int) {
+                for (i64 c = ccuts[t]; c < ccuts[t + 1] && !bad[t]; c++)
+                    for (i64 p = Ap[c]; p < Ap[c + 1]; p++)
+                        if (Ai[p] < 0 || Ai[p] >= n) {
+                            bad[t] = 1;
+                            break;
+                        }
+            });
+            for (int t = 0; t < T; t++)
+                if (bad[t]) return -9;
+            std::vector<i32> ptr32;
+            stable_buckets(T, (i32)n, ptr32, true,
+                           [&](int t, int, auto f) {
+                               for (i64 c = ccuts[t]; c < ccuts[t + 1]; c++)
+                                   for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+                                       const i64 r = Ai[p];
+                                       if (r == c) continue;
+                                       f((i32)r, c);
+                                       f((i32)c, r);
+                                   }
+                           },
+                           [&](i32, i64 other, i32 u) { adj[(size_t)u] = (I)other; });
+            for (i64 i = 0; i <= n; i++) ast[(size_t)i] = (I)ptr32[(size_t)i];
+        }
+    } else {
     run_threads(T, [&](int t, int TT) {
         const I k0 = (I)(n * t / TT), k1 = (I)(n * (t + 1) / TT);
         for (I c = 0; c < n; c++)
@@ -67,7 +97,6 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     for (int t = 0; t < T; t++)
         if (bad[t]) return -9;
     for (I i = 0; i < n; i++) ast[i + 1] += ast[i];
-    std::vector<I> adj((size_t)ast[n] + 1);
     {
         std::vector<I> fillp(ast.begin(), ast.end() - 1);
         const std::vector<int64_t> cuts = balanced_cuts(ast.data(), n, T);
@@ -82,6 +111,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
                     if (c >= k0 && c < k1) adj[fillp[c]++] = r;
                 }
         });
+    }
     }
     std::vector<I> alen((size_t)n), aelen((size_t)n, 0);
     for (I i = 0; i < n; i++) alen[i] = ast[i + 1] - ast[i];

@@ -399,7 +399,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
         CHIP_HIP(hipMemcpy(E.Kx, vx.data(), (size_t)K.nnz * sizeof(double), hipMemcpyHostToDevice));
     }
     // every LDLDataMap index the kernels use is translated ONCE into a position of that store
-    const std::vector<i32> &k2v = S.k2v;
+    const bigvec &k2v = S.k2v;
     auto narrow = [&k2v](const std::vector<i64> &v, size_t cnt) {
         std::vector<int> o(cnt);
         for (size_t i = 0; i < cnt; i++) o[i] = k2v[(size_t)v[i]];

@@ -32,7 +32,7 @@ template <typename T> int Engine::alloc(T **dst, size_t n) {
     *dst = (T *)p;
     return CHIP_OK;
 }
-template <typename T> int Engine::upload(T **dst, const std::vector<T> &src, size_t n) {
+template <typename T, typename A> int Engine::upload(T **dst, const std::vector<T, A> &src, size_t n) {
     int rc = alloc(dst, n);
     if (rc) return rc;
     if (n) CHIP_HIP(hipMemcpy(*dst, src.data(), n * sizeof(T), hipMemcpyHostToDevice));

@@ -70,7 +70,7 @@ struct Engine {
     double *Ux = nullptr; // == Kx: the U rows are the first nnzU entries of the value store
     // Kx holds the caller's K.nzval in T order V (host.hpp: Symbolic::k2v): h_k2v[p] = position of K.nzval[p];
     // d_v2k (device, allocated on first use) serves wholesale uploads in the caller's order (L1 boundary)
-    std::vector<i32> h_k2v, h_v2k;
+    bigvec h_k2v, h_v2k;
     int *d_v2k = nullptr;
     double *d_stage = nullptr;
     int8_t *dsigns = nullptr;
@@ -108,7 +108,8 @@ struct Engine {
     int nfill = 0;
     std::vector<i32> h_perm, h_lvlptr, h_etree;
     bool host_only = false;          // CHIP_DEVICE_HOST_ONLY: symbolic results only
-    std::vector<i32> h_Lp, h_Li;     // kept only for host-only handles
+    std::vector<i32> h_Lp;           // kept only for host-only handles
+    bigvec h_Li;
     AmdInfo amd;
     bool factored = false;
     i64 last_regularize_count = 0;
@@ -145,7 +146,7 @@ struct Engine {
     int init(const Symbolic &S, const chip_settings &settings);
     void init_host_only(const Symbolic &S, const chip_settings &settings);
     int get_symbolic(uint64_t *etree, uint64_t *Lp, uint64_t *Li, uint64_t *lvlptr) const;
-    template <typename T> int upload(T **dst, const std::vector<T> &src, size_t n);
+    template <typename T, typename A> int upload(T **dst, const std::vector<T, A> &src, size_t n);
     template <typename T> int alloc(T **dst, size_t n);
     // chain_max_w: most W rows a level may have to count as "narrow" (runs of narrow levels are chained)
     int upload_lists(DeviceLists &D, const LevelLists &L, int chain_max_w = 64);

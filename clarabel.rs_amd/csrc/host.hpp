@@ -9,6 +9,8 @@
 #include <chrono>
 #include <functional>
 #include <string>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace chip {
@@ -48,6 +50,20 @@ struct LevelLists {
     std::vector<i32> br_ptr, br_idx;
 };
 
+// std::vector whose resize() does NOT value-initialise (trivial element types): the arrays of the analysis that have
+// one entry per entry of K or L are filled by the threads right after they are sized -- a zero fill first is a second,
+// single-threaded pass over gigabytes (config 5: ~9 GB of them).  assign(n, v) still fills.
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
+};
+using bigvec = std::vector<i32, NoInitAlloc<i32>>;
+
 struct Symbolic {
     i32 N = 0;
     i64 nnzK = 0; // nnz(triu K)
@@ -60,14 +76,17 @@ struct Symbolic {
     // owns V[Vp[lo] .. Vp[lo+1]).  Rows lo < NF (bundle nodes) are the U rows below; for the rows of the top
     // v2l[u - Vp[NF]] says where V[u] lands in the factor's storage: < nnzL -> Lx position (CSC of L),
     // otherwise nnzL + j -> D[j].
-    std::vector<i32> k2v, v2k, Vp, v2l;
+    bigvec k2v, v2k, v2l;
+    std::vector<i32> Vp;
     // slots of L in TOP columns (CSC positions) that no entry of K maps to: structural fill-in
     std::vector<i32> fill_idx;
     // L, CSC with ascending rows (structure only; values live on the device)
-    std::vector<i32> Lp, Li;
+    std::vector<i32> Lp;
+    bigvec Li;
     // L, CSR (row j: columns k ascending), Rpos = CSC position of the entry,
     // Tpos = CSR position of each CSC entry
-    std::vector<i32> Rp, Rcol, Rpos, Tpos;
+    std::vector<i32> Rp;
+    bigvec Rcol, Rpos, Tpos;
     std::vector<i32> etree; // parent in the final numbering, -1 = root
     std::vector<i32> level; // elimination-tree level of every node (leaves = 0)
     i32 tree_depth = 0;
@@ -161,11 +180,13 @@ struct Symbolic {
     //   S : rows i >= NF (top nodes): the full row (both triangles); Sp has N+1 entries, empty rows for
     //       i < NF; Smap = position in V (values refreshed by a gather at every refactor)
     i64 nnzS = 0, nnzU = 0;
-    std::vector<i32> Sp, Scol, Smap;
+    std::vector<i32> Sp;
+    bigvec Scol, Smap;
     // with chain supernodes: Scol refers to positions of a copy of x in which the members of a supernode are
     // consecutive (xs[i] = x[xperm[i]]; empty = Scol holds node indices)
     std::vector<i32> xperm;
-    std::vector<i32> Up, Ucol;
+    std::vector<i32> Up;
+    bigvec Ucol;
     // kernel work lists
     LevelLists fac, fwd, bwd; // factor (by column), forward solve (rows of L), backward (columns)
     LevelLists smv;           // symv: a single pseudo-level over all rows
@@ -248,6 +269,50 @@ template <class P> std::vector<int64_t> balanced_cuts(const P *ptr, int64_t n, i
         cuts[t] = j;
     }
     return cuts;
+}
+// Scratch array WITHOUT value initialisation: std::vector zero-fills on the constructing thread -- 650 MB per
+// array of config 5's 1.6e8-entry passes, one thread, before the threads that own the data ever touch it (that,
+// not the passes themselves, was most of the "T / C2 orders" stage) -- here the first touch is the parallel fill.
+template <class T> struct RawBuf {
+    std::unique_ptr<T[]> p;
+    explicit RawBuf(size_t k) : p(new T[k]) {}
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+};
+// Stable parallel bucket placement (the counting pass of a radix sort): the source is T ordered chunks, chunk t being
+// the t-th part of the source order; scan(t, T, f) calls f(key, payload) for the items of chunk t in order.  Every
+// item is placed at ptr[key] + (its rank among the items of its key, in source order) -- the result does not depend
+// on T.  Work: two scans of the source plus O(T x nkeys) counters (the destination-owning passes this replaces had
+// every thread scan the WHOLE source: T x nnz reads per pass, 84 GB per pass for config 5's 1.6e8 entries of K).
+template <class Scan, class Place>
+void stable_buckets(int T, i32 nkeys, std::vector<i32> &ptr, bool compute_ptr, Scan scan, Place place) {
+    if (T < 1) T = 1;
+    std::vector<std::vector<i32>> cnt((size_t)T);
+    run_threads(T, [&](int t, int TT) {
+        std::vector<i32> &c = cnt[(size_t)t];
+        c.assign((size_t)nkeys + 1, 0);
+        scan(t, TT, [&](i32 key, i64) { c[(size_t)key]++; });
+    });
+    if (compute_ptr) ptr.assign((size_t)nkeys + 1, 0);
+    run_threads(T, [&](int t, int TT) { // per key: the chunks' counts become their offsets inside the key's range
+        for (i64 key = (i64)nkeys * t / TT; key < (i64)nkeys * (t + 1) / TT; key++) {
+            i32 run = 0;
+            for (int c = 0; c < TT; c++) {
+                const i32 k = cnt[(size_t)c][(size_t)key];
+                cnt[(size_t)c][(size_t)key] = run;
+                run += k;
+            }
+            if (compute_ptr) ptr[(size_t)key + 1] = run;
+        }
+    });
+    if (compute_ptr)
+        for (i32 key = 0; key < nkeys; key++) ptr[(size_t)key + 1] += ptr[(size_t)key];
+    run_threads(T, [&](int t, int TT) {
+        std::vector<i32> &c = cnt[(size_t)t];
+        scan(t, TT, [&](i32 key, i64 payload) { place(key, payload, ptr[(size_t)key] + c[(size_t)key]++); });
+    });
 }
 const char *get_error();
 

@@ -88,7 +88,7 @@ inline int par_threads(i64 items) {
 // upper-triangular pattern of P K P' (row = min, col = max), columns unsorted,
 // plus (optionally) for each source entry its destination slot.
 void permuted_triu(i64 n, const i64 *Ap, const i64 *Ai, const std::vector<i32> &iperm,
-                   std::vector<i64> &Cp, std::vector<i32> &Ci) {
+                   std::vector<i64> &Cp, bigvec &Ci) {
     // Threads own ranges of DESTINATION columns: every thread scans all of K (sequential reads) and
     // places the entries of its own columns in source order, so the result does not depend on the
     // number of threads.
@@ -116,8 +116,9 @@ void permuted_triu(i64 n, const i64 *Ap, const i64 *Ai, const std::vector<i32> &
         }
         return;
     }
-    // the permuted (row, col) of every entry once, by source chunks; the two scans below are streams
-    std::vector<i32> erow((size_t)nnz + 1), ecol((size_t)nnz + 1);
+    // the permuted (row, col) of every entry once, by source chunks, then one stable bucket pass by column
+    // (host.hpp: stable_buckets -- the entries of a column keep their source order for any thread count)
+    RawBuf<i32> erow((size_t)nnz + 1), ecol((size_t)nnz + 1);
     {
         const std::vector<int64_t> ccuts = balanced_cuts(Ap, n, T);
         run_threads(T, [&](int t, int) {
@@ -131,29 +132,19 @@ void permuted_triu(i64 n, const i64 *Ap, const i64 *Ai, const std::vector<i32> &
             }
         });
     }
-    run_threads(T, [&](int t, int TT) {
-        const i32 k0 = (i32)(n * t / TT), k1 = (i32)(n * (t + 1) / TT);
-        for (i64 p = 0; p < nnz; p++) {
-            const i32 col = ecol[p];
-            if (col >= k0 && col < k1) Cp[col + 1]++;
-        }
-    });
-    for (i64 c = 0; c < n; c++) Cp[c + 1] += Cp[c];
-    Ci.resize((size_t)Cp[n] + 1);
-    std::vector<i64> nextp(Cp.begin(), Cp.end() - 1);
-    const std::vector<int64_t> cuts = balanced_cuts(Cp.data(), n, T);
-    run_threads(T, [&](int t, int) {
-        const i32 k0 = (i32)cuts[t], k1 = (i32)cuts[t + 1];
-        if (k0 >= k1) return;
-        for (i64 p = 0; p < nnz; p++) {
-            const i32 col = ecol[p];
-            if (col >= k0 && col < k1) Ci[nextp[col]++] = erow[p];
-        }
-    });
+    Ci.resize((size_t)nnz + 1);
+    Ci[(size_t)nnz] = 0;
+    std::vector<i32> cp32;
+    stable_buckets(T, (i32)n, cp32, true,
+                   [&](int t, int TT, auto f) {
+                       for (i64 p = nnz * t / TT; p < nnz * (t + 1) / TT; p++) f(ecol[p], p);
+                   },
+                   [&](i32, i64 p, i32 u) { Ci[(size_t)u] = erow[p]; });
+    for (i64 c = 0; c <= n; c++) Cp[(size_t)c] = cp32[(size_t)c];
 }
 
 // elimination tree (parent, -1 = root) and strictly-lower column counts of L.
-void etree_counts(i64 n, const std::vector<i64> &Cp, const std::vector<i32> &Ci,
+void etree_counts(i64 n, const std::vector<i64> &Cp, const bigvec &Ci,
                   std::vector<i32> &parent, std::vector<i32> &cnt, std::vector<i32> *rowcnt = nullptr) {
     parent.assign((size_t)n, -1);
     cnt.assign((size_t)n, 0);
@@ -199,8 +190,8 @@ struct ListBuilder {
     // tail(t) = Lp[k+1] - (Rpos[t]+1) entries; a chunk closes at B_CHUNK contributions or at its
     // share of the column's updates (about 1/96 of them, between 1024 and 4096: a 33k-update column
     // of config 2 becomes ~32 chunks, an 800k-update dense PSD column of config 5 ~200)
-    void add_B_work(i32 r, i64 beg, i64 end, const std::vector<i32> &Rcol, const std::vector<i32> &Rpos,
-                    const std::vector<i32> &Lp, i64 total_work) {
+    void add_B_work(i32 r, i64 beg, i64 end, const i32 *Rcol, const i32 *Rpos, const std::vector<i32> &Lp,
+                    i64 total_work) {
         L.br_idx.push_back(r);
         const i64 F_CHUNK_WORK = std::min(F_CHUNK_MAX, std::max(F_CHUNK_MIN, total_work / F_CHUNK_PARTS));
         i64 b = beg, work = 0;
@@ -274,7 +265,8 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     }
     clk("ordering");
     std::vector<i64> Cp;
-    std::vector<i32> Ci, parent, cnt;
+    bigvec Ci;
+    std::vector<i32> parent, cnt;
     std::vector<i32> rowcnt;
     // ---- shallower tree, same fill: reorder inside chains ----------------------
     // A chain j -> parent(j) -> ... in which every column is its parent's column plus the parent
@@ -357,7 +349,8 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 ip1[p1[t]] = t;
             }
             std::vector<i64> Cp1;
-            std::vector<i32> Ci1, parent1, cnt1, rowcnt1;
+            bigvec Ci1;
+            std::vector<i32> parent1, cnt1, rowcnt1;
             permuted_triu(n, Ap, Ai, ip1, Cp1, Ci1);
             etree_counts(n, Cp1, Ci1, parent1, cnt1, &rowcnt1);
             i64 nnzL1 = 0;
@@ -756,7 +749,8 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         S.Lp[j + 1] = (i32)nnzL;
     }
     S.nnzL = nnzL;
-    S.Li.resize((size_t)nnzL + 1);
+    S.Li.resize((size_t)nnzL + 1); // (bigvec: not zero filled; every entry is written below)
+    S.Li[(size_t)nnzL] = 0;
     {
         // rows of L by row-subtree traversal; k ascending => ascending rows per column
         // (a supernode's members form a path of the tree and only its LAST column is written here -- the others
@@ -819,7 +813,8 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         S.nnzR = S.Rp[n];
         S.Rcol.resize((size_t)S.nnzR + 1);
         S.Rpos.resize((size_t)S.nnzR + 1);
-        S.Tpos.assign((size_t)nnzL + 1, 0);
+        S.Tpos.resize((size_t)nnzL + 1); // (entries of member columns stay unwritten: nothing reads them)
+        S.Rcol[(size_t)S.nnzR] = S.Rpos[(size_t)S.nnzR] = S.Tpos[(size_t)nnzL] = 0;
         std::vector<i32> nextp(S.Rp.begin(), S.Rp.end() - 1);
         const std::vector<int64_t> cuts = balanced_cuts(S.Rp.data(), n, T);
         run_threads(T, [&](int t, int) { // threads own ranges of rows; columns scanned in order by all
@@ -842,14 +837,14 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // ---- the permuted upper triangle of K, twice sorted (three counting passes, no comparisons):
     //      T : by smaller index lo, larger index hi ascending;  C2 : by hi, lo ascending; each entry
     //      carries its position p in the caller's K.nzval.  Feeds the scatter map and the residual rows.
-    std::vector<i32> Tp((size_t)n + 1, 0), Thi((size_t)nnzK + 1), Tsrc((size_t)nnzK + 1);
-    std::vector<i32> C2p((size_t)n + 1, 0), C2lo((size_t)nnzK + 1), C2src((size_t)nnzK + 1);
+    std::vector<i32> Tp((size_t)n + 1, 0), C2p((size_t)n + 1, 0);
+    RawBuf<i32> Thi((size_t)nnzK + 1), Tsrc((size_t)nnzK + 1), C2lo((size_t)nnzK + 1), C2src((size_t)nnzK + 1); // (host.hpp: no zero fill)
     {
         // (each pass: threads own ranges of destination keys and scan the whole source in order; the
         // permuted (lo, hi) of every entry is computed once, by source chunks, so that the scans are streams)
         const int T = par_threads(nnzK);
-        std::vector<i32> hp((size_t)n + 1, 0), hlo((size_t)nnzK + 1), hsrc((size_t)nnzK + 1);
-        std::vector<i32> elo((size_t)nnzK + 1), ehi((size_t)nnzK + 1);
+        std::vector<i32> hp((size_t)n + 1, 0);
+        RawBuf<i32> hlo((size_t)nnzK + 1), hsrc((size_t)nnzK + 1), elo((size_t)nnzK + 1), ehi((size_t)nnzK + 1);
         {
             const std::vector<int64_t> ccuts = balanced_cuts(Ap, n, T);
             run_threads(T, [&](int t, int) {
@@ -863,63 +858,42 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 }
             });
         }
-        run_threads(T, [&](int t, int TT) {
-            const i32 k0 = (i32)(n * t / TT), k1 = (i32)(n * (t + 1) / TT);
-            for (i64 p = 0; p < nnzK; p++) {
-                const i32 hi = ehi[p], lo = elo[p];
-                if (hi >= k0 && hi < k1) hp[hi + 1]++;
-                if (lo >= k0 && lo < k1) Tp[lo + 1]++;
-            }
-        });
-        for (i32 j = 0; j < n; j++) {
-            hp[j + 1] += hp[j];
-            Tp[j + 1] += Tp[j];
+        // three stable bucket passes (host.hpp: stable_buckets), each over chunks of its source in order:
+        //   1. by hi (source order)        -> (hlo, hsrc) grouped by hi
+        //   2. by lo, from the hi groups   -> T  : by lo, hi ascending
+        //   3. by hi, from T               -> C2 : by hi, lo ascending
+        stable_buckets(T, (i32)n, hp, true,
+                       [&](int t, int TT, auto f) {
+                           for (i64 p = nnzK * t / TT; p < nnzK * (t + 1) / TT; p++) f(ehi[p], p);
+                       },
+                       [&](i32, i64 p, i32 u) {
+                           hlo[u] = elo[p];
+                           hsrc[u] = (i32)p;
+                       });
+        {
+            const std::vector<int64_t> hcuts = balanced_cuts(hp.data(), n, T);
+            stable_buckets(T, (i32)n, Tp, true,
+                           [&](int t, int, auto f) {
+                               for (i32 hi = (i32)hcuts[t]; hi < (i32)hcuts[t + 1]; hi++)
+                                   for (i32 w = hp[hi]; w < hp[hi + 1]; w++) f(hlo[w], ((i64)hi << 32) | (uint32_t)w);
+                           },
+                           [&](i32, i64 pl, i32 u) {
+                               Thi[u] = (i32)(pl >> 32);
+                               Tsrc[u] = hsrc[(uint32_t)pl];
+                           });
         }
         C2p = hp;
-        const std::vector<int64_t> hcuts = balanced_cuts(hp.data(), n, T), tcuts = balanced_cuts(Tp.data(), n, T);
         {
-            std::vector<i32> nx(hp.begin(), hp.end() - 1);
-            run_threads(T, [&](int t, int) { // pass 1: grouped by hi
-                const i32 k0 = (i32)hcuts[t], k1 = (i32)hcuts[t + 1];
-                if (k0 >= k1) return;
-                for (i64 p = 0; p < nnzK; p++) {
-                    const i32 hi = ehi[p];
-                    if (hi < k0 || hi >= k1) continue;
-                    const i32 u = nx[hi]++;
-                    hlo[u] = elo[p];
-                    hsrc[u] = (i32)p;
-                }
-            });
-        }
-        {
-            std::vector<i32> nx(Tp.begin(), Tp.end() - 1);
-            run_threads(T, [&](int t, int) { // pass 2: by lo, hi ascending
-                const i32 k0 = (i32)tcuts[t], k1 = (i32)tcuts[t + 1];
-                if (k0 >= k1) return;
-                for (i32 hi = 0; hi < n; hi++)
-                    for (i32 w = hp[hi]; w < hp[hi + 1]; w++) {
-                        const i32 lo = hlo[w];
-                        if (lo < k0 || lo >= k1) continue;
-                        const i32 u = nx[lo]++;
-                        Thi[u] = hi;
-                        Tsrc[u] = hsrc[w];
-                    }
-            });
-        }
-        {
-            std::vector<i32> nx(C2p.begin(), C2p.end() - 1);
-            run_threads(T, [&](int t, int) { // pass 3: by hi, lo ascending
-                const i32 k0 = (i32)hcuts[t], k1 = (i32)hcuts[t + 1];
-                if (k0 >= k1) return;
-                for (i32 lo = 0; lo < n; lo++)
-                    for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) {
-                        const i32 hi = Thi[u];
-                        if (hi < k0 || hi >= k1) continue;
-                        const i32 w = nx[hi]++;
-                        C2lo[w] = lo;
-                        C2src[w] = u; // position in V (T order)
-                    }
-            });
+            const std::vector<int64_t> tcuts = balanced_cuts(Tp.data(), n, T);
+            stable_buckets(T, (i32)n, C2p, false,
+                           [&](int t, int, auto f) {
+                               for (i32 lo = (i32)tcuts[t]; lo < (i32)tcuts[t + 1]; lo++)
+                                   for (i32 u = Tp[lo]; u < Tp[lo + 1]; u++) f(Thi[u], ((i64)lo << 32) | (uint32_t)u);
+                           },
+                           [&](i32, i64 pl, i32 w) {
+                               C2lo[w] = (i32)(pl >> 32);
+                               C2src[w] = (i32)(uint32_t)pl; // position in V (T order)
+                           });
         }
     }
     clk("T / C2 orders of K");
@@ -929,18 +903,26 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     //      factorisation); rows lo >= NF (entries with both ends in the top) are scattered into the top
     //      columns of L by v2l: merge of row lo of T with column lo of L ----------
     S.k2v.resize((size_t)nnzK + 1);
+    S.k2v[(size_t)nnzK] = 0;
     run_threads(par_threads(nnzK), [&](int t, int TT) {
         for (i64 u = nnzK * t / TT; u < nnzK * (t + 1) / TT; u++) S.k2v[Tsrc[u]] = (i32)u;
     });
-    S.v2k.assign(Tsrc.begin(), Tsrc.begin() + nnzK);
+    S.v2k.assign(Tsrc.data(), Tsrc.data() + nnzK);
     S.Vp = Tp;
     {
         const i32 NFi = S.NF;
         const i32 u0 = Tp[NFi];
         S.v2l.resize((size_t)(nnzK - u0) + 1);
+        S.v2l[(size_t)(nnzK - u0)] = 0;
         // (only the rows of the top: the bundle columns merge their U rows inside k_bundle_factor)
         const i64 q0 = S.Lp[NFi];
-        std::vector<char> covered((size_t)(nnzL - q0) + 1, 0);
+        RawBuf<char> covered((size_t)(nnzL - q0) + 1); // (zeroed by the threads: 3.9e8 flags for config 5)
+        {
+            const i64 span = nnzL - q0 + 1;
+            run_threads(par_threads(span), [&](int t, int TT) {
+                std::fill(covered.data() + span * t / TT, covered.data() + span * (t + 1) / TT, (char)0);
+            });
+        }
         const int T = par_threads(nnzK - u0);
         std::vector<int64_t> cuts = balanced_cuts(Tp.data() + NFi, (i64)n - NFi, T); // rows NF.., by their entries
         std::vector<int> bad((size_t)T, 0);
@@ -970,8 +952,16 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 return -9;
             }
         // fill slots of the TOP columns (the bundle kernels zero their own while they merge the U rows)
-        for (i64 q = q0; q < nnzL; q++)
-            if (!covered[(size_t)(q - q0)]) S.fill_idx.push_back((i32)q);
+        {
+            const int Tf = par_threads(nnzL - q0);
+            std::vector<std::vector<i32>> parts((size_t)Tf);
+            run_threads(Tf, [&](int t, int TT) {
+                const i64 span = nnzL - q0;
+                for (i64 q = q0 + span * t / TT; q < q0 + span * (t + 1) / TT; q++)
+                    if (!covered[(size_t)(q - q0)]) parts[(size_t)t].push_back((i32)q);
+            });
+            for (int t = 0; t < Tf; t++) S.fill_idx.insert(S.fill_idx.end(), parts[(size_t)t].begin(), parts[(size_t)t].end());
+        }
     }
     clk("v2l map, fill slots");
     // ---- K for the refinement residual e = b - K x (permuted numbering) ------
@@ -985,7 +975,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         // U: rows lo < NF = rows of T (diagonal first, ancestors ascending)
         S.Up.assign(Tp.begin(), Tp.begin() + NFi + 1);
         S.nnzU = S.Up[NFi];
-        S.Ucol.assign(Thi.begin(), Thi.begin() + S.nnzU);
+        S.Ucol.assign(Thi.data(), Thi.data() + S.nnzU);
         S.Ucol.push_back(0);
         // S: full rows r >= NF = column r of C2 (lo <= r ascending, diagonal last) then row r of T without its diagonal
         S.Sp.assign((size_t)n + 1, 0);
@@ -1001,6 +991,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         S.nnzS = S.Sp[n];
         S.Scol.resize((size_t)S.nnzS + 1);
         S.Smap.resize((size_t)S.nnzS + 1);
+        S.Scol[(size_t)S.nnzS] = S.Smap[(size_t)S.nnzS] = 0;
         const int T = par_threads(S.nnzS);
         const std::vector<int64_t> cuts = balanced_cuts(S.Sp.data() + NFi, (i64)n - NFi, T);
         run_threads(T, [&](int t, int) {
@@ -1357,8 +1348,8 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 }
             }
         }
-        const std::vector<i32> &FRp = nsn > 0 ? S.Rf_p : S.Rp, &FRcol = nsn > 0 ? S.Rf_col : S.Rcol,
-                               &FRpos = nsn > 0 ? S.Rf_pos : S.Rpos;
+        const std::vector<i32> &FRp = nsn > 0 ? S.Rf_p : S.Rp;
+        const i32 *FRcol = nsn > 0 ? S.Rf_col.data() : S.Rcol.data(), *FRpos = nsn > 0 ? S.Rf_pos.data() : S.Rpos.data();
         // buckets by unit level
         std::vector<i32> lcount((size_t)nfl + 1, 0), bucket((size_t)std::max<i64>(n - NFi, 0));
         for (i32 j = NFi; j < n; j++)

@@ -188,6 +188,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     i64 wflg = 2;
 
     double tph[5] = {0, 0, 0, 0, 0};
+    long long c_lme = 0, c_p1 = 0, c_p2e = 0, c_p2v = 0; // (work counters, printed with CHIP_TIMING)
     auto tick = [&](int k, std::chrono::steady_clock::time_point &t0) {
         if (!timing) return;
         const auto t1 = std::chrono::steady_clock::now();
@@ -255,6 +256,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         }
         est[me] = mstart;
         elen[me] = (I)epool.size() - mstart;
+        c_lme += elen[me];
         const I mend = mstart + elen[me];
         w[me] = 1;
         lemax = std::max(lemax, degme);
@@ -264,6 +266,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         for (I q = mstart; q < mend; q++) {
             const I i = epool[q];
             const I nvi = -nv[i];
+            c_p1 += alen[i] - avlen[i];
             for (I p = ast[i] + avlen[i]; p < ast[i] + alen[i]; p++) {
                 const I e = adj[p];
                 const i64 we = w[e];
@@ -277,6 +280,8 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
             const I p1 = ast[i], avl = avlen[i], eb = p1 + avl, ee = p1 + alen[i];
             I deg = 0, pn = eb;
             uint64_t hash = 0;
+            c_p2e += ee - eb;
+            if (scan) c_p2v += avl;
             for (I p = eb; p < ee; p++) { // elements, compacted in place
                 const I e = adj[p];
                 const i64 we = w[e];
@@ -442,6 +447,8 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_adj).count(), (long long)pivots.size());
         std::fprintf(stderr, "[chip amd]   element %.3f, pass 1 %.3f, pass 2 %.3f, supervariables %.3f, finalise %.3f s\n",
                      tph[0], tph[1], tph[2], tph[3], tph[4]);
+        std::fprintf(stderr, "[chip amd]   sum |Lme| %lld, element-list entries visited: pass 1 %lld, pass 2 %lld, variable-list entries rescanned %lld\n",
+                     c_lme, c_p1, c_p2e, c_p2v);
     }
     // ---- expand supervariables: every absorbed variable follows its pivot ---
     std::vector<char> is_pivot((size_t)n, 0);

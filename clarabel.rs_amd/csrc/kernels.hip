@@ -1665,6 +1665,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
         }
     }
     sn_stamp(sv.dbg, dbgme, 20, true);
+    if (sv.dbg && tid == 0) atomicMax((unsigned long long *)&sv.dbg[21], (unsigned long long)wall_clock64()); // last workgroup's end
 }
 
 __device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
@@ -2053,6 +2054,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int jj = 0; jj < SN_NB; ++jj)
         if (jj < nbw) v.Lx[colbase[jj] + R] = x[jj] * dinvl[jj];
     sn_stamp(sv.dbg, dbgme, 7, true);
+    if (sv.dbg && tid == 0) atomicMax((unsigned long long *)&sv.dbg[8], (unsigned long long)wall_clock64()); // last workgroup's end
 }
 
 // Substitutions through a chain supernode, one workgroup per supernode of the unit level, the
@@ -6547,7 +6549,7 @@ struct SnDebug {
         kinds.push_back(kind);
         return dev + 64 + (size_t)(nring++ % RING) * 32;
     }
-    double gap_sum[2] = {0, 0}, in_sum[2] = {0, 0};
+    double gap_sum[2] = {0, 0}, in_sum[2] = {0, 0}, skew_sum[2] = {0, 0};
     long gap_n[2] = {0, 0};
     void flush_ring() {
         (void)hipDeviceSynchronize();
@@ -6560,7 +6562,10 @@ struct SnDebug {
             const int base = kinds[k] ? 16 : 0, hi = kinds[k] ? 20 : 7;
             long long first = r[base], last = 0;
             for (int i = base; i <= hi; i++) last = std::max(last, r[i]);
-            if (first && prev_last && first > prev_last && first - prev_last < 100000) { // (< 1 ms: same factorisation)
+            const long long wg0_last = last;
+            last = std::max(last, r[kinds[k] ? 21 : 8]); // (the end of the launch's LAST workgroup)
+            if (first) skew_sum[kinds[k]] += (last - wg0_last) * 0.01;
+            if (first && prev_last && first > prev_last && first - prev_last < 100000 && k > 0 && kinds[k - 1] != kinds[k]) { // (update <-> panel pairs of one block column)
                 gap_sum[kinds[k]] += (first - prev_last) * 0.01;
                 in_sum[kinds[k]] += (last - first) * 0.01;
                 gap_n[kinds[k]]++;
@@ -6578,8 +6583,8 @@ struct SnDebug {
             flush_ring();
             for (int k = 0; k < 2; k++)
                 if (gap_n[k])
-                    std::fprintf(stderr, "[chip sn debug] %s: mean over %ld launches: %.2f us between the previous launch's last stamp and this one's first, %.2f us inside (workgroup 0)\n",
-                                 k ? "k_snode_update" : "k_snode_panel", gap_n[k], gap_sum[k] / gap_n[k], in_sum[k] / gap_n[k]);
+                    std::fprintf(stderr, "[chip sn debug] %s: mean over %ld launches: %.2f us between the END of the previous launch's last workgroup and this one's first stamp, %.2f us from there to the end of its last workgroup (workgroup 0 ends %.2f us before the last one)\n",
+                                 k ? "k_snode_update" : "k_snode_panel", gap_n[k], gap_sum[k] / gap_n[k], in_sum[k] / gap_n[k], skew_sum[k] / std::max(1L, n[k]));
         }
         if (!on) return;
         const char *pn[8] = {"", "geometry+colbase", "block loads", "block factorisation", "write-back", "row loads", "rows recurrence", "stores"};

@@ -1923,6 +1923,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     sn_stamp(sv.dbg, dbgme, 1);
     const int ci = live ? g.cols[j0 + i] : 0;
     double di = live ? v.D[ci] : 1.0; // running diagonal entry of row i (kept by all four threads of the row)
+    const double sgl = sgn[i];        // lane j: sign of column j (read by v_readlane: an LDS read per pivot sat on the chain)
     double T[16];
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
@@ -1942,7 +1943,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int t = 0; t < SNP_CB; ++t) {
                     const int c = c0 + t;
                     double d = readlane_f64(di, c); // (c is wave uniform)
-                    const double sg = sgn[c];
+                    const double sg = readlane_f64(sgl, c);
                     const bool reg = d * sg < v.reg_eps;
                     if (reg) d = v.reg_delta * sg;
                     const double dinv = 1.0 / d;

@@ -1895,9 +1895,12 @@ __global__ __launch_bounds__(SN_RWG) void k_snode_rows(LdlView v, SnodeView sv, 
 // ---------------------------------------------------------------------------
 constexpr int SNP_WG = 256;
 constexpr int SNP_CB = 4;
-__global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snode_panel(LdlView v, SnodeView sv, const int *__restrict__ order, int b) {
+constexpr int SNP_XLD = 17; // row stride of a wave's head block in LDS (odd: lanes = rows hit distinct banks)
+__global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snode_panel(LdlView v, SnodeView sv, const int *__restrict__ order, int b,
+                                                                                                  int rows_mfma) {
     __shared__ __attribute__((aligned(16))) double Ll[SN_NB * SN_NB];        // Ll[k * 64 + i] = l(i, k), 0 for i <= k
     __shared__ __attribute__((aligned(16))) double ucol[2][SNP_CB][SN_NB];   // unscaled entries of a group's columns (0 for i <= c)
+    __shared__ double xh[SNP_WG / 64][64 * SNP_XLD];                       // rows phase (matrix-core form): a wave's head block, [row][column]
     __shared__ double dinvl[SN_NB], sgn[SN_NB];
     __shared__ int colbase[SN_NB];
     __shared__ int s_nreg, s_bad;
@@ -2021,6 +2024,101 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     sn_stamp(sv.dbg, dbgme, 4, true);
     if (row0 >= g.h) return;
+    if (rows_mfma) {
+        // ---- the rows below the block, blocked by 16 columns (round 3): a wave owns 64 rows.  Block kb of every row is
+        //      finished by the recurrence in the lane = row form (120 products per row instead of 2016), and its effect
+        //      on the blocks behind it is a (64 x 16) x (16 x 16) product on the f64 matrix cores -- 96 instructions per
+        //      wave for all six block pairs.  The blocks behind the head live in the accumulator layout (lane = column,
+        //      registers = rows), the head block crosses between the two forms through the wave's own LDS slice.
+        //      Per entry the subtractions still go k = 0, 1, ...; inside a matrix instruction they are fused
+        //      multiply-adds (as in the update tiles).
+        const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        double *xw = xh[wave];
+        const int R0w = row0 + 64 * wave;         // first row of the wave
+        const int R = R0w + lane;                  // lane = row form
+        const bool rowok = R < g.h;
+        const int Rc = min(R, g.h - 1);
+        if (R0w >= g.h) return;                   // (whole wave beyond the panel; no workgroup barrier below)
+        // blocks 1..3 in the accumulator layout: acc[jb - 1][t][r] = X[row 16 t + kq + 4 r][column 16 jb + l15]
+        snode_v4d acc[3][4];
+#pragma unroll
+        for (int jb = 1; jb < 4; ++jb) {
+            const int jj = 16 * jb + l15;
+            const int cb = colbase[jj];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = min(R0w + 16 * t + kq + 4 * r, g.h - 1);
+                    const double xv = v.Lx[cb + row];
+                    acc[jb - 1][t][r] = jj < nbw ? xv : 0.0;
+                }
+        }
+        double h[16]; // the head block of the own row, lane = row form
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h[c] = v.Lx[colbase[c] + Rc];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h[c] = c < nbw ? h[c] : 0.0;
+        sn_stamp(sv.dbg, dbgme, 5, true);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb > 0) { // the head block leaves the accumulator layout: [row][column] in LDS, then a row per lane
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = acc[kb - 1][t][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) h[c] = xw[lane * SNP_XLD + c];
+                __builtin_amdgcn_wave_barrier();
+            }
+            // the block's own triangle: u_c -= l(16 kb + c, 16 kb + kk) u_kk
+            const double *Lb = Ll + (16 * kb) * SN_NB + 16 * kb;
+#pragma unroll
+            for (int kk = 0; kk < 15; ++kk) {
+                const double uq = h[kk];
+                int zoff; // (ties the column's LDS reads to its place in the chain, see below)
+                asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(uq)));
+                const snode_v2d *cf = (const snode_v2d *)(Lb + kk * SN_NB + zoff);
+#pragma unroll
+                for (int p2 = (kk + 1) / 2; p2 < 8; ++p2) {
+                    const snode_v2d cc = cf[p2]; // (the pair that straddles kk meets a stored zero)
+                    h[2 * p2] -= cc.x * uq;
+                    h[2 * p2 + 1] -= cc.y * uq;
+                }
+            }
+            if (rowok) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int jj = 16 * kb + c;
+                    if (jj < nbw) v.Lx[colbase[jj] + R] = h[c] * dinvl[jj];
+                }
+            }
+            if (kb == 3) break;
+            // the finished block, negated, as the A operand of the products: [row][column] in LDS
+#pragma unroll
+            for (int c = 0; c < 16; ++c) xw[lane * SNP_XLD + c] = -h[c];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                double a4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a4[t] = xw[(16 * t + l15) * SNP_XLD + 4 * s4 + kq]; // A[m = l15][k = 4 s4 + kq] of tile t
+#pragma unroll
+                for (int jb = kb + 1; jb < 4; ++jb) {
+                    const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * jb + l15]; // B[k][n] = l(16 jb + n, 16 kb + k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[jb - 1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], bv, acc[jb - 1][t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        sn_stamp(sv.dbg, dbgme, 6);
+        sn_stamp(sv.dbg, dbgme, 7, true);
+        if (sv.dbg && lane == 0) atomicMax((unsigned long long *)&sv.dbg[8], (unsigned long long)wall_clock64());
+        return;
+    }
     // ---- the rows below the block: thread = row, its 64 entries in registers, right-looking (the products of one
     //      column are independent; per entry the subtractions happen in the order k = 0, 1, ... of qdldl.rs:610-640).
     //      (Measured and dropped: the same recurrence blocked by 16 columns with one rolled code body -- 30 KB of
@@ -6640,7 +6738,8 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
             const int below = hmax - b * SN_NB - 1;
             pb(PFK_SN_DIAG);
             if (dbg.mode == 2) sv.dbg = dbg.ring_slot(0);
-            k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b);
+            static const bool rows_mfma = std::getenv("CHIP_NO_PANEL_MFMA") == nullptr;
+            k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b, rows_mfma ? 1 : 0);
             pe(PFK_SN_DIAG);
             if (dbg.on && dbg.mode != 2) dbg.collect(s, 0);
             continue;

@@ -1928,14 +1928,93 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     double di = live ? v.D[ci] : 1.0; // running diagonal entry of row i (kept by all four threads of the row)
     const double sgl = sgn[i];        // lane j: sign of column j (read by v_readlane: an LDS read per pivot sat on the chain)
     double T[16];
+    double dfin = 1.0, dinvfin = 1.0; // pivot of row i, recorded by the owner of column i
+    int nreg = 0, bad = 0;
+    if (rows_mfma & 2) {
+        // ---- block factorisation, matrix-core form (round 3): wave q owns column quarter q of the 64 x 64 block, ALL
+        //      64 rows of it, in the accumulator layout (lane = column 16 q + l15, registers = rows: 4 tiles x 4).
+        //      Quarter kb is factored by its owner alone in the lane = row form (through the wave's LDS slice): the
+        //      diagonal entries live IN the block (entry (c, c) is the pivot candidate), 16 pivots with the
+        //      in-quarter updates by v_readlane; it publishes the unscaled panel (negated, [row][k]) and the scaled
+        //      one (Ll); after ONE barrier the quarters behind it subtract (64 x 16) x (16 x 16) on the matrix cores
+        //      (16 instructions per wave).  Four barriers per block (sixteen before, sixty-four in round 2).
+        const int l15 = i & 15, kq = i >> 4;
+        double *xw = xh[q];
+        snode_v4d Aq[4];
+        {
+            const int j = 16 * q + l15; // this lane's column
+            const bool jok = j < nbw;
+            const int cb = colbase[j];
+            const double djj = jok ? v.D[g.cols[j0 + min(j, nbw - 1)]] : 1.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + kq + 4 * r;
+                    double val = (jok && row < nbw && row > j) ? v.Lx[cb + j0 + row] : 0.0;
+                    if (row == j) val = djj;
+                    Aq[t][r] = val;
+                }
+        }
+        sn_stamp(sv.dbg, dbgme, 2, true);
+#pragma unroll 1
+        for (int kb = 0; kb < SN_NB / 16; ++kb) {
+            if (q == kb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = Aq[t][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) T[c] = xw[i * SNP_XLD + c];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int c = 16 * kb + t;
+                    double d = readlane_f64(T[t], c); // entry (c, c): (c is wave uniform)
+                    const double sg = readlane_f64(sgl, c);
+                    const bool reg = d * sg < v.reg_eps;
+                    if (reg) d = v.reg_delta * sg;
+                    const double dinv = 1.0 / d;
+                    if (i == c) {
+                        dfin = d;
+                        dinvfin = dinv;
+                        if (reg) nreg = 1;
+                        if (d == 0.0) bad |= 2;
+                        if (!isfinite(dinv)) bad |= 1;
+                    }
+                    const double uc = i > c ? T[t] : 0.0;
+                    const double l = uc * dinv;
+                    T[t] = l;
+                    xw[i * SNP_XLD + t] = -uc;
+                    Ll[c * SN_NB + i] = l;
+                    if (i == 0) dinvl[c] = dinv;
+#pragma unroll
+                    for (int t2 = t + 1; t2 < 16; ++t2) // entry (i, c2) -= l(c2, c) u(i, c), the diagonal entries included
+                        T[t2] -= readlane_f64(l, 16 * kb + t2) * uc;
+                }
+            }
+            __syncthreads();
+            if (q > kb) {
+                const double *xo = xh[kb];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * q + l15]; // B[k][n] = l(16 q + n, 16 kb + k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = xo[(16 * t + l15) * SNP_XLD + 4 * s4 + kq]; // A[m][k] = -u(16 t + m, 16 kb + k)
+                        Aq[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Aq[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
         const int j = 16 * q + cc;
         T[cc] = (live && j < nbw && i > j) ? v.Lx[colbase[j] + j0 + i] : 0.0;
     }
     sn_stamp(sv.dbg, dbgme, 2, true);
-    double dfin = 1.0, dinvfin = 1.0; // pivot of row i, recorded by the owner of column i
-    int nreg = 0, bad = 0;
     // the quarter loop stays rolled; the 16 columns of a quarter are unrolled, so T[..] are fixed registers
     for (int qq = 0; qq < SN_NB / 16; ++qq) {
 #pragma unroll
@@ -1989,6 +2068,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
     }
+    } // (round-2 form of the block factorisation)
     sn_stamp(sv.dbg, dbgme, 3);
     if (nreg) atomicAdd(&s_nreg, 1);
     if (bad) atomicOr(&s_bad, bad);
@@ -2024,7 +2104,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     sn_stamp(sv.dbg, dbgme, 4, true);
     if (row0 >= g.h) return;
-    if (rows_mfma) {
+    if (rows_mfma & 1) {
         // ---- the rows below the block, blocked by 16 columns (round 3): a wave owns 64 rows.  Block kb of every row is
         //      finished by the recurrence in the lane = row form (120 products per row instead of 2016), and its effect
         //      on the blocks behind it is a (64 x 16) x (16 x 16) product on the f64 matrix cores -- 96 instructions per
@@ -6738,8 +6818,9 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
             const int below = hmax - b * SN_NB - 1;
             pb(PFK_SN_DIAG);
             if (dbg.mode == 2) sv.dbg = dbg.ring_slot(0);
-            static const bool rows_mfma = std::getenv("CHIP_NO_PANEL_MFMA") == nullptr;
-            k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b, rows_mfma ? 1 : 0);
+            // (bit 0: rows phase on the matrix cores; bit 1: block factorisation on the matrix cores)
+            static const int panel_mode = (std::getenv("CHIP_NO_PANEL_MFMA") ? 0 : 1) | (std::getenv("CHIP_NO_PANEL_DIAG_MFMA") ? 0 : 2);
+            k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
             pe(PFK_SN_DIAG);
             if (dbg.on && dbg.mode != 2) dbg.collect(s, 0);
             continue;

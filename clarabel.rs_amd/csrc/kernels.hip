@@ -6813,13 +6813,13 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
                 if (dbg.on && dbg.mode != 2) dbg.collect(s, 1);
             }
         }
-        static const bool no_panel = std::getenv("CHIP_NO_SNODE_PANEL") != nullptr;
+        const bool no_panel = std::getenv("CHIP_NO_SNODE_PANEL") != nullptr; // (read per call: the tests switch forms inside one process)
         if (!no_panel) { // the diagonal block and the rows below it in one launch of one-wave workgroups
             const int below = hmax - b * SN_NB - 1;
             pb(PFK_SN_DIAG);
             if (dbg.mode == 2) sv.dbg = dbg.ring_slot(0);
             // (bit 0: rows phase on the matrix cores; bit 1: block factorisation on the matrix cores)
-            static const int panel_mode = (std::getenv("CHIP_NO_PANEL_MFMA") ? 0 : 1) | (std::getenv("CHIP_NO_PANEL_DIAG_MFMA") ? 0 : 2);
+            const int panel_mode = (std::getenv("CHIP_NO_PANEL_MFMA") ? 0 : 1) | (std::getenv("CHIP_NO_PANEL_DIAG_MFMA") ? 0 : 2);
             k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
             pe(PFK_SN_DIAG);
             if (dbg.on && dbg.mode != 2) dbg.collect(s, 0);

@@ -1468,6 +1468,34 @@ def test_chain_supernodes_factor_parity(hip, oracle, which, monkeypatch):
         assert np.abs(np.asarray(La[pad.nonzero()])).max() == 0.0
 
 
+@pytest.mark.parametrize("form", ["CHIP_NO_SNODE_PANEL", "CHIP_NO_PANEL_MFMA", "CHIP_NO_PANEL_DIAG_MFMA"])
+@pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
+def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
+    """the block column of a supernode has three older forms behind switches -- separate k_snode_diag / k_snode_rows
+    launches, and the scalar forms of the panel kernel's two phases: each against the oracle, and its factor against
+    the default form's (same pivots, entries within rounding)"""
+    if which == "banded_qp":
+        pr, hs = problems.random_qp(20000, 40000, band=50, seed=1), None
+    else:
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1)
+    assert len(ks.supernodes()) > 0
+    K = ks.kkt_matrix()
+    Kc = hip.CscMatrix(ks.N, ks.N, K.colptr, K.rowval, ks.values())
+    dsigns = ks.maps()["dsigns"]
+    fa = hip.HipDirectLDLSolver(Kc, dsigns, hip.Settings.default(), perm=ks.perm)
+    fa.refactor()
+    _, _, Lxa, Da, _ = fa.factors()
+    monkeypatch.setenv(form, "1")
+    ks2, _ = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1)
+    fb = hip.HipDirectLDLSolver(Kc, dsigns, hip.Settings.default(), perm=ks.perm)
+    fb.refactor()
+    _, _, Lxb, Db, _ = fb.factors()
+    assert relerr(Da, Db) <= 1e-10
+    assert np.max(np.abs(Lxa - Lxb)) <= 1e-10 * max(1.0, np.max(np.abs(Lxa)))
+
+
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
 def test_chain_supernodes_solve_without_lds_rows(hip, oracle, which, monkeypatch):
     """the substitutions through supernodes whose rows of B exceed the LDS budget (forced here by

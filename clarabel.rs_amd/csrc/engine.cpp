@@ -1,6 +1,6 @@
 // engine.cpp -- device-resident numeric LDL' / solve / residual sequences.
 // One HIP stream per handle; dependencies between elimination-tree levels are
-// kernel boundaries on that stream (see kernels.hip for the rationale).
+// kernel boundaries on that stream (see dev_common.hpp for the rationale).
 #include "engine.hpp"
 
 #include <cstdlib>
@@ -204,7 +204,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         if ((rc = upload(&sn_ptr, S.sn_ptr, S.sn_ptr.size()))) return rc;
         if ((rc = upload(&sn_col, S.sn_col, S.sn_col.size()))) return rc;
         {
-            // the supernodes in level order as records (kernels.hip: SN_REC = 8 ints): id, first member, width, last
+            // the supernodes in level order as records (snode.hip: SN_REC = 8 ints): id, first member, width, last
             // member column, rows of B
             std::vector<i32> rec(S.sn_order.size() * 8 + 8, 0);
             for (size_t k = 0; k < S.sn_order.size(); k++) {
@@ -225,7 +225,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 geo[2 * sn + 1] = S.Lp[e + 1] - S.Lp[e];
             }
             if ((rc = upload(&sn_geo, geo, geo.size()))) return rc;
-            // column bases of the dense panels (kernels.hip: SnodeGeom::cb): every supernode kernel started with
+            // column bases of the dense panels (snode.hip: SnodeGeom::cb): every supernode kernel started with
             // Lp[cols[t]] - t - 1 for its columns, two dependent loads before the first useful one
             std::vector<i32> cb(S.sn_col.size() + 1, 0);
             for (int sn = 0; sn < nsn; sn++)
@@ -342,7 +342,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         std::getenv("CHIP_NO_FUSED_IR") == nullptr) {
         int cap = dev::bundle_ir_capacity(bundles, &ir_tw);
         if (cap > 0 && std::getenv("CHIP_NO_SYMV_SPLIT") == nullptr) {
-            // the residual's "split" form (kernels.hip: bundle_symv_split) needs nloc + max(0, nloc - 2 nleaf) doubles
+            // the residual's "split" form (bundle_symv.hpp: bundle_symv_split) needs nloc + max(0, nloc - 2 nleaf) doubles
             // of LDS per bundle: taken when the larger slice leaves the co-resident grid and the workgroup size as
             // they are
             int need = 0;

@@ -48,7 +48,7 @@ static_assert(sizeof(Mailbox) <= 512, "mailbox");
 // profile families (hipEvent pairs around each launch of ONE selected family)
 enum ProfFamily {
     PF_NONE = 0, PF_SYMV_T = 1, PF_BWD_T = 2, PF_FWD_T = 3, PF_FACTOR_T = 4, PF_IR = 5, PF_BFACTOR = 6,
-    // supernode kernels (ids shared with the launchers in kernels.hip: dev::PFK_*)
+    // supernode kernels (ids shared with the launchers in snode.hip: dev::PFK_*)
     PF_SN_UPDATE = dev::PFK_SN_UPDATE, PF_SN_DIAG = dev::PFK_SN_DIAG, PF_SN_ROWS = dev::PFK_SN_ROWS,
     PF_SN_EXTEND = dev::PFK_SN_EXTEND, PF_SN_TRI = dev::PFK_SN_TRI,
     PF_SN_GATHER = 12, // k_gather_merged launches of the supernode substitution path
@@ -181,7 +181,7 @@ struct Engine {
     void prof_end(int family);
     void prof_pair(int family, hipEvent_t *ev0, hipEvent_t *ev1);
     void prof_collect();
-    dev::LaunchProf launch_prof(); // hook handed to the launchers in kernels.hip (nullptr-equivalent when off)
+    dev::LaunchProf launch_prof(); // hook handed to the launchers in snode.hip (nullptr-equivalent when off)
     // work model of the chain supernodes, per refactor / per sweep (host.hpp: Symbolic::sn_*), for the roofline
     // figures of bench.py: [0] multiply-add flops of k_snode_update (2 per multiply-add, useful part of the
     // tiles: rows >= the block's first row), [1] entries of the dense trapezoids (what one sweep streams),

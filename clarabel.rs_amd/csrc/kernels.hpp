@@ -1,4 +1,4 @@
-// kernels.hpp -- launch wrappers of the hand-written gfx950 kernels (kernels.hip).
+// kernels.hpp -- launch wrappers of the hand-written gfx950 kernels (algebra / bundle_factor / bundle_solve / bundle_ir / snode / cones .hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -193,7 +193,7 @@ struct SnodeView {
 int snode_kernel_attributes(int wmax, int nbmax);
 
 // optional per-launch hook: hipEvent pairs around the launches of ONE selected kernel family (engine.hpp:
-// ProfFamily; the ids of the supernode kernels are fixed here because the launchers live in kernels.hip)
+// ProfFamily; the ids of the supernode kernels are fixed here because the launchers live in snode.hip)
 enum { PFK_SN_UPDATE = 7, PFK_SN_DIAG = 8, PFK_SN_ROWS = 9, PFK_SN_EXTEND = 10, PFK_SN_TRI = 11 };
 struct LaunchProf {
     void (*begin)(void *ctx, int family);

@@ -1,0 +1,1466 @@
+// snode.hip -- chain supernodes: MFMA update tiles, panel factorisation, ancestor updates, substitutions (k_snode_*)
+// (one of the translation units behind kernels.hpp; the design rules and the reference citations are in
+// dev_common.hpp)
+#include "dev_common.hpp"
+
+namespace chip {
+namespace dev {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Chain supernodes (host.hpp: Symbolic::sn_*): w columns c_0 < ... < c_{w-1}, each the parent of the
+// previous one, all padded to the dense trapezoid  rows(c_t) = [c_{t+1}, ..., c_{w-1}, B...]  with
+// B = struct(c_{w-1}), so that panel entry (i, t), i > t, is Lx[Lp[c_t] + i - t - 1] (panel rows i < w
+// are the members, rows >= w the nb rows of B).  On entry Lx / D of the members hold K minus the
+// contributions of all columns that are NOT supernode members (the sparse column kernels over the
+// filtered row lists) and minus the dense updates of descendant supernodes (k_snode_extend).
+// All supernodes of a unit level advance together, one block column of SN_NB at a time, kernel
+// boundaries acting as the grid-wide synchronisation:
+//   k_snode_update(b): A'[i, J_b] -= sum_{k < j0} L[i,k] d_k L[j,k] for all panel rows i >= j0 = 64 b,
+//      left-looking, 16 x 64 tiles on the f64 matrix cores (v_mfma_f64_16x16x4_f64, four per A
+//      operand); the (d_k L[j,k]) operand is staged in LDS SN_KC columns at a time, the L[i,k] operand is
+//      streamed from the finished columns in 128-byte runs, SN_U requests in flight per lane;
+//   k_snode_diag(b): the 64 x 64 diagonal block column by column with the sign-based dynamic
+//      regularisation of qdldl.rs:645-665 in LDS;  k_snode_rows(b): the rows below it, one thread per
+//      row, by forward substitution against the block;
+//   k_snode_extend: once a supernode is complete, its update of the ANCESTORS' columns, the
+//      nb x nb matrix L_B D L_B' (the multifrontal "update matrix"), computed with the same tiles
+//      and subtracted at precomputed slots (upd_slot) with fp64 atomics.
+// ~64 flops per streamed double instead of the ~1/8 of the per-entry gathers of the column kernels.
+// ---------------------------------------------------------------------------
+constexpr int SN_NB = 64;
+constexpr int SN_KC = 128;  // 64 * 128 * 8 = 64 KiB
+constexpr int SN_U = 4;     // k-groups of A operands in flight per lane (x 2 tiles; 8 needs more than 128 registers)
+constexpr int SN_WST = 4;   // k rows (entry + pivot) in flight per thread while the LDS operand is staged
+constexpr int SN_WG = 512;
+constexpr int SN_ROWS = 256; // panel rows per workgroup of the update kernels: 8 waves x 2 tiles of 16
+typedef double snode_v4d __attribute__((ext_vector_type(4)));
+typedef double snode_v2d __attribute__((ext_vector_type(2)));
+
+// broadcast of lane `src` (a compile-time constant after unrolling) without the LDS crossbar
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// x <- (I + T)^-1 x (FWDMODE) or (I + T)^-T x for one SN_NB block held by ONE wave, lane = row.  Tt is the block
+// in LDS with the LANE index fastest (forward: Tt[jj * SN_NB + row] = T(row, jj); backward: Tt[jj * SN_NB +
+// row] = T(jj, row)), zero outside the strict triangle, so a narrow last block needs no bounds.  The 64
+// coefficients of a lane do not depend on x: they are read up front (conflict-free), and the 64 dependent
+// steps are a v_readlane + v_fma each (with __shfl through LDS and a 512-byte-stride read per step the same
+// loop took ~3 us of a ~9 us pipeline stage of k_snode_tri).
+template <bool FWDMODE> __device__ __forceinline__ double snode_block_solve(const double *Tt, double xv, int lane) {
+    double t[SN_NB];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) t[jj] = Tt[jj * SN_NB + lane];
+    if (FWDMODE) {
+#pragma unroll
+        for (int jj = 0; jj < SN_NB - 1; ++jj) xv -= t[jj] * readlane_f64(xv, jj);
+    } else {
+#pragma unroll
+        for (int jj = SN_NB - 1; jj > 0; --jj) xv -= t[jj] * readlane_f64(xv, jj);
+    }
+    return xv;
+}
+
+// CHIP_SN_DEBUG: wall-clock stamps (10 ns ticks) of ONE workgroup of a supernode launch at its phase boundaries;
+// `drain` first waits for the loads in flight, so that a phase owns the latency of what it requested
+__device__ __forceinline__ void sn_stamp(long long *dbg, bool me, int slot, bool drain = false) {
+    if (!dbg) return;
+    if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (me) dbg[slot] = wall_clock64();
+}
+struct SnodeGeom {
+    const int *cols;
+    const int *cb; // column bases of the panel (host-computed: Lp[cols[t]] - t - 1)
+    double *d;     // pivots of the members, packed (k_snode_diag)
+    const int8_t *sg; // signs of the members, packed
+    int w, nb, h, e;
+};
+// The supernodes of a unit level come as RECORDS in level order (`order` points at the level's first record):
+// (supernode id, first member p0, width w, last member column e, rows of B, -, -, -) -- one 32-byte read where the
+// kernels of rounds 1-2 chased order -> sn -> sn_ptr / sn_geo (three dependent loads at the head of every launch).
+constexpr int SN_REC = 8;
+__device__ __forceinline__ SnodeGeom snode_geom(const SnodeView &sv, const int *__restrict__ order, int idx, int &sn) {
+    typedef int rec_v4i __attribute__((ext_vector_type(4)));
+    const rec_v4i r0 = *(const rec_v4i *)(order + SN_REC * idx);
+    const int nb = order[SN_REC * idx + 4];
+    SnodeGeom g;
+    sn = r0.x;
+    g.cols = sv.sn_col + r0.y;
+    g.cb = sv.sn_cb + r0.y;
+    g.d = sv.sn_d + r0.y;
+    g.sg = sv.sn_sg + r0.y;
+    g.w = r0.z;
+    g.e = r0.w;
+    g.nb = nb;
+    g.h = g.w + g.nb;
+    return g;
+}
+
+// acc[2][4] += L[rows of this wave's two tiles, k0..kend) * (d L[jrow0.., k])' ; emit per element.
+// EXTEND = false: targets are the supernode's own block column (each element owned by one lane unless the k
+// range is split: atomic_emit); true: the ancestors' columns through upd_slot (atomics).
+//
+// Round 3 (the launch ran at 0.17 of the f64 matrix peak, one workgroup per CU):
+//  * 128 registers per lane, so that TWO workgroups share a CU (four waves per SIMD): one stages its (d L)'
+//    operand while the other multiplies.  The A operands are no longer double buffered in registers -- the
+//    entries of k-group g + 1 are requested INTO the registers of group g right after the matrix instructions
+//    that read them, SN_U groups of loads in flight per lane;
+//  * the A loads are unconditional: rows beyond the panel and columns beyond the chunk are clamped to valid
+//    entries (their products meet stored zeros of the LDS operand, or rows that are never emitted) -- the
+//    predicated form compiled to a branch and an LDS round trip per load;
+//  * the result leaves through LDS, transposed: the matrix instruction leaves a lane with ONE column of the tile
+//    (16 columns per instruction, 32 bytes of each cache line), the panel is column-major, so every emitted
+//    instruction touched 16 lines -- now a lane owns a ROW, an instruction covers four columns x 16 consecutive
+//    rows (128-byte runs), and the slot indices of the ancestor update are read the same way.
+template <bool EXTEND>
+__device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &sv, const SnodeGeom &g, int sn,
+                                            const int *colbase, double *Wl, int jrow0, int ncols, int kend,
+                                            int row_begin, int kbeg = 0, bool atomic_emit = false) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4, l15 = lane & 15;
+    const int i0[2] = {row_begin + wave * 32, row_begin + wave * 32 + 16};
+    // (clamped: a row beyond the panel reads the last row, its results are not emitted)
+    const int irc[2] = {min(i0[0] + l15, g.h - 1), min(i0[1] + l15, g.h - 1)};
+    snode_v4d acc[2][SN_NB / 16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < SN_NB / 16; ++c) acc[t][c] = snode_v4d{0.0, 0.0, 0.0, 0.0};
+    // the A operands are one stream of k-groups (4 SN_U columns each) over the whole k range, chunk boundaries
+    // included: group g + 1 is requested into the registers of group g as they are released, unconditionally
+    // (beyond the range: clamped, never used), so that the number of loads in flight is a constant the
+    // compiler can count (a conditional request made it wait for ALL loads at the head of every group)
+    double a[2][SN_U];
+    const bool wave_live = i0[0] < g.h; // (wave uniform)
+    auto request = [&](int u, int kabs) { // two independent 4 x 128-byte runs
+        const int cb = colbase[min(kabs + 4 * u + kq, kend - 1)];
+        a[0][u] = v.Lx[cb + irc[0]];
+        a[1][u] = v.Lx[cb + irc[1]];
+    };
+    const bool dbgme = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+    sn_stamp(sv.dbg, dbgme, 16);
+    __syncthreads(); // (the caller has just filled colbase)
+    sn_stamp(sv.dbg, dbgme, 17, true);
+    if (wave_live && kbeg < kend) {
+#pragma unroll
+        for (int u = 0; u < SN_U; ++u) request(u, kbeg);
+    }
+    for (int kc0 = kbeg; kc0 < kend; kc0 += SN_KC) {
+        const int kcn = min(SN_KC, kend - kc0);
+        const int kcnu = (kcn + 4 * SN_U - 1) / (4 * SN_U) * (4 * SN_U); // whole groups: the tail rows of the operand are zeros
+        __syncthreads(); // the previous chunk has been consumed
+        // the (d_k L[j,k]) operand: a wave stages whole k rows -- lane = column of the block --, SN_WST rows in
+        // flight; the column base is a wave-uniform LDS read and the pivot a wave-uniform load from the packed
+        // pivots (SnodeView::sn_d), issued together with the entry it scales: ONE global round trip per batch
+        // (round 2: cols -> D -> LDS, a barrier, then the entries)
+        for (int kr = wave; kr < kcnu; kr += SN_WST * (SN_WG / 64)) {
+            double wv[SN_WST], dv[SN_WST];
+#pragma unroll
+            for (int r = 0; r < SN_WST; ++r) {
+                const int kk = min(kr + r * (SN_WG / 64), kcn - 1); // (clamped: no branch per load)
+                wv[r] = v.Lx[colbase[kc0 + kk] + jrow0 + min(lane, ncols - 1)];
+                dv[r] = g.d[kc0 + kk];
+            }
+#pragma unroll
+            for (int r = 0; r < SN_WST; ++r) {
+                const int kk = kr + r * (SN_WG / 64);
+                if (kk < kcnu) Wl[kk * SN_NB + lane] = (kk < kcn && lane < ncols) ? wv[r] * dv[r] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (kc0 == kbeg) sn_stamp(sv.dbg, dbgme, 18);
+        if (!wave_live) continue; // (after the barriers: the whole wave is beyond the panel)
+        for (int kk = 0; kk < kcnu; kk += 4 * SN_U) {
+            const int knext = kk + 4 * SN_U < kcnu ? kc0 + kk + 4 * SN_U : kc0 + SN_KC; // (the next chunk's first group)
+#pragma unroll
+            for (int u = 0; u < SN_U; ++u) {
+                const int kl = kk + 4 * u + kq;
+#pragma unroll
+                for (int c = 0; c < SN_NB / 16; ++c) {
+                    const double bw = Wl[kl * SN_NB + 16 * c + l15];
+                    acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][u], bw, acc[0][c], 0, 0, 0);
+                    acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][u], bw, acc[1][c], 0, 0, 0);
+                }
+                request(u, knext);
+            }
+        }
+    }
+    sn_stamp(sv.dbg, dbgme, 19);
+    // ---- emit through LDS: this wave's 16 x 64 tile in its own 8 KiB of the (now free) operand buffer, element
+    //      (row rr, column jj) at jj * 16 + (rr ^ (jj & 15)) -- the swizzle keeps both the column-per-lane writes
+    //      and the row-per-lane reads off common banks
+    __syncthreads();
+    if (i0[0] >= g.h) return;
+    double *Tw = Wl + wave * (16 * SN_NB);
+    const int *Bn = v.Li + v.Lp[g.e]; // node ids of the rows of B
+    const long long ubase = EXTEND ? sv.upd_ptr[sn] : 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t == 1) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < SN_NB / 16; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = l15 + 16 * c, rr = kq + 4 * r;
+                Tw[jj * 16 + (rr ^ l15)] = acc[t][c][r];
+            }
+        __builtin_amdgcn_wave_barrier();
+        const int i = i0[t] + l15; // lane = row of the tile; an instruction covers columns 4 m + kq
+        if (i0[t] >= g.h) break;
+        const int rB = i - g.w;
+#pragma unroll
+        for (int m0 = 0; m0 < 16; m0 += 8) { // (eight at a time: registers)
+            double val[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int jj = 4 * (m0 + m) + kq;
+                val[m] = Tw[jj * 16 + (l15 ^ (jj & 15))];
+            }
+            if (i >= g.h) continue;
+            if (!EXTEND) {
+                if (atomic_emit) { // split-k: several workgroups share the element
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int jj = 4 * (m0 + m) + kq, j = jrow0 + jj;
+                        if (jj >= ncols) continue;
+                        if (i > j) atomicAdd(&v.Lx[colbase[j] + i], -val[m]);
+                        else if (i == j) atomicAdd(&v.D[g.cols[j]], -val[m]);
+                    }
+                } else {
+                    double cur[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) { // (the eight reads together, then the eight writes)
+                        const int jj = 4 * (m0 + m) + kq, j = jrow0 + jj;
+                        cur[m] = (jj < ncols && i > j) ? v.Lx[colbase[j] + i] : 0.0;
+                    }
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int jj = 4 * (m0 + m) + kq, j = jrow0 + jj;
+                        if (jj >= ncols) continue;
+                        if (i > j) v.Lx[colbase[j] + i] = cur[m] - val[m];
+                        else if (i == j) v.D[g.cols[j]] -= val[m];
+                    }
+                }
+            } else {
+                int slot[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { // (consecutive rows of one column: consecutive slots)
+                    const int jj = 4 * (m0 + m) + kq, cB = jrow0 + jj - g.w;
+                    const bool lower = jj < ncols && rB > cB;
+                    slot[m] = lower ? sv.upd_slot[ubase + (long long)cB * g.nb - (long long)cB * (cB + 1) / 2 + (rB - cB - 1)] : -1;
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int jj = 4 * (m0 + m) + kq, cB = jrow0 + jj - g.w;
+                    if (slot[m] >= 0) atomicAdd(&v.Lx[slot[m]], -val[m]);
+                    else if (jj < ncols && rB == cB) atomicAdd(&v.D[Bn[cB]], -val[m]);
+                }
+            }
+        }
+    }
+    sn_stamp(sv.dbg, dbgme, 20, true);
+    if (sv.dbg && tid == 0) atomicMax((unsigned long long *)&sv.dbg[21], (unsigned long long)wall_clock64()); // last workgroup's end
+}
+
+__device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
+    Wl = (double *)smem;
+    return (int *)(Wl + SN_KC * SN_NB);
+}
+// grid (row groups, supernodes of the level, k splits): with few workgroups in flight (the narrow
+// levels near the root) the finished columns are divided among gridDim.z workgroups per tile group,
+// which then meet in fp64 atomics
+__global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_update(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                        int b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Wl;
+    int *colbase = snode_lds(smem, Wl);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int row_begin = j0 + (int)blockIdx.x * SN_ROWS;
+    if (row_begin >= g.h) return;
+    // this split's share of the k range, in units of one block column (j0 is a multiple of SN_NB)
+    const int nunits = j0 / SN_NB, ns = (int)gridDim.z;
+    const int c0 = (int)(((long long)nunits * blockIdx.z) / ns), c1 = (int)(((long long)nunits * (blockIdx.z + 1)) / ns);
+    if (c0 >= c1) return;
+    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
+    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), c1 * SN_NB, row_begin, c0 * SN_NB, ns > 1);
+}
+// grid (row groups, column blocks of B, supernodes of the level)
+__global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Wl;
+    int *colbase = snode_lds(smem, Wl);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.z, sn);
+    const int c0 = (int)blockIdx.y * SN_NB;
+    if (c0 >= g.nb) return;
+    const int row_begin = g.w + c0 + (int)blockIdx.x * SN_ROWS;
+    if (row_begin >= g.h) return;
+    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
+    snode_tiles<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SN_NB, g.nb - c0), g.w, row_begin);
+}
+// grid (supernodes of the level): the SN_NB x SN_NB diagonal block of block column b, right-looking, the
+// block in REGISTERS: thread (row i = lane, column quarter q = wave) holds T[i][16 q .. 16 q + 15]; the loop
+// over the 64 columns is fully unrolled, so every register index is a compile-time constant.  Per column ONE
+// barrier: the wave that owns the column publishes it UNSCALED together with the pivot candidate (the running
+// diagonal entry of that row) in LDS -- double buffered --, then every thread evaluates the pivot rule of
+// qdldl.rs:645-665 itself, scales (l = c / d, as the reference: c * (1/d)) and applies the rank-1 update to
+// its 16 entries and to its row's running diagonal.  (The previous version kept the block in LDS with two
+// barriers and a div/mod-indexed trailing update per column: 91 us per block column; this step is the
+// sequential part of every supernode's factorisation.)  Leaves the scaled block in Lx, (d, 1/d) in D / Dinv.
+constexpr int SN_DWG = 256;
+__global__ __launch_bounds__(SN_DWG) void k_snode_diag(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                       int b) {
+    __shared__ __attribute__((aligned(16))) double lcol[2][SN_NB];
+    __shared__ double piv[2];
+    __shared__ double sgn[SN_NB];
+    __shared__ int colbase[SN_NB];
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.x, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    const bool live = i < nbw;
+    if (tid < SN_NB) {
+        colbase[tid] = tid < nbw ? g.cb[j0 + tid] : 0;
+        sgn[tid] = tid < nbw ? (double)g.sg[j0 + tid] : 1.0; // (rows beyond a narrow last block: an identity)
+    }
+    __syncthreads();
+    const int ci = live ? g.cols[j0 + i] : 0;
+    double di = live ? v.D[ci] : 1.0; // running diagonal entry of row i (kept by all four threads of the row)
+    double T[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int j = 16 * q + cc;
+        T[cc] = (live && j < nbw && i > j) ? v.Lx[colbase[j] + j0 + i] : 0.0;
+    }
+    double dfin = 1.0, dinvfin = 1.0; // pivot of row i, recorded by the threads of wave 0
+    int nreg = 0, bad = 0;
+    // column jj = 16 qq + c: the quarter loop stays rolled, the 16 columns of a quarter are unrolled, so T[c]
+    // is a fixed register.  The owner publishes the strictly-lower part of the column (zeros from the
+    // diagonal up) and the pivot candidate separately: every product below is then unconditional -- the 16
+    // column entries a thread needs come in as eight 16-byte LDS reads, no per-entry branches (the first
+    // version's `j2 > jj ? lcol[j2] : 0` compiled to 16 serialised conditional LDS round trips per column,
+    // 53 of its 62 us).
+    for (int qq = 0; qq < SN_NB / 16; ++qq) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int jj = 16 * qq + c, buf = c & 1;
+            if (q == qq) {
+                lcol[buf][i] = i > jj ? T[c] : 0.0;
+                if (i == jj) piv[buf] = di;
+            }
+            __syncthreads();
+            double d = piv[buf];
+            const double sg = sgn[jj];
+            const bool reg = d * sg < v.reg_eps;
+            if (reg) d = v.reg_delta * sg;
+            const double dinv = 1.0 / d;
+            if (q == 0 && i == jj) {
+                dfin = d;
+                dinvfin = dinv;
+                if (reg) nreg = 1;
+                if (d == 0.0) bad |= 2;
+                if (!isfinite(dinv)) bad |= 1;
+            }
+            const double l = lcol[buf][i] * dinv; // 0 for i <= jj
+            if (q == qq) T[c] = i > jj ? l : T[c];
+            const double w = l * d;
+            di -= w * l;
+            const snode_v2d *lc = (const snode_v2d *)&lcol[buf][16 * q];
+#pragma unroll
+            for (int c2 = 0; c2 < 8; ++c2) {
+                const snode_v2d pr = lc[c2];
+                T[2 * c2] -= w * (pr.x * dinv);
+                T[2 * c2 + 1] -= w * (pr.y * dinv);
+            }
+        }
+    }
+    if (q == 0 && live) {
+        v.D[ci] = dfin;
+        g.d[j0 + i] = dfin;
+        v.Dinv[ci] = dinvfin;
+        if (nreg) atomicAdd(&v.status[2], 1);
+        if (bad & 2) v.status[1] = 1;
+        if (bad & 1) v.status[0] = 1;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int j = 16 * q + cc;
+        if (live && j < nbw && i > j) v.Lx[colbase[j] + j0 + i] = T[cc];
+    }
+}
+// grid (row groups of SN_DWG rows, supernodes of the level): the rows below the diagonal block of
+// block column b, one thread per row, forward substitution against the (finished) block
+// (one WAVE per workgroup: the 2016 products of a row each read a coefficient from LDS -- broadcast reads, bound
+// by the LDS issue rate of the CU -- so 64 rows per CU over many CUs beat 256 rows on a few)
+constexpr int SN_RWG = 64;
+__global__ __launch_bounds__(SN_RWG) void k_snode_rows(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                       int b) {
+    __shared__ __attribute__((aligned(16))) double dT[SN_NB * SN_NB];
+    __shared__ double dinvl[SN_NB], dl[SN_NB];
+    __shared__ int colbase[SN_NB];
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x;
+    const int i = j0 + nbw + (int)blockIdx.x * SN_RWG + tid;
+    if (j0 + nbw + (int)blockIdx.x * SN_RWG >= g.h) return;
+    {
+        const bool in = tid < nbw; // (a narrow last block is padded with an identity)
+        const int c = in ? g.cols[j0 + tid] : 0;
+        colbase[tid] = in ? g.cb[j0 + tid] : 0;
+        dinvl[tid] = in ? v.Dinv[c] : 1.0;
+        dl[tid] = in ? v.D[c] : 0.0;
+    }
+    __syncthreads();
+    // dTt[q * SN_NB + jj] = d_q L_JJ(jj, q) for jj > q, else 0 (column q of the block contiguous); the pivots come
+    // from LDS (v.D[g.cols[..]] inside this loop was a chain of two dependent global loads per round)
+    for (int base = 0; base < SN_NB * SN_NB; base += 32 * SN_RWG) {
+        double tv[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int idx = base + tid + r * SN_RWG, q = idx / SN_NB, jj = idx % SN_NB;
+            tv[r] = (jj > q && jj < nbw) ? v.Lx[colbase[q] + j0 + jj] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int idx = base + tid + r * SN_RWG;
+            dT[idx] = tv[r] * dl[idx / SN_NB];
+        }
+    }
+    double x[SN_NB];
+    const bool rowok = i < g.h;
+    const int ic = rowok ? i : g.h - 1; // (unconditional loads from a valid row: no branch per entry)
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = v.Lx[colbase[jj < nbw ? jj : 0] + ic];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = jj < nbw ? x[jj] : 0.0;
+    __syncthreads();
+    if (!rowok) return;
+    // right-looking: x_q is final after the updates of columns < q; it then updates every later entry of the
+    // row.  The products of one q are independent (the left-looking form chained 2016 FMAs on one accumulator
+    // behind serialised LDS reads: 48 us); per entry the subtractions still happen in the order q = 0, 1, ...
+    // of qdldl.rs:708-719.  Coefficients come in as 16-byte pairs (jj even, jj + 1); the pair that straddles q
+    // multiplies a stored zero.
+#pragma unroll
+    for (int q = 0; q < SN_NB; ++q) {
+        const double xq = x[q] * dinvl[q];
+        x[q] = xq;
+        // (an opaque zero that "depends" on x_q ties this column's LDS reads to its place in the chain: left
+        // alone the compiler reads all 1024 coefficient pairs before the first product and spills them)
+        int zoff;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(xq)));
+        const snode_v2d *cf = (const snode_v2d *)&dT[q * SN_NB + zoff];
+#pragma unroll
+        for (int p2 = (q + 1) / 2; p2 < SN_NB / 2; ++p2) {
+            const snode_v2d cc = cf[p2];
+            x[2 * p2] -= xq * cc.x;
+            x[2 * p2 + 1] -= xq * cc.y;
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj)
+        if (jj < nbw) v.Lx[colbase[jj] + i] = x[jj];
+    // (no row-major mirror Rx for supernode columns: with supernodes the forward sweep of the top reads
+    // the filtered lists Rfx -- non-member columns only -- and k_snode_fwd reads Lx itself)
+}
+
+// ---------------------------------------------------------------------------
+// Block column b of every supernode of a unit level in ONE launch (round 3; k_snode_diag + k_snode_rows were
+// two launches of ~28 + ~33 us whatever the size, most of it latency: 64 pivots one barrier apart, then the
+// coefficient block fetched again by every workgroup of the rows kernel).  Grid (groups of SNP_WG panel rows
+// below the block, supernodes), SNP_WG = 256 threads:
+//   1. EVERY workgroup factors the 64 x 64 diagonal block itself (redundantly: latency, not throughput, is what
+//      counts here; only group 0 writes it back).  Thread (row i = lane, quarter q = wave) holds the 16 entries
+//      (i, 16 q ..) of its row, unscaled (u), and a copy of the row's running diagonal.  The columns go in
+//      groups of SNP_CB = 4: the wave that owns a group factors its four columns by itself -- pivots and the
+//      six l(c', c) it needs across lanes by v_readlane, no barrier --, publishes their unscaled entries u
+//      (double buffered) and scaled entries l (Ll, which stays) plus the pivots in LDS; after ONE barrier
+//      every thread applies the four columns to its entries right of the group: 16 barriers per block instead
+//      of 64.  Per entry the subtractions are those of the reference's row solve (qdldl.rs:610-640), in its
+//      order: u_ic -= l_ck * u_ik for k = 0, 1, ... (the SCALED entry of row c times the UNSCALED entry of the
+//      own row); d_i = a_ii - sum_k u_ik l_ik (qdldl.rs:634); the sign rule of qdldl.rs:645-665 by all lanes;
+//   2. then its SNP_WG rows below the block, one row per thread, by the same recurrence against Ll (u_Rq is
+//      final after the columns < q; l_Rq = u_Rq / d_q on the way out).
+// ---------------------------------------------------------------------------
+constexpr int SNP_WG = 256;
+constexpr int SNP_CB = 4;
+constexpr int SNP_XLD = 17; // row stride of a wave's head block in LDS (odd: lanes = rows hit distinct banks)
+__global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snode_panel(LdlView v, SnodeView sv, const int *__restrict__ order, int b,
+                                                                                                  int rows_mfma) {
+    __shared__ __attribute__((aligned(16))) double Ll[SN_NB * SN_NB];        // Ll[k * 64 + i] = l(i, k), 0 for i <= k
+    __shared__ __attribute__((aligned(16))) double ucol[2][SNP_CB][SN_NB];   // unscaled entries of a group's columns (0 for i <= c)
+    __shared__ double xh[SNP_WG / 64][64 * SNP_XLD];                       // rows phase (matrix-core form): a wave's head block, [row][column]
+    __shared__ double dinvl[SN_NB], sgn[SN_NB];
+    __shared__ int colbase[SN_NB];
+    __shared__ int s_nreg, s_bad;
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    const bool dbgme = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    sn_stamp(sv.dbg, dbgme, 0);
+    const int row0 = j0 + nbw + (int)blockIdx.x * SNP_WG; // first of this group's rows below the block
+    if (blockIdx.x > 0 && row0 >= g.h) return;
+    const bool live = i < nbw;
+    if (tid < SN_NB) {
+        colbase[tid] = g.cb[j0 + min(tid, nbw - 1)];
+        sgn[tid] = tid < nbw ? (double)g.sg[j0 + tid] : 1.0; // (columns beyond a narrow last block: an identity)
+    }
+    if (tid == 0) {
+        s_nreg = 0;
+        s_bad = 0;
+    }
+    __syncthreads();
+    sn_stamp(sv.dbg, dbgme, 1);
+    const int ci = live ? g.cols[j0 + i] : 0;
+    double di = live ? v.D[ci] : 1.0; // running diagonal entry of row i (kept by all four threads of the row)
+    const double sgl = sgn[i];        // lane j: sign of column j (read by v_readlane: an LDS read per pivot sat on the chain)
+    double T[16];
+    double dfin = 1.0, dinvfin = 1.0; // pivot of row i, recorded by the owner of column i
+    int nreg = 0, bad = 0;
+    if (rows_mfma & 2) {
+        // ---- block factorisation, matrix-core form (round 3): wave q owns column quarter q of the 64 x 64 block, ALL
+        //      64 rows of it, in the accumulator layout (lane = column 16 q + l15, registers = rows: 4 tiles x 4).
+        //      Quarter kb is factored by its owner alone in the lane = row form (through the wave's LDS slice): the
+        //      diagonal entries live IN the block (entry (c, c) is the pivot candidate), 16 pivots with the
+        //      in-quarter updates by v_readlane; it publishes the unscaled panel (negated, [row][k]) and the scaled
+        //      one (Ll); after ONE barrier the quarters behind it subtract (64 x 16) x (16 x 16) on the matrix cores
+        //      (16 instructions per wave).  Four barriers per block (sixteen before, sixty-four in round 2).
+        const int l15 = i & 15, kq = i >> 4;
+        double *xw = xh[q];
+        snode_v4d Aq[4];
+        {
+            const int j = 16 * q + l15; // this lane's column
+            const bool jok = j < nbw;
+            const int cb = colbase[j];
+            const double djj = jok ? v.D[g.cols[j0 + min(j, nbw - 1)]] : 1.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + kq + 4 * r;
+                    double val = (jok && row < nbw && row > j) ? v.Lx[cb + j0 + row] : 0.0;
+                    if (row == j) val = djj;
+                    Aq[t][r] = val;
+                }
+        }
+        sn_stamp(sv.dbg, dbgme, 2, true);
+#pragma unroll 1
+        for (int kb = 0; kb < SN_NB / 16; ++kb) {
+            if (q == kb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = Aq[t][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) T[c] = xw[i * SNP_XLD + c];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int c = 16 * kb + t;
+                    double d = readlane_f64(T[t], c); // entry (c, c): (c is wave uniform)
+                    const double sg = readlane_f64(sgl, c);
+                    const bool reg = d * sg < v.reg_eps;
+                    if (reg) d = v.reg_delta * sg;
+                    const double dinv = 1.0 / d;
+                    if (i == c) {
+                        dfin = d;
+                        dinvfin = dinv;
+                        if (reg) nreg = 1;
+                        if (d == 0.0) bad |= 2;
+                        if (!isfinite(dinv)) bad |= 1;
+                    }
+                    const double uc = i > c ? T[t] : 0.0;
+                    const double l = uc * dinv;
+                    T[t] = l;
+                    xw[i * SNP_XLD + t] = -uc;
+                    Ll[c * SN_NB + i] = l;
+                    if (i == 0) dinvl[c] = dinv;
+#pragma unroll
+                    for (int t2 = t + 1; t2 < 16; ++t2) // entry (i, c2) -= l(c2, c) u(i, c), the diagonal entries included
+                        T[t2] -= readlane_f64(l, 16 * kb + t2) * uc;
+                }
+            }
+            __syncthreads();
+            if (q > kb) {
+                const double *xo = xh[kb];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * q + l15]; // B[k][n] = l(16 q + n, 16 kb + k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = xo[(16 * t + l15) * SNP_XLD + 4 * s4 + kq]; // A[m][k] = -u(16 t + m, 16 kb + k)
+                        Aq[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Aq[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int j = 16 * q + cc;
+        T[cc] = (live && j < nbw && i > j) ? v.Lx[colbase[j] + j0 + i] : 0.0;
+    }
+    sn_stamp(sv.dbg, dbgme, 2, true);
+    // the quarter loop stays rolled; the 16 columns of a quarter are unrolled, so T[..] are fixed registers
+    for (int qq = 0; qq < SN_NB / 16; ++qq) {
+#pragma unroll
+        for (int gc = 0; gc < 16; gc += SNP_CB) {
+            const int c0 = 16 * qq + gc, buf = (gc / SNP_CB) & 1;
+            if (q == qq) { // the owner: the group's columns among themselves
+#pragma unroll
+                for (int t = 0; t < SNP_CB; ++t) {
+                    const int c = c0 + t;
+                    double d = readlane_f64(di, c); // (c is wave uniform)
+                    const double sg = readlane_f64(sgl, c);
+                    const bool reg = d * sg < v.reg_eps;
+                    if (reg) d = v.reg_delta * sg;
+                    const double dinv = 1.0 / d;
+                    if (i == c) {
+                        dfin = d;
+                        dinvfin = dinv;
+                        if (reg) nreg = 1;
+                        if (d == 0.0) bad |= 2;
+                        if (!isfinite(dinv)) bad |= 1;
+                    }
+                    const double uc = i > c ? T[gc + t] : 0.0;
+                    const double l = uc * dinv;
+                    di -= uc * l;
+                    T[gc + t] = i > c ? l : T[gc + t];
+                    ucol[buf][t][i] = uc;
+                    Ll[c * SN_NB + i] = l;
+                    if (i == 0) dinvl[c] = dinv;
+#pragma unroll
+                    for (int t2 = t + 1; t2 < SNP_CB; ++t2) // entry (i, c0 + t2) -= l(c0 + t2, c) u(i, c)
+                        T[gc + t2] -= readlane_f64(l, c0 + t2) * uc;
+                }
+            }
+            __syncthreads();
+            // everybody: the group's columns applied to the own entries right of the group (and to the copy of the
+            // running diagonal, which the owner has already updated)
+#pragma unroll
+            for (int t = 0; t < SNP_CB; ++t) {
+                const int c = c0 + t;
+                const double uc = ucol[buf][t][i];
+                if (q != qq) di -= uc * Ll[c * SN_NB + i];
+                if (q >= qq) { // (wave uniform; earlier quarters are finished)
+                    const snode_v2d *lr = (const snode_v2d *)&Ll[c * SN_NB + 16 * q];
+#pragma unroll
+                    for (int c2 = 0; c2 < 8; ++c2) {
+                        const snode_v2d pr = lr[c2]; // l(16 q + 2 c2, c), l(16 q + 2 c2 + 1, c): zero up to the diagonal
+                        if (q > qq || 2 * c2 >= gc + SNP_CB) T[2 * c2] -= pr.x * uc;
+                        if (q > qq || 2 * c2 + 1 >= gc + SNP_CB) T[2 * c2 + 1] -= pr.y * uc;
+                    }
+                }
+            }
+        }
+    }
+    } // (round-2 form of the block factorisation)
+    sn_stamp(sv.dbg, dbgme, 3);
+    if (nreg) atomicAdd(&s_nreg, 1);
+    if (bad) atomicOr(&s_bad, bad);
+    __syncthreads(); // (also: Ll and dinvl are complete, and every entry of the unfactored block has been consumed)
+    // The factored block goes back IN PLACE, and the workgroups of a large launch do not all run at the same time:
+    // a workgroup that starts late must still find the UNFACTORED block.  So the block is written by the last of
+    // the supernode's workgroups to get here -- all of them hold the same result -- which needs no waiting: a
+    // counter per supernode, reset by the one that finds it complete.
+    if (tid == 0) {
+        const int nwg = max(1, (g.h - (j0 + nbw) + SNP_WG - 1) / SNP_WG); // workgroups of this supernode that got past the early return
+        const int old = __hip_atomic_fetch_add(&sv.sn_cnt[sn], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_nreg = old == nwg - 1 ? (s_nreg | 0x40000000) : s_nreg;
+        if (old == nwg - 1) __hip_atomic_store(&sv.sn_cnt[sn], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool writer = (s_nreg & 0x40000000) != 0;
+    if (writer) {
+        if (q == i / 16 && live) { // the owner of column i
+            v.D[ci] = dfin;
+            v.Dinv[ci] = dinvfin;
+            g.d[j0 + i] = dfin;
+        }
+        if (tid == 0) {
+            if (s_nreg & 0xffff) atomicAdd(&v.status[2], s_nreg & 0xffff);
+            if (s_bad & 2) v.status[1] = 1;
+            if (s_bad & 1) v.status[0] = 1;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int j = 16 * q + cc;
+            if (live && j < nbw && i > j) v.Lx[colbase[j] + j0 + i] = T[cc];
+        }
+    }
+    sn_stamp(sv.dbg, dbgme, 4, true);
+    if (row0 >= g.h) return;
+    if (rows_mfma & 1) {
+        // ---- the rows below the block, blocked by 16 columns (round 3): a wave owns 64 rows.  Block kb of every row is
+        //      finished by the recurrence in the lane = row form (120 products per row instead of 2016), and its effect
+        //      on the blocks behind it is a (64 x 16) x (16 x 16) product on the f64 matrix cores -- 96 instructions per
+        //      wave for all six block pairs.  The blocks behind the head live in the accumulator layout (lane = column,
+        //      registers = rows), the head block crosses between the two forms through the wave's own LDS slice.
+        //      Per entry the subtractions still go k = 0, 1, ...; inside a matrix instruction they are fused
+        //      multiply-adds (as in the update tiles).
+        const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        double *xw = xh[wave];
+        const int R0w = row0 + 64 * wave;         // first row of the wave
+        const int R = R0w + lane;                  // lane = row form
+        const bool rowok = R < g.h;
+        const int Rc = min(R, g.h - 1);
+        if (R0w >= g.h) return;                   // (whole wave beyond the panel; no workgroup barrier below)
+        // blocks 1..3 in the accumulator layout: acc[jb - 1][t][r] = X[row 16 t + kq + 4 r][column 16 jb + l15]
+        snode_v4d acc[3][4];
+#pragma unroll
+        for (int jb = 1; jb < 4; ++jb) {
+            const int jj = 16 * jb + l15;
+            const int cb = colbase[jj];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = min(R0w + 16 * t + kq + 4 * r, g.h - 1);
+                    const double xv = v.Lx[cb + row];
+                    acc[jb - 1][t][r] = jj < nbw ? xv : 0.0;
+                }
+        }
+        double h[16]; // the head block of the own row, lane = row form
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h[c] = v.Lx[colbase[c] + Rc];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h[c] = c < nbw ? h[c] : 0.0;
+        sn_stamp(sv.dbg, dbgme, 5, true);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb > 0) { // the head block leaves the accumulator layout: [row][column] in LDS, then a row per lane
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = acc[kb - 1][t][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) h[c] = xw[lane * SNP_XLD + c];
+                __builtin_amdgcn_wave_barrier();
+            }
+            // the block's own triangle: u_c -= l(16 kb + c, 16 kb + kk) u_kk
+            const double *Lb = Ll + (16 * kb) * SN_NB + 16 * kb;
+#pragma unroll
+            for (int kk = 0; kk < 15; ++kk) {
+                const double uq = h[kk];
+                int zoff; // (ties the column's LDS reads to its place in the chain, see below)
+                asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(uq)));
+                const snode_v2d *cf = (const snode_v2d *)(Lb + kk * SN_NB + zoff);
+#pragma unroll
+                for (int p2 = (kk + 1) / 2; p2 < 8; ++p2) {
+                    const snode_v2d cc = cf[p2]; // (the pair that straddles kk meets a stored zero)
+                    h[2 * p2] -= cc.x * uq;
+                    h[2 * p2 + 1] -= cc.y * uq;
+                }
+            }
+            if (rowok) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int jj = 16 * kb + c;
+                    if (jj < nbw) v.Lx[colbase[jj] + R] = h[c] * dinvl[jj];
+                }
+            }
+            if (kb == 3) break;
+            // the finished block, negated, as the A operand of the products: [row][column] in LDS
+#pragma unroll
+            for (int c = 0; c < 16; ++c) xw[lane * SNP_XLD + c] = -h[c];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                double a4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a4[t] = xw[(16 * t + l15) * SNP_XLD + 4 * s4 + kq]; // A[m = l15][k = 4 s4 + kq] of tile t
+#pragma unroll
+                for (int jb = kb + 1; jb < 4; ++jb) {
+                    const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * jb + l15]; // B[k][n] = l(16 jb + n, 16 kb + k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[jb - 1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], bv, acc[jb - 1][t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        sn_stamp(sv.dbg, dbgme, 6);
+        sn_stamp(sv.dbg, dbgme, 7, true);
+        if (sv.dbg && lane == 0) atomicMax((unsigned long long *)&sv.dbg[8], (unsigned long long)wall_clock64());
+        return;
+    }
+    // ---- the rows below the block: thread = row, its 64 entries in registers, right-looking (the products of one
+    //      column are independent; per entry the subtractions happen in the order k = 0, 1, ... of qdldl.rs:610-640).
+    //      (Measured and dropped: the same recurrence blocked by 16 columns with one rolled code body -- 30 KB of
+    //      code instead of 75 KB --: 57.5 us per launch against 55; the launch is not bound by instruction fetch.)
+    const int R = row0 + tid;
+    const bool rowok = R < g.h;
+    const int Rc = rowok ? R : g.h - 1; // (unconditional loads from a valid row)
+    double x[SN_NB];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = v.Lx[colbase[jj] + Rc];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) x[jj] = jj < nbw ? x[jj] : 0.0;
+    sn_stamp(sv.dbg, dbgme, 5, true);
+#pragma unroll
+    for (int k = 0; k < SN_NB; ++k) {
+        const double uq = x[k];
+        // (an opaque zero that "depends" on u_q ties this column's LDS reads to its place in the chain: left
+        // alone the compiler reads all 1024 coefficient pairs before the first product and spills them)
+        int zoff;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(uq)));
+        const snode_v2d *cf = (const snode_v2d *)&Ll[k * SN_NB + zoff];
+#pragma unroll
+        for (int p2 = (k + 1) / 2; p2 < SN_NB / 2; ++p2) {
+            const snode_v2d cc = cf[p2];
+            x[2 * p2] -= cc.x * uq;
+            x[2 * p2 + 1] -= cc.y * uq;
+        }
+    }
+    sn_stamp(sv.dbg, dbgme, 6);
+    if (!rowok) return;
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj)
+        if (jj < nbw) v.Lx[colbase[jj] + R] = x[jj] * dinvl[jj];
+    sn_stamp(sv.dbg, dbgme, 7, true);
+    if (sv.dbg && tid == 0) atomicMax((unsigned long long *)&sv.dbg[8], (unsigned long long)wall_clock64()); // last workgroup's end
+}
+
+// Substitutions through a chain supernode, one workgroup per supernode of the unit level, the
+// members' slice of x (and the nb entries of the rows of B) in LDS, block columns of SN_NB:
+//   forward  (qdldl.rs:708-719): x_S <- (I + L_SS)^-1 x_S block by block -- the 64 unknowns of a block
+//            by one wave (values in registers, broadcast by lane shuffles), then every row below the
+//            block subtracts its 64 products (columns streamed, one row per thread) -- and finally
+//            x_B -= L_BS x_S is pushed to the ancestors' entries with one atomic per row;
+//   backward (qdldl.rs:737-752): x_S <- D^-1 x_S - L_BS' x_B - L_SS' x_S, last block first: one wave per
+//            column reduces the rows below the block, then the block itself backwards in one wave.
+// The rows' contributions from columns that are not supernode members are gathered beforehand by the
+// row-gather kernels over the filtered lists (Engine: fwu / bwu).
+constexpr int SN_XB_CAP = 4096; // rows of B kept in LDS (beyond: global atomics / loads)
+struct SnodeSolveLds {
+    double *xs, *xB, *Tl, *csum;
+    int *colbase;
+};
+__device__ __forceinline__ SnodeSolveLds snode_solve_lds(char *smem, int wmax, int nbcap) {
+    SnodeSolveLds L;
+    L.xs = (double *)smem;
+    L.xB = L.xs + wmax;
+    L.Tl = L.xB + nbcap;
+    L.csum = L.Tl + SN_NB * SN_NB;
+    L.colbase = (int *)(L.csum + SN_NB);
+    return L;
+}
+// with_B = 0: the rows of B are left to k_snode_push / k_snode_pull (their own multi-workgroup launches)
+__global__ __launch_bounds__(SN_WG) void k_snode_fwd(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                     double *x, int wmax, int nbcap, int with_B) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SnodeSolveLds L = snode_solve_lds(smem, wmax, nbcap);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.x, sn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *Bn = v.Li + v.Lp[g.e];
+    const bool ldsB = g.nb <= nbcap;
+    const int hrows = with_B ? g.h : g.w;
+    for (int t = tid; t < g.w; t += SN_WG) {
+        L.colbase[t] = g.cb[t];
+        L.xs[t] = x[g.cols[t]];
+    }
+    if (ldsB && with_B)
+        for (int r = tid; r < g.nb; r += SN_WG) L.xB[r] = 0.0;
+    __syncthreads();
+    for (int j0 = 0; j0 < g.w; j0 += SN_NB) {
+        const int nbw = min(SN_NB, g.w - j0);
+        for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_WG) { // Tl[col * SN_NB + row] (snode_block_solve)
+            const int jj = idx / SN_NB, ii = idx % SN_NB;
+            L.Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[L.colbase[j0 + jj] + j0 + ii] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) { // the block's unknowns: lane = row, values in registers
+            double xv = lane < nbw ? L.xs[j0 + lane] : 0.0;
+            xv = snode_block_solve<true>(L.Tl, xv, lane);
+            if (lane < nbw) L.xs[j0 + lane] = xv;
+        }
+        __syncthreads();
+        // rows below the block
+        for (int i = j0 + nbw + tid; i < hrows; i += SN_WG) {
+            double sacc = 0.0;
+            if (nbw == SN_NB) { // 32 column runs in flight per thread
+#pragma unroll
+                for (int j2 = 0; j2 < SN_NB; j2 += 32) {
+                    double lv[32];
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) lv[q] = v.Lx[L.colbase[j0 + j2 + q] + i];
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) sacc += lv[q] * L.xs[j0 + j2 + q];
+                }
+            } else {
+#pragma unroll 8
+                for (int jj = 0; jj < nbw; ++jj) sacc += v.Lx[L.colbase[j0 + jj] + i] * L.xs[j0 + jj];
+            }
+            if (i < g.w) L.xs[i] -= sacc;
+            else if (ldsB) L.xB[i - g.w] -= sacc;
+            else atomicAdd(&x[Bn[i - g.w]], -sacc);
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < g.w; t += SN_WG) x[g.cols[t]] = L.xs[t];
+    if (ldsB && with_B)
+        for (int r = tid; r < g.nb; r += SN_WG) atomicAdd(&x[Bn[r]], L.xB[r]);
+}
+// x_B -= L_BS x_S after k_snode_fwd(with_B = 0): grid (groups of SN_WG rows of B, chunks of SN_PCH member
+// columns, supernodes); one thread per row, the chunk of x_S in LDS, one atomic per (row, chunk)
+constexpr int SN_PCH = 256;
+__global__ __launch_bounds__(SN_WG) void k_snode_push(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                      double *x) {
+    __shared__ double xs[SN_PCH];
+    __shared__ int cb[SN_PCH];
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.z, sn);
+    const int t0 = (int)blockIdx.y * SN_PCH;
+    const int r0 = (int)blockIdx.x * SN_WG;
+    if (t0 >= g.w || r0 >= g.nb) return;
+    const int nt = min(SN_PCH, g.w - t0), tid = threadIdx.x;
+    if (tid < nt) {
+        const int c = g.cols[t0 + tid];
+        xs[tid] = x[c];
+        cb[tid] = g.cb[t0 + tid] + g.w; // + panel row w + r
+    }
+    __syncthreads();
+    const int r = r0 + tid;
+    if (r >= g.nb) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int t = 0;
+    for (; t + 7 < nt; t += 8) { // eight column runs in flight per thread
+        const double l0 = v.Lx[cb[t] + r], l1 = v.Lx[cb[t + 1] + r], l2 = v.Lx[cb[t + 2] + r], l3 = v.Lx[cb[t + 3] + r];
+        const double l4 = v.Lx[cb[t + 4] + r], l5 = v.Lx[cb[t + 5] + r], l6 = v.Lx[cb[t + 6] + r],
+                     l7 = v.Lx[cb[t + 7] + r];
+        s0 += l0 * xs[t] + l4 * xs[t + 4];
+        s1 += l1 * xs[t + 1] + l5 * xs[t + 5];
+        s2 += l2 * xs[t + 2] + l6 * xs[t + 6];
+        s3 += l3 * xs[t + 3] + l7 * xs[t + 7];
+    }
+    for (; t < nt; ++t) s0 += v.Lx[cb[t] + r] * xs[t];
+    const int *Bn = v.Li + v.Lp[g.e];
+    atomicAdd(&x[Bn[r]], -((s0 + s1) + (s2 + s3)));
+}
+// x_S <- D^-1 x_S - L_BS' x_B before k_snode_bwd(with_B = 0): grid (groups of 64 member columns,
+// supernodes); one wave per column over the nb rows of B (x_B in LDS)
+__global__ __launch_bounds__(SN_WG) void k_snode_pull(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                      double *x, int nbcap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xB = (double *)smem;
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
+    const int t0 = (int)blockIdx.x * SN_NB;
+    if (t0 >= g.w) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *Bn = v.Li + v.Lp[g.e];
+    const bool ldsB = g.nb <= nbcap;
+    if (ldsB)
+        for (int r = tid; r < g.nb; r += SN_WG) xB[r] = x[Bn[r]];
+    __syncthreads();
+    const int nt = min(SN_NB, g.w - t0);
+    for (int tt = wave; tt < nt; tt += SN_WG / 64) {
+        const int t = t0 + tt, c = g.cols[t];
+        const int base = g.cb[t] + g.w;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        auto xat = [&](int r) { return ldsB ? xB[r] : x[Bn[r]]; };
+        int r = lane;
+        for (; r + 192 < g.nb; r += 256) {
+            const double l0 = v.Lx[base + r], l1 = v.Lx[base + r + 64], l2 = v.Lx[base + r + 128], l3 = v.Lx[base + r + 192];
+            s0 += l0 * xat(r);
+            s1 += l1 * xat(r + 64);
+            s2 += l2 * xat(r + 128);
+            s3 += l3 * xat(r + 192);
+        }
+        for (; r < g.nb; r += 64) s0 += v.Lx[base + r] * xat(r);
+        const double tot = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) x[c] = x[c] * v.Dinv[c] - tot;
+    }
+}
+__global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                     double *x, int wmax, int nbcap, int with_B) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SnodeSolveLds L = snode_solve_lds(smem, wmax, nbcap);
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.x, sn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *Bn = v.Li + v.Lp[g.e];
+    const bool ldsB = g.nb <= nbcap;
+    const int hrows = with_B ? g.h : g.w;
+    for (int t = tid; t < g.w; t += SN_WG) {
+        const int c = g.cols[t];
+        L.colbase[t] = g.cb[t];
+        L.xs[t] = with_B ? x[c] * v.Dinv[c] : x[c]; // (k_snode_pull has applied D^-1 already)
+    }
+    if (ldsB && with_B)
+        for (int r = tid; r < g.nb; r += SN_WG) L.xB[r] = x[Bn[r]];
+    __syncthreads();
+    const int nblk = (g.w + SN_NB - 1) / SN_NB;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * SN_NB, nbw = min(SN_NB, g.w - j0), j1 = j0 + nbw;
+        for (int idx = tid; idx < SN_NB * SN_NB; idx += SN_WG) {
+            const int ii = idx / SN_NB, jj = idx % SN_NB;
+            L.Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[L.colbase[j0 + jj] + j0 + ii] : 0.0;
+        }
+        // rows below the block (finished members, then B): each wave owns the columns wave, wave + 8, ...
+        // of the block and walks them together, lanes along the columns (8 x 2 runs in flight per lane)
+        {
+            constexpr int CPW = SN_NB / (SN_WG / 64); // columns per wave
+            auto xat = [&](int i) { return i < g.w ? L.xs[i] : (ldsB ? L.xB[i - g.w] : x[Bn[i - g.w]]); };
+            double sc[CPW];
+            int cbq[CPW];
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                sc[q] = 0.0;
+                const int jj = wave + q * (SN_WG / 64);
+                cbq[q] = jj < nbw ? L.colbase[j0 + jj] : INT_MIN; // (colbase itself may be -1)
+            }
+            int i = j1 + lane;
+            for (; i + 64 < hrows; i += 128) {
+                double l0[CPW], l1[CPW];
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) {
+                    l0[q] = cbq[q] != INT_MIN ? v.Lx[cbq[q] + i] : 0.0;
+                    l1[q] = cbq[q] != INT_MIN ? v.Lx[cbq[q] + i + 64] : 0.0;
+                }
+                const double x0 = xat(i), x1 = xat(i + 64);
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) sc[q] += l0[q] * x0 + l1[q] * x1;
+            }
+            for (; i < hrows; i += 64) {
+                const double x0 = xat(i);
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) sc[q] += (cbq[q] != INT_MIN ? v.Lx[cbq[q] + i] : 0.0) * x0;
+            }
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                const double tot = wave_sum(sc[q]);
+                const int jj = wave + q * (SN_WG / 64);
+                if (lane == 0 && jj < nbw) L.csum[jj] = tot;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double xv = lane < nbw ? L.xs[j0 + lane] - L.csum[lane] : 0.0;
+            xv = snode_block_solve<false>(L.Tl, xv, lane);
+            if (lane < nbw) L.xs[j0 + lane] = xv;
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < g.w; t += SN_WG) x[g.cols[t]] = L.xs[t];
+}
+
+// ---------------------------------------------------------------------------
+// Substitutions through WIDE chain supernodes with several workgroups per supernode (config 5: 830..1750
+// member columns; one workgroup streaming a 6 MB triangle is latency bound at ~30 GB/s).  The triangle
+// (I + L_SS) is cut into 64 x 64 blocks; workgroup (r, s) owns block row r of supernode s of the level:
+//   forward :  x_r <- (I + L_rr)^-1 (x_r - sum_{c < r} L_rc x_c)
+//   backward:  x_r <- (I + L_rr)^-T (x_r - sum_{c > r} L_cr' x_c)      (x_r already scaled by D^-1 and
+//                                                                        with L_BS' x_B taken off: k_snode_pull)
+// as a pipeline INSIDE one launch: a workgroup consumes block c as soon as the flag of x_c shows this
+// sweep's epoch, its own 64 x 64 products accumulated in registers (lane = row of the block, every wave a
+// quarter of the columns; the cross-lane / cross-wave reduction happens once at the end), then solves its
+// diagonal block in one wave and publishes x_r and its flag.  A workgroup only ever waits for workgroups
+// with a SMALLER linear block id (the backward launch numbers the block rows in reverse), which the
+// dispatcher starts first -- the usual synchronisation-free sparse triangular solve -- and the wait times
+// out rather than hang.  x_c and the flags cross workgroups inside the launch: device-coherent atomic
+// stores / loads, no agent-scope fence (see ir_arrive_wait).  The rows of B are handled by k_snode_push /
+// k_snode_pull in their own launches.
+// ---------------------------------------------------------------------------
+// One 16-byte message per unknown: (value lo, epoch, value hi, epoch) written by ONE dwordx4 store and read by ONE dwordx4
+// load, both device coherent (sc1, what the compiler emits for agent-scope atomics) -- a consumer that sees
+// this sweep's epoch has the value with it, in one round trip; value and flag as two stores needed the
+// producer to wait for the first to be acknowledged and the consumer to load twice (~2 of ~4.5 us per hop).
+typedef int msg_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void msg_store(int *slot, double val, int tag) {
+    msg_v4i m;
+    // (val_lo, tag, val_hi, tag): each 8-byte half carries its own tag, so a store that the memory system
+    // splits at 8-byte granularity can never pair a fresh tag with a stale half of the value
+    m.x = __double2loint(val);
+    m.y = tag;
+    m.z = __double2hiint(val);
+    m.w = tag;
+    // (s_nop: a store of more than 8 bytes reads its data registers a few cycles after issue; the compiler pads
+    // that hazard for its own stores, not for inline assembly -- without it the next VALU write clobbered the tags)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" ::"v"(slot), "v"(m) : "memory");
+}
+__device__ __forceinline__ msg_v4i msg_load(const int *slot) {
+    msg_v4i m;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(m) : "v"(slot) : "memory");
+    return m;
+}
+constexpr int SN2_WG = 256;
+constexpr int SN2_WMAX = 4096; // widest supernode (symbolic.cpp: SN_MAX_W); its column bases are kept in LDS
+template <bool FWDMODE>
+__global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                      const int *__restrict__ blk_ptr, int *msg, int epoch,
+                                                      double *x, int *timeout_flag) {
+    __shared__ double Tl[SN_NB * SN_NB];
+    __shared__ double part[SN2_WG / 64][SN_NB];
+    __shared__ double pulled[SN_NB]; // backward: L_B,r' x_B of the own columns; forward: the finished x_r
+    __shared__ int colbase[SN2_WMAX]; // forward: of all earlier columns; backward: of the own block only
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
+    const int nblk = (g.w + SN_NB - 1) / SN_NB;
+    if ((int)blockIdx.x >= nblk) return;
+    const int r = FWDMODE ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = r * SN_NB, nbw = min(SN_NB, g.w - j0);
+    int *mb = msg + (size_t)blk_ptr[sn] * 256; // this supernode's message slots: block c, lane l at (c * 64 + l) * 4
+    constexpr int CPW = SN_NB / (SN2_WG / 64); // columns per wave: of block c (forward) / of the own block (backward)
+    // nothing below depends on x: column bases, the diagonal block and the own entries are requested first
+    const int cb_lo = FWDMODE ? 0 : j0, cb_hi = j0 + nbw;
+    for (int t = cb_lo + tid; t < cb_hi; t += SN2_WG) colbase[t - cb_lo] = g.cb[t];
+    double xown = (wave == 0 && lane < nbw) ? x[g.cols[j0 + lane]] : 0.0; // (last written before this launch)
+    __syncthreads();
+    const int *cbr = colbase + (FWDMODE ? j0 : 0); // column bases of the own block
+    const int *Bn = v.Li + v.Lp[g.e];              // node ids of the rows of B
+    if (!FWDMODE) {
+        // the block's own columns first take D^-1 and the rows of B: x_j <- x_j / d_j - sum_r L(B_r, j) x(B_r)
+        // (what k_snode_pull did in a launch of its own; here every block does it while it would otherwise
+        // wait for the flags of the later blocks).  Rows of B along the lanes, this wave's CPW columns together.
+        double pacc[CPW];
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) pacc[q] = 0.0;
+        for (int r0 = 0; r0 < g.nb; r0 += 64) {
+            const int r = r0 + lane;
+            const bool rok = r < g.nb;
+            const double xb = rok ? x[Bn[r]] : 0.0;
+            double lq[CPW];
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                const int j = wave * CPW + q;
+                lq[q] = (rok && j < nbw) ? v.Lx[cbr[j] + g.w + r] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) pacc[q] += lq[q] * xb;
+        }
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const double tot = wave_sum(pacc[q]);
+            if (lane == 0) pulled[wave * CPW + q] = tot;
+        }
+        __syncthreads();
+        if (wave == 0 && lane < nbw) xown = xown * v.Dinv[g.cols[j0 + lane]] - pulled[lane];
+    }
+    // the diagonal block with the solve's lane index fastest (snode_block_solve): forward Tl[col * SN_NB + row],
+    // backward Tl[row * SN_NB + col]
+    for (int idx = tid; idx < SN_NB * SN_NB; idx += SN2_WG) {
+        const int hi = idx / SN_NB, lo = idx % SN_NB;
+        const int ii = FWDMODE ? lo : hi, jj = FWDMODE ? hi : lo;
+        Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[cbr[jj] + j0 + ii] : 0.0;
+    }
+    double acc[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) acc[q] = 0.0;
+    const int nsteps = FWDMODE ? r : nblk - 1 - r;
+    // every WAVE runs the pipeline on its own (no workgroup barrier per step): it requests the L entries of
+    // the next step, waits for the flag of x_c, reads x_c (one entry per lane) and accumulates
+    double lv[CPW], ln[CPW];
+    auto request = [&](double(&dst)[CPW], int step) {
+        const int c = FWDMODE ? step : nblk - 1 - step;
+        const int c0 = c * SN_NB, ncw = min(SN_NB, g.w - c0);
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const int j = wave * CPW + q;
+            if (FWDMODE) dst[q] = (lane < nbw && j < ncw) ? v.Lx[colbase[c0 + j] + j0 + lane] : 0.0; // L(j0 + lane, c0 + j)
+            else dst[q] = (lane < ncw && j < nbw) ? v.Lx[cbr[j] + c0 + lane] : 0.0;                  // L(c0 + lane, j0 + j)
+        }
+    };
+    if (nsteps > 0) request(ln, 0);
+    bool ok = true;
+    for (int step = 0; step < nsteps && ok; ++step) {
+        const int c = FWDMODE ? step : nblk - 1 - step;
+        const int c0 = c * SN_NB, ncw = min(SN_NB, g.w - c0);
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) lv[q] = ln[q];
+        if (step + 1 < nsteps) request(ln, step + 1);
+        // every lane polls the message of "its" unknown of block c
+        msg_v4i mm;
+        for (long long spins = 0;; ++spins) {
+            mm = msg_load(mb + (c * 64 + lane) * 4);
+            const bool got = lane >= ncw || (mm.y == epoch && mm.w == epoch);
+            if (__all(got)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (spins > (1ll << 18)) {
+                ok = false;
+                if (lane == 0) *timeout_flag = 1;
+                break;
+            }
+        }
+        if (!ok) break;
+        const double xcv = lane < ncw ? __hiloint2double(mm.z, mm.x) : 0.0;
+        if (FWDMODE) {
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) acc[0] += lv[q] * __shfl(xcv, wave * CPW + q, 64);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) acc[q] += lv[q] * xcv;
+        }
+    }
+    // reduce: forward across the waves (each holds its columns' share of every row), backward across lanes
+    if (FWDMODE) {
+        part[wave][lane] = acc[0];
+    } else {
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const double tot = wave_sum(acc[q]);
+            if (lane == 0) part[0][wave * CPW + q] = tot;
+        }
+    }
+    __syncthreads(); // (also: Tl is complete)
+    if (wave == 0 && ok) {
+        double xv = xown;
+        if (lane < nbw) {
+            if (FWDMODE) {
+#pragma unroll
+                for (int w = 0; w < SN2_WG / 64; ++w) xv -= part[w][lane];
+            } else {
+                xv -= part[0][lane];
+            }
+        }
+        xv = snode_block_solve<FWDMODE>(Tl, xv, lane);
+        if (lane < nbw) {
+            msg_store(mb + (r * 64 + lane) * 4, xv, epoch); // to the other blocks of this sweep
+            x[g.cols[j0 + lane]] = xv;                      // to the launches that follow
+        }
+        if (FWDMODE) pulled[lane] = lane < nbw ? xv : 0.0;
+    }
+    if (FWDMODE && g.nb > 0) {
+        // after the flag (off the pipeline's critical path): this block's share of x_B -= L_BS x_S, one row of B
+        // per thread, one atomic per (row, block) -- what k_snode_push did in a launch of its own
+        __syncthreads();
+        if (!ok) return;
+        for (int rb = tid; rb < g.nb; rb += SN2_WG) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int j2 = 0; j2 < SN_NB; j2 += 16) {
+                double lv2[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) lv2[q] = (j2 + q < nbw) ? v.Lx[cbr[j2 + q] + g.w + rb] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sacc += lv2[q] * pulled[j2 + q];
+            }
+            atomicAdd(&x[Bn[rb]], -sacc);
+        }
+    }
+}
+
+
+} // namespace
+
+static size_t snode_solve_lds_bytes(int wmax, int nbcap) {
+    return (size_t)(wmax + nbcap + SN_NB * SN_NB + SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int);
+}
+static size_t snode_lds_bytes(int wmax) { return (size_t)(SN_KC * SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int); }
+int snode_kernel_attributes(int wmax, int nbmax) {
+    const int lds = (int)snode_lds_bytes(wmax);
+    int rc = (int)hipFuncSetAttribute((const void *)k_snode_update, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_extend, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
+    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    return rc;
+}
+// wlvl / nblvl: maxima over the supernodes of this launch.  Levels with a large B part run it in
+// separate multi-workgroup launches: one workgroup per supernode is latency bound.
+void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
+                  int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri,
+                  const LaunchProf *lp) {
+    if (!count) return;
+    if (tri && tri->msg && wlvl > 2 * SN_NB) {
+        if (lp) lp->begin(lp->ctx, PFK_SN_TRI);
+        // wide supernodes: the triangle by several workgroups per supernode (k_snode_tri), the rows of B by
+        // their own multi-workgroup launches
+        const int nblkmax = (wlvl + SN_NB - 1) / SN_NB;
+        if (m == FWD) {
+            k_snode_tri<true><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri->epoch, x,
+                                                                    tri->timeout_flag);
+        } else {
+            k_snode_tri<false><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri->epoch, x,
+                                                                     tri->timeout_flag);
+        }
+        (void)nblvl;
+        if (lp) lp->end(lp->ctx, PFK_SN_TRI);
+        return;
+    }
+    int cap = SN_XB_CAP;
+    if (const char *e = std::getenv("CHIP_SN_XB_CAP")) cap = std::max(1, std::min(SN_XB_CAP, std::atoi(e))); // tests
+    const int nbcap = std::min(nbmax_all, cap);
+    const size_t lds = snode_solve_lds_bytes(wmax_all, nbcap);
+    const bool split = nblvl >= 256;
+    if (m == FWD) {
+        k_snode_fwd<<<count, SN_WG, lds, s>>>(v, sv, order, x, wmax_all, nbcap, split ? 0 : 1);
+        if (split)
+            k_snode_push<<<dim3((nblvl + SN_WG - 1) / SN_WG, (wlvl + SN_PCH - 1) / SN_PCH, count), SN_WG, 0, s>>>(
+                v, sv, order, x);
+    } else {
+        if (split)
+            k_snode_pull<<<dim3((wlvl + SN_NB - 1) / SN_NB, count), SN_WG, (size_t)nbcap * sizeof(double), s>>>(
+                v, sv, order, x, nbcap);
+        k_snode_bwd<<<count, SN_WG, lds, s>>>(v, sv, order, x, wmax_all, nbcap, split ? 0 : 1);
+    }
+}
+// all supernodes order[0..count) of one unit level: block columns one after the other, then their
+// updates of the ancestors.  nblk / hmax / nbmax: maxima over these supernodes.
+namespace {
+// CHIP_SN_DEBUG=1: every launch of the update tiles / the panel kernel is followed by a synchronisation and the
+// stamps of its workgroup 0 are accumulated; the per-phase means are printed when the process ends
+struct SnDebug {
+    long long *dev = nullptr;
+    double sum[2][8] = {};
+    long n[2] = {0, 0};
+    bool on = false;
+    SnDebug() {
+        on = std::getenv("CHIP_SN_DEBUG") != nullptr;
+        mode = on ? std::atoi(std::getenv("CHIP_SN_DEBUG")) : 0;
+        if (on) {
+            (void)hipMalloc((void **)&dev, (64 + (size_t)RING * 32) * sizeof(long long));
+            (void)hipMemset(dev, 0, (64 + (size_t)RING * 32) * sizeof(long long));
+        }
+    }
+    void collect(hipStream_t s, int kind) { // kind 0: panel (slots 0..7), 1: update tiles (slots 16..20)
+        long long t[64];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(t, dev, sizeof(t), hipMemcpyDeviceToHost);
+        const int base = kind ? 16 : 0, cnt = kind ? 5 : 8;
+        for (int i = 1; i < cnt; i++)
+            if (t[base + i] && t[base + i - 1]) sum[kind][i] += (t[base + i] - t[base + i - 1]) * 0.01;
+        n[kind]++;
+        (void)hipMemset(dev, 0, 64 * sizeof(long long));
+    }
+    // CHIP_SN_DEBUG=2: no synchronisation; launch k stamps into its own 32 slots of a ring, and at the end the time
+    // between the LAST stamp of a launch and the FIRST stamp of the next one (what a kernel boundary costs) is printed
+    static constexpr int RING = 2048;
+    int mode = 0;
+    long nring = 0;
+    std::vector<int> kinds;
+    long long *ring_slot(int kind) {
+        if ((nring % RING) == 0 && nring) flush_ring();
+        kinds.push_back(kind);
+        return dev + 64 + (size_t)(nring++ % RING) * 32;
+    }
+    double gap_sum[2] = {0, 0}, in_sum[2] = {0, 0}, skew_sum[2] = {0, 0};
+    long gap_n[2] = {0, 0};
+    void flush_ring() {
+        (void)hipDeviceSynchronize();
+        std::vector<long long> t((size_t)RING * 32);
+        (void)hipMemcpy(t.data(), dev + 64, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        const long cnt = (long)kinds.size();
+        long long prev_last = 0;
+        for (long k = 0; k < cnt; k++) {
+            const long long *r = t.data() + (size_t)k * 32;
+            const int base = kinds[k] ? 16 : 0, hi = kinds[k] ? 20 : 7;
+            long long first = r[base], last = 0;
+            for (int i = base; i <= hi; i++) last = std::max(last, r[i]);
+            const long long wg0_last = last;
+            last = std::max(last, r[kinds[k] ? 21 : 8]); // (the end of the launch's LAST workgroup)
+            if (first) skew_sum[kinds[k]] += (last - wg0_last) * 0.01;
+            if (first && prev_last && first > prev_last && first - prev_last < 100000 && k > 0 && kinds[k - 1] != kinds[k]) { // (update <-> panel pairs of one block column)
+                gap_sum[kinds[k]] += (first - prev_last) * 0.01;
+                in_sum[kinds[k]] += (last - first) * 0.01;
+                gap_n[kinds[k]]++;
+                for (int i = base + 1; i <= hi; i++)
+                    if (r[i] && r[i - 1]) sum[kinds[k]][i - base] += (r[i] - r[i - 1]) * 0.01;
+                n[kinds[k]]++;
+            }
+            prev_last = last;
+        }
+        kinds.clear();
+        (void)hipMemset(dev + 64, 0, (size_t)RING * 32 * sizeof(long long));
+    }
+    ~SnDebug() {
+        if (on && mode == 2) {
+            flush_ring();
+            for (int k = 0; k < 2; k++)
+                if (gap_n[k])
+                    std::fprintf(stderr, "[chip sn debug] %s: mean over %ld launches: %.2f us between the END of the previous launch's last workgroup and this one's first stamp, %.2f us from there to the end of its last workgroup (workgroup 0 ends %.2f us before the last one)\n",
+                                 k ? "k_snode_update" : "k_snode_panel", gap_n[k], gap_sum[k] / gap_n[k], in_sum[k] / gap_n[k], skew_sum[k] / std::max(1L, n[k]));
+        }
+        if (!on) return;
+        const char *pn[8] = {"", "geometry+colbase", "block loads", "block factorisation", "write-back", "row loads", "rows recurrence", "stores"};
+        const char *un[5] = {"", "colbase", "first operand staged", "matrix instructions (all chunks)", "emit"};
+        if (n[0]) {
+            std::fprintf(stderr, "[chip sn debug] k_snode_panel, workgroup 0, mean over %ld launches (us):", n[0]);
+            for (int i = 1; i < 8; i++) std::fprintf(stderr, " %s %.2f;", pn[i], sum[0][i] / n[0]);
+            std::fprintf(stderr, "\n");
+        }
+        if (n[1]) {
+            std::fprintf(stderr, "[chip sn debug] k_snode_update, workgroup 0, mean over %ld launches (us):", n[1]);
+            for (int i = 1; i < 5; i++) std::fprintf(stderr, " %s %.2f;", un[i], sum[1][i] / n[1]);
+            std::fprintf(stderr, "\n");
+        }
+    }
+};
+SnDebug &sn_debug() {
+    static SnDebug d;
+    return d;
+}
+} // namespace
+void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, const int *order, int count, int wmax_all,
+                   int nblk, int hmax, int nbmax, const LaunchProf *lp) {
+    if (!count) return;
+    SnodeView sv = sv_in;
+    SnDebug &dbg = sn_debug();
+    if (dbg.on) sv.dbg = dbg.dev;
+    const size_t lds = snode_lds_bytes(wmax_all);
+    auto pb = [&](int f) { if (lp) lp->begin(lp->ctx, f); };
+    auto pe = [&](int f) { if (lp) lp->end(lp->ctx, f); };
+    for (int b = 0; b < nblk; ++b) {
+        if (b > 0) {
+            const int rows = hmax - b * SN_NB;
+            if (rows > 0) {
+                const int groups = (rows + SN_ROWS - 1) / SN_ROWS;
+                int ksplit = 1; // fill the chip when the level has few supernodes: the finished columns in shares of whole block columns
+                // (CHIP_NO_SPLITK: no split -> no fp64 atomics between the splits, a fixed summation order)
+                static const bool no_splitk = std::getenv("CHIP_NO_SPLITK") != nullptr;
+                static const int split_target = std::getenv("CHIP_SN_SPLIT_TARGET") ? std::atoi(std::getenv("CHIP_SN_SPLIT_TARGET")) : 256;
+                static const int split_max = std::getenv("CHIP_SN_SPLIT_MAX") ? std::atoi(std::getenv("CHIP_SN_SPLIT_MAX")) : 8;
+                static const int split_unit = std::getenv("CHIP_SN_SPLIT_UNIT") ? std::atoi(std::getenv("CHIP_SN_SPLIT_UNIT")) : 1; // block columns per share, at least
+                while (!no_splitk && ksplit < split_max && ksplit * 2 * split_unit <= b && groups * count * ksplit < split_target) ksplit *= 2;
+                pb(PFK_SN_UPDATE);
+                if (dbg.mode == 2) sv.dbg = dbg.ring_slot(1) - 16 + 16; // (slots 16..20 of the launch's 32)
+                k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b);
+                pe(PFK_SN_UPDATE);
+                if (dbg.on && dbg.mode != 2) dbg.collect(s, 1);
+            }
+        }
+        const bool no_panel = std::getenv("CHIP_NO_SNODE_PANEL") != nullptr; // (read per call: the tests switch forms inside one process)
+        if (!no_panel) { // the diagonal block and the rows below it in one launch of one-wave workgroups
+            const int below = hmax - b * SN_NB - 1;
+            pb(PFK_SN_DIAG);
+            if (dbg.mode == 2) sv.dbg = dbg.ring_slot(0);
+            // (bit 0: rows phase on the matrix cores; bit 1: block factorisation on the matrix cores)
+            const int panel_mode = (std::getenv("CHIP_NO_PANEL_MFMA") ? 0 : 1) | (std::getenv("CHIP_NO_PANEL_DIAG_MFMA") ? 0 : 2);
+            k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
+            pe(PFK_SN_DIAG);
+            if (dbg.on && dbg.mode != 2) dbg.collect(s, 0);
+            continue;
+        }
+        pb(PFK_SN_DIAG);
+        k_snode_diag<<<count, SN_DWG, 0, s>>>(v, sv, order, b);
+        pe(PFK_SN_DIAG);
+        const int below = hmax - b * SN_NB - 1; // (a narrow last block leaves more rows below it)
+        if (below > 0) {
+            pb(PFK_SN_ROWS);
+            k_snode_rows<<<dim3((below + SN_RWG - 1) / SN_RWG, count), SN_RWG, 0, s>>>(v, sv, order, b);
+            pe(PFK_SN_ROWS);
+        }
+    }
+    if (nbmax > 0 && sv.upd_slot) {
+        pb(PFK_SN_EXTEND);
+        k_snode_extend<<<dim3((nbmax + SN_ROWS - 1) / SN_ROWS, (nbmax + SN_NB - 1) / SN_NB, count), SN_WG, lds, s>>>(
+            v, sv_in, order);
+        pe(PFK_SN_EXTEND);
+    }
+}
+
+} // namespace dev
+} // namespace chip

@@ -54,17 +54,17 @@ void run_threads(int T, const std::function<void(int, int)> &body) {
 namespace {
 
 
-// kernel work-list thresholds (see kernels.hip)
+// kernel work-list thresholds (see bundle_factor.hip, bundle_solve.hip, snode.hip)
 constexpr i32 T_MAX = 32;      // <= T_MAX entries: one thread per row
 constexpr i32 B_MIN = 16384;   // >  B_MIN entries: split over workgroups
 constexpr i32 B_CHUNK = 4096;  // entries per B chunk
 constexpr i32 TOPFOLD_MAX = 8;    // at most this many top rows are folded into the bundle kernels (kernels.hpp)
-constexpr i32 TOPBLK = 128;       // rows per block of the blocked top substitution (kernels.hip: TOPBLK)
+constexpr i32 TOPBLK = 128;       // rows per block of the blocked top substitution (bundle_solve.hip: TOPBLK)
 constexpr i64 F_MIN_WORK = 16384;    // factor: a column with more (contribution, tail entry) updates than this
 constexpr i64 F_CHUNK_MIN = 1024, F_CHUNK_MAX = 4096, F_CHUNK_PARTS = 96;  // ... is split over workgroups in chunks of about this many updates
 constexpr i32 FAC_T_ROW = 8;   // factor: thread-per-column if contributions <= this
 constexpr i32 FAC_T_COL = 48;  // ... and column length <= this
-// chain supernodes of the top (dense trapezoids factored by one workgroup each, kernels.hip k_factor_snode)
+// chain supernodes of the top (dense trapezoids factored by one workgroup each, snode.hip)
 constexpr i32 SN_MIN_W = 16;       // shorter chains stay ordinary columns
 constexpr i32 SN_MAX_W = 4096;     // longer chains are cut
 constexpr i32 SN_PAD_ABS = 16;     // explicit zeros tolerated per column: max(SN_PAD_ABS, SN_PAD_REL * padded length)

@@ -810,9 +810,17 @@ class DeviceArray:
 
 
 def debug_spin(device, blocks, threads=256, lds_bytes=0, usec=1000.0):
-    """diagnostics: a co-resident kernel that only spins (chip_debug_spin); blocks = 0 waits for the spinners"""
+    """test hook (include/clarabel_hip_testing.h; CHIP_TESTING builds): a co-resident kernel that only spins;
+    blocks = 0 waits for the spinners"""
     lib().chip_debug_spin.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double]
     _check(lib().chip_debug_spin(device, blocks, threads, lds_bytes, float(usec)), "debug_spin")
+
+
+def debug_set_switch(name, value=None):
+    """test hook: set (value given) or clear one CHIP_* diagnostic switch and re-parse the switch table
+    (csrc/switches.hpp) -- for handles that already exist; the environment is read whenever a handle is created"""
+    lib().chip_debug_set_switch.argtypes = [C.c_char_p, C.c_char_p]
+    _check(lib().chip_debug_set_switch(name.encode(), None if value is None else str(value).encode()), "debug_set_switch")
 
 
 def set_device(ordinal):

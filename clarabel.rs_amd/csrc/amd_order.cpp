@@ -39,13 +39,12 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         if (info) *info = st;
         return 0;
     }
-    const bool timing = std::getenv("CHIP_TIMING") != nullptr;
+    const bool timing = switches().timing;
     const auto t_begin = std::chrono::steady_clock::now();
     // ---- symmetric adjacency without the diagonal ---------------------------
     // (threads own ranges of nodes and scan all of K in order: the lists come out the same for any count)
     const i64 nnzA = Ap[n];
-    i64 par_min = 2000000;
-    if (const char *e = std::getenv("CHIP_HOST_PAR_MIN")) par_min = std::atoll(e);
+    const i64 par_min = switches().host_par_min;
     const int T = nnzA >= par_min ? host_threads() : 1;
     std::vector<I> ast((size_t)n + 1, 0);
     std::vector<int> bad((size_t)T, 0);
@@ -164,7 +163,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     // implementations (default), or first-in-first-out (CHIP_AMD_FIFO: a variable that has been
     // waiting at this degree goes before one that just joined it, which spreads equal-degree pivots
     // over independent subtrees; same kind of fill, often a shallower tree, sometimes a deeper one)
-    static const bool lifo = getenv("CHIP_AMD_FIFO") == nullptr;
+    const bool lifo = !switches().amd_fifo;
     auto dl_insert_tail = [&](I i, I d) {
         if (lifo) return dl_insert(i, d);
         prv[i] = tail[d];
@@ -211,7 +210,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     std::vector<uint64_t> hashA((size_t)n, 0);
     std::vector<char> dirty((size_t)n, 0), cand;
     I seq = 0;
-    const bool rescan_all = std::getenv("CHIP_AMD_RESCAN") != nullptr; // every member rescans (the textbook update; tests)
+    const bool rescan_all = switches().amd_rescan; // every member rescans (the textbook update; tests)
     while (nelim < nlive) {
         auto tp0 = std::chrono::steady_clock::now();
         while (mindeg <= n && head[mindeg] == NONE) mindeg++;
@@ -515,7 +514,7 @@ int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vect
 // dense-row threshold stays that of the whole matrix.  One component: the plain call.
 int amd_order_components(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
                          AmdInfo *info) {
-    if (n <= 1 || std::getenv("CHIP_NO_COMPONENTS") != nullptr) return amd_order(n, Ap, Ai, dense_scale, perm, info);
+    if (n <= 1 || switches().no_components) return amd_order(n, Ap, Ai, dense_scale, perm, info);
     // ---- connected components (union-find with path halving; the smaller index stays the root) ----
     std::vector<i64> root((size_t)n);
     for (i64 i = 0; i < n; i++) root[i] = i;
@@ -637,7 +636,7 @@ int amd_order_components(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale
         tot.nmultsubs_ldl += rinfo[k].nmultsubs_ldl;
         tot.ndense += rinfo[k].ndense;
     }
-    if (std::getenv("CHIP_TIMING") != nullptr)
+    if (switches().timing)
         std::fprintf(stderr, "[chip amd] %lld connected components, %lld distinct patterns\n", (long long)nc, (long long)nr);
     if (info) *info = tot;
     return 0;

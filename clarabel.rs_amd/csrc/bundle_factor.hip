@@ -987,7 +987,7 @@ bool bundle_factor_lds_ok(int lds_doubles) {
 }
 void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles) {
     if (!bv.nb) return;
-    static const bool no_flat = std::getenv("CHIP_NO_FACTOR_FLAT") != nullptr;
+    const bool no_flat = switches().no_factor_flat;
     if (lds_doubles > 0 && v.fu_rec && !no_flat) k_bundle_factor_flat<<<bv.nb, FFWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold);
     else if (lds_doubles > 0) k_bundle_factor_lds<<<bv.nb, FLWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold, lds_doubles);
     else k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);

@@ -10,6 +10,7 @@
 #include <memory>
 
 #include "engine.hpp"
+#include "../../include/clarabel_hip_testing.h"
 
 using namespace chip;
 
@@ -99,7 +100,11 @@ struct chip_kkt {
         double *lx, *lz;
     } fused_args[Engine::IR_RING] = {};
     int fused_fallbacks = 0;
-    bool ir_test_drop = std::getenv("CHIP_IR_TEST_DROP") != nullptr; // (tests, read when the handle is created)
+    #ifdef CHIP_TESTING
+    bool ir_test_drop = switches().ir_test_drop; // (tests, read when the handle is created)
+#else
+    static constexpr bool ir_test_drop = false;
+#endif
     int world = 1;               // ranks sharing the problem (chip_kkt_attach_comm)
     double *d_partial = nullptr; // per-block partial minima / sums of the cone reductions
     int partial_cap = 0;
@@ -170,7 +175,7 @@ int32_t chip_amd_order(int64_t n, const uint64_t *colptr, const uint64_t *rowval
 // workgroups the device keeps resident for the fused solve kernel (4 x 256 threads per CU): a forest with fewer
 // bundles than that is cut finer by the analysis (grouped fold).  Host-only handles: an MI355X's 256 CUs.
 static int target_workgroups(const chip_settings &st) {
-    if (const char *e = std::getenv("CHIP_TARGET_WG")) return std::atoi(e); // (tests; 0 = never refine)
+    if (switches().has_target_wg) return switches().target_wg; // (tests; 0 = never refine)
     if (st.device == CHIP_DEVICE_HOST_ONLY) return 1024;
     int dev = st.device, cus = 0;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return 1024;
@@ -188,6 +193,7 @@ int32_t chip_ldl_create(chip_ldl **out, int64_t n, const uint64_t *colptr, const
                         const chip_settings *settings) {
     if (!out || n < 0 || !colptr || !rowval || !nzval) return fail(CHIP_ERR_ARG, "chip_ldl_create: bad argument");
     *out = nullptr;
+    switches_reload(); // the CHIP_* diagnostic switches are read from the environment here, never in a launch loop
     chip_settings st;
     if (settings) st = *settings;
     else chip_settings_default(&st);
@@ -363,6 +369,7 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
                         const uint64_t *perm_or_null) {
     if (!out || n < 0 || m < 0 || !Pcolptr || !Acolptr) return fail(CHIP_ERR_ARG, "chip_kkt_create: bad argument");
     *out = nullptr;
+    switches_reload(); // the CHIP_* diagnostic switches are read from the environment here, never in a launch loop
     chip_settings st;
     if (settings) st = *settings;
     else chip_settings_default(&st);
@@ -971,7 +978,7 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     ir.maxiter = st.iterative_refinement_max_iter;
     ir.ir_enable = st.iterative_refinement_enable;
     static long long *dbg_dev = nullptr;
-    static const bool dbg_on = std::getenv("CHIP_IR_DEBUG") != nullptr;
+    const bool dbg_on = switches().ir_debug > 0;
     if (dbg_on && !dbg_dev) {
         (void)hipMalloc((void **)&dbg_dev, 256 * sizeof(long long));
     }
@@ -979,7 +986,7 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     ir.dbg = dbg_on ? dbg_dev : nullptr;
     // CHIP_IR_DEBUG=2: stamps of EVERY workgroup, dumped to the file CHIP_IR_DEBUG_FILE (default /tmp/chip_ir_stamps.bin:
     // int32 G, then G x 32 int64) after each launch -- tools/ir_skew.py turns them into per-phase statistics
-    static const bool dbg_all_on = dbg_on && std::atoi(std::getenv("CHIP_IR_DEBUG")) >= 2;
+    const bool dbg_all_on = switches().ir_debug >= 2;
     static long long *dbg_all_dev = nullptr;
     static size_t dbg_all_len = 0;
     ir.dbg_all = nullptr;
@@ -994,8 +1001,7 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
         ir.dbg_all = dbg_all_dev;
     }
     ir.test_drop = h->ir_test_drop ? 1 : 0;
-    static const bool no_flat = std::getenv("CHIP_NO_FLAT") != nullptr;
-    ir.flat = no_flat ? 0 : 1;
+    ir.flat = switches().no_flat ? 0 : 1;
     h->fused_args[*slot] = {h->rhs_x, h->rhs_z, lhsx_dev, lhsz_dev};
     h->rhs_deferred = false;
     h->x_holds_b = false;
@@ -1007,8 +1013,8 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
         (void)hipStreamSynchronize(E.stream);
         std::vector<long long> t((size_t)E.ir_grid * 32);
         (void)hipMemcpy(t.data(), dbg_all_dev, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
-        const char *path = std::getenv("CHIP_IR_DEBUG_FILE");
-        if (FILE *f = std::fopen(path ? path : "/tmp/chip_ir_stamps.bin", "wb")) {
+        const std::string &path = switches().ir_debug_file;
+        if (FILE *f = std::fopen(path.empty() ? "/tmp/chip_ir_stamps.bin" : path.c_str(), "wb")) {
             const int g = E.ir_grid;
             std::fwrite(&g, sizeof(int), 1, f);
             std::fwrite(t.data(), sizeof(long long), t.size(), f);
@@ -1505,11 +1511,21 @@ int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]) {
     out[7] = h->E.ir_fused ? h->E.ir_tw : 0; // threads per workgroup of the fused solve launch (0: not fused)
     return CHIP_OK;
 }
-// diagnostics: a kernel that only spins, on a stream of its own (co-residency tests of the persistent launches)
+#ifdef CHIP_TESTING
+// test hooks (include/clarabel_hip_testing.h): a kernel that only spins, on a stream of its own (co-residency tests of
+// the persistent launches); a switch of csrc/switches.hpp set or cleared by name
 int32_t chip_debug_spin(int32_t device, int32_t blocks, int32_t threads, int32_t lds_bytes, double usec) {
     static hipStream_t spin_stream[16] = {};
     if (device < 0 || device >= 16 || blocks < 0 || threads <= 0 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024)
         return CHIP_ERR_ARG;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    struct Restore { // the caller's current device is left as it was
+        int d;
+        ~Restore() {
+            if (d >= 0) (void)hipSetDevice(d);
+        }
+    } restore{prev};
     CHIP_HIP(hipSetDevice(device));
     if (blocks == 0) { // wait for the spinners launched so far
         if (spin_stream[device]) CHIP_HIP(hipStreamSynchronize(spin_stream[device]));
@@ -1520,5 +1536,9 @@ int32_t chip_debug_spin(int32_t device, int32_t blocks, int32_t threads, int32_t
     CHIP_HIP(hipGetLastError());
     return CHIP_OK;
 }
+int32_t chip_debug_set_switch(const char *name, const char *value_or_null) {
+    return switches_set(name, value_or_null) ? CHIP_OK : fail(CHIP_ERR_ARG, "chip_debug_set_switch: unknown switch");
+}
+#endif
 
 } // extern "C"

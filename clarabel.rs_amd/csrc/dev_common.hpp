@@ -35,6 +35,7 @@
 //   sparse gemv, dots, waxpby   algebra/csc/matrix_math.rs:258-343, vecmath.rs
 #pragma once
 #include "kernels.hpp"
+#include "switches.hpp"
 #include <hip/hip_ext.h>
 
 #include <algorithm>

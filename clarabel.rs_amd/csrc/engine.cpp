@@ -339,9 +339,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     bool need_ring = false;
     const bool grouped = S.gf_ng > 0;
     if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || grouped || NF == N) && !S.Li16.empty() &&
-        std::getenv("CHIP_NO_FUSED_IR") == nullptr) {
+        !switches().no_fused_ir) {
         int cap = dev::bundle_ir_capacity(bundles, &ir_tw);
-        if (cap > 0 && std::getenv("CHIP_NO_SYMV_SPLIT") == nullptr) {
+        if (cap > 0 && !switches().no_symv_split) {
             // the residual's "split" form (bundle_symv.hpp: bundle_symv_split) needs nloc + max(0, nloc - 2 nleaf) doubles
             // of LDS per bundle: taken when the larger slice leaves the co-resident grid and the workgroup size as
             // they are
@@ -370,7 +370,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             if ((rc = upload(&Urow16, S.Urow16, S.Urow16.size()))) return rc;
             if ((rc = upload(&Rk16, S.Rk16, S.Rk16.size()))) return rc;
             if ((rc = upload(&Ro16, S.Ro16, S.Ro16.size()))) return rc;
-            if (std::getenv("CHIP_NO_FACTOR_LDS") == nullptr) {
+            if (!switches().no_factor_lds) {
                 // the bundle factorisation with its L and D values in LDS: every bundle's entries must be addressable
                 // in 16 bits and two workgroups must fit a CU
                 int need = 0;
@@ -575,7 +575,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     const bool top_folded = fold.k == 1 || gfold.ng > 0;
     if (fold.k == 1) dev::fold_top_pivot(stream, v, fold);
     if (gfold.ng > 0) dev::gfold_top_factor(stream, v, bundles, gfold);
-    const bool use_chain = std::getenv("CHIP_NO_FACTOR_CHAIN") == nullptr;
+    const bool use_chain = !switches().no_factor_chain;
     // units (single columns, chain supernodes) by unit level; a level's supernodes run after its
     // single columns: first the contributions of outside columns into their members (the chunked
     // column kernel over the external lists, no pivots), then one workgroup per supernode
@@ -696,8 +696,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, nullptr, sn_cnt};
         // wide supernodes: several workgroups per supernode, pipelined through per-block flags that carry this
         // sweep's epoch (not inside a captured graph: a replay would meet its own flags)
-        static const bool no_tri = std::getenv("CHIP_NO_SNODE_TRI") != nullptr;
-        const bool use_tri = !no_tri && !st.use_graph;
+        const bool use_tri = !switches().no_snode_tri && !st.use_graph;
         dev::SnodeTriView tri{sn_blk_ptr, sn_flags, 0, norm_nan(1)};
         dev::GatherArgs f{Rf_p, Rf_col, Rfx, xp, xp, nullptr, nullptr, nullptr};
         tri.epoch = ++sn_epoch;

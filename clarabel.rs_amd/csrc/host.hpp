@@ -13,6 +13,8 @@
 #include <utility>
 #include <vector>
 
+#include "switches.hpp"
+
 namespace chip {
 
 using i64 = int64_t;
@@ -242,7 +244,7 @@ void set_error(const std::string &msg);
 // CHIP_TIMING=1: wall-clock of the analysis phases on stderr
 struct PhaseClock {
     const char *tag = "analyse";
-    bool on = std::getenv("CHIP_TIMING") != nullptr;
+    bool on = switches().timing;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void operator()(const char *what) {
         if (!on) return;

@@ -1292,7 +1292,7 @@ void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView
         return;
     }
     int cap = SN_XB_CAP;
-    if (const char *e = std::getenv("CHIP_SN_XB_CAP")) cap = std::max(1, std::min(SN_XB_CAP, std::atoi(e))); // tests
+    if (switches().sn_xb_cap > 0) cap = std::min(SN_XB_CAP, switches().sn_xb_cap); // tests
     const int nbcap = std::min(nbmax_all, cap);
     const size_t lds = snode_solve_lds_bytes(wmax_all, nbcap);
     const bool split = nblvl >= 256;
@@ -1319,8 +1319,8 @@ struct SnDebug {
     long n[2] = {0, 0};
     bool on = false;
     SnDebug() {
-        on = std::getenv("CHIP_SN_DEBUG") != nullptr;
-        mode = on ? std::atoi(std::getenv("CHIP_SN_DEBUG")) : 0;
+        mode = switches().sn_debug;
+        on = mode > 0;
         if (on) {
             (void)hipMalloc((void **)&dev, (64 + (size_t)RING * 32) * sizeof(long long));
             (void)hipMemset(dev, 0, (64 + (size_t)RING * 32) * sizeof(long long));
@@ -1420,10 +1420,10 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
                 const int groups = (rows + SN_ROWS - 1) / SN_ROWS;
                 int ksplit = 1; // fill the chip when the level has few supernodes: the finished columns in shares of whole block columns
                 // (CHIP_NO_SPLITK: no split -> no fp64 atomics between the splits, a fixed summation order)
-                static const bool no_splitk = std::getenv("CHIP_NO_SPLITK") != nullptr;
-                static const int split_target = std::getenv("CHIP_SN_SPLIT_TARGET") ? std::atoi(std::getenv("CHIP_SN_SPLIT_TARGET")) : 256;
-                static const int split_max = std::getenv("CHIP_SN_SPLIT_MAX") ? std::atoi(std::getenv("CHIP_SN_SPLIT_MAX")) : 8;
-                static const int split_unit = std::getenv("CHIP_SN_SPLIT_UNIT") ? std::atoi(std::getenv("CHIP_SN_SPLIT_UNIT")) : 1; // block columns per share, at least
+                const bool no_splitk = switches().no_splitk || switches().deterministic;
+                const int split_target = switches().sn_split_target;
+                const int split_max = switches().sn_split_max;
+                const int split_unit = switches().sn_split_unit; // block columns per share, at least
                 while (!no_splitk && ksplit < split_max && ksplit * 2 * split_unit <= b && groups * count * ksplit < split_target) ksplit *= 2;
                 pb(PFK_SN_UPDATE);
                 if (dbg.mode == 2) sv.dbg = dbg.ring_slot(1) - 16 + 16; // (slots 16..20 of the launch's 32)
@@ -1432,13 +1432,13 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
                 if (dbg.on && dbg.mode != 2) dbg.collect(s, 1);
             }
         }
-        const bool no_panel = std::getenv("CHIP_NO_SNODE_PANEL") != nullptr; // (read per call: the tests switch forms inside one process)
+        const bool no_panel = switches().no_snode_panel;
         if (!no_panel) { // the diagonal block and the rows below it in one launch of one-wave workgroups
             const int below = hmax - b * SN_NB - 1;
             pb(PFK_SN_DIAG);
             if (dbg.mode == 2) sv.dbg = dbg.ring_slot(0);
             // (bit 0: rows phase on the matrix cores; bit 1: block factorisation on the matrix cores)
-            const int panel_mode = (std::getenv("CHIP_NO_PANEL_MFMA") ? 0 : 1) | (std::getenv("CHIP_NO_PANEL_DIAG_MFMA") ? 0 : 2);
+            const int panel_mode = (switches().no_panel_mfma ? 0 : 1) | (switches().no_panel_diag_mfma ? 0 : 2);
             k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
             pe(PFK_SN_DIAG);
             if (dbg.on && dbg.mode != 2) dbg.collect(s, 0);

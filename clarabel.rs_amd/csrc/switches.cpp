@@ -1,0 +1,108 @@
+// switches.cpp -- see switches.hpp
+#include "switches.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace chip {
+namespace {
+
+struct Entry {
+    const char *name;
+    enum Kind { FLAG, INT, LONG, STR } kind;
+    size_t off;
+    size_t given_off; // FLAG-typed "was given" companion of an INT entry, or 0
+};
+#define SW(field) offsetof(Switches, field)
+const Entry TABLE[] = {
+    {"CHIP_TIMING", Entry::FLAG, SW(timing), 0},
+    {"CHIP_HOST_THREADS", Entry::INT, SW(host_threads), 0},
+    {"CHIP_HOST_PAR_MIN", Entry::LONG, SW(host_par_min), 0},
+    {"CHIP_AMD_FIFO", Entry::FLAG, SW(amd_fifo), 0},
+    {"CHIP_AMD_RESCAN", Entry::FLAG, SW(amd_rescan), 0},
+    {"CHIP_NO_COMPONENTS", Entry::FLAG, SW(no_components), 0},
+    {"CHIP_NO_CHAIN_REORDER", Entry::FLAG, SW(no_chain_reorder), 0},
+    {"CHIP_NO_BUNDLES", Entry::FLAG, SW(no_bundles), 0},
+    {"CHIP_BUNDLE_MAX_WORK", Entry::LONG, SW(bundle_max_work), 0},
+    {"CHIP_NO_GROUPFOLD", Entry::FLAG, SW(no_groupfold), 0},
+    {"CHIP_GROUPFOLD_MIN", Entry::LONG, SW(groupfold_min), 0},
+    {"CHIP_TARGET_WG", Entry::INT, SW(target_wg), SW(has_target_wg)},
+    {"CHIP_NO_LEVEL_SORT", Entry::FLAG, SW(no_level_sort), 0},
+    {"CHIP_NO_SNODE", Entry::FLAG, SW(no_snode), 0},
+    {"CHIP_NO_TOPFOLD", Entry::FLAG, SW(no_topfold), 0},
+    {"CHIP_NO_FACTOR_FLAT", Entry::FLAG, SW(no_factor_flat), 0},
+    {"CHIP_NO_TOPBLK", Entry::FLAG, SW(no_topblk), 0},
+    {"CHIP_NO_GATHER_HOIST", Entry::FLAG, SW(no_gather_hoist), 0},
+    {"CHIP_NO_XPERM", Entry::FLAG, SW(no_xperm), 0},
+    {"CHIP_NO_FUSED_IR", Entry::FLAG, SW(no_fused_ir), 0},
+    {"CHIP_NO_SYMV_SPLIT", Entry::FLAG, SW(no_symv_split), 0},
+    {"CHIP_NO_FACTOR_LDS", Entry::FLAG, SW(no_factor_lds), 0},
+    {"CHIP_NO_FACTOR_CHAIN", Entry::FLAG, SW(no_factor_chain), 0},
+    {"CHIP_NO_SNODE_TRI", Entry::FLAG, SW(no_snode_tri), 0},
+    {"CHIP_NO_FLAT", Entry::FLAG, SW(no_flat), 0},
+    {"CHIP_NO_IR1024", Entry::FLAG, SW(no_ir1024), 0},
+    {"CHIP_IR_TEST_DROP", Entry::FLAG, SW(ir_test_drop), 0},
+    {"CHIP_IR_DEBUG", Entry::INT, SW(ir_debug), 0},
+    {"CHIP_IR_DEBUG_FILE", Entry::STR, SW(ir_debug_file), 0},
+    {"CHIP_NO_STEP_KERNEL", Entry::FLAG, SW(no_step_kernel), 0},
+    {"CHIP_SN_XB_CAP", Entry::INT, SW(sn_xb_cap), 0},
+    {"CHIP_SN_DEBUG", Entry::INT, SW(sn_debug), 0},
+    {"CHIP_NO_SPLITK", Entry::FLAG, SW(no_splitk), 0},
+    {"CHIP_SN_SPLIT_TARGET", Entry::INT, SW(sn_split_target), 0},
+    {"CHIP_SN_SPLIT_MAX", Entry::INT, SW(sn_split_max), 0},
+    {"CHIP_SN_SPLIT_UNIT", Entry::INT, SW(sn_split_unit), 0},
+    {"CHIP_NO_SNODE_PANEL", Entry::FLAG, SW(no_snode_panel), 0},
+    {"CHIP_NO_PANEL_MFMA", Entry::FLAG, SW(no_panel_mfma), 0},
+    {"CHIP_NO_PANEL_DIAG_MFMA", Entry::FLAG, SW(no_panel_diag_mfma), 0},
+    {"CHIP_DETERMINISTIC", Entry::FLAG, SW(deterministic), 0},
+};
+#undef SW
+
+Switches g_sw;
+bool g_parsed = false;
+std::mutex g_mu;
+
+void parse_locked() {
+    Switches s; // defaults
+    char *base = reinterpret_cast<char *>(&s);
+    for (const Entry &e : TABLE) {
+        const char *v = std::getenv(e.name);
+        if (!v) continue;
+        switch (e.kind) {
+        case Entry::FLAG: *reinterpret_cast<bool *>(base + e.off) = true; break;
+        case Entry::INT: *reinterpret_cast<int *>(base + e.off) = std::atoi(v); break;
+        case Entry::LONG: *reinterpret_cast<long long *>(base + e.off) = std::atoll(v); break;
+        case Entry::STR: *reinterpret_cast<std::string *>(base + e.off) = v; break;
+        }
+        if (e.given_off) *reinterpret_cast<bool *>(base + e.given_off) = true;
+    }
+    g_sw = s;
+    g_parsed = true;
+}
+
+} // namespace
+
+const Switches &switches() {
+    if (!g_parsed) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_parsed) parse_locked();
+    }
+    return g_sw;
+}
+void switches_reload() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    parse_locked();
+}
+bool switches_set(const char *name, const char *value) {
+    if (!name) return false;
+    bool known = false;
+    for (const Entry &e : TABLE) known = known || std::strcmp(e.name, name) == 0;
+    if (!known) return false;
+    if (value) setenv(name, value, 1);
+    else unsetenv(name);
+    switches_reload();
+    return true;
+}
+
+} // namespace chip

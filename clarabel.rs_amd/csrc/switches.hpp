@@ -1,0 +1,66 @@
+// switches.hpp -- the CHIP_* diagnostic switches, parsed from the environment ONCE into a struct.
+//
+// The switches exist so that every code path stays covered by the tests (older forms of a kernel, mechanisms
+// turned off one at a time) and for the profiling tools; none of them is part of the C ABI's contract.  They
+// are read from the environment when a handle is created (chip_ldl_create / chip_kkt_create call
+// switches_reload()) and never inside a launch loop: launchers and engine code read the parsed struct.
+// Tests flip a switch either by setting the environment variable before they create a handle or, for a handle
+// that already exists, through chip_debug_set_switch (include/clarabel_hip.h; CHIP_TESTING builds only).
+#pragma once
+#include <string>
+
+namespace chip {
+
+struct Switches {
+    // ---- host analysis (symbolic.cpp, amd_order.cpp) ----
+    bool timing = false;            // CHIP_TIMING: wall-clock of the analysis phases on stderr
+    int host_threads = 0;           // CHIP_HOST_THREADS (0: min(16, hardware threads))
+    long long host_par_min = 2000000; // CHIP_HOST_PAR_MIN: smallest pass that is split over threads
+    bool amd_fifo = false;          // CHIP_AMD_FIFO: first-in-first-out ties in the degree lists
+    bool amd_rescan = false;        // CHIP_AMD_RESCAN: every member of a new element rescans its lists
+    bool no_components = false;     // CHIP_NO_COMPONENTS: order the whole graph, not one component per pattern
+    bool no_chain_reorder = false;  // CHIP_NO_CHAIN_REORDER
+    bool no_bundles = false;        // CHIP_NO_BUNDLES
+    long long bundle_max_work = 0;  // CHIP_BUNDLE_MAX_WORK (0: default)
+    bool no_groupfold = false;      // CHIP_NO_GROUPFOLD
+    long long groupfold_min = 0;    // CHIP_GROUPFOLD_MIN (0: default)
+    bool has_target_wg = false;     // CHIP_TARGET_WG given
+    int target_wg = 0;
+    bool no_level_sort = false;     // CHIP_NO_LEVEL_SORT
+    bool no_snode = false;          // CHIP_NO_SNODE
+    bool no_topfold = false;        // CHIP_NO_TOPFOLD
+    bool no_factor_flat = false;    // CHIP_NO_FACTOR_FLAT (also read by the launcher of the bundle factorisation)
+    bool no_topblk = false;         // CHIP_NO_TOPBLK
+    bool no_gather_hoist = false;   // CHIP_NO_GATHER_HOIST
+    bool no_xperm = false;          // CHIP_NO_XPERM
+    // ---- engine / launchers ----
+    bool no_fused_ir = false;       // CHIP_NO_FUSED_IR: one kernel per phase, refinement control on the host
+    bool no_symv_split = false;     // CHIP_NO_SYMV_SPLIT
+    bool no_factor_lds = false;     // CHIP_NO_FACTOR_LDS
+    bool no_factor_chain = false;   // CHIP_NO_FACTOR_CHAIN
+    bool no_snode_tri = false;      // CHIP_NO_SNODE_TRI
+    bool no_flat = false;           // CHIP_NO_FLAT: column-per-thread sweeps inside k_bundle_ir
+    bool no_ir1024 = false;         // CHIP_NO_IR1024
+    bool ir_test_drop = false;      // CHIP_IR_TEST_DROP (tests: a fused launch that cannot complete its barrier)
+    int ir_debug = 0;               // CHIP_IR_DEBUG: 1 = stamps of two workgroups on stderr, 2 = all workgroups -> file
+    std::string ir_debug_file;      // CHIP_IR_DEBUG_FILE
+    bool no_step_kernel = false;    // CHIP_NO_STEP_KERNEL: the grouped-fold step kernels of round 4 off
+    // ---- supernode kernels (snode.hip) ----
+    int sn_xb_cap = 0;              // CHIP_SN_XB_CAP (0: default)
+    int sn_debug = 0;               // CHIP_SN_DEBUG
+    bool no_splitk = false;         // CHIP_NO_SPLITK
+    int sn_split_target = 256, sn_split_max = 8, sn_split_unit = 1; // CHIP_SN_SPLIT_TARGET / _MAX / _UNIT
+    bool no_snode_panel = false;    // CHIP_NO_SNODE_PANEL: separate diag / rows launches
+    bool no_panel_mfma = false;     // CHIP_NO_PANEL_MFMA
+    bool no_panel_diag_mfma = false; // CHIP_NO_PANEL_DIAG_MFMA
+    bool deterministic = false;     // CHIP_DETERMINISTIC: fixed-order reductions wherever an fp64 atomic decides a sum
+};
+
+// the parsed switches (first call parses the environment)
+const Switches &switches();
+// read the environment again (called when a handle is created)
+void switches_reload();
+// set (value != nullptr) or clear one switch by its environment name and re-parse; false: unknown name
+bool switches_set(const char *name, const char *value);
+
+} // namespace chip

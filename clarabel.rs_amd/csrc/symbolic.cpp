@@ -31,11 +31,11 @@ static thread_local std::string g_err; // per thread, like errno: handles may li
 void set_error(const std::string &msg) { g_err = msg; }
 const char *get_error() { return g_err.c_str(); }
 
-int host_threads() { // (environment read on every call: a handful of calls per analysis)
+int host_threads() {
     int t = (int)std::thread::hardware_concurrency();
     if (t < 1) t = 1;
     if (t > 16) t = 16;
-    if (const char *e = std::getenv("CHIP_HOST_THREADS")) t = std::max(1, std::atoi(e));
+    if (switches().host_threads > 0) t = switches().host_threads;
     return t;
 }
 
@@ -80,8 +80,7 @@ constexpr i64 BUNDLE_MAX_WORK = 1000000;   // sum of (column length)^2 one workg
 // threads worth starting for a pass over `items` entries
 // (CHIP_HOST_PAR_MIN: the smallest pass that is split, 2e6 entries by default; tests set it to 0)
 inline int par_threads(i64 items) {
-    i64 min_items = 2000000;
-    if (const char *e = std::getenv("CHIP_HOST_PAR_MIN")) min_items = std::atoll(e);
+    const i64 min_items = switches().host_par_min;
     return items >= min_items ? host_threads() : 1;
 }
 
@@ -285,7 +284,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     for (i32 j = 0; j < n; j++) nnzL0 += cnt[j];
     // (the walk costs one more pass over nnz(L): skipped for factors beyond 1e8 entries -- dense fronts, whose
     // depth is a matter of the supernode kernels, not of single columns)
-    if (perm0.empty() && n > 0 && nnzL0 <= 100000000 && std::getenv("CHIP_NO_CHAIN_REORDER") == nullptr) {
+    if (perm0.empty() && n > 0 && nnzL0 <= 100000000 && !switches().no_chain_reorder) {
         std::vector<i32> chain((size_t)n), nlev((size_t)n, 0), rel((size_t)n, 0), stamp((size_t)n, -1);
         std::vector<i32> cfirst((size_t)n, -1), cnext((size_t)n, -1); // members of a chain, linked in old order
         i32 nchains = 0;
@@ -388,9 +387,9 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             sub_ent[parent[j]] += sub_ent[j];
             sub_work[parent[j]] += sub_work[j];
         }
-    const bool no_bundles = std::getenv("CHIP_NO_BUNDLES") != nullptr;
+    const bool no_bundles = switches().no_bundles;
     i64 max_work = BUNDLE_MAX_WORK; // (CHIP_BUNDLE_MAX_WORK: tuning / tests)
-    if (const char *e = std::getenv("CHIP_BUNDLE_MAX_WORK")) max_work = std::max<i64>(1, std::atoll(e));
+    if (switches().bundle_max_work > 0) max_work = switches().bundle_max_work;
     std::vector<char> top((size_t)n, 0);
     i64 NF = 0, maxsub = 0;
     auto cut_at = [&](i64 cap_nodes, std::vector<char> &tp) {
@@ -451,12 +450,12 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         };
         i32 ng = 0, gmax = 0;
         groups_of(top, ng, gmax);
-        const bool refine_ok = target_wg > 0 && !no_bundles && perm0.empty() && std::getenv("CHIP_NO_GROUPFOLD") == nullptr;
+        const bool refine_ok = target_wg > 0 && !no_bundles && perm0.empty() && !switches().no_groupfold;
         // (measured on an MI355X, config 4's shares: 128 trees -> 8 bundles per tree 0.48 ms against 0.53 ms per step
         // as whole trees; 256 trees -> 4 per tree 0.66 against 0.61; 512 -> 2 per tree 1.25 against 0.98: the finer cut
         // pays once a tree can be cut into about eight bundles -- CHIP_GROUPFOLD_MIN overrides the factor)
         i64 min_factor = 8;
-        if (const char *e = std::getenv("CHIP_GROUPFOLD_MIN")) min_factor = std::max<i64>(1, std::atoll(e));
+        if (switches().groupfold_min > 0) min_factor = switches().groupfold_min;
         if (refine_ok && gmax <= TOPFOLD_MAX && estimate_bundles(top, NF) * min_factor <= (i64)target_wg) {
             i64 cap_nodes = BUNDLE_MAX_NODES;
             std::vector<char> cand;
@@ -603,7 +602,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // permutation becomes a handful of long ascending runs per bundle (config 3: the x block, the
     // Nonnegative rows and the second-order-cone rows of a block) -- the fused solve kernel then stages
     // its right-hand side and writes its result with coalesced copies instead of per-element gathers
-    for (i32 g = 0; g < nb && std::getenv("CHIP_NO_LEVEL_SORT") == nullptr; g++) {
+    for (i32 g = 0; g < nb && !switches().no_level_sort; g++) {
         i32 t = gptr[g];
         const i32 tend = gptr[g + 1];
         while (t < tend) {
@@ -681,7 +680,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     std::vector<char> sn_skip((size_t)n, 0); // member that is not the last column of its supernode
     S.sn_of.assign((size_t)n, -1);
     S.sn_ptr.assign(1, 0);
-    if (std::getenv("CHIP_NO_SNODE") == nullptr && S.NF < n) {
+    if (!switches().no_snode && S.NF < n) {
         const i32 NFi = S.NF;
         std::vector<i32> best((size_t)n, -1);
         for (i32 j = NFi; j < n; j++) {
@@ -1014,7 +1013,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     {
         const i32 ntop = (i32)n - S.NF;
         const i32 nbun = S.bundle_ptr.empty() ? 0 : (i32)S.bundle_ptr.size() - 1;
-        if (ntop >= 1 && ntop <= TOPFOLD_MAX && nbun > 0 && std::getenv("CHIP_NO_TOPFOLD") == nullptr) {
+        if (ntop >= 1 && ntop <= TOPFOLD_MAX && nbun > 0 && !switches().no_topfold) {
             const i32 k = ntop;
             S.nfold = k;
             S.fold_rseg.assign((size_t)nbun * k * 2, 0);
@@ -1044,7 +1043,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     }
     // ---- grouped fold (host.hpp): per tree with a non-empty top ------------------------------
     std::vector<i32> gpos; // index of a top node inside its group (by node - NF), grouped fold only
-    if (grouped && S.nfold == 0 && ngroups >= 2 && std::getenv("CHIP_NO_TOPFOLD") == nullptr) {
+    if (grouped && S.nfold == 0 && ngroups >= 2 && !switches().no_topfold) {
         const i32 nbun = (i32)S.bundle_ptr.size() - 1;
         bool ok = nbun > 0;
         for (i32 g = 0; g < ngroups && ok; g++) ok = grp_first_bundle[g + 1] > grp_first_bundle[g];
@@ -1156,7 +1155,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         }
     }
     // ---- update records of the entry-parallel bundle factorisation (host.hpp: fu_rec) ----------------
-    if (!S.Li16.empty() && std::getenv("CHIP_NO_FACTOR_FLAT") == nullptr) {
+    if (!S.Li16.empty() && !switches().no_factor_flat) {
         const i32 nbun = (i32)S.bundle_ptr.size() - 1;
         bool ok = true;
         for (i32 b = 0; b < nbun && ok; b++) {
@@ -1235,7 +1234,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // ---- blocked substitution for tall tops -----------------------------------
     {
         const i32 ntop = (i32)n - S.NF;
-        const bool off = std::getenv("CHIP_NO_TOPBLK") != nullptr;
+        const bool off = switches().no_topblk;
         // worthwhile only for chain-like tops: a block step costs ~3x a level step, so the number of
         // blocks must be well below the number of levels (config 2: 272 blocks for 4383 levels;
         // config 5's wide levels -- 200 rows each -- stay level scheduled)
@@ -1378,7 +1377,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         // sweep become a handful.  (CHIP_NO_GATHER_HOIST keeps every row at its own level.)
         std::vector<std::vector<i32>> hoisted((size_t)nfl);
         if (nsn > 0) {
-            const bool no_hoist = std::getenv("CHIP_NO_GATHER_HOIST") != nullptr;
+            const bool no_hoist = switches().no_gather_hoist;
             for (i32 sn = 0; sn < nsn; sn++)
                 for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) {
                     const i32 j = S.sn_col[t];
@@ -1457,7 +1456,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // every lane its own 64-byte sector, the residual over the top rows ran at 1.8 TB/s, bound by L2 sectors,
     // not HBM).  The residual therefore reads a copy of x in which every supernode's members are consecutive
     // (one N-element gather per residual) and Scol is renumbered to match.
-    if (S.sn_ptr.size() > 1 && S.nfold == 0 && std::getenv("CHIP_NO_XPERM") == nullptr) {
+    if (S.sn_ptr.size() > 1 && S.nfold == 0 && !switches().no_xperm) {
         const i32 NFi = S.NF;
         S.xperm.resize((size_t)n);
         std::vector<i32> xinv((size_t)n);

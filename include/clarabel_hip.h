@@ -353,10 +353,8 @@ int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]);
  * repeat happens in chip_kkt_collect, for the timed-out solve and every solve enqueued behind it, from the right-hand
  * side buffers as they are THEN: the buffers of pending solves must stay untouched until collect. */
 int32_t chip_kkt_fused_fallbacks(const chip_kkt *h);
-/* diagnostics / tests: launches a kernel of `blocks` x `threads` (+ lds_bytes of LDS per workgroup) that only spins
- * for `usec` microseconds, on a private stream of `device` -- the persistent launches (k_bundle_ir) must survive a
- * co-resident kernel (the RCCL ring of the sharded path).  blocks = 0: waits for the spinners launched so far. */
-int32_t chip_debug_spin(int32_t device, int32_t blocks, int32_t threads, int32_t lds_bytes, double usec);
+/* (test hooks -- chip_debug_spin, chip_debug_set_switch -- are declared in clarabel_hip_testing.h and exist only in
+ * libraries built with -DCHIP_TESTING, the in-tree default: `make TESTING=0` builds without them) */
 
 /* ===========================================================================
  * L3 -- the caller either side of the KKT solve, device resident:

@@ -1,0 +1,22 @@
+/* clarabel_hip_testing.h -- test hooks of libclarabel_hip.so.  NOT part of the drop-in boundary (clarabel_hip.h):
+ * these entry points exist only in libraries built with -DCHIP_TESTING (the in-tree default of csrc/Makefile, which
+ * the test-suite needs; `make TESTING=0` leaves them out). */
+#ifndef CLARABEL_HIP_TESTING_H
+#define CLARABEL_HIP_TESTING_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* launches a kernel of `blocks` x `threads` (+ lds_bytes of LDS per workgroup) that only spins for `usec`
+ * microseconds, on a private stream of `device` -- the persistent launches (k_bundle_ir, k_gstep_*) must survive a
+ * co-resident kernel (the RCCL ring of the sharded path).  blocks = 0: waits for the spinners launched so far.
+ * The calling thread's current device is left as it was. */
+int32_t chip_debug_spin(int32_t device, int32_t blocks, int32_t threads, int32_t lds_bytes, double usec);
+/* sets (value != NULL) or clears one CHIP_* diagnostic switch by its environment name and re-parses the switch
+ * table (csrc/switches.hpp) -- for flipping a switch on handles that already exist; switches given in the
+ * environment are picked up whenever a handle is created.  Returns CHIP_ERR_ARG for an unknown name. */
+int32_t chip_debug_set_switch(const char *name, const char *value_or_null);
+#ifdef __cplusplus
+}
+#endif
+#endif

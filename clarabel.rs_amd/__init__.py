@@ -537,6 +537,10 @@ class HipKKTSolver:
     def fused_fallbacks(self):
         return int(lib().chip_kkt_fused_fallbacks(self._h))
 
+    def step_kernels(self):
+        """bit 0: the fused solve is k_gstep_solve, bit 1: the bundle factorisation is k_gstep_factor (grouped fold)"""
+        return int(lib().chip_kkt_step_kernels(self._h))
+
 
 class CVars(C.Structure):
     """chip_vars: DefaultVariables (default/variables.rs:12-36) with device pointers"""

@@ -272,7 +272,7 @@ void eps_from_slots(hipStream_t s, unsigned long long *slots, double c, double p
 
 void debug_spin(hipStream_t s, int blocks, int threads, int lds_bytes, double usec) {
     if (lds_bytes > 65536)
-        (void)hipFuncSetAttribute((const void *)k_debug_spin, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)raise_dynamic_lds((const void *)k_debug_spin, (size_t)lds_bytes);
     k_debug_spin<<<blocks, threads, (size_t)lds_bytes, s>>>((long long)(usec * 100.0)); // 100 MHz clock
 }
 void permute_in(hipStream_t s, double *y, const double *b, const int *perm, int N) {

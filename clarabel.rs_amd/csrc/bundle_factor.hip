@@ -978,19 +978,20 @@ bool bundle_factor_lds_ok(int lds_doubles) {
         return false;
     }
     if (fa.sharedSizeBytes + lds > 80 * 1024 - 512) return false; // two workgroups per CU
-    if (hipFuncSetAttribute((const void *)k_bundle_factor_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_bundle_factor_flat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (raise_dynamic_lds((const void *)k_bundle_factor_lds, (size_t)lds) != hipSuccess ||
+        raise_dynamic_lds((const void *)k_bundle_factor_flat, (size_t)lds) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     return true;
 }
-void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles) {
-    if (!bv.nb) return;
+int bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles) {
+    if (!bv.nb) return 0;
     const bool no_flat = switches().no_factor_flat;
     if (lds_doubles > 0 && v.fu_rec && !no_flat) k_bundle_factor_flat<<<bv.nb, FFWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold);
     else if (lds_doubles > 0) k_bundle_factor_lds<<<bv.nb, FLWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold, lds_doubles);
     else k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
+    return (int)hipGetLastError(); // (a rejected launch would leave the factor stale)
 }
 void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf) {
     if (gf.ng <= 0) return;

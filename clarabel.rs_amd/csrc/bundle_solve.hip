@@ -671,15 +671,15 @@ void gather_merged(hipStream_t s, GatherMode m, const GatherArgs &a, ListView t,
 void topblk_build(hipStream_t s, const LdlView &v, const TopBlkView &tb) {
     if (!tb.nblocks) return;
     const size_t lds = (size_t)2 * TOPBLK_PACK * sizeof(double);
-    (void)hipFuncSetAttribute((const void *)k_topblk_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)raise_dynamic_lds((const void *)k_topblk_build, (size_t)lds);
     k_topblk_build<<<tb.nblocks, WG, lds, s>>>(v, tb);
 }
 // kernels of the solve sequence that need more than 64 KB of dynamic LDS: allowed once per process,
 // outside any stream capture
 void solve_kernel_attributes() {
     const size_t lds = (size_t)(TOPBLK_PACK + TOPBLK) * sizeof(double);
-    (void)hipFuncSetAttribute((const void *)k_topblk_step<FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void *)k_topblk_step<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)raise_dynamic_lds((const void *)k_topblk_step<FWD>, (size_t)lds);
+    (void)raise_dynamic_lds((const void *)k_topblk_step<BWD>, (size_t)lds);
 }
 void topblk_solve(hipStream_t s, GatherMode m, const LdlView &v, const TopBlkView &tb, double *x) {
     if (!tb.nblocks) return;

@@ -200,7 +200,9 @@ int32_t chip_ldl_create(chip_ldl **out, int64_t n, const uint64_t *colptr, const
     std::vector<i64> perm0;
     if (perm_or_null) perm0.assign(as_i64(perm_or_null), as_i64(perm_or_null) + n);
     Symbolic S;
-    int rc = analyse(n, as_i64(colptr), as_i64(rowval), dsigns, perm0, st.amd_dense_scale, S, target_workgroups(st));
+    // (target_wg = 0: L1 handles never take the fused launches, so a forest is not cut finer for them -- the grouped
+    // fold's extra top nodes would only add level-scheduled launches to every solve)
+    int rc = analyse(n, as_i64(colptr), as_i64(rowval), dsigns, perm0, st.amd_dense_scale, S, 0);
     if (rc) return rc;
     std::unique_ptr<chip_ldl> h(new chip_ldl());
     h->hK.assign(nzval, nzval + S.nnzK);
@@ -1006,9 +1008,16 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     h->rhs_deferred = false;
     h->x_holds_b = false;
     E.prof_begin(PF_IR);
-    const int rc = dev::bundle_ir(E.stream, E.view(), E.bundles, E.fold, ir, E.ir_grid, E.ir_tw, E.gfold);
+    int rc;
+    if (E.gstep_solve_on && !switches().no_step_kernel && ir.maxiter <= 30) {
+        // grouped fold with small bundles: the register-resident form of the same launch (bundle_gstep.hip)
+        E.gstep.epoch += 1;
+        rc = dev::gstep_solve(E.stream, E.view(), E.bundles, ir, E.gfold, E.gstep);
+    } else {
+        rc = dev::bundle_ir(E.stream, E.view(), E.bundles, E.fold, ir, E.ir_grid, E.ir_tw, E.gfold);
+    }
     E.prof_end(PF_IR);
-    if (rc) return fail(CHIP_ERR_HIP, hip_err((hipError_t)rc, "k_bundle_ir launch"));
+    if (rc) return fail(CHIP_ERR_HIP, hip_err((hipError_t)rc, "fused solve launch"));
     if (dbg_all_on) {
         (void)hipStreamSynchronize(E.stream);
         std::vector<long long> t((size_t)E.ir_grid * 32);
@@ -1501,6 +1510,11 @@ int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]) {
     out[1] = h->E.prof_ms_total;
     out[2] = (double)h->E.prof_family;
     return CHIP_OK;
+}
+int32_t chip_kkt_step_kernels(const chip_kkt *h) {
+    if (!h) return CHIP_ERR_ARG;
+    const bool on = !switches().no_step_kernel;
+    return (on && h->E.gstep_solve_on ? 1 : 0) | (on && h->E.gstep_factor_on ? 2 : 0);
 }
 int32_t chip_kkt_fused_fallbacks(const chip_kkt *h) { return h ? h->fused_fallbacks : CHIP_ERR_ARG; }
 int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]) {

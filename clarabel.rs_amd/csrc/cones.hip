@@ -1776,7 +1776,7 @@ void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const
         return;
     }
     const size_t lds = ((size_t)(4 * v.maxdim * v.maxdim + 3 * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_psd_update_scaling<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) (void)raise_dynamic_lds((const void *)k_psd_update_scaling<false>, (size_t)lds);
     k_psd_update_scaling<false><<<v.ncones, WG, lds, s>>>(v, sv, zv);
 }
 void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx) {
@@ -1794,7 +1794,7 @@ static size_t psd_ops_lds(const PsdView &v) {
     return ((size_t)(3 * v.maxdim * v.maxdim + 4 * v.maxdim + 8) * sizeof(double) + 15) & ~(size_t)15;
 }
 template <typename K> static void psd_allow_lds(K kernel, size_t lds) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) (void)raise_dynamic_lds((const void *)kernel, (size_t)lds);
 }
 #define PSD_LAUNCH(OP, ...)                                                          \
     do {                                                                             \

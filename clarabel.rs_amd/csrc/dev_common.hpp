@@ -39,6 +39,9 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstdlib>
 
 namespace chip {
@@ -61,6 +64,22 @@ inline int grid_for(int count) {
 inline int stream_grid(int N) {
     int nb = grid_for(N);
     return nb > 2048 ? 2048 : nb;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a handle: it is only ever RAISED
+// (a later handle with smaller bundles must not lower the limit under an earlier handle's launches)
+inline hipError_t raise_dynamic_lds(const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> cur;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &c = cur[{dev, fn}];
+    if (bytes <= c) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) c = bytes;
+    else (void)hipGetLastError();
+    return e;
 }
 
 __device__ __forceinline__ double wave_sum_all(double v);

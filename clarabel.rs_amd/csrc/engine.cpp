@@ -432,6 +432,106 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 gfold.fac = fac;
                 gfold.gcnt = ir_ctl + dev::ir_ctl_ints();
             }
+            if (grouped && !switches().no_step_kernel) {
+                // the step kernels (bundle_gstep.hip): the bundles' entries of L and K in "gs order" (kernels.hpp:
+                // GStepView), kept in registers by the kernels; taken when every bundle fits the register slots compiled
+                const int nbn = bundles.nb;
+                i64 mxE = 0, mxU = 0, mxN = 0, mxL = 0;
+                for (int b = 0; b < nbn; b++) {
+                    const int s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
+                    mxE = std::max<i64>(mxE, S.Lp[s1] - S.Lp[s0]);
+                    mxU = std::max<i64>(mxU, S.Up[s1] - S.Up[s0]);
+                    mxN = std::max<i64>(mxN, s1 - s0);
+                    mxL = std::max<i64>(mxL, S.blvl_ptr[b + 1] - S.blvl_ptr[b] - 1);
+                }
+                dev::GStepView g{};
+                g.lr = (int)((mxE + 255) / 256);
+                g.ur = (int)((mxU + 255) / 256);
+                g.nr = (int)((mxN + 255) / 256);
+                if (mxL <= dev::GS_MAXL && mxE < 65535 && mxU < 65535 && g.lr <= 8 && g.ur <= 10 && g.nr <= 4) {
+                    const i32 NFn = S.NF;
+                    std::vector<i32> lptr((size_t)nbn * dev::GS_LST, 0), untop((size_t)nbn, 0);
+                    std::vector<uint16_t> lsrc((size_t)S.Lp[NFn]), usrc((size_t)S.Up[NFn]);
+                    std::vector<uint32_t> lij((size_t)S.Lp[NFn]), uij((size_t)S.Up[NFn]);
+                    std::vector<std::pair<uint32_t, i32>> tops; // (top index << 16 | column or row, source)
+                    for (int b = 0; b < nbn; b++) {
+                        const int s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1], nloc = s1 - s0;
+                        const i32 e0 = S.Lp[s0], ub = S.Up[s0];
+                        const i32 *lv = S.blvl.data() + S.blvl_ptr[b];
+                        const int nl = S.blvl_ptr[b + 1] - S.blvl_ptr[b] - 1;
+                        i32 p = 0;
+                        tops.clear();
+                        for (int l = 0; l < nl; l++) {
+                            lptr[(size_t)b * dev::GS_LST + l] = p;
+                            for (i32 j = lv[l]; j < lv[l + 1]; j++)
+                                for (i32 q = S.Lp[j]; q < S.Lp[j + 1]; q++) {
+                                    const uint32_t r16 = S.Li16[(size_t)q];
+                                    if ((int)r16 < nloc) {
+                                        lsrc[(size_t)e0 + p] = (uint16_t)(q - e0);
+                                        lij[(size_t)e0 + p] = (r16 << 16) | (uint32_t)(j - s0);
+                                        p++;
+                                    } else {
+                                        tops.push_back({((r16 - (uint32_t)nloc) << 16) | (uint32_t)(j - s0), q});
+                                    }
+                                }
+                        }
+                        lptr[(size_t)b * dev::GS_LST + nl] = p;
+                        std::sort(tops.begin(), tops.end());
+                        for (const auto &t : tops) {
+                            lsrc[(size_t)e0 + p] = (uint16_t)(t.second - e0);
+                            lij[(size_t)e0 + p] = (((t.first >> 16) + (uint32_t)nloc) << 16) | (t.first & 0xFFFFu);
+                            p++;
+                        }
+                        lptr[(size_t)b * dev::GS_LST + nl + 1] = p; // == S.Lp[s1] - e0
+                        // the U rows: entries outside the top columns in their stored order, then the top columns'
+                        i32 pu = 0;
+                        tops.clear();
+                        for (i32 u = ub; u < S.Up[s1]; u++) {
+                            const uint32_t r16 = S.Urow16[(size_t)u], c16 = S.Ucol16[(size_t)u];
+                            if ((int)c16 < nloc) {
+                                usrc[(size_t)ub + pu] = (uint16_t)(u - ub);
+                                uij[(size_t)ub + pu] = (r16 << 16) | c16;
+                                pu++;
+                            } else {
+                                tops.push_back({((c16 - (uint32_t)nloc) << 16) | r16, u});
+                            }
+                        }
+                        untop[(size_t)b] = pu;
+                        std::sort(tops.begin(), tops.end());
+                        for (const auto &t : tops) {
+                            usrc[(size_t)ub + pu] = (uint16_t)(t.second - ub);
+                            uij[(size_t)ub + pu] = ((t.first & 0xFFFFu) << 16) | ((t.first >> 16) + (uint32_t)nloc);
+                            pu++;
+                        }
+                    }
+                    int *d_lptr = nullptr, *d_untop = nullptr, *d_msg = nullptr, *d_fmsg = nullptr;
+                    unsigned short *d_lsrc = nullptr, *d_usrc = nullptr;
+                    unsigned int *d_lij = nullptr, *d_uij = nullptr;
+                    if ((rc = upload(&d_lptr, lptr, lptr.size()))) return rc;
+                    if ((rc = upload(&d_untop, untop, untop.size()))) return rc;
+                    if ((rc = upload(&d_lsrc, lsrc, lsrc.size()))) return rc;
+                    if ((rc = upload(&d_usrc, usrc, usrc.size()))) return rc;
+                    if ((rc = upload(&d_lij, lij, lij.size()))) return rc;
+                    if ((rc = upload(&d_uij, uij, uij.size()))) return rc;
+                    const size_t nmsg = (size_t)nbn * 4 * 8 * 4, nfmsg = (size_t)nbn * 36 * 4;
+                    if ((rc = alloc(&d_msg, nmsg))) return rc;
+                    if ((rc = alloc(&d_fmsg, nfmsg))) return rc;
+                    CHIP_HIP(hipMemset(d_msg, 0, nmsg * sizeof(int)));
+                    CHIP_HIP(hipMemset(d_fmsg, 0, nfmsg * sizeof(int)));
+                    g.lptr = d_lptr;
+                    g.untop = d_untop;
+                    g.lsrc = d_lsrc;
+                    g.usrc = d_usrc;
+                    g.lij = d_lij;
+                    g.uij = d_uij;
+                    g.msg = d_msg;
+                    g.fmsg = d_fmsg;
+                    g.epoch = 0;
+                    gstep = g;
+                    gstep_solve_on = dev::gstep_solve_capacity(bundles, gstep) >= bundles.nb;
+                    gstep_factor_on = factor_lds_doubles > 0 && fu_rec != nullptr && dev::gstep_factor_ok(factor_lds_doubles);
+                }
+            }
         }
     }
     if ((rc = alloc(&mb_dev, 1))) return rc;
@@ -568,13 +668,28 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     // columns take their initial values straight from the U rows inside k_bundle_factor.
     dev::scatter_init(stream, Kx + nnzU, v2l, (int)(nnzK - nnzU), (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                       mb_dev->status);
-    prof_begin(PF_BFACTOR);
-    dev::bundle_factor(stream, v, bundles, fold, factor_lds_doubles); // everything below the cut: one launch
-    prof_end(PF_BFACTOR);
-    // single top column: pivot accumulated by the bundles; grouped fold: the k x k tops from the bundles' Schur shares
     const bool top_folded = fold.k == 1 || gfold.ng > 0;
-    if (fold.k == 1) dev::fold_top_pivot(stream, v, fold);
-    if (gfold.ng > 0) dev::gfold_top_factor(stream, v, bundles, gfold);
+    prof_begin(PF_BFACTOR);
+    if (gstep_factor_on && !switches().no_step_kernel) {
+        // grouped fold with small bundles: bundle columns, Schur shares and the groups' k x k tops in ONE launch
+        gstep.epoch += 1;
+        const int lrc = dev::gstep_factor(stream, v, bundles, gfold, gstep, factor_lds_doubles);
+        prof_end(PF_BFACTOR);
+        if (lrc) {
+            set_error(hip_err((hipError_t)lrc, "k_gstep_factor launch"));
+            return CHIP_ERR_HIP;
+        }
+    } else {
+        const int lrc = dev::bundle_factor(stream, v, bundles, fold, factor_lds_doubles); // everything below the cut: one launch
+        prof_end(PF_BFACTOR);
+        if (lrc) {
+            set_error(hip_err((hipError_t)lrc, "bundle factorisation launch"));
+            return CHIP_ERR_HIP;
+        }
+        // single top column: pivot accumulated by the bundles; grouped fold: the k x k tops from the bundles' Schur shares
+        if (fold.k == 1) dev::fold_top_pivot(stream, v, fold);
+        if (gfold.ng > 0) dev::gfold_top_factor(stream, v, bundles, gfold);
+    }
     const bool use_chain = !switches().no_factor_chain;
     // units (single columns, chain supernodes) by unit level; a level's supernodes run after its
     // single columns: first the contributions of outside columns into their members (the chunked

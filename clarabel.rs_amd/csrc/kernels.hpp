@@ -120,7 +120,8 @@ void scatter_values(hipStream_t s, double *Kx, const int *map, const double *val
 // then applies the pivot rule to it (the top needs no factor launches of its own)
 // lds_doubles > 0: k_bundle_factor_lds, the bundle's L and D values resident in LDS (lds_doubles = the largest
 // bundle's entries + nodes; bundle_factor_lds_ok says whether the handle qualifies)
-void bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles = 0);
+// returns hipSuccess (0) or the launch error
+int bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles = 0);
 bool bundle_factor_lds_ok(int lds_doubles);
 void fold_top_pivot(hipStream_t s, const LdlView &v, const FoldView &fold);
 // fold.k > 0: every bundle also subtracts its part of the k top rows of L from x[NF + i]
@@ -172,6 +173,37 @@ int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldV
 // grouped fold, after bundle_factor: every bundle's contribution to the Schur complement of its group's top
 // (k_gfold_schur -> gf.fac), then the k x k LDL' of every group's top (k_gfold_top_factor)
 void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf);
+
+// ---- grouped fold, small bundles: the "step" kernels (bundle_gstep.hip) ------------------------------------
+// The entries of a bundle's columns of L and of its U rows in the order the kernels keep them in registers ("gs order"):
+// L: the entries inside the bundle level by level (level of the column), then the entries in the group's top rows
+// sorted by (top row, column); U: the entries that are not in top columns in their stored order, then those in top
+// columns sorted by (top column, row).  All arrays are parallel to the bundle columns of L / the bundles' U rows.
+constexpr int GS_MAXL = 14;          // elimination levels inside a bundle the step kernels handle
+constexpr int GS_LST = GS_MAXL + 2;  // ints per bundle in GStepView::lptr
+struct GStepView {
+    int lr, ur, nr;               // register slots a thread needs: ceil(max L entries / 256), ceil(max U entries / 256),
+                                  // ceil(max nodes / 256)
+    const int *lptr;              // [nb * GS_LST] per bundle: gs positions where levels 0 .. nl begin, then the end of
+                                  // the top-row entries (= the bundle's entry count)
+    const unsigned short *lsrc;   // gs position -> CSC slot of the value, relative to the bundle's first slot
+    const unsigned int *lij;      // gs position -> (row16 << 16) | column16, bundle-local; row >= nloc: top row nloc + t
+    const int *untop;             // [nb]: gs position of the first U entry in a top column
+    const unsigned short *usrc;   // gs position -> position inside the bundle's U range the value comes from
+    const unsigned int *uij;      // gs position -> (row16 << 16) | column16; column >= nloc: top column nloc + t
+    int *msg;                     // k_gstep_solve: [nb][4 phase slots][8] messages of 16 bytes (value, tag)
+    int *fmsg;                    // k_gstep_factor: [nb][36] messages (a bundle's Schur share, packed lower triangle)
+    int epoch;                    // tags of this launch's messages (the host counts launches)
+};
+// largest co-resident grid of k_gstep_solve for these bundles (0: cannot run)
+int gstep_solve_capacity(const BundleView &bv, const GStepView &gs);
+// one launch = setrhs + LDL' solve + iterative refinement with its decisions + getlhs (as bundle_ir); grid = bv.nb
+int gstep_solve(hipStream_t s, const LdlView &v, const BundleView &bv, const IrView &ir, const GFoldView &gf,
+                const GStepView &gs);
+// bundle factorisation + Schur shares + the groups' k x k tops in one launch (lds_doubles as bundle_factor)
+bool gstep_factor_ok(int lds_doubles);
+int gstep_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf, const GStepView &gs,
+                 int lds_doubles);
 
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);

@@ -2,6 +2,7 @@
 // (one of the translation units behind kernels.hpp; the design rules and the reference citations are in
 // dev_common.hpp)
 #include "dev_common.hpp"
+#include "grid_sync.hpp"
 
 namespace chip {
 namespace dev {
@@ -1078,24 +1079,6 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
 // load, both device coherent (sc1, what the compiler emits for agent-scope atomics) -- a consumer that sees
 // this sweep's epoch has the value with it, in one round trip; value and flag as two stores needed the
 // producer to wait for the first to be acknowledged and the consumer to load twice (~2 of ~4.5 us per hop).
-typedef int msg_v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void msg_store(int *slot, double val, int tag) {
-    msg_v4i m;
-    // (val_lo, tag, val_hi, tag): each 8-byte half carries its own tag, so a store that the memory system
-    // splits at 8-byte granularity can never pair a fresh tag with a stale half of the value
-    m.x = __double2loint(val);
-    m.y = tag;
-    m.z = __double2hiint(val);
-    m.w = tag;
-    // (s_nop: a store of more than 8 bytes reads its data registers a few cycles after issue; the compiler pads
-    // that hazard for its own stores, not for inline assembly -- without it the next VALU write clobbered the tags)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" ::"v"(slot), "v"(m) : "memory");
-}
-__device__ __forceinline__ msg_v4i msg_load(const int *slot) {
-    msg_v4i m;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(m) : "v"(slot) : "memory");
-    return m;
-}
 constexpr int SN2_WG = 256;
 constexpr int SN2_WMAX = 4096; // widest supernode (symbolic.cpp: SN_MAX_W); its column bases are kept in LDS
 template <bool FWDMODE>
@@ -1262,11 +1245,11 @@ static size_t snode_solve_lds_bytes(int wmax, int nbcap) {
 static size_t snode_lds_bytes(int wmax) { return (size_t)(SN_KC * SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int); }
 int snode_kernel_attributes(int wmax, int nbmax) {
     const int lds = (int)snode_lds_bytes(wmax);
-    int rc = (int)hipFuncSetAttribute((const void *)k_snode_update, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_extend, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int rc = (int)raise_dynamic_lds((const void *)k_snode_update, (size_t)lds);
+    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_extend, (size_t)lds);
     const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
-    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-    if (!rc) rc = (int)hipFuncSetAttribute((const void *)k_snode_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_fwd, (size_t)lds2);
+    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_bwd, (size_t)lds2);
     return rc;
 }
 // wlvl / nblvl: maxima over the supernodes of this launch.  Levels with a large B part run it in

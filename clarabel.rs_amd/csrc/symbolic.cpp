@@ -1472,6 +1472,35 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         });
         clk("supernode-contiguous x view");
     }
+    if (switches().timing && S.bundle_ptr.size() > 1) { // the bundle geometry the kernels see
+        const i32 nb = (i32)S.bundle_ptr.size() - 1;
+        i64 mx_n = 0, mx_e = 0, mx_u = 0, mx_l = 0, sum_n = 0, sum_e = 0, sum_u = 0, mx_top = 0, mx_utop = 0;
+        for (i32 b = 0; b < nb; b++) {
+            const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
+            const i64 ne = S.Lp[s1] - S.Lp[s0], nu = S.Up.empty() ? 0 : S.Up[s1] - S.Up[s0];
+            i64 ntop = 0, nutop = 0;
+            if (!S.Li16.empty())
+                for (i64 q = S.Lp[s0]; q < S.Lp[s1]; q++) ntop += S.Li16[(size_t)q] >= s1 - s0;
+            if (!S.Ucol16.empty())
+                for (i64 q = S.Up[s0]; q < S.Up[s1]; q++) nutop += S.Ucol16[(size_t)q] >= s1 - s0;
+            mx_n = std::max<i64>(mx_n, s1 - s0), mx_e = std::max(mx_e, ne), mx_u = std::max(mx_u, nu);
+            mx_l = std::max<i64>(mx_l, S.blvl_ptr[b + 1] - S.blvl_ptr[b] - 1);
+            mx_top = std::max(mx_top, ntop), mx_utop = std::max(mx_utop, nutop);
+            sum_n += s1 - s0, sum_e += ne, sum_u += nu;
+        }
+        i64 mx_g = 0, mx_k = 0;
+        for (i32 g = 0; g < S.gf_ng; g++) {
+            mx_g = std::max<i64>(mx_g, S.gf_bptr[g + 1] - S.gf_bptr[g]);
+            mx_k = std::max<i64>(mx_k, S.gf_ptr[g + 1] - S.gf_ptr[g]);
+        }
+        std::fprintf(stderr,
+                     "[chip analyse] bundles %d: nodes max %lld mean %.0f, L entries max %lld mean %.0f (to top rows max %lld), "
+                     "U entries max %lld mean %.0f (to top columns max %lld), levels max %lld; NF %d of %lld; fold k %d; groups %d "
+                     "(bundles per group max %lld, top nodes max %lld)\n",
+                     nb, (long long)mx_n, (double)sum_n / nb, (long long)mx_e, (double)sum_e / nb, (long long)mx_top,
+                     (long long)mx_u, (double)sum_u / nb, (long long)mx_utop, (long long)mx_l, S.NF, (long long)n, S.nfold,
+                     S.gf_ng, (long long)mx_g, (long long)mx_k);
+    }
     return 0;
 }
 

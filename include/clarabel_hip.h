@@ -347,6 +347,10 @@ int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]);
  * nodes folded into its bundles' kernels; 0 = none), out[6] = subtree bundles, out[7] = threads per workgroup of the
  * fused solve launch (0 = the handle's solve is not the fused launch). */
 int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]);
+/* which of the grouped-fold step kernels (csrc/bundle_gstep.hip) this handle uses: bit 0 = the fused solve launch is
+ * k_gstep_solve (a bundle's entries of L and K in registers), bit 1 = the refactor's bundle part is k_gstep_factor
+ * (bundle columns + Schur shares + the groups' tops in one launch); 0 = neither (diagnostics) */
+int32_t chip_kkt_step_kernels(const chip_kkt *h);
 /* number of fused solve launches (k_bundle_ir) of this handle whose grid barrier timed out -- their workgroups were not
  * all resident because another long-running kernel held the slots -- and that were repeated on the
  * one-kernel-per-phase path (refinement decisions on the host, same results up to rounding).  For enqueued solves the

@@ -914,10 +914,18 @@ def test_grouped_fold_ragged_forest(hip, oracle, late, monkeypatch):
     pr = problems.blockdiag(parts)
     ks, ko = _check_update_and_solve(hip, oracle, pr, nrhs=3)
     assert ks.work_model()["fold_groups"] >= 10
+    assert ks.step_kernels() == 3  # (solve and factorisation of the grouped fold: the register-resident step kernels)
     st = hip.Settings.default(iterative_refinement_enable=0)
     _check_update_and_solve(hip, oracle, pr, nrhs=1, settings=st)
     st = hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0, iterative_refinement_abstol=0.0)
     _check_update_and_solve(hip, oracle, pr, nrhs=2, settings=st)
+    st = hip.Settings.default(iterative_refinement_max_iter=0)
+    _check_update_and_solve(hip, oracle, pr, nrhs=1, settings=st, tol=1e-5)
+    # the same through k_bundle_ir's grouped form + the three-launch factorisation (the step kernels switched off)
+    monkeypatch.setenv("CHIP_NO_STEP_KERNEL", "1")
+    ks1, _ = _check_update_and_solve(hip, oracle, pr, nrhs=2)
+    assert ks1.work_model()["fold_groups"] >= 10 and ks1.step_kernels() == 0
+    monkeypatch.delenv("CHIP_NO_STEP_KERNEL")
     monkeypatch.setenv("CHIP_NO_GROUPFOLD", "1")
     ks2, _ = _check_update_and_solve(hip, oracle, pr, nrhs=1)
     assert ks2.work_model()["fold_groups"] == 0

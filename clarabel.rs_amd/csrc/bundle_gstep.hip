@@ -28,7 +28,6 @@ namespace dev {
 namespace {
 
 constexpr int GS_TW = 256;
-constexpr int GS_MAXRUNS = 32;
 
 // per-workgroup state shared through LDS (written by thread 0 / wave 0, read after a barrier)
 struct GsState {
@@ -38,37 +37,61 @@ struct GsState {
     double fsum[8], rsum[8];         // the group's totals of the published shares
     double dxt[8], acct[8], candt[8], rtop[8];
     double tacc[8];                  // this bundle's shares (forward sweep / residual)
-    double mtop;                     // max |top rows of the residual| (the group's first workgroup)
+    double gnorm[2];                 // max over the group's bundles of ||e||inf / ||b||inf of their rows
+    double vn, vb;                   // the verdict's inputs: ||e||inf, ||b||inf over the whole system
     int lev[GS_MAXL + 2];
-    int runs[3 * GS_MAXRUNS];
+    int tnode[8], torig[8];          // node / original index of the group's top rows
     int timeout;
 };
 
-// Poll the messages of phase slot `slot` of the bundles [gb0, gb0 + gnb) until all carry `tag`; out[t], t < 8 = the sum
-// over the bundles of value t, in a fixed order (every workgroup of the group computes the same bits).  Wave 0 only.
-// Returns false on a timeout.
-__device__ __forceinline__ bool gs_poll_sum(const int *msg, int gb0, int gnb, int k, int slot, int tag, double *out) {
+// Poll the messages of the bundles [gb0, gb0 + gnb) until all carry their tag, one round trip per poll for everything:
+//   FWD:   the forward shares in phase slot slot_f (tag_f): out_f[t], t < 8 = their sum over the bundles;
+//   RES:   the residual shares and norms in phase slot slot_r (tag_r): out_r[t] = the sum of share t, out_max[0 / 1] = the
+//          NaN-propagating max of values 8 / 9 (a bundle's ||e||inf and ||b||inf);
+// sums in a fixed order (every workgroup of the group computes the same bits).  Wave 0 only; lane = (bundle q < 8,
+// value t < 8).  Returns false on a timeout.
+template <bool FWD, bool RES>
+__device__ __forceinline__ bool gs_poll_group(const int *msg, int gb0, int gnb, int k, int slot_f, int tag_f, int slot_r,
+                                              int tag_r, double *out_f, double *out_r, double *out_max) {
     const int lane = threadIdx.x & 63, q = lane >> 3, t = lane & 7;
-    double tot = 0.0;
+    double totf = 0.0, totr = 0.0, mx = 0.0;
     for (int base = 0; base < gnb; base += 8) {
-        const bool valid = base + q < gnb && t < k;
-        const int *addr = msg + ((size_t)((gb0 + base + (valid ? q : 0)) * 4 + slot) * 8 + t) * 4;
-        msg_v4i m;
+        const bool mate = base + q < gnb;
+        const bool vs = mate && t < k, vn = RES && mate && t < 2;
+        const int *recf = msg + (size_t)((gb0 + base + (mate ? q : 0)) * 4 + slot_f) * GS_MV * 4;
+        const int *recr = msg + (size_t)((gb0 + base + (mate ? q : 0)) * 4 + slot_r) * GS_MV * 4;
+        msg_v4i mf, mr, mn;
         long long spins = 0;
         for (;;) {
-            m = msg_load(addr);
-            const bool ready = !valid || (m.y == tag && m.w == tag);
+            if (FWD && RES) msg_load3(recf + t * 4, recr + t * 4, recr + (8 + (t & 1)) * 4, mf, mr, mn);
+            else if (RES) msg_load2(recr + t * 4, recr + (8 + (t & 1)) * 4, mr, mn);
+            else mf = msg_load(recf + t * 4);
+            bool ready = true;
+            if (FWD) ready = ready && (!vs || msg_ready(mf, tag_f));
+            if (RES) ready = ready && (!vs || msg_ready(mr, tag_r)) && (!vn || msg_ready(mn, tag_r));
             if (__all(ready)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1ll << 20)) return false; // (~2 s)
         }
-        double val = valid ? __hiloint2double(m.z, m.x) : 0.0;
-        val += __shfl_xor(val, 8, 64);
-        val += __shfl_xor(val, 16, 64);
-        val += __shfl_xor(val, 32, 64);
-        tot += val;
+        auto gsum = [&](double val) {
+            val += __shfl_xor(val, 8, 64);
+            val += __shfl_xor(val, 16, 64);
+            val += __shfl_xor(val, 32, 64);
+            return val;
+        };
+        if (FWD) totf += gsum(vs ? msg_value(mf) : 0.0);
+        if (RES) {
+            totr += gsum(vs ? msg_value(mr) : 0.0);
+            double nv = vn ? msg_value(mn) : 0.0;
+            nv = nanmax(nv, __shfl_xor(nv, 8, 64));
+            nv = nanmax(nv, __shfl_xor(nv, 16, 64));
+            nv = nanmax(nv, __shfl_xor(nv, 32, 64));
+            mx = nanmax(mx, nv);
+        }
     }
-    if (lane < 8) out[lane] = tot;
+    if (FWD && lane < 8) out_f[lane] = totf;
+    if (RES && lane < 8) out_r[lane] = totr;
+    if (RES && lane < 2) out_max[lane] = mx;
     return true;
 }
 
@@ -80,42 +103,55 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[16];
     __shared__ GsState st;
-    const int nb = bv.nb, G = gridDim.x, tid = threadIdx.x, b = blockIdx.x;
-    const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
+    const int G = gridDim.x, tid = threadIdx.x, b = blockIdx.x;
+    int dbgn = 0;
+    auto stamp = [&]() { // diagnostics (CHIP_IR_DEBUG=2): phase boundaries of every workgroup on the 100 MHz clock
+        if (ir.dbg_all && tid == 0 && dbgn < 31) {
+            if (dbgn == 0)
+                ir.dbg_all[(size_t)b * 32] = (long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) |
+                                             ((long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32);
+            ir.dbg_all[(size_t)b * 32 + 1 + dbgn++] = wall_clock64();
+        }
+    };
+    stamp();
+    // ---- stage A: the bundle's descriptor (one 128-byte line: no chain of dependent pointer loads) ----
+    const int *dsc = gs.desc + (size_t)b * GS_DESC;
+    const int s0 = dsc[0], nloc = dsc[1], e0 = dsc[2], nE = dsc[3], ub = dsc[4], nU = dsc[5], nl = dsc[6], grp = dsc[7];
+    const int k = dsc[9], gb0 = dsc[10], gnb = dsc[11], ntop0 = dsc[12], lead = dsc[14], nlead = dsc[15];
+    const bool gfirst = b == gb0; // the group's leader (a bundle without group is a group of one)
     const int nmax = bv.max_nodes;
-    double *xs = (double *)smem;         // work: right-hand side -> y -> dx, then the residual
+    double *xs = (double *)smem;             // work: right-hand side -> y -> dx, then the residual
     double *A0 = xs + nmax, *A1 = A0 + nmax; // accepted iterate / candidate (roles swap)
     double *bs = A1 + nmax, *dis = bs + nmax; // the right-hand side slice, 1 / d
-    const int grp = gf.bgrp[b];
-    const int gbase = grp >= 0 ? gf.ptr[grp] : 0;
-    const int k = grp >= 0 ? gf.ptr[grp + 1] - gbase : 0;
-    const int gb0 = grp >= 0 ? gf.bptr[grp] : 0, gnb = grp >= 0 ? gf.bptr[grp + 1] - gb0 : 0;
-    const bool gfirst = grp >= 0 && b == gb0;
-    const int e0 = v.Lp[s0], nE = v.Lp[s0 + nloc] - e0;
-    const int ub = v.Up[s0], nU = v.Up[s0 + nloc] - ub;
-    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    double *pnb = ir.part, *pn = pnb + nb, *pub = pn + 2 * nb; // partial norms / published reductions (as k_bundle_ir)
+    int *og = (int *)(dis + nmax);            // original index of every node (setrhs / getlhs)
     if (ir.test_drop && b == G - 1 && G > 1) return; // (tests: a launch that is not co-resident)
 
-    // ---- the bundle's entries of L and K into registers; 1 / d; the folded top's constants ----
+    // ---- stage B: every index the launch needs (one round trip, all loads independent) ----
+    // (every load is UNCONDITIONAL with a clamped index and its result masked afterwards: a predicated load compiles to
+    // a branch with a wait of its own, which would turn the round trip into a chain of them; the host pads the tables)
     unsigned lij[LR], uij[UR];
     double lv[LR], uv[UR];
+    double normb_mine = 0.0; // ||b||inf over this bundle's rows
     {
-        int lsrc[LR], usrc[UR];
+        // (issue order = order of first use: the right-hand side and the top's tables, then L; the entries of K are
+        // requested behind the first forward sweep -- their 28 KB per bundle would only delay everybody's L, and they are
+        // not needed before the first residual: the requests travel in the shadow of the group exchange)
+        int lsrc[LR], orig[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) orig[u] = ir.perm[s0 + min(tid + u * TW, nloc - 1)];
+        // the folded top's tables (per group, host made): lane t < 8: node / original index of top row t; lanes
+        // 64..127: CSC slot of L(top_i, top_j); lanes 128..191: position in V of K(top_i, top_c)
+        const int *gt = gs.gtop + (size_t)(grp < 0 ? 0 : grp) * GS_GTOP;
+        const bool topt = grp >= 0 && tid < k, toptt = grp >= 0 && tid >= 64 && tid < 192;
+        int tnode = gt[tid & 7], torig = gt[8 + (tid & 7)], tslot = gt[16 + ((tid - 64) & 127)];
+        const bool gsv = gs.gsl != nullptr; // the last refactor left L's and K's values in gs order: no gather
 #pragma unroll
         for (int u = 0; u < LR; ++u) {
-            const int p = tid + u * TW;
-            lsrc[u] = p < nE ? (int)gs.lsrc[e0 + p] : -1;
-            lij[u] = p < nE ? gs.lij[e0 + p] : 0xFFFFFFFFu;
+            const int p = min(tid + u * TW, max(nE - 1, 0));
+            lsrc[u] = gsv ? p : (int)gs.lsrc[e0 + p];
+            lij[u] = gs.lij[e0 + p];
         }
-#pragma unroll
-        for (int u = 0; u < UR; ++u) {
-            const int p = tid + u * TW;
-            usrc[u] = p < nU ? (int)gs.usrc[ub + p] : -1;
-            uij[u] = p < nU ? gs.uij[ub + p] : 0xFFFFFFFFu;
-        }
-        for (int i = tid; i < nloc; i += TW) dis[i] = v.Dinv[s0 + i];
-        if (tid <= nl + 1) st.lev[tid] = gs.lptr[(size_t)b * GS_LST + tid];
+        if (tid <= nl + 1) st.lev[tid] = dsc[16 + tid];
         if (tid == 0) {
             st.normb = st.norme = st.lastnorme = 0.0;
             st.rounds = 0;
@@ -130,89 +166,75 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
                 ir.res[2] = 0;
             }
         }
-        if (tid >= 64 && tid < 128) {
-            st.ltt[tid - 64] = 0.0;
-            st.ktt[tid - 64] = 0.0;
+        // ---- stage C: the values (second round trip), in the same order ----
+        tnode = topt ? tnode : -1;
+        torig = topt ? torig : -1;
+        tslot = toptt ? tslot : -1;
+        double breg[NR], dreg[NR];
+        auto rhs_ptr = [&](int o) { // (rows beyond n + m -- the sparse cones' extra rows -- read a valid address and are masked)
+            return o < ir.n ? ir.rx + o : ir.rz + (o < ir.n + ir.m ? o - ir.n : 0);
+        };
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            breg[u] = *rhs_ptr(orig[u]);
+            dreg[u] = v.Dinv[s0 + min(tid + u * TW, nloc - 1)];
+        }
+        const double tv0 = *rhs_ptr(max(torig, 0));
+        const double tv1 = v.Dinv[max(tnode, 0)];
+        const double tv2 = (tid < 128 ? v.Lx : v.Ux)[max(tslot, 0)];
+        const double *lvals = gsv ? gs.gsl : v.Lx;
+#pragma unroll
+        for (int u = 0; u < LR; ++u) lv[u] = lvals[e0 + lsrc[u]];
+        // ---- masks ----
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const bool in = tid + u * TW < nloc;
+            breg[u] = (in && orig[u] < ir.n + ir.m) ? breg[u] : 0.0;
+            if (in) og[tid + u * TW] = orig[u];
         }
 #pragma unroll
-        for (int u = 0; u < LR; ++u) lv[u] = lsrc[u] >= 0 ? v.Lx[e0 + lsrc[u]] : 0.0;
-#pragma unroll
-        for (int u = 0; u < UR; ++u) uv[u] = usrc[u] >= 0 ? v.Ux[ub + usrc[u]] : 0.0;
-    }
-    auto topnode = [&](int i) { return gf.node[gbase + i]; };
-    auto rhs_of = [&](int o) { return o < ir.n ? ir.rx[o] : (o < ir.n + ir.m ? ir.rz[o - ir.n] : 0.0); };
-    __syncthreads();
-    if (tid < 8) {
-        const double bt = tid < k ? rhs_of(ir.perm[topnode(tid)]) : 0.0;
-        st.btop[tid] = bt;
-        if (tid < k && gfirst) ir.bp[topnode(tid)] = bt; // (bp holds the whole permuted right-hand side afterwards)
-        st.dinvt[tid] = tid < k ? v.Dinv[topnode(tid)] : 0.0;
-        st.acct[tid] = st.candt[tid] = st.dxt[tid] = st.rtop[tid] = 0.0;
-    } else if (tid >= 64 && tid < 64 + k * k) {
-        const int ti = (tid - 64) / k, tj = (tid - 64) % k;
-        const int q = gf.tt[grp * 64 + ti * 8 + tj];
-        if (q >= 0) st.ltt[ti * 8 + tj] = v.Lx[q];
-    } else if (tid >= 128 && tid < 128 + k) {
-        const int i = tid - 128;
-        const int *sp = gf.sp + gbase;
-        for (int t = sp[i]; t < sp[i + 1]; ++t) st.ktt[i * 8 + gf.scol[t]] += v.Ux[gf.sslot[t]];
-    }
-    // ---- setrhs (directldlkktsolver.rs:160-166): the bundle's slice of the permuted right-hand side ----
-    {
-        const int nruns = ir.runs ? ir.run_ptr[b + 1] - ir.run_ptr[b] : 0;
-        double mx = 0.0, breg[NR];
+        for (int u = 0; u < LR; ++u) {
+            const bool in = tid + u * TW < nE;
+            lij[u] = in ? lij[u] : 0xFFFFFFFFu;
+            lv[u] = in ? lv[u] : 0.0;
+        }
+        double tval = 0.0, tdinv = 0.0;
+        if (tid < 8) {
+            tval = (torig >= 0 && torig < ir.n + ir.m) ? tv0 : 0.0;
+            tdinv = tnode >= 0 ? tv1 : 0.0;
+        } else if (tid >= 64 && tid < 192) {
+            tval = tslot >= 0 ? tv2 : 0.0;
+        }
+        // ---- setrhs (directldlkktsolver.rs:160-166): the slices into LDS, ||b||inf of the bundle's rows ----
+        double mx = 0.0;
         bool nan = false;
-        if (nruns > 0 && nruns <= GS_MAXRUNS) {
-            for (int q = tid; q < 3 * nruns; q += TW) st.runs[q] = ir.runs[3 * ir.run_ptr[b] + q];
-            __syncthreads();
-            int r = 0;
-#pragma unroll
-            for (int u = 0; u < NR; ++u) {
-                const int i = tid + u * TW;
-                double val = 0.0;
-                if (i < nloc) {
-                    while (i >= st.runs[3 * r] + st.runs[3 * r + 2]) ++r; // (runs ascend in the local index)
-                    val = rhs_of(st.runs[3 * r + 1] + (i - st.runs[3 * r]));
-                }
-                breg[u] = val;
-            }
-        } else {
-            int o[NR];
-#pragma unroll
-            for (int u = 0; u < NR; ++u) o[u] = tid + u * TW < nloc ? ir.perm[s0 + tid + u * TW] : -1;
-#pragma unroll
-            for (int u = 0; u < NR; ++u) breg[u] = o[u] >= 0 ? rhs_of(o[u]) : 0.0;
-        }
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             const int i = tid + u * TW;
             if (i < nloc) {
                 xs[i] = breg[u];
                 bs[i] = breg[u];
+                dis[i] = dreg[u];
                 ir.bp[s0 + i] = breg[u];
                 if (breg[u] != breg[u]) nan = true;
                 else mx = fmax(mx, fabs(breg[u]));
             }
         }
-        mx = block_max(mx, red);
-        const bool anynan = __syncthreads_or(nan);
-        if (tid == 0) {
-            double part = anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx;
-            if (gfirst)
-                for (int i = 0; i < k; ++i) part = nanmax(part, fabs(st.btop[i]));
-            ir_store(&pnb[b], part);
+        if (tid < 8) {
+            st.btop[tid] = tval;
+            if (tnode >= 0 && gfirst) ir.bp[tnode] = tval; // (bp holds the whole permuted right-hand side afterwards)
+            st.dinvt[tid] = tdinv;
+            st.acct[tid] = st.candt[tid] = st.dxt[tid] = st.rtop[tid] = 0.0;
+            st.tnode[tid] = tnode;
+            st.torig[tid] = torig;
+        } else if (tid >= 64 && tid < 128) {
+            st.ltt[tid - 64] = tval;
+        } else if (tid >= 128 && tid < 192) {
+            st.ktt[tid - 128] = tval;
         }
+        normb_mine = lds_block_nanmax(mx, nan, red);
     }
-    __syncthreads();
-    int dbgn = 0;
-    auto stamp = [&]() { // diagnostics (CHIP_IR_DEBUG=2): phase boundaries of every workgroup on the 100 MHz clock
-        if (ir.dbg_all && tid == 0 && dbgn < 31) {
-            if (dbgn == 0)
-                ir.dbg_all[(size_t)b * 32] = (long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) |
-                                             ((long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32);
-            ir.dbg_all[(size_t)b * 32 + 1 + dbgn++] = wall_clock64();
-        }
-    };
+    lds_barrier();
     stamp();
     auto bail = [&]() { // a wait that cannot complete: report the timeout (the host repeats the solve unfused)
         if (tid == 0) ir.res[2] = 1;
@@ -232,7 +254,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
     auto forward = [&]() { // qdldl.rs:708-719: x_i -= l_ij y_j, level by level; the top rows' shares -> st.tacc
         opaque_l();
         if (tid < 8) st.tacc[tid] = 0.0;
-        if (nl == 0) __syncthreads();
+        if (nl == 0) lds_barrier();
         for (int l = 0; l < nl; ++l) {
             const int pa = st.lev[l], pb = st.lev[l + 1];
 #pragma unroll
@@ -240,7 +262,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
                 const int p = tid + u * TW;
                 if (p >= pa && p < pb) atomicAdd(&xs[lij[u] >> 16], -(lv[u] * xs[lij[u] & 0xFFFFu]));
             }
-            __syncthreads();
+            lds_barrier();
         }
         const int pa = st.lev[nl], pb = st.lev[nl + 1];
 #pragma unroll
@@ -249,7 +271,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
             const bool in = p >= pa && p < pb;
             lds_scatter_add(st.tacc, in ? (int)(lij[u] >> 16) - nloc : -1, in ? lv[u] * xs[lij[u] & 0xFFFFu] : 0.0);
         }
-        __syncthreads();
+        lds_barrier();
     };
     auto backward = [&]() { // qdldl.rs:737-752: x_j = y_j / d_j - sum_i l_ij x_i, the top rows' unknowns from st.dxt
         opaque_l();
@@ -258,7 +280,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
             const int i = tid + u * TW;
             if (i < nloc) xs[i] *= dis[i];
         }
-        __syncthreads();
+        lds_barrier();
         {
             const int pa = st.lev[nl], pb = st.lev[nl + 1];
 #pragma unroll
@@ -267,7 +289,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
                 if (p >= pa && p < pb) atomicAdd(&xs[lij[u] & 0xFFFFu], -(lv[u] * st.dxt[(lij[u] >> 16) - nloc]));
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int l = nl - 1; l >= 0; --l) {
             const int pa = st.lev[l], pb = st.lev[l + 1];
 #pragma unroll
@@ -275,7 +297,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
                 const int p = tid + u * TW;
                 if (p >= pa && p < pb) atomicAdd(&xs[lij[u] & 0xFFFFu], -(lv[u] * xs[lij[u] >> 16]));
             }
-            __syncthreads();
+            lds_barrier();
         }
     };
     // e = b - K x (unregularised K, csc/matrix_math.rs:178-208: every off-diagonal entry used twice) for the candidate in
@@ -288,8 +310,8 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
             const int i = tid + u * TW;
             if (i < nloc) xs[i] = bs[i];
         }
-        __syncthreads();
-        const int ntop0 = gs.untop[b]; // entries at or beyond this position lie in the top columns
+        lds_barrier();
+        // (entries at or beyond position ntop0 lie in the top columns)
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             const int p = tid + u * TW;
@@ -306,7 +328,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
             }
             lds_scatter_add(st.tacc, top ? j - nloc : -1, top ? uv[u] * cnd[i] : 0.0);
         }
-        __syncthreads();
+        lds_barrier();
         double m = 0.0;
         bool nan = false;
 #pragma unroll
@@ -318,31 +340,20 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
                 else m = fmax(m, fabs(val));
             }
         }
-        m = block_max(m, red);
-        const bool anynan = __syncthreads_or(nan);
-        return anynan ? __longlong_as_double(0x7ff8000000000000ll) : m;
+        return lds_block_nanmax(m, nan, red);
     };
-    auto publish = [&](int slot, int tag) { // st.tacc[0 .. k) as tagged messages
-        if (tid < k) msg_store(gs.msg + ((size_t)(b * 4 + slot) * 8 + tid) * 4, st.tacc[tid], tag);
+    // st.tacc[0 .. k) as tagged messages; with_norms: also this bundle's ||e||inf and ||b||inf (values 8, 9)
+    int oz = 0;
+    auto publish = [&](int slot, int tag, bool with_norms, double nrm) {
+        int *recm = gs.msg + oz + (size_t)(b * 4 + slot) * GS_MV * 4;
+        if (tid < k) msg_store(recm + tid * 4, st.tacc[tid], tag);
+        else if (with_norms && (tid == 8 || tid == 9)) msg_store(recm + tid * 4, tid == 8 ? nrm : normb_mine, tag);
     };
-    // fixed-order reductions of the last arriver of a barrier, and the reference's decisions (as k_bundle_ir)
-    auto reduce_norms = [&](int par, bool first) {
-        double mb = 0.0, m = 0.0;
-        for (int q = tid; q < nb; q += TW) {
-            if (first) mb = nanmax(mb, ir_load(&pnb[q]));
-            m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
-        }
-        if (first) {
-            mb = block_nanmax(mb, red);
-            if (tid == 0) ir_store(&pub[par * 32 + 9], mb);
-        }
-        m = block_nanmax(m, red);
-        if (tid == 0) ir_store(&pub[par * 32 + 8], m);
-    };
-    auto decide = [&](int round, int par) {
+    // the reference's decisions (as k_bundle_ir) from the system-wide norms in st.vn / st.vb
+    auto decide = [&](int round) {
         if (tid == 0) {
-            const double newnorm = ir_load(&pub[par * 32 + 8]);
-            if (round == 0) st.normb = ir_load(&pub[par * 32 + 9]);
+            const double newnorm = st.vn;
+            if (round == 0) st.normb = st.vb;
             const double tol = ir.abstol + ir.reltol * st.normb;
             bool accept, done = false;
             if (round == 0) {
@@ -375,7 +386,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
             st.lastnorme = st.norme;
             st.done = done ? 1 : 0;
         }
-        __syncthreads();
+        lds_barrier();
     };
     // the k x k top part of both sweeps (every workgroup of the group alike): rhs - (the group's forward shares)
     auto top_solve = [&](int round) {
@@ -407,33 +418,118 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
         }
         return m;
     };
+    // The group's view of a candidate whose residual shares / norms were published in slot `slot` with `tag`: totals of
+    // the shares -> st.rsum, top rows of the residual -> st.rtop, and the group's contribution to the system-wide norms
+    // (its bundles' rows and its top rows), which the group's leader publishes to the other leaders.  All threads.
+    auto group_collect = [&](int slot_f, int tag_f, bool with_f, int slot, int tag, int par) {
+        if (tid < 64) {
+            const bool ok = with_f ? gs_poll_group<true, true>(gs.msg + oz, gb0, gnb, k, slot_f, tag_f, slot, tag, st.fsum, st.rsum, st.gnorm)
+                                   : gs_poll_group<false, true>(gs.msg + oz, gb0, gnb, k, 0, 0, slot, tag, nullptr, st.rsum, st.gnorm);
+            if (!ok && tid == 0) st.timeout = 1;
+        }
+        lds_barrier();
+        if (st.timeout) return false;
+        if (tid == 0) {
+            double gn = st.gnorm[0], gb = st.gnorm[1];
+            if (ir.ir_enable) gn = nanmax(gn, top_residual());
+            else // no refinement: the top entries of x take part in the finiteness test instead (:180)
+                for (int i = 0; i < k; ++i) gn = nanmax(gn, fabs(st.candt[i]));
+            for (int i = 0; i < k; ++i) gb = nanmax(gb, fabs(st.btop[i]));
+            st.gnorm[0] = gn;
+            st.gnorm[1] = gb;
+        }
+        lds_barrier();
+        if (gfirst && tid < 2) msg_store(gs.lmsg + oz + ((size_t)(lead * 2 + par) * 2 + tid) * 4, st.gnorm[tid], tag);
+        return true;
+    };
+    // The system-wide norms of that candidate -> st.vn / st.vb: EVERY workgroup polls all leaders' messages (no counter,
+    // no last arriver, nobody reduces for the others, no second hop from a leader to its group: 16 bytes per leader and
+    // poll, a few KB per workgroup) and reduces them itself, NaN propagating.
+    auto verdict_inputs = [&](int tag, int par) {
+        double vn = 0.0, vb = 0.0;
+        bool ok = true;
+        for (int q = tid; q < nlead && ok; q += TW) {
+            const int *recl = gs.lmsg + oz + (size_t)(q * 2 + par) * 2 * 4;
+            msg_v4i ma, mb;
+            long long spins = 0;
+            for (;;) {
+                msg_load2(recl, recl + 4, ma, mb);
+                if (msg_ready(ma, tag) && msg_ready(mb, tag)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1ll << 20)) {
+                    ok = false;
+                    break;
+                }
+            }
+            vn = nanmax(vn, msg_value(ma));
+            vb = nanmax(vb, msg_value(mb));
+        }
+        if (!ok) st.timeout = 1;
+        const double n1 = lds_block_nanmax(vn != vn ? 0.0 : vn, vn != vn, red);
+        const double n2 = lds_block_nanmax(vb != vb ? 0.0 : vb, vb != vb, red);
+        if (tid == 0) {
+            st.vn = n1;
+            st.vb = n2;
+        }
+        lds_barrier();
+        return st.timeout == 0;
+    };
+    // ---- round 0's forward sweep and shares; then the entries of K (see above): indices and values as two dependent
+    // requests while the shares travel to the group's other workgroups ----
+    forward();
+    stamp();
+    if (k > 0) publish(0, gs.epoch * 64, false, 0.0);
+    {
+        int usrc[UR];
+        const bool gsv = gs.gsu != nullptr;
+        const double *uvals = gsv ? gs.gsu : v.Ux;
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int p = min(tid + u * TW, max(nU - 1, 0));
+            usrc[u] = gsv ? p : (int)gs.usrc[ub + p];
+            uij[u] = gs.uij[ub + p];
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) uv[u] = uvals[ub + usrc[u]];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const bool in = tid + u * TW < nU;
+            uij[u] = in ? uij[u] : 0xFFFFFFFFu;
+            uv[u] = in ? uv[u] : 0.0;
+        }
+    }
     bool pending = false;
     for (int round = 0;; ++round) {
         const int par = round & 1;
-        // tags of this launch's messages: forward shares of round r, residual shares of round r
+        // tags of this launch's messages: forward shares of round r, residual shares / norms of round r
         const int tagF = gs.epoch * 64 + 2 * round, tagR = tagF + 1, tagRprev = tagF - 1;
-        forward();
-        stamp();
-        if (grp >= 0) {
-            publish(par, tagF);
-            if (tid < 64) {
-                bool ok = gs_poll_sum(gs.msg, gb0, gnb, k, par, tagF, st.fsum);
-                if (ok && round > 0) ok = gs_poll_sum(gs.msg, gb0, gnb, k, 2 + (par ^ 1), tagRprev, st.rsum);
-                if (!ok && tid == 0) st.timeout = 1;
-            }
-            __syncthreads();
-            if (st.timeout) return bail();
-            if (tid == 0 && round > 0) (void)top_residual(); // -> st.rtop: the top rows' right-hand side of this round
-            __syncthreads();
-            top_solve(round);
-            __syncthreads();
+        // (an opaque zero added to the message bases: their lane addresses are recomputed where they are used instead of
+        // being kept in registers across the whole loop)
+        oz = 0;
+        asm volatile("" : "+v"(oz));
+        if (round > 0) { // (round 0's sweep and shares: ahead of the loop)
+            forward();
+            stamp();
+            if (k > 0) publish(par, tagF, false, 0.0);
         }
+        // the group's forward shares; and what the previous round's candidate left: its residual's top rows (this
+        // round's right-hand side there) and the group's norms, which go out to the other leaders
+        if (pending) {
+            if (!group_collect(par, tagF, k > 0, 2 + (par ^ 1), tagRprev, par ^ 1)) return bail();
+        } else if (k > 0) {
+            if (tid < 64 && !gs_poll_group<true, false>(gs.msg + oz, gb0, gnb, k, par, tagF, 0, 0, st.fsum, nullptr, nullptr) && tid == 0)
+                st.timeout = 1;
+            lds_barrier();
+            if (st.timeout) return bail();
+        }
+        top_solve(round);
+        lds_barrier();
         stamp();
         backward();
         stamp();
-        if (pending) { // the verdict on the previous round's candidate (arrived for at the end of that round)
-            if (ir_wait_word(ir.ctl + 32 * (1 + IR_NSUB + (b % IR_NSUB)), st.gen) == IR_TIMEOUT) return bail();
-            decide(round - 1, par ^ 1);
+        if (pending) { // the verdict on the previous round's candidate
+            if (!verdict_inputs(tagRprev, par ^ 1)) return bail();
+            decide(round - 1);
             pending = false;
             if (__builtin_amdgcn_readfirstlane(st.done)) break; // (this round's sweeps were speculative)
         }
@@ -448,7 +544,7 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
             if (i < nloc) cnd[i] = round == 0 ? xs[i] : 1.0 * acc[i] + 1.0 * xs[i];
         }
         if (tid < 8) st.candt[tid] = round == 0 ? st.dxt[tid] : 1.0 * st.acct[tid] + 1.0 * st.dxt[tid];
-        __syncthreads();
+        lds_barrier();
         double mine;
         if (!ir.ir_enable) { // no refinement: only x.is_finite() is asked for (:180)
             double mx = 0.0;
@@ -462,50 +558,22 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
                     else mx = fmax(mx, fabs(val));
                 }
             }
-            mx = block_max(mx, red);
-            const bool anynan = __syncthreads_or(nan);
-            mine = anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx;
-            if (gfirst)
-                for (int i = 0; i < k; ++i) mine = nanmax(mine, fabs(st.candt[i]));
+            mine = lds_block_nanmax(mx, nan, red);
+            if (tid < 8) st.tacc[tid] = 0.0;
+            lds_barrier();
         } else {
             mine = residual(cnd);
-            stamp();
-            if (grp >= 0) {
-                publish(2 + par, tagR);
-                if (gfirst) { // the top rows of the residual belong to the group's first workgroup's partial norm
-                    if (tid < 64 && !gs_poll_sum(gs.msg, gb0, gnb, k, 2 + par, tagR, st.rsum) && tid == 0) st.timeout = 1;
-                    __syncthreads();
-                    if (st.timeout) return bail();
-                    // (st.rtop is written here and recomputed from the same numbers at the next group wait)
-                    if (tid == 0) st.mtop = top_residual();
-                    __syncthreads();
-                    mine = nanmax(mine, st.mtop);
-                }
-            }
         }
-        if (tid == 0) ir_store(&pn[(size_t)par * nb + b], mine);
+        stamp();
+        publish(2 + par, tagR, true, mine);
         pending = true;
-        const bool more_possible = ir.ir_enable && round < ir.maxiter;
-        if (tid == 0) st.gen += 1;
-        if (more_possible) {
-            // arrival for the verdict on this round's candidate; it is awaited in the middle of the next round
-            if (ir_arrive_nowait(ir.ctl, st.gen, G) == IR_LAST) {
-                reduce_norms(par, round == 0);
-                ir_release(ir.ctl, st.gen, G);
-            }
-            stamp();
-            continue;
-        }
         stamp();
-        const int state = ir_arrive_wait(ir.ctl, st.gen, G);
-        if (state == IR_TIMEOUT) return bail();
-        if (state == IR_LAST) {
-            reduce_norms(par, round == 0);
-            ir_release(ir.ctl, st.gen, G);
-        }
-        __syncthreads();
+        if (ir.ir_enable && round < ir.maxiter) continue; // (the verdict is awaited in the middle of the next round)
+        if (!group_collect(0, 0, false, 2 + par, tagR, par)) return bail();
         stamp();
-        decide(round, par);
+        if (!verdict_inputs(tagR, par)) return bail();
+        stamp();
+        decide(round);
         pending = false;
         break;
     }
@@ -521,96 +589,164 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
                 if (ir.lhsz) ir.lhsz[o - ir.n] = val;
             }
         };
-        const int nruns = ir.runs ? ir.run_ptr[b + 1] - ir.run_ptr[b] : 0;
-        if (nruns > 0 && nruns <= GS_MAXRUNS) {
-            int r = 0;
 #pragma unroll
-            for (int u = 0; u < NR; ++u) {
-                const int i = tid + u * TW;
-                if (i < nloc) {
-                    while (i >= st.runs[3 * r] + st.runs[3 * r + 2]) ++r;
-                    put(st.runs[3 * r + 1] + (i - st.runs[3 * r]), acc[i]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < NR; ++u) {
-                const int i = tid + u * TW;
-                if (i < nloc) put(ir.perm[s0 + i], acc[i]);
-            }
+        for (int u = 0; u < NR; ++u) {
+            const int i = tid + u * TW;
+            if (i < nloc) put(og[i], acc[i]);
         }
-        if (gfirst && tid < k) put(ir.perm[topnode(tid)], st.acct[tid]);
+        if (gfirst && tid < k) put(st.torig[tid], st.acct[tid]);
     }
     if (b == 0 && tid == 0) {
         ir.res[0] = ok ? 1 : -1; // (0 = the kernel never got here)
         ir.res[1] = st.rounds;
         ir.res[3] = 0;
-        pub[64] = st.normb;
-        pub[65] = st.norme;
     }
     stamp();
-    ir_grid_exit(ir.ctl, __builtin_amdgcn_readfirstlane(st.gen) + 1, G);
 }
 
 // ---------------------------------------------------------------------------
-// k_gstep_factor: numeric LDL' of every bundle as k_bundle_factor_flat (entry-parallel, right-looking, the bundle's
-// values in LDS, update records walked flat), then the bundle's contribution to the Schur complement of its group's top
-// S[i][j] = sum over the bundle's columns c of l_ic d_c l_jc straight from LDS (the entries of a column in the top
-// rows carry 16-bit row indices >= nloc), published as tagged messages; the LAST workgroup of a group to deposit its
-// share (one arrival counter per group, no waiting) sums the shares in a fixed order, subtracts them from K_tt and
-// factors the k x k block with the pivot rule of qdldl.rs:645-665.
+// k_gstep_factor: numeric LDL' of every bundle, entry-parallel and right-looking with the bundle's values in LDS and the
+// symbolic phase's update records walked flat (as k_bundle_factor_flat), then the bundle's contribution to the Schur
+// complement of its group's top S[i][j] = sum over the bundle's columns c of l_ic d_c l_jc straight from LDS, published
+// as tagged messages; the LAST workgroup of a group to deposit its share (one arrival counter per group, nobody waits)
+// sums the shares in a fixed order, subtracts them from K_tt and factors the k x k block with the pivot rule of
+// qdldl.rs:645-665.  Built for bundles so small that the launch is a chain of latencies, not bandwidth: every index the
+// launch needs (column pointers, 16-bit rows / columns of the entries, signs, the levels' first update records) is
+// requested in ONE round trip behind the bundle's descriptor and parked in LDS / registers; a level then costs three
+// barriers of LDS work -- pivots (thread per column), scaling (thread per ENTRY: a separator column has hundreds), updates.
 // ---------------------------------------------------------------------------
-constexpr int GF_TW = 512;
+constexpr int GF_TW = 256; // (four workgroups per CU at <= 128 registers: every bundle of a 1024-bundle share is resident at once)
+constexpr int GF_FU = 8; // update records in flight per thread
+struct GfLds { // layout of the dynamic LDS of k_gstep_factor (doubles first)
+    double *Ls, *Ds, *Di;
+    int *lp;
+    unsigned short *li, *lj;
+    signed char *sg;
+};
+__host__ __device__ inline size_t gf_lds_bytes(int nE, int nloc) {
+    size_t b = (size_t)(nE + 2 * nloc) * sizeof(double) + (size_t)(nloc + 1) * sizeof(int);
+    b += (size_t)2 * ((nE + 3) & ~3) * sizeof(unsigned short) + (size_t)((nloc + 7) & ~7);
+    return (b + 15) & ~(size_t)15;
+}
+// nE / nloc: the launch's maxima (the same layout in every workgroup); nE_own: this bundle's entry count -- its pivots
+// follow its entries directly, because an update record addresses a pivot as target nE_own + row
+__device__ __forceinline__ GfLds gf_lds(char *smem, int nE, int nloc, int nE_own) {
+    GfLds l;
+    l.Ls = (double *)smem;
+    l.Ds = l.Ls + nE_own;
+    l.Di = l.Ls + nE + nloc;
+    l.lp = (int *)(l.Di + nloc);
+    l.li = (unsigned short *)(l.lp + nloc + 1);
+    l.lj = l.li + ((nE + 3) & ~3);
+    l.sg = (signed char *)(l.lj + ((nE + 3) & ~3));
+    return l;
+}
 __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv, GFoldView gf, GStepView gs) {
-    constexpr int TW = GF_TW;
+    constexpr int TW = GF_TW, FU = GF_FU;
     extern __shared__ __attribute__((aligned(16))) char ff_smem[];
     __shared__ double A[36], wsum[(GF_TW / 64) * 36];
-    __shared__ int s_last;
+    __shared__ int s_last, s_tp[GS_MAXL + 2], s_ln[GS_MAXL + 2];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
-    const int e0 = v.Lp[s0], nE = v.Lp[s1] - e0;
-    double *Ls = (double *)ff_smem, *Ds = Ls + nE; // (contiguous: a record's target addresses either)
-    const double eps = v.eps_ptr ? v.eps_ptr[0] : 0.0;
-    const int *lv = bv.blvl + bv.blvl_ptr[b];
-    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    const int *tp = v.fu_ptr + bv.blvl_ptr[b];
-    for (int q = tid; q < nE; q += TW) Ls[q] = 0.0; // (fill-in slots stay zero)
-    if (tid < 36) A[tid] = 0.0;
-    __syncthreads();
-    {
-        const int ub = v.Up[s0], ue = v.Up[s1];
-        for (int u = ub + tid; u < ue; u += TW) {
-            const unsigned short slot = v.fu_slot[u];
-            const double val = v.Ux[u];
-            if (slot == 0xFFFFu) {
-                const int j = (int)v.Urow16[u];
-                Ds[j] = v.eps_ptr ? (v.dsigns[s0 + j] == 1 ? val + eps : val - eps) : val;
-            } else {
-                Ls[slot] = val;
-            }
-        }
-    }
-    __syncthreads();
+    // ---- stage A: the bundle's descriptor ----
+    const int *dsc = gs.desc + (size_t)b * GS_DESC;
+    const int s0 = dsc[0], nloc = dsc[1], e0 = dsc[2], nE = dsc[3], ub = dsc[4], nU = dsc[5], nl = dsc[6], grp = dsc[7];
+    const int gbase = dsc[8], k = dsc[9], gb0 = dsc[10], gnb = dsc[11];
+    const int np = k * (k + 1) / 2;
+    const GfLds L = gf_lds(ff_smem, bv.max_entries, bv.max_nodes, nE);
+    double *Ls = L.Ls, *Ds = L.Ds, *Di = L.Di;
     typedef unsigned short fu_v4 __attribute__((ext_vector_type(4)));
     const fu_v4 *rec = (const fu_v4 *)v.fu_rec;
-    constexpr int FU = 8; // records in flight per thread
-    for (int l = 0; l < nl; ++l) {
-        const int rb = tp[l], re = tp[l + 1];
-        fu_v4 r[FU];
-        auto request = [&](int base) {
+    int dbgn = 0;
+    auto stamp = [&]() { // diagnostics (CHIP_IR_DEBUG=3): phase boundaries of every workgroup on the 100 MHz clock
+        if (gs.dbg && tid == 0 && dbgn < 31) {
+            if (dbgn == 0)
+                gs.dbg[(size_t)b * 32] = (long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) |
+                                         ((long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32);
+            gs.dbg[(size_t)b * 32 + 1 + dbgn++] = wall_clock64();
+        }
+    };
+    stamp();
+    // ---- stage B: every index and value the launch needs, in one round trip ----
+    // The bundle's U entries (K's values) are read through the gs order of the solve kernel and written back in that
+    // order (gs.gsu): the solves then load them, and L (gs.gsl, below), fully coalesced -- the gather through the 16-bit
+    // source positions is paid once per refactor here instead of once per solve there.
+    constexpr int UF = 8; // U entries per thread held in registers (more: streamed)
+    constexpr int LF = 8; // gs positions of L per thread whose source slot is prefetched (more: loaded at the end)
+    unsigned short uslot[UF], urow[UF], usrc[UF], lsrcr[LF];
+    double uval[UF];
 #pragma unroll
-            for (int u = 0; u < FU; ++u) {
-                const int t = base + u * TW + tid;
-                if (t < re) r[u] = rec[t];
-                else r[u] = fu_v4{0, 0, 0, 0xFFFF};
-            }
-        };
-        request(rb);
-        // the level's columns are final: pivot rule, scale
-        for (int j = lv[l] + tid; j < lv[l + 1]; j += TW) {
-            const int cb = v.Lp[j] - e0, ce = v.Lp[j + 1] - e0;
-            double d = Ds[j - s0];
-            const double sign = (double)v.dsigns[j];
+    for (int u = 0; u < UF; ++u) {
+        const int t = min(tid + u * TW, max(nU - 1, 0));
+        usrc[u] = gs.usrc[ub + t];
+        uslot[u] = gs.ufs[ub + t];
+        urow[u] = (unsigned short)(gs.uij[ub + t] >> 16);
+    }
+#pragma unroll
+    for (int u = 0; u < LF; ++u) lsrcr[u] = gs.lsrc[e0 + min(tid + u * TW, max(nE - 1, 0))];
+    for (int i = tid; i <= nloc; i += TW) L.lp[i] = v.Lp[s0 + i] - e0;
+    for (int i = tid; i < nloc; i += TW) L.sg[i] = v.dsigns[s0 + i];
+    for (int q = tid; q < nE; q += TW) {
+        L.li[q] = v.Li16[e0 + q];
+        L.lj[q] = v.Lj16[e0 + q];
+        Ls[q] = 0.0; // (fill-in slots stay zero)
+    }
+    if (tid <= nl) {
+        s_tp[tid] = dsc[32 + tid]; // first update record of every level, then the end
+        s_ln[tid] = dsc[48 + tid]; // first node of every level (bundle-local), then the node count
+    }
+    const double eps = v.eps_ptr ? v.eps_ptr[0] : 0.0;
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+        uval[u] = v.Ux[ub + usrc[u]];
+        if (tid + u * TW >= nU) uslot[u] = (unsigned short)0xFFFEu;
+    }
+    // the level-0 records, and K_tt for whoever turns out to be the group's last arriver (lane p < np of wave 0)
+    fu_v4 r[FU];
+    auto request = [&](int base, int re) {
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int t = base + u * TW + tid;
+            if (t < re) r[u] = rec[t];
+            else r[u] = fu_v4{0, 0, 0, 0xFFFF};
+        }
+    };
+    request(dsc[32], dsc[33]);
+    int tq = -2, tnode = -1, ti = 0, tj = 0;
+    if (grp >= 0 && tid < np) {
+        while ((ti + 1) * (ti + 2) / 2 <= tid) ++ti;
+        tj = tid - ti * (ti + 1) / 2;
+        const int *gt = gs.gtop + (size_t)grp * GS_GTOP;
+        tnode = gt[ti];
+        tq = ti == tj ? -2 : gt[16 + ti * 8 + tj];
+    }
+    double ktt0 = 0.0; // K_tt entry (scattered into D / the top-top slots of Lx by k_scatter_init, static regulariser included)
+    if (grp >= 0 && tid < np) ktt0 = ti == tj ? v.D[tnode] : (tq >= 0 ? v.Lx[tq] : 0.0);
+    if (tid < 36) A[tid] = 0.0;
+    __syncthreads();
+    stamp();
+    // ---- the bundle's U entries (initial values of its columns) into LDS ----
+    auto place = [&](unsigned short slot, unsigned short row, double val) {
+        if (slot == 0xFFFFu) Ds[row] = v.eps_ptr ? (L.sg[row] == 1 ? val + eps : val - eps) : val;
+        else if (slot != 0xFFFEu) Ls[slot] = val;
+    };
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+        place(uslot[u], urow[u], uval[u]);
+        if (tid + u * TW < nU) gs.gsu[ub + tid + u * TW] = uval[u];
+    }
+    for (int t = tid + UF * TW; t < nU; t += TW) {
+        const double val = v.Ux[ub + gs.usrc[ub + t]];
+        place(gs.ufs[ub + t], (unsigned short)(gs.uij[ub + t] >> 16), val);
+        gs.gsu[ub + t] = val;
+    }
+    __syncthreads();
+    stamp();
+    for (int l = 0; l < nl; ++l) {
+        const int rb = s_tp[l], re = s_tp[l + 1];
+        // the level's columns are final: pivot rule (thread per column) ...
+        for (int j = s_ln[l] + tid; j < s_ln[l + 1]; j += TW) {
+            double d = Ds[j];
+            const double sign = (double)L.sg[j];
             if (d * sign < v.reg_eps) {
                 d = v.reg_delta * sign;
                 atomicAdd(&v.status[2], 1); // rare
@@ -618,14 +754,18 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
             if (d == 0.0) v.status[1] = 1;
             const double dinv = 1.0 / d;
             if (!isfinite(dinv)) v.status[0] = 1;
-            v.D[j] = d;
-            v.Dinv[j] = dinv;
-            Ds[j - s0] = d;
-            for (int q = cb; q < ce; ++q) Ls[q] *= dinv;
+            v.D[s0 + j] = d;
+            v.Dinv[s0 + j] = dinv;
+            Ds[j] = d;
+            Di[j] = dinv;
         }
         __syncthreads();
+        // ... scale (thread per entry of the level's columns: one contiguous range of the CSC arrays)
+        for (int q = L.lp[s_ln[l]] + tid; q < L.lp[s_ln[l + 1]]; q += TW) Ls[q] *= Di[L.lj[q]];
+        __syncthreads();
+        // ... and the updates the level's columns cause: target -= l_a (l_b d_k)
         for (int base = rb; base < re; base += TW * FU) { // (wave-uniform bounds: lds_scatter_add is cross-lane)
-            if (base != rb) request(base);
+            if (base != rb) request(base, re);
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
                 const bool ok = r[u].w != 0xFFFFu;
@@ -633,22 +773,26 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
                 lds_scatter_add(Ls, ok ? (int)r[u].w : -1, -val);
             }
         }
+        if (l + 1 < nl) request(s_tp[l + 1], s_tp[l + 2]); // (index data: in flight across the barrier)
         __syncthreads();
+        stamp();
     }
     for (int q = tid; q < nE; q += TW) v.Lx[e0 + q] = Ls[q];
-    const int grp = gf.bgrp[b];
+#pragma unroll
+    for (int u = 0; u < LF; ++u)
+        if (tid + u * TW < nE) gs.gsl[e0 + tid + u * TW] = Ls[lsrcr[u]];
+    for (int p = tid + LF * TW; p < nE; p += TW) gs.gsl[e0 + p] = Ls[gs.lsrc[e0 + p]];
+    stamp();
     if (grp < 0) return;
     // ---- this bundle's share of the Schur complement of its group's top: a column's entries in the top rows are its
     // last ones (16-bit row index >= nloc); per-thread register accumulators over the packed lower triangle, reduced
-    // wave by wave in a fixed order (as k_gfold_schur, with L and D read from LDS) ----
-    const int gbase = gf.ptr[grp], k = gf.ptr[grp + 1] - gbase;
-    const int np = k * (k + 1) / 2;
+    // wave by wave in a fixed order (as k_gfold_schur, with L, D and the indices read from LDS) ----
     {
         double sa[36];
 #pragma unroll
         for (int p = 0; p < 36; ++p) sa[p] = 0.0;
-        for (int j = s0 + tid; j < s1; j += TW) {
-            const int cb = v.Lp[j] - e0, ce = v.Lp[j + 1] - e0;
+        for (int j = tid; j < nloc; j += TW) {
+            const int cb = L.lp[j], ce = L.lp[j + 1];
             double vv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) vv[i] = 0.0;
@@ -656,17 +800,17 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int q = ce - 1 - e;
-                const int ti = q >= cb ? (int)v.Li16[e0 + q] - nloc : -1;
-                if (ti >= 0) {
+                const int tt = q >= cb ? (int)L.li[q] - nloc : -1;
+                if (tt >= 0) {
                     const double val = Ls[q];
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (ti == i) vv[i] = val;
+                        if (tt == i) vv[i] = val;
                     any = true;
                 }
             }
             if (any) {
-                const double dj = Ds[j - s0];
+                const double dj = Ds[j];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const double wi = vv[i] * dj;
@@ -687,50 +831,36 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
             double t = 0.0;
             for (int w = 0; w < TW / 64; ++w) t += wsum[w * 36 + tid];
             A[tid] = t;
+            msg_store(gs.fmsg + ((size_t)b * 36 + tid) * 4, t, gs.epoch);
         }
     }
-    __syncthreads();
-    if (tid < np) msg_store(gs.fmsg + ((size_t)b * 36 + tid) * 4, A[tid], gs.epoch);
-    __syncthreads();
+    stamp();
     if (tid == 0) {
-        __builtin_amdgcn_s_waitcnt(0); // (this workgroup's messages have been acknowledged before it arrives)
-        const int gnb = gf.bptr[grp + 1] - gf.bptr[grp];
+        __builtin_amdgcn_s_waitcnt(0); // (this workgroup's messages -- all from wave 0 -- have been acknowledged)
         const int old = atomicAdd(gf.gcnt + grp * 32 + 2, 1);
         s_last = (old + 1 == gnb) ? 1 : 0;
         if (s_last) __hip_atomic_store(gf.gcnt + grp * 32 + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    stamp();
     if (!s_last) return;
-    // ---- the last arriver: K_tt (scattered into D / the top-top slots of Lx by k_scatter_init, static regulariser
-    // included) minus the shares in bundle order, then the k x k LDL' ----
-    if (tid < 64) {
-        const int lane = tid;
-        if (lane < np) {
-            int i = 0;
-            while ((i + 1) * (i + 2) / 2 <= lane) ++i;
-            const int j = lane - i * (i + 1) / 2;
-            double a;
-            if (i == j) a = v.D[gf.node[gbase + i]];
-            else {
-                const int q = gf.tt[grp * 64 + i * 8 + j];
-                a = q >= 0 ? v.Lx[q] : 0.0;
-            }
-            for (int q = gf.bptr[grp]; q < gf.bptr[grp + 1]; ++q) {
-                const int *addr = gs.fmsg + ((size_t)q * 36 + lane) * 4;
-                msg_v4i m = msg_load(addr);
-                long long spins = 0;
-                while ((m.y != gs.epoch || m.w != gs.epoch) && ++spins < (1ll << 20)) m = msg_load(addr); // (never spins:
-                // every mate's messages were acknowledged before its arrival; the bound only guards a broken launch)
-                a -= __hiloint2double(m.z, m.x);
-            }
-            A[lane] = a;
+    // ---- the last arriver: K_tt minus the shares in bundle order, then the k x k LDL' ----
+    if (tid < np) {
+        double a = ktt0;
+        for (int q = gb0; q < gb0 + gnb; ++q) {
+            const int *addr = gs.fmsg + ((size_t)q * 36 + tid) * 4;
+            msg_v4i m = msg_load(addr);
+            long long spins = 0; // (never spins: every mate's messages were acknowledged before its arrival)
+            while ((m.y != gs.epoch || m.w != gs.epoch) && ++spins < (1ll << 20)) m = msg_load(addr);
+            a -= __hiloint2double(m.z, m.x);
         }
+        A[tid] = a;
     }
     __syncthreads();
     if (tid != 0) return;
+    const int *gt = gs.gtop + (size_t)grp * GS_GTOP;
     for (int j = 0; j < k; ++j) {
-        const int nj = gf.node[gbase + j];
-        const double dinv = pivot_rule(v, nj, A[j * (j + 1) / 2 + j]);
+        const double dinv = pivot_rule(v, gt[j], A[j * (j + 1) / 2 + j]);
         for (int i = j + 1; i < k; ++i) {
             const double aij = A[i * (i + 1) / 2 + j];
             for (int i2 = j + 1; i2 <= i; ++i2) A[i * (i + 1) / 2 + i2] -= aij * (A[i2 * (i2 + 1) / 2 + j] * dinv);
@@ -738,13 +868,15 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
         for (int i = j + 1; i < k; ++i) {
             const double lij = A[i * (i + 1) / 2 + j] * dinv;
             A[i * (i + 1) / 2 + j] = lij;
-            const int q = gf.tt[grp * 64 + i * 8 + j];
+            const int q = gt[16 + i * 8 + j];
             if (q >= 0) {
                 v.Lx[q] = lij;
                 if (v.mirror_rows) v.Rx[v.Tpos[q]] = lij;
             }
         }
     }
+    stamp();
+    (void)gbase;
 }
 
 } // namespace
@@ -752,8 +884,9 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
 // ===========================================================================
 // launch wrappers
 // ===========================================================================
-static size_t gstep_solve_lds(const BundleView &bv) { return ((size_t)5 * bv.max_nodes * sizeof(double) + 15) & ~(size_t)15; }
-static size_t gstep_factor_lds(int lds_doubles) { return ((size_t)lds_doubles * sizeof(double) + 15) & ~(size_t)15; }
+static size_t gstep_solve_lds(const BundleView &bv) {
+    return ((size_t)bv.max_nodes * (5 * sizeof(double) + sizeof(int)) + 15) & ~(size_t)15;
+}
 template <int LR, int UR, int NR> static int gstep_capacity_of(const BundleView &bv) {
     const size_t lds = gstep_solve_lds(bv);
     const void *fn = (const void *)k_gstep_solve<LR, UR, NR>;
@@ -797,18 +930,13 @@ int gstep_solve(hipStream_t s, const LdlView &v, const BundleView &bv, const IrV
     }
     return (int)hipGetLastError();
 }
-bool gstep_factor_ok(int lds_doubles) {
-    const size_t lds = gstep_factor_lds(lds_doubles);
-    if (lds > 36 * 1024) return false; // four workgroups per CU
-    if (raise_dynamic_lds((const void *)k_gstep_factor, (size_t)lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return true;
+bool gstep_factor_ok(const BundleView &bv) {
+    const size_t lds = gf_lds_bytes(bv.max_entries, bv.max_nodes);
+    if (lds > 37 * 1024) return false; // four workgroups per CU
+    return raise_dynamic_lds((const void *)k_gstep_factor, lds) == hipSuccess;
 }
-int gstep_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf, const GStepView &gs,
-                 int lds_doubles) {
-    k_gstep_factor<<<bv.nb, GF_TW, gstep_factor_lds(lds_doubles), s>>>(v, bv, gf, gs);
+int gstep_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf, const GStepView &gs) {
+    k_gstep_factor<<<bv.nb, GF_TW, gf_lds_bytes(bv.max_entries, bv.max_nodes), s>>>(v, bv, gf, gs);
     return (int)hipGetLastError();
 }
 

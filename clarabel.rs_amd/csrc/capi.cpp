@@ -1012,7 +1012,9 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     if (E.gstep_solve_on && !switches().no_step_kernel && ir.maxiter <= 30) {
         // grouped fold with small bundles: the register-resident form of the same launch (bundle_gstep.hip)
         E.gstep.epoch += 1;
-        rc = dev::gstep_solve(E.stream, E.view(), E.bundles, ir, E.gfold, E.gstep);
+        dev::GStepView gsv = E.gstep;
+        if (!E.gstep_vals_valid) gsv.gsl = gsv.gsu = nullptr; // (gather L and K through the source positions instead)
+        rc = dev::gstep_solve(E.stream, E.view(), E.bundles, ir, E.gfold, gsv);
     } else {
         rc = dev::bundle_ir(E.stream, E.view(), E.bundles, E.fold, ir, E.ir_grid, E.ir_tw, E.gfold);
     }

@@ -450,19 +450,46 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 g.nr = (int)((mxN + 255) / 256);
                 if (mxL <= dev::GS_MAXL && mxE < 65535 && mxU < 65535 && g.lr <= 8 && g.ur <= 10 && g.nr <= 4) {
                     const i32 NFn = S.NF;
-                    std::vector<i32> lptr((size_t)nbn * dev::GS_LST, 0), untop((size_t)nbn, 0);
-                    std::vector<uint16_t> lsrc((size_t)S.Lp[NFn]), usrc((size_t)S.Up[NFn]);
-                    std::vector<uint32_t> lij((size_t)S.Lp[NFn]), uij((size_t)S.Up[NFn]);
+                    std::vector<i32> desc((size_t)nbn * dev::GS_DESC, 0), gtop((size_t)std::max(1, (int)S.gf_ng) * dev::GS_GTOP, -1);
+                    std::vector<i32> bgrp_h((size_t)nbn, -1);
+                    for (int g = 0; g < S.gf_ng; g++) {
+                        for (int b = S.gf_bptr[g]; b < S.gf_bptr[g + 1]; b++) bgrp_h[(size_t)b] = g;
+                        i32 *gt = gtop.data() + (size_t)g * dev::GS_GTOP;
+                        const int base = S.gf_ptr[g], kk = S.gf_ptr[g + 1] - base;
+                        for (int t = 0; t < kk; t++) {
+                            gt[t] = S.gf_node[(size_t)base + t];
+                            gt[8 + t] = h_perm[(size_t)gt[t]];
+                            for (int j = 0; j < 8; j++) gt[16 + t * 8 + j] = S.gf_tt[(size_t)g * 64 + t * 8 + j];
+                            for (i32 q = S.gf_sp[(size_t)base + t]; q < S.gf_sp[(size_t)base + t + 1]; q++)
+                                gt[80 + t * 8 + S.gf_scol[(size_t)q]] = S.gf_sslot[(size_t)q];
+                        }
+                    }
+                    // (+ 8: the kernels clamp their indices instead of predicating their loads)
+                    std::vector<uint16_t> lsrc((size_t)S.Lp[NFn] + 8, 0), usrc((size_t)S.Up[NFn] + 8, 0), ufs((size_t)S.Up[NFn] + 8, 0);
+                    std::vector<uint32_t> lij((size_t)S.Lp[NFn] + 8, 0), uij((size_t)S.Up[NFn] + 8, 0);
                     std::vector<std::pair<uint32_t, i32>> tops; // (top index << 16 | column or row, source)
+                    int nlead = 0;
                     for (int b = 0; b < nbn; b++) {
                         const int s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1], nloc = s1 - s0;
                         const i32 e0 = S.Lp[s0], ub = S.Up[s0];
                         const i32 *lv = S.blvl.data() + S.blvl_ptr[b];
                         const int nl = S.blvl_ptr[b + 1] - S.blvl_ptr[b] - 1;
+                        i32 *dsc = desc.data() + (size_t)b * dev::GS_DESC;
+                        const int g = bgrp_h[(size_t)b];
+                        dsc[0] = s0, dsc[1] = nloc, dsc[2] = e0, dsc[3] = S.Lp[s1] - e0, dsc[4] = ub, dsc[5] = S.Up[s1] - ub;
+                        dsc[6] = nl, dsc[7] = g;
+                        dsc[8] = g >= 0 ? S.gf_ptr[g] : 0, dsc[9] = g >= 0 ? S.gf_ptr[g + 1] - S.gf_ptr[g] : 0;
+                        dsc[10] = g >= 0 ? S.gf_bptr[g] : b, dsc[11] = g >= 0 ? S.gf_bptr[g + 1] - S.gf_bptr[g] : 1;
+                        if (dsc[10] == b) nlead++; // (a group's first bundle -- or a bundle without group -- leads)
+                        dsc[14] = nlead - 1;
+                        dsc[13] = S.blvl_ptr[b];
+                        for (int l = 0; l <= nl; l++) dsc[48 + l] = lv[l] - s0;
+                        if (!S.fu_ptr.empty())
+                            for (int l = 0; l <= nl; l++) dsc[32 + l] = S.fu_ptr[(size_t)S.blvl_ptr[b] + l];
                         i32 p = 0;
                         tops.clear();
                         for (int l = 0; l < nl; l++) {
-                            lptr[(size_t)b * dev::GS_LST + l] = p;
+                            dsc[16 + l] = p;
                             for (i32 j = lv[l]; j < lv[l + 1]; j++)
                                 for (i32 q = S.Lp[j]; q < S.Lp[j + 1]; q++) {
                                     const uint32_t r16 = S.Li16[(size_t)q];
@@ -475,14 +502,14 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                                     }
                                 }
                         }
-                        lptr[(size_t)b * dev::GS_LST + nl] = p;
+                        dsc[16 + nl] = p;
                         std::sort(tops.begin(), tops.end());
                         for (const auto &t : tops) {
                             lsrc[(size_t)e0 + p] = (uint16_t)(t.second - e0);
                             lij[(size_t)e0 + p] = (((t.first >> 16) + (uint32_t)nloc) << 16) | (t.first & 0xFFFFu);
                             p++;
                         }
-                        lptr[(size_t)b * dev::GS_LST + nl + 1] = p; // == S.Lp[s1] - e0
+                        dsc[16 + nl + 1] = p; // == S.Lp[s1] - e0
                         // the U rows: entries outside the top columns in their stored order, then the top columns'
                         i32 pu = 0;
                         tops.clear();
@@ -496,40 +523,54 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                                 tops.push_back({((c16 - (uint32_t)nloc) << 16) | r16, u});
                             }
                         }
-                        untop[(size_t)b] = pu;
+                        dsc[12] = pu;
                         std::sort(tops.begin(), tops.end());
                         for (const auto &t : tops) {
                             usrc[(size_t)ub + pu] = (uint16_t)(t.second - ub);
                             uij[(size_t)ub + pu] = ((t.first & 0xFFFFu) << 16) | ((t.first >> 16) + (uint32_t)nloc);
                             pu++;
                         }
+                        if (!S.fu_slot.empty())
+                            for (i32 q = 0; q < pu; q++) ufs[(size_t)ub + q] = S.fu_slot[(size_t)ub + usrc[(size_t)ub + q]];
                     }
-                    int *d_lptr = nullptr, *d_untop = nullptr, *d_msg = nullptr, *d_fmsg = nullptr;
-                    unsigned short *d_lsrc = nullptr, *d_usrc = nullptr;
+                    for (int b = 0; b < nbn; b++) desc[(size_t)b * dev::GS_DESC + 15] = nlead;
+                    int *d_desc = nullptr, *d_gtop = nullptr, *d_msg = nullptr, *d_fmsg = nullptr, *d_lmsg = nullptr;
+                    unsigned short *d_lsrc = nullptr, *d_usrc = nullptr, *d_ufs = nullptr;
+                    double *d_gsl = nullptr, *d_gsu = nullptr;
                     unsigned int *d_lij = nullptr, *d_uij = nullptr;
-                    if ((rc = upload(&d_lptr, lptr, lptr.size()))) return rc;
-                    if ((rc = upload(&d_untop, untop, untop.size()))) return rc;
+                    if ((rc = upload(&d_desc, desc, desc.size()))) return rc;
+                    if ((rc = upload(&d_gtop, gtop, gtop.size()))) return rc;
                     if ((rc = upload(&d_lsrc, lsrc, lsrc.size()))) return rc;
                     if ((rc = upload(&d_usrc, usrc, usrc.size()))) return rc;
+                    if ((rc = upload(&d_ufs, ufs, ufs.size()))) return rc;
+                    if ((rc = alloc(&d_gsl, lsrc.size()))) return rc;
+                    if ((rc = alloc(&d_gsu, usrc.size()))) return rc;
                     if ((rc = upload(&d_lij, lij, lij.size()))) return rc;
                     if ((rc = upload(&d_uij, uij, uij.size()))) return rc;
-                    const size_t nmsg = (size_t)nbn * 4 * 8 * 4, nfmsg = (size_t)nbn * 36 * 4;
+                    const size_t nmsg = (size_t)nbn * 4 * dev::GS_MV * 4, nfmsg = (size_t)nbn * 36 * 4, nlmsg = (size_t)nlead * 2 * 2 * 4;
                     if ((rc = alloc(&d_msg, nmsg))) return rc;
                     if ((rc = alloc(&d_fmsg, nfmsg))) return rc;
                     CHIP_HIP(hipMemset(d_msg, 0, nmsg * sizeof(int)));
                     CHIP_HIP(hipMemset(d_fmsg, 0, nfmsg * sizeof(int)));
-                    g.lptr = d_lptr;
-                    g.untop = d_untop;
+                    if ((rc = alloc(&d_lmsg, nlmsg))) return rc;
+                    CHIP_HIP(hipMemset(d_lmsg, 0, nlmsg * sizeof(int)));
+                    g.desc = d_desc;
+                    g.gtop = d_gtop;
                     g.lsrc = d_lsrc;
                     g.usrc = d_usrc;
+                    g.ufs = d_ufs;
+                    g.gsl = d_gsl;
+                    g.gsu = d_gsu;
                     g.lij = d_lij;
                     g.uij = d_uij;
                     g.msg = d_msg;
                     g.fmsg = d_fmsg;
+                    g.lmsg = d_lmsg;
                     g.epoch = 0;
                     gstep = g;
                     gstep_solve_on = dev::gstep_solve_capacity(bundles, gstep) >= bundles.nb;
-                    gstep_factor_on = factor_lds_doubles > 0 && fu_rec != nullptr && dev::gstep_factor_ok(factor_lds_doubles);
+                    bundles.max_entries = (int)mxE;
+                    gstep_factor_on = fu_rec != nullptr && dev::gstep_factor_ok(bundles);
                 }
             }
         }
@@ -673,13 +714,35 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     if (gstep_factor_on && !switches().no_step_kernel) {
         // grouped fold with small bundles: bundle columns, Schur shares and the groups' k x k tops in ONE launch
         gstep.epoch += 1;
-        const int lrc = dev::gstep_factor(stream, v, bundles, gfold, gstep, factor_lds_doubles);
+        long long *fdbg = nullptr;
+        if (switches().ir_debug >= 3) { // stamps of every workgroup of the factor launch -> <CHIP_IR_DEBUG_FILE>.factor
+            (void)hipMalloc((void **)&fdbg, (size_t)bundles.nb * 32 * sizeof(long long));
+            (void)hipMemsetAsync(fdbg, 0, (size_t)bundles.nb * 32 * sizeof(long long), stream);
+        }
+        gstep.dbg = fdbg;
+        const int lrc = dev::gstep_factor(stream, v, bundles, gfold, gstep);
+        gstep.dbg = nullptr;
+        gstep_vals_valid = true; // (gs.gsl / gs.gsu hold this factorisation's L and K in gs order)
+        if (fdbg) {
+            (void)hipStreamSynchronize(stream);
+            std::vector<long long> t((size_t)bundles.nb * 32);
+            (void)hipMemcpy(t.data(), fdbg, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            (void)hipFree(fdbg);
+            const std::string path = (switches().ir_debug_file.empty() ? std::string("/tmp/chip_ir_stamps.bin") : switches().ir_debug_file) + ".factor";
+            if (FILE *f = std::fopen(path.c_str(), "wb")) {
+                const int g = bundles.nb;
+                std::fwrite(&g, sizeof(int), 1, f);
+                std::fwrite(t.data(), sizeof(long long), t.size(), f);
+                std::fclose(f);
+            }
+        }
         prof_end(PF_BFACTOR);
         if (lrc) {
             set_error(hip_err((hipError_t)lrc, "k_gstep_factor launch"));
             return CHIP_ERR_HIP;
         }
     } else {
+        gstep_vals_valid = false;
         const int lrc = dev::bundle_factor(stream, v, bundles, fold, factor_lds_doubles); // everything below the cut: one launch
         prof_end(PF_BFACTOR);
         if (lrc) {

@@ -131,9 +131,10 @@ struct Engine {
     unsigned short *Li16 = nullptr, *Ucol16 = nullptr, *Lj16 = nullptr, *Urow16 = nullptr, *Rk16 = nullptr, *Ro16 = nullptr;
     unsigned short *fu_rec = nullptr, *fu_slot = nullptr;
     int *fu_ptr = nullptr;
-    // grouped fold with small bundles: the step kernels (dev::gstep_solve / gstep_factor); gstep.lptr == nullptr: not used
+    // grouped fold with small bundles: the step kernels (dev::gstep_solve / gstep_factor); gstep.desc == nullptr: not used
     dev::GStepView gstep{};
     bool gstep_solve_on = false, gstep_factor_on = false;
+    bool gstep_vals_valid = false; // the last refactor went through k_gstep_factor: gstep.gsl / gsu are current
     int factor_lds_doubles = 0; // > 0: the bundle factorisation keeps its values in LDS (k_bundle_factor_lds)
     int ir_grid = 0, ir_next = 0, ir_tw = 256;
     int *ir_ctl = nullptr, *ir_res = nullptr, *ir_res_host = nullptr;

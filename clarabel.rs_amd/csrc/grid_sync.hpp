@@ -156,6 +156,23 @@ __device__ __forceinline__ double block_nanmax(double v, double *red) {
     return t;
 }
 
+// Barrier for data exchanged through LDS only: waits for this wave's LDS operations (lgkmcnt), NOT for its outstanding
+// global loads and stores -- __syncthreads() is a workgroup-scope fence + barrier and drains both, which would pull the
+// wait for operands requested early and needed late (the step kernels' K entries) to the first barrier of the launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// NaN-propagating max over the workgroup through LDS (red: one double per wave), broadcast; `bad`: this thread saw a NaN
+__device__ __forceinline__ double lds_block_nanmax(double m, bool bad, double *red) {
+    m = wave_max_all(m);
+    const bool wbad = __ballot(bad) != 0ull;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    lds_barrier(); // (red may still be read from an earlier call)
+    if (lane == 0) red[wv] = wbad ? __longlong_as_double(0x7ff8000000000000ll) : m;
+    lds_barrier();
+    double t = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = nanmax(t, red[i]);
+    return t;
+}
+
 // one value + the epoch it belongs to as ONE 16-byte device-coherent message (k_snode_tri's unknowns, the group
 // exchange of k_gstep_*): the reader polls the slot until both tags carry the epoch it waits for
 typedef int msg_v4i __attribute__((ext_vector_type(4)));
@@ -176,6 +193,24 @@ __device__ __forceinline__ msg_v4i msg_load(const int *slot) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(m) : "v"(slot) : "memory");
     return m;
 }
+
+// two messages in one round trip
+__device__ __forceinline__ void msg_load2(const int *slot_a, const int *slot_b, msg_v4i &a, msg_v4i &b) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(slot_a), "v"(slot_b)
+                 : "memory");
+}
+__device__ __forceinline__ void msg_load3(const int *slot_a, const int *slot_b, const int *slot_c, msg_v4i &a, msg_v4i &b,
+                                          msg_v4i &c) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c)
+                 : "v"(slot_a), "v"(slot_b), "v"(slot_c)
+                 : "memory");
+}
+__device__ __forceinline__ bool msg_ready(const msg_v4i &m, int tag) { return m.y == tag && m.w == tag; }
+__device__ __forceinline__ double msg_value(const msg_v4i &m) { return __hiloint2double(m.z, m.x); }
 
 } // namespace
 

@@ -41,6 +41,7 @@ struct BundleView {
     int nb;
     const int *bundle_ptr, *blvl_ptr, *blvl;
     int max_nodes;
+    int max_entries; // most entries of L in one bundle's columns (the step kernels' LDS layout)
     // k_bundle_ir only: doubles of dynamic LDS per workgroup (0: max_nodes) and whether the residual runs in its
     // "split" form (bundle_symv_split: x of the non-leaf nodes AND the residual in LDS, no gathers from global
     // memory), which needs nloc + max(0, nloc - 2 nleaf) doubles for every bundle
@@ -180,30 +181,48 @@ void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, con
 // sorted by (top row, column); U: the entries that are not in top columns in their stored order, then those in top
 // columns sorted by (top column, row).  All arrays are parallel to the bundle columns of L / the bundles' U rows.
 constexpr int GS_MAXL = 14;          // elimination levels inside a bundle the step kernels handle
-constexpr int GS_LST = GS_MAXL + 2;  // ints per bundle in GStepView::lptr
+constexpr int GS_LST = GS_MAXL + 2;
+constexpr int GS_DESC = 64;          // ints per bundle descriptor (two 128-byte lines)
+constexpr int GS_GTOP = 144;         // ints per group: top table
+constexpr int GS_MV = 12;            // messages per (bundle, phase slot): 8 shares of the top rows, the bundle's ||e||inf, ||b||inf
 struct GStepView {
     int lr, ur, nr;               // register slots a thread needs: ceil(max L entries / 256), ceil(max U entries / 256),
                                   // ceil(max nodes / 256)
-    const int *lptr;              // [nb * GS_LST] per bundle: gs positions where levels 0 .. nl begin, then the end of
-                                  // the top-row entries (= the bundle's entry count)
+    // per bundle, one 128-byte line: [0] first node s0, [1] nodes, [2] first CSC slot of its columns of L, [3] entries of L,
+    // [4] first entry of its U rows, [5] entries of U, [6] levels nl, [7] group (-1: none), [8] first top row of the group
+    // in GFoldView::node, [9] top rows k, [10] first bundle of the group, [11] bundles of the group, [12] gs position of
+    // the first U entry in a top column, [13] BundleView::blvl_ptr of the bundle, [14] index of the group's leader among
+    // the leaders (the first bundle of every group; a bundle without group leads itself: [10] = itself, [11] = 1), [15] leaders; [16 .. 16 + nl + 1]: gs positions where
+    // levels 0 .. nl begin (level nl = the top-row entries), then the bundle's entry count; [32 .. 32 + nl]: first update
+    // record (LdlView::fu_rec) of every level, then the end of the last level's records; [48 .. 48 + nl]: first node of every
+    // level (bundle-local), then the node count
+    const int *desc;
+    // per group: [0, 8) node of top row t (final numbering, -1 beyond k), [8, 16) its index in the caller's order,
+    // [16, 80) CSC slot of L(top_i, top_j) at i * 8 + j (-1: structurally zero / j >= i), [80, 144) position in V of
+    // K(top_i, top_c) at i * 8 + c (-1: zero)
+    const int *gtop;
     const unsigned short *lsrc;   // gs position -> CSC slot of the value, relative to the bundle's first slot
     const unsigned int *lij;      // gs position -> (row16 << 16) | column16, bundle-local; row >= nloc: top row nloc + t
-    const int *untop;             // [nb]: gs position of the first U entry in a top column
     const unsigned short *usrc;   // gs position -> position inside the bundle's U range the value comes from
     const unsigned int *uij;      // gs position -> (row16 << 16) | column16; column >= nloc: top column nloc + t
-    int *msg;                     // k_gstep_solve: [nb][4 phase slots][8] messages of 16 bytes (value, tag)
+    const unsigned short *ufs;    // gs position of a U entry -> where it lands in the factorisation's value store (LdlView::fu_slot)
+    // values in gs order, written by k_gstep_factor (nullptr in the view handed to k_gstep_solve: gather through lsrc / usrc)
+    double *gsl, *gsu;
+    int *msg;                     // k_gstep_solve: [nb][4 phase slots][GS_MV] messages of 16 bytes (value, tag)
+    int *lmsg;                    // [leaders][2][2]: a group's ||e||inf, ||b||inf, published by its leader, polled by every workgroup
     int *fmsg;                    // k_gstep_factor: [nb][36] messages (a bundle's Schur share, packed lower triangle)
     int epoch;                    // tags of this launch's messages (the host counts launches)
+    long long *dbg;               // diagnostics (CHIP_IR_DEBUG=3): 32 words per workgroup of k_gstep_factor, or nullptr
 };
 // largest co-resident grid of k_gstep_solve for these bundles (0: cannot run)
 int gstep_solve_capacity(const BundleView &bv, const GStepView &gs);
 // one launch = setrhs + LDL' solve + iterative refinement with its decisions + getlhs (as bundle_ir); grid = bv.nb
 int gstep_solve(hipStream_t s, const LdlView &v, const BundleView &bv, const IrView &ir, const GFoldView &gf,
                 const GStepView &gs);
-// bundle factorisation + Schur shares + the groups' k x k tops in one launch (lds_doubles as bundle_factor)
-bool gstep_factor_ok(int lds_doubles);
-int gstep_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf, const GStepView &gs,
-                 int lds_doubles);
+// bundle factorisation + Schur shares + the groups' k x k tops in one launch (needs LdlView::fu_rec and
+// BundleView::max_entries)
+bool gstep_factor_ok(const BundleView &bv);
+int gstep_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf, const GStepView &gs);
 
 void factor_T(hipStream_t s, const LdlView &v, ListView cols);
 void factor_W(hipStream_t s, const LdlView &v, ListView cols);

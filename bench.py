@@ -99,6 +99,7 @@ class Workload:
         self.lhs = [hip.DeviceArray(n + m) for _ in range(nrhs)]
         self.n, self.m = n, m
         self.gather_every_solve = False
+        self.repeats = 0   # solves repeated at collect time after a fused launch timed out (chip_kkt_collect: 2)
 
     def step(self, comm=None, gathered=None, counts=None):
         # one interior-point iteration's KKT work is ENQUEUED as a whole; the reference's bools (update:
@@ -123,6 +124,16 @@ class Workload:
         uok, sok = ks.collect()
         if not uok or len(sok) != len(self.rhs) or not all(sok):
             raise RuntimeError("KKT step failed: update %s, solves %s" % (uok, sok))
+        if ks.repeated_solves:
+            # a fused launch timed out (its workgroups were not all resident) and collect repeated the solve: what was
+            # enqueued behind it consumed garbage.  The exchange is re-issued for the affected solves; the step is no
+            # longer a clean measurement and the line says so.
+            self.repeats += len(ks.repeated_solves)
+            if comm is not None:
+                for k in ks.repeated_solves:
+                    if self.gather_every_solve or k == last:
+                        comm.wait(ks)
+                        comm.allgather_step(ks, self.lhs[k].ptr, gathered[k].ptr, counts)
 
     def run(self, steps, warmup, profile_family=0, comm=None, gathered=None, counts=None):
         def sync():
@@ -188,6 +199,7 @@ def oracle_leg(w, args, time_it=True):
     t0 = time.perf_counter()
     step(ref_r1)
     t1 = time.perf_counter() - t0
+    oracle_leg.last_step_s = t1  # (the compact lines of configs 2 / 5 quote this one step as their cpu_baseline)
     got_r1 = w.solutions()
     err_r1 = max(relerr(g, r) for g, r in zip(got_r1, ref_r1))
     # default refinement (reltol 1e-13, abstol 1e-12, <= 10 rounds) on both sides, same factorisation
@@ -358,6 +370,133 @@ def quarter_c5_cpu_baseline(hip, problems, args):
                       "of src/qdldl + DirectLDLKKTSolver, Hs blocks from oracle/psd_numpy" % (ko.N, os.cpu_count() or 0)}
 
 
+def extra_workload(hip, problems, which, args, device):
+    """compact object of the default N = 1 line for BASELINE configs 2 / 5: the same Workload.step (1 update + 3 solves,
+    one refinement round each), device resident, with its roofline figure, parity and host setup time -- so that the
+    driver's own run sees every config, not only config 3 (bench.py --workload c2 / c5 print the full lines)"""
+    try:
+        if which == "c2":
+            pr = problems.random_qp(100000, 200000, band=50, seed=1)
+            desc, fam = "random sparse QP (BASELINE config 2): n=100000, m=200000, Nonnegative cone", 11
+        else:
+            pr = problems.chordal_sdp(200, 50, 10, 200, 51, seed=5, with_hs=False)
+            desc, fam = "chordal SDP (BASELINE config 5): 200 x PSD(50) cliques with overlap 10 + 200 x SOC(51)", 7
+        w = Workload(hip, pr, device, 0)
+        steps, warm = max(3, min(args.steps, 10)), max(1, min(args.warmup, 2))
+        el, prof = w.run(steps, warm, fam)
+        ms = 1e3 * el / steps
+        ks = w.ks
+        info = ks.linear_solver_info()
+        wm = ks.work_model()
+        Bm = algorithmic_bytes(ks.N, ks.nnzK, info.nnzL, ks.nHs, w.m)
+        roof = None
+        if prof["launches"] > 0 and which == "c2" and wm["sn_panel_entries"] > 0:
+            sweeps = 2 * len(w.rhs) * 2   # forward + backward, 3 solves x (1 + 1 refinement round)
+            per_launch = 12.0 * wm["sn_panel_entries"] * sweeps * steps / prof["launches"]
+            avg_ms = prof["ms"] / prof["launches"]
+            ach = per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_snode_tri", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "launches_per_step": round(prof["launches"] / steps, 1),
+                    "kernel_ms_per_step": round(prof["ms"] / steps, 3)}
+        elif prof["launches"] > 0 and which == "c5" and wm["sn_update_flops"] > 0:
+            per_launch = wm["sn_update_flops"] * steps / prof["launches"]
+            avg_ms = prof["ms"] / prof["launches"]
+            ach = per_launch / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "k_snode_update", "achieved": round(ach, 2), "peak": MFMA_F64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F64_PEAK_TFLOPS, 4),
+                    "launches_per_step": round(prof["launches"] / steps, 1), "kernel_ms_per_step": round(prof["ms"] / steps, 3)}
+        whole = round(Bm["iter"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        cpu = None
+        if which == "c2":
+            parity, _, ko = oracle_leg(w, args, time_it=False)
+            del ko
+            t1 = getattr(oracle_leg, "last_step_s", None)
+            if t1:
+                cpu = {"value": round(1.0 / t1, 4), "unit": "iterations/s", "cores": 1, "kind": "port",
+                       "sample": "1 full step of the same workload on 1 of the host's %d cores (the oracle's parity step, timed)"
+                                 % (os.cpu_count() or 0)}
+        else:
+            parity = fixture_parity_c5(w, hip)
+        out = {"workload": desc, "value": round(steps / el, 3), "unit": "iterations/s", "ms_per_step": round(ms, 4),
+               "steps": steps, "step_ms": w.step_ms, "kkt_dim": ks.N, "nnz_L": int(info.nnzL), "setup_s": round(w.t_setup, 2),
+               "roofline": roof, "whole_step_frac_of_hbm_peak": whole,
+               "parity": None if parity is None else {k: parity[k] for k in ("rel_err_vs_oracle", "tol", "ok") if k in parity},
+               "cpu_baseline": cpu}
+        del w
+        return out
+    except Exception as ex:  # an extra, never a reason to lose the bench line
+        return {"error": repr(ex)[:300]}
+
+
+def l1_dropin_leg(hip, w, args):
+    """BASELINE config 3 through the STRICT drop-in boundary (L1, trait DirectLDLSolver): host buffers in, host buffers
+    out, exactly the calls directldlkktsolver.rs:143,174,253,297 make per interior-point iteration -- the values of K
+    handed over (the update_values stream of :143 / :245 as one chip_ldl_set_values: the engine reads them at refactor,
+    the Pardiso pattern of SURVEY a26), refactor(), then solve(x, b) for each of the 3 solves and for each refinement
+    round's correction (3 x (1 + 1) = 6 with the bench's fixed r = 1; the residuals in between are the CALLER's host work
+    in the reference and are not timed).  Every byte crosses PCIe: that is what this row measures."""
+    try:
+        ks = w.ks
+        K = ks.kkt_matrix()
+        vals = np.ascontiguousarray(ks.values())
+        maps = ks.maps()
+        dsigns = maps["dsigns"]
+        eps = float(ks.linear_solver_info().last_regularizer)
+        reg = vals.copy()   # the caller applies the static regulariser before refactor (:217-250)
+        dfull = np.asarray(maps["diag_full"], dtype=np.int64)
+        reg[dfull] += eps * np.asarray(dsigns, dtype=np.float64)
+        N = ks.N
+        t0 = time.time()
+        f = hip.HipDirectLDLSolver(hip.CscMatrix(N, N, K.colptr, K.rowval, reg), dsigns, hip.Settings.default(device=ks.settings.device),
+                                   perm=ks.perm)
+        t_setup = time.time() - t0
+        rng = np.random.default_rng(77)
+        bs = [rng.standard_normal(N) for _ in range(3)]
+        xs = [np.zeros(N) for _ in range(6)]
+        nsolve = 6
+
+        def step():
+            f.set_values(reg)
+            if not f.refactor():
+                raise RuntimeError("L1 refactor failed")
+            for k in range(nsolve):
+                f.solve(None, xs[k], bs[k % 3])
+
+        steps = max(3, min(args.steps, 10))
+        step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        el = time.perf_counter() - t0
+        # check: backward error of the raw LDL' solve against the same regularised K (scipy SpMV of the symmetric matrix),
+        # and the solution against the oracle's factorisation with the same permutation and pivot rule
+        import scipy.sparse as sp
+        Ku = sp.csc_matrix((reg, np.asarray(K.rowval, dtype=np.int64), np.asarray(K.colptr, dtype=np.int64)), shape=(N, N))
+        Kf = Ku + sp.triu(Ku, 1).T
+        res = bs[0] - Kf @ xs[0]
+        berr = float(np.max(np.abs(res)) / (float(np.max(np.abs(Kf).sum(axis=1))) * float(np.max(np.abs(xs[0]))) + float(np.max(np.abs(bs[0])))))
+        from oracle import oracle as orc
+        st0 = hip.Settings.default()
+        fo = orc.QDLDL(N, K.colptr, K.rowval, reg, perm=ks.perm, Dsigns=dsigns, regularize_eps=st0.dynamic_regularization_eps,
+                       regularize_delta=st0.dynamic_regularization_delta)
+        xo = fo.solve(bs[0])
+        err = relerr(xs[0], xo)
+        bytes_step = 8 * len(reg) + nsolve * 2 * 8 * N
+        del f, fo
+        return {"what": "config 3 through chip_ldl_set_values / chip_ldl_refactor / chip_ldl_solve with HOST buffers (pageable numpy "
+                        "arrays): per step 1 refactor + 6 solves, every operand over PCIe",
+                "value": round(steps / el, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+                "pcie_bytes_per_step": int(bytes_step), "pcie_GBs": round(bytes_step / (el / steps) / 1e9, 1),
+                "setup_s": round(t_setup, 2),
+                "backward_error": berr, "rel_err_vs_oracle_ldl_solve": err, "ok": bool(berr <= 1e-10),
+                "note": "raw LDL' solve of the statically regularised K (no refinement: that is the caller's loop at this boundary): "
+                        "backward error ||b - K x||inf / (||K||inf ||x||inf + ||b||inf) by an independent SpMV, and the solution "
+                        "against the oracle's factorisation of the same matrix with the same permutation (the pivots of the "
+                        "regularised zero rows are +-1e-8: forward errors of 1e-7 between two elimination orders are rounding)"}
+    except Exception as ex:
+        return {"error": repr(ex)[:300]}
+
+
 def launch_ranks(args):
     """stdlib launcher for --gpus N > 1 when no launcher set WORLD_SIZE: N subprocesses of this script, one per GPU,
     with the environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)"""
@@ -522,6 +661,16 @@ def main():
         gathered = [hip.DeviceArray(int(sum(counts))) for _ in range(3)]
     elapsed, prof = w.run(args.steps, args.warmup, args.profile_family, comm, gathered, counts)
     ir = w.ks.linear_solver_info().last_ir_iterations
+    # N > 1: the same steps once more with the OTHER exchange policy, so that the driver's curve can be read either way
+    # (SURVEY 8(e) says one all-gather per solve; the default gathers the step direction only)
+    other_policy = None
+    if comm is not None and world > 1:
+        w.gather_every_solve = not w.gather_every_solve
+        el2, _ = w.run(args.steps, args.warmup, 0, comm, gathered, counts)
+        other_policy = {"policy": "3 x all-gather per step (every solve's solution)" if w.gather_every_solve else
+                                  "1 x all-gather per step (the step direction: the last solve's solution)",
+                        "value": round(args.steps / el2, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * el2 / args.steps, 4)}
+        w.gather_every_solve = not w.gather_every_solve
 
     # ---- N > 1: every rank checks ITS shard against the oracle; the ranks reduce the verdict ----------------
     parity_sharded = None
@@ -640,7 +789,9 @@ def main():
                     "avg_launch_us": round(1e3 * prof["ms"] / prof["launches"], 2),
                     "kernel_ms_per_step": round(prof["ms"] / args.steps, 3), "whole_step": whole}
         parity = cpu = cpu_mt = c4 = None
+        extras = {}
         step_ms = getattr(w, "step_ms", None)
+        w_repeats = w.repeats  # (solves repeated at collect time after a fused launch timed out: 0 in a clean run)
         if world > 1:
             parity = parity_sharded
         elif not args.no_extras and workload == "c5":
@@ -652,6 +803,8 @@ def main():
             if args.cpu_steps != 0 and workload in ("c3", "c4"):
                 cpu_mt = mt_leg(w, ko)
             del ko
+            if workload == "c3" and args.workload == "auto":
+                extras["l1_dropin"] = l1_dropin_leg(hip, w, args)
             if workload == "c3" and args.workload == "auto":
                 # the N = 1 point of the sharded workload's strong-scaling curve: config 4 whole on this GPU
                 del w
@@ -669,6 +822,10 @@ def main():
                       "whole_step_frac_of_hbm_peak": round(B4["iter"] / (el4 / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                       "parity": par4,
                       "note": "the --gpus N > 1 lines run THIS workload sharded (strong scaling); this is their N = 1 base"}
+                del w4
+                # the other BASELINE configs and the strict drop-in boundary, compact (driver-visible in the default line)
+                extras["c2"] = extra_workload(hip, problems, "c2", args, device)
+                extras["c5"] = extra_workload(hip, problems, "c5", args, device)
         out = {
             "metric": baseline_metric(),
             "value": round(value, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
@@ -687,6 +844,9 @@ def main():
                                          int(sum(counts)))) if comm is not None else "none"},
             "step_ms": step_ms,
             "roofline": roof, "parity": parity, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt, "batched_c4": c4,
+            "c2": extras.get("c2"), "c5": extras.get("c5"), "l1_dropin": extras.get("l1_dropin"),
+            "other_exchange_policy": other_policy,
+            "fused_launch_repeats": int(w_repeats),
         }
         print(json.dumps(out))
         sys.stdout.flush()

@@ -504,11 +504,16 @@ class HipKKTSolver:
         _check(lib().chip_kkt_solve_dev_enqueue(self._h, C.c_void_p(x_ptr), C.c_void_p(z_ptr)), "solve_dev_enqueue")
 
     def collect(self):
-        """-> (update_ok, [solve_ok, ...]) of everything enqueued since the last collect; one synchronisation"""
+        """-> (update_ok, [solve_ok, ...]) of everything enqueued since the last collect; one synchronisation.
+        self.repeated_solves: indices (into that list) of solves whose fused launch timed out and that collect repeated
+        on the one-kernel-per-phase path -- their lhs held garbage until now: device work enqueued behind them that
+        consumed it (an all-gather, a dependent right-hand side) must be re-issued"""
         uok, n = C.c_int32(1), C.c_int32(0)
         sok = (C.c_int32 * 16)()
         _check(lib().chip_kkt_collect(self._h, C.byref(uok), C.byref(n), sok), "collect")
-        return bool(uok.value), [bool(sok[i]) for i in range(min(n.value, 16))]
+        cnt = min(n.value, 16)
+        self.repeated_solves = [i for i in range(cnt) if sok[i] == 2]
+        return bool(uok.value), [bool(sok[i]) for i in range(cnt)]
 
     def set_settings(self, settings):
         """the reference passes `settings` to update() / solve() on every call (kktsolvers/mod.rs:7-18)"""

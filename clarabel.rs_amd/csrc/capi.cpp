@@ -1147,16 +1147,19 @@ int32_t chip_kkt_collect(chip_kkt *h, int32_t *update_ok, int32_t *nsolves, int3
     bool suspect = false; // a timed-out launch leaves the barrier counters dirty for the launches queued behind it
     for (int sl : h->pend_slots) {
         int v;
+        bool repeated = false;
         if (sl < 0) v = -1 - sl;
         else {
             v = fused_verdict(h, sl);
             if (v == FUSED_TIMEOUT || suspect) {
                 suspect = true;
+                repeated = true;
                 v = fused_retry_unfused(h, sl);
             }
             if (v < 0) rc = v;
         }
-        if (solves_ok && n < 16) solves_ok[n] = v > 0 ? 1 : 0;
+        // (2: the lhs was garbage until this repeat -- whatever consumed it on the device must be re-issued)
+        if (solves_ok && n < 16) solves_ok[n] = v > 0 ? (repeated ? 2 : 1) : 0;
         n++;
     }
     h->pend_slots.clear();

@@ -242,8 +242,14 @@ int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_d
  *                               for; other systems run the synchronous solve and queue its verdict
  *   chip_kkt_collect          synchronises the stream once; *update_ok = verdict of the last enqueued update
  *                               (1 if none), *nsolves = solves enqueued since the last collect (at most 16
- *                               may be pending), solves_ok[i] their bools in order.  Returns CHIP_OK or a
- *                               negative chip_status. */
+ *                               may be pending), solves_ok[i] their verdicts in order: 0 = failed (the
+ *                               reference's false), 1 = ok, 2 = ok BUT REPEATED AT COLLECT TIME: the fused launch of
+ *                               that solve timed out (its workgroups were not all resident), so its lhs held garbage
+ *                               until collect repeated it on the one-kernel-per-phase path.  Device work that was
+ *                               enqueued behind such a solve and consumed its lhs -- an all-gather
+ *                               (chip_kkt_allgather_step), a right-hand side computed from it -- used the garbage and
+ *                               must be re-issued by the caller; the repeat itself read the right-hand side buffers
+ *                               as they were at collect time.  Returns CHIP_OK or a negative chip_status. */
 int32_t chip_kkt_update_enqueue(chip_kkt *h, const double *hsblocks_or_null);
 int32_t chip_kkt_solve_dev_enqueue(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_dev_or_null);
 int32_t chip_kkt_collect(chip_kkt *h, int32_t *update_ok, int32_t *nsolves, int32_t solves_ok[16]);

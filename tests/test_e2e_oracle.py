@@ -49,7 +49,14 @@ def test_json_fixture_hs35(oracle):
     examples/data/hs35.json): Hock-Schittkowski 35, optimum x = (4/3, 7/9, 4/9), f = 1/9"""
     import os
     from tests import json_problem
-    pr = json_problem.load(os.path.join(os.path.dirname(__file__), "golden", "hs35.json"))
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    pr = json_problem.load(os.path.join(gold, "hs35_reference.json"))  # byte-identical copy of the reference's file
+    assert pr["settings"]["direct_solve_method"] == "qdldl"  # (what the reference saved it with)
+    hand = json_problem.load(os.path.join(gold, "hs35.json"))  # the same problem entered by hand from its definition
+    for key in ("P", "A"):  # (same pattern; the reference's file carries its values with a last-bit rounding of its own)
+        assert np.array_equal(pr[key][0], hand[key][0]) and np.array_equal(pr[key][1], hand[key][1])
+        assert np.allclose(pr[key][2], hand[key][2], rtol=1e-14, atol=0.0)
+    assert np.allclose(pr["q"], hand["q"], rtol=1e-14) and np.allclose(pr["b"], hand["b"], rtol=1e-14) and pr["cones"] == hand["cones"]
     out = _run(oracle, pr)
     assert out["status"] == "Solved"
     assert np.linalg.norm(out["x"] - np.array([4.0 / 3.0, 7.0 / 9.0, 4.0 / 9.0])) <= 1e-6

@@ -467,6 +467,8 @@ def test_fused_solve_timeout_falls_back(hip, oracle, monkeypatch):
     rhs, lhs = _enqueue_three(hip, ks, pr, rng)
     uok, sok = ks.collect()
     assert uok and list(sok) == [True, True, True]
+    # every one of them is reported as repeated at collect time: consumers of its lhs must be re-issued
+    assert ks.repeated_solves == [0, 1, 2]
     for (drx, drz), l in zip(rhs, lhs):
         ko.setrhs(drx.numpy(), drz.numpy())
         ok, xo, zo = ko.solve()
@@ -1269,7 +1271,7 @@ def test_json_fixture_hs35_on_device(hip):
     import os
     from tests import ipm_driver as ipm
     from tests import json_problem
-    pr = json_problem.load(os.path.join(os.path.dirname(__file__), "golden", "hs35.json"))
+    pr = json_problem.load(os.path.join(os.path.dirname(__file__), "golden", "hs35_reference.json"))  # the reference's own file
     be = ipm.HipBackend(hip, pr["n"], pr["m"], pr["P"], pr["A"], pr["q"], pr["b"], pr["cones"])
     out = ipm.solve(be, pr["cones"], pr["q"], pr["b"])
     assert out["status"] == "Solved"

@@ -106,8 +106,8 @@ class Workload:
         # pivots finite and cones interior; solve: refinement residuals finite) are produced on the device
         # and collected with one synchronisation at the end of the step
         ks = self.ks
-        ks.update_scaling_dev(self.s_d.ptr, self.z_d.ptr)
-        ks.update_enqueue()
+        # (cones.update_scaling + kktsystem.update's KKT part, core/solver.rs:334-352, as one enqueue)
+        ks.update_scaled_enqueue(self.s_d.ptr, self.z_d.ptr)
         last = len(self.rhs) - 1
         for k, (rx, rz) in enumerate(self.rhs):
             exchange = comm is not None and (self.gather_every_solve or k == last)

@@ -500,6 +500,13 @@ class HipKKTSolver:
         hb = None if hsblocks is None else _f(hsblocks)
         _check(lib().chip_kkt_update_enqueue(self._h, None if hb is None else _pf(hb)), "update_enqueue")
 
+    def update_scaled_enqueue(self, s_ptr, z_ptr, mu=1.0, strategy=0, hsblocks=None):
+        """cones.update_scaling + the KKT update as ONE enqueue (core/solver.rs:334-352), verdicts with collect()"""
+        hb = None if hsblocks is None else _f(hsblocks)
+        _check(lib().chip_kkt_update_scaled_enqueue(self._h, C.c_void_p(s_ptr), C.c_void_p(z_ptr), C.c_double(mu),
+                                                    C.c_int32(strategy), None if hb is None else _pf(hb)),
+               "update_scaled_enqueue")
+
     def solve_dev_enqueue(self, x_ptr, z_ptr):
         _check(lib().chip_kkt_solve_dev_enqueue(self._h, C.c_void_p(x_ptr), C.c_void_p(z_ptr)), "solve_dev_enqueue")
 

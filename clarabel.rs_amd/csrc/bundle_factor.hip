@@ -753,12 +753,15 @@ __global__ __launch_bounds__(FFWG) void k_bundle_factor_flat(LdlView v, BundleVi
     const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
     const int e0 = v.Lp[s0], nE = v.Lp[s1] - e0;
     double *Ls = (double *)ff_smem, *Ds = Ls + nE; // (contiguous: a record's target addresses either)
-    const double eps = v.eps_ptr ? v.eps_ptr[0] : 0.0;
+    bool eps_on;
+    __shared__ double s_eps;
+    (void)static_eps(v, &eps_on, &s_eps);
     const int *lv = bv.blvl + bv.blvl_ptr[b];
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
     const int *tp = v.fu_ptr + bv.blvl_ptr[b];
     for (int q = tid; q < nE; q += FFWG) Ls[q] = 0.0; // (fill-in slots stay zero)
     __syncthreads();
+    const double eps = s_eps;
     {
         const int ub = v.Up[s0], ue = v.Up[s1];
         for (int u = ub + tid; u < ue; u += FFWG) {
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(FFWG) void k_bundle_factor_flat(LdlView v, BundleVi
             const double val = v.Ux[u];
             if (slot == 0xFFFFu) {
                 const int j = (int)v.Urow16[u];
-                Ds[j] = v.eps_ptr ? (v.dsigns[s0 + j] == 1 ? val + eps : val - eps) : val;
+                Ds[j] = eps_on ? (v.dsigns[s0 + j] == 1 ? val + eps : val - eps) : val;
             } else {
                 Ls[slot] = val;
             }
@@ -822,10 +825,21 @@ __global__ __launch_bounds__(FFWG) void k_bundle_factor_flat(LdlView v, BundleVi
         if (tid == 0 && sacc != 0.0) atomicAdd(&fold.acc[fold_acc_index(2, 0, b % FOLD_SLOTS)], sacc);
     }
     for (int q = tid; q < nE; q += FFWG) v.Lx[e0 + q] = Ls[q];
+    static_eps_epilogue(v, eps);
 }
 __global__ void k_fold_top_pivot(LdlView v, FoldView fold) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double d = v.D[fold.NF];
+    // the top column's initial pivot: as k_scatter_init left it in D, or -- fast preparation (fold.top_k) -- K's diagonal
+    // entry shifted by the static regulariser the bundle factorisation published (LdlView::eps_out).
+    // (Folding this into the bundle kernel as a last-arriver epilogue was measured: inlined it cost that kernel 40 %,
+    // out of line 170 %, although one thread runs it once.)
+    double d;
+    if (fold.top_k) {
+        d = fold.top_k[0];
+        if (v.eps_out) d = fold.top_sign == 1 ? d + v.eps_out[0] : d - v.eps_out[0];
+    } else {
+        d = v.D[fold.NF];
+    }
     for (int q = 0; q < FOLD_SLOTS; ++q) {
         double *a = &fold.acc[fold_acc_index(2, 0, q)];
         d -= *a;

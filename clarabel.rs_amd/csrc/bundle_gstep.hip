@@ -694,7 +694,9 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
         s_tp[tid] = dsc[32 + tid]; // first update record of every level, then the end
         s_ln[tid] = dsc[48 + tid]; // first node of every level (bundle-local), then the node count
     }
-    const double eps = v.eps_ptr ? v.eps_ptr[0] : 0.0;
+    bool eps_on;
+    __shared__ double s_eps;
+    (void)static_eps(v, &eps_on, &s_eps);
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
         uval[u] = v.Ux[ub + usrc[u]];
@@ -711,22 +713,33 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
         }
     };
     request(dsc[32], dsc[33]);
-    int tq = -2, tnode = -1, ti = 0, tj = 0;
+    int tq = -2, tnode = -1, ti = 0, tj = 0, tks = -1, tsg = 0;
     if (grp >= 0 && tid < np) {
         while ((ti + 1) * (ti + 2) / 2 <= tid) ++ti;
         tj = tid - ti * (ti + 1) / 2;
         const int *gt = gs.gtop + (size_t)grp * GS_GTOP;
         tnode = gt[ti];
         tq = ti == tj ? -2 : gt[16 + ti * 8 + tj];
+        tks = gt[80 + ti * 8 + tj]; // position of K(top_i, top_j) in V, -1: structurally zero
+        tsg = gt[144 + ti];
     }
-    double ktt0 = 0.0; // K_tt entry (scattered into D / the top-top slots of Lx by k_scatter_init, static regulariser included)
-    if (grp >= 0 && tid < np) ktt0 = ti == tj ? v.D[tnode] : (tq >= 0 ? v.Lx[tq] : 0.0);
+    // K_tt entry: fast preparation -- straight from K (+- eps on the diagonal); otherwise as k_scatter_init left it in
+    // D / the top-top slots of Lx (static regulariser included)
+    double ktt0 = 0.0;
+    if (grp >= 0 && tid < np) {
+        if (v.eps_slots) {
+            ktt0 = tks >= 0 ? v.Ux[tks] : 0.0; // (+- eps on the diagonal: applied by the last arriver, below)
+        } else {
+            ktt0 = ti == tj ? v.D[tnode] : (tq >= 0 ? v.Lx[tq] : 0.0);
+        }
+    }
     if (tid < 36) A[tid] = 0.0;
     __syncthreads();
+    const double eps = s_eps;
     stamp();
     // ---- the bundle's U entries (initial values of its columns) into LDS ----
     auto place = [&](unsigned short slot, unsigned short row, double val) {
-        if (slot == 0xFFFFu) Ds[row] = v.eps_ptr ? (L.sg[row] == 1 ? val + eps : val - eps) : val;
+        if (slot == 0xFFFFu) Ds[row] = eps_on ? (L.sg[row] == 1 ? val + eps : val - eps) : val;
         else if (slot != 0xFFFEu) Ls[slot] = val;
     };
 #pragma unroll
@@ -782,6 +795,7 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
     for (int u = 0; u < LF; ++u)
         if (tid + u * TW < nE) gs.gsl[e0 + tid + u * TW] = Ls[lsrcr[u]];
     for (int p = tid + LF * TW; p < nE; p += TW) gs.gsl[e0 + p] = Ls[gs.lsrc[e0 + p]];
+    static_eps_epilogue(v, eps);
     stamp();
     if (grp < 0) return;
     // ---- this bundle's share of the Schur complement of its group's top: a column's entries in the top rows are its
@@ -847,6 +861,7 @@ __global__ __launch_bounds__(GF_TW) void k_gstep_factor(LdlView v, BundleView bv
     // ---- the last arriver: K_tt minus the shares in bundle order, then the k x k LDL' ----
     if (tid < np) {
         double a = ktt0;
+        if (v.eps_slots && ti == tj && eps_on) a = tsg == 1 ? a + eps : a - eps;
         for (int q = gb0; q < gb0 + gnb; ++q) {
             const int *addr = gs.fmsg + ((size_t)q * 36 + tid) * 4;
             msg_v4i m = msg_load(addr);

@@ -826,6 +826,36 @@ int32_t chip_kkt_update_enqueue(chip_kkt *h, const double *hsblocks_or_null) {
     return CHIP_OK;
 }
 
+// solver.rs:334-352 as ONE enqueue: cones.update_scaling(s, z, mu, strategy), then kktsystem.update's KKT part
+// (get_Hs scatter, static regularisation, numeric refactor).  With Zero / Nonnegative / SecondOrder cones only, the
+// scaling and the Hs / sparse-cone writes of a cone run in one launch (dev::sym_scale_write) and -- where the bundle
+// factorisation can take over the preparation work (Engine::fast_prep_ok) -- nothing else is launched ahead of it.
+int32_t chip_kkt_update_scaled_enqueue(chip_kkt *h, const double *s_dev, const double *z_dev, double mu, int32_t strategy,
+                                       const double *hsblocks_or_null) {
+    if (!h || !s_dev || !z_dev) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    const bool sym_only = !(h->has_hostHs || h->ns3.ncones || h->gpw.ncones || h->psd.ncones);
+    if (!sym_only || !E.st.static_regularization_enable || switches().no_step_kernel) {
+        int rc = chip_kkt_update_scaling_dev(h, s_dev, z_dev, mu, strategy);
+        if (rc < 0) return rc;
+        return chip_kkt_update_enqueue(h, hsblocks_or_null);
+    }
+    h->scaling_gen += 1; // (no memset of the flag: a failure is recognised by its generation)
+    h->soc.fail_gen = h->scaling_gen;
+    h->psd.fail_gen = h->scaling_gen;
+    h->scaling_pending_check = h->soc.ncones > 0;
+    dev::sym_scale_write(E.stream, h->soc, h->nn_rows, h->nn_hsidx, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam, h->mapHs, E.Kx,
+                         E.diag_slots(), (E.fast_prep_ok && !switches().no_fast_prep) ? E.mb_dev->status : nullptr);
+    CHIP_HIP(hipGetLastError());
+    int rc = E.refactor_enqueue(true, nullptr, h->static_diag_max, E.fast_prep_ok && !switches().no_fast_prep);
+    if (rc) return rc;
+    h->pend_update = 1;
+    E.factored = true; // provisionally: the verdict arrives with chip_kkt_collect
+    return CHIP_OK;
+}
+
 int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *rhsz_dev) {
     if (!h) return CHIP_ERR_ARG;
     Engine &E = h->E;

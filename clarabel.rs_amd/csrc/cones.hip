@@ -207,6 +207,44 @@ __device__ __forceinline__ void soc_write_kkt_body(const SocView &v, double *Kx,
     }
 }
 
+// update_scaling and the KKT update's get_Hs scatter of the same rows in ONE launch (solver.rs:334-352 calls them back to
+// back): a cone's workgroup scales it and writes its K entries while w is hot; a slab of Nonnegative rows reads s, z once
+// and writes lambda, w and -w^2.  status: the refactor's 4 status words, cleared here (its preparation launch is skipped).
+__global__ __launch_bounds__(WG) void k_sym_scale_write(SocView v, const int *__restrict__ nn_rows,
+                                                        const int *__restrict__ nn_hsidx, int nn,
+                                                        const double *__restrict__ sv, const double *__restrict__ zv,
+                                                        double *w, double *lam, const int *__restrict__ mapHs, double *Kx,
+                                                        unsigned long long *dslots, int *status) {
+    __shared__ double red[16];
+    if (status && blockIdx.x == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
+    if ((int)blockIdx.x < v.ncones) {
+        soc_update_scaling_body(v, sv, zv, blockIdx.x, red);
+        __syncthreads(); // (w and the cone's state, written by this workgroup, are read back below)
+        soc_write_kkt_body(v, Kx, dslots, blockIdx.x);
+        return;
+    }
+    const int nblk = gridDim.x - v.ncones, blk = blockIdx.x - v.ncones;
+    double mx = 0.0;
+    bool nan = false;
+    for (int t = blk * WG + threadIdx.x; t < nn; t += nblk * WG) {
+        const int r = nn_rows[t];
+        const double s = sv[r], z = zv[r];
+        lam[r] = sqrt(s * z);
+        const double wi = sqrt(s / z);
+        w[r] = wi;
+        const double h = wi * wi;
+        Kx[mapHs[nn_hsidx[t]]] = -h;
+        if (h != h) nan = true;
+        else mx = fmax(mx, h);
+    }
+    if (dslots) {
+        mx = block_max(mx, red);
+        int *nanflag = (int *)(dslots + (size_t)NRM_SLOTS * NRM_STRIDE);
+        if (threadIdx.x == 0) fold_norm(dslots, nanflag, mx, false, blockIdx.x);
+        if (nan) *nanflag = 1;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Exponential / Power cones: 3x3 closed forms, one thread per cone.
 // state per cone (18 doubles): Hs[6] | H_dual[6] | grad[3] | z[3]; packed triu
@@ -1763,6 +1801,12 @@ void sym_update_scaling(hipStream_t s, const SocView &v, const int *nn_rows, int
                         const double *zv, double *w, double *lam) {
     const int grid = v.ncones + nn_blocks(nn);
     if (grid) k_sym_update_scaling<<<grid, WG, 0, s>>>(v, nn_rows, nn, sv, zv, w, lam);
+}
+void sym_scale_write(hipStream_t s, const SocView &v, const int *nn_rows, const int *nn_hsidx, int nn, const double *sv,
+                     const double *zv, double *w, double *lam, const int *mapHs, double *Kx, unsigned long long *dslots,
+                     int *status_or_null) {
+    const int grid = v.ncones + nn_blocks(nn);
+    if (grid) k_sym_scale_write<<<grid, WG, 0, s>>>(v, nn_rows, nn_hsidx, nn, sv, zv, w, lam, mapHs, Kx, dslots, status_or_null);
 }
 void sym_write_kkt(hipStream_t s, const SocView &v, const int *nn_rows, const int *nn_hsidx, int nn, const double *w,
                    const int *mapHs, double *Kx, unsigned long long *dslots) {

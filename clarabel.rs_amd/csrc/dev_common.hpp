@@ -181,6 +181,38 @@ __device__ __forceinline__ double block_max(double v, double *red) {
     return t;
 }
 
+// the static regulariser of this refactor (directldlkktsolver.rs:324-329): the device scalar of the preparation launch,
+// or -- fast preparation -- reduced by every wavefront itself from the 64 slotted maxima (+ NaN flag) of |diag K|
+// (fast preparation: wave 0 alone reads the slots -- a thousand workgroups x all their waves on the same 64 lines is a hot
+// spot -- and hands eps to the others through *share, an LDS word; the caller's next __syncthreads() publishes it: use
+// static_eps_get() after that barrier)
+__device__ __forceinline__ double static_eps(const LdlView &v, bool *on, double *share) {
+    if (v.eps_slots) {
+        *on = true;
+        if (threadIdx.x >= 64) return 0.0;
+        const int lane = threadIdx.x & 63;
+        // (plain loads: the slots were written by an earlier launch on the stream)
+        double m = lane < NRM_SLOTS ? __longlong_as_double((long long)v.eps_slots[(size_t)lane * NRM_STRIDE]) : 0.0;
+        const int nanflag = *(const int *)(v.eps_slots + (size_t)NRM_SLOTS * NRM_STRIDE);
+        m = wave_max_all(m);
+        m = fmax(m, v.eps_static_max);
+        if (nanflag || v.eps_static_max != v.eps_static_max) m = __longlong_as_double(0x7ff8000000000000ll);
+        const double eps = v.eps_c + v.eps_prop * m;
+        if (lane == 0) *share = eps;
+        return eps;
+    }
+    *on = v.eps_ptr != nullptr;
+    const double eps = v.eps_ptr ? v.eps_ptr[0] : 0.0;
+    if (threadIdx.x == 0) *share = eps;
+    return eps;
+}
+// workgroup 0 of the bundle factorisation, fast preparation: publish eps, clear the other set of slots
+__device__ __forceinline__ void static_eps_epilogue(const LdlView &v, double eps) {
+    if (!v.eps_slots || blockIdx.x != 0) return;
+    if (threadIdx.x == 0 && v.eps_out) *v.eps_out = eps;
+    if (v.eps_clear && threadIdx.x <= NRM_SLOTS) v.eps_clear[(size_t)threadIdx.x * NRM_STRIDE] = 0ull;
+}
+
 // qdldl.rs:645-665: sign-based dynamic regularisation, then invert.
 __device__ __forceinline__ double pivot_rule(const LdlView &v, int j, double d) {
     const double sign = (double)v.dsigns[j];

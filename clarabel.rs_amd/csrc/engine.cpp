@@ -314,6 +314,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         fold.scol = a4;
         fold.sslot = a5;
         fold.acc = ts;
+        if (S.nfold == 1 && !S.dsigns.empty()) h_top_sign = (int)S.dsigns[(size_t)S.NF];
     }
     if (S.topblk > 0) {
         int *rs = nullptr, *ls = nullptr;
@@ -459,6 +460,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                         for (int t = 0; t < kk; t++) {
                             gt[t] = S.gf_node[(size_t)base + t];
                             gt[8 + t] = h_perm[(size_t)gt[t]];
+                            gt[144 + t] = S.dsigns.empty() ? 1 : (int)S.dsigns[(size_t)gt[t]];
                             for (int j = 0; j < 8; j++) gt[16 + t * 8 + j] = S.gf_tt[(size_t)g * 64 + t * 8 + j];
                             for (i32 q = S.gf_sp[(size_t)base + t]; q < S.gf_sp[(size_t)base + t + 1]; q++)
                                 gt[80 + t * 8 + S.gf_scol[(size_t)q]] = S.gf_sslot[(size_t)q];
@@ -583,8 +585,16 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         ir_res = mb_dev->ring; // (address arithmetic only)
         ir_res_host = mb_host->ring;
     }
-    if ((rc = alloc(&dslot_dev, (size_t)NRM_SET_WORDS))) return rc;
-    CHIP_HIP(hipMemset(dslot_dev, 0, (size_t)NRM_SET_WORDS * sizeof(unsigned long long)));
+    if ((rc = alloc(&dslot_dev, (size_t)2 * NRM_SET_WORDS))) return rc;
+    CHIP_HIP(hipMemset(dslot_dev, 0, (size_t)2 * NRM_SET_WORDS * sizeof(unsigned long long)));
+    // fast preparation (refactor_enqueue): the grouped-fold step factorisation, or an arrow with ONE top column whose
+    // only top-top entry of K is its diagonal, factored by the flat bundle kernel
+    fast_prep_ok = gstep_factor_on || (ir_fused && fold.k == 1 && factor_lds_doubles > 0 && fu_rec != nullptr && nfill == 0 &&
+                                       nnzK - nnzU == 1 && nsn == 0);
+    if (fast_prep_ok && fold.k == 1) {
+        if ((rc = alloc(&fold_cnt, (size_t)32))) return rc;
+        CHIP_HIP(hipMemset(fold_cnt, 0, 32 * sizeof(int)));
+    }
     if ((rc = alloc(&nrm_dev, (size_t)NRM_SETS * NRM_SET_WORDS))) return rc;
     CHIP_HIP(hipMemset(nrm_dev, 0, (size_t)NRM_SETS * NRM_SET_WORDS * sizeof(unsigned long long)));
     CHIP_HIP(hipHostMalloc((void **)&nrm_host, 3 * NRM_SET_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
@@ -692,10 +702,26 @@ int Engine::refactor(bool static_reg, const int *diag_idx_dev, double static_dia
     if (rc) return rc;
     return refactor_collect();
 }
-int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double static_diag_max) {
+int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double static_diag_max, bool status_cleared) {
     dev::LdlView v = view();
     const double *eps_ptr = nullptr;
-    if (static_reg) {
+    // fast preparation: eps from the slots inside the bundle factorisation, the top's initial values read from K there,
+    // status words cleared by the cone kernel -- no eps / scatter launches (and no pivot launch for a single top column)
+    const bool fast = fast_prep_ok && static_reg && !diag_idx_dev && status_cleared && !switches().no_step_kernel && !switches().no_fast_prep;
+    dev::FoldView ffold = fold;
+    if (fast) {
+        v.eps_slots = diag_slots();
+        v.eps_clear = dslot_dev + (size_t)(slot_parity ^ 1) * NRM_SET_WORDS;
+        v.eps_c = st.static_regularization_constant;
+        v.eps_prop = st.static_regularization_proportional;
+        v.eps_static_max = static_diag_max;
+        v.eps_out = &mb_dev->eps;
+        slot_parity ^= 1; // (the next update's cone kernels write the set this launch clears)
+        if (fold.k == 1) {
+            ffold.top_k = Kx + nnzU;
+            ffold.top_sign = h_top_sign;
+        }
+    } else if (static_reg) {
         if (diag_idx_dev)
             dev::diag_absmax_eps(stream, Kx, diag_idx_dev, N, st.static_regularization_constant,
                                  st.static_regularization_proportional, (double *)mb_dev);
@@ -707,8 +733,9 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     v.eps_ptr = eps_ptr;
     // entries with both ends in the top -> the top columns of L / D; clears the status words.  The bundle
     // columns take their initial values straight from the U rows inside k_bundle_factor.
-    dev::scatter_init(stream, Kx + nnzU, v2l, (int)(nnzK - nnzU), (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
-                      mb_dev->status);
+    if (!fast)
+        dev::scatter_init(stream, Kx + nnzU, v2l, (int)(nnzK - nnzU), (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
+                          mb_dev->status);
     const bool top_folded = fold.k == 1 || gfold.ng > 0;
     prof_begin(PF_BFACTOR);
     if (gstep_factor_on && !switches().no_step_kernel) {
@@ -743,14 +770,14 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         }
     } else {
         gstep_vals_valid = false;
-        const int lrc = dev::bundle_factor(stream, v, bundles, fold, factor_lds_doubles); // everything below the cut: one launch
+        const int lrc = dev::bundle_factor(stream, v, bundles, ffold, factor_lds_doubles); // everything below the cut: one launch
         prof_end(PF_BFACTOR);
         if (lrc) {
             set_error(hip_err((hipError_t)lrc, "bundle factorisation launch"));
             return CHIP_ERR_HIP;
         }
         // single top column: pivot accumulated by the bundles; grouped fold: the k x k tops from the bundles' Schur shares
-        if (fold.k == 1) dev::fold_top_pivot(stream, v, fold);
+        if (fold.k == 1) dev::fold_top_pivot(stream, v, ffold); // (fast preparation: reads the top's K entry itself)
         if (gfold.ng > 0) dev::gfold_top_factor(stream, v, bundles, gfold);
     }
     const bool use_chain = !switches().no_factor_chain;

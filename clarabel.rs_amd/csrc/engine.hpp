@@ -163,10 +163,18 @@ struct Engine {
     // Kx) or, with diag_idx_dev == nullptr, taken from the slotted maxima the cone kernels left in
     // diag_slots() combined with static_diag_max (the part of the diagonal no cone kernel writes)
     int refactor(bool static_reg, const int *diag_idx_dev, double static_diag_max = 0.0);
-    int refactor_enqueue(bool static_reg, const int *diag_idx_dev, double static_diag_max);
+    // status_cleared: the caller's cone kernel has cleared the status words (dev::sym_scale_write); together with
+    // fast_prep_ok and slotted maxima this skips the preparation launches (eps, scatter) -- "fast preparation"
+    int refactor_enqueue(bool static_reg, const int *diag_idx_dev, double static_diag_max, bool status_cleared = false);
     int refactor_collect();
-    unsigned long long *diag_slots() const { return dslot_dev; }
-    unsigned long long *dslot_dev = nullptr; // NRM_SLOTS slotted maxima of |diag| + one NaN flag line
+    // the set of slots the cone kernels of the NEXT update write and its refactor reads (two sets: with the fast
+    // preparation the bundle factorisation itself reduces the current set and clears the other one)
+    unsigned long long *diag_slots() const { return dslot_dev + (size_t)slot_parity * NRM_SET_WORDS; }
+    unsigned long long *dslot_dev = nullptr; // 2 x (NRM_SLOTS slotted maxima of |diag| + one NaN flag line)
+    int slot_parity = 0;
+    bool fast_prep_ok = false; // the bundle factorisation can do the preparation launches' work itself (engine.cpp)
+    int *fold_cnt = nullptr;   // arrival counter of the flat bundle factorisation's last-arriver top pivot
+    int h_top_sign = 1;        // Dsigns of the single folded top column
     // values in the caller's order <-> the device's T order
     int upload_values(const double *host_nzval);
     int download_values(double *host_nzval);

@@ -24,6 +24,14 @@ struct LdlView {
     const int *Up, *Ucol;
     const double *Ux;
     const double *eps_ptr; // static regulariser (device scalar) applied to the diagonal while it is read; nullptr: none
+    // ... or, eps_slots != nullptr (the refactor's "fast preparation": no eps / scatter launches ahead of the bundle
+    // factorisation), computed by every workgroup itself from the slotted maxima of |diag K| the cone kernels left:
+    // eps = eps_c + eps_prop * max(eps_static_max, slots); workgroup 0 stores it to eps_out and clears the OTHER set
+    // of slots (eps_clear) for the next update
+    const unsigned long long *eps_slots;
+    unsigned long long *eps_clear;
+    double eps_c, eps_prop, eps_static_max;
+    double *eps_out;
     // bundles + folded top only (else nullptr): 16-bit bundle-local row indices parallel to Li / Ucol for the
     // bundle part (host.hpp: Symbolic::Li16); mirror_rows: the factorisation keeps the row-major copy Rx
     // up to date (the fused solve kernel does not read it)
@@ -58,6 +66,11 @@ struct FoldView {
     // x FOLD_SLOTS slots, one 128-byte line per slot -- a thousand bundles adding to ONE address would
     // serialise at ~13 ns each right at the tail of the launch
     double *acc;
+    // fast preparation, k == 1: the top's diagonal entry of K (its initial pivot; sign top_sign) is read by the LAST
+    // workgroup of the bundle factorisation to arrive at cnt, which then applies the pivot rule itself
+    const double *top_k;
+    int *cnt;
+    int top_sign;
 };
 // GROUPED fold (host.hpp: Symbolic::gf_*): a forest of small trees, each with a top of at most 8 nodes that is
 // folded into the bundle kernels of ITS tree.  ng == 0: unused.  Only k_bundle_ir, k_bundle_factor and
@@ -183,7 +196,7 @@ void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, con
 constexpr int GS_MAXL = 14;          // elimination levels inside a bundle the step kernels handle
 constexpr int GS_LST = GS_MAXL + 2;
 constexpr int GS_DESC = 64;          // ints per bundle descriptor (two 128-byte lines)
-constexpr int GS_GTOP = 144;         // ints per group: top table
+constexpr int GS_GTOP = 152;         // ints per group: top table
 constexpr int GS_MV = 12;            // messages per (bundle, phase slot): 8 shares of the top rows, the bundle's ||e||inf, ||b||inf
 struct GStepView {
     int lr, ur, nr;               // register slots a thread needs: ceil(max L entries / 256), ceil(max U entries / 256),
@@ -199,7 +212,7 @@ struct GStepView {
     const int *desc;
     // per group: [0, 8) node of top row t (final numbering, -1 beyond k), [8, 16) its index in the caller's order,
     // [16, 80) CSC slot of L(top_i, top_j) at i * 8 + j (-1: structurally zero / j >= i), [80, 144) position in V of
-    // K(top_i, top_c) at i * 8 + c (-1: zero)
+    // K(top_i, top_c) at i * 8 + c (-1: zero), [144, 152) Dsigns of the top rows
     const int *gtop;
     const unsigned short *lsrc;   // gs position -> CSC slot of the value, relative to the bundle's first slot
     const unsigned int *lij;      // gs position -> (row16 << 16) | column16, bundle-local; row >= nloc: top row nloc + t
@@ -415,6 +428,12 @@ void sym_update_scaling(hipStream_t s, const SocView &v, const int *nn_rows, int
                         const double *zv, double *w, double *lam);
 void sym_write_kkt(hipStream_t s, const SocView &v, const int *nn_rows, const int *nn_hsidx, int nn, const double *w,
                    const int *mapHs, double *Kx, unsigned long long *dslots);
+// both in one launch (solver.rs:334-352: cones.update_scaling, then the KKT update's get_Hs scatter): every workgroup
+// scales its cone / slab and writes its K entries at once; status_or_null: the 4 status words of the refactor that
+// follows are cleared here (its own preparation launch is skipped)
+void sym_scale_write(hipStream_t s, const SocView &v, const int *nn_rows, const int *nn_hsidx, int nn, const double *sv,
+                     const double *zv, double *w, double *lam, const int *mapHs, double *Kx, unsigned long long *dslots,
+                     int *status_or_null);
 // step / rhs operations of the symmetric cones (Zero rows, Nonnegative rows, SecondOrder cones)
 // Exponential / Power cones either side of the solve (expcone.rs:129-181, powcone.rs:128-180)
 void ns3_affine_ds(hipStream_t s, const Ns3View &v, double *ds, const double *sv);

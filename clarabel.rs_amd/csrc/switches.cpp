@@ -46,6 +46,7 @@ const Entry TABLE[] = {
     {"CHIP_IR_DEBUG", Entry::INT, SW(ir_debug), 0},
     {"CHIP_IR_DEBUG_FILE", Entry::STR, SW(ir_debug_file), 0},
     {"CHIP_NO_STEP_KERNEL", Entry::FLAG, SW(no_step_kernel), 0},
+    {"CHIP_NO_FAST_PREP", Entry::FLAG, SW(no_fast_prep), 0},
     {"CHIP_SN_XB_CAP", Entry::INT, SW(sn_xb_cap), 0},
     {"CHIP_SN_DEBUG", Entry::INT, SW(sn_debug), 0},
     {"CHIP_NO_SPLITK", Entry::FLAG, SW(no_splitk), 0},

@@ -45,6 +45,7 @@ struct Switches {
     int ir_debug = 0;               // CHIP_IR_DEBUG: 1 = stamps of two workgroups on stderr, 2 = all workgroups -> file
     std::string ir_debug_file;      // CHIP_IR_DEBUG_FILE
     bool no_step_kernel = false;    // CHIP_NO_STEP_KERNEL: the grouped-fold step kernels of round 4 off
+    bool no_fast_prep = false;      // CHIP_NO_FAST_PREP: the refactor keeps its preparation launches (eps, scatter, top pivot)
     // ---- supernode kernels (snode.hip) ----
     int sn_xb_cap = 0;              // CHIP_SN_XB_CAP (0: default)
     int sn_debug = 0;               // CHIP_SN_DEBUG

@@ -251,6 +251,13 @@ int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_d
  *                               must be re-issued by the caller; the repeat itself read the right-hand side buffers
  *                               as they were at collect time.  Returns CHIP_OK or a negative chip_status. */
 int32_t chip_kkt_update_enqueue(chip_kkt *h, const double *hsblocks_or_null);
+/* chip_kkt_update_scaling_dev + chip_kkt_update_enqueue as ONE enqueue (core/solver.rs:334-352 calls
+ * cones.update_scaling and kktsystem.update back to back): with Zero / Nonnegative / SecondOrder cones the scaling
+ * and the Hs / sparse-cone writes of a cone run in one launch and the refactor's preparation launches are folded
+ * into the bundle factorisation; other cone kinds take the two calls as they are.  Verdicts (cones interior, pivots
+ * finite) with chip_kkt_collect. */
+int32_t chip_kkt_update_scaled_enqueue(chip_kkt *h, const double *s_dev, const double *z_dev, double mu, int32_t strategy,
+                                       const double *hsblocks_or_null);
 int32_t chip_kkt_solve_dev_enqueue(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_dev_or_null);
 int32_t chip_kkt_collect(chip_kkt *h, int32_t *update_ok, int32_t *nsolves, int32_t solves_ok[16]);
 /* KKTSolver::solve / ::update receive `settings: &CoreSettings` on EVERY call in the reference

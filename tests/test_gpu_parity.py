@@ -933,6 +933,55 @@ def test_grouped_fold_ragged_forest(hip, oracle, late, monkeypatch):
     assert ks2.work_model()["fold_groups"] == 0
 
 
+@pytest.mark.parametrize("which", ["arrow", "forest", "qp", "expcone"])
+def test_update_scaled_enqueue_matches_the_two_calls(hip, oracle, which):
+    """chip_kkt_update_scaled_enqueue = cones.update_scaling + the KKT update as one enqueue (core/solver.rs:334-352): the
+    fused cone launch and -- where the bundle factorisation takes over the preparation work (an arrow with one top
+    column: config 3's shape; a grouped fold) -- the launch sequence without eps / scatter / pivot launches must give
+    the same K values, the same static regulariser, the same pivots' bookkeeping and solutions as the two calls, twice
+    in a row (the slotted maxima alternate between two sets), and match the oracle"""
+    if which == "arrow":
+        pr = problems.portfolio_socp(12, 300, seed=3)
+    elif which == "forest":
+        parts = [problems.portfolio_socp(2 + (i % 3), 120 + 40 * (i % 4), seed=100 + i) for i in range(14)]
+        pr = problems.blockdiag(parts)
+    elif which == "qp":
+        pr = problems.random_qp(3000, 6000, band=20, seed=1)
+    else:
+        pr = problems.mixed_conic(nexp=20, npow=10, nsoc=3, socdim=9, nn=30, seed=11)  # (other cone kinds: the two calls as they are)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    ks2, _, _ = _solvers(hip, oracle, pr)
+    rng = np.random.default_rng(9)
+    s_d, z_d = hip.DeviceArray(pr["s"]), hip.DeviceArray(pr["z"])
+    for rep in range(3):
+        s = pr["s"] * (1.0 + 0.1 * rep)
+        z = pr["z"] * (1.0 + 0.05 * rep)
+        s_d.copy_from(s)
+        z_d.copy_from(z)
+        ks.update_scaled_enqueue(s_d.ptr, z_d.ptr)
+        uok, sok = ks.collect()
+        assert uok and sok == []
+        assert ks2.update_scaling(s, z) and ks2.update()
+        assert cones.update_scaling(s, z) and ko.update()
+        assert relerr(ks.values(), ks2.values()) == 0.0
+        assert relerr(ks.values(), ko.kkt.nzval) <= 1e-13
+        i1, i2 = ks.linear_solver_info(), ks2.linear_solver_info()
+        assert i1.last_regularizer == i2.last_regularizer
+        assert abs(i1.last_regularizer - ko.regularizer) <= 1e-20 + 1e-12 * ko.regularizer
+        assert i1.regularize_count == i2.regularize_count and i1.positive_inertia == i2.positive_inertia
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        x, zz, x2, z2 = np.zeros(pr["n"]), np.zeros(pr["m"]), np.zeros(pr["n"]), np.zeros(pr["m"])
+        ks.setrhs(rx, rz)
+        assert ks.solve(x, zz)
+        ks2.setrhs(rx, rz)
+        assert ks2.solve(x2, z2)
+        ko.setrhs(rx, rz)
+        ok, xo, zo = ko.solve()
+        assert ok
+        assert relerr(np.concatenate([x, zz]), np.concatenate([xo, zo])) <= TOL
+        assert relerr(np.concatenate([x, zz]), np.concatenate([x2, z2])) <= 1e-10
+
+
 def test_parity_c5_24_cliques(hip, oracle):
     """BASELINE config 5's shape with 24 cliques of PSD(50) + 24 sparse SOC(51) -- the largest instance the
     scalar oracle factors in well under a minute (the full 200-clique instance takes it ~10 minutes);

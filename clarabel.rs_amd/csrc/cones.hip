@@ -39,12 +39,16 @@ __device__ __forceinline__ double block_norm_tail(const double *x, int n, double
 // one cone each, the following ones a slab of Nonnegative rows (nonnegativecone.rs:77-90)
 __device__ __forceinline__ void soc_update_scaling_body(const SocView &v, const double *__restrict__ sv,
                                                         const double *__restrict__ zv, int c, double *red);
+template <bool KKT>
+__device__ __forceinline__ bool soc_scaling_reg(const SocView &v, const double *__restrict__ sv, const double *__restrict__ zv,
+                                                int c, double *red, double *Kx, unsigned long long *dslots);
 __global__ __launch_bounds__(WG) void k_sym_update_scaling(SocView v, const int *__restrict__ nn_rows, int nn,
                                                            const double *__restrict__ sv,
                                                            const double *__restrict__ zv, double *w, double *lam) {
     __shared__ double red[16];
     if ((int)blockIdx.x < v.ncones) {
-        soc_update_scaling_body(v, sv, zv, blockIdx.x, red);
+        // (cones that fit the registers of a workgroup: one round trip for s, z instead of six passes through memory)
+        if (!soc_scaling_reg<false>(v, sv, zv, blockIdx.x, red, nullptr, nullptr)) soc_update_scaling_body(v, sv, zv, blockIdx.x, red);
         return;
     }
     const int nblk = gridDim.x - v.ncones, blk = blockIdx.x - v.ncones;
@@ -207,6 +211,149 @@ __device__ __forceinline__ void soc_write_kkt_body(const SocView &v, double *Kx,
     }
 }
 
+// The same scaling for cones of dimension <= 1 + SOC_RPT * WG with s, z, w of the cone in REGISTERS: the body above walks
+// s and z through memory six times behind seven workgroup reductions -- for a 1001-row cone that is a chain of ~13 memory
+// round trips (30 us for config 3's thousand cones); here one round trip loads the cone, every later pass is register
+// work.  Thread t holds the tail elements 1 + t + u * WG (the mapping of block_norm_tail, so its partial sums are the
+// same); element 0 is everybody's.  KKT: also get_Hs negated and the sparse expansion columns (soc_write_kkt_body) from
+// the registers, the K positions requested with the cone's data.  Returns false when the cone does not fit (dim too
+// large: the caller takes the memory-walking bodies).
+constexpr int SOC_RPT = 4;
+__device__ __forceinline__ double reg_norm_tail(const double (&x)[SOC_RPT], const bool (&in)[SOC_RPT], double *red) {
+    double amax = 0.0;
+#pragma unroll
+    for (int u = 0; u < SOC_RPT; ++u)
+        if (in[u]) amax = fmax(amax, fabs(x[u]));
+    amax = block_max(amax, red);
+    if (amax == 0.0) return 0.0;
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < SOC_RPT; ++u)
+        if (in[u]) {
+            const double r = fabs(x[u]) / amax;
+            ss += r * r;
+        }
+    ss = block_sum(ss, red);
+    return amax * sqrt(ss);
+}
+template <bool KKT>
+__device__ __forceinline__ bool soc_scaling_reg(const SocView &v, const double *__restrict__ sv, const double *__restrict__ zv,
+                                                int c, double *red, double *Kx, unsigned long long *dslots) {
+    const int n = v.dim[c];
+    if (n > 1 + SOC_RPT * WG) return false;
+    const int start = v.start[c], tid = threadIdx.x;
+    const double *s = sv + start, *z = zv + start;
+    double *w = v.w + start, *lam = v.lam + start;
+    double sr[SOC_RPT], zr[SOC_RPT], wr[SOC_RPT];
+    bool in[SOC_RPT];
+    int mh[SOC_RPT], mu[SOC_RPT], mv[SOC_RPT];
+    const int sidx = v.sparse_idx[c];
+    const int *pmh = v.mapHs + v.hs_start[c];
+    const int *pmu = (KKT && sidx >= 0) ? v.mapU + v.sp_ptr[sidx] : pmh, *pmv = (KKT && sidx >= 0) ? v.mapV + v.sp_ptr[sidx] : pmh;
+#pragma unroll
+    for (int u = 0; u < SOC_RPT; ++u) {
+        const int i = 1 + tid + u * WG;
+        in[u] = i < n;
+        const int ic = in[u] ? i : 0; // (clamped, unconditional loads)
+        sr[u] = s[ic];
+        zr[u] = z[ic];
+        if (KKT) {
+            mh[u] = pmh[sidx >= 0 ? ic : 0];
+            mu[u] = pmu[sidx >= 0 ? ic : 0];
+            mv[u] = pmv[sidx >= 0 ? ic : 0];
+        }
+    }
+    const double z0 = z[0], s0 = s[0];
+    const double z1n = reg_norm_tail(zr, in, red);
+    const double s1n = reg_norm_tail(sr, in, red);
+    const double zres = (z0 - z1n) * (z0 + z1n), sres = (s0 - s1n) * (s0 + s1n);
+    const double zscale = zres > 0.0 ? sqrt(zres) : 0.0;
+    const double sscale = sres > 0.0 ? sqrt(sres) : 0.0;
+    if (zscale == 0.0 || sscale == 0.0) {
+        if (tid == 0) *v.fail = v.fail_gen;
+        return true;
+    }
+    const double eta = sqrt(sscale / zscale);
+    const double rs = 1.0 / sscale, mrz = -(1.0 / zscale);
+#pragma unroll
+    for (int u = 0; u < SOC_RPT; ++u) wr[u] = mrz * zr[u] + 1.0 * (sr[u] * rs);
+    const double w0a = s0 * rs + z0 / zscale;
+    const double w1n = reg_norm_tail(wr, in, red);
+    const double wres = (w0a - w1n) * (w0a + w1n);
+    const double wscale = wres > 0.0 ? sqrt(wres) : 0.0;
+    if (wscale == 0.0) {
+        if (tid == 0) *v.fail = v.fail_gen;
+        return true;
+    }
+    const double rw = 1.0 / wscale;
+    double sq = 0.0;
+#pragma unroll
+    for (int u = 0; u < SOC_RPT; ++u) {
+        wr[u] = wr[u] * rw;
+        if (in[u]) sq += wr[u] * wr[u];
+    }
+    const double w1sq = block_sum(sq, red);
+    const double w0 = sqrt(1.0 + w1sq);
+    // lambda, socone.rs:174-184
+    const double gamma = 0.5 * wscale;
+    const double ca = (gamma + z0 / zscale) / sscale, cb = (gamma + s0 / sscale) / zscale;
+    const double sc = 1.0 / (s0 / sscale + z0 / zscale + 2.0 * gamma);
+    const double sqz = sqrt(sscale * zscale);
+    // rank-2 terms, socone.rs:187-208
+    const double alpha = 2.0 * w0;
+    const double wsq = w0 * w0 + w1sq;
+    const double wsqinv = 1.0 / wsq;
+    const double d = 0.5 * wsqinv;
+    const double u0 = sqrt(wsq - d);
+    const double u1 = alpha / u0;
+    const double v1 = sqrt(2.0 * (2.0 + wsqinv) / (2.0 * wsq - wsqinv));
+#pragma unroll
+    for (int u = 0; u < SOC_RPT; ++u)
+        if (in[u]) {
+            const int i = 1 + tid + u * WG;
+            w[i] = wr[u];
+            lam[i] = ((ca * sr[u] + cb * zr[u]) * sc) * sqz;
+        }
+    if (tid == 0) {
+        w[0] = w0;
+        lam[0] = gamma * sqz;
+        double *st = v.eta + 8 * c;
+        st[0] = eta;
+        st[1] = d;
+        st[2] = u0;
+        st[3] = u1;
+        st[4] = v1;
+    }
+    if (!KKT) return true;
+    // ---- get_Hs negated + the sparse expansion columns (socone.rs:217-246, datamaps.rs:199-220) ----
+    const double eta2 = eta * eta;
+    if (sidx >= 0) {
+        if (dslots && tid == 0) {
+            const double mx = fmax(fabs(eta2 * d), fabs(eta2));
+            int *nanflag = (int *)(dslots + (size_t)NRM_SLOTS * NRM_STRIDE);
+            fold_norm(dslots, nanflag, mx != mx ? 0.0 : mx, mx != mx, c);
+        }
+#pragma unroll
+        for (int u = 0; u < SOC_RPT; ++u)
+            if (in[u]) {
+                Kx[mh[u]] = -eta2;
+                Kx[mu[u]] = (u1 * wr[u]) * (-eta2);
+                Kx[mv[u]] = (v1 * wr[u]) * (-eta2);
+            }
+        if (tid == 0) {
+            Kx[pmh[0]] = -(eta2 * d);
+            Kx[pmu[0]] = u0 * (-eta2);
+            Kx[pmv[0]] = 0.0 * (-eta2);
+            Kx[v.mapD[2 * sidx]] = -eta2;
+            Kx[v.mapD[2 * sidx + 1]] = eta2;
+        }
+    } else {
+        __syncthreads(); // (dense form, dim <= 4: thread 0 reads w back)
+        soc_write_kkt_body(v, Kx, dslots, c);
+    }
+    return true;
+}
+
 // update_scaling and the KKT update's get_Hs scatter of the same rows in ONE launch (solver.rs:334-352 calls them back to
 // back): a cone's workgroup scales it and writes its K entries while w is hot; a slab of Nonnegative rows reads s, z once
 // and writes lambda, w and -w^2.  status: the refactor's 4 status words, cleared here (its preparation launch is skipped).
@@ -218,6 +365,7 @@ __global__ __launch_bounds__(WG) void k_sym_scale_write(SocView v, const int *__
     __shared__ double red[16];
     if (status && blockIdx.x == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
     if ((int)blockIdx.x < v.ncones) {
+        if (soc_scaling_reg<true>(v, sv, zv, blockIdx.x, red, Kx, dslots)) return;
         soc_update_scaling_body(v, sv, zv, blockIdx.x, red);
         __syncthreads(); // (w and the cone's state, written by this workgroup, are read back below)
         soc_write_kkt_body(v, Kx, dslots, blockIdx.x);

@@ -29,9 +29,12 @@ namespace {
 
 // I = index type of the quotient graph: int32 whenever the symmetric adjacency (2 x off-diagonal
 // entries) fits -- the ordering is memory bound, half-width indices are ~1.5x faster -- else int64
+// wgt (may be nullptr): initial supervariable sizes -- node i stands for wgt[i] >= 1 indistinguishable variables of the
+// original graph (amd_order_grouped: the rows of a dense cone block enter as one node); degrees, the dense-row test and
+// the fill statistics count weights
 template <typename I>
 int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
-                   AmdInfo *info, i64 dense_n) {
+                   AmdInfo *info, i64 dense_n, const i64 *wgt = nullptr) {
     constexpr I NONE = -1;
     perm.assign((size_t)n, 0);
     AmdInfo st;
@@ -117,9 +120,17 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
 
     // ---- node state ---------------------------------------------------------
     std::vector<I> nv((size_t)n, 1);      // supervariable size; 0 = not a live variable
+    i64 wtot = n;                         // total weight = largest possible degree
+    if (wgt) {
+        wtot = 0;
+        for (I i = 0; i < n; i++) {
+            nv[i] = (I)wgt[i];
+            wtot += wgt[i];
+        }
+    }
     std::vector<I> degree((size_t)n, 0);  // variables: approx external degree; elements: |Le|
     std::vector<i64> w((size_t)n, 1);     // 0 = dead element; otherwise pass stamps
-    std::vector<I> head((size_t)n + 1, NONE), nxt((size_t)n, NONE), prv((size_t)n, NONE);
+    std::vector<I> head((size_t)wtot + 1, NONE), nxt((size_t)n, NONE), prv((size_t)n, NONE);
     std::vector<I> vparent((size_t)n, NONE); // absorbed variable -> variable/pivot it joined
     std::vector<I> est((size_t)n, 0), elen((size_t)n, 0);
     std::vector<I> epool;
@@ -136,22 +147,31 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     if (dth < 16.0) dth = 16.0;
     if (dth > (double)n) dth = (double)n;
     I ndense = 0;
-    for (I i = 0; i < n; i++)
-        if ((double)alen[i] > dth) {
+    i64 wdense = 0;
+    if (dth > (double)wtot) dth = (double)wtot;
+    for (I i = 0; i < n; i++) {
+        double di = (double)alen[i];
+        if (wgt) { // (weighted degree)
+            di = 0.0;
+            for (I p = ast[i]; p < ast[i] + alen[i]; p++) di += (double)wgt[adj[p]];
+        }
+        if (di > dth) {
             is_dense[i] = 1;
+            wdense += nv[i];
             nv[i] = 0;
             ndense++;
         }
-    st.ndense = ndense;
-    const I nlive = n - ndense;
+    }
+    st.ndense = wgt ? wdense : ndense;
+    const I nlive = (I)(wtot - wdense);
     for (I i = 0; i < n; i++) {
         if (is_dense[i]) continue;
         I d = 0;
         for (I p = ast[i]; p < ast[i] + alen[i]; p++)
-            if (!is_dense[adj[p]]) d++;
+            if (!is_dense[adj[p]]) d += wgt ? (I)wgt[adj[p]] : 1;
         degree[i] = d;
     }
-    std::vector<I> tail((size_t)n + 1, NONE);
+    std::vector<I> tail((size_t)wtot + 1, NONE);
     auto dl_insert = [&](I i, I d) {
         nxt[i] = head[d];
         prv[i] = NONE;
@@ -211,11 +231,38 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     std::vector<char> dirty((size_t)n, 0), cand;
     I seq = 0;
     const bool rescan_all = switches().amd_rescan; // every member rescans (the textbook update; tests)
+    // Grouped ordering (wgt): MULTIPLE elimination with a degree tolerance.  A stage eliminates an independent set of
+    // nodes whose degree is within (1 + tol) of the stage's minimum -- a node adjacent to one of the stage's pivots (a
+    // member of its element) waits for the next stage.  Plain minimum degree walks a chain of cliques (BASELINE config
+    // 5: 200 PSD blocks tied pairwise by overlap variables) from its ends inward, one block after the other: minimal
+    // fill, but an elimination tree that IS the chain -- every block swallows the overlap variables towards its
+    // predecessor and becomes that block's parent: 200 dependent levels of dense fronts, nothing for the device to run
+    // side by side.  With the stages the blocks leave odd-even: the even ones as leaves, the odd ones with the overlap
+    // variables of both sides as their parents -- depth 2 instead of 200 for the same fill.
+    std::vector<I> blocked(wgt ? (size_t)n : (size_t)0, 0);
+    I stage = 1, stage_thr = -1;
+    const double stage_tol = 0.01 * (double)switches().amd_stage_tol;
     while (nelim < nlive) {
         auto tp0 = std::chrono::steady_clock::now();
-        while (mindeg <= n && head[mindeg] == NONE) mindeg++;
-        const I me = head[mindeg];
-        dl_remove(me, mindeg);
+        while (mindeg <= wtot && head[mindeg] == NONE) mindeg++;
+        I me = head[mindeg], medeg = mindeg;
+        if (wgt) {
+            for (;;) {
+                if (stage_thr < 0) stage_thr = (I)std::min<double>((double)wtot, (double)mindeg * (1.0 + stage_tol) + 1.0);
+                me = NONE;
+                for (I d = mindeg; d <= stage_thr && me == NONE; d++)
+                    for (I c = head[d]; c != NONE; c = nxt[c])
+                        if (blocked[c] != stage) {
+                            me = c;
+                            medeg = d;
+                            break;
+                        }
+                if (me != NONE) break;
+                stage++; // nothing eligible is left: the next stage starts from the current minimum degree
+                stage_thr = -1;
+            }
+        }
+        dl_remove(me, medeg);
         I nvpiv = nv[me];
         nelim += nvpiv;
         nv[me] = -nvpiv;
@@ -255,6 +302,21 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         }
         est[me] = mstart;
         elen[me] = (I)epool.size() - mstart;
+        if (wgt) // (this stage's pivots are independent at distance 2: the members of the new element wait, and so do their
+                 // variable neighbours -- two cone blocks tied by a handful of overlap variables are not eliminated in the
+                 // same stage, or the second would swallow the variables between them and become the first one's parent)
+            for (I q = mstart; q < (I)epool.size(); q++) {
+                const I i = epool[q];
+                blocked[i] = stage;
+                for (I p = ast[i]; p < ast[i] + avlen[i]; p++) blocked[adj[p]] = stage;
+                // ... and the nodes it meets in its elements: a later pivot of this stage next to i would swallow i
+                // (mass elimination) once i's other neighbours are gone, and become this pivot's parent
+                for (I p = ast[i] + avlen[i]; p < ast[i] + alen[i]; p++) {
+                    const I e = adj[p];
+                    if (w[e] == 0) continue;
+                    for (I t = est[e]; t < est[e] + elen[e]; t++) blocked[epool[t]] = stage;
+                }
+            }
         c_lme += elen[me];
         const I mend = mstart + elen[me];
         w[me] = 1;
@@ -382,6 +444,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
                         vparent[b2] = a;
                         nv[a] += nv[b2]; // both negative here
                         nv[b2] = 0;
+                        if (wgt && blocked[b2] == stage) blocked[a] = stage; // (the merged variable waits if a part of it does)
                         aelen[b2] = -1;
                         // the neighbours' cached weight sums still hold (a took b2's weight), their lists and
                         // hashes do not (b2 is dead): they rescan when they next meet an element
@@ -421,9 +484,11 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         tick(4, tp0);
         nv[me] = 0;
         pivots.push_back(me);
+        if (timing && wgt && n < 4000 && nvpiv >= 8)
+            std::fprintf(stderr, "[chip amd] pivot %d weight %d degree %d stage %d\n", (int)me, (int)nvpiv, (int)degme, (int)stage);
         // fill statistics in the style of amd::Info (used by ldlsolvers/auto.rs:69-77)
         {
-            const double f = (double)nvpiv, r = (double)(degme + ndense);
+            const double f = (double)nvpiv, r = (double)(degme + (wgt ? (I)wdense : ndense));
             const double lnzme = f * r + (f - 1) * f / 2.0;
             st.lnz += lnzme;
             st.ndiv += lnzme;
@@ -432,7 +497,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         }
     }
     if (ndense > 0) {
-        const double f = (double)ndense;
+        const double f = (double)(wgt ? wdense : (i64)ndense);
         const double lnzme = (f - 1) * f / 2.0;
         st.lnz += lnzme;
         st.ndiv += lnzme;
@@ -494,13 +559,94 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
 } // namespace
 
 static int amd_order_dn(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
-                        AmdInfo *info, i64 dense_n) {
+                        AmdInfo *info, i64 dense_n, const i64 *wgt = nullptr) {
     const i64 nnz = n > 0 ? Ap[n] : 0;
-    if (n < ((i64)1 << 30) && 2 * nnz < ((i64)1 << 31) - 16) {
-        const int rc = amd_order_impl<i32>(n, Ap, Ai, dense_scale, perm, info, dense_n);
+    if (n < ((i64)1 << 30) && 2 * nnz < ((i64)1 << 31) - 16 && dense_n < ((i64)1 << 30)) {
+        const int rc = amd_order_impl<i32>(n, Ap, Ai, dense_scale, perm, info, dense_n, wgt);
         if (rc != -77) return rc;
     }
-    return amd_order_impl<i64>(n, Ap, Ai, dense_scale, perm, info, dense_n);
+    return amd_order_impl<i64>(n, Ap, Ai, dense_scale, perm, info, dense_n, wgt);
+}
+// Ordering with dense cone blocks entering as ONE weighted node each (group[i] >= 0: node i belongs to that group; -1:
+// on its own).  The rows of a PSD cone's Hs block are mutually adjacent: once the first of them is eliminated the others
+// inherit its outside neighbours, so minimum degree orders them consecutively anyway -- but it gets there by carrying a
+// 1275-row clique through its quotient graph (BASELINE config 5: 1.6e8 entries of K, 8 s of elimination; the compressed
+// graph has 2e4 nodes).  The group's node has the union of its members' outside neighbours and their count as weight;
+// members leave consecutively, ascending.
+int amd_order_grouped(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, const i32 *group, std::vector<i64> &perm,
+                      AmdInfo *info) {
+    std::vector<i64> cid((size_t)n, -1), gfirst;
+    i64 ngroups = 0;
+    for (i64 i = 0; i < n; i++)
+        if (group[i] >= 0) ngroups = std::max<i64>(ngroups, group[i] + 1);
+    gfirst.assign((size_t)ngroups, -1);
+    i64 nc = 0;
+    std::vector<i64> wgt;
+    for (i64 i = 0; i < n; i++) {
+        const i32 g = group[i];
+        if (g < 0) {
+            cid[i] = nc++;
+            wgt.push_back(1);
+        } else if (gfirst[g] < 0) {
+            gfirst[g] = nc;
+            cid[i] = nc++;
+            wgt.push_back(1);
+        } else {
+            cid[i] = gfirst[g];
+            wgt[(size_t)gfirst[g]]++;
+        }
+    }
+    if (nc == n) return amd_order_components(n, Ap, Ai, dense_scale, perm, info);
+    // edges of the compressed graph (upper triangle), deduplicated
+    std::vector<uint64_t> keys;
+    for (i64 c = 0; c < n; c++)
+        for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
+            const i64 r = Ai[p];
+            if (r < 0 || r >= n) return -9;
+            const i64 a = cid[r], b = cid[c];
+            if (a == b) continue;
+            keys.push_back((uint64_t)std::max(a, b) * (uint64_t)nc + (uint64_t)std::min(a, b)); // (column-major)
+        }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<i64> cp((size_t)nc + 1, 0), ci(keys.size());
+    for (size_t k = 0; k < keys.size(); k++) {
+        cp[(size_t)(keys[k] / (uint64_t)nc) + 1]++;
+        ci[k] = (i64)(keys[k] % (uint64_t)nc);
+    }
+    for (i64 c = 0; c < nc; c++) cp[c + 1] += cp[c];
+    std::vector<i64> cperm;
+    const int rc = amd_order_dn(nc, cp.data(), ci.data(), dense_scale, cperm, info, n, wgt.data());
+    if (rc) return rc;
+    // expand: a group's members in ascending order at their node's place
+    std::vector<i64> mptr((size_t)nc + 1, 0), mem((size_t)n);
+    for (i64 i = 0; i < n; i++) mptr[cid[i] + 1]++;
+    for (i64 c = 0; c < nc; c++) mptr[c + 1] += mptr[c];
+    {
+        std::vector<i64> fill(mptr.begin(), mptr.end() - 1);
+        for (i64 i = 0; i < n; i++) mem[(size_t)fill[cid[i]]++] = i;
+    }
+    perm.assign((size_t)n, 0);
+    i64 out = 0;
+    for (i64 k = 0; k < nc; k++)
+        for (i64 q = mptr[cperm[k]]; q < mptr[cperm[k] + 1]; q++) perm[out++] = mem[(size_t)q];
+    if (switches().timing) {
+        std::fprintf(stderr, "[chip amd] %lld groups compressed: %lld -> %lld nodes, %zu edges\n", (long long)ngroups, (long long)n,
+                     (long long)nc, keys.size());
+        if (nc < 4000) { // (debug: the order in which heavy nodes leave, light ones as run lengths)
+            std::fprintf(stderr, "[chip amd] order:");
+            i64 run = 0;
+            for (i64 k = 0; k < nc; k++) {
+                if (wgt[(size_t)cperm[k]] > 1) {
+                    if (run) std::fprintf(stderr, " (%lld)", (long long)run);
+                    run = 0;
+                    std::fprintf(stderr, " G%lld", (long long)mem[(size_t)mptr[cperm[k]]]);
+                } else run++;
+            }
+            std::fprintf(stderr, " (%lld)\n", (long long)run);
+        }
+    }
+    return out == n ? 0 : -9;
 }
 int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
               AmdInfo *info) {

@@ -390,7 +390,20 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     std::vector<i64> perm0;
     if (perm_or_null) perm0.assign(as_i64(perm_or_null), as_i64(perm_or_null) + K.N);
     Symbolic S;
-    rc = analyse(K.N, K.colptr.data(), K.rowval.data(), K.dsigns.data(), perm0, st.amd_dense_scale, S, target_workgroups(st));
+    // dense cone blocks (the Hs block of a cone that is not diagonal: its rows are a clique of K) enter the ordering as
+    // one weighted node each -- worth it from a few dozen rows per block (PSD cones; not the 3 x 3 / 4 x 4 blocks)
+    std::vector<i32> clique_of;
+    {
+        i32 g = 0;
+        for (const ConeSpec &c : K.cones)
+            if (!c.hs_diag && c.numel >= 16) {
+                if (clique_of.empty()) clique_of.assign((size_t)K.N, -1);
+                for (i64 r = 0; r < c.numel; r++) clique_of[(size_t)(n + c.start + r)] = g;
+                g++;
+            }
+    }
+    rc = analyse(K.N, K.colptr.data(), K.rowval.data(), K.dsigns.data(), perm0, st.amd_dense_scale, S, target_workgroups(st),
+                 clique_of.empty() ? nullptr : &clique_of);
     if (rc) return rc;
     clk("analysis (total)");
     Engine &E = h->E;

@@ -35,6 +35,9 @@ int amd_order(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vect
 // the same by connected components: identical patterns ordered once, distinct ones in parallel (amd_order.cpp)
 int amd_order_components(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std::vector<i64> &perm,
                          AmdInfo *info);
+// the same with dense cone blocks entering as one weighted node each (group[i]: block of node i, -1: none)
+int amd_order_grouped(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, const i32 *group, std::vector<i64> &perm,
+                      AmdInfo *info);
 
 // ---------------------------------------------------------------------------
 // symbolic analysis (symbolic.cpp)
@@ -198,8 +201,11 @@ struct Symbolic {
 // `perm0` empty => AMD.  Returns 0 or a negative chip_status.
 // target_wg: workgroups the device keeps resident for the fused solve kernel (CUs x 4): a forest with fewer
 // bundles than that is cut finer (grouped fold, above); 0 = never refine.
+// clique_of (may be nullptr): node -> dense cone block it belongs to (-1: none); the ordering then takes every block as
+// one weighted node (amd_order_grouped)
 int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns_or_null,
-            const std::vector<i64> &perm0, double amd_dense_scale, Symbolic &S, i32 target_wg = 1024);
+            const std::vector<i64> &perm0, double amd_dense_scale, Symbolic &S, i32 target_wg = 1024,
+            const std::vector<i32> *clique_of = nullptr);
 
 // ---------------------------------------------------------------------------
 // KKT assembly (kkt_assembly.cpp)  -- kkt_assembly.rs:20-183, datamaps.rs

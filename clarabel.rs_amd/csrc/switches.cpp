@@ -22,6 +22,8 @@ const Entry TABLE[] = {
     {"CHIP_AMD_FIFO", Entry::FLAG, SW(amd_fifo), 0},
     {"CHIP_AMD_RESCAN", Entry::FLAG, SW(amd_rescan), 0},
     {"CHIP_NO_COMPONENTS", Entry::FLAG, SW(no_components), 0},
+    {"CHIP_NO_CLIQUE_ORDER", Entry::FLAG, SW(no_clique_order), 0},
+    {"CHIP_AMD_STAGE_TOL", Entry::INT, SW(amd_stage_tol), 0},
     {"CHIP_NO_CHAIN_REORDER", Entry::FLAG, SW(no_chain_reorder), 0},
     {"CHIP_NO_BUNDLES", Entry::FLAG, SW(no_bundles), 0},
     {"CHIP_BUNDLE_MAX_WORK", Entry::LONG, SW(bundle_max_work), 0},

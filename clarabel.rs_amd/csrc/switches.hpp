@@ -19,6 +19,8 @@ struct Switches {
     bool amd_fifo = false;          // CHIP_AMD_FIFO: first-in-first-out ties in the degree lists
     bool amd_rescan = false;        // CHIP_AMD_RESCAN: every member of a new element rescans its lists
     bool no_components = false;     // CHIP_NO_COMPONENTS: order the whole graph, not one component per pattern
+    bool no_clique_order = false;   // CHIP_NO_CLIQUE_ORDER: dense cone blocks enter the ordering row by row, not as one node
+    int amd_stage_tol = 100;        // CHIP_AMD_STAGE_TOL: degree tolerance (percent) of a stage of the grouped ordering
     bool no_chain_reorder = false;  // CHIP_NO_CHAIN_REORDER
     bool no_bundles = false;        // CHIP_NO_BUNDLES
     long long bundle_max_work = 0;  // CHIP_BUNDLE_MAX_WORK (0: default)

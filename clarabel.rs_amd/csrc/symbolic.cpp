@@ -216,7 +216,7 @@ struct ListBuilder {
 } // namespace
 
 int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std::vector<i64> &perm0,
-            double amd_dense_scale, Symbolic &S, i32 target_wg) {
+            double amd_dense_scale, Symbolic &S, i32 target_wg, const std::vector<i32> *clique_of) {
     S = Symbolic();
     if (n < 0 || n >= (i64)1 << 31) {
         set_error("KKT dimension out of int32 range");
@@ -247,7 +247,9 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // ---- ordering -----------------------------------------------------------
     std::vector<i64> p0 = perm0;
     if (p0.empty() && n > 0) {
-        int rc = amd_order_components(n, Ap, Ai, amd_dense_scale, p0, &S.amd);
+        const bool grouped = clique_of && (i64)clique_of->size() == n && !switches().no_clique_order;
+        int rc = grouped ? amd_order_grouped(n, Ap, Ai, amd_dense_scale, clique_of->data(), p0, &S.amd)
+                         : amd_order_components(n, Ap, Ai, amd_dense_scale, p0, &S.amd);
         if (rc) {
             set_error("amd_order failed");
             return rc;
@@ -690,6 +692,15 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         std::vector<char> linked((size_t)n, 0);
         for (i32 pj = NFi; pj < n; pj++)
             if (best[pj] >= 0) linked[best[pj]] = 1;
+        // dense cone blocks (clique_of): a supernode never runs across a block's boundary.  The rows of a block are a
+        // leaf subtree of the elimination tree; merged with the overlap / coupling variables above them -- which are the
+        // parents of the NEIGHBOURING blocks' rows too -- a block's supernode would sit above its neighbours' supernodes
+        // and the blocks, all independent, would be factored one unit level after the other.
+        std::vector<i32> cqf;
+        if (clique_of && (i64)clique_of->size() == n && !switches().no_clique_order) {
+            cqf.resize((size_t)n);
+            for (i32 t = 0; t < n; t++) cqf[(size_t)t] = (*clique_of)[(size_t)S.perm[(size_t)t]];
+        }
         std::vector<i32> chain;
         std::vector<std::pair<i32, std::vector<i32>>> found; // (first column, columns ascending)
         for (i32 h = NFi; h < n; h++) {
@@ -704,6 +715,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 const i32 e = chain[a];
                 size_t b = a + 1;
                 while (b < chain.size() && (i32)(b - a) < SN_MAX_W) {
+                    if (!cqf.empty() && cqf[(size_t)chain[b]] != cqf[(size_t)chain[b - 1]]) break;
                     const i64 padded = (i64)cnt[e] + (i64)(b - a);
                     const i64 zeros = padded - cnt[chain[b]];
                     if (zeros > std::max<i64>(SN_PAD_ABS, (i64)(SN_PAD_REL * (double)padded))) break;

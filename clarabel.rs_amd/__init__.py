@@ -839,6 +839,14 @@ def debug_set_switch(name, value=None):
     _check(lib().chip_debug_set_switch(name.encode(), None if value is None else str(value).encode()), "debug_set_switch")
 
 
+def debug_counter(kkt, name):
+    """test hook: one structural figure of a HipKKTSolver by name (include/clarabel_hip_testing.h: chip_debug_counter)"""
+    out = C.c_double(0.0)
+    lib().chip_debug_counter.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+    _check(lib().chip_debug_counter(kkt._h, name.encode(), C.byref(out)), "debug_counter")
+    return out.value
+
+
 def set_device(ordinal):
     """hipSetDevice for this thread (one process per GPU: the rank's local device)"""
     rc = _hiprt().hipSetDevice(C.c_int(int(ordinal)))

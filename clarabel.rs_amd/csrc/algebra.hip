@@ -41,6 +41,80 @@ __global__ __launch_bounds__(WG) void k_gather_values(double *__restrict__ Sx,
                                                       const int *__restrict__ Smap, int nnzS) {
     for (int t = logical_block() * WG + threadIdx.x; t < nnzS; t += gridDim.x * WG) Sx[t] = Kx[Smap[t]];
 }
+// ---------------------------------------------------------------------------
+// Dense diagonal blocks of the top in the residual e = b - K x (kernels.hpp: DblkView).  Block b is symmetric m x m (its
+// i-th row and column belong to node rownode[rowbase + i]) with only its strict upper triangle stored, row a
+// contiguous: entry (a, i), i > a, at start[a] + i - a - 1.  Workgroup
+// (s, b) owns the rows a = s, s + split, ... ("columns" below: by symmetry row a of the upper triangle is column a of the
+// lower one) and reads each of their entries ONCE: entry h = H(i, a) serves y_i += h x_a (a register of the lane that
+// owns row i) and y_a += h x_i (a wave reduction per column).  Rows go in tiles of 512 -- lane l of every wave holds rows
+// T0 + 64 k + l, k < 8, and their x in registers --, a wave walks its columns through the tile with eight loads in
+// flight per lane, and at the end of the tile the eight waves' row sums are added in a fixed order.  No atomics: the
+// sum of every y_i has the same order in every run.  P[(rowbase + i) * split + s] = this workgroup's share of y_i.
+// ---------------------------------------------------------------------------
+constexpr int DB_WG = 512, DB_RT = 8, DB_TILE = 64 * DB_RT;
+__global__ __launch_bounds__(DB_WG) void k_dblk_symv(DblkView d, const double *__restrict__ Kx, const double *__restrict__ x, int mpad) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    double *xs = (double *)dsm, *yl = xs + mpad, *part = yl + mpad;
+    int *sts = (int *)(part + (DB_WG / 64) * DB_TILE);
+    const int b = (int)blockIdx.y, s = (int)blockIdx.x, split = (int)gridDim.x;
+    const int m = d.m[b], rb = d.rowbase[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < m; i += DB_WG) {
+        xs[i] = x[d.rownode[rb + i]];
+        yl[i] = 0.0;
+        sts[i] = d.start[rb + i] - i - 1; // entry (i', i) of column i at sts[i] + i'
+    }
+    __syncthreads();
+    for (int T0 = 0; T0 < m; T0 += DB_TILE) {
+        double xr[DB_RT], acc[DB_RT];
+#pragma unroll
+        for (int k = 0; k < DB_RT; ++k) {
+            const int i = T0 + 64 * k + lane;
+            xr[k] = i < m ? xs[i] : 0.0;
+            acc[k] = 0.0;
+        }
+        const int aend = min(m - 1, T0 + DB_TILE - 1); // columns with a row in this tile (column a has the rows a + 1 .. m - 1)
+        for (int a = s + split * wave; a < aend; a += split * (DB_WG / 64)) {
+            const int base = sts[a];
+            const double xa = xs[a];
+            double h[DB_RT];
+#pragma unroll
+            for (int k = 0; k < DB_RT; ++k) {
+                const int i = T0 + 64 * k + lane;
+                const bool ok = i > a && i < m;
+                h[k] = Kx[base + (ok ? i : a + 1)]; // (clamped: unconditional loads)
+                h[k] = ok ? h[k] : 0.0;
+            }
+            double dsum = 0.0;
+#pragma unroll
+            for (int k = 0; k < DB_RT; ++k) {
+                acc[k] += h[k] * xa;
+                dsum += h[k] * xr[k];
+            }
+            dsum = wave_sum(dsum);
+            if (lane == 0) yl[a] += dsum; // (column a belongs to this wave alone)
+        }
+#pragma unroll
+        for (int k = 0; k < DB_RT; ++k) part[wave * DB_TILE + 64 * k + lane] = acc[k];
+        __syncthreads();
+        if (T0 + tid < m) {
+            double r = 0.0;
+#pragma unroll
+            for (int w = 0; w < DB_WG / 64; ++w) r += part[w * DB_TILE + tid];
+            yl[T0 + tid] += r;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < m; i += DB_WG) d.P[(size_t)(rb + i) * split + s] = yl[i];
+}
+__global__ __launch_bounds__(WG) void k_dblk_finish(DblkView d, double *__restrict__ bt) {
+    const int j = blockIdx.x * WG + threadIdx.x;
+    if (j >= d.nrows) return;
+    double r = 0.0;
+    for (int s = 0; s < d.split; ++s) r += d.P[(size_t)j * d.split + s];
+    bt[d.rownode[j]] -= r;
+}
 __global__ __launch_bounds__(WG) void k_scatter_values(double *Kx, const int *__restrict__ map,
                                                        const double *__restrict__ vals, int k,
                                                        double scale) {
@@ -247,6 +321,17 @@ void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap,
     int nb = grid_for(nnzS);
     if (nb > 4096) nb = 4096;
     k_gather_values<<<nb, WG, 0, s>>>(Sx, Kx, Smap, nnzS);
+}
+static size_t dblk_lds_bytes(int mpad) { return (size_t)(2 * mpad + (DB_WG / 64) * DB_TILE) * sizeof(double) + (size_t)mpad * sizeof(int); }
+int dblk_attributes(int mmax) {
+    const int mpad = (mmax + 63) / 64 * 64;
+    return (int)raise_dynamic_lds((const void *)k_dblk_symv, dblk_lds_bytes(mpad));
+}
+void dblk_symv(hipStream_t s, const DblkView &d, const double *Kx, const double *x, double *bt) {
+    if (!d.nblk) return;
+    const int mpad = (d.mmax + 63) / 64 * 64;
+    k_dblk_symv<<<dim3(d.split, d.nblk), DB_WG, dblk_lds_bytes(mpad), s>>>(d, Kx, x, mpad);
+    k_dblk_finish<<<(d.nrows + WG - 1) / WG, WG, 0, s>>>(d, bt);
 }
 void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale) {
     if (k == 0) return;

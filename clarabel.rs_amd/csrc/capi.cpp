@@ -1601,6 +1601,22 @@ int32_t chip_debug_spin(int32_t device, int32_t blocks, int32_t threads, int32_t
 int32_t chip_debug_set_switch(const char *name, const char *value_or_null) {
     return switches_set(name, value_or_null) ? CHIP_OK : fail(CHIP_ERR_ARG, "chip_debug_set_switch: unknown switch");
 }
+int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out) {
+    const chip_kkt *h = (const chip_kkt *)kkt_handle;
+    if (!h || !name || !out) return CHIP_ERR_ARG;
+    const std::string k(name);
+    const Engine &E = h->E;
+    if (k == "dense_blocks") *out = E.dblk.nblk;
+    else if (k == "dense_block_rows") *out = E.dblk.nrows;
+    else if (k == "nnzS") *out = (double)E.nnzS;
+    else if (k == "assembled_levels") {
+        int c = 0;
+        for (size_t l = 0; l + 1 < E.asm_lvl_ptr.size(); l++) c += E.asm_lvl_ptr[l + 1] > E.asm_lvl_ptr[l];
+        *out = c;
+    } else if (k == "assembled_targets") *out = E.asm_lvl_ptr.empty() ? 0 : E.asm_lvl_ptr.back();
+    else return fail(CHIP_ERR_ARG, "chip_debug_counter: unknown name");
+    return CHIP_OK;
+}
 #endif
 
 } // extern "C"

@@ -177,6 +177,38 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         if ((rc = alloc(&xs_view, n))) return rc;
     }
     if ((rc = upload(&Smap, S.Smap, (size_t)nnzS))) return rc;
+    if (!S.dblk_p0.empty()) {
+        const int nblk = (int)S.dblk_p0.size();
+        std::vector<i32> rowbase((size_t)nblk, 0);
+        const std::vector<i32> &rownode = S.dblk_node;
+        int mmax = 0;
+        for (int b = 0, o = 0; b < nblk; b++) {
+            rowbase[(size_t)b] = o;
+            o += S.dblk_m[(size_t)b];
+            mmax = std::max(mmax, (int)S.dblk_m[(size_t)b]);
+        }
+        int *dp0 = nullptr, *dm = nullptr, *drb = nullptr, *dst = nullptr, *drn = nullptr;
+        if ((rc = upload(&dp0, S.dblk_p0, S.dblk_p0.size()))) return rc;
+        if ((rc = upload(&dm, S.dblk_m, S.dblk_m.size()))) return rc;
+        if ((rc = upload(&drb, rowbase, rowbase.size()))) return rc;
+        if ((rc = upload(&dst, S.dblk_start, S.dblk_start.size()))) return rc;
+        if ((rc = upload(&drn, rownode, rownode.size()))) return rc;
+        dblk.nblk = nblk;
+        dblk.split = std::max(1, std::min(8, 1024 / nblk)); // (enough workgroups to fill the chip; a block's rows interleaved)
+        dblk.mmax = mmax;
+        dblk.nrows = (int)rownode.size();
+        dblk.p0 = dp0;
+        dblk.m = dm;
+        dblk.rowbase = drb;
+        dblk.start = dst;
+        dblk.rownode = drn;
+        if ((rc = alloc(&dblk.P, (size_t)dblk.nrows * dblk.split))) return rc;
+        if ((rc = alloc(&bt_view, n))) return rc;
+        if (dev::dblk_attributes(mmax)) {
+            set_error("k_dblk_symv: dynamic LDS attribute");
+            return CHIP_ERR_HIP;
+        }
+    }
     if ((rc = upload(&Up, S.Up, S.Up.size()))) return rc;
     if ((rc = upload(&Ucol, S.Ucol, (size_t)nnzU))) return rc;
     if ((rc = upload(&dsigns, S.dsigns, n))) return rc;
@@ -247,6 +279,23 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         {
             std::vector<long long> up(S.upd_ptr.begin(), S.upd_ptr.end());
             if ((rc = upload(&upd_ptr, up, up.size()))) return rc;
+        }
+        asm_lvl_ptr = S.asm_lvl_ptr;
+        if (!S.asm_tgt.empty()) {
+            std::vector<long long> src(S.asm_src.size() * 3), uoff(S.asm_uoff.begin(), S.asm_uoff.end());
+            for (size_t q = 0; q < S.asm_src.size(); q++) {
+                src[3 * q] = S.asm_src[q].uo;
+                src[3 * q + 1] = S.asm_src[q].so;
+                src[3 * q + 2] = (long long)(unsigned)S.asm_src[q].cnt | ((long long)S.asm_src[q].dofs << 32);
+            }
+            if ((rc = upload(&asm_src, src, src.size()))) return rc;
+            if ((rc = upload(&asm_uoff, uoff, uoff.size()))) return rc;
+            if ((rc = upload(&asm_doff, S.asm_doff, S.asm_doff.size()))) return rc;
+            if ((rc = upload(&asm_tgt, S.asm_tgt, S.asm_tgt.size()))) return rc;
+            if ((rc = upload(&asm_src_ptr, S.asm_src_ptr, S.asm_src_ptr.size()))) return rc;
+            if ((rc = alloc(&asm_U, (size_t)S.asm_usize + 1))) return rc;
+            if ((rc = alloc(&asm_Ud, (size_t)S.asm_dsize + 1))) return rc;
+            CHIP_HIP(hipMemset(asm_U, 0, ((size_t)S.asm_usize + 1) * sizeof(double)));
         }
         {
             std::vector<i32> bp((size_t)nsn + 1, 0);
@@ -790,14 +839,27 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         vf.Rcol = Rf_col;
         vf.Rpos = Rf_pos;
     }
-    const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, nullptr, sn_cnt};
+    dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, nullptr, sn_cnt};
+    sview.U = asm_U;
+    sview.Ud = asm_Ud;
+    sview.asm_uoff = asm_uoff;
+    sview.asm_doff = asm_doff;
     auto has_sn = [&](int l) { return nsn > 0 && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
     const dev::LaunchProf lprof = launch_prof();
+    // a level's ancestor updates are assembled per target column (no atomics, a fixed order of summation) when enough
+    // supernodes share targets for the atomics to collide -- or always, on request (settings: deterministic)
+    const int asm_min = switches().deterministic ? 2 : switches().extend_asm_min > 0 ? switches().extend_asm_min : 4;
     auto run_supernodes = [&](int l) {
         if (!has_sn(l)) return;
         dev::factor_B(stream, vf, snx.B(l));
-        dev::factor_snodes(stream, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l], sn_wmax,
-                           sn_lvl_nblk[l], sn_lvl_hmax[l], sn_lvl_nbmax[l], prof_family >= PF_SN_UPDATE ? &lprof : nullptr);
+        const int count = sn_lvl_ptr[l + 1] - sn_lvl_ptr[l];
+        dev::SnodeAsmView av{asm_tgt, asm_src_ptr, asm_src, 0, 0};
+        if (asm_U && !switches().no_extend_asm && count >= asm_min) {
+            av.t0 = asm_lvl_ptr[l];
+            av.nt = asm_lvl_ptr[l + 1] - asm_lvl_ptr[l];
+        }
+        dev::factor_snodes(stream, v, sview, sn_order + 8 * sn_lvl_ptr[l], count, sn_wmax, sn_lvl_nblk[l], sn_lvl_hmax[l],
+                           sn_lvl_nbmax[l], prof_family >= PF_SN_UPDATE ? &lprof : nullptr, &av);
     };
     for (int l = top_folded ? nfaclevels : 0; l < nfaclevels;) {
         int e = fac.chain_end[l];
@@ -990,6 +1052,11 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
     if (xperm) {
         dev::gather_values(stream, xs_view, x, xperm, N);
         a.xin = xs_view;
+    }
+    if (dblk.nblk) { // dense diagonal blocks of the top: multiplied from K's values directly, taken off b beforehand
+        (void)hipMemcpyAsync(bt_view, b, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, stream);
+        dev::dblk_symv(stream, dblk, Kx, x, bt_view);
+        a.aux = bt_view;
     }
     const dev::ChunkView bc = smv.B(0);
     if (bc.count) dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));

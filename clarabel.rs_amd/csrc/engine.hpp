@@ -87,6 +87,13 @@ struct Engine {
     long long *upd_ptr = nullptr;
     double *sn_d = nullptr; // pivots of the supernode members, packed (dev::SnodeView::sn_d)
     int *sn_cnt = nullptr;  // dev::SnodeView::sn_cnt
+    dev::DblkView dblk;       // dense diagonal blocks of the top in the residual (host.hpp: Symbolic::dblk_*)
+    double *bt_view = nullptr; // b minus the blocks' products (enqueue_residual)
+    // ancestor updates assembled per target column (dev::SnodeAsmView; host.hpp: Symbolic::asm_*)
+    int *asm_tgt = nullptr, *asm_src_ptr = nullptr, *asm_doff = nullptr;
+    long long *asm_src = nullptr, *asm_uoff = nullptr;
+    double *asm_U = nullptr, *asm_Ud = nullptr;
+    std::vector<i32> asm_lvl_ptr;
     int8_t *sn_sg = nullptr; // dev::SnodeView::sn_sg
     std::vector<i32> sn_lvl_ptr, sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax, h_sn_ptr, h_sn_col;
     // pipelined substitution through wide supernodes (dev::SnodeTriView): one flag per 64-column block

@@ -171,6 +171,22 @@ struct Symbolic {
     std::vector<i32> Rf_p, Rf_col, Rf_pos;
     std::vector<i64> upd_ptr;   // per supernode: its range of upd_slot (packed strict lower triangle of B x B)
     std::vector<i32> upd_slot;  // CSC slot of L(B[r], B[c])
+    // The same updates ASSEMBLED instead of scattered with atomics: the supernodes of a unit level write their
+    // update matrices to a private buffer (supernode s at asm_uoff[s], packed like upd_slot; its diagonal at
+    // asm_doff[s]) and one workgroup per TARGET column sums its sources in a fixed order (k_snode_assemble).
+    // Per level l: targets asm_lvl_ptr[l] .. asm_lvl_ptr[l+1]; target t = node asm_tgt[t] with the sources
+    // asm_src_ptr[t] .. asm_src_ptr[t+1], source = (offset in the level's buffer, offset in upd_slot, entries,
+    // offset of its diagonal entry).  Levels with fewer than two contributing supernodes have no targets.
+    std::vector<i64> asm_uoff;
+    std::vector<i32> asm_doff;
+    std::vector<i32> asm_lvl_ptr, asm_tgt, asm_src_ptr;
+    struct AsmSrc {
+        i64 uo, so;
+        i32 cnt, dofs;
+    };
+    std::vector<AsmSrc> asm_src;
+    i64 asm_usize = 0; // doubles: the largest level's buffer
+    i32 asm_dsize = 0;
     std::vector<i32> sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax; // per unit level: maxima over its supernodes
     std::vector<i32> sn_lvl_ptr, sn_order;      // supernodes by unit level
     i32 nfaclevels = 0;
@@ -184,7 +200,11 @@ struct Symbolic {
     //       the first nnzU entries of V (no copy)
     //   S : rows i >= NF (top nodes): the full row (both triangles); Sp has N+1 entries, empty rows for
     //       i < NF; Smap = position in V (values refreshed by a gather at every refactor)
+    //   dense diagonal blocks of the top (dblk_m[b] nodes joined pairwise, first node dblk_p0[b]; nodes and the position
+    //       in V of each node's first block entry in dblk_node / dblk_start, block after block): multiplied from V
+    //       directly, their off-diagonal entries are NOT in S (symbolic.cpp; k_dblk_symv)
     i64 nnzS = 0, nnzU = 0;
+    std::vector<i32> dblk_p0, dblk_m, dblk_start, dblk_node;
     std::vector<i32> Sp;
     bigvec Scol, Smap;
     // with chain supernodes: Scol refers to positions of a copy of x in which the members of a supernode are

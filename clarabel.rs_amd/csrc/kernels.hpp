@@ -125,6 +125,19 @@ void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int
 void eps_from_slots(hipStream_t s, unsigned long long *slots, double c, double prop, double static_max,
                     double *scal);
 void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap, int nnzS);
+// Dense diagonal blocks of the top in the residual (host.hpp: Symbolic::dblk_*): block b = the m[b] nodes
+// rownode[rowbase[b] ..], its strict upper triangle row by row in the device's K values, row a starting at
+// start[rowbase[b] + a].
+struct DblkView {
+    int nblk = 0, split = 1, mmax = 0, nrows = 0;
+    const int *p0 = nullptr, *m = nullptr, *rowbase = nullptr; // per block
+    const int *start = nullptr;                                // per block row
+    const int *rownode = nullptr;                              // per block row: its node
+    double *P = nullptr;                                       // nrows x split partial products
+};
+int dblk_attributes(int mmax);
+// bt[i] = b[i] - (H x)[i] for the rows of the blocks (bt holds a copy of b on entry); every entry of a block is read once
+void dblk_symv(hipStream_t s, const DblkView &d, const double *Kx, const double *x, double *bt);
 void diag_absmax_eps(hipStream_t s, const double *Kx, const int *diag_idx, int N, double c,
                      double prop, double *scal /*[0]=eps out, uses [1] as scratch*/);
 void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale);
@@ -253,6 +266,19 @@ struct SnodeView {
     long long *dbg;           // CHIP_SN_DEBUG: phase stamps of workgroup 0 of the launch (64 slots), else nullptr
     int *sn_cnt;              // per supernode: workgroups of k_snode_panel that have finished with the unfactored diagonal
                               // block (zero between launches: the last one resets it)
+    // ancestor updates ASSEMBLED (SnodeAsmView): k_snode_extend stores supernode s's update matrix at U + asm_uoff[s]
+    // (packed like upd_slot) and its diagonal at Ud + asm_doff[s] instead of subtracting it with atomics (nullptr)
+    double *U = nullptr, *Ud = nullptr;
+    const long long *asm_uoff = nullptr;
+    const int *asm_doff = nullptr;
+};
+// One unit level's update matrices summed per TARGET column (host.hpp: Symbolic::asm_*): workgroup t owns node
+// tgt[t0 + t] and subtracts its sources src_ptr[..] one after the other -- a fixed order, no atomics.  Source q =
+// src[3 q .. 3 q + 2] = (offset in U, offset in upd_slot, entries | offset in Ud << 32).
+struct SnodeAsmView {
+    const int *tgt, *src_ptr;
+    const long long *src;
+    int t0 = 0, nt = 0;
 };
 int snode_kernel_attributes(int wmax, int nbmax);
 
@@ -265,7 +291,7 @@ struct LaunchProf {
     void *ctx;
 };
 void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order, int count, int wmax_all,
-                   int nblk, int hmax, int nbmax, const LaunchProf *lp = nullptr);
+                   int nblk, int hmax, int nbmax, const LaunchProf *lp = nullptr, const SnodeAsmView *av = nullptr);
 void factor_finalize(hipStream_t s, const LdlView &v, ListView cols);
 
 // ---- triangular solves + symv (row-gather family) -------------------------------

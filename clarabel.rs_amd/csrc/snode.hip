@@ -244,6 +244,17 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
                         else if (i == j) v.D[g.cols[j]] -= val[m];
                     }
                 }
+            } else if (sv.U) {
+                // assembled per target column afterwards (k_snode_assemble): plain stores, consecutive rows of one
+                // column are consecutive entries of the supernode's packed triangle
+                double *Us = sv.U + sv.asm_uoff[sn];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int jj = 4 * (m0 + m) + kq, cB = jrow0 + jj - g.w;
+                    if (jj >= ncols) continue;
+                    if (rB > cB) Us[(long long)cB * g.nb - (long long)cB * (cB + 1) / 2 + (rB - cB - 1)] = val[m];
+                    else if (rB == cB) sv.Ud[sv.asm_doff[sn] + cB] = val[m];
+                }
             } else {
                 int slot[8];
 #pragma unroll
@@ -290,19 +301,116 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
     snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), c1 * SN_NB, row_begin, c0 * SN_NB, ns > 1);
 }
-// grid (row groups, column blocks of B, supernodes of the level)
-__global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order) {
+// grid (row groups, column blocks of B, supernodes of the level) -- or, xcd != 0, ONE dimension that is decoded so that
+// the tiles of a supernode share an XCD: workgroups go to the eight XCDs round-robin by their linear id, every XCD has
+// its own L2, and the 15 column blocks x 4 row groups of a config 5 clique all stream the same 9 MB panel, k chunk by
+// k chunk and roughly in step.  Spread over the chip each tile fetched its operands through the fabric (23 GB per
+// launch of the leaf level, ~2.9 TB/s: the launch was bound by that, not by the matrix cores); with a supernode per
+// XCD a k chunk (~1 MB) is fetched once and the other tiles find it in the L2.  id = 8 q + r: XCD r works on supernode
+// 8 (q / T) + r, tile q % T of T = gx * gy.
+__global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                                                                   int xcd, int gx, int gy, int count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
     int *colbase = snode_lds(smem, Wl);
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    if (xcd) {
+        const int id = (int)blockIdx.x, r = id & 7, q = id >> 3, T = gx * gy, tile = q % T;
+        bz = 8 * (q / T) + r;
+        if (bz >= count) return;
+        by = tile / gx; // (column blocks outermost: the tiles of one column block share the staged operand as well)
+        bx = tile % gx;
+    }
     int sn;
-    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.z, sn);
-    const int c0 = (int)blockIdx.y * SN_NB;
+    const SnodeGeom g = snode_geom(sv, order, bz, sn);
+    const int c0 = by * SN_NB;
     if (c0 >= g.nb) return;
-    const int row_begin = g.w + c0 + (int)blockIdx.x * SN_ROWS;
+    const int row_begin = g.w + c0 + bx * SN_ROWS;
     if (row_begin >= g.h) return;
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
     snode_tiles<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SN_NB, g.nb - c0), g.w, row_begin);
+}
+// grid (target columns of the level): the update matrices the level's supernodes left in U, summed per target column
+// in LDS -- source after source, a barrier between them: two sources may hit the same row from different threads --
+// and subtracted from the column once.  The sums have a fixed order (the sources are sorted by supernode on the host):
+// what the fp64 atomics of k_snode_extend cannot promise, and ~200 supernodes hammering the same ~4e5 addresses
+// (config 5's leaf level) was the slowest part of that launch.  The headers of up to SNA_WG sources are staged in LDS
+// together and the entries of source k + 1 are requested before those of source k are added; a column longer than the
+// LDS buffer is done in windows of SNA_CAP rows (its sources are read once per window).
+constexpr int SNA_WG = 256;
+constexpr int SNA_CAP = 4096; // doubles of LDS per target column (32 KiB: four workgroups per CU)
+constexpr int SNA_PF = 4;     // entries per thread of one source, requested together
+__global__ __launch_bounds__(SNA_WG) void k_snode_assemble(LdlView v, SnodeView sv, SnodeAsmView av, int cap) {
+    __shared__ double acc[SNA_CAP];
+    __shared__ long long h_uo[SNA_WG], h_so[SNA_WG];
+    __shared__ int h_cnt[SNA_WG], h_do[SNA_WG];
+    const int t = av.t0 + (int)blockIdx.x, tid = threadIdx.x;
+    const int c = av.tgt[t];
+    const int q0 = av.src_ptr[t], q1 = av.src_ptr[t + 1];
+    const int base = v.Lp[c], len = v.Lp[c + 1] - base;
+    for (int w0 = 0; w0 == 0 || w0 < len; w0 += cap) {
+        const int nl = max(0, min(len - w0, cap));
+        for (int i = tid; i < nl; i += SNA_WG) acc[i] = 0.0;
+        double dacc = 0.0; // thread 0, first window: the diagonal entries, in source order
+        for (int qc = q0; qc < q1; qc += SNA_WG) {
+            const int nq = min(SNA_WG, q1 - qc);
+            __syncthreads(); // (the previous chunk's headers have been consumed; acc is zeroed)
+            if (tid < nq) {
+                const long long *hq = av.src + 3 * (long long)(qc + tid);
+                const long long cd = hq[2];
+                h_uo[tid] = hq[0];
+                h_so[tid] = hq[1];
+                h_cnt[tid] = (int)(cd & 0xffffffffll);
+                h_do[tid] = (int)(cd >> 32);
+            }
+            __syncthreads();
+            int slot[SNA_PF], slotn[SNA_PF];
+            double val[SNA_PF], valn[SNA_PF], dn = 0.0;
+            auto request = [&](int k, int i0, int(&sl)[SNA_PF], double(&vl)[SNA_PF]) {
+                const long long uo = h_uo[k], so = h_so[k];
+                const int cnt = h_cnt[k];
+#pragma unroll
+                for (int u = 0; u < SNA_PF; ++u) {
+                    const int i = max(0, min(i0 + u * SNA_WG, cnt - 1)); // (clamped: unconditional loads; cnt = 0: entry 0 of the
+                    sl[u] = sv.upd_slot[so + i];                          //  next source or the array's spare element, never used)
+                    vl[u] = sv.U[uo + i];
+                }
+            };
+            auto apply = [&](int k, int i0, const int(&sl)[SNA_PF], const double(&vl)[SNA_PF]) {
+                const int cnt = h_cnt[k];
+#pragma unroll
+                for (int u = 0; u < SNA_PF; ++u) {
+                    const int p = sl[u] - base - w0;
+                    if (i0 + u * SNA_WG < cnt && p >= 0 && p < nl) acc[p] += vl[u]; // (the rows of one source are distinct)
+                }
+            };
+            request(0, tid, slotn, valn);
+            if (tid == 0 && w0 == 0) dn = sv.Ud[h_do[0]];
+            for (int k = 0; k < nq; ++k) {
+#pragma unroll
+                for (int u = 0; u < SNA_PF; ++u) slot[u] = slotn[u], val[u] = valn[u];
+                const double dk = dn;
+                if (k + 1 < nq) {
+                    request(k + 1, tid, slotn, valn);
+                    if (tid == 0 && w0 == 0) dn = sv.Ud[h_do[k + 1]];
+                }
+                dacc += dk;
+                apply(k, tid, slot, val);
+                for (int i0 = tid + SNA_WG * SNA_PF; i0 < h_cnt[k]; i0 += SNA_WG * SNA_PF) { // (more than 1024 rows of B)
+                    request(k, i0, slot, val);
+                    apply(k, i0, slot, val);
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nl; i += SNA_WG) {
+            const double a = acc[i];
+            if (a != 0.0) v.Lx[base + w0 + i] -= a;
+        }
+        if (tid == 0 && w0 == 0) v.D[c] -= dacc;
+        __syncthreads();
+    }
 }
 // grid (supernodes of the level): the SN_NB x SN_NB diagonal block of block column b, right-looking, the
 // block in REGISTERS: thread (row i = lane, column quarter q = wave) holds T[i][16 q .. 16 q + 15]; the loop
@@ -1388,7 +1496,7 @@ SnDebug &sn_debug() {
 }
 } // namespace
 void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, const int *order, int count, int wmax_all,
-                   int nblk, int hmax, int nbmax, const LaunchProf *lp) {
+                   int nblk, int hmax, int nbmax, const LaunchProf *lp, const SnodeAsmView *av) {
     if (!count) return;
     SnodeView sv = sv_in;
     SnDebug &dbg = sn_debug();
@@ -1439,8 +1547,16 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
     }
     if (nbmax > 0 && sv.upd_slot) {
         pb(PFK_SN_EXTEND);
-        k_snode_extend<<<dim3((nbmax + SN_ROWS - 1) / SN_ROWS, (nbmax + SN_NB - 1) / SN_NB, count), SN_WG, lds, s>>>(
-            v, sv_in, order);
+        SnodeView se = sv_in;
+        if (!av || !av->nt) se.U = nullptr; // (this level scatters with atomics)
+        const int gx = (nbmax + SN_ROWS - 1) / SN_ROWS, gy = (nbmax + SN_NB - 1) / SN_NB;
+        const bool xcd = count >= 8 && !switches().no_xcd_map; // (fewer supernodes than XCDs: spread the tiles)
+        if (xcd) k_snode_extend<<<dim3((unsigned)(8 * ((count + 7) / 8) * gx * gy)), SN_WG, lds, s>>>(v, se, order, 1, gx, gy, count);
+        else k_snode_extend<<<dim3(gx, gy, count), SN_WG, lds, s>>>(v, se, order, 0, gx, gy, count);
+        if (se.U) {
+            const int cap = switches().sn_asm_cap > 0 ? std::min(switches().sn_asm_cap, SNA_CAP) : SNA_CAP; // (tests: short windows)
+            k_snode_assemble<<<av->nt, SNA_WG, 0, s>>>(v, se, *av, cap);
+        }
         pe(PFK_SN_EXTEND);
     }
 }

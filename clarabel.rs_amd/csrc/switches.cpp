@@ -37,6 +37,8 @@ const Entry TABLE[] = {
     {"CHIP_NO_TOPBLK", Entry::FLAG, SW(no_topblk), 0},
     {"CHIP_NO_GATHER_HOIST", Entry::FLAG, SW(no_gather_hoist), 0},
     {"CHIP_NO_XPERM", Entry::FLAG, SW(no_xperm), 0},
+    {"CHIP_NO_DENSE_SYMV", Entry::FLAG, SW(no_dense_symv), 0},
+    {"CHIP_DENSE_SYMV_MIN", Entry::LONG, SW(dense_symv_min), 0},
     {"CHIP_NO_FUSED_IR", Entry::FLAG, SW(no_fused_ir), 0},
     {"CHIP_NO_SYMV_SPLIT", Entry::FLAG, SW(no_symv_split), 0},
     {"CHIP_NO_FACTOR_LDS", Entry::FLAG, SW(no_factor_lds), 0},
@@ -58,6 +60,10 @@ const Entry TABLE[] = {
     {"CHIP_NO_SNODE_PANEL", Entry::FLAG, SW(no_snode_panel), 0},
     {"CHIP_NO_PANEL_MFMA", Entry::FLAG, SW(no_panel_mfma), 0},
     {"CHIP_NO_PANEL_DIAG_MFMA", Entry::FLAG, SW(no_panel_diag_mfma), 0},
+    {"CHIP_NO_EXTEND_ASM", Entry::FLAG, SW(no_extend_asm), 0},
+    {"CHIP_EXTEND_ASM_MIN", Entry::INT, SW(extend_asm_min), 0},
+    {"CHIP_NO_XCD_MAP", Entry::FLAG, SW(no_xcd_map), 0},
+    {"CHIP_SN_ASM_CAP", Entry::INT, SW(sn_asm_cap), 0},
     {"CHIP_DETERMINISTIC", Entry::FLAG, SW(deterministic), 0},
 };
 #undef SW

@@ -35,6 +35,8 @@ struct Switches {
     bool no_topblk = false;         // CHIP_NO_TOPBLK
     bool no_gather_hoist = false;   // CHIP_NO_GATHER_HOIST
     bool no_xperm = false;          // CHIP_NO_XPERM
+    long long dense_symv_min = 0;   // CHIP_DENSE_SYMV_MIN: fewest block entries for which the blocks leave S (tests; 0: 2^20)
+    bool no_dense_symv = false;     // CHIP_NO_DENSE_SYMV: dense diagonal blocks of the top stay in the full rows S of the residual
     // ---- engine / launchers ----
     bool no_fused_ir = false;       // CHIP_NO_FUSED_IR: one kernel per phase, refinement control on the host
     bool no_symv_split = false;     // CHIP_NO_SYMV_SPLIT
@@ -56,6 +58,10 @@ struct Switches {
     bool no_snode_panel = false;    // CHIP_NO_SNODE_PANEL: separate diag / rows launches
     bool no_panel_mfma = false;     // CHIP_NO_PANEL_MFMA
     bool no_panel_diag_mfma = false; // CHIP_NO_PANEL_DIAG_MFMA
+    bool no_extend_asm = false;     // CHIP_NO_EXTEND_ASM: ancestor updates always by fp64 atomics (k_snode_extend), never assembled
+    int extend_asm_min = 0;         // CHIP_EXTEND_ASM_MIN: fewest supernodes of a level whose updates are assembled (0: default 4)
+    bool no_xcd_map = false;        // CHIP_NO_XCD_MAP: the tiles of k_snode_extend spread over the XCDs, not one supernode per XCD
+    int sn_asm_cap = 0;             // CHIP_SN_ASM_CAP: rows of a target column per LDS window of k_snode_assemble (tests; 0: 4096)
     bool deterministic = false;     // CHIP_DETERMINISTIC: fixed-order reductions wherever an fp64 atomic decides a sum
 };
 

@@ -58,6 +58,9 @@ namespace {
 constexpr i32 T_MAX = 32;      // <= T_MAX entries: one thread per row
 constexpr i32 B_MIN = 16384;   // >  B_MIN entries: split over workgroups
 constexpr i32 B_CHUNK = 4096;  // entries per B chunk
+constexpr i32 DBLK_MIN_M = 64;          // smallest dense diagonal block of the top that the residual multiplies from V directly
+constexpr i32 DBLK_MAX_M = 6144;        // largest (k_dblk_symv keeps x and y of the block in LDS)
+constexpr i64 DBLK_MIN_ENTRIES = 1 << 20; // fewer block entries than this in total: the blocks stay in the full rows S
 constexpr i32 TOPFOLD_MAX = 8;    // at most this many top rows are folded into the bundle kernels (kernels.hpp)
 constexpr i32 TOPBLK = 128;       // rows per block of the blocked top substitution (bundle_solve.hip: TOPBLK)
 constexpr i64 F_MIN_WORK = 16384;    // factor: a column with more (contribution, tail entry) updates than this
@@ -988,13 +991,67 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         S.nnzU = S.Up[NFi];
         S.Ucol.assign(Thi.data(), Thi.data() + S.nnzU);
         S.Ucol.push_back(0);
+        // Dense diagonal blocks of the top: top nodes p_0 < p_1 < ... < p_{m-1} that K joins pairwise (a PSD or dense
+        // second-order cone's Hs block) and whose rows of T list each other FIRST: row p_a = (diagonal, p_{a+1}, ...,
+        // p_{m-1}, then whatever else).  The block's strict upper triangle then sits in V row by row, each row contiguous
+        // -- the residual multiplies it straight from there (k_dblk_symv: every entry read ONCE, no index arrays), and
+        // the full-row copy S below leaves these entries out.  Config 5: 200 blocks of 1275 hold 3.2e8 of S's 3.3e8
+        // entries; S cost 12 bytes per entry per product and an uncoalesced gather per refactor.
+        std::vector<i32> dblk_of((size_t)n, -1);
+        S.dblk_p0.clear();
+        S.dblk_m.clear();
+        S.dblk_start.clear();
+        S.dblk_node.clear();
+        if (!switches().no_dense_symv) {
+            for (i32 r = NFi; r < n; r++) {
+                if (dblk_of[(size_t)r] >= 0) continue;
+                i32 m = std::min<i32>(Tp[r + 1] - Tp[r], DBLK_MAX_M); // (the diagonal comes first: row length = 1 + others)
+                if (m < DBLK_MIN_M) continue;
+                const i32 *row0 = &Thi[Tp[r]];                        // row0[a] = p_a for a >= 1
+                for (i32 a = 1; a < m; a++) {
+                    const i32 q = row0[a];
+                    if (dblk_of[(size_t)q] >= 0) {
+                        m = a;
+                        break;
+                    }
+                    const i32 want = m - 1 - a, have = std::min<i32>(Tp[q + 1] - Tp[q] - 1, want);
+                    const i32 *rq = &Thi[Tp[q] + 1];
+                    i32 k = 0;
+                    while (k < have && rq[k] == row0[a + 1 + k]) k++;
+                    if (k < want) m = a + 1 + k;
+                }
+                if (m < DBLK_MIN_M) continue;
+                for (i32 a = 0; a < m; a++) {
+                    const i32 q = a ? row0[a] : r;
+                    dblk_of[(size_t)q] = (i32)S.dblk_p0.size();
+                    S.dblk_node.push_back(q);
+                    S.dblk_start.push_back(Tp[q] + 1);
+                }
+                S.dblk_p0.push_back(r);
+                S.dblk_m.push_back(m);
+            }
+            i64 ent = 0;
+            for (i32 m : S.dblk_m) ent += (i64)m * (m - 1) / 2;
+            if (ent < (switches().dense_symv_min > 0 ? switches().dense_symv_min : DBLK_MIN_ENTRIES)) { // (not worth two more launches per product)
+                S.dblk_p0.clear();
+                S.dblk_m.clear();
+                S.dblk_start.clear();
+                S.dblk_node.clear();
+                std::fill(dblk_of.begin(), dblk_of.end(), -1);
+            }
+            if (switches().timing)
+                std::fprintf(stderr, "[chip analyse] dense diagonal blocks of the top: %d (%lld entries leave the full rows)\n",
+                             (int)S.dblk_p0.size(), (long long)(S.dblk_p0.empty() ? 0 : ent));
+        }
+        auto in_block = [&](i32 r, i32 c) { return dblk_of[(size_t)r] >= 0 && dblk_of[(size_t)r] == dblk_of[(size_t)c] && r != c; };
         // S: full rows r >= NF = column r of C2 (lo <= r ascending, diagonal last) then row r of T without its diagonal
         S.Sp.assign((size_t)n + 1, 0);
         run_threads(par_threads((i64)Tp[n] - Tp[NFi]), [&](int t, int TT) {
             const i64 span = (i64)n - NFi;
             for (i32 r = NFi + (i32)(span * t / TT); r < NFi + (i32)(span * (t + 1) / TT); r++) {
-                i32 cntr = C2p[r + 1] - C2p[r];
-                for (i32 u = Tp[r]; u < Tp[r + 1]; u++) cntr += Thi[u] != r;
+                i32 cntr = 0;
+                for (i32 w = C2p[r]; w < C2p[r + 1]; w++) cntr += !in_block(r, C2lo[w]);
+                for (i32 u = Tp[r]; u < Tp[r + 1]; u++) cntr += Thi[u] != r && !in_block(r, Thi[u]);
                 S.Sp[r + 1] = cntr;
             }
         });
@@ -1009,11 +1066,12 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             for (i32 r = NFi + (i32)cuts[t]; r < NFi + (i32)cuts[t + 1]; r++) {
                 i32 o = S.Sp[r];
                 for (i32 w = C2p[r]; w < C2p[r + 1]; w++) {
+                    if (in_block(r, C2lo[w])) continue;
                     S.Scol[o] = C2lo[w];
                     S.Smap[o++] = C2src[w];
                 }
                 for (i32 u = Tp[r]; u < Tp[r + 1]; u++)
-                    if (Thi[u] != r) {
+                    if (Thi[u] != r && !in_block(r, Thi[u])) {
                         S.Scol[o] = Thi[u];
                         S.Smap[o++] = u;
                     }
@@ -1057,7 +1115,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     std::vector<i32> gpos; // index of a top node inside its group (by node - NF), grouped fold only
     if (grouped && S.nfold == 0 && ngroups >= 2 && !switches().no_topfold) {
         const i32 nbun = (i32)S.bundle_ptr.size() - 1;
-        bool ok = nbun > 0;
+        bool ok = nbun > 0 && S.dblk_p0.empty(); // (dense blocks of the top are not in the rows S the groups read)
         for (i32 g = 0; g < ngroups && ok; g++) ok = grp_first_bundle[g + 1] > grp_first_bundle[g];
         // group of every top node through its tree root (root_of / grp_of_root are in pass A's numbering:
         // order[t] = pass-A node of final node t)
@@ -1380,6 +1438,56 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         S.sn_lvl_nblk.assign((size_t)nfl, 0);
         S.sn_lvl_hmax.assign((size_t)nfl, 0);
         S.sn_lvl_nbmax.assign((size_t)nfl, 0);
+        // ancestor updates assembled per target column (host.hpp: asm_*)
+        if (nsn > 0) {
+            S.asm_uoff.assign((size_t)nsn, 0);
+            S.asm_doff.assign((size_t)nsn, 0);
+            S.asm_lvl_ptr.assign((size_t)nfl + 1, 0);
+            struct Trip {
+                i32 node, sn, cB;
+            };
+            std::vector<Trip> trips;
+            for (i32 l = 0; l < nfl; l++) {
+                trips.clear();
+                i64 uo = 0;
+                i32 dofs = 0, contributing = 0;
+                for (i32 u = S.sn_lvl_ptr[l]; u < S.sn_lvl_ptr[l + 1]; u++) {
+                    const i32 sn = S.sn_order[u];
+                    const i32 e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                    const i32 nb = S.Lp[e + 1] - S.Lp[e];
+                    S.asm_uoff[sn] = uo;
+                    S.asm_doff[sn] = dofs;
+                    uo += (i64)nb * (nb - 1) / 2;
+                    dofs += nb;
+                    contributing += nb > 0;
+                }
+                if (contributing >= 2) {
+                    for (i32 u = S.sn_lvl_ptr[l]; u < S.sn_lvl_ptr[l + 1]; u++) {
+                        const i32 sn = S.sn_order[u];
+                        const i32 e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                        const i32 *B = S.Li.data() + S.Lp[e];
+                        const i32 nb = S.Lp[e + 1] - S.Lp[e];
+                        for (i32 c = 0; c < nb; c++) trips.push_back({B[c], sn, c});
+                    }
+                    std::stable_sort(trips.begin(), trips.end(), [](const Trip &a, const Trip &b) { return a.node < b.node; });
+                    for (size_t k = 0; k < trips.size(); k++) {
+                        const Trip &t = trips[k];
+                        if (k == 0 || trips[k - 1].node != t.node) {
+                            S.asm_tgt.push_back(t.node);
+                            S.asm_src_ptr.push_back((i32)S.asm_src.size());
+                        }
+                        const i32 e = S.sn_col[S.sn_ptr[t.sn + 1] - 1];
+                        const i64 nb = S.Lp[e + 1] - S.Lp[e];
+                        const i64 tri = (i64)t.cB * nb - (i64)t.cB * (t.cB + 1) / 2;
+                        S.asm_src.push_back({S.asm_uoff[t.sn] + tri, S.upd_ptr[t.sn] + tri, (i32)(nb - t.cB - 1), S.asm_doff[t.sn] + t.cB});
+                    }
+                    S.asm_usize = std::max(S.asm_usize, uo);
+                    S.asm_dsize = std::max(S.asm_dsize, dofs);
+                }
+                S.asm_lvl_ptr[l + 1] = (i32)S.asm_tgt.size();
+            }
+            S.asm_src_ptr.push_back((i32)S.asm_src.size());
+        }
         // Forward substitution, supernode members: a member's row restricted to NON-member columns (bundle
         // columns and ordinary top columns; member columns of any supernode reach it through the dense pushes)
         // can be gathered as soon as the ordinary top columns it refers to are final -- usually long before its own

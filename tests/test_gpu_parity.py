@@ -1555,6 +1555,72 @@ def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
     assert np.max(np.abs(Lxa - Lxb)) <= 1e-10 * max(1.0, np.max(np.abs(Lxa)))
 
 
+@pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp", "chordal_sdp_long_columns"])
+def test_ancestor_updates_assembled_per_target_column(hip, oracle, which, monkeypatch):
+    """a unit level's update matrices written to a private buffer and summed per target column (k_snode_assemble, a
+    fixed order of summation) against the fp64 atomics of k_snode_extend: each against the oracle, their factors
+    against each other.  CHIP_EXTEND_ASM_MIN=2 assembles every level with two supernodes or more (default: four)."""
+    if which == "banded_qp":
+        pr, hs = problems.random_qp(20000, 40000, band=50, seed=1), None
+    elif which == "chordal_sdp":
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    else:  # target columns longer than the kernel's LDS window (4096 rows; here cut to 100)
+        pr = problems.chordal_sdp(12, 36, 8, 4, 9, seed=3)
+        hs = pr["hsblocks"]
+        monkeypatch.setenv("CHIP_SN_ASM_CAP", "100")
+    factors = {}
+    for form in ("CHIP_NO_EXTEND_ASM", "CHIP_EXTEND_ASM_MIN"):
+        monkeypatch.setenv(form, "2" if form == "CHIP_EXTEND_ASM_MIN" else "1")
+        ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1)
+        assert len(ks.supernodes()) > 1
+        K = ks.kkt_matrix()
+        Kc = hip.CscMatrix(ks.N, ks.N, K.colptr, K.rowval, ks.values())
+        f = hip.HipDirectLDLSolver(Kc, ks.maps()["dsigns"], hip.Settings.default(), perm=ks.perm)
+        f.refactor()
+        Lp, _, Lx, D, _ = f.factors()
+        factors[form] = (Lx, D, int(np.max(np.diff(Lp))))
+        monkeypatch.delenv(form)
+    (Lxa, Da, _), (Lxb, Db, longest) = factors["CHIP_NO_EXTEND_ASM"], factors["CHIP_EXTEND_ASM_MIN"]
+    assert relerr(Da, Db) <= 1e-10
+    assert np.max(np.abs(Lxa - Lxb)) <= 1e-10 * max(1.0, np.max(np.abs(Lxa)))
+    if which == "chordal_sdp_long_columns":
+        assert longest > 300
+
+
+@pytest.mark.parametrize("which", ["chordal_sdp", "wide_psd", "three_tiles"])
+def test_dense_blocks_of_the_top_in_the_residual(hip, oracle, which, monkeypatch):
+    """the Hs blocks of PSD cones whose rows sit in the top: the refinement residual multiplies them from K's values
+    directly (k_dblk_symv, every entry read once) and the full-row copy S of the top rows leaves them out -- the refined
+    solutions against the oracle and against the form without the mechanism
+    (CHIP_NO_DENSE_SYMV).  CHIP_DENSE_SYMV_MIN=1: the mechanism also for these small totals (default: 2^20 entries)."""
+    if which == "chordal_sdp":
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+    elif which == "wide_psd":
+        pr = problems.chordal_sdp(2, 40, 6, 1, 5, seed=7)
+    else:  # blocks of 1275: three row tiles of the kernel, the last one ragged
+        pr = problems.chordal_sdp(3, 50, 10, 3, 9, seed=2)
+    monkeypatch.setenv("CHIP_NO_DENSE_SYMV", "1")
+    ks0, _ = _check_update_and_solve(hip, oracle, pr, hs=pr["hsblocks"], nrhs=1)
+    assert hip.debug_counter(ks0, "dense_blocks") == 0
+    monkeypatch.delenv("CHIP_NO_DENSE_SYMV")
+    monkeypatch.setenv("CHIP_DENSE_SYMV_MIN", "1")
+    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=pr["hsblocks"], nrhs=3)
+    nb, rows = hip.debug_counter(ks, "dense_blocks"), hip.debug_counter(ks, "dense_block_rows")
+    assert nb >= 2 and rows >= 64 * nb
+    assert hip.debug_counter(ks, "nnzS") < hip.debug_counter(ks0, "nnzS") - rows * 60
+    # the same right-hand side through both handles: the refined solutions agree to rounding
+    rng = np.random.default_rng(3)
+    rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+    sols = []
+    for k in (ks0, ks):
+        k.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert k.solve(x, z)
+        sols.append(np.concatenate([x, z]))
+    assert relerr(sols[1], sols[0]) <= 1e-12
+
+
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
 def test_chain_supernodes_solve_without_lds_rows(hip, oracle, which, monkeypatch):
     """the substitutions through supernodes whose rows of B exceed the LDS budget (forced here by

@@ -38,7 +38,10 @@ exchange all go through the C ABI (include/clarabel_hip.h).
 --workload c2|c5|c5m: the other BASELINE configs (systems whose top runs as chain supernodes), with
         their own `roofline` (c2: HBM, the pipelined supernode substitution k_snode_tri; c5 / c5m: the f64
         matrix cores, k_snode_update, flops from the supernode geometry), `cpu_baseline` (the oracle, bounded;
-        c5 at quarter size) and `parity` (c2 / c5m: the oracle live; c5: tests/golden/c5_full_oracle.npz).
+        c5 at quarter size), `cpu_baseline_mt` (oracle/ldl_sn.c: a supernodal multifrontal LDL' on OpenMP threads --
+        the kind of engine the reference itself would pick for these systems, labelled "port-supernodal, NOT faer")
+        and `parity` (c2 / c5m: the oracle live; c5: tests/golden/c5_full_oracle.npz).  The default line carries
+        compact `c2` / `c5` objects with the same fields.
 """
 import argparse
 import json
@@ -307,6 +310,80 @@ def mt_leg(w, ko):
         return {"value": None, "error": repr(ex)[:300]}
 
 
+def sn_leg(w, hip, budget_s=60.0):
+    """labelled NON-reference comparator for the systems with dense fronts (configs 2 / 5), where the reference itself
+    would take faer's supernodal LDL' instead of QDLDL (ldlsolvers/auto.rs:60-88): oracle/ldl_sn.c, a multifrontal
+    supernodal LDL' with relaxed amalgamation on OpenMP threads -- "port-supernodal, NOT faer" (faer needs a Rust
+    toolchain).  Same K (the values the device holds + the static shift), same signs, same pivot rule, the product's
+    permutation re-postordered; one step = factor + 3 x (solve, residual, solve, residual), best of several thread
+    counts; its solution against the device's for the same right-hand side."""
+    try:
+        from oracle import ldl_sn
+        ks = w.ks
+        ncpu = os.cpu_count() or 1
+        N = ks.N
+        K = ks.kkt_matrix()
+        Kp, Ki = np.asarray(K.colptr).astype(np.int64), np.asarray(K.rowval).astype(np.int64)
+        Kx = np.ascontiguousarray(ks.values())
+        signs = np.asarray(ks.maps()["dsigns"]).astype(np.int8)
+        info = ks.linear_solver_info()
+        cols = np.repeat(np.arange(N), np.diff(Kp))
+        dpos = np.nonzero(Ki == cols)[0]
+        Kreg = Kx.copy()
+        Kreg[dpos] += info.last_regularizer * signs[cols[dpos]]
+        del cols
+        st = ks.settings
+        rng = np.random.default_rng(5)
+        bs = [rng.standard_normal(N) for _ in range(3)]
+        # the device's solution of the first right-hand side (default refinement)
+        ks.setrhs(bs[0][:w.n], bs[0][w.n:])
+        xg, zg = np.zeros(w.n), np.zeros(w.m)
+        ok_dev = ks.solve(xg, zg)
+        x_dev = np.concatenate([xg, zg])
+        best, prev, sn = None, None, None
+        t_leg = time.perf_counter()
+        t_an = None
+        for threads in [t for t in (1, 16, 64) if t <= ncpu] or [1]:
+            if prev is not None and (time.perf_counter() - t_leg > budget_s or best is not prev):
+                break  # (bounded: more threads only while they pay)
+            t0 = time.perf_counter()
+            del sn
+            sn = ldl_sn.LdlSN(N, Kp, Ki, np.asarray(ks.perm), threads=threads)
+            if t_an is None:
+                t_an = time.perf_counter() - t0
+            sn.factor(Kreg, signs, st.dynamic_regularization_eps, st.dynamic_regularization_delta)  # warm-up (pages, thread pool)
+            t0 = time.perf_counter()
+            okf, nreg = sn.factor(Kreg, signs, st.dynamic_regularization_eps, st.dynamic_regularization_delta)
+            xs = []
+            e = np.empty(N)
+            for b in bs:
+                x = b.copy()
+                sn.solve(x)
+                sn.residual(Kx, x, b, e)   # (one refinement round, as in the timed GPU step)
+                sn.solve(e)
+                x += e
+                sn.residual(Kx, x, b, e)
+                xs.append(x)
+            el = time.perf_counter() - t0
+            err = float(np.max(np.abs(xs[0] - x_dev)) / max(1.0, np.max(np.abs(x_dev)))) if ok_dev else None
+            cand = {"value": round(1.0 / el, 4), "threads": threads, "err": err, "ok": bool(okf), "nreg": nreg}
+            if best is None or cand["value"] > best["value"]:
+                best = cand
+            prev = cand
+        out = {"value": best["value"], "unit": "iterations/s", "cores": best["threads"],
+               "kind": "port-supernodal, NOT faer (oracle/ldl_sn.c: multifrontal LDL' with relaxed amalgamation, OpenMP over the "
+                       "assembly tree and inside the dense updates; the reference would run faer here, which needs a Rust toolchain)",
+               "sample": "1 step (factor + 3 x (solve, residual, solve, residual)) at N=%d for thread counts of {1, 16, 64} up to "
+                         "the host's %d cores, best kept; %d supernodes, %.3g flops per factorisation, analysis %.1f s (not timed); "
+                         "its solution against the device's: %s"
+                         % (N, ncpu, sn.nsn, sn.flops, t_an or 0.0, "%.1e" % best["err"] if best["err"] is not None else "n/a"),
+               "regularize_count": [int(best["nreg"]), int(info.regularize_count)]}
+        del sn
+        return out
+    except Exception as ex:  # a comparator, never a reason to lose the bench line
+        return {"value": None, "error": repr(ex)[:300]}
+
+
 def fixture_parity_c5(w, hip):
     """BASELINE config 5 at FULL size: the scalar oracle needs ~10 CPU-minutes for this factorisation, so its
     answers are a committed fixture (tests/golden/c5_full_oracle.npz, made by tests/golden/make_c5_fixture.py:
@@ -421,7 +498,7 @@ def extra_workload(hip, problems, which, args, device):
                "steps": steps, "step_ms": w.step_ms, "kkt_dim": ks.N, "nnz_L": int(info.nnzL), "setup_s": round(w.t_setup, 2),
                "roofline": roof, "whole_step_frac_of_hbm_peak": whole,
                "parity": None if parity is None else {k: parity[k] for k in ("rel_err_vs_oracle", "tol", "ok") if k in parity},
-               "cpu_baseline": cpu}
+               "cpu_baseline": cpu, "cpu_baseline_mt": None if args.cpu_steps == 0 else sn_leg(w, hip)}
         del w
         return out
     except Exception as ex:  # an extra, never a reason to lose the bench line
@@ -798,10 +875,13 @@ def main():
             parity = fixture_parity_c5(w, hip)
             if args.cpu_steps != 0:
                 cpu = quarter_c5_cpu_baseline(hip, problems, args)
+                cpu_mt = sn_leg(w, hip)
         elif not args.no_extras:
             parity, cpu, ko = oracle_leg(w, args, time_it=args.cpu_steps != 0)
             if args.cpu_steps != 0 and workload in ("c3", "c4"):
                 cpu_mt = mt_leg(w, ko)
+            elif args.cpu_steps != 0 and workload == "c2":
+                cpu_mt = sn_leg(w, hip)
             del ko
             if workload == "c3" and args.workload == "auto":
                 extras["l1_dropin"] = l1_dropin_leg(hip, w, args)

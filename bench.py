@@ -334,10 +334,11 @@ def sn_leg(w, hip, budget_s=60.0):
         del cols
         st = ks.settings
         rng = np.random.default_rng(5)
-        bs = [rng.standard_normal(N) for _ in range(3)]
+        nm = ks.n + ks.m  # (the sparse second-order cones' expansion variables follow: right-hand side 0, kktsolver setrhs)
+        bs = [np.concatenate([rng.standard_normal(nm), np.zeros(N - nm)]) for _ in range(3)]
         # the device's solution of the first right-hand side (default refinement)
-        ks.setrhs(bs[0][:w.n], bs[0][w.n:])
-        xg, zg = np.zeros(w.n), np.zeros(w.m)
+        ks.setrhs(bs[0][:ks.n], bs[0][ks.n:nm])
+        xg, zg = np.zeros(ks.n), np.zeros(ks.m)
         ok_dev = ks.solve(xg, zg)
         x_dev = np.concatenate([xg, zg])
         best, prev, sn = None, None, None
@@ -365,7 +366,7 @@ def sn_leg(w, hip, budget_s=60.0):
                 sn.residual(Kx, x, b, e)
                 xs.append(x)
             el = time.perf_counter() - t0
-            err = float(np.max(np.abs(xs[0] - x_dev)) / max(1.0, np.max(np.abs(x_dev)))) if ok_dev else None
+            err = float(np.max(np.abs(xs[0][:nm] - x_dev)) / max(1.0, np.max(np.abs(x_dev)))) if ok_dev else None
             cand = {"value": round(1.0 / el, 4), "threads": threads, "err": err, "ok": bool(okf), "nreg": nreg}
             if best is None or cand["value"] > best["value"]:
                 best = cand
@@ -381,7 +382,8 @@ def sn_leg(w, hip, budget_s=60.0):
         del sn
         return out
     except Exception as ex:  # a comparator, never a reason to lose the bench line
-        return {"value": None, "error": repr(ex)[:300]}
+        import traceback
+        return {"value": None, "error": repr(ex)[:200], "where": traceback.format_exc().strip().splitlines()[-3:]}
 
 
 def fixture_parity_c5(w, hip):

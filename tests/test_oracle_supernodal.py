@@ -7,10 +7,14 @@ import pytest
 from tests import problems
 
 
-def _kkt_case(oracle, pr, hs=None):
+def _kkt_case(hip, oracle, pr, hs=None):
+    """the oracle's factorisation under the PRODUCT's permutation (host analysis only: no GPU)"""
+    st = hip.Settings.default(device=hip.DEVICE_HOST_ONLY)
+    hk = hip.HipKKTSolver(hip.CscMatrix(pr["n"], pr["n"], *pr["P"]), hip.CscMatrix(pr["m"], pr["n"], *pr["A"]),
+                          pr["cones"], pr["m"], pr["n"], settings=st)
     cones = oracle.Cones(pr["cones"])
     assert cones.update_scaling(pr["s"], pr["z"])
-    ko = oracle.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones)
+    ko = oracle.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones, perm=hk.perm)
     assert ko.update(hs)
     import ctypes as C
     L = oracle.lib()
@@ -28,16 +32,16 @@ def _kkt_case(oracle, pr, hs=None):
 
 @pytest.mark.parametrize("threads", [1, 4])
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp", "socp"])
-def test_supernodal_comparator_reproduces_the_oracle(oracle, which, threads):
+def test_supernodal_comparator_reproduces_the_oracle(hip, oracle, which, threads):
     from oracle import ldl_sn
     if which == "banded_qp":
-        pr, hs = problems.random_qp(1500, 3000, band=20, seed=1), None
+        pr, hs = problems.random_qp(3000, 6000, band=20, seed=1), None
     elif which == "chordal_sdp":
         pr = problems.chordal_sdp(5, 12, 3, 4, 7, seed=5)
         hs = pr["hsblocks"]
     else:
         pr, hs = problems.portfolio_socp(6, 40, seed=3), None
-    ko, perm, D_o = _kkt_case(oracle, pr, hs)
+    ko, perm, D_o = _kkt_case(hip, oracle, pr, hs)
     Kp, Ki, Kx = np.asarray(ko.kkt.colptr), np.asarray(ko.kkt.rowval), np.asarray(ko.kkt.nzval).copy()
     N = ko.N
     signs = np.asarray(ko.dsigns).astype(np.int8)
@@ -77,11 +81,11 @@ def test_supernodal_comparator_reproduces_the_oracle(oracle, which, threads):
     assert np.max(np.abs(e - (b - Kf @ x))) <= 1e-12 * max(1.0, np.max(np.abs(b)))
 
 
-def test_supernodal_comparator_amalgamates_narrow_supernodes(oracle):
+def test_supernodal_comparator_amalgamates_narrow_supernodes(hip, oracle):
     """relaxed amalgamation: fewer, wider supernodes, same pivots"""
     from oracle import ldl_sn
-    pr = problems.random_qp(1500, 3000, band=20, seed=1)
-    ko, perm, D_o = _kkt_case(oracle, pr)
+    pr = problems.random_qp(3000, 6000, band=20, seed=1)
+    ko, perm, D_o = _kkt_case(hip, oracle, pr)
     Kp, Ki, Kx = np.asarray(ko.kkt.colptr), np.asarray(ko.kkt.rowval), np.asarray(ko.kkt.nzval).copy()
     N = ko.N
     signs = np.asarray(ko.dsigns).astype(np.int8)

@@ -799,8 +799,9 @@ def main():
         fam_name = {1: "k_bundle_symv (residual e = b - Kx over the %d bundle rows, ||e||inf folded in)" % ks.NF,
                     2: "k_gather_merged<1> (BWD top levels)", 3: "k_gather_merged<0> (FWD top levels)",
                     4: "k_factor_T",
-                    5: "k_bundle_ir (one launch = setrhs + %d x (LDL' solve + residual) + refinement decisions + getlhs; "
-                       "algorithmic bytes = %d x (B_solve + B_symv))" % (int(ir) + 1, int(ir) + 1),
+                    5: "%s (one launch = setrhs + %d x (LDL' solve + residual) + refinement decisions + getlhs; "
+                       "algorithmic bytes = %d x (B_solve + B_symv))"
+                       % ("k_gstep_solve" if ks.step_kernels() & 1 else "k_bundle_ir", int(ir) + 1, int(ir) + 1),
                     6: "k_bundle_factor (numeric LDL' of all bundle columns)",
                     7: "k_snode_update (left-looking update of a 64-column block of every supernode of a unit level: "
                        "16 x 64 tiles of v_mfma_f64_16x16x4_f64)",

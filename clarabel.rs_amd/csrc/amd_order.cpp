@@ -671,14 +671,19 @@ int amd_order_components(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale
         }
         return x;
     };
-    for (i64 c = 0; c < n; c++)
+    i64 ncomp = n; // (one component left: the whole graph is ordered at once, the rest of the scan is not needed)
+    for (i64 c = 0; c < n && ncomp > 1; c++)
         for (i64 p = Ap[c]; p < Ap[c + 1]; p++) {
             const i64 r = Ai[p];
             if (r < 0 || r >= n) return -9;
             if (r == c) continue;
             const i64 a = find(r), b = find(c);
-            if (a != b) root[a > b ? a : b] = a > b ? b : a;
+            if (a != b) {
+                root[a > b ? a : b] = a > b ? b : a;
+                ncomp--;
+            }
         }
+    if (ncomp == 1) return amd_order(n, Ap, Ai, dense_scale, perm, info);
     std::vector<i64> comp((size_t)n, -1), csize;
     for (i64 i = 0; i < n; i++) {
         const i64 r = find(i);

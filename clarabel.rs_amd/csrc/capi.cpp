@@ -558,6 +558,51 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
         pv.state = qs;
         pv.mapHs = h->mapHs;
         pv.fail = &E.mb_dev->soc_fail;
+        // every cone's Hs block one of the dense diagonal blocks of the top?  Then Hs is written row by row of the
+        // device's value order (k_psd_write_hs_rows) instead of through mapHs
+        if (pv.ncones > 0 && pd_max <= 64 && E.dblk.nblk > 0) {
+            const int nblk = E.dblk.nblk;
+            std::vector<i32> blk_cone((size_t)nblk, -1), row_ij(E.h_dblk_node.size(), 0);
+            std::vector<char> covered(pd_start.size(), 0);
+            size_t nc = 0;
+            for (int b = 0, o = 0; b < nblk; o += E.h_dblk_m[(size_t)b], b++) {
+                const i32 mb = E.h_dblk_m[(size_t)b];
+                const i64 z0 = (i64)E.h_perm[(size_t)E.h_dblk_node[(size_t)o]] - n;
+                if (z0 < 0) continue;
+                // the cone that holds z0 (cones ascend by start)
+                const size_t c = (size_t)(std::upper_bound(pd_start.begin(), pd_start.end(), (i32)z0) - pd_start.begin());
+                if (c == 0) continue;
+                const i32 st = pd_start[c - 1], nd = pd_dim[c - 1], numel = nd * (nd + 1) / 2;
+                if (mb != numel || covered[c - 1]) continue;
+                bool ok = true;
+                for (i32 a = 0; a < mb && ok; a++) {
+                    const i64 t = (i64)E.h_perm[(size_t)E.h_dblk_node[(size_t)(o + a)]] - n - st;
+                    if (t < 0 || t >= numel) {
+                        ok = false;
+                        break;
+                    }
+                    i32 j = (i32)((std::sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+                    while ((i64)j * (j + 1) / 2 > t) j--;
+                    while ((i64)(j + 1) * (j + 2) / 2 <= t) j++;
+                    row_ij[(size_t)(o + a)] = (i32)(t - (i64)j * (j + 1) / 2) | (j << 16);
+                }
+                if (!ok) continue;
+                blk_cone[(size_t)b] = (i32)(c - 1);
+                covered[c - 1] = 1;
+                nc++;
+            }
+            if (nc == pd_start.size()) {
+                int *r1, *r2;
+                if ((rc = E.upload(&r1, blk_cone, blk_cone.size()))) return rc;
+                if ((rc = E.upload(&r2, row_ij, row_ij.size()))) return rc;
+                pv.rows_nblk = nblk;
+                pv.blk_cone = r1;
+                pv.row_ij = r2;
+                pv.blk_m = E.dblk.m;
+                pv.blk_rowbase = E.dblk.rowbase;
+                pv.blk_start = E.dblk.start;
+            }
+        }
     }
     {
         dev::Ns3View &nv = h->ns3;
@@ -1609,6 +1654,7 @@ int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out
     if (k == "dense_blocks") *out = E.dblk.nblk;
     else if (k == "dense_block_rows") *out = E.dblk.nrows;
     else if (k == "nnzS") *out = (double)E.nnzS;
+    else if (k == "psd_hs_row_blocks") *out = h->psd.rows_nblk;
     else if (k == "assembled_levels") {
         int c = 0;
         for (size_t l = 0; l + 1 < E.asm_lvl_ptr.size(); l++) c += E.asm_lvl_ptr[l + 1] > E.asm_lvl_ptr[l];

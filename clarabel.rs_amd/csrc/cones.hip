@@ -1102,6 +1102,42 @@ __global__ __launch_bounds__(WG) void k_psd_write_hs(PsdView v, double *Kx, int 
     }
 }
 
+// The same entries written in the order they have in the device's value store: the Hs block of a cone is one of the
+// dense diagonal blocks of the top (kernels.hpp: DblkView), whose strict upper triangle sits there row by row, every
+// row contiguous -- a workgroup takes rows a = x, x + gridDim.x, ... of the block, threads run along a row: coalesced
+// 8-byte stores, no index array, no square roots (the svec pair (i, j) of every row comes packed from the host).
+// k_psd_write_hs walks the entries in the CALLER's order and scatters them through mapHs: 1.6e8 uncoalesced stores
+// per update on config 5 (2.2-2.6 ms; this form: see DESIGN 4.1).
+__global__ __launch_bounds__(WG) void k_psd_write_hs_rows(PsdView v, double *Kx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y, c = v.blk_cone[b];
+    if (c < 0) return;
+    const int n = v.dim[c], m = v.blk_m[b], rb = v.blk_rowbase[b];
+    double *Bl = (double *)smem;
+    int *ijl = (int *)(Bl + n * n);
+    const double *Bin = v.state + v.state_off[c];
+    for (int idx = threadIdx.x; idx < n * n; idx += WG) Bl[idx] = Bin[idx];
+    for (int a = threadIdx.x; a < m; a += WG) ijl[a] = v.row_ij[rb + a];
+    __syncthreads();
+    const double sqrt2 = 1.4142135623730951;
+    auto entry = [&](int i, int j, int k, int l) {
+        const double Ajl = Bl[j + l * n], Ajk = Bl[j + k * n];
+        if (i != j && k != l) return Bl[i + k * n] * Ajl + Bl[i + l * n] * Ajk;
+        if (i == j && k != l) return sqrt2 * Ajl * Ajk;
+        if (i != j && k == l) return sqrt2 * Bl[i + l * n] * Ajk;
+        return Ajl * Ajl;
+    };
+    for (int a = blockIdx.x; a < m; a += gridDim.x) {
+        const int ij = ijl[a], i = ij & 0xffff, j = ij >> 16;
+        const int st = v.blk_start[rb + a]; // first entry right of the diagonal; the diagonal itself sits just before
+        if (threadIdx.x == 0) Kx[st - 1] = -entry(i, j, i, j);
+        for (int bb = a + 1 + threadIdx.x; bb < m; bb += WG) {
+            const int kl = ijl[bb];
+            Kx[st + bb - a - 1] = -entry(i, j, kl & 0xffff, kl >> 16);
+        }
+    }
+}
+
 // mul_Hs: nonnegativecone.rs:103-108, zerocone.rs:98-100
 __global__ __launch_bounds__(WG) void k_nn_mul_hs(const int *__restrict__ rows, int count,
                                                   const double *__restrict__ w, double *y,
@@ -1979,6 +2015,13 @@ void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx) {
         return;
     }
     const int bpc = 16;
+    if (v.rows_nblk > 0 && !switches().no_psd_rows) { // every cone's block is a dense block of the top: row by row of the value store
+        const int numel = v.maxdim * (v.maxdim + 1) / 2;
+        const size_t lds2 = ((size_t)(v.maxdim * v.maxdim) * sizeof(double) + (size_t)numel * sizeof(int) + 15) & ~(size_t)15;
+        if (lds2 > 64 * 1024) (void)raise_dynamic_lds((const void *)k_psd_write_hs_rows, lds2);
+        k_psd_write_hs_rows<<<dim3(bpc, v.rows_nblk), WG, lds2, s>>>(v, Kx);
+        return;
+    }
     const size_t lds = ((size_t)(v.maxdim * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
     k_psd_write_hs<false><<<v.ncones * bpc, WG, lds, s>>>(v, Kx, bpc);
 }

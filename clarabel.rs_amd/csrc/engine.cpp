@@ -193,6 +193,8 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         if ((rc = upload(&drb, rowbase, rowbase.size()))) return rc;
         if ((rc = upload(&dst, S.dblk_start, S.dblk_start.size()))) return rc;
         if ((rc = upload(&drn, rownode, rownode.size()))) return rc;
+        h_dblk_node = S.dblk_node;
+        h_dblk_m = S.dblk_m;
         dblk.nblk = nblk;
         dblk.split = std::max(1, std::min(8, 1024 / nblk)); // (enough workgroups to fill the chip; a block's rows interleaved)
         dblk.mmax = mmax;

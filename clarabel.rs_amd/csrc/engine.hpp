@@ -88,6 +88,7 @@ struct Engine {
     double *sn_d = nullptr; // pivots of the supernode members, packed (dev::SnodeView::sn_d)
     int *sn_cnt = nullptr;  // dev::SnodeView::sn_cnt
     dev::DblkView dblk;       // dense diagonal blocks of the top in the residual (host.hpp: Symbolic::dblk_*)
+    std::vector<i32> h_dblk_node, h_dblk_m; // (host copies: the cone layer matches its Hs blocks against them)
     double *bt_view = nullptr; // b minus the blocks' products (enqueue_residual)
     // ancestor updates assembled per target column (dev::SnodeAsmView; host.hpp: Symbolic::asm_*)
     int *asm_tgt = nullptr, *asm_src_ptr = nullptr, *asm_doff = nullptr;

@@ -426,6 +426,11 @@ struct PsdView {
     const int *mapHs;
     int *fail;
     int fail_gen;
+    // Hs written row by row of the device's value order (k_psd_write_hs_rows): set when every PSD cone's block of K is
+    // one of the dense diagonal blocks of the top (DblkView) -- block b belongs to cone blk_cone[b] (-1: not a PSD
+    // cone's), its i-th row is the svec entry (row_ij & 0xffff, row_ij >> 16) of the cone
+    int rows_nblk = 0;
+    const int *blk_cone = nullptr, *row_ij = nullptr, *blk_m = nullptr, *blk_rowbase = nullptr, *blk_start = nullptr;
 };
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv);
 void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx);

@@ -616,8 +616,11 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, q = tid >> 6;
     const bool dbgme = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
     sn_stamp(sv.dbg, dbgme, 0);
-    const int row0 = j0 + nbw + (int)blockIdx.x * SNP_WG; // first of this group's rows below the block
-    if (blockIdx.x > 0 && row0 >= g.h) return;
+    // the rows below the block in groups of SNP_WG; workgroup x takes the groups x, x + gridDim.x, ... (a launch with
+    // many supernodes gets fewer workgroups per supernode than groups: each factors the diagonal block once and then
+    // walks several groups, instead of nine workgroups per supernode all repeating the 23 us block factorisation)
+    const int row_first = j0 + nbw + (int)blockIdx.x * SNP_WG; // first row of this workgroup's first group
+    if (blockIdx.x > 0 && row_first >= g.h) return;
     const bool live = i < nbw;
     if (tid < SN_NB) {
         colbase[tid] = g.cb[j0 + min(tid, nbw - 1)];
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // the supernode's workgroups to get here -- all of them hold the same result -- which needs no waiting: a
     // counter per supernode, reset by the one that finds it complete.
     if (tid == 0) {
-        const int nwg = max(1, (g.h - (j0 + nbw) + SNP_WG - 1) / SNP_WG); // workgroups of this supernode that got past the early return
+        const int nwg = max(1, min((int)gridDim.x, (g.h - (j0 + nbw) + SNP_WG - 1) / SNP_WG)); // workgroups of this supernode that got past the early return
         const int old = __hip_atomic_fetch_add(&sv.sn_cnt[sn], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         s_nreg = old == nwg - 1 ? (s_nreg | 0x40000000) : s_nreg;
         if (old == nwg - 1) __hip_atomic_store(&sv.sn_cnt[sn], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     sn_stamp(sv.dbg, dbgme, 4, true);
-    if (row0 >= g.h) return;
+    for (int row0 = row_first; row0 < g.h; row0 += (int)gridDim.x * SNP_WG) {
     if (rows_mfma & 1) {
         // ---- the rows below the block, blocked by 16 columns (round 3): a wave owns 64 rows.  Block kb of every row is
         //      finished by the recurrence in the lane = row form (120 products per row instead of 2016), and its effect
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int R = R0w + lane;                  // lane = row form
         const bool rowok = R < g.h;
         const int Rc = min(R, g.h - 1);
-        if (R0w >= g.h) return;                   // (whole wave beyond the panel; no workgroup barrier below)
+        if (R0w >= g.h) continue;                 // (whole wave beyond the panel; no workgroup barrier below)
         // blocks 1..3 in the accumulator layout: acc[jb - 1][t][r] = X[row 16 t + kq + 4 r][column 16 jb + l15]
         snode_v4d acc[3][4];
 #pragma unroll
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         sn_stamp(sv.dbg, dbgme, 6);
         sn_stamp(sv.dbg, dbgme, 7, true);
         if (sv.dbg && lane == 0) atomicMax((unsigned long long *)&sv.dbg[8], (unsigned long long)wall_clock64());
-        return;
+        continue;
     }
     // ---- the rows below the block: thread = row, its 64 entries in registers, right-looking (the products of one
     //      column are independent; per entry the subtractions happen in the order k = 0, 1, ... of qdldl.rs:610-640).
@@ -933,12 +936,13 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     sn_stamp(sv.dbg, dbgme, 6);
-    if (!rowok) return;
+    if (!rowok) continue;
 #pragma unroll
     for (int jj = 0; jj < SN_NB; ++jj)
         if (jj < nbw) v.Lx[colbase[jj] + R] = x[jj] * dinvl[jj];
     sn_stamp(sv.dbg, dbgme, 7, true);
     if (sv.dbg && tid == 0) atomicMax((unsigned long long *)&sv.dbg[8], (unsigned long long)wall_clock64()); // last workgroup's end
+    } // (groups of rows)
 }
 
 // Substitutions through a chain supernode, one workgroup per supernode of the unit level, the
@@ -1530,7 +1534,11 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
             if (dbg.mode == 2) sv.dbg = dbg.ring_slot(0);
             // (bit 0: rows phase on the matrix cores; bit 1: block factorisation on the matrix cores)
             const int panel_mode = (switches().no_panel_mfma ? 0 : 1) | (switches().no_panel_diag_mfma ? 0 : 2);
-            k_snode_panel<<<dim3(std::max(1, (below + SNP_WG - 1) / SNP_WG), count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
+            // (measured on config 5: 256 / 512 / 768 / 1024 workgroups per launch -> 50.4 / 51.0 / 50.6 / 50.8 ms per step; one group per workgroup: 52.2)
+            const int groups = std::max(1, (below + SNP_WG - 1) / SNP_WG);
+            const int slots = switches().sn_panel_slots > 0 ? switches().sn_panel_slots : 256;
+            const int gx = std::max(1, std::min(groups, slots / std::max(1, count)));
+            k_snode_panel<<<dim3(gx, count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
             pe(PFK_SN_DIAG);
             if (dbg.on && dbg.mode != 2) dbg.collect(s, 0);
             continue;

@@ -36,6 +36,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_FACTOR_FLAT", Entry::FLAG, SW(no_factor_flat), 0},
     {"CHIP_NO_TOPBLK", Entry::FLAG, SW(no_topblk), 0},
     {"CHIP_NO_GATHER_HOIST", Entry::FLAG, SW(no_gather_hoist), 0},
+    {"CHIP_NO_PSD_ROWS", Entry::FLAG, SW(no_psd_rows), 0},
     {"CHIP_NO_XPERM", Entry::FLAG, SW(no_xperm), 0},
     {"CHIP_NO_DENSE_SYMV", Entry::FLAG, SW(no_dense_symv), 0},
     {"CHIP_DENSE_SYMV_MIN", Entry::LONG, SW(dense_symv_min), 0},
@@ -58,6 +59,7 @@ const Entry TABLE[] = {
     {"CHIP_SN_SPLIT_MAX", Entry::INT, SW(sn_split_max), 0},
     {"CHIP_SN_SPLIT_UNIT", Entry::INT, SW(sn_split_unit), 0},
     {"CHIP_NO_SNODE_PANEL", Entry::FLAG, SW(no_snode_panel), 0},
+    {"CHIP_SN_PANEL_SLOTS", Entry::INT, SW(sn_panel_slots), 0},
     {"CHIP_NO_PANEL_MFMA", Entry::FLAG, SW(no_panel_mfma), 0},
     {"CHIP_NO_PANEL_DIAG_MFMA", Entry::FLAG, SW(no_panel_diag_mfma), 0},
     {"CHIP_NO_EXTEND_ASM", Entry::FLAG, SW(no_extend_asm), 0},

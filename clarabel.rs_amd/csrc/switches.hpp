@@ -34,6 +34,7 @@ struct Switches {
     bool no_factor_flat = false;    // CHIP_NO_FACTOR_FLAT (also read by the launcher of the bundle factorisation)
     bool no_topblk = false;         // CHIP_NO_TOPBLK
     bool no_gather_hoist = false;   // CHIP_NO_GATHER_HOIST
+    bool no_psd_rows = false;       // CHIP_NO_PSD_ROWS: the Hs blocks of PSD cones written through mapHs (caller's order), not row by row
     bool no_xperm = false;          // CHIP_NO_XPERM
     long long dense_symv_min = 0;   // CHIP_DENSE_SYMV_MIN: fewest block entries for which the blocks leave S (tests; 0: 2^20)
     bool no_dense_symv = false;     // CHIP_NO_DENSE_SYMV: dense diagonal blocks of the top stay in the full rows S of the residual
@@ -56,6 +57,8 @@ struct Switches {
     bool no_splitk = false;         // CHIP_NO_SPLITK
     int sn_split_target = 256, sn_split_max = 8, sn_split_unit = 1; // CHIP_SN_SPLIT_TARGET / _MAX / _UNIT
     bool no_snode_panel = false;    // CHIP_NO_SNODE_PANEL: separate diag / rows launches
+    int sn_panel_slots = 0;         // CHIP_SN_PANEL_SLOTS: workgroups of one k_snode_panel launch beyond which a workgroup walks several
+                                    // groups of 256 rows (0: 256; tests: 1 -> every workgroup walks all groups)
     bool no_panel_mfma = false;     // CHIP_NO_PANEL_MFMA
     bool no_panel_diag_mfma = false; // CHIP_NO_PANEL_DIAG_MFMA
     bool no_extend_asm = false;     // CHIP_NO_EXTEND_ASM: ancestor updates always by fp64 atomics (k_snode_extend), never assembled

@@ -18,7 +18,8 @@ int32_t chip_debug_spin(int32_t device, int32_t blocks, int32_t threads, int32_t
 int32_t chip_debug_set_switch(const char *name, const char *value_or_null);
 /* one structural figure of a KKT handle (opaque chip_kkt *, clarabel_hip.h) by name, for tests that must know which
  * mechanism a handle ended up with: "dense_blocks" / "dense_block_rows" (dense diagonal blocks of the top that the
- * residual multiplies from K's values directly), "nnzS" (entries of the full-row copy of the top rows),
+ * residual multiplies from K's values directly), "nnzS" (entries of the full-row copy of the top rows), "psd_hs_row_blocks" (> 0: the PSD cones write Hs row by row
+ * of the value store, k_psd_write_hs_rows),
  * "assembled_levels" (unit levels whose ancestor updates can be assembled per target column), "assembled_targets".
  * Returns CHIP_ERR_ARG for an unknown name. */
 int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out);

@@ -292,6 +292,37 @@ def test_c5_psd_scaling_on_device(hip, oracle, dim):
     assert ok and relerr(np.concatenate([x, z]), np.concatenate([xo, zo])) <= TOL
 
 
+@pytest.mark.parametrize("dim", [8, 21, 50])
+def test_psd_hs_written_row_by_row_of_the_value_store(hip, oracle, dim, monkeypatch):
+    """when every PSD cone's Hs block is one of the dense diagonal blocks of the top, the cones write Hs in the order the
+    entries have in the device's value store (k_psd_write_hs_rows: coalesced stores, no index array) instead of
+    scattering through mapHs: K against the oracle's, and against the scattered form (CHIP_NO_PSD_ROWS)"""
+    pr = problems.chordal_sdp(1 if dim >= 50 else 4, dim, min(3, dim - 1), 2, 7, seed=dim)
+    monkeypatch.setenv("CHIP_DENSE_SYMV_MIN", "1")
+    vals = {}
+    for form in ("rows", "CHIP_NO_PSD_ROWS"):
+        if form != "rows":
+            monkeypatch.setenv(form, "1")
+        ks, ko, cones = _solvers(hip, oracle, pr)
+        if dim >= 50:  # (a single clique: its block is in the top as a whole; the smaller instances may keep cone rows in
+            #            bundles.  The counter tells the structure; CHIP_NO_PSD_ROWS only selects the launch.)
+            assert hip.debug_counter(ks, "psd_hs_row_blocks") > 0
+        assert ks.update_scaling(pr["s"], pr["z"]) and cones.update_scaling(pr["s"], pr["z"])
+        assert ks.update()
+        assert ko.update(pr["hsblocks"])
+        assert relerr(ks.values(), ko.kkt.nzval) <= 1e-11
+        vals[form] = ks.values().copy()
+        rng = np.random.default_rng(1)
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        ks.setrhs(rx, rz)
+        ko.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert ks.solve(x, z)
+        ok, xo, zo = ko.solve()
+        assert ok and relerr(np.concatenate([x, z]), np.concatenate([xo, zo])) <= TOL
+    assert np.array_equal(vals["rows"], vals["CHIP_NO_PSD_ROWS"])  # (the same arithmetic per entry)
+
+
 def test_psd_scaling_failure_reported(hip):
     pr = problems.chordal_sdp(2, 4, 2, 1, 6, seed=2)
     P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])
@@ -1527,12 +1558,14 @@ def test_chain_supernodes_factor_parity(hip, oracle, which, monkeypatch):
         assert np.abs(np.asarray(La[pad.nonzero()])).max() == 0.0
 
 
-@pytest.mark.parametrize("form", ["CHIP_NO_SNODE_PANEL", "CHIP_NO_PANEL_MFMA", "CHIP_NO_PANEL_DIAG_MFMA"])
+@pytest.mark.parametrize("form", ["CHIP_NO_SNODE_PANEL", "CHIP_NO_PANEL_MFMA", "CHIP_NO_PANEL_DIAG_MFMA", "CHIP_SN_PANEL_SLOTS"])
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
 def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
     """the block column of a supernode has three older forms behind switches -- separate k_snode_diag / k_snode_rows
-    launches, and the scalar forms of the panel kernel's two phases: each against the oracle, and its factor against
-    the default form's (same pivots, entries within rounding)"""
+    launches, and the scalar forms of the panel kernel's two phases -- and, in launches with many supernodes, a form in
+    which a workgroup walks several groups of 256 rows (CHIP_SN_PANEL_SLOTS=1 forces it here: one workgroup per
+    supernode): each against the oracle, and its factor against the default form's (same pivots, entries within
+    rounding)"""
     if which == "banded_qp":
         pr, hs = problems.random_qp(20000, 40000, band=50, seed=1), None
     else:

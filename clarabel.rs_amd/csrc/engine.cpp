@@ -848,9 +848,10 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     sview.asm_doff = asm_doff;
     auto has_sn = [&](int l) { return nsn > 0 && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
     const dev::LaunchProf lprof = launch_prof();
-    // a level's ancestor updates are assembled per target column (no atomics, a fixed order of summation) when enough
-    // supernodes share targets for the atomics to collide -- or always, on request (settings: deterministic)
-    const int asm_min = switches().deterministic ? 2 : switches().extend_asm_min > 0 ? switches().extend_asm_min : 4;
+    // a level's ancestor updates can be assembled per target column (no atomics, a fixed order of summation): on request
+    // only (CHIP_DETERMINISTIC, or CHIP_EXTEND_ASM_MIN = fewest supernodes of a level).  Measured: the atomics are NOT
+    // what bounds k_snode_extend -- with the assembly config 5 is 0.5 ms per step slower (49.2 against 48.7), config 2 0.2 ms
+    const int asm_min = switches().deterministic ? 2 : switches().extend_asm_min > 0 ? switches().extend_asm_min : (1 << 30);
     auto run_supernodes = [&](int l) {
         if (!has_sn(l)) return;
         dev::factor_B(stream, vf, snx.B(l));

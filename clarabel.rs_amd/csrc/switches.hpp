@@ -62,7 +62,7 @@ struct Switches {
     bool no_panel_mfma = false;     // CHIP_NO_PANEL_MFMA
     bool no_panel_diag_mfma = false; // CHIP_NO_PANEL_DIAG_MFMA
     bool no_extend_asm = false;     // CHIP_NO_EXTEND_ASM: ancestor updates always by fp64 atomics (k_snode_extend), never assembled
-    int extend_asm_min = 0;         // CHIP_EXTEND_ASM_MIN: fewest supernodes of a level whose updates are assembled (0: default 4)
+    int extend_asm_min = 0;         // CHIP_EXTEND_ASM_MIN: fewest supernodes of a level whose updates are assembled (0: never, unless CHIP_DETERMINISTIC)
     bool no_xcd_map = false;        // CHIP_NO_XCD_MAP: the tiles of k_snode_extend spread over the XCDs, not one supernode per XCD
     int sn_asm_cap = 0;             // CHIP_SN_ASM_CAP: rows of a target column per LDS window of k_snode_assemble (tests; 0: 4096)
     bool deterministic = false;     // CHIP_DETERMINISTIC: fixed-order reductions wherever an fp64 atomic decides a sum

@@ -816,9 +816,11 @@ def main():
         traffic = traffic_src = None
         try:
             import glob
-            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-            kname = {1: "k_bundle_symv", 5: "k_bundle_ir", 6: "k_bundle_factor"}.get(fam)
-            if pj and kname and workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000:
+            suffix = {"c3": "", "c2": "_c2", "c5": "_c5"}.get(workload)
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic%s.json" % suffix))) if suffix is not None else []
+            kname = {1: "k_bundle_symv", 5: "k_bundle_ir", 6: "k_bundle_factor", 7: "k_snode_update", 11: "k_snode_tri"}.get(fam)
+            full_size = (workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000) or workload in ("c2", "c5")
+            if pj and kname and full_size:
                 traffic = json.load(open(pj[-1]))["kernels"][kname]["hbm_bytes"]
                 traffic_src = os.path.basename(pj[-1])
         except Exception:
@@ -843,7 +845,8 @@ def main():
             ach = per_launch / (avg_ms * 1e-3) / 1e12
             f_dense = wm["sn_update_flops"] + wm["sn_extend_flops"] + wm["sn_diag_rows_flops"]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_F64_PEAK_TFLOPS, 4), "traffic": None, "kernel": fam_name,
+                    "frac": round(ach / MFMA_F64_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_profiled_in": traffic_src,
+                    "kernel": fam_name,
                     "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
                     "flops_per_launch": round(per_launch), "flops_per_refactor_update_tiles": wm["sn_update_flops"],
                     "kernel_ms_per_step": round(prof["ms"] / args.steps, 3),
@@ -859,7 +862,8 @@ def main():
             avg_ms = prof["ms"] / prof["launches"]
             ach = per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": fam_name,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profiled_in": traffic_src,
+                    "kernel": fam_name,
                     "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
                     "algorithmic_bytes_per_launch": round(per_launch),
                     "kernel_ms_per_step": round(prof["ms"] / args.steps, 3), "whole_step": whole}

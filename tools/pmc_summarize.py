@@ -26,10 +26,14 @@ def per_kernel(path, counter):
 
 def main():
     base, out = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "auto"
+    desc = {"auto": "bench.py default (config 3, n=10^6)", "c2": "bench.py --workload c2 (config 2, QP n=1e5)",
+            "c5": "bench.py --workload c5 (config 5, 200 x PSD(50) + 200 x SOC(51))",
+            "c4": "bench.py --workload c4"}.get(workload, workload)
     f = per_kernel(base + "/pmc_FETCH_SIZE/p_counter_collection.csv", "FETCH_SIZE")
     w = per_kernel(base + "/pmc_WRITE_SIZE/p_counter_collection.csv", "WRITE_SIZE")
     res = {"unit": "bytes per launch", "correction": "read = 2 x FETCH_SIZE (gfx950), write = WRITE_SIZE",
-           "workload": "bench.py default (config 3, n=10^6)", "kernels": {}}
+           "workload": desc, "kernels": {}}
     for k in sorted(set(f) | set(w)):
         if not k.startswith("k_"):
             continue

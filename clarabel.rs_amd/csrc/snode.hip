@@ -945,6 +945,251 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     } // (groups of rows)
 }
 
+// ---------------------------------------------------------------------------
+// k_snode_panel with the two phases OVERLAPPED (round 4).  In k_snode_panel the block factorisation goes quarter by
+// quarter -- one wave does 16 pivots while the other three wait, ~5.8 us per quarter -- and only then do the rows below
+// the block start their own four quarter steps (~4.8 us each): 23 + 19 us one after the other, on the critical path of
+// every one of config 2's 129 block columns.  Rows step kb needs nothing but quarter kb of the factored block.  Here a
+// workgroup has EIGHT waves: waves 0-3 factor the block exactly as before, waves 4-7 hold the first group of 256 rows
+// in registers and take step kb right after the barrier that publishes quarter kb, while the block team is busy with
+// quarter kb + 1.  Afterwards all eight waves walk the workgroup's remaining row groups (512 rows per round).  Both
+// phases in their matrix-core forms only (the scalar forms stay in k_snode_panel); Ll and the waves' head blocks in
+// dynamic LDS (~104 KiB).
+// ---------------------------------------------------------------------------
+constexpr int SNQ_WG = 512;
+__device__ __forceinline__ void snq_rows(const LdlView &v, const SnodeGeom &g, const double *Ll, const double *dinvl,
+                                         const int *colbase, double *xw, int R0w, int nbw, int lane, int kb_from, int kb_to,
+                                         snode_v4d (&acc)[3][4], double (&h)[16], bool load) {
+    // rows R0w .. R0w + 63 of the panel (lane = row in the head-block form): steps kb_from .. kb_to - 1 of the blocked
+    // recurrence of k_snode_panel; `load`: fetch the rows first (step 0 only)
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int R = R0w + lane;
+    const bool rowok = R < g.h;
+    const int Rc = min(R, g.h - 1);
+    if (load) {
+#pragma unroll
+        for (int jb = 1; jb < 4; ++jb) {
+            const int jj = 16 * jb + l15;
+            const int cb = colbase[jj];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = min(R0w + 16 * t + kq + 4 * r, g.h - 1);
+                    const double xv = v.Lx[cb + row];
+                    acc[jb - 1][t][r] = jj < nbw ? xv : 0.0;
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h[c] = v.Lx[colbase[c] + Rc];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h[c] = c < nbw ? h[c] : 0.0;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        if (kb < kb_from || kb >= kb_to) continue;
+        if (kb > 0) { // the head block leaves the accumulator layout: [row][column] in LDS, then a row per lane
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = acc[kb - 1][t][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) h[c] = xw[lane * SNP_XLD + c];
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double *Lb = Ll + (16 * kb) * SN_NB + 16 * kb;
+#pragma unroll
+        for (int kk = 0; kk < 15; ++kk) {
+            const double uq = h[kk];
+            int zoff; // (ties the column's LDS reads to its place in the chain, see k_snode_panel)
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(uq)));
+            const snode_v2d *cf = (const snode_v2d *)(Lb + kk * SN_NB + zoff);
+#pragma unroll
+            for (int p2 = (kk + 1) / 2; p2 < 8; ++p2) {
+                const snode_v2d cc = cf[p2];
+                h[2 * p2] -= cc.x * uq;
+                h[2 * p2 + 1] -= cc.y * uq;
+            }
+        }
+        if (rowok) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int jj = 16 * kb + c;
+                if (jj < nbw) v.Lx[colbase[jj] + R] = h[c] * dinvl[jj];
+            }
+        }
+        if (kb == 3) break;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) xw[lane * SNP_XLD + c] = -h[c];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            double a4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a4[t] = xw[(16 * t + l15) * SNP_XLD + 4 * s4 + kq];
+#pragma unroll
+            for (int jb = kb + 1; jb < 4; ++jb) {
+                const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * jb + l15];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[jb - 1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], bv, acc[jb - 1][t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ __launch_bounds__(SNQ_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snode_panel2(LdlView v, SnodeView sv, const int *__restrict__ order,
+                                                                                                   int b) {
+    extern __shared__ __attribute__((aligned(16))) char qsm[];
+    double *Ll = (double *)qsm;                 // Ll[k * 64 + i] = l(i, k), 0 for i <= k
+    double *xhb = Ll + SN_NB * SN_NB;           // eight head blocks, [row][column], stride SNP_XLD
+    __shared__ double dinvl[SN_NB], sgn[SN_NB];
+    __shared__ int colbase[SN_NB];
+    __shared__ int s_nreg, s_bad;
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
+    const int j0 = b * SN_NB;
+    if (j0 >= g.w) return;
+    const int nbw = min(SN_NB, g.w - j0), tid = threadIdx.x, i = tid & 63, wave = tid >> 6;
+    const bool teamD = wave < 4;
+    const int q = wave & 3;
+    // row groups of 256 below the block; workgroup x takes the groups x, x + gridDim.x, ...: the first one by the rows
+    // team alongside the block factorisation, the others by all eight waves
+    const int row_first = j0 + nbw + (int)blockIdx.x * SNP_WG;
+    if (blockIdx.x > 0 && row_first >= g.h) return;
+    const bool live = i < nbw;
+    if (tid < SN_NB) {
+        colbase[tid] = g.cb[j0 + min(tid, nbw - 1)];
+        sgn[tid] = tid < nbw ? (double)g.sg[j0 + tid] : 1.0;
+    }
+    if (tid == 0) {
+        s_nreg = 0;
+        s_bad = 0;
+    }
+    __syncthreads();
+    const int ci = live ? g.cols[j0 + i] : 0;
+    const double sgl = sgn[i];
+    double dfin = 1.0, dinvfin = 1.0;
+    int nreg = 0, bad = 0;
+    const int l15 = i & 15, kq = i >> 4;
+    double *xw = xhb + wave * (64 * SNP_XLD);
+    snode_v4d racc[3][4];
+    double rh[16];
+    // (a wave belongs to one team: the block team's quarter and its lane = row copy live in the registers the rows team
+    // uses for its rows -- both sets at once do not fit 256 registers)
+    snode_v4d(&Aq)[4] = racc[0];
+    double(&T)[16] = rh;
+    const int R0first = row_first + 64 * q; // rows team: this wave's 64 rows of the first group
+    const bool rlive = !teamD && R0first < g.h;
+    if (teamD) {
+        const int j = 16 * q + l15; // this lane's column
+        const bool jok = j < nbw;
+        const int cb = colbase[j];
+        const double djj = jok ? v.D[g.cols[j0 + min(j, nbw - 1)]] : 1.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + kq + 4 * r;
+                double val = (jok && row < nbw && row > j) ? v.Lx[cb + j0 + row] : 0.0;
+                if (row == j) val = djj;
+                Aq[t][r] = val;
+            }
+    } else if (rlive) {
+        snq_rows(v, g, Ll, dinvl, colbase, xw, R0first, nbw, i, 0, 0, racc, rh, true); // (loads only)
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < SN_NB / 16; ++kb) {
+        if (teamD && q == kb) { // (as in k_snode_panel: the owner factors its quarter in the lane = row form)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = Aq[t][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) T[c] = xw[i * SNP_XLD + c];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int c = 16 * kb + t;
+                double d = readlane_f64(T[t], c);
+                const double sg = readlane_f64(sgl, c);
+                const bool reg = d * sg < v.reg_eps;
+                if (reg) d = v.reg_delta * sg;
+                const double dinv = 1.0 / d;
+                if (i == c) {
+                    dfin = d;
+                    dinvfin = dinv;
+                    if (reg) nreg = 1;
+                    if (d == 0.0) bad |= 2;
+                    if (!isfinite(dinv)) bad |= 1;
+                }
+                const double uc = i > c ? T[t] : 0.0;
+                const double l = uc * dinv;
+                T[t] = l;
+                xw[i * SNP_XLD + t] = -uc;
+                Ll[c * SN_NB + i] = l;
+                if (i == 0) dinvl[c] = dinv;
+#pragma unroll
+                for (int t2 = t + 1; t2 < 16; ++t2) T[t2] -= readlane_f64(l, 16 * kb + t2) * uc;
+            }
+        }
+        __syncthreads(); // quarter kb of Ll, its pivots and the owner's negated panel are published
+        if (teamD) {
+            if (q > kb) {
+                const double *xo = xhb + kb * (64 * SNP_XLD);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * q + l15];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = xo[(16 * t + l15) * SNP_XLD + 4 * s4 + kq];
+                        Aq[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Aq[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (rlive) {
+            snq_rows(v, g, Ll, dinvl, colbase, xw, R0first, nbw, i, kb, kb + 1, racc, rh, false);
+        }
+    }
+    if (nreg) atomicAdd(&s_nreg, 1);
+    if (bad) atomicOr(&s_bad, bad);
+    __syncthreads();
+    // the factored block goes back in place, written by the LAST of the supernode's workgroups to get here (see k_snode_panel)
+    if (tid == 0) {
+        const int nwg = max(1, min((int)gridDim.x, (g.h - (j0 + nbw) + SNP_WG - 1) / SNP_WG));
+        const int old = __hip_atomic_fetch_add(&sv.sn_cnt[sn], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_nreg = old == nwg - 1 ? (s_nreg | 0x40000000) : s_nreg;
+        if (old == nwg - 1) __hip_atomic_store(&sv.sn_cnt[sn], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool writer = (s_nreg & 0x40000000) != 0;
+    if (writer && teamD) {
+        if (q == i / 16 && live) { // the owner of column i
+            v.D[ci] = dfin;
+            v.Dinv[ci] = dinvfin;
+            g.d[j0 + i] = dfin;
+        }
+        if (tid == 0) {
+            if (s_nreg & 0xffff) atomicAdd(&v.status[2], s_nreg & 0xffff);
+            if (s_bad & 2) v.status[1] = 1;
+            if (s_bad & 1) v.status[0] = 1;
+        }
+        // (T holds the scaled quarter in the lane = row form only for the quarter's owner: wave q owns columns 16 q ..)
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int j = 16 * q + cc;
+            if (live && j < nbw && i > j) v.Lx[colbase[j] + j0 + i] = T[cc];
+        }
+    }
+    // the workgroup's other row groups: all eight waves, two groups (512 rows) per round
+    const int gstride = (int)gridDim.x * SNP_WG;
+    for (int base = row_first + gstride; base < g.h; base += 2 * gstride) {
+        const int R0w = (teamD ? base : base + gstride) + 64 * q;
+        if (R0w < g.h) snq_rows(v, g, Ll, dinvl, colbase, xw, R0w, nbw, i, 0, 4, racc, rh, true);
+    }
+}
+
 // Substitutions through a chain supernode, one workgroup per supernode of the unit level, the
 // members' slice of x (and the nb entries of the rows of B) in LDS, block columns of SN_NB:
 //   forward  (qdldl.rs:708-719): x_S <- (I + L_SS)^-1 x_S block by block -- the 64 unknowns of a block
@@ -1360,6 +1605,7 @@ int snode_kernel_attributes(int wmax, int nbmax) {
     int rc = (int)raise_dynamic_lds((const void *)k_snode_update, (size_t)lds);
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_extend, (size_t)lds);
     const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
+    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_fwd, (size_t)lds2);
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_bwd, (size_t)lds2);
     return rc;
@@ -1538,7 +1784,12 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
             const int groups = std::max(1, (below + SNP_WG - 1) / SNP_WG);
             const int slots = switches().sn_panel_slots > 0 ? switches().sn_panel_slots : 256;
             const int gx = std::max(1, std::min(groups, slots / std::max(1, count)));
-            k_snode_panel<<<dim3(gx, count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
+            if (panel_mode == 3 && !dbg.on && !switches().no_panel_overlap) { // both phases on the matrix cores, overlapped
+                const size_t qlds = (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double);
+                k_snode_panel2<<<dim3(gx, count), SNQ_WG, qlds, s>>>(v, sv, order, b);
+            } else {
+                k_snode_panel<<<dim3(gx, count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
+            }
             pe(PFK_SN_DIAG);
             if (dbg.on && dbg.mode != 2) dbg.collect(s, 0);
             continue;

@@ -1558,14 +1558,16 @@ def test_chain_supernodes_factor_parity(hip, oracle, which, monkeypatch):
         assert np.abs(np.asarray(La[pad.nonzero()])).max() == 0.0
 
 
-@pytest.mark.parametrize("form", ["CHIP_NO_SNODE_PANEL", "CHIP_NO_PANEL_MFMA", "CHIP_NO_PANEL_DIAG_MFMA", "CHIP_SN_PANEL_SLOTS"])
+@pytest.mark.parametrize("form", ["CHIP_NO_SNODE_PANEL", "CHIP_NO_PANEL_MFMA", "CHIP_NO_PANEL_DIAG_MFMA", "CHIP_SN_PANEL_SLOTS",
+                                  "CHIP_NO_PANEL_OVERLAP", "CHIP_NO_PANEL_OVERLAP+CHIP_SN_PANEL_SLOTS"])
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
 def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
     """the block column of a supernode has three older forms behind switches -- separate k_snode_diag / k_snode_rows
     launches, and the scalar forms of the panel kernel's two phases -- and, in launches with many supernodes, a form in
     which a workgroup walks several groups of 256 rows (CHIP_SN_PANEL_SLOTS=1 forces it here: one workgroup per
-    supernode): each against the oracle, and its factor against the default form's (same pivots, entries within
-    rounding)"""
+    supernode); CHIP_NO_PANEL_OVERLAP: the panel kernel whose block factorisation and rows run one after the other
+    (k_snode_panel) instead of overlapped by two teams of waves (k_snode_panel2, the default): each against the oracle,
+    and its factor against the default form's (same pivots, entries within rounding)"""
     if which == "banded_qp":
         pr, hs = problems.random_qp(20000, 40000, band=50, seed=1), None
     else:
@@ -1579,7 +1581,8 @@ def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
     fa = hip.HipDirectLDLSolver(Kc, dsigns, hip.Settings.default(), perm=ks.perm)
     fa.refactor()
     _, _, Lxa, Da, _ = fa.factors()
-    monkeypatch.setenv(form, "1")
+    for name in form.split("+"):
+        monkeypatch.setenv(name, "1")
     ks2, _ = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1)
     fb = hip.HipDirectLDLSolver(Kc, dsigns, hip.Settings.default(), perm=ks.perm)
     fb.refactor()

@@ -635,6 +635,47 @@ __device__ bool lds_cholesky(double *A, int n, int *flag) {
 // GS = false: the four n x n work matrices live in LDS (n <= 64); GS = true: in this cone's slice of a scratch
 // buffer in HBM (L2 resident: 4 n^2 doubles = 0.5 MB at n = 128) -- the same algorithm for cones of any size
 // (the reference calls LAPACK and has no limit, psdtrianglecone.rs:144-204)
+// C = op(A) op(B), all n x n column major; A / B may live in LDS or (L2-resident) global memory.
+// n >= 16 (and not switched off: CHIP_NO_PSD_MFMA): 16 x 16 tiles of C on the f64 matrix cores, a wave per tile, k in
+// steps of four (v_mfma_f64_16x16x4_f64: lane (l15, kq) supplies A(row l15, k kq) and B(k kq, column l15) and receives
+// C(rows kq + 4 r, column l15)); rows / columns / k beyond n are clamped loads multiplied by zero.  One thread per
+// element of C with an n-long dot product -- the form below -- issues 2 n loads and n multiply-adds per element: at
+// n = 96 the three n x n products of an operation took most of its time.  The matrix instruction fuses its
+// multiply-adds and sums k in another order than the scalar loop: results agree to rounding (the cone tests' tolerances).
+__device__ int g_psd_no_mfma = 0;
+template <bool TA, bool TB>
+__device__ __forceinline__ void psd_gemm(double *C, const double *A, const double *B, int n) {
+    if (n >= 16 && !g_psd_no_mfma) {
+        typedef double gemm_v4d __attribute__((ext_vector_type(4)));
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
+        const int nt = (n + 15) / 16;
+        for (int tile = wave; tile < nt * nt; tile += WG / 64) {
+            const int i0 = 16 * (tile % nt), j0 = 16 * (tile / nt);
+            const int ia = min(i0 + l15, n - 1), jb = min(j0 + l15, n - 1);
+            const double am = i0 + l15 < n ? 1.0 : 0.0, bm = j0 + l15 < n ? 1.0 : 0.0;
+            gemm_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < n; k0 += 4) {
+                const int kk = min(k0 + kq, n - 1);
+                const double km = k0 + kq < n ? 1.0 : 0.0;
+                const double a = (TA ? A[kk + ia * n] : A[ia + kk * n]) * (am * km);
+                const double b = (TB ? B[jb + kk * n] : B[kk + jb * n]) * bm;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + kq + 4 * r, col = j0 + l15;
+                if (row < n && col < n) C[row + col * n] = acc[r];
+            }
+        }
+        return;
+    }
+    for (int idx = threadIdx.x; idx < n * n; idx += WG) {
+        const int i = idx % n, j = idx / n;
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc += (TA ? A[k + i * n] : A[i + k * n]) * (TB ? B[j + k * n] : B[k + j * n]);
+        C[idx] = acc;
+    }
+}
 template <bool GS>
 __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const double *__restrict__ sv,
                                                            const double *__restrict__ zv) {
@@ -665,14 +706,18 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
         if (tid == 0) *v.fail = v.fail_gen;
         return;
     }
-    // M = L2' L1 ; V = I
+    // M = L2' L1 ; V = I  (the factors' strict upper triangles still hold the symmetric input: zeroed, so that the
+    // products below are plain n x n products for the matrix cores)
     for (int idx = tid; idx < n * n; idx += WG) {
         const int a = idx % n, b = idx / n;
-        double acc = 0.0;
-        for (int i = (a > b ? a : b); i < n; ++i) acc += Bm[i + a * n] * A[i + b * n];
-        Cm[idx] = acc;
+        if (a < b) {
+            A[idx] = 0.0;
+            Bm[idx] = 0.0;
+        }
         Vm[idx] = (a == b) ? 1.0 : 0.0;
     }
+    __syncthreads();
+    psd_gemm<true, false>(Cm, Bm, A, n);
     __syncthreads();
     // one-sided Jacobi, round-robin pairing over np players (np even), EIGHT lanes per pair: each lane takes every
     // eighth row of the two columns (dot products as 8 partial sums + three butterfly steps inside the 8-lane
@@ -767,26 +812,29 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
         lam[rank[p]] = sig[p];
         lis[rank[p]] = 1.0 / sqrt(sig[p]);
     }
-    // R = L1 V Sigma^-1/2 (column p -> rank[p]);  Rinv = Sigma^-1/2 U' L2' with U = (M V) Sigma^-1
+    // R = L1 V Sigma^-1/2 (column p -> rank[p]);  Rinv = Sigma^-1/2 U' L2' with U = (M V) Sigma^-1: the two products
+    // L1 V and L2 (M V) through Bout as scratch (it receives B = R R' last), then scaled and permuted into place
+    psd_gemm<false, false>(Bout, A, Vm, n);
+    __syncthreads();
+    __threadfence_block(); // (Bout is global memory: written by one wave, read by another)
     for (int idx = tid; idx < n * n; idx += WG) {
         const int i = idx % n, p = idx / n;
-        double acc = 0.0;
-        for (int k = 0; k <= i; ++k) acc += A[i + k * n] * Vm[k + p * n];
         const double lsq = 1.0 / sqrt(sig[p]);
-        Rout[i + rank[p] * n] = acc * sgn[p] * lsq;
-        double acc2 = 0.0; // Rinv[p, i] = lsq/sig * sum_k Cm[k,p] L2[i,k]
-        for (int k = 0; k <= i; ++k) acc2 += Cm[k + p * n] * Bm[i + k * n];
-        Riout[rank[p] + i * n] = (acc2 / sig[p]) * sgn[p] * lsq;
+        Rout[i + rank[p] * n] = Bout[idx] * sgn[p] * lsq;
+    }
+    __syncthreads();
+    psd_gemm<false, false>(Bout, Bm, Cm, n); // (L2 (M V))[i, p] = sum_k L2[i,k] Cm[k,p]
+    __syncthreads();
+    __threadfence_block();
+    for (int idx = tid; idx < n * n; idx += WG) {
+        const int i = idx % n, p = idx / n;
+        const double lsq = 1.0 / sqrt(sig[p]);
+        Riout[rank[p] + i * n] = (Bout[idx] / sig[p]) * sgn[p] * lsq;
     }
     __syncthreads();
     __threadfence_block();
     // B = R R' (invariant under the conventions above)
-    for (int idx = tid; idx < n * n; idx += WG) {
-        const int i = idx % n, j = idx / n;
-        double acc = 0.0;
-        for (int p = 0; p < n; ++p) acc += Rout[i + p * n] * Rout[j + p * n];
-        Bout[idx] = acc;
-    }
+    psd_gemm<false, true>(Bout, Rout, Rout, n);
 }
 
 // ---- PSD cone operations either side of the solve: one workgroup per cone, matrices in LDS ----
@@ -808,16 +856,6 @@ __device__ __forceinline__ void psd_mat_to_svec(double *y, const double *M, int 
         while ((col + 1) * (col + 2) / 2 <= t) ++col;
         const int row = t - col * (col + 1) / 2;
         y[t] = row == col ? M[row + col * n] : (M[row + col * n] + M[col + row * n]) * isq2;
-    }
-}
-// C = op(A) op(B), all n x n column major; A / B may live in LDS or (L2-resident) global memory
-template <bool TA, bool TB>
-__device__ __forceinline__ void psd_gemm(double *C, const double *A, const double *B, int n) {
-    for (int idx = threadIdx.x; idx < n * n; idx += WG) {
-        const int i = idx % n, j = idx / n;
-        double acc = 0.0;
-        for (int k = 0; k < n; ++k) acc += (TA ? A[k + i * n] : A[i + k * n]) * (TB ? B[j + k * n] : B[k + j * n]);
-        C[idx] = acc;
     }
 }
 // Y = Rx' X Rx (transpose == false: W x, W^-1 x) or Rx X Rx' (true: W' x, W^-T x), psdtrianglecone.rs:340-396
@@ -968,12 +1006,15 @@ __global__ __launch_bounds__(WG) void k_psd_ops(PsdView v, double *o0, double *o
         psd_mul_Wx(X, T, X, st.Ri, n, true); // X = W^-T ds (T = X Ri' is complete before X is overwritten)
         psd_mat_to_svec(o2 + off, X, n);
         __syncthreads();
-        // shift = (X Y + Y X) / 2 - sc I
+        // shift = (X Y + Y X) / 2 - sc I = (Z + Z') / 2 - sc I with Z = X Y (X and Y are symmetric: Y X = (X Y)')
+        psd_gemm<false, false>(Z, X, Y, n);
+        __syncthreads();
         for (int idx = tid; idx < n * n; idx += WG) {
             const int i = idx % n, j = idx / n;
-            double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += X[i + k * n] * Y[k + j * n] + Y[i + k * n] * X[k + j * n];
-            Z[idx] = 0.5 * acc - (i == j ? sc : 0.0);
+            if (i > j) continue;
+            const double sym = 0.5 * (Z[i + j * n] + Z[j + i * n]) - (i == j ? sc : 0.0);
+            Z[i + j * n] = sym;
+            Z[j + i * n] = sym;
         }
         __syncthreads();
         psd_mat_to_svec(o0 + off, Z, n);
@@ -1997,8 +2038,19 @@ void sym_write_kkt(hipStream_t s, const SocView &v, const int *nn_rows, const in
     const int grid = v.ncones + nn_blocks(nn);
     if (grid) k_sym_write_kkt<<<grid, WG, 0, s>>>(v, nn_rows, nn_hsidx, nn, w, mapHs, Kx, dslots);
 }
+// CHIP_NO_PSD_MFMA -> the device-side flag psd_gemm reads (set when it changes; the launches that follow on `s` see it)
+static void psd_sync_switch(hipStream_t s) {
+    static int cur = 0;
+    const int want = switches().no_psd_mfma ? 1 : 0;
+    if (want != cur) {
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_psd_no_mfma), &want, sizeof(int), 0, hipMemcpyHostToDevice, s);
+        (void)hipStreamSynchronize(s);
+        cur = want;
+    }
+}
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv) {
     if (!v.ncones) return;
+    psd_sync_switch(s);
     if (v.scratch) { // cones too large for LDS: work matrices in HBM scratch
         k_psd_update_scaling<true><<<v.ncones, WG, 0, s>>>(v, sv, zv);
         return;
@@ -2033,6 +2085,7 @@ template <typename K> static void psd_allow_lds(K kernel, size_t lds) {
 }
 #define PSD_LAUNCH(OP, ...)                                                          \
     do {                                                                             \
+        psd_sync_switch(s);                                                          \
         if (v.scratch) {                                                             \
             k_psd_ops<OP, true><<<v.ncones, WG, 0, s>>>(v, __VA_ARGS__);             \
         } else {                                                                     \

@@ -36,6 +36,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_FACTOR_FLAT", Entry::FLAG, SW(no_factor_flat), 0},
     {"CHIP_NO_TOPBLK", Entry::FLAG, SW(no_topblk), 0},
     {"CHIP_NO_GATHER_HOIST", Entry::FLAG, SW(no_gather_hoist), 0},
+    {"CHIP_NO_PSD_MFMA", Entry::FLAG, SW(no_psd_mfma), 0},
     {"CHIP_NO_PSD_ROWS", Entry::FLAG, SW(no_psd_rows), 0},
     {"CHIP_NO_XPERM", Entry::FLAG, SW(no_xperm), 0},
     {"CHIP_NO_DENSE_SYMV", Entry::FLAG, SW(no_dense_symv), 0},

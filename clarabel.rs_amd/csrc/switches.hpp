@@ -34,6 +34,7 @@ struct Switches {
     bool no_factor_flat = false;    // CHIP_NO_FACTOR_FLAT (also read by the launcher of the bundle factorisation)
     bool no_topblk = false;         // CHIP_NO_TOPBLK
     bool no_gather_hoist = false;   // CHIP_NO_GATHER_HOIST
+    bool no_psd_mfma = false;       // CHIP_NO_PSD_MFMA: the n x n products of the PSD cone kernels as scalar dot products, not on the matrix cores
     bool no_psd_rows = false;       // CHIP_NO_PSD_ROWS: the Hs blocks of PSD cones written through mapHs (caller's order), not row by row
     bool no_xperm = false;          // CHIP_NO_XPERM
     long long dense_symv_min = 0;   // CHIP_DENSE_SYMV_MIN: fewest block entries for which the blocks leave S (tests; 0: 2^20)

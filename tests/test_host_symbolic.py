@@ -45,6 +45,26 @@ def test_switches_are_parsed_once_and_settable_by_name(hip, monkeypatch):
             assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
+def test_dense_blocks_of_the_top_leave_the_full_rows(hip, monkeypatch):
+    """host analysis only: the Hs blocks of PSD cones whose rows were ordered together are recognised as dense diagonal
+    blocks of the top (symbolic.cpp) and their off-diagonal entries leave S, the full-row copy of the top rows the
+    residual reads -- every other entry stays.  (The numeric side: tests/test_gpu_parity.py.)"""
+    pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)  # 8 cliques of PSD(20): svec blocks of 210 rows
+    monkeypatch.setenv("CHIP_NO_DENSE_SYMV", "1")
+    full = hip.debug_counter(_mk(hip, pr), "nnzS")
+    monkeypatch.delenv("CHIP_NO_DENSE_SYMV")
+    monkeypatch.setenv("CHIP_DENSE_SYMV_MIN", "1")  # (the default leaves totals below 2^20 entries alone)
+    ks = _mk(hip, pr)
+    left = hip.debug_counter(ks, "nnzS")
+    # S holds both triangles of the top rows: a block of m rows that leaves takes m (m - 1) entries with it.  The blocks
+    # found are the parts of the cones' 210 svec rows that sit in the top next to each other (~190 of them per cone)
+    taken = full - left
+    assert taken % 2 == 0 and taken >= 8 * 150 * 149, (full, left)
+    assert left < full / 4
+    monkeypatch.delenv("CHIP_DENSE_SYMV_MIN")
+    assert hip.debug_counter(_mk(hip, pr), "nnzS") == full  # (below the default threshold: nothing moves)
+
+
 def test_settings_defaults(hip):
     s = hip.Settings.default()
     # settings.rs:139-181

@@ -937,6 +937,13 @@ def main():
         }
         print(json.dumps(out))
         sys.stdout.flush()
+    # the JSON line stays the LAST line of stdout: RCCL prints a version banner to file descriptor 1 when a communicator
+    # goes away (at interpreter exit) -- everything written to it from here on goes to stderr
+    try:
+        sys.stdout.flush()
+        os.dup2(2, 1)
+    except OSError:
+        pass
     if comm is not None:
         comm.synchronize()
         comm.barrier()

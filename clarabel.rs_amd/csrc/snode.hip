@@ -1436,7 +1436,12 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
 // load, both device coherent (sc1, what the compiler emits for agent-scope atomics) -- a consumer that sees
 // this sweep's epoch has the value with it, in one round trip; value and flag as two stores needed the
 // producer to wait for the first to be acknowledged and the consumer to load twice (~2 of ~4.5 us per hop).
-constexpr int SN2_WG = 256;
+// Eight waves per block (round 4; four before): a step's 64 columns are eight per wave instead of sixteen -- half the
+// streamed entries per lane and step --, the diagonal block is fetched and the rows of B are pulled / pushed by twice
+// the threads (that part sits in front of the first hop of every backward launch and at the tail of every forward
+// one).  Config 2: 25.0 -> 23.6 ms per step, config 5: 47.4 -> 45.8.  (Sixteen waves leave 128 registers per lane: the
+// wave that solves the diagonal block holds its 64 coefficients in registers and needs more.)
+constexpr int SN2_WG = 512;
 constexpr int SN2_WMAX = 4096; // widest supernode (symbolic.cpp: SN_MAX_W); its column bases are kept in LDS
 template <bool FWDMODE>
 __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, const int *__restrict__ order,

@@ -283,7 +283,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             if ((rc = upload(&upd_ptr, up, up.size()))) return rc;
         }
         asm_lvl_ptr = S.asm_lvl_ptr;
-        if (!S.asm_tgt.empty()) {
+        // (the assembled form of the ancestor updates is a mode -- CHIP_DETERMINISTIC / CHIP_EXTEND_ASM_MIN, read when the
+        // handle is created --: without it neither its tables nor its buffer, 0.9 GB on config 5, are put on the device)
+        if (!S.asm_tgt.empty() && (switches().deterministic || switches().extend_asm_min > 0)) {
             std::vector<long long> src(S.asm_src.size() * 3), uoff(S.asm_uoff.begin(), S.asm_uoff.end());
             for (size_t q = 0; q < S.asm_src.size(); q++) {
                 src[3 * q] = S.asm_src[q].uo;

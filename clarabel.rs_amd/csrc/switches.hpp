@@ -67,7 +67,7 @@ struct Switches {
     int extend_asm_min = 0;         // CHIP_EXTEND_ASM_MIN: fewest supernodes of a level whose updates are assembled (0: never, unless CHIP_DETERMINISTIC)
     bool no_xcd_map = false;        // CHIP_NO_XCD_MAP: the tiles of k_snode_extend spread over the XCDs, not one supernode per XCD
     int sn_asm_cap = 0;             // CHIP_SN_ASM_CAP: rows of a target column per LDS window of k_snode_assemble (tests; 0: 4096)
-    bool deterministic = false;     // CHIP_DETERMINISTIC: fixed-order reductions wherever an fp64 atomic decides a sum
+    bool deterministic = false;     // CHIP_DETERMINISTIC (read when a handle is created): no k-split of the update tiles, ancestor updates assembled in a fixed order
 };
 
 // the parsed switches (first call parses the environment)

@@ -65,6 +65,18 @@ def test_dense_blocks_of_the_top_leave_the_full_rows(hip, monkeypatch):
     assert hip.debug_counter(_mk(hip, pr), "nnzS") == full  # (below the default threshold: nothing moves)
 
 
+def test_every_object_depends_on_every_header():
+    """struct Switches and the kernel views are shared by all translation units: an object that is not rebuilt when a
+    header changes reads the wrong fields without any diagnostic (it happened: a switch read through a stale layout).
+    Every compile rule of csrc/Makefile must list $(HEADERS)."""
+    mk = open(os.path.join(ROOT, "clarabel.rs_amd", "csrc", "Makefile")).read()
+    assert "HEADERS  = $(wildcard *.hpp)" in mk
+    rules = [ln for ln in mk.splitlines() if ln and not ln.startswith(("\t", "#")) and ".o:" in ln]
+    assert len(rules) >= 6
+    for ln in rules:
+        assert "$(HEADERS)" in ln, ln
+
+
 def test_settings_defaults(hip):
     s = hip.Settings.default()
     # settings.rs:139-181

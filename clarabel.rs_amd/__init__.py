@@ -99,9 +99,10 @@ class Info(C.Structure):
 _LIB = None
 
 
-def build(verbose=False):
-    """Compile csrc/ into libclarabel_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+def build(verbose=False, testing=True):
+    """Compile csrc/ into libclarabel_hip.so for gfx950 (hipcc cross-compiles without a GPU).  testing: with the
+    hooks of include/clarabel_hip_testing.h (what the test suite needs; the Makefile's own default leaves them out)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8", "TESTING=%d" % (1 if testing else 0)]
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
     return LIB_PATH
 

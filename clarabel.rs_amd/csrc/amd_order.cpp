@@ -145,7 +145,10 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     // component of it is being ordered)
     double dth = 10.0 * dense_scale * std::sqrt((double)(dense_n > 0 ? dense_n : n));
     if (dth < 16.0) dth = 16.0;
-    if (dth > (double)n) dth = (double)n;
+    // (the degrees compared against dth are WEIGHTED when dense blocks enter as one node each: the clamp is then the
+    // total weight, not the compressed node count -- a node next to a block of >= 16 rows has a weighted degree
+    // above n on small problems and would be pulled out as "dense")
+    if (!wgt && dth > (double)n) dth = (double)n;
     I ndense = 0;
     i64 wdense = 0;
     if (dth > (double)wtot) dth = (double)wtot;

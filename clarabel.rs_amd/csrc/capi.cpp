@@ -904,10 +904,14 @@ int32_t chip_kkt_update_scaled_enqueue(chip_kkt *h, const double *s_dev, const d
     h->soc.fail_gen = h->scaling_gen;
     h->psd.fail_gen = h->scaling_gen;
     h->scaling_pending_check = h->soc.ncones > 0;
+    // the cone launch clears the status words of the refactor -- when it launches anything at all (no SOC cones and no
+    // Nonnegative rows: an empty grid) and when the factor kernel that reads the slots is the one that will run
+    const bool cone_clears = E.fast_prep_ok && !switches().no_fast_prep && (h->soc.ncones + h->nn_count) > 0 &&
+                             (E.gstep_factor_on || !switches().no_factor_flat);
     dev::sym_scale_write(E.stream, h->soc, h->nn_rows, h->nn_hsidx, h->nn_count, s_dev, z_dev, h->d_w, h->d_lam, h->mapHs, E.Kx,
-                         E.diag_slots(), (E.fast_prep_ok && !switches().no_fast_prep) ? E.mb_dev->status : nullptr);
+                         E.diag_slots(), cone_clears ? E.mb_dev->status : nullptr);
     CHIP_HIP(hipGetLastError());
-    int rc = E.refactor_enqueue(true, nullptr, h->static_diag_max, E.fast_prep_ok && !switches().no_fast_prep);
+    int rc = E.refactor_enqueue(true, nullptr, h->static_diag_max, cone_clears);
     if (rc) return rc;
     h->pend_update = 1;
     E.factored = true; // provisionally: the verdict arrives with chip_kkt_collect

@@ -1,6 +1,7 @@
 // cones.hip -- cone scalings fused into the KKT value update, Hs products, step operations, barriers (NN / SOC / Exp / Pow / GenPow / PSD)
 // (one of the translation units behind kernels.hpp; the design rules and the reference citations are in
 // dev_common.hpp)
+#include <atomic>
 #include "dev_common.hpp"
 
 namespace chip {
@@ -2040,12 +2041,16 @@ void sym_write_kkt(hipStream_t s, const SocView &v, const int *nn_rows, const in
 }
 // CHIP_NO_PSD_MFMA -> the device-side flag psd_gemm reads (set when it changes; the launches that follow on `s` see it)
 static void psd_sync_switch(hipStream_t s) {
-    static int cur = 0;
+    // g_psd_no_mfma is a per-DEVICE symbol: the cached state is kept per device (one process may drive several GPUs)
+    static std::atomic<int> cur[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 ? 0 : dev % 64;
     const int want = switches().no_psd_mfma ? 1 : 0;
-    if (want != cur) {
+    if (want != cur[dev].load(std::memory_order_acquire)) {
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_psd_no_mfma), &want, sizeof(int), 0, hipMemcpyHostToDevice, s);
         (void)hipStreamSynchronize(s);
-        cur = want;
+        cur[dev].store(want, std::memory_order_release);
     }
 }
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv) {

@@ -760,7 +760,10 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     const double *eps_ptr = nullptr;
     // fast preparation: eps from the slots inside the bundle factorisation, the top's initial values read from K there,
     // status words cleared by the cone kernel -- no eps / scatter launches (and no pivot launch for a single top column)
-    const bool fast = fast_prep_ok && static_reg && !diag_idx_dev && status_cleared && !switches().no_step_kernel && !switches().no_fast_prep;
+    // (fold.k == 1 handles: only k_bundle_factor_flat reads the slots -- with CHIP_NO_FACTOR_FLAT the launcher falls back
+    // to kernels that look at eps_ptr, so the preparation launches must stay)
+    const bool fast = fast_prep_ok && static_reg && !diag_idx_dev && status_cleared && !switches().no_step_kernel && !switches().no_fast_prep &&
+                      (gstep_factor_on || !switches().no_factor_flat);
     dev::FoldView ffold = fold;
     if (fast) {
         v.eps_slots = diag_slots();
@@ -778,8 +781,9 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         if (diag_idx_dev)
             dev::diag_absmax_eps(stream, Kx, diag_idx_dev, N, st.static_regularization_constant,
                                  st.static_regularization_proportional, (double *)mb_dev);
-        else // the cone kernels left the maxima of the diagonal entries they wrote in the slots
-            dev::eps_from_slots(stream, dslot_dev, st.static_regularization_constant,
+        else // the cone kernels left the maxima of the diagonal entries they wrote in the CURRENT set of slots (the fast
+             // preparation alternates between two sets: after an odd number of fast refactors that is set 1)
+            dev::eps_from_slots(stream, diag_slots(), st.static_regularization_constant,
                                 st.static_regularization_proportional, static_diag_max, (double *)mb_dev);
         eps_ptr = (const double *)mb_dev;
     }

@@ -1,8 +1,10 @@
 // switches.cpp -- see switches.hpp
 #include "switches.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 
 namespace chip {
@@ -72,8 +74,12 @@ const Entry TABLE[] = {
 };
 #undef SW
 
-Switches g_sw;
-bool g_parsed = false;
+// Handles may live on several threads: a reader gets a pointer to an IMMUTABLE snapshot; a reload (every handle
+// creation, test hooks) parses into a new snapshot and publishes it with one atomic store.  Old snapshots stay
+// alive (a deque never moves its elements; a snapshot is ~300 bytes per handle creation), so a reference taken
+// before a reload remains valid.
+std::deque<Switches> g_snapshots;
+std::atomic<const Switches *> g_cur{nullptr};
 std::mutex g_mu;
 
 void parse_locked() {
@@ -90,18 +96,20 @@ void parse_locked() {
         }
         if (e.given_off) *reinterpret_cast<bool *>(base + e.given_off) = true;
     }
-    g_sw = s;
-    g_parsed = true;
+    g_snapshots.push_back(std::move(s));
+    g_cur.store(&g_snapshots.back(), std::memory_order_release);
 }
 
 } // namespace
 
 const Switches &switches() {
-    if (!g_parsed) {
+    const Switches *p = g_cur.load(std::memory_order_acquire);
+    if (!p) {
         std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_parsed) parse_locked();
+        if (!g_cur.load(std::memory_order_relaxed)) parse_locked();
+        p = g_cur.load(std::memory_order_relaxed);
     }
-    return g_sw;
+    return *p;
 }
 void switches_reload() {
     std::lock_guard<std::mutex> lk(g_mu);

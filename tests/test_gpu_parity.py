@@ -923,12 +923,16 @@ def test_full_scale_parity_c4(hip, oracle):
 
 
 def test_full_scale_parity_c4_share_grouped_fold(hip, oracle):
-    """one GPU's share of BASELINE config 4 at N = 8 (128 of the 1024 trees): the forest is cut into several bundles
-    per tree and every tree's top (its last few columns) is folded into the kernels of ITS bundles -- grouped fold:
-    k_gfold_schur / k_gfold_top_factor in the factorisation, the group phases of k_bundle_ir<.., true> in the solve"""
+    """one GPU's share of BASELINE config 4 at N = 8 (128 of the 1024 trees) at FULL size: the forest is cut into several
+    bundles per tree and every tree's top (its last few columns) is folded into the kernels of ITS bundles -- grouped
+    fold -- and both the factorisation and the solve run as the register-resident step kernels (k_gstep_factor,
+    k_gstep_solve): the kernels the 8-GPU bound of DESIGN.md section 7 rests on.  step_kernels() == 3 proves it is THOSE
+    kernels this full-size parity holds for (not k_bundle_ir<.., true> + the three-launch factorisation, their fallback)."""
     ks, ko = _full_scale_parity(hip, oracle, problems.batched_socp(128, 2000, 2, seed=100), nrhs=2)
     wm = ks.work_model()
     assert wm["fold_groups"] == 128 and wm["n_bundles"] > 512 and wm["fused_threads"] == 256
+    assert ks.step_kernels() == 3
+    assert ks.fused_fallbacks() == 0
     assert ks.linear_solver_info().regularize_count == ko.ldl_regularize_count()
     # the one-kernel-per-phase path on the same handle (the fallback of the fused launch) sees an ordinary top
     rng = np.random.default_rng(3)
@@ -1011,6 +1015,45 @@ def test_update_scaled_enqueue_matches_the_two_calls(hip, oracle, which):
         assert ok
         assert relerr(np.concatenate([x, zz]), np.concatenate([xo, zo])) <= TOL
         assert relerr(np.concatenate([x, zz]), np.concatenate([x2, z2])) <= 1e-10
+
+
+@pytest.mark.parametrize("which", ["arrow", "forest"])
+def test_fast_and_plain_refactor_alternate_on_one_handle(hip, oracle, which):
+    """chip_kkt_update_scaled_enqueue (fast preparation: eps from the slotted maxima inside the factor kernel, the two
+    sets of slots alternating) and the plain update_scaling + update calls MIXED on one handle: after an odd number of
+    fast refactors the cone kernels write set 1, and the plain path must reduce (and clear) THAT set -- the static
+    regulariser of every refactor equals the oracle's (directldlkktsolver.rs:324-329), whichever path ran before"""
+    if which == "arrow":
+        pr = problems.portfolio_socp(12, 300, seed=3)
+    else:
+        parts = [problems.portfolio_socp(2 + (i % 3), 120 + 40 * (i % 4), seed=100 + i) for i in range(14)]
+        pr = problems.blockdiag(parts)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    s_d, z_d = hip.DeviceArray(pr["s"]), hip.DeviceArray(pr["z"])
+    rng = np.random.default_rng(5)
+    # fast, plain, fast, fast, plain, plain, fast: every transition, on both parities
+    for rep, fast in enumerate([True, False, True, True, False, False, True]):
+        s = pr["s"] * (1.0 + 0.3 * rep)  # (the diagonal maxima differ from refactor to refactor: a stale set would show)
+        z = pr["z"] * (1.0 + 0.2 * rep) / (1.0 + 0.5 * (rep % 2))
+        if fast:
+            s_d.copy_from(s)
+            z_d.copy_from(z)
+            ks.update_scaled_enqueue(s_d.ptr, z_d.ptr)
+            uok, sok = ks.collect()
+            assert uok and sok == []
+        else:
+            assert ks.update_scaling(s, z) and ks.update()
+        assert cones.update_scaling(s, z) and ko.update()
+        info = ks.linear_solver_info()
+        assert abs(info.last_regularizer - ko.regularizer) <= 1e-20 + 1e-12 * ko.regularizer, (rep, fast)
+        assert info.regularize_count == ko.ldl_regularize_count()
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        x, zz = np.zeros(pr["n"]), np.zeros(pr["m"])
+        ks.setrhs(rx, rz)
+        assert ks.solve(x, zz)
+        ko.setrhs(rx, rz)
+        ok, xo, zo = ko.solve()
+        assert ok and relerr(np.concatenate([x, zz]), np.concatenate([xo, zo])) <= TOL
 
 
 def test_parity_c5_24_cliques(hip, oracle):

@@ -1664,6 +1664,15 @@ int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out
         for (size_t l = 0; l + 1 < E.asm_lvl_ptr.size(); l++) c += E.asm_lvl_ptr[l + 1] > E.asm_lvl_ptr[l];
         *out = c;
     } else if (k == "assembled_targets") *out = E.asm_lvl_ptr.empty() ? 0 : E.asm_lvl_ptr.back();
+    else if (k == "g_levels") { // unit levels whose supernodes use the one-pass substitution matrices (snode_g.hip)
+        int c = 0;
+        for (char f : E.sn_lvl_g) c += f != 0;
+        *out = E.sn_g_ntasks > 0 ? c : 0;
+    } else if (k == "sn_levels") {
+        int c = 0;
+        for (size_t l = 0; l + 1 < E.sn_lvl_ptr.size(); l++) c += E.sn_lvl_ptr[l + 1] > E.sn_lvl_ptr[l];
+        *out = c;
+    } else if (k == "g_entries") *out = E.sn_g_entries;
     else return fail(CHIP_ERR_ARG, "chip_debug_counter: unknown name");
     return CHIP_OK;
 }

@@ -336,6 +336,76 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             set_error("k_factor_snode: dynamic LDS size rejected");
             return CHIP_ERR_HIP;
         }
+        // ---- one-pass substitution matrices G = [I; L_B] T^-1 (snode_g.hip) for the unit levels whose supernodes are
+        //      all of moderate width: a sweep through such a level is one launch without a chain of block hops
+        sn_lvl_g.assign((size_t)S.nfaclevels, 0);
+        sn_lvl_wmax.assign((size_t)S.nfaclevels, 0);
+        {
+            const int gmaxw = std::min(dev::snode_g_max_width(), switches().sn_g_maxw > 0 ? switches().sn_g_maxw : dev::snode_g_max_width());
+            const int gmaxh = 6144; // (rows: the backward kernel keeps [D^-1 y_S; -x_B] in LDS)
+            std::vector<long long> goff((size_t)nsn + 1, -1);
+            std::vector<i32> tasks;
+            long long total = 0;
+            int ghmax = 0;
+            for (int l = 0; l < S.nfaclevels && !switches().no_snode_g; l++) {
+                bool ok = S.sn_lvl_ptr[l + 1] > S.sn_lvl_ptr[l];
+                int wl = 0;
+                for (int u = S.sn_lvl_ptr[l]; u < S.sn_lvl_ptr[l + 1]; u++) {
+                    const i32 sn = S.sn_order[u], e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                    const int w = S.sn_ptr[sn + 1] - S.sn_ptr[sn], h = w + (S.Lp[e + 1] - S.Lp[e]);
+                    ok = ok && w <= gmaxw && h <= gmaxh;
+                    wl = std::max(wl, w);
+                }
+                sn_lvl_wmax[l] = wl;
+                if (!ok) continue;
+                sn_lvl_g[l] = 1;
+                for (int u = S.sn_lvl_ptr[l]; u < S.sn_lvl_ptr[l + 1]; u++) {
+                    const i32 sn = S.sn_order[u], e = S.sn_col[S.sn_ptr[sn + 1] - 1];
+                    const int w = S.sn_ptr[sn + 1] - S.sn_ptr[sn], h = w + (S.Lp[e + 1] - S.Lp[e]);
+                    goff[sn] = total;
+                    total += dev::snode_g_ld(h) * (long long)w;
+                    ghmax = std::max(ghmax, h);
+                    for (int r0 = 0; r0 < h; r0 += 256) {
+                        tasks.push_back(u); // (the record's index in sn_order)
+                        tasks.push_back(r0);
+                    }
+                }
+            }
+            if (total > (1ll << 31)) { // (16 GB of G: keep the pipelined substitution)
+                std::fill(sn_lvl_g.begin(), sn_lvl_g.end(), 0);
+                std::fill(goff.begin(), goff.end(), -1);
+                tasks.clear();
+                total = 0;
+            }
+            if (total > 0) {
+                // the widest (longest-running) rows of the build first
+                const size_t nt = tasks.size() / 2;
+                std::vector<size_t> ord(nt);
+                for (size_t k = 0; k < nt; k++) ord[k] = k;
+                auto wof = [&](size_t k) {
+                    const i32 sn = S.sn_order[(size_t)tasks[2 * k]];
+                    return S.sn_ptr[sn + 1] - S.sn_ptr[sn];
+                };
+                std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return wof(a) > wof(b); });
+                std::vector<i32> sorted(tasks.size());
+                for (size_t k = 0; k < nt; k++) {
+                    sorted[2 * k] = tasks[2 * ord[k]];
+                    sorted[2 * k + 1] = tasks[2 * ord[k] + 1];
+                }
+                if ((rc = upload(&sn_g_tasks, sorted, sorted.size()))) return rc;
+                sn_g_ntasks = (int)nt;
+                if ((rc = upload(&sn_g_off, goff, goff.size()))) return rc;
+                if ((rc = alloc(&sn_Gx, (size_t)total + 8))) return rc;
+                CHIP_HIP(hipMemset(sn_Gx, 0, ((size_t)total + 8) * sizeof(double))); // (entries above a row's diagonal block are never written)
+                if ((rc = alloc(&sn_yt, n))) return rc;
+                CHIP_HIP(hipMemset(sn_yt, 0, n * sizeof(double)));
+                sn_g_entries = (double)total;
+                if (dev::snode_g_attributes(ghmax) != 0) {
+                    set_error("k_snode_ginv: dynamic LDS size rejected");
+                    return CHIP_ERR_HIP;
+                }
+            }
+        }
     }
     {
         int *bp = nullptr, *lp = nullptr, *lv = nullptr;
@@ -740,6 +810,13 @@ void Engine::prof_collect() {
     prof_used = 0;
 }
 
+dev::SnodeView Engine::snode_view() const {
+    dev::SnodeView sv{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, nullptr, sn_cnt};
+    sv.Gx = sn_Gx;
+    sv.g_off = sn_g_off;
+    return sv;
+}
+
 int Engine::read_mailbox() {
     CHIP_HIP(hipMemcpyAsync(mb_host, mb_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, stream));
     CHIP_HIP(hipStreamSynchronize(stream));
@@ -847,7 +924,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         vf.Rcol = Rf_col;
         vf.Rpos = Rf_pos;
     }
-    dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, nullptr, sn_cnt};
+    dev::SnodeView sview = snode_view();
     sview.U = asm_U;
     sview.Ud = asm_Ud;
     sview.asm_uoff = asm_uoff;
@@ -896,7 +973,11 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         l++;
     }
     if (nsn > 0) dev::gather_values(stream, Rfx, Lx, Rf_pos, nRf); // L at the filtered row lists (forward sweep)
-    else dev::topblk_build(stream, v, topblk); // inverses of the diagonal blocks of a tall top
+    if (sn_g_ntasks > 0) { // the substitution matrices of the supernodes of moderate width, all of them in one launch
+        dev::SnodeView sg = snode_view();
+        dev::snode_ginv(stream, v, sg, sn_order, sn_g_tasks, sn_g_ntasks);
+    }
+    if (nsn <= 0) dev::topblk_build(stream, v, topblk); // inverses of the diagonal blocks of a tall top
     // full rows of the top for the residual of the one-kernel-per-phase path; a handle whose fused launch folds the
     // top per group never reads them unless that launch falls back: refreshed on demand (enqueue_residual)
     sx_valid = false;
@@ -969,7 +1050,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         // chain supernodes: units by unit level.  Forward: every top row first gathers from the columns
         // that are not supernode members, then the level's supernodes solve their dense triangles and
         // push L_BS x_S to their ancestors' entries; backward: the reverse, column oriented.
-        const dev::SnodeView sview{sn_ptr, sn_col, upd_ptr, upd_slot, sn_geo, sn_cb, sn_d, sn_sg, nullptr, sn_cnt};
+        const dev::SnodeView sview = snode_view();
         // wide supernodes: several workgroups per supernode, pipelined through per-block flags that carry this
         // sweep's epoch (not inside a captured graph: a replay would meet its own flags)
         const bool use_tri = !switches().no_snode_tri && !st.use_graph;
@@ -982,12 +1063,20 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
             prof_begin(PF_SN_GATHER);
             dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
             prof_end(PF_SN_GATHER);
+            if (sn_g_ntasks > 0 && sn_lvl_g[l]) // one pass over G, no hops (x_S(new) -> sn_yt, the rows of B subtracted in place)
+                dev::solve_snodes_g(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                                    sn_lvl_wmax[l], sn_lvl_hmax[l], xp, sn_yt, lp);
+            else
             dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
                               sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
         }
         tri.epoch = ++sn_epoch;
         dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
         for (int l = nfaclevels - 1; l >= 0; l--) {
+            if (sn_g_ntasks > 0 && sn_lvl_g[l])
+                dev::solve_snodes_g(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                                    sn_lvl_wmax[l], sn_lvl_hmax[l], xp, sn_yt, lp);
+            else
             dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
                               sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
             const dev::ChunkView b = bwu.B(l);

@@ -96,6 +96,15 @@ struct Engine {
     double *asm_U = nullptr, *asm_Ud = nullptr;
     std::vector<i32> asm_lvl_ptr;
     int8_t *sn_sg = nullptr; // dev::SnodeView::sn_sg
+    // one-pass substitution matrices of the supernodes of moderate width (snode_g.hip): per unit level whether its
+    // supernodes take the path (all of them or none), the matrices, the build's task list, the forward sweep's output
+    std::vector<char> sn_lvl_g;
+    std::vector<i32> sn_lvl_wmax;
+    double *sn_Gx = nullptr, *sn_yt = nullptr;
+    long long *sn_g_off = nullptr;
+    int *sn_g_tasks = nullptr;
+    int sn_g_ntasks = 0;
+    double sn_g_entries = 0; // doubles of G (what one sweep through these supernodes streams)
     std::vector<i32> sn_lvl_ptr, sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax, h_sn_ptr, h_sn_col;
     // pipelined substitution through wide supernodes (dev::SnodeTriView): one flag per 64-column block
     int *sn_blk_ptr = nullptr, *sn_flags = nullptr;
@@ -201,6 +210,7 @@ struct Engine {
     void prof_end(int family);
     void prof_pair(int family, hipEvent_t *ev0, hipEvent_t *ev1);
     void prof_collect();
+    dev::SnodeView snode_view() const;
     dev::LaunchProf launch_prof(); // hook handed to the launchers in snode.hip (nullptr-equivalent when off)
     // work model of the chain supernodes, per refactor / per sweep (host.hpp: Symbolic::sn_*), for the roofline
     // figures of bench.py: [0] multiply-add flops of k_snode_update (2 per multiply-add, useful part of the

@@ -271,6 +271,10 @@ struct SnodeView {
     double *U = nullptr, *Ud = nullptr;
     const long long *asm_uoff = nullptr;
     const int *asm_doff = nullptr;
+    // one-pass substitution matrices (snode_g.hip): supernode s keeps G = [I; L_B] T^-1, (w + nb) x w, column-major with
+    // leading dimension snode_g_ld(w + nb), at Gx + g_off[s] (g_off[s] < 0: the supernode keeps the pipelined substitution)
+    double *Gx = nullptr;
+    const long long *g_off = nullptr;
 };
 // One unit level's update matrices summed per TARGET column (host.hpp: Symbolic::asm_*): workgroup t owns node
 // tgt[t0 + t] and subtracts its sources src_ptr[..] one after the other -- a fixed order, no atomics.  Source q =
@@ -337,6 +341,17 @@ struct SnodeTriView {
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
                   int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri = nullptr,
                   const LaunchProf *lp = nullptr);
+// ---- supernodes of moderate width: substitutions in one pass over G = [I; L_B] T^-1 (snode_g.hip) ----
+int snode_g_max_width();            // widest supernode that may take this path
+long long snode_g_ld(int h);        // leading dimension of a supernode's G
+int snode_g_attributes(int hmax);   // once per handle (dynamic LDS of the kernels)
+// after the numeric factorisation: G of every supernode on the path; tasks = (record in order_all, first row) pairs,
+// 256 rows of G per workgroup
+void snode_ginv(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order_all, const int *tasks, int ntasks);
+// one unit level's supernodes, forward (x_S(new) -> yt, x_B -= M x_S) or backward (x_S <- G' [D^-1 yt_S; -x_B]);
+// wlvl / hlvl: the level's largest width / height
+void solve_snodes_g(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count, int wlvl,
+                    int hlvl, double *x, double *yt, const LaunchProf *lp = nullptr);
 // diagnostics / tests: a kernel of `blocks` x `threads` that only spins for `usec` microseconds on stream s
 // (co-residency tests of the persistent launches)
 void debug_spin(hipStream_t s, int blocks, int threads, int lds_bytes, double usec);

@@ -1,0 +1,347 @@
+// snode_g.hip -- chain supernodes of moderate width: substitutions WITHOUT a dependency chain inside a supernode
+// (one of the translation units behind kernels.hpp; geometry and helpers in snode_common.hpp).
+//
+// The substitutions through a supernode S (w member columns, nb rows of B below; qdldl.rs:708-768 restricted to the
+// dense trapezoid) are
+//     forward :  x_S <- T^-1 x_S ,   x_B <- x_B - L_B x_S          T = I + strict lower triangle of L_SS
+//     backward:  x_S <- T^-T (D^-1 x_S - L_B' x_B)
+// k_snode_tri walks T block by block: one hop of ~4 us per 64 columns, 129 dependent hops per sweep on BASELINE
+// config 2, twelve sweeps per step.  Here the chain is paid ONCE per refactorisation: k_snode_ginv forms
+//     G = [ I ; L_B ] T^-1        ((w + nb) x w:  T^-1 on top,  M = L_B T^-1 below)
+// and a sweep through S is ONE pass over G with no order among its rows / columns:
+//     forward :  [ x_S ; dx_B ] = G x_S(old)      x_B -= dx_B                       (k_snode_gfwd: a row per lane)
+//     backward:  x_S = G' [ D^-1 x_S ; -x_B ]                                       (k_snode_gbwd: a column per wave)
+// Every ROW of G is independent of the others (row i solves y T = p with p = e_i or row i of L_B): the build is
+// embarrassingly parallel over rows -- 256 rows per workgroup, column blocks from the last to the first:
+//     Y[:, J_c] = ( P[:, J_c] - sum_{k > c} Y[:, J_k] T[J_k, J_c] ) T_cc^-1
+// the sum on the f64 matrix cores (the finished column blocks of G streamed as the A operand, T staged in LDS), the
+// 64 x 64 triangular part by the 16-blocked recurrence of the panel kernels, mirrored (columns in reverse order).
+// Results of a sweep differ from the substitution's in rounding only (the reference's order of subtractions is that
+// of the substitution, qdldl.rs:708-752); the refinement of directldlkktsolver.rs:266-321 runs on top as before and
+// parity is asserted on the refined solution.  Supernodes wider than SG_WMAX keep the pipelined substitution.
+#include "dev_common.hpp"
+#include "snode_common.hpp"
+
+namespace chip {
+namespace dev {
+
+namespace {
+
+constexpr int SG_WG = 256;        // 4 waves: 256 rows of G per workgroup of the build
+constexpr int SG_KC = 128;        // rows of T staged per chunk
+constexpr int SG_KLD = SG_KC + 1; // stride of a staged column (odd: the 16 lanes of a matrix-core operand read hit distinct banks)
+constexpr int SG_U = 4;           // k-groups of A operands in flight per lane
+constexpr int SG_XLD = 17;        // row stride of a wave's head block in LDS
+constexpr int SG_WMAX = 512;      // widest supernode that takes this path (column bases / x_S in LDS)
+
+__device__ __forceinline__ int sg_ldg(int h) { return (h + 7) & ~7; }
+
+// This wave's 64 x 64 tile in the accumulator layout of v_mfma_f64_16x16x4_f64:
+//     acc[jb][t][r] = X[row 16 t + kq + 4 r][column 16 jb + l15]          (l15 = lane & 15, kq = lane >> 4).
+// For every row: x_c -= sum_{k < c} coef(c, k) x_k, c = 0 .. 63, with coef(c, k) = Ll[k * 64 + c] (zero for c <= k),
+// blocked by 16 as in the panel kernels (snode.hip: snq_rows): head block kb leaves the accumulator layout through
+// the wave's LDS slice xw ([row][column], stride SG_XLD), is finished in the lane = row form -- 120 products per row
+// --, handed to store(kb, h) and applied to the blocks behind it as a (64 x 16) x (16 x 16) product on the matrix
+// cores.  Per entry the subtractions go k = 0, 1, ...; inside a matrix instruction they are fused multiply-adds.
+template <class Store>
+__device__ __forceinline__ void sg_block_recur(snode_v4d (&acc)[4][4], const double *Ll, double *xw, int lane, Store store) {
+    const int l15 = lane & 15, kq = lane >> 4;
+    double h[16];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SG_XLD + l15] = acc[kb][t][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) h[c] = xw[lane * SG_XLD + c];
+        __builtin_amdgcn_wave_barrier();
+        const double *Lb = Ll + (16 * kb) * SN_NB + 16 * kb;
+#pragma unroll
+        for (int kk = 0; kk < 15; ++kk) {
+            const double uq = h[kk];
+            int zoff; // (an opaque zero that "depends" on u_q ties this column's LDS reads to its place in the chain, see k_snode_panel)
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(uq)));
+            const snode_v2d *cf = (const snode_v2d *)(Lb + kk * SN_NB + zoff);
+#pragma unroll
+            for (int p2 = (kk + 1) / 2; p2 < 8; ++p2) {
+                const snode_v2d cc = cf[p2]; // (the pair that straddles kk meets a stored zero)
+                h[2 * p2] -= cc.x * uq;
+                h[2 * p2 + 1] -= cc.y * uq;
+            }
+        }
+        store(kb, h);
+        if (kb == 3) break;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) xw[lane * SG_XLD + c] = -h[c];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            double a4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a4[t] = xw[(16 * t + l15) * SG_XLD + 4 * s4 + kq]; // A[m = l15][k = 4 s4 + kq] of row tile t
+#pragma unroll
+            for (int jb = kb + 1; jb < 4; ++jb) {
+                const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * jb + l15]; // B[k][n] = coef(16 jb + n, 16 kb + k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[jb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], bv, acc[jb][t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// One workgroup per task = (record of the supernode in `order_all`, first of its 256 rows of G).  Inside a column
+// block the columns are taken in REVERSE order (column' = 63 - column), which turns y T = z -- y_c = z_c - sum_{k > c}
+// y_k T[k][c], last column first -- into the forward recurrence sg_block_recur knows.
+__global__ __launch_bounds__(SG_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snode_ginv(LdlView v, SnodeView sv, const int *__restrict__ order_all,
+                                                      const int *__restrict__ tasks) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    double *Wt = (double *)gsm;          // products: Wt[column' * SG_KLD + k] = -T[kc0 + k][j0 + 63 - column']
+    double *Ll = (double *)gsm;          // recurrence (after the products; the same bytes): Ll[k' * 64 + c']
+    double *xwb = Ll + SN_NB * SN_NB;    // ... and the four waves' head blocks
+    __shared__ int colbase[SG_WMAX];
+    const int rec = tasks[2 * blockIdx.x], R0 = tasks[2 * blockIdx.x + 1];
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order_all, rec, sn);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int ldg = sg_ldg(g.h);
+    double *G = sv.Gx + sv.g_off[sn];
+    for (int t = tid; t < g.w; t += SG_WG) colbase[t] = g.cb[t];
+    const int nblk = (g.w + SN_NB - 1) / SN_NB;
+    const int Rlast = min(R0 + SG_WG, g.h) - 1;                      // last row of this workgroup
+    const int cstart = Rlast < g.w ? Rlast / SN_NB : nblk - 1;       // rows of T^-1 end at their diagonal block
+    const int kend = min(g.w, SN_NB * (cstart + 1));                 // columns of G this workgroup's rows own
+    const int R0w = R0 + 64 * wave;
+    const bool wlive = R0w < g.h;
+    int rowA[4]; // rows of the A operand (clamped: a row beyond the panel reads the last one, its results are not stored)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rowA[t] = min(R0w + 16 * t + l15, g.h - 1);
+    __syncthreads();
+    for (int c = cstart; c >= 0; --c) {
+        const int j0 = SN_NB * c, ncw = min(SN_NB, g.w - j0);
+        const int kbeg = j0 + SN_NB;
+        // a wave whose rows all lie above the block (rows of T^-1) owns zeros only: G is zero-filled once, nothing to do
+        const bool wact = wlive && R0w + 63 >= j0;
+        snode_v4d acc[4][4];
+        // ---- P = [I; L_B], this block's columns reversed
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int jj = 63 - (16 * jb + l15);
+            const int cbj = colbase[j0 + min(jj, ncw - 1)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = R0w + 16 * t + kq + 4 * r;
+                    double val = 0.0;
+                    if (wact && jj < ncw) {
+                        if (row < g.w) val = row == j0 + jj ? 1.0 : 0.0;
+                        else if (row < g.h) val = v.Lx[cbj + row];
+                    }
+                    acc[jb][t][r] = val;
+                }
+        }
+        // ---- minus the finished column blocks times T[J_k, J_c]
+        if (kbeg < kend) { // (workgroup uniform)
+            double a[SG_U][4];
+            auto request = [&](int u, int kabs) {
+                const size_t col = (size_t)min(kabs + 4 * u + kq, kend - 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[u][t] = G[col * ldg + rowA[t]];
+            };
+            if (wact) {
+#pragma unroll
+                for (int u = 0; u < SG_U; ++u) request(u, kbeg);
+            }
+            for (int kc0 = kbeg; kc0 < kend; kc0 += SG_KC) {
+                const int kcn = min(SG_KC, kend - kc0);
+                const int kcnu = (kcn + 4 * SG_U - 1) / (4 * SG_U) * (4 * SG_U); // whole groups: the tail rows of the operand are zeros
+                __syncthreads(); // the previous chunk (or the previous block's recurrence) is done with these bytes
+                // lanes along k: 512-byte runs of a column of L, eight requests in flight per thread
+                for (int i0 = tid; i0 < SN_NB * SG_KC; i0 += 8 * SG_WG) {
+                    double tv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int idx = i0 + q * SG_WG, kk = idx & (SG_KC - 1), jjp = idx >> 7, jj = 63 - jjp;
+                        tv[q] = v.Lx[colbase[j0 + min(jj, ncw - 1)] + kc0 + min(kk, kcn - 1)]; // (clamped: unconditional loads)
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int idx = i0 + q * SG_WG, kk = idx & (SG_KC - 1), jjp = idx >> 7, jj = 63 - jjp;
+                        if (kk < kcnu) Wt[jjp * SG_KLD + kk] = (kk < kcn && jj < ncw) ? -tv[q] : 0.0;
+                    }
+                }
+                __syncthreads();
+                if (!wact) continue; // (after the barriers)
+                for (int kk = 0; kk < kcnu; kk += 4 * SG_U) {
+                    const int knext = kk + 4 * SG_U < kcnu ? kc0 + kk + 4 * SG_U : kc0 + SG_KC; // (the next chunk's first group)
+#pragma unroll
+                    for (int u = 0; u < SG_U; ++u) {
+                        const int kl = kk + 4 * u + kq;
+#pragma unroll
+                        for (int jb = 0; jb < 4; ++jb) {
+                            const double bw = Wt[(16 * jb + l15) * SG_KLD + kl];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc[jb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], bw, acc[jb][t], 0, 0, 0);
+                        }
+                        request(u, knext);
+                    }
+                }
+            }
+        }
+        // ---- times T_cc^-1: coef(c', k') = T[j0 + 63 - k'][j0 + 63 - c'], k' < c'
+        __syncthreads();
+        for (int idx = tid; idx < SN_NB * SN_NB; idx += SG_WG) {
+            const int kp = idx >> 6, cp = idx & 63, jr = 63 - kp, jc = 63 - cp;
+            double val = 0.0;
+            if (cp > kp && jr < ncw) val = v.Lx[colbase[j0 + jc] + j0 + jr]; // (jc < jr < ncw)
+            Ll[idx] = val;
+        }
+        __syncthreads();
+        if (wact) {
+            const int row = R0w + lane;
+            sg_block_recur(acc, Ll, xwb + wave * (64 * SG_XLD), lane, [&](int kb, const double(&hh)[16]) {
+                if (row >= g.h) return;
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    const int jj = 63 - (16 * kb + cc);
+                    if (jj < ncw) G[(size_t)(j0 + jj) * ldg + row] = hh[cc];
+                }
+            });
+        }
+        __syncthreads(); // (the next block stages its operand over Ll / the head blocks; this block's columns of G are visible)
+    }
+}
+
+// forward: grid (64-row blocks of G, supernodes of the unit level).  Lane = row, the columns a quarter per wave (eight
+// column runs in flight per lane), the four partial sums meet in LDS.  Member rows go to yt (the other workgroups of
+// the supernode still read x_S(old) from x), the rows of B leave as one atomic per (row, supernode).
+__global__ __launch_bounds__(SG_WG) void k_snode_gfwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
+                                                      double *yt) {
+    __shared__ double xs[SG_WMAX];
+    __shared__ double part[SG_WG / 64][64];
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
+    const int r0 = 64 * (int)blockIdx.x;
+    if (r0 >= g.h) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncols = r0 < g.w ? min(g.w, r0 + 64) : g.w; // (rows of T^-1 end at their diagonal block)
+    for (int t = tid; t < ncols; t += SG_WG) xs[t] = x[g.cols[t]];
+    __syncthreads();
+    const int ldg = sg_ldg(g.h);
+    const int i = r0 + lane;
+    const double *Gr = sv.Gx + sv.g_off[sn] + min(i, g.h - 1);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = wave;
+    for (; j + 28 < ncols; j += 32) {
+        double l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l[u] = Gr[(size_t)(j + 4 * u) * ldg];
+        s0 += l[0] * xs[j] + l[4] * xs[j + 16];
+        s1 += l[1] * xs[j + 4] + l[5] * xs[j + 20];
+        s2 += l[2] * xs[j + 8] + l[6] * xs[j + 24];
+        s3 += l[3] * xs[j + 12] + l[7] * xs[j + 28];
+    }
+    for (; j < ncols; j += 4) s0 += Gr[(size_t)j * ldg] * xs[j];
+    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && i < g.h) {
+        const double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (i < g.w) yt[g.cols[i]] = tot;
+        else atomicAdd(&x[(v.Li + v.Lp[g.e])[i - g.w]], -tot);
+    }
+}
+// backward: grid (64-column blocks, supernodes of the unit level).  s = [D^-1 y_S ; -x_B] from the block's first row
+// on in LDS, a wave per column (four columns together, rows along the lanes), fixed order of summation, no atomics.
+__global__ __launch_bounds__(SG_WG) void k_snode_gbwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
+                                                      const double *yt) {
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    double *ss = (double *)bsm;
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
+    const int j0 = 64 * (int)blockIdx.x;
+    if (j0 >= g.w) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *Bn = v.Li + v.Lp[g.e];
+    for (int i = j0 + tid; i < g.h; i += SG_WG) {
+        double val;
+        if (i < g.w) {
+            const int c = g.cols[i];
+            val = yt[c] * v.Dinv[c];
+        } else {
+            val = -x[Bn[i - g.w]];
+        }
+        ss[i - j0] = val;
+    }
+    __syncthreads();
+    const int ldg = sg_ldg(g.h);
+    const double *G = sv.Gx + sv.g_off[sn];
+    const int nr = g.h - j0;
+#pragma unroll 1
+    for (int t0 = 0; t0 < 16; t0 += 4) {
+        const int jf = j0 + 16 * wave + t0;
+        if (jf >= g.w) break; // (wave uniform)
+        const double *Gc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Gc[u] = G + (size_t)min(jf + u, g.w - 1) * ldg + j0;
+        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+        int i = lane;
+        for (; i + 64 < nr; i += 128) { // (entries above the diagonal inside the block are stored zeros)
+            double l0[4], l1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                l0[u] = Gc[u][i];
+                l1[u] = Gc[u][i + 64];
+            }
+            const double sa = ss[i], sb = ss[i + 64];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0[u] += l0[u] * sa;
+                a1[u] += l1[u] * sb;
+            }
+        }
+        for (; i < nr; i += 64) {
+            const double sa = ss[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a0[u] += Gc[u][i] * sa;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double tot = wave_sum(a0[u] + a1[u]);
+            if (lane == 0 && jf + u < g.w) x[g.cols[jf + u]] = tot;
+        }
+    }
+}
+
+} // namespace
+
+static size_t ginv_lds_bytes() {
+    const size_t a = (size_t)SN_NB * SG_KLD * sizeof(double);
+    const size_t b = (size_t)(SN_NB * SN_NB + (SG_WG / 64) * 64 * SG_XLD) * sizeof(double);
+    return std::max(a, b);
+}
+int snode_g_max_width() { return SG_WMAX; }
+int snode_g_attributes(int hmax) {
+    int rc = (int)raise_dynamic_lds((const void *)k_snode_ginv, ginv_lds_bytes());
+    if (!rc && (size_t)hmax * sizeof(double) > 48 * 1024)
+        rc = (int)raise_dynamic_lds((const void *)k_snode_gbwd, (size_t)hmax * sizeof(double));
+    return rc;
+}
+long long snode_g_ld(int h) { return (h + 7) & ~7; }
+void snode_ginv(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order_all, const int *tasks, int ntasks) {
+    if (ntasks <= 0) return;
+    k_snode_ginv<<<ntasks, SG_WG, ginv_lds_bytes(), s>>>(v, sv, order_all, tasks);
+}
+void solve_snodes_g(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count, int wlvl,
+                    int hlvl, double *x, double *yt, const LaunchProf *lp) {
+    if (!count) return;
+    if (lp) lp->begin(lp->ctx, PFK_SN_TRI);
+    if (m == FWD) k_snode_gfwd<<<dim3((hlvl + 63) / 64, count), SG_WG, 0, s>>>(v, sv, order, x, yt);
+    else k_snode_gbwd<<<dim3((wlvl + 63) / 64, count), SG_WG, (size_t)hlvl * sizeof(double), s>>>(v, sv, order, x, yt);
+    if (lp) lp->end(lp->ctx, PFK_SN_TRI);
+}
+
+} // namespace dev
+} // namespace chip

@@ -1703,8 +1703,10 @@ def test_dense_blocks_of_the_top_in_the_residual(hip, oracle, which, monkeypatch
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
 def test_chain_supernodes_solve_without_lds_rows(hip, oracle, which, monkeypatch):
     """the substitutions through supernodes whose rows of B exceed the LDS budget (forced here by
-    CHIP_SN_XB_CAP): global atomics / loads instead of the LDS copy, same solution"""
+    CHIP_SN_XB_CAP): global atomics / loads instead of the LDS copy, same solution (the block-by-block substitution
+    kernels: CHIP_NO_SNODE_G keeps these supernodes off the one-pass matrices)"""
     monkeypatch.setenv("CHIP_SN_XB_CAP", "16")
+    monkeypatch.setenv("CHIP_NO_SNODE_G", "1")
     if which == "banded_qp":
         pr, hs = problems.random_qp(20000, 40000, band=50, seed=1), None
     else:
@@ -1712,6 +1714,54 @@ def test_chain_supernodes_solve_without_lds_rows(hip, oracle, which, monkeypatch
         hs = pr["hsblocks"]
     ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=2)
     assert len(ks.supernodes()) > 0
+
+
+@pytest.mark.parametrize("which", ["banded_qp", "banded_qp_late", "chordal_sdp", "wide_psd", "mixed_widths"])
+def test_supernode_substitution_matrices(hip, oracle, which, monkeypatch):
+    """substitutions through supernodes of moderate width in ONE pass over G = [I; L_B] T^-1 (snode_g.hip: k_snode_ginv
+    per refactor, k_snode_gfwd / k_snode_gbwd per sweep) against the oracle and against the block-by-block substitution
+    of the same factors (CHIP_NO_SNODE_G): benign and late-iterate scalings, a supernode wider than one staged chunk of
+    the build (w > 416), and a handle on which only the narrow levels take the path (CHIP_SN_G_MAXW)"""
+    hs = None
+    if which == "banded_qp":
+        pr = problems.random_qp(20000, 40000, band=50, seed=1)
+    elif which == "banded_qp_late":
+        pr = problems.random_qp(20000, 40000, band=50, seed=1, late=True)
+    elif which == "chordal_sdp":
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    elif which == "wide_psd":
+        pr = problems.chordal_sdp(2, 40, 6, 1, 5, seed=7)
+        hs = pr["hsblocks"]
+    else:
+        pr = problems.random_qp(20000, 40000, band=50, seed=1)
+        monkeypatch.setenv("CHIP_SN_G_MAXW", "100")
+    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=3)
+    ng, nl = hip.debug_counter(ks, "g_levels"), hip.debug_counter(ks, "sn_levels")
+    assert ng >= 1 and nl >= ng
+    if which == "mixed_widths":
+        assert ng < nl  # (some levels keep the block-by-block substitution)
+    elif which != "wide_psd":
+        assert ng == nl
+    # the same handle shape without the matrices: refined solutions agree to rounding (both handles refactor a second
+    # time first: the matrices are rebuilt by every refactor)
+    monkeypatch.setenv("CHIP_NO_SNODE_G", "1")
+    ks0, _ = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1)
+    assert hip.debug_counter(ks0, "g_levels") == 0
+    monkeypatch.delenv("CHIP_NO_SNODE_G")
+    rng = np.random.default_rng(11)
+    rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+    sols = []
+    for k in (ks0, ks):
+        assert k.update_scaling(pr["s"], pr["z"]) and k.update(hs)
+        k.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert k.solve(x, z)
+        sols.append(np.concatenate([x, z]))
+    assert relerr(sols[1], sols[0]) <= 1e-9
+    # without refinement the two forms still agree to the accuracy of one LDL' solve
+    st = hip.Settings.default(iterative_refinement_enable=0)
+    _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1, settings=st, tol=1e-5 if "late" in which else 1e-6)
 
 
 @pytest.mark.parametrize("seed", range(10))

@@ -248,6 +248,9 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 rec[8 * k + 2] = S.sn_ptr[sn + 1] - p0;
                 rec[8 * k + 3] = e;
                 rec[8 * k + 4] = S.Lp[e + 1] - S.Lp[e];
+                rec[8 * k + 5] = S.Lp[e];
+                rec[8 * k + 6] = -1; // (offset of G: filled in below for the supernodes that keep one)
+                rec[8 * k + 7] = -1;
             }
             if ((rc = upload(&sn_order, rec, rec.size()))) return rc;
         }
@@ -395,6 +398,16 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 if ((rc = upload(&sn_g_tasks, sorted, sorted.size()))) return rc;
                 sn_g_ntasks = (int)nt;
                 if ((rc = upload(&sn_g_off, goff, goff.size()))) return rc;
+                { // the offsets also travel in the supernodes' records (snode_common.hpp: SnodeGeom::goff)
+                    std::vector<i32> rec(S.sn_order.size() * 8 + 8, 0);
+                    CHIP_HIP(hipMemcpy(rec.data(), sn_order, rec.size() * sizeof(i32), hipMemcpyDeviceToHost));
+                    for (size_t k = 0; k < S.sn_order.size(); k++) {
+                        const long long o = goff[(size_t)S.sn_order[k]];
+                        rec[8 * k + 6] = (i32)(unsigned)(o & 0xffffffffll);
+                        rec[8 * k + 7] = (i32)(unsigned)((unsigned long long)o >> 32);
+                    }
+                    CHIP_HIP(hipMemcpy(sn_order, rec.data(), rec.size() * sizeof(i32), hipMemcpyHostToDevice));
+                }
                 if ((rc = alloc(&sn_Gx, (size_t)total + 8))) return rc;
                 CHIP_HIP(hipMemset(sn_Gx, 0, ((size_t)total + 8) * sizeof(double))); // (entries above a row's diagonal block are never written)
                 if ((rc = alloc(&sn_yt, n))) return rc;

@@ -916,6 +916,7 @@ __global__ __launch_bounds__(SNP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // dynamic LDS (~104 KiB).
 // ---------------------------------------------------------------------------
 constexpr int SNQ_WG = 512;
+constexpr int SNQ_GS = 8; // pivots a lane factors by itself at a time (k_snode_panel2<true>)
 __device__ __forceinline__ void snq_rows(const LdlView &v, const SnodeGeom &g, const double *Ll, const double *dinvl,
                                          const int *colbase, double *xw, int R0w, int nbw, int lane, int kb_from, int kb_to,
                                          snode_v4d (&acc)[3][4], double (&h)[16], bool load) {
@@ -997,12 +998,22 @@ __device__ __forceinline__ void snq_rows(const LdlView &v, const SnodeGeom &g, c
         __builtin_amdgcn_wave_barrier();
     }
 }
+// UNI (round 5): the owner wave factors its quarter in groups of SNQ_GS pivots WITHOUT cross-lane traffic on the pivot
+// chain.  A group's SNQ_GS x SNQ_GS diagonal sub-block goes through LDS to EVERY lane, which factors it by itself (the
+// divisions, the multiply-adds, the sign rule) and applies the group's pivots to its own row with coefficients it now
+// holds; the quarter's columns behind the group take the group's pivots as one block (coefficients: the scaled
+// entries of the rows behind the sub-block, through LDS).  The readlane form broadcast the pivot and every
+// coefficient l(c', c) from its lane -- two v_readlane per product on the chain of all 64 pivots, ~360 ns per pivot.
+// Per entry the same operations in the same order: the factors are bitwise those of the readlane form
+// (CHIP_NO_PANEL_UNIFORM).
+template <bool UNI>
 __global__ __launch_bounds__(SNQ_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snode_panel2(LdlView v, SnodeView sv, const int *__restrict__ order,
                                                                                                    int b) {
     extern __shared__ __attribute__((aligned(16))) char qsm[];
     double *Ll = (double *)qsm;                 // Ll[k * 64 + i] = l(i, k), 0 for i <= k
     double *xhb = Ll + SN_NB * SN_NB;           // eight head blocks, [row][column], stride SNP_XLD
     __shared__ double dinvl[SN_NB], sgn[SN_NB];
+    __shared__ __attribute__((aligned(16))) double sdl[64 + 16 * SNQ_GS]; // UNI: a group's sub-block | the coefficients of the cross update
     __shared__ int colbase[SN_NB];
     __shared__ int s_nreg, s_bad;
     int sn;
@@ -1032,69 +1043,148 @@ __global__ __launch_bounds__(SNQ_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     int nreg = 0, bad = 0;
     const int l15 = i & 15, kq = i >> 4;
     double *xw = xhb + wave * (64 * SNP_XLD);
-    snode_v4d racc[3][4];
-    double rh[16];
-    // (a wave belongs to one team: the block team's quarter and its lane = row copy live in the registers the rows team
-    // uses for its rows -- both sets at once do not fit 256 registers)
-    snode_v4d(&Aq)[4] = racc[0];
-    double(&T)[16] = rh;
+    // A wave belongs to ONE team for the block column's first pass, and the two teams run their own loops over the quarters
+    // (wave-uniform branches; both execute the same four barriers): the block team's quarter, its lane = row copy and the
+    // sub-blocks it factors are then never live together with the rows team's 64 x 64 tile -- in one common loop the
+    // register allocator had to keep both sets (more than 256 registers, spills on the pivot chain).
+    double T[16]; // block team: the owner's quarter in the lane = row form (scaled on the way out: written back below)
     const int R0first = row_first + 64 * q; // rows team: this wave's 64 rows of the first group
-    const bool rlive = !teamD && R0first < g.h;
     if (teamD) {
-        const int j = 16 * q + l15; // this lane's column
-        const bool jok = j < nbw;
-        const int cb = colbase[j];
-        const double djj = jok ? v.D[g.cols[j0 + min(j, nbw - 1)]] : 1.0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * t + kq + 4 * r;
-                double val = (jok && row < nbw && row > j) ? v.Lx[cb + j0 + row] : 0.0;
-                if (row == j) val = djj;
-                Aq[t][r] = val;
-            }
-    } else if (rlive) {
-        snq_rows(v, g, Ll, dinvl, colbase, xw, R0first, nbw, i, 0, 0, racc, rh, true); // (loads only)
-    }
-#pragma unroll 1
-    for (int kb = 0; kb < SN_NB / 16; ++kb) {
-        if (teamD && q == kb) { // (as in k_snode_panel: the owner factors its quarter in the lane = row form)
+        snode_v4d Aq[4];
+        {
+            const int j = 16 * q + l15; // this lane's column
+            const bool jok = j < nbw;
+            const int cb = colbase[j];
+            const double djj = jok ? v.D[g.cols[j0 + min(j, nbw - 1)]] : 1.0;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = Aq[t][r];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int c = 0; c < 16; ++c) T[c] = xw[i * SNP_XLD + c];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int c = 16 * kb + t;
-                double d = readlane_f64(T[t], c);
-                const double sg = readlane_f64(sgl, c);
-                const bool reg = d * sg < v.reg_eps;
-                if (reg) d = v.reg_delta * sg;
-                const double dinv = 1.0 / d;
-                if (i == c) {
-                    dfin = d;
-                    dinvfin = dinv;
-                    if (reg) nreg = 1;
-                    if (d == 0.0) bad |= 2;
-                    if (!isfinite(dinv)) bad |= 1;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + kq + 4 * r;
+                    double val = (jok && row < nbw && row > j) ? v.Lx[cb + j0 + row] : 0.0;
+                    if (row == j) val = djj;
+                    Aq[t][r] = val;
                 }
-                const double uc = i > c ? T[t] : 0.0;
-                const double l = uc * dinv;
-                T[t] = l;
-                xw[i * SNP_XLD + t] = -uc;
-                Ll[c * SN_NB + i] = l;
-                if (i == 0) dinvl[c] = dinv;
-#pragma unroll
-                for (int t2 = t + 1; t2 < 16; ++t2) T[t2] -= readlane_f64(l, 16 * kb + t2) * uc;
-            }
         }
-        __syncthreads(); // quarter kb of Ll, its pivots and the owner's negated panel are published
-        if (teamD) {
+#pragma unroll 1
+        for (int kb = 0; kb < SN_NB / 16; ++kb) {
+            if (q == kb) { // (as in k_snode_panel: the owner factors its quarter in the lane = row form)
+    #pragma unroll
+                for (int t = 0; t < 4; ++t)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = Aq[t][r];
+                __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                for (int c = 0; c < 16; ++c) T[c] = xw[i * SNP_XLD + c];
+                __builtin_amdgcn_wave_barrier();
+                if (UNI) {
+                    const int cbase = 16 * kb;
+                    constexpr int GS = SNQ_GS; // pivots per group
+    #pragma unroll
+                    for (int gq = 0; gq < 16 / GS; ++gq) {
+                        const int a_me = i - cbase - GS * gq; // this lane's row inside the group's GS x GS sub-block (if 0 <= a_me < GS)
+                        if (a_me >= 0 && a_me < GS) {
+    #pragma unroll
+                            for (int bb = 0; bb < GS; ++bb) sdl[a_me * GS + bb] = T[GS * gq + bb];
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        double S[GS][GS];
+    #pragma unroll
+                        for (int a = 0; a < GS; ++a)
+    #pragma unroll
+                            for (int bb = 0; bb <= a; ++bb) S[a][bb] = sdl[a * GS + bb];
+                        __builtin_amdgcn_wave_barrier();
+                        double ug[GS]; // this row's unscaled entries of the group's columns
+    #pragma unroll
+                        for (int t = 0; t < GS; ++t) {
+                            const int c = cbase + GS * gq + t;
+                            double d = S[t][t];
+                            const double sg = readlane_f64(sgl, c);
+                            const bool reg = d * sg < v.reg_eps;
+                            if (reg) d = v.reg_delta * sg;
+                            const double dinv = 1.0 / d;
+                            if (i == c) {
+                                dfin = d;
+                                dinvfin = dinv;
+                                if (reg) nreg = 1;
+                                if (d == 0.0) bad |= 2;
+                                if (!isfinite(dinv)) bad |= 1;
+                            }
+                            double la[GS];
+    #pragma unroll
+                            for (int a = t + 1; a < GS; ++a) la[a] = S[a][t] * dinv; // l(c + a - t, c), known to every lane
+    #pragma unroll
+                            for (int a = t + 1; a < GS; ++a)
+    #pragma unroll
+                                for (int bb = t + 1; bb <= a; ++bb) S[a][bb] -= la[bb] * S[a][t];
+                            const double uc = i > c ? T[GS * gq + t] : 0.0;
+                            const double l = uc * dinv;
+                            ug[t] = uc;
+                            T[GS * gq + t] = l;
+                            xw[i * SNP_XLD + GS * gq + t] = -uc;
+                            Ll[c * SN_NB + i] = l;
+                            if (i == 0) dinvl[c] = dinv;
+    #pragma unroll
+                            for (int t2 = t + 1; t2 < GS; ++t2) T[GS * gq + t2] -= la[t2] * uc;
+                        }
+                        constexpr int NX_MAX = 16 - GS;
+                        const int nx = 16 - GS * (gq + 1); // columns of the quarter behind the group
+                        if (nx > 0) {
+                            // they take the group's pivots, t = 0 .. GS - 1 in order: the coefficients l(cbase + GS (gq + 1) + b, c_t) are
+                            // the scaled entries of the rows behind the sub-block -- those lanes' T[GS gq + t]
+                            const int b_me = i - cbase - GS * (gq + 1);
+                            if (b_me >= 0 && b_me < nx) {
+    #pragma unroll
+                                for (int t = 0; t < GS; ++t) sdl[64 + t * 16 + b_me] = T[GS * gq + t]; // [pivot][row]: a pivot's coefficients contiguous
+                            }
+                            __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                            for (int t = 0; t < GS; ++t) {
+                                // (an opaque zero that depends on the previous pivot's first result keeps the compiler from
+                                // requesting all coefficients at once ahead of the first product)
+                                int zoff;
+                                asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(T[GS * (gq + 1)])));
+                                const snode_v2d *cf = (const snode_v2d *)(sdl + 64 + t * 16 + zoff);
+    #pragma unroll
+                                for (int p2 = 0; p2 < NX_MAX / 2; ++p2) {
+                                    if (2 * p2 >= nx) continue; // (compile time after unrolling)
+                                    const snode_v2d cc = cf[p2];
+                                    T[GS * (gq + 1) + 2 * p2] -= cc.x * ug[t];
+                                    T[GS * (gq + 1) + 2 * p2 + 1] -= cc.y * ug[t];
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else {
+    #pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int c = 16 * kb + t;
+                    double d = readlane_f64(T[t], c);
+                    const double sg = readlane_f64(sgl, c);
+                    const bool reg = d * sg < v.reg_eps;
+                    if (reg) d = v.reg_delta * sg;
+                    const double dinv = 1.0 / d;
+                    if (i == c) {
+                        dfin = d;
+                        dinvfin = dinv;
+                        if (reg) nreg = 1;
+                        if (d == 0.0) bad |= 2;
+                        if (!isfinite(dinv)) bad |= 1;
+                    }
+                    const double uc = i > c ? T[t] : 0.0;
+                    const double l = uc * dinv;
+                    T[t] = l;
+                    xw[i * SNP_XLD + t] = -uc;
+                    Ll[c * SN_NB + i] = l;
+                    if (i == 0) dinvl[c] = dinv;
+    #pragma unroll
+                    for (int t2 = t + 1; t2 < 16; ++t2) T[t2] -= readlane_f64(l, 16 * kb + t2) * uc;
+                }
+                }
+            }
+
+            __syncthreads(); // quarter kb of Ll, its pivots and the owner's negated panel are published
             if (q > kb) {
                 const double *xo = xhb + kb * (64 * SNP_XLD);
 #pragma unroll
@@ -1107,8 +1197,16 @@ __global__ __launch_bounds__(SNQ_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     }
                 }
             }
-        } else if (rlive) {
-            snq_rows(v, g, Ll, dinvl, colbase, xw, R0first, nbw, i, kb, kb + 1, racc, rh, false);
+        }
+    } else {
+        const bool rlive = R0first < g.h;
+        snode_v4d racc[3][4];
+        double rh[16];
+        if (rlive) snq_rows(v, g, Ll, dinvl, colbase, xw, R0first, nbw, i, 0, 0, racc, rh, true); // (loads only)
+#pragma unroll 1
+        for (int kb = 0; kb < SN_NB / 16; ++kb) {
+            __syncthreads(); // (the block team's barrier of quarter kb)
+            if (rlive) snq_rows(v, g, Ll, dinvl, colbase, xw, R0first, nbw, i, kb, kb + 1, racc, rh, false);
         }
     }
     if (nreg) atomicAdd(&s_nreg, 1);
@@ -1145,6 +1243,8 @@ __global__ __launch_bounds__(SNQ_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int gstride = (int)gridDim.x * SNP_WG;
     for (int base = row_first + gstride; base < g.h; base += 2 * gstride) {
         const int R0w = (teamD ? base : base + gstride) + 64 * q;
+        snode_v4d racc[3][4];
+        double rh[16];
         if (R0w < g.h) snq_rows(v, g, Ll, dinvl, colbase, xw, R0w, nbw, i, 0, 4, racc, rh, true);
     }
 }
@@ -1569,7 +1669,8 @@ int snode_kernel_attributes(int wmax, int nbmax) {
     int rc = (int)raise_dynamic_lds((const void *)k_snode_update, (size_t)lds);
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_extend, (size_t)lds);
     const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
-    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
+    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<true>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
+    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<false>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_fwd, (size_t)lds2);
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_bwd, (size_t)lds2);
     return rc;
@@ -1750,7 +1851,8 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
             const int gx = std::max(1, std::min(groups, slots / std::max(1, count)));
             if (panel_mode == 3 && !dbg.on && !switches().no_panel_overlap) { // both phases on the matrix cores, overlapped
                 const size_t qlds = (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double);
-                k_snode_panel2<<<dim3(gx, count), SNQ_WG, qlds, s>>>(v, sv, order, b);
+                if (switches().no_panel_uniform) k_snode_panel2<false><<<dim3(gx, count), SNQ_WG, qlds, s>>>(v, sv, order, b);
+                else k_snode_panel2<true><<<dim3(gx, count), SNQ_WG, qlds, s>>>(v, sv, order, b);
             } else {
                 k_snode_panel<<<dim3(gx, count), SNP_WG, 0, s>>>(v, sv, order, b, panel_mode);
             }

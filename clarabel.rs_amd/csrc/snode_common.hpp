@@ -28,16 +28,21 @@ struct SnodeGeom {
     double *d;     // pivots of the members, packed (k_snode_diag)
     const int8_t *sg; // signs of the members, packed
     int w, nb, h, e;
+    int bn0;        // Lp[e]: where the node ids of the rows of B start in Li
+    long long goff; // offset of the supernode's substitution matrix G in SnodeView::Gx, < 0: none (snode_g.hip)
 };
 // The supernodes of a unit level come as RECORDS in level order (`order` points at the level's first record):
-// (supernode id, first member p0, width w, last member column e, rows of B, -, -, -) -- one 32-byte read where the
+// (supernode id, first member p0, width w, last member column e, rows of B, Lp[e], offset of G lo / hi) -- one 32-byte read where the
 // kernels of rounds 1-2 chased order -> sn -> sn_ptr / sn_geo (three dependent loads at the head of every launch).
 constexpr int SN_REC = 8;
 __device__ __forceinline__ SnodeGeom snode_geom(const SnodeView &sv, const int *__restrict__ order, int idx, int &sn) {
     typedef int rec_v4i __attribute__((ext_vector_type(4)));
     const rec_v4i r0 = *(const rec_v4i *)(order + SN_REC * idx);
-    const int nb = order[SN_REC * idx + 4];
+    const rec_v4i r1 = *(const rec_v4i *)(order + SN_REC * idx + 4);
+    const int nb = r1.x;
     SnodeGeom g;
+    g.bn0 = r1.y;
+    g.goff = (long long)(((unsigned long long)(unsigned)r1.w << 32) | (unsigned long long)(unsigned)r1.z);
     sn = r0.x;
     g.cols = sv.sn_col + r0.y;
     g.cb = sv.sn_cb + r0.y;

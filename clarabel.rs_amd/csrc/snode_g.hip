@@ -107,7 +107,7 @@ __global__ __launch_bounds__(SG_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const SnodeGeom g = snode_geom(sv, order_all, rec, sn);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int ldg = sg_ldg(g.h);
-    double *G = sv.Gx + sv.g_off[sn];
+    double *G = sv.Gx + g.goff;
     for (int t = tid; t < g.w; t += SG_WG) colbase[t] = g.cb[t];
     const int nblk = (g.w + SN_NB - 1) / SN_NB;
     const int Rlast = min(R0 + SG_WG, g.h) - 1;                      // last row of this workgroup
@@ -215,48 +215,67 @@ __global__ __launch_bounds__(SG_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
 }
 
-// forward: grid (64-row blocks of G, supernodes of the unit level).  Lane = row, the columns a quarter per wave (eight
-// column runs in flight per lane), the four partial sums meet in LDS.  Member rows go to yt (the other workgroups of
-// the supernode still read x_S(old) from x), the rows of B leave as one atomic per (row, supernode).
-__global__ __launch_bounds__(SG_WG) void k_snode_gfwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
-                                                      double *yt) {
+// forward: grid (64-row blocks of G, supernodes of the unit level), sixteen waves.  Lane = row; wave q takes the columns
+// q, q + 16, ...: their entries are REQUESTED FIRST -- they depend on nothing but the record -- and x_S is staged while
+// they are in flight (a launch is a handful of dependent memory round trips, not bandwidth); the sixteen partial sums
+// meet in LDS.  Member rows go to yt (the other workgroups of the supernode still read x_S(old) from x), the rows of B
+// leave as one atomic per (row, supernode).
+constexpr int SGS_WG = 1024;
+constexpr int SGS_NW = SGS_WG / 64;
+__global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
+                                                       double *yt) {
     __shared__ double xs[SG_WMAX];
-    __shared__ double part[SG_WG / 64][64];
+    __shared__ double part[SGS_NW][64];
     int sn;
     const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int r0 = 64 * (int)blockIdx.x;
     if (r0 >= g.h) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncols = r0 < g.w ? min(g.w, r0 + 64) : g.w; // (rows of T^-1 end at their diagonal block)
-    for (int t = tid; t < ncols; t += SG_WG) xs[t] = x[g.cols[t]];
-    __syncthreads();
     const int ldg = sg_ldg(g.h);
     const int i = r0 + lane;
-    const double *Gr = sv.Gx + sv.g_off[sn] + min(i, g.h - 1);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int j = wave;
-    for (; j + 28 < ncols; j += 32) {
-        double l[8];
+    const double *Gr = sv.Gx + g.goff + min(i, g.h - 1);
+    double l[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) l[u] = Gr[(size_t)(j + 4 * u) * ldg];
-        s0 += l[0] * xs[j] + l[4] * xs[j + 16];
-        s1 += l[1] * xs[j + 4] + l[5] * xs[j + 20];
-        s2 += l[2] * xs[j + 8] + l[6] * xs[j + 24];
-        s3 += l[3] * xs[j + 12] + l[7] * xs[j + 28];
+    for (int q = 0; q < 16; ++q) l[q] = Gr[(size_t)min(wave + SGS_NW * q, ncols - 1) * ldg]; // (clamped: unconditional)
+    for (int t = tid; t < ncols; t += SGS_WG) xs[t] = x[g.cols[t]];
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) {
+        const int j = wave + SGS_NW * q;
+        s0 += j < ncols ? l[q] * xs[j] : 0.0;
+        s1 += j + SGS_NW < ncols ? l[q + 1] * xs[j + SGS_NW] : 0.0;
+        s2 += j + 2 * SGS_NW < ncols ? l[q + 2] * xs[j + 2 * SGS_NW] : 0.0;
+        s3 += j + 3 * SGS_NW < ncols ? l[q + 3] * xs[j + 3 * SGS_NW] : 0.0;
     }
-    for (; j < ncols; j += 4) s0 += Gr[(size_t)j * ldg] * xs[j];
+    for (int jb = 16 * SGS_NW; jb < ncols; jb += 16 * SGS_NW) { // (supernodes wider than 256)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) l[q] = Gr[(size_t)min(jb + wave + SGS_NW * q, ncols - 1) * ldg];
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+            const int j = jb + wave + SGS_NW * q;
+            s0 += j < ncols ? l[q] * xs[j] : 0.0;
+            s1 += j + SGS_NW < ncols ? l[q + 1] * xs[j + SGS_NW] : 0.0;
+            s2 += j + 2 * SGS_NW < ncols ? l[q + 2] * xs[j + 2 * SGS_NW] : 0.0;
+            s3 += j + 3 * SGS_NW < ncols ? l[q + 3] * xs[j + 3 * SGS_NW] : 0.0;
+        }
+    }
     part[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0 && i < g.h) {
-        const double tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < SGS_NW; ++q) tot += part[q][lane];
         if (i < g.w) yt[g.cols[i]] = tot;
-        else atomicAdd(&x[(v.Li + v.Lp[g.e])[i - g.w]], -tot);
+        else atomicAdd(&x[v.Li[g.bn0 + i - g.w]], -tot);
     }
 }
-// backward: grid (64-column blocks, supernodes of the unit level).  s = [D^-1 y_S ; -x_B] from the block's first row
-// on in LDS, a wave per column (four columns together, rows along the lanes), fixed order of summation, no atomics.
-__global__ __launch_bounds__(SG_WG) void k_snode_gbwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
-                                                      const double *yt) {
+// backward: grid (64-column blocks, supernodes of the unit level), sixteen waves of four columns each.  A wave's first
+// 4 x 4 x 64 entries are requested first, s = [D^-1 y_S ; -x_B] (from the block's first row on) is staged in LDS while
+// they are in flight; rows along the lanes, fixed order of summation, no atomics.
+__global__ __launch_bounds__(SGS_WG) void k_snode_gbwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
+                                                       const double *yt) {
     extern __shared__ __attribute__((aligned(16))) char bsm[];
     double *ss = (double *)bsm;
     int sn;
@@ -264,8 +283,19 @@ __global__ __launch_bounds__(SG_WG) void k_snode_gbwd(LdlView v, SnodeView sv, c
     const int j0 = 64 * (int)blockIdx.x;
     if (j0 >= g.w) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int *Bn = v.Li + v.Lp[g.e];
-    for (int i = j0 + tid; i < g.h; i += SG_WG) {
+    const int ldg = sg_ldg(g.h);
+    const int nr = g.h - j0;
+    const int jf = j0 + 4 * wave; // this wave's columns jf .. jf + 3
+    const double *Gc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Gc[u] = sv.Gx + g.goff + (size_t)min(jf + u, g.w - 1) * ldg + j0;
+    double l[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) l[u][rr] = Gc[u][min(lane + 64 * rr, nr - 1)]; // (entries above the diagonal inside the block are stored zeros)
+    const int *Bn = v.Li + g.bn0;
+    for (int i = j0 + tid; i < g.h; i += SGS_WG) {
         double val;
         if (i < g.w) {
             const int c = g.cols[i];
@@ -276,42 +306,32 @@ __global__ __launch_bounds__(SG_WG) void k_snode_gbwd(LdlView v, SnodeView sv, c
         ss[i - j0] = val;
     }
     __syncthreads();
-    const int ldg = sg_ldg(g.h);
-    const double *G = sv.Gx + sv.g_off[sn];
-    const int nr = g.h - j0;
-#pragma unroll 1
-    for (int t0 = 0; t0 < 16; t0 += 4) {
-        const int jf = j0 + 16 * wave + t0;
-        if (jf >= g.w) break; // (wave uniform)
-        const double *Gc[4];
+    if (jf >= g.w) return; // (wave uniform; after the barrier)
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Gc[u] = G + (size_t)min(jf + u, g.w - 1) * ldg + j0;
-        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
-        int i = lane;
-        for (; i + 64 < nr; i += 128) { // (entries above the diagonal inside the block are stored zeros)
-            double l0[4], l1[4];
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = lane + 64 * rr;
+        const double sa = i < nr ? ss[i] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                l0[u] = Gc[u][i];
-                l1[u] = Gc[u][i + 64];
-            }
-            const double sa = ss[i], sb = ss[i + 64];
+        for (int u = 0; u < 4; ++u) a[u] += l[u][rr] * sa;
+    }
+    for (int ib = 256; ib < nr; ib += 256) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a0[u] += l0[u] * sa;
-                a1[u] += l1[u] * sb;
-            }
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) l[u][rr] = Gc[u][min(ib + lane + 64 * rr, nr - 1)];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = ib + lane + 64 * rr;
+            const double sa = i < nr ? ss[i] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += l[u][rr] * sa;
         }
-        for (; i < nr; i += 64) {
-            const double sa = ss[i];
+    }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a0[u] += Gc[u][i] * sa;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double tot = wave_sum(a0[u] + a1[u]);
-            if (lane == 0 && jf + u < g.w) x[g.cols[jf + u]] = tot;
-        }
+    for (int u = 0; u < 4; ++u) {
+        const double tot = wave_sum(a[u]);
+        if (lane == 0 && jf + u < g.w) x[g.cols[jf + u]] = tot;
     }
 }
 
@@ -338,8 +358,8 @@ void solve_snodes_g(hipStream_t s, GatherMode m, const LdlView &v, const SnodeVi
                     int hlvl, double *x, double *yt, const LaunchProf *lp) {
     if (!count) return;
     if (lp) lp->begin(lp->ctx, PFK_SN_TRI);
-    if (m == FWD) k_snode_gfwd<<<dim3((hlvl + 63) / 64, count), SG_WG, 0, s>>>(v, sv, order, x, yt);
-    else k_snode_gbwd<<<dim3((wlvl + 63) / 64, count), SG_WG, (size_t)hlvl * sizeof(double), s>>>(v, sv, order, x, yt);
+    if (m == FWD) k_snode_gfwd<<<dim3((hlvl + 63) / 64, count), SGS_WG, 0, s>>>(v, sv, order, x, yt);
+    else k_snode_gbwd<<<dim3((wlvl + 63) / 64, count), SGS_WG, (size_t)hlvl * sizeof(double), s>>>(v, sv, order, x, yt);
     if (lp) lp->end(lp->ctx, PFK_SN_TRI);
 }
 

@@ -64,6 +64,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_SNODE_PANEL", Entry::FLAG, SW(no_snode_panel), 0},
     {"CHIP_SN_PANEL_SLOTS", Entry::INT, SW(sn_panel_slots), 0},
     {"CHIP_NO_PANEL_OVERLAP", Entry::FLAG, SW(no_panel_overlap), 0},
+    {"CHIP_NO_PANEL_UNIFORM", Entry::FLAG, SW(no_panel_uniform), 0},
     {"CHIP_NO_PANEL_MFMA", Entry::FLAG, SW(no_panel_mfma), 0},
     {"CHIP_NO_PANEL_DIAG_MFMA", Entry::FLAG, SW(no_panel_diag_mfma), 0},
     {"CHIP_NO_EXTEND_ASM", Entry::FLAG, SW(no_extend_asm), 0},

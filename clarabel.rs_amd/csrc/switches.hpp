@@ -61,6 +61,7 @@ struct Switches {
     int sn_panel_slots = 0;         // CHIP_SN_PANEL_SLOTS: workgroups of one k_snode_panel launch beyond which a workgroup walks several
                                     // groups of 256 rows (0: 256; tests: 1 -> every workgroup walks all groups)
     bool no_panel_overlap = false;  // CHIP_NO_PANEL_OVERLAP: k_snode_panel (block factorisation, then the rows) instead of k_snode_panel2
+    bool no_panel_uniform = false;  // CHIP_NO_PANEL_UNIFORM: the block team of k_snode_panel2 broadcasts pivots / coefficients by v_readlane (round 4) instead of factoring 8 x 8 sub-blocks in every lane
     bool no_panel_mfma = false;     // CHIP_NO_PANEL_MFMA
     bool no_panel_diag_mfma = false; // CHIP_NO_PANEL_DIAG_MFMA
     bool no_extend_asm = false;     // CHIP_NO_EXTEND_ASM: ancestor updates always by fp64 atomics (k_snode_extend), never assembled

@@ -231,6 +231,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     h_sn_col = S.sn_col;
     if (nsn > 0) {
         if ((rc = upload_lists(snx, S.snx))) return rc;
+        if ((rc = upload_lists(snb, S.snb))) return rc;
         if ((rc = upload_lists(fwu, S.fwu))) return rc;
         if ((rc = upload_lists(bwu, S.bwu))) return rc;
         nRf = S.Rf_p.empty() ? 0 : S.Rf_p.back();
@@ -960,6 +961,9 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         dev::factor_snodes(stream, v, sview, sn_order + 8 * sn_lvl_ptr[l], count, sn_wmax, sn_lvl_nblk[l], sn_lvl_hmax[l],
                            sn_lvl_nbmax[l], prof_family >= PF_SN_UPDATE ? &lprof : nullptr, &av);
     };
+    // the bundle columns' contributions into the supernode members of ALL unit levels: one launch (they depend on nothing
+    // in the top; the chunks meet the other contributions in the same fp64 atomics)
+    if (nsn > 0 && !top_folded && !snb.b_ptr.empty() && snb.b_ptr.size() > 1) dev::factor_B(stream, vf, snb.B(0));
     for (int l = top_folded ? nfaclevels : 0; l < nfaclevels;) {
         int e = fac.chain_end[l];
         for (int k = l; k < e; k++)

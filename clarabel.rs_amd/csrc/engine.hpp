@@ -79,7 +79,7 @@ struct Engine {
     DeviceLists fac, fwd, bwd, smv;
     // chain supernodes (host.hpp: Symbolic::sn_*): factor lists `fac` and `snx` are indexed by UNIT level
     int nfaclevels = 0, nsn = 0, sn_wmax = 0;
-    DeviceLists snx, fwu, bwu;
+    DeviceLists snx, snb, fwu, bwu;
     double *Rfx = nullptr; // values of L at the filtered row lists (refreshed per refactor)
     int nRf = 0, sn_nbmax = 0;
     int *sn_geo = nullptr, *sn_cb = nullptr, *sn_ptr = nullptr, *sn_col = nullptr, *sn_order = nullptr, *Rf_p = nullptr, *Rf_col = nullptr,

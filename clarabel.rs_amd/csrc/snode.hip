@@ -242,8 +242,12 @@ __device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
 // grid (row groups, supernodes of the level, k splits): with few workgroups in flight (the narrow
 // levels near the root) the finished columns are divided among gridDim.z workgroups per tile group,
 // which then meet in fp64 atomics
+// emit_atomic: every element leaves as ONE fp64 atomic add of the negated product sum instead of a read-modify-write -- the
+// same rounded result (cur + (-val)), but the tile does not wait for a second round trip of loads after the matrix
+// instructions (round 3's stamps: the emit phase took 10 of the launch's 22 us on config 2); a launch without k-split
+// still has exactly one contribution per element, so the result does not depend on the order of arrival.
 __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_update(LdlView v, SnodeView sv, const int *__restrict__ order,
-                                                        int b) {
+                                                        int b, int emit_atomic) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
     int *colbase = snode_lds(smem, Wl);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const int c0 = (int)(((long long)nunits * blockIdx.z) / ns), c1 = (int)(((long long)nunits * (blockIdx.z + 1)) / ns);
     if (c0 >= c1) return;
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
-    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), c1 * SN_NB, row_begin, c0 * SN_NB, ns > 1);
+    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), c1 * SN_NB, row_begin, c0 * SN_NB, ns > 1 || emit_atomic);
 }
 // grid (row groups, column blocks of B, supernodes of the level) -- or, xcd != 0, ONE dimension that is decoded so that
 // the tiles of a supernode share an XCD: workgroups go to the eight XCDs round-robin by their linear id, every XCD has
@@ -267,18 +271,22 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 // launch of the leaf level, ~2.9 TB/s: the launch was bound by that, not by the matrix cores); with a supernode per
 // XCD a k chunk (~1 MB) is fetched once and the other tiles find it in the L2.  id = 8 q + r: XCD r works on supernode
 // 8 (q / T) + r, tile q % T of T = gx * gy.
+// ks > 1 (round 5; levels with few supernodes -- BASELINE config 2's 26 deep levels ran 3 workgroups per supernode for
+// ~56 us): the member columns k are divided among ks workgroups per tile, which meet in the fp64 atomics the tiles
+// leave through anyway (not with the assembled form, whose stores are plain).
 __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_extend(LdlView v, SnodeView sv, const int *__restrict__ order,
-                                                                                                   int xcd, int gx, int gy, int count) {
+                                                                                                   int xcd, int gx, int gy, int count, int ks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
     int *colbase = snode_lds(smem, Wl);
-    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    int bx = (int)blockIdx.x % gx, ksi = (int)blockIdx.x / gx, by = (int)blockIdx.y, bz = (int)blockIdx.z;
     if (xcd) {
-        const int id = (int)blockIdx.x, r = id & 7, q = id >> 3, T = gx * gy, tile = q % T;
+        const int id = (int)blockIdx.x, r = id & 7, q = id >> 3, T = gx * gy * ks, tile = q % T, rem = tile % (gx * gy);
         bz = 8 * (q / T) + r;
         if (bz >= count) return;
-        by = tile / gx; // (column blocks outermost: the tiles of one column block share the staged operand as well)
-        bx = tile % gx;
+        ksi = tile / (gx * gy);
+        by = rem / gx; // (column blocks outermost: the tiles of one column block share the staged operand as well)
+        bx = rem % gx;
     }
     int sn;
     const SnodeGeom g = snode_geom(sv, order, bz, sn);
@@ -286,8 +294,12 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     if (c0 >= g.nb) return;
     const int row_begin = g.w + c0 + bx * SN_ROWS;
     if (row_begin >= g.h) return;
+    // this split's share of the member columns, in units of one block column
+    const int nunits = (g.w + SN_NB - 1) / SN_NB;
+    const int kbeg = (int)(((long long)nunits * ksi) / ks) * SN_NB, kend = min(g.w, (int)(((long long)nunits * (ksi + 1)) / ks) * SN_NB);
+    if (kbeg >= kend) return;
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
-    snode_tiles<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SN_NB, g.nb - c0), g.w, row_begin);
+    snode_tiles<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SN_NB, g.nb - c0), kend, row_begin, kbeg);
 }
 // grid (target columns of the level): the update matrices the level's supernodes left in U, summed per target column
 // in LDS -- source after source, a barrier between them: two sources may hit the same row from different threads --
@@ -1833,7 +1845,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
                 while (!no_splitk && ksplit < split_max && ksplit * 2 * split_unit <= b && groups * count * ksplit < split_target) ksplit *= 2;
                 pb(PFK_SN_UPDATE);
                 if (dbg.mode == 2) sv.dbg = dbg.ring_slot(1) - 16 + 16; // (slots 16..20 of the launch's 32)
-                k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b);
+                k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b, switches().no_emit_atomic ? 0 : 1);
                 pe(PFK_SN_UPDATE);
                 if (dbg.on && dbg.mode != 2) dbg.collect(s, 1);
             }
@@ -1876,8 +1888,11 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
         if (!av || !av->nt) se.U = nullptr; // (this level scatters with atomics)
         const int gx = (nbmax + SN_ROWS - 1) / SN_ROWS, gy = (nbmax + SN_NB - 1) / SN_NB;
         const bool xcd = count >= 8 && !switches().no_xcd_map; // (fewer supernodes than XCDs: spread the tiles)
-        if (xcd) k_snode_extend<<<dim3((unsigned)(8 * ((count + 7) / 8) * gx * gy)), SN_WG, lds, s>>>(v, se, order, 1, gx, gy, count);
-        else k_snode_extend<<<dim3(gx, gy, count), SN_WG, lds, s>>>(v, se, order, 0, gx, gy, count);
+        int ks = 1; // k-split of the tiles while the launch would leave most of the chip idle (atomics only: not with the assembled form)
+        if (!se.U && !switches().no_splitk && !switches().deterministic)
+            while (ks < 8 && ks * 2 <= nblk && (long long)gx * gy * count * ks * 2 <= 512) ks *= 2;
+        if (xcd) k_snode_extend<<<dim3((unsigned)(8 * ((count + 7) / 8) * gx * gy * ks)), SN_WG, lds, s>>>(v, se, order, 1, gx, gy, count, ks);
+        else k_snode_extend<<<dim3(gx * ks, gy, count), SN_WG, lds, s>>>(v, se, order, 0, gx, gy, count, ks);
         if (se.U) {
             const int cap = switches().sn_asm_cap > 0 ? std::min(switches().sn_asm_cap, SNA_CAP) : SNA_CAP; // (tests: short windows)
             k_snode_assemble<<<av->nt, SNA_WG, 0, s>>>(v, se, *av, cap);

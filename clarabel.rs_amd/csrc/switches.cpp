@@ -38,6 +38,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_FACTOR_FLAT", Entry::FLAG, SW(no_factor_flat), 0},
     {"CHIP_NO_TOPBLK", Entry::FLAG, SW(no_topblk), 0},
     {"CHIP_NO_GATHER_HOIST", Entry::FLAG, SW(no_gather_hoist), 0},
+    {"CHIP_NO_SNX_HOIST", Entry::FLAG, SW(no_snx_hoist), 0},
     {"CHIP_NO_PSD_MFMA", Entry::FLAG, SW(no_psd_mfma), 0},
     {"CHIP_NO_PSD_ROWS", Entry::FLAG, SW(no_psd_rows), 0},
     {"CHIP_NO_XPERM", Entry::FLAG, SW(no_xperm), 0},
@@ -58,6 +59,7 @@ const Entry TABLE[] = {
     {"CHIP_SN_XB_CAP", Entry::INT, SW(sn_xb_cap), 0},
     {"CHIP_SN_DEBUG", Entry::INT, SW(sn_debug), 0},
     {"CHIP_NO_SPLITK", Entry::FLAG, SW(no_splitk), 0},
+    {"CHIP_NO_EMIT_ATOMIC", Entry::FLAG, SW(no_emit_atomic), 0},
     {"CHIP_SN_SPLIT_TARGET", Entry::INT, SW(sn_split_target), 0},
     {"CHIP_SN_SPLIT_MAX", Entry::INT, SW(sn_split_max), 0},
     {"CHIP_SN_SPLIT_UNIT", Entry::INT, SW(sn_split_unit), 0},

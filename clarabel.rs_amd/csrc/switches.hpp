@@ -34,6 +34,7 @@ struct Switches {
     bool no_factor_flat = false;    // CHIP_NO_FACTOR_FLAT (also read by the launcher of the bundle factorisation)
     bool no_topblk = false;         // CHIP_NO_TOPBLK
     bool no_gather_hoist = false;   // CHIP_NO_GATHER_HOIST
+    bool no_snx_hoist = false;      // CHIP_NO_SNX_HOIST: the bundle columns' contributions into supernode members stay in the launches of the members' unit levels
     bool no_psd_mfma = false;       // CHIP_NO_PSD_MFMA: the n x n products of the PSD cone kernels as scalar dot products, not on the matrix cores
     bool no_psd_rows = false;       // CHIP_NO_PSD_ROWS: the Hs blocks of PSD cones written through mapHs (caller's order), not row by row
     bool no_xperm = false;          // CHIP_NO_XPERM
@@ -56,6 +57,7 @@ struct Switches {
     int sn_xb_cap = 0;              // CHIP_SN_XB_CAP (0: default)
     int sn_debug = 0;               // CHIP_SN_DEBUG
     bool no_splitk = false;         // CHIP_NO_SPLITK
+    bool no_emit_atomic = false;    // CHIP_NO_EMIT_ATOMIC: the update tiles of a launch without k-split leave by read-modify-write (round 4), not as one atomic per element
     int sn_split_target = 256, sn_split_max = 8, sn_split_unit = 1; // CHIP_SN_SPLIT_TARGET / _MAX / _UNIT
     bool no_snode_panel = false;    // CHIP_NO_SNODE_PANEL: separate diag / rows launches
     int sn_panel_slots = 0;         // CHIP_SN_PANEL_SLOTS: workgroups of one k_snode_panel launch beyond which a workgroup walks several

@@ -1542,7 +1542,13 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 S.sn_lvl_nbmax[l] = std::max(S.sn_lvl_nbmax[l], nbel);
                 for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) {
                     const i32 j = S.sn_col[t];
-                    const i32 eb = FRp[j], ee = FRp[j + 1];
+                    i32 eb = FRp[j];
+                    const i32 ee = FRp[j + 1];
+                    // the contributions of BUNDLE columns (the head of the list: bundle columns are numbered first) depend
+                    // on nothing in the top: they are taken by ONE launch ahead of all levels (snb, below); the level's
+                    // own launch keeps the contributions of ordinary top columns (CHIP_NO_SNX_HOIST: everything)
+                    if (!switches().no_snx_hoist)
+                        while (eb < ee && FRcol[eb] < NFi) eb++;
                     if (ee == eb) continue;
                     i64 work = 0;
                     for (i32 q = eb; q < ee; q++) work += S.Lp[FRcol[q] + 1] - (FRpos[q] + 1) + 1;
@@ -1559,6 +1565,23 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             snx.close_level();
             fwu.close_level();
             bwu.close_level();
+        }
+        {
+            // contributions of bundle columns into supernode members, all unit levels together (see above)
+            ListBuilder snb(S.snb);
+            if (nsn > 0 && !switches().no_snx_hoist)
+                for (i32 sn = 0; sn < nsn; sn++)
+                    for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) {
+                        const i32 j = S.sn_col[t];
+                        const i32 eb = FRp[j];
+                        i32 mid = eb;
+                        while (mid < FRp[j + 1] && FRcol[mid] < NFi) mid++;
+                        if (mid == eb) continue;
+                        i64 work = 0;
+                        for (i32 q = eb; q < mid; q++) work += S.Lp[FRcol[q] + 1] - (FRpos[q] + 1) + 1;
+                        snb.add_B_work(j, eb, mid, FRcol, FRpos, S.Lp, work);
+                    }
+            snb.close_level();
         }
         ListBuilder smv(S.smv);
         for (i32 j = S.NF; j < n; j++) {

@@ -1286,7 +1286,9 @@ __global__ __launch_bounds__(SNQ_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // ---------------------------------------------------------------------------
 constexpr int SNT_WG = 512;
 constexpr int SNT_WMAX = 320; // the rows team holds four 64-row tiles: w - 64 <= 256
-constexpr int SNT_U = 4;      // k-groups of A operands in flight per lane
+constexpr int SNT_U = 4;      // k-groups of A operands in flight per lane (a wave with 16 matrix instructions per group)
+constexpr int SNT_UD = 8;     // ... of a wave with 4 matrix instructions per group (the block team: 256 cycles per group, the requests must be further ahead)
+constexpr int SNT_UB = 16;    // ... of k_snode_brows' waves (16 rows: 4 matrix instructions per group)
 
 // steps kb_from .. kb_to - 1 of the 16-blocked recurrence on a wave's tile of 16 RT rows x 64 columns in the accumulator
 // layout (acc[jb][t][r] = X[row 16 t + kq + 4 r][column 16 jb + l15]): x_c -= sum_{k < c} Ll[k * 64 + c] x_k; head block kb
@@ -1455,7 +1457,7 @@ __global__ __launch_bounds__(SNT_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     double *Wl = (double *)tsm;        // update phase: SN_KC x 64 (64 KiB)
     double *Ll = (double *)tsm;        // panel phase (the same bytes): Ll[k * 64 + i] = l(i, k), 0 for i <= k
     double *xhb = Ll + SN_NB * SN_NB;  // ... and eight head blocks, [row][column], stride SNP_XLD
-    __shared__ double dinvl[SN_NB], sgn[SN_NB];
+    __shared__ double dinvl[SN_NB];
     __shared__ __attribute__((aligned(16))) double sdl[64 + 16 * SNQ_GS];
     __shared__ int colbase[SNT_WMAX];
     __shared__ int s_nreg, s_bad;
@@ -1509,23 +1511,23 @@ __global__ __launch_bounds__(SNT_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 int rowA[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) rowA[t] = min(j0 + 16 * t + l15, g.w - 1);
-                double a[SNT_U][4];
+                double a[SNT_UD][4];
                 auto request = [&](int u, int kabs) {
                     const int cb = colbase[min(kabs + 4 * u + kq, j0 - 1)];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) a[u][t] = v.Lx[cb + rowA[t]];
                 };
 #pragma unroll
-                for (int u = 0; u < SNT_U; ++u) request(u, 0);
+                for (int u = 0; u < SNT_UD; ++u) request(u, 0);
                 for (int kc0 = 0; kc0 < j0; kc0 += SN_KC) {
                     const int kcn = min(SN_KC, j0 - kc0); // (a multiple of 64)
                     __syncthreads();
                     snt_stage_w<SNT_WG>(v, g, colbase, Wl, kc0, kcn, j0, nbw, tid);
                     __syncthreads();
-                    for (int kk = 0; kk < kcn; kk += 4 * SNT_U) {
-                        const int knext = kk + 4 * SNT_U < kcn ? kc0 + kk + 4 * SNT_U : kc0 + SN_KC;
+                    for (int kk = 0; kk < kcn; kk += 4 * SNT_UD) {
+                        const int knext = kk + 4 * SNT_UD < kcn ? kc0 + kk + 4 * SNT_UD : kc0 + SN_KC;
 #pragma unroll
-                        for (int u = 0; u < SNT_U; ++u) {
+                        for (int u = 0; u < SNT_UD; ++u) {
                             const double bw = Wl[(kk + 4 * u + kq) * SN_NB + 16 * q + l15];
 #pragma unroll
                             for (int t = 0; t < 4; ++t) Aq[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], bw, Aq[t], 0, 0, 0);
@@ -1700,11 +1702,11 @@ __global__ __launch_bounds__(SNB_WG) void k_snode_brows(LdlView v, SnodeView sv,
             }
         }
         if (j0 > 0) {
-            double a[SNT_U];
+            double a[SNT_UB];
             auto request = [&](int u, int kabs) { a[u] = v.Lx[colbase[min(kabs + 4 * u + kq, j0 - 1)] + rowA]; };
             if (wlive) {
 #pragma unroll
-                for (int u = 0; u < SNT_U; ++u) request(u, 0);
+                for (int u = 0; u < SNT_UB; ++u) request(u, 0);
             }
             for (int kc0 = 0; kc0 < j0; kc0 += SN_KC) {
                 const int kcn = min(SN_KC, j0 - kc0);
@@ -1712,10 +1714,10 @@ __global__ __launch_bounds__(SNB_WG) void k_snode_brows(LdlView v, SnodeView sv,
                 snt_stage_w<SNB_WG>(v, g, colbase, Wl, kc0, kcn, j0, nbw, tid);
                 __syncthreads();
                 if (!wlive) continue;
-                for (int kk = 0; kk < kcn; kk += 4 * SNT_U) {
-                    const int knext = kk + 4 * SNT_U < kcn ? kc0 + kk + 4 * SNT_U : kc0 + SN_KC;
+                for (int kk = 0; kk < kcn; kk += 4 * SNT_UB) { // (kcn is a multiple of 64 = 4 SNT_UB)
+                    const int knext = kk + 4 * SNT_UB < kcn ? kc0 + kk + 4 * SNT_UB : kc0 + SN_KC;
 #pragma unroll
-                    for (int u = 0; u < SNT_U; ++u) {
+                    for (int u = 0; u < SNT_UB; ++u) {
 #pragma unroll
                         for (int jb = 0; jb < 4; ++jb) {
                             const double bw = Wl[(kk + 4 * u + kq) * SN_NB + 16 * jb + l15];
@@ -2329,7 +2331,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
     auto pe = [&](int f) { if (lp) lp->end(lp->ctx, f); };
     // supernodes of moderate width: the triangle by one workgroup per supernode, then the rows of B -- two launches for the
     // whole level (k_snode_tfactor, k_snode_brows) instead of two per block column
-    const bool level_form = nblk * SN_NB <= SNT_WMAX && !switches().no_snode_tfactor && !dbg.on && !switches().no_snode_panel &&
+    const bool level_form = nblk * SN_NB <= SNT_WMAX && switches().snode_tfactor && !dbg.on && !switches().no_snode_panel &&
                             !switches().no_panel_mfma && !switches().no_panel_diag_mfma && !switches().no_panel_overlap &&
                             !switches().no_panel_uniform && !switches().no_emit_atomic && switches().sn_panel_slots <= 0; // (switches that select older forms of the two-launch kernels keep those kernels in use)
     if (level_form) {

@@ -1262,495 +1262,6 @@ __global__ __launch_bounds__(SNQ_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 
-// ---------------------------------------------------------------------------
-// Round 5: a unit level of supernodes of MODERATE width in two launches instead of two per 64-column block.
-// On BASELINE config 2 a supernode is 100 .. 365 columns wide with ~180 rows of B below: four to six block columns, each
-// an update launch (26 us) and a panel launch (29 us) with ~3.5 us between launches -- 129 dependent block columns per
-// refactorisation, most of them on 2 .. 16 workgroups.  What is sequential in a supernode is its TRIANGLE (the w x w
-// member part: every block column needs all earlier ones); the rows of B only ever need the finished triangle and are
-// independent of each other row by row.  So:
-//   k_snode_tfactor : ONE workgroup per supernode walks the block columns of the triangle without leaving the CU.  A
-//       block column lives in registers from its update to its final values: the 64 x 64 diagonal block as four column
-//       quarters (waves 0-3, the block team of k_snode_panel2), the rows below it inside the triangle as 64 x 64 tiles
-//       in the accumulator layout (waves 4-7) -- loaded with K's values, minus the products of the finished columns on
-//       the matrix cores (operand (d_k L[j,k]) staged in LDS, negated, so that the accumulators ARE the updated values),
-//       then the block factorisation and the rows' recurrence overlapped quarter by quarter exactly as in
-//       k_snode_panel2, and stored once.  No round trip through memory between "update" and "panel", no launch
-//       boundary, no atomics.
-//   k_snode_brows   : the rows of B, 16 per wave, all block columns in one launch: the same update + recurrence against
-//       the finished triangle (its diagonal blocks staged in LDS), every row independent -- 64 rows per workgroup, so
-//       that a level with one supernode still spreads over several CUs.
-// Per entry the operations of the reference's row solve (qdldl.rs:602-641) in its order k = 0, 1, ..., products inside
-// a matrix instruction fused; the accumulators start from the entry's value instead of zero, so results differ from
-// the two-launch form in rounding only.  Levels with a supernode wider than SNT_WMAX keep the two-launch form.
-// ---------------------------------------------------------------------------
-constexpr int SNT_WG = 512;
-constexpr int SNT_WMAX = 320; // the rows team holds four 64-row tiles: w - 64 <= 256
-constexpr int SNT_U = 4;      // k-groups of A operands in flight per lane (a wave with 16 matrix instructions per group)
-constexpr int SNT_UD = 8;     // ... of a wave with 4 matrix instructions per group (the block team: 256 cycles per group, the requests must be further ahead)
-constexpr int SNT_UB = 16;    // ... of k_snode_brows' waves (16 rows: 4 matrix instructions per group)
-
-// steps kb_from .. kb_to - 1 of the 16-blocked recurrence on a wave's tile of 16 RT rows x 64 columns in the accumulator
-// layout (acc[jb][t][r] = X[row 16 t + kq + 4 r][column 16 jb + l15]): x_c -= sum_{k < c} Ll[k * 64 + c] x_k; head block kb
-// leaves the accumulator layout through the wave's LDS slice xw, is finished in the lane = row form (lanes < 16 RT),
-// handed to store(kb, h) and applied to the blocks behind it on the matrix cores (cf. snq_rows).
-template <int RT, class Store>
-__device__ __forceinline__ void snt_recur(snode_v4d (&acc)[4][RT], const double *Ll, double *xw, int lane, int kb_from, int kb_to,
-                                          Store store) {
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int lrow = RT == 4 ? lane : min(lane, 16 * RT - 1);
-    double h[16];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        if (kb < kb_from || kb >= kb_to) continue;
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = acc[kb][t][r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < 16; ++c) h[c] = xw[lrow * SNP_XLD + c];
-        __builtin_amdgcn_wave_barrier();
-        const double *Lb = Ll + (16 * kb) * SN_NB + 16 * kb;
-#pragma unroll
-        for (int kk = 0; kk < 15; ++kk) {
-            const double uq = h[kk];
-            int zoff; // (ties the column's LDS reads to its place in the chain, see k_snode_panel)
-            asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(uq)));
-            const snode_v2d *cf = (const snode_v2d *)(Lb + kk * SN_NB + zoff);
-#pragma unroll
-            for (int p2 = (kk + 1) / 2; p2 < 8; ++p2) {
-                const snode_v2d cc = cf[p2];
-                h[2 * p2] -= cc.x * uq;
-                h[2 * p2 + 1] -= cc.y * uq;
-            }
-        }
-        store(kb, h);
-        if (kb == 3) break;
-        if (RT == 4 || lane < 16 * RT) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) xw[lane * SNP_XLD + c] = -h[c];
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            double a4[RT];
-#pragma unroll
-            for (int t = 0; t < RT; ++t) a4[t] = xw[(16 * t + l15) * SNP_XLD + 4 * s4 + kq];
-#pragma unroll
-            for (int jb = kb + 1; jb < 4; ++jb) {
-                const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * jb + l15];
-#pragma unroll
-                for (int t = 0; t < RT; ++t) acc[jb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[t], bv, acc[jb][t], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// the owner wave's quarter kb of the 64 x 64 block in the lane = row form (T[c] = entry (i, 16 kb + c), the diagonal
-// entries inside): SNQ_GS pivots at a time factored by every lane itself (see k_snode_panel2<true>); publishes the scaled
-// entries (Ll), the pivots' inverses (dinvl) and the negated unscaled panel (xw, [row][column]); T leaves scaled.
-__device__ __forceinline__ void snt_quarter(const LdlView &v, double (&T)[16], double *xw, double *Ll, double *dinvl, double *sdl,
-                                            double sgl, int i, int kb, double &dfin, double &dinvfin, int &nreg, int &bad) {
-    const int cbase = 16 * kb;
-    constexpr int GS = SNQ_GS;
-#pragma unroll
-    for (int gq = 0; gq < 16 / GS; ++gq) {
-        const int a_me = i - cbase - GS * gq;
-        if (a_me >= 0 && a_me < GS) {
-#pragma unroll
-            for (int bb = 0; bb < GS; ++bb) sdl[a_me * GS + bb] = T[GS * gq + bb];
-        }
-        __builtin_amdgcn_wave_barrier();
-        double S[GS][GS];
-#pragma unroll
-        for (int a = 0; a < GS; ++a)
-#pragma unroll
-            for (int bb = 0; bb <= a; ++bb) S[a][bb] = sdl[a * GS + bb];
-        __builtin_amdgcn_wave_barrier();
-        double ug[GS];
-#pragma unroll
-        for (int t = 0; t < GS; ++t) {
-            const int c = cbase + GS * gq + t;
-            double d = S[t][t];
-            const double sg = readlane_f64(sgl, c);
-            const bool reg = d * sg < v.reg_eps;
-            if (reg) d = v.reg_delta * sg;
-            const double dinv = 1.0 / d;
-            if (i == c) {
-                dfin = d;
-                dinvfin = dinv;
-                if (reg) nreg += 1;
-                if (d == 0.0) bad |= 2;
-                if (!isfinite(dinv)) bad |= 1;
-            }
-            double la[GS];
-#pragma unroll
-            for (int a = t + 1; a < GS; ++a) la[a] = S[a][t] * dinv;
-#pragma unroll
-            for (int a = t + 1; a < GS; ++a)
-#pragma unroll
-                for (int bb = t + 1; bb <= a; ++bb) S[a][bb] -= la[bb] * S[a][t];
-            const double uc = i > c ? T[GS * gq + t] : 0.0;
-            const double l = uc * dinv;
-            ug[t] = uc;
-            T[GS * gq + t] = l;
-            xw[i * SNP_XLD + GS * gq + t] = -uc;
-            Ll[c * SN_NB + i] = l;
-            if (i == 0) dinvl[c] = dinv;
-#pragma unroll
-            for (int t2 = t + 1; t2 < GS; ++t2) T[GS * gq + t2] -= la[t2] * uc;
-        }
-        constexpr int NX_MAX = 16 - GS;
-        const int nx = 16 - GS * (gq + 1);
-        if (nx > 0) {
-            const int b_me = i - cbase - GS * (gq + 1);
-            if (b_me >= 0 && b_me < nx) {
-#pragma unroll
-                for (int t = 0; t < GS; ++t) sdl[64 + t * 16 + b_me] = T[GS * gq + t];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int t = 0; t < GS; ++t) {
-                int zoff;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(zoff) : "v"(__double2hiint(T[GS * (gq + 1)])));
-                const snode_v2d *cf = (const snode_v2d *)(sdl + 64 + t * 16 + zoff);
-#pragma unroll
-                for (int p2 = 0; p2 < NX_MAX / 2; ++p2) {
-                    if (2 * p2 >= nx) continue;
-                    const snode_v2d cc = cf[p2];
-                    T[GS * (gq + 1) + 2 * p2] -= cc.x * ug[t];
-                    T[GS * (gq + 1) + 2 * p2 + 1] -= cc.y * ug[t];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-// Wl[kk * 64 + jj] = -(d_k L[jrow0 + jj, k]) for the kcn columns k = kc0 + kk (kcn a multiple of 16), jj < ncols, zero beyond:
-// a wave stages whole k rows, lane = column of the block (cf. snode_tiles); all NT threads of the workgroup
-template <int NT>
-__device__ __forceinline__ void snt_stage_w(const LdlView &v, const SnodeGeom &g, const int *colbase, double *Wl, int kc0, int kcn,
-                                            int jrow0, int ncols, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = NT / 64;
-    for (int kr = wave; kr < kcn; kr += 4 * NW) {
-        double wv[4], dv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kk = min(kr + r * NW, kcn - 1); // (clamped: no branch per load)
-            wv[r] = v.Lx[colbase[kc0 + kk] + jrow0 + min(lane, ncols - 1)];
-            dv[r] = g.d[kc0 + kk];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kk = kr + r * NW;
-            if (kk < kcn) Wl[kk * SN_NB + lane] = lane < ncols ? -(wv[r] * dv[r]) : 0.0;
-        }
-    }
-}
-
-__global__ __launch_bounds__(SNT_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snode_tfactor(LdlView v, SnodeView sv, const int *__restrict__ order) {
-    extern __shared__ __attribute__((aligned(16))) char tsm[];
-    double *Wl = (double *)tsm;        // update phase: SN_KC x 64 (64 KiB)
-    double *Ll = (double *)tsm;        // panel phase (the same bytes): Ll[k * 64 + i] = l(i, k), 0 for i <= k
-    double *xhb = Ll + SN_NB * SN_NB;  // ... and eight head blocks, [row][column], stride SNP_XLD
-    __shared__ double dinvl[SN_NB];
-    __shared__ __attribute__((aligned(16))) double sdl[64 + 16 * SNQ_GS];
-    __shared__ int colbase[SNT_WMAX];
-    __shared__ int s_nreg, s_bad;
-    int sn;
-    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.x, sn);
-    const int tid = threadIdx.x, i = tid & 63, wave = tid >> 6, l15 = i & 15, kq = i >> 4;
-    const bool teamD = wave < 4;
-    const int q = wave & 3;
-    const int nblk = (g.w + SN_NB - 1) / SN_NB;
-    for (int t = tid; t < g.w; t += SNT_WG) colbase[t] = g.cb[t];
-    if (tid == 0) {
-        s_nreg = 0;
-        s_bad = 0;
-    }
-    int nreg = 0, bad = 0;
-    double *xw = xhb + wave * (64 * SNP_XLD);
-    __syncthreads();
-    // (the two teams run their own loops over the block columns -- wave-uniform branches executing the same barriers --, so
-    // that the register allocator never sees one team's tiles live in the other team's code)
-    if (teamD) {
-#pragma unroll 1
-        for (int b = 0; b < nblk; ++b) {
-            const int j0 = b * SN_NB, nbw = min(SN_NB, g.w - j0);
-            // ================= block team: column quarter q of the 64 x 64 diagonal block, all 64 rows =================
-            const bool live = i < nbw;
-            const int ci = live ? g.cols[j0 + i] : 0;
-            const double sgl = i < nbw ? (double)g.sg[j0 + i] : 1.0; // (rows beyond a narrow last block: an identity)
-            snode_v4d Aq[4];
-            {
-                const int j = 16 * q + l15; // this lane's column
-                const bool jok = j < nbw;
-                const double djj = jok ? v.D[g.cols[j0 + min(j, nbw - 1)]] : 1.0;
-                // unconditional loads from a VALID entry, selected afterwards (the predicated form compiles to a branch per
-                // load): column jc of the block has the in-block rows jc + 1 .. nbw - 1 -- none for the block's last column,
-                // whose lanes read the always-present entry (1, 0) of the supernode instead (w >= 16)
-                const int jc = min(j, nbw - 1);
-                const bool inblk = jc < nbw - 1;
-                const int cbs = inblk ? colbase[j0 + jc] + j0 : colbase[0] + 1;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * t + kq + 4 * r;
-                        const double ld = v.Lx[cbs + (inblk ? min(max(row, jc + 1), nbw - 1) : 0)];
-                        double val = (jok && row < nbw && row > j) ? ld : 0.0;
-                        if (row == j) val = djj;
-                        Aq[t][r] = val;
-                    }
-            }
-            if (j0 > 0) {
-                int rowA[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) rowA[t] = min(j0 + 16 * t + l15, g.w - 1);
-                double a[SNT_UD][4];
-                auto request = [&](int u, int kabs) {
-                    const int cb = colbase[min(kabs + 4 * u + kq, j0 - 1)];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) a[u][t] = v.Lx[cb + rowA[t]];
-                };
-#pragma unroll
-                for (int u = 0; u < SNT_UD; ++u) request(u, 0);
-                for (int kc0 = 0; kc0 < j0; kc0 += SN_KC) {
-                    const int kcn = min(SN_KC, j0 - kc0); // (a multiple of 64)
-                    __syncthreads();
-                    snt_stage_w<SNT_WG>(v, g, colbase, Wl, kc0, kcn, j0, nbw, tid);
-                    __syncthreads();
-                    for (int kk = 0; kk < kcn; kk += 4 * SNT_UD) {
-                        const int knext = kk + 4 * SNT_UD < kcn ? kc0 + kk + 4 * SNT_UD : kc0 + SN_KC;
-#pragma unroll
-                        for (int u = 0; u < SNT_UD; ++u) {
-                            const double bw = Wl[(kk + 4 * u + kq) * SN_NB + 16 * q + l15];
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) Aq[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], bw, Aq[t], 0, 0, 0);
-                            request(u, knext);
-                        }
-                    }
-                }
-            }
-            __syncthreads(); // (the staged operand has been consumed: its bytes become Ll and the head blocks)
-            double T[16];
-            double dfin = 1.0, dinvfin = 1.0;
-#pragma unroll 1
-            for (int kb = 0; kb < SN_NB / 16; ++kb) {
-                if (q == kb) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) xw[(16 * t + kq + 4 * r) * SNP_XLD + l15] = Aq[t][r];
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) T[c] = xw[i * SNP_XLD + c];
-                    __builtin_amdgcn_wave_barrier();
-                    snt_quarter(v, T, xw, Ll, dinvl, sdl, sgl, i, kb, dfin, dinvfin, nreg, bad);
-                }
-                __syncthreads(); // quarter kb of Ll, its pivots and the owner's negated panel are published
-                if (q > kb) {
-                    const double *xo = xhb + kb * (64 * SNP_XLD);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const double bv = Ll[(16 * kb + 4 * s4 + kq) * SN_NB + 16 * q + l15];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const double av = xo[(16 * t + l15) * SNP_XLD + 4 * s4 + kq];
-                            Aq[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Aq[t], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            // the factored block and its pivots: wave q holds columns 16 q .. of row i, scaled, and the pivot of row i if i / 16 == q
-            if (q == i / 16 && live) {
-                v.D[ci] = dfin;
-                v.Dinv[ci] = dinvfin;
-                g.d[j0 + i] = dfin;
-            }
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) {
-                const int j = 16 * q + cc;
-                if (live && j < nbw && i > j) v.Lx[colbase[j0 + j] + j0 + i] = T[cc];
-            }
-            __syncthreads(); // this block column is final and visible to the whole workgroup; Ll / the head blocks are free
-        }
-    } else {
-#pragma unroll 1
-        for (int b = 0; b < nblk; ++b) {
-            const int j0 = b * SN_NB, nbw = min(SN_NB, g.w - j0);
-            // ================= rows team: the 64 rows R0 .. of the triangle below the block, all 64 columns =================
-            const int R0 = j0 + SN_NB + 64 * q;
-            const bool rlive = R0 < g.w;
-            snode_v4d acc[4][4];
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                const int jj = 16 * jb + l15;
-                const int cb = colbase[j0 + min(jj, nbw - 1)];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = R0 + 16 * t + kq + 4 * r;
-                        // (unconditional: a live wave's rows lie below every column of the block; a dead wave reads entry (1, 0))
-                        const double ld = v.Lx[rlive ? cb + min(row, g.w - 1) : colbase[0] + 1];
-                        acc[jb][t][r] = (rlive && jj < nbw && row < g.w) ? ld : 0.0;
-                    }
-            }
-            if (j0 > 0) {
-                int rowA[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) rowA[t] = min(R0 + 16 * t + l15, g.w - 1);
-                double a[SNT_U][4];
-                auto request = [&](int u, int kabs) {
-                    const int cb = colbase[min(kabs + 4 * u + kq, j0 - 1)];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) a[u][t] = v.Lx[cb + rowA[t]];
-                };
-                if (rlive) {
-#pragma unroll
-                    for (int u = 0; u < SNT_U; ++u) request(u, 0);
-                }
-                for (int kc0 = 0; kc0 < j0; kc0 += SN_KC) {
-                    const int kcn = min(SN_KC, j0 - kc0);
-                    __syncthreads();
-                    snt_stage_w<SNT_WG>(v, g, colbase, Wl, kc0, kcn, j0, nbw, tid);
-                    __syncthreads();
-                    if (!rlive) continue;
-                    for (int kk = 0; kk < kcn; kk += 4 * SNT_U) {
-                        const int knext = kk + 4 * SNT_U < kcn ? kc0 + kk + 4 * SNT_U : kc0 + SN_KC;
-#pragma unroll
-                        for (int u = 0; u < SNT_U; ++u) {
-#pragma unroll
-                            for (int jb = 0; jb < 4; ++jb) {
-                                const double bw = Wl[(kk + 4 * u + kq) * SN_NB + 16 * jb + l15];
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) acc[jb][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], bw, acc[jb][t], 0, 0, 0);
-                            }
-                            request(u, knext);
-                        }
-                    }
-                }
-            }
-            __syncthreads(); // (matches the block team's barrier after the update)
-            const int R = R0 + i;
-#pragma unroll 1
-            for (int kb = 0; kb < SN_NB / 16; ++kb) {
-                __syncthreads(); // (the block team's barrier of quarter kb)
-                if (rlive)
-                    snt_recur<4>(acc, Ll, xw, i, kb, kb + 1, [&](int kq4, const double(&hh)[16]) {
-                        if (R >= g.w) return;
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) {
-                            const int jj = 16 * kq4 + c;
-                            if (jj < nbw) v.Lx[colbase[j0 + jj] + R] = hh[c] * dinvl[jj];
-                        }
-                    });
-            }
-            __syncthreads(); // (the block team's barrier at the end of the block column)
-        }
-    }
-    if (nreg) atomicAdd(&s_nreg, nreg);
-    if (bad) atomicOr(&s_bad, bad);
-    __syncthreads();
-    if (tid == 0) {
-        if (s_nreg) atomicAdd(&v.status[2], s_nreg);
-        if (s_bad & 2) v.status[1] = 1;
-        if (s_bad & 1) v.status[0] = 1;
-    }
-}
-
-// the rows of B against the finished triangle: grid (groups of 64 rows of B, supernodes of the level); a wave owns 16 rows
-constexpr int SNB_WG = 256;
-constexpr int SNB_WMAX = 512; // (column bases in LDS)
-__global__ __launch_bounds__(SNB_WG) void k_snode_brows(LdlView v, SnodeView sv, const int *__restrict__ order) {
-    extern __shared__ __attribute__((aligned(16))) char bsm2[];
-    double *Wl = (double *)bsm2;        // update: SN_KC x 64
-    double *Ll = (double *)bsm2;        // recurrence (the same bytes)
-    double *xhb = Ll + SN_NB * SN_NB;   // four head blocks of 16 rows
-    __shared__ double dinvl[SN_NB];
-    __shared__ int colbase[SNB_WMAX];
-    int sn;
-    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
-    const int Rg = g.w + 64 * (int)blockIdx.x;
-    if (Rg >= g.h) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    const int nblk = (g.w + SN_NB - 1) / SN_NB;
-    for (int t = tid; t < g.w; t += SNB_WG) colbase[t] = g.cb[t];
-    const int R0w = Rg + 16 * wave;
-    const bool wlive = R0w < g.h;
-    const int rowA = min(R0w + l15, g.h - 1);
-    double *xw = xhb + wave * (16 * SNP_XLD);
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < nblk; ++c) {
-        const int j0 = c * SN_NB, nbw = min(SN_NB, g.w - j0);
-        snode_v4d acc[4][1];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            const int jj = 16 * jb + l15;
-            const int cb = colbase[j0 + min(jj, nbw - 1)];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = R0w + kq + 4 * r;
-                const double ld = v.Lx[wlive ? cb + min(row, g.h - 1) : colbase[0] + 1]; // (unconditional, see k_snode_tfactor)
-                acc[jb][0][r] = (wlive && jj < nbw && row < g.h) ? ld : 0.0;
-            }
-        }
-        if (j0 > 0) {
-            double a[SNT_UB];
-            auto request = [&](int u, int kabs) { a[u] = v.Lx[colbase[min(kabs + 4 * u + kq, j0 - 1)] + rowA]; };
-            if (wlive) {
-#pragma unroll
-                for (int u = 0; u < SNT_UB; ++u) request(u, 0);
-            }
-            for (int kc0 = 0; kc0 < j0; kc0 += SN_KC) {
-                const int kcn = min(SN_KC, j0 - kc0);
-                __syncthreads();
-                snt_stage_w<SNB_WG>(v, g, colbase, Wl, kc0, kcn, j0, nbw, tid);
-                __syncthreads();
-                if (!wlive) continue;
-                for (int kk = 0; kk < kcn; kk += 4 * SNT_UB) { // (kcn is a multiple of 64 = 4 SNT_UB)
-                    const int knext = kk + 4 * SNT_UB < kcn ? kc0 + kk + 4 * SNT_UB : kc0 + SN_KC;
-#pragma unroll
-                    for (int u = 0; u < SNT_UB; ++u) {
-#pragma unroll
-                        for (int jb = 0; jb < 4; ++jb) {
-                            const double bw = Wl[(kk + 4 * u + kq) * SN_NB + 16 * jb + l15];
-                            acc[jb][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bw, acc[jb][0], 0, 0, 0);
-                        }
-                        request(u, knext);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // the block's scaled strict lower triangle (lanes along the rows of a column: contiguous) and the pivots' inverses
-        for (int idx = tid; idx < SN_NB * SN_NB; idx += SNB_WG) {
-            const int k = idx >> 6, ii = idx & 63;
-            Ll[idx] = (ii > k && ii < nbw) ? v.Lx[colbase[j0 + k] + j0 + ii] : 0.0;
-        }
-        if (tid < SN_NB) dinvl[tid] = tid < nbw ? v.Dinv[g.cols[j0 + tid]] : 1.0;
-        __syncthreads();
-        if (wlive) {
-            const int R = R0w + lane;
-            snt_recur<1>(acc, Ll, xw, lane, 0, 4, [&](int kb, const double(&hh)[16]) {
-                if (lane >= 16 || R >= g.h) return;
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) {
-                    const int jj = 16 * kb + cc;
-                    if (jj < nbw) v.Lx[colbase[j0 + jj] + R] = hh[cc] * dinvl[jj];
-                }
-            });
-        }
-        __syncthreads(); // (the next block column stages its operand over Ll; this one's entries are visible to the workgroup)
-    }
-}
-
 // Substitutions through a chain supernode, one workgroup per supernode of the unit level, the
 // members' slice of x (and the nb entries of the rows of B) in LDS, block columns of SN_NB:
 //   forward  (qdldl.rs:708-719): x_S <- (I + L_SS)^-1 x_S block by block -- the 64 unknowns of a block
@@ -2162,12 +1673,6 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
 
 } // namespace
 
-static size_t snt_tfactor_lds() {
-    return std::max((size_t)SN_KC * SN_NB, (size_t)(SN_NB * SN_NB + (SNT_WG / 64) * 64 * SNP_XLD)) * sizeof(double);
-}
-static size_t snt_brows_lds() {
-    return std::max((size_t)SN_KC * SN_NB, (size_t)(SN_NB * SN_NB + (SNB_WG / 64) * 16 * SNP_XLD)) * sizeof(double);
-}
 static size_t snode_solve_lds_bytes(int wmax, int nbcap) {
     return (size_t)(wmax + nbcap + SN_NB * SN_NB + SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int);
 }
@@ -2179,8 +1684,6 @@ int snode_kernel_attributes(int wmax, int nbmax) {
     const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<true>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<false>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
-    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_tfactor, snt_tfactor_lds());
-    if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_brows, snt_brows_lds());
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_fwd, (size_t)lds2);
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_bwd, (size_t)lds2);
     return rc;
@@ -2329,22 +1832,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
     const size_t lds = snode_lds_bytes(wmax_all);
     auto pb = [&](int f) { if (lp) lp->begin(lp->ctx, f); };
     auto pe = [&](int f) { if (lp) lp->end(lp->ctx, f); };
-    // supernodes of moderate width: the triangle by one workgroup per supernode, then the rows of B -- two launches for the
-    // whole level (k_snode_tfactor, k_snode_brows) instead of two per block column
-    const bool level_form = nblk * SN_NB <= SNT_WMAX && switches().snode_tfactor && !dbg.on && !switches().no_snode_panel &&
-                            !switches().no_panel_mfma && !switches().no_panel_diag_mfma && !switches().no_panel_overlap &&
-                            !switches().no_panel_uniform && !switches().no_emit_atomic && switches().sn_panel_slots <= 0; // (switches that select older forms of the two-launch kernels keep those kernels in use)
-    if (level_form) {
-        pb(PFK_SN_DIAG);
-        k_snode_tfactor<<<count, SNT_WG, snt_tfactor_lds(), s>>>(v, sv, order);
-        pe(PFK_SN_DIAG);
-        if (nbmax > 0) {
-            pb(PFK_SN_UPDATE);
-            k_snode_brows<<<dim3((nbmax + 63) / 64, count), SNB_WG, snt_brows_lds(), s>>>(v, sv, order);
-            pe(PFK_SN_UPDATE);
-        }
-    }
-    for (int b = 0; b < (level_form ? 0 : nblk); ++b) {
+    for (int b = 0; b < nblk; ++b) {
         if (b > 0) {
             const int rows = hmax - b * SN_NB;
             if (rows > 0) {

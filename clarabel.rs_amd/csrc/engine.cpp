@@ -1076,27 +1076,44 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         tri.epoch = ++sn_epoch;
         const dev::LaunchProf lprof = launch_prof();
         const dev::LaunchProf *lp = prof_family >= PF_SN_UPDATE ? &lprof : nullptr;
+        // levels on the one-pass matrices take the NEXT level's row gathers (forward) / their own ordinary columns (backward)
+        // into the supernodes' launch (snode_g.hip: SweepGather); CHIP_NO_SWEEP_MERGE keeps the two launches per level
+        const bool merge = sn_g_ntasks > 0 && !switches().no_sweep_merge;
+        auto is_g = [&](int l) { return sn_g_ntasks > 0 && sn_lvl_g[l] && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
+        bool gathered = false; // level l's gathers already ran inside the previous level's launch
         for (int l = 0; l < nfaclevels; l++) {
-            prof_begin(PF_SN_GATHER);
-            dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
-            prof_end(PF_SN_GATHER);
-            if (sn_g_ntasks > 0 && sn_lvl_g[l]) // one pass over G, no hops (x_S(new) -> sn_yt, the rows of B subtracted in place)
+            if (!gathered) {
+                prof_begin(PF_SN_GATHER);
+                dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
+                prof_end(PF_SN_GATHER);
+            }
+            gathered = false;
+            if (is_g(l)) { // one pass over G, no hops (x_S(new) -> sn_yt, the rows of B subtracted in place)
+                const bool ride = merge && l + 1 < nfaclevels;
                 dev::solve_snodes_g(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                                    sn_lvl_wmax[l], sn_lvl_hmax[l], xp, sn_yt, lp);
-            else
-            dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
+                                    sn_lvl_wmax[l], sn_lvl_hmax[l], xp, sn_yt, lp, ride ? &f : nullptr,
+                                    ride ? fwu.T(l + 1) : dev::ListView{nullptr, 0}, ride ? fwu.W(l + 1) : dev::ListView{nullptr, 0},
+                                    ride ? fwu.B(l + 1) : dev::ChunkView{nullptr, nullptr, nullptr, 0});
+                gathered = ride;
+            } else {
+                dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                                  sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
+            }
         }
         tri.epoch = ++sn_epoch;
         dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
         for (int l = nfaclevels - 1; l >= 0; l--) {
-            if (sn_g_ntasks > 0 && sn_lvl_g[l])
-                dev::solve_snodes_g(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                                    sn_lvl_wmax[l], sn_lvl_hmax[l], xp, sn_yt, lp);
-            else
-            dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
-                              sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
             const dev::ChunkView b = bwu.B(l);
+            if (is_g(l)) {
+                const bool ride = merge && b.count == 0; // (chunked columns need their preparation pass first)
+                dev::solve_snodes_g(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                                    sn_lvl_wmax[l], sn_lvl_hmax[l], xp, sn_yt, lp, ride ? &g : nullptr,
+                                    ride ? bwu.T(l) : dev::ListView{nullptr, 0}, ride ? bwu.W(l) : dev::ListView{nullptr, 0});
+                if (ride) continue;
+            } else {
+                dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                                  sn_wmax, sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xp, use_tri ? &tri : nullptr, lp);
+            }
             if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwu.BR(l));
             prof_begin(PF_SN_GATHER);
             dev::gather_merged(stream, dev::BWD, g, bwu.T(l), bwu.W(l), b);

@@ -350,8 +350,11 @@ int snode_g_attributes(int hmax);   // once per handle (dynamic LDS of the kerne
 void snode_ginv(hipStream_t s, const LdlView &v, const SnodeView &sv, const int *order_all, const int *tasks, int ntasks);
 // one unit level's supernodes, forward (x_S(new) -> yt, x_B -= M x_S) or backward (x_S <- G' [D^-1 yt_S; -x_B]);
 // wlvl / hlvl: the level's largest width / height
+// ga != nullptr: the launch also takes the row gathers (t, w, c) of ga -- forward: those of the NEXT unit level (every final
+// store an atomic subtraction), backward: the ordinary columns of THIS level (c must be empty) -- see snode_g.hip: SweepGather
 void solve_snodes_g(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count, int wlvl,
-                    int hlvl, double *x, double *yt, const LaunchProf *lp = nullptr);
+                    int hlvl, double *x, double *yt, const LaunchProf *lp = nullptr, const GatherArgs *ga = nullptr,
+                    ListView t = ListView{nullptr, 0}, ListView w = ListView{nullptr, 0}, ChunkView c = ChunkView{nullptr, nullptr, nullptr, 0});
 // diagnostics / tests: a kernel of `blocks` x `threads` that only spins for `usec` microseconds on stream s
 // (co-residency tests of the persistent launches)
 void debug_spin(hipStream_t s, int blocks, int threads, int lds_bytes, double usec);

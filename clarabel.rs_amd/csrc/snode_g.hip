@@ -215,17 +215,101 @@ __global__ __launch_bounds__(SG_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
 }
 
+// ---- the sparse rows / columns of a unit level inside the same launch (round 5) -------------------------------------
+// A sweep used to alternate two launches per unit level: the row gathers over the columns that are NOT supernode members
+// (k_gather_merged over the filtered lists) and the supernodes' kernel.  Forward, the gathers of level l + 1 need nothing
+// the supernodes of level l write (those push into ancestors; the gathers read bundle columns and ordinary top columns
+// of levels <= l, final since the previous launch) and both only SUBTRACT from rows of later levels: with the gathers'
+// final store an atomic as well, the two run side by side in one launch.  Backward, the ordinary columns of level l and
+// the supernodes of level l both depend on higher levels only.  The extra blocks of the grid: first the chunks of long
+// rows (forward only; one atomic per chunk), then the wave-per-row list (16 rows per block), then the thread-per-row list.
+struct SweepGather {
+    GatherArgs a;
+    const int *trows, *wrows, *crow, *cbeg, *cend;
+    int tcount, wcount, ccount;
+};
+constexpr int SGS_WG_ = 1024;
+__host__ __device__ inline int sweep_gather_blocks(int tcount, int wcount, int ccount) {
+    return ccount + (wcount + 15) / 16 + (tcount + SGS_WG_ - 1) / SGS_WG_;
+}
+template <int MODE>
+__device__ __forceinline__ void sg_gather_block(const SweepGather &q, int gb, double *red) {
+    const GatherArgs &a = q.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nW = (q.wcount + 15) / 16;
+    if (gb < q.ccount) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const int ce = q.cend[gb];
+        int t = q.cbeg[gb] + tid;
+        for (; t + 3 * SGS_WG_ < ce; t += 4 * SGS_WG_) {
+            const int i0 = a.idx[t], i1 = a.idx[t + SGS_WG_], i2 = a.idx[t + 2 * SGS_WG_], i3 = a.idx[t + 3 * SGS_WG_];
+            const double v0 = a.val[t], v1 = a.val[t + SGS_WG_], v2 = a.val[t + 2 * SGS_WG_], v3 = a.val[t + 3 * SGS_WG_];
+            s0 += v0 * a.xin[i0];
+            s1 += v1 * a.xin[i1];
+            s2 += v2 * a.xin[i2];
+            s3 += v3 * a.xin[i3];
+        }
+        for (; t < ce; t += SGS_WG_) s0 += a.val[t] * a.xin[a.idx[t]];
+        const double ws = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) red[wave] = ws;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < SGS_WG_ / 64; ++w) tot += red[w];
+            atomicAdd(&a.out[q.crow[gb]], -tot);
+        }
+        return;
+    }
+    if (gb < q.ccount + nW) {
+        const int wid = (gb - q.ccount) * 16 + wave;
+        if (wid >= q.wcount) return;
+        const int r = q.wrows[wid];
+        const int b = a.ptr[r], e = a.ptr[r + 1];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int t = b + lane;
+        for (; t + 192 < e; t += 256) {
+            const int i0 = a.idx[t], i1 = a.idx[t + 64], i2 = a.idx[t + 128], i3 = a.idx[t + 192];
+            const double v0 = a.val[t], v1 = a.val[t + 64], v2 = a.val[t + 128], v3 = a.val[t + 192];
+            s0 += v0 * a.xin[i0];
+            s1 += v1 * a.xin[i1];
+            s2 += v2 * a.xin[i2];
+            s3 += v3 * a.xin[i3];
+        }
+        for (; t < e; t += 64) s0 += a.val[t] * a.xin[a.idx[t]];
+        const double sm = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) {
+            if (MODE == FWD) atomicAdd(&a.out[r], -sm);
+            else a.out[r] = a.out[r] * a.aux[r] - sm;
+        }
+        return;
+    }
+    const int k = (gb - q.ccount - nW) * SGS_WG_ + tid;
+    if (k >= q.tcount) return;
+    const int r = q.trows[k];
+    const int b = a.ptr[r], e = a.ptr[r + 1];
+    double sm = 0.0;
+    for (int t = b; t < e; ++t) sm += a.val[t] * a.xin[a.idx[t]];
+    if (MODE == FWD) atomicAdd(&a.out[r], -sm);
+    else a.out[r] = a.out[r] * a.aux[r] - sm;
+}
+
 // forward: grid (64-row blocks of G, supernodes of the unit level), sixteen waves.  Lane = row; wave q takes the columns
 // q, q + 16, ...: their entries are REQUESTED FIRST -- they depend on nothing but the record -- and x_S is staged while
 // they are in flight (a launch is a handful of dependent memory round trips, not bandwidth); the sixteen partial sums
 // meet in LDS.  Member rows go to yt (the other workgroups of the supernode still read x_S(old) from x), the rows of B
 // leave as one atomic per (row, supernode).
-constexpr int SGS_WG = 1024;
+constexpr int SGS_WG = SGS_WG_;
 constexpr int SGS_NW = SGS_WG / 64;
 __global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
-                                                       double *yt) {
+                                                       double *yt, int count, SweepGather sg) {
     __shared__ double xs[SG_WMAX];
     __shared__ double part[SGS_NW][64];
+    if ((int)blockIdx.y >= count) { // the next level's row gathers ride along (see SweepGather)
+        const int gb = ((int)blockIdx.y - count) * (int)gridDim.x + (int)blockIdx.x;
+        if (gb < sweep_gather_blocks(sg.tcount, sg.wcount, sg.ccount)) sg_gather_block<FWD>(sg, gb, &part[0][0]);
+        return;
+    }
     int sn;
     const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int r0 = 64 * (int)blockIdx.x;
@@ -275,9 +359,14 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, 
 // 4 x 4 x 64 entries are requested first, s = [D^-1 y_S ; -x_B] (from the block's first row on) is staged in LDS while
 // they are in flight; rows along the lanes, fixed order of summation, no atomics.
 __global__ __launch_bounds__(SGS_WG) void k_snode_gbwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
-                                                       const double *yt) {
+                                                       const double *yt, int count, SweepGather sg) {
     extern __shared__ __attribute__((aligned(16))) char bsm[];
     double *ss = (double *)bsm;
+    if ((int)blockIdx.y >= count) { // this level's ordinary columns ride along (see SweepGather)
+        const int gb = ((int)blockIdx.y - count) * (int)gridDim.x + (int)blockIdx.x;
+        if (gb < sweep_gather_blocks(sg.tcount, sg.wcount, sg.ccount)) sg_gather_block<BWD>(sg, gb, ss);
+        return;
+    }
     int sn;
     const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int j0 = 64 * (int)blockIdx.x;
@@ -355,11 +444,27 @@ void snode_ginv(hipStream_t s, const LdlView &v, const SnodeView &sv, const int 
     k_snode_ginv<<<ntasks, SG_WG, ginv_lds_bytes(), s>>>(v, sv, order_all, tasks);
 }
 void solve_snodes_g(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count, int wlvl,
-                    int hlvl, double *x, double *yt, const LaunchProf *lp) {
+                    int hlvl, double *x, double *yt, const LaunchProf *lp, const GatherArgs *ga, ListView t, ListView w, ChunkView c) {
     if (!count) return;
+    SweepGather sg{};
+    int extra = 0;
+    if (ga) {
+        sg.a = *ga;
+        sg.trows = t.idx;
+        sg.tcount = t.count;
+        sg.wrows = w.idx;
+        sg.wcount = w.count;
+        sg.crow = c.row;
+        sg.cbeg = c.beg;
+        sg.cend = c.end;
+        sg.ccount = c.count;
+        extra = sweep_gather_blocks(t.count, w.count, c.count);
+    }
     if (lp) lp->begin(lp->ctx, PFK_SN_TRI);
-    if (m == FWD) k_snode_gfwd<<<dim3((hlvl + 63) / 64, count), SGS_WG, 0, s>>>(v, sv, order, x, yt);
-    else k_snode_gbwd<<<dim3((wlvl + 63) / 64, count), SGS_WG, (size_t)hlvl * sizeof(double), s>>>(v, sv, order, x, yt);
+    const int gx = m == FWD ? (hlvl + 63) / 64 : (wlvl + 63) / 64;
+    const dim3 grid(gx, count + (extra + gx - 1) / gx);
+    if (m == FWD) k_snode_gfwd<<<grid, SGS_WG, 0, s>>>(v, sv, order, x, yt, count, sg);
+    else k_snode_gbwd<<<grid, SGS_WG, std::max((size_t)hlvl, (size_t)16) * sizeof(double), s>>>(v, sv, order, x, yt, count, sg);
     if (lp) lp->end(lp->ctx, PFK_SN_TRI);
 }
 

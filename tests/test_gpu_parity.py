@@ -1765,6 +1765,10 @@ def test_supernode_substitution_matrices(hip, oracle, which, monkeypatch):
         assert k.solve(x, z)
         sols.append(np.concatenate([x, z]))
     assert relerr(sols[1], sols[0]) <= 1e-9
+    # the row gathers over non-member columns in their own launches instead of inside the supernodes' launches
+    monkeypatch.setenv("CHIP_NO_SWEEP_MERGE", "1")
+    _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=2)
+    monkeypatch.delenv("CHIP_NO_SWEEP_MERGE")
     # without refinement the two forms still agree to the accuracy of one LDL' solve
     st = hip.Settings.default(iterative_refinement_enable=0)
     _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1, settings=st, tol=1e-5 if "late" in which else 1e-6)

@@ -242,12 +242,8 @@ __device__ __forceinline__ int *snode_lds(char *smem, double *&Wl) {
 // grid (row groups, supernodes of the level, k splits): with few workgroups in flight (the narrow
 // levels near the root) the finished columns are divided among gridDim.z workgroups per tile group,
 // which then meet in fp64 atomics
-// emit_atomic: every element leaves as ONE fp64 atomic add of the negated product sum instead of a read-modify-write -- the
-// same rounded result (cur + (-val)), but the tile does not wait for a second round trip of loads after the matrix
-// instructions (round 3's stamps: the emit phase took 10 of the launch's 22 us on config 2); a launch without k-split
-// still has exactly one contribution per element, so the result does not depend on the order of arrival.
 __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_snode_update(LdlView v, SnodeView sv, const int *__restrict__ order,
-                                                        int b, int emit_atomic) {
+                                                        int b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
     int *colbase = snode_lds(smem, Wl);
@@ -262,7 +258,7 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const int c0 = (int)(((long long)nunits * blockIdx.z) / ns), c1 = (int)(((long long)nunits * (blockIdx.z + 1)) / ns);
     if (c0 >= c1) return;
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
-    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), c1 * SN_NB, row_begin, c0 * SN_NB, ns > 1 || emit_atomic);
+    snode_tiles<false>(v, sv, g, sn, colbase, Wl, j0, min(SN_NB, g.w - j0), c1 * SN_NB, row_begin, c0 * SN_NB, ns > 1);
 }
 // grid (row groups, column blocks of B, supernodes of the level) -- or, xcd != 0, ONE dimension that is decoded so that
 // the tiles of a supernode share an XCD: workgroups go to the eight XCDs round-robin by their linear id, every XCD has
@@ -1846,7 +1842,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
                 while (!no_splitk && ksplit < split_max && ksplit * 2 * split_unit <= b && groups * count * ksplit < split_target) ksplit *= 2;
                 pb(PFK_SN_UPDATE);
                 if (dbg.mode == 2) sv.dbg = dbg.ring_slot(1) - 16 + 16; // (slots 16..20 of the launch's 32)
-                k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b, switches().no_emit_atomic ? 0 : 1);
+                k_snode_update<<<dim3(groups, count, ksplit), SN_WG, lds, s>>>(v, sv, order, b);
                 pe(PFK_SN_UPDATE);
                 if (dbg.on && dbg.mode != 2) dbg.collect(s, 1);
             }

@@ -59,7 +59,6 @@ const Entry TABLE[] = {
     {"CHIP_SN_XB_CAP", Entry::INT, SW(sn_xb_cap), 0},
     {"CHIP_SN_DEBUG", Entry::INT, SW(sn_debug), 0},
     {"CHIP_NO_SPLITK", Entry::FLAG, SW(no_splitk), 0},
-    {"CHIP_NO_EMIT_ATOMIC", Entry::FLAG, SW(no_emit_atomic), 0},
     {"CHIP_SN_SPLIT_TARGET", Entry::INT, SW(sn_split_target), 0},
     {"CHIP_SN_SPLIT_MAX", Entry::INT, SW(sn_split_max), 0},
     {"CHIP_SN_SPLIT_UNIT", Entry::INT, SW(sn_split_unit), 0},

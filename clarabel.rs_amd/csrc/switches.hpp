@@ -57,7 +57,6 @@ struct Switches {
     int sn_xb_cap = 0;              // CHIP_SN_XB_CAP (0: default)
     int sn_debug = 0;               // CHIP_SN_DEBUG
     bool no_splitk = false;         // CHIP_NO_SPLITK
-    bool no_emit_atomic = false;    // CHIP_NO_EMIT_ATOMIC: the update tiles of a launch without k-split leave by read-modify-write (round 4), not as one atomic per element
     int sn_split_target = 256, sn_split_max = 8, sn_split_unit = 1; // CHIP_SN_SPLIT_TARGET / _MAX / _UNIT
     bool no_snode_panel = false;    // CHIP_NO_SNODE_PANEL: separate diag / rows launches
     int sn_panel_slots = 0;         // CHIP_SN_PANEL_SLOTS: workgroups of one k_snode_panel launch beyond which a workgroup walks several

@@ -1604,7 +1604,7 @@ def test_chain_supernodes_factor_parity(hip, oracle, which, monkeypatch):
 
 
 @pytest.mark.parametrize("form", ["CHIP_NO_SNODE_PANEL", "CHIP_NO_PANEL_MFMA", "CHIP_NO_PANEL_DIAG_MFMA", "CHIP_SN_PANEL_SLOTS",
-                                  "CHIP_NO_PANEL_OVERLAP", "CHIP_NO_PANEL_OVERLAP+CHIP_SN_PANEL_SLOTS", "CHIP_NO_PANEL_UNIFORM", "CHIP_NO_EMIT_ATOMIC"])
+                                  "CHIP_NO_PANEL_OVERLAP", "CHIP_NO_PANEL_OVERLAP+CHIP_SN_PANEL_SLOTS", "CHIP_NO_PANEL_UNIFORM"])
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
 def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
     """the block column of a supernode has three older forms behind switches -- separate k_snode_diag / k_snode_rows

@@ -81,8 +81,10 @@ def algorithmic_bytes(N, nnzK, nnzL, nnzHs, m):
 
 
 def bench_settings(hip, device):
+    # (BENCH_USE_GRAPH=1: the launch sequence of an LDL' solve replayed as a hipGraph -- an experiment switch of the tools)
     return hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0,
-                                iterative_refinement_abstol=0.0, device=device)
+                                iterative_refinement_abstol=0.0, device=device,
+                                use_graph=1 if os.environ.get("BENCH_USE_GRAPH") else 0)
 
 
 class Workload:
@@ -138,7 +140,12 @@ class Workload:
                         comm.wait(ks)
                         comm.allgather_step(ks, self.lhs[k].ptr, gathered[k].ptr, counts)
 
-    def run(self, steps, warmup, profile_family=0, comm=None, gathered=None, counts=None):
+    def run(self, steps, warmup, profile_family=0, comm=None, gathered=None, counts=None, events_in_timed_region=True):
+        """W warm-up steps, then K timed steps bracketed by synchronisations.  The dominant kernel's launch durations come from
+        hipEvent pairs on the engine's stream around each of its launches (chip_kkt_profile): inside the timed region when the
+        family has a handful of launches per step (config 3: 3), in a SECOND pass of the same steps right after it when a step
+        has hundreds of them (configs 2 / 5: 324 / 77 -- the event pairs themselves cost ~6 us each, 2 ms of an 18 ms step on
+        config 2, which would be charged to `value`)."""
         def sync():
             self.ks.synchronize()
             if comm is not None:
@@ -148,7 +155,7 @@ class Workload:
         for _ in range(warmup):
             self.step(comm, gathered, counts)
         sync()
-        self.ks.profile(profile_family)
+        self.ks.profile(profile_family if events_in_timed_region else 0)
         t0 = time.perf_counter()
         marks = [t0]
         for _ in range(steps):
@@ -159,6 +166,14 @@ class Workload:
         d = np.diff(np.asarray(marks)) * 1e3
         self.step_ms = {"min": round(float(d.min()), 4), "median": round(float(np.median(d)), 4),
                         "max": round(float(d.max()), 4)} if len(d) else None
+        self.events_pass = None
+        if not events_in_timed_region and profile_family:
+            self.ks.profile(profile_family)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                self.step(comm, gathered, counts)
+            sync()
+            self.events_pass = {"steps": steps, "ms_per_step_with_events": round(1e3 * (time.perf_counter() - t1) / steps, 4)}
         prof = self.ks.profile_read()
         self.ks.profile(0)
         if comm is not None:
@@ -172,6 +187,31 @@ class Workload:
 
 def relerr(a, b):
     return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
+
+
+def sweep_roofline(ks, wm, prof, steps, nsolves):
+    """HBM roofline object of the sweeps through the chain supernodes (profile family 11): supernodes on the one-pass
+    matrices stream G = [I; L_B] T^-1 once per sweep and unit level (8 B per entry: dense, no index; k_snode_gfwd /
+    k_snode_gbwd), the others their trapezoid of L (k_snode_tri; 12 B per entry of SURVEY 8(d)'s B_solve, the model is
+    kept).  achieved = algorithmic bytes of all launches of the family / their total duration."""
+    sm = ks.sweep_model()
+    sweeps = 2 * nsolves
+    if sm["g_levels"] > 0 and sm["g_levels"] == sm["sn_levels"]:
+        per_sweep = 8.0 * sm["g_doubles"]
+        kernel = ("k_snode_gfwd / k_snode_gbwd (one pass over G = [I; L_B] T^-1 of every supernode of a unit level, forward "
+                  "and backward sweeps; %d unit levels, G built once per refactor by k_snode_ginv)" % sm["g_levels"])
+        short = "k_snode_gfwd"
+    else:
+        per_sweep = 12.0 * wm["sn_panel_entries"]
+        kernel = ("k_snode_tri (pipelined substitution through the wide chain supernodes of one unit level, forward and "
+                  "backward sweeps)%s" % ("; %d of %d levels on the one-pass matrices" % (sm["g_levels"], sm["sn_levels"]) if sm["g_levels"] else ""))
+        short = "k_snode_tri"
+    tot_bytes = per_sweep * sweeps * steps
+    avg_ms = prof["ms"] / prof["launches"]
+    ach = tot_bytes / prof["launches"] / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "kernel_short": short, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * avg_ms, 2),
+            "algorithmic_bytes_per_launch": round(tot_bytes / prof["launches"])}
 
 
 def oracle_leg(w, args, time_it=True):
@@ -462,7 +502,7 @@ def extra_workload(hip, problems, which, args, device):
             desc, fam = "chordal SDP (BASELINE config 5): 200 x PSD(50) cliques with overlap 10 + 200 x SOC(51)", 7
         w = Workload(hip, pr, device, 0)
         steps, warm = max(3, min(args.steps, 10)), max(1, min(args.warmup, 2))
-        el, prof = w.run(steps, warm, fam)
+        el, prof = w.run(steps, warm, fam, events_in_timed_region=False)
         ms = 1e3 * el / steps
         ks = w.ks
         info = ks.linear_solver_info()
@@ -470,13 +510,8 @@ def extra_workload(hip, problems, which, args, device):
         Bm = algorithmic_bytes(ks.N, ks.nnzK, info.nnzL, ks.nHs, w.m)
         roof = None
         if prof["launches"] > 0 and which == "c2" and wm["sn_panel_entries"] > 0:
-            sweeps = 2 * len(w.rhs) * 2   # forward + backward, 3 solves x (1 + 1 refinement round)
-            per_launch = 12.0 * wm["sn_panel_entries"] * sweeps * steps / prof["launches"]
-            avg_ms = prof["ms"] / prof["launches"]
-            ach = per_launch / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_snode_tri", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "launches_per_step": round(prof["launches"] / steps, 1),
-                    "kernel_ms_per_step": round(prof["ms"] / steps, 3)}
+            roof = sweep_roofline(ks, wm, prof, steps, len(w.rhs) * 2)
+            roof.update({"launches_per_step": round(prof["launches"] / steps, 1), "kernel_ms_per_step": round(prof["ms"] / steps, 3)})
         elif prof["launches"] > 0 and which == "c5" and wm["sn_update_flops"] > 0:
             per_launch = wm["sn_update_flops"] * steps / prof["launches"]
             avg_ms = prof["ms"] / prof["launches"]
@@ -497,7 +532,7 @@ def extra_workload(hip, problems, which, args, device):
         else:
             parity = fixture_parity_c5(w, hip)
         out = {"workload": desc, "value": round(steps / el, 3), "unit": "iterations/s", "ms_per_step": round(ms, 4),
-               "steps": steps, "step_ms": w.step_ms, "kkt_dim": ks.N, "nnz_L": int(info.nnzL), "setup_s": round(w.t_setup, 2),
+               "steps": steps, "step_ms": w.step_ms, "roofline_events_pass": w.events_pass, "kkt_dim": ks.N, "nnz_L": int(info.nnzL), "setup_s": round(w.t_setup, 2),
                "roofline": roof, "whole_step_frac_of_hbm_peak": whole,
                "parity": None if parity is None else {k: parity[k] for k in ("rel_err_vs_oracle", "tol", "ok") if k in parity},
                "cpu_baseline": cpu, "cpu_baseline_mt": None if args.cpu_steps == 0 else sn_leg(w, hip)}
@@ -738,7 +773,8 @@ def main():
         comm = FileComm(hip, world, rank) if args.fake_comm else hip.Comm(rendezvous_id(hip, rank, world), world, rank, device)
         comm.attach(w.ks)
         gathered = [hip.DeviceArray(int(sum(counts))) for _ in range(3)]
-    elapsed, prof = w.run(args.steps, args.warmup, args.profile_family, comm, gathered, counts)
+    elapsed, prof = w.run(args.steps, args.warmup, args.profile_family, comm, gathered, counts,
+                          events_in_timed_region=workload not in ("c2", "c5", "c5m"))
     ir = w.ks.linear_solver_info().last_ir_iterations
     # N > 1: the same steps once more with the OTHER exchange policy, so that the driver's curve can be read either way
     # (SURVEY 8(e) says one all-gather per solve; the default gathers the step direction only)
@@ -854,19 +890,9 @@ def main():
                                        dense_TFLOPs_over_step=round(f_dense / (ms_per_step * 1e-3) / 1e12, 2),
                                        dense_frac_of_mfma_peak=round(f_dense / (ms_per_step * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4))}
         elif prof["launches"] > 0 and fam == 11 and wm["sn_panel_entries"] > 0:
-            # one sweep through the supernodes streams every entry of their dense trapezoids once: 12 B per entry
-            # of SURVEY 8(d)'s B_solve (value + index; the trapezoids need no index, the model is kept)
-            sweeps = 2 * nsolves
-            tot_bytes = 12.0 * wm["sn_panel_entries"] * sweeps * args.steps
-            per_launch = tot_bytes / prof["launches"]
-            avg_ms = prof["ms"] / prof["launches"]
-            ach = per_launch / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profiled_in": traffic_src,
-                    "kernel": fam_name,
-                    "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
-                    "algorithmic_bytes_per_launch": round(per_launch),
-                    "kernel_ms_per_step": round(prof["ms"] / args.steps, 3), "whole_step": whole}
+            roof = sweep_roofline(ks, wm, prof, args.steps, nsolves)
+            roof.update({"traffic": traffic, "traffic_profiled_in": traffic_src, "launches": prof["launches"],
+                         "kernel_ms_per_step": round(prof["ms"] / args.steps, 3), "whole_step": whole})
         elif prof["launches"] > 0:
             roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                     "kernel": fam_name, "launches": prof["launches"],
@@ -930,6 +956,7 @@ def main():
                                          "1 x all-gather of the step direction (the last solve's solution)",
                                          int(sum(counts)))) if comm is not None else "none"},
             "step_ms": step_ms,
+            "roofline_events_pass": getattr(w, "events_pass", None),
             "roofline": roof, "parity": parity, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt, "batched_c4": c4,
             "c2": extras.get("c2"), "c5": extras.get("c5"), "l1_dropin": extras.get("l1_dropin"),
             "other_exchange_policy": other_policy,

@@ -547,6 +547,12 @@ class HipKKTSolver:
                 "sn_diag_rows_flops": float(out[3]), "n_supernodes": int(out[4]), "fold_groups": int(out[5]),
                 "n_bundles": int(out[6]), "fused_threads": int(out[7])}
 
+    def sweep_model(self):
+        """how the substitutions run through the chain supernodes (chip_kkt_sweep_model)"""
+        out = (C.c_double * 4)()
+        _check(lib().chip_kkt_sweep_model(self._h, out), "sweep_model")
+        return {"g_doubles": float(out[0]), "g_levels": int(out[1]), "sn_levels": int(out[2]), "g_build_launches": int(out[3])}
+
     def fused_fallbacks(self):
         return int(lib().chip_kkt_fused_fallbacks(self._h))
 

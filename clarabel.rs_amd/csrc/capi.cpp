@@ -1622,6 +1622,18 @@ int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]) {
     out[7] = h->E.ir_fused ? h->E.ir_tw : 0; // threads per workgroup of the fused solve launch (0: not fused)
     return CHIP_OK;
 }
+int32_t chip_kkt_sweep_model(const chip_kkt *h, double out[4]) {
+    if (!h || !out) return CHIP_ERR_ARG;
+    const Engine &E = h->E;
+    int gl = 0, sl = 0;
+    for (char f : E.sn_lvl_g) gl += f != 0;
+    for (size_t l = 0; l + 1 < E.sn_lvl_ptr.size(); l++) sl += E.sn_lvl_ptr[l + 1] > E.sn_lvl_ptr[l];
+    out[0] = E.sn_g_ntasks > 0 ? E.sn_g_entries : 0.0;
+    out[1] = E.sn_g_ntasks > 0 ? gl : 0;
+    out[2] = sl;
+    out[3] = E.sn_g_ntasks > 0 ? 1 : 0;
+    return CHIP_OK;
+}
 #ifdef CHIP_TESTING
 // test hooks (include/clarabel_hip_testing.h): a kernel that only spins, on a stream of its own (co-residency tests of
 // the persistent launches); a switch of csrc/switches.hpp set or cleared by name

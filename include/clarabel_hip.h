@@ -360,6 +360,12 @@ int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]);
  * nodes folded into its bundles' kernels; 0 = none), out[6] = subtree bundles, out[7] = threads per workgroup of the
  * fused solve launch (0 = the handle's solve is not the fused launch). */
 int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]);
+/* chip_kkt_sweep_model (round 5): how the substitutions run through the chain supernodes.  Supernodes of moderate width
+ * keep a substitution matrix G = [I; L_B] T^-1 (built once per refactor) and a sweep is ONE pass over it per unit level,
+ * without a chain of block hops (csrc/snode_g.hip); wider ones keep the pipelined block-by-block substitution.
+ * out[0] = doubles of all G (what one sweep through those supernodes streams), out[1] = unit levels on that path,
+ * out[2] = unit levels that hold supernodes, out[3] = launches of the build per refactor (0 or 1). */
+int32_t chip_kkt_sweep_model(const chip_kkt *h, double out[4]);
 /* which of the grouped-fold step kernels (csrc/bundle_gstep.hip) this handle uses: bit 0 = the fused solve launch is
  * k_gstep_solve (a bundle's entries of L and K in registers), bit 1 = the refactor's bundle part is k_gstep_factor
  * (bundle columns + Schur shares + the groups' tops in one launch); 0 = neither (diagnostics) */

@@ -105,6 +105,7 @@ class Workload:
         self.n, self.m = n, m
         self.gather_every_solve = False
         self.repeats = 0   # solves repeated at collect time after a fused launch timed out (chip_kkt_collect: 2)
+        self.coresident = None  # (blocks, usec, device): see --coresident
 
     def step(self, comm=None, gathered=None, counts=None):
         # one interior-point iteration's KKT work is ENQUEUED as a whole; the reference's bools (update:
@@ -126,6 +127,8 @@ class Workload:
                 # every rank ends up with the full step direction (dx, dz): RCCL all-gather over xGMI,
                 # enqueued behind this solve by an event and left running behind the next solves
                 comm.allgather_step(ks, self.lhs[k].ptr, gathered[k].ptr, counts)
+                if self.coresident:
+                    self.hip.debug_spin(self.coresident[2], self.coresident[0], 256, 0, self.coresident[1])
         uok, sok = ks.collect()
         if not uok or len(sok) != len(self.rhs) or not all(sok):
             raise RuntimeError("KKT step failed: update %s, solves %s" % (uok, sok))
@@ -709,6 +712,11 @@ def main():
     ap.add_argument("--nbatch", type=int, default=1024, help="c4: independent SOCPs (default: config 4)")
     ap.add_argument("--force-comm", action="store_true",
                     help="c4 at N = 1: run the all-gather path with a one-rank RCCL communicator (plumbing check)")
+    ap.add_argument("--coresident", default="",
+                    help="BLOCKS:USEC -- rehearsal of a rank of the sharded run on ONE GPU: every step, where the all-gather of the step "
+                         "direction is enqueued, a kernel of BLOCKS workgroups (256 threads) that holds its CUs for USEC microseconds is "
+                         "launched on a stream of its own (what RCCL's ring kernel does next to the persistent launches); use with "
+                         "--workload c4 --nbatch 128 --force-comm.  Needs the library's test hooks (chip_debug_spin).")
     ap.add_argument("--fake-comm", action="store_true",
                     help="N > 1 on ONE GPU with a file-based stand-in for the RCCL exchange: plumbing check of this script's "
                          "N > 1 code (never a measurement)")
@@ -766,6 +774,9 @@ def main():
         counts = [(e - b) * (pr["n"] + pr["m"]) // (b1 - b0) for b, e in ranges]
     w = Workload(hip, pr, device, rank)
     w.gather_every_solve = bool(args.gather_every_solve)
+    if args.coresident:
+        cb, cu = args.coresident.split(":")
+        w.coresident = (int(cb), float(cu), device)
     info = w.ks.linear_solver_info()
     t_setup = w.t_setup
     if world > 1 or (args.force_comm and workload == "c4"):
@@ -853,11 +864,16 @@ def main():
         try:
             import glob
             suffix = {"c3": "", "c2": "_c2", "c5": "_c5"}.get(workload)
+            if workload == "c4" and world == 1 and args.nbatch in (128, 256):
+                suffix = "_c4_%d" % args.nbatch
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic%s.json" % suffix))) if suffix is not None else []
-            kname = {1: "k_bundle_symv", 5: "k_bundle_ir", 6: "k_bundle_factor", 7: "k_snode_update", 11: "k_snode_tri"}.get(fam)
-            full_size = (workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000) or workload in ("c2", "c5")
-            if pj and kname and full_size:
-                traffic = json.load(open(pj[-1]))["kernels"][kname]["hbm_bytes"]
+            knames = {1: ["k_bundle_symv"], 5: ["k_gstep_solve" if ks.step_kernels() & 1 else "k_bundle_ir"], 6: ["k_bundle_factor"],
+                      7: ["k_snode_update"],
+                      11: ["k_snode_gfwd", "k_snode_gbwd"] if ks.sweep_model()["g_levels"] else ["k_snode_tri"]}.get(fam)
+            full_size = (workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000) or workload in ("c2", "c5", "c4")
+            if pj and knames and full_size:
+                kk = json.load(open(pj[-1]))["kernels"]
+                traffic = round(sum(kk[k]["hbm_bytes"] for k in knames) / len(knames))  # (mean over the family's kernels, per launch)
                 traffic_src = os.path.basename(pj[-1])
         except Exception:
             traffic = None
@@ -961,6 +977,13 @@ def main():
             "c2": extras.get("c2"), "c5": extras.get("c5"), "l1_dropin": extras.get("l1_dropin"),
             "other_exchange_policy": other_policy,
             "fused_launch_repeats": int(w_repeats),
+            "rehearsal": None if not args.coresident else {
+                "what": "one rank of the sharded run rehearsed on one GPU: the exchange path with a one-rank RCCL communicator "
+                        "(the all-gather enqueued every step behind the last solve, overlapping the next step) plus a co-resident "
+                        "kernel of %s workgroups x 256 threads spinning for %s us per step on its own stream -- what RCCL's ring "
+                        "kernel occupies next to the persistent launches at N = 8" % tuple(args.coresident.split(":")),
+                "ms_per_step": round(ms_per_step, 4), "fused_launch_repeats": int(w_repeats),
+                "fused_fallbacks": int(w.ks.fused_fallbacks())},
         }
         print(json.dumps(out))
         sys.stdout.flush()

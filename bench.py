@@ -599,9 +599,69 @@ def l1_dropin_leg(hip, w, args):
         xo = fo.solve(bs[0])
         err = relerr(xs[0], xo)
         bytes_step = 8 * len(reg) + nsolve * 2 * 8 * N
-        del f, fo
+        del fo
+        # ---- the same iteration through the FAST path of the boundary (chip_ldl_register_index / *_values_id /
+        # chip_ldl_solve_refined / chip_ldl_pin_buffer): the entries that change between two scalings as one registered set,
+        # diag_full + Dsigns as another; per step update_values on the set, regulariser on, refactor, regulariser off
+        # (directldlkktsolver.rs:143, 245, 255-261) and 3 solves with ONE refinement round each on the device (:266-321)
+        fast = None
+        try:
+            ks.update_scaling(w.pr["s"] * 1.25, w.pr["z"] * 0.8)
+            ks.update()
+            vals2 = np.ascontiguousarray(ks.values())
+            ks.update_scaling(w.pr["s"], w.pr["z"])
+            ks.update()
+            changed = np.nonzero(vals != vals2)[0].astype(np.int64)
+            del vals2
+            id_upd = f.register_index(changed)
+            id_diag = f.register_index(dfull, signs=dsigns)
+            newv = np.ascontiguousarray(vals[changed])
+            xf = [np.zeros(N) for _ in range(3)]
+            for a in [newv] + bs + xf:
+                f.pin_buffer(a)
+            st1 = hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0, iterative_refinement_abstol=0.0,
+                                       device=ks.settings.device)
+
+            def fstep():
+                f.update_values_id(id_upd, newv)
+                f.offset_values_id(id_diag, eps)
+                if not f.refactor():
+                    raise RuntimeError("L1 refactor failed")
+                f.offset_values_id(id_diag, -eps)
+                for k in range(3):
+                    ok, _ = f.solve_refined(xf[k], bs[k], st1)
+                    if not ok:
+                        raise RuntimeError("L1 refined solve failed")
+
+            f.set_values(vals)   # (the unregularised values: the fast path applies the regulariser itself)
+            fstep()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fstep()
+            elf = time.perf_counter() - t0
+            # against the device-resident L2 solve of the same right-hand side (same refinement setting)
+            nm = w.n + w.m
+            ks.set_settings(st1)
+            ks.setrhs(bs[0][:w.n], bs[0][w.n:nm])
+            xg, zg = np.zeros(w.n), np.zeros(w.m)
+            okd = ks.solve(xg, zg)
+            ks.set_settings(bench_settings(hip, ks.settings.device))
+            bfull = np.concatenate([bs[0][:nm], np.zeros(N - nm)])
+            okf, _ = f.solve_refined(xf[0], bfull, st1)
+            errf = relerr(xf[0][:nm], np.concatenate([xg, zg])) if (okd and okf) else None
+            fbytes = 8 * len(changed) + 3 * 2 * 8 * N
+            fast = {"what": "the same iteration through registered index sets (%d changed entries of K + diag_full), the device-resident "
+                            "refinement (chip_ldl_solve_refined, one round) and page-locked caller buffers: per step 1 x update_values, "
+                            "2 x offset_values, 1 refactor, 3 refined solves" % len(changed),
+                    "value": round(steps / elf, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * elf / steps, 3),
+                    "pcie_bytes_per_step": int(fbytes), "pcie_GBs": round(fbytes / (elf / steps) / 1e9, 1),
+                    "rel_err_vs_L2_solution": errf, "ok": bool(errf is not None and errf <= TOL)}
+        except Exception as ex:
+            fast = {"error": repr(ex)[:300]}
+        del f
         return {"what": "config 3 through chip_ldl_set_values / chip_ldl_refactor / chip_ldl_solve with HOST buffers (pageable numpy "
                         "arrays): per step 1 refactor + 6 solves, every operand over PCIe",
+                "fast_path": fast,
                 "value": round(steps / el, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
                 "pcie_bytes_per_step": int(bytes_step), "pcie_GBs": round(bytes_step / (el / steps) / 1e9, 1),
                 "setup_s": round(t_setup, 2),

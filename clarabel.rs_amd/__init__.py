@@ -250,6 +250,35 @@ class HipDirectLDLSolver:
         nzval = _f(nzval)
         _check(lib().chip_ldl_set_values(self._h, _pf(nzval)), "set_values")
 
+    # ---- fast path of the strict drop-in (include/clarabel_hip.h: chip_ldl_register_index ...) ----
+    def register_index(self, index, signs=None):
+        index = _u(index)
+        sg = None if signs is None else np.ascontiguousarray(signs, dtype=np.int8)
+        out = C.c_int32()
+        _check(lib().chip_ldl_register_index(self._h, _pu(index), C.c_int64(len(index)),
+                                             None if sg is None else sg.ctypes.data_as(C.POINTER(C.c_int8)), C.byref(out)),
+               "ldl_register_index")
+        return int(out.value)
+
+    def update_values_id(self, set_id, values):
+        values = _f(values)
+        _check(lib().chip_ldl_update_values_id(self._h, C.c_int32(set_id), _pf(values)), "ldl_update_values_id")
+
+    def scale_values_id(self, set_id, scale):
+        _check(lib().chip_ldl_scale_values_id(self._h, C.c_int32(set_id), C.c_double(scale)), "ldl_scale_values_id")
+
+    def offset_values_id(self, set_id, offset):
+        _check(lib().chip_ldl_offset_values_id(self._h, C.c_int32(set_id), C.c_double(offset)), "ldl_offset_values_id")
+
+    def pin_buffer(self, array):
+        _check(lib().chip_ldl_pin_buffer(self._h, C.c_void_p(array.ctypes.data), C.c_uint64(array.nbytes)), "ldl_pin_buffer")
+
+    def solve_refined(self, x, b, settings=None):
+        """solve + device-resident refinement (directldlkktsolver.rs:266-321); returns (ok, rounds)"""
+        its = C.c_int32()
+        rc = lib().chip_ldl_solve_refined(self._h, _pf(x), _pf(_f(b)), None if settings is None else C.byref(settings), C.byref(its))
+        return bool(_status(rc, "ldl_solve_refined")), int(its.value)
+
     def refactor(self, kkt=None):
         """-> bool (all Dinv finite), ldlsolvers/qdldl.rs:98-106"""
         return bool(_check(lib().chip_ldl_refactor(self._h), "refactor"))

@@ -120,6 +120,19 @@ __global__ __launch_bounds__(WG) void k_scatter_values(double *Kx, const int *__
                                                        double scale) {
     for (int t = blockIdx.x * WG + threadIdx.x; t < k; t += gridDim.x * WG) Kx[map[t]] = vals[t] * scale;
 }
+// Kx[map[t]] += sign[t] * offset (sign 0: untouched; signs == nullptr: +offset) / Kx[map[t]] *= scale -- the L1 boundary's
+// offset_values / scale_values on a registered index set (capi.cpp: chip_ldl_*_values_id)
+__global__ __launch_bounds__(WG) void k_offset_values(double *Kx, const int *__restrict__ map, const int8_t *__restrict__ signs,
+                                                      int k, double offset) {
+    for (int t = blockIdx.x * WG + threadIdx.x; t < k; t += gridDim.x * WG) {
+        const int sg = signs ? (int)signs[t] : 1;
+        if (sg > 0) Kx[map[t]] += offset;
+        else if (sg < 0) Kx[map[t]] -= offset;
+    }
+}
+__global__ __launch_bounds__(WG) void k_scale_values(double *Kx, const int *__restrict__ map, int k, double scale) {
+    for (int t = blockIdx.x * WG + threadIdx.x; t < k; t += gridDim.x * WG) Kx[map[t]] *= scale;
+}
 // max |K[diag]| -> bits in scal[1] (u64 compare is monotone for non-negative doubles);
 // NaN propagates like vecmath.rs:132-142 through the flag in scal[2].
 __global__ __launch_bounds__(WG) void k_diag_absmax(const double *__restrict__ Kx,
@@ -338,6 +351,14 @@ void scatter_values(hipStream_t s, double *Kx, const int *map, const double *val
     int nb = (k + WG - 1) / WG;
     if (nb > 4096) nb = 4096;
     k_scatter_values<<<nb, WG, 0, s>>>(Kx, map, vals, k, scale);
+}
+void offset_values(hipStream_t s, double *Kx, const int *map, const int8_t *signs, int k, double offset) {
+    if (k == 0) return;
+    k_offset_values<<<std::min((k + WG - 1) / WG, 4096), WG, 0, s>>>(Kx, map, signs, k, offset);
+}
+void scale_values(hipStream_t s, double *Kx, const int *map, int k, double scale) {
+    if (k == 0) return;
+    k_scale_values<<<std::min((k + WG - 1) / WG, 4096), WG, 0, s>>>(Kx, map, k, scale);
 }
 void diag_absmax_eps(hipStream_t s, const double *Kx, const int *didx, int N, double c, double prop,
                      double *scal) {

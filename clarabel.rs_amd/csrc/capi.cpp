@@ -58,6 +58,27 @@ struct chip_ldl {
     std::vector<double> hK; // host mirror of the caller's K.nzval (update/scale/offset land here)
     bool dirty = true;
     double *d_b = nullptr, *d_x = nullptr, *d_y = nullptr;
+    // ---- fast path of the strict drop-in (round 5) ----
+    // registered index sets: the reference's update_values / scale_values / offset_values always come with one of a few
+    // FIXED index vectors of the LDLDataMap (Hsblocks, diag_full, the sparse cones' u / v / D: datamaps.rs:350-362);
+    // registered once, a set lives on the device as positions in the value store and an update moves 8 bytes per entry
+    struct IndexSet {
+        int *pos = nullptr;      // device: position of entry t in the device's value order
+        int8_t *signs = nullptr; // device (or nullptr): the signs of offset_values
+        i64 k = 0;
+    };
+    std::vector<IndexSet> sets;
+    double *d_vals = nullptr; // staging of one update's values
+    i64 d_vals_cap = 0;
+    // once an update went to the device copy directly, THAT copy is the caller's K.nzval (the host mirror is stale and
+    // chip_ldl_refactor no longer uploads it); chip_ldl_set_values makes the host mirror current again
+    bool dev_values = false;
+    // device-resident refinement (chip_ldl_solve_refined): permuted right-hand side, iterate, residual, correction
+    double *r_bp = nullptr, *r_x = nullptr, *r_e = nullptr, *r_w = nullptr;
+    std::vector<void *> pinned; // caller buffers registered with chip_ldl_pin_buffer
+    ~chip_ldl() {
+        for (void *p : pinned) (void)hipHostUnregister(p);
+    }
 };
 
 struct chip_kkt {
@@ -223,8 +244,11 @@ int32_t chip_ldl_create(chip_ldl **out, int64_t n, const uint64_t *colptr, const
 
 void chip_ldl_destroy(chip_ldl *h) { delete h; }
 
+static int ldl_plain_on_device(chip_ldl *h, int kind, const uint64_t *index, const double *values, double scalar,
+                               const int8_t *signs, int64_t k);
 int32_t chip_ldl_update_values(chip_ldl *h, const uint64_t *index, const double *values, int64_t k) {
     if (!h) return CHIP_ERR_ARG;
+    if (h->dev_values) return ldl_plain_on_device(h, 0, index, values, 0.0, nullptr, k);
     for (i64 i = 0; i < k; i++) {
         if (index[i] >= (uint64_t)h->E.nnzK) return fail(CHIP_ERR_ARG, "update_values: index out of range");
         h->hK[index[i]] = values[i];
@@ -234,6 +258,7 @@ int32_t chip_ldl_update_values(chip_ldl *h, const uint64_t *index, const double 
 }
 int32_t chip_ldl_scale_values(chip_ldl *h, const uint64_t *index, double scale, int64_t k) {
     if (!h) return CHIP_ERR_ARG;
+    if (h->dev_values) return ldl_plain_on_device(h, 1, index, nullptr, scale, nullptr, k);
     for (i64 i = 0; i < k; i++) {
         if (index[i] >= (uint64_t)h->E.nnzK) return fail(CHIP_ERR_ARG, "scale_values: index out of range");
         h->hK[index[i]] *= scale;
@@ -244,6 +269,7 @@ int32_t chip_ldl_scale_values(chip_ldl *h, const uint64_t *index, double scale, 
 int32_t chip_ldl_offset_values(chip_ldl *h, const uint64_t *index, double offset, const int8_t *signs,
                                int64_t k) {
     if (!h) return CHIP_ERR_ARG;
+    if (h->dev_values) return ldl_plain_on_device(h, 2, index, nullptr, offset, signs, k);
     for (i64 i = 0; i < k; i++) {
         if (index[i] >= (uint64_t)h->E.nnzK) return fail(CHIP_ERR_ARG, "offset_values: index out of range");
         if (signs[i] > 0) h->hK[index[i]] += offset;
@@ -256,6 +282,7 @@ int32_t chip_ldl_set_values(chip_ldl *h, const double *kkt_nzval) {
     if (!h || !kkt_nzval) return CHIP_ERR_ARG;
     std::memcpy(h->hK.data(), kkt_nzval, (size_t)h->E.nnzK * sizeof(double));
     h->dirty = true;
+    h->dev_values = false; // (the host mirror is the caller's K.nzval again; the next refactor uploads it)
     return CHIP_OK;
 }
 extern "C++" {
@@ -281,11 +308,11 @@ int32_t chip_ldl_refactor(chip_ldl *h) {
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
-    if (h->dirty && E.nnzK) {
+    if (h->dirty && !h->dev_values && E.nnzK) {
         int rc = E.upload_values(h->hK.data());
         if (rc) return rc;
-        h->dirty = false;
     }
+    h->dirty = false;
     return E.refactor(false, nullptr);
 }
 int32_t chip_ldl_solve_dev(chip_ldl *h, double *x_dev, const double *b_dev) {
@@ -960,34 +987,19 @@ int32_t chip_kkt_setrhs(chip_kkt *h, const double *rhsx, const double *rhsz) {
 // Buffer rotation instead of copies: x (solution), e (residual, then solved IN PLACE into the
 // correction, then turned into the candidate x + dx), w (next residual).  Accepting a round
 // renames (x, e, w) <- (e, w, x): the reference's mem::swap(x, dx) without moving data.
-static int solve_core(chip_kkt *h) {
-    Engine &E = h->E;
+// (the refinement loop itself, shared by the L2 handle and by chip_ldl_solve_refined: xio / eio / wio are the three work
+// vectors and come back renamed; x holds K^-1 bp's first approximation on entry)
+static int refine_core(Engine &E, const double *bp, double *&xio, double *&eio, double *&wio, int &last_ir) {
     const chip_settings &st = E.st;
     const int N = E.N;
-    if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
-    h->last_ir = 0;
     int rc;
-    if (h->rhs_deferred) { // (fused path not taken for this solve: stage the noted right-hand side now)
-        h->rhs_deferred = false;
-        if ((rc = E.zero_norm_sets())) return rc;
-        dev::setrhs_perm(E.stream, h->bp, h->x, h->rhs_x, h->rhs_z, E.perm, (int)h->K.n, (int)h->K.m, E.N,
-                         E.norm_set(0), E.norm_nan(0));
-        h->x_holds_b = true;
-    }
-    if (!h->x_holds_b) { // solve() again on the same right-hand side, or a full-N rhs in bp
-        if ((rc = E.zero_norm_sets())) return rc;
-        CHIP_HIP(hipMemcpyAsync(h->x, h->bp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
-        dev::norm_inf(E.stream, h->bp, N, E.norm_set(0), E.norm_nan(0));
-    }
-    h->x_holds_b = false;
-    E.enqueue_solve_inplace(h->x);
     if (!st.iterative_refinement_enable) {
-        dev::norm_inf(E.stream, h->x, N, E.norm_set(1), E.norm_nan(1));
+        dev::norm_inf(E.stream, xio, N, E.norm_set(1), E.norm_nan(1));
         double nx;
         if ((rc = E.read_norm(1, &nx))) return rc;
         return std::isfinite(nx) ? 1 : 0; // x.is_finite(), directldlkktsolver.rs:180
     }
-    double *x = h->x, *e = h->e, *w = h->dx;
+    double *x = xio, *e = eio, *w = wio;
     const double abstol = st.iterative_refinement_abstol, reltol = st.iterative_refinement_reltol;
     const double stopratio = st.iterative_refinement_stop_ratio;
     const int maxiter = st.iterative_refinement_max_iter;
@@ -995,12 +1007,12 @@ static int solve_core(chip_kkt *h) {
     // so that one host synchronisation (one D2H copy of norm sets 0..2) serves both decisions of
     // directldlkktsolver.rs:288-318; if ||e0|| already meets the tolerance the speculative
     // candidate is simply never looked at.  Decisions are exactly the reference's.
-    E.enqueue_residual(e, h->bp, x, 1);
+    E.enqueue_residual(e, bp, x, 1);
     if (maxiter >= 1) {
         // w <- e0 is needed if the round is rejected?  No: a rejected round leaves x untouched and e
         // is dead afterwards, so e is solved in place.
         E.enqueue_solve_inplace(e, x); // e <- x + K^-1 e0   (the candidate; "+ x" fused into the sweep)
-        E.enqueue_residual(w, h->bp, e, 2);
+        E.enqueue_residual(w, bp, e, 2);
     }
     double nn[3] = {0, 0, 0};
     if ((rc = E.read_norms(0, maxiter >= 1 ? 3 : 2, nn))) return rc;
@@ -1019,10 +1031,10 @@ static int solve_core(chip_kkt *h) {
             if (set >= NRM_SETS) set = 3;
             if (it + 2 >= NRM_SETS) // the set is being reused: clear it first
                 CHIP_HIP(hipMemsetAsync(E.norm_set(set), 0, NRM_SET_WORDS * sizeof(unsigned long long), E.stream));
-            E.enqueue_residual(w, h->bp, e, set);
+            E.enqueue_residual(w, bp, e, set);
             if ((rc = E.read_norm(set, &norme))) return rc;
         }
-        h->last_ir += 1;
+        last_ir += 1;
         if (!std::isfinite(norme)) return 0;
         const double improved = lastnorme / norme;
         const bool accept = !(improved < stopratio) || improved > 1.0;
@@ -1034,9 +1046,219 @@ static int solve_core(chip_kkt *h) {
         }
         if (improved < stopratio) break;
     }
-    h->x = x;
-    h->e = e;
-    h->dx = w;
+    xio = x;
+    eio = e;
+    wio = w;
+    return 1;
+}
+static int solve_core(chip_kkt *h) {
+    Engine &E = h->E;
+    const int N = E.N;
+    if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
+    h->last_ir = 0;
+    int rc;
+    if (h->rhs_deferred) { // (fused path not taken for this solve: stage the noted right-hand side now)
+        h->rhs_deferred = false;
+        if ((rc = E.zero_norm_sets())) return rc;
+        dev::setrhs_perm(E.stream, h->bp, h->x, h->rhs_x, h->rhs_z, E.perm, (int)h->K.n, (int)h->K.m, E.N,
+                         E.norm_set(0), E.norm_nan(0));
+        h->x_holds_b = true;
+    }
+    if (!h->x_holds_b) { // solve() again on the same right-hand side, or a full-N rhs in bp
+        if ((rc = E.zero_norm_sets())) return rc;
+        CHIP_HIP(hipMemcpyAsync(h->x, h->bp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
+        dev::norm_inf(E.stream, h->bp, N, E.norm_set(0), E.norm_nan(0));
+    }
+    h->x_holds_b = false;
+    E.enqueue_solve_inplace(h->x);
+    return refine_core(E, h->bp, h->x, h->e, h->dx, h->last_ir);
+}
+
+// ---- L1 fast path (round 5): registered index sets, device-resident refinement, pinned caller buffers -----------------
+// The strict drop-in moved 352 MB over PCIe per interior-point iteration of config 3 (all of K.nzval per refactor, b and x
+// of every LDL' solve of every refinement round).  What the reference's DirectLDLKKTSolver actually changes per
+// iteration are the entries of a few fixed index vectors (directldlkktsolver.rs:143,245; datamaps.rs:213-219), and its
+// refinement (:266-321) needs nothing from the host but b.
+static int ldl_values_to_device(chip_ldl *h) { // first direct update: the device copy becomes the caller's K.nzval
+    Engine &E = h->E;
+    if (h->dev_values) return CHIP_OK;
+    if (h->dirty && E.nnzK) {
+        int rc = E.upload_values(h->hK.data());
+        if (rc) return rc;
+    }
+    h->dev_values = true;
+    return CHIP_OK;
+}
+static int ldl_stage(chip_ldl *h, i64 k) {
+    if (k <= h->d_vals_cap) return CHIP_OK;
+    int rc = h->E.alloc(&h->d_vals, (size_t)k); // (the engine frees it with the handle; earlier, smaller ones too)
+    if (rc) return rc;
+    h->d_vals_cap = k;
+    return CHIP_OK;
+}
+// a plain (index-carrying) update on a handle whose device copy is authoritative: index translated and shipped each time
+static int ldl_plain_on_device(chip_ldl *h, int kind, const uint64_t *index, const double *values, double scalar,
+                               const int8_t *signs, int64_t k) {
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    if (k <= 0) return CHIP_OK;
+    CHIP_HIP(hipSetDevice(E.device));
+    std::vector<i32> pos((size_t)k);
+    for (i64 i = 0; i < k; i++) {
+        if (index[i] >= (uint64_t)E.nnzK) return fail(CHIP_ERR_ARG, "values update: index out of range");
+        pos[(size_t)i] = E.h_k2v[(size_t)index[i]];
+    }
+    int *dpos = nullptr;
+    int8_t *dsg = nullptr;
+    CHIP_HIP(hipMalloc((void **)&dpos, (size_t)k * sizeof(int)));
+    CHIP_HIP(hipMemcpyAsync(dpos, pos.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, E.stream));
+    int rc = CHIP_OK;
+    if (kind == 0) {
+        if ((rc = ldl_stage(h, k)) == CHIP_OK) {
+            (void)hipMemcpyAsync(h->d_vals, values, (size_t)k * sizeof(double), hipMemcpyHostToDevice, E.stream);
+            dev::scatter_values(E.stream, E.Kx, dpos, h->d_vals, (int)k, 1.0);
+        }
+    } else if (kind == 1) {
+        dev::scale_values(E.stream, E.Kx, dpos, (int)k, scalar);
+    } else {
+        if (hipMalloc((void **)&dsg, (size_t)k) == hipSuccess) {
+            (void)hipMemcpyAsync(dsg, signs, (size_t)k, hipMemcpyHostToDevice, E.stream);
+            dev::offset_values(E.stream, E.Kx, dpos, dsg, (int)k, scalar);
+        } else rc = CHIP_ERR_HIP;
+    }
+    (void)hipStreamSynchronize(E.stream);
+    (void)hipFree(dpos);
+    if (dsg) (void)hipFree(dsg);
+    E.sx_valid = false;
+    h->dirty = true;
+    return rc;
+}
+int32_t chip_ldl_register_index(chip_ldl *h, const uint64_t *index, int64_t k, const int8_t *signs_or_null, int32_t *id_out) {
+    if (!h || !id_out || k < 0 || (k > 0 && !index)) return fail(CHIP_ERR_ARG, "chip_ldl_register_index: bad argument");
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    std::vector<i32> pos((size_t)k);
+    for (i64 i = 0; i < k; i++) {
+        if (index[i] >= (uint64_t)E.nnzK) return fail(CHIP_ERR_ARG, "chip_ldl_register_index: index out of range");
+        pos[(size_t)i] = E.h_k2v[(size_t)index[i]];
+    }
+    chip_ldl::IndexSet st;
+    st.k = k;
+    int rc;
+    if ((rc = E.upload(&st.pos, pos, (size_t)k))) return rc;
+    if (signs_or_null) {
+        std::vector<int8_t> sg(signs_or_null, signs_or_null + k);
+        if ((rc = E.upload(&st.signs, sg, (size_t)k))) return rc;
+    }
+    h->sets.push_back(st);
+    *id_out = (int32_t)h->sets.size() - 1;
+    return CHIP_OK;
+}
+static int ldl_set_of(chip_ldl *h, int32_t id, chip_ldl::IndexSet **st) {
+    if (!h || id < 0 || (size_t)id >= h->sets.size()) return fail(CHIP_ERR_ARG, "unknown index set");
+    *st = &h->sets[(size_t)id];
+    return CHIP_OK;
+}
+int32_t chip_ldl_update_values_id(chip_ldl *h, int32_t id, const double *values) {
+    chip_ldl::IndexSet *st;
+    int rc = ldl_set_of(h, id, &st);
+    if (rc) return rc;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    if (st->k == 0) return CHIP_OK;
+    if (!values) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(E.device));
+    if ((rc = ldl_values_to_device(h))) return rc;
+    if ((rc = ldl_stage(h, st->k))) return rc;
+    CHIP_HIP(hipMemcpyAsync(h->d_vals, values, (size_t)st->k * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    dev::scatter_values(E.stream, E.Kx, st->pos, h->d_vals, (int)st->k, 1.0);
+    // (the caller may reuse `values` at once: the reference's update_values copies; a pinned source is read by the DMA
+    // engine asynchronously, so wait for the copy -- not for the kernel)
+    CHIP_HIP(hipStreamSynchronize(E.stream));
+    E.sx_valid = false;
+    h->dirty = true;
+    return CHIP_OK;
+}
+int32_t chip_ldl_scale_values_id(chip_ldl *h, int32_t id, double scale) {
+    chip_ldl::IndexSet *st;
+    int rc = ldl_set_of(h, id, &st);
+    if (rc) return rc;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    if ((rc = ldl_values_to_device(h))) return rc;
+    dev::scale_values(E.stream, E.Kx, st->pos, (int)st->k, scale);
+    E.sx_valid = false;
+    h->dirty = true;
+    return CHIP_OK;
+}
+int32_t chip_ldl_offset_values_id(chip_ldl *h, int32_t id, double offset) {
+    chip_ldl::IndexSet *st;
+    int rc = ldl_set_of(h, id, &st);
+    if (rc) return rc;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    if ((rc = ldl_values_to_device(h))) return rc;
+    dev::offset_values(E.stream, E.Kx, st->pos, st->signs, (int)st->k, offset);
+    E.sx_valid = false;
+    h->dirty = true;
+    return CHIP_OK;
+}
+int32_t chip_ldl_pin_buffer(chip_ldl *h, void *ptr, uint64_t bytes) {
+    if (!h || !ptr || !bytes) return CHIP_ERR_ARG;
+    NEED_DEVICE(h->E);
+    CHIP_HIP(hipSetDevice(h->E.device));
+    for (void *p : h->pinned)
+        if (p == ptr) return CHIP_OK;
+    CHIP_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    h->pinned.push_back(ptr);
+    return CHIP_OK;
+}
+// solve + iterative refinement of directldlkktsolver.rs:266-321 with the handle's CURRENT values as K (the caller has
+// restored the unregularised diagonal after refactor, :255-261): b in, x out, everything in between on the device
+int32_t chip_ldl_solve_refined(chip_ldl *h, double *x, const double *b, const chip_settings *ir_settings, int32_t *iterations) {
+    if (!h || !x || !b) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first refactor()");
+    CHIP_HIP(hipSetDevice(E.device));
+    int rc;
+    const size_t N = (size_t)E.N;
+    if (!h->r_bp) {
+        if ((rc = E.alloc(&h->r_bp, N))) return rc;
+        if ((rc = E.alloc(&h->r_x, N))) return rc;
+        if ((rc = E.alloc(&h->r_e, N))) return rc;
+        if ((rc = E.alloc(&h->r_w, N))) return rc;
+    }
+    if (h->dirty && !h->dev_values && E.nnzK) { // plain updates since the refactor (the restored diagonal): the residual reads them
+        if ((rc = E.upload_values(h->hK.data()))) return rc;
+        E.sx_valid = false;
+        h->dirty = false;
+    }
+    const chip_settings saved = E.st;
+    if (ir_settings) {
+        E.st.iterative_refinement_enable = ir_settings->iterative_refinement_enable;
+        E.st.iterative_refinement_reltol = ir_settings->iterative_refinement_reltol;
+        E.st.iterative_refinement_abstol = ir_settings->iterative_refinement_abstol;
+        E.st.iterative_refinement_max_iter = ir_settings->iterative_refinement_max_iter;
+        E.st.iterative_refinement_stop_ratio = ir_settings->iterative_refinement_stop_ratio;
+    }
+    if (N) CHIP_HIP(hipMemcpyAsync(h->d_b, b, N * sizeof(double), hipMemcpyHostToDevice, E.stream));
+    if ((rc = E.zero_norm_sets())) return rc;
+    dev::permute_in(E.stream, h->r_bp, h->d_b, E.perm, E.N);
+    if (N) CHIP_HIP(hipMemcpyAsync(h->r_x, h->r_bp, N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
+    dev::norm_inf(E.stream, h->r_bp, E.N, E.norm_set(0), E.norm_nan(0));
+    E.enqueue_solve_inplace(h->r_x);
+    int its = 0;
+    const int ok = refine_core(E, h->r_bp, h->r_x, h->r_e, h->r_w, its);
+    E.st = saved;
+    if (iterations) *iterations = its;
+    if (ok != 1) return ok;
+    dev::permute_out(E.stream, h->d_x, h->r_x, E.perm, E.N);
+    if (N) CHIP_HIP(hipMemcpyAsync(x, h->d_x, N * sizeof(double), hipMemcpyDeviceToHost, E.stream));
+    CHIP_HIP(hipStreamSynchronize(E.stream));
     return 1;
 }
 

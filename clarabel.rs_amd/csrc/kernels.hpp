@@ -141,6 +141,9 @@ void dblk_symv(hipStream_t s, const DblkView &d, const double *Kx, const double 
 void diag_absmax_eps(hipStream_t s, const double *Kx, const int *diag_idx, int N, double c,
                      double prop, double *scal /*[0]=eps out, uses [1] as scratch*/);
 void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale);
+// Kx[map[t]] += sign[t] * offset (signs == nullptr: +offset) / Kx[map[t]] *= scale over an index set held on the device
+void offset_values(hipStream_t s, double *Kx, const int *map, const int8_t *signs, int k, double offset);
+void scale_values(hipStream_t s, double *Kx, const int *map, int k, double scale);
 
 // ---- numeric LDL' -------------------------------------------------------------
 // fold.k == 1: every bundle also subtracts its share of the single top column's pivot; fold_top_pivot

@@ -160,6 +160,35 @@ int32_t chip_ldl_refactor(chip_ldl *h);
 /* solve(&mut self, kkt, x:&mut[T], b:&mut[T])   mod.rs:24, ldlsolvers/qdldl.rs:91-96.
  * b is left untouched. */
 int32_t chip_ldl_solve(chip_ldl *h, double *x, const double *b);
+/* ---- fast path of the strict drop-in (round 5; opt-in, the calls above keep their meaning) ----------------------
+ * What DirectLDLKKTSolver changes in K per interior-point iteration are the entries of a FEW FIXED index vectors of its
+ * LDLDataMap -- Hsblocks (directldlkktsolver.rs:143), diag_full with Dsigns (:245, :255-261: the static regulariser on and
+ * off), the sparse cones' u / v / D (datamaps.rs:213-219) -- and its iterative refinement (:266-321) needs nothing from
+ * the host but b.  Through the calls above every index vector crosses PCIe with every update (or, with set_values, all of
+ * K.nzval with every refactor), and b / x of every LDL' solve of every refinement round: 352 MB per iteration of
+ * BASELINE config 3.  The fast path:
+ *   chip_ldl_register_index   once per index vector: the set lives on the device (as positions in the engine's value
+ *                             order, with the signs of offset_values if given); returns its id
+ *   chip_ldl_update_values_id / _scale_values_id / _offset_values_id
+ *                             = update_values / scale_values / offset_values on a registered set: 8 bytes per changed entry
+ *                             (update) or nothing but a scalar (scale, offset) cross the boundary.  From the first such call
+ *                             the DEVICE copy is the caller's K.nzval (refactor uploads nothing); plain update / scale /
+ *                             offset calls keep working (they then ship their index vector each time);
+ *                             chip_ldl_set_values makes the host side current again.
+ *   chip_ldl_solve_refined    solve + the refinement loop of directldlkktsolver.rs:266-321, decisions as the reference's,
+ *                             with the handle's CURRENT values as K (i.e. after the caller restored the diagonal):
+ *                             one host-to-device copy of b, one device-to-host copy of x.  ir_settings: the
+ *                             iterative_refinement_* fields are read (NULL: the handle's settings).  Returns 1 ok /
+ *                             0 numerical failure (non-finite residual) / < 0 chip_status; *iterations = rounds taken.
+ *   chip_ldl_pin_buffer       page-locks a caller buffer that is handed to the calls above again and again (the solver's
+ *                             workspace vectors), so that its transfers are direct DMA; unpinned when the handle goes.
+ *                             The buffer must outlive the handle. */
+int32_t chip_ldl_register_index(chip_ldl *h, const uint64_t *index, int64_t k, const int8_t *signs_or_null, int32_t *id_out);
+int32_t chip_ldl_update_values_id(chip_ldl *h, int32_t id, const double *values);
+int32_t chip_ldl_scale_values_id(chip_ldl *h, int32_t id, double scale);
+int32_t chip_ldl_offset_values_id(chip_ldl *h, int32_t id, double offset);
+int32_t chip_ldl_solve_refined(chip_ldl *h, double *x, const double *b, const chip_settings *ir_settings, int32_t *iterations);
+int32_t chip_ldl_pin_buffer(chip_ldl *h, void *ptr, uint64_t bytes);
 /* device-resident variant: x_dev / b_dev are HBM pointers (may alias). */
 int32_t chip_ldl_solve_dev(chip_ldl *h, double *x_dev, const double *b_dev);
 /* linear_solver_info()  kktsolvers/mod.rs:20-24 */

@@ -400,6 +400,77 @@ def test_refactor_sequence_and_update_PA(hip, oracle):
         assert relerr(np.concatenate([x, zz]), np.concatenate([xo, zo])) <= TOL
 
 
+@pytest.mark.parametrize("which", ["qp", "arrow", "supernodes"])
+def test_l1_fast_path_registered_sets_and_device_refinement(hip, oracle, which):
+    """the strict drop-in's fast path (chip_ldl_register_index / *_values_id / chip_ldl_solve_refined / chip_ldl_pin_buffer):
+    the call sequence DirectLDLKKTSolver makes per interior-point iteration -- update_values on the changed entries
+    (directldlkktsolver.rs:143), the static regulariser on (offset_values, :245), refactor, the regulariser off (:255-261),
+    solve with refinement (:266-321) -- through registered index sets and the device-resident refinement, through the plain
+    calls, and mixed on one handle: solutions against the oracle's KKTSolver on the same K, three iterations"""
+    if which == "qp":
+        pr = problems.random_qp(500, 1000, band=10, seed=21)
+    elif which == "arrow":
+        pr = problems.portfolio_socp(6, 120, seed=3)
+    else:
+        pr = problems.random_qp(3000, 6000, band=30, seed=2)
+    ks, ko, cones = _solvers(hip, oracle, pr)
+    rng = np.random.default_rng(8)
+    scal = [(pr["s"] * (1.0 + 0.4 * k), pr["z"] / (1.0 + 0.3 * k)) for k in range(4)]
+    vals = []
+    for s_, z_ in scal[:2]:
+        assert ks.update_scaling(s_, z_) and ks.update()
+        vals.append(ks.values().copy())
+    changed = np.nonzero(vals[0] != vals[1])[0].astype(np.int64)  # (the Hs blocks and the sparse cones' u / v / D entries)
+    assert 0 < len(changed) < ks.nnzK
+    K = ks.kkt_matrix()
+    maps = ks.maps()
+    dsigns, dfull = maps["dsigns"], maps["diag_full"]
+    N = ks.N
+    mk = lambda: hip.HipDirectLDLSolver(hip.CscMatrix(N, N, K.colptr, K.rowval, vals[1]), dsigns, hip.Settings.default(), perm=ks.perm)
+    fast, plain = mk(), mk()
+    id_upd = fast.register_index(changed)
+    id_diag = fast.register_index(dfull, signs=dsigns)
+    xbuf, bbuf = np.zeros(N), np.zeros(N)
+    fast.pin_buffer(xbuf)
+    fast.pin_buffer(bbuf)
+    for it, (s_, z_) in enumerate(scal):
+        assert ks.update_scaling(s_, z_) and ks.update()
+        assert cones.update_scaling(s_, z_) and ko.update()
+        v = ks.values()
+        eps = float(ks.linear_solver_info().last_regularizer)
+        b = np.concatenate([rng.standard_normal(pr["n"] + pr["m"]), np.zeros(N - pr["n"] - pr["m"])])
+        okr, xr = ko.solve_full(b)
+        assert okr
+        # -- registered sets (iteration 2: the update through the PLAIN call on the same handle, index shipped)
+        if it == 2:
+            fast.update_values(changed, v[changed])
+        else:
+            fast.update_values_id(id_upd, v[changed])
+        fast.offset_values_id(id_diag, eps)
+        assert fast.refactor()
+        fast.offset_values_id(id_diag, -eps)
+        bbuf[:] = b
+        ok, rounds = fast.solve_refined(xbuf, bbuf)
+        assert ok and relerr(xbuf, xr) <= TOL, (it, rounds)
+        # -- the same through the plain calls + the device-resident refinement
+        plain.update_values(changed, v[changed])
+        plain.offset_values(dfull, eps, dsigns)
+        assert plain.refactor()
+        plain.offset_values(dfull, -eps, dsigns)
+        x2 = np.zeros(N)
+        ok2, _ = plain.solve_refined(x2, b)
+        assert ok2 and relerr(x2, xr) <= TOL
+        # -- and the refinement's settings: one round fixed / none (the raw LDL' solve of the regularised system)
+        st1 = hip.Settings.default(iterative_refinement_max_iter=1, iterative_refinement_reltol=0.0, iterative_refinement_abstol=0.0)
+        ok3, r3 = fast.solve_refined(xbuf, bbuf, st1)
+        assert ok3 and r3 == 1 and relerr(xbuf, xr) <= 1e-7
+        x4 = np.zeros(N)
+        fast.solve(None, x4, b)
+        st0 = hip.Settings.default(iterative_refinement_enable=0)
+        ok5, r5 = fast.solve_refined(xbuf, bbuf, st0)
+        assert ok5 and r5 == 0 and relerr(xbuf, x4) <= 1e-13
+
+
 def test_ir_fixed_one_round(hip, oracle):
     """the benchmark's refinement setting: max_iter=1, tolerances 0 => exactly one extra
     round, same on both sides"""

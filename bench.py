@@ -978,6 +978,8 @@ def main():
         extras = {}
         step_ms = getattr(w, "step_ms", None)
         w_repeats = w.repeats  # (solves repeated at collect time after a fused launch timed out: 0 in a clean run)
+        w_events_pass = getattr(w, "events_pass", None)
+        w_fallbacks = int(w.ks.fused_fallbacks())
         if world > 1:
             parity = parity_sharded
         elif not args.no_extras and workload == "c5":
@@ -1032,7 +1034,7 @@ def main():
                                          "1 x all-gather of the step direction (the last solve's solution)",
                                          int(sum(counts)))) if comm is not None else "none"},
             "step_ms": step_ms,
-            "roofline_events_pass": getattr(w, "events_pass", None),
+            "roofline_events_pass": w_events_pass,
             "roofline": roof, "parity": parity, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt, "batched_c4": c4,
             "c2": extras.get("c2"), "c5": extras.get("c5"), "l1_dropin": extras.get("l1_dropin"),
             "other_exchange_policy": other_policy,
@@ -1043,7 +1045,7 @@ def main():
                         "kernel of %s workgroups x 256 threads spinning for %s us per step on its own stream -- what RCCL's ring "
                         "kernel occupies next to the persistent launches at N = 8" % tuple(args.coresident.split(":")),
                 "ms_per_step": round(ms_per_step, 4), "fused_launch_repeats": int(w_repeats),
-                "fused_fallbacks": int(w.ks.fused_fallbacks())},
+                "fused_fallbacks": w_fallbacks},
         }
         print(json.dumps(out))
         sys.stdout.flush()

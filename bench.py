@@ -106,6 +106,10 @@ class Workload:
         self.gather_every_solve = False
         self.repeats = 0   # solves repeated at collect time after a fused launch timed out (chip_kkt_collect: 2)
         self.coresident = None  # (blocks, usec, device): see --coresident
+        # the first two of an iteration's three solves do not depend on each other (the constant right-hand side of
+        # kktsystem.rs:108-125 and the affine direction of core/solver.rs:351-361): they go to the device as ONE call,
+        # chip_kkt_solve2_dev_enqueue; the third (the combined direction) depends on the affine result.  False: three calls.
+        self.pair = nrhs == 3
 
     def step(self, comm=None, gathered=None, counts=None):
         # one interior-point iteration's KKT work is ENQUEUED as a whole; the reference's bools (update:
@@ -115,7 +119,15 @@ class Workload:
         # (cones.update_scaling + kktsystem.update's KKT part, core/solver.rs:334-352, as one enqueue)
         ks.update_scaled_enqueue(self.s_d.ptr, self.z_d.ptr)
         last = len(self.rhs) - 1
+        first = 0
+        if self.pair and not (comm is not None and self.gather_every_solve):
+            (ra, za), (rb, zb) = self.rhs[0], self.rhs[1]
+            ks.solve2_dev_enqueue(ra.ptr, za.ptr, self.lhs[0].ptr, self.lhs[0].ptr + 8 * self.n,
+                                  rb.ptr, zb.ptr, self.lhs[1].ptr, self.lhs[1].ptr + 8 * self.n)
+            first = 2
         for k, (rx, rz) in enumerate(self.rhs):
+            if k < first:
+                continue
             exchange = comm is not None and (self.gather_every_solve or k == last)
             if exchange:
                 # lhs[k] / gathered[k] were handed to the all-gather one step ago: this stream waits
@@ -170,6 +182,21 @@ class Workload:
         self.step_ms = {"min": round(float(d.min()), 4), "median": round(float(np.median(d)), 4),
                         "max": round(float(d.max()), 4)} if len(d) else None
         self.events_pass = None
+        self.sequential = None
+        if not events_in_timed_region and self.pair:
+            # (level-scheduled systems: the paired call overlaps two chains of launches on two streams; the same steps with three
+            # separate solve calls, for the line's other policy)
+            self.pair = False
+            for _ in range(min(2, warmup)):
+                self.step(comm, gathered, counts)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                self.step(comm, gathered, counts)
+            sync()
+            self.sequential = {"policy": "1 update + 3 separate solve calls", "steps": steps,
+                               "ms_per_step": round(1e3 * (time.perf_counter() - t1) / steps, 4)}
+            self.pair = True
         if not events_in_timed_region and profile_family:
             self.ks.profile(profile_family)
             t1 = time.perf_counter()
@@ -535,7 +562,8 @@ def extra_workload(hip, problems, which, args, device):
         else:
             parity = fixture_parity_c5(w, hip)
         out = {"workload": desc, "value": round(steps / el, 3), "unit": "iterations/s", "ms_per_step": round(ms, 4),
-               "steps": steps, "step_ms": w.step_ms, "roofline_events_pass": w.events_pass, "kkt_dim": ks.N, "nnz_L": int(info.nnzL), "setup_s": round(w.t_setup, 2),
+               "steps": steps, "step_ms": w.step_ms, "roofline_events_pass": w.events_pass,
+               "per_step": "1 update + (2 paired + 1) solves, one refinement round each", "other_solve_policy": w.sequential, "kkt_dim": ks.N, "nnz_L": int(info.nnzL), "setup_s": round(w.t_setup, 2),
                "roofline": roof, "whole_step_frac_of_hbm_peak": whole,
                "parity": None if parity is None else {k: parity[k] for k in ("rel_err_vs_oracle", "tol", "ok") if k in parity},
                "cpu_baseline": cpu, "cpu_baseline_mt": None if args.cpu_steps == 0 else sn_leg(w, hip)}
@@ -979,6 +1007,7 @@ def main():
         step_ms = getattr(w, "step_ms", None)
         w_repeats = w.repeats  # (solves repeated at collect time after a fused launch timed out: 0 in a clean run)
         w_events_pass = getattr(w, "events_pass", None)
+        w_sequential = getattr(w, "sequential", None)
         w_fallbacks = int(w.ks.fused_fallbacks())
         if world > 1:
             parity = parity_sharded
@@ -1025,7 +1054,10 @@ def main():
             "config": {"workload": desc, "kkt_dim": ks.N * world if workload == "c4" else ks.N,
                        "kkt_dim_per_gpu": ks.N, "nnz_triu_K": ks.nnzK, "nnz_L": int(info.nnzL),
                        "etree_levels": int(info.n_levels),
-                       "per_step": "1 update(scaling+Hs+static reg+refactor) + 3 solves x (LDL solve + 1 IR round)",
+                       "per_step": "1 update(scaling+Hs+static reg+refactor) + (2 paired + 1) solves x (LDL solve + 1 IR round): the constant "
+                                   "right-hand side and the affine direction are independent and go to the device as one call "
+                                   "(chip_kkt_solve2_dev_enqueue); the combined direction depends on the affine result",
+                       "other_solve_policy": w_sequential,
                        "ir_rounds": int(ir), "setup_s": round(t_setup, 2),
                        "gpus_on_problem": int(info.threads) if world == 1 else world,
                        "collective": "FILE-BASED STAND-IN on one GPU (--fake-comm): a plumbing check, NOT a measurement" if args.fake_comm else

@@ -540,6 +540,12 @@ class HipKKTSolver:
     def solve_dev_enqueue(self, x_ptr, z_ptr):
         _check(lib().chip_kkt_solve_dev_enqueue(self._h, C.c_void_p(x_ptr), C.c_void_p(z_ptr)), "solve_dev_enqueue")
 
+    def solve2_dev_enqueue(self, rxa, rza, lxa, lza, rxb, rzb, lxb, lzb):
+        """two independent solves as one call (chip_kkt_solve2_dev_enqueue): device pointers of the two right-hand sides
+        and of the two results"""
+        args = [C.c_void_p(int(p)) for p in (rxa, rza, lxa, lza, rxb, rzb, lxb, lzb)]
+        _check(lib().chip_kkt_solve2_dev_enqueue(self._h, *args), "solve2_dev_enqueue")
+
     def collect(self):
         """-> (update_ok, [solve_ok, ...]) of everything enqueued since the last collect; one synchronisation.
         self.repeated_solves: indices (into that list) of solves whose fused launch timed out and that collect repeated

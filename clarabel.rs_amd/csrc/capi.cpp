@@ -98,6 +98,8 @@ struct chip_kkt {
     double *d_s = nullptr, *d_z = nullptr, *d_w = nullptr, *d_lam = nullptr;
     double *d_rhs = nullptr, *d_lhs = nullptr; // n+m staging
     double *bp = nullptr, *x = nullptr, *e = nullptr, *dx = nullptr; // N, permuted numbering
+    double *bp2 = nullptr, *x2 = nullptr, *e2 = nullptr, *dx2 = nullptr; // ... of the second solve of a pair (chip_kkt_solve2_dev_enqueue)
+    int last_ir2 = 0;
     double *d_tmp = nullptr;                                         // max(N, nHs, nnzP, nnzA) staging
     size_t tmp_len = 0;
     int last_ir = 0;
@@ -989,12 +991,29 @@ int32_t chip_kkt_setrhs(chip_kkt *h, const double *rhsx, const double *rhsz) {
 // renames (x, e, w) <- (e, w, x): the reference's mem::swap(x, dx) without moving data.
 // (the refinement loop itself, shared by the L2 handle and by chip_ldl_solve_refined: xio / eio / wio are the three work
 // vectors and come back renamed; x holds K^-1 bp's first approximation on entry)
-static int refine_core(Engine &E, const double *bp, double *&xio, double *&eio, double *&wio, int &last_ir) {
+// (in two halves, so that two independent solves can be enqueued on two streams before either is waited for)
+static void refine_begin(Engine &E, const double *bp, double *x, double *e, double *w) {
     const chip_settings &st = E.st;
-    const int N = E.N;
+    if (!st.iterative_refinement_enable) {
+        dev::norm_inf(E.stream, x, E.N, E.norm_set(1), E.norm_nan(1));
+        return;
+    }
+    // The first refinement round is enqueued SPECULATIVELY together with the initial residual,
+    // so that one host synchronisation (one D2H copy of norm sets 0..2) serves both decisions of
+    // directldlkktsolver.rs:288-318; if ||e0|| already meets the tolerance the speculative
+    // candidate is simply never looked at.  Decisions are exactly the reference's.
+    E.enqueue_residual(e, bp, x, 1);
+    if (st.iterative_refinement_max_iter >= 1) {
+        // w <- e0 is needed if the round is rejected?  No: a rejected round leaves x untouched and e
+        // is dead afterwards, so e is solved in place.
+        E.enqueue_solve_inplace(e, x); // e <- x + K^-1 e0   (the candidate; "+ x" fused into the sweep)
+        E.enqueue_residual(w, bp, e, 2);
+    }
+}
+static int refine_finish(Engine &E, const double *bp, double *&xio, double *&eio, double *&wio, int &last_ir) {
+    const chip_settings &st = E.st;
     int rc;
     if (!st.iterative_refinement_enable) {
-        dev::norm_inf(E.stream, xio, N, E.norm_set(1), E.norm_nan(1));
         double nx;
         if ((rc = E.read_norm(1, &nx))) return rc;
         return std::isfinite(nx) ? 1 : 0; // x.is_finite(), directldlkktsolver.rs:180
@@ -1003,17 +1022,6 @@ static int refine_core(Engine &E, const double *bp, double *&xio, double *&eio, 
     const double abstol = st.iterative_refinement_abstol, reltol = st.iterative_refinement_reltol;
     const double stopratio = st.iterative_refinement_stop_ratio;
     const int maxiter = st.iterative_refinement_max_iter;
-    // The first refinement round is enqueued SPECULATIVELY together with the initial residual,
-    // so that one host synchronisation (one D2H copy of norm sets 0..2) serves both decisions of
-    // directldlkktsolver.rs:288-318; if ||e0|| already meets the tolerance the speculative
-    // candidate is simply never looked at.  Decisions are exactly the reference's.
-    E.enqueue_residual(e, bp, x, 1);
-    if (maxiter >= 1) {
-        // w <- e0 is needed if the round is rejected?  No: a rejected round leaves x untouched and e
-        // is dead afterwards, so e is solved in place.
-        E.enqueue_solve_inplace(e, x); // e <- x + K^-1 e0   (the candidate; "+ x" fused into the sweep)
-        E.enqueue_residual(w, bp, e, 2);
-    }
     double nn[3] = {0, 0, 0};
     if ((rc = E.read_norms(0, maxiter >= 1 ? 3 : 2, nn))) return rc;
     const double normb = nn[0];
@@ -1050,6 +1058,10 @@ static int refine_core(Engine &E, const double *bp, double *&xio, double *&eio, 
     eio = e;
     wio = w;
     return 1;
+}
+static int refine_core(Engine &E, const double *bp, double *&xio, double *&eio, double *&wio, int &last_ir) {
+    refine_begin(E, bp, xio, eio, wio);
+    return refine_finish(E, bp, xio, eio, wio, last_ir);
 }
 static int solve_core(chip_kkt *h) {
     Engine &E = h->E;
@@ -1435,6 +1447,78 @@ int32_t chip_kkt_solve_dev_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_d
     const int ok = chip_kkt_solve_dev(h, lhsx_dev, lhsz_dev);
     if (ok < 0) return ok;
     h->pend_slots.push_back(-1 - ok); // -1 = failed, -2 = succeeded (already known)
+    return CHIP_OK;
+}
+// Two INDEPENDENT solves of one interior-point iteration -- K x = [-q; b] of kktsystem.rs:108-125 (it does not depend on
+// the residuals) and the affine direction of core/solver.rs:351-361 -- as one call.  Systems whose top is level-scheduled
+// (a sweep = a chain of small launches, refinement decisions on the host) run them on two streams: both chains are
+// enqueued before either is waited for, and the device overlaps them; the third solve of the iteration (the combined
+// direction) depends on the affine result and stays a call of its own.  Fused handles (one persistent launch per solve,
+// which fills the chip) run the two launches one after the other.  Same results as two chip_kkt_solve_dev_enqueue calls;
+// two verdicts are appended for chip_kkt_collect.
+int32_t chip_kkt_solve2_dev_enqueue(chip_kkt *h, const double *rhsx_a, const double *rhsz_a, double *lhsx_a, double *lhsz_a,
+                                    const double *rhsx_b, const double *rhsz_b, double *lhsx_b, double *lhsz_b) {
+    if (!h) return CHIP_ERR_ARG;
+    Engine &E = h->E;
+    NEED_DEVICE(E);
+    CHIP_HIP(hipSetDevice(E.device));
+    if ((int)h->pend_slots.size() + 2 > Engine::IR_RING) return fail(CHIP_ERR_ARG, "solve2_dev_enqueue: 16 solves pending, collect first");
+    int rc;
+    if (E.ir_fused || !E.pair_ok() || switches().no_solve_pair || E.prof_family != PF_NONE) { // (one after the other)
+        if ((rc = chip_kkt_setrhs_dev(h, rhsx_a, rhsz_a))) return rc;
+        if ((rc = chip_kkt_solve_dev_enqueue(h, lhsx_a, lhsz_a))) return rc;
+        if ((rc = chip_kkt_setrhs_dev(h, rhsx_b, rhsz_b))) return rc;
+        return chip_kkt_solve_dev_enqueue(h, lhsx_b, lhsz_b);
+    }
+    if (h->pend_update) { // the refinement decisions need the host: the pending update's verdict first
+        h->pend_update = 2;
+        h->pend_update_ok = update_verdict(h, E.refactor_collect());
+        if (h->pend_update_ok != 1) {
+            h->pend_slots.push_back(-1);
+            h->pend_slots.push_back(-1);
+            return CHIP_OK;
+        }
+    }
+    if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
+    const size_t N = (size_t)E.N;
+    if (!h->bp2) {
+        if ((rc = E.alloc(&h->bp2, N))) return rc;
+        if ((rc = E.alloc(&h->x2, N))) return rc;
+        if ((rc = E.alloc(&h->e2, N))) return rc;
+        if ((rc = E.alloc(&h->dx2, N))) return rc;
+    }
+    if ((rc = E.pair_begin())) return rc;
+    const int n = (int)h->K.n, m = (int)h->K.m;
+    h->last_ir = h->last_ir2 = 0;
+    h->rhs_deferred = false;
+    h->x_holds_b = false;
+    // ---- both chains enqueued: A on the engine's stream, B on the second one
+    if ((rc = E.zero_norm_sets())) return rc;
+    dev::setrhs_perm(E.stream, h->bp, h->x, rhsx_a, rhsz_a, E.perm, n, m, E.N, E.norm_set(0), E.norm_nan(0));
+    E.enqueue_solve_inplace(h->x);
+    refine_begin(E, h->bp, h->x, h->e, h->dx);
+    E.swap_ctx();
+    rc = E.zero_norm_sets();
+    if (!rc) {
+        dev::setrhs_perm(E.stream, h->bp2, h->x2, rhsx_b, rhsz_b, E.perm, n, m, E.N, E.norm_set(0), E.norm_nan(0));
+        E.enqueue_solve_inplace(h->x2);
+        refine_begin(E, h->bp2, h->x2, h->e2, h->dx2);
+    }
+    E.swap_ctx();
+    if (rc) return rc;
+    // ---- decisions (and any further rounds) of A, then of B
+    const int oka = refine_finish(E, h->bp, h->x, h->e, h->dx, h->last_ir);
+    if (oka == 1) dev::getlhs_perm(E.stream, lhsx_a, lhsz_a, h->x, E.iperm, n, m);
+    E.swap_ctx();
+    const int okb = refine_finish(E, h->bp2, h->x2, h->e2, h->dx2, h->last_ir2);
+    if (okb == 1) dev::getlhs_perm(E.stream, lhsx_b, lhsz_b, h->x2, E.iperm, n, m);
+    const hipError_t se = hipStreamSynchronize(E.stream); // (the second stream: its results are complete when this call returns)
+    E.swap_ctx();
+    if (se != hipSuccess) return fail(CHIP_ERR_HIP, hip_err(se, "second solve stream"));
+    if (oka < 0) return oka;
+    if (okb < 0) return okb;
+    h->pend_slots.push_back(-1 - oka);
+    h->pend_slots.push_back(-1 - okb);
     return CHIP_OK;
 }
 int32_t chip_kkt_collect(chip_kkt *h, int32_t *update_ok, int32_t *nsolves, int32_t solves_ok[16]) {

@@ -21,7 +21,11 @@ Engine::~Engine() {
     for (SolveGraph &g : graphs) (void)hipGraphExecDestroy(g.exec);
     for (void *p : allocs) (void)hipFree(p);
     if (mb_host) (void)hipHostFree(mb_host);
+    if (alt_active) swap_ctx();
     if (nrm_host) (void)hipHostFree(nrm_host);
+    if (alt.nrm_host) (void)hipHostFree(alt.nrm_host);
+    if (alt.stream) (void)hipStreamDestroy(alt.stream);
+    if (pair_event) (void)hipEventDestroy(pair_event);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -822,6 +826,58 @@ void Engine::prof_collect() {
         }
     }
     prof_used = 0;
+}
+
+int Engine::ensure_alt() {
+    if (alt_ready) return CHIP_OK;
+    int rc;
+    CHIP_HIP(hipStreamCreateWithFlags(&alt.stream, hipStreamNonBlocking));
+    CHIP_HIP(hipEventCreateWithFlags(&pair_event, hipEventDisableTiming));
+    const size_t n = (size_t)N;
+    if (sn_yt) {
+        if ((rc = alloc(&alt.sn_yt, n))) return rc;
+        CHIP_HIP(hipMemset(alt.sn_yt, 0, n * sizeof(double)));
+    }
+    if (xs_view && (rc = alloc(&alt.xs_view, n))) return rc;
+    if (bt_view && (rc = alloc(&alt.bt_view, n))) return rc;
+    if (dblk.P && (rc = alloc(&alt.dblk_P, (size_t)dblk.nrows * dblk.split))) return rc;
+    if ((rc = alloc(&alt.nrm_dev, (size_t)NRM_SETS * NRM_SET_WORDS))) return rc;
+    CHIP_HIP(hipMemset(alt.nrm_dev, 0, (size_t)NRM_SETS * NRM_SET_WORDS * sizeof(unsigned long long)));
+    CHIP_HIP(hipHostMalloc((void **)&alt.nrm_host, 3 * NRM_SET_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    if (sn_flags && nsn > 0) {
+        size_t blocks = 0;
+        for (int sn = 0; sn < nsn; sn++) blocks += (size_t)(h_sn_ptr[sn + 1] - h_sn_ptr[sn] + 63) / 64;
+        if ((rc = alloc(&alt.sn_flags, (blocks + 1) * 256))) return rc;
+        CHIP_HIP(hipMemset(alt.sn_flags, 0, (blocks + 1) * 256 * sizeof(int)));
+    }
+    alt_ready = true;
+    return CHIP_OK;
+}
+void Engine::swap_ctx() {
+    std::swap(stream, alt.stream);
+    std::swap(sn_yt, alt.sn_yt);
+    std::swap(xs_view, alt.xs_view);
+    std::swap(bt_view, alt.bt_view);
+    std::swap(dblk.P, alt.dblk_P);
+    std::swap(nrm_dev, alt.nrm_dev);
+    std::swap(nrm_host, alt.nrm_host);
+    std::swap(sn_flags, alt.sn_flags);
+    alt_active = !alt_active;
+}
+int Engine::pair_begin() {
+    int rc = ensure_alt();
+    if (rc) return rc;
+    if (!rx_valid) {
+        dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzR);
+        rx_valid = true;
+    }
+    if (!fold.k && !sx_valid) {
+        dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
+        sx_valid = true;
+    }
+    CHIP_HIP(hipEventRecord(pair_event, stream));
+    CHIP_HIP(hipStreamWaitEvent(alt.stream, pair_event, 0));
+    return CHIP_OK;
 }
 
 dev::SnodeView Engine::snode_view() const {

@@ -211,6 +211,25 @@ struct Engine {
     void prof_pair(int family, hipEvent_t *ev0, hipEvent_t *ev1);
     void prof_collect();
     dev::SnodeView snode_view() const;
+    // ---- a second solve context (round 5): two INDEPENDENT solves of an interior-point iteration (the constant right-hand side
+    // of kktsystem.rs:108-125 and the affine direction of core/solver.rs:351-361) enqueued on two streams.  On systems whose
+    // top is level-scheduled a sweep is a chain of small launches that leave most of the chip idle; two such chains overlap.
+    // Everything a solve writes besides its own vectors lives here and is swapped with the engine's members by swap_ctx().
+    struct SolveCtx {
+        hipStream_t stream = nullptr;
+        double *sn_yt = nullptr, *xs_view = nullptr, *bt_view = nullptr, *dblk_P = nullptr;
+        unsigned long long *nrm_dev = nullptr, *nrm_host = nullptr;
+        int *sn_flags = nullptr;
+    };
+    SolveCtx alt;
+    bool alt_ready = false, alt_active = false;
+    hipEvent_t pair_event = nullptr;
+    bool pair_ok() const { return !ir_fused && fold.k == 0 && gfold.ng == 0 && topblk.nblocks == 0; } // (no shared accumulators)
+    int ensure_alt();
+    void swap_ctx();
+    // makes the second stream wait for everything enqueued on the first one so far (the refactor), after the value mirrors a
+    // solve reads lazily (Rx, Sx) have been refreshed on the first stream
+    int pair_begin();
     dev::LaunchProf launch_prof(); // hook handed to the launchers in snode.hip (nullptr-equivalent when off)
     // work model of the chain supernodes, per refactor / per sweep (host.hpp: Symbolic::sn_*), for the roofline
     // figures of bench.py: [0] multiply-add flops of k_snode_update (2 per multiply-add, useful part of the

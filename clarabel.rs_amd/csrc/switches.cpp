@@ -72,6 +72,7 @@ const Entry TABLE[] = {
     {"CHIP_EXTEND_ASM_MIN", Entry::INT, SW(extend_asm_min), 0},
     {"CHIP_NO_XCD_MAP", Entry::FLAG, SW(no_xcd_map), 0},
     {"CHIP_SN_ASM_CAP", Entry::INT, SW(sn_asm_cap), 0},
+    {"CHIP_NO_SOLVE_PAIR", Entry::FLAG, SW(no_solve_pair), 0},
     {"CHIP_NO_SWEEP_MERGE", Entry::FLAG, SW(no_sweep_merge), 0},
     {"CHIP_NO_SNODE_G", Entry::FLAG, SW(no_snode_g), 0},
     {"CHIP_SN_G_MAXW", Entry::INT, SW(sn_g_maxw), 0},

@@ -69,6 +69,7 @@ struct Switches {
     int extend_asm_min = 0;         // CHIP_EXTEND_ASM_MIN: fewest supernodes of a level whose updates are assembled (0: never, unless CHIP_DETERMINISTIC)
     bool no_xcd_map = false;        // CHIP_NO_XCD_MAP: the tiles of k_snode_extend spread over the XCDs, not one supernode per XCD
     int sn_asm_cap = 0;             // CHIP_SN_ASM_CAP: rows of a target column per LDS window of k_snode_assemble (tests; 0: 4096)
+    bool no_solve_pair = false;     // CHIP_NO_SOLVE_PAIR: chip_kkt_solve2_dev_enqueue runs its two solves one after the other on every handle
     bool no_sweep_merge = false;    // CHIP_NO_SWEEP_MERGE: the row gathers of a unit level in their own launch, also next to supernodes on the one-pass matrices
     bool no_snode_g = false;        // CHIP_NO_SNODE_G: no one-pass substitution matrices G = [I; L_B] T^-1 (snode_g.hip): every supernode keeps the pipelined substitution
     int sn_g_maxw = 0;              // CHIP_SN_G_MAXW: widest supernode that takes the G path (0: the kernels' limit, 512)

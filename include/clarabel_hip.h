@@ -280,6 +280,15 @@ int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev_or_null, double *lhsz_d
  *                               must be re-issued by the caller; the repeat itself read the right-hand side buffers
  *                               as they were at collect time.  Returns CHIP_OK or a negative chip_status. */
 int32_t chip_kkt_update_enqueue(chip_kkt *h, const double *hsblocks_or_null);
+/* chip_kkt_solve2_dev_enqueue (round 5): TWO INDEPENDENT solves of one interior-point iteration as one call -- the constant
+ * right-hand side [-q; b] inside kktsystem.update (default/kktsystem.rs:108-125) and the affine direction
+ * (core/solver.rs:351-361) do not depend on each other; only the combined direction depends on the affine result and stays a
+ * call of its own (per iteration: 1 update + (2 paired + 1) solves).  Equivalent to setrhs_dev + solve_dev_enqueue twice (two
+ * verdicts for chip_kkt_collect, in this order).  On systems whose top is level-scheduled the two chains of launches are
+ * enqueued on two streams before either is waited for and overlap on the device; fused handles run their two persistent
+ * launches one after the other. */
+int32_t chip_kkt_solve2_dev_enqueue(chip_kkt *h, const double *rhsx_a, const double *rhsz_a, double *lhsx_a, double *lhsz_a,
+                                    const double *rhsx_b, const double *rhsz_b, double *lhsx_b, double *lhsz_b);
 /* chip_kkt_update_scaling_dev + chip_kkt_update_enqueue as ONE enqueue (core/solver.rs:334-352 calls
  * cones.update_scaling and kktsystem.update back to back): with Zero / Nonnegative / SecondOrder cones the scaling
  * and the Hs / sparse-cone writes of a cone run in one launch and the refactor's preparation launches are folded

@@ -471,6 +471,59 @@ def test_l1_fast_path_registered_sets_and_device_refinement(hip, oracle, which):
         assert ok5 and r5 == 0 and relerr(xbuf, x4) <= 1e-13
 
 
+@pytest.mark.parametrize("which", ["qp_supernodes", "chordal_sdp", "arrow", "forest", "general"])
+def test_paired_solves_match_separate_solves(hip, oracle, which, monkeypatch):
+    """chip_kkt_solve2_dev_enqueue: the two independent solves of an interior-point iteration (constant right-hand side,
+    affine direction) as one call -- on level-scheduled systems enqueued on two streams and overlapped -- against the
+    oracle's two solves and against two separate calls (bitwise on the deterministic kernels, to rounding where sweeps
+    use atomics); three iterations, default refinement and the refinement switched off; CHIP_NO_SOLVE_PAIR: one after
+    the other"""
+    hs = None
+    if which == "qp_supernodes":
+        pr = problems.random_qp(20000, 40000, band=50, seed=1)
+    elif which == "chordal_sdp":
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    elif which == "arrow":
+        pr = problems.portfolio_socp(12, 300, seed=3)
+    elif which == "forest":
+        pr = problems.blockdiag([problems.portfolio_socp(2 + (i % 3), 120 + 40 * (i % 4), seed=100 + i) for i in range(14)])
+    else:
+        pr = problems.mixed_conic(nexp=20, npow=10, nsoc=3, socdim=9, nn=30, seed=11)
+    n, m = pr["n"], pr["m"]
+    for env, st in ((None, None), ("CHIP_NO_SOLVE_PAIR", None), (None, hip.Settings.default(iterative_refinement_enable=0))):
+        if env:
+            monkeypatch.setenv(env, "1")
+        ks, ko, cones = _solvers(hip, oracle, pr, settings=st)
+        if env:
+            monkeypatch.delenv(env)
+        rng = np.random.default_rng(4)
+        outs = [hip.DeviceArray(n + m) for _ in range(4)]
+        for it in range(3):
+            s_, z_ = pr["s"] * (1.0 + 0.3 * it), pr["z"] / (1.0 + 0.2 * it)
+            assert ks.update_scaling(s_, z_) and ks.update(hs)
+            assert cones.update_scaling(s_, z_) and ko.update(hs)
+            rhs = [(rng.standard_normal(n), rng.standard_normal(m)) for _ in range(2)]
+            dev = [(hip.DeviceArray(a), hip.DeviceArray(b)) for a, b in rhs]
+            ks.solve2_dev_enqueue(dev[0][0].ptr, dev[0][1].ptr, outs[0].ptr, outs[0].ptr + 8 * n,
+                                  dev[1][0].ptr, dev[1][1].ptr, outs[1].ptr, outs[1].ptr + 8 * n)
+            uok, sok = ks.collect()
+            assert uok and sok == [True, True]
+            for k in range(2):  # the same two solves as separate calls on the same handle
+                ks.setrhs_dev(dev[k][0].ptr, dev[k][1].ptr)
+                ks.solve_dev_enqueue(outs[2 + k].ptr, outs[2 + k].ptr + 8 * n)
+            uok, sok = ks.collect()
+            assert uok and sok == [True, True]
+            for k in range(2):
+                ko.setrhs(*rhs[k])
+                ok, xo, zo = ko.solve()
+                assert ok
+                ref = np.concatenate([xo, zo])
+                tol = TOL if st is None else 1e-5
+                assert relerr(outs[k].numpy(), ref) <= tol, (which, env, it, k)
+                assert relerr(outs[k].numpy(), outs[2 + k].numpy()) <= (1e-10 if st is None else 1e-7)
+
+
 def test_ir_fixed_one_round(hip, oracle):
     """the benchmark's refinement setting: max_iter=1, tolerances 0 => exactly one extra
     round, same on both sides"""

@@ -500,9 +500,11 @@ def test_paired_solves_match_separate_solves(hip, oracle, which, monkeypatch):
         rng = np.random.default_rng(4)
         outs = [hip.DeviceArray(n + m) for _ in range(4)]
         for it in range(3):
-            s_, z_ = pr["s"] * (1.0 + 0.3 * it), pr["z"] / (1.0 + 0.2 * it)
+            # (host-supplied Hs blocks belong to the problem's own (s, z): that instance keeps its scaling point)
+            s_, z_ = (pr["s"], pr["z"]) if hs is not None else (pr["s"] * (1.0 + 0.3 * it), pr["z"] / (1.0 + 0.2 * it))
             assert ks.update_scaling(s_, z_) and ks.update(hs)
             assert cones.update_scaling(s_, z_) and ko.update(hs)
+            assert relerr(ks.values(), ko.kkt.nzval) <= 1e-13
             rhs = [(rng.standard_normal(n), rng.standard_normal(m)) for _ in range(2)]
             dev = [(hip.DeviceArray(a), hip.DeviceArray(b)) for a, b in rhs]
             ks.solve2_dev_enqueue(dev[0][0].ptr, dev[0][1].ptr, outs[0].ptr, outs[0].ptr + 8 * n,

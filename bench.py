@@ -139,7 +139,11 @@ class Workload:
                 # every rank ends up with the full step direction (dx, dz): RCCL all-gather over xGMI,
                 # enqueued behind this solve by an event and left running behind the next solves
                 comm.allgather_step(ks, self.lhs[k].ptr, gathered[k].ptr, counts)
-                if self.coresident:
+            if k == last and self.coresident:
+                if exchange and hasattr(comm, "debug_spin"):
+                    # on the communicator's stream, behind the all-gather: the time RCCL's kernel would hold CUs at N = 8
+                    comm.debug_spin(self.coresident[0], 256, self.coresident[1])
+                else:  # (no communicator: a foreign kernel on a stream of its own, with no ordering at all)
                     self.hip.debug_spin(self.coresident[2], self.coresident[0], 256, 0, self.coresident[1])
         uok, sok = ks.collect()
         if not uok or len(sok) != len(self.rhs) or not all(sok):

@@ -778,6 +778,11 @@ class Comm:
         """kkt's stream waits on the device for the last all-gather"""
         _check(lib().chip_kkt_wait_comm(kkt._h, self._h), "wait_comm")
 
+    def debug_spin(self, blocks, threads=256, usec=60.0):
+        """test hook: a spinner on the communicator's stream behind the last collective (chip_comm_debug_spin)"""
+        lib().chip_comm_debug_spin.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double]
+        _check(lib().chip_comm_debug_spin(self._h, blocks, threads, float(usec)), "comm_debug_spin")
+
     def synchronize(self):
         _check(lib().chip_comm_synchronize(self._h), "comm_synchronize")
 

@@ -129,6 +129,13 @@ struct chip_kkt {
     static constexpr bool ir_test_drop = false;
 #endif
     int world = 1;               // ranks sharing the problem (chip_kkt_attach_comm)
+    // the exchange of the sharded path runs on the communicator's stream, overlapped with what this handle enqueues next:
+    // the cone update and the factorisation may run beside its kernels, a PERSISTENT solve launch may not -- its grid fills
+    // every register slot of the chip, and a foreign wave that is resident while it starts leaves the register file
+    // fragmented, so that some of its workgroups can never become resident (measured: a one-workgroup kernel of 60 us next
+    // to k_gstep_solve made every solve run into its wait budget).  The next fused launch waits for this event on the device.
+    hipEvent_t exch_event = nullptr;
+    bool exch_pending = false;
     double *d_partial = nullptr; // per-block partial minima / sums of the cone reductions
     int partial_cap = 0;
     std::vector<double> h_partial;
@@ -292,6 +299,10 @@ namespace chip {
 int kkt_device(const ::chip_kkt *h) { return h->E.device; }
 hipStream_t kkt_stream(::chip_kkt *h) { return h->E.host_only ? nullptr : h->E.stream; }
 void kkt_set_world(::chip_kkt *h, int world) { h->world = world; }
+void kkt_note_exchange(::chip_kkt *h, hipEvent_t done) {
+    h->exch_event = done;
+    h->exch_pending = done != nullptr;
+}
 bool kkt_host_only(const ::chip_kkt *h) { return h->E.host_only; }
 } // namespace chip
 }
@@ -1330,6 +1341,10 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     }
     ir.test_drop = h->ir_test_drop ? 1 : 0;
     ir.flat = switches().no_flat ? 0 : 1;
+    if (h->exch_pending) { // (see chip_kkt::exch_event: no foreign kernel of ours beside a persistent launch)
+        (void)hipStreamWaitEvent(E.stream, h->exch_event, 0);
+        h->exch_pending = false;
+    }
     h->fused_args[*slot] = {h->rhs_x, h->rhs_z, lhsx_dev, lhsz_dev};
     h->rhs_deferred = false;
     h->x_holds_b = false;

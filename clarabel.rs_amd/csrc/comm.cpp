@@ -46,6 +46,7 @@ int fail_nccl(ncclResult_t r, const char *what) {
 namespace chip {
 hipStream_t kkt_stream(::chip_kkt *h);      // capi.cpp
 void kkt_set_world(::chip_kkt *h, int world);
+void kkt_note_exchange(::chip_kkt *h, hipEvent_t done);
 } // namespace chip
 
 extern "C" {
@@ -145,8 +146,24 @@ int32_t chip_kkt_allgather_step(chip_kkt *h, chip_comm *c, const double *send_de
         CHIP_NCCL(ncclGroupEnd());
     }
     CHIP_HIP(hipEventRecord(c->ev_done, c->stream));
+    // the handle's next PERSISTENT solve launch waits for the exchange on the device (capi.cpp: chip_kkt::exch_event); the
+    // cone update and the factorisation enqueued before it run beside the collective's kernels
+    chip::kkt_note_exchange(h, c->ev_done);
     return CHIP_OK;
 }
+
+#ifdef CHIP_TESTING
+// test hook (include/clarabel_hip_testing.h): a kernel that only holds `blocks` workgroups for `usec` microseconds ON THE
+// COMMUNICATOR'S STREAM, behind the collective enqueued last -- a stand-in, on one GPU, for the time RCCL's ring kernel
+// occupies CUs when eight ranks exchange over xGMI; the completion event moves behind it
+int32_t chip_comm_debug_spin(chip_comm *c, int32_t blocks, int32_t threads, double usec) {
+    if (!c || blocks <= 0 || threads <= 0 || threads > 1024) return CHIP_ERR_ARG;
+    CHIP_HIP(hipSetDevice(c->device));
+    chip::dev::debug_spin(c->stream, blocks, threads, 0, usec);
+    CHIP_HIP(hipEventRecord(c->ev_done, c->stream));
+    return CHIP_OK;
+}
+#endif
 
 int32_t chip_kkt_wait_comm(chip_kkt *h, chip_comm *c) {
     if (!h || !c) return CHIP_ERR_ARG;

@@ -23,6 +23,10 @@ int32_t chip_debug_set_switch(const char *name, const char *value_or_null);
  * "assembled_levels" (unit levels whose ancestor updates can be assembled per target column), "assembled_targets".
  * Returns CHIP_ERR_ARG for an unknown name. */
 int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out);
+/* a spinner of `blocks` x `threads` for `usec` microseconds on the stream of a communicator (opaque chip_comm *), behind
+ * the collective enqueued last; the communicator's completion event moves behind it.  On one GPU this stands in for
+ * the time RCCL's ring kernel holds CUs when several ranks exchange (bench.py --coresident). */
+int32_t chip_comm_debug_spin(void *comm, int32_t blocks, int32_t threads, double usec);
 #ifdef __cplusplus
 }
 #endif

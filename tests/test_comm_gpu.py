@@ -46,6 +46,53 @@ def test_comm_single_rank_allgather_and_allreduce(hip):
     comm.barrier()
 
 
+def test_rank_rehearsal_exchange_beside_the_step_kernels(hip, oracle):
+    """One rank of the 8-GPU sharded run rehearsed on one GPU: a 128-tree share (the register-resident step kernels, whose
+    grid fills the chip exactly), five iterations; behind every iteration's last solve the all-gather of the step direction
+    is enqueued on the communicator's stream, FOLLOWED by a kernel that holds 16 workgroups for 60 us on that stream (the
+    time RCCL's ring kernel occupies CUs when eight ranks exchange).  The exchange runs beside the next iteration's cone
+    update and factorisation; the next persistent solve launch waits for it on the device -- a foreign wave that is
+    resident while such a launch starts fragments the register file and strands some of its workgroups (measured: every
+    solve then ran into its wait budget and was repeated).  No repeats, no fallbacks, solutions against the oracle."""
+    pr = problems.batched_socp(128, 2000, 2, seed=100)
+    n, m = pr["n"], pr["m"]
+    ks = hip.HipKKTSolver(hip.CscMatrix(n, n, *pr["P"]), hip.CscMatrix(m, n, *pr["A"]), pr["cones"], m, n)
+    assert ks.step_kernels() == 3
+    comm = hip.Comm(hip.comm_unique_id(), 1, 0)
+    comm.attach(ks)
+    rng = np.random.default_rng(5)
+    s_d, z_d = hip.DeviceArray(pr["s"]), hip.DeviceArray(pr["z"])
+    rhs = [(rng.standard_normal(n), rng.standard_normal(m)) for _ in range(3)]
+    dev = [(hip.DeviceArray(a), hip.DeviceArray(b)) for a, b in rhs]
+    lhs = [hip.DeviceArray(n + m) for _ in range(3)]
+    gathered = hip.DeviceArray(n + m)
+    for it in range(5):
+        ks.update_scaled_enqueue(s_d.ptr, z_d.ptr)
+        for k in range(3):
+            if k == 2:
+                comm.wait(ks)  # (the buffers of the previous iteration's exchange are about to be overwritten)
+            ks.setrhs_dev(dev[k][0].ptr, dev[k][1].ptr)
+            ks.solve_dev_enqueue(lhs[k].ptr, lhs[k].ptr + 8 * n)
+        comm.allgather_step(ks, lhs[2].ptr, gathered.ptr, [n + m])
+        comm.debug_spin(16, 256, 60.0)
+        uok, sok = ks.collect()
+        assert uok and sok == [True, True, True] and not ks.repeated_solves, (it, sok, ks.repeated_solves)
+    comm.wait(ks)
+    comm.synchronize()
+    ks.synchronize()
+    assert ks.fused_fallbacks() == 0
+    assert np.array_equal(gathered.numpy(), lhs[2].numpy())
+    cones = oracle.Cones(pr["cones"])
+    assert cones.update_scaling(pr["s"], pr["z"])
+    ko = oracle.KKTSolver(n, m, pr["P"], pr["A"], cones, perm=ks.perm)
+    assert ko.update()
+    for k in range(3):
+        ko.setrhs(*rhs[k])
+        ok, xo, zo = ko.solve()
+        ref = np.concatenate([xo, zo])
+        assert ok and float(np.max(np.abs(lhs[k].numpy() - ref)) / max(1.0, np.max(np.abs(ref)))) <= 1e-8
+
+
 def _rank_main(rank, world, token, q):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g

@@ -720,6 +720,21 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
     __syncthreads();
     psd_gemm<true, false>(Cm, Bm, A, n);
     __syncthreads();
+    // (round 5) cones beyond 64: M and V of the Jacobi iteration staged in LDS when the launch provided room for both --
+    // ~30 sweeps x (n - 1) rounds, a barrier apart, were each a round trip to the L2-resident scratch (15 ms at n = 96)
+    double *Cg = Cm, *Vg = Vm;
+    const bool staged = GS && v.jacobi_lds >= 2 * n * n;
+    if (staged) {
+        __threadfence_block();
+        double *Cl = (double *)smem, *Vl = Cl + n * n;
+        for (int idx = tid; idx < n * n; idx += WG) {
+            Cl[idx] = Cm[idx];
+            Vl[idx] = Vm[idx];
+        }
+        Cm = Cl;
+        Vm = Vl;
+        __syncthreads();
+    }
     // one-sided Jacobi, round-robin pairing over np players (np even), EIGHT lanes per pair: each lane takes every
     // eighth row of the two columns (dot products as 8 partial sums + three butterfly steps inside the 8-lane
     // group, then its share of the rotation) -- with one thread per pair 25 of the 256 threads worked and a round
@@ -785,6 +800,16 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
         __syncthreads();
     }
     __syncthreads();
+    if (staged) { // back to the scratch slice: the products below read them from there
+        for (int idx = tid; idx < n * n; idx += WG) {
+            Cg[idx] = Cm[idx];
+            Vg[idx] = Vm[idx];
+        }
+        Cm = Cg;
+        Vm = Vg;
+        __syncthreads();
+        __threadfence_block();
+    }
     // sigma_p = ||m_p||; conventions LAPACK leaves open, fixed like the oracle: singular values in
     // descending order, each right singular vector signed so that its largest entry is positive
     for (int p = tid; p < n; p += WG) {
@@ -1037,7 +1062,15 @@ __global__ __launch_bounds__(WG) void k_psd_ops(PsdView v, double *o0, double *o
             psd_mul_Wx(Y, T, X, pass == 0 ? st.R : st.Ri, n, pass == 1);
             for (int idx = tid; idx < n * n; idx += WG) Y[idx] *= st.lis[idx % n] * st.lis[idx / n]; // lrscale
             __syncthreads();
-            const double g = psd_eig_min(Y, n, cs, red, &flag, nullptr);
+            double *Ye = Y, *cse = cs;
+            if (GS && v.jacobi_lds >= n * n + 3 * n + 16) { // (round 5: the eigenvalue iteration on an LDS copy, see PsdView::jacobi_lds)
+                __threadfence_block();
+                Ye = (double *)smem;
+                cse = Ye + n * n;
+                for (int idx = tid; idx < n * n; idx += WG) Ye[idx] = Y[idx];
+                __syncthreads();
+            }
+            const double g = psd_eig_min(Ye, n, cse, red, &flag, nullptr);
             if (g < 0.0) amin = fmin(amin, fmin(-(1.0 / g), sc));
             __syncthreads();
         }
@@ -1046,7 +1079,15 @@ __global__ __launch_bounds__(WG) void k_psd_ops(PsdView v, double *o0, double *o
         psd_svec_to_mat(X, i0 + off, n);
         __syncthreads();
         double sp;
-        const double mn = psd_eig_min(X, n, cs, red, &flag, &sp);
+        double *Xe = X, *cse = cs;
+        if (GS && v.jacobi_lds >= n * n + 3 * n + 16) {
+            __threadfence_block();
+            Xe = (double *)smem;
+            cse = Xe + n * n;
+            for (int idx = tid; idx < n * n; idx += WG) Xe[idx] = X[idx];
+            __syncthreads();
+        }
+        const double mn = psd_eig_min(Xe, n, cse, red, &flag, &sp);
         if (tid == 0) {
             partial[c] = mn;
             partial2[c] = sp;
@@ -2040,6 +2081,7 @@ void sym_write_kkt(hipStream_t s, const SocView &v, const int *nn_rows, const in
     if (grid) k_sym_write_kkt<<<grid, WG, 0, s>>>(v, nn_rows, nn_hsidx, nn, w, mapHs, Kx, dslots);
 }
 // CHIP_NO_PSD_MFMA -> the device-side flag psd_gemm reads (set when it changes; the launches that follow on `s` see it)
+constexpr size_t PSD_JACOBI_LDS_MAX = 158 * 1024; // dynamic LDS a launch may ask for beside the kernels' small static arrays (160 KiB per CU)
 static void psd_sync_switch(hipStream_t s) {
     // g_psd_no_mfma is a per-DEVICE symbol: the cached state is kept per device (one process may drive several GPUs)
     static std::atomic<int> cur[64];
@@ -2056,8 +2098,13 @@ static void psd_sync_switch(hipStream_t s) {
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv) {
     if (!v.ncones) return;
     psd_sync_switch(s);
-    if (v.scratch) { // cones too large for LDS: work matrices in HBM scratch
-        k_psd_update_scaling<true><<<v.ncones, WG, 0, s>>>(v, sv, zv);
+    if (v.scratch) { // cones too large for LDS: work matrices in HBM scratch, the Jacobi iteration's two in LDS when they fit
+        PsdView vs = v;
+        const size_t need = (size_t)2 * v.maxdim * v.maxdim * sizeof(double);
+        size_t lds = 0;
+        if (need <= PSD_JACOBI_LDS_MAX && raise_dynamic_lds((const void *)k_psd_update_scaling<true>, need) == hipSuccess) lds = need;
+        vs.jacobi_lds = (int)(lds / sizeof(double));
+        k_psd_update_scaling<true><<<v.ncones, WG, lds, s>>>(vs, sv, zv);
         return;
     }
     const size_t lds = ((size_t)(4 * v.maxdim * v.maxdim + 3 * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;
@@ -2092,7 +2139,14 @@ template <typename K> static void psd_allow_lds(K kernel, size_t lds) {
     do {                                                                             \
         psd_sync_switch(s);                                                          \
         if (v.scratch) {                                                             \
-            k_psd_ops<OP, true><<<v.ncones, WG, 0, s>>>(v, __VA_ARGS__);             \
+            PsdView vs_ = v;                                                         \
+            size_t jl_ = 0;                                                          \
+            if (OP == 4 || OP == 5) { /* the eigenvalue iterations on an LDS copy */   \
+                const size_t need_ = ((size_t)v.maxdim * v.maxdim + 3 * (size_t)v.maxdim + 16) * sizeof(double); \
+                if (need_ <= PSD_JACOBI_LDS_MAX && raise_dynamic_lds((const void *)k_psd_ops<OP, true>, need_) == hipSuccess) jl_ = need_; \
+            }                                                                        \
+            vs_.jacobi_lds = (int)(jl_ / sizeof(double));                            \
+            k_psd_ops<OP, true><<<v.ncones, WG, jl_, s>>>(vs_, __VA_ARGS__);         \
         } else {                                                                     \
             const size_t lds_ = psd_ops_lds(v);                                      \
             psd_allow_lds(k_psd_ops<OP, false>, lds_);                               \

@@ -450,6 +450,11 @@ struct PsdView {
     // Hs written row by row of the device's value order (k_psd_write_hs_rows): set when every PSD cone's block of K is
     // one of the dense diagonal blocks of the top (DblkView) -- block b belongs to cone blk_cone[b] (-1: not a PSD
     // cone's), its i-th row is the svec entry (row_ij & 0xffff, row_ij >> 16) of the cone
+    // cones larger than 64 (work matrices in HBM scratch): doubles of dynamic LDS the launch provides for the JACOBI phases
+    // -- the eigenvalue iteration of step_length / margins (one n x n matrix) and the one-sided SVD of update_scaling (two)
+    // are hundreds of rounds, each a few barriers apart, every access a round trip to the L2 when the matrix sits in
+    // scratch; staged in LDS they run as for the small cones.  0: not staged (set by the launchers in cones.hip).
+    int jacobi_lds = 0;
     int rows_nblk = 0;
     const int *blk_cone = nullptr, *row_ij = nullptr, *blk_m = nullptr, *blk_rowbase = nullptr, *blk_start = nullptr;
 };

@@ -723,6 +723,8 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
     // (round 5) cones beyond 64: M and V of the Jacobi iteration staged in LDS when the launch provided room for both --
     // ~30 sweeps x (n - 1) rounds, a barrier apart, were each a round trip to the L2-resident scratch (15 ms at n = 96)
     double *Cg = Cm, *Vg = Vm;
+    // (columns padded to a leading dimension = 8 mod 32, so that the pairs of a half wave start 16 banks apart, were
+    // measured too: no change at n = 96 -- the rounds are bound by their dependent chains, not by LDS bank conflicts)
     const bool staged = GS && v.jacobi_lds >= 2 * n * n;
     if (staged) {
         __threadfence_block();
@@ -766,18 +768,14 @@ __global__ __launch_bounds__(WG) void k_psd_update_scaling(PsdView v, const doub
                         be += b0 * b0;
                         ga += a0 * b0;
                     }
+                // (a butterfly of commutative adds: the eight lanes of a pair end with bit-identical sums, so they agree
+                // on the rotation and on whether to rotate at all)
 #pragma unroll
                 for (int off = 1; off < JG; off <<= 1) {
                     al += __shfl_xor(al, off, 64);
                     be += __shfl_xor(be, off, 64);
                     ga += __shfl_xor(ga, off, 64);
                 }
-                // (the butterfly adds in a different order on every lane: all eight take the leader's sums, so
-                // that they agree bit for bit on the rotation and on whether to rotate at all)
-                const int lead = (tid & 63) & ~(JG - 1);
-                al = __shfl(al, lead, 64);
-                be = __shfl(be, lead, 64);
-                ga = __shfl(ga, lead, 64);
                 if (valid && fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
                     const double zeta = (be - al) / (2.0 * ga);
                     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -934,7 +932,7 @@ __device__ double psd_eig_min(double *A, int n, double *cs, double *red, int *fl
                         if (fabs(apq) > 1e-15 * (fabs(app) + fabs(aqq))) *flag = 1;
                     }
                 } else {
-                    p = -1;
+                    q = -1; // (odd n: the player that sits this round out -- no partner, the identity rotation)
                 }
                 pp[pr] = p;
                 qq[pr] = q;
@@ -942,26 +940,33 @@ __device__ double psd_eig_min(double *A, int n, double *cs, double *red, int *fl
                 ss[pr] = sn;
             }
             __syncthreads();
-            // columns: A <- A J
-            for (int w = tid; w < half * n; w += WG) {
-                const int k = w / n, i = w % n;
-                const int p = pp[k], q = qq[k];
-                if (p < 0) continue;
-                const double c = cc[k], sn = ss[k];
-                const double a = A[i + p * n], b = A[i + q * n];
-                A[i + p * n] = c * a - sn * b;
-                A[i + q * n] = sn * a + c * b;
-            }
-            __syncthreads();
-            // rows: A <- J' A
-            for (int w = tid; w < half * n; w += WG) {
-                const int k = w / n, j = w % n;
-                const int p = pp[k], q = qq[k];
-                if (p < 0) continue;
-                const double c = cc[k], sn = ss[k];
-                const double a = A[p + j * n], b = A[q + j * n];
-                A[p + j * n] = c * a - sn * b;
-                A[q + j * n] = sn * a + c * b;
+            // A <- J' A J, both sides in ONE pass (round 5): the 2 x 2 block (p1, q1) x (p2, q2) of the pairs k1, k2 takes
+            // the column rotation of k2 on its two rows, then the row rotation of k1 on its two columns -- the arithmetic
+            // of a column pass followed by a row pass, element for element, in half the LDS traffic and one barrier less;
+            // lanes run over k1 (p1 ascending, q1 descending: consecutive words), where the row pass read with stride n
+            // (n = 96: every lane on one bank)
+            {
+                int k1 = tid % half, k2 = tid / half;
+                const int d1 = WG % half, d2 = WG / half;
+                for (int w = tid; w < half * half; w += WG) {
+                    const int p1 = pp[k1], q1 = qq[k1], p2 = pp[k2], q2 = qq[k2];
+                    const bool h1 = q1 >= 0, h2 = q2 >= 0; // (false: the player that sits this round out)
+                    const double c1 = cc[k1], s1 = ss[k1], c2 = cc[k2], s2 = ss[k2];
+                    const double app = A[p1 + p2 * n], apq = h2 ? A[p1 + q2 * n] : 0.0;
+                    const double aqp = h1 ? A[q1 + p2 * n] : 0.0, aqq = (h1 && h2) ? A[q1 + q2 * n] : 0.0;
+                    const double bpp = c2 * app - s2 * apq, bpq = s2 * app + c2 * apq;
+                    const double bqp = c2 * aqp - s2 * aqq, bqq = s2 * aqp + c2 * aqq;
+                    A[p1 + p2 * n] = c1 * bpp - s1 * bqp;
+                    if (h1) A[q1 + p2 * n] = s1 * bpp + c1 * bqp;
+                    if (h2) A[p1 + q2 * n] = c1 * bpq - s1 * bqq;
+                    if (h1 && h2) A[q1 + q2 * n] = s1 * bpq + c1 * bqq;
+                    k1 += d1;
+                    k2 += d2;
+                    if (k1 >= half) {
+                        k1 -= half;
+                        ++k2;
+                    }
+                }
             }
             __syncthreads();
         }

@@ -2006,6 +2006,13 @@ int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out
         for (size_t l = 0; l + 1 < E.sn_lvl_ptr.size(); l++) c += E.sn_lvl_ptr[l + 1] > E.sn_lvl_ptr[l];
         *out = c;
     } else if (k == "g_entries") *out = E.sn_g_entries;
+    else if (k == "gsweep_runs") *out = (double)E.gs_runs.size(); // runs of unit levels taken by one persistent launch per sweep (after the first solve)
+    else if (k == "gsweep_launches") *out = E.gs_launches;
+    else if (k == "gsweep_levels") {
+        int c = 0;
+        for (const auto &r : E.gs_runs) c += r.nlev;
+        *out = c;
+    }
     else return fail(CHIP_ERR_ARG, "chip_debug_counter: unknown name");
     return CHIP_OK;
 }

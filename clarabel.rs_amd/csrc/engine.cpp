@@ -417,6 +417,8 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 CHIP_HIP(hipMemset(sn_Gx, 0, ((size_t)total + 8) * sizeof(double))); // (entries above a row's diagonal block are never written)
                 if ((rc = alloc(&sn_yt, n))) return rc;
                 CHIP_HIP(hipMemset(sn_yt, 0, n * sizeof(double)));
+                if ((rc = alloc(&gs_ctl, (size_t)dev::ir_ctl_ints()))) return rc;
+                CHIP_HIP(hipMemset(gs_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int)));
                 sn_g_entries = (double)total;
                 if (dev::snode_g_attributes(ghmax) != 0) {
                     set_error("k_snode_ginv: dynamic LDS size rejected");
@@ -838,6 +840,10 @@ int Engine::ensure_alt() {
         if ((rc = alloc(&alt.sn_yt, n))) return rc;
         CHIP_HIP(hipMemset(alt.sn_yt, 0, n * sizeof(double)));
     }
+    if (gs_ctl) {
+        if ((rc = alloc(&alt.gs_ctl, (size_t)dev::ir_ctl_ints()))) return rc;
+        CHIP_HIP(hipMemset(alt.gs_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int)));
+    }
     if (xs_view && (rc = alloc(&alt.xs_view, n))) return rc;
     if (bt_view && (rc = alloc(&alt.bt_view, n))) return rc;
     if (dblk.P && (rc = alloc(&alt.dblk_P, (size_t)dblk.nrows * dblk.split))) return rc;
@@ -862,6 +868,7 @@ void Engine::swap_ctx() {
     std::swap(nrm_dev, alt.nrm_dev);
     std::swap(nrm_host, alt.nrm_host);
     std::swap(sn_flags, alt.sn_flags);
+    std::swap(gs_ctl, alt.gs_ctl);
     alt_active = !alt_active;
 }
 int Engine::pair_begin() {
@@ -877,6 +884,107 @@ int Engine::pair_begin() {
     }
     CHIP_HIP(hipEventRecord(pair_event, stream));
     CHIP_HIP(hipStreamWaitEvent(alt.stream, pair_event, 0));
+    return CHIP_OK;
+}
+
+// Runs of >= 2 consecutive unit levels on the one-pass matrices: one persistent launch per run and sweep (snode_g.hip:
+// k_snode_gsweep).  Forward, level l carries the row gathers of level l + 1; backward, a level qualifies when its ordinary
+// columns need no chunk preparation and carries them itself -- exactly what the per-level launches do (enqueue_solve_direct).
+// The grid is at most HALF the chip's compute units (one 1024-thread workgroup each): the two solves of a pair run their
+// sweeps side by side on two streams, and two persistent grids must be co-resident together whatever order their
+// workgroups are dispatched in.
+int Engine::build_gsweeps() {
+    gs_built = true;
+    gs_runs.clear();
+    gs_run_f.assign((size_t)nfaclevels, -1);
+    gs_run_b.assign((size_t)nfaclevels, -1);
+    if (sn_g_ntasks <= 0 || !gs_ctl || switches().no_sweep_merge || switches().no_sweep_persist) return CHIP_OK;
+    std::vector<dev::GSweepLevel> tab;
+    int ncu = 0, devid = 0;
+    {
+        hipDeviceProp_t prop;
+        CHIP_HIP(hipGetDevice(&devid));
+        CHIP_HIP(hipGetDeviceProperties(&prop, devid));
+        ncu = prop.multiProcessorCount;
+    }
+    const int gmax = switches().gsweep_grid > 0 ? switches().gsweep_grid : std::max(1, ncu / 2);
+    // a level with more blocks than two rounds of the grid stays a launch of its own: there the chip-wide grid of the plain
+    // launch wins (config 5's leaf level: 200 supernodes; measured 0.3 - 0.6 ms per step slower inside a run)
+    const int task_cap = switches().gsweep_grid > 0 ? (1 << 30) : 2 * gmax;
+    auto is_g = [&](int l, bool fwd_dir) {
+        if (!(sn_lvl_g[l] && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l])) return false;
+        const int gx = ((fwd_dir ? sn_lvl_hmax[l] : sn_lvl_wmax[l]) + 63) / 64;
+        return (long long)gx * (sn_lvl_ptr[l + 1] - sn_lvl_ptr[l]) <= task_cap;
+    };
+    auto close_run = [&](dev::GatherMode m, size_t first, int start_level, int hmax) {
+        const int nlev = (int)(tab.size() - first);
+        if (nlev < 2) {
+            tab.resize(first);
+            return;
+        }
+        const size_t lds = dev::snode_gsweep_lds(m, hmax);
+        int most = 1;
+        for (size_t k = first; k < tab.size(); k++) {
+            const dev::GSweepLevel &L = tab[k];
+            most = std::max(most, L.gx * L.count + L.ccount + (L.wcount + 15) / 16 + (L.tcount + 1023) / 1024);
+        }
+        const int grid = std::min(std::min(gmax, dev::snode_gsweep_capacity(m, lds)), most);
+        if (grid <= 0) {
+            tab.resize(first);
+            return;
+        }
+        (m == dev::FWD ? gs_run_f : gs_run_b)[(size_t)start_level] = (i32)gs_runs.size();
+        gs_runs.push_back({nlev, (int)first, grid, lds});
+    };
+    for (int l = 0; l < nfaclevels;) { // forward
+        if (!is_g(l, true)) {
+            l++;
+            continue;
+        }
+        const size_t first = tab.size();
+        const int l0 = l;
+        for (; l < nfaclevels && is_g(l, true); l++) {
+            dev::GSweepLevel L{};
+            L.off = sn_lvl_ptr[l];
+            L.count = sn_lvl_ptr[l + 1] - sn_lvl_ptr[l];
+            L.gx = (sn_lvl_hmax[l] + 63) / 64;
+            if (l + 1 < nfaclevels) {
+                const dev::ListView t = fwu.T(l + 1), w = fwu.W(l + 1);
+                const dev::ChunkView c = fwu.B(l + 1);
+                L.trows = t.idx, L.tcount = t.count, L.wrows = w.idx, L.wcount = w.count;
+                L.crow = c.row, L.cbeg = c.beg, L.cend = c.end, L.ccount = c.count;
+            }
+            tab.push_back(L);
+        }
+        close_run(dev::FWD, first, l0, 0);
+    }
+    auto bwd_ok = [&](int l) { return is_g(l, false) && bwu.B(l).count == 0; };
+    for (int l = nfaclevels - 1; l >= 0;) { // backward
+        if (!bwd_ok(l)) {
+            l--;
+            continue;
+        }
+        const size_t first = tab.size();
+        const int l0 = l;
+        int hmax = 0;
+        for (; l >= 0 && bwd_ok(l); l--) {
+            dev::GSweepLevel L{};
+            L.off = sn_lvl_ptr[l];
+            L.count = sn_lvl_ptr[l + 1] - sn_lvl_ptr[l];
+            L.gx = (sn_lvl_wmax[l] + 63) / 64;
+            const dev::ListView t = bwu.T(l), w = bwu.W(l);
+            L.trows = t.idx, L.tcount = t.count, L.wrows = w.idx, L.wcount = w.count;
+            hmax = std::max(hmax, sn_lvl_hmax[l]);
+            tab.push_back(L);
+        }
+        close_run(dev::BWD, first, l0, hmax);
+    }
+    if (tab.empty()) return CHIP_OK;
+    void *p = nullptr;
+    CHIP_HIP(hipMalloc(&p, tab.size() * sizeof(dev::GSweepLevel)));
+    allocs.push_back(p);
+    CHIP_HIP(hipMemcpy(p, tab.data(), tab.size() * sizeof(dev::GSweepLevel), hipMemcpyHostToDevice));
+    gs_lv = (dev::GSweepLevel *)p;
     return CHIP_OK;
 }
 
@@ -1079,6 +1187,7 @@ int Engine::refactor_collect() {
 
 // qdldl.rs:755-768 in the permuted numbering, in place
 void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
+    if (!gs_built && nsn > 0) (void)build_gsweeps(); // (outside any capture: allocates)
     // (a fused handle taking the one-kernel-per-phase path: these kernels stream L by rows.  Refreshed here,
     // ahead of the graph lookup and outside any capture: a replayed graph contains no gather)
     if (!rx_valid) {
@@ -1136,6 +1245,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         // into the supernodes' launch (snode_g.hip: SweepGather); CHIP_NO_SWEEP_MERGE keeps the two launches per level
         const bool merge = sn_g_ntasks > 0 && !switches().no_sweep_merge;
         auto is_g = [&](int l) { return sn_g_ntasks > 0 && sn_lvl_g[l] && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
+        const bool persist = merge && gs_lv && !switches().no_sweep_persist; // runs of such levels: one persistent launch each
         bool gathered = false; // level l's gathers already ran inside the previous level's launch
         for (int l = 0; l < nfaclevels; l++) {
             if (!gathered) {
@@ -1144,6 +1254,15 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
                 prof_end(PF_SN_GATHER);
             }
             gathered = false;
+            if (persist && gs_run_f[(size_t)l] >= 0) { // a run of such levels: one persistent launch
+                const GRun &r = gs_runs[(size_t)gs_run_f[(size_t)l]];
+                dev::solve_snodes_gsweep(stream, dev::FWD, v, sview, sn_order, xp, sn_yt, gs_lv + r.off, r.nlev, r.grid, r.lds, f,
+                                         gs_ctl, norm_nan(1), lp);
+                gs_launches++;
+                l += r.nlev - 1;
+                gathered = l + 1 < nfaclevels; // (the run's last level carried them)
+                continue;
+            }
             if (is_g(l)) { // one pass over G, no hops (x_S(new) -> sn_yt, the rows of B subtracted in place)
                 const bool ride = merge && l + 1 < nfaclevels;
                 dev::solve_snodes_g(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
@@ -1159,6 +1278,14 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         tri.epoch = ++sn_epoch;
         dev::GatherArgs g{Lp, Li, Lx, xp, xp, Dinv, nullptr, nullptr};
         for (int l = nfaclevels - 1; l >= 0; l--) {
+            if (persist && gs_run_b[(size_t)l] >= 0) {
+                const GRun &r = gs_runs[(size_t)gs_run_b[(size_t)l]];
+                dev::solve_snodes_gsweep(stream, dev::BWD, v, sview, sn_order, xp, sn_yt, gs_lv + r.off, r.nlev, r.grid, r.lds, g,
+                                         gs_ctl, norm_nan(1), lp);
+                gs_launches++;
+                l -= r.nlev - 1;
+                continue;
+            }
             const dev::ChunkView b = bwu.B(l);
             if (is_g(l)) {
                 const bool ride = merge && b.count == 0; // (chunked columns need their preparation pass first)

@@ -105,6 +105,18 @@ struct Engine {
     int *sn_g_tasks = nullptr;
     int sn_g_ntasks = 0;
     double sn_g_entries = 0; // doubles of G (what one sweep through these supernodes streams)
+    // runs of consecutive unit levels on that path as ONE persistent launch per sweep (k_snode_gsweep); built on the first solve
+    struct GRun {
+        int nlev, off, grid; // levels of the run (sweep order), first entry in gs_lv, co-resident grid
+        size_t lds;
+    };
+    std::vector<GRun> gs_runs;
+    std::vector<i32> gs_run_f, gs_run_b; // per unit level: the run that STARTS there in the forward / backward sweep, or -1
+    dev::GSweepLevel *gs_lv = nullptr;
+    int *gs_ctl = nullptr; // the grid barrier's counters (per solve context)
+    bool gs_built = false;
+    int gs_launches = 0; // (tests: persistent launches enqueued so far)
+    int build_gsweeps();
     std::vector<i32> sn_lvl_ptr, sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax, h_sn_ptr, h_sn_col;
     // pipelined substitution through wide supernodes (dev::SnodeTriView): one flag per 64-column block
     int *sn_blk_ptr = nullptr, *sn_flags = nullptr;
@@ -219,7 +231,7 @@ struct Engine {
         hipStream_t stream = nullptr;
         double *sn_yt = nullptr, *xs_view = nullptr, *bt_view = nullptr, *dblk_P = nullptr;
         unsigned long long *nrm_dev = nullptr, *nrm_host = nullptr;
-        int *sn_flags = nullptr;
+        int *sn_flags = nullptr, *gs_ctl = nullptr;
     };
     SolveCtx alt;
     bool alt_ready = false, alt_active = false;

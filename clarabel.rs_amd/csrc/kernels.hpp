@@ -358,6 +358,22 @@ void snode_ginv(hipStream_t s, const LdlView &v, const SnodeView &sv, const int 
 void solve_snodes_g(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count, int wlvl,
                     int hlvl, double *x, double *yt, const LaunchProf *lp = nullptr, const GatherArgs *ga = nullptr,
                     ListView t = ListView{nullptr, 0}, ListView w = ListView{nullptr, 0}, ChunkView c = ChunkView{nullptr, nullptr, nullptr, 0});
+// a RUN of consecutive unit levels on the one-pass matrices in ONE persistent launch (k_snode_gsweep): the levels in sweep
+// order, each with the row gathers that ride along (forward: the next level's; backward: the level's ordinary columns)
+struct GSweepLevel {
+    int off, count;              // the level's records: order_all + 8 * off, count supernodes
+    int gx;                      // 64-row (forward) / 64-column (backward) blocks per supernode
+    int tcount, wcount, ccount;  // the riding gathers' lists (SweepGather)
+    int pad0, pad1;
+    const int *trows, *wrows, *crow, *cbeg, *cend;
+};
+// largest co-resident grid of the persistent sweep with `lds` bytes of dynamic LDS (0: cannot run)
+int snode_gsweep_capacity(GatherMode m, size_t lds);
+size_t snode_gsweep_lds(GatherMode m, int hmax);
+// ctl: ir_ctl_ints() zeros (zero again when the launch ends); fail: raised when a barrier times out
+void solve_snodes_gsweep(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order_all, double *x,
+                         double *yt, const GSweepLevel *lv, int nlev, int grid, size_t lds, const GatherArgs &ga, int *ctl,
+                         int *fail, const LaunchProf *lp = nullptr);
 // diagnostics / tests: a kernel of `blocks` x `threads` that only spins for `usec` microseconds on stream s
 // (co-residency tests of the persistent launches)
 void debug_spin(hipStream_t s, int blocks, int threads, int lds_bytes, double usec);

@@ -21,6 +21,7 @@
 // parity is asserted on the refined solution.  Supernodes wider than SG_WMAX keep the pipelined substitution.
 #include "dev_common.hpp"
 #include "snode_common.hpp"
+#include "grid_sync.hpp"
 
 namespace chip {
 namespace dev {
@@ -232,7 +233,14 @@ constexpr int SGS_WG_ = 1024;
 __host__ __device__ inline int sweep_gather_blocks(int tcount, int wcount, int ccount) {
     return ccount + (wcount + 15) / 16 + (tcount + SGS_WG_ - 1) / SGS_WG_;
 }
-template <int MODE>
+// COH (the persistent sweeps, k_snode_gsweep): the vector is written by other workgroups EARLIER IN THE SAME LAUNCH --
+// every access to it goes to the device's coherence point (grid_sync.hpp), never through this XCD's L2
+template <bool COH> __device__ __forceinline__ double sg_xload(const double *p) { return COH ? ir_load(p) : *p; }
+template <bool COH> __device__ __forceinline__ void sg_xstore(double *p, double val) {
+    if (COH) ir_store(p, val);
+    else *p = val;
+}
+template <int MODE, bool COH>
 __device__ __forceinline__ void sg_gather_block(const SweepGather &q, int gb, double *red) {
     const GatherArgs &a = q.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -244,12 +252,12 @@ __device__ __forceinline__ void sg_gather_block(const SweepGather &q, int gb, do
         for (; t + 3 * SGS_WG_ < ce; t += 4 * SGS_WG_) {
             const int i0 = a.idx[t], i1 = a.idx[t + SGS_WG_], i2 = a.idx[t + 2 * SGS_WG_], i3 = a.idx[t + 3 * SGS_WG_];
             const double v0 = a.val[t], v1 = a.val[t + SGS_WG_], v2 = a.val[t + 2 * SGS_WG_], v3 = a.val[t + 3 * SGS_WG_];
-            s0 += v0 * a.xin[i0];
-            s1 += v1 * a.xin[i1];
-            s2 += v2 * a.xin[i2];
-            s3 += v3 * a.xin[i3];
+            s0 += v0 * sg_xload<COH>(&a.xin[i0]);
+            s1 += v1 * sg_xload<COH>(&a.xin[i1]);
+            s2 += v2 * sg_xload<COH>(&a.xin[i2]);
+            s3 += v3 * sg_xload<COH>(&a.xin[i3]);
         }
-        for (; t < ce; t += SGS_WG_) s0 += a.val[t] * a.xin[a.idx[t]];
+        for (; t < ce; t += SGS_WG_) s0 += a.val[t] * sg_xload<COH>(&a.xin[a.idx[t]]);
         const double ws = wave_sum((s0 + s1) + (s2 + s3));
         if (lane == 0) red[wave] = ws;
         __syncthreads();
@@ -271,16 +279,16 @@ __device__ __forceinline__ void sg_gather_block(const SweepGather &q, int gb, do
         for (; t + 192 < e; t += 256) {
             const int i0 = a.idx[t], i1 = a.idx[t + 64], i2 = a.idx[t + 128], i3 = a.idx[t + 192];
             const double v0 = a.val[t], v1 = a.val[t + 64], v2 = a.val[t + 128], v3 = a.val[t + 192];
-            s0 += v0 * a.xin[i0];
-            s1 += v1 * a.xin[i1];
-            s2 += v2 * a.xin[i2];
-            s3 += v3 * a.xin[i3];
+            s0 += v0 * sg_xload<COH>(&a.xin[i0]);
+            s1 += v1 * sg_xload<COH>(&a.xin[i1]);
+            s2 += v2 * sg_xload<COH>(&a.xin[i2]);
+            s3 += v3 * sg_xload<COH>(&a.xin[i3]);
         }
-        for (; t < e; t += 64) s0 += a.val[t] * a.xin[a.idx[t]];
+        for (; t < e; t += 64) s0 += a.val[t] * sg_xload<COH>(&a.xin[a.idx[t]]);
         const double sm = wave_sum((s0 + s1) + (s2 + s3));
         if (lane == 0) {
             if (MODE == FWD) atomicAdd(&a.out[r], -sm);
-            else a.out[r] = a.out[r] * a.aux[r] - sm;
+            else sg_xstore<COH>(&a.out[r], sg_xload<COH>(&a.out[r]) * a.aux[r] - sm);
         }
         return;
     }
@@ -289,9 +297,9 @@ __device__ __forceinline__ void sg_gather_block(const SweepGather &q, int gb, do
     const int r = q.trows[k];
     const int b = a.ptr[r], e = a.ptr[r + 1];
     double sm = 0.0;
-    for (int t = b; t < e; ++t) sm += a.val[t] * a.xin[a.idx[t]];
+    for (int t = b; t < e; ++t) sm += a.val[t] * sg_xload<COH>(&a.xin[a.idx[t]]);
     if (MODE == FWD) atomicAdd(&a.out[r], -sm);
-    else a.out[r] = a.out[r] * a.aux[r] - sm;
+    else sg_xstore<COH>(&a.out[r], sg_xload<COH>(&a.out[r]) * a.aux[r] - sm);
 }
 
 // forward: grid (64-row blocks of G, supernodes of the unit level), sixteen waves.  Lane = row; wave q takes the columns
@@ -301,18 +309,14 @@ __device__ __forceinline__ void sg_gather_block(const SweepGather &q, int gb, do
 // leave as one atomic per (row, supernode).
 constexpr int SGS_WG = SGS_WG_;
 constexpr int SGS_NW = SGS_WG / 64;
-__global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
-                                                       double *yt, int count, SweepGather sg) {
-    __shared__ double xs[SG_WMAX];
-    __shared__ double part[SGS_NW][64];
-    if ((int)blockIdx.y >= count) { // the next level's row gathers ride along (see SweepGather)
-        const int gb = ((int)blockIdx.y - count) * (int)gridDim.x + (int)blockIdx.x;
-        if (gb < sweep_gather_blocks(sg.tcount, sg.wcount, sg.ccount)) sg_gather_block<FWD>(sg, gb, &part[0][0]);
-        return;
-    }
+constexpr size_t SGS_FWD_LDS = (size_t)(SG_WMAX + SGS_NW * 64) * sizeof(double); // x_S + the sixteen partial sums
+// one (64-row block bx, supernode by of the level) of the forward pass; xs[SG_WMAX], part[SGS_NW * 64] in LDS
+template <bool COH>
+__device__ __forceinline__ void sg_fwd_task(const LdlView &v, const SnodeView &sv, const int *__restrict__ order, double *x,
+                                            double *yt, int by, int bx, double *xs, double *part) {
     int sn;
-    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
-    const int r0 = 64 * (int)blockIdx.x;
+    const SnodeGeom g = snode_geom(sv, order, by, sn);
+    const int r0 = 64 * bx;
     if (r0 >= g.h) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncols = r0 < g.w ? min(g.w, r0 + 64) : g.w; // (rows of T^-1 end at their diagonal block)
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, 
     double l[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) l[q] = Gr[(size_t)min(wave + SGS_NW * q, ncols - 1) * ldg]; // (clamped: unconditional)
-    for (int t = tid; t < ncols; t += SGS_WG) xs[t] = x[g.cols[t]];
+    for (int t = tid; t < ncols; t += SGS_WG) xs[t] = sg_xload<COH>(&x[g.cols[t]]);
     __syncthreads();
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -345,31 +349,36 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, 
             s3 += j + 3 * SGS_NW < ncols ? l[q + 3] * xs[j + 3 * SGS_NW] : 0.0;
         }
     }
-    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    part[wave * 64 + lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0 && i < g.h) {
         double tot = 0.0;
 #pragma unroll
-        for (int q = 0; q < SGS_NW; ++q) tot += part[q][lane];
-        if (i < g.w) yt[g.cols[i]] = tot;
+        for (int q = 0; q < SGS_NW; ++q) tot += part[q * 64 + lane];
+        if (i < g.w) yt[g.cols[i]] = tot; // (read by the backward sweep: another launch)
         else atomicAdd(&x[v.Li[g.bn0 + i - g.w]], -tot);
     }
+}
+__global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
+                                                       double *yt, int count, SweepGather sg) {
+    __shared__ double xs[SG_WMAX];
+    __shared__ double part[SGS_NW * 64];
+    if ((int)blockIdx.y >= count) { // the next level's row gathers ride along (see SweepGather)
+        const int gb = ((int)blockIdx.y - count) * (int)gridDim.x + (int)blockIdx.x;
+        if (gb < sweep_gather_blocks(sg.tcount, sg.wcount, sg.ccount)) sg_gather_block<FWD, false>(sg, gb, part);
+        return;
+    }
+    sg_fwd_task<false>(v, sv, order, x, yt, (int)blockIdx.y, (int)blockIdx.x, xs, part);
 }
 // backward: grid (64-column blocks, supernodes of the unit level), sixteen waves of four columns each.  A wave's first
 // 4 x 4 x 64 entries are requested first, s = [D^-1 y_S ; -x_B] (from the block's first row on) is staged in LDS while
 // they are in flight; rows along the lanes, fixed order of summation, no atomics.
-__global__ __launch_bounds__(SGS_WG) void k_snode_gbwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
-                                                       const double *yt, int count, SweepGather sg) {
-    extern __shared__ __attribute__((aligned(16))) char bsm[];
-    double *ss = (double *)bsm;
-    if ((int)blockIdx.y >= count) { // this level's ordinary columns ride along (see SweepGather)
-        const int gb = ((int)blockIdx.y - count) * (int)gridDim.x + (int)blockIdx.x;
-        if (gb < sweep_gather_blocks(sg.tcount, sg.wcount, sg.ccount)) sg_gather_block<BWD>(sg, gb, ss);
-        return;
-    }
+template <bool COH>
+__device__ __forceinline__ void sg_bwd_task(const LdlView &v, const SnodeView &sv, const int *__restrict__ order, double *x,
+                                            const double *yt, int by, int bx, double *ss) {
     int sn;
-    const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
-    const int j0 = 64 * (int)blockIdx.x;
+    const SnodeGeom g = snode_geom(sv, order, by, sn);
+    const int j0 = 64 * bx;
     if (j0 >= g.w) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ldg = sg_ldg(g.h);
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gbwd(LdlView v, SnodeView sv, 
             const int c = g.cols[i];
             val = yt[c] * v.Dinv[c];
         } else {
-            val = -x[Bn[i - g.w]];
+            val = -sg_xload<COH>(&x[Bn[i - g.w]]);
         }
         ss[i - j0] = val;
     }
@@ -420,8 +429,69 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gbwd(LdlView v, SnodeView sv, 
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const double tot = wave_sum(a[u]);
-        if (lane == 0 && jf + u < g.w) x[g.cols[jf + u]] = tot;
+        if (lane == 0 && jf + u < g.w) sg_xstore<COH>(&x[g.cols[jf + u]], tot);
     }
+}
+__global__ __launch_bounds__(SGS_WG) void k_snode_gbwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
+                                                       const double *yt, int count, SweepGather sg) {
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    double *ss = (double *)bsm;
+    if ((int)blockIdx.y >= count) { // this level's ordinary columns ride along (see SweepGather)
+        const int gb = ((int)blockIdx.y - count) * (int)gridDim.x + (int)blockIdx.x;
+        if (gb < sweep_gather_blocks(sg.tcount, sg.wcount, sg.ccount)) sg_gather_block<BWD, false>(sg, gb, ss);
+        return;
+    }
+    sg_bwd_task<false>(v, sv, order, x, yt, (int)blockIdx.y, (int)blockIdx.x, ss);
+}
+
+// ---- a RUN of consecutive unit levels in one persistent launch (round 5) ---------------------------------------------
+// A sweep through k unit levels on the one-pass matrices was k launches of a handful of dependent memory round trips
+// each (8 - 9 us of kernel + the boundary: config 2 has 27 such levels, twelve sweeps per step).  k_snode_gsweep walks
+// the levels of a run itself: the tasks of a level (its supernodes' blocks + the row gathers that ride along) are spread
+// over a co-resident grid, a grid barrier (grid_sync.hpp) separates the levels.  The vector crosses workgroups inside
+// the launch: read and written at the device's coherence point (COH above); G, L, the index lists and yt do not.
+// A barrier that cannot complete (the grid was not co-resident) raises *fail -- the solve reports a non-finite result.
+template <int MODE>
+__global__ __launch_bounds__(SGS_WG) void k_snode_gsweep(LdlView v, SnodeView sv, const int *__restrict__ order_all, double *x,
+                                                         double *yt, const GSweepLevel *__restrict__ lv, int nlev, GatherArgs ga,
+                                                         int *ctl, int *fail) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    double *sm = (double *)gsm;
+    const int G = (int)gridDim.x;
+    for (int li = 0; li < nlev; ++li) {
+        const GSweepLevel L = lv[li];
+        SweepGather sg;
+        sg.a = ga;
+        sg.trows = L.trows;
+        sg.wrows = L.wrows;
+        sg.crow = L.crow;
+        sg.cbeg = L.cbeg;
+        sg.cend = L.cend;
+        sg.tcount = L.tcount;
+        sg.wcount = L.wcount;
+        sg.ccount = L.ccount;
+        const int nsn_tasks = L.gx * L.count, ntasks = nsn_tasks + sweep_gather_blocks(L.tcount, L.wcount, L.ccount);
+        for (int task = (int)blockIdx.x; task < ntasks; task += G) {
+            if (task < nsn_tasks) {
+                const int by = task / L.gx, bx = task - by * L.gx;
+                if (MODE == FWD) sg_fwd_task<true>(v, sv, order_all + 8 * (size_t)L.off, x, yt, by, bx, sm, sm + SG_WMAX);
+                else sg_bwd_task<true>(v, sv, order_all + 8 * (size_t)L.off, x, yt, by, bx, sm);
+            } else {
+                sg_gather_block<MODE, true>(sg, task - nsn_tasks, sm);
+            }
+            __syncthreads(); // (the next task stages over the same LDS)
+        }
+        if (li + 1 < nlev) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's stores and atomics are performed
+            const int state = ir_arrive_wait(ctl, li + 1, G);
+            if (state == IR_TIMEOUT) {
+                if (threadIdx.x == 0) *fail = 1;
+                return;
+            }
+            if (state == IR_LAST) ir_release(ctl, li + 1, G);
+        }
+    }
+    ir_grid_exit(ctl, nlev, G);
 }
 
 } // namespace
@@ -465,6 +535,35 @@ void solve_snodes_g(hipStream_t s, GatherMode m, const LdlView &v, const SnodeVi
     const dim3 grid(gx, count + (extra + gx - 1) / gx);
     if (m == FWD) k_snode_gfwd<<<grid, SGS_WG, 0, s>>>(v, sv, order, x, yt, count, sg);
     else k_snode_gbwd<<<grid, SGS_WG, std::max((size_t)hlvl, (size_t)16) * sizeof(double), s>>>(v, sv, order, x, yt, count, sg);
+    if (lp) lp->end(lp->ctx, PFK_SN_TRI);
+}
+
+size_t snode_gsweep_lds(GatherMode m, int hmax) {
+    return m == FWD ? SGS_FWD_LDS : std::max((size_t)hmax, (size_t)64) * sizeof(double);
+}
+int snode_gsweep_capacity(GatherMode m, size_t lds) {
+    const void *k = m == FWD ? (const void *)k_snode_gsweep<FWD> : (const void *)k_snode_gsweep<BWD>;
+    if (lds > 48 * 1024 && raise_dynamic_lds(k, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    const hipError_t e = m == FWD ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_snode_gsweep<FWD>, SGS_WG, lds)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_snode_gsweep<BWD>, SGS_WG, lds);
+    if (e != hipSuccess || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return per_cu * prop.multiProcessorCount;
+}
+void solve_snodes_gsweep(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order_all, double *x,
+                         double *yt, const GSweepLevel *lv, int nlev, int grid, size_t lds, const GatherArgs &ga, int *ctl,
+                         int *fail, const LaunchProf *lp) {
+    if (nlev <= 0 || grid <= 0) return;
+    if (lp) lp->begin(lp->ctx, PFK_SN_TRI);
+    if (m == FWD) k_snode_gsweep<FWD><<<grid, SGS_WG, lds, s>>>(v, sv, order_all, x, yt, lv, nlev, ga, ctl, fail);
+    else k_snode_gsweep<BWD><<<grid, SGS_WG, lds, s>>>(v, sv, order_all, x, yt, lv, nlev, ga, ctl, fail);
     if (lp) lp->end(lp->ctx, PFK_SN_TRI);
 }
 

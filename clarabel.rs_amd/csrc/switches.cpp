@@ -74,6 +74,8 @@ const Entry TABLE[] = {
     {"CHIP_SN_ASM_CAP", Entry::INT, SW(sn_asm_cap), 0},
     {"CHIP_NO_SOLVE_PAIR", Entry::FLAG, SW(no_solve_pair), 0},
     {"CHIP_NO_SWEEP_MERGE", Entry::FLAG, SW(no_sweep_merge), 0},
+    {"CHIP_NO_SWEEP_PERSIST", Entry::FLAG, SW(no_sweep_persist), 0},
+    {"CHIP_GSWEEP_GRID", Entry::INT, SW(gsweep_grid), 0},
     {"CHIP_NO_SNODE_G", Entry::FLAG, SW(no_snode_g), 0},
     {"CHIP_SN_G_MAXW", Entry::INT, SW(sn_g_maxw), 0},
     {"CHIP_DETERMINISTIC", Entry::FLAG, SW(deterministic), 0},

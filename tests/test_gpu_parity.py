@@ -1900,6 +1900,47 @@ def test_supernode_substitution_matrices(hip, oracle, which, monkeypatch):
     _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1, settings=st, tol=1e-5 if "late" in which else 1e-6)
 
 
+@pytest.mark.parametrize("which,grid", [("banded_qp", 0), ("banded_qp", 1), ("banded_qp", 3), ("chordal_sdp", 0),
+                                        ("chordal_sdp", 2), ("mixed_widths", 0)])
+def test_persistent_sweeps_over_runs_of_unit_levels(hip, oracle, which, grid, monkeypatch):
+    """a run of consecutive unit levels on the one-pass matrices is ONE persistent launch per sweep (snode_g.hip:
+    k_snode_gsweep, a grid barrier between the levels, the vector read and written at the coherence point): solutions
+    against the oracle, and against the launch-per-level form of the same handle shape (CHIP_NO_SWEEP_PERSIST) -- the two
+    run the same arithmetic on the supernodes' blocks; also with grids of 1, 2 and 3 workgroups (every workgroup walks
+    several tasks per level) and on a handle whose wide levels split the sweep into several runs"""
+    hs = None
+    if which == "chordal_sdp":
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    else:
+        pr = problems.random_qp(20000, 40000, band=50, seed=1)
+        if which == "mixed_widths":
+            monkeypatch.setenv("CHIP_SN_G_MAXW", "250")
+    if grid:
+        monkeypatch.setenv("CHIP_GSWEEP_GRID", str(grid))
+    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=3)
+    runs, lv = hip.debug_counter(ks, "gsweep_runs"), hip.debug_counter(ks, "gsweep_levels")
+    if which == "chordal_sdp" and runs == 0:
+        pytest.skip("no two consecutive unit levels on the one-pass matrices on this handle")
+    assert runs >= 2 and lv >= 2 * runs                      # (a forward and a backward run at least)
+    assert hip.debug_counter(ks, "gsweep_launches") >= runs  # the solves above went through them
+    monkeypatch.setenv("CHIP_NO_SWEEP_PERSIST", "1")
+    ks0, _ = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1)
+    assert hip.debug_counter(ks0, "gsweep_runs") == 0 and hip.debug_counter(ks0, "gsweep_launches") == 0
+    monkeypatch.delenv("CHIP_NO_SWEEP_PERSIST")
+    rng = np.random.default_rng(17)
+    for _ in range(2):
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        sols = []
+        for k in (ks0, ks):
+            assert k.update_scaling(pr["s"], pr["z"]) and k.update(hs)
+            k.setrhs(rx, rz)
+            x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+            assert k.solve(x, z)
+            sols.append(np.concatenate([x, z]))
+        assert relerr(sols[1], sols[0]) <= 1e-10
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_ldl_structure_fuzz_with_supernodes(hip, oracle, seed):
     """random quasidefinite matrices built to produce all kinds of tops -- banded parts (long chains),

@@ -310,23 +310,42 @@ __device__ __forceinline__ void sg_gather_block(const SweepGather &q, int gb, do
 constexpr int SGS_WG = SGS_WG_;
 constexpr int SGS_NW = SGS_WG / 64;
 constexpr size_t SGS_FWD_LDS = (size_t)(SG_WMAX + SGS_NW * 64) * sizeof(double); // x_S + the sixteen partial sums
-// one (64-row block bx, supernode by of the level) of the forward pass; xs[SG_WMAX], part[SGS_NW * 64] in LDS
-template <bool COH>
-__device__ __forceinline__ void sg_fwd_task(const LdlView &v, const SnodeView &sv, const int *__restrict__ order, double *x,
-                                            double *yt, int by, int bx, double *xs, double *part) {
-    int sn;
-    const SnodeGeom g = snode_geom(sv, order, by, sn);
-    const int r0 = 64 * bx;
-    if (r0 >= g.h) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ncols = r0 < g.w ? min(g.w, r0 + 64) : g.w; // (rows of T^-1 end at their diagonal block)
-    const int ldg = sg_ldg(g.h);
-    const int i = r0 + lane;
-    const double *Gr = sv.Gx + g.goff + min(i, g.h - 1);
+// one (64-row block bx, supernode by of the level) of the forward pass, in two halves: sg_fwd_prepare requests everything
+// that does not depend on the vector (the record, the first sixteen columns' entries of this lane's row of G, the node
+// ids of x_S) -- the persistent sweep issues it BEFORE it waits at the level's barrier --, sg_fwd_finish stages x_S and
+// does the arithmetic; xs[SG_WMAX], part[SGS_NW * 64] in LDS
+struct SgFwdPrep {
+    SnodeGeom g;
     double l[16];
+    int r0, cidx;
+    bool active;
+};
+__device__ __forceinline__ int sg_fwd_ncols(const SnodeGeom &g, int r0) { return r0 < g.w ? min(g.w, r0 + 64) : g.w; } // (rows of T^-1 end at their diagonal block)
+__device__ __forceinline__ void sg_fwd_prepare(SgFwdPrep &p, const LdlView &v, const SnodeView &sv, const int *__restrict__ order,
+                                               int by, int bx) {
+    int sn;
+    p.g = snode_geom(sv, order, by, sn);
+    const SnodeGeom &g = p.g;
+    p.r0 = 64 * bx;
+    p.active = p.r0 < g.h;
+    if (!p.active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncols = sg_fwd_ncols(g, p.r0), ldg = sg_ldg(g.h);
+    const double *Gr = sv.Gx + g.goff + min(p.r0 + lane, g.h - 1);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) l[q] = Gr[(size_t)min(wave + SGS_NW * q, ncols - 1) * ldg]; // (clamped: unconditional)
-    for (int t = tid; t < ncols; t += SGS_WG) xs[t] = sg_xload<COH>(&x[g.cols[t]]);
+    for (int q = 0; q < 16; ++q) p.l[q] = Gr[(size_t)min(wave + SGS_NW * q, ncols - 1) * ldg]; // (clamped: unconditional)
+    p.cidx = g.cols[min(tid, ncols - 1)]; // (SGS_WG >= SG_WMAX: one member per thread)
+}
+template <bool COH>
+__device__ __forceinline__ void sg_fwd_finish(SgFwdPrep &p, const LdlView &v, const SnodeView &sv, double *x, double *yt,
+                                              double *xs, double *part) {
+    if (!p.active) return;
+    const SnodeGeom &g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncols = sg_fwd_ncols(g, p.r0), ldg = sg_ldg(g.h), i = p.r0 + lane;
+    const double *Gr = sv.Gx + g.goff + min(i, g.h - 1);
+    double(&l)[16] = p.l;
+    if (tid < ncols) xs[tid] = sg_xload<COH>(&x[p.cidx]);
     __syncthreads();
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -359,6 +378,13 @@ __device__ __forceinline__ void sg_fwd_task(const LdlView &v, const SnodeView &s
         else atomicAdd(&x[v.Li[g.bn0 + i - g.w]], -tot);
     }
 }
+template <bool COH>
+__device__ __forceinline__ void sg_fwd_task(const LdlView &v, const SnodeView &sv, const int *__restrict__ order, double *x,
+                                            double *yt, int by, int bx, double *xs, double *part) {
+    SgFwdPrep p;
+    sg_fwd_prepare(p, v, sv, order, by, bx);
+    sg_fwd_finish<COH>(p, v, sv, x, yt, xs, part);
+}
 __global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
                                                        double *yt, int count, SweepGather sg) {
     __shared__ double xs[SG_WMAX];
@@ -373,27 +399,55 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gfwd(LdlView v, SnodeView sv, 
 // backward: grid (64-column blocks, supernodes of the unit level), sixteen waves of four columns each.  A wave's first
 // 4 x 4 x 64 entries are requested first, s = [D^-1 y_S ; -x_B] (from the block's first row on) is staged in LDS while
 // they are in flight; rows along the lanes, fixed order of summation, no atomics.
-template <bool COH>
-__device__ __forceinline__ void sg_bwd_task(const LdlView &v, const SnodeView &sv, const int *__restrict__ order, double *x,
-                                            const double *yt, int by, int bx, double *ss) {
-    int sn;
-    const SnodeGeom g = snode_geom(sv, order, by, sn);
-    const int j0 = 64 * bx;
-    if (j0 >= g.w) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ldg = sg_ldg(g.h);
-    const int nr = g.h - j0;
-    const int jf = j0 + 4 * wave; // this wave's columns jf .. jf + 3
-    const double *Gc[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) Gc[u] = sv.Gx + g.goff + (size_t)min(jf + u, g.w - 1) * ldg + j0;
+// (in the same two halves: the record, the wave's first 4 x 4 x 64 entries of G, and this thread's first entry of
+// s -- complete for a member row, the node id for a row of B -- do not depend on the vector)
+struct SgBwdPrep {
+    SnodeGeom g;
     double l[4][4];
+    double sval;
+    int j0, sidx;
+    bool active;
+};
+__device__ __forceinline__ const double *sg_bwd_col(const SnodeView &sv, const SnodeGeom &g, int j0, int j) {
+    return sv.Gx + g.goff + (size_t)min(j, g.w - 1) * sg_ldg(g.h) + j0;
+}
+__device__ __forceinline__ void sg_bwd_prepare(SgBwdPrep &p, const LdlView &v, const SnodeView &sv, const int *__restrict__ order,
+                                               const double *yt, int by, int bx) {
+    int sn;
+    p.g = snode_geom(sv, order, by, sn);
+    const SnodeGeom &g = p.g;
+    p.j0 = 64 * bx;
+    p.active = p.j0 < g.w;
+    if (!p.active) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nr = g.h - p.j0, jf = p.j0 + 4 * wave; // this wave's columns jf .. jf + 3
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+    for (int u = 0; u < 4; ++u) {
+        const double *Gc = sg_bwd_col(sv, g, p.j0, jf + u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) l[u][rr] = Gc[u][min(lane + 64 * rr, nr - 1)]; // (entries above the diagonal inside the block are stored zeros)
+        for (int rr = 0; rr < 4; ++rr) p.l[u][rr] = Gc[min(lane + 64 * rr, nr - 1)]; // (entries above the diagonal inside the block are stored zeros)
+    }
+    const int i = p.j0 + tid;
+    p.sidx = -1;
+    p.sval = 0.0;
+    if (i < g.w) {
+        const int c = g.cols[i];
+        p.sval = yt[c] * v.Dinv[c];
+    } else if (i < g.h) {
+        p.sidx = v.Li[g.bn0 + i - g.w];
+    }
+}
+template <bool COH>
+__device__ __forceinline__ void sg_bwd_finish(SgBwdPrep &p, const LdlView &v, const SnodeView &sv, double *x, const double *yt,
+                                              double *ss) {
+    if (!p.active) return;
+    const SnodeGeom &g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int j0 = p.j0, nr = g.h - p.j0, jf = p.j0 + 4 * (tid >> 6);
+    double(&l)[4][4] = p.l;
     const int *Bn = v.Li + g.bn0;
-    for (int i = j0 + tid; i < g.h; i += SGS_WG) {
+    if (j0 + tid < g.h) ss[tid] = p.sidx >= 0 ? -sg_xload<COH>(&x[p.sidx]) : p.sval;
+    for (int i = j0 + tid + SGS_WG; i < g.h; i += SGS_WG) {
         double val;
         if (i < g.w) {
             const int c = g.cols[i];
@@ -417,7 +471,7 @@ __device__ __forceinline__ void sg_bwd_task(const LdlView &v, const SnodeView &s
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) l[u][rr] = Gc[u][min(ib + lane + 64 * rr, nr - 1)];
+            for (int u = 0; u < 4; ++u) l[u][rr] = sg_bwd_col(sv, g, j0, jf + u)[min(ib + lane + 64 * rr, nr - 1)];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int i = ib + lane + 64 * rr;
@@ -431,6 +485,13 @@ __device__ __forceinline__ void sg_bwd_task(const LdlView &v, const SnodeView &s
         const double tot = wave_sum(a[u]);
         if (lane == 0 && jf + u < g.w) sg_xstore<COH>(&x[g.cols[jf + u]], tot);
     }
+}
+template <bool COH>
+__device__ __forceinline__ void sg_bwd_task(const LdlView &v, const SnodeView &sv, const int *__restrict__ order, double *x,
+                                            const double *yt, int by, int bx, double *ss) {
+    SgBwdPrep p;
+    sg_bwd_prepare(p, v, sv, order, yt, by, bx);
+    sg_bwd_finish<COH>(p, v, sv, x, yt, ss);
 }
 __global__ __launch_bounds__(SGS_WG) void k_snode_gbwd(LdlView v, SnodeView sv, const int *__restrict__ order, double *x,
                                                        const double *yt, int count, SweepGather sg) {
@@ -451,15 +512,70 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gbwd(LdlView v, SnodeView sv, 
 // over a co-resident grid, a grid barrier (grid_sync.hpp) separates the levels.  The vector crosses workgroups inside
 // the launch: read and written at the device's coherence point (COH above); G, L, the index lists and yt do not.
 // A barrier that cannot complete (the grid was not co-resident) raises *fail -- the solve reports a non-finite result.
+// the sweep's own barrier: ONE arrival counter (ctl[0], monotonic over the launch) and eight release words a cache line
+// apart (ctl[32 (1 + q)], polled by the workgroups with blockIdx = q mod 8) -- at most half the chip takes part, the
+// two-level counters of grid_sync.hpp (built for 1000 workgroups) would add a dependent round trip per level.  (Waiting
+// workgroups polling the arrival counter itself, one round trip less on paper, was measured: the polls queue behind the
+// arrivals on that one address and the gain of the persistent launch all but disappears.)
+__device__ __forceinline__ bool gs_barrier(int *ctl, int gen, int nwg) {
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        int ok = 1;
+        if (atomicAdd(ctl, 1) + 1 == nwg * gen) {
+            for (int q = 0; q < 8; ++q) __hip_atomic_store(ctl + 32 * (1 + q), gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const int *rel = ctl + 32 * (1 + ((int)blockIdx.x & 7));
+            long long spins = 0;
+            while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1ll << 22)) {
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+// (the last use of the words in a launch: whoever completes the count zeroes them -- every workgroup is past the last wait)
+__device__ __forceinline__ void gs_exit(int *ctl, int gen, int nwg) {
+    if (threadIdx.x != 0) return;
+    if (atomicAdd(ctl, 1) + 1 == nwg * gen) {
+        for (int q = 0; q < 8; ++q) __hip_atomic_store(ctl + 32 * (1 + q), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 template <int MODE>
 __global__ __launch_bounds__(SGS_WG) void k_snode_gsweep(LdlView v, SnodeView sv, const int *__restrict__ order_all, double *x,
                                                          double *yt, const GSweepLevel *__restrict__ lv, int nlev, GatherArgs ga,
                                                          int *ctl, int *fail) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     double *sm = (double *)gsm;
-    const int G = (int)gridDim.x;
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    SgFwdPrep pf;
+    SgBwdPrep pb;
+    pf.active = false;
+    pb.active = false;
+    GSweepLevel L = lv[0];
+    // this workgroup's FIRST task of a level is prepared ahead of the level's barrier: what it needs besides the vector
+    auto prepare_first = [&](const GSweepLevel &Lq) {
+        const bool mine = bid < Lq.gx * Lq.count;
+        const int by = mine ? bid / Lq.gx : 0, bx = mine ? bid - by * Lq.gx : 0;
+        if (MODE == FWD) {
+            pf.active = false;
+            if (mine) sg_fwd_prepare(pf, v, sv, order_all + 8 * (size_t)Lq.off, by, bx);
+        } else {
+            pb.active = false;
+            if (mine) sg_bwd_prepare(pb, v, sv, order_all + 8 * (size_t)Lq.off, yt, by, bx);
+        }
+    };
+    prepare_first(L);
     for (int li = 0; li < nlev; ++li) {
-        const GSweepLevel L = lv[li];
         SweepGather sg;
         sg.a = ga;
         sg.trows = L.trows;
@@ -471,7 +587,16 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gsweep(LdlView v, SnodeView sv
         sg.wcount = L.wcount;
         sg.ccount = L.ccount;
         const int nsn_tasks = L.gx * L.count, ntasks = nsn_tasks + sweep_gather_blocks(L.tcount, L.wcount, L.ccount);
-        for (int task = (int)blockIdx.x; task < ntasks; task += G) {
+        if (bid < ntasks) { // the task prepared ahead of the barrier
+            if (bid < nsn_tasks) {
+                if (MODE == FWD) sg_fwd_finish<true>(pf, v, sv, x, yt, sm, sm + SG_WMAX);
+                else sg_bwd_finish<true>(pb, v, sv, x, yt, sm);
+            } else {
+                sg_gather_block<MODE, true>(sg, bid - nsn_tasks, sm);
+            }
+            __syncthreads(); // (the next task stages over the same LDS)
+        }
+        for (int task = bid + G; task < ntasks; task += G) {
             if (task < nsn_tasks) {
                 const int by = task / L.gx, bx = task - by * L.gx;
                 if (MODE == FWD) sg_fwd_task<true>(v, sv, order_all + 8 * (size_t)L.off, x, yt, by, bx, sm, sm + SG_WMAX);
@@ -479,19 +604,19 @@ __global__ __launch_bounds__(SGS_WG) void k_snode_gsweep(LdlView v, SnodeView sv
             } else {
                 sg_gather_block<MODE, true>(sg, task - nsn_tasks, sm);
             }
-            __syncthreads(); // (the next task stages over the same LDS)
+            __syncthreads();
         }
         if (li + 1 < nlev) {
+            L = lv[li + 1];
+            prepare_first(L);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's stores and atomics are performed
-            const int state = ir_arrive_wait(ctl, li + 1, G);
-            if (state == IR_TIMEOUT) {
+            if (!gs_barrier(ctl, li + 1, G)) {
                 if (threadIdx.x == 0) *fail = 1;
                 return;
             }
-            if (state == IR_LAST) ir_release(ctl, li + 1, G);
         }
     }
-    ir_grid_exit(ctl, nlev, G);
+    gs_exit(ctl, nlev, G);
 }
 
 } // namespace

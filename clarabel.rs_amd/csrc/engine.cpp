@@ -26,6 +26,9 @@ Engine::~Engine() {
     if (alt.nrm_host) (void)hipHostFree(alt.nrm_host);
     if (alt.stream) (void)hipStreamDestroy(alt.stream);
     if (pair_event) (void)hipEventDestroy(pair_event);
+    if (snb_ready) (void)hipEventDestroy(snb_ready);
+    for (hipEvent_t ev : snb_events)
+        if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -236,6 +239,21 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if (nsn > 0) {
         if ((rc = upload_lists(snx, S.snx))) return rc;
         if ((rc = upload_lists(snb, S.snb))) return rc;
+        { // groups of unit levels whose bundle contributions run beside the supernode chain (refactor_enqueue): level 0
+          // alone, then levels until a group holds >= 8 % of the work
+            long long total = 0;
+            for (long long w : S.snb_work) total += w;
+            snb_group_at.assign((size_t)S.nfaclevels + 1, -1);
+            const int nl = std::min((int)S.snb_work.size(), S.nfaclevels);
+            for (int l = 0; l < nl && total > 0;) {
+                const int l0 = l;
+                long long acc = 0;
+                do acc += S.snb_work[(size_t)l++];
+                while (l0 > 0 && l < nl && acc * 100 < total * 8);
+                snb_group_at[(size_t)l0] = (i32)snb_groups.size();
+                snb_groups.push_back({l0, l});
+            }
+        }
         if ((rc = upload_lists(fwu, S.fwu))) return rc;
         if ((rc = upload_lists(bwu, S.bwu))) return rc;
         nRf = S.Rf_p.empty() ? 0 : S.Rf_p.back();
@@ -1113,8 +1131,13 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     // only (CHIP_DETERMINISTIC, or CHIP_EXTEND_ASM_MIN = fewest supernodes of a level).  Measured: the atomics are NOT
     // what bounds k_snode_extend -- with the assembly config 5 is 0.5 ms per step slower (49.2 against 48.7), config 2 0.2 ms
     const int asm_min = switches().deterministic ? 2 : switches().extend_asm_min > 0 ? switches().extend_asm_min : (1 << 30);
+    size_t snb_waited = 1; // groups whose event the stream has waited for (group 0 runs on the stream itself)
+    bool snb_beside = false;
     auto run_supernodes = [&](int l) {
         if (!has_sn(l)) return;
+        if (snb_beside)
+            for (; snb_waited < snb_groups.size() && snb_groups[snb_waited].first <= l; snb_waited++)
+                (void)hipStreamWaitEvent(stream, snb_events[snb_waited], 0);
         dev::factor_B(stream, vf, snx.B(l));
         const int count = sn_lvl_ptr[l + 1] - sn_lvl_ptr[l];
         dev::SnodeAsmView av{asm_tgt, asm_src_ptr, asm_src, 0, 0};
@@ -1127,7 +1150,33 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     };
     // the bundle columns' contributions into the supernode members of ALL unit levels: one launch (they depend on nothing
     // in the top; the chunks meet the other contributions in the same fp64 atomics)
-    if (nsn > 0 && !top_folded && !snb.b_ptr.empty() && snb.b_ptr.size() > 1) dev::factor_B(stream, vf, snb.B(0));
+    // Beside the chain (round 5): the chain of block columns that follows is a sequence of small dependent launches that
+    // leaves most of the chip idle, and only level 0's supernodes need their contributions before it starts -- the lists
+    // of the later levels run on the second stream, group by group, each group's event awaited ahead of its first level.
+    // Everything that lands in a member column while the chain runs is an fp64 atomic (these chunks, k_snode_extend);
+    // not with assembled updates / CHIP_DETERMINISTIC (plain read-modify-writes), not while launches are being timed.
+    const int nsl = (int)snb.b_ptr.size() - 1;
+    bool beside = nsn > 0 && !top_folded && snb_groups.size() > 1 && !switches().no_factor_overlap && asm_min == (1 << 30) &&
+                  prof_family == PF_NONE && !alt_active;
+    if (beside && ensure_alt() != CHIP_OK) beside = false;
+    if (beside) {
+        if (!snb_ready) CHIP_HIP(hipEventCreateWithFlags(&snb_ready, hipEventDisableTiming));
+        while (snb_events.size() < snb_groups.size()) {
+            hipEvent_t ev = nullptr;
+            CHIP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            snb_events.push_back(ev);
+        }
+        dev::factor_B(stream, vf, snb.Brange(snb_groups[0].first, snb_groups[0].second));
+        CHIP_HIP(hipEventRecord(snb_ready, stream));
+        CHIP_HIP(hipStreamWaitEvent(alt.stream, snb_ready, 0));
+        for (size_t g = 1; g < snb_groups.size(); g++) {
+            dev::factor_B(alt.stream, vf, snb.Brange(snb_groups[g].first, snb_groups[g].second));
+            CHIP_HIP(hipEventRecord(snb_events[g], alt.stream));
+        }
+    } else if (nsn > 0 && !top_folded && nsl >= 1) {
+        dev::factor_B(stream, vf, snb.Brange(0, nsl));
+    }
+    snb_beside = beside;
     for (int l = top_folded ? nfaclevels : 0; l < nfaclevels;) {
         int e = fac.chain_end[l];
         for (int k = l; k < e; k++)
@@ -1153,6 +1202,8 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         run_supernodes(l);
         l++;
     }
+    if (snb_beside)
+        for (; snb_waited < snb_groups.size(); snb_waited++) (void)hipStreamWaitEvent(stream, snb_events[snb_waited], 0);
     if (nsn > 0) dev::gather_values(stream, Rfx, Lx, Rf_pos, nRf); // L at the filtered row lists (forward sweep)
     if (sn_g_ntasks > 0) { // the substitution matrices of the supernodes of moderate width, all of them in one launch
         dev::SnodeView sg = snode_view();

@@ -26,6 +26,9 @@ struct DeviceLists {
     dev::ChunkView B(int l) const {
         return {b_row + b_ptr[l], b_beg + b_ptr[l], b_end + b_ptr[l], b_ptr[l + 1] - b_ptr[l]};
     }
+    dev::ChunkView Brange(int l0, int l1) const { // the chunks of levels [l0, l1): contiguous
+        return {b_row + b_ptr[l0], b_beg + b_ptr[l0], b_end + b_ptr[l0], b_ptr[l1] - b_ptr[l0]};
+    }
 };
 
 // small device<->host mailbox (one 256-byte D2H copy per decision point)
@@ -80,6 +83,12 @@ struct Engine {
     // chain supernodes (host.hpp: Symbolic::sn_*): factor lists `fac` and `snx` are indexed by UNIT level
     int nfaclevels = 0, nsn = 0, sn_wmax = 0;
     DeviceLists snx, snb, fwu, bwu;
+    // snb beside the supernode chain (refactor_enqueue): groups of unit levels [first, second), the event each group's launch
+    // on the second stream records, the group that starts at a level (-1: none)
+    std::vector<std::pair<int, int>> snb_groups;
+    std::vector<hipEvent_t> snb_events;
+    std::vector<i32> snb_group_at;
+    hipEvent_t snb_ready = nullptr;
     double *Rfx = nullptr; // values of L at the filtered row lists (refreshed per refactor)
     int nRf = 0, sn_nbmax = 0;
     int *sn_geo = nullptr, *sn_cb = nullptr, *sn_ptr = nullptr, *sn_col = nullptr, *sn_order = nullptr, *Rf_p = nullptr, *Rf_col = nullptr,

@@ -195,8 +195,9 @@ struct Symbolic {
     // k_snode_fwd), bwu = columns of the single top columns (the members' columns: k_snode_bwd)
     LevelLists fwu, bwu;
     LevelLists snx;                             // per unit level: B chunks (b_row = member column, ranges into Rf_*)
-    LevelLists snb;                             // ONE level: the chunks of all members over the bundle columns of their lists
-                                                // (taken ahead of the top's levels; snx then keeps the top columns only)
+    LevelLists snb;                             // per unit level of the target: the chunks of the members over the bundle columns of
+                                                // their lists (they depend on nothing in the top; snx then keeps the top columns only)
+    std::vector<long long> snb_work;            // ... and their work (multiply-adds) per level
     // K for the residual e = b - K x, permuted numbering:
     //   U : rows i < NF (bundle nodes): diagonal + entries to ancestors, each K entry ONCE -- these ARE
     //       the first nnzU entries of V (no copy)

@@ -29,6 +29,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_CHAIN_REORDER", Entry::FLAG, SW(no_chain_reorder), 0},
     {"CHIP_NO_BUNDLES", Entry::FLAG, SW(no_bundles), 0},
     {"CHIP_BUNDLE_MAX_WORK", Entry::LONG, SW(bundle_max_work), 0},
+    {"CHIP_SNB_CHUNK", Entry::LONG, SW(snb_chunk), 0},
     {"CHIP_NO_GROUPFOLD", Entry::FLAG, SW(no_groupfold), 0},
     {"CHIP_GROUPFOLD_MIN", Entry::LONG, SW(groupfold_min), 0},
     {"CHIP_TARGET_WG", Entry::INT, SW(target_wg), SW(has_target_wg)},
@@ -72,6 +73,7 @@ const Entry TABLE[] = {
     {"CHIP_EXTEND_ASM_MIN", Entry::INT, SW(extend_asm_min), 0},
     {"CHIP_NO_XCD_MAP", Entry::FLAG, SW(no_xcd_map), 0},
     {"CHIP_SN_ASM_CAP", Entry::INT, SW(sn_asm_cap), 0},
+    {"CHIP_NO_FACTOR_OVERLAP", Entry::FLAG, SW(no_factor_overlap), 0},
     {"CHIP_NO_SOLVE_PAIR", Entry::FLAG, SW(no_solve_pair), 0},
     {"CHIP_NO_SWEEP_MERGE", Entry::FLAG, SW(no_sweep_merge), 0},
     {"CHIP_NO_SWEEP_PERSIST", Entry::FLAG, SW(no_sweep_persist), 0},

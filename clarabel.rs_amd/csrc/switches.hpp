@@ -34,6 +34,7 @@ struct Switches {
     bool no_factor_flat = false;    // CHIP_NO_FACTOR_FLAT (also read by the launcher of the bundle factorisation)
     bool no_topblk = false;         // CHIP_NO_TOPBLK
     bool no_gather_hoist = false;   // CHIP_NO_GATHER_HOIST
+    long long snb_chunk = 0;        // CHIP_SNB_CHUNK: fewest updates of a chunk of the bundle columns' contributions into a supernode member (0: default)
     bool no_snx_hoist = false;      // CHIP_NO_SNX_HOIST: the bundle columns' contributions into supernode members stay in the launches of the members' unit levels
     bool no_psd_mfma = false;       // CHIP_NO_PSD_MFMA: the n x n products of the PSD cone kernels as scalar dot products, not on the matrix cores
     bool no_psd_rows = false;       // CHIP_NO_PSD_ROWS: the Hs blocks of PSD cones written through mapHs (caller's order), not row by row
@@ -69,6 +70,7 @@ struct Switches {
     int extend_asm_min = 0;         // CHIP_EXTEND_ASM_MIN: fewest supernodes of a level whose updates are assembled (0: never, unless CHIP_DETERMINISTIC)
     bool no_xcd_map = false;        // CHIP_NO_XCD_MAP: the tiles of k_snode_extend spread over the XCDs, not one supernode per XCD
     int sn_asm_cap = 0;             // CHIP_SN_ASM_CAP: rows of a target column per LDS window of k_snode_assemble (tests; 0: 4096)
+    bool no_factor_overlap = false; // CHIP_NO_FACTOR_OVERLAP: the bundle columns' contributions into supernode members all ahead of the supernode chain, none beside it on the second stream
     bool no_solve_pair = false;     // CHIP_NO_SOLVE_PAIR: chip_kkt_solve2_dev_enqueue runs its two solves one after the other on every handle
     bool no_sweep_merge = false;    // CHIP_NO_SWEEP_MERGE: the row gathers of a unit level in their own launch, also next to supernodes on the one-pass matrices
     bool no_sweep_persist = false;  // CHIP_NO_SWEEP_PERSIST: a launch per unit level on the one-pass matrices, no persistent launch per run of levels (k_snode_gsweep)

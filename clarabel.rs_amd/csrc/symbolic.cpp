@@ -192,10 +192,12 @@ struct ListBuilder {
     // tail(t) = Lp[k+1] - (Rpos[t]+1) entries; a chunk closes at B_CHUNK contributions or at its
     // share of the column's updates (about 1/96 of them, between 1024 and 4096: a 33k-update column
     // of config 2 becomes ~32 chunks, an 800k-update dense PSD column of config 5 ~200)
+    // (chunk_min / chunk_max: other bounds of a chunk's updates, 0: the defaults above)
     void add_B_work(i32 r, i64 beg, i64 end, const i32 *Rcol, const i32 *Rpos, const std::vector<i32> &Lp,
-                    i64 total_work) {
+                    i64 total_work, i64 chunk_min = 0, i64 chunk_max = 0) {
         L.br_idx.push_back(r);
-        const i64 F_CHUNK_WORK = std::min(F_CHUNK_MAX, std::max(F_CHUNK_MIN, total_work / F_CHUNK_PARTS));
+        const i64 F_CHUNK_WORK = std::min(chunk_max > 0 ? chunk_max : F_CHUNK_MAX,
+                                          std::max(chunk_min > 0 ? chunk_min : F_CHUNK_MIN, total_work / F_CHUNK_PARTS));
         i64 b = beg, work = 0;
         for (i64 t = beg; t < end; t++) {
             work += Lp[Rcol[t] + 1] - (Rpos[t] + 1) + 1;
@@ -1567,21 +1569,40 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             bwu.close_level();
         }
         {
-            // contributions of bundle columns into supernode members, all unit levels together (see above)
+            // contributions of bundle columns into supernode members (see above), one list per unit level of the TARGET's
+            // supernode: the engine takes the first levels' lists ahead of the supernode chain and the rest beside it
             ListBuilder snb(S.snb);
-            if (nsn > 0 && !switches().no_snx_hoist)
-                for (i32 sn = 0; sn < nsn; sn++)
-                    for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) {
-                        const i32 j = S.sn_col[t];
-                        const i32 eb = FRp[j];
-                        i32 mid = eb;
-                        while (mid < FRp[j + 1] && FRcol[mid] < NFi) mid++;
-                        if (mid == eb) continue;
-                        i64 work = 0;
-                        for (i32 q = eb; q < mid; q++) work += S.Lp[FRcol[q] + 1] - (FRpos[q] + 1) + 1;
-                        snb.add_B_work(j, eb, mid, FRcol, FRpos, S.Lp, work);
+            // (chunks of >= 16384 updates: a member column is rarely split -- with the general bounds, 1024 - 4096, config 2's
+            // 184 M updates were 170 000 workgroups of ~4 updates per thread, each paying the staging of its column, a scan and
+            // one global atomic per row of the column: 0.4 ms per step)
+            const i64 snb_chunk = switches().snb_chunk > 0 ? switches().snb_chunk : 16384;
+            for (i32 l = 0; l < nfl; l++) {
+                i64 lwork = 0, lcontrib = 0, lcols = 0, lrows = 0;
+                if (nsn > 0 && !switches().no_snx_hoist)
+                    for (i32 o = S.sn_lvl_ptr[l]; o < S.sn_lvl_ptr[l + 1]; o++) {
+                        const i32 sn = S.sn_order[o];
+                        for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) {
+                            const i32 j = S.sn_col[t];
+                            const i32 eb = FRp[j];
+                            i32 mid = eb;
+                            while (mid < FRp[j + 1] && FRcol[mid] < NFi) mid++;
+                            if (mid == eb) continue;
+                            i64 work = 0;
+                            for (i32 q = eb; q < mid; q++) work += S.Lp[FRcol[q] + 1] - (FRpos[q] + 1) + 1;
+                            snb.add_B_work(j, eb, mid, FRcol, FRpos, S.Lp, work, snb_chunk, 4 * snb_chunk);
+                            lwork += work;
+                            lcontrib += mid - eb;
+                            lcols++;
+                            lrows += S.Lp[j + 1] - S.Lp[j];
+                        }
                     }
-            snb.close_level();
+                snb.close_level();
+                S.snb_work.push_back(lwork);
+                if (switches().timing && lwork)
+                    fprintf(stderr, "[chip] snb level %d: work %lld, %lld contributions into %lld columns (%lld rows), %d chunks\n", (int)l,
+                            (long long)lwork, (long long)lcontrib, (long long)lcols, (long long)lrows,
+                            (int)(S.snb.b_ptr.empty() ? 0 : S.snb.b_ptr.back()));
+            }
         }
         ListBuilder smv(S.smv);
         for (i32 j = S.NF; j < n; j++) {

@@ -1730,15 +1730,18 @@ def test_chain_supernodes_factor_parity(hip, oracle, which, monkeypatch):
 
 
 @pytest.mark.parametrize("form", ["CHIP_NO_SNODE_PANEL", "CHIP_NO_PANEL_MFMA", "CHIP_NO_PANEL_DIAG_MFMA", "CHIP_SN_PANEL_SLOTS",
-                                  "CHIP_NO_PANEL_OVERLAP", "CHIP_NO_PANEL_OVERLAP+CHIP_SN_PANEL_SLOTS", "CHIP_NO_PANEL_UNIFORM"])
+                                  "CHIP_NO_PANEL_OVERLAP", "CHIP_NO_PANEL_OVERLAP+CHIP_SN_PANEL_SLOTS", "CHIP_NO_PANEL_UNIFORM",
+                                  "CHIP_NO_FACTOR_OVERLAP"])
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp"])
 def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
     """the block column of a supernode has three older forms behind switches -- separate k_snode_diag / k_snode_rows
     launches, and the scalar forms of the panel kernel's two phases -- and, in launches with many supernodes, a form in
     which a workgroup walks several groups of 256 rows (CHIP_SN_PANEL_SLOTS=1 forces it here: one workgroup per
     supernode); CHIP_NO_PANEL_OVERLAP: the panel kernel whose block factorisation and rows run one after the other
-    (k_snode_panel) instead of overlapped by two teams of waves (k_snode_panel2, the default): each against the oracle,
-    and its factor against the default form's (same pivots, entries within rounding)"""
+    (k_snode_panel) instead of overlapped by two teams of waves (k_snode_panel2, the default); CHIP_NO_FACTOR_OVERLAP: the
+    bundle columns' contributions into the supernode members all ahead of the chain of block columns instead of beside it
+    on the second stream: each against the oracle, and its factor against the default form's (same pivots, entries
+    within rounding)"""
     if which == "banded_qp":
         pr, hs = problems.random_qp(20000, 40000, band=50, seed=1), None
     else:

@@ -232,9 +232,10 @@ def sweep_roofline(ks, wm, prof, steps, nsolves):
     sweeps = 2 * nsolves
     if sm["g_levels"] > 0 and sm["g_levels"] == sm["sn_levels"]:
         per_sweep = 8.0 * sm["g_doubles"]
-        kernel = ("k_snode_gfwd / k_snode_gbwd (one pass over G = [I; L_B] T^-1 of every supernode of a unit level, forward "
-                  "and backward sweeps; %d unit levels, G built once per refactor by k_snode_ginv)" % sm["g_levels"])
-        short = "k_snode_gfwd"
+        kernel = ("k_snode_gsweep / k_snode_gfwd / k_snode_gbwd (one pass over G = [I; L_B] T^-1 of every supernode, forward and "
+                  "backward sweeps; %d unit levels -- a run of consecutive levels is one persistent launch, a level with more "
+                  "blocks than two rounds of its grid a launch of its own; G built once per refactor by k_snode_ginv)" % sm["g_levels"])
+        short = "k_snode_gsweep"
     else:
         per_sweep = 12.0 * wm["sn_panel_entries"]
         kernel = ("k_snode_tri (pipelined substitution through the wide chain supernodes of one unit level, forward and "
@@ -961,11 +962,13 @@ def main():
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic%s.json" % suffix))) if suffix is not None else []
             knames = {1: ["k_bundle_symv"], 5: ["k_gstep_solve" if ks.step_kernels() & 1 else "k_bundle_ir"], 6: ["k_bundle_factor"],
                       7: ["k_snode_update"],
-                      11: ["k_snode_gfwd", "k_snode_gbwd"] if ks.sweep_model()["g_levels"] else ["k_snode_tri"]}.get(fam)
+                      11: ["k_snode_gsweep", "k_snode_gfwd", "k_snode_gbwd"] if ks.sweep_model()["g_levels"] else ["k_snode_tri"]}.get(fam)
             full_size = (workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000) or workload in ("c2", "c5", "c4")
             if pj and knames and full_size:
                 kk = json.load(open(pj[-1]))["kernels"]
-                traffic = round(sum(kk[k]["hbm_bytes"] for k in knames) / len(knames))  # (mean over the family's kernels, per launch)
+                have = [k for k in knames if k in kk]  # (launch-weighted mean over the family's kernels, per launch)
+                traffic = round(sum(kk[k]["hbm_bytes"] * kk[k].get("launches_sampled", 1) for k in have) /
+                                sum(kk[k].get("launches_sampled", 1) for k in have))
                 traffic_src = os.path.basename(pj[-1])
         except Exception:
             traffic = None

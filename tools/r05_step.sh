@@ -6,6 +6,6 @@ case $W in
   *) extra="--workload $W";;
 esac
 (cd /tmp && export TMPDIR=/tmp && env "$@" timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/step_$TAG -o r -- python $R/bench.py $extra --cpu-steps 0 --steps 4 --warmup 1 --no-extras > $O/step_$TAG.log 2>&1)
-python $R/tools/trace_step.py $O/step_$TAG/r_kernel_trace.csv > $O/${TAG}_step_$W.txt 2>&1
+python $R/tools/trace_step.py $O/step_$TAG/r_kernel_trace.csv $MARKER > $O/${TAG}_step_$W.txt 2>&1
 head -5 $O/${TAG}_step_$W.txt | cut -c1-200
 rm -rf $O/step_$TAG

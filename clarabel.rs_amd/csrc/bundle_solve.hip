@@ -7,6 +7,8 @@
 namespace chip {
 namespace dev {
 
+constexpr int BSF_MAXLEV = 64; // levels of a bundle the entry-parallel stand-alone sweeps keep entry pointers for
+
 namespace {
 
 // one row (forward: row of L, all inside the bundle; backward: column of L, ancestors inside the
@@ -238,6 +240,120 @@ __device__ __forceinline__ double store_row(const GatherArgs &a, int r, double s
     else v = a.aux[r] - s;
     a.out[r] = v;
     return v;
+}
+
+// ---------------------------------------------------------------------------
+// The same two sweeps ENTRY-parallel (round 5), for systems whose top is level-scheduled (BASELINE config 2: 645 bundles
+// of ~360 nodes and up to 39 levels): the row- / column-per-thread form above pays one dependent round trip per shot of
+// a row's entries on every level (2.7 us per level, 106 us per sweep, twelve sweeps per step).  The entries of a bundle's
+// columns are contiguous level by level and do not depend on x: they are walked as ONE stream of batches of BWG * BSF_U
+// (row, column, value) triples, the next batch requested before the current one is consumed -- across level boundaries
+// too --, every entry one LDS atomic: a level costs its barrier plus the LDS work (as bundle_sweep_flat of k_bundle_ir).
+//   forward : x_i -= l_ij x_j for the rows i INSIDE the bundle (the top rows gather from the bundle columns in their own
+//             launches, as before); row 0xFFFF = a top row: skipped.
+//   backward: the top rows' share  x_j -= l_ij x_i (i in the top: final)  is independent of the bundle's own unknowns and
+//             taken by a flat prologue over all entries; the level loop then handles the rows inside the bundle only.
+// The sums meet in ds_add_f64 in arrival order (like the fused kernels'); CHIP_DETERMINISTIC / CHIP_NO_BUNDLE_FLAT_SWEEP
+// keep the form above.
+// ---------------------------------------------------------------------------
+constexpr int BSF_U = 4;
+template <bool FWDMODE>
+__global__ __launch_bounds__(BWG) void k_bundle_sweep_flat(LdlView v, BundleView bv, double *x, const double *__restrict__ addv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem;
+    __shared__ int lev_e[BSF_MAXLEV + 1];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
+    const int *lv = bv.blvl + bv.blvl_ptr[b];
+    const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
+    const unsigned short *__restrict__ Li16 = v.sLi16, *__restrict__ Lj16 = v.sLj16;
+    if (tid <= nl) lev_e[tid] = v.Lp[lv[tid]];
+    if (FWDMODE) {
+        for (int i = tid; i < nloc; i += BWG) xs[i] = x[s0 + i];
+    } else {
+        for (int i = tid; i < nloc; i += BWG) xs[i] = x[s0 + i] * v.Dinv[s0 + i];
+    }
+    __syncthreads();
+    if (!FWDMODE) {
+        // the top rows' share: eight entries per thread in flight, the gathers from x behind them
+        const int e0 = lev_e[0], e1 = lev_e[nl];
+        for (int base = e0; base < e1; base += 8 * BWG) {
+            int gi[8], jj[8];
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = base + u * BWG + tid;
+                const bool top = t < e1 && Li16[min(t, e1 - 1)] == 0xFFFFu;
+                gi[u] = top ? v.Li[t] : -1;
+                jj[u] = top ? (int)Lj16[t] : 0;
+                vv[u] = top ? v.Lx[t] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (gi[u] >= 0) atomicAdd(&xs[jj[u]], -(vv[u] * x[gi[u]]));
+        }
+        __syncthreads();
+    }
+    // levels: forward ascending (leaves first), backward descending
+    int step = 0, base = 0, ee = 0;
+    auto level_range = [&](int st_, int &eb_, int &ee_) {
+        const int l = FWDMODE ? st_ : nl - 1 - st_;
+        eb_ = lev_e[l];
+        ee_ = lev_e[l + 1];
+    };
+    while (step < nl) { // first non-empty level
+        level_range(step, base, ee);
+        if (base < ee) break;
+        ++step;
+    }
+    int ci[BSF_U], cj[BSF_U], ni[BSF_U], nj[BSF_U];
+    double cv[BSF_U], nv[BSF_U];
+    auto request = [&](int bs, int en, int *ii, int *jj, double *vv) {
+#pragma unroll
+        for (int u = 0; u < BSF_U; ++u) {
+            const int t = bs + u * BWG + tid;
+            const bool ok = t < en;
+            ii[u] = ok ? (int)Li16[t] : 0xFFFF;
+            jj[u] = ok ? (int)Lj16[t] : 0;
+            vv[u] = ok ? v.Lx[t] : 0.0;
+        }
+    };
+    if (step < nl) request(base, ee, ci, cj, cv);
+    while (step < nl) {
+        int nstep = step, nbase = base + BWG * BSF_U, nee = ee; // the batch after this one
+        if (nbase >= nee) {
+            nstep = step + 1;
+            while (nstep < nl) {
+                level_range(nstep, nbase, nee);
+                if (nbase < nee) break;
+                ++nstep;
+            }
+        }
+        if (nstep < nl) request(nbase, nee, ni, nj, nv);
+#pragma unroll
+        for (int u = 0; u < BSF_U; ++u) {
+            const int i = ci[u];
+            if (i >= nloc) continue; // (a top row, or beyond the batch)
+            if (FWDMODE) atomicAdd(&xs[i], -(cv[u] * xs[cj[u]]));
+            else atomicAdd(&xs[cj[u]], -(cv[u] * xs[i]));
+        }
+        if (nstep != step) __syncthreads(); // the level is complete
+        step = nstep;
+        base = nbase;
+        ee = nee;
+#pragma unroll
+        for (int u = 0; u < BSF_U; ++u) {
+            ci[u] = ni[u];
+            cj[u] = nj[u];
+            cv[u] = nv[u];
+        }
+    }
+    __syncthreads();
+    // addv: the refinement step x + dx folded into the final write of the backward sweep
+    if (addv)
+        for (int i = tid; i < nloc; i += BWG) x[s0 + i] = xs[i] + addv[s0 + i];
+    else
+        for (int i = tid; i < nloc; i += BWG) x[s0 + i] = xs[i];
 }
 
 template <int MODE>
@@ -628,11 +744,20 @@ __global__ __launch_bounds__(WG) void k_norm_rows(const double *__restrict__ vv,
 } // namespace
 
 static size_t bundle_lds(const BundleView &bv) { return ((size_t)bv.max_nodes * sizeof(double) + 15) & ~(size_t)15; }
+// the entry-parallel form: the system has the 16-bit local indices, every bundle's level table fits, no fold
+static bool bundle_sweeps_flat(const LdlView &v, const BundleView &bv, const FoldView *fold) {
+    return v.sLi16 && v.sLj16 && bv.max_levels <= BSF_MAXLEV && !(fold && fold->k) && !switches().no_bundle_flat_sweep &&
+           !switches().deterministic;
+}
 void bundle_fwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const FoldView &fold) {
-    if (bv.nb) k_bundle_fwd<<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, fold);
+    if (!bv.nb) return;
+    if (bundle_sweeps_flat(v, bv, &fold)) k_bundle_sweep_flat<true><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, nullptr);
+    else k_bundle_fwd<<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, fold);
 }
 void bundle_bwd(hipStream_t s, const LdlView &v, const BundleView &bv, double *x, const double *addv) {
-    if (bv.nb) k_bundle_bwd<<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv);
+    if (!bv.nb) return;
+    if (bundle_sweeps_flat(v, bv, nullptr)) k_bundle_sweep_flat<false><<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv);
+    else k_bundle_bwd<<<bv.nb, BWG, bundle_lds(bv), s>>>(v, bv, x, addv);
 }
 void fold_top_solve(hipStream_t s, const LdlView &v, const FoldView &fold, double *x) {
     if (fold.k) k_fold_top_solve<<<1, 64, 0, s>>>(v, fold, x);

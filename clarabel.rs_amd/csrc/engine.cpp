@@ -455,6 +455,11 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         bundles.blvl_ptr = lp;
         bundles.blvl = lv;
         bundles.max_nodes = S.max_bundle_nodes;
+        bundles.max_levels = S.max_bundle_levels;
+        if (!S.sLi16.empty()) {
+            if ((rc = upload(&sLi16, S.sLi16, S.sLi16.size()))) return rc;
+            if ((rc = upload(&sLj16, S.sLj16, S.sLj16.size()))) return rc;
+        }
     }
     if (S.nfold > 0) {
         int *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *a4 = nullptr, *a5 = nullptr;
@@ -794,6 +799,8 @@ dev::LdlView Engine::view() const {
     v.Ro16 = Ro16;
     v.Ucol16 = Ucol16;
     v.mirror_rows = ir_fused ? 0 : 1;
+    v.sLi16 = sLi16;
+    v.sLj16 = sLj16;
     return v;
 }
 

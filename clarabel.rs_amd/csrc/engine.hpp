@@ -167,6 +167,7 @@ struct Engine {
     bool rx_valid = false; // fused handles: the row-major copy Rx of L is only refreshed when the one-kernel-per-phase path runs
     bool sx_valid = false; // grouped fold: the full rows Sx of the top likewise (the fused launch reads K's own values)
     unsigned short *Li16 = nullptr, *Ucol16 = nullptr, *Lj16 = nullptr, *Urow16 = nullptr, *Rk16 = nullptr, *Ro16 = nullptr;
+    unsigned short *sLi16 = nullptr, *sLj16 = nullptr; // dev::LdlView::sLi16
     unsigned short *fu_rec = nullptr, *fu_slot = nullptr;
     int *fu_ptr = nullptr;
     // grouped fold with small bundles: the step kernels (dev::gstep_solve / gstep_factor); gstep.desc == nullptr: not used

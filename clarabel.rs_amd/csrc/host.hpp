@@ -139,6 +139,11 @@ struct Symbolic {
     // columns of L (Li16, parallel to Li[0 .. Lp[NF])) and of the U rows (Ucol16); an index >= the
     // bundle's node count nloc stands for top row NF + (index - nloc).  Empty otherwise.
     std::vector<uint16_t> Li16, Ucol16;
+    // ... or, for systems with a level-scheduled top (no fold), only what the entry-parallel sweeps of the stand-alone bundle
+    // kernels need (k_bundle_sweep_flat): bundle-local row (0xFFFF: a top row) and column of every entry of the bundle
+    // columns of L, and the most levels of a bundle.  Empty when Li16 is not (the fused solve covers those systems).
+    std::vector<uint16_t> sLi16, sLj16;
+    i32 max_bundle_levels = 0;
     // ... and, for the entry-parallel ("flat") sweeps and residual of k_bundle_ir, the bundle-local COLUMN of every
     // entry of the bundle columns of L (Lj16) and the bundle-local ROW of every entry of the U rows (Urow16)
     std::vector<uint16_t> Lj16, Urow16;

@@ -41,6 +41,9 @@ struct LdlView {
     const unsigned short *fu_rec, *fu_slot; // entry-parallel bundle factorisation (host.hpp: Symbolic::fu_rec), or nullptr
     const int *fu_ptr;
     int mirror_rows;
+    // systems with a level-scheduled top: bundle-local row (0xFFFF: a top row) / column of the entries of the bundle columns,
+    // for the entry-parallel stand-alone sweeps (k_bundle_sweep_flat; host.hpp: Symbolic::sLi16), or nullptr
+    const unsigned short *sLi16, *sLj16;
 };
 
 // subtree bundles: bundle b = nodes [bundle_ptr[b], bundle_ptr[b+1]); its level boundaries are
@@ -54,6 +57,7 @@ struct BundleView {
     // "split" form (bundle_symv_split: x of the non-leaf nodes AND the residual in LDS, no gathers from global
     // memory), which needs nloc + max(0, nloc - 2 nleaf) doubles for every bundle
     int ir_lds_doubles, symv_split;
+    int max_levels; // most levels of a bundle
 };
 
 // Few dense top rows folded into the bundle kernels (host.hpp: Symbolic::nfold); k == 0: unused

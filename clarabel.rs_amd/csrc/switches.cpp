@@ -50,6 +50,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_FACTOR_LDS", Entry::FLAG, SW(no_factor_lds), 0},
     {"CHIP_NO_FACTOR_CHAIN", Entry::FLAG, SW(no_factor_chain), 0},
     {"CHIP_NO_SNODE_TRI", Entry::FLAG, SW(no_snode_tri), 0},
+    {"CHIP_NO_BUNDLE_FLAT_SWEEP", Entry::FLAG, SW(no_bundle_flat_sweep), 0},
     {"CHIP_NO_FLAT", Entry::FLAG, SW(no_flat), 0},
     {"CHIP_NO_IR1024", Entry::FLAG, SW(no_ir1024), 0},
     {"CHIP_IR_TEST_DROP", Entry::FLAG, SW(ir_test_drop), 0},

@@ -47,6 +47,7 @@ struct Switches {
     bool no_factor_lds = false;     // CHIP_NO_FACTOR_LDS
     bool no_factor_chain = false;   // CHIP_NO_FACTOR_CHAIN
     bool no_snode_tri = false;      // CHIP_NO_SNODE_TRI
+    bool no_bundle_flat_sweep = false; // CHIP_NO_BUNDLE_FLAT_SWEEP: the stand-alone bundle sweeps keep the row- / column-per-thread form (k_bundle_fwd / bwd), no entry-parallel form (k_bundle_sweep_flat)
     bool no_flat = false;           // CHIP_NO_FLAT: column-per-thread sweeps inside k_bundle_ir
     bool no_ir1024 = false;         // CHIP_NO_IR1024
     bool ir_test_drop = false;      // CHIP_IR_TEST_DROP (tests: a fused launch that cannot complete its barrier)

@@ -1226,6 +1226,29 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             }
         }
     }
+    // ---- ... and for the entry-parallel sweeps of the stand-alone bundle kernels (systems with a level-scheduled top) ----
+    {
+        const i32 nbun = S.bundle_ptr.empty() ? 0 : (i32)S.bundle_ptr.size() - 1;
+        S.max_bundle_levels = 0;
+        for (i32 b = 0; b < nbun; b++) S.max_bundle_levels = std::max(S.max_bundle_levels, S.blvl_ptr[b + 1] - S.blvl_ptr[b] - 1);
+        if (nbun > 0 && S.Li16.empty() && S.nfold == 0 && S.gf_ng == 0 && S.max_bundle_nodes < 65535 && !switches().no_bundle_flat_sweep) {
+            const i64 nLb = S.Lp[S.NF];
+            S.sLi16.resize((size_t)nLb + 1);
+            S.sLj16.resize((size_t)nLb + 1);
+            const int T = par_threads(nLb);
+            run_threads(T, [&](int t, int TT) {
+                for (i32 b = t; b < nbun; b += TT) {
+                    const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
+                    for (i32 j = s0; j < s1; j++)
+                        for (i32 q = S.Lp[j]; q < S.Lp[j + 1]; q++) {
+                            const i32 i = S.Li[q];
+                            S.sLi16[q] = (uint16_t)(i < s1 ? i - s0 : 0xFFFF);
+                            S.sLj16[q] = (uint16_t)(j - s0);
+                        }
+                }
+            });
+        }
+    }
     // ---- update records of the entry-parallel bundle factorisation (host.hpp: fu_rec) ----------------
     if (!S.Li16.empty() && !switches().no_factor_flat) {
         const i32 nbun = (i32)S.bundle_ptr.size() - 1;

@@ -206,6 +206,42 @@ def test_c2_random_qp(hip, oracle, late):
     _check_update_and_solve(hip, oracle, problems.random_qp(3000, 6000, band=20, seed=1, late=late))
 
 
+@pytest.mark.parametrize("which", ["band20", "band50", "band50_late", "chordal_sdp", "no_supernodes"])
+def test_bundle_sweeps_entry_parallel_against_row_form(hip, oracle, which, monkeypatch):
+    """systems with a level-scheduled top: the stand-alone bundle sweeps entry-parallel (bundle_solve.hip:
+    k_bundle_sweep_flat -- one stream of (row, column, value) batches per bundle, an LDS atomic per entry, the top rows'
+    share of the backward sweep in a flat prologue) against the oracle, and against the row- / column-per-thread form of
+    the same handle shape (CHIP_NO_BUNDLE_FLAT_SWEEP): refined solutions agree to rounding, unrefined ones to the accuracy
+    of one LDL' solve"""
+    hs = None
+    if which == "band20":
+        pr = problems.random_qp(3000, 6000, band=20, seed=1)
+    elif which == "chordal_sdp":
+        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    else:
+        pr = problems.random_qp(20000, 40000, band=50, seed=1, late=(which == "band50_late"))
+        if which == "no_supernodes":
+            monkeypatch.setenv("CHIP_NO_SNODE", "1")
+    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=3)
+    monkeypatch.setenv("CHIP_NO_BUNDLE_FLAT_SWEEP", "1")
+    ks0, _ = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1)
+    monkeypatch.delenv("CHIP_NO_BUNDLE_FLAT_SWEEP")
+    rng = np.random.default_rng(23)
+    for _ in range(2):
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        sols = []
+        for k in (ks0, ks):
+            assert k.update_scaling(pr["s"], pr["z"]) and k.update(hs)
+            k.setrhs(rx, rz)
+            x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+            assert k.solve(x, z)
+            sols.append(np.concatenate([x, z]))
+        assert relerr(sols[1], sols[0]) <= 1e-9
+    st = hip.Settings.default(iterative_refinement_enable=0)
+    _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1, settings=st, tol=1e-5 if "late" in which else 1e-6)
+
+
 def test_c2_solve_sequence_as_hipgraph(hip, oracle):
     """settings.use_graph: the launch sequence of the LDL' solves replayed as hipGraphs -- same
     results as direct launches (several right-hand sides, so every graph is replayed)"""
@@ -1903,28 +1939,27 @@ def test_supernode_substitution_matrices(hip, oracle, which, monkeypatch):
     _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1, settings=st, tol=1e-5 if "late" in which else 1e-6)
 
 
-@pytest.mark.parametrize("which,grid", [("banded_qp", 0), ("banded_qp", 1), ("banded_qp", 3), ("chordal_sdp", 0),
-                                        ("chordal_sdp", 2), ("mixed_widths", 0)])
+@pytest.mark.parametrize("which,grid", [("banded_qp", 0), ("banded_qp", 1), ("banded_qp", 3), ("banded_qp_late", 0),
+                                        ("narrow_band", 2), ("mixed_widths", 0)])
 def test_persistent_sweeps_over_runs_of_unit_levels(hip, oracle, which, grid, monkeypatch):
     """a run of consecutive unit levels on the one-pass matrices is ONE persistent launch per sweep (snode_g.hip:
     k_snode_gsweep, a grid barrier between the levels, the vector read and written at the coherence point): solutions
     against the oracle, and against the launch-per-level form of the same handle shape (CHIP_NO_SWEEP_PERSIST) -- the two
     run the same arithmetic on the supernodes' blocks; also with grids of 1, 2 and 3 workgroups (every workgroup walks
-    several tasks per level) and on a handle whose wide levels split the sweep into several runs"""
+    several tasks per level), at a late iterate's scaling and on a handle whose wide levels split the sweep into several
+    runs.  (The chordal SDPs of this suite alternate supernode levels with levels of ordinary columns -- no run of two;
+    BASELINE config 5, whose narrow levels form runs, is checked against the oracle by bench.py at full size.)"""
     hs = None
-    if which == "chordal_sdp":
-        pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
-        hs = pr["hsblocks"]
+    if which == "narrow_band":
+        pr = problems.random_qp(12000, 24000, band=30, seed=4)
     else:
-        pr = problems.random_qp(20000, 40000, band=50, seed=1)
+        pr = problems.random_qp(20000, 40000, band=50, seed=1, late=(which == "banded_qp_late"))
         if which == "mixed_widths":
             monkeypatch.setenv("CHIP_SN_G_MAXW", "250")
     if grid:
         monkeypatch.setenv("CHIP_GSWEEP_GRID", str(grid))
     ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=3)
     runs, lv = hip.debug_counter(ks, "gsweep_runs"), hip.debug_counter(ks, "gsweep_levels")
-    if which == "chordal_sdp" and runs == 0:
-        pytest.skip("no two consecutive unit levels on the one-pass matrices on this handle")
     assert runs >= 2 and lv >= 2 * runs                      # (a forward and a backward run at least)
     assert hip.debug_counter(ks, "gsweep_launches") >= runs  # the solves above went through them
     monkeypatch.setenv("CHIP_NO_SWEEP_PERSIST", "1")

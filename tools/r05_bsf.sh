@@ -1,0 +1,8 @@
+# entry-parallel stand-alone bundle sweeps: tests, then same-box A/B on configs 2 and 5:  bash tools/r05_bsf.sh <tag>
+TAG=${1:-r05_bsf}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+cd $R
+timeout 900 python -m pytest tests -m gpu -x -q -k "bundle_sweeps_entry or c2_ or persistent_sweeps or paired_solves or e2e_reference or structure_fuzz or l1_fast or faer" > $O/${TAG}_pytest.log 2>&1
+tail -5 $O/${TAG}_pytest.log | cut -c1-300
+bash tools/r05_ab.sh $TAG c2 "CHIP_NO_BUNDLE_FLAT_SWEEP"
+bash tools/r05_ab.sh $TAG c5 "CHIP_NO_BUNDLE_FLAT_SWEEP"

@@ -1003,7 +1003,7 @@ int bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const F
     if (!bv.nb) return 0;
     const bool no_flat = switches().no_factor_flat;
     if (lds_doubles > 0 && v.fu_rec && !no_flat) k_bundle_factor_flat<<<bv.nb, FFWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold);
-    else if (lds_doubles > 0) k_bundle_factor_lds<<<bv.nb, FLWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold, lds_doubles);
+    else if (lds_doubles > 0 && v.Li16) k_bundle_factor_lds<<<bv.nb, FLWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold, lds_doubles); // (needs the 16-bit row lists)
     else k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
     return (int)hipGetLastError(); // (a rejected launch would leave the factor stale)
 }

@@ -459,6 +459,22 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         if (!S.sLi16.empty()) {
             if ((rc = upload(&sLi16, S.sLi16, S.sLi16.size()))) return rc;
             if ((rc = upload(&sLj16, S.sLj16, S.sLj16.size()))) return rc;
+            // ... and the entry-parallel bundle factorisation (k_bundle_factor_flat) when its records were built and a
+            // bundle's L and D fit the LDS of half a CU (config 2: 645 bundles, 23 M records)
+            if (!S.fu_rec.empty() && !switches().no_factor_lds) {
+                int need = 0;
+                for (int b = 0; b < bundles.nb; b++) {
+                    const int s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
+                    need = std::max(need, (int)(S.Lp[s1] - S.Lp[s0]) + (s1 - s0));
+                }
+                if (dev::bundle_factor_lds_ok(need)) {
+                    if ((rc = upload(&fu_rec, S.fu_rec, S.fu_rec.size()))) return rc;
+                    if ((rc = upload(&fu_slot, S.fu_slot, S.fu_slot.size()))) return rc;
+                    if ((rc = upload(&fu_ptr, S.fu_ptr, S.fu_ptr.size()))) return rc;
+                    if ((rc = upload(&Urow16, S.Urow16, S.Urow16.size()))) return rc;
+                    factor_lds_doubles = need;
+                }
+            }
         }
     }
     if (S.nfold > 0) {
@@ -899,7 +915,7 @@ void Engine::swap_ctx() {
 int Engine::pair_begin() {
     int rc = ensure_alt();
     if (rc) return rc;
-    if (!rx_valid) {
+    if (!rx_valid && rx_needed()) {
         dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzR);
         rx_valid = true;
     }
@@ -1224,7 +1240,8 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
         sx_valid = true;
     }
-    rx_valid = !ir_fused;
+    // (the entry-parallel bundle factorisation keeps no row-major mirror either)
+    rx_valid = !ir_fused && !(factor_lds_doubles > 0 && fu_rec && !switches().no_factor_flat);
     return CHIP_OK;
 }
 int Engine::refactor_collect() {
@@ -1248,7 +1265,7 @@ void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
     if (!gs_built && nsn > 0) (void)build_gsweeps(); // (outside any capture: allocates)
     // (a fused handle taking the one-kernel-per-phase path: these kernels stream L by rows.  Refreshed here,
     // ahead of the graph lookup and outside any capture: a replayed graph contains no gather)
-    if (!rx_valid) {
+    if (!rx_valid && rx_needed()) {
         dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzR);
         rx_valid = true;
     }

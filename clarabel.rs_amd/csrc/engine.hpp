@@ -164,6 +164,12 @@ struct Engine {
     // folded top, and all its workgroups are co-resident
     static constexpr int IR_RING = 16; // result quads of the last IR_RING enqueued solves
     bool ir_fused = false;
+    // who reads Rx: the row-per-thread forward sweep of the bundles, and tops without chain supernodes (their row gathers,
+    // the blocked substitution); a top with supernodes gathers from its filtered copy Rfx
+    bool rx_needed() const {
+        const bool flat_sweeps = sLi16 && bundles.max_levels <= 64 && !fold.k && !switches().no_bundle_flat_sweep && !switches().deterministic;
+        return !(nsn > 0 && flat_sweeps);
+    }
     bool rx_valid = false; // fused handles: the row-major copy Rx of L is only refreshed when the one-kernel-per-phase path runs
     bool sx_valid = false; // grouped fold: the full rows Sx of the top likewise (the fused launch reads K's own values)
     unsigned short *Li16 = nullptr, *Ucol16 = nullptr, *Lj16 = nullptr, *Urow16 = nullptr, *Rk16 = nullptr, *Ro16 = nullptr;

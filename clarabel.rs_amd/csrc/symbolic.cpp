@@ -1235,22 +1235,28 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             const i64 nLb = S.Lp[S.NF];
             S.sLi16.resize((size_t)nLb + 1);
             S.sLj16.resize((size_t)nLb + 1);
+            S.Urow16.resize((size_t)S.nnzU + 1); // (the entry-parallel factorisation finds a diagonal entry's node here)
             const int T = par_threads(nLb);
             run_threads(T, [&](int t, int TT) {
                 for (i32 b = t; b < nbun; b += TT) {
                     const i32 s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
-                    for (i32 j = s0; j < s1; j++)
+                    for (i32 j = s0; j < s1; j++) {
                         for (i32 q = S.Lp[j]; q < S.Lp[j + 1]; q++) {
                             const i32 i = S.Li[q];
                             S.sLi16[q] = (uint16_t)(i < s1 ? i - s0 : 0xFFFF);
                             S.sLj16[q] = (uint16_t)(j - s0);
                         }
+                        for (i32 u = S.Up[j]; u < S.Up[j + 1]; u++) S.Urow16[u] = (uint16_t)(j - s0);
+                    }
                 }
             });
         }
     }
     // ---- update records of the entry-parallel bundle factorisation (host.hpp: fu_rec) ----------------
-    if (!S.Li16.empty() && !switches().no_factor_flat) {
+    // (systems with a level-scheduled top take the records too when it has chain supernodes -- nothing there reads the
+    // row-major mirror of the bundle columns that this form of the factorisation does not keep -- and they stay small)
+    const bool flat_unfused = S.Li16.empty() && !S.sLi16.empty() && S.sn_ptr.size() > 1;
+    if ((!S.Li16.empty() || flat_unfused) && !switches().no_factor_flat) {
         const i32 nbun = (i32)S.bundle_ptr.size() - 1;
         bool ok = true;
         for (i32 b = 0; b < nbun && ok; b++) {
@@ -1277,7 +1283,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 }
             });
             for (i32 b = 0; b < nbun; b++) bcount[b + 1] += bcount[b];
-            if (bcount[nbun] < ((i64)1 << 30)) {
+            if (bcount[nbun] < (flat_unfused ? (i64)48 << 20 : (i64)1 << 30)) {
                 S.fu_rec.resize((size_t)bcount[nbun] * 4 + 4);
                 S.fu_ptr.assign(S.blvl.size() + 1, 0);
                 S.fu_slot.assign((size_t)S.nnzU + 1, 0xFFFF);

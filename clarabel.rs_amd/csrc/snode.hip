@@ -170,6 +170,27 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
         const int i = i0[t] + l15; // lane = row of the tile; an instruction covers columns 4 m + kq
         if (i0[t] >= g.h) break;
         const int rB = i - g.w;
+        if (!EXTEND && !atomic_emit) {
+            // (round 5: the tile's sixteen read-modify-writes per lane as ONE batch of loads and one of stores -- in two
+            // batches of eight the emit was four dependent round trips per workgroup, 7 of the 13 us of a config 2 launch)
+            // (the tile's values stay in LDS until the stores: sixteen loads in flight cost sixteen registers pairs, not 32)
+            if (i >= g.h) continue;
+            double cur[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int jj = 4 * m + kq, j = jrow0 + jj;
+                cur[m] = (jj < ncols && i > j) ? v.Lx[colbase[j] + i] : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int jj = 4 * m + kq, j = jrow0 + jj;
+                if (jj >= ncols) continue;
+                const double val = Tw[jj * 16 + (l15 ^ (jj & 15))];
+                if (i > j) v.Lx[colbase[j] + i] = cur[m] - val;
+                else if (i == j) v.D[g.cols[j]] -= val;
+            }
+            continue;
+        }
 #pragma unroll
         for (int m0 = 0; m0 < 16; m0 += 8) { // (eight at a time: registers)
             double val[8];

@@ -159,12 +159,14 @@ class Workload:
                         comm.wait(ks)
                         comm.allgather_step(ks, self.lhs[k].ptr, gathered[k].ptr, counts)
 
-    def run(self, steps, warmup, profile_family=0, comm=None, gathered=None, counts=None, events_in_timed_region=True):
+    def run(self, steps, warmup, profile_family=0, comm=None, gathered=None, counts=None, events_in_timed_region=True,
+            sequential_pass=True):
         """W warm-up steps, then K timed steps bracketed by synchronisations.  The dominant kernel's launch durations come from
         hipEvent pairs on the engine's stream around each of its launches (chip_kkt_profile): inside the timed region when the
-        family has a handful of launches per step (config 3: 3), in a SECOND pass of the same steps right after it when a step
-        has hundreds of them (configs 2 / 5: 324 / 77 -- the event pairs themselves cost ~6 us each, 2 ms of an 18 ms step on
-        config 2, which would be charged to `value`)."""
+        events_in_timed_region, in a SECOND pass of the same steps right after it otherwise (the default of every workload
+        since the end of round 5): an event pair costs ~6 us on the stream -- 2 ms of an 18 ms step of config 2 (324 pairs), and
+        33 us of config 3's 0.78 ms step (3 pairs: 1282 it/s with them in the timed region, 1337 without, same box) -- which would
+        be charged to `value`.  The pass with the pairs is on the line too (`roofline_events_pass`)."""
         def sync():
             self.ks.synchronize()
             if comm is not None:
@@ -187,7 +189,7 @@ class Workload:
                         "max": round(float(d.max()), 4)} if len(d) else None
         self.events_pass = None
         self.sequential = None
-        if not events_in_timed_region and self.pair:
+        if not events_in_timed_region and self.pair and sequential_pass:
             # (level-scheduled systems: the paired call overlaps two chains of launches on two streams; the same steps with three
             # separate solve calls, for the line's other policy)
             self.pair = False
@@ -878,7 +880,7 @@ def main():
         comm.attach(w.ks)
         gathered = [hip.DeviceArray(int(sum(counts))) for _ in range(3)]
     elapsed, prof = w.run(args.steps, args.warmup, args.profile_family, comm, gathered, counts,
-                          events_in_timed_region=workload not in ("c2", "c5", "c5m"))
+                          events_in_timed_region=False, sequential_pass=workload in ("c2", "c5", "c5m"))
     ir = w.ks.linear_solver_info().last_ir_iterations
     # N > 1: the same steps once more with the OTHER exchange policy, so that the driver's curve can be read either way
     # (SURVEY 8(e) says one all-gather per solve; the default gathers the step direction only)
@@ -1073,6 +1075,9 @@ def main():
                                          "1 x all-gather of the step direction (the last solve's solution)",
                                          int(sum(counts)))) if comm is not None else "none"},
             "step_ms": step_ms,
+            "timing": "value / ms_per_step: K steps between two synchronisations WITHOUT the hipEvent pairs of the roofline "
+                      "measurement on the stream; roofline: the same K steps once more, right after, with a pair around every launch "
+                      "of the dominant kernel (roofline_events_pass.ms_per_step_with_events is that pass)",
             "roofline_events_pass": w_events_pass,
             "roofline": roof, "parity": parity, "cpu_baseline": cpu, "cpu_baseline_mt": cpu_mt, "batched_c4": c4,
             "c2": extras.get("c2"), "c5": extras.get("c5"), "l1_dropin": extras.get("l1_dropin"),

@@ -1940,7 +1940,7 @@ def test_supernode_substitution_matrices(hip, oracle, which, monkeypatch):
 
 
 @pytest.mark.parametrize("which,grid", [("banded_qp", 0), ("banded_qp", 1), ("banded_qp", 3), ("banded_qp_late", 0),
-                                        ("narrow_band", 2), ("mixed_widths", 0)])
+                                        ("narrow_band", 2), ("mixed_widths", 0), ("banded_qp_graph", 0)])
 def test_persistent_sweeps_over_runs_of_unit_levels(hip, oracle, which, grid, monkeypatch):
     """a run of consecutive unit levels on the one-pass matrices is ONE persistent launch per sweep (snode_g.hip:
     k_snode_gsweep, a grid barrier between the levels, the vector read and written at the coherence point): solutions
@@ -1958,7 +1958,10 @@ def test_persistent_sweeps_over_runs_of_unit_levels(hip, oracle, which, grid, mo
             monkeypatch.setenv("CHIP_SN_G_MAXW", "250")
     if grid:
         monkeypatch.setenv("CHIP_GSWEEP_GRID", str(grid))
-    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=3)
+    # (banded_qp_graph: the solve sequence captured and replayed as hipGraphs -- the barrier's words are back at zero when
+    # a persistent launch ends, so a replay meets them as the first launch did)
+    st = hip.Settings.default(use_graph=1) if which == "banded_qp_graph" else None
+    ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=4 if st else 3, settings=st)
     runs, lv = hip.debug_counter(ks, "gsweep_runs"), hip.debug_counter(ks, "gsweep_levels")
     assert runs >= 2 and lv >= 2 * runs                      # (a forward and a backward run at least)
     assert hip.debug_counter(ks, "gsweep_launches") >= runs  # the solves above went through them

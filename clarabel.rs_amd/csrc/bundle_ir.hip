@@ -261,7 +261,9 @@ __device__ __forceinline__ void bundle_sweep_flat(const LdlView &v, const Bundle
                                                   const double *xt, double *tacc, int k, const int *lev_e) {
     const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid)); // (no hoisting of this phase's address arithmetic out of the caller's round loop)
+    const int lane = tid & 63;
     if (FWDMODE && tid < 8) tacc[tid] = 0.0;
     if (!FWDMODE)
         for (int i = tid; i < nloc; i += TW) xs[i] *= v.Dinv[s0 + i];
@@ -1083,6 +1085,613 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
 }
 
 
+// ---------------------------------------------------------------------------
+// k_bundle_irs: the fused solve for the shape the bench workload has (round 6) -- EVERY workgroup owns exactly one
+// bundle (grid == nb), every bundle takes the entry-parallel sweeps and the split residual, its slice of the
+// permutation is a few runs, at most IRS_NPT nodes per thread.  Same phases, barriers and decisions as k_bundle_ir
+// (directldlkktsolver.rs:168-189, :266-321); what differs is where the VECTORS live.  k_bundle_ir moved 863 MB per
+// launch on config 3, a third of it vectors: the permuted right-hand side written to bp and read back by both
+// residuals, every candidate written to xa / xb and gathered back by its residual, the leaves' residual spilled and
+// re-read, the accepted iterate read once more for getlhs.  Here a thread KEEPS its IRS_NPT entries of the candidate
+// in registers from the end of the backward sweep on (c[]): the residual takes x of the thread's own rows from there
+// and stages the non-leaf entries into LDS from there; the leaves' residual returns through the same registers; the
+// right-hand side is read through the runs from the caller's vectors each time (never written: bp is the HOST's
+// business now, capi.cpp: chip_kkt::bp_stale); a candidate goes to HBM only when a further round can follow (it is
+// that round's accepted iterate), and the result is written from the registers when the last candidate is the accepted
+// one.  Config 3, one solve + one round: 24 (b) + 2 x 24 (b again) + 24 + 24 (round 0's x out and back) + 24 (result)
+// MB of vectors instead of ~310.
+// ---------------------------------------------------------------------------
+constexpr int IRS_NPT = 12;
+// The thread id behind an empty asm: whatever is computed from it cannot be hoisted out of the loop over the refinement
+// rounds.  Without it the compiler moves every phase's address arithmetic (a dozen arrays x tid) in front of that loop,
+// where it stays live across ALL phases: the 128-register budget then spills inside the loop (measured: 85 spilled
+// registers, the phases 10 - 20 % slower), although no phase needs more than 76 registers by itself.
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// original index of bundle-local node i through the runs (LDS); successive calls with ascending i: one monotone walk
+struct RunWalk {
+    const int *runs;
+    int r;
+    __device__ __forceinline__ int orig(int i) {
+        while (i >= runs[3 * r] + runs[3 * r + 2]) ++r; // (runs ascend in the local index)
+        return runs[3 * r + 1] + (i - runs[3 * r]);
+    }
+};
+
+// e = b - K c for the rows of the workgroup's bundle, c = the candidate in the threads' registers; split LDS layout of
+// bundle_symv_split (e of the non-leaf rows at xs[nleaf .. nloc), x of the non-leaf nodes in the space around it).
+// keep_e: a further round can follow -- the leaves' residual is put into xs[0 .. nleaf) at the end, so xs holds the whole
+// residual; otherwise only the norms leave.
+template <int TW, int NPT, int NLP>
+__device__ __forceinline__ void irs_symv(const LdlView &v, const IrView &ir, const int *runs, const double (&c)[NPT],
+                                         bool keep_e, double *xs, double *red, double *tacc3, int k, int s0,
+                                         int nloc, int nleaf, const double *xt, double *out_norm, double *out_share) {
+    double cl[NLP]; // the candidate at the thread's leaf nodes, then (keep_e) their residual
+    const int *__restrict__ Up = v.Up;
+    const unsigned short *__restrict__ Ucol16 = v.Ucol16, *__restrict__ Urow16 = v.Urow16;
+    const double *__restrict__ Ux = v.Ux;
+    const int tid = opaque_tid();
+    auto xpos = [&](int t) { return t < nleaf ? t : nloc + (t - nleaf); }; // x of non-leaf t
+    auto rhs_of = [&](int o) { return o < ir.n ? ir.rx[o] : (o < ir.n + ir.m ? ir.rz[o - ir.n] : 0.0); };
+    constexpr int LR = 4, LS = 3;
+    static_assert(NLP % LR == 0 && NLP <= NPT, "leaf passes");
+    int tb[LR], te[LR];
+#pragma unroll
+    for (int u = 0; u < LR; ++u) {
+        const int i = tid + u * TW;
+        tb[u] = i < nleaf ? Up[s0 + i] : 0;
+        te[u] = i < nleaf ? Up[s0 + i + 1] : 0;
+    }
+    const int fb = Up[s0 + nleaf], fe = Up[s0 + nloc]; // the flat range: rows of the non-leaf nodes
+    {
+        // the non-leaf rows' b and x into LDS (b through the runs from the caller's vectors)
+        RunWalk rw{runs, 0};
+        double bq[NPT];
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const int i = tid + u * TW;
+            bq[u] = (i >= nleaf && i < nloc) ? rhs_of(rw.orig(i)) : 0.0;
+        }
+        __syncthreads(); // (every thread has taken its candidate entries out of xs)
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const int i = tid + u * TW;
+            if (i >= nleaf && i < nloc) {
+                xs[xpos(i - nleaf)] = c[u];
+                xs[i] = bq[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NLP; ++u) cl[u] = c[u];
+    }
+    double tpart = 0.0;
+    if (k > 1 && tid < 8) tacc3[tid] = 0.0;
+    double mleaf = 0.0;
+    bool nan = false;
+    __syncthreads();
+    // ---- leaf rows: the thread's own, four per pass; x_i from the registers ----
+    RunWalk rl{runs, 0};
+#pragma unroll
+    for (int p = 0; p < NLP / LR; ++p) {
+        if (p * LR * TW < nleaf) {
+            int jj[LR][LS];
+            double vv[LR][LS], bi[LR], acc[LR];
+#pragma unroll
+            for (int u = 0; u < LR; ++u) {
+                const int i = (p * LR + u) * TW + tid;
+                bi[u] = i < nleaf ? rhs_of(rl.orig(i)) : 0.0;
+                acc[u] = 0.0;
+#pragma unroll
+                for (int q = 0; q < LS; ++q) {
+                    const int t = tb[u] + q;
+                    const bool ok = t < te[u];
+                    jj[u][q] = ok ? (int)Ucol16[t] : -1;
+                    vv[u][q] = ok ? Ux[t] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LR; ++u) {
+                const int i = (p * LR + u) * TW + tid;
+                const double xi = cl[p * LR + u];
+                auto apply = [&](int j, double val) {
+                    if (j >= nloc) {
+                        acc[u] += val * xt[j - nloc];
+                        if (k == 1) tpart += val * xi;
+                        else atomicAdd(&tacc3[j - nloc], val * xi);
+                    } else if (j == i) {
+                        acc[u] += val * xi;
+                    } else {
+                        acc[u] += val * xs[xpos(j - nleaf)];
+                        atomicAdd(&xs[j], -(val * xi));
+                    }
+                };
+#pragma unroll
+                for (int q = 0; q < LS; ++q)
+                    if (jj[u][q] >= 0) apply(jj[u][q], vv[u][q]);
+                for (int t = tb[u] + LS; t < te[u]; ++t) apply((int)Ucol16[t], Ux[t]); // (a leaf with a long row: rare)
+                if (i < nleaf) {
+                    const double val = bi[u] - acc[u];
+                    if (keep_e) cl[p * LR + u] = val;
+                    if (val != val) nan = true;
+                    else mleaf = fmax(mleaf, fabs(val));
+                }
+                const int in = i + LR * TW;
+                tb[u] = in < nleaf ? Up[s0 + in] : 0;
+                te[u] = in < nleaf ? Up[s0 + in + 1] : 0;
+            }
+        }
+    }
+    // ---- rows of the non-leaf nodes: flat over their entries, the next batch in flight while this one is consumed ----
+    {
+        int ii[FLAT_U], jj[FLAT_U], ni[FLAT_U], nj[FLAT_U];
+        double vv[FLAT_U], nv[FLAT_U];
+        auto request = [&](int bs, int *pi, int *pj, double *pv) {
+#pragma unroll
+            for (int u = 0; u < FLAT_U; ++u) {
+                const int t = bs + u * TW + tid;
+                const bool ok = t < fe;
+                pi[u] = ok ? (int)Urow16[t] : -1;
+                pj[u] = ok ? (int)Ucol16[t] : 0;
+                pv[u] = ok ? Ux[t] : 0.0;
+            }
+        };
+        if (fb < fe) request(fb, ii, jj, vv);
+        for (int base = fb; base < fe; base += TW * FLAT_U) {
+            if (base + TW * FLAT_U < fe) request(base + TW * FLAT_U, ni, nj, nv);
+            else {
+#pragma unroll
+                for (int u = 0; u < FLAT_U; ++u) ni[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < FLAT_U; ++u) {
+                const int i = ii[u], j = jj[u];
+                if (i < 0) continue;
+                const double xi = xs[xpos(i - nleaf)];
+                if (j >= nloc) {
+                    atomicAdd(&xs[i], -(vv[u] * xt[j - nloc]));
+                    if (k == 1) tpart += vv[u] * xi;
+                    else atomicAdd(&tacc3[j - nloc], vv[u] * xi);
+                } else if (j == i) {
+                    atomicAdd(&xs[i], -(vv[u] * xi));
+                } else {
+                    atomicAdd(&xs[i], -(vv[u] * xs[xpos(j - nleaf)]));
+                    atomicAdd(&xs[j], -(vv[u] * xi));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FLAT_U; ++u) {
+                ii[u] = ni[u];
+                jj[u] = nj[u];
+                vv[u] = nv[u];
+            }
+        }
+    }
+    __syncthreads();
+    double m = mleaf;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const int i = tid + u * TW;
+        if (i >= nleaf && i < nloc) {
+            const double val = xs[i];
+            if (val != val) nan = true;
+            else m = fmax(m, fabs(val));
+        }
+    }
+    if (keep_e) { // (the x of the non-leaf nodes that lived in xs[0 .. nleaf) has been consumed)
+#pragma unroll
+        for (int u = 0; u < NLP; ++u)
+            if (tid + u * TW < nleaf) xs[tid + u * TW] = cl[u];
+    }
+    m = block_max(m, red);
+    const bool anynan = __syncthreads_or(nan);
+    if (tid == 0)
+        __hip_atomic_store(out_norm, anynan ? __longlong_as_double(0x7ff8000000000000ll) : m, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (k == 1) {
+        tpart = block_sum(tpart, red);
+        if (tid == 0) __hip_atomic_store(out_share, tpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (k > 1) {
+        __syncthreads();
+        if (tid == 0)
+            for (int i = 0; i < k; ++i)
+                __hip_atomic_store(out_share + i, tacc3[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int TW, int NLP>
+__global__ __launch_bounds__(TW) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
+    constexpr int NPT = IRS_NPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xs = (double *)smem;
+    __shared__ double red[16];
+    __shared__ int lev_e[FLAT_MAXLEV + 1];
+    __shared__ double tacc3[8];
+    __shared__ IrState st;
+    const int nb = bv.nb, G = gridDim.x, tid = threadIdx.x, b = blockIdx.x;
+    const int k = fold.k;
+    const bool folded = k > 0; // a barrier in the middle of every round
+    const int NF = k ? fold.NF : ir.N;
+    if (ir.test_drop && b == G - 1 && G > 1) return; // (tests: a launch that is not co-resident)
+    const int s0 = bv.bundle_ptr[b], nloc = bv.bundle_ptr[b + 1] - s0;
+    const int nleaf = bv.blvl[bv.blvl_ptr[b] + 1] - s0;
+    // partial results: device-coherent stores before a barrier, reduced in a fixed order by its last arriver
+    double *pnb = ir.part;                  // [nb]       ||b||inf of the bundles' rows
+    double *pn = pnb + nb;                  // [2][nb]    ||e||inf of the bundles' rows
+    double *shf = pn + 2 * nb;              // [nb*k]     forward sweep: shares of the top rows
+    double *shs = shf + (size_t)nb * k;     // [2][nb*k]  residual: shares of (K x)[top]
+    double *pub = shs + 2 * (size_t)nb * k; // [2][32]    published reductions
+    auto rhs_of = [&](int o) { return o < ir.n ? ir.rx[o] : (o < ir.n + ir.m ? ir.rz[o - ir.n] : 0.0); };
+    if (tid == 0) {
+        st.normb = st.norme = st.lastnorme = 0.0;
+        st.rounds = 0;
+        st.ok = 1;
+        st.done = 0;
+        st.sel = 0;
+        st.par = 0;
+        st.gen = 0;
+        st.pad = 0; // (1: the last verdict accepted its candidate)
+        if (b == 0) {
+            ir.res[0] = 0; // "did not finish" until the verdict is written at the very end
+            ir.res[2] = 0;
+        }
+    }
+    if (tid < 64) {
+        st.ltt[tid] = 0.0;
+        st.ktt[tid] = 0.0;
+    }
+    {
+        const int r0 = ir.run_ptr[b], nruns = ir.run_ptr[b + 1] - r0;
+        if (tid < 3 * nruns) st.runs[tid] = ir.runs[3 * r0 + tid];
+    }
+    flat_level_table(v, bv, b, lev_e);
+    __syncthreads();
+    auto load_top_constants = [&]() {
+        if (tid < 8) {
+            st.btop[tid] = tid < k ? rhs_of(ir.perm[NF + tid]) : 0.0;
+            if (ir.bp && tid < k && b == 0) ir.bp[NF + tid] = st.btop[tid];
+            st.curt[tid] = 0.0;
+            st.dinvt[tid] = tid < k ? v.Dinv[NF + tid] : 0.0;
+        } else if (tid >= 64 && tid < 64 + k * k) {
+            const int ti = (tid - 64) / k, tj = (tid - 64) % k;
+            const int q = fold.tt[tid - 64];
+            if (q >= 0) st.ltt[ti * 8 + tj] = v.Lx[q];
+        } else if (tid >= 128 && tid < 128 + k) {
+            const int i = tid - 128;
+            for (int t = fold.sp[i]; t < fold.sp[i + 1]; ++t) st.ktt[i * 8 + fold.scol[t]] += v.Ux[fold.sslot[t]];
+        }
+    };
+    if (k == 0) load_top_constants(); // (a forest: only btop / curt are cleared)
+    int dbgn = 0;
+    auto stamp = [&]() { // diagnostics (CHIP_IR_DEBUG): phase boundaries on the 100 MHz clock
+        if (ir.dbg_all) {
+            if (tid == 0 && dbgn < 31) {
+                if (dbgn == 0)
+                    ir.dbg_all[(size_t)b * 32] = (long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) |
+                                                 ((long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32);
+                ir.dbg_all[(size_t)b * 32 + 1 + dbgn++] = wall_clock64();
+            }
+        } else if (ir.dbg && tid == 0 && (b == 0 || b == G / 2) && dbgn < 64)
+            ir.dbg[(b ? 64 : 0) + dbgn++] = wall_clock64();
+    };
+    auto reduce_forward = [&](int par) {
+        for (int i = 0; i < k; ++i) {
+            double part = 0.0;
+            for (int q = tid; q < nb; q += TW) part += ir_load(&shf[(size_t)q * k + i]);
+            part = block_sum(part, red);
+            if (tid == 0) ir_store(&pub[par * 32 + i], part);
+        }
+    };
+    auto reduce_residual = [&](int par, bool first) { // norms NaN propagating; every load is issued before any reduction
+        double mb = 0.0, m = 0.0, part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int q = tid; q < nb; q += TW) {
+            if (first) mb = nanmax(mb, ir_load(&pnb[q]));
+            m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
+            if (ir.ir_enable) {
+                if (k == 1) part[0] += ir_load(&shs[(size_t)par * nb + q]);
+                else
+                    for (int i = 0; i < k; ++i) part[i] += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
+            }
+        }
+        if (first) {
+            mb = block_nanmax(mb, red);
+            if (tid == 0) ir_store(&pub[par * 32 + 9], mb);
+        }
+        m = block_nanmax(m, red);
+        if (tid == 0) ir_store(&pub[par * 32 + 8], m);
+        for (int i = 0; i < k; ++i) {
+            const double tot = block_sum(part[i], red);
+            if (tid == 0) ir_store(&pub[par * 32 + 16 + i], tot);
+        }
+    };
+    // the reference's decisions about the candidate of round `round` (k_bundle_ir: decide)
+    auto decide = [&](int round, int par) {
+        if (tid == 0) {
+            double m = ir_load(&pub[par * 32 + 8]);
+            if (round == 0) {
+                double nbm = ir_load(&pub[par * 32 + 9]);
+                for (int i = 0; i < k; ++i) nbm = nanmax(nbm, fabs(st.btop[i]));
+                st.normb = nbm;
+            }
+            for (int i = 0; i < k; ++i) {
+                double sacc = ir_load(&pub[par * 32 + 16 + i]);
+                for (int cc = 0; cc < k; ++cc) sacc += st.ktt[i * 8 + cc] * st.candt[cc];
+                st.rtop[i] = ir.ir_enable ? st.btop[i] - sacc : st.candt[i];
+                m = nanmax(m, fabs(st.rtop[i]));
+            }
+            const double newnorm = m, tol = ir.abstol + ir.reltol * st.normb;
+            bool accept, done = false;
+            if (round == 0) {
+                accept = true;
+                st.norme = newnorm;
+                if (!(newnorm - newnorm == 0.0)) { // non-finite (:284-286; without refinement: x.is_finite(), :180)
+                    st.ok = 0;
+                    done = true;
+                } else if (!ir.ir_enable || ir.maxiter <= 0 || newnorm <= tol) {
+                    done = true;
+                }
+            } else {
+                st.rounds += 1;
+                if (!(newnorm - newnorm == 0.0)) { // :305-307
+                    st.ok = 0;
+                    accept = false;
+                    done = true;
+                } else {
+                    const double improved = st.lastnorme / newnorm;
+                    accept = !(improved < ir.stopratio) || improved > 1.0; // :309-318
+                    if (improved < ir.stopratio) done = true;
+                    if (accept) st.norme = newnorm;
+                }
+            }
+            st.pad = accept ? 1 : 0;
+            if (accept) {
+                st.sel ^= 1;
+                for (int i = 0; i < k; ++i) st.curt[i] = st.candt[i];
+            }
+            if (!done && (st.rounds >= ir.maxiter || st.norme <= tol)) done = true; // :288-293
+            st.lastnorme = st.norme;
+            st.done = done ? 1 : 0;
+        }
+        __syncthreads();
+    };
+    stamp();
+    // ---- setrhs (directldlkktsolver.rs:160-166): the bundle's slice of the permuted right-hand side into LDS ----
+    {
+        double c[NPT];
+        RunWalk rw{st.runs, 0};
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const int i = tid + u * TW;
+            c[u] = i < nloc ? rhs_of(rw.orig(i)) : 0.0;
+        }
+        double mx = 0.0;
+        bool nan = false;
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const int i = tid + u * TW;
+            if (i < nloc) {
+                xs[i] = c[u];
+                if (ir.bp) ir.bp[s0 + i] = c[u]; // (only when the host asks for the permuted copy)
+                if (c[u] != c[u]) nan = true;
+                else mx = fmax(mx, fabs(c[u]));
+            }
+        }
+        mx = block_max(mx, red);
+        const bool anynan = __syncthreads_or(nan);
+        if (tid == 0) ir_store(&pnb[b], anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx);
+    }
+    bool pending = false;   // a candidate whose residual partials have been stored but not yet reduced
+    // Where the iterates live.  Round 0's candidate x0 stays in the threads' REGISTERS (xk) when a round can follow: it
+    // is that round's accepted iterate (round 0 is always accepted), x1 = x0 + dx is formed from there.  The candidate of
+    // the LAST possible round is written straight to the caller's lhs vectors (spec_out: they do not overlap the
+    // right-hand side, which the residual still reads) -- if the verdict then rejects it, the accepted iterate is
+    // written over it.  Only candidates that further rounds may build on (round >= 1 with rounds left) go to xa / xb.
+    double xk[NPT];
+    bool xk_valid = false;  // x0 lives in xk only
+    bool spec_done = false; // the last candidate has been written to lhs
+    for (int round = 0;; ++round) {
+        const int par = round & 1;
+        __syncthreads();
+        stamp();
+        bundle_sweep_flat<true, TW>(v, bv, b, xs, nullptr, st.tacc, k, lev_e);
+        stamp();
+        if (tid < k) ir_store(&shf[(size_t)b * k + tid], st.tacc[tid]);
+        if (folded) {
+            stamp();
+            if (round == 0) load_top_constants();
+            if (tid == 0) st.gen += 1;
+            const int state = ir_arrive_wait(ir.ctl, st.gen, G);
+            if (state == IR_TIMEOUT) {
+                if (tid == 0) ir.res[2] = 1;
+                return;
+            }
+            stamp();
+            if (state == IR_LAST) {
+                reduce_forward(par);
+                if (pending) reduce_residual(par ^ 1, round == 1);
+                ir_release(ir.ctl, st.gen, G);
+            }
+            __syncthreads();
+            if (pending) { // the verdict on the previous round's candidate
+                decide(round - 1, par ^ 1);
+                pending = false;
+                if (__builtin_amdgcn_readfirstlane(st.done)) break; // (this round's forward sweep was speculative)
+            }
+            if (tid == 0) {
+                // the k x k top part of both sweeps, by every workgroup alike (k <= 8)
+                double y[8];
+                for (int i = 0; i < k; ++i) {
+                    double sacc = (round == 0 ? st.btop[i] : st.rtop[i]) - ir_load(&pub[par * 32 + i]);
+                    for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * y[j];
+                    y[i] = sacc;
+                }
+                for (int i = k - 1; i >= 0; --i) {
+                    double sacc = y[i] * st.dinvt[i];
+                    for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * y[j];
+                    y[i] = sacc;
+                }
+                for (int i = 0; i < k; ++i) {
+                    st.dxt[i] = y[i];
+                    st.candt[i] = round == 0 ? y[i] : 1.0 * st.curt[i] + 1.0 * y[i];
+                }
+            }
+        }
+        __syncthreads();
+        stamp();
+        bundle_sweep_flat<false, TW>(v, bv, b, xs, st.dxt, nullptr, k, lev_e);
+        stamp();
+        // the candidate: x (round 0) or x + dx (directldlkktsolver.rs:300 axpby(1, x, 1)), into the registers
+        const bool more_possible = ir.ir_enable && round < ir.maxiter;
+        double c[NPT];
+        {
+            const int tid = opaque_tid();
+            const int sel = __builtin_amdgcn_readfirstlane(st.sel);
+            double *cur = sel ? ir.xb : ir.xa;
+            double *alt = sel ? ir.xa : ir.xb;
+            if (round == 0) {
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) {
+                    const int i = tid + u * TW;
+                    c[u] = i < nloc ? xs[i] : 0.0;
+                }
+            } else {
+                if (!xk_valid) {
+#pragma unroll
+                    for (int u = 0; u < NPT; ++u) {
+                        const int i = tid + u * TW;
+                        xk[u] = i < nloc ? cur[s0 + i] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) {
+                    const int i = tid + u * TW;
+                    c[u] = i < nloc ? 1.0 * xk[u] + 1.0 * xs[i] : 0.0;
+                }
+            }
+            if (more_possible && round == 0 && (ir.sf_flags & 1)) {
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) xk[u] = c[u];
+                xk_valid = true;
+            } else if (more_possible || !ir.spec_out) {
+                // (a later round may build on it / the result vectors overlap the right-hand side: through xa / xb)
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) {
+                    const int i = tid + u * TW;
+                    if (i < nloc) {
+                        alt[s0 + i] = c[u];
+                        if (xk_valid) cur[s0 + i] = xk[u]; // (x0 leaves the registers: later rounds read it from there)
+                    }
+                }
+                xk_valid = false;
+            } else {
+                RunWalk rw{st.runs, 0};
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) {
+                    const int i = tid + u * TW;
+                    if (i < nloc) {
+                        const int o = rw.orig(i);
+                        if (o < ir.n) {
+                            if (ir.lhsx) ir.lhsx[o] = c[u];
+                        } else if (o < ir.n + ir.m) {
+                            if (ir.lhsz) ir.lhsz[o - ir.n] = c[u];
+                        }
+                    }
+                }
+                spec_done = true;
+            }
+        }
+        if (!ir.ir_enable) { // no refinement: only x.is_finite() is asked for (:180)
+            double mx = 0.0;
+            bool nan = false;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                if (tid + u * TW < nloc) {
+                    if (c[u] != c[u]) nan = true;
+                    else mx = fmax(mx, fabs(c[u]));
+                }
+            }
+            mx = block_max(mx, red);
+            const bool anynan = __syncthreads_or(nan);
+            if (tid == 0) ir_store(&pn[(size_t)par * nb + b], anynan ? __longlong_as_double(0x7ff8000000000000ll) : mx);
+        } else {
+            stamp();
+            irs_symv<TW, NPT, NLP>(v, ir, st.runs, c, more_possible, xs, red, tacc3, k, s0, nloc, nleaf, st.candt,
+                                   &pn[(size_t)par * nb + b], &shs[(size_t)par * nb * k + (size_t)b * k]);
+        }
+        pending = true;
+        if (folded && more_possible) continue; // (the verdict rides on the next round's barrier)
+        stamp();
+        if (tid == 0) st.gen += 1;
+        const int state = ir_arrive_wait(ir.ctl, st.gen, G);
+        if (state == IR_TIMEOUT) {
+            if (tid == 0) ir.res[2] = 1;
+            return;
+        }
+        stamp();
+        if (state == IR_LAST) {
+            reduce_residual(par, round == 0);
+            ir_release(ir.ctl, st.gen, G);
+        }
+        __syncthreads();
+        decide(round, par);
+        pending = false;
+        if (__builtin_amdgcn_readfirstlane(st.done)) break;
+    }
+    stamp();
+    // ---- getlhs (directldlkktsolver.rs:205-215): the accepted x, un-permuted ----
+    const int ok = __builtin_amdgcn_readfirstlane(st.ok);
+    if (ok) {
+        // the last candidate is on its way already (spec_done) and the verdict accepted it: nothing to do; else the
+        // accepted iterate from the registers (x0) or from xa / xb
+        const bool accepted_last = __builtin_amdgcn_readfirstlane(st.pad) != 0;
+        if (!(spec_done && accepted_last)) {
+            const int tid = opaque_tid();
+            const double *cur = __builtin_amdgcn_readfirstlane(st.sel) ? ir.xb : ir.xa;
+            if (!xk_valid) {
+#pragma unroll
+                for (int u = 0; u < NPT; ++u) {
+                    const int i = tid + u * TW;
+                    xk[u] = i < nloc ? cur[s0 + i] : 0.0;
+                }
+            }
+            RunWalk rw{st.runs, 0};
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const int i = tid + u * TW;
+                if (i < nloc) {
+                    const int o = rw.orig(i);
+                    if (o < ir.n) {
+                        if (ir.lhsx) ir.lhsx[o] = xk[u];
+                    } else if (o < ir.n + ir.m) {
+                        if (ir.lhsz) ir.lhsz[o - ir.n] = xk[u];
+                    }
+                }
+            }
+        }
+        if (b == 0 && tid < k) {
+            const int o = ir.perm[NF + tid];
+            if (o < ir.n) {
+                if (ir.lhsx) ir.lhsx[o] = st.curt[tid];
+            } else if (o < ir.n + ir.m) {
+                if (ir.lhsz) ir.lhsz[o - ir.n] = st.curt[tid];
+            }
+        }
+    }
+    if (b == 0 && tid == 0) {
+        ir.res[0] = ok ? 1 : -1; // (0 = the kernel never got here)
+        ir.res[1] = st.rounds;
+        ir.res[3] = st.sel;
+        pub[64] = st.normb;
+        pub[65] = st.norme;
+    }
+    stamp();
+    ir_grid_exit(ir.ctl, __builtin_amdgcn_readfirstlane(st.gen) + 1, G);
+}
+
 } // namespace
 
 int ir_ctl_ints() { return IR_CTL_INTS; }
@@ -1144,11 +1753,38 @@ int bundle_ir_capacity(const BundleView &bv, int *tw) {
     *tw = 512;
     return bundle_ir_capacity_tw<512>(bv);
 }
+// k_bundle_irs can take this handle's solves: co-resident grid of nb workgroups of 256 threads (the per-bundle conditions
+// -- flat sweeps, nodes per thread, runs of the permutation -- are the caller's to check, see irs_bundle_ok)
+bool bundle_irs_capacity_ok(const BundleView &bv) {
+    if (!bv.nb || !bv.symv_split) return false;
+    const size_t lds = bundle_ir_lds(bv);
+    if (raise_dynamic_lds((const void *)k_bundle_irs<256, 4>, lds) != hipSuccess) return false;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    hipFuncAttributes fa;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_bundle_irs<256, 4>, 256, lds) != hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipFuncGetAttributes(&fa, (const void *)k_bundle_irs<256, 4>) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const size_t per_wg = ((fa.sharedSizeBytes + lds + 1023) / 1024) * 1024;
+    per_cu = std::min(per_cu, std::min((int)(prop.maxSharedMemoryPerMultiProcessor / per_wg), 4));
+    return per_cu * prop.multiProcessorCount >= bv.nb;
+}
+bool irs_bundle_ok(int nloc, int nleaf, int nlevels, int nruns) {
+    return nloc >= FLAT_MIN_NODES && nloc <= IRS_NPT * 256 && nleaf <= 4 * 256 && nlevels <= FLAT_MAXLEV && nruns > 0 &&
+           nruns <= IR_MAXRUNS;
+}
 int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid,
               int tw, const GFoldView &gf) {
     // grid <= bundle_ir_capacity(): every workgroup is resident on an otherwise idle device, and a grid
     // barrier that cannot complete times out instead of hanging
     const size_t lds = bundle_ir_lds(bv);
+    if (ir.sf) { // (the caller has checked bundle_irs_capacity_ok / irs_bundle_ok)
+        k_bundle_irs<256, 4><<<bv.nb, 256, lds, s>>>(v, bv, fold, ir);
+        return (int)hipGetLastError();
+    }
     if (gf.ng > 0) {
         if (tw == 256) k_bundle_ir<256, true><<<grid, 256, lds, s>>>(v, bv, fold, ir, gf);
         else if (tw == 1024) k_bundle_ir<1024, true><<<grid, 1024, lds, s>>>(v, bv, fold, ir, gf);

@@ -113,6 +113,11 @@ struct chip_kkt {
     const double *rhs_x = nullptr, *rhs_z = nullptr;
     bool rhs_deferred = false;
     int *ir_run_ptr = nullptr, *ir_runs = nullptr; // run-length form of the permutation inside the bundles (dev::IrView)
+    // k_bundle_irs takes this handle's fused solves (checked once at creation: every bundle qualifies, the grid is
+    // co-resident).  That kernel does NOT leave the permuted right-hand side in bp: bp_stale says so, and a solve() that
+    // follows without a new setrhs() reads the noted vectors (rhs_x / rhs_z) again -- they stay borrowed until the next
+    // setrhs (include/clarabel_hip.h)
+    bool ir_sf = false, bp_stale = false;
     int pend_update = 0;             // 1: an update has been enqueued and its verdict not read; 2: read, kept
     int pend_update_ok = 1;
     std::vector<int> pend_slots;     // ring slots of the solves enqueued since the last collect
@@ -742,6 +747,15 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
         if (!runs.empty() && (i64)(runs.size() / 3) * 64 <= (i64)E.NF) {
             if ((rc = E.upload(&h->ir_run_ptr, rp, rp.size()))) return rc;
             if ((rc = E.upload(&h->ir_runs, runs, runs.size()))) return rc;
+            bool sf = E.gfold.ng == 0 && E.ir_tw == 256 && E.bundles.symv_split && E.bundles.nb == E.ir_grid &&
+                      !switches().no_ir_sf && !switches().no_flat;
+            for (int b = 0; b < E.bundles.nb && sf; b++) {
+                const int s0 = S.bundle_ptr[(size_t)b], nloc = S.bundle_ptr[(size_t)b + 1] - s0;
+                const int nleaf = S.blvl[(size_t)S.blvl_ptr[(size_t)b] + 1] - s0;
+                const int nlev = S.blvl_ptr[(size_t)b + 1] - S.blvl_ptr[(size_t)b] - 1;
+                sf = dev::irs_bundle_ok(nloc, nleaf, nlev, rp[(size_t)b + 1] - rp[(size_t)b]);
+            }
+            h->ir_sf = sf && dev::bundle_irs_capacity_ok(E.bundles);
         }
     }
     clk("maps, cone tables");
@@ -1080,8 +1094,10 @@ static int solve_core(chip_kkt *h) {
     if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
     h->last_ir = 0;
     int rc;
+    if (h->bp_stale && !h->rhs_deferred) h->rhs_deferred = true; // (the last fused solve left no permuted copy of b)
     if (h->rhs_deferred) { // (fused path not taken for this solve: stage the noted right-hand side now)
         h->rhs_deferred = false;
+        h->bp_stale = false;
         if ((rc = E.zero_norm_sets())) return rc;
         dev::setrhs_perm(E.stream, h->bp, h->x, h->rhs_x, h->rhs_z, E.perm, (int)h->K.n, (int)h->K.m, E.N,
                          E.norm_set(0), E.norm_nan(0));
@@ -1341,6 +1357,21 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     }
     ir.test_drop = h->ir_test_drop ? 1 : 0;
     ir.flat = switches().no_flat ? 0 : 1;
+    const bool step_kernel = E.gstep_solve_on && !switches().no_step_kernel && ir.maxiter <= 30;
+    ir.sf = (h->ir_sf && !step_kernel) ? 1 : 0;
+    if (ir.sf) ir.bp = nullptr; // (k_bundle_irs reads b through the runs every time; see chip_kkt::bp_stale)
+    {
+        // (the residual of the last round still reads the right-hand side when that round's candidate is written)
+        auto overlap = [](const double *a, size_t na, const double *b_, size_t nb_) {
+            return a && b_ && a < b_ + nb_ && b_ < a + na;
+        };
+        const size_t n = (size_t)h->K.n, m = (size_t)h->K.m;
+        const int flags = switches().irs_flags < 0 ? 3 : switches().irs_flags;
+        ir.sf_flags = flags;
+        ir.spec_out = (flags & 2) && !(overlap(lhsx_dev, n, ir.rx, n) || overlap(lhsx_dev, n, ir.rz, m) || overlap(lhsz_dev, m, ir.rx, n) ||
+                        overlap(lhsz_dev, m, ir.rz, m));
+    }
+    h->bp_stale = ir.sf != 0;
     if (h->exch_pending) { // (see chip_kkt::exch_event: no foreign kernel of ours beside a persistent launch)
         (void)hipStreamWaitEvent(E.stream, h->exch_event, 0);
         h->exch_pending = false;
@@ -1350,7 +1381,7 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     h->x_holds_b = false;
     E.prof_begin(PF_IR);
     int rc;
-    if (E.gstep_solve_on && !switches().no_step_kernel && ir.maxiter <= 30) {
+    if (step_kernel) {
         // grouped fold with small bundles: the register-resident form of the same launch (bundle_gstep.hip)
         E.gstep.epoch += 1;
         dev::GStepView gsv = E.gstep;
@@ -1422,6 +1453,10 @@ int32_t chip_kkt_solve_dev(chip_kkt *h, double *lhsx_dev, double *lhsz_dev) {
     Engine &E = h->E;
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
+    if (h->bp_stale && !h->rhs_deferred) { // (solve() again on the same right-hand side: the noted vectors once more)
+        h->rhs_deferred = true;
+        h->x_holds_b = true;
+    }
     if (E.ir_fused && h->rhs_deferred && (E.prof_family == PF_NONE || E.prof_family >= PF_IR)) {
         int slot = 0;
         int rc = fused_enqueue(h, lhsx_dev, lhsz_dev, &slot);
@@ -1442,6 +1477,10 @@ int32_t chip_kkt_solve_dev_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_d
     NEED_DEVICE(E);
     CHIP_HIP(hipSetDevice(E.device));
     if ((int)h->pend_slots.size() >= Engine::IR_RING) return fail(CHIP_ERR_ARG, "solve_dev_enqueue: 16 solves pending, collect first");
+    if (h->bp_stale && !h->rhs_deferred) { // (solve() again on the same right-hand side: the noted vectors once more)
+        h->rhs_deferred = true;
+        h->x_holds_b = true;
+    }
     if (E.ir_fused && h->rhs_deferred && (E.prof_family == PF_NONE || E.prof_family >= PF_IR)) {
         int slot = 0;
         int rc = fused_enqueue(h, lhsx_dev, lhsz_dev, &slot);
@@ -1507,6 +1546,7 @@ int32_t chip_kkt_solve2_dev_enqueue(chip_kkt *h, const double *rhsx_a, const dou
     h->last_ir = h->last_ir2 = 0;
     h->rhs_deferred = false;
     h->x_holds_b = false;
+    h->bp_stale = false;
     // ---- both chains enqueued: A on the engine's stream, B on the second one
     if ((rc = E.zero_norm_sets())) return rc;
     dev::setrhs_perm(E.stream, h->bp, h->x, rhsx_a, rhsz_a, E.perm, n, m, E.N, E.norm_set(0), E.norm_nan(0));
@@ -1630,6 +1670,7 @@ int32_t chip_kkt_solve_full(chip_kkt *h, double *x, const double *b) {
     h->x_holds_b = false;
     // bp was written directly: a right-hand side noted by an earlier setrhs() (borrowed pointers) is void
     h->rhs_deferred = false;
+    h->bp_stale = false;
     h->rhs_x = h->rhs_z = nullptr;
     int ok = solve_core(h);
     if (ok != 1) return ok;

@@ -195,6 +195,9 @@ struct IrView {
     long long *dbg_all;    // diagnostics (CHIP_IR_DEBUG=2): 32 words per workgroup: [0] hardware id, [1..] time stamps
     int test_drop;         // tests: the last workgroup leaves at once, so every grid barrier times out
     int flat;              // entry-parallel sweeps / residual (bundle_sweep_flat, bundle_symv_flat); 0: column per thread
+    int sf_flags;          // k_bundle_irs, experiment bits (CHIP_IRS_FLAGS): 1 = round 0's iterate stays in registers
+    int spec_out;          // k_bundle_irs: lhsx / lhsz do not overlap rx / rz -- the last candidate may be written before its verdict
+    int sf;                // k_bundle_irs (one bundle per workgroup, the candidate in registers; bp may be nullptr: not written)
 };
 int ir_ctl_ints();                 // (+ 32 per group of a grouped fold, appended: GFoldView::gcnt)
 size_t ir_part_doubles(int nb, int k);
@@ -204,6 +207,9 @@ int bundle_ir_capacity(const BundleView &bv, int *tw);
 // returns hipSuccess (0) or the launch error; grid <= bundle_ir_capacity, grid >= nb when fold.k > 0
 int bundle_ir(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, const IrView &ir, int grid,
               int tw, const GFoldView &gf);
+// k_bundle_irs: whether a co-resident grid of one 256-thread workgroup per bundle exists / whether a bundle qualifies
+bool bundle_irs_capacity_ok(const BundleView &bv);
+bool irs_bundle_ok(int nloc, int nleaf, int nlevels, int nruns);
 // grouped fold, after bundle_factor: every bundle's contribution to the Schur complement of its group's top
 // (k_gfold_schur -> gf.fac), then the k x k LDL' of every group's top (k_gfold_top_factor)
 void gfold_top_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const GFoldView &gf);

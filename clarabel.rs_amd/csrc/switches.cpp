@@ -53,6 +53,8 @@ const Entry TABLE[] = {
     {"CHIP_NO_BUNDLE_FLAT_SWEEP", Entry::FLAG, SW(no_bundle_flat_sweep), 0},
     {"CHIP_NO_FLAT", Entry::FLAG, SW(no_flat), 0},
     {"CHIP_NO_IR1024", Entry::FLAG, SW(no_ir1024), 0},
+    {"CHIP_NO_IR_SF", Entry::FLAG, SW(no_ir_sf), 0},
+    {"CHIP_IRS_FLAGS", Entry::INT, SW(irs_flags), 0},
     {"CHIP_IR_TEST_DROP", Entry::FLAG, SW(ir_test_drop), 0},
     {"CHIP_IR_DEBUG", Entry::INT, SW(ir_debug), 0},
     {"CHIP_IR_DEBUG_FILE", Entry::STR, SW(ir_debug_file), 0},

@@ -50,6 +50,8 @@ struct Switches {
     bool no_bundle_flat_sweep = false; // CHIP_NO_BUNDLE_FLAT_SWEEP: the stand-alone bundle sweeps keep the row- / column-per-thread form (k_bundle_fwd / bwd), no entry-parallel form (k_bundle_sweep_flat)
     bool no_flat = false;           // CHIP_NO_FLAT: column-per-thread sweeps inside k_bundle_ir
     bool no_ir1024 = false;         // CHIP_NO_IR1024
+    int irs_flags = -1;             // CHIP_IRS_FLAGS: experiment bits of k_bundle_irs (-1: the defaults; kernels.hpp: IrView::sf)
+    bool no_ir_sf = false;          // CHIP_NO_IR_SF: the fused solve stays on k_bundle_ir also where k_bundle_irs (candidate on chip, no permuted copy of b) applies
     bool ir_test_drop = false;      // CHIP_IR_TEST_DROP (tests: a fused launch that cannot complete its barrier)
     int ir_debug = 0;               // CHIP_IR_DEBUG: 1 = stamps of two workgroups on stderr, 2 = all workgroups -> file
     std::string ir_debug_file;      // CHIP_IR_DEBUG_FILE

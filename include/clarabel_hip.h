@@ -249,10 +249,13 @@ int32_t chip_kkt_update_scaling_dev(chip_kkt *h, const double *s_dev, const doub
  * is kept for callers that compute Hs themselves.  Returns the reference's bool. */
 int32_t chip_kkt_update(chip_kkt *h, const double *hsblocks_or_null);
 /* setrhs(rhsx, rhsz)   directldlkktsolver.rs:160-166.  The host variant copies the vectors.  The _dev
- * variant may BORROW the two device buffers until the following chip_kkt_solve* has run on the handle's
- * stream: when the whole solve runs as one fused launch (systems made of subtree bundles and at most a few
- * dense top rows: configs 3 and 4) that launch reads and permutes them itself -- they must not be
- * overwritten from another stream or from the host in between. */
+ * variant may BORROW the two device buffers until the NEXT chip_kkt_setrhs* (or chip_kkt_solve_full / the
+ * handle's destruction): when the whole solve runs as one fused launch (systems made of subtree bundles and
+ * at most a few dense top rows: configs 3 and 4) that launch reads and permutes them itself, in every
+ * refinement round (no permuted copy of b is written: 24 N bytes less traffic per solve), and a further
+ * chip_kkt_solve* on the same right-hand side (the reference keeps self.b, :168-175) reads them again.  They
+ * must not be overwritten from another stream or from the host in between, and they must not overlap the
+ * lhs buffers of those solves. */
 int32_t chip_kkt_setrhs(chip_kkt *h, const double *rhsx, const double *rhsz);
 int32_t chip_kkt_setrhs_dev(chip_kkt *h, const double *rhsx_dev, const double *rhsz_dev);
 /* solve(lhsx, lhsz, settings) -> bool   directldlkktsolver.rs:168-189,

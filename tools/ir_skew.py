@@ -36,6 +36,16 @@ work = np.zeros(G)
 for i in range(1, n):
     d = st[:, i] - st[:, i - 1]
     work += np.minimum(d, np.median(d) * 3)
+xs_ = sorted(set(xcc.tolist()))
+print("per-XCC median duration of every phase (us), one row per stamp; last column: spread of the XCC medians")
+for i in range(1, n):
+    d = st[:, i] - st[:, i - 1]
+    med = [float(np.median(d[xcc == x])) for x in xs_]
+    print("%3d   " % i + " ".join("%6.1f" % m for m in med) + "   | %5.1f" % (max(med) - min(med)))
+print("per-XCC median ARRIVAL at every stamp (us since the first start)")
+for i in range(n):
+    a = st[:, i] - t0
+    print("%3d   " % i + " ".join("%6.1f" % float(np.median(a[xcc == x])) for x in xs_))
 print("per-XCC mean start %s" % np.round([np.mean(st[xcc == x, 0] - t0) for x in sorted(set(xcc.tolist()))], 1))
 late = np.argsort(-(st[:, 2] - t0))[:10]
 print("latest 10 workgroups at stamp 2 (end of the first forward sweep): id, xcc, se, sh, cu, start, arrival")

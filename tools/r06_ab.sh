@@ -1,0 +1,16 @@
+# same-box A/B on config 3:  bash tools/r06_ab.sh <tag> "ENV=VAL[,ENV2=VAL2] ..."   (each setting twice, interleaved)
+TAG=$1; SETS=$2; W=${3:-c3}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+cd $R
+for rep in 1 2; do
+for st in $SETS; do
+  e=$(echo $st | tr ',' ' ')
+  if [ "$st" = "default" ]; then e=""; fi
+  env $e timeout 600 python bench.py --workload $W --cpu-steps 0 --no-extras --steps 20 --warmup 3 2> /dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+r=d.get('roofline') or {}
+print('%-40s ms/step %.4f  it/s %8.2f  launch_us %s' % ('$st', d['ms_per_step'], d['value'], r.get('avg_launch_us')))
+" | tee -a $O/${TAG}_ab.txt
+done
+done

@@ -30,3 +30,9 @@ for s, e, n in step:
 t0 = step[0][0]
 for k, n, d, s, e in runs:
     print("%9.1f us  %-44s x%-4d total %8.1f us  mean %7.1f us  span %8.1f us" % ((s - t0) / 1e3, k, n, d / 1e3, d / n / 1e3, (e - s) / 1e3))
+# every dispatch of the step with the idle time since the previous dispatch ended (what a kernel boundary costs here)
+print("dispatch by dispatch: start (us), duration (us), gap since the previous dispatch ended (us)")
+prev_end = None
+for s, e, n in step:
+    print("%9.1f  %8.1f  %6.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, 0.0 if prev_end is None else (s - prev_end) / 1e3, short(n)))
+    prev_end = e

@@ -906,21 +906,20 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
                 }
                 if (tid == 0) {
                     // the k x k top part of both sweeps, by every workgroup alike (k <= 8)
-                    double y[8];
+                    // (y in LDS, st.dxt: a private array indexed by a loop variable lives in scratch memory, and its
+                    // reloads sat on the critical path right behind the barrier)
                     for (int i = 0; i < k; ++i) {
                         double sacc = (round == 0 ? st.btop[i] : st.rtop[i]) - ir_load(&pub[par * 32 + i]);
-                        for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * y[j];
-                        y[i] = sacc;
+                        for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * st.dxt[j];
+                        st.dxt[i] = sacc;
                     }
                     for (int i = k - 1; i >= 0; --i) {
-                        double sacc = y[i] * st.dinvt[i];
-                        for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * y[j];
-                        y[i] = sacc;
+                        double sacc = st.dxt[i] * st.dinvt[i];
+                        for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * st.dxt[j];
+                        st.dxt[i] = sacc;
                     }
-                    for (int i = 0; i < k; ++i) {
-                        st.dxt[i] = y[i];
-                        st.candt[i] = round == 0 ? y[i] : 1.0 * st.curt[i] + 1.0 * y[i];
-                    }
+                    for (int i = 0; i < k; ++i)
+                        st.candt[i] = round == 0 ? st.dxt[i] : 1.0 * st.curt[i] + 1.0 * st.dxt[i];
                 }
                 } // (!GR)
             }
@@ -1387,15 +1386,11 @@ void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         }
     };
     auto reduce_residual = [&](int par, bool first) { // norms NaN propagating; every load is issued before any reduction
-        double mb = 0.0, m = 0.0, part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double mb = 0.0, m = 0.0, part0 = 0.0; // (no private array: it would live in scratch memory)
         for (int q = tid; q < nb; q += TW) {
             if (first) mb = nanmax(mb, ir_load(&pnb[q]));
             m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
-            if (ir.ir_enable) {
-                if (k == 1) part[0] += ir_load(&shs[(size_t)par * nb + q]);
-                else
-                    for (int i = 0; i < k; ++i) part[i] += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
-            }
+            if (ir.ir_enable && k >= 1) part0 += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k]);
         }
         if (first) {
             mb = block_nanmax(mb, red);
@@ -1404,7 +1399,13 @@ void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         m = block_nanmax(m, red);
         if (tid == 0) ir_store(&pub[par * 32 + 8], m);
         for (int i = 0; i < k; ++i) {
-            const double tot = block_sum(part[i], red);
+            double part = part0;
+            if (i > 0) {
+                part = 0.0;
+                if (ir.ir_enable)
+                    for (int q = tid; q < nb; q += TW) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
+            }
+            const double tot = block_sum(part, red);
             if (tid == 0) ir_store(&pub[par * 32 + 16 + i], tot);
         }
     };
@@ -1523,21 +1524,20 @@ void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
             }
             if (tid == 0) {
                 // the k x k top part of both sweeps, by every workgroup alike (k <= 8)
-                double y[8];
+                // (y in LDS, st.dxt: a private array indexed by a loop variable lives in scratch memory, and its
+                // reloads sat on the critical path right behind the barrier)
                 for (int i = 0; i < k; ++i) {
                     double sacc = (round == 0 ? st.btop[i] : st.rtop[i]) - ir_load(&pub[par * 32 + i]);
-                    for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * y[j];
-                    y[i] = sacc;
+                    for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * st.dxt[j];
+                    st.dxt[i] = sacc;
                 }
                 for (int i = k - 1; i >= 0; --i) {
-                    double sacc = y[i] * st.dinvt[i];
-                    for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * y[j];
-                    y[i] = sacc;
+                    double sacc = st.dxt[i] * st.dinvt[i];
+                    for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * st.dxt[j];
+                    st.dxt[i] = sacc;
                 }
-                for (int i = 0; i < k; ++i) {
-                    st.dxt[i] = y[i];
-                    st.candt[i] = round == 0 ? y[i] : 1.0 * st.curt[i] + 1.0 * y[i];
-                }
+                for (int i = 0; i < k; ++i)
+                    st.candt[i] = round == 0 ? st.dxt[i] : 1.0 * st.curt[i] + 1.0 * st.dxt[i];
             }
         }
         __syncthreads();

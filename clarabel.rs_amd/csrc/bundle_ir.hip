@@ -393,7 +393,8 @@ __device__ __forceinline__ void bundle_symv_flat(const LdlView &v, const BundleV
     const double *__restrict__ Ux = v.Ux;
     const int s0 = bv.bundle_ptr[bid], nloc = bv.bundle_ptr[bid + 1] - s0;
     const int nleaf = bv.blvl[bv.blvl_ptr[bid] + 1] - s0, nin = nloc - nleaf;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid)); // (no hoisting of this phase's address arithmetic out of the caller's round loop)
     auto xpos = [&](int t) { return t < nleaf ? t : nloc + (t - nleaf); }; // x of non-leaf t
     // leaf rows: pointers of this thread's first four rows are requested before the staging pass
     constexpr int LR = 4, LS = 3;
@@ -540,6 +541,7 @@ struct IrState {
     double btop[8], rtop[8], dxt[8], curt[8], candt[8];
     double dinvt[8], ltt[64], ktt[64]; // constants of the folded top: 1/d, L(top, top), K(top, top) (full rows)
     double tacc[8];                    // this bundle's shares of the top rows in the forward sweep
+    double pubv[20];                   // k_bundle_irs: a barrier's results: [0, k) forward sums, [k] ||e||, [k + 1] ||b||, [k + 2, 2k + 2) residual sums
     int runs[3 * IR_MAXRUNS];          // run-length form of the bundle's slice of the permutation
 };
 
@@ -662,15 +664,11 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
         }
     };
     auto reduce_residual = [&](int par, bool first) { // norms NaN propagating; every load is issued before any reduction
-        double mb = 0.0, m = 0.0, part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double mb = 0.0, m = 0.0, part0 = 0.0; // (no private array: it would live in scratch memory)
         for (int q = tid; q < nb; q += TW) {
             if (first) mb = nanmax(mb, ir_load(&pnb[q]));
             m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
-            if (ir.ir_enable && !GR) {
-                if (k == 1) part[0] += ir_load(&shs[(size_t)par * nb + q]);
-                else
-                    for (int i = 0; i < k; ++i) part[i] += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
-            }
+            if (ir.ir_enable && !GR && k >= 1) part0 += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k]);
         }
         if (GR) // the top rows of every group: reduced by the groups' last arrivers, published in their records
             for (int q = tid; q < gf.ng; q += TW) {
@@ -685,7 +683,13 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
         if (tid == 0) ir_store(&pub[par * 32 + 8], m);
         if (!GR)
             for (int i = 0; i < k; ++i) {
-                const double tot = block_sum(part[i], red);
+                double part = part0;
+                if (i > 0) {
+                    part = 0.0;
+                    if (ir.ir_enable)
+                        for (int q = tid; q < nb; q += TW) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
+                }
+                const double tot = block_sum(part, red);
                 if (tid == 0) ir_store(&pub[par * 32 + 16 + i], tot);
             }
     };
@@ -826,23 +830,25 @@ void k_bundle_ir(LdlView v, BundleView bv, FoldView fold, IrView ir, GFoldView g
                     if (ir_group_arrive(gf.gcnt + grp * 32, gnb * gph)) {
                         group_sums(gf.fsh);
                         if (tid == 0) {
-                            double y[8], nt = 0.0, nbt = 0.0;
+                            // (y in LDS, st.dxt -- rewritten from the group's record after the barrier: a private array
+                            // indexed by a loop variable lives in scratch memory)
+                            double nt = 0.0, nbt = 0.0;
                             for (int i = 0; i < k; ++i) {
                                 const double rhs_i = round == 0 ? st.btop[i] : ir_load(&grec[(par ^ 1) * 32 + 16 + i]);
                                 double sacc = rhs_i - st.tacc[i];
-                                for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * y[j];
-                                y[i] = sacc;
+                                for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * st.dxt[j];
+                                st.dxt[i] = sacc;
                             }
                             for (int i = k - 1; i >= 0; --i) {
-                                double sacc = y[i] * st.dinvt[i];
-                                for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * y[j];
-                                y[i] = sacc;
+                                double sacc = st.dxt[i] * st.dinvt[i];
+                                for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * st.dxt[j];
+                                st.dxt[i] = sacc;
                             }
                             // (the candidate x_top + dx_top is formed AFTER the barrier: whether the previous
                             // candidate was accepted is decided there)
                             for (int i = 0; i < k; ++i) {
-                                ir_store(&grec[par * 32 + i], y[i]);
-                                nt = nanmax(nt, fabs(y[i]));
+                                ir_store(&grec[par * 32 + i], st.dxt[i]);
+                                nt = nanmax(nt, fabs(st.dxt[i]));
                                 nbt = nanmax(nbt, fabs(st.btop[i]));
                             }
                             if (!ir.ir_enable) { // no refinement: the top entries take part in x.is_finite() (:180)
@@ -1377,49 +1383,89 @@ void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         } else if (ir.dbg && tid == 0 && (b == 0 || b == G / 2) && dbgn < 64)
             ir.dbg[(b ? 64 : 0) + dbgn++] = wall_clock64();
     };
-    auto reduce_forward = [&](int par) {
-        for (int i = 0; i < k; ++i) {
-            double part = 0.0;
-            for (int q = tid; q < nb; q += TW) part += ir_load(&shf[(size_t)q * k + i]);
-            part = block_sum(part, red);
-            if (tid == 0) ir_store(&pub[par * 32 + i], part);
-        }
-    };
-    auto reduce_residual = [&](int par, bool first) { // norms NaN propagating; every load is issued before any reduction
-        double mb = 0.0, m = 0.0, part0 = 0.0; // (no private array: it would live in scratch memory)
-        for (int q = tid; q < nb; q += TW) {
-            if (first) mb = nanmax(mb, ir_load(&pnb[q]));
-            m = nanmax(m, ir_load(&pn[(size_t)par * nb + q]));
-            if (ir.ir_enable && k >= 1) part0 += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k]);
-        }
-        if (first) {
-            mb = block_nanmax(mb, red);
-            if (tid == 0) ir_store(&pub[par * 32 + 9], mb);
-        }
-        m = block_nanmax(m, red);
-        if (tid == 0) ir_store(&pub[par * 32 + 8], m);
-        for (int i = 0; i < k; ++i) {
-            double part = part0;
-            if (i > 0) {
-                part = 0.0;
-                if (ir.ir_enable)
-                    for (int q = tid; q < nb; q += TW) part += ir_load(&shs[(size_t)par * nb * k + (size_t)q * k + i]);
+    __shared__ double redm[4 * 16];
+    // The grid barrier with its reductions.  Every workgroup has stored its partial results (forward shares shf, norms
+    // pn / pnb, residual shares shs) with device-coherent stores; the LAST arriver sums them in a fixed order -- all
+    // loads in flight at once, ONE pass of workgroup reductions for the four numbers of the usual single top row -- and
+    // publishes the results inside the release messages (grid_sync.hpp: ir_publish); everyone else finds them in its
+    // sub-group's record.  Afterwards st.pubv holds them in every workgroup.
+    //   fwd: this round's forward sums;  resid: norms / residual sums of the candidate whose partials have parity rpar
+    const int nmsg = 2 * k + 2;
+    const int tagbase = ir.epoch << 8;
+    auto barrier = [&](bool fwd, bool resid, int rpar, bool first) -> int {
+        if (tid == 0) st.gen += 1;
+        const int state = ir_arrive_nowait(ir.ctl, st.gen, G);
+        const int tag = tagbase | (__builtin_amdgcn_readfirstlane(st.gen) & 0xff);
+        if (state == IR_LAST) {
+            double f0 = 0.0, r0 = 0.0, mb = 0.0, m = 0.0;
+            for (int q = tid; q < nb; q += TW) {
+                if (fwd && k >= 1) f0 += ir_load(&shf[(size_t)q * k]);
+                if (resid) {
+                    if (first) mb = nanmax(mb, ir_load(&pnb[q]));
+                    m = nanmax(m, ir_load(&pn[(size_t)rpar * nb + q]));
+                    if (ir.ir_enable && k >= 1) r0 += ir_load(&shs[(size_t)rpar * nb * k + (size_t)q * k]);
+                }
             }
-            const double tot = block_sum(part, red);
-            if (tid == 0) ir_store(&pub[par * 32 + 16 + i], tot);
+            f0 = wave_sum(f0);
+            r0 = wave_sum(r0);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mb = nanmax(mb, __shfl_down(mb, o, 64));
+                m = nanmax(m, __shfl_down(m, o, 64));
+            }
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane == 0) {
+                redm[wv * 4 + 0] = f0;
+                redm[wv * 4 + 1] = r0;
+                redm[wv * 4 + 2] = mb;
+                redm[wv * 4 + 3] = m;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double tf = redm[0], tr = redm[1], tmb = redm[2], tm = redm[3];
+                for (int w = 1; w < TW / 64; ++w) {
+                    tf += redm[w * 4 + 0];
+                    tr += redm[w * 4 + 1];
+                    tmb = nanmax(tmb, redm[w * 4 + 2]);
+                    tm = nanmax(tm, redm[w * 4 + 3]);
+                }
+                if (k >= 1) {
+                    st.pubv[0] = tf;
+                    st.pubv[k + 2] = tr;
+                }
+                st.pubv[k] = tm;
+                if (first || !resid) st.pubv[k + 1] = tmb;
+            }
+            for (int i = 1; i < k; ++i) { // (further top rows: a pass each)
+                double pf = 0.0, pr = 0.0;
+                for (int q = tid; q < nb; q += TW) {
+                    if (fwd) pf += ir_load(&shf[(size_t)q * k + i]);
+                    if (resid && ir.ir_enable) pr += ir_load(&shs[(size_t)rpar * nb * k + (size_t)q * k + i]);
+                }
+                pf = block_sum(pf, red);
+                pr = block_sum(pr, red);
+                if (tid == 0) {
+                    st.pubv[i] = pf;
+                    st.pubv[k + 2 + i] = pr;
+                }
+            }
+            __syncthreads();
+            ir_publish(ir.rel, st.pubv, nmsg, tag, G);
+            return IR_LAST;
         }
+        return ir_wait_record(ir.rel, st.pubv, nmsg, tag);
     };
     // the reference's decisions about the candidate of round `round` (k_bundle_ir: decide)
     auto decide = [&](int round, int par) {
         if (tid == 0) {
-            double m = ir_load(&pub[par * 32 + 8]);
+            double m = st.pubv[k];
             if (round == 0) {
-                double nbm = ir_load(&pub[par * 32 + 9]);
+                double nbm = st.pubv[k + 1];
                 for (int i = 0; i < k; ++i) nbm = nanmax(nbm, fabs(st.btop[i]));
                 st.normb = nbm;
             }
             for (int i = 0; i < k; ++i) {
-                double sacc = ir_load(&pub[par * 32 + 16 + i]);
+                double sacc = st.pubv[k + 2 + i];
                 for (int cc = 0; cc < k; ++cc) sacc += st.ktt[i * 8 + cc] * st.candt[cc];
                 st.rtop[i] = ir.ir_enable ? st.btop[i] - sacc : st.candt[i];
                 m = nanmax(m, fabs(st.rtop[i]));
@@ -1504,19 +1550,11 @@ void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         if (folded) {
             stamp();
             if (round == 0) load_top_constants();
-            if (tid == 0) st.gen += 1;
-            const int state = ir_arrive_wait(ir.ctl, st.gen, G);
-            if (state == IR_TIMEOUT) {
+            if (barrier(true, pending, par ^ 1, round == 1) == IR_TIMEOUT) {
                 if (tid == 0) ir.res[2] = 1;
                 return;
             }
             stamp();
-            if (state == IR_LAST) {
-                reduce_forward(par);
-                if (pending) reduce_residual(par ^ 1, round == 1);
-                ir_release(ir.ctl, st.gen, G);
-            }
-            __syncthreads();
             if (pending) { // the verdict on the previous round's candidate
                 decide(round - 1, par ^ 1);
                 pending = false;
@@ -1527,7 +1565,7 @@ void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
                 // (y in LDS, st.dxt: a private array indexed by a loop variable lives in scratch memory, and its
                 // reloads sat on the critical path right behind the barrier)
                 for (int i = 0; i < k; ++i) {
-                    double sacc = (round == 0 ? st.btop[i] : st.rtop[i]) - ir_load(&pub[par * 32 + i]);
+                    double sacc = (round == 0 ? st.btop[i] : st.rtop[i]) - st.pubv[i];
                     for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * st.dxt[j];
                     st.dxt[i] = sacc;
                 }
@@ -1625,18 +1663,11 @@ void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
         pending = true;
         if (folded && more_possible) continue; // (the verdict rides on the next round's barrier)
         stamp();
-        if (tid == 0) st.gen += 1;
-        const int state = ir_arrive_wait(ir.ctl, st.gen, G);
-        if (state == IR_TIMEOUT) {
+        if (barrier(false, true, par, round == 0) == IR_TIMEOUT) {
             if (tid == 0) ir.res[2] = 1;
             return;
         }
         stamp();
-        if (state == IR_LAST) {
-            reduce_residual(par, round == 0);
-            ir_release(ir.ctl, st.gen, G);
-        }
-        __syncthreads();
         decide(round, par);
         pending = false;
         if (__builtin_amdgcn_readfirstlane(st.done)) break;
@@ -1695,6 +1726,7 @@ void k_bundle_irs(LdlView v, BundleView bv, FoldView fold, IrView ir) {
 } // namespace
 
 int ir_ctl_ints() { return IR_CTL_INTS; }
+int ir_rel_ints() { return IR_REL_INTS; }
 size_t ir_part_doubles(int nb, int k) { return (size_t)nb * (3 + 3 * (size_t)k) + 72; }
 // workgroup size of k_bundle_ir for these bundles and the largest co-resident grid (0: the kernel cannot run)
 static size_t bundle_ir_lds(const BundleView &bv) {

@@ -1326,6 +1326,8 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
     ir.lhsz = lhsz_dev;
     ir.part = E.ir_part;
     ir.ctl = E.ir_ctl;
+    ir.rel = E.ir_rel;
+    ir.epoch = (E.ir_epoch = (E.ir_epoch + 1) & 0x3fffff); // (tags are epoch << 8 | barrier number)
     ir.res = E.ir_res + 4 * *slot;
     ir.abstol = st.iterative_refinement_abstol;
     ir.reltol = st.iterative_refinement_reltol;

@@ -575,6 +575,8 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
             ir_ctl_len = (size_t)dev::ir_ctl_ints() + (grouped ? (size_t)32 * S.gf_ng : 0);
             if ((rc = alloc(&ir_ctl, ir_ctl_len))) return rc;
             CHIP_HIP(hipMemset(ir_ctl, 0, ir_ctl_len * sizeof(int)));
+            if ((rc = alloc(&ir_rel, (size_t)dev::ir_rel_ints()))) return rc;
+            CHIP_HIP(hipMemset(ir_rel, 0, (size_t)dev::ir_rel_ints() * sizeof(int)));
             need_ring = true; // (ir_res = the ring inside the mailbox, set once that is allocated)
             if ((rc = alloc(&ir_part, dev::ir_part_doubles(bundles.nb, fold.k)))) return rc;
             if (grouped) {

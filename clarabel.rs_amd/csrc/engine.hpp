@@ -183,6 +183,8 @@ struct Engine {
     int factor_lds_doubles = 0; // > 0: the bundle factorisation keeps its values in LDS (k_bundle_factor_lds)
     int ir_grid = 0, ir_next = 0, ir_tw = 256;
     int *ir_ctl = nullptr, *ir_res = nullptr, *ir_res_host = nullptr;
+    int *ir_rel = nullptr;     // k_bundle_irs: release records of the grid barrier (dev::ir_rel_ints())
+    int ir_epoch = 0;          // launches of k_bundle_irs so far (tags of the messages)
     double *ir_part = nullptr;
     // profiling
     int prof_family = PF_NONE;

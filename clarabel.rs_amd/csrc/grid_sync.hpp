@@ -212,6 +212,45 @@ __device__ __forceinline__ void msg_load3(const int *slot_a, const int *slot_b, 
 __device__ __forceinline__ bool msg_ready(const msg_v4i &m, int tag) { return m.y == tag && m.w == tag; }
 __device__ __forceinline__ double msg_value(const msg_v4i &m) { return __hiloint2double(m.z, m.x); }
 
+// Release of the grid barrier WITH its results (k_bundle_irs, round 6): the last arriver writes the few reduced numbers
+// as tagged 16-byte messages (value + the barrier's tag in one store), one copy per sub-group of workgroups; a waiting
+// workgroup polls the messages of its sub-group with wave 0 -- lane j owns message j -- until all carry the tag, and has
+// the values at that moment.  The older form (ir_release) stored the numbers, waited for the stores to be acknowledged,
+// wrote the release words, and every workgroup then loaded the numbers: two more trips through the fabric per barrier.
+constexpr int IR_REC_MSGS = 32; // message slots per sub-group record (512 bytes)
+constexpr int IR_REL_INTS = IR_NSUB * IR_REC_MSGS * 4;
+__device__ __forceinline__ void ir_publish(int *rel, const double *vals, int nmsg, int tag, int nwg) {
+    const int nsub = min(IR_NSUB, nwg);
+    for (int t = threadIdx.x; t < nsub * nmsg; t += blockDim.x) {
+        const int sgrp = t / nmsg, j = t - sgrp * nmsg;
+        msg_store(rel + (sgrp * IR_REC_MSGS + j) * 4, vals[j], tag);
+    }
+}
+// vals[0 .. nmsg) <- the record of this workgroup's sub-group once every message carries `tag`; IR_TIMEOUT / IR_WAITED
+__device__ __forceinline__ int ir_wait_record(const int *rel, double *vals, int nmsg, int tag) {
+    __shared__ int s_state4;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int *slot = rel + ((int)(blockIdx.x % IR_NSUB) * IR_REC_MSGS + (lane < nmsg ? lane : 0)) * 4;
+        int state = IR_WAITED;
+        long long spins = 0;
+        msg_v4i m;
+        for (;;) {
+            m = msg_load(slot);
+            if (__all(msg_ready(m, tag) ? 1 : 0)) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1ll << 21)) {
+                state = IR_TIMEOUT;
+                break;
+            }
+        }
+        if (state != IR_TIMEOUT && lane < nmsg) vals[lane] = msg_value(m);
+        if (lane == 0) s_state4 = state;
+    }
+    __syncthreads();
+    return s_state4;
+}
+
 } // namespace
 
 } // namespace dev

@@ -195,10 +195,13 @@ struct IrView {
     long long *dbg_all;    // diagnostics (CHIP_IR_DEBUG=2): 32 words per workgroup: [0] hardware id, [1..] time stamps
     int test_drop;         // tests: the last workgroup leaves at once, so every grid barrier times out
     int flat;              // entry-parallel sweeps / residual (bundle_sweep_flat, bundle_symv_flat); 0: column per thread
+    int *rel;              // k_bundle_irs: ir_rel_ints() ints, the barrier's release records (tagged messages; any content at launch)
+    int epoch;             // k_bundle_irs: distinguishes this launch's messages from an earlier launch's (the host counts)
     int sf_flags;          // k_bundle_irs, experiment bits (CHIP_IRS_FLAGS): 1 = round 0's iterate stays in registers
     int spec_out;          // k_bundle_irs: lhsx / lhsz do not overlap rx / rz -- the last candidate may be written before its verdict
     int sf;                // k_bundle_irs (one bundle per workgroup, the candidate in registers; bp may be nullptr: not written)
 };
+int ir_rel_ints();
 int ir_ctl_ints();                 // (+ 32 per group of a grouped fold, appended: GFoldView::gcnt)
 size_t ir_part_doubles(int nb, int k);
 // largest co-resident grid of k_bundle_ir for these bundles (0: the kernel cannot run) and the workgroup

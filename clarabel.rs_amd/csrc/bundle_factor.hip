@@ -746,85 +746,163 @@ __global__ __launch_bounds__(FLWG) void k_bundle_factor_lds(LdlView v, BundleVie
 // flat pass over the bundle's U entries (fu_slot says where each lands).
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(FFWG) void k_bundle_factor_flat(LdlView v, BundleView bv, FoldView fold) {
+// Round 6: everything the launch reads is REQUESTED UP FRONT -- the U entries with their landing slots, the first
+// batch of update records, the column pointers and signs of the thread's own columns (CPT per thread, level-major numbering:
+// thread t owns columns t, t + 1024, ...), the slotted maxima of the regulariser -- so the level loop works on LDS and
+// registers only.  Before, a workgroup walked a chain of ~9 dependent round trips (U pass with a dependent load for the
+// diagonal rows, per level the records and the columns' pointers, a closing pass over Lp -> Li16 for the top row's
+// share): ~43 us per workgroup for 300 KB, two rounds of workgroups per launch.  The single folded top row's pivot
+// share sum l_tc^2 d_c now arrives through the records as well (target nE + nloc, symbolic.cpp), no closing pass.
+template <int CPT>
+__global__ __launch_bounds__(FFWG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bundle_factor_flat(LdlView v, BundleView bv, FoldView fold) {
     extern __shared__ __attribute__((aligned(16))) char ff_smem[];
-    __shared__ double red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int s0 = bv.bundle_ptr[b], s1 = bv.bundle_ptr[b + 1], nloc = s1 - s0;
     const int e0 = v.Lp[s0], nE = v.Lp[s1] - e0;
-    double *Ls = (double *)ff_smem, *Ds = Ls + nE; // (contiguous: a record's target addresses either)
-    bool eps_on;
-    __shared__ double s_eps;
-    (void)static_eps(v, &eps_on, &s_eps);
+    double *Ls = (double *)ff_smem, *Ds = Ls + nE; // (contiguous: a record's target addresses either; Ds[nloc]: the top row's share)
     const int *lv = bv.blvl + bv.blvl_ptr[b];
     const int nl = bv.blvl_ptr[b + 1] - bv.blvl_ptr[b] - 1;
     const int *tp = v.fu_ptr + bv.blvl_ptr[b];
-    for (int q = tid; q < nE; q += FFWG) Ls[q] = 0.0; // (fill-in slots stay zero)
-    __syncthreads();
-    const double eps = s_eps;
-    {
-        const int ub = v.Up[s0], ue = v.Up[s1];
-        for (int u = ub + tid; u < ue; u += FFWG) {
-            const unsigned short slot = v.fu_slot[u];
-            const double val = v.Ux[u];
-            if (slot == 0xFFFFu) {
-                const int j = (int)v.Urow16[u];
-                Ds[j] = eps_on ? (v.dsigns[s0 + j] == 1 ? val + eps : val - eps) : val;
-            } else {
-                Ls[slot] = val;
-            }
-        }
-    }
-    __syncthreads();
     typedef unsigned short fu_v4 __attribute__((ext_vector_type(4)));
     const fu_v4 *rec = (const fu_v4 *)v.fu_rec;
     constexpr int FU = 8; // records in flight per thread
-    for (int l = 0; l < nl; ++l) {
-        const int rb = tp[l], re = tp[l + 1];
-        // the level's first records are requested BEFORE its columns are finalised: they are index data
-        fu_v4 r[FU];
-        auto request = [&](int base) {
-#pragma unroll
-            for (int u = 0; u < FU; ++u) {
-                const int t = base + u * FFWG + tid;
-                if (t < re) r[u] = rec[t];
-                else r[u] = fu_v4{0, 0, 0, 0xFFFF};
-            }
-        };
-        request(rb);
-        // the level's columns are final: pivot rule, scale
-        for (int j = lv[l] + tid; j < lv[l + 1]; j += FFWG) {
-            const int cb = v.Lp[j] - e0, ce = v.Lp[j + 1] - e0;
-            double dd;
-            const double dinv = pivot_rule_local(v, j, Ds[j - s0], &dd);
-            Ds[j - s0] = dd;
-            for (int q = cb; q < ce; ++q) Ls[q] *= dinv;
+    constexpr int UF = 8; // U entries per thread and pass
+    int dbgn = 0;
+    auto stamp = [&]() { // diagnostics (CHIP_IR_DEBUG=3): phase boundaries of every workgroup on the 100 MHz clock
+        if (bv.fdbg && tid == 0 && dbgn < 31) {
+            if (dbgn == 0)
+                bv.fdbg[(size_t)b * 32] = (long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) |
+                                          ((long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32);
+            bv.fdbg[(size_t)b * 32 + 1 + dbgn++] = wall_clock64();
         }
-        __syncthreads();
-        for (int base = rb; base < re; base += FFWG * FU) { // (wave-uniform bounds: lds_scatter_add is cross-lane)
-            if (base != rb) request(base);
+    };
+    stamp();
+    // ---- requests: own columns, first pass of U entries, first batch of records ----
+    // (packed: 64 registers per thread -- two workgroups per CU -- must hold all of it: column = first slot | length << 16,
+    // signs as a bit mask, a U entry's slot | row << 16)
+    unsigned ccol[CPT];
+    unsigned csgm = 0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int j = tid + q * FFWG;
+        const bool ok = j < nloc;
+        const int cb = ok ? v.Lp[s0 + j] - e0 : 0, ce = ok ? v.Lp[s0 + j + 1] - e0 : 0;
+        ccol[q] = (unsigned)cb | ((unsigned)(ce - cb) << 16);
+        if (ok && v.dsigns[s0 + j] == 1) csgm |= 1u << q;
+    }
+    const int ub = v.Up[s0], ue = v.Up[s1];
+    unsigned usr[UF];
+    double uval[UF];
+    auto request_u = [&](int base) {
+#pragma unroll
+        for (int q = 0; q < UF; ++q) {
+            const int u = base + q * FFWG + tid;
+            const bool ok = u < ue;
+            usr[q] = ok ? ((unsigned)v.fu_slot[u] | ((unsigned)v.Urow16[u] << 16)) : 0xFFFEu; // (slot 0xFFFE: nothing)
+            uval[q] = ok ? v.Ux[u] : 0.0;
+        }
+    };
+    request_u(ub);
+    const int rend = tp[nl];
+    fu_v4 r[FU];
+    auto request = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int t = base + u * FFWG + tid;
+            if (t < rend) r[u] = rec[t];
+            else r[u] = fu_v4{0, 0, 0, 0xFFFF};
+        }
+    };
+    int base = tp[0];
+    bool eps_on;
+    __shared__ double s_eps;
+    (void)static_eps(v, &eps_on, &s_eps);
+    for (int q = tid; q <= nE + nloc; q += FFWG) Ls[q] = 0.0; // (fill-in slots stay zero; Ds[nloc] collects the top row's share)
+    lds_barrier();
+    stamp();
+    const double eps = s_eps;
+    // ---- initial values: the U entries to their slots ----
+    for (int ubase = ub;;) {
+#pragma unroll
+        for (int q = 0; q < UF; ++q) {
+            const unsigned slot = usr[q] & 0xFFFFu;
+            if (slot == 0xFFFFu) Ds[usr[q] >> 16] = uval[q];
+            else if (slot != 0xFFFEu) Ls[slot] = uval[q];
+        }
+        ubase += UF * FFWG;
+        if (ubase >= ue) break;
+        request_u(ubase);
+    }
+    request(base); // (the first batch of records: in flight under the regulariser pass and the first level's pivots)
+    lds_barrier();
+    stamp();
+    if (eps_on) { // static regularisation of the diagonal (directldlkktsolver.rs:217-250), before any update lands on it
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = tid + q * FFWG;
+            if (j < nloc) Ds[j] = ((csgm >> q) & 1u) ? Ds[j] + eps : Ds[j] - eps;
+        }
+    }
+    for (int l = 0; l < nl; ++l) {
+        // the level's columns are final: pivot rule (qdldl.rs:645-665), scale -- the thread's own columns of this level
+        const int lb = lv[l] - s0, le = lv[l + 1] - s0;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = tid + q * FFWG;
+            if (j >= lb && j < le) {
+                double d = Ds[j];
+                const double sign = ((csgm >> q) & 1u) ? 1.0 : -1.0;
+                if (d * sign < v.reg_eps) {
+                    d = v.reg_delta * sign;
+                    atomicAdd(&v.status[2], 1); // rare
+                }
+                if (d == 0.0) v.status[1] = 1;
+                const double dinv = 1.0 / d;
+                if (!isfinite(dinv)) v.status[0] = 1;
+                Ds[j] = d; // (D and 1 / D leave in one coalesced pass at the end)
+                const int cb = (int)(ccol[q] & 0xFFFFu), cn = (int)(ccol[q] >> 16);
+                for (int t = cb; t < cb + cn; ++t) Ls[t] *= dinv;
+            }
+        }
+        lds_barrier();
+        stamp();
+        const int rb = tp[l], re = tp[l + 1];
+        for (;;) { // (wave-uniform bounds: lds_scatter_add is cross-lane)
+            // (the level's records sit in the register slots ulo .. uhi of the batch: the others are skipped by a
+            // uniform branch -- these phases are bound by the instruction count, 8 waves per SIMD)
+            const int ulo = rb > base ? (rb - base) / FFWG : 0, uhi = (min(re, base + FU * FFWG) - 1 - base) / FFWG;
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
-                const bool ok = r[u].w != 0xFFFFu;
+                if (u < ulo || u > uhi) continue;
+                const int t = base + u * FFWG + tid;
+                const bool ok = t >= rb && t < re;
                 const double val = ok ? Ls[r[u].x] * (Ls[r[u].y] * Ds[r[u].z]) : 0.0;
                 lds_scatter_add(Ls, ok ? (int)r[u].w : -1, -val);
             }
+            if (base + FU * FFWG >= re) break; // (the batch reaches into the next level: that level goes on with it)
+            base += FU * FFWG;
+            request(base);
         }
-        __syncthreads();
+        if (base + FU * FFWG == re && re < rend) { // (the batch ended with the level: the next one, under the barrier)
+            base += FU * FFWG;
+            request(base);
+        }
+        lds_barrier();
+        stamp();
     }
-    if (fold.k == 1) {
-        double sacc = 0.0;
-        for (int j = s0 + tid; j < s1; j += FFWG) {
-            const int ce = v.Lp[j + 1] - e0;
-            if (ce > v.Lp[j] - e0 && (int)v.Li16[e0 + ce - 1] >= nloc) {
-                const double lt = Ls[ce - 1];
-                sacc += lt * (lt * Ds[j - s0]);
-            }
-        }
-        sacc = block_sum(sacc, red);
-        if (tid == 0 && sacc != 0.0) atomicAdd(&fold.acc[fold_acc_index(2, 0, b % FOLD_SLOTS)], sacc);
+    if (fold.k == 1 && tid == 0) {
+        // a single dense top row: d_t -= sum l_tc^2 d_c over this bundle's columns -- collected by the records of the
+        // (top, top) pairs in Ds[nloc] (as its negative); k_fold_top_pivot applies the pivot rule
+        const double sacc = -Ds[nloc];
+        if (sacc != 0.0) atomicAdd(&fold.acc[fold_acc_index(2, 0, b % FOLD_SLOTS)], sacc);
     }
     for (int q = tid; q < nE; q += FFWG) v.Lx[e0 + q] = Ls[q];
+    for (int j = tid; j < nloc; j += FFWG) {
+        const double d = Ds[j];
+        v.D[s0 + j] = d;
+        v.Dinv[s0 + j] = 1.0 / d;
+    }
+    stamp();
     static_eps_epilogue(v, eps);
 }
 __global__ void k_fold_top_pivot(LdlView v, FoldView fold) {
@@ -993,7 +1071,8 @@ bool bundle_factor_lds_ok(int lds_doubles) {
     }
     if (fa.sharedSizeBytes + lds > 80 * 1024 - 512) return false; // two workgroups per CU
     if (raise_dynamic_lds((const void *)k_bundle_factor_lds, (size_t)lds) != hipSuccess ||
-        raise_dynamic_lds((const void *)k_bundle_factor_flat, (size_t)lds) != hipSuccess) {
+        raise_dynamic_lds((const void *)k_bundle_factor_flat<4>, (size_t)lds) != hipSuccess ||
+        raise_dynamic_lds((const void *)k_bundle_factor_flat<8>, (size_t)lds) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
@@ -1002,7 +1081,10 @@ bool bundle_factor_lds_ok(int lds_doubles) {
 int bundle_factor(hipStream_t s, const LdlView &v, const BundleView &bv, const FoldView &fold, int lds_doubles) {
     if (!bv.nb) return 0;
     const bool no_flat = switches().no_factor_flat;
-    if (lds_doubles > 0 && v.fu_rec && !no_flat) k_bundle_factor_flat<<<bv.nb, FFWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold);
+    if (lds_doubles > 0 && v.fu_rec && !no_flat && bv.max_nodes <= 8 * FFWG) {
+        if (bv.max_nodes <= 4 * FFWG) k_bundle_factor_flat<4><<<bv.nb, FFWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold);
+        else k_bundle_factor_flat<8><<<bv.nb, FFWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold);
+    }
     else if (lds_doubles > 0 && v.Li16) k_bundle_factor_lds<<<bv.nb, FLWG, factor_lds_bytes(lds_doubles), s>>>(v, bv, fold, lds_doubles); // (needs the 16-bit row lists)
     else k_bundle_factor<<<bv.nb, BWG, 0, s>>>(v, bv, fold);
     return (int)hipGetLastError(); // (a rejected launch would leave the factor stale)

@@ -284,7 +284,7 @@ __device__ __forceinline__ void bundle_sweep_flat(const LdlView &v, const Bundle
             ++step;
         }
     };
-    __syncthreads(); // (lev_e, the scaled slice)
+    lds_barrier(); // (lev_e, the scaled slice)
     if (TW == 512) {
         // (80 registers per thread in the 512-thread variant: no second batch in flight)
         for (int st_ = 0; st_ < nl; ++st_) {
@@ -315,13 +315,13 @@ __device__ __forceinline__ void bundle_sweep_flat(const LdlView &v, const Bundle
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         if (FWDMODE && k == 1) {
             tpart = wave_sum_all(tpart);
             if (lane == 0 && tpart != 0.0) atomicAdd(&tacc[0], tpart);
         }
-        __syncthreads();
+        lds_barrier();
         return;
     }
     skip_empty();
@@ -363,7 +363,7 @@ __device__ __forceinline__ void bundle_sweep_flat(const LdlView &v, const Bundle
                 atomicAdd(&xs[cj[u]], -(cv[u] * (i < nloc ? xs[i] : xt[i - nloc])));
             }
         }
-        if (nstep != step) __syncthreads(); // the level is complete
+        if (nstep != step) lds_barrier(); // the level is complete
         step = nstep;
         base = nbase;
         ee = nee;
@@ -378,7 +378,7 @@ __device__ __forceinline__ void bundle_sweep_flat(const LdlView &v, const Bundle
         tpart = wave_sum_all(tpart);
         if (lane == 0 && tpart != 0.0) atomicAdd(&tacc[0], tpart);
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // The residual of k_bundle_ir in the split LDS layout of bundle_symv_split, entry-parallel: the rows of the non-leaf
@@ -1161,7 +1161,7 @@ __device__ __forceinline__ void irs_symv(const LdlView &v, const IrView &ir, con
             const int i = tid + u * TW;
             bq[u] = (i >= nleaf && i < nloc) ? rhs_of(rw.orig(i)) : 0.0;
         }
-        __syncthreads(); // (every thread has taken its candidate entries out of xs)
+        lds_barrier(); // (every thread has taken its candidate entries out of xs)
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
             const int i = tid + u * TW;
@@ -1177,7 +1177,7 @@ __device__ __forceinline__ void irs_symv(const LdlView &v, const IrView &ir, con
     if (k > 1 && tid < 8) tacc3[tid] = 0.0;
     double mleaf = 0.0;
     bool nan = false;
-    __syncthreads();
+    lds_barrier();
     // ---- leaf rows: the thread's own, four per pass; x_i from the registers ----
     RunWalk rl{runs, 0};
 #pragma unroll
@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void irs_symv(const LdlView &v, const IrView &ir, con
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     double m = mleaf;
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
@@ -1300,7 +1300,7 @@ __device__ __forceinline__ void irs_symv(const LdlView &v, const IrView &ir, con
         tpart = block_sum(tpart, red);
         if (tid == 0) __hip_atomic_store(out_share, tpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (k > 1) {
-        __syncthreads();
+        lds_barrier();
         if (tid == 0)
             for (int i = 0; i < k; ++i)
                 __hip_atomic_store(out_share + i, tacc3[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

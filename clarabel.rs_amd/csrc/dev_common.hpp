@@ -228,6 +228,13 @@ __device__ __forceinline__ double pivot_rule(const LdlView &v, int j, double d) 
     return dinv;
 }
 
+// Barrier for data exchanged through LDS only: waits for this wave's LDS operations (lgkmcnt), NOT for its outstanding
+// global loads and stores -- __syncthreads() is a workgroup-scope fence + barrier and drains both (s_waitcnt vmcnt(0)),
+// which pulls the wait for operands requested early and needed late to the next barrier: a "prefetch across the level
+// barrier" behind __syncthreads() is no prefetch at all (round 6: measured on the bundle factorisation, whose record
+// loads were meant to fly under the pivots of a level and instead held every barrier of the level loop).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // bundle kernels: thin / fat thresholds shared by the factorisation and the substitutions
 constexpr int FAC_THIN_ROW = 8, FAC_THIN_COL = 48, THIN_MAX = 32;
 constexpr int BWG = 512;      // bundle workgroup: 8 waves -> more loads in flight per subtree

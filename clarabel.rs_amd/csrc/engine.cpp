@@ -465,7 +465,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                 int need = 0;
                 for (int b = 0; b < bundles.nb; b++) {
                     const int s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
-                    need = std::max(need, (int)(S.Lp[s1] - S.Lp[s0]) + (s1 - s0));
+                    need = std::max(need, (int)(S.Lp[s1] - S.Lp[s0]) + (s1 - s0) + 1); // (+ 1: the folded top row's share)
                 }
                 if (dev::bundle_factor_lds_ok(need)) {
                     if ((rc = upload(&fu_rec, S.fu_rec, S.fu_rec.size()))) return rc;
@@ -562,7 +562,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                     const int s0 = S.bundle_ptr[b], s1 = S.bundle_ptr[b + 1];
                     const int ne = S.Lp[s1] - S.Lp[s0];
                     ok = ne < 65535;
-                    need = std::max(need, ne + (s1 - s0));
+                    need = std::max(need, ne + (s1 - s0) + 1); // (+ 1: the folded top row's share, k_bundle_factor_flat)
                 }
                 if (ok && dev::bundle_factor_lds_ok(need)) factor_lds_doubles = need;
                 if (factor_lds_doubles > 0 && !S.fu_rec.empty()) {
@@ -1125,8 +1125,28 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         }
     } else {
         gstep_vals_valid = false;
-        const int lrc = dev::bundle_factor(stream, v, bundles, ffold, factor_lds_doubles); // everything below the cut: one launch
+        long long *fdbg = nullptr;
+        if (switches().ir_debug >= 3) { // stamps of every workgroup of the factor launch -> <CHIP_IR_DEBUG_FILE>.factor
+            (void)hipMalloc((void **)&fdbg, (size_t)bundles.nb * 32 * sizeof(long long));
+            (void)hipMemsetAsync(fdbg, 0, (size_t)bundles.nb * 32 * sizeof(long long), stream);
+        }
+        dev::BundleView bdbg = bundles;
+        bdbg.fdbg = fdbg;
+        const int lrc = dev::bundle_factor(stream, v, bdbg, ffold, factor_lds_doubles); // everything below the cut: one launch
         prof_end(PF_BFACTOR);
+        if (fdbg) {
+            (void)hipStreamSynchronize(stream);
+            std::vector<long long> t((size_t)bundles.nb * 32);
+            (void)hipMemcpy(t.data(), fdbg, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            (void)hipFree(fdbg);
+            const std::string path = (switches().ir_debug_file.empty() ? std::string("/tmp/chip_ir_stamps.bin") : switches().ir_debug_file) + ".factor";
+            if (FILE *f = std::fopen(path.c_str(), "wb")) {
+                const int g = bundles.nb;
+                std::fwrite(&g, sizeof(int), 1, f);
+                std::fwrite(t.data(), sizeof(long long), t.size(), f);
+                std::fclose(f);
+            }
+        }
         if (lrc) {
             set_error(hip_err((hipError_t)lrc, "bundle factorisation launch"));
             return CHIP_ERR_HIP;

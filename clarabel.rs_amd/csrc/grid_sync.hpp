@@ -156,10 +156,7 @@ __device__ __forceinline__ double block_nanmax(double v, double *red) {
     return t;
 }
 
-// Barrier for data exchanged through LDS only: waits for this wave's LDS operations (lgkmcnt), NOT for its outstanding
-// global loads and stores -- __syncthreads() is a workgroup-scope fence + barrier and drains both, which would pull the
-// wait for operands requested early and needed late (the step kernels' K entries) to the first barrier of the launch.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (lds_barrier: dev_common.hpp)
 // NaN-propagating max over the workgroup through LDS (red: one double per wave), broadcast; `bad`: this thread saw a NaN
 __device__ __forceinline__ double lds_block_nanmax(double m, bool bad, double *red) {
     m = wave_max_all(m);

@@ -58,6 +58,7 @@ struct BundleView {
     // memory), which needs nloc + max(0, nloc - 2 nleaf) doubles for every bundle
     int ir_lds_doubles, symv_split;
     int max_levels; // most levels of a bundle
+    long long *fdbg; // diagnostics (CHIP_IR_DEBUG=3): 32 words per workgroup of k_bundle_factor_flat ([0] hardware id, [1..] stamps), or nullptr
 };
 
 // Few dense top rows folded into the bundle kernels (host.hpp: Symbolic::nfold); k == 0: unused

@@ -1273,6 +1273,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 i32 nin = 0;
                 while (cb + nin < ce && S.Li[cb + nin] < s1) nin++;
                 c = (i64)nin * (ce - cb) - (i64)nin * (nin - 1) / 2; // b over the nin in-bundle rows, a from b to the end
+                if (S.nfold == 1 && cb + nin < ce) c += 1; // (the single folded top row: its pivot share l_tk^2 d_k)
                 return c;
             };
             run_threads(T, [&](int t, int TT) {
@@ -1308,6 +1309,11 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                                         lvl.push_back({(uint16_t)(qa - e0), (uint16_t)(qb - e0), (uint16_t)(k - s0), tgt});
                                     }
                                 }
+                                // one folded top row (the last entry of a column that reaches it): its pivot takes
+                                // l_tk (l_tk d_k) like any other target -- slot nE + nloc, behind the bundle's pivots
+                                if (S.nfold == 1 && ce > cb && S.Li[ce - 1] >= s1)
+                                    lvl.push_back({(uint16_t)(ce - 1 - e0), (uint16_t)(ce - 1 - e0), (uint16_t)(k - s0),
+                                                   (uint16_t)(nE + (s1 - s0))});
                             }
                             std::stable_sort(lvl.begin(), lvl.end(),
                                              [](const std::array<uint16_t, 4> &x, const std::array<uint16_t, 4> &y) { return x[3] < y[3]; });

@@ -1110,7 +1110,18 @@ static int solve_core(chip_kkt *h) {
     }
     h->x_holds_b = false;
     E.enqueue_solve_inplace(h->x);
-    return refine_core(E, h->bp, h->x, h->e, h->dx, h->last_ir);
+    int ok = refine_core(E, h->bp, h->x, h->e, h->dx, h->last_ir);
+    if (ok == 0 && E.sweeps_after_failure()) {
+        // non-finite with persistent sweeps in use: possibly a level barrier that timed out -- once more on the per-level
+        // launches (a genuinely non-finite system fails again, at the price of one more solve)
+        h->last_ir = 0;
+        if ((rc = E.zero_norm_sets())) return rc;
+        CHIP_HIP(hipMemcpyAsync(h->x, h->bp, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, E.stream));
+        dev::norm_inf(E.stream, h->bp, N, E.norm_set(0), E.norm_nan(0));
+        E.enqueue_solve_inplace(h->x);
+        ok = refine_core(E, h->bp, h->x, h->e, h->dx, h->last_ir);
+    }
+    return ok;
 }
 
 // ---- L1 fast path (round 5): registered index sets, device-resident refinement, pinned caller buffers -----------------
@@ -1292,6 +1303,7 @@ int32_t chip_ldl_solve_refined(chip_ldl *h, double *x, const double *b, const ch
     E.enqueue_solve_inplace(h->r_x);
     int its = 0;
     const int ok = refine_core(E, h->r_bp, h->r_x, h->r_e, h->r_w, its);
+    if (ok == 0) (void)E.sweeps_after_failure(); // (stale barrier words must not outlive a failed solve)
     E.st = saved;
     if (iterations) *iterations = its;
     if (ok != 1) return ok;
@@ -1568,6 +1580,7 @@ int32_t chip_kkt_solve2_dev_enqueue(chip_kkt *h, const double *rhsx_a, const dou
     if (oka == 1) dev::getlhs_perm(E.stream, lhsx_a, lhsz_a, h->x, E.iperm, n, m);
     E.swap_ctx();
     const int okb = refine_finish(E, h->bp2, h->x2, h->e2, h->dx2, h->last_ir2);
+    if (oka == 0 || okb == 0) (void)E.sweeps_after_failure(); // (stale barrier words must not outlive a failed solve)
     if (okb == 1) dev::getlhs_perm(E.stream, lhsx_b, lhsz_b, h->x2, E.iperm, n, m);
     const hipError_t se = hipStreamSynchronize(E.stream); // (the second stream: its results are complete when this call returns)
     E.swap_ctx();
@@ -2051,6 +2064,7 @@ int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out
     } else if (k == "g_entries") *out = E.sn_g_entries;
     else if (k == "gsweep_runs") *out = (double)E.gs_runs.size(); // runs of unit levels taken by one persistent launch per sweep (after the first solve)
     else if (k == "gsweep_launches") *out = E.gs_launches;
+    else if (k == "gsweep_recoveries") *out = E.gs_recoveries;
     else if (k == "gsweep_levels") {
         int c = 0;
         for (const auto &r : E.gs_runs) c += r.nlev;

@@ -873,6 +873,16 @@ void Engine::prof_collect() {
     prof_used = 0;
 }
 
+bool Engine::sweeps_after_failure() {
+    if (!gs_ctl || gs_off || gs_launches == 0) return false;
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(gs_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int));
+    if (alt.gs_ctl) (void)hipMemset(alt.gs_ctl, 0, (size_t)dev::ir_ctl_ints() * sizeof(int));
+    (void)hipGetLastError();
+    gs_off = true;
+    gs_recoveries += 1;
+    return true;
+}
 int Engine::ensure_alt() {
     if (alt_ready) return CHIP_OK;
     int rc;
@@ -1342,7 +1352,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         // into the supernodes' launch (snode_g.hip: SweepGather); CHIP_NO_SWEEP_MERGE keeps the two launches per level
         const bool merge = sn_g_ntasks > 0 && !switches().no_sweep_merge;
         auto is_g = [&](int l) { return sn_g_ntasks > 0 && sn_lvl_g[l] && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
-        const bool persist = merge && gs_lv && !switches().no_sweep_persist; // runs of such levels: one persistent launch each
+        const bool persist = merge && gs_lv && !switches().no_sweep_persist && !gs_off; // runs of such levels: one persistent launch each
         bool gathered = false; // level l's gathers already ran inside the previous level's launch
         for (int l = 0; l < nfaclevels; l++) {
             if (!gathered) {

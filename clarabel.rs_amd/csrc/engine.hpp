@@ -125,6 +125,12 @@ struct Engine {
     int *gs_ctl = nullptr; // the grid barrier's counters (per solve context)
     bool gs_built = false;
     int gs_launches = 0; // (tests: persistent launches enqueued so far)
+    // A persistent sweep whose level barrier timed out (a launch that was not co-resident) raises the solve's
+    // non-finite flag and leaves the barrier words dirty.  After a solve that ended non-finite: clear the words of both
+    // solve contexts and keep this handle to the per-level launches (gs_off); true: the caller may repeat the solve.
+    bool gs_off = false;
+    int gs_recoveries = 0; // (tests)
+    bool sweeps_after_failure();
     int build_gsweeps();
     std::vector<i32> sn_lvl_ptr, sn_lvl_nblk, sn_lvl_hmax, sn_lvl_nbmax, h_sn_ptr, h_sn_col;
     // pipelined substitution through wide supernodes (dev::SnodeTriView): one flag per 64-column block

@@ -553,10 +553,11 @@ __device__ __forceinline__ void gs_exit(int *ctl, int gen, int nwg) {
 template <int MODE>
 __global__ __launch_bounds__(SGS_WG) void k_snode_gsweep(LdlView v, SnodeView sv, const int *__restrict__ order_all, double *x,
                                                          double *yt, const GSweepLevel *__restrict__ lv, int nlev, GatherArgs ga,
-                                                         int *ctl, int *fail) {
+                                                         int *ctl, int *fail, int test_drop) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     double *sm = (double *)gsm;
     const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    if (test_drop && bid == G - 1 && G > 1 && nlev > 1) return; // (tests: a launch whose level barrier cannot complete)
     SgFwdPrep pf;
     SgBwdPrep pb;
     pf.active = false;
@@ -687,8 +688,9 @@ void solve_snodes_gsweep(hipStream_t s, GatherMode m, const LdlView &v, const Sn
                          int *fail, const LaunchProf *lp) {
     if (nlev <= 0 || grid <= 0) return;
     if (lp) lp->begin(lp->ctx, PFK_SN_TRI);
-    if (m == FWD) k_snode_gsweep<FWD><<<grid, SGS_WG, lds, s>>>(v, sv, order_all, x, yt, lv, nlev, ga, ctl, fail);
-    else k_snode_gsweep<BWD><<<grid, SGS_WG, lds, s>>>(v, sv, order_all, x, yt, lv, nlev, ga, ctl, fail);
+    const int drop = switches().gs_test_drop ? 1 : 0;
+    if (m == FWD) k_snode_gsweep<FWD><<<grid, SGS_WG, lds, s>>>(v, sv, order_all, x, yt, lv, nlev, ga, ctl, fail, drop);
+    else k_snode_gsweep<BWD><<<grid, SGS_WG, lds, s>>>(v, sv, order_all, x, yt, lv, nlev, ga, ctl, fail, drop);
     if (lp) lp->end(lp->ctx, PFK_SN_TRI);
 }
 

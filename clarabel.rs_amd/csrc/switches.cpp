@@ -80,6 +80,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_SOLVE_PAIR", Entry::FLAG, SW(no_solve_pair), 0},
     {"CHIP_NO_SWEEP_MERGE", Entry::FLAG, SW(no_sweep_merge), 0},
     {"CHIP_NO_SWEEP_PERSIST", Entry::FLAG, SW(no_sweep_persist), 0},
+    {"CHIP_GS_TEST_DROP", Entry::FLAG, SW(gs_test_drop), 0},
     {"CHIP_GSWEEP_GRID", Entry::INT, SW(gsweep_grid), 0},
     {"CHIP_NO_SNODE_G", Entry::FLAG, SW(no_snode_g), 0},
     {"CHIP_SN_G_MAXW", Entry::INT, SW(sn_g_maxw), 0},

@@ -77,6 +77,7 @@ struct Switches {
     bool no_solve_pair = false;     // CHIP_NO_SOLVE_PAIR: chip_kkt_solve2_dev_enqueue runs its two solves one after the other on every handle
     bool no_sweep_merge = false;    // CHIP_NO_SWEEP_MERGE: the row gathers of a unit level in their own launch, also next to supernodes on the one-pass matrices
     bool no_sweep_persist = false;  // CHIP_NO_SWEEP_PERSIST: a launch per unit level on the one-pass matrices, no persistent launch per run of levels (k_snode_gsweep)
+    bool gs_test_drop = false;      // CHIP_GS_TEST_DROP (tests: the last workgroup of a persistent sweep leaves at once, so its level barrier times out)
     int gsweep_grid = 0;            // CHIP_GSWEEP_GRID: workgroups of a persistent sweep (0: half the compute units; tests: 1, 3)
     bool no_snode_g = false;        // CHIP_NO_SNODE_G: no one-pass substitution matrices G = [I; L_B] T^-1 (snode_g.hip): every supernode keeps the pipelined substitution
     int sn_g_maxw = 0;              // CHIP_SN_G_MAXW: widest supernode that takes the G path (0: the kernels' limit, 512)

@@ -1982,6 +1982,39 @@ def test_persistent_sweeps_over_runs_of_unit_levels(hip, oracle, which, grid, mo
         assert relerr(sols[1], sols[0]) <= 1e-10
 
 
+def test_persistent_sweep_timeout_recovers(hip, oracle):
+    """a persistent sweep whose level barrier cannot complete (CHIP_GS_TEST_DROP: the launch behaves as if it were not
+    co-resident) times out, raises the solve's non-finite flag and leaves the barrier words dirty: the solve is repeated
+    on the per-level launches, the words are cleared, and the handle keeps to the per-level launches afterwards -- every
+    later solve is right (round 5's advisor finding: stale words poisoned every later persistent sweep)"""
+    pr = problems.random_qp(12000, 24000, band=30, seed=4)
+    ks, ko = _check_update_and_solve(hip, oracle, pr, nrhs=1)
+    assert hip.debug_counter(ks, "gsweep_launches") > 0 and hip.debug_counter(ks, "gsweep_recoveries") == 0
+    rng = np.random.default_rng(5)
+    try:
+        hip.debug_set_switch("CHIP_GS_TEST_DROP", 1)
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        ks.setrhs(rx, rz)
+        ko.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert ks.solve(x, z)  # (timed out inside, repeated without the persistent launches)
+        ok, xo, zo = ko.solve()
+        assert ok and relerr(np.concatenate([x, z]), np.concatenate([xo, zo])) <= TOL
+        assert hip.debug_counter(ks, "gsweep_recoveries") == 1
+    finally:
+        hip.debug_set_switch("CHIP_GS_TEST_DROP", None)
+    n0 = hip.debug_counter(ks, "gsweep_launches")
+    for _ in range(2):  # later solves: per-level launches only, right answers
+        rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+        ks.setrhs(rx, rz)
+        ko.setrhs(rx, rz)
+        x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+        assert ks.solve(x, z)
+        ok, xo, zo = ko.solve()
+        assert ok and relerr(np.concatenate([x, z]), np.concatenate([xo, zo])) <= TOL
+    assert hip.debug_counter(ks, "gsweep_launches") == n0
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_ldl_structure_fuzz_with_supernodes(hip, oracle, seed):
     """random quasidefinite matrices built to produce all kinds of tops -- banded parts (long chains),

@@ -943,7 +943,8 @@ def main():
                     4: "k_factor_T",
                     5: "%s (one launch = setrhs + %d x (LDL' solve + residual) + refinement decisions + getlhs; "
                        "algorithmic bytes = %d x (B_solve + B_symv))"
-                       % ("k_gstep_solve" if ks.step_kernels() & 1 else "k_bundle_ir", int(ir) + 1, int(ir) + 1),
+                       % ("k_gstep_solve" if ks.step_kernels() & 1 else ("k_bundle_irs" if ks.step_kernels() & 4 else "k_bundle_ir"),
+                          int(ir) + 1, int(ir) + 1),
                     6: "k_bundle_factor (numeric LDL' of all bundle columns)",
                     7: "k_snode_update (left-looking update of a 64-column block of every supernode of a unit level: "
                        "16 x 64 tiles of v_mfma_f64_16x16x4_f64)",
@@ -962,7 +963,8 @@ def main():
             if workload == "c4" and world == 1 and args.nbatch in (128, 256):
                 suffix = "_c4_%d" % args.nbatch
             pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic%s.json" % suffix))) if suffix is not None else []
-            knames = {1: ["k_bundle_symv"], 5: ["k_gstep_solve" if ks.step_kernels() & 1 else "k_bundle_ir"], 6: ["k_bundle_factor"],
+            knames = {1: ["k_bundle_symv"], 5: ["k_gstep_solve" if ks.step_kernels() & 1 else ("k_bundle_irs" if ks.step_kernels() & 4 else "k_bundle_ir")],
+                      6: ["k_bundle_factor"],
                       7: ["k_snode_update"],
                       11: ["k_snode_gsweep", "k_snode_gfwd", "k_snode_gbwd"] if ks.sweep_model()["g_levels"] else ["k_snode_tri"]}.get(fam)
             full_size = (workload == "c3" and args.nblocks == 1000 and args.blocksize == 1000) or workload in ("c2", "c5", "c4")

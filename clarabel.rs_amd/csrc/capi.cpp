@@ -1988,7 +1988,7 @@ int32_t chip_kkt_profile_read(chip_kkt *h, double out[8]) {
 int32_t chip_kkt_step_kernels(const chip_kkt *h) {
     if (!h) return CHIP_ERR_ARG;
     const bool on = !switches().no_step_kernel;
-    return (on && h->E.gstep_solve_on ? 1 : 0) | (on && h->E.gstep_factor_on ? 2 : 0);
+    return (on && h->E.gstep_solve_on ? 1 : 0) | (on && h->E.gstep_factor_on ? 2 : 0) | (h->ir_sf && !(on && h->E.gstep_solve_on) ? 4 : 0);
 }
 int32_t chip_kkt_fused_fallbacks(const chip_kkt *h) { return h ? h->fused_fallbacks : CHIP_ERR_ARG; }
 int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]) {

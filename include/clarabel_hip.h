@@ -409,7 +409,8 @@ int32_t chip_kkt_work_model(const chip_kkt *h, double out[8]);
 int32_t chip_kkt_sweep_model(const chip_kkt *h, double out[4]);
 /* which of the grouped-fold step kernels (csrc/bundle_gstep.hip) this handle uses: bit 0 = the fused solve launch is
  * k_gstep_solve (a bundle's entries of L and K in registers), bit 1 = the refactor's bundle part is k_gstep_factor
- * (bundle columns + Schur shares + the groups' tops in one launch); 0 = neither (diagnostics) */
+ * (bundle columns + Schur shares + the groups' tops in one launch); bit 2 = the fused solve launch is k_bundle_irs (one
+ * bundle per workgroup, the iterates on chip, no permuted copy of b: csrc/bundle_ir.hip); 0 = none of them (diagnostics) */
 int32_t chip_kkt_step_kernels(const chip_kkt *h);
 /* number of fused solve launches (k_bundle_ir) of this handle whose grid barrier timed out -- their workgroups were not
  * all resident because another long-running kernel held the slots -- and that were repeated on the

@@ -28,7 +28,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclarabel_hip.so")
+# (CLARABEL_HIP_LIB: another build of the same ABI -- tests load the library as it ships, libclarabel_hip_ship.so, through it)
+LIB_PATH = os.environ.get("CLARABEL_HIP_LIB") or os.path.join(_HERE, "libclarabel_hip.so")
+SHIP_LIB_PATH = os.path.join(_HERE, "libclarabel_hip_ship.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clarabel_hip.h")
 
 u64 = np.uint64
@@ -105,6 +107,13 @@ def build(verbose=False, testing=True):
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8", "TESTING=%d" % (1 if testing else 0)]
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
     return LIB_PATH
+
+
+def build_ship(verbose=False):
+    """the library as it ships (TESTING=0: no test hooks) beside the test build: libclarabel_hip_ship.so"""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8", "ship"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return SHIP_LIB_PATH
 
 
 def lib():

@@ -139,8 +139,6 @@ struct chip_kkt {
     // every register slot of the chip, and a foreign wave that is resident while it starts leaves the register file
     // fragmented, so that some of its workgroups can never become resident (measured: a one-workgroup kernel of 60 us next
     // to k_gstep_solve made every solve run into its wait budget).  The next fused launch waits for this event on the device.
-    hipEvent_t exch_event = nullptr;
-    bool exch_pending = false;
     double *d_partial = nullptr; // per-block partial minima / sums of the cone reductions
     int partial_cap = 0;
     std::vector<double> h_partial;
@@ -304,9 +302,21 @@ namespace chip {
 int kkt_device(const ::chip_kkt *h) { return h->E.device; }
 hipStream_t kkt_stream(::chip_kkt *h) { return h->E.host_only ? nullptr : h->E.stream; }
 void kkt_set_world(::chip_kkt *h, int world) { h->world = world; }
-void kkt_note_exchange(::chip_kkt *h, hipEvent_t done) {
-    h->exch_event = done;
-    h->exch_pending = done != nullptr;
+// The exchange's completion as an event the HANDLE owns (recorded here on the communicator's stream): a communicator
+// destroyed before the handle's next persistent launch takes nothing the handle waits on with it.
+int kkt_note_exchange(::chip_kkt *h, hipStream_t comm_stream) {
+    Engine &E = h->E;
+    if (!E.exch_event && hipEventCreateWithFlags(&E.exch_event, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        E.exch_event = nullptr;
+        return CHIP_ERR_HIP;
+    }
+    if (hipEventRecord(E.exch_event, comm_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return CHIP_ERR_HIP;
+    }
+    E.exch_pending = true;
+    return CHIP_OK;
 }
 bool kkt_host_only(const ::chip_kkt *h) { return h->E.host_only; }
 } // namespace chip
@@ -1160,24 +1170,28 @@ static int ldl_plain_on_device(chip_ldl *h, int kind, const uint64_t *index, con
     }
     int *dpos = nullptr;
     int8_t *dsg = nullptr;
-    CHIP_HIP(hipMalloc((void **)&dpos, (size_t)k * sizeof(int)));
-    CHIP_HIP(hipMemcpyAsync(dpos, pos.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, E.stream));
     int rc = CHIP_OK;
-    if (kind == 0) {
-        if ((rc = ldl_stage(h, k)) == CHIP_OK) {
-            (void)hipMemcpyAsync(h->d_vals, values, (size_t)k * sizeof(double), hipMemcpyHostToDevice, E.stream);
-            dev::scatter_values(E.stream, E.Kx, dpos, h->d_vals, (int)k, 1.0);
-        }
-    } else if (kind == 1) {
-        dev::scale_values(E.stream, E.Kx, dpos, (int)k, scalar);
-    } else {
-        if (hipMalloc((void **)&dsg, (size_t)k) == hipSuccess) {
-            (void)hipMemcpyAsync(dsg, signs, (size_t)k, hipMemcpyHostToDevice, E.stream);
+    // (every HIP call checked; the two temporaries are released on every path)
+    auto hipok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == CHIP_OK) rc = fail(CHIP_ERR_HIP, hip_err(e, what));
+        return e == hipSuccess;
+    };
+    if (hipok(hipMalloc((void **)&dpos, (size_t)k * sizeof(int)), "values update: index buffer") &&
+        hipok(hipMemcpyAsync(dpos, pos.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, E.stream), "values update: index copy")) {
+        if (kind == 0) {
+            if ((rc = ldl_stage(h, k)) == CHIP_OK &&
+                hipok(hipMemcpyAsync(h->d_vals, values, (size_t)k * sizeof(double), hipMemcpyHostToDevice, E.stream), "values update: value copy"))
+                dev::scatter_values(E.stream, E.Kx, dpos, h->d_vals, (int)k, 1.0);
+        } else if (kind == 1) {
+            dev::scale_values(E.stream, E.Kx, dpos, (int)k, scalar);
+        } else if (hipok(hipMalloc((void **)&dsg, (size_t)k), "values update: sign buffer") &&
+                   hipok(hipMemcpyAsync(dsg, signs, (size_t)k, hipMemcpyHostToDevice, E.stream), "values update: sign copy")) {
             dev::offset_values(E.stream, E.Kx, dpos, dsg, (int)k, scalar);
-        } else rc = CHIP_ERR_HIP;
+        }
+        (void)hipok(hipGetLastError(), "values update: launch");
     }
-    (void)hipStreamSynchronize(E.stream);
-    (void)hipFree(dpos);
+    (void)hipok(hipStreamSynchronize(E.stream), "values update: synchronise");
+    if (dpos) (void)hipFree(dpos);
     if (dsg) (void)hipFree(dsg);
     E.sx_valid = false;
     h->dirty = true;
@@ -1287,7 +1301,11 @@ int32_t chip_ldl_solve_refined(chip_ldl *h, double *x, const double *b, const ch
         E.sx_valid = false;
         h->dirty = false;
     }
-    const chip_settings saved = E.st;
+    struct RestoreSettings { // (every return below leaves the handle with its own refinement settings)
+        Engine &E;
+        chip_settings saved;
+        ~RestoreSettings() { E.st = saved; }
+    } restore{E, E.st};
     if (ir_settings) {
         E.st.iterative_refinement_enable = ir_settings->iterative_refinement_enable;
         E.st.iterative_refinement_reltol = ir_settings->iterative_refinement_reltol;
@@ -1304,7 +1322,6 @@ int32_t chip_ldl_solve_refined(chip_ldl *h, double *x, const double *b, const ch
     int its = 0;
     const int ok = refine_core(E, h->r_bp, h->r_x, h->r_e, h->r_w, its);
     if (ok == 0) (void)E.sweeps_after_failure(); // (stale barrier words must not outlive a failed solve)
-    E.st = saved;
     if (iterations) *iterations = its;
     if (ok != 1) return ok;
     dev::permute_out(E.stream, h->d_x, h->r_x, E.perm, E.N);
@@ -1317,6 +1334,7 @@ int32_t chip_ldl_solve_refined(chip_ldl *h, double *x, const double *b, const ch
 // persistent launch; *slot = where the verdict will appear in the result ring
 static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *slot) {
     Engine &E = h->E;
+    int rc0;
     if (!E.factored) return fail(CHIP_ERR_NOT_FACTORED, "solve() before the first update()");
     const chip_settings &st = E.st;
     *slot = E.ir_next;
@@ -1386,10 +1404,7 @@ static int fused_enqueue(chip_kkt *h, double *lhsx_dev, double *lhsz_dev, int *s
                         overlap(lhsz_dev, m, ir.rz, m));
     }
     h->bp_stale = ir.sf != 0;
-    if (h->exch_pending) { // (see chip_kkt::exch_event: no foreign kernel of ours beside a persistent launch)
-        (void)hipStreamWaitEvent(E.stream, h->exch_event, 0);
-        h->exch_pending = false;
-    }
+    if ((rc0 = E.wait_for_exchange())) return rc0; // (no foreign kernel of ours beside a persistent launch)
     h->fused_args[*slot] = {h->rhs_x, h->rhs_z, lhsx_dev, lhsz_dev};
     h->rhs_deferred = false;
     h->x_holds_b = false;

@@ -46,7 +46,7 @@ int fail_nccl(ncclResult_t r, const char *what) {
 namespace chip {
 hipStream_t kkt_stream(::chip_kkt *h);      // capi.cpp
 void kkt_set_world(::chip_kkt *h, int world);
-void kkt_note_exchange(::chip_kkt *h, hipEvent_t done);
+int kkt_note_exchange(::chip_kkt *h, hipStream_t comm_stream);
 } // namespace chip
 
 extern "C" {
@@ -148,8 +148,7 @@ int32_t chip_kkt_allgather_step(chip_kkt *h, chip_comm *c, const double *send_de
     CHIP_HIP(hipEventRecord(c->ev_done, c->stream));
     // the handle's next PERSISTENT solve launch waits for the exchange on the device (capi.cpp: chip_kkt::exch_event); the
     // cone update and the factorisation enqueued before it run beside the collective's kernels
-    chip::kkt_note_exchange(h, c->ev_done);
-    return CHIP_OK;
+    return chip::kkt_note_exchange(h, c->stream);
 }
 
 #ifdef CHIP_TESTING

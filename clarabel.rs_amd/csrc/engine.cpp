@@ -26,6 +26,7 @@ Engine::~Engine() {
     if (alt.nrm_host) (void)hipHostFree(alt.nrm_host);
     if (alt.stream) (void)hipStreamDestroy(alt.stream);
     if (pair_event) (void)hipEventDestroy(pair_event);
+    if (exch_event) (void)hipEventDestroy(exch_event);
     if (snb_ready) (void)hipEventDestroy(snb_ready);
     for (hipEvent_t ev : snb_events)
         if (ev) (void)hipEventDestroy(ev);
@@ -167,6 +168,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     h_k2v = S.k2v;
     h_v2k = S.v2k;
     nfill = (int)S.fill_idx.size();
+    fill_from = S.fill_from;
     if ((rc = upload(&fill_idx, S.fill_idx, S.fill_idx.size()))) return rc;
     if ((rc = upload(&Lp, S.Lp, n + 1))) return rc;
     if ((rc = upload(&Li, S.Li, (size_t)nnzL))) return rc;
@@ -397,7 +399,14 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                     }
                 }
             }
-            if (total > (1ll << 31)) { // (16 GB of G: keep the pipelined substitution)
+            size_t mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) {
+                (void)hipGetLastError();
+                mem_free = 0;
+            }
+            // (16 GB of G, or more than a third of what is free on the device -- a second solve context and the vectors
+            // still have to fit: keep the pipelined substitution)
+            if (total > (1ll << 31) || (mem_free > 0 && (unsigned long long)total * sizeof(double) > mem_free / 3)) {
                 std::fill(sn_lvl_g.begin(), sn_lvl_g.end(), 0);
                 std::fill(goff.begin(), goff.end(), -1);
                 tasks.clear();
@@ -431,7 +440,19 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                     }
                     CHIP_HIP(hipMemcpy(sn_order, rec.data(), rec.size() * sizeof(i32), hipMemcpyHostToDevice));
                 }
-                if ((rc = alloc(&sn_Gx, (size_t)total + 8))) return rc;
+                if (alloc(&sn_Gx, (size_t)total + 8) != CHIP_OK) {
+                    // no room for G after all: the handle works without it (pipelined substitution everywhere)
+                    (void)hipGetLastError();
+                    sn_Gx = nullptr;
+                    std::fill(sn_lvl_g.begin(), sn_lvl_g.end(), 0);
+                    sn_g_ntasks = 0;
+                    std::vector<i32> rec(S.sn_order.size() * 8 + 8, 0);
+                    CHIP_HIP(hipMemcpy(rec.data(), sn_order, rec.size() * sizeof(i32), hipMemcpyDeviceToHost));
+                    for (size_t k = 0; k < S.sn_order.size(); k++) rec[8 * k + 6] = rec[8 * k + 7] = -1;
+                    CHIP_HIP(hipMemcpy(sn_order, rec.data(), rec.size() * sizeof(i32), hipMemcpyHostToDevice));
+                    total = 0;
+                }
+                if (total > 0) {
                 CHIP_HIP(hipMemset(sn_Gx, 0, ((size_t)total + 8) * sizeof(double))); // (entries above a row's diagonal block are never written)
                 if ((rc = alloc(&sn_yt, n))) return rc;
                 CHIP_HIP(hipMemset(sn_yt, 0, n * sizeof(double)));
@@ -442,6 +463,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                     set_error("k_snode_ginv: dynamic LDS size rejected");
                     return CHIP_ERR_HIP;
                 }
+                } // (G allocated)
             }
         }
     }
@@ -773,7 +795,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     CHIP_HIP(hipMemset(dslot_dev, 0, (size_t)2 * NRM_SET_WORDS * sizeof(unsigned long long)));
     // fast preparation (refactor_enqueue): the grouped-fold step factorisation, or an arrow with ONE top column whose
     // only top-top entry of K is its diagonal, factored by the flat bundle kernel
-    fast_prep_ok = gstep_factor_on || (ir_fused && fold.k == 1 && factor_lds_doubles > 0 && fu_rec != nullptr && nfill == 0 &&
+    fast_prep_ok = gstep_factor_on || (ir_fused && fold.k == 1 && factor_lds_doubles > 0 && fu_rec != nullptr && nfill == 0 && fill_from < 0 &&
                                        nnzK - nnzU == 1 && nsn == 0);
     if (fast_prep_ok && fold.k == 1) {
         if ((rc = alloc(&fold_cnt, (size_t)32))) return rc;
@@ -883,11 +905,36 @@ bool Engine::sweeps_after_failure() {
     gs_recoveries += 1;
     return true;
 }
+// a device-side wait that cannot be enqueued becomes a host-side one: the chain of block columns must not read member
+// columns while the second stream still adds into them
+static void wait_event_or_sync(hipStream_t s, hipEvent_t ev) {
+    if (hipStreamWaitEvent(s, ev, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipEventSynchronize(ev);
+    }
+}
+int Engine::wait_for_exchange() {
+    if (!exch_pending) return CHIP_OK;
+    exch_pending = false;
+    if (hipStreamWaitEvent(stream, exch_event, 0) != hipSuccess) { // (fall back to the host: the exchange must be over)
+        (void)hipGetLastError();
+        CHIP_HIP(hipEventSynchronize(exch_event));
+    }
+    return CHIP_OK;
+}
+// (restartable: the stream and the event are created once; a failed set-up is remembered and not repeated on every
+// refactor -- the buffers it did allocate stay with the handle's allocation list)
 int Engine::ensure_alt() {
     if (alt_ready) return CHIP_OK;
+    if (alt_failed) return CHIP_ERR_HIP;
+    const int rc_all = ensure_alt_once();
+    if (rc_all != CHIP_OK) alt_failed = true;
+    return rc_all;
+}
+int Engine::ensure_alt_once() {
     int rc;
-    CHIP_HIP(hipStreamCreateWithFlags(&alt.stream, hipStreamNonBlocking));
-    CHIP_HIP(hipEventCreateWithFlags(&pair_event, hipEventDisableTiming));
+    if (!alt.stream) CHIP_HIP(hipStreamCreateWithFlags(&alt.stream, hipStreamNonBlocking));
+    if (!pair_event) CHIP_HIP(hipEventCreateWithFlags(&pair_event, hipEventDisableTiming));
     const size_t n = (size_t)N;
     if (sn_yt) {
         if ((rc = alloc(&alt.sn_yt, n))) return rc;
@@ -1098,6 +1145,8 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     v.eps_ptr = eps_ptr;
     // entries with both ends in the top -> the top columns of L / D; clears the status words.  The bundle
     // columns take their initial values straight from the U rows inside k_bundle_factor.
+    if (!fast && fill_from >= 0 && (long long)nnzL > fill_from)
+        CHIP_HIP(hipMemsetAsync(Lx + fill_from, 0, (size_t)((long long)nnzL - fill_from) * sizeof(double), stream));
     if (!fast)
         dev::scatter_init(stream, Kx + nnzU, v2l, (int)(nnzK - nnzU), (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                           mb_dev->status);
@@ -1192,7 +1241,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         if (!has_sn(l)) return;
         if (snb_beside)
             for (; snb_waited < snb_groups.size() && snb_groups[snb_waited].first <= l; snb_waited++)
-                (void)hipStreamWaitEvent(stream, snb_events[snb_waited], 0);
+                wait_event_or_sync(stream, snb_events[snb_waited]);
         dev::factor_B(stream, vf, snx.B(l));
         const int count = sn_lvl_ptr[l + 1] - sn_lvl_ptr[l];
         dev::SnodeAsmView av{asm_tgt, asm_src_ptr, asm_src, 0, 0};
@@ -1258,7 +1307,7 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
         l++;
     }
     if (snb_beside)
-        for (; snb_waited < snb_groups.size(); snb_waited++) (void)hipStreamWaitEvent(stream, snb_events[snb_waited], 0);
+        for (; snb_waited < snb_groups.size(); snb_waited++) wait_event_or_sync(stream, snb_events[snb_waited]);
     if (nsn > 0) dev::gather_values(stream, Rfx, Lx, Rf_pos, nRf); // L at the filtered row lists (forward sweep)
     if (sn_g_ntasks > 0) { // the substitution matrices of the supernodes of moderate width, all of them in one launch
         dev::SnodeView sg = snode_view();
@@ -1353,6 +1402,7 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
         const bool merge = sn_g_ntasks > 0 && !switches().no_sweep_merge;
         auto is_g = [&](int l) { return sn_g_ntasks > 0 && sn_lvl_g[l] && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
         const bool persist = merge && gs_lv && !switches().no_sweep_persist && !gs_off; // runs of such levels: one persistent launch each
+        if (persist && exch_pending) (void)wait_for_exchange(); // (a persistent sweep beside the collective's kernels may not be co-resident)
         bool gathered = false; // level l's gathers already ran inside the previous level's launch
         for (int l = 0; l < nfaclevels; l++) {
             if (!gathered) {

@@ -150,6 +150,7 @@ struct Engine {
     unsigned long long *nrm_dev = nullptr, *nrm_host = nullptr; // NRM_SETS slotted inf-norm accumulators
     int *fill_idx = nullptr;
     int nfill = 0;
+    long long fill_from = -1; // >= 0: Lx[fill_from .. nnzL) is cleared as a range before K's entries are scattered (host.hpp)
     std::vector<i32> h_perm, h_lvlptr, h_etree;
     bool host_only = false;          // CHIP_DEVICE_HOST_ONLY: symbolic results only
     std::vector<i32> h_Lp;           // kept only for host-only handles
@@ -259,9 +260,16 @@ struct Engine {
     };
     SolveCtx alt;
     bool alt_ready = false, alt_active = false;
+    bool alt_failed = false; // the second solve context could not be set up once: not tried again
+    // the exchange of the sharded path (comm.cpp) as an event of this handle: a persistent launch (the fused solve, the
+    // persistent sweeps) needs every workgroup co-resident and must not start beside the collective's kernels
+    hipEvent_t exch_event = nullptr;
+    bool exch_pending = false;
+    int wait_for_exchange();
     hipEvent_t pair_event = nullptr;
     bool pair_ok() const { return !ir_fused && fold.k == 0 && gfold.ng == 0 && topblk.nblocks == 0; } // (no shared accumulators)
     int ensure_alt();
+    int ensure_alt_once();
     void swap_ctx();
     // makes the second stream wait for everything enqueued on the first one so far (the refactor), after the value mirrors a
     // solve reads lazily (Rx, Sx) have been refreshed on the first stream

@@ -85,6 +85,9 @@ struct Symbolic {
     std::vector<i32> Vp;
     // slots of L in TOP columns (CSC positions) that no entry of K maps to: structural fill-in
     std::vector<i32> fill_idx;
+    // ... or, when most of the top's slots are fill-in (the dense trapezoids of chain supernodes: config 5 has 3.9e8 such
+    // slots, 1.6 GB of indices), no list at all: the whole range [fill_from, nnz(L)) is cleared before K's entries land
+    i64 fill_from = -1;
     // L, CSC with ascending rows (structure only; values live on the device)
     std::vector<i32> Lp;
     bigvec Li;

@@ -101,7 +101,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
     };
     const bool dbgme = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
     sn_stamp(sv.dbg, dbgme, 16);
-    __syncthreads(); // (the caller has just filled colbase)
+    lds_barrier(); // (the caller has just filled colbase; LDS only: see dev_common.hpp)
     sn_stamp(sv.dbg, dbgme, 17, true);
     if (wave_live && kbeg < kend) {
 #pragma unroll
@@ -110,7 +110,8 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
     for (int kc0 = kbeg; kc0 < kend; kc0 += SN_KC) {
         const int kcn = min(SN_KC, kend - kc0);
         const int kcnu = (kcn + 4 * SN_U - 1) / (4 * SN_U) * (4 * SN_U); // whole groups: the tail rows of the operand are zeros
-        __syncthreads(); // the previous chunk has been consumed
+        lds_barrier(); // the previous chunk has been consumed (the A operands requested for this chunk stay in flight:
+                       // __syncthreads() would wait for them here, one exposed round trip per chunk)
         // the (d_k L[j,k]) operand: a wave stages whole k rows -- lane = column of the block --, SN_WST rows in
         // flight; the column base is a wave-uniform LDS read and the pivot a wave-uniform load from the packed
         // pivots (SnodeView::sn_d), issued together with the entry it scales: ONE global round trip per batch
@@ -129,7 +130,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
                 if (kk < kcnu) Wl[kk * SN_NB + lane] = (kk < kcn && lane < ncols) ? wv[r] * dv[r] : 0.0;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (kc0 == kbeg) sn_stamp(sv.dbg, dbgme, 18);
         if (!wave_live) continue; // (after the barriers: the whole wave is beyond the panel)
         for (int kk = 0; kk < kcnu; kk += 4 * SN_U) {
@@ -151,7 +152,7 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
     // ---- emit through LDS: this wave's 16 x 64 tile in its own 8 KiB of the (now free) operand buffer, element
     //      (row rr, column jj) at jj * 16 + (rr ^ (jj & 15)) -- the swizzle keeps both the column-per-lane writes
     //      and the row-per-lane reads off common banks
-    __syncthreads();
+    lds_barrier();
     if (i0[0] >= g.h) return;
     double *Tw = Wl + wave * (16 * SN_NB);
     const int *Bn = v.Li + v.Lp[g.e]; // node ids of the rows of B

@@ -968,7 +968,21 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
                 return -9;
             }
         // fill slots of the TOP columns (the bundle kernels zero their own while they merge the U rows)
+        i64 nuncovered = 0;
         {
+            const int Tc = par_threads(nnzL - q0);
+            std::vector<i64> cnt((size_t)Tc, 0);
+            run_threads(Tc, [&](int t, int TT) {
+                const i64 span = nnzL - q0;
+                i64 c = 0;
+                for (i64 q = q0 + span * t / TT; q < q0 + span * (t + 1) / TT; q++) c += covered[(size_t)(q - q0)] ? 0 : 1;
+                cnt[(size_t)t] = c;
+            });
+            for (int t = 0; t < Tc; t++) nuncovered += cnt[(size_t)t];
+        }
+        if (nuncovered * 2 > nnzL - q0 && nuncovered > (i64)1 << 20) {
+            S.fill_from = q0; // (mostly fill-in: the range is cleared as a whole, no index list)
+        } else {
             const int Tf = par_threads(nnzL - q0);
             std::vector<std::vector<i32>> parts((size_t)Tf);
             run_threads(Tf, [&](int t, int TT) {

@@ -155,3 +155,65 @@ def test_bench_sharded_code_path_with_file_comm(hip):
     assert par["ok"] and par["rel_err_vs_oracle"] <= 1e-8
     assert par["gathered_vs_local"]["own_slice_bit_equal_on_every_rank"]
     assert par["gathered_vs_local"]["max_abs_diff_of_segment_checksums"] == 0.0
+
+
+def test_sharded_scalars_of_an_iteration_through_allreduce(hip):
+    """The only numbers of an interior-point iteration that cross ranks when a block-diagonal problem is sharded by whole
+    blocks: the two sums of the step in tau (default/kktsystem.rs:175-186: q'x1 + b'z1 + 2 xi'P x1, and
+    q'x2 + b'z2 - |xi - x2|_P^2 + |x2|_P^2) and the step length, a minimum over the cones (compositecone.rs:300-340).
+    Two shards of a four-block QP are solved by their own handles; every shard's partial sums go through
+    chip_comm_allreduce (a 1-rank communicator: RCCL refuses two ranks on one device -- the call sequence and the
+    reduction operators are what is pinned, the second rank's contribution is added on the host as the collective
+    would) and the results are compared with the unsharded problem's."""
+    import scipy.sparse as sp
+    parts = [problems.random_qp(300, 600, band=10, seed=40 + i) for i in range(4)]
+    whole = problems.blockdiag(parts)
+    shards = [problems.blockdiag(parts[:2]), problems.blockdiag(parts[2:])]
+    rng = np.random.default_rng(11)
+    n, m = whole["n"], whole["m"]
+    q, b = rng.standard_normal(n), rng.standard_normal(m)
+    rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+    xvar, tau, kappa, rtau, rkappa = rng.standard_normal(n), 1.3, 0.7, 0.4, -0.2
+    dz_, ds_ = rng.standard_normal(m), rng.standard_normal(m)
+
+    def Pfull(pr):
+        Pu = sp.csc_matrix((pr["P"][2], pr["P"][1], pr["P"][0]), shape=(pr["n"], pr["n"]))
+        return Pu + sp.triu(Pu, 1).T
+
+    def shard_values(pr, sl_n, sl_m):
+        """one shard: the two solves, its partial sums and its step length"""
+        ks = hip.HipKKTSolver(hip.CscMatrix(pr["n"], pr["n"], *pr["P"]), hip.CscMatrix(pr["m"], pr["n"], *pr["A"]),
+                              pr["cones"], pr["m"], pr["n"])
+        assert ks.update_scaling(pr["s"], pr["z"]) and ks.update()
+        sols = []
+        for fx, fz in ((rx[sl_n], rz[sl_m]), (-q[sl_n], b[sl_m])):  # (x1, z1) and the constant part (x2, z2), :108-125
+            ks.setrhs(fx, fz)
+            x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+            assert ks.solve(x, z)
+            sols.append((x, z))
+        (x1, z1), (x2, z2) = sols
+        P = Pfull(pr)
+        xi = xvar[sl_n] / tau
+        num = q[sl_n] @ x1 + b[sl_m] @ z1 + 2.0 * (xi @ (P @ x1))
+        den = -(q[sl_n] @ x2) - (b[sl_m] @ z2) + (xi - x2) @ (P @ (xi - x2)) - x2 @ (P @ x2)
+        D = hip.DeviceArray
+        d_dz, d_ds, d_z, d_s = D(dz_[sl_m]), D(ds_[sl_m]), D(pr["z"]), D(pr["s"])  # (kept alive across the call)
+        alpha = ks.step_length_dev(d_dz.ptr, d_ds.ptr, d_z.ptr, d_s.ptr, 1.0)
+        return np.array([num, den]), alpha, np.concatenate([x1, z1])
+
+    truth_sums, truth_alpha, truth_sol = shard_values(whole, slice(0, n), slice(0, m))
+    comm = hip.Comm(hip.comm_unique_id(), 1, 0)
+    sums, alpha, off_n, off_m, sols = np.zeros(2), np.inf, 0, 0, []
+    for pr in shards:
+        part, a, sol = shard_values(pr, slice(off_n, off_n + pr["n"]), slice(off_m, off_m + pr["m"]))
+        sums += np.asarray(comm.allreduce(part.tolist(), "sum"))   # this rank's share through the collective
+        alpha = min(alpha, comm.allreduce([a], "min")[0])
+        sols.append((sol[:pr["n"]], sol[pr["n"]:]))
+        off_n += pr["n"]
+        off_m += pr["m"]
+    dtau = (rtau - rkappa / tau + sums[0]) / (kappa / tau + sums[1])
+    dtau_truth = (rtau - rkappa / tau + truth_sums[0]) / (kappa / tau + truth_sums[1])
+    assert abs(dtau - dtau_truth) <= 1e-9 * max(1.0, abs(dtau_truth))
+    assert abs(alpha - truth_alpha) <= 1e-12 * max(1.0, abs(truth_alpha))
+    gathered = np.concatenate([s_[0] for s_ in sols] + [s_[1] for s_ in sols])  # (the all-gathered step direction)
+    assert np.max(np.abs(gathered - truth_sol)) <= 1e-8 * max(1.0, np.max(np.abs(truth_sol)))

@@ -23,6 +23,42 @@ def test_abi_exports_every_declared_symbol(hip):
             assert hasattr(L, s), s
 
 
+def test_shipped_library_exports_the_abi_and_no_test_hooks(hip):
+    """the library as it ships (make ship: TESTING=0, libclarabel_hip_ship.so): every symbol of include/clarabel_hip.h,
+    none of include/clarabel_hip_testing.h, and a call that needs no GPU (chip_settings_default) answers like the test
+    build's"""
+    import ctypes as C
+    path = hip.SHIP_LIB_PATH
+    assert os.path.exists(path), "run __graft_entry__.build() (make ship)"
+    L = C.CDLL(path)
+
+    def syms(name):
+        hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", name)).read(), flags=re.S)
+        return sorted(set(re.findall(r"\b(chip_[a-z_A-Z0-9]+)\s*\(", hdr)))
+    for s_ in syms("clarabel_hip.h"):
+        assert hasattr(L, s_), s_
+    for s_ in syms("clarabel_hip_testing.h"):
+        assert not hasattr(L, s_), "test hook %s in the shipped library" % s_
+    a, b = hip.Settings(), hip.Settings()
+    L.chip_settings_default(C.byref(a))
+    hip.lib().chip_settings_default(C.byref(b))
+    assert bytes(a) == bytes(b)
+
+
+@pytest.mark.gpu
+def test_shipped_library_runs_the_smoke_problem():
+    """one small KKT update + solve on cuda:0 THROUGH the shipped library (a fresh interpreter with CLARABEL_HIP_LIB set),
+    checked against the oracle like __graft_entry__.smoke()"""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import __graft_entry__ as g; pkg = g.load_package(); "
+            "assert pkg.LIB_PATH.endswith('libclarabel_hip_ship.so'); assert not hasattr(pkg.lib(), 'chip_debug_set_switch'); "
+            "g.smoke(); print('ship smoke ok')") % ROOT
+    env = dict(os.environ, CLARABEL_HIP_LIB=os.path.join(ROOT, "clarabel.rs_amd", "libclarabel_hip_ship.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ship smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_switches_are_parsed_once_and_settable_by_name(hip, monkeypatch):
     """the CHIP_* diagnostic switches: read from the environment when a handle is created (csrc/switches.hpp), set or
     cleared by name through the test hook, unknown names refused; no launch loop calls getenv"""

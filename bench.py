@@ -212,6 +212,7 @@ class Workload:
             self.events_pass = {"steps": steps, "ms_per_step_with_events": round(1e3 * (time.perf_counter() - t1) / steps, 4)}
         prof = self.ks.profile_read()
         self.ks.profile(0)
+        self.own_elapsed = elapsed  # (this rank's clock; the line's value uses the maximum over the ranks)
         if comm is not None:
             elapsed = float(comm.allreduce([elapsed], "max")[0])
         return elapsed, prof
@@ -893,6 +894,36 @@ def main():
                         "value": round(args.steps / el2, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * el2 / args.steps, 4)}
         w.gather_every_solve = not w.gather_every_solve
 
+    # ---- every rank's own figures on the line (N > 1, or the one-rank rehearsal): its ms per step on its own clock, the
+    #      solves it had to repeat, its fall-backs, and what ONE exchange costs when nothing else runs -- so that the first
+    #      real run on several GPUs can be read: a slow rank, a rank whose persistent launches lost co-residency, or the
+    #      collective itself
+    per_rank = None
+    if comm is not None:
+        last = len(w.rhs) - 1
+        w.ks.synchronize()
+        comm.synchronize()
+        comm.barrier()
+        reps = 20
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            comm.wait(w.ks)
+            comm.allgather_step(w.ks, w.lhs[last].ptr, gathered[last].ptr, counts)
+        comm.synchronize()
+        w.ks.synchronize()
+        exch_us = 1e6 * (time.perf_counter() - t1) / reps
+        mine = np.zeros(4 * world)
+        mine[4 * rank:4 * rank + 4] = [1e3 * w.own_elapsed / args.steps, float(w.repeats), float(w.ks.fused_fallbacks()), exch_us]
+        allv = np.asarray(comm.allreduce(mine.tolist(), "sum")).reshape(world, 4)
+        per_rank = {"ms_per_step": [round(float(v), 4) for v in allv[:, 0]],
+                    "fused_launch_repeats": [int(v) for v in allv[:, 1]],
+                    "fused_fallbacks": [int(v) for v in allv[:, 2]],
+                    "exchange_alone_us": [round(float(v), 1) for v in allv[:, 3]],
+                    "what": "per rank, in rank order: ms per step on the rank's own clock (value uses the maximum), solves "
+                            "repeated after a fused launch lost co-residency, solves that fell back to the per-phase path, and the "
+                            "all-gather of the step direction alone (%d back-to-back exchanges of %d doubles, host clock)"
+                            % (reps, int(sum(counts)))}
+
     # ---- N > 1: every rank checks ITS shard against the oracle; the ranks reduce the verdict ----------------
     parity_sharded = None
     if world > 1 and not args.no_extras:
@@ -1085,6 +1116,7 @@ def main():
             "c2": extras.get("c2"), "c5": extras.get("c5"), "l1_dropin": extras.get("l1_dropin"),
             "other_exchange_policy": other_policy,
             "fused_launch_repeats": int(w_repeats),
+            "per_rank": per_rank,
             "rehearsal": None if not args.coresident else {
                 "what": "one rank of the sharded run rehearsed on one GPU: the exchange path with a one-rank RCCL communicator "
                         "(the all-gather enqueued every step behind the last solve, overlapping the next step) plus a co-resident "

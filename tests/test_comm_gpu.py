@@ -155,6 +155,9 @@ def test_bench_sharded_code_path_with_file_comm(hip):
     assert par["ok"] and par["rel_err_vs_oracle"] <= 1e-8
     assert par["gathered_vs_local"]["own_slice_bit_equal_on_every_rank"]
     assert par["gathered_vs_local"]["max_abs_diff_of_segment_checksums"] == 0.0
+    pr_ = line["per_rank"]  # (every rank's own clock, repeats, fall-backs and the exchange alone: what a real N > 1 run is read by)
+    assert len(pr_["ms_per_step"]) == 2 and all(v > 0 for v in pr_["ms_per_step"]) and all(v > 0 for v in pr_["exchange_alone_us"])
+    assert pr_["fused_launch_repeats"] == [0, 0] and max(pr_["ms_per_step"]) <= line["ms_per_step"] * 1.0001
 
 
 def test_sharded_scalars_of_an_iteration_through_allreduce(hip):

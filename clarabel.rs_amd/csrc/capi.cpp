@@ -1577,6 +1577,37 @@ int32_t chip_kkt_solve2_dev_enqueue(chip_kkt *h, const double *rhsx_a, const dou
     h->x_holds_b = false;
     h->bp_stale = false;
     // ---- both chains enqueued: A on the engine's stream, B on the second one
+    if (E.pair_lockstep_ok()) {
+        // (wide chain supernodes with a form for two right-hand sides: the two chains walk the levels together, the wide
+        // levels as ONE launch that streams the panels for both vectors -- Engine::enqueue_solve_pair)
+        if ((rc = E.zero_norm_sets())) return rc;
+        dev::setrhs_perm(E.stream, h->bp, h->x, rhsx_a, rhsz_a, E.perm, n, m, E.N, E.norm_set(0), E.norm_nan(0));
+        E.swap_ctx();
+        rc = E.zero_norm_sets();
+        if (!rc) dev::setrhs_perm(E.stream, h->bp2, h->x2, rhsx_b, rhsz_b, E.perm, n, m, E.N, E.norm_set(0), E.norm_nan(0));
+        E.swap_ctx();
+        if (rc) return rc;
+        E.enqueue_solve_pair(h->x, nullptr, h->x2, nullptr);
+        const chip_settings &st = E.st;
+        if (!st.iterative_refinement_enable) {
+            dev::norm_inf(E.stream, h->x, E.N, E.norm_set(1), E.norm_nan(1));
+            E.swap_ctx();
+            dev::norm_inf(E.stream, h->x2, E.N, E.norm_set(1), E.norm_nan(1));
+            E.swap_ctx();
+        } else { // (refine_begin for both: the residuals, then the first round enqueued ahead of its decision)
+            E.enqueue_residual(h->e, h->bp, h->x, 1);
+            E.swap_ctx();
+            E.enqueue_residual(h->e2, h->bp2, h->x2, 1);
+            E.swap_ctx();
+            if (st.iterative_refinement_max_iter >= 1) {
+                E.enqueue_solve_pair(h->e, h->x, h->e2, h->x2);
+                E.enqueue_residual(h->dx, h->bp, h->e, 2);
+                E.swap_ctx();
+                E.enqueue_residual(h->dx2, h->bp2, h->e2, 2);
+                E.swap_ctx();
+            }
+        }
+    } else {
     if ((rc = E.zero_norm_sets())) return rc;
     dev::setrhs_perm(E.stream, h->bp, h->x, rhsx_a, rhsz_a, E.perm, n, m, E.N, E.norm_set(0), E.norm_nan(0));
     E.enqueue_solve_inplace(h->x);
@@ -1590,6 +1621,7 @@ int32_t chip_kkt_solve2_dev_enqueue(chip_kkt *h, const double *rhsx_a, const dou
     }
     E.swap_ctx();
     if (rc) return rc;
+    }
     // ---- decisions (and any further rounds) of A, then of B
     const int oka = refine_finish(E, h->bp, h->x, h->e, h->dx, h->last_ir);
     if (oka == 1) dev::getlhs_perm(E.stream, lhsx_a, lhsz_a, h->x, E.iperm, n, m);
@@ -2080,6 +2112,7 @@ int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out
     else if (k == "gsweep_runs") *out = (double)E.gs_runs.size(); // runs of unit levels taken by one persistent launch per sweep (after the first solve)
     else if (k == "gsweep_launches") *out = E.gs_launches;
     else if (k == "gsweep_recoveries") *out = E.gs_recoveries;
+    else if (k == "tri2_launches") *out = E.tri2_launches;
     else if (k == "gsweep_levels") {
         int c = 0;
         for (const auto &r : E.gs_runs) c += r.nlev;

@@ -26,6 +26,8 @@ Engine::~Engine() {
     if (alt.nrm_host) (void)hipHostFree(alt.nrm_host);
     if (alt.stream) (void)hipStreamDestroy(alt.stream);
     if (pair_event) (void)hipEventDestroy(pair_event);
+    if (pair_ev_a) (void)hipEventDestroy(pair_ev_a);
+    if (pair_ev_b) (void)hipEventDestroy(pair_ev_b);
     if (exch_event) (void)hipEventDestroy(exch_event);
     if (snb_ready) (void)hipEventDestroy(snb_ready);
     for (hipEvent_t ev : snb_events)
@@ -935,6 +937,8 @@ int Engine::ensure_alt_once() {
     int rc;
     if (!alt.stream) CHIP_HIP(hipStreamCreateWithFlags(&alt.stream, hipStreamNonBlocking));
     if (!pair_event) CHIP_HIP(hipEventCreateWithFlags(&pair_event, hipEventDisableTiming));
+    if (!pair_ev_a) CHIP_HIP(hipEventCreateWithFlags(&pair_ev_a, hipEventDisableTiming));
+    if (!pair_ev_b) CHIP_HIP(hipEventCreateWithFlags(&pair_ev_b, hipEventDisableTiming));
     const size_t n = (size_t)N;
     if (sn_yt) {
         if ((rc = alloc(&alt.sn_yt, n))) return rc;
@@ -1374,6 +1378,157 @@ void Engine::enqueue_solve_inplace(double *xp, const double *addv) {
         }
     }
     enqueue_solve_direct(xp, addv);
+}
+bool Engine::pair_lockstep_ok() {
+    if (nsn <= 0 || fold.k || st.use_graph || switches().no_snode_tri || switches().no_pair_lockstep || prof_family != PF_NONE ||
+        !sn_flags || !alt.sn_flags)
+        return false;
+    for (int l = 0; l < nfaclevels; l++) {
+        const bool g = sn_g_ntasks > 0 && sn_lvl_g[l];
+        if (sn_lvl_ptr[l + 1] > sn_lvl_ptr[l] && !g && sn_lvl_nblk[l] * 64 > 2 * 64) return true; // (a level k_snode_tri takes)
+    }
+    return false;
+}
+void Engine::enqueue_solve_pair(double *xa, const double *addva, double *xb, const double *addvb) {
+    if (!pair_lockstep_ok()) {
+        enqueue_solve_inplace(xa, addva);
+        swap_ctx();
+        enqueue_solve_inplace(xb, addvb);
+        swap_ctx();
+        return;
+    }
+    if (!gs_built && nsn > 0) (void)build_gsweeps();
+    if (!rx_valid && rx_needed()) {
+        dev::gather_values(stream, Rx, Lx, Rpos, (int)nnzR);
+        rx_valid = true;
+    }
+    // The level loop of enqueue_solve_direct's supernode branch, once, for both contexts: `each` runs a stage for A on
+    // A's stream, swaps the contexts (stream, scratch vectors, barrier words, message buffers), runs it for B, swaps back.
+    double *xs[2] = {xa, xb};
+    const double *addvs[2] = {addva, addvb};
+    int ctx = 0;
+    auto each = [&](auto &&fn) {
+        ctx = 0;
+        fn(xs[0], addvs[0]);
+        swap_ctx();
+        ctx = 1;
+        fn(xs[1], addvs[1]);
+        swap_ctx();
+        ctx = 0;
+    };
+    hipStream_t sA = stream, sB = alt.stream;
+    const dev::LdlView v = view();
+    const dev::SnodeView sview = snode_view();
+    each([&](double *x, const double *) { dev::bundle_fwd(stream, v, bundles, x, fold); });
+    const bool merge = sn_g_ntasks > 0 && !switches().no_sweep_merge;
+    auto is_g = [&](int l) { return sn_g_ntasks > 0 && sn_lvl_g[l] && sn_lvl_ptr[l + 1] > sn_lvl_ptr[l]; };
+    const bool persist = merge && gs_lv && !switches().no_sweep_persist && !gs_off;
+    if (persist && exch_pending) (void)wait_for_exchange();
+    int epoch = ++sn_epoch;
+    // the wide levels: B's stream hands its vector over (event), A's stream runs the launch for both, B's stream waits for it
+    auto tri_level = [&](dev::GatherMode m, int l) {
+        dev::SnodeTriView ta{sn_blk_ptr, sn_flags, epoch, norm_nan(1)};
+        swap_ctx();
+        dev::SnodeTriView tb{sn_blk_ptr, sn_flags, epoch, norm_nan(1)};
+        swap_ctx();
+        (void)hipEventRecord(pair_ev_b, sB);
+        if (hipStreamWaitEvent(sA, pair_ev_b, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipEventSynchronize(pair_ev_b);
+        }
+        dev::solve_snodes(sA, m, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l], sn_wmax, sn_nbmax,
+                          sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], xs[0], &ta, nullptr, xs[1], &tb);
+        tri2_launches++;
+        (void)hipEventRecord(pair_ev_a, sA);
+        if (hipStreamWaitEvent(sB, pair_ev_a, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipEventSynchronize(pair_ev_a);
+        }
+    };
+    bool gathered = false;
+    for (int l = 0; l < nfaclevels; l++) {
+        if (!gathered)
+            each([&](double *x, const double *) {
+                dev::GatherArgs f{Rf_p, Rf_col, Rfx, x, x, nullptr, nullptr, nullptr};
+                dev::gather_merged(stream, dev::FWD, f, fwu.T(l), fwu.W(l), fwu.B(l));
+            });
+        gathered = false;
+        if (persist && gs_run_f[(size_t)l] >= 0) {
+            const GRun &r = gs_runs[(size_t)gs_run_f[(size_t)l]];
+            each([&](double *x, const double *) {
+                dev::GatherArgs f{Rf_p, Rf_col, Rfx, x, x, nullptr, nullptr, nullptr};
+                dev::solve_snodes_gsweep(stream, dev::FWD, v, sview, sn_order, x, sn_yt, gs_lv + r.off, r.nlev, r.grid, r.lds, f, gs_ctl,
+                                         norm_nan(1), nullptr);
+                gs_launches++;
+            });
+            l += r.nlev - 1;
+            gathered = l + 1 < nfaclevels;
+            continue;
+        }
+        if (is_g(l)) {
+            const bool ride = merge && l + 1 < nfaclevels;
+            each([&](double *x, const double *) {
+                dev::GatherArgs f{Rf_p, Rf_col, Rfx, x, x, nullptr, nullptr, nullptr};
+                dev::solve_snodes_g(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                                    sn_lvl_wmax[l], sn_lvl_hmax[l], x, sn_yt, nullptr, ride ? &f : nullptr,
+                                    ride ? fwu.T(l + 1) : dev::ListView{nullptr, 0}, ride ? fwu.W(l + 1) : dev::ListView{nullptr, 0},
+                                    ride ? fwu.B(l + 1) : dev::ChunkView{nullptr, nullptr, nullptr, 0});
+            });
+            gathered = ride;
+        } else if (sn_lvl_ptr[l + 1] > sn_lvl_ptr[l] && sn_lvl_nblk[l] * 64 > 2 * 64) {
+            tri_level(dev::FWD, l);
+        } else {
+            each([&](double *x, const double *) {
+                dev::SnodeTriView t{sn_blk_ptr, sn_flags, epoch, norm_nan(1)};
+                dev::solve_snodes(stream, dev::FWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l], sn_wmax,
+                                  sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], x, &t, nullptr);
+            });
+        }
+    }
+    epoch = ++sn_epoch;
+    for (int l = nfaclevels - 1; l >= 0; l--) {
+        if (persist && gs_run_b[(size_t)l] >= 0) {
+            const GRun &r = gs_runs[(size_t)gs_run_b[(size_t)l]];
+            each([&](double *x, const double *) {
+                dev::GatherArgs g{Lp, Li, Lx, x, x, Dinv, nullptr, nullptr};
+                dev::solve_snodes_gsweep(stream, dev::BWD, v, sview, sn_order, x, sn_yt, gs_lv + r.off, r.nlev, r.grid, r.lds, g, gs_ctl,
+                                         norm_nan(1), nullptr);
+                gs_launches++;
+            });
+            l -= r.nlev - 1;
+            continue;
+        }
+        const dev::ChunkView b = bwu.B(l);
+        bool rode = false;
+        if (is_g(l)) {
+            const bool ride = merge && b.count == 0;
+            each([&](double *x, const double *) {
+                dev::GatherArgs g{Lp, Li, Lx, x, x, Dinv, nullptr, nullptr};
+                dev::solve_snodes_g(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l],
+                                    sn_lvl_wmax[l], sn_lvl_hmax[l], x, sn_yt, nullptr, ride ? &g : nullptr,
+                                    ride ? bwu.T(l) : dev::ListView{nullptr, 0}, ride ? bwu.W(l) : dev::ListView{nullptr, 0});
+            });
+            rode = ride;
+        } else if (sn_lvl_ptr[l + 1] > sn_lvl_ptr[l] && sn_lvl_nblk[l] * 64 > 2 * 64) {
+            tri_level(dev::BWD, l);
+        } else {
+            each([&](double *x, const double *) {
+                dev::SnodeTriView t{sn_blk_ptr, sn_flags, epoch, norm_nan(1)};
+                dev::solve_snodes(stream, dev::BWD, v, sview, sn_order + 8 * sn_lvl_ptr[l], sn_lvl_ptr[l + 1] - sn_lvl_ptr[l], sn_wmax,
+                                  sn_nbmax, sn_lvl_nblk[l] * 64, sn_lvl_nbmax[l], x, &t, nullptr);
+            });
+        }
+        if (rode) continue;
+        each([&](double *x, const double *) {
+            dev::GatherArgs g{Lp, Li, Lx, x, x, Dinv, nullptr, nullptr};
+            if (b.count) dev::gather_Bprep(stream, dev::BWD, g, bwu.BR(l));
+            dev::gather_merged(stream, dev::BWD, g, bwu.T(l), bwu.W(l), b);
+        });
+    }
+    each([&](double *x, const double *addv) {
+        dev::bundle_bwd(stream, v, bundles, x, addv);
+        if (addv && N > NF) dev::add_vec(stream, x + NF, addv + NF, N - NF);
+    });
 }
 void Engine::enqueue_solve_direct(double *xp, const double *addv) {
     const dev::LdlView v = view();

@@ -235,6 +235,12 @@ struct Engine {
     // xp <- K^-1 xp (permuted numbering); with addv the result is xp <- K^-1 xp + addv
     void enqueue_solve_inplace(double *xp, const double *addv = nullptr);
     void enqueue_solve_direct(double *xp, const double *addv);
+    // two independent solves (context A = the active one, context B = alt; pair_begin() has run): systems whose wide chain
+    // supernodes have a form for two right-hand sides walk the levels ONCE, every other stage twice (a launch per context
+    // on its own stream), the wide levels as one launch that streams the panels for both vectors; everything else: two chains
+    void enqueue_solve_pair(double *xa, const double *addva, double *xb, const double *addvb);
+    bool pair_lockstep_ok();
+    int tri2_launches = 0; // (tests: two-right-hand-side launches of k_snode_tri so far)
     // e = b - K x (permuted numbering); ||e||inf is folded into norm set `set` (>= 0)
     void enqueue_residual(double *e, const double *b, const double *x, int set);
     int zero_norm_sets();                                                    // enqueue
@@ -266,7 +272,7 @@ struct Engine {
     hipEvent_t exch_event = nullptr;
     bool exch_pending = false;
     int wait_for_exchange();
-    hipEvent_t pair_event = nullptr;
+    hipEvent_t pair_event = nullptr, pair_ev_a = nullptr, pair_ev_b = nullptr;
     bool pair_ok() const { return !ir_fused && fold.k == 0 && gfold.ng == 0 && topblk.nblocks == 0; } // (no shared accumulators)
     int ensure_alt();
     int ensure_alt_once();

@@ -357,7 +357,10 @@ struct SnodeTriView {
 // forward / backward substitution through the supernodes order[0..count) of one unit level
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
                   int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri = nullptr,
-                  const LaunchProf *lp = nullptr);
+                  const LaunchProf *lp = nullptr, double *x2 = nullptr, const SnodeTriView *tri2 = nullptr);
+// whether solve_snodes takes the pipelined multi-workgroup path for a level of this width (the only one with a form for
+// two right-hand sides: x2 / tri2 -- the second vector and ITS message buffer -- are ignored elsewhere)
+bool solve_snodes_is_tri(const SnodeTriView *tri, int wlvl);
 // ---- supernodes of moderate width: substitutions in one pass over G = [I; L_B] T^-1 (snode_g.hip) ----
 int snode_g_max_width();            // widest supernode that may take this path
 long long snode_g_ld(int h);        // leading dimension of a supernode's G

@@ -51,6 +51,25 @@ template <bool FWDMODE> __device__ __forceinline__ double snode_block_solve(cons
     return xv;
 }
 
+// the same for NR vectors at once: the coefficients are read once and the NR dependent chains interleave (the second
+// vector's 64 steps hide in the first one's latencies instead of doubling a hop of k_snode_tri's pipeline)
+template <bool FWDMODE, int NR> __device__ __forceinline__ void snode_block_solve_n(const double *Tt, double (&xv)[NR], int lane) {
+    double t[SN_NB];
+#pragma unroll
+    for (int jj = 0; jj < SN_NB; ++jj) t[jj] = Tt[jj * SN_NB + lane];
+    if (FWDMODE) {
+#pragma unroll
+        for (int jj = 0; jj < SN_NB - 1; ++jj)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) xv[k] -= t[jj] * readlane_f64(xv[k], jj);
+    } else {
+#pragma unroll
+        for (int jj = SN_NB - 1; jj > 0; --jj)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) xv[k] -= t[jj] * readlane_f64(xv[k], jj);
+    }
+}
+
 // CHIP_SN_DEBUG: wall-clock stamps (10 ns ticks) of ONE workgroup of a supernode launch at its phase boundaries;
 // `drain` first waits for the loads in flight, so that a phase owns the latency of what it requested
 __device__ __forceinline__ void sn_stamp(long long *dbg, bool me, int slot, bool drain = false) {
@@ -1532,15 +1551,20 @@ __global__ __launch_bounds__(SN_WG) void k_snode_bwd(LdlView v, SnodeView sv, co
 // one).  Config 2: 25.0 -> 23.6 ms per step, config 5: 47.4 -> 45.8.  (Sixteen waves leave 128 registers per lane: the
 // wave that solves the diagonal block holds its 64 coefficients in registers and needs more.)
 constexpr int SN2_WG = 512;
-constexpr int SN2_WMAX = 4096; // widest supernode (symbolic.cpp: SN_MAX_W); its column bases are kept in LDS
-template <bool FWDMODE>
+// NR right-hand sides per pass (round 6): the two independent solves of an interior-point iteration (kktsystem.rs:108-125,
+// core/solver.rs:351-361) and their refinement rounds walk the SAME entries of L -- with NR = 2 a launch streams the
+// panel once and applies it to both vectors (their messages live in two buffers, one per solve context).  These sweeps
+// run at ~0.5 of the HBM peak: the bytes are what is left to save.
+template <bool FWDMODE, int NR>
 __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, const int *__restrict__ order,
-                                                      const int *__restrict__ blk_ptr, int *msg, int epoch,
-                                                      double *x, int *timeout_flag) {
+                                                      const int *__restrict__ blk_ptr, int *msg0, int *msg1, int epoch0,
+                                                      int epoch1, double *x0, double *x1, int *timeout_flag, int *timeout_flag1) {
     __shared__ double Tl[SN_NB * SN_NB];
-    __shared__ double part[SN2_WG / 64][SN_NB];
-    __shared__ double pulled[SN_NB]; // backward: L_B,r' x_B of the own columns; forward: the finished x_r
-    __shared__ int colbase[SN2_WMAX]; // forward: of all earlier columns; backward: of the own block only
+    __shared__ double part[NR][SN2_WG / 64][SN_NB];
+    __shared__ double pulled[NR][SN_NB]; // backward: L_B,r' x_B of the own columns; forward: the finished x_r
+    // (dynamic: as many column bases as the level's widest supernode has columns -- a fixed SN2_WMAX array cost 16 KB and,
+    // with the second right-hand side's partial sums, the third workgroup of a CU)
+    extern __shared__ int colbase[]; // forward: of all earlier columns; backward: of the own block only
     int sn;
     const SnodeGeom g = snode_geom(sv, order, (int)blockIdx.y, sn);
     const int nblk = (g.w + SN_NB - 1) / SN_NB;
@@ -1548,12 +1572,17 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
     const int r = FWDMODE ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = r * SN_NB, nbw = min(SN_NB, g.w - j0);
-    int *mb = msg + (size_t)blk_ptr[sn] * 256; // this supernode's message slots: block c, lane l at (c * 64 + l) * 4
+    double *const xv_[2] = {x0, NR > 1 ? x1 : x0};
+    const int ep_[2] = {epoch0, NR > 1 ? epoch1 : epoch0};
+    // this supernode's message slots: block c, lane l at (c * 64 + l) * 4
+    int *const mb_[2] = {msg0 + (size_t)blk_ptr[sn] * 256, (NR > 1 ? msg1 : msg0) + (size_t)blk_ptr[sn] * 256};
     constexpr int CPW = SN_NB / (SN2_WG / 64); // columns per wave: of block c (forward) / of the own block (backward)
     // nothing below depends on x: column bases, the diagonal block and the own entries are requested first
     const int cb_lo = FWDMODE ? 0 : j0, cb_hi = j0 + nbw;
     for (int t = cb_lo + tid; t < cb_hi; t += SN2_WG) colbase[t - cb_lo] = g.cb[t];
-    double xown = (wave == 0 && lane < nbw) ? x[g.cols[j0 + lane]] : 0.0; // (last written before this launch)
+    double xown[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) xown[k] = (wave == 0 && lane < nbw) ? xv_[k][g.cols[j0 + lane]] : 0.0; // (last written before this launch)
     __syncthreads();
     const int *cbr = colbase + (FWDMODE ? j0 : 0); // column bases of the own block
     const int *Bn = v.Li + v.Lp[g.e];              // node ids of the rows of B
@@ -1561,29 +1590,42 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
         // the block's own columns first take D^-1 and the rows of B: x_j <- x_j / d_j - sum_r L(B_r, j) x(B_r)
         // (what k_snode_pull did in a launch of its own; here every block does it while it would otherwise
         // wait for the flags of the later blocks).  Rows of B along the lanes, this wave's CPW columns together.
-        double pacc[CPW];
+        double pacc[NR][CPW];
 #pragma unroll
-        for (int q = 0; q < CPW; ++q) pacc[q] = 0.0;
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) pacc[k][q] = 0.0;
         for (int r0 = 0; r0 < g.nb; r0 += 64) {
-            const int r = r0 + lane;
-            const bool rok = r < g.nb;
-            const double xb = rok ? x[Bn[r]] : 0.0;
+            const int rr = r0 + lane;
+            const bool rok = rr < g.nb;
+            const int node = rok ? Bn[rr] : 0;
+            double xb[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) xb[k] = rok ? xv_[k][node] : 0.0;
             double lq[CPW];
 #pragma unroll
             for (int q = 0; q < CPW; ++q) {
                 const int j = wave * CPW + q;
-                lq[q] = (rok && j < nbw) ? v.Lx[cbr[j] + g.w + r] : 0.0;
+                lq[q] = (rok && j < nbw) ? v.Lx[cbr[j] + g.w + rr] : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < CPW; ++q) pacc[q] += lq[q] * xb;
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) pacc[k][q] += lq[q] * xb[k];
         }
 #pragma unroll
-        for (int q = 0; q < CPW; ++q) {
-            const double tot = wave_sum(pacc[q]);
-            if (lane == 0) pulled[wave * CPW + q] = tot;
-        }
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                const double tot = wave_sum(pacc[k][q]);
+                if (lane == 0) pulled[k][wave * CPW + q] = tot;
+            }
         __syncthreads();
-        if (wave == 0 && lane < nbw) xown = xown * v.Dinv[g.cols[j0 + lane]] - pulled[lane];
+        if (wave == 0 && lane < nbw) {
+            const double dinv = v.Dinv[g.cols[j0 + lane]];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) xown[k] = xown[k] * dinv - pulled[k][lane];
+        }
     }
     // the diagonal block with the solve's lane index fastest (snode_block_solve): forward Tl[col * SN_NB + row],
     // backward Tl[row * SN_NB + col]
@@ -1592,9 +1634,11 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
         const int ii = FWDMODE ? lo : hi, jj = FWDMODE ? hi : lo;
         Tl[idx] = (ii > jj && ii < nbw) ? v.Lx[cbr[jj] + j0 + ii] : 0.0;
     }
-    double acc[CPW];
+    double acc[NR][CPW];
 #pragma unroll
-    for (int q = 0; q < CPW; ++q) acc[q] = 0.0;
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) acc[k][q] = 0.0;
     const int nsteps = FWDMODE ? r : nblk - 1 - r;
     // every WAVE runs the pipeline on its own (no workgroup barrier per step): it requests the L entries of
     // the next step, waits for the flag of x_c, reads x_c (one entry per lane) and accumulates
@@ -1617,73 +1661,100 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
 #pragma unroll
         for (int q = 0; q < CPW; ++q) lv[q] = ln[q];
         if (step + 1 < nsteps) request(ln, step + 1);
-        // every lane polls the message of "its" unknown of block c
-        msg_v4i mm;
+        // every lane polls the message(s) of "its" unknown of block c
+        msg_v4i mm[NR];
         for (long long spins = 0;; ++spins) {
-            mm = msg_load(mb + (c * 64 + lane) * 4);
-            const bool got = lane >= ncw || (mm.y == epoch && mm.w == epoch);
+            bool got = true;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                mm[k] = msg_load(mb_[k] + (c * 64 + lane) * 4);
+                got = got && (lane >= ncw || (mm[k].y == ep_[k] && mm[k].w == ep_[k]));
+            }
             if (__all(got)) break;
             __builtin_amdgcn_s_sleep(1);
             if (spins > (1ll << 18)) {
                 ok = false;
-                if (lane == 0) *timeout_flag = 1;
+                if (lane == 0) {
+                    *timeout_flag = 1;
+                    if (NR > 1) *timeout_flag1 = 1; // (both solves see the failure)
+                }
                 break;
             }
         }
         if (!ok) break;
-        const double xcv = lane < ncw ? __hiloint2double(mm.z, mm.x) : 0.0;
-        if (FWDMODE) {
 #pragma unroll
-            for (int q = 0; q < CPW; ++q) acc[0] += lv[q] * __shfl(xcv, wave * CPW + q, 64);
-        } else {
+        for (int k = 0; k < NR; ++k) {
+            const double xcv = lane < ncw ? __hiloint2double(mm[k].z, mm[k].x) : 0.0;
+            if (FWDMODE) {
 #pragma unroll
-            for (int q = 0; q < CPW; ++q) acc[q] += lv[q] * xcv;
+                for (int q = 0; q < CPW; ++q) acc[k][0] += lv[q] * readlane_f64(xcv, wave * CPW + q); // (a wave-uniform lane: v_readlane, not a trip through the LDS crossbar)
+            } else {
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) acc[k][q] += lv[q] * xcv;
+            }
         }
     }
     // reduce: forward across the waves (each holds its columns' share of every row), backward across lanes
-    if (FWDMODE) {
-        part[wave][lane] = acc[0];
-    } else {
 #pragma unroll
-        for (int q = 0; q < CPW; ++q) {
-            const double tot = wave_sum(acc[q]);
-            if (lane == 0) part[0][wave * CPW + q] = tot;
+    for (int k = 0; k < NR; ++k) {
+        if (FWDMODE) {
+            part[k][wave][lane] = acc[k][0];
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                const double tot = wave_sum(acc[k][q]);
+                if (lane == 0) part[k][0][wave * CPW + q] = tot;
+            }
         }
     }
     __syncthreads(); // (also: Tl is complete)
     if (wave == 0 && ok) {
-        double xv = xown;
-        if (lane < nbw) {
-            if (FWDMODE) {
+        double xr[NR];
 #pragma unroll
-                for (int w = 0; w < SN2_WG / 64; ++w) xv -= part[w][lane];
-            } else {
-                xv -= part[0][lane];
+        for (int k = 0; k < NR; ++k) {
+            double xv = xown[k];
+            if (lane < nbw) {
+                if (FWDMODE) {
+#pragma unroll
+                    for (int w = 0; w < SN2_WG / 64; ++w) xv -= part[k][w][lane];
+                } else {
+                    xv -= part[k][0][lane];
+                }
             }
+            xr[k] = xv;
         }
-        xv = snode_block_solve<FWDMODE>(Tl, xv, lane);
-        if (lane < nbw) {
-            msg_store(mb + (r * 64 + lane) * 4, xv, epoch); // to the other blocks of this sweep
-            x[g.cols[j0 + lane]] = xv;                      // to the launches that follow
+        snode_block_solve_n<FWDMODE, NR>(Tl, xr, lane);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            if (lane < nbw) {
+                msg_store(mb_[k] + (r * 64 + lane) * 4, xr[k], ep_[k]); // to the other blocks of this sweep
+                xv_[k][g.cols[j0 + lane]] = xr[k];                      // to the launches that follow
+            }
+            if (FWDMODE) pulled[k][lane] = lane < nbw ? xr[k] : 0.0;
         }
-        if (FWDMODE) pulled[lane] = lane < nbw ? xv : 0.0;
     }
     if (FWDMODE && g.nb > 0) {
         // after the flag (off the pipeline's critical path): this block's share of x_B -= L_BS x_S, one row of B
-        // per thread, one atomic per (row, block) -- what k_snode_push did in a launch of its own
+        // per thread, one atomic per (row, block, vector) -- what k_snode_push did in a launch of its own
         __syncthreads();
         if (!ok) return;
         for (int rb = tid; rb < g.nb; rb += SN2_WG) {
-            double sacc = 0.0;
+            double sacc[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) sacc[k] = 0.0;
 #pragma unroll
             for (int j2 = 0; j2 < SN_NB; j2 += 16) {
                 double lv2[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) lv2[q] = (j2 + q < nbw) ? v.Lx[cbr[j2 + q] + g.w + rb] : 0.0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) sacc += lv2[q] * pulled[j2 + q];
+                for (int k = 0; k < NR; ++k)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) sacc[k] += lv2[q] * pulled[k][j2 + q];
             }
-            atomicAdd(&x[Bn[rb]], -sacc);
+            const int node = Bn[rb];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) atomicAdd(&xv_[k][node], -sacc[k]);
         }
     }
 }
@@ -1708,21 +1779,30 @@ int snode_kernel_attributes(int wmax, int nbmax) {
 }
 // wlvl / nblvl: maxima over the supernodes of this launch.  Levels with a large B part run it in
 // separate multi-workgroup launches: one workgroup per supernode is latency bound.
+bool solve_snodes_is_tri(const SnodeTriView *tri, int wlvl) { return tri && tri->msg && wlvl > 2 * SN_NB; }
 void solve_snodes(hipStream_t s, GatherMode m, const LdlView &v, const SnodeView &sv, const int *order, int count,
                   int wmax_all, int nbmax_all, int wlvl, int nblvl, double *x, const SnodeTriView *tri,
-                  const LaunchProf *lp) {
+                  const LaunchProf *lp, double *x2, const SnodeTriView *tri2) {
     if (!count) return;
     if (tri && tri->msg && wlvl > 2 * SN_NB) {
         if (lp) lp->begin(lp->ctx, PFK_SN_TRI);
         // wide supernodes: the triangle by several workgroups per supernode (k_snode_tri), the rows of B by
         // their own multi-workgroup launches
         const int nblkmax = (wlvl + SN_NB - 1) / SN_NB;
-        if (m == FWD) {
-            k_snode_tri<true><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri->epoch, x,
-                                                                    tri->timeout_flag);
+        const size_t cbytes = (size_t)((m == FWD ? wlvl : SN_NB) + 64) * sizeof(int); // (column bases: all earlier columns / the own block)
+        if (x2 && tri2 && tri2->msg) { // two right-hand sides, one pass over the panels
+            if (m == FWD)
+                k_snode_tri<true, 2><<<dim3(nblkmax, count), SN2_WG, cbytes, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri2->msg, tri->epoch,
+                                                                           tri2->epoch, x, x2, tri->timeout_flag, tri2->timeout_flag);
+            else
+                k_snode_tri<false, 2><<<dim3(nblkmax, count), SN2_WG, cbytes, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri2->msg, tri->epoch,
+                                                                            tri2->epoch, x, x2, tri->timeout_flag, tri2->timeout_flag);
+        } else if (m == FWD) {
+            k_snode_tri<true, 1><<<dim3(nblkmax, count), SN2_WG, cbytes, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri->msg, tri->epoch,
+                                                                       tri->epoch, x, x, tri->timeout_flag, tri->timeout_flag);
         } else {
-            k_snode_tri<false><<<dim3(nblkmax, count), SN2_WG, 0, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri->epoch, x,
-                                                                     tri->timeout_flag);
+            k_snode_tri<false, 1><<<dim3(nblkmax, count), SN2_WG, cbytes, s>>>(v, sv, order, tri->blk_ptr, tri->msg, tri->msg, tri->epoch,
+                                                                        tri->epoch, x, x, tri->timeout_flag, tri->timeout_flag);
         }
         (void)nblvl;
         if (lp) lp->end(lp->ctx, PFK_SN_TRI);

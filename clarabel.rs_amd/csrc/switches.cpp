@@ -78,6 +78,7 @@ const Entry TABLE[] = {
     {"CHIP_SN_ASM_CAP", Entry::INT, SW(sn_asm_cap), 0},
     {"CHIP_NO_FACTOR_OVERLAP", Entry::FLAG, SW(no_factor_overlap), 0},
     {"CHIP_NO_SOLVE_PAIR", Entry::FLAG, SW(no_solve_pair), 0},
+    {"CHIP_NO_PAIR_LOCKSTEP", Entry::FLAG, SW(no_pair_lockstep), 0},
     {"CHIP_NO_SWEEP_MERGE", Entry::FLAG, SW(no_sweep_merge), 0},
     {"CHIP_NO_SWEEP_PERSIST", Entry::FLAG, SW(no_sweep_persist), 0},
     {"CHIP_GS_TEST_DROP", Entry::FLAG, SW(gs_test_drop), 0},

@@ -74,6 +74,7 @@ struct Switches {
     bool no_xcd_map = false;        // CHIP_NO_XCD_MAP: the tiles of k_snode_extend spread over the XCDs, not one supernode per XCD
     int sn_asm_cap = 0;             // CHIP_SN_ASM_CAP: rows of a target column per LDS window of k_snode_assemble (tests; 0: 4096)
     bool no_factor_overlap = false; // CHIP_NO_FACTOR_OVERLAP: the bundle columns' contributions into supernode members all ahead of the supernode chain, none beside it on the second stream
+    bool no_pair_lockstep = false;  // CHIP_NO_PAIR_LOCKSTEP: the paired solves keep two independent chains of launches, also where the wide supernodes have a two-right-hand-side form (k_snode_tri<.., 2>)
     bool no_solve_pair = false;     // CHIP_NO_SOLVE_PAIR: chip_kkt_solve2_dev_enqueue runs its two solves one after the other on every handle
     bool no_sweep_merge = false;    // CHIP_NO_SWEEP_MERGE: the row gathers of a unit level in their own launch, also next to supernodes on the one-pass matrices
     bool no_sweep_persist = false;  // CHIP_NO_SWEEP_PERSIST: a launch per unit level on the one-pass matrices, no persistent launch per run of levels (k_snode_gsweep)

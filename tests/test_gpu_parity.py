@@ -507,7 +507,7 @@ def test_l1_fast_path_registered_sets_and_device_refinement(hip, oracle, which):
         assert ok5 and r5 == 0 and relerr(xbuf, x4) <= 1e-13
 
 
-@pytest.mark.parametrize("which", ["qp_supernodes", "chordal_sdp", "arrow", "forest", "general"])
+@pytest.mark.parametrize("which", ["qp_supernodes", "chordal_sdp", "chordal_sdp_wide", "arrow", "forest", "general"])
 def test_paired_solves_match_separate_solves(hip, oracle, which, monkeypatch):
     """chip_kkt_solve2_dev_enqueue: the two independent solves of an interior-point iteration (constant right-hand side,
     affine direction) as one call -- on level-scheduled systems enqueued on two streams and overlapped -- against the
@@ -519,6 +519,11 @@ def test_paired_solves_match_separate_solves(hip, oracle, which, monkeypatch):
         pr = problems.random_qp(20000, 40000, band=50, seed=1)
     elif which == "chordal_sdp":
         pr = problems.chordal_sdp(8, 20, 4, 8, 9, seed=5)
+        hs = pr["hsblocks"]
+    elif which == "chordal_sdp_wide":
+        # (cliques of 40: chain supernodes several hundred columns wide -- the pipelined substitution k_snode_tri, whose
+        # paired form streams a panel ONCE for both right-hand sides: k_snode_tri<., 2>, asserted below)
+        pr = problems.chordal_sdp(5, 40, 8, 5, 21, seed=5)
         hs = pr["hsblocks"]
     elif which == "arrow":
         pr = problems.portfolio_socp(12, 300, seed=3)
@@ -547,6 +552,8 @@ def test_paired_solves_match_separate_solves(hip, oracle, which, monkeypatch):
                                   dev[1][0].ptr, dev[1][1].ptr, outs[1].ptr, outs[1].ptr + 8 * n)
             uok, sok = ks.collect()
             assert uok and sok == [True, True]
+            if which == "chordal_sdp_wide":  # the two-right-hand-side launches ran exactly when the pair is allowed to share them
+                assert (hip.debug_counter(ks, "tri2_launches") > 0) == (env is None), (env, hip.debug_counter(ks, "tri2_launches"))
             for k in range(2):  # the same two solves as separate calls on the same handle
                 ks.setrhs_dev(dev[k][0].ptr, dev[k][1].ptr)
                 ks.solve_dev_enqueue(outs[2 + k].ptr, outs[2 + k].ptr + 8 * n)

@@ -882,6 +882,7 @@ def main():
         gathered = [hip.DeviceArray(int(sum(counts))) for _ in range(3)]
     elapsed, prof = w.run(args.steps, args.warmup, args.profile_family, comm, gathered, counts,
                           events_in_timed_region=False, sequential_pass=workload in ("c2", "c5", "c5m"))
+    own_elapsed_main, own_repeats_main = getattr(w, "own_elapsed", elapsed), w.repeats  # (this rank's clock of the run `value` comes from)
     ir = w.ks.linear_solver_info().last_ir_iterations
     # N > 1: the same steps once more with the OTHER exchange policy, so that the driver's curve can be read either way
     # (SURVEY 8(e) says one all-gather per solve; the default gathers the step direction only)
@@ -913,7 +914,7 @@ def main():
         w.ks.synchronize()
         exch_us = 1e6 * (time.perf_counter() - t1) / reps
         mine = np.zeros(4 * world)
-        mine[4 * rank:4 * rank + 4] = [1e3 * w.own_elapsed / args.steps, float(w.repeats), float(w.ks.fused_fallbacks()), exch_us]
+        mine[4 * rank:4 * rank + 4] = [1e3 * own_elapsed_main / args.steps, float(own_repeats_main), float(w.ks.fused_fallbacks()), exch_us]
         allv = np.asarray(comm.allreduce(mine.tolist(), "sum")).reshape(world, 4)
         per_rank = {"ms_per_step": [round(float(v), 4) for v in allv[:, 0]],
                     "fused_launch_repeats": [int(v) for v in allv[:, 1]],

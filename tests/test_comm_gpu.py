@@ -157,7 +157,7 @@ def test_bench_sharded_code_path_with_file_comm(hip):
     assert par["gathered_vs_local"]["max_abs_diff_of_segment_checksums"] == 0.0
     pr_ = line["per_rank"]  # (every rank's own clock, repeats, fall-backs and the exchange alone: what a real N > 1 run is read by)
     assert len(pr_["ms_per_step"]) == 2 and all(v > 0 for v in pr_["ms_per_step"]) and all(v > 0 for v in pr_["exchange_alone_us"])
-    assert pr_["fused_launch_repeats"] == [0, 0] and max(pr_["ms_per_step"]) <= line["ms_per_step"] * 1.0001
+    assert pr_["fused_launch_repeats"] == [0, 0] and max(pr_["ms_per_step"]) <= line["ms_per_step"] * 1.01 + 1e-3  # (rounded to four decimals on the line)
 
 
 def test_sharded_scalars_of_an_iteration_through_allreduce(hip):

@@ -1937,6 +1937,25 @@ def test_supernode_substitution_matrices(hip, oracle, which, monkeypatch):
         assert k.solve(x, z)
         sols.append(np.concatenate([x, z]))
     assert relerr(sols[1], sols[0]) <= 1e-9
+    # backward error BEFORE refinement of the two forms (what decides whether a hard iterate costs one refinement round
+    # or three): ||b - K x||inf / (||K||inf ||x||inf + ||b||inf) of ONE LDL' solve, K = the device's unregularised values.
+    # G = [I; L_B] T^-1 holds an explicit triangular inverse: it may lose digits where T is ill conditioned, and the bound
+    # below is where that would show.
+    Kc = ks.kkt_matrix()
+    Ku = sp.csc_matrix((ks.values(), Kc.rowval.astype(np.int64), Kc.colptr.astype(np.int64)), shape=(ks.N, ks.N))  # (the CURRENT values)
+    Kf = Ku + sp.triu(Ku, 1).T
+    knorm = float(abs(Kf).sum(axis=1).max())
+    bfull = np.concatenate([rx, rz, np.zeros(ks.N - pr["n"] - pr["m"])])
+    st0 = hip.Settings.default(iterative_refinement_enable=0)
+    berr = []
+    for k in (ks0, ks):
+        k.set_settings(st0)
+        ok, xf = k.solve_full(bfull)
+        assert ok
+        berr.append(float(np.max(np.abs(bfull - Kf @ xf)) / (knorm * np.max(np.abs(xf)) + np.max(np.abs(bfull)))))
+        k.set_settings(hip.Settings.default())
+    print("backward error before refinement [%s]: block substitution %.2e, one-pass matrices %.2e" % (which, berr[0], berr[1]))
+    assert berr[1] <= max(64.0 * berr[0], 1e-13), berr
     # the row gathers over non-member columns in their own launches instead of inside the supernodes' launches
     monkeypatch.setenv("CHIP_NO_SWEEP_MERGE", "1")
     _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=2)

@@ -2,7 +2,8 @@
 (device = HOST_ONLY): KKT assembly, ordering, symbolic analysis.  CHIP_TIMING=1 prints the stages.
 usage: CHIP_TIMING=1 python tools/host_setup_timing.py [ncliques]"""
 import sys, time, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import __graft_entry__ as g
 hip = g.load_package()
 import clarabel_rs_amd.synthetic as problems

@@ -542,6 +542,7 @@ def extra_workload(hip, problems, which, args, device):
         steps, warm = max(3, min(args.steps, 10)), max(1, min(args.warmup, 2))
         el, prof = w.run(steps, warm, fam, events_in_timed_region=False)
         ms = 1e3 * el / steps
+        step_ms0, events_pass0, sequential0 = w.step_ms, w.events_pass, w.sequential  # (of THIS run: later passes overwrite them)
         ks = w.ks
         info = ks.linear_solver_info()
         wm = ks.work_model()
@@ -558,6 +559,28 @@ def extra_workload(hip, problems, which, args, device):
                     "unit": "TFLOP/s", "frac": round(ach / MFMA_F64_PEAK_TFLOPS, 4),
                     "launches_per_step": round(prof["launches"] / steps, 1), "kernel_ms_per_step": round(prof["ms"] / steps, 3)}
         whole = round(Bm["iter"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        chain = None
+        if which == "c2" and wm["sn_update_flops"] > 0:
+            # the factorisation's chain of block columns -- the LARGEST share of this step (the sweeps above are the second):
+            # every block column of every unit level is a k_snode_update launch (left-looking update of the 64 columns, f64
+            # matrix cores) followed by a k_snode_panel2 launch (the block's LDL' + the rows below it); two short passes
+            # with event pairs around those launches.  flops from the supernode geometry (chip_kkt_work_model).
+            fams = {}
+            for f_, nm in ((7, "k_snode_update"), (8, "k_snode_panel2")):
+                _, pf = w.run(3, 1, f_, events_in_timed_region=True, sequential_pass=False)
+                if pf["launches"] > 0:
+                    fams[nm] = {"launches_per_step": round(pf["launches"] / 3.0, 1), "avg_launch_us": round(1e3 * pf["ms"] / pf["launches"], 2),
+                                "ms_per_step": round(pf["ms"] / 3.0, 3)}
+            if fams:
+                tot_ms = sum(v_["ms_per_step"] for v_ in fams.values())
+                flops = wm["sn_update_flops"] + wm["sn_diag_rows_flops"]
+                chain = {"bound": "mfma", "kernel": "k_snode_update + k_snode_panel2 (one pair per block column of a unit level, each waiting for the one before: a chain of dependent launches)",
+                         "families": fams, "ms_per_step": round(tot_ms, 3), "flops_per_refactor": flops,
+                         "achieved": round(flops / (tot_ms * 1e-3) / 1e12, 3), "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops / (tot_ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4),
+                         "what": "latency of %d dependent launches, not arithmetic: %.0f MFLOP per launch"
+                                 % (int(sum(v_["launches_per_step"] for v_ in fams.values())),
+                                    flops / max(1.0, sum(v_["launches_per_step"] for v_ in fams.values())) / 1e6)}
         cpu = None
         if which == "c2":
             parity, _, ko = oracle_leg(w, args, time_it=False)
@@ -570,9 +593,9 @@ def extra_workload(hip, problems, which, args, device):
         else:
             parity = fixture_parity_c5(w, hip)
         out = {"workload": desc, "value": round(steps / el, 3), "unit": "iterations/s", "ms_per_step": round(ms, 4),
-               "steps": steps, "step_ms": w.step_ms, "roofline_events_pass": w.events_pass,
-               "per_step": "1 update + (2 paired + 1) solves, one refinement round each", "other_solve_policy": w.sequential, "kkt_dim": ks.N, "nnz_L": int(info.nnzL), "setup_s": round(w.t_setup, 2),
-               "roofline": roof, "whole_step_frac_of_hbm_peak": whole,
+               "steps": steps, "step_ms": step_ms0, "roofline_events_pass": events_pass0,
+               "per_step": "1 update + (2 paired + 1) solves, one refinement round each", "other_solve_policy": sequential0, "kkt_dim": ks.N, "nnz_L": int(info.nnzL), "setup_s": round(w.t_setup, 2),
+               "roofline": roof, "roofline_factor_chain": chain, "whole_step_frac_of_hbm_peak": whole,
                "parity": None if parity is None else {k: parity[k] for k in ("rel_err_vs_oracle", "tol", "ok") if k in parity},
                "cpu_baseline": cpu, "cpu_baseline_mt": None if args.cpu_steps == 0 else sn_leg(w, hip)}
         del w

@@ -646,7 +646,7 @@ __device__ bool lds_cholesky(double *A, int n, int *flag) {
 __device__ int g_psd_no_mfma = 0;
 template <bool TA, bool TB>
 __device__ __forceinline__ void psd_gemm(double *C, const double *A, const double *B, int n) {
-    if (n >= 16 && !g_psd_no_mfma) {
+    if (n >= 16 && !(g_psd_no_mfma & 1)) {
         typedef double gemm_v4d __attribute__((ext_vector_type(4)));
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
         const int nt = (n + 15) / 16;
@@ -899,7 +899,94 @@ __device__ __forceinline__ void psd_mul_Wx(double *Y, double *T, const double *X
 // eigenvalues of the symmetric matrix A (LDS, destroyed) by parallel two-sided Jacobi: per round the
 // n/2 disjoint pairs of a round-robin schedule are rotated together (columns, then rows).  Returns
 // the smallest eigenvalue and (psum) the sum of the positive ones to every thread.
+// Round 6: for n >= 12 the eigenvalues come from a Householder reduction to tridiagonal form (n - 2 reflections, each a
+// matrix-vector product and a rank-2 update of the trailing block: 4/3 n^3 flops in all) and Sturm-count bisection on the
+// tridiagonal matrix, one eigenvalue per thread -- what LAPACK's syevr does for the reference
+// (psdtrianglecone.rs:437-463), instead of ~8 sweeps x (n - 1) rounds of dependent rotation steps (n = 96: 3.6 ms per
+// decomposition on 256 threads; the rounds are chains of barriers, not arithmetic).  Only the VALUES are needed here
+// (smallest one, sum of the positive ones).  cs: 3 n doubles of work space (w, then d and e^2).
+__device__ double psd_eig_tridiag(double *A, int n, double *cs, double *red, double *psum) {
+    const int tid = threadIdx.x;
+    double *w = cs, *dd = cs + n, *e2 = cs + 2 * n;
+    for (int k = 0; k + 2 < n; ++k) {
+        const int m = n - k - 1;          // x = A[k + 1 .. n, k]: the column below the diagonal (contiguous)
+        double *x = A + (k + 1) + (size_t)k * n;
+        double s2 = 0.0;
+        for (int i = 1 + tid; i < m; i += WG) s2 += x[i] * x[i];
+        s2 = block_sum(s2, red);
+        const double x0 = x[0];
+        if (s2 == 0.0) continue;          // (already tridiagonal in this column; uniform: s2 is broadcast)
+        const double nrm = sqrt(x0 * x0 + s2), alpha = x0 >= 0.0 ? -nrm : nrm;
+        const double u0 = x0 - alpha, tau = 2.0 / (s2 + u0 * u0); // H = I - tau u u', u = x - alpha e_1
+        __syncthreads();                  // (every thread has read x[0])
+        if (tid == 0) x[0] = u0;
+        __syncthreads();
+        // p = tau A22 u (A22 = the trailing m x m block, full symmetric storage: row i is read along a column stride)
+        for (int i = tid; i < m; i += WG) {
+            const double *row = A + (k + 1 + i) + (size_t)(k + 1) * n;
+            double acc = 0.0;
+            for (int j = 0; j < m; ++j) acc += row[(size_t)j * n] * x[j];
+            w[i] = tau * acc;
+        }
+        __syncthreads();
+        double kk = 0.0;
+        for (int i = tid; i < m; i += WG) kk += x[i] * w[i];
+        kk = 0.5 * tau * block_sum(kk, red);
+        for (int i = tid; i < m; i += WG) w[i] -= kk * x[i]; // w = p - (tau / 2)(u'p) u
+        __syncthreads();
+        // A22 <- A22 - u w' - w u'
+        for (int idx = tid; idx < m * m; idx += WG) {
+            const int i = idx % m, j = idx / m;
+            A[(k + 1 + i) + (size_t)(k + 1 + j) * n] -= x[i] * w[j] + w[i] * x[j];
+        }
+        __syncthreads();
+        if (tid == 0) x[0] = alpha;       // the subdiagonal entry e_k
+        __syncthreads();
+    }
+    // d (diagonal) and e^2 (squared subdiagonal); Gershgorin bounds
+    double lo = INFINITY, hi = -INFINITY;
+    for (int i = tid; i < n; i += WG) {
+        const double di = A[i + (size_t)i * n];
+        const double el = i > 0 ? A[i + (size_t)(i - 1) * n] : 0.0, er = i + 1 < n ? A[(i + 1) + (size_t)i * n] : 0.0;
+        dd[i] = di;
+        e2[i] = el * el; // e2[i] = e_{i-1}^2 (e2[0] = 0)
+        const double rad = fabs(el) + fabs(er);
+        lo = fmin(lo, di - rad);
+        hi = fmax(hi, di + rad);
+    }
+    lo = -block_max(-lo, red);
+    hi = block_max(hi, red);
+    __syncthreads();
+    // eigenvalue number t (ascending) by bisection on the number of eigenvalues below a shift (Sturm count of the LDL'
+    // recurrence q_i = d_i - s - e_{i-1}^2 / q_{i-1}; a zero pivot is replaced by a tiny one)
+    double ev = 0.0;
+    if (tid < n) {
+        double a = lo, b = hi;
+        const double scale = fmax(fabs(lo), fabs(hi));
+        const double tiny = 2.2250738585072014e-308 / 2.220446049250313e-16;
+        for (int it = 0; it < 120; ++it) {
+            const double mid = 0.5 * (a + b);
+            if (mid <= a || mid >= b || b - a <= 4.440892098500626e-16 * scale) break;
+            int cnt = 0;
+            double q = 1.0;
+            for (int i = 0; i < n; ++i) {
+                q = dd[i] - mid - (i > 0 ? e2[i] / q : 0.0);
+                if (fabs(q) < tiny) q = -tiny;
+                cnt += q < 0.0 ? 1 : 0;
+            }
+            if (cnt > tid) b = mid;
+            else a = mid;
+        }
+        ev = 0.5 * (a + b);
+    }
+    double mn = tid == 0 ? ev : INFINITY; // (thread 0 holds the smallest eigenvalue)
+    mn = -block_max(-mn, red);
+    const double sp = block_sum(tid < n ? fmax(ev, 0.0) : 0.0, red);
+    if (psum) *psum = sp;
+    return mn;
+}
 __device__ double psd_eig_min(double *A, int n, double *cs, double *red, int *flag, double *psum) {
+    if (n >= 12 && n <= WG && !(g_psd_no_mfma & 2)) return psd_eig_tridiag(A, n, cs, red, psum);
     const int np = (n + 1) & ~1, half = np / 2, tid = threadIdx.x;
     double *cc = cs, *ss = cs + half;
     int *pp = (int *)(cs + 2 * half), *qq = pp + half;
@@ -2093,7 +2180,7 @@ static void psd_sync_switch(hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 ? 0 : dev % 64;
-    const int want = switches().no_psd_mfma ? 1 : 0;
+    const int want = (switches().no_psd_mfma ? 1 : 0) | (switches().psd_jacobi_eig ? 2 : 0); // (bit 1: psd_eig_min keeps the Jacobi iteration)
     if (want != cur[dev].load(std::memory_order_acquire)) {
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_psd_no_mfma), &want, sizeof(int), 0, hipMemcpyHostToDevice, s);
         (void)hipStreamSynchronize(s);

@@ -42,6 +42,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_SNX_HOIST", Entry::FLAG, SW(no_snx_hoist), 0},
     {"CHIP_NO_PSD_MFMA", Entry::FLAG, SW(no_psd_mfma), 0},
     {"CHIP_NO_PSD_ROWS", Entry::FLAG, SW(no_psd_rows), 0},
+    {"CHIP_PSD_JACOBI_EIG", Entry::FLAG, SW(psd_jacobi_eig), 0},
     {"CHIP_NO_XPERM", Entry::FLAG, SW(no_xperm), 0},
     {"CHIP_NO_DENSE_SYMV", Entry::FLAG, SW(no_dense_symv), 0},
     {"CHIP_DENSE_SYMV_MIN", Entry::LONG, SW(dense_symv_min), 0},

@@ -37,6 +37,7 @@ struct Switches {
     long long snb_chunk = 0;        // CHIP_SNB_CHUNK: fewest updates of a chunk of the bundle columns' contributions into a supernode member (0: default)
     bool no_snx_hoist = false;      // CHIP_NO_SNX_HOIST: the bundle columns' contributions into supernode members stay in the launches of the members' unit levels
     bool no_psd_mfma = false;       // CHIP_NO_PSD_MFMA: the n x n products of the PSD cone kernels as scalar dot products, not on the matrix cores
+    bool psd_jacobi_eig = false;    // CHIP_PSD_JACOBI_EIG: eigenvalues of PSD cones (step length, margins) by the two-sided Jacobi iteration of rounds 1 - 5, not by tridiagonal reduction + bisection
     bool no_psd_rows = false;       // CHIP_NO_PSD_ROWS: the Hs blocks of PSD cones written through mapHs (caller's order), not row by row
     bool no_xperm = false;          // CHIP_NO_XPERM
     long long dense_symv_min = 0;   // CHIP_DENSE_SYMV_MIN: fewest block entries for which the blocks leave S (tests; 0: 2^20)

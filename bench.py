@@ -59,6 +59,7 @@ import numpy as np
 import __graft_entry__ as graft
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a plain copy reaches on this part (same guide): `frac_of_achievable` beside `frac`
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 matrix-core peak
 TOL = 1e-8             # north_star: "solution within 1e-8 relative of reference"
 
@@ -220,6 +221,20 @@ class Workload:
     def solutions(self):
         self.ks.synchronize()
         return [a.numpy() for a in self.lhs]
+
+
+def profile_commit(name):
+    """the commit that put profiles/<name> into the tree (so that a quoted PMC figure can be matched to the code it was taken
+    on); None outside a git checkout (the GPU box gets a snapshot without .git)"""
+    if not name:
+        return None
+    try:
+        import subprocess
+        out = subprocess.run(["git", "-C", ROOT, "log", "-n", "1", "--format=%h %cs", "--", os.path.join("profiles", name)],
+                             capture_output=True, text=True, timeout=10)
+        return out.stdout.strip() or None
+    except Exception:
+        return None
 
 
 def relerr(a, b):
@@ -1039,7 +1054,9 @@ def main():
             avg_ms = prof["ms"] / prof["launches"]
             ach = fam_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profiled_in": traffic_src,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_achievable": round(ach / HBM_ACHIEVABLE_GBS, 4),
+                    "traffic": traffic, "traffic_profiled_in": traffic_src,
+                    "traffic_profiled_at": profile_commit(traffic_src),
                     "kernel": fam_name,
                     "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
                     "algorithmic_bytes_per_launch": fam_bytes, "whole_step": whole}

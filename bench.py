@@ -1026,7 +1026,7 @@ def main():
         # profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, see that script).  PMC counters cannot be
         # collected from inside the timed run: the committed summary of the same command is QUOTED (with the
         # file it comes from) -- null when the workload differs from the profiled one.
-        traffic = traffic_src = None
+        traffic = traffic_src = traffic_commit = None
         try:
             import glob
             suffix = {"c3": "", "c2": "_c2", "c5": "_c5"}.get(workload)
@@ -1044,6 +1044,7 @@ def main():
                 traffic = round(sum(kk[k]["hbm_bytes"] * kk[k].get("launches_sampled", 1) for k in have) /
                                 sum(kk[k].get("launches_sampled", 1) for k in have))
                 traffic_src = os.path.basename(pj[-1])
+                traffic_commit = json.load(open(pj[-1])).get("taken_at_commit")
         except Exception:
             traffic = None
         whole = {"algorithmic_bytes": Bm["iter"],
@@ -1056,7 +1057,7 @@ def main():
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_achievable": round(ach / HBM_ACHIEVABLE_GBS, 4),
                     "traffic": traffic, "traffic_profiled_in": traffic_src,
-                    "traffic_profiled_at": profile_commit(traffic_src),
+                    "traffic_profiled_at": traffic_commit or profile_commit(traffic_src),
                     "kernel": fam_name,
                     "launches": prof["launches"], "avg_launch_us": round(1e3 * avg_ms, 2),
                     "algorithmic_bytes_per_launch": fam_bytes, "whole_step": whole}

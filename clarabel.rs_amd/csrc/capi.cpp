@@ -757,7 +757,9 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
         if (!runs.empty() && (i64)(runs.size() / 3) * 64 <= (i64)E.NF) {
             if ((rc = E.upload(&h->ir_run_ptr, rp, rp.size()))) return rc;
             if ((rc = E.upload(&h->ir_runs, runs, runs.size()))) return rc;
-            bool sf = E.gfold.ng == 0 && E.ir_tw == 256 && E.bundles.symv_split && E.bundles.nb == E.ir_grid &&
+            // (arrow systems only: a forest without top rows whose bundles qualify did not occur in any test problem -- block-diagonal
+            // problems become grouped folds --, so that path of the kernel stays unreachable rather than untested)
+            bool sf = E.gfold.ng == 0 && E.fold.k >= 1 && E.ir_tw == 256 && E.bundles.symv_split && E.bundles.nb == E.ir_grid &&
                       !switches().no_ir_sf && !switches().no_flat;
             for (int b = 0; b < E.bundles.nb && sf; b++) {
                 const int s0 = S.bundle_ptr[(size_t)b], nloc = S.bundle_ptr[(size_t)b + 1] - s0;

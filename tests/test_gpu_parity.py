@@ -170,6 +170,7 @@ def _solvers(hip, oracle, pr, settings=None, hs=None, late=False):
         ost.ir_reltol = settings.iterative_refinement_reltol
         ost.ir_abstol = settings.iterative_refinement_abstol
         ost.ir_enable = settings.iterative_refinement_enable
+        ost.ir_stop_ratio = settings.iterative_refinement_stop_ratio
         ost.static_reg_enable = settings.static_regularization_enable
     ko = oracle.KKTSolver(pr["n"], pr["m"], pr["P"], pr["A"], cones, settings=ost, perm=ks.perm)
     return ks, ko, cones
@@ -576,6 +577,62 @@ def test_ir_fixed_one_round(hip, oracle):
                               iterative_refinement_abstol=0.0)
     ks, ko = _check_update_and_solve(hip, oracle, problems.portfolio_socp(6, 100, seed=5), settings=st, tol=1e-7)
     assert ks.linear_solver_info().last_ir_iterations == 1 and ko.last_ir_iters == 1
+
+
+@pytest.mark.parametrize("case", ["default", "loose_tol", "three_rounds", "no_refinement", "aliased", "flags0", "old_kernel"])
+def test_fused_solve_iterates_on_chip(hip, oracle, case, monkeypatch):
+    """k_bundle_irs (round 6: one bundle per workgroup, the iterates on chip) through every way it can end: the default
+    settings; a tolerance that round 0 already meets (the verdict arrives at the middle barrier of a speculative round 1 and
+    the result is x0 FROM THE REGISTERS); three forced rounds (candidates that later rounds build on go through xa / xb, x0
+    leaves the registers at round 1); refinement off (one round, the candidate straight to the result vectors); result
+    vectors that ALIAS the right-hand side (no write ahead of the verdict); the kernel's experiment bits off
+    (CHIP_IRS_FLAGS=0); and the same problems on k_bundle_ir (CHIP_NO_IR_SF) -- all against the oracle with the same
+    settings, device vectors in and out, and the refinement rounds taken must equal the oracle's"""
+    pr = problems.portfolio_socp(6, 700, seed=11)
+    kw = {}
+    if case == "loose_tol":
+        kw = dict(iterative_refinement_reltol=1e-3, iterative_refinement_abstol=1e-3)
+    elif case == "three_rounds":
+        kw = dict(iterative_refinement_max_iter=3, iterative_refinement_reltol=0.0, iterative_refinement_abstol=0.0,
+                  iterative_refinement_stop_ratio=0.0)
+    elif case == "no_refinement":
+        kw = dict(iterative_refinement_enable=0)
+    if case == "flags0":
+        monkeypatch.setenv("CHIP_IRS_FLAGS", "0")
+    if case == "old_kernel":
+        monkeypatch.setenv("CHIP_NO_IR_SF", "1")
+    st = hip.Settings.default(**kw) if kw else None
+    ks, ko, cones = _solvers(hip, oracle, pr, settings=st)
+    assert bool(ks.step_kernels() & 4) == (case != "old_kernel")
+    n, m = pr["n"], pr["m"]
+    rng = np.random.default_rng(3)
+    for it in range(2):
+        s_, z_ = pr["s"] * (1.0 + 0.3 * it), pr["z"] / (1.0 + 0.2 * it)
+        assert ks.update_scaling(s_, z_) and ks.update() and cones.update_scaling(s_, z_) and ko.update()
+        rx, rz = rng.standard_normal(n), rng.standard_normal(m)
+        ko.setrhs(rx, rz)
+        ok, xo, zo = ko.solve()
+        assert ok
+        ref = np.concatenate([xo, zo])
+        if case == "aliased":  # one buffer for (rhsx, rhsz) and (lhsx, lhsz)
+            buf = hip.DeviceArray(np.concatenate([rx, rz]))
+            ks.setrhs_dev(buf.ptr, buf.ptr + 8 * n)
+            assert ks.solve_dev(buf.ptr, buf.ptr + 8 * n)
+            got = buf.numpy()
+        else:
+            d_rx, d_rz, out = hip.DeviceArray(rx), hip.DeviceArray(rz), hip.DeviceArray(n + m)
+            ks.setrhs_dev(d_rx.ptr, d_rz.ptr)
+            assert ks.solve_dev(out.ptr, out.ptr + 8 * n)
+            got = out.numpy()
+            assert np.array_equal(d_rx.numpy(), rx) and np.array_equal(d_rz.numpy(), rz)  # (the lent vectors are only read)
+        tol = 1e-5 if case in ("no_refinement", "loose_tol") else TOL
+        assert relerr(got, ref) <= tol, (case, it, relerr(got, ref))
+        assert ks.linear_solver_info().last_ir_iterations == ko.last_ir_iters, (case, ks.linear_solver_info().last_ir_iterations, ko.last_ir_iters)
+        if case == "three_rounds":
+            assert ko.last_ir_iters == 3
+        if case == "loose_tol":
+            assert ko.last_ir_iters == 0
+    assert ks.fused_fallbacks() == 0
 
 
 @pytest.mark.parametrize("which", ["arrow", "forest"])

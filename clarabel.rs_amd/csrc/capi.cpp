@@ -471,15 +471,19 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     if (rc) return rc;
     clk("engine init (uploads)");
     if (K.nnz) { // the device keeps K.nzval in T order (host.hpp: Symbolic::k2v)
-        std::vector<double> vx((size_t)K.nnz);
-        for (i64 u = 0; u < K.nnz; u++) vx[(size_t)u] = K.nzval[(size_t)S.v2k[(size_t)u]];
+        rawvec<double> vx((size_t)K.nnz);
+        run_threads(K.nnz >= (i64)1 << 22 ? host_threads() : 1, [&](int t, int TT) {
+            for (i64 u = K.nnz * t / TT; u < K.nnz * (t + 1) / TT; u++) vx[(size_t)u] = K.nzval[(size_t)S.v2k[(size_t)u]];
+        });
         CHIP_HIP(hipMemcpy(E.Kx, vx.data(), (size_t)K.nnz * sizeof(double), hipMemcpyHostToDevice));
     }
     // every LDLDataMap index the kernels use is translated ONCE into a position of that store
     const bigvec &k2v = S.k2v;
-    auto narrow = [&k2v](const std::vector<i64> &v, size_t cnt) {
-        std::vector<int> o(cnt);
-        for (size_t i = 0; i < cnt; i++) o[i] = k2v[(size_t)v[i]];
+    auto narrow = [&k2v](const auto &v, size_t cnt) { // (by host threads when the map is long: config 5's mapHs has 1.6e8 entries)
+        rawvec<int> o(cnt);
+        run_threads(cnt >= (size_t)1 << 22 ? host_threads() : 1, [&](int t, int TT) {
+            for (size_t i = cnt * (size_t)t / (size_t)TT; i < cnt * (size_t)(t + 1) / (size_t)TT; i++) o[i] = k2v[(size_t)v[i]];
+        });
         return o;
     };
     {
@@ -679,8 +683,11 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
     }
     const size_t nsp = K.sp_ptr.size() ? K.sp_ptr.size() - 1 : 0;
     s_ptr = narrow_plain(K.sp_ptr, nsp + 1);
-    mapU = narrow(K.sp_u, (size_t)(nsp ? K.sp_ptr[nsp] : 0));
-    mapV = narrow(K.sp_v, (size_t)(nsp ? K.sp_ptr[nsp] : 0));
+    {
+        const auto nu = narrow(K.sp_u, (size_t)(nsp ? K.sp_ptr[nsp] : 0)), nv_ = narrow(K.sp_v, (size_t)(nsp ? K.sp_ptr[nsp] : 0));
+        mapU.assign(nu.begin(), nu.end());
+        mapV.assign(nv_.begin(), nv_.end());
+    }
     for (size_t s = 0; s < nsp; s++) {
         mapD.push_back(k2v[(size_t)K.sp_D[3 * s]]);
         mapD.push_back(k2v[(size_t)K.sp_D[3 * s + 1]]);
@@ -840,7 +847,7 @@ int32_t chip_kkt_get_map(const chip_kkt *h, uint64_t *mapP, uint64_t *mapA, uint
                          uint64_t *diag_full, int8_t *dsigns) {
     if (!h) return CHIP_ERR_ARG;
     const KktLayout &K = h->K;
-    auto cp = [](uint64_t *dst, const std::vector<i64> &src, size_t n) {
+    auto cp = [](uint64_t *dst, const auto &src, size_t n) {
         if (dst)
             for (size_t i = 0; i < n; i++) dst[i] = (uint64_t)src[i];
     };

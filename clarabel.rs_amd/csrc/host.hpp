@@ -68,6 +68,7 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
     template <class U, class... Args> void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
 };
 using bigvec = std::vector<i32, NoInitAlloc<i32>>;
+template <class T> using rawvec = std::vector<T, NoInitAlloc<T>>; // (sized, then filled by threads: no zero fill in between)
 
 struct Symbolic {
     i32 N = 0;
@@ -259,10 +260,14 @@ struct KktLayout {
     std::vector<ConeSpec> cones;
     i64 nHs = 0;
     // triu K
-    std::vector<i64> colptr, rowval;
-    std::vector<double> nzval;
+    // (rowval / nzval / mapHs: one entry per entry of K or of the Hs blocks -- config 5: 1.6e8 each --, every slot written exactly
+    // once by assemble_kkt_triu, the cone blocks by several threads: no zero fill)
+    std::vector<i64> colptr;
+    rawvec<i64> rowval;
+    rawvec<double> nzval;
     // LDLDataMap (datamaps.rs:350-362)
-    std::vector<i64> mapP, mapA, mapHs, diagP, diag_full;
+    std::vector<i64> mapP, mapA, diagP, diag_full;
+    rawvec<i64> mapHs;
     // sparse maps, flattened: for sparse cone s the u-entries are
     // sp_u[sp_ptr[s] .. sp_ptr[s]+numel), same for v; D indices sp_D[3*s..]
     std::vector<i64> sp_ptr, sp_u, sp_v, sp_D;

@@ -140,11 +140,14 @@ int assemble_kkt_triu(i64 n, i64 m, const i64 *Pp, const i64 *Pi, const double *
     K.colptr.assign((size_t)N + 1, 0);
     for (i64 j = 0; j < N; j++) K.colptr[j + 1] = K.colptr[j] + len[j];
     K.nnz = K.colptr[N];
-    K.rowval.assign((size_t)K.nnz + 1, 0);
-    K.nzval.assign((size_t)K.nnz + 1, 0.0);
+    K.rowval.resize((size_t)K.nnz + 1); // (no fill: every slot below nnz is written exactly once, checked at the end)
+    K.nzval.resize((size_t)K.nnz + 1);
+    K.rowval[(size_t)K.nnz] = 0;
+    K.nzval[(size_t)K.nnz] = 0.0;
     K.mapP.assign((size_t)nnzP + 1, 0);
     K.mapA.assign((size_t)nnzA + 1, 0);
-    K.mapHs.assign((size_t)K.nHs + 1, 0);
+    K.mapHs.resize((size_t)K.nHs + 1);
+    K.mapHs[(size_t)K.nHs] = 0;
     K.diagP.assign((size_t)n + 1, 0);
     K.diag_full.assign((size_t)N + 1, 0);
     std::vector<i64> wr(K.colptr.begin(), K.colptr.end() - 1); // write cursors
@@ -191,7 +194,12 @@ int assemble_kkt_triu(i64 n, i64 m, const i64 *Pp, const i64 *Pi, const double *
     K.dsigns.assign((size_t)N + 1, 1);
     for (i64 i = n; i < n + m; i++) K.dsigns[i] = -1;
 
-    for (const ConeSpec &c : K.cones) {
+    // the cones' blocks: every cone writes columns of its own only (its rows of the (2, 2) block, its expansion columns),
+    // so the cones are shared out among host threads -- config 5's 200 dense PSD blocks are 1.6e8 of K's entries
+    const int TC = K.nHs >= (i64)1 << 22 ? host_threads() : 1;
+    run_threads(TC, [&](int tc, int TT) {
+    for (size_t ci = (size_t)tc; ci < K.cones.size(); ci += (size_t)TT) {
+        const ConeSpec &c = K.cones[ci];
         const i64 row0 = n + c.start;
         i64 h = c.block_start;
         if (c.hs_diag) {
@@ -224,6 +232,7 @@ int assemble_kkt_triu(i64 n, i64 m, const i64 *Pp, const i64 *Pi, const double *
             K.dsigns[col + 2] = 1;
         }
     }
+    });
     for (i64 j = 0; j < N; j++) {
         if (wr[j] != K.colptr[j + 1]) {
             set_error("internal: KKT column fill mismatch");

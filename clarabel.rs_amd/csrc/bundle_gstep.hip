@@ -391,18 +391,18 @@ void k_gstep_solve(LdlView v, BundleView bv, IrView ir, GFoldView gf, GStepView 
     // the k x k top part of both sweeps (every workgroup of the group alike): rhs - (the group's forward shares)
     auto top_solve = [&](int round) {
         if (tid == 0) {
-            double y[8];
+            // (y in LDS, st.dxt: a private array indexed by a loop variable lives in scratch memory -- its reloads sat on
+            // the critical path of every round; round 6, found on k_bundle_irs)
             for (int i = 0; i < k; ++i) {
                 double sacc = (round == 0 ? st.btop[i] : st.rtop[i]) - st.fsum[i];
-                for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * y[j];
-                y[i] = sacc;
+                for (int j = 0; j < i; ++j) sacc -= st.ltt[i * 8 + j] * st.dxt[j];
+                st.dxt[i] = sacc;
             }
             for (int i = k - 1; i >= 0; --i) {
-                double sacc = y[i] * st.dinvt[i];
-                for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * y[j];
-                y[i] = sacc;
+                double sacc = st.dxt[i] * st.dinvt[i];
+                for (int j = i + 1; j < k; ++j) sacc -= st.ltt[j * 8 + i] * st.dxt[j];
+                st.dxt[i] = sacc;
             }
-            for (int i = 0; i < k; ++i) st.dxt[i] = y[i];
         }
     };
     // top rows of the residual of the candidate in st.candt from the group's residual shares st.rsum -> st.rtop;

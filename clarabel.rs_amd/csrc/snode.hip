@@ -4,6 +4,7 @@
 #include "dev_common.hpp"
 #include "grid_sync.hpp"
 #include "snode_common.hpp"
+#include <type_traits>
 
 namespace chip {
 namespace dev {
@@ -338,6 +339,234 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
     snode_tiles<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SN_NB, g.nb - c0), kend, row_begin, kbeg);
 }
+// ---------------------------------------------------------------------------
+// Wide tiles for the ancestors' update of levels with many supernodes (round 6): k_snode_extend_wide.
+//
+// A wave owns 16 rows x 256 columns (sixteen accumulator tiles, 128 registers): an A operand (an entry of the panel,
+// read from HBM) feeds 16 matrix instructions instead of 4.  The (d L)' operand of the 256 target columns is staged per
+// 32 k rows, double buffered in LDS by the workgroup itself -- the next chunk's entries are requested before the
+// current chunk's matrix instructions and written behind them, one LDS barrier per chunk -- because with 2 x 64 KiB of
+// LDS and 256 registers ONE workgroup of eight waves fits a CU and nothing else would cover its staging (what made
+// round 5's 128-column update slower).  All tiles of a supernode stage the same operand: the launch places a
+// supernode's workgroups on one XCD so that they find it in its L2.  tools/micro/mfma_f64_probe.hip: with two waves per
+// SIMD, 16 accumulators and one ds_read_b64 per matrix instruction the matrix cores reach 77.5 of their 78.6 TFLOP/s.
+// Config 5's leaf level (200 supernodes, 903 rows of B, 1275 member columns): 6.4 ms against 8.5 with the 64-column
+// tiles, although the 128 x 256 tiles compute 1.6 x the triangle's useful area (1.28 x with 256 x 64) -- per executed
+// flop 0.66 against 0.40 of the matrix peak.  The same form for the update of a panel's own block columns (the columns
+// before a group of four applied to all four, k_snode_update with the group's own columns in between) was measured
+// and not kept: 8.6 + 3.6 ms against 11.1 -- the short launches for the columns inside a group cost what the wide
+// tiles save.
+// ---------------------------------------------------------------------------
+constexpr int SNW_NC = 256;   // target columns of a wide tile
+constexpr int SNW_KC = 32;    // k rows per LDS buffer: 32 * 256 * 8 = 64 KiB
+constexpr int SNW_U = 4;      // k-groups of A operands in flight per lane
+constexpr int SNW_ROWS = 128; // panel rows per workgroup: 8 waves x 16
+constexpr int SNW_SR = SNW_KC / (SN_WG / 64); // k rows a wave stages per chunk
+
+// element (k row kl, column j) of a staged buffer: odd k rows swap the halves of every 32-column group, so that the
+// four k rows a matrix instruction's B operand takes (lanes 16 q .. 16 q + 15 = row kq) hit disjoint banks pairwise
+__device__ __forceinline__ int snw_at(int kl, int j) { return kl * SNW_NC + (j ^ ((kl & 1) << 4)); }
+
+// (kl = KOFF + kq with KOFF even: the swizzle bit is the lane's kq & 1, so the sixteen operands of a k-group sit at
+// compile-time offsets from two per-lane pointers -- pe for even c, po for odd c)
+template <int NCW, int KOFF>
+__device__ __forceinline__ void snw_group(snode_v4d (&acc)[SNW_NC / 16], double a, const double *pe, const double *po) {
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) {
+        const double bw = ((c & 1) ? po : pe)[KOFF * SNW_NC + 16 * c];
+        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bw, acc[c], 0, 0, 0);
+    }
+}
+
+// one 16 x 64 slice of a wave's tile leaves through the wave's 8 KiB of LDS, transposed (see snode_tiles)
+template <bool EXTEND>
+__device__ __forceinline__ void snw_emit_slice(const LdlView &v, const SnodeView &sv, const SnodeGeom &g, int sn,
+                                               const int *colbase, double *Tw, const snode_v4d *acc4, int jbase,
+                                               int nc, int i0, bool atomic_emit, int lane) {
+    const int kq = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jj = l15 + 16 * c, rr = kq + 4 * r;
+            Tw[jj * 16 + (rr ^ l15)] = acc4[c][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    const int i = i0 + l15; // lane = row of the tile; an instruction covers columns 4 m + kq
+    if (i < g.h) {
+        if (!EXTEND && !atomic_emit) {
+            double cur[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int jj = 4 * m + kq, j = jbase + jj;
+                cur[m] = (jj < nc && i > j) ? v.Lx[colbase[j] + i] : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int jj = 4 * m + kq, j = jbase + jj;
+                if (jj >= nc) continue;
+                const double val = Tw[jj * 16 + (l15 ^ (jj & 15))];
+                if (i > j) v.Lx[colbase[j] + i] = cur[m] - val;
+                else if (i == j) v.D[g.cols[j]] -= val;
+            }
+        } else if (!EXTEND) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int jj = 4 * m + kq, j = jbase + jj;
+                if (jj >= nc) continue;
+                const double val = Tw[jj * 16 + (l15 ^ (jj & 15))];
+                if (i > j) atomicAdd(&v.Lx[colbase[j] + i], -val);
+                else if (i == j) atomicAdd(&v.D[g.cols[j]], -val);
+            }
+        } else {
+            const int rB = i - g.w;
+            const int *Bn = v.Li + v.Lp[g.e];
+            if (sv.U) {
+                double *Us = sv.U + sv.asm_uoff[sn];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const int jj = 4 * m + kq, cB = jbase + jj - g.w;
+                    if (jj >= nc) continue;
+                    const double val = Tw[jj * 16 + (l15 ^ (jj & 15))];
+                    if (rB > cB) Us[(long long)cB * g.nb - (long long)cB * (cB + 1) / 2 + (rB - cB - 1)] = val;
+                    else if (rB == cB) sv.Ud[sv.asm_doff[sn] + cB] = val;
+                }
+            } else {
+                const long long ubase = sv.upd_ptr[sn];
+#pragma unroll
+                for (int m0 = 0; m0 < 16; m0 += 8) {
+                    int slot[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int jj = 4 * (m0 + m) + kq, cB = jbase + jj - g.w;
+                        const bool lower = jj < nc && rB > cB;
+                        slot[m] = lower ? sv.upd_slot[ubase + (long long)cB * g.nb - (long long)cB * (cB + 1) / 2 + (rB - cB - 1)] : -1;
+                    }
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int jj = 4 * (m0 + m) + kq, cB = jbase + jj - g.w;
+                        const double val = Tw[jj * 16 + (l15 ^ (jj & 15))];
+                        if (slot[m] >= 0) atomicAdd(&v.Lx[slot[m]], -val);
+                        else if (jj < nc && rB == cB) atomicAdd(&v.D[Bn[cB]], -val);
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier(); // (the next slice overwrites Tw)
+}
+
+// acc[16 rows of this wave, 256 columns from jrow0] += L[rows, kbeg..kend) (d L[jrow0.., k])'; emitted per element.
+// Wl: two buffers of SNW_KC x SNW_NC doubles.
+template <bool EXTEND>
+__device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeView &sv, const SnodeGeom &g, int sn,
+                                                 const int *colbase, double *Wl, int jrow0, int ncols, int kend,
+                                                 int row_begin, int kbeg, bool atomic_emit) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4, l15 = lane & 15;
+    const int i0 = row_begin + wave * 16;
+    const int irc = min(i0 + l15, g.h - 1); // (clamped: a row beyond the panel reads the last row, never emitted)
+    const bool wave_live = i0 < g.h;
+    // tiles at or below the diagonal only: columns jrow0 + 16 c <= i0 + 15
+    const int ncw = min((ncols + 15) / 16, (i0 + 15 - jrow0) / 16 + 1);
+    snode_v4d acc[SNW_NC / 16];
+#pragma unroll
+    for (int c = 0; c < SNW_NC / 16; ++c) acc[c] = snode_v4d{0.0, 0.0, 0.0, 0.0};
+    double a[SNW_U];
+    auto request = [&](int u, int kabs) { a[u] = v.Lx[colbase[min(kabs + kq, kend - 1)] + irc]; };
+    // the staged operand: this wave's SNW_SR k rows of a chunk, the 256 columns as four runs of 64 lanes
+    double wv[SNW_SR][4], dv[SNW_SR];
+    auto stage_request = [&](int kc0) {
+#pragma unroll
+        for (int r = 0; r < SNW_SR; ++r) {
+            const int k = min(kc0 + wave + r * (SN_WG / 64), kend - 1); // (clamped: no branch per load)
+            const int cb = colbase[k] + jrow0;
+            dv[r] = g.d[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[r][q] = v.Lx[cb + min(lane + 64 * q, ncols - 1)];
+        }
+    };
+    auto stage_commit = [&](double *Wb, int kc0) {
+#pragma unroll
+        for (int r = 0; r < SNW_SR; ++r) {
+            const int kl = wave + r * (SN_WG / 64);
+            const bool kok = kc0 + kl < kend;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Wb[snw_at(kl, lane + 64 * q)] = (kok && lane + 64 * q < ncols) ? wv[r][q] * dv[r] : 0.0;
+        }
+    };
+    lds_barrier(); // (the caller has just filled colbase)
+    if (kbeg < kend) {
+        stage_request(kbeg);
+        if (wave_live) {
+#pragma unroll
+            for (int u = 0; u < SNW_U; ++u) request(u, kbeg + 4 * u);
+        }
+        stage_commit(Wl, kbeg);
+    }
+    lds_barrier();
+    int buf = 0;
+    for (int kc0 = kbeg; kc0 < kend; kc0 += SNW_KC, buf ^= 1) {
+        const bool more = kc0 + SNW_KC < kend;
+        if (more) stage_request(kc0 + SNW_KC);
+        const double *Wb = Wl + buf * (SNW_KC * SNW_NC);
+        if (wave_live) {
+            // (whole chunks: rows beyond kend are stored zeros, the A operands there clamped to valid entries)
+            const int swz = (kq & 1) << 4;
+            const double *pe = Wb + kq * SNW_NC + l15 + swz, *po = Wb + kq * SNW_NC + l15 - swz;
+            auto chunk = [&](auto nc) {
+                constexpr int NCW = decltype(nc)::value;
+                static_assert(SNW_KC == 8 * SNW_U, "two rounds of the operand ring per chunk");
+#define SNW_G(KK, UU) snw_group<NCW, KK + 4 * UU>(acc, a[UU], pe, po); request(UU, kc0 + KK + 4 * UU + 4 * SNW_U);
+                SNW_G(0, 0) SNW_G(0, 1) SNW_G(0, 2) SNW_G(0, 3)
+                SNW_G(16, 0) SNW_G(16, 1) SNW_G(16, 2) SNW_G(16, 3)
+#undef SNW_G
+            };
+            if (ncw > 12) chunk(std::integral_constant<int, 16>{});
+            else if (ncw > 8) chunk(std::integral_constant<int, 12>{});
+            else if (ncw > 4) chunk(std::integral_constant<int, 8>{});
+            else chunk(std::integral_constant<int, 4>{});
+        }
+        if (more) stage_commit(Wl + (buf ^ 1) * (SNW_KC * SNW_NC), kc0 + SNW_KC);
+        lds_barrier();
+    }
+    if (!wave_live) return;
+    double *Tw = Wl + wave * (16 * SN_NB);
+#pragma unroll
+    for (int cs = 0; cs < SNW_NC / SN_NB; ++cs) {
+        if (4 * cs >= ncw) break;
+        snw_emit_slice<EXTEND>(v, sv, g, sn, colbase, Tw, &acc[4 * cs], jrow0 + cs * SN_NB,
+                               min(SN_NB, ncols - cs * SN_NB), i0, atomic_emit, lane);
+    }
+}
+
+__device__ __forceinline__ int *snode_lds_wide(char *smem, double *&Wl) {
+    Wl = (double *)smem;
+    return (int *)(Wl + 2 * SNW_KC * SNW_NC);
+}
+// the ancestors' update in 128 x 256 tiles: gx row groups x gy column blocks x ks shares of the member columns
+__global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_snode_extend_wide(LdlView v, SnodeView sv, const int *__restrict__ order, int gx, int gy, int count, int ks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Wl;
+    int *colbase = snode_lds_wide(smem, Wl);
+    const int id = (int)blockIdx.x, r = id & 7, q = id >> 3, T = gx * gy * ks, tile = q % T, rem = tile % (gx * gy);
+    const int bz = 8 * (q / T) + r;
+    if (bz >= count) return;
+    const int ksi = tile / (gx * gy), by = rem / gx, bx = rem % gx;
+    int sn;
+    const SnodeGeom g = snode_geom(sv, order, bz, sn);
+    const int c0 = by * SNW_NC;
+    if (c0 >= g.nb) return;
+    const int row_begin = g.w + bx * SNW_ROWS;
+    if (row_begin >= g.h || row_begin + SNW_ROWS <= g.w + c0) return; // (beyond the panel / above the diagonal)
+    const int nunits = (g.w + SN_NB - 1) / SN_NB;
+    const int kbeg = (int)(((long long)nunits * ksi) / ks) * SN_NB, kend = min(g.w, (int)(((long long)nunits * (ksi + 1)) / ks) * SN_NB);
+    if (kbeg >= kend) return;
+    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
+    snode_tiles_wide<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SNW_NC, g.nb - c0), kend, row_begin, kbeg, false);
+}
+
 // grid (target columns of the level): the update matrices the level's supernodes left in U, summed per target column
 // in LDS -- source after source, a barrier between them: two sources may hit the same row from different threads --
 // and subtracted from the column once.  The sums have a fixed order (the sources are sorted by supernode on the host):
@@ -1765,11 +1994,15 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
 static size_t snode_solve_lds_bytes(int wmax, int nbcap) {
     return (size_t)(wmax + nbcap + SN_NB * SN_NB + SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int);
 }
+constexpr size_t SNW_LDS_MAX = (size_t)160 * 1024;
+static size_t snode_lds_wide_bytes(int wmax) { return (size_t)2 * SNW_KC * SNW_NC * sizeof(double) + (size_t)wmax * sizeof(int); }
 static size_t snode_lds_bytes(int wmax) { return (size_t)(SN_KC * SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int); }
 int snode_kernel_attributes(int wmax, int nbmax) {
     const int lds = (int)snode_lds_bytes(wmax);
     int rc = (int)raise_dynamic_lds((const void *)k_snode_update, (size_t)lds);
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_extend, (size_t)lds);
+    const size_t ldsw = snode_lds_wide_bytes(wmax);
+    if (!rc && ldsw <= SNW_LDS_MAX) rc = (int)raise_dynamic_lds((const void *)k_snode_extend_wide, ldsw);
     const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<true>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<false>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
@@ -1985,13 +2218,20 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
         pb(PFK_SN_EXTEND);
         SnodeView se = sv_in;
         if (!av || !av->nt) se.U = nullptr; // (this level scatters with atomics)
-        const int gx = (nbmax + SN_ROWS - 1) / SN_ROWS, gy = (nbmax + SN_NB - 1) / SN_NB;
-        const bool xcd = count >= 8 && !switches().no_xcd_map; // (fewer supernodes than XCDs: spread the tiles)
-        int ks = 1; // k-split of the tiles while the launch would leave most of the chip idle (atomics only: not with the assembled form)
-        if (!se.U && !switches().no_splitk && !switches().deterministic)
-            while (ks < 8 && ks * 2 <= nblk && (long long)gx * gy * count * ks * 2 <= 512) ks *= 2;
-        if (xcd) k_snode_extend<<<dim3((unsigned)(8 * ((count + 7) / 8) * gx * gy * ks)), SN_WG, lds, s>>>(v, se, order, 1, gx, gy, count, ks);
-        else k_snode_extend<<<dim3(gx * ks, gy, count), SN_WG, lds, s>>>(v, se, order, 0, gx, gy, count, ks);
+        // levels with at least one supernode per XCD and more than one wide column block: 128 x 256 tiles
+        const size_t lds_wide = snode_lds_wide_bytes(wmax_all);
+        if (lds_wide <= SNW_LDS_MAX && count >= switches().sn_wide_min_count && nbmax > SNW_NC && !switches().no_sn_wide) {
+            const int gx = (nbmax + SNW_ROWS - 1) / SNW_ROWS, gy = (nbmax + SNW_NC - 1) / SNW_NC;
+            k_snode_extend_wide<<<dim3((unsigned)(8 * ((count + 7) / 8) * gx * gy)), SN_WG, lds_wide, s>>>(v, se, order, gx, gy, count, 1);
+        } else {
+            const int gx = (nbmax + SN_ROWS - 1) / SN_ROWS, gy = (nbmax + SN_NB - 1) / SN_NB;
+            const bool xcd = count >= 8 && !switches().no_xcd_map; // (fewer supernodes than XCDs: spread the tiles)
+            int ks = 1; // k-split of the tiles while the launch would leave most of the chip idle (atomics only: not with the assembled form)
+            if (!se.U && !switches().no_splitk && !switches().deterministic)
+                while (ks < 8 && ks * 2 <= nblk && (long long)gx * gy * count * ks * 2 <= 512) ks *= 2;
+            if (xcd) k_snode_extend<<<dim3((unsigned)(8 * ((count + 7) / 8) * gx * gy * ks)), SN_WG, lds, s>>>(v, se, order, 1, gx, gy, count, ks);
+            else k_snode_extend<<<dim3(gx * ks, gy, count), SN_WG, lds, s>>>(v, se, order, 0, gx, gy, count, ks);
+        }
         if (se.U) {
             const int cap = switches().sn_asm_cap > 0 ? std::min(switches().sn_asm_cap, SNA_CAP) : SNA_CAP; // (tests: short windows)
             k_snode_assemble<<<av->nt, SNA_WG, 0, s>>>(v, se, *av, cap);

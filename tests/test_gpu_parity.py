@@ -1869,6 +1869,37 @@ def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
         assert np.array_equal(Da, Db) and np.array_equal(Lxa, Lxb)
 
 
+@pytest.mark.parametrize("emit", ["atomics", "assembled"])
+def test_ancestor_updates_in_wide_tiles(hip, oracle, emit, monkeypatch):
+    """k_snode_extend_wide (128 x 256 tiles, a wave 16 rows x 256 columns, the staged operand double buffered) against
+    the 256 x 64 tiles of k_snode_extend on supernodes with more than 256 rows of B -- a last column block narrower than
+    256, row groups that end inside a tile, tiles on and above the diagonal: each against the oracle, their factors
+    against each other; with both ways the tiles leave (fp64 atomics / stores into the per-target-column assembly).
+    CHIP_SN_WIDE_MIN_COUNT=1: on levels of any size (default: from eight supernodes on)."""
+    pr = problems.chordal_sdp(4, 40, 24, 2, 9, seed=11)  # (supernodes of 820 columns with 316 / 616 rows of B)
+    hs = pr["hsblocks"]
+    monkeypatch.setenv("CHIP_SN_WIDE_MIN_COUNT", "1")
+    monkeypatch.setenv("CHIP_NO_EXTEND_ASM" if emit == "atomics" else "CHIP_EXTEND_ASM_MIN", "1" if emit == "atomics" else "2")
+    factors = {}
+    for form in ("wide", "CHIP_NO_SN_WIDE"):
+        if form != "wide":
+            monkeypatch.setenv(form, "1")
+        ks, ko = _check_update_and_solve(hip, oracle, pr, hs=hs, nrhs=1)
+        sns = ks.supernodes()
+        et, Lp, Li, lv = ks.symbolic()
+        cnt = np.diff(Lp)
+        assert max(int(cnt[c[-1]]) for c in sns) > 256  # rows of B of the widest update: more than one wide column block
+        K = ks.kkt_matrix()
+        Kc = hip.CscMatrix(ks.N, ks.N, K.colptr, K.rowval, ks.values())
+        f = hip.HipDirectLDLSolver(Kc, ks.maps()["dsigns"], hip.Settings.default(), perm=ks.perm)
+        f.refactor()
+        _, _, Lx, D, _ = f.factors()
+        factors[form] = (Lx, D)
+    (Lxa, Da), (Lxb, Db) = factors["wide"], factors["CHIP_NO_SN_WIDE"]
+    assert relerr(Da, Db) <= 1e-10
+    assert np.max(np.abs(Lxa - Lxb)) <= 1e-10 * max(1.0, np.max(np.abs(Lxa)))
+
+
 @pytest.mark.parametrize("which", ["banded_qp", "chordal_sdp", "chordal_sdp_long_columns"])
 def test_ancestor_updates_assembled_per_target_column(hip, oracle, which, monkeypatch):
     """a unit level's update matrices written to a private buffer and summed per target column (k_snode_assemble, a

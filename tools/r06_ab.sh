@@ -10,7 +10,8 @@ for st in $SETS; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d.get('roofline') or {}
-print('%-40s ms/step %.4f  it/s %8.2f  launch_us %s' % ('$st', d['ms_per_step'], d['value'], r.get('avg_launch_us')))
+p=d.get('parity') or {}
+print('%-40s ms/step %.4f  it/s %8.2f  launch_us %s  parity %s %s' % ('$st', d['ms_per_step'], d['value'], r.get('avg_launch_us'), p.get('ok'), p.get('rel_err_vs_oracle')))
 " | tee -a $O/${TAG}_ab.txt
 done
 done

@@ -1971,8 +1971,8 @@ __global__ __launch_bounds__(SN2_WG) void k_snode_tri(LdlView v, SnodeView sv, c
             double sacc[NR];
 #pragma unroll
             for (int k = 0; k < NR; ++k) sacc[k] = 0.0;
-#pragma unroll
-            for (int j2 = 0; j2 < SN_NB; j2 += 16) {
+#pragma unroll 1
+            for (int j2 = 0; j2 < SN_NB; j2 += 16) { // (not unrolled: 64 entries in flight per thread took 255 registers -- one workgroup per CU for the whole kernel)
                 double lv2[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) lv2[q] = (j2 + q < nbw) ? v.Lx[cbr[j2 + q] + g.w + rb] : 0.0;

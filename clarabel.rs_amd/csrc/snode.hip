@@ -358,10 +358,9 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 // tiles save.
 // ---------------------------------------------------------------------------
 constexpr int SNW_NC = 256;   // target columns of a wide tile
-constexpr int SNW_KC = 32;    // k rows per LDS buffer: 32 * 256 * 8 = 64 KiB
+// (k rows per LDS buffer: four per wave of the workgroup -- 8 waves: 32 * 256 * 8 = 64 KiB, 4 waves: 32 KiB)
 constexpr int SNW_U = 4;      // k-groups of A operands in flight per lane
-constexpr int SNW_ROWS = 128; // panel rows per workgroup: 8 waves x 16
-constexpr int SNW_SR = SNW_KC / (SN_WG / 64); // k rows a wave stages per chunk
+constexpr int SNW_SR = 4;     // k rows a wave stages per chunk
 
 // element (k row kl, column j) of a staged buffer: odd k rows swap the halves of every 32-column group, so that the
 // four k rows a matrix instruction's B operand takes (lanes 16 q .. 16 q + 15 = row kq) hit disjoint banks pairwise
@@ -458,10 +457,11 @@ __device__ __forceinline__ void snw_emit_slice(const LdlView &v, const SnodeView
 
 // acc[16 rows of this wave, 256 columns from jrow0] += L[rows, kbeg..kend) (d L[jrow0.., k])'; emitted per element.
 // Wl: two buffers of SNW_KC x SNW_NC doubles.
-template <bool EXTEND>
+template <bool EXTEND, int NW>
 __device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeView &sv, const SnodeGeom &g, int sn,
                                                  const int *colbase, double *Wl, int jrow0, int ncols, int kend,
                                                  int row_begin, int kbeg, bool atomic_emit) {
+    constexpr int SNW_KC = SNW_SR * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, l15 = lane & 15;
     const int i0 = row_begin + wave * 16;
@@ -479,7 +479,7 @@ __device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeVi
     auto stage_request = [&](int kc0) {
 #pragma unroll
         for (int r = 0; r < SNW_SR; ++r) {
-            const int k = min(kc0 + wave + r * (SN_WG / 64), kend - 1); // (clamped: no branch per load)
+            const int k = min(kc0 + wave + r * NW, kend - 1); // (clamped: no branch per load)
             const int cb = colbase[k] + jrow0;
             dv[r] = g.d[k];
 #pragma unroll
@@ -489,7 +489,7 @@ __device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeVi
     auto stage_commit = [&](double *Wb, int kc0) {
 #pragma unroll
         for (int r = 0; r < SNW_SR; ++r) {
-            const int kl = wave + r * (SN_WG / 64);
+            const int kl = wave + r * NW;
             const bool kok = kc0 + kl < kend;
 #pragma unroll
             for (int q = 0; q < 4; ++q) Wb[snw_at(kl, lane + 64 * q)] = (kok && lane + 64 * q < ncols) ? wv[r][q] * dv[r] : 0.0;
@@ -516,10 +516,10 @@ __device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeVi
             const double *pe = Wb + kq * SNW_NC + l15 + swz, *po = Wb + kq * SNW_NC + l15 - swz;
             auto chunk = [&](auto nc) {
                 constexpr int NCW = decltype(nc)::value;
-                static_assert(SNW_KC == 8 * SNW_U, "two rounds of the operand ring per chunk");
+                static_assert(SNW_KC == 4 * SNW_U || SNW_KC == 8 * SNW_U, "one or two rounds of the operand ring per chunk");
 #define SNW_G(KK, UU) snw_group<NCW, KK + 4 * UU>(acc, a[UU], pe, po); request(UU, kc0 + KK + 4 * UU + 4 * SNW_U);
                 SNW_G(0, 0) SNW_G(0, 1) SNW_G(0, 2) SNW_G(0, 3)
-                SNW_G(16, 0) SNW_G(16, 1) SNW_G(16, 2) SNW_G(16, 3)
+                if (SNW_KC == 8 * SNW_U) { SNW_G(16, 0) SNW_G(16, 1) SNW_G(16, 2) SNW_G(16, 3) }
 #undef SNW_G
             };
             if (ncw > 12) chunk(std::integral_constant<int, 16>{});
@@ -540,16 +540,19 @@ __device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeVi
     }
 }
 
-__device__ __forceinline__ int *snode_lds_wide(char *smem, double *&Wl) {
+template <int NW> __device__ __forceinline__ int *snode_lds_wide(char *smem, double *&Wl) {
     Wl = (double *)smem;
-    return (int *)(Wl + 2 * SNW_KC * SNW_NC);
+    return (int *)(Wl + 2 * SNW_SR * NW * SNW_NC);
 }
-// the ancestors' update in 128 x 256 tiles: gx row groups x gy column blocks x ks shares of the member columns
-__global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// the ancestors' update in (16 NW) x 256 tiles: gx row groups x gy column blocks x ks shares of the member columns.
+// NW = 8: one workgroup per CU (2 x 64 KiB of LDS); NW = 4: two (2 x 32 KiB each), the other one's matrix instructions
+// cover a workgroup's first loads, its barriers and the way its tiles leave.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_snode_extend_wide(LdlView v, SnodeView sv, const int *__restrict__ order, int gx, int gy, int count, int ks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Wl;
-    int *colbase = snode_lds_wide(smem, Wl);
+    int *colbase = snode_lds_wide<NW>(smem, Wl);
     const int id = (int)blockIdx.x, r = id & 7, q = id >> 3, T = gx * gy * ks, tile = q % T, rem = tile % (gx * gy);
     const int bz = 8 * (q / T) + r;
     if (bz >= count) return;
@@ -558,13 +561,13 @@ void k_snode_extend_wide(LdlView v, SnodeView sv, const int *__restrict__ order,
     const SnodeGeom g = snode_geom(sv, order, bz, sn);
     const int c0 = by * SNW_NC;
     if (c0 >= g.nb) return;
-    const int row_begin = g.w + bx * SNW_ROWS;
-    if (row_begin >= g.h || row_begin + SNW_ROWS <= g.w + c0) return; // (beyond the panel / above the diagonal)
+    const int row_begin = g.w + bx * (16 * NW);
+    if (row_begin >= g.h || row_begin + 16 * NW <= g.w + c0) return; // (beyond the panel / above the diagonal)
     const int nunits = (g.w + SN_NB - 1) / SN_NB;
     const int kbeg = (int)(((long long)nunits * ksi) / ks) * SN_NB, kend = min(g.w, (int)(((long long)nunits * (ksi + 1)) / ks) * SN_NB);
     if (kbeg >= kend) return;
-    for (int t = threadIdx.x; t < g.w; t += SN_WG) colbase[t] = g.cb[t];
-    snode_tiles_wide<true>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SNW_NC, g.nb - c0), kend, row_begin, kbeg, false);
+    for (int t = threadIdx.x; t < g.w; t += 64 * NW) colbase[t] = g.cb[t];
+    snode_tiles_wide<true, NW>(v, sv, g, sn, colbase, Wl, g.w + c0, min(SNW_NC, g.nb - c0), kend, row_begin, kbeg, false);
 }
 
 // grid (target columns of the level): the update matrices the level's supernodes left in U, summed per target column
@@ -1995,14 +1998,14 @@ static size_t snode_solve_lds_bytes(int wmax, int nbcap) {
     return (size_t)(wmax + nbcap + SN_NB * SN_NB + SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int);
 }
 constexpr size_t SNW_LDS_MAX = (size_t)160 * 1024;
-static size_t snode_lds_wide_bytes(int wmax) { return (size_t)2 * SNW_KC * SNW_NC * sizeof(double) + (size_t)wmax * sizeof(int); }
+static size_t snode_lds_wide_bytes(int wmax, int nw) { return (size_t)2 * SNW_SR * nw * SNW_NC * sizeof(double) + (size_t)wmax * sizeof(int); }
 static size_t snode_lds_bytes(int wmax) { return (size_t)(SN_KC * SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int); }
 int snode_kernel_attributes(int wmax, int nbmax) {
     const int lds = (int)snode_lds_bytes(wmax);
     int rc = (int)raise_dynamic_lds((const void *)k_snode_update, (size_t)lds);
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_extend, (size_t)lds);
-    const size_t ldsw = snode_lds_wide_bytes(wmax);
-    if (!rc && ldsw <= SNW_LDS_MAX) rc = (int)raise_dynamic_lds((const void *)k_snode_extend_wide, ldsw);
+    if (!rc && snode_lds_wide_bytes(wmax, 8) <= SNW_LDS_MAX) rc = (int)raise_dynamic_lds((const void *)k_snode_extend_wide<8>, snode_lds_wide_bytes(wmax, 8));
+    if (!rc && snode_lds_wide_bytes(wmax, 4) <= SNW_LDS_MAX) rc = (int)raise_dynamic_lds((const void *)k_snode_extend_wide<4>, snode_lds_wide_bytes(wmax, 4));
     const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<true>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<false>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
@@ -2219,10 +2222,13 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
         SnodeView se = sv_in;
         if (!av || !av->nt) se.U = nullptr; // (this level scatters with atomics)
         // levels with at least one supernode per XCD and more than one wide column block: 128 x 256 tiles
-        const size_t lds_wide = snode_lds_wide_bytes(wmax_all);
+        const int nw = switches().sn_wide_waves == 8 ? 8 : 4;
+        const size_t lds_wide = snode_lds_wide_bytes(wmax_all, nw);
         if (lds_wide <= SNW_LDS_MAX && count >= switches().sn_wide_min_count && nbmax > SNW_NC && !switches().no_sn_wide) {
-            const int gx = (nbmax + SNW_ROWS - 1) / SNW_ROWS, gy = (nbmax + SNW_NC - 1) / SNW_NC;
-            k_snode_extend_wide<<<dim3((unsigned)(8 * ((count + 7) / 8) * gx * gy)), SN_WG, lds_wide, s>>>(v, se, order, gx, gy, count, 1);
+            const int gx = (nbmax + 16 * nw - 1) / (16 * nw), gy = (nbmax + SNW_NC - 1) / SNW_NC;
+            const dim3 grid((unsigned)(8 * ((count + 7) / 8) * gx * gy));
+            if (nw == 8) k_snode_extend_wide<8><<<grid, 512, lds_wide, s>>>(v, se, order, gx, gy, count, 1);
+            else k_snode_extend_wide<4><<<grid, 256, lds_wide, s>>>(v, se, order, gx, gy, count, 1);
         } else {
             const int gx = (nbmax + SN_ROWS - 1) / SN_ROWS, gy = (nbmax + SN_NB - 1) / SN_NB;
             const bool xcd = count >= 8 && !switches().no_xcd_map; // (fewer supernodes than XCDs: spread the tiles)

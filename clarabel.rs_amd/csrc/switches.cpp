@@ -78,6 +78,7 @@ const Entry TABLE[] = {
     {"CHIP_NO_XCD_MAP", Entry::FLAG, SW(no_xcd_map), 0},
     {"CHIP_NO_SN_WIDE", Entry::FLAG, SW(no_sn_wide), 0},
     {"CHIP_SN_WIDE_MIN_COUNT", Entry::INT, SW(sn_wide_min_count), 0},
+    {"CHIP_SN_WIDE_WAVES", Entry::INT, SW(sn_wide_waves), 0},
     {"CHIP_SN_ASM_CAP", Entry::INT, SW(sn_asm_cap), 0},
     {"CHIP_NO_FACTOR_OVERLAP", Entry::FLAG, SW(no_factor_overlap), 0},
     {"CHIP_NO_SOLVE_PAIR", Entry::FLAG, SW(no_solve_pair), 0},

@@ -1869,9 +1869,10 @@ def test_chain_supernodes_fallback_forms(hip, oracle, which, form, monkeypatch):
         assert np.array_equal(Da, Db) and np.array_equal(Lxa, Lxb)
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("emit", ["atomics", "assembled"])
-def test_ancestor_updates_in_wide_tiles(hip, oracle, emit, monkeypatch):
-    """k_snode_extend_wide (128 x 256 tiles, a wave 16 rows x 256 columns, the staged operand double buffered) against
+def test_ancestor_updates_in_wide_tiles(hip, oracle, emit, waves, monkeypatch):
+    """k_snode_extend_wide (64 x 256 / 128 x 256 tiles: four / eight waves of 16 rows x 256 columns, the staged operand double buffered) against
     the 256 x 64 tiles of k_snode_extend on supernodes with more than 256 rows of B -- a last column block narrower than
     256, row groups that end inside a tile, tiles on and above the diagonal: each against the oracle, their factors
     against each other; with both ways the tiles leave (fp64 atomics / stores into the per-target-column assembly).
@@ -1879,6 +1880,7 @@ def test_ancestor_updates_in_wide_tiles(hip, oracle, emit, monkeypatch):
     pr = problems.chordal_sdp(4, 40, 24, 2, 9, seed=11)  # (supernodes of 820 columns with 316 / 616 rows of B)
     hs = pr["hsblocks"]
     monkeypatch.setenv("CHIP_SN_WIDE_MIN_COUNT", "1")
+    monkeypatch.setenv("CHIP_SN_WIDE_WAVES", str(waves))
     monkeypatch.setenv("CHIP_NO_EXTEND_ASM" if emit == "atomics" else "CHIP_EXTEND_ASM_MIN", "1" if emit == "atomics" else "2")
     factors = {}
     for form in ("wide", "CHIP_NO_SN_WIDE"):

@@ -123,50 +123,64 @@ __device__ __forceinline__ void snode_tiles(const LdlView &v, const SnodeView &s
     sn_stamp(sv.dbg, dbgme, 16);
     lds_barrier(); // (the caller has just filled colbase; LDS only: see dev_common.hpp)
     sn_stamp(sv.dbg, dbgme, 17, true);
-    if (wave_live && kbeg < kend) {
+    // The (d_k L[j,k]) operand of the 64 target columns, double buffered (round 6): two buffers of SN_KC / 2 k rows; a wave
+    // stages whole k rows -- lane = column of the block.  The entries of the NEXT chunk are requested before this chunk's
+    // matrix instructions and written into the other buffer behind them: one LDS barrier per chunk and no global round
+    // trip between two chunks (rounds 2-5: four batches of loads per 128 k rows between two barriers -- ~7 us per chunk
+    // against 7-14 us of matrix instructions, hidden only while the CU's other workgroup happened to multiply).  The
+    // pivots of a wave's rows come as ONE load (lane r holds row r's) and are broadcast when the entries are written.
+    constexpr int KCB = SN_KC / 2, SR = KCB / (SN_WG / 64);
+    double wv[SR], dvec = 0.0;
+    auto stage_request = [&](int kc0) {
+        dvec = g.d[min(kc0 + wave + (lane & (SR - 1)) * (SN_WG / 64), kend - 1)];
 #pragma unroll
-        for (int u = 0; u < SN_U; ++u) request(u, kbeg);
+        for (int r = 0; r < SR; ++r) {
+            const int k = min(kc0 + wave + r * (SN_WG / 64), kend - 1); // (clamped: no branch per load)
+            wv[r] = v.Lx[colbase[k] + jrow0 + min(lane, ncols - 1)];
+        }
+    };
+    auto stage_commit = [&](double *Wb, int kc0) {
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const int kl = wave + r * (SN_WG / 64);
+            Wb[kl * SN_NB + lane] = (kc0 + kl < kend && lane < ncols) ? wv[r] * readlane_f64(dvec, r) : 0.0;
+        }
+    };
+    if (kbeg < kend) {
+        stage_request(kbeg);
+        if (wave_live) {
+#pragma unroll
+            for (int u = 0; u < SN_U; ++u) request(u, kbeg);
+        }
+        stage_commit(Wl, kbeg);
     }
-    for (int kc0 = kbeg; kc0 < kend; kc0 += SN_KC) {
-        const int kcn = min(SN_KC, kend - kc0);
+    lds_barrier();
+    sn_stamp(sv.dbg, dbgme, 18);
+    int buf = 0;
+    for (int kc0 = kbeg; kc0 < kend; kc0 += KCB, buf ^= 1) {
+        const bool more = kc0 + KCB < kend;
+        if (more) stage_request(kc0 + KCB);
+        const int kcn = min(KCB, kend - kc0);
         const int kcnu = (kcn + 4 * SN_U - 1) / (4 * SN_U) * (4 * SN_U); // whole groups: the tail rows of the operand are zeros
-        lds_barrier(); // the previous chunk has been consumed (the A operands requested for this chunk stay in flight:
-                       // __syncthreads() would wait for them here, one exposed round trip per chunk)
-        // the (d_k L[j,k]) operand: a wave stages whole k rows -- lane = column of the block --, SN_WST rows in
-        // flight; the column base is a wave-uniform LDS read and the pivot a wave-uniform load from the packed
-        // pivots (SnodeView::sn_d), issued together with the entry it scales: ONE global round trip per batch
-        // (round 2: cols -> D -> LDS, a barrier, then the entries)
-        for (int kr = wave; kr < kcnu; kr += SN_WST * (SN_WG / 64)) {
-            double wv[SN_WST], dv[SN_WST];
+        const double *Wb = Wl + buf * (KCB * SN_NB);
+        if (wave_live) { // (else: the whole wave is beyond the panel; it still stages)
+            for (int kk = 0; kk < kcnu; kk += 4 * SN_U) {
+                const int knext = kk + 4 * SN_U < kcnu ? kc0 + kk + 4 * SN_U : kc0 + KCB; // (the next chunk's first group)
 #pragma unroll
-            for (int r = 0; r < SN_WST; ++r) {
-                const int kk = min(kr + r * (SN_WG / 64), kcn - 1); // (clamped: no branch per load)
-                wv[r] = v.Lx[colbase[kc0 + kk] + jrow0 + min(lane, ncols - 1)];
-                dv[r] = g.d[kc0 + kk];
-            }
+                for (int u = 0; u < SN_U; ++u) {
+                    const int kl = kk + 4 * u + kq;
 #pragma unroll
-            for (int r = 0; r < SN_WST; ++r) {
-                const int kk = kr + r * (SN_WG / 64);
-                if (kk < kcnu) Wl[kk * SN_NB + lane] = (kk < kcn && lane < ncols) ? wv[r] * dv[r] : 0.0;
-            }
-        }
-        lds_barrier();
-        if (kc0 == kbeg) sn_stamp(sv.dbg, dbgme, 18);
-        if (!wave_live) continue; // (after the barriers: the whole wave is beyond the panel)
-        for (int kk = 0; kk < kcnu; kk += 4 * SN_U) {
-            const int knext = kk + 4 * SN_U < kcnu ? kc0 + kk + 4 * SN_U : kc0 + SN_KC; // (the next chunk's first group)
-#pragma unroll
-            for (int u = 0; u < SN_U; ++u) {
-                const int kl = kk + 4 * u + kq;
-#pragma unroll
-                for (int c = 0; c < SN_NB / 16; ++c) {
-                    const double bw = Wl[kl * SN_NB + 16 * c + l15];
-                    acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][u], bw, acc[0][c], 0, 0, 0);
-                    acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][u], bw, acc[1][c], 0, 0, 0);
+                    for (int c = 0; c < SN_NB / 16; ++c) {
+                        const double bw = Wb[kl * SN_NB + 16 * c + l15];
+                        acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][u], bw, acc[0][c], 0, 0, 0);
+                        acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][u], bw, acc[1][c], 0, 0, 0);
+                    }
+                    request(u, knext);
                 }
-                request(u, knext);
             }
         }
+        if (more) stage_commit(Wl + (buf ^ 1) * (KCB * SN_NB), kc0 + KCB);
+        lds_barrier(); // (LDS only: the A operands requested for the next chunk stay in flight)
     }
     sn_stamp(sv.dbg, dbgme, 19);
     // ---- emit through LDS: this wave's 16 x 64 tile in its own 8 KiB of the (now free) operand buffer, element

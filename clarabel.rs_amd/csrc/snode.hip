@@ -357,19 +357,21 @@ __global__ __launch_bounds__(SN_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 // Wide tiles for the ancestors' update of levels with many supernodes (round 6): k_snode_extend_wide.
 //
 // A wave owns 16 rows x 256 columns (sixteen accumulator tiles, 128 registers): an A operand (an entry of the panel,
-// read from HBM) feeds 16 matrix instructions instead of 4.  The (d L)' operand of the 256 target columns is staged per
-// 32 k rows, double buffered in LDS by the workgroup itself -- the next chunk's entries are requested before the
-// current chunk's matrix instructions and written behind them, one LDS barrier per chunk -- because with 2 x 64 KiB of
-// LDS and 256 registers ONE workgroup of eight waves fits a CU and nothing else would cover its staging (what made
-// round 5's 128-column update slower).  All tiles of a supernode stage the same operand: the launch places a
-// supernode's workgroups on one XCD so that they find it in its L2.  tools/micro/mfma_f64_probe.hip: with two waves per
-// SIMD, 16 accumulators and one ds_read_b64 per matrix instruction the matrix cores reach 77.5 of their 78.6 TFLOP/s.
-// Config 5's leaf level (200 supernodes, 903 rows of B, 1275 member columns): 6.4 ms against 8.5 with the 64-column
-// tiles, although the 128 x 256 tiles compute 1.6 x the triangle's useful area (1.28 x with 256 x 64) -- per executed
-// flop 0.66 against 0.40 of the matrix peak.  The same form for the update of a panel's own block columns (the columns
-// before a group of four applied to all four, k_snode_update with the group's own columns in between) was measured
-// and not kept: 8.6 + 3.6 ms against 11.1 -- the short launches for the columns inside a group cost what the wide
-// tiles save.
+// read from HBM) feeds 16 matrix instructions instead of 4.  The (d L)' operand of the 256 target columns is staged in
+// chunks of four k rows per wave of the workgroup and DOUBLE BUFFERED in LDS by the workgroup itself -- the next chunk's
+// entries are requested before the current chunk's matrix instructions and written behind them, one LDS barrier per
+// chunk.  NW = 4 waves (64 x 256 tiles, 2 x 32 KiB of LDS, ~230 registers): two workgroups per CU, one's matrix
+// instructions cover the other's first loads, barriers and the way its tiles leave; NW = 8 (128 x 256, 2 x 64 KiB): one
+// per CU -- 36.9 against 36.3 ms per step of config 5.  All tiles of a supernode stage the same operand: the launch
+// places a supernode's workgroups on one XCD so that they find it in its L2.  tools/micro/mfma_f64_probe.hip: with two
+// waves per SIMD, 16 accumulators and one ds_read_b64 per matrix instruction the matrix cores reach 77.5 of their 78.6
+// TFLOP/s.
+// Config 5's leaf level (200 supernodes, 903 rows of B, 1275 member columns): 5.8 ms against 8.5 with the 64-column
+// tiles; the computed tiles cover 1.09 x the triangle's useful area (1.28 x with 256 x 64 tiles that are not skipped
+// above the diagonal) -- per executed flop 0.50 against 0.40 of the matrix peak.  The same form for the update of a
+// panel's own block columns (the columns before a group of four applied to all four, k_snode_update with the group's own
+// columns in between) was measured and not kept: 8.6 + 3.6 ms against 11.1 -- the short launches for the columns inside
+// a group cost what the wide tiles save.
 // ---------------------------------------------------------------------------
 constexpr int SNW_NC = 256;   // target columns of a wide tile
 // (k rows per LDS buffer: four per wave of the workgroup -- 8 waves: 32 * 256 * 8 = 64 KiB, 4 waves: 32 KiB)

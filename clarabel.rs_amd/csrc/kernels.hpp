@@ -292,7 +292,6 @@ struct SnodeView {
     // leading dimension snode_g_ld(w + nb), at Gx + g_off[s] (g_off[s] < 0: the supernode keeps the pipelined substitution)
     double *Gx = nullptr;
     const long long *g_off = nullptr;
-    int ablate = 0;
 };
 // One unit level's update matrices summed per TARGET column (host.hpp: Symbolic::asm_*): workgroup t owns node
 // tgt[t0 + t] and subtracts its sources src_ptr[..] one after the other -- a fixed order, no atomics.  Source q =

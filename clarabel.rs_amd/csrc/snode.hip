@@ -489,8 +489,7 @@ __device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeVi
 #pragma unroll
     for (int c = 0; c < SNW_NC / 16; ++c) acc[c] = snode_v4d{0.0, 0.0, 0.0, 0.0};
     double a[SNW_U];
-    const int ablate = sv.ablate;
-    auto request = [&](int u, int kabs) { a[u] = (ablate & 1) ? 1.0 : v.Lx[colbase[min(kabs + kq, kend - 1)] + irc]; };
+    auto request = [&](int u, int kabs) { a[u] = v.Lx[colbase[min(kabs + kq, kend - 1)] + irc]; };
     // the staged operand: this wave's SNW_SR k rows of a chunk, the 256 columns as four runs of 64 lanes
     double wv[SNW_SR][4], dv[SNW_SR];
     auto stage_request = [&](int kc0) {
@@ -500,7 +499,7 @@ __device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeVi
             const int cb = colbase[k] + jrow0;
             dv[r] = g.d[k];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wv[r][q] = (ablate & 2) ? 1.0 : v.Lx[cb + min(lane + 64 * q, ncols - 1)];
+            for (int q = 0; q < 4; ++q) wv[r][q] = v.Lx[cb + min(lane + 64 * q, ncols - 1)];
         }
     };
     auto stage_commit = [&](double *Wb, int kc0) {
@@ -547,7 +546,7 @@ __device__ __forceinline__ void snode_tiles_wide(const LdlView &v, const SnodeVi
         if (more) stage_commit(Wl + (buf ^ 1) * (SNW_KC * SNW_NC), kc0 + SNW_KC);
         lds_barrier();
     }
-    if (!wave_live || (ablate & 4)) return;
+    if (!wave_live) return;
     double *Tw = Wl + wave * (16 * SN_NB);
 #pragma unroll
     for (int cs = 0; cs < SNW_NC / SN_NB; ++cs) {
@@ -2237,7 +2236,6 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
     if (nbmax > 0 && sv.upd_slot) {
         pb(PFK_SN_EXTEND);
         SnodeView se = sv_in;
-        se.ablate = switches().sn_ablate;
         if (!av || !av->nt) se.U = nullptr; // (this level scatters with atomics)
         // levels with at least one supernode per XCD and more than one wide column block: 128 x 256 tiles
         const int nw = switches().sn_wide_waves == 8 ? 8 : 4;

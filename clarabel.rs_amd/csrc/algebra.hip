@@ -53,31 +53,45 @@ __global__ __launch_bounds__(WG) void k_gather_values(double *__restrict__ Sx,
 // sum of every y_i has the same order in every run.  P[(rowbase + i) * split + s] = this workgroup's share of y_i.
 // ---------------------------------------------------------------------------
 constexpr int DB_WG = 512, DB_RT = 8, DB_TILE = 64 * DB_RT;
-__global__ __launch_bounds__(DB_WG) void k_dblk_symv(DblkView d, const double *__restrict__ Kx, const double *__restrict__ x, int mpad) {
+// NR = 2 (round 6): the residuals of the two solves of a pair in ONE pass over the blocks' entries -- every entry is read
+// once and serves both vectors; per vector the same operations in the same order as the one-vector launch (its sums are
+// bitwise the same).  Vector 1's partial sums go to P1 (the second solve context's buffer).
+template <int NR>
+__global__ __launch_bounds__(DB_WG) void k_dblk_symv(DblkView d, const double *__restrict__ Kx, const double *__restrict__ x0,
+                                                      const double *__restrict__ x1, double *__restrict__ P1, int mpad) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    double *xs = (double *)dsm, *yl = xs + mpad, *part = yl + mpad;
+    double *xs = (double *)dsm, *yl = xs + NR * mpad, *part = yl + NR * mpad; // xs[k][i], yl[k][i]
     int *sts = (int *)(part + (DB_WG / 64) * DB_TILE);
     const int b = (int)blockIdx.y, s = (int)blockIdx.x, split = (int)gridDim.x;
     const int m = d.m[b], rb = d.rowbase[b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < m; i += DB_WG) {
-        xs[i] = x[d.rownode[rb + i]];
+        const int node = d.rownode[rb + i];
+        xs[i] = x0[node];
         yl[i] = 0.0;
+        if (NR > 1) {
+            xs[mpad + i] = x1[node];
+            yl[mpad + i] = 0.0;
+        }
         sts[i] = d.start[rb + i] - i - 1; // entry (i', i) of column i at sts[i] + i'
     }
     __syncthreads();
     for (int T0 = 0; T0 < m; T0 += DB_TILE) {
-        double xr[DB_RT], acc[DB_RT];
+        double xr[NR][DB_RT], acc[NR][DB_RT];
 #pragma unroll
-        for (int k = 0; k < DB_RT; ++k) {
-            const int i = T0 + 64 * k + lane;
-            xr[k] = i < m ? xs[i] : 0.0;
-            acc[k] = 0.0;
-        }
+        for (int v = 0; v < NR; ++v)
+#pragma unroll
+            for (int k = 0; k < DB_RT; ++k) {
+                const int i = T0 + 64 * k + lane;
+                xr[v][k] = i < m ? xs[v * mpad + i] : 0.0;
+                acc[v][k] = 0.0;
+            }
         const int aend = min(m - 1, T0 + DB_TILE - 1); // columns with a row in this tile (column a has the rows a + 1 .. m - 1)
         for (int a = s + split * wave; a < aend; a += split * (DB_WG / 64)) {
             const int base = sts[a];
-            const double xa = xs[a];
+            double xa[NR];
+#pragma unroll
+            for (int v = 0; v < NR; ++v) xa[v] = xs[v * mpad + a];
             double h[DB_RT];
 #pragma unroll
             for (int k = 0; k < DB_RT; ++k) {
@@ -86,27 +100,36 @@ __global__ __launch_bounds__(DB_WG) void k_dblk_symv(DblkView d, const double *_
                 h[k] = Kx[base + (ok ? i : a + 1)]; // (clamped: unconditional loads)
                 h[k] = ok ? h[k] : 0.0;
             }
-            double dsum = 0.0;
 #pragma unroll
-            for (int k = 0; k < DB_RT; ++k) {
-                acc[k] += h[k] * xa;
-                dsum += h[k] * xr[k];
+            for (int v = 0; v < NR; ++v) {
+                double dsum = 0.0;
+#pragma unroll
+                for (int k = 0; k < DB_RT; ++k) {
+                    acc[v][k] += h[k] * xa[v];
+                    dsum += h[k] * xr[v][k];
+                }
+                dsum = wave_sum(dsum);
+                if (lane == 0) yl[v * mpad + a] += dsum; // (column a belongs to this wave alone)
             }
-            dsum = wave_sum(dsum);
-            if (lane == 0) yl[a] += dsum; // (column a belongs to this wave alone)
         }
 #pragma unroll
-        for (int k = 0; k < DB_RT; ++k) part[wave * DB_TILE + 64 * k + lane] = acc[k];
-        __syncthreads();
-        if (T0 + tid < m) {
-            double r = 0.0;
+        for (int v = 0; v < NR; ++v) { // (one vector after the other through the same buffer)
 #pragma unroll
-            for (int w = 0; w < DB_WG / 64; ++w) r += part[w * DB_TILE + tid];
-            yl[T0 + tid] += r;
+            for (int k = 0; k < DB_RT; ++k) part[wave * DB_TILE + 64 * k + lane] = acc[v][k];
+            __syncthreads();
+            if (T0 + tid < m) {
+                double r = 0.0;
+#pragma unroll
+                for (int w = 0; w < DB_WG / 64; ++w) r += part[w * DB_TILE + tid];
+                yl[v * mpad + T0 + tid] += r;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    for (int i = tid; i < m; i += DB_WG) d.P[(size_t)(rb + i) * split + s] = yl[i];
+    for (int i = tid; i < m; i += DB_WG) {
+        d.P[(size_t)(rb + i) * split + s] = yl[i];
+        if (NR > 1) P1[(size_t)(rb + i) * split + s] = yl[mpad + i];
+    }
 }
 __global__ __launch_bounds__(WG) void k_dblk_finish(DblkView d, double *__restrict__ bt) {
     const int j = blockIdx.x * WG + threadIdx.x;
@@ -335,15 +358,33 @@ void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap,
     if (nb > 4096) nb = 4096;
     k_gather_values<<<nb, WG, 0, s>>>(Sx, Kx, Smap, nnzS);
 }
-static size_t dblk_lds_bytes(int mpad) { return (size_t)(2 * mpad + (DB_WG / 64) * DB_TILE) * sizeof(double) + (size_t)mpad * sizeof(int); }
+static size_t dblk_lds_bytes(int mpad, int nr) { return (size_t)(2 * nr * mpad + (DB_WG / 64) * DB_TILE) * sizeof(double) + (size_t)mpad * sizeof(int); }
+// bit 0 of the result: the two-vector form fits the LDS as well (dblk_symv2); < 0: error
 int dblk_attributes(int mmax) {
     const int mpad = (mmax + 63) / 64 * 64;
-    return (int)raise_dynamic_lds((const void *)k_dblk_symv, dblk_lds_bytes(mpad));
+    if (raise_dynamic_lds((const void *)k_dblk_symv<1>, dblk_lds_bytes(mpad, 1)) != hipSuccess) return -1;
+    if (dblk_lds_bytes(mpad, 2) > (size_t)160 * 1024 || raise_dynamic_lds((const void *)k_dblk_symv<2>, dblk_lds_bytes(mpad, 2)) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return 1;
 }
 void dblk_symv(hipStream_t s, const DblkView &d, const double *Kx, const double *x, double *bt) {
     if (!d.nblk) return;
     const int mpad = (d.mmax + 63) / 64 * 64;
-    k_dblk_symv<<<dim3(d.split, d.nblk), DB_WG, dblk_lds_bytes(mpad), s>>>(d, Kx, x, mpad);
+    k_dblk_symv<1><<<dim3(d.split, d.nblk), DB_WG, dblk_lds_bytes(mpad, 1), s>>>(d, Kx, x, x, nullptr, mpad);
+    k_dblk_finish<<<(d.nrows + WG - 1) / WG, WG, 0, s>>>(d, bt);
+}
+// two vectors, one pass: the products of both (d.P / P1); bt of the FIRST vector is finished here, the second one's by
+// dblk_finish on its own stream once this launch is done
+void dblk_symv2(hipStream_t s, const DblkView &d, const double *Kx, const double *x0, const double *x1, double *P1, double *bt0) {
+    if (!d.nblk) return;
+    const int mpad = (d.mmax + 63) / 64 * 64;
+    k_dblk_symv<2><<<dim3(d.split, d.nblk), DB_WG, dblk_lds_bytes(mpad, 2), s>>>(d, Kx, x0, x1, P1, mpad);
+    k_dblk_finish<<<(d.nrows + WG - 1) / WG, WG, 0, s>>>(d, bt0);
+}
+void dblk_finish(hipStream_t s, const DblkView &d, double *bt) {
+    if (!d.nblk) return;
     k_dblk_finish<<<(d.nrows + WG - 1) / WG, WG, 0, s>>>(d, bt);
 }
 void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale) {

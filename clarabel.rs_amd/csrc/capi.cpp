@@ -1604,16 +1604,10 @@ int32_t chip_kkt_solve2_dev_enqueue(chip_kkt *h, const double *rhsx_a, const dou
             dev::norm_inf(E.stream, h->x2, E.N, E.norm_set(1), E.norm_nan(1));
             E.swap_ctx();
         } else { // (refine_begin for both: the residuals, then the first round enqueued ahead of its decision)
-            E.enqueue_residual(h->e, h->bp, h->x, 1);
-            E.swap_ctx();
-            E.enqueue_residual(h->e2, h->bp2, h->x2, 1);
-            E.swap_ctx();
+            E.enqueue_residual_pair(h->e, h->bp, h->x, h->e2, h->bp2, h->x2, 1);
             if (st.iterative_refinement_max_iter >= 1) {
                 E.enqueue_solve_pair(h->e, h->x, h->e2, h->x2);
-                E.enqueue_residual(h->dx, h->bp, h->e, 2);
-                E.swap_ctx();
-                E.enqueue_residual(h->dx2, h->bp2, h->e2, 2);
-                E.swap_ctx();
+                E.enqueue_residual_pair(h->dx, h->bp, h->e, h->dx2, h->bp2, h->e2, 2);
             }
         }
     } else {
@@ -2122,6 +2116,8 @@ int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out
     else if (k == "gsweep_launches") *out = E.gs_launches;
     else if (k == "gsweep_recoveries") *out = E.gs_recoveries;
     else if (k == "tri2_launches") *out = E.tri2_launches;
+    else if (k == "dblk2_launches") *out = (double)E.dblk2_launches;
+    else if (k == "dblk_blocks") *out = E.dblk.nblk;
     else if (k == "gsweep_levels") {
         int c = 0;
         for (const auto &r : E.gs_runs) c += r.nlev;

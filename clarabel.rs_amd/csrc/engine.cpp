@@ -217,10 +217,12 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         dblk.rownode = drn;
         if ((rc = alloc(&dblk.P, (size_t)dblk.nrows * dblk.split))) return rc;
         if ((rc = alloc(&bt_view, n))) return rc;
-        if (dev::dblk_attributes(mmax)) {
+        const int da = dev::dblk_attributes(mmax);
+        if (da < 0) {
             set_error("k_dblk_symv: dynamic LDS attribute");
             return CHIP_ERR_HIP;
         }
+        dblk_pair_ok = (da & 1) != 0;
     }
     if ((rc = upload(&Up, S.Up, S.Up.size()))) return rc;
     if ((rc = upload(&Ucol, S.Ucol, (size_t)nnzU))) return rc;
@@ -1659,32 +1661,37 @@ void Engine::enqueue_solve_direct(double *xp, const double *addv) {
 }
 
 // e = b - K x with the UNregularised K (directldlkktsolver.rs:334-347)
-void Engine::enqueue_residual(double *e, const double *b, const double *x, int set) {
+// phases (enqueue_residual_pair runs them separately): 1 = what precedes the dense diagonal blocks' products, 2 = those
+// products for this vector alone, 4 = everything after them
+void Engine::enqueue_residual(double *e, const double *b, const double *x, int set, int phases) {
     dev::GatherArgs a{Sp, Scol, Sx, x, e, b, nullptr, nullptr};
     if (set >= 0) {
         a.nrm = norm_set(set);
         a.nan = norm_nan(set);
     }
     if (fold.k) { // top rows: bundle shares accumulated by the bundle kernel, finished by one tiny launch
+        if (!(phases & 4)) return;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         prof_pair(PF_SYMV_T, &ev0, &ev1);
         dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, fold, ev0, ev1);
         dev::fold_top_residual(stream, fold, Kx, x, b, e, a.nrm, a.nan); // (top-top entries by their position in Kx)
         return;
     }
-    if (!sx_valid) { // (K's values have not changed since the refactor: every write to them is followed by one)
-        dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
-        sx_valid = true;
+    if (phases & 1) {
+        if (!sx_valid) { // (K's values have not changed since the refactor: every write to them is followed by one)
+            dev::gather_values(stream, Sx, Kx, Smap, (int)nnzS);
+            sx_valid = true;
+        }
+        if (xperm) dev::gather_values(stream, xs_view, x, xperm, N);
+        // dense diagonal blocks of the top: multiplied from K's values directly, taken off b beforehand
+        if (dblk.nblk) (void)hipMemcpyAsync(bt_view, b, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, stream);
     }
-    if (xperm) {
-        dev::gather_values(stream, xs_view, x, xperm, N);
-        a.xin = xs_view;
-    }
-    if (dblk.nblk) { // dense diagonal blocks of the top: multiplied from K's values directly, taken off b beforehand
-        (void)hipMemcpyAsync(bt_view, b, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, stream);
-        dev::dblk_symv(stream, dblk, Kx, x, bt_view);
+    if (xperm) a.xin = xs_view;
+    if (dblk.nblk) {
+        if (phases & 2) dev::dblk_symv(stream, dblk, Kx, x, bt_view);
         a.aux = bt_view;
     }
+    if (!(phases & 4)) return;
     const dev::ChunkView bc = smv.B(0);
     if (bc.count) dev::gather_Bprep(stream, dev::SYMV, a, smv.BR(0));
     dev::gather_merged(stream, dev::SYMV, a, smv.T(0), smv.W(0), bc); // the top rows (full rows)
@@ -1692,6 +1699,42 @@ void Engine::enqueue_residual(double *e, const double *b, const double *x, int s
     prof_pair(PF_SYMV_T, &ev0, &ev1);
     dev::bundle_symv(stream, bundles, Up, Ucol, Ux, x, b, e, a.nrm, a.nan, dev::FoldView{}, ev0, ev1); // everything else
     if (bc.count && set >= 0) dev::norm_rows(stream, e, smv.BR(0), a.nrm, a.nan);
+}
+// The residuals of the two solves of a pair (A: this context, B: the second one).  With dense diagonal blocks in the top
+// their products are ONE launch for both vectors (k_dblk_symv<2>: every entry of the blocks read once) on A's stream:
+// B's stream hands its vector over (event), waits for the launch and finishes its own sums.
+void Engine::enqueue_residual_pair(double *eA, const double *bA, const double *xA, double *eB, const double *bB, const double *xB, int set) {
+    const bool two = dblk.nblk > 0 && dblk_pair_ok && !fold.k && pair_ev_a && pair_ev_b && !switches().no_dblk_pair && prof_family == PF_NONE;
+    if (!two) {
+        enqueue_residual(eA, bA, xA, set);
+        swap_ctx();
+        enqueue_residual(eB, bB, xB, set);
+        swap_ctx();
+        return;
+    }
+    hipStream_t sA = stream, sB = alt.stream;
+    enqueue_residual(eA, bA, xA, set, 1);
+    swap_ctx();
+    enqueue_residual(eB, bB, xB, set, 1);
+    double *PB = dblk.P, *btB = bt_view;
+    swap_ctx();
+    (void)hipEventRecord(pair_ev_b, sB);
+    if (hipStreamWaitEvent(sA, pair_ev_b, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipEventSynchronize(pair_ev_b);
+    }
+    dev::dblk_symv2(sA, dblk, Kx, xA, xB, PB, bt_view);
+    dblk2_launches++;
+    (void)hipEventRecord(pair_ev_a, sA);
+    if (hipStreamWaitEvent(sB, pair_ev_a, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipEventSynchronize(pair_ev_a);
+    }
+    enqueue_residual(eA, bA, xA, set, 4);
+    swap_ctx();
+    dev::dblk_finish(stream, dblk, btB); // (this context's partial sums, written by the launch on the other stream)
+    enqueue_residual(eB, bB, xB, set, 4);
+    swap_ctx();
 }
 
 int Engine::zero_norm_sets() {

@@ -242,7 +242,10 @@ struct Engine {
     bool pair_lockstep_ok();
     int tri2_launches = 0; // (tests: two-right-hand-side launches of k_snode_tri so far)
     // e = b - K x (permuted numbering); ||e||inf is folded into norm set `set` (>= 0)
-    void enqueue_residual(double *e, const double *b, const double *x, int set);
+    void enqueue_residual(double *e, const double *b, const double *x, int set, int phases = 7);
+    void enqueue_residual_pair(double *eA, const double *bA, const double *xA, double *eB, const double *bB, const double *xB, int set);
+    bool dblk_pair_ok = false; // k_dblk_symv<2> fits the LDS
+    long long dblk2_launches = 0;
     int zero_norm_sets();                                                    // enqueue
     unsigned long long *norm_set(int set) const { return nrm_dev + (size_t)set * NRM_SET_WORDS; }
     int *norm_nan(int set) const { return (int *)(norm_set(set) + dev::NRM_SLOTS * dev::NRM_STRIDE); }

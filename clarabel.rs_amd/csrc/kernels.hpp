@@ -143,6 +143,8 @@ struct DblkView {
 int dblk_attributes(int mmax);
 // bt[i] = b[i] - (H x)[i] for the rows of the blocks (bt holds a copy of b on entry); every entry of a block is read once
 void dblk_symv(hipStream_t s, const DblkView &d, const double *Kx, const double *x, double *bt);
+void dblk_symv2(hipStream_t s, const DblkView &d, const double *Kx, const double *x0, const double *x1, double *P1, double *bt0);
+void dblk_finish(hipStream_t s, const DblkView &d, double *bt); // (d.P: the context's own partial sums)
 void diag_absmax_eps(hipStream_t s, const double *Kx, const int *diag_idx, int N, double c,
                      double prop, double *scal /*[0]=eps out, uses [1] as scratch*/);
 void scatter_values(hipStream_t s, double *Kx, const int *map, const double *vals, int k, double scale);

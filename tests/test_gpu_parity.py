@@ -555,6 +555,9 @@ def test_paired_solves_match_separate_solves(hip, oracle, which, monkeypatch):
             assert uok and sok == [True, True]
             if which == "chordal_sdp_wide":  # the two-right-hand-side launches ran exactly when the pair is allowed to share them
                 assert (hip.debug_counter(ks, "tri2_launches") > 0) == (env is None), (env, hip.debug_counter(ks, "tri2_launches"))
+                # ... and the residuals' products with the dense diagonal blocks of the top were one launch per pair (k_dblk_symv<2>)
+                assert hip.debug_counter(ks, "dblk_blocks") > 0
+                assert (hip.debug_counter(ks, "dblk2_launches") > 0) == (env is None and st is None)
             for k in range(2):  # the same two solves as separate calls on the same handle
                 ks.setrhs_dev(dev[k][0].ptr, dev[k][1].ptr)
                 ks.solve_dev_enqueue(outs[2 + k].ptr, outs[2 + k].ptr + 8 * n)

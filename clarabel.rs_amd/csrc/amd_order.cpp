@@ -183,10 +183,10 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
         head[d] = i;
     };
     // Ties among the variables of a freshly formed element: last-in-first-out like the classic
-    // implementations (default), or first-in-first-out (CHIP_AMD_FIFO: a variable that has been
+    // implementations (default), or first-in-first-out (measured and dropped: a variable that has been
     // waiting at this degree goes before one that just joined it, which spreads equal-degree pivots
     // over independent subtrees; same kind of fill, often a shallower tree, sometimes a deeper one)
-    const bool lifo = !switches().amd_fifo;
+    const bool lifo = true; // (last-in-first-out ties in the degree lists; the other order was measured and dropped)
     auto dl_insert_tail = [&](I i, I d) {
         if (lifo) return dl_insert(i, d);
         prv[i] = tail[d];
@@ -244,7 +244,7 @@ int amd_order_impl(i64 n, const i64 *Ap, const i64 *Ai, double dense_scale, std:
     // variables of both sides as their parents -- depth 2 instead of 200 for the same fill.
     std::vector<I> blocked(wgt ? (size_t)n : (size_t)0, 0);
     I stage = 1, stage_thr = -1;
-    const double stage_tol = 0.01 * (double)switches().amd_stage_tol;
+    const double stage_tol = 1.0; // degree tolerance of a stage of the grouped ordering
     while (nelim < nlive) {
         auto tp0 = std::chrono::steady_clock::now();
         while (mindeg <= wtot && head[mindeg] == NONE) mindeg++;

@@ -1774,7 +1774,7 @@ int bundle_ir_capacity(const BundleView &bv, int *tw) {
     }
     // few large bundles (a batched problem's share of one GPU of eight): one 1024-thread workgroup per CU --
     // a bundle's sweeps are latency chains, twice the threads take a level's columns in half the passes
-    const bool no1024 = switches().no_ir1024;
+    const bool no1024 = false;
     if (!no1024 && bv.nb <= prop.multiProcessorCount) {
         const int c1024 = bundle_ir_capacity_tw<1024>(bv);
         if (c1024 >= bv.nb) {

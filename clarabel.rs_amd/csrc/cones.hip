@@ -2180,7 +2180,7 @@ static void psd_sync_switch(hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 ? 0 : dev % 64;
-    const int want = (switches().no_psd_mfma ? 1 : 0) | (switches().psd_jacobi_eig ? 2 : 0); // (bit 1: psd_eig_min keeps the Jacobi iteration)
+    const int want = switches().no_psd_mfma ? 1 : 0; // (bit 1 of g_psd_no_mfma: psd_eig_min keeps the Jacobi iteration -- measured, not selectable any more)
     if (want != cur[dev].load(std::memory_order_acquire)) {
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_psd_no_mfma), &want, sizeof(int), 0, hipMemcpyHostToDevice, s);
         (void)hipStreamSynchronize(s);

@@ -550,7 +550,7 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
     if (bundles.nb > 0 && nsn == 0 && topblk.nblocks == 0 && (fold.k > 0 || grouped || NF == N) && !S.Li16.empty() &&
         !switches().no_fused_ir) {
         int cap = dev::bundle_ir_capacity(bundles, &ir_tw);
-        if (cap > 0 && !switches().no_symv_split) {
+        if (cap > 0) {
             // the residual's "split" form (bundle_symv.hpp: bundle_symv_split) needs nloc + max(0, nloc - 2 nleaf) doubles
             // of LDS per bundle: taken when the larger slice leaves the co-resident grid and the workgroup size as
             // they are

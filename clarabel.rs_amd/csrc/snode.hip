@@ -2190,9 +2190,9 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
                 int ksplit = 1; // fill the chip when the level has few supernodes: the finished columns in shares of whole block columns
                 // (CHIP_NO_SPLITK: no split -> no fp64 atomics between the splits, a fixed summation order)
                 const bool no_splitk = switches().no_splitk || switches().deterministic;
-                const int split_target = switches().sn_split_target;
-                const int split_max = switches().sn_split_max;
-                const int split_unit = switches().sn_split_unit; // block columns per share, at least
+                // (256 workgroups wanted, at most 8 shares of at least one block column: 128 / 512 wanted or 16 shares
+                // change config 5's step by less than the noise, round 6)
+                const int split_target = 256, split_max = 8, split_unit = 1;
                 while (!no_splitk && ksplit < split_max && ksplit * 2 * split_unit <= b && groups * count * ksplit < split_target) ksplit *= 2;
                 pb(PFK_SN_UPDATE);
                 if (dbg.mode == 2) sv.dbg = dbg.ring_slot(1) - 16 + 16; // (slots 16..20 of the launch's 32)
@@ -2247,7 +2247,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
             else k_snode_extend_wide<4><<<grid, 256, lds_wide, s>>>(v, se, order, gx, gy, count, 1);
         } else {
             const int gx = (nbmax + SN_ROWS - 1) / SN_ROWS, gy = (nbmax + SN_NB - 1) / SN_NB;
-            const bool xcd = count >= 8 && !switches().no_xcd_map; // (fewer supernodes than XCDs: spread the tiles)
+            const bool xcd = count >= 8; // (fewer supernodes than XCDs: spread the tiles; with them spread always: 794 against 564 us)
             int ks = 1; // k-split of the tiles while the launch would leave most of the chip idle (atomics only: not with the assembled form)
             if (!se.U && !switches().no_splitk && !switches().deterministic)
                 while (ks < 8 && ks * 2 <= nblk && (long long)gx * gy * count * ks * 2 <= 512) ks *= 2;

@@ -21,39 +21,30 @@ const Entry TABLE[] = {
     {"CHIP_TIMING", Entry::FLAG, SW(timing), 0},
     {"CHIP_HOST_THREADS", Entry::INT, SW(host_threads), 0},
     {"CHIP_HOST_PAR_MIN", Entry::LONG, SW(host_par_min), 0},
-    {"CHIP_AMD_FIFO", Entry::FLAG, SW(amd_fifo), 0},
     {"CHIP_AMD_RESCAN", Entry::FLAG, SW(amd_rescan), 0},
     {"CHIP_NO_COMPONENTS", Entry::FLAG, SW(no_components), 0},
     {"CHIP_NO_CLIQUE_ORDER", Entry::FLAG, SW(no_clique_order), 0},
-    {"CHIP_AMD_STAGE_TOL", Entry::INT, SW(amd_stage_tol), 0},
-    {"CHIP_NO_CHAIN_REORDER", Entry::FLAG, SW(no_chain_reorder), 0},
     {"CHIP_NO_BUNDLES", Entry::FLAG, SW(no_bundles), 0},
     {"CHIP_BUNDLE_MAX_WORK", Entry::LONG, SW(bundle_max_work), 0},
     {"CHIP_SNB_CHUNK", Entry::LONG, SW(snb_chunk), 0},
     {"CHIP_NO_GROUPFOLD", Entry::FLAG, SW(no_groupfold), 0},
     {"CHIP_GROUPFOLD_MIN", Entry::LONG, SW(groupfold_min), 0},
     {"CHIP_TARGET_WG", Entry::INT, SW(target_wg), SW(has_target_wg)},
-    {"CHIP_NO_LEVEL_SORT", Entry::FLAG, SW(no_level_sort), 0},
     {"CHIP_NO_SNODE", Entry::FLAG, SW(no_snode), 0},
     {"CHIP_NO_TOPFOLD", Entry::FLAG, SW(no_topfold), 0},
     {"CHIP_NO_FACTOR_FLAT", Entry::FLAG, SW(no_factor_flat), 0},
     {"CHIP_NO_TOPBLK", Entry::FLAG, SW(no_topblk), 0},
-    {"CHIP_NO_GATHER_HOIST", Entry::FLAG, SW(no_gather_hoist), 0},
     {"CHIP_NO_SNX_HOIST", Entry::FLAG, SW(no_snx_hoist), 0},
     {"CHIP_NO_PSD_MFMA", Entry::FLAG, SW(no_psd_mfma), 0},
     {"CHIP_NO_PSD_ROWS", Entry::FLAG, SW(no_psd_rows), 0},
-    {"CHIP_PSD_JACOBI_EIG", Entry::FLAG, SW(psd_jacobi_eig), 0},
-    {"CHIP_NO_XPERM", Entry::FLAG, SW(no_xperm), 0},
     {"CHIP_NO_DENSE_SYMV", Entry::FLAG, SW(no_dense_symv), 0},
     {"CHIP_DENSE_SYMV_MIN", Entry::LONG, SW(dense_symv_min), 0},
     {"CHIP_NO_FUSED_IR", Entry::FLAG, SW(no_fused_ir), 0},
-    {"CHIP_NO_SYMV_SPLIT", Entry::FLAG, SW(no_symv_split), 0},
     {"CHIP_NO_FACTOR_LDS", Entry::FLAG, SW(no_factor_lds), 0},
     {"CHIP_NO_FACTOR_CHAIN", Entry::FLAG, SW(no_factor_chain), 0},
     {"CHIP_NO_SNODE_TRI", Entry::FLAG, SW(no_snode_tri), 0},
     {"CHIP_NO_BUNDLE_FLAT_SWEEP", Entry::FLAG, SW(no_bundle_flat_sweep), 0},
     {"CHIP_NO_FLAT", Entry::FLAG, SW(no_flat), 0},
-    {"CHIP_NO_IR1024", Entry::FLAG, SW(no_ir1024), 0},
     {"CHIP_NO_IR_SF", Entry::FLAG, SW(no_ir_sf), 0},
     {"CHIP_IRS_FLAGS", Entry::INT, SW(irs_flags), 0},
     {"CHIP_IR_TEST_DROP", Entry::FLAG, SW(ir_test_drop), 0},
@@ -64,9 +55,6 @@ const Entry TABLE[] = {
     {"CHIP_SN_XB_CAP", Entry::INT, SW(sn_xb_cap), 0},
     {"CHIP_SN_DEBUG", Entry::INT, SW(sn_debug), 0},
     {"CHIP_NO_SPLITK", Entry::FLAG, SW(no_splitk), 0},
-    {"CHIP_SN_SPLIT_TARGET", Entry::INT, SW(sn_split_target), 0},
-    {"CHIP_SN_SPLIT_MAX", Entry::INT, SW(sn_split_max), 0},
-    {"CHIP_SN_SPLIT_UNIT", Entry::INT, SW(sn_split_unit), 0},
     {"CHIP_NO_SNODE_PANEL", Entry::FLAG, SW(no_snode_panel), 0},
     {"CHIP_SN_PANEL_SLOTS", Entry::INT, SW(sn_panel_slots), 0},
     {"CHIP_NO_PANEL_OVERLAP", Entry::FLAG, SW(no_panel_overlap), 0},
@@ -75,7 +63,6 @@ const Entry TABLE[] = {
     {"CHIP_NO_PANEL_DIAG_MFMA", Entry::FLAG, SW(no_panel_diag_mfma), 0},
     {"CHIP_NO_EXTEND_ASM", Entry::FLAG, SW(no_extend_asm), 0},
     {"CHIP_EXTEND_ASM_MIN", Entry::INT, SW(extend_asm_min), 0},
-    {"CHIP_NO_XCD_MAP", Entry::FLAG, SW(no_xcd_map), 0},
     {"CHIP_NO_DBLK_PAIR", Entry::FLAG, SW(no_dblk_pair), 0},
     {"CHIP_NO_SN_WIDE", Entry::FLAG, SW(no_sn_wide), 0},
     {"CHIP_SN_WIDE_MIN_COUNT", Entry::INT, SW(sn_wide_min_count), 0},

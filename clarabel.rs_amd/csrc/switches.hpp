@@ -16,41 +16,32 @@ struct Switches {
     bool timing = false;            // CHIP_TIMING: wall-clock of the analysis phases on stderr
     int host_threads = 0;           // CHIP_HOST_THREADS (0: min(16, hardware threads))
     long long host_par_min = 2000000; // CHIP_HOST_PAR_MIN: smallest pass that is split over threads
-    bool amd_fifo = false;          // CHIP_AMD_FIFO: first-in-first-out ties in the degree lists
     bool amd_rescan = false;        // CHIP_AMD_RESCAN: every member of a new element rescans its lists
     bool no_components = false;     // CHIP_NO_COMPONENTS: order the whole graph, not one component per pattern
     bool no_clique_order = false;   // CHIP_NO_CLIQUE_ORDER: dense cone blocks enter the ordering row by row, not as one node
-    int amd_stage_tol = 100;        // CHIP_AMD_STAGE_TOL: degree tolerance (percent) of a stage of the grouped ordering
-    bool no_chain_reorder = false;  // CHIP_NO_CHAIN_REORDER
     bool no_bundles = false;        // CHIP_NO_BUNDLES
     long long bundle_max_work = 0;  // CHIP_BUNDLE_MAX_WORK (0: default)
     bool no_groupfold = false;      // CHIP_NO_GROUPFOLD
     long long groupfold_min = 0;    // CHIP_GROUPFOLD_MIN (0: default)
     bool has_target_wg = false;     // CHIP_TARGET_WG given
     int target_wg = 0;
-    bool no_level_sort = false;     // CHIP_NO_LEVEL_SORT
     bool no_snode = false;          // CHIP_NO_SNODE
     bool no_topfold = false;        // CHIP_NO_TOPFOLD
     bool no_factor_flat = false;    // CHIP_NO_FACTOR_FLAT (also read by the launcher of the bundle factorisation)
     bool no_topblk = false;         // CHIP_NO_TOPBLK
-    bool no_gather_hoist = false;   // CHIP_NO_GATHER_HOIST
     long long snb_chunk = 0;        // CHIP_SNB_CHUNK: fewest updates of a chunk of the bundle columns' contributions into a supernode member (0: default)
     bool no_snx_hoist = false;      // CHIP_NO_SNX_HOIST: the bundle columns' contributions into supernode members stay in the launches of the members' unit levels
     bool no_psd_mfma = false;       // CHIP_NO_PSD_MFMA: the n x n products of the PSD cone kernels as scalar dot products, not on the matrix cores
-    bool psd_jacobi_eig = false;    // CHIP_PSD_JACOBI_EIG: eigenvalues of PSD cones (step length, margins) by the two-sided Jacobi iteration of rounds 1 - 5, not by tridiagonal reduction + bisection
     bool no_psd_rows = false;       // CHIP_NO_PSD_ROWS: the Hs blocks of PSD cones written through mapHs (caller's order), not row by row
-    bool no_xperm = false;          // CHIP_NO_XPERM
     long long dense_symv_min = 0;   // CHIP_DENSE_SYMV_MIN: fewest block entries for which the blocks leave S (tests; 0: 2^20)
     bool no_dense_symv = false;     // CHIP_NO_DENSE_SYMV: dense diagonal blocks of the top stay in the full rows S of the residual
     // ---- engine / launchers ----
     bool no_fused_ir = false;       // CHIP_NO_FUSED_IR: one kernel per phase, refinement control on the host
-    bool no_symv_split = false;     // CHIP_NO_SYMV_SPLIT
     bool no_factor_lds = false;     // CHIP_NO_FACTOR_LDS
     bool no_factor_chain = false;   // CHIP_NO_FACTOR_CHAIN
     bool no_snode_tri = false;      // CHIP_NO_SNODE_TRI
     bool no_bundle_flat_sweep = false; // CHIP_NO_BUNDLE_FLAT_SWEEP: the stand-alone bundle sweeps keep the row- / column-per-thread form (k_bundle_fwd / bwd), no entry-parallel form (k_bundle_sweep_flat)
     bool no_flat = false;           // CHIP_NO_FLAT: column-per-thread sweeps inside k_bundle_ir
-    bool no_ir1024 = false;         // CHIP_NO_IR1024
     int irs_flags = -1;             // CHIP_IRS_FLAGS: experiment bits of k_bundle_irs (-1: the defaults; kernels.hpp: IrView::sf)
     bool no_ir_sf = false;          // CHIP_NO_IR_SF: the fused solve stays on k_bundle_ir also where k_bundle_irs (candidate on chip, no permuted copy of b) applies
     bool ir_test_drop = false;      // CHIP_IR_TEST_DROP (tests: a fused launch that cannot complete its barrier)
@@ -62,7 +53,6 @@ struct Switches {
     int sn_xb_cap = 0;              // CHIP_SN_XB_CAP (0: default)
     int sn_debug = 0;               // CHIP_SN_DEBUG
     bool no_splitk = false;         // CHIP_NO_SPLITK
-    int sn_split_target = 256, sn_split_max = 8, sn_split_unit = 1; // CHIP_SN_SPLIT_TARGET / _MAX / _UNIT
     bool no_snode_panel = false;    // CHIP_NO_SNODE_PANEL: separate diag / rows launches
     int sn_panel_slots = 0;         // CHIP_SN_PANEL_SLOTS: workgroups of one k_snode_panel launch beyond which a workgroup walks several
                                     // groups of 256 rows (0: 256; tests: 1 -> every workgroup walks all groups)
@@ -76,7 +66,6 @@ struct Switches {
     bool no_sn_wide = false;        // CHIP_NO_SN_WIDE: no 128 x 256 tiles for the ancestors' update (k_snode_extend_wide)
     int sn_wide_waves = 4;          // CHIP_SN_WIDE_WAVES: waves per workgroup of k_snode_extend_wide (4: two workgroups per CU; 8: one)
     int sn_wide_min_count = 8;      // CHIP_SN_WIDE_MIN_COUNT: supernodes of a level from which they are used (tests: 1)
-    bool no_xcd_map = false;        // CHIP_NO_XCD_MAP: the tiles of k_snode_extend spread over the XCDs, not one supernode per XCD
     int sn_asm_cap = 0;             // CHIP_SN_ASM_CAP: rows of a target column per LDS window of k_snode_assemble (tests; 0: 4096)
     bool no_factor_overlap = false; // CHIP_NO_FACTOR_OVERLAP: the bundle columns' contributions into supernode members all ahead of the supernode chain, none beside it on the second stream
     bool no_pair_lockstep = false;  // CHIP_NO_PAIR_LOCKSTEP: the paired solves keep two independent chains of launches, also where the wide supernodes have a two-right-hand-side form (k_snode_tri<.., 2>)

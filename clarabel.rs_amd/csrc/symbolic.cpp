@@ -291,7 +291,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     for (i32 j = 0; j < n; j++) nnzL0 += cnt[j];
     // (the walk costs one more pass over nnz(L): skipped for factors beyond 1e8 entries -- dense fronts, whose
     // depth is a matter of the supernode kernels, not of single columns)
-    if (perm0.empty() && n > 0 && nnzL0 <= 100000000 && !switches().no_chain_reorder) {
+    if (perm0.empty() && n > 0 && nnzL0 <= 100000000) {
         std::vector<i32> chain((size_t)n), nlev((size_t)n, 0), rel((size_t)n, 0), stamp((size_t)n, -1);
         std::vector<i32> cfirst((size_t)n, -1), cnext((size_t)n, -1); // members of a chain, linked in old order
         i32 nchains = 0;
@@ -609,7 +609,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // permutation becomes a handful of long ascending runs per bundle (config 3: the x block, the
     // Nonnegative rows and the second-order-cone rows of a block) -- the fused solve kernel then stages
     // its right-hand side and writes its result with coalesced copies instead of per-element gathers
-    for (i32 g = 0; g < nb && !switches().no_level_sort; g++) {
+    for (i32 g = 0; g < nb; g++) {
         i32 t = gptr[g];
         const i32 tend = gptr[g + 1];
         while (t < tend) {
@@ -1545,10 +1545,10 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
         // unit level.  Each member row therefore joins the gather launch of level 1 + (highest unit level of an
         // ordinary top column in its list), 0 when it only refers to bundle columns: the gathers and the pushes
         // are both subtractions from the same entry, their order is free.  Config 2: 27 gather launches per
-        // sweep become a handful.  (CHIP_NO_GATHER_HOIST keeps every row at its own level.)
+        // sweep become a handful.  
         std::vector<std::vector<i32>> hoisted((size_t)nfl);
         if (nsn > 0) {
-            const bool no_hoist = switches().no_gather_hoist;
+            const bool no_hoist = false;
             for (i32 sn = 0; sn < nsn; sn++)
                 for (i32 t = S.sn_ptr[sn]; t < S.sn_ptr[sn + 1]; t++) {
                     const i32 j = S.sn_col[t];
@@ -1669,7 +1669,7 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
     // every lane its own 64-byte sector, the residual over the top rows ran at 1.8 TB/s, bound by L2 sectors,
     // not HBM).  The residual therefore reads a copy of x in which every supernode's members are consecutive
     // (one N-element gather per residual) and Scol is renumbered to match.
-    if (S.sn_ptr.size() > 1 && S.nfold == 0 && !switches().no_xperm) {
+    if (S.sn_ptr.size() > 1 && S.nfold == 0) {
         const i32 NFi = S.NF;
         S.xperm.resize((size_t)n);
         std::vector<i32> xinv((size_t)n);

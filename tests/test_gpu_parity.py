@@ -533,7 +533,8 @@ def test_paired_solves_match_separate_solves(hip, oracle, which, monkeypatch):
     else:
         pr = problems.mixed_conic(nexp=20, npow=10, nsoc=3, socdim=9, nn=30, seed=11)
     n, m = pr["n"], pr["m"]
-    for env, st in ((None, None), ("CHIP_NO_SOLVE_PAIR", None), (None, hip.Settings.default(iterative_refinement_enable=0))):
+    # (CHIP_NO_PAIR_LOCKSTEP: the pair as two independent chains of launches on two streams, no two-vector launches)
+    for env, st in ((None, None), ("CHIP_NO_SOLVE_PAIR", None), ("CHIP_NO_PAIR_LOCKSTEP", None), (None, hip.Settings.default(iterative_refinement_enable=0))):
         if env:
             monkeypatch.setenv(env, "1")
         ks, ko, cones = _solvers(hip, oracle, pr, settings=st)

@@ -2014,14 +2014,21 @@ static size_t snode_solve_lds_bytes(int wmax, int nbcap) {
     return (size_t)(wmax + nbcap + SN_NB * SN_NB + SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int);
 }
 constexpr size_t SNW_LDS_MAX = (size_t)160 * 1024;
+static size_t g_wide_lds[2] = {0, 0}; // the largest LDS the wide kernels (4 / 8 waves) have been granted, 0: none
 static size_t snode_lds_wide_bytes(int wmax, int nw) { return (size_t)2 * SNW_SR * nw * SNW_NC * sizeof(double) + (size_t)wmax * sizeof(int); }
 static size_t snode_lds_bytes(int wmax) { return (size_t)(SN_KC * SN_NB) * sizeof(double) + (size_t)wmax * sizeof(int); }
 int snode_kernel_attributes(int wmax, int nbmax) {
     const int lds = (int)snode_lds_bytes(wmax);
     int rc = (int)raise_dynamic_lds((const void *)k_snode_update, (size_t)lds);
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_extend, (size_t)lds);
-    if (!rc && snode_lds_wide_bytes(wmax, 8) <= SNW_LDS_MAX) rc = (int)raise_dynamic_lds((const void *)k_snode_extend_wide<8>, snode_lds_wide_bytes(wmax, 8));
-    if (!rc && snode_lds_wide_bytes(wmax, 4) <= SNW_LDS_MAX) rc = (int)raise_dynamic_lds((const void *)k_snode_extend_wide<4>, snode_lds_wide_bytes(wmax, 4));
+    // (the wide tiles are an option: a device that refuses their LDS keeps the 64-column tiles)
+    if (!rc) {
+        if (snode_lds_wide_bytes(wmax, 8) <= SNW_LDS_MAX && raise_dynamic_lds((const void *)k_snode_extend_wide<8>, snode_lds_wide_bytes(wmax, 8)) == hipSuccess)
+            g_wide_lds[1] = std::max(g_wide_lds[1], snode_lds_wide_bytes(wmax, 8)); // (only ever raised, like the attribute)
+        if (snode_lds_wide_bytes(wmax, 4) <= SNW_LDS_MAX && raise_dynamic_lds((const void *)k_snode_extend_wide<4>, snode_lds_wide_bytes(wmax, 4)) == hipSuccess)
+            g_wide_lds[0] = std::max(g_wide_lds[0], snode_lds_wide_bytes(wmax, 4));
+        (void)hipGetLastError();
+    }
     const int lds2 = (int)snode_solve_lds_bytes(wmax, std::min(nbmax, SN_XB_CAP));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<true>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
     if (!rc) rc = (int)raise_dynamic_lds((const void *)k_snode_panel2<false>, (size_t)(SN_NB * SN_NB + (SNQ_WG / 64) * 64 * SNP_XLD) * sizeof(double));
@@ -2240,7 +2247,7 @@ void factor_snodes(hipStream_t s, const LdlView &v, const SnodeView &sv_in, cons
         // levels with at least one supernode per XCD and more than one wide column block: 128 x 256 tiles
         const int nw = switches().sn_wide_waves == 8 ? 8 : 4;
         const size_t lds_wide = snode_lds_wide_bytes(wmax_all, nw);
-        if (lds_wide <= SNW_LDS_MAX && count >= switches().sn_wide_min_count && nbmax > SNW_NC && !switches().no_sn_wide) {
+        if (lds_wide <= g_wide_lds[nw == 8 ? 1 : 0] && count >= switches().sn_wide_min_count && nbmax > SNW_NC && !switches().no_sn_wide) {
             const int gx = (nbmax + 16 * nw - 1) / (16 * nw), gy = (nbmax + SNW_NC - 1) / SNW_NC;
             const dim3 grid((unsigned)(8 * ((count + 7) / 8) * gx * gy));
             if (nw == 8) k_snode_extend_wide<8><<<grid, 512, lds_wide, s>>>(v, se, order, gx, gy, count, 1);

@@ -36,6 +36,24 @@ __global__ __launch_bounds__(WG) void k_scatter_init(const double *__restrict__ 
         }
     }
 }
+// the same scatter for a LIST of K's top entries (rest[q] indexes Kx / a2l): what is left when the dense diagonal blocks'
+// strict triangles have been written into L by the kernel that produced them (Engine::hs_direct_begin)
+__global__ __launch_bounds__(WG) void k_scatter_rest(const double *__restrict__ Kx, const int *__restrict__ a2l,
+                                                     const int *__restrict__ rest, int nrest, int nnzL, double *Lx, double *D,
+                                                     const int8_t *__restrict__ dsigns, const double *eps_ptr, int *status) {
+    const double eps = eps_ptr ? eps_ptr[0] : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x < 4) status[threadIdx.x] = 0;
+    for (int q = logical_block() * WG + threadIdx.x; q < nrest; q += gridDim.x * WG) {
+        const int t = rest[q], tgt = a2l[t];
+        const double val = Kx[t];
+        if (tgt >= nnzL) {
+            const int j = tgt - nnzL;
+            D[j] = eps_ptr ? (dsigns[j] == 1 ? val + eps : val - eps) : val;
+        } else {
+            Lx[tgt] = val;
+        }
+    }
+}
 __global__ __launch_bounds__(WG) void k_gather_values(double *__restrict__ Sx,
                                                       const double *__restrict__ Kx,
                                                       const int *__restrict__ Smap, int nnzS) {
@@ -351,6 +369,12 @@ void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int
     int nb = grid_for(nnzK > 0 ? nnzK : 1);
     if (nb > 4096) nb = 4096;
     k_scatter_init<<<nb, WG, 0, s>>>(Kx, a2l, nnzK, nnzL, Lx, D, dsigns, eps, fill_idx, nfill, status);
+}
+void scatter_rest(hipStream_t s, const double *Kx, const int *a2l, const int *rest, int nrest, int nnzL, double *Lx, double *D,
+                  const int8_t *dsigns, const double *eps, int *status) {
+    int nb = grid_for(nrest > 0 ? nrest : 1);
+    if (nb > 4096) nb = 4096;
+    k_scatter_rest<<<nb, WG, 0, s>>>(Kx, a2l, rest, nrest, nnzL, Lx, D, dsigns, eps, status);
 }
 void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap, int nnzS) {
     if (nnzS == 0) return;

@@ -105,6 +105,7 @@ struct chip_kkt {
     int last_ir = 0;
     double last_eps = 0;
     bool scaling_pending_check = false;
+    bool psd_rows_all_blocks = false; // every dense diagonal block of the top is a PSD cone's Hs block (k_psd_write_hs_rows)
     int scaling_gen = 0; // generation of the last update_scaling: a failing cone writes it into mailbox.soc_fail
     bool x_holds_b = false; // x was initialised with the rhs by setrhs (skips a D2D copy)
     double static_diag_max = 0.0; // max |P_ii|: the diagonal entries of K that no cone kernel writes
@@ -651,6 +652,8 @@ int32_t chip_kkt_create(chip_kkt **out, int64_t n, int64_t m, const uint64_t *Pc
                 nc++;
             }
             if (nc == pd_start.size()) {
+                // (every dense block belongs to a cone: the blocks may be written into L directly, Engine::hs_direct_begin)
+                h->psd_rows_all_blocks = std::all_of(blk_cone.begin(), blk_cone.end(), [](i32 c) { return c >= 0; });
                 int *r1, *r2;
                 if ((rc = E.upload(&r1, blk_cone, blk_cone.size()))) return rc;
                 if ((rc = E.upload(&r2, row_ij, row_ij.size()))) return rc;
@@ -922,7 +925,9 @@ static int update_enqueue(chip_kkt *h, const double *hsblocks_or_null) {
     dev::sym_write_kkt(E.stream, h->soc, h->nn_rows, h->nn_hsidx, h->nn_count, h->d_w, h->mapHs, E.Kx, dslots);
     dev::ns3_write_hs(E.stream, h->ns3, E.Kx);
     dev::gpw_write_kkt(E.stream, h->gpw, E.Kx);
-    dev::psd_write_hs(E.stream, h->psd, E.Kx);
+    // PSD blocks that are dense diagonal blocks of the top, contiguous in L too: written into K AND L by the one kernel
+    const bool direct = h->psd_rows_all_blocks && dev::psd_write_hs_rows_active(h->psd) && E.hs_direct_begin();
+    dev::psd_write_hs(E.stream, h->psd, E.Kx, direct ? E.Lx : nullptr, direct ? E.dblk_l0 : nullptr);
     return E.refactor_enqueue(h->E.st.static_regularization_enable != 0, slot_eps ? nullptr : h->diag_full,
                               h->static_diag_max);
 }
@@ -2118,6 +2123,7 @@ int32_t chip_debug_counter(const void *kkt_handle, const char *name, double *out
     else if (k == "tri2_launches") *out = E.tri2_launches;
     else if (k == "dblk2_launches") *out = (double)E.dblk2_launches;
     else if (k == "dblk_blocks") *out = E.dblk.nblk;
+    else if (k == "hs_direct_refactors") *out = (double)E.hs_direct_refactors;
     else if (k == "gsweep_levels") {
         int c = 0;
         for (const auto &r : E.gs_runs) c += r.nlev;

@@ -1283,7 +1283,9 @@ __global__ __launch_bounds__(WG) void k_psd_write_hs(PsdView v, double *Kx, int 
 // 8-byte stores, no index array, no square roots (the svec pair (i, j) of every row comes packed from the host).
 // k_psd_write_hs walks the entries in the CALLER's order and scatters them through mapHs: 1.6e8 uncoalesced stores
 // per update on config 5 (2.2-2.6 ms; this form: see DESIGN 4.1).
-__global__ __launch_bounds__(WG) void k_psd_write_hs_rows(PsdView v, double *Kx) {
+// Lx / l0 (or nullptr): the same values into the rows' places in L (Engine::dblk_l0: contiguous there as well) -- the
+// refactor then does not read them back from K
+__global__ __launch_bounds__(WG) void k_psd_write_hs_rows(PsdView v, double *Kx, double *Lx, const int *__restrict__ l0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.y, c = v.blk_cone[b];
     if (c < 0) return;
@@ -1306,9 +1308,12 @@ __global__ __launch_bounds__(WG) void k_psd_write_hs_rows(PsdView v, double *Kx)
         const int ij = ijl[a], i = ij & 0xffff, j = ij >> 16;
         const int st = v.blk_start[rb + a]; // first entry right of the diagonal; the diagonal itself sits just before
         if (threadIdx.x == 0) Kx[st - 1] = -entry(i, j, i, j);
+        const int ls = Lx ? l0[rb + a] : 0;
         for (int bb = a + 1 + threadIdx.x; bb < m; bb += WG) {
             const int kl = ijl[bb];
-            Kx[st + bb - a - 1] = -entry(i, j, kl & 0xffff, kl >> 16);
+            const double val = -entry(i, j, kl & 0xffff, kl >> 16);
+            Kx[st + bb - a - 1] = val;
+            if (Lx) Lx[ls + bb - a - 1] = val;
         }
     }
 }
@@ -2203,7 +2208,8 @@ void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const
     if (lds > 64 * 1024) (void)raise_dynamic_lds((const void *)k_psd_update_scaling<false>, (size_t)lds);
     k_psd_update_scaling<false><<<v.ncones, WG, lds, s>>>(v, sv, zv);
 }
-void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx) {
+bool psd_write_hs_rows_active(const PsdView &v) { return v.ncones > 0 && !v.scratch && v.rows_nblk > 0 && !switches().no_psd_rows; }
+void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx, double *Lx, const int *l0) {
     if (!v.ncones) return;
     if (v.scratch) {
         const int bpc = 64; // numel^2 / 2 entries per cone: 3.4e7 at n = 128
@@ -2215,7 +2221,7 @@ void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx) {
         const int numel = v.maxdim * (v.maxdim + 1) / 2;
         const size_t lds2 = ((size_t)(v.maxdim * v.maxdim) * sizeof(double) + (size_t)numel * sizeof(int) + 15) & ~(size_t)15;
         if (lds2 > 64 * 1024) (void)raise_dynamic_lds((const void *)k_psd_write_hs_rows, lds2);
-        k_psd_write_hs_rows<<<dim3(bpc, v.rows_nblk), WG, lds2, s>>>(v, Kx);
+        k_psd_write_hs_rows<<<dim3(bpc, v.rows_nblk), WG, lds2, s>>>(v, Kx, Lx, l0);
         return;
     }
     const size_t lds = ((size_t)(v.maxdim * v.maxdim) * sizeof(double) + 15) & ~(size_t)15;

@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -217,6 +218,51 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
         dblk.rownode = drn;
         if ((rc = alloc(&dblk.P, (size_t)dblk.nrows * dblk.split))) return rc;
         if ((rc = alloc(&bt_view, n))) return rc;
+        { // rows of the blocks that are contiguous in L too -> dblk_l0, and the rest of K's top entries -> rest_idx
+            const size_t nrows = rownode.size();
+            const i64 ntop = (i64)nnzK - (i64)nnzU;
+            std::vector<i32> l0(nrows, -1), rowlen(nrows, 0);
+            for (int b = 0, o = 0; b < nblk; o += S.dblk_m[(size_t)b], b++)
+                for (i32 a = 0; a < S.dblk_m[(size_t)b]; a++) rowlen[(size_t)(o + a)] = S.dblk_m[(size_t)b] - a - 1;
+            std::atomic<int> bad{0};
+            run_threads(host_threads(), [&](int t, int TT) {
+                for (size_t r = (size_t)t; r < nrows; r += (size_t)TT) {
+                    const i64 u0 = (i64)S.dblk_start[r] - (i64)nnzU, len = rowlen[r];
+                    if (len <= 0) continue;
+                    if (u0 < 0 || u0 + len > ntop) {
+                        bad = 1;
+                        continue;
+                    }
+                    const i64 base = S.v2l[(size_t)u0];
+                    if (base < 0 || base + len > (i64)nnzL) bad = 1;
+                    for (i64 q = 1; q < len && !bad; q++)
+                        if ((i64)S.v2l[(size_t)(u0 + q)] != base + q) bad = 1;
+                    l0[r] = (i32)base;
+                }
+            });
+            if (!bad && S.fill_from >= 0 && ntop < (i64)2000000000) {
+                std::vector<std::pair<i64, i64>> iv;
+                iv.reserve(nrows);
+                for (size_t r = 0; r < nrows; r++)
+                    if (rowlen[r] > 0) iv.emplace_back((i64)S.dblk_start[r] - (i64)nnzU, (i64)rowlen[r]);
+                std::sort(iv.begin(), iv.end());
+                std::vector<i32> rest;
+                i64 pos = 0;
+                bool overlap = false;
+                for (const auto &pr : iv) {
+                    if (pr.first < pos) overlap = true;
+                    for (i64 u = pos; u < pr.first; u++) rest.push_back((i32)u);
+                    pos = std::max(pos, pr.first + pr.second);
+                }
+                for (i64 u = pos; u < ntop; u++) rest.push_back((i32)u);
+                if (!overlap) {
+                    if ((rc = upload(&dblk_l0, l0, l0.size()))) return rc;
+                    if ((rc = upload(&rest_idx, rest, rest.size()))) return rc;
+                    nrest = (int)rest.size();
+                    hs_direct_ok = true;
+                }
+            }
+        }
         const int da = dev::dblk_attributes(mmax);
         if (da < 0) {
             set_error("k_dblk_symv: dynamic LDS attribute");
@@ -1101,6 +1147,16 @@ dev::SnodeView Engine::snode_view() const {
     return sv;
 }
 
+bool Engine::hs_direct_begin() {
+    if (!hs_direct_ok || fill_from < 0 || switches().no_hs_direct || (long long)nnzL <= fill_from) return false;
+    // (the fill-in range holds the blocks' L entries: cleared BEFORE they are written, not by the refactor)
+    if (hipMemsetAsync(Lx + fill_from, 0, (size_t)((long long)nnzL - fill_from) * sizeof(double), stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    hs_direct_armed = true;
+    return true;
+}
 int Engine::read_mailbox() {
     CHIP_HIP(hipMemcpyAsync(mb_host, mb_dev, sizeof(Mailbox), hipMemcpyDeviceToHost, stream));
     CHIP_HIP(hipStreamSynchronize(stream));
@@ -1151,9 +1207,14 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     v.eps_ptr = eps_ptr;
     // entries with both ends in the top -> the top columns of L / D; clears the status words.  The bundle
     // columns take their initial values straight from the U rows inside k_bundle_factor.
-    if (!fast && fill_from >= 0 && (long long)nnzL > fill_from)
+    const bool direct = hs_direct_armed && !fast; // (one refactor per armed write: L no longer holds the blocks afterwards)
+    hs_direct_armed = false;
+    if (!fast && !direct && fill_from >= 0 && (long long)nnzL > fill_from)
         CHIP_HIP(hipMemsetAsync(Lx + fill_from, 0, (size_t)((long long)nnzL - fill_from) * sizeof(double), stream));
-    if (!fast)
+    if (direct) hs_direct_refactors++;
+    if (direct)
+        dev::scatter_rest(stream, Kx + nnzU, v2l, rest_idx, nrest, (int)nnzL, Lx, D, dsigns, eps_ptr, mb_dev->status);
+    else if (!fast)
         dev::scatter_init(stream, Kx + nnzU, v2l, (int)(nnzK - nnzU), (int)nnzL, Lx, D, dsigns, eps_ptr, fill_idx, nfill,
                           mb_dev->status);
     const bool top_folded = fold.k == 1 || gfold.ng > 0;

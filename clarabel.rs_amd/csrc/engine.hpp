@@ -88,6 +88,16 @@ struct Engine {
     std::vector<std::pair<int, int>> snb_groups;
     std::vector<hipEvent_t> snb_events;
     std::vector<i32> snb_group_at;
+    // Dense diagonal blocks of the top whose rows are CONTIGUOUS in L as well (row a of the stored upper triangle = column
+    // a of L's panel, entry for entry): the kernel that writes such a block's values into K writes them into L too
+    // (dblk_l0[row] = L position of the row's first entry), and the refactor scatters only the REST of K's top entries
+    // (rest_idx) instead of reading all of them back -- config 5: 1.6e8 of 1.6e8.  hs_direct_begin() clears the fill-in range
+    // ahead of that kernel and arms the next refactor_enqueue().
+    int *dblk_l0 = nullptr, *rest_idx = nullptr;
+    int nrest = 0;
+    bool hs_direct_ok = false, hs_direct_armed = false;
+    long long hs_direct_refactors = 0;
+    bool hs_direct_begin();
     hipEvent_t snb_ready = nullptr;
     double *Rfx = nullptr; // values of L at the filtered row lists (refreshed per refactor)
     int nRf = 0, sn_nbmax = 0;

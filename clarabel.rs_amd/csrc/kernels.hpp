@@ -129,6 +129,8 @@ void scatter_init(hipStream_t s, const double *Kx, const int *a2l, int nnzK, int
 // cleared for the next update.  scal[0] = eps out.
 void eps_from_slots(hipStream_t s, unsigned long long *slots, double c, double prop, double static_max,
                     double *scal);
+void scatter_rest(hipStream_t s, const double *Kx, const int *a2l, const int *rest, int nrest, int nnzL, double *Lx, double *D,
+                  const int8_t *dsigns, const double *eps, int *status);
 void gather_values(hipStream_t s, double *Sx, const double *Kx, const int *Smap, int nnzS);
 // Dense diagonal blocks of the top in the residual (host.hpp: Symbolic::dblk_*): block b = the m[b] nodes
 // rownode[rowbase[b] ..], its strict upper triangle row by row in the device's K values, row a starting at
@@ -494,7 +496,9 @@ struct PsdView {
     const int *blk_cone = nullptr, *row_ij = nullptr, *blk_m = nullptr, *blk_rowbase = nullptr, *blk_start = nullptr;
 };
 void psd_update_scaling(hipStream_t s, const PsdView &v, const double *sv, const double *zv);
-void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx);
+// (Lx / l0: k_psd_write_hs_rows writes the blocks into L as well -- only when the rows form runs, see psd_write_hs_rows_active)
+void psd_write_hs(hipStream_t s, const PsdView &v, double *Kx, double *Lx = nullptr, const int *l0 = nullptr);
+bool psd_write_hs_rows_active(const PsdView &v);
 // PSD cone operations either side of the solve (psdtrianglecone.rs:104-303, symmetric_common.rs:53-95)
 void psd_mul_hs(hipStream_t s, const PsdView &v, double *y, const double *x);
 void psd_affine_ds(hipStream_t s, const PsdView &v, double *ds);

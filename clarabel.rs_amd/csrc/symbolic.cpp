@@ -980,7 +980,9 @@ int analyse(i64 n, const i64 *Ap, const i64 *Ai, const int8_t *dsigns, const std
             });
             for (int t = 0; t < Tc; t++) nuncovered += cnt[(size_t)t];
         }
-        if (nuncovered * 2 > nnzL - q0 && nuncovered > (i64)1 << 20) {
+        // (CHIP_FILL_RANGE_MIN, tests: 0 = always the range form, whatever the share of fill-in)
+        const long long fmin = switches().fill_range_min;
+        if (fmin == 0 || (nuncovered * 2 > nnzL - q0 && nuncovered > (i64)fmin)) {
             S.fill_from = q0; // (mostly fill-in: the range is cleared as a whole, no index list)
         } else {
             const int Tf = par_threads(nnzL - q0);

@@ -362,6 +362,46 @@ def test_psd_hs_written_row_by_row_of_the_value_store(hip, oracle, dim, monkeypa
     assert np.array_equal(vals["rows"], vals["CHIP_NO_PSD_ROWS"])  # (the same arithmetic per entry)
 
 
+@pytest.mark.parametrize("which", ["one_clique_50", "four_cliques_40"])
+def test_psd_hs_written_into_the_factor_storage_directly(hip, oracle, which, monkeypatch):
+    """PSD blocks that are dense diagonal blocks of the top AND contiguous row by row in L's panels are written into K and
+    into L by the one kernel (k_psd_write_hs_rows with Lx; Engine::hs_direct_begin clears the fill-in range ahead of it);
+    the refactor then scatters only the REST of K's top entries (k_scatter_rest) instead of reading 1.6e8 entries back
+    (config 5).  First update against the oracle; a second update at another scaling point (its refactor must not see
+    the first one's factor in L) against the scattered form (CHIP_NO_HS_DIRECT): same K, solutions equal to rounding."""
+    pr = problems.chordal_sdp(1, 50, 3, 2, 7, seed=50) if which == "one_clique_50" else problems.chordal_sdp(4, 40, 24, 2, 9, seed=11)
+    monkeypatch.setenv("CHIP_DENSE_SYMV_MIN", "1")
+    monkeypatch.setenv("CHIP_FILL_RANGE_MIN", "0")  # (the top's fill-in cleared as a range whatever its share: what the direct form needs)
+    res = {}
+    for form in ("direct", "CHIP_NO_HS_DIRECT"):
+        if form != "direct":
+            monkeypatch.setenv(form, "1")
+        ks, ko, cones = _solvers(hip, oracle, pr)
+        out = []
+        for it in range(2):
+            s_, z_ = pr["s"] * (1.0 + 0.25 * it), pr["z"] / (1.0 + 0.5 * it)
+            assert ks.update_scaling(s_, z_)
+            assert ks.update()
+            rng = np.random.default_rng(1 + it)
+            rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+            ks.setrhs(rx, rz)
+            x, z = np.zeros(pr["n"]), np.zeros(pr["m"])
+            assert ks.solve(x, z)
+            out.append((ks.values().copy(), np.concatenate([x, z])))
+            if it == 0:
+                assert cones.update_scaling(s_, z_) and ko.update(pr["hsblocks"])
+                assert relerr(ks.values(), ko.kkt.nzval) <= 1e-11
+                ko.setrhs(rx, rz)
+                ok, xo, zo = ko.solve()
+                assert ok and relerr(out[0][1], np.concatenate([xo, zo])) <= TOL
+        n_direct = hip.debug_counter(ks, "hs_direct_refactors")
+        assert (n_direct == 2) == (form == "direct"), (form, n_direct)
+        res[form] = out
+    for it in range(2):
+        assert np.array_equal(res["direct"][it][0], res["CHIP_NO_HS_DIRECT"][it][0])  # K: the same arithmetic per entry
+        assert relerr(res["direct"][it][1], res["CHIP_NO_HS_DIRECT"][it][1]) <= 1e-10
+
+
 def test_psd_scaling_failure_reported(hip):
     pr = problems.chordal_sdp(2, 4, 2, 1, 6, seed=2)
     P = hip.CscMatrix(pr["n"], pr["n"], *pr["P"])

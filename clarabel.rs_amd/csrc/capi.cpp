@@ -974,6 +974,8 @@ int32_t chip_kkt_update_scaled_enqueue(chip_kkt *h, const double *s_dev, const d
     CHIP_HIP(hipSetDevice(E.device));
     const bool sym_only = !(h->has_hostHs || h->ns3.ncones || h->gpw.ncones || h->psd.ncones);
     if (!sym_only || !E.st.static_regularization_enable || switches().no_step_kernel) {
+        // (PSD blocks that go into L directly: the clear of L's fill-in range starts now, beside the scaling kernels)
+        if (h->psd_rows_all_blocks && !h->has_hostHs && dev::psd_write_hs_rows_active(h->psd)) E.hs_direct_prefill_async();
         int rc = chip_kkt_update_scaling_dev(h, s_dev, z_dev, mu, strategy);
         if (rc < 0) return rc;
         return chip_kkt_update_enqueue(h, hsblocks_or_null);

@@ -31,6 +31,8 @@ Engine::~Engine() {
     if (pair_ev_b) (void)hipEventDestroy(pair_ev_b);
     if (exch_event) (void)hipEventDestroy(exch_event);
     if (snb_ready) (void)hipEventDestroy(snb_ready);
+    for (hipEvent_t e : hs_ev)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t ev : snb_events)
         if (ev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1147,7 +1149,34 @@ dev::SnodeView Engine::snode_view() const {
     return sv;
 }
 
+void Engine::hs_direct_prefill_async() {
+    if (!hs_direct_ok || fill_from < 0 || switches().no_hs_direct || switches().no_hs_prefill_async || (long long)nnzL <= fill_from ||
+        hs_prefill_pending || alt_active || prof_family != PF_NONE)
+        return;
+    if (ensure_alt() != CHIP_OK) return;
+    for (hipEvent_t &e : hs_ev)
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            e = nullptr;
+            return;
+        }
+    // (L's last readers -- the previous step's solves -- are on the main stream: the clear waits for them)
+    if (hipEventRecord(hs_ev[0], stream) != hipSuccess || hipStreamWaitEvent(alt.stream, hs_ev[0], 0) != hipSuccess ||
+        hipMemsetAsync(Lx + fill_from, 0, (size_t)((long long)nnzL - fill_from) * sizeof(double), alt.stream) != hipSuccess ||
+        hipEventRecord(hs_ev[1], alt.stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(alt.stream); // (whatever was enqueued there is done before the main stream goes on)
+        return;
+    }
+    hs_prefill_pending = true;
+}
 bool Engine::hs_direct_begin() {
+    if (hs_prefill_pending) { // the clear is under way on the second stream
+        hs_prefill_pending = false;
+        wait_event_or_sync(stream, hs_ev[1]);
+        hs_direct_armed = true;
+        return true;
+    }
     if (!hs_direct_ok || fill_from < 0 || switches().no_hs_direct || (long long)nnzL <= fill_from) return false;
     // (the fill-in range holds the blocks' L entries: cleared BEFORE they are written, not by the refactor)
     if (hipMemsetAsync(Lx + fill_from, 0, (size_t)((long long)nnzL - fill_from) * sizeof(double), stream) != hipSuccess) {
@@ -1207,6 +1236,10 @@ int Engine::refactor_enqueue(bool static_reg, const int *diag_idx_dev, double st
     v.eps_ptr = eps_ptr;
     // entries with both ends in the top -> the top columns of L / D; clears the status words.  The bundle
     // columns take their initial values straight from the U rows inside k_bundle_factor.
+    if (hs_prefill_pending) { // (a clear started for a write that did not happen: joined, and the refactor clears again)
+        hs_prefill_pending = false;
+        wait_event_or_sync(stream, hs_ev[1]);
+    }
     const bool direct = hs_direct_armed && !fast; // (one refactor per armed write: L no longer holds the blocks afterwards)
     hs_direct_armed = false;
     if (!fast && !direct && fill_from >= 0 && (long long)nnzL > fill_from)

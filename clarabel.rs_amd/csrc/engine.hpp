@@ -98,6 +98,11 @@ struct Engine {
     bool hs_direct_ok = false, hs_direct_armed = false;
     long long hs_direct_refactors = 0;
     bool hs_direct_begin();
+    // the same clear started EARLY on the second stream (beside the cones' scaling kernels, which do not touch L): the main
+    // stream only waits for it in hs_direct_begin()
+    void hs_direct_prefill_async();
+    hipEvent_t hs_ev[2] = {nullptr, nullptr};
+    bool hs_prefill_pending = false;
     hipEvent_t snb_ready = nullptr;
     double *Rfx = nullptr; // values of L at the filtered row lists (refreshed per refactor)
     int nRf = 0, sn_nbmax = 0;

@@ -65,6 +65,7 @@ const Entry TABLE[] = {
     {"CHIP_EXTEND_ASM_MIN", Entry::INT, SW(extend_asm_min), 0},
     {"CHIP_NO_DBLK_PAIR", Entry::FLAG, SW(no_dblk_pair), 0},
     {"CHIP_FILL_RANGE_MIN", Entry::LONG, SW(fill_range_min), 0},
+    {"CHIP_NO_HS_PREFILL_ASYNC", Entry::FLAG, SW(no_hs_prefill_async), 0},
     {"CHIP_NO_HS_DIRECT", Entry::FLAG, SW(no_hs_direct), 0},
     {"CHIP_NO_SN_WIDE", Entry::FLAG, SW(no_sn_wide), 0},
     {"CHIP_SN_WIDE_MIN_COUNT", Entry::INT, SW(sn_wide_min_count), 0},

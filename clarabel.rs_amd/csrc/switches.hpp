@@ -64,6 +64,7 @@ struct Switches {
     int extend_asm_min = 0;         // CHIP_EXTEND_ASM_MIN: fewest supernodes of a level whose updates are assembled (0: never, unless CHIP_DETERMINISTIC)
     bool no_dblk_pair = false;      // CHIP_NO_DBLK_PAIR: the dense diagonal blocks' residual products per vector, not one launch for a pair
     long long fill_range_min = 1 << 20; // CHIP_FILL_RANGE_MIN: fewest fill-in slots of the top from which they are cleared as a range (tests: 0 = always)
+    bool no_hs_prefill_async = false; // CHIP_NO_HS_PREFILL_ASYNC: that clear on the main stream, after the scaling kernels
     bool no_hs_direct = false;      // CHIP_NO_HS_DIRECT: the PSD blocks reach L through the refactor's scatter of K, not from the kernel that writes them
     bool no_sn_wide = false;        // CHIP_NO_SN_WIDE: no 128 x 256 tiles for the ancestors' update (k_snode_extend_wide)
     int sn_wide_waves = 4;          // CHIP_SN_WIDE_WAVES: waves per workgroup of k_snode_extend_wide (4: two workgroups per CU; 8: one)

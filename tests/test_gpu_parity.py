@@ -396,8 +396,23 @@ def test_psd_hs_written_into_the_factor_storage_directly(hip, oracle, which, mon
                 assert ok and relerr(out[0][1], np.concatenate([xo, zo])) <= TOL
         n_direct = hip.debug_counter(ks, "hs_direct_refactors")
         assert (n_direct == 2) == (form == "direct"), (form, n_direct)
+        # scaling + update as ONE enqueue (chip_kkt_update_scaled_enqueue): the clear of L's fill-in range runs on the
+        # second stream beside the scaling kernels (Engine::hs_direct_prefill_async), twice in a row
+        for it in range(2, 4):
+            s_, z_ = pr["s"] * (1.0 + 0.25 * it), pr["z"] / (1.0 + 0.5 * it)
+            s_d, z_d = hip.DeviceArray(s_), hip.DeviceArray(z_)
+            ks.update_scaled_enqueue(s_d.ptr, z_d.ptr)
+            rng = np.random.default_rng(1 + it)
+            rx, rz = rng.standard_normal(pr["n"]), rng.standard_normal(pr["m"])
+            rxd, rzd, lhs = hip.DeviceArray(rx), hip.DeviceArray(rz), hip.DeviceArray(pr["n"] + pr["m"])
+            ks.setrhs_dev(rxd.ptr, rzd.ptr)
+            ks.solve_dev_enqueue(lhs.ptr, lhs.ptr + 8 * pr["n"])
+            uok, sok = ks.collect()
+            assert uok and sok == [True]
+            out.append((ks.values().copy(), lhs.numpy().copy()))
+        assert (hip.debug_counter(ks, "hs_direct_refactors") == 4) == (form == "direct")
         res[form] = out
-    for it in range(2):
+    for it in range(4):
         assert np.array_equal(res["direct"][it][0], res["CHIP_NO_HS_DIRECT"][it][0])  # K: the same arithmetic per entry
         assert relerr(res["direct"][it][1], res["CHIP_NO_HS_DIRECT"][it][1]) <= 1e-10
 

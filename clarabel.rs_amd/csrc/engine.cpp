@@ -242,7 +242,10 @@ int Engine::init(const Symbolic &S, const chip_settings &settings) {
                     l0[r] = (i32)base;
                 }
             });
-            if (!bad && S.fill_from >= 0 && ntop < (i64)2000000000) {
+            i64 covered = 0;
+            for (size_t r = 0; r < nrows; r++) covered += rowlen[r];
+            // (worth it -- and the list of the other entries short -- only where the blocks are most of K's top entries)
+            if (!bad && S.fill_from >= 0 && ntop < (i64)2000000000 && covered * 2 > ntop) {
                 std::vector<std::pair<i64, i64>> iv;
                 iv.reserve(nrows);
                 for (size_t r = 0; r < nrows; r++)
